@@ -1,0 +1,163 @@
+/*
+ * score_hip.h -- C ABI of the MI355X conic solver that replaces the reference's
+ * solver boundary for the SCORE relaxation.
+ *
+ * What it replaces.  The reference builds a Gurobi model
+ * (score/utils/gurobi_utils.py:173-187 initialize_model) and crosses into
+ * native code exactly once, at `model.optimize()` (score/solve_score.py:76),
+ * then reads `.X`, `.Runtime`, `.status` back (gurobi_utils.py:133-135,
+ * :194-195).  gurobipy's object API cannot be re-bound, so the boundary is
+ * restated as "hand over the assembled convex program, get the optimiser
+ * back":
+ *
+ *     minimise    1/2 x'Px + q'x + c0
+ *     subject to  A x + s = b,   s in {0}^z  x  SOC(d_1) x ... x SOC(d_k)
+ *
+ *   score_create[_batch]   <-  gp.Model() + addMVar/addVars/addConstr/
+ *                              setObjective/update
+ *                              (gurobi_utils.py:206-215, :233-352, :186-187)
+ *   score_solve            <-  model.optimize()           (solve_score.py:76)
+ *   outputs x / y / s      <-  Var.X                (gurobi_utils.py:133-135)
+ *   score_info.status      <-  model.status == GRB.OPTIMAL        (:195)
+ *   score_info.solve_ms    <-  model.Runtime                      (:194)
+ *   score_solve_steps      <-  BarIterLimit = k; optimize()
+ *                              (solve_score.py:103-105, intermediate iterates)
+ *   score_destroy          <-  model disposal
+ *
+ * Conventions.  Plain pointers and sizes only.  All input arrays are BORROWED
+ * for the duration of the call and copied to the device in score_create*;
+ * outputs are written into caller-owned buffers.  Return value 0 = ok,
+ * negative = error (message via score_last_error(), thread-local).  No
+ * exceptions cross the ABI.  One handle = one HIP device + one stream; a
+ * handle is not thread-safe, distinct handles are independent.  A handle may
+ * hold a BATCH of independent problems that advance in lock-step through the
+ * same kernel launches (per-problem step sizes, penalty and termination).
+ * There is no CPU fallback: without a usable HIP device score_create* fails.
+ */
+#ifndef SCORE_HIP_H
+#define SCORE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct score_problem {
+    int32_t n;                 /* unknowns                                   */
+    int32_t m;                 /* constraint rows                            */
+    /* P: FULL symmetric n x n matrix in CSR (both triangles), sorted columns */
+    const int32_t* P_rowptr;   /* n + 1                                      */
+    const int32_t* P_col;
+    const double*  P_val;
+    const double*  q;          /* n                                          */
+    double         c0;         /* objective constant                         */
+    /* A: m x n in CSR; rows ordered: z zero-cone rows, then the SOC blocks  */
+    const int32_t* A_rowptr;   /* m + 1                                      */
+    const int32_t* A_col;
+    const double*  A_val;
+    const double*  b;          /* m                                          */
+    int32_t        z;          /* leading zero-cone (equality) rows          */
+    int32_t        n_soc;      /* number of second-order cones               */
+    const int32_t* soc_dims;   /* n_soc entries, each >= 1, sum == m - z     */
+    /* Optional block-tridiagonal preconditioner hint (0 / NULL = none):
+     * chain c consists of nodes chain_ptr[c] .. chain_ptr[c+1]-1 in order;
+     * node j owns the block_size consecutive columns
+     * node_first_col[j] .. node_first_col[j] + block_size - 1.  Consecutive
+     * nodes of a chain are assumed to be the strongly coupled ones (for SCORE:
+     * one chain per robot and pose-matrix row, one node per pose).  Columns in
+     * no node get a Jacobi preconditioner.                                   */
+    int32_t        block_size; /* 1..4                                       */
+    int32_t        n_chains;
+    const int32_t* chain_ptr;  /* n_chains + 1                               */
+    const int32_t* node_first_col;
+} score_problem;
+
+typedef struct score_settings {
+    double  eps_abs;           /* absolute tolerance (unscaled residuals)    */
+    double  eps_rel;           /* relative tolerance                         */
+    int32_t max_iters;         /* ADMM iteration cap                         */
+    int32_t check_interval;    /* iterations per launch graph / convergence test */
+    double  rho;               /* initial penalty                            */
+    double  sigma;             /* proximal weight on x                       */
+    double  alpha;             /* over-relaxation in (0, 2)                  */
+    int32_t scale_iters;       /* Ruiz equilibration passes (0 = off)        */
+    int32_t cg_iters;          /* PCG iterations per ADMM iteration (initial) */
+    int32_t adaptive_cg;       /* 0/1: adapt cg_iters to the measured reduction */
+    int32_t max_cg_iters;      /* cap for adaptive_cg                        */
+    double  cg_target;         /* wanted M^-1-norm residual reduction per KKT solve */
+    int32_t adaptive_rho;      /* 0/1                                        */
+    int32_t adaptive_rho_interval; /* in ADMM iterations (multiple of check_interval) */
+    double  adaptive_rho_tol;  /* refactor when rho changes by this factor   */
+    int32_t chain_radix;       /* partition radix of the chain solver (2..8) */
+    int32_t device;            /* HIP device ordinal                         */
+    int32_t use_graph;         /* replay iterations from a hipGraph          */
+    int32_t verbose;
+} score_settings;
+
+enum {
+    SCORE_STATUS_UNSOLVED = 0,
+    SCORE_STATUS_SOLVED = 1,          /* all three termination tests passed  */
+    SCORE_STATUS_MAX_ITERS = 2,
+    SCORE_STATUS_NUMERICAL = 3        /* NaN/Inf encountered                 */
+};
+
+typedef struct score_info {
+    int32_t status;
+    int32_t iters;             /* ADMM ("SOCP") iterations                   */
+    int32_t cg_iters;          /* total PCG iterations                       */
+    int32_t rho_updates;
+    double  rho;               /* final penalty                              */
+    double  pobj;              /* primal objective incl. c0                  */
+    double  dobj;              /* dual objective incl. c0                    */
+    double  res_pri;           /* |Ax + s - b|_inf                           */
+    double  res_dual;          /* |Px + q + A'y|_inf                         */
+    double  gap;               /* |pobj - dobj|                              */
+    double  setup_ms;          /* score_create time                          */
+    double  solve_ms;          /* wall time of the last score_solve          */
+    double  kkt_bytes;         /* algorithmic bytes of one K-apply (this problem) */
+} score_info;
+
+typedef struct score_handle score_handle;
+
+void score_default_settings(score_settings* s);
+
+/* Build a solver for ONE problem / for a batch of `count` independent problems. */
+int  score_create(const score_problem* p, const score_settings* s, score_handle** out);
+int  score_create_batch(const score_problem* p, int32_t count, const score_settings* s,
+                        score_handle** out);
+
+/* Concatenated sizes of the handle's problems (sum of n, sum of m, count).  */
+int  score_dims(const score_handle* h, int64_t* n_total, int64_t* m_total, int32_t* count);
+
+/* Cold-start solve.  x: sum n, y and s: sum m (problem after problem), any may
+ * be NULL; infos: `count` entries (may be NULL).                             */
+int  score_solve(score_handle* h, double* x, double* y, double* s, score_info* infos);
+
+/* Run exactly `iters` more ADMM iterations from the current iterate (after
+ * score_reset: from zero), then report the iterate -- the intermediate-iterate
+ * interface (solve_score.py:89-116).                                         */
+int  score_reset(score_handle* h);
+int  score_solve_steps(score_handle* h, int32_t iters, double* x, double* y, double* s,
+                       score_info* infos);
+
+/* Time `reps` applications of the KKT operator w = K p on the handle's stream
+ * with HIP events (the roofline probe bench.py reports); returns the average
+ * milliseconds per launch in *ms_per_apply and the algorithmic bytes of one
+ * launch in *bytes_per_apply.                                                */
+int  score_time_kkt_apply(score_handle* h, int32_t reps, double* ms_per_apply,
+                          double* bytes_per_apply);
+
+/* Debug/test access to an internal device vector by name ("x", "xt", "s", "y",
+ * "u", "r", "z", "p", "w"); copies min(len, size) doubles, returns the size. */
+int64_t score_debug_get(score_handle* h, const char* name, double* out, int64_t len);
+
+void score_destroy(score_handle* h);
+
+const char* score_last_error(void);
+const char* score_backend(void);   /* "hip-gfx950" or "cpu-twin"             */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCORE_HIP_H */

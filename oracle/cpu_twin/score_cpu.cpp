@@ -1,0 +1,339 @@
+// ORACLE / TEST INFRASTRUCTURE -- CPU twin of the HIP solver (libscore_cpu.so).
+//
+// Same C ABI (include/score_hip.h), same host-side setup and ADMM driver
+// (score_amd/csrc/score_host.hpp, score_driver.hpp), but every device kernel
+// is restated as a plain loop.  It exists so that (1) the algorithm, the
+// equilibration, the KKT assembly and the multi-level chain factorisation can
+// be tested in a container without a GPU, (2) the GPU kernels can be compared
+// vector-by-vector against an independent execution of the same iteration,
+// and (3) bench.py has a CPU baseline ("port") to time beside the GPU.
+// The product path (score_amd/) never loads this library: only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+//
+// The reference has no counterpart: its solve is Gurobi's barrier method
+// (score/solve_score.py:76), which is closed source and absent here.
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../../score_amd/csrc/score_driver.hpp"
+
+namespace {
+
+using namespace score;
+
+thread_local std::string g_err;
+
+struct CpuBackend {
+    const HostSystem* H = nullptr;
+    score_settings st{};
+    std::vector<double> xtu, xy, s, r, z, p, w;  // xtu = [xt | u], xy = [x | y]
+    std::vector<double> scr;
+    std::vector<int> done;
+    std::vector<double> cg_red;  // last measured sqrt(r'z_final / r'z_init) per problem
+    int cg_iters = 2;
+
+    void set_cg_iters(int k) { cg_iters = k; }
+    void cg_reduction(std::vector<double>& out) { out = cg_red; }
+
+    void init(const HostSystem& h, const score_settings& s_) {
+        H = &h;
+        st = s_;
+        xtu.assign(h.n_tot + h.m_tot, 0.0);
+        xy.assign(h.n_tot + h.m_tot, 0.0);
+        s.assign(h.m_tot, 0.0);
+        r.assign(h.n_tot, 0.0);
+        z.assign(h.n_tot, 0.0);
+        p.assign(h.n_tot, 0.0);
+        w.assign(h.n_tot, 0.0);
+        scr.assign((size_t)std::max<int64_t>(1, h.scratch_nodes) * std::max(1, h.bs), 0.0);
+        done.assign(h.count, 0);
+        cg_red.assign(h.count, 0.0);
+        cg_iters = st.cg_iters;
+        reset();
+    }
+    void upload_rho(const HostSystem& h) {
+        // u = rho (b - s) - y depends on rho
+        for (int pi = 0; pi < h.count; ++pi)
+            for (int64_t i = h.roff[pi]; i < h.roff[pi + 1]; ++i)
+                xtu[h.n_tot + i] = h.rho[pi] * (h.b[i] - s[i]) - xy[h.n_tot + i];
+    }
+    void set_done(const std::vector<int>& d) { done = d; }
+    void reset() {
+        std::fill(xtu.begin(), xtu.end(), 0.0);
+        std::fill(xy.begin(), xy.end(), 0.0);
+        std::fill(s.begin(), s.end(), 0.0);
+        std::fill(r.begin(), r.end(), 0.0);
+        std::fill(z.begin(), z.end(), 0.0);
+        std::fill(p.begin(), p.end(), 0.0);
+        std::fill(w.begin(), w.end(), 0.0);
+        upload_rho(*H);
+    }
+
+    static double row_dot(const Csr& M, int64_t i, const double* v) {
+        double acc = 0;
+        for (int k = M.ptr[i]; k < M.ptr[i + 1]; ++k) acc += M.val[k] * v[M.col[k]];
+        return acc;
+    }
+
+    void precond(int pi, double& rz) {  // z = M^{-1} r for problem pi, returns r'z
+        const HostSystem& h = *H;
+        const int w0 = h.prec_part_ptr[pi], w1 = h.prec_part_ptr[pi + 1];
+        double acc = 0;
+#pragma omp parallel for reduction(+ : acc) schedule(dynamic, 1)
+        for (int wi = w0; wi < w1; ++wi) {
+            const PrecWork& pw = h.prec_work[wi];
+            if (pw.kind == 0) {
+                const ChainDesc& ch = h.chains[pw.index];
+                chain_solve_host(ch, h.levels.data(), h.fac.data(), h.node_col.data(), h.bs, r.data(), z.data(),
+                                 scr.data() + (size_t)ch.scratch_off * h.bs);
+                for (int i = 0; i < ch.N; ++i)
+                    for (int c = 0; c < h.bs; ++c) {
+                        const int col = h.node_col[ch.node_begin + i] + c;
+                        acc += r[col] * z[col];
+                    }
+            } else {
+                for (int e = pw.index; e < pw.index + pw.count; ++e) {
+                    const int col = h.diag_cols[e];
+                    z[col] = r[col] * h.dinv[e];
+                    acc += r[col] * z[col];
+                }
+            }
+        }
+        rz = acc;
+    }
+
+    void iterate_problem(int pi, bool measure) {
+        const HostSystem& h = *H;
+        const int64_t x0 = h.xoff[pi], x1 = h.xoff[pi + 1];
+        const double rho = h.rho[pi], sigma = h.sigma, al = st.alpha;
+        double* xt = xtu.data();
+        double* x = xy.data();
+        double* u = xtu.data() + h.n_tot;
+        double* y = xy.data() + h.n_tot;
+        // r = sigma x - q + [-K | A'] [xt ; u]
+#pragma omp parallel for schedule(static)
+        for (int64_t i = x0; i < x1; ++i) r[i] = sigma * x[i] - h.q[i] + row_dot(h.G1, i, xtu.data());
+        double rz = 0;
+        precond(pi, rz);
+        const double rz_init = rz;
+        for (int64_t i = x0; i < x1; ++i) p[i] = z[i];
+        for (int j = 1; j <= cg_iters; ++j) {
+            double pw = 0;
+#pragma omp parallel for reduction(+ : pw) schedule(static)
+            for (int64_t i = x0; i < x1; ++i) {
+                w[i] = row_dot(h.K, i, p.data());
+                pw += p[i] * w[i];
+            }
+            const double a = pw > 0 ? rz / pw : 0.0;
+#pragma omp parallel for schedule(static)
+            for (int64_t i = x0; i < x1; ++i) {
+                xt[i] += a * p[i];
+                r[i] -= a * w[i];
+            }
+            if (j == cg_iters && measure) {
+                double rzf = 0;
+                precond(pi, rzf);
+                cg_red[pi] = rz_init > 0 ? std::sqrt(std::max(0.0, rzf) / rz_init) : 0.0;
+            }
+            if (j < cg_iters) {
+                double rz2 = 0;
+                precond(pi, rz2);
+                const double beta = rz > 0 ? rz2 / rz : 0.0;
+#pragma omp parallel for schedule(static)
+                for (int64_t i = x0; i < x1; ++i) p[i] = z[i] + beta * p[i];
+                rz = rz2;
+            }
+        }
+#pragma omp parallel for schedule(static)
+        for (int64_t i = x0; i < x1; ++i) x[i] = al * xt[i] + (1.0 - al) * x[i];
+        // cones
+        const int cb0 = h.cone_block_first[h.cone_part_ptr[pi]];
+        const int cb1 = h.cone_block_first[h.cone_part_ptr[pi + 1]];
+#pragma omp parallel for schedule(static)
+        for (int c = cb0; c < cb1; ++c) {
+            const int row = h.cone_row[c], dim = h.cone_dim[c];
+            double nz2 = 0, t0 = 0;
+            for (int k = 0; k < dim; ++k) {
+                const int i = row + k;
+                const double t = row_dot(h.A, i, xt);
+                const double v = al * (h.b[i] - t) + (1.0 - al) * s[i];
+                const double wv = v - y[i] / rho;
+                // stash v in u and wv in s until the projection is known
+                u[i] = v;
+                s[i] = wv;
+                if (k == 0) t0 = wv; else nz2 += wv * wv;
+            }
+            if (h.cone_type[c] == 0) {
+                for (int k = 0; k < dim; ++k) s[row + k] = 0.0;
+            } else {
+                const double nz = std::sqrt(nz2);
+                double sc_head, sc_tail;  // s+ = (head, sc_tail * tail)
+                if (nz <= t0) { sc_head = t0; sc_tail = 1.0; }
+                else if (nz <= -t0) { sc_head = 0.0; sc_tail = 0.0; }
+                else { const double a = 0.5 * (t0 + nz); sc_head = a; sc_tail = a / nz; }
+                s[row] = sc_head;
+                for (int k = 1; k < dim; ++k) s[row + k] *= sc_tail;
+            }
+            for (int k = 0; k < dim; ++k) {
+                const int i = row + k;
+                const double v = u[i];
+                y[i] += rho * (s[i] - v);
+                u[i] = rho * (h.b[i] - s[i]) - y[i];
+            }
+        }
+    }
+
+    void run(int iters) {
+        for (int it = 0; it < iters; ++it)
+            for (int pi = 0; pi < H->count; ++pi)
+                if (!done[pi]) iterate_problem(pi, it == iters - 1);
+    }
+
+    void residuals(std::vector<ResidualSums>& R) {
+        const HostSystem& h = *H;
+        const double* x = xy.data();
+        const double* y = xy.data() + h.n_tot;
+        for (int pi = 0; pi < h.count; ++pi) {
+            ResidualSums a;
+            for (int64_t i = h.roff[pi]; i < h.roff[pi + 1]; ++i) {
+                const double t = row_dot(h.A, i, x);
+                const double pr = t + s[i] - h.b[i];
+                const double ie = 1.0 / h.E[i];
+                a.rp_u = std::max(a.rp_u, std::fabs(pr) * ie);
+                a.ax_u = std::max(a.ax_u, std::fabs(t) * ie);
+                a.s_u = std::max(a.s_u, std::fabs(s[i]) * ie);
+                a.rp_s = std::max(a.rp_s, std::fabs(pr));
+                a.ax_s = std::max(a.ax_s, std::fabs(t));
+                a.s_s = std::max(a.s_s, std::fabs(s[i]));
+                a.by += h.b[i] * y[i];
+                if (pr != pr) a.rp_u = pr;
+            }
+            for (int64_t i = h.xoff[pi]; i < h.xoff[pi + 1]; ++i) {
+                double px = 0, aty = 0;
+                for (int k = h.G2.ptr[i]; k < h.g2_split[i]; ++k) px += h.G2.val[k] * xy[h.G2.col[k]];
+                for (int k = h.g2_split[i]; k < h.G2.ptr[i + 1]; ++k) aty += h.G2.val[k] * xy[h.G2.col[k]];
+                const double dr = px + h.q[i] + aty;
+                const double id = 1.0 / h.D[i];
+                a.rd_u = std::max(a.rd_u, std::fabs(dr) * id);
+                a.px_u = std::max(a.px_u, std::fabs(px) * id);
+                a.aty_u = std::max(a.aty_u, std::fabs(aty) * id);
+                a.rd_s = std::max(a.rd_s, std::fabs(dr));
+                a.px_s = std::max(a.px_s, std::fabs(px));
+                a.aty_s = std::max(a.aty_s, std::fabs(aty));
+                a.xPx += x[i] * px;
+                a.qx += h.q[i] * x[i];
+                if (dr != dr) a.rd_u = dr;
+            }
+            R[pi] = a;
+        }
+    }
+
+    void download(const HostSystem& h, double* x, double* y, double* s_out) {
+        if (x) for (int64_t i = 0; i < h.n_tot; ++i) x[i] = xy[i] * h.D[i];
+        if (y) for (int64_t i = 0; i < h.m_tot; ++i) y[i] = xy[h.n_tot + i] * h.E[i];
+        if (s_out) for (int64_t i = 0; i < h.m_tot; ++i) s_out[i] = s[i] / h.E[i];
+    }
+
+    int64_t get_vec(const char* name, double* out, int64_t len) {
+        const HostSystem& h = *H;
+        const double* src = nullptr;
+        int64_t sz = 0;
+        std::string nm(name);
+        if (nm == "xt") { src = xtu.data(); sz = h.n_tot; }
+        else if (nm == "u") { src = xtu.data() + h.n_tot; sz = h.m_tot; }
+        else if (nm == "x") { src = xy.data(); sz = h.n_tot; }
+        else if (nm == "y") { src = xy.data() + h.n_tot; sz = h.m_tot; }
+        else if (nm == "s") { src = s.data(); sz = h.m_tot; }
+        else if (nm == "r") { src = r.data(); sz = h.n_tot; }
+        else if (nm == "z") { src = z.data(); sz = h.n_tot; }
+        else if (nm == "p") { src = p.data(); sz = h.n_tot; }
+        else if (nm == "w") { src = w.data(); sz = h.n_tot; }
+        else if (nm == "D") { src = h.D.data(); sz = h.n_tot; }
+        else if (nm == "E") { src = h.E.data(); sz = h.m_tot; }
+        else if (nm == "Kval") { src = h.K.val.data(); sz = (int64_t)h.K.val.size(); }
+        else return -1;
+        if (out) std::memcpy(out, src, sizeof(double) * (size_t)std::min(len, sz));
+        return sz;
+    }
+
+    void time_kkt(int reps, double* ms, double* bytes) {
+        const HostSystem& h = *H;
+        for (int64_t i = 0; i < h.n_tot; ++i) p[i] = 1.0 + 1e-3 * (double)(i % 7);
+        const double t0 = now_ms();
+        for (int rep = 0; rep < reps; ++rep) {
+#pragma omp parallel for schedule(static)
+            for (int64_t i = 0; i < h.n_tot; ++i) w[i] = row_dot(h.K, i, p.data());
+        }
+        *ms = (now_ms() - t0) / std::max(1, reps);
+        double bsum = 0;
+        for (double v : h.kkt_bytes) bsum += v;
+        *bytes = bsum;
+    }
+};
+
+}  // namespace
+
+struct score_handle {
+    score::Solver<CpuBackend> solver;
+};
+
+extern "C" {
+
+void score_default_settings(score_settings* s) { score::default_settings(s); }
+
+int score_create_batch(const score_problem* p, int32_t count, const score_settings* s, score_handle** out) {
+    try {
+        score_settings st;
+        if (s) st = *s; else score::default_settings(&st);
+        auto* h = new score_handle();
+        try {
+            h->solver.create(p, count, st);
+        } catch (...) {
+            delete h;
+            throw;
+        }
+        *out = h;
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+int score_create(const score_problem* p, const score_settings* s, score_handle** out) {
+    return score_create_batch(p, 1, s, out);
+}
+int score_dims(const score_handle* h, int64_t* n_total, int64_t* m_total, int32_t* count) {
+    if (!h) { g_err = "null handle"; return -1; }
+    if (n_total) *n_total = h->solver.H.n_tot;
+    if (m_total) *m_total = h->solver.H.m_tot;
+    if (count) *count = h->solver.H.count;
+    return 0;
+}
+int score_solve(score_handle* h, double* x, double* y, double* s, score_info* infos) {
+    try { return h->solver.solve(x, y, s, infos); }
+    catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_reset(score_handle* h) {
+    try { h->solver.reset(); return 0; }
+    catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_solve_steps(score_handle* h, int32_t iters, double* x, double* y, double* s, score_info* infos) {
+    try { return h->solver.steps(iters, x, y, s, infos); }
+    catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_time_kkt_apply(score_handle* h, int32_t reps, double* ms, double* bytes) {
+    try { h->solver.be.time_kkt(reps, ms, bytes); return 0; }
+    catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int64_t score_debug_get(score_handle* h, const char* name, double* out, int64_t len) {
+    return h->solver.be.get_vec(name, out, len);
+}
+void score_destroy(score_handle* h) { delete h; }
+const char* score_last_error(void) { return g_err.c_str(); }
+const char* score_backend(void) { return "cpu-twin"; }
+}

@@ -1,0 +1,231 @@
+// score_driver.hpp -- the ADMM outer loop, shared by every backend.
+//
+// The backend owns the iterates and runs blocks of ADMM iterations; the driver
+// decides, between blocks, which problems have converged, whether a problem's
+// penalty rho should change (which re-factors its preconditioner on the host
+// and re-uploads the rho-dependent data), and when to stop.  This is the role
+// Gurobi's `model.optimize()` plays for the reference (score/solve_score.py:76);
+// `solved` there is `status == OPTIMAL` (gurobi_utils.py:195), here it is
+// "all three termination tests passed".
+#pragma once
+
+#include <chrono>
+#include <cstdio>
+#include <vector>
+
+#include "score_host.hpp"
+
+namespace score {
+
+struct ResidualSums {  // per problem, filled by the backend
+    // primal side (cone kernel): inf-norms of Ax+s-b, Ax, s  (unscaled, scaled), b'y
+    double rp_u = 0, ax_u = 0, s_u = 0, rp_s = 0, ax_s = 0, s_s = 0, by = 0;
+    // dual side (G2 SpMV): inf-norms of Px+q+A'y, Px, A'y (unscaled, scaled), x'Px, q'x
+    double rd_u = 0, px_u = 0, aty_u = 0, rd_s = 0, px_s = 0, aty_s = 0, xPx = 0, qx = 0;
+};
+
+inline double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+template <class Backend>
+struct Solver {
+    HostSystem H;
+    score_settings st;
+    Backend be;
+    std::vector<score_info> infos;
+    std::vector<int> done;
+    int iters_done = 0;
+    int cg_now = 2;       // PCG iterations per ADMM iteration currently in use
+    int64_t cg_total = 0; // PCG iterations performed since reset
+    double setup_ms = 0;
+
+    void create(const score_problem* probs, int count, const score_settings& s) {
+        const double t0 = now_ms();
+        st = s;
+        if (st.check_interval < 1) st.check_interval = 25;
+        if (st.cg_iters < 1) st.cg_iters = 1;
+        if (st.adaptive_rho_interval < st.check_interval) st.adaptive_rho_interval = st.check_interval;
+        if (st.max_cg_iters < st.cg_iters) st.max_cg_iters = st.cg_iters;
+        if (!(st.cg_target > 0.0 && st.cg_target < 1.0)) st.cg_target = 0.3;
+        cg_now = st.cg_iters;
+        build_system(probs, count, st, H);
+        be.init(H, st);
+        infos.assign(count, score_info{});
+        done.assign(count, 0);
+        setup_ms = now_ms() - t0;
+    }
+
+    void reset() {
+        bool changed = false;
+        for (int p = 0; p < H.count; ++p)
+            if (H.rho[p] != st.rho) {
+                H.rho[p] = st.rho;
+                refresh_rho(H, p);
+                changed = true;
+            }
+        if (changed) be.upload_rho(H);
+        be.reset();
+        if (cg_now != st.cg_iters) { cg_now = st.cg_iters; be.set_cg_iters(cg_now); }
+        cg_total = 0;
+        iters_done = 0;
+        std::fill(done.begin(), done.end(), 0);
+        be.set_done(done);
+        for (auto& i : infos) i = score_info{};
+    }
+
+    // one convergence test; returns true when every problem is finished
+    bool check(bool allow_rho) {
+        std::vector<ResidualSums> R(H.count);
+        be.residuals(R);
+        bool all = true, any_rho = false, newly_done = false;
+        for (int p = 0; p < H.count; ++p) {
+            if (done[p]) continue;
+            const ResidualSums& r = R[p];
+            score_info& I = infos[p];
+            I.iters = iters_done;
+            I.cg_iters = (int32_t)std::min<int64_t>(cg_total, 2147483647);
+            I.rho = H.rho[p];
+            I.res_pri = r.rp_u;
+            I.res_dual = r.rd_u;
+            I.pobj = 0.5 * r.xPx + r.qx + H.c0[p];
+            I.dobj = -0.5 * r.xPx - r.by + H.c0[p];
+            I.gap = std::fabs(I.pobj - I.dobj);
+            I.kkt_bytes = H.kkt_bytes[p];
+            const bool finite = std::isfinite(r.rp_u) && std::isfinite(r.rd_u) && std::isfinite(I.pobj);
+            if (!finite) {
+                I.status = SCORE_STATUS_NUMERICAL;
+                done[p] = 1;
+                newly_done = true;
+                continue;
+            }
+            const double pn = std::max(std::max(r.ax_u, r.s_u), H.bnorm_u[p]);
+            const double dn = std::max(std::max(r.px_u, r.aty_u), H.qnorm_u[p]);
+            const bool ok_p = r.rp_u <= st.eps_abs + st.eps_rel * pn;
+            const bool ok_d = r.rd_u <= st.eps_abs + st.eps_rel * dn;
+            const bool ok_g = I.gap <= st.eps_abs + st.eps_rel * std::max(std::fabs(I.pobj), std::fabs(I.dobj));
+            if (st.verbose)
+                std::fprintf(stderr, "[score] prob %d it %d rp %.3e rd %.3e gap %.3e pobj %.9g rho %.3g\n", p,
+                             iters_done, r.rp_u, r.rd_u, I.gap, I.pobj, H.rho[p]);
+            if (ok_p && ok_d && ok_g) {
+                I.status = SCORE_STATUS_SOLVED;
+                done[p] = 1;
+                newly_done = true;
+                continue;
+            }
+            all = false;
+            if (allow_rho && st.adaptive_rho && iters_done % st.adaptive_rho_interval == 0) {
+                const double tiny = 1e-30;
+                const double pns = std::max(std::max(std::max(r.ax_s, r.s_s), H.bnorm_s[p]), tiny);
+                const double dns = std::max(std::max(std::max(r.px_s, r.aty_s), H.qnorm_s[p]), tiny);
+                double ratio = std::sqrt((r.rp_s / pns) / (std::max(r.rd_s, tiny) / dns));
+                double nr = std::min(1e6, std::max(1e-6, H.rho[p] * ratio));
+                if (nr > st.adaptive_rho_tol * H.rho[p] || nr < H.rho[p] / st.adaptive_rho_tol) {
+                    H.rho[p] = nr;
+                    refresh_rho(H, p);
+                    I.rho_updates++;
+                    any_rho = true;
+                }
+            }
+        }
+        if (any_rho) be.upload_rho(H);
+        if (newly_done) be.set_done(done);
+        if (allow_rho && st.adaptive_cg && !all) {
+            // worst measured reduction of the M^-1-norm KKT residual over the active problems
+            std::vector<double> red(H.count, 0.0);
+            be.cg_reduction(red);
+            double worst = 0.0;
+            for (int p = 0; p < H.count; ++p)
+                if (!done[p] && red[p] == red[p]) worst = std::max(worst, red[p]);
+            int want = cg_now;
+            if (worst > st.cg_target) want = std::min(st.max_cg_iters, cg_now < 4 ? cg_now + 1 : cg_now + cg_now / 2);
+            else if (worst < 0.01 * st.cg_target && cg_now > st.cg_iters) want = std::max(st.cg_iters, cg_now - std::max(1, cg_now / 4));
+            if (st.verbose) std::fprintf(stderr, "[score] it %d cg %d reduction %.3e -> cg %d\n", iters_done, cg_now, worst, want);
+            if (want != cg_now) { cg_now = want; be.set_cg_iters(cg_now); }
+        }
+        return all;
+    }
+
+    void finish(double* x, double* y, double* s, score_info* out, double t0) {
+        const double ms = now_ms() - t0;
+        for (int p = 0; p < H.count; ++p) {
+            if (!done[p] && infos[p].status == SCORE_STATUS_UNSOLVED) infos[p].status = SCORE_STATUS_MAX_ITERS;
+            infos[p].setup_ms = setup_ms;
+            infos[p].solve_ms = ms;
+        }
+        be.download(H, x, y, s);
+        if (out)
+            for (int p = 0; p < H.count; ++p) out[p] = infos[p];
+    }
+
+    int solve(double* x, double* y, double* s, score_info* out) {
+        const double t0 = now_ms();
+        reset();
+        bool all = false;
+        while (!all && iters_done < st.max_iters) {
+            const int k = std::min(st.check_interval, st.max_iters - iters_done);
+            be.run(k);
+            iters_done += k;
+            cg_total += (int64_t)k * cg_now;
+            all = check(true);
+        }
+        finish(x, y, s, out, t0);
+        return 0;
+    }
+
+    int steps(int iters, double* x, double* y, double* s, score_info* out) {
+        const double t0 = now_ms();
+        int left = iters;
+        while (left > 0) {
+            const int k = std::min(st.check_interval, left);
+            be.run(k);
+            iters_done += k;
+            cg_total += (int64_t)k * cg_now;
+            left -= k;
+        }
+        std::vector<int> keep = done;
+        check(false);
+        for (int p = 0; p < H.count; ++p) {
+            // stepping never freezes a problem: report, do not latch
+            if (!keep[p] && done[p] && infos[p].status == SCORE_STATUS_SOLVED) done[p] = 0;
+        }
+        be.set_done(done);
+        std::vector<score_info> snap = infos;
+        for (int p = 0; p < H.count; ++p)
+            if (snap[p].status == SCORE_STATUS_UNSOLVED) snap[p].status = SCORE_STATUS_MAX_ITERS;
+        const double ms = now_ms() - t0;
+        be.download(H, x, y, s);
+        if (out)
+            for (int p = 0; p < H.count; ++p) {
+                out[p] = snap[p];
+                out[p].setup_ms = setup_ms;
+                out[p].solve_ms = ms;
+            }
+        return 0;
+    }
+};
+
+inline void default_settings(score_settings* s) {
+    s->eps_abs = 1e-7;
+    s->eps_rel = 1e-7;
+    s->max_iters = 20000;
+    s->check_interval = 25;
+    s->rho = 0.1;
+    s->sigma = 1e-6;
+    s->alpha = 1.6;
+    s->scale_iters = 10;
+    s->cg_iters = 2;
+    s->adaptive_cg = 1;
+    s->max_cg_iters = 64;
+    s->cg_target = 0.3;
+    s->adaptive_rho = 1;
+    s->adaptive_rho_interval = 100;
+    s->adaptive_rho_tol = 5.0;
+    s->chain_radix = 4;
+    s->device = 0;
+    s->use_graph = 1;
+    s->verbose = 0;
+}
+
+}  // namespace score

@@ -1,0 +1,779 @@
+// score_host.hpp -- host-side setup for the MI355X SCORE conic solver.
+//
+// Everything the device needs that is computed ONCE per problem (or once per
+// penalty update) lives here, in plain C++17 with no HIP dependency:
+//   * Ruiz equilibration of [[P, A'], [A, 0]] with one scale per cone,
+//   * the KKT operator K = P + sigma*I + rho*A'A on a fixed sparsity pattern
+//     (values K0 + rho*K1), and the two "wide" operators
+//       G1 = [-K | A']  applied to [xt ; u]   (KKT right-hand side / residual)
+//       G2 = [ P | A']  applied to [x  ; y]   (dual residual),
+//   * the row-block tiling the CSR-stream SpMV kernel consumes,
+//   * the multi-level (radix-p nested-dissection) factorisation of the
+//     per-chain block-tridiagonal preconditioner.
+// The reference has no counterpart for any of this: its solve happens inside
+// Gurobi (score/solve_score.py:76).  The problem it receives is the one
+// score/utils/gurobi_utils.py:173-187 builds.
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/score_hip.h"
+
+namespace score {
+
+constexpr int kRowsPerBlock = 256;  // rows (= threads) per SpMV workgroup
+constexpr int kTileNnz = 3072;      // products staged in LDS per workgroup (24 KiB)
+constexpr int kLongRow = 48;        // rows longer than this get a workgroup of their own
+constexpr int kConesPerBlock = 256;
+constexpr int kMaxBs = 4;
+
+struct Csr {
+    int64_t nrows = 0, ncols = 0;
+    std::vector<int32_t> ptr, col;
+    std::vector<double> val;
+    int64_t nnz() const { return (int64_t)col.size(); }
+};
+
+struct RowBlocks {
+    std::vector<int32_t> first_row;  // nb + 1
+    std::vector<int32_t> prob;       // nb
+    std::vector<int32_t> part_ptr;   // count + 1 : block range of each problem
+    int nb() const { return (int)prob.size(); }
+};
+
+struct ChainLevelDesc {
+    int32_t N;         // nodes on this level
+    int32_t p;         // radix (0 = last level: one sequential run)
+    int32_t data_off;  // first node of this level in `fac` (units of nodes)
+    int32_t vec_off;   // first node of this level in the chain's scratch (level >= 1)
+};
+
+struct ChainDesc {
+    int32_t level_begin, n_levels;
+    int32_t prob;
+    int32_t node_begin;  // first level-0 node in node_col
+    int32_t N;           // level-0 nodes
+    int32_t scratch_off; // first scratch node (global scratch, units of nodes)
+    int32_t scratch_nodes;
+    int32_t pad;
+};
+
+// Work item of the preconditioner kernel: a chain, or a block of Jacobi columns.
+struct PrecWork {
+    int32_t kind;   // 0 = chain, 1 = jacobi block
+    int32_t index;  // chain id, or first entry in diag_cols
+    int32_t count;  // jacobi: entries in this block
+    int32_t prob;
+};
+
+inline void mat_mul(const double* A, const double* B, double* C, int bs) {
+    for (int i = 0; i < bs; ++i)
+        for (int j = 0; j < bs; ++j) {
+            double s = 0;
+            for (int k = 0; k < bs; ++k) s += A[i * bs + k] * B[k * bs + j];
+            C[i * bs + j] = s;
+        }
+}
+inline void mat_mul_bt(const double* A, const double* B, double* C, int bs) {  // A * B'
+    for (int i = 0; i < bs; ++i)
+        for (int j = 0; j < bs; ++j) {
+            double s = 0;
+            for (int k = 0; k < bs; ++k) s += A[i * bs + k] * B[j * bs + k];
+            C[i * bs + j] = s;
+        }
+}
+inline void mat_mul_at(const double* A, const double* B, double* C, int bs) {  // A' * B
+    for (int i = 0; i < bs; ++i)
+        for (int j = 0; j < bs; ++j) {
+            double s = 0;
+            for (int k = 0; k < bs; ++k) s += A[k * bs + i] * B[k * bs + j];
+            C[i * bs + j] = s;
+        }
+}
+inline void mat_t(const double* A, double* C, int bs) {
+    for (int i = 0; i < bs; ++i)
+        for (int j = 0; j < bs; ++j) C[i * bs + j] = A[j * bs + i];
+}
+inline bool mat_inv(const double* A, double* Ainv, int bs) {  // Gauss-Jordan, partial pivoting
+    double M[kMaxBs][2 * kMaxBs];
+    for (int i = 0; i < bs; ++i)
+        for (int j = 0; j < bs; ++j) {
+            M[i][j] = A[i * bs + j];
+            M[i][bs + j] = (i == j) ? 1.0 : 0.0;
+        }
+    for (int c = 0; c < bs; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < bs; ++r)
+            if (std::fabs(M[r][c]) > std::fabs(M[piv][c])) piv = r;
+        if (!(std::fabs(M[piv][c]) > 0.0)) return false;
+        if (piv != c)
+            for (int j = 0; j < 2 * bs; ++j) std::swap(M[c][j], M[piv][j]);
+        double inv = 1.0 / M[c][c];
+        for (int j = 0; j < 2 * bs; ++j) M[c][j] *= inv;
+        for (int r = 0; r < bs; ++r) {
+            if (r == c) continue;
+            double f = M[r][c];
+            if (f != 0.0)
+                for (int j = 0; j < 2 * bs; ++j) M[r][j] -= f * M[c][j];
+        }
+    }
+    for (int i = 0; i < bs; ++i)
+        for (int j = 0; j < bs; ++j) Ainv[i * bs + j] = M[i][bs + j];
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// multi-level factorisation of one SPD block-tridiagonal chain
+//   diagonal blocks Ad[i], sub-diagonal blocks Bs[i] = T[i, i-1] (Bs[0] unused)
+// Node record (4 blocks of bs*bs): interior node  [Lf, Dinv, V, W]
+//                                  separator node [Cl, Cr, -, -]
+// ---------------------------------------------------------------------------
+inline void factor_chain_levels(int bs, int radix, int N0, const std::vector<double>& Ad,
+                                const std::vector<double>& Bs, std::vector<ChainLevelDesc>& levels,
+                                std::vector<double>& fac, int& scratch_nodes) {
+    const int b2 = bs * bs;
+    std::vector<double> curA = Ad, curB = Bs;
+    int N = N0, vec_off = 0;
+    double D[16], T1[16], T2[16];
+    for (int lvl = 0;; ++lvl) {
+        ChainLevelDesc L;
+        L.N = N;
+        L.data_off = (int32_t)(fac.size() / (size_t)(4 * b2));
+        L.vec_off = (lvl == 0) ? -1 : vec_off;
+        if (lvl > 0) vec_off += N;
+        const size_t base = fac.size();
+        fac.resize(base + (size_t)N * 4 * b2, 0.0);
+        auto nd = [&](int i, int slot) { return &fac[base + ((size_t)i * 4 + slot) * b2]; };
+        const bool last = (N <= radix);
+        L.p = last ? 0 : radix;
+        const int nsep = last ? 0 : N / radix;
+        std::vector<double> nA((size_t)nsep * b2, 0.0), nB((size_t)nsep * b2, 0.0);
+        for (int j = 0; j <= nsep; ++j) {
+            const int lo = last ? 0 : j * radix;
+            const int hi = last ? N : std::min(j * radix + radix - 1, N);
+            if (lo >= hi) continue;
+            for (int i = lo; i < hi; ++i) {
+                if (i == lo) {
+                    std::memcpy(D, &curA[(size_t)i * b2], sizeof(double) * b2);
+                } else {
+                    mat_mul(&curB[(size_t)i * b2], nd(i - 1, 1), nd(i, 0), bs);    // Lf = B Dinv_prev
+                    mat_mul_bt(nd(i, 0), &curB[(size_t)i * b2], T1, bs);           // Lf B'
+                    for (int k = 0; k < b2; ++k) D[k] = curA[(size_t)i * b2 + k] - T1[k];
+                }
+                if (!mat_inv(D, nd(i, 1), bs))
+                    throw std::runtime_error("chain preconditioner: singular diagonal block");
+            }
+            if (last) continue;
+            const bool hasL = (j >= 1), hasR = (j < nsep);
+            for (int side = 0; side < 2; ++side) {
+                if ((side == 0 && !hasL) || (side == 1 && !hasR)) continue;
+                const int slot = 2 + side;
+                // right-hand side: block at lo (V) = B[lo]; block at hi-1 (W) = B[hi]'
+                // forward: a_i = rhs_i - Lf_i a_{i-1}
+                for (int i = lo; i < hi; ++i) {
+                    double* a = nd(i, slot);
+                    for (int k = 0; k < b2; ++k) a[k] = 0.0;
+                    if (side == 0 && i == lo) std::memcpy(a, &curB[(size_t)lo * b2], sizeof(double) * b2);
+                    if (side == 1 && i == hi - 1) mat_t(&curB[(size_t)hi * b2], a, bs);
+                    if (i > lo) {
+                        mat_mul(nd(i, 0), nd(i - 1, slot), T1, bs);
+                        for (int k = 0; k < b2; ++k) a[k] -= T1[k];
+                    }
+                }
+                // diagonal + backward: y_i = Dinv_i a_i - Lf_{i+1}' y_{i+1}
+                for (int i = hi - 1; i >= lo; --i) {
+                    double* a = nd(i, slot);
+                    mat_mul(nd(i, 1), a, T1, bs);
+                    if (i + 1 < hi) {
+                        mat_mul_at(nd(i + 1, 0), nd(i + 1, slot), T2, bs);
+                        for (int k = 0; k < b2; ++k) T1[k] -= T2[k];
+                    }
+                    std::memcpy(a, T1, sizeof(double) * b2);
+                }
+            }
+        }
+        for (int j = 0; j < nsep; ++j) {
+            const int s = j * radix + radix - 1;
+            std::memcpy(nd(s, 0), &curB[(size_t)s * b2], sizeof(double) * b2);  // Cl = T[s, s-1]
+            double* S = &nA[(size_t)j * b2];
+            std::memcpy(S, &curA[(size_t)s * b2], sizeof(double) * b2);
+            mat_mul(nd(s, 0), nd(s - 1, 3), T1, bs);  // Cl * W_{s-1}
+            for (int k = 0; k < b2; ++k) S[k] -= T1[k];
+            if (s + 1 < N) {
+                mat_t(&curB[(size_t)(s + 1) * b2], nd(s, 1), bs);  // Cr = T[s, s+1] = B[s+1]'
+                mat_mul(nd(s, 1), nd(s + 1, 2), T1, bs);           // Cr * V_{s+1}
+                for (int k = 0; k < b2; ++k) S[k] -= T1[k];
+            }
+            if (j >= 1) {
+                mat_mul(nd(s, 0), nd(s - 1, 2), T1, bs);  // Cl * V_{s-1}
+                for (int k = 0; k < b2; ++k) nB[(size_t)j * b2 + k] = -T1[k];
+            }
+        }
+        levels.push_back(L);
+        if (last) break;
+        curA.swap(nA);
+        curB.swap(nB);
+        N = nsep;
+    }
+    scratch_nodes = vec_off;
+}
+
+// Reference (host) application of the factorisation: z = M^{-1} r for one chain.
+// r/z are indexed by column (level 0 gathers through node_col); `scr` holds the
+// level >= 1 vectors.  The HIP kernel performs exactly these operations.
+inline void chain_solve_host(const ChainDesc& ch, const ChainLevelDesc* levels, const double* fac,
+                             const int32_t* node_col, int bs, const double* r, double* z, double* scr) {
+    const int b2 = bs * bs;
+    const int32_t* nc = node_col + ch.node_begin;
+    auto rec = [&](const ChainLevelDesc& L, int i, int slot) {
+        return fac + ((size_t)(L.data_off + i) * 4 + slot) * b2;
+    };
+    for (int lvl = 0; lvl < ch.n_levels; ++lvl) {
+        const ChainLevelDesc& L = levels[ch.level_begin + lvl];
+        const bool last = (L.p == 0);
+        const int nsep = last ? 0 : L.N / L.p;
+        auto in = [&](int i, int c) { return lvl == 0 ? r[nc[i] + c] : scr[(size_t)(L.vec_off + i) * bs + c]; };
+        auto out = [&](int i, int c) -> double& {
+            return lvl == 0 ? z[nc[i] + c] : scr[(size_t)(L.vec_off + i) * bs + c];
+        };
+        for (int j = 0; j <= nsep; ++j) {
+            const int lo = last ? 0 : j * L.p;
+            const int hi = last ? L.N : std::min(j * L.p + L.p - 1, L.N);
+            if (lo >= hi) continue;
+            double prev[kMaxBs], cur[kMaxBs];
+            for (int i = lo; i < hi; ++i) {  // forward
+                for (int c = 0; c < bs; ++c) cur[c] = in(i, c);
+                if (i > lo) {
+                    const double* Lf = rec(L, i, 0);
+                    for (int c = 0; c < bs; ++c)
+                        for (int k = 0; k < bs; ++k) cur[c] -= Lf[c * bs + k] * prev[k];
+                }
+                for (int c = 0; c < bs; ++c) { out(i, c) = cur[c]; prev[c] = cur[c]; }
+            }
+            for (int i = hi - 1; i >= lo; --i) {  // diagonal + backward
+                const double* Di = rec(L, i, 1);
+                double a[kMaxBs];
+                for (int c = 0; c < bs; ++c) a[c] = out(i, c);
+                for (int c = 0; c < bs; ++c) {
+                    double s = 0;
+                    for (int k = 0; k < bs; ++k) s += Di[c * bs + k] * a[k];
+                    cur[c] = s;
+                }
+                if (i + 1 < hi) {
+                    const double* Lf = rec(L, i + 1, 0);
+                    for (int c = 0; c < bs; ++c)
+                        for (int k = 0; k < bs; ++k) cur[c] -= Lf[k * bs + c] * prev[k];
+                }
+                for (int c = 0; c < bs; ++c) { out(i, c) = cur[c]; prev[c] = cur[c]; }
+            }
+        }
+        if (last) break;
+        const ChainLevelDesc& Ln = levels[ch.level_begin + lvl + 1];
+        for (int j = 0; j < nsep; ++j) {
+            const int s = j * L.p + L.p - 1;
+            const double* Cl = rec(L, s, 0);
+            const double* Cr = rec(L, s, 1);
+            for (int c = 0; c < bs; ++c) {
+                double v = in(s, c);
+                for (int k = 0; k < bs; ++k) v -= Cl[c * bs + k] * out(s - 1, k);
+                if (s + 1 < L.N)
+                    for (int k = 0; k < bs; ++k) v -= Cr[c * bs + k] * out(s + 1, k);
+                scr[(size_t)(Ln.vec_off + j) * bs + c] = v;
+            }
+        }
+    }
+    for (int lvl = ch.n_levels - 2; lvl >= 0; --lvl) {
+        const ChainLevelDesc& L = levels[ch.level_begin + lvl];
+        const ChainLevelDesc& Ln = levels[ch.level_begin + lvl + 1];
+        const int nsep = L.N / L.p;
+        auto out = [&](int i, int c) -> double& {
+            return lvl == 0 ? z[nc[i] + c] : scr[(size_t)(L.vec_off + i) * bs + c];
+        };
+        for (int i = 0; i < L.N; ++i) {
+            const int j = i / L.p;
+            if (i % L.p == L.p - 1 && j < nsep) {
+                for (int c = 0; c < bs; ++c) out(i, c) = scr[(size_t)(Ln.vec_off + j) * bs + c];
+                continue;
+            }
+            const double* V = rec(L, i, 2);
+            const double* W = rec(L, i, 3);
+            for (int c = 0; c < bs; ++c) {
+                double v = out(i, c);
+                if (j >= 1)
+                    for (int k = 0; k < bs; ++k) v -= V[c * bs + k] * scr[(size_t)(Ln.vec_off + j - 1) * bs + k];
+                if (j < nsep)
+                    for (int k = 0; k < bs; ++k) v -= W[c * bs + k] * scr[(size_t)(Ln.vec_off + j) * bs + k];
+                out(i, c) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The assembled batch
+// ---------------------------------------------------------------------------
+struct HostSystem {
+    int count = 0;
+    int64_t n_tot = 0, m_tot = 0;
+    std::vector<int64_t> xoff, roff;  // count + 1
+    std::vector<double> c0;
+    double sigma = 1e-6;
+    int bs = 0, radix = 4;
+
+    // scaling (x = D xhat, s = shat / E, y = E yhat)
+    std::vector<double> D, E, q, b;        // q, b scaled
+    std::vector<double> qnorm_u, bnorm_u;  // per problem |q|_inf, |b|_inf (unscaled)
+    std::vector<double> qnorm_s, bnorm_s;  // scaled
+
+    // cones ("type 0" = zero-cone row, "type 1" = second-order cone)
+    std::vector<int32_t> cone_row, cone_dim, cone_type;
+    std::vector<int32_t> cone_block_first, cone_block_prob, cone_part_ptr;
+
+    Csr A;  // scaled, global indices
+    Csr K;
+    std::vector<double> K0, K1;
+    Csr G1;
+    std::vector<int32_t> g1_kidx;
+    Csr G2;
+    std::vector<int32_t> g2_split;  // per row: first entry of the A' part
+    RowBlocks rbK, rbG1, rbG2;
+
+    // preconditioner
+    std::vector<int32_t> node_col;            // level-0 node -> first (global) column
+    std::vector<int32_t> pos_diag, pos_sub;   // K.val positions of the block entries (-1 = 0)
+    std::vector<ChainDesc> chains;
+    std::vector<ChainLevelDesc> levels;
+    std::vector<double> fac;
+    int64_t scratch_nodes = 0;
+    int max_chain_scratch = 0;
+    std::vector<int32_t> diag_cols, diag_kpos;
+    std::vector<double> dinv;  // per entry of diag_cols
+    std::vector<PrecWork> prec_work;
+    std::vector<int32_t> prec_part_ptr;  // count + 1
+
+    std::vector<double> rho;       // per problem
+    std::vector<double> kkt_bytes; // per problem: algorithmic bytes of one K-apply
+
+    std::vector<int64_t> fac_off;  // per chain: offset of its records in `fac` (doubles)
+};
+
+inline int find_in_row(const Csr& M, int64_t row, int32_t col) {
+    const int32_t* b = M.col.data() + M.ptr[row];
+    const int32_t* e = M.col.data() + M.ptr[row + 1];
+    const int32_t* it = std::lower_bound(b, e, col);
+    if (it != e && *it == col) return (int)(it - M.col.data());
+    return -1;
+}
+
+inline RowBlocks make_rowblocks(const Csr& M, const std::vector<int64_t>& xoff) {
+    RowBlocks rb;
+    const int count = (int)xoff.size() - 1;
+    rb.part_ptr.assign(count + 1, 0);
+    for (int p = 0; p < count; ++p) {
+        int64_t r = xoff[p];
+        const int64_t rend = xoff[p + 1];
+        while (r < rend) {
+            rb.first_row.push_back((int32_t)r);
+            rb.prob.push_back(p);
+            int64_t len0 = M.ptr[r + 1] - M.ptr[r];
+            if (len0 > kLongRow) {  // a long row is a block of its own
+                ++r;
+                continue;
+            }
+            int64_t nn = 0, r1 = r;
+            while (r1 < rend && r1 - r < kRowsPerBlock) {
+                int64_t len = M.ptr[r1 + 1] - M.ptr[r1];
+                if (len > kLongRow || nn + len > kTileNnz) break;
+                nn += len;
+                ++r1;
+            }
+            r = r1;
+        }
+        rb.part_ptr[p + 1] = (int32_t)rb.prob.size();
+    }
+    rb.first_row.push_back((int32_t)xoff[count]);
+    return rb;
+}
+
+struct ProblemScaled {
+    Csr P, A;
+    std::vector<double> q, b, D, E;
+};
+
+// Ruiz equilibration of one problem; rows of one cone share a scale.
+inline void ruiz_scale(const score_problem& p, int iters, ProblemScaled& out) {
+    const int n = p.n, m = p.m;
+    out.P.nrows = out.P.ncols = n;
+    out.P.ptr.assign(p.P_rowptr, p.P_rowptr + n + 1);
+    out.P.col.assign(p.P_col, p.P_col + p.P_rowptr[n]);
+    out.P.val.assign(p.P_val, p.P_val + p.P_rowptr[n]);
+    out.A.nrows = m;
+    out.A.ncols = n;
+    out.A.ptr.assign(p.A_rowptr, p.A_rowptr + m + 1);
+    out.A.col.assign(p.A_col, p.A_col + p.A_rowptr[m]);
+    out.A.val.assign(p.A_val, p.A_val + p.A_rowptr[m]);
+    out.D.assign(n, 1.0);
+    out.E.assign(m, 1.0);
+    std::vector<double> cn(n), rn(m), d(n), e(m);
+    for (int it = 0; it < iters; ++it) {
+        std::fill(cn.begin(), cn.end(), 0.0);
+        std::fill(rn.begin(), rn.end(), 0.0);
+        for (int i = 0; i < n; ++i)
+            for (int k = out.P.ptr[i]; k < out.P.ptr[i + 1]; ++k)
+                cn[out.P.col[k]] = std::max(cn[out.P.col[k]], std::fabs(out.P.val[k]));
+        for (int r = 0; r < m; ++r)
+            for (int k = out.A.ptr[r]; k < out.A.ptr[r + 1]; ++k) {
+                double v = std::fabs(out.A.val[k]);
+                cn[out.A.col[k]] = std::max(cn[out.A.col[k]], v);
+                rn[r] = std::max(rn[r], v);
+            }
+        int row = p.z;
+        for (int c = 0; c < p.n_soc; ++c) {  // one scale per cone
+            double mx = 0;
+            for (int k = 0; k < p.soc_dims[c]; ++k) mx = std::max(mx, rn[row + k]);
+            for (int k = 0; k < p.soc_dims[c]; ++k) rn[row + k] = mx;
+            row += p.soc_dims[c];
+        }
+        for (int j = 0; j < n; ++j) d[j] = cn[j] > 1e-12 ? 1.0 / std::sqrt(cn[j]) : 1.0;
+        for (int r = 0; r < m; ++r) e[r] = rn[r] > 1e-12 ? 1.0 / std::sqrt(rn[r]) : 1.0;
+        for (int i = 0; i < n; ++i)
+            for (int k = out.P.ptr[i]; k < out.P.ptr[i + 1]; ++k) out.P.val[k] *= d[i] * d[out.P.col[k]];
+        for (int r = 0; r < m; ++r)
+            for (int k = out.A.ptr[r]; k < out.A.ptr[r + 1]; ++k) out.A.val[k] *= e[r] * d[out.A.col[k]];
+        for (int j = 0; j < n; ++j) out.D[j] *= d[j];
+        for (int r = 0; r < m; ++r) out.E[r] *= e[r];
+    }
+    out.q.resize(n);
+    out.b.resize(m);
+    for (int j = 0; j < n; ++j) out.q[j] = p.q[j] * out.D[j];
+    for (int r = 0; r < m; ++r) out.b[r] = p.b[r] * out.E[r];
+}
+
+inline void validate_problem(const score_problem& p) {
+    if (p.n <= 0) throw std::runtime_error("score_problem: n must be positive");
+    if (p.m < 0 || p.z < 0 || p.z > p.m) throw std::runtime_error("score_problem: bad m / z");
+    if (!p.P_rowptr || !p.q || !p.A_rowptr) throw std::runtime_error("score_problem: null array");
+    int64_t tot = p.z;
+    for (int c = 0; c < p.n_soc; ++c) {
+        if (p.soc_dims[c] < 1) throw std::runtime_error("score_problem: cone dimension < 1");
+        tot += p.soc_dims[c];
+    }
+    if (tot != p.m) throw std::runtime_error("score_problem: z + sum(soc_dims) != m");
+    if (p.P_rowptr[0] != 0 || p.A_rowptr[0] != 0) throw std::runtime_error("score_problem: rowptr[0] != 0");
+    for (int i = 0; i < p.n; ++i) {
+        if (p.P_rowptr[i + 1] < p.P_rowptr[i]) throw std::runtime_error("score_problem: P_rowptr not monotone");
+        for (int k = p.P_rowptr[i]; k < p.P_rowptr[i + 1]; ++k) {
+            if (p.P_col[k] < 0 || p.P_col[k] >= p.n) throw std::runtime_error("score_problem: P column out of range");
+            if (k > p.P_rowptr[i] && p.P_col[k] <= p.P_col[k - 1])
+                throw std::runtime_error("score_problem: P columns must be sorted and unique per row");
+        }
+    }
+    for (int r = 0; r < p.m; ++r) {
+        if (p.A_rowptr[r + 1] < p.A_rowptr[r]) throw std::runtime_error("score_problem: A_rowptr not monotone");
+        for (int k = p.A_rowptr[r]; k < p.A_rowptr[r + 1]; ++k) {
+            if (p.A_col[k] < 0 || p.A_col[k] >= p.n) throw std::runtime_error("score_problem: A column out of range");
+            if (k > p.A_rowptr[r] && p.A_col[k] <= p.A_col[k - 1])
+                throw std::runtime_error("score_problem: A columns must be sorted and unique per row");
+        }
+    }
+    if (p.n_chains > 0) {
+        if (p.block_size < 1 || p.block_size > kMaxBs) throw std::runtime_error("score_problem: block_size must be 1..4");
+        if (!p.chain_ptr || !p.node_first_col) throw std::runtime_error("score_problem: null chain hint");
+        std::vector<char> used(p.n, 0);
+        for (int j = p.chain_ptr[0]; j < p.chain_ptr[p.n_chains]; ++j)
+            for (int c = 0; c < p.block_size; ++c) {
+                int col = p.node_first_col[j] + c;
+                if (col < 0 || col >= p.n) throw std::runtime_error("score_problem: chain node column out of range");
+                if (used[col]) throw std::runtime_error("score_problem: chain nodes overlap");
+                used[col] = 1;
+            }
+    }
+}
+
+// Append problem `b` (already scaled) to the batch: A, K (pattern + K0/K1), G1, G2.
+inline void append_problem(HostSystem& H, int pi, const score_problem& p, const ProblemScaled& S) {
+    const int n = p.n, m = p.m;
+    const int64_t xo = H.xoff[pi], ro = H.roff[pi];
+    // ---- A (global indices) ----
+    for (int r = 0; r < m; ++r) {
+        for (int k = S.A.ptr[r]; k < S.A.ptr[r + 1]; ++k) {
+            H.A.col.push_back((int32_t)(xo + S.A.col[k]));
+            H.A.val.push_back(S.A.val[k]);
+        }
+        H.A.ptr.push_back((int32_t)H.A.col.size());
+    }
+    // ---- A' (local) ----
+    std::vector<int32_t> atp(n + 1, 0), atr(S.A.col.size());
+    std::vector<double> atv(S.A.col.size());
+    for (size_t k = 0; k < S.A.col.size(); ++k) atp[S.A.col[k] + 1]++;
+    for (int j = 0; j < n; ++j) atp[j + 1] += atp[j];
+    {
+        std::vector<int32_t> fill(atp.begin(), atp.end() - 1);
+        for (int r = 0; r < m; ++r)
+            for (int k = S.A.ptr[r]; k < S.A.ptr[r + 1]; ++k) {
+                int pos = fill[S.A.col[k]]++;
+                atr[pos] = r;
+                atv[pos] = S.A.val[k];
+            }
+    }
+    // ---- K rows via a sparse accumulator (Gustavson) ----
+    std::vector<double> acc0(n, 0.0), acc1(n, 0.0);
+    std::vector<int32_t> mark(n, -1), cols;
+    const size_t k_row0 = H.K.ptr.size() - 1;  // == xo
+    (void)k_row0;
+    for (int i = 0; i < n; ++i) {
+        cols.clear();
+        auto touch = [&](int j) {
+            if (mark[j] != i) {
+                mark[j] = i;
+                acc0[j] = 0.0;
+                acc1[j] = 0.0;
+                cols.push_back(j);
+            }
+        };
+        touch(i);
+        acc0[i] += H.sigma;
+        for (int k = S.P.ptr[i]; k < S.P.ptr[i + 1]; ++k) {
+            touch(S.P.col[k]);
+            acc0[S.P.col[k]] += S.P.val[k];
+        }
+        for (int t = atp[i]; t < atp[i + 1]; ++t) {
+            const int r = atr[t];
+            const double a = atv[t];
+            for (int k = S.A.ptr[r]; k < S.A.ptr[r + 1]; ++k) {
+                touch(S.A.col[k]);
+                acc1[S.A.col[k]] += a * S.A.val[k];
+            }
+        }
+        std::sort(cols.begin(), cols.end());
+        // K row
+        for (int j : cols) {
+            H.K.col.push_back((int32_t)(xo + j));
+            H.K0.push_back(acc0[j]);
+            H.K1.push_back(acc1[j]);
+        }
+        H.K.ptr.push_back((int32_t)H.K.col.size());
+        // G1 row = [-K | A']
+        const int32_t kbase = H.K.ptr[H.K.ptr.size() - 2];
+        for (size_t c = 0; c < cols.size(); ++c) {
+            H.G1.col.push_back((int32_t)(xo + cols[c]));
+            H.G1.val.push_back(0.0);
+            H.g1_kidx.push_back(kbase + (int32_t)c);
+        }
+        for (int t = atp[i]; t < atp[i + 1]; ++t) {
+            H.G1.col.push_back((int32_t)(H.n_tot + ro + atr[t]));
+            H.G1.val.push_back(atv[t]);
+            H.g1_kidx.push_back(-1);
+        }
+        H.G1.ptr.push_back((int32_t)H.G1.col.size());
+        // G2 row = [P | A']
+        for (int k = S.P.ptr[i]; k < S.P.ptr[i + 1]; ++k) {
+            H.G2.col.push_back((int32_t)(xo + S.P.col[k]));
+            H.G2.val.push_back(S.P.val[k]);
+        }
+        H.g2_split.push_back((int32_t)H.G2.col.size());
+        for (int t = atp[i]; t < atp[i + 1]; ++t) {
+            H.G2.col.push_back((int32_t)(H.n_tot + ro + atr[t]));
+            H.G2.val.push_back(atv[t]);
+        }
+        H.G2.ptr.push_back((int32_t)H.G2.col.size());
+    }
+}
+
+// (Re)compute everything that depends on rho for problem `pi`: K values, G1
+// values, the chain factorisation and the Jacobi diagonal.
+inline void refresh_rho(HostSystem& H, int pi) {
+    const double rho = H.rho[pi];
+    const int64_t r0 = H.xoff[pi], r1 = H.xoff[pi + 1];
+    for (int64_t k = H.K.ptr[r0]; k < H.K.ptr[r1]; ++k) H.K.val[k] = H.K0[k] + rho * H.K1[k];
+    for (int64_t k = H.G1.ptr[r0]; k < H.G1.ptr[r1]; ++k)
+        if (H.g1_kidx[k] >= 0) H.G1.val[k] = -H.K.val[H.g1_kidx[k]];
+    const int bs = H.bs, b2 = bs * bs;
+    for (size_t ci = 0; ci < H.chains.size(); ++ci) {
+        ChainDesc& ch = H.chains[ci];
+        if (ch.prob != pi) continue;
+        std::vector<double> Ad((size_t)ch.N * b2), Bs((size_t)ch.N * b2, 0.0);
+        for (int i = 0; i < ch.N; ++i) {
+            const size_t g = (size_t)(ch.node_begin + i) * b2;
+            for (int k = 0; k < b2; ++k) {
+                int pd = H.pos_diag[g + k];
+                Ad[(size_t)i * b2 + k] = pd >= 0 ? H.K.val[pd] : 0.0;
+                int ps = H.pos_sub[g + k];
+                Bs[(size_t)i * b2 + k] = (i > 0 && ps >= 0) ? H.K.val[ps] : 0.0;
+            }
+        }
+        std::vector<ChainLevelDesc> lv;
+        std::vector<double> fac;
+        int scr = 0;
+        factor_chain_levels(bs, H.radix, ch.N, Ad, Bs, lv, fac, scr);
+        // level structure depends only on (N, radix): it was laid out at setup
+        const int64_t off = H.fac_off[ci];
+        std::memcpy(&H.fac[off], fac.data(), sizeof(double) * fac.size());
+    }
+    for (size_t e = 0; e < H.diag_cols.size(); ++e) {
+        int32_t c = H.diag_cols[e];
+        if (c < r0 || c >= r1) continue;
+        H.dinv[e] = 1.0 / H.K.val[H.diag_kpos[e]];
+    }
+}
+
+inline void build_system(const score_problem* probs, int count, const score_settings& st, HostSystem& H) {
+    if (count <= 0) throw std::runtime_error("score_create: count must be positive");
+    H = HostSystem();
+    H.count = count;
+    H.sigma = st.sigma;
+    H.radix = std::min(8, std::max(2, st.chain_radix));
+    H.xoff.assign(count + 1, 0);
+    H.roff.assign(count + 1, 0);
+    int bs = 0;
+    for (int p = 0; p < count; ++p) {
+        validate_problem(probs[p]);
+        H.xoff[p + 1] = H.xoff[p] + probs[p].n;
+        H.roff[p + 1] = H.roff[p] + probs[p].m;
+        if (probs[p].n_chains > 0) {
+            if (bs && bs != probs[p].block_size)
+                throw std::runtime_error("score_create_batch: all problems must share block_size");
+            bs = probs[p].block_size;
+        }
+    }
+    H.bs = bs;
+    H.n_tot = H.xoff[count];
+    H.m_tot = H.roff[count];
+    if (H.n_tot + H.m_tot >= (int64_t)1 << 31) throw std::runtime_error("batch too large for 32-bit indices");
+    H.A.nrows = H.m_tot; H.A.ncols = H.n_tot; H.A.ptr.assign(1, 0);
+    H.K.nrows = H.K.ncols = H.n_tot; H.K.ptr.assign(1, 0);
+    H.G1.nrows = H.n_tot; H.G1.ncols = H.n_tot + H.m_tot; H.G1.ptr.assign(1, 0);
+    H.G2.nrows = H.n_tot; H.G2.ncols = H.n_tot + H.m_tot; H.G2.ptr.assign(1, 0);
+    H.cone_part_ptr.assign(count + 1, 0);
+    H.prec_part_ptr.assign(count + 1, 0);
+    H.rho.assign(count, st.rho);
+    for (int p = 0; p < count; ++p) {
+        const score_problem& pr = probs[p];
+        ProblemScaled S;
+        ruiz_scale(pr, std::max(0, st.scale_iters), S);
+        H.D.insert(H.D.end(), S.D.begin(), S.D.end());
+        H.E.insert(H.E.end(), S.E.begin(), S.E.end());
+        H.q.insert(H.q.end(), S.q.begin(), S.q.end());
+        H.b.insert(H.b.end(), S.b.begin(), S.b.end());
+        H.c0.push_back(pr.c0);
+        double qu = 0, bu = 0, qs = 0, bsn = 0;
+        for (int j = 0; j < pr.n; ++j) { qu = std::max(qu, std::fabs(pr.q[j])); qs = std::max(qs, std::fabs(S.q[j])); }
+        for (int r = 0; r < pr.m; ++r) { bu = std::max(bu, std::fabs(pr.b[r])); bsn = std::max(bsn, std::fabs(S.b[r])); }
+        H.qnorm_u.push_back(qu); H.bnorm_u.push_back(bu); H.qnorm_s.push_back(qs); H.bnorm_s.push_back(bsn);
+        append_problem(H, p, pr, S);
+        // cones, in blocks of kConesPerBlock that never straddle problems
+        const size_t c_first = H.cone_row.size();
+        for (int r = 0; r < pr.z; ++r) {
+            H.cone_row.push_back((int32_t)(H.roff[p] + r)); H.cone_dim.push_back(1); H.cone_type.push_back(0);
+        }
+        int row = pr.z;
+        for (int c = 0; c < pr.n_soc; ++c) {
+            H.cone_row.push_back((int32_t)(H.roff[p] + row)); H.cone_dim.push_back(pr.soc_dims[c]); H.cone_type.push_back(1);
+            row += pr.soc_dims[c];
+        }
+        for (size_t c = c_first; c < H.cone_row.size(); c += kConesPerBlock) {
+            H.cone_block_first.push_back((int32_t)c);
+            H.cone_block_prob.push_back(p);
+        }
+        H.cone_part_ptr[p + 1] = (int32_t)H.cone_block_prob.size();
+    }
+    H.cone_block_first.push_back((int32_t)H.cone_row.size());
+    H.K.val.assign(H.K.col.size(), 0.0);
+    H.rbK = make_rowblocks(H.K, H.xoff);
+    H.rbG1 = make_rowblocks(H.G1, H.xoff);
+    H.rbG2 = make_rowblocks(H.G2, H.xoff);
+
+    // ---- preconditioner layout ----
+    const int b2 = bs * bs;
+    std::vector<char> in_chain(H.n_tot, 0);
+    const int max_nodes = 1 << 20;
+    for (int p = 0; p < count; ++p) {
+        const score_problem& pr = probs[p];
+        for (int c = 0; c < pr.n_chains; ++c) {
+            const int nb = pr.chain_ptr[c], ne = pr.chain_ptr[c + 1];
+            if (ne <= nb) continue;
+            if (ne - nb > max_nodes) throw std::runtime_error("chain too long");
+            ChainDesc ch{};
+            ch.prob = p;
+            ch.node_begin = (int32_t)H.node_col.size();
+            ch.N = ne - nb;
+            for (int j = nb; j < ne; ++j) {
+                const int32_t col = (int32_t)(H.xoff[p] + pr.node_first_col[j]);
+                H.node_col.push_back(col);
+                for (int a = 0; a < bs; ++a) in_chain[col + a] = 1;
+                for (int a = 0; a < bs; ++a)
+                    for (int bcol = 0; bcol < bs; ++bcol) {
+                        H.pos_diag.push_back(find_in_row(H.K, col + a, col + bcol));
+                        if (j > nb) {
+                            const int32_t pc = (int32_t)(H.xoff[p] + pr.node_first_col[j - 1]);
+                            H.pos_sub.push_back(find_in_row(H.K, col + a, pc + bcol));
+                        } else {
+                            H.pos_sub.push_back(-1);
+                        }
+                    }
+            }
+            H.chains.push_back(ch);
+        }
+    }
+    // level layout (structure only) + storage
+    H.fac_off.clear();
+    for (auto& ch : H.chains) {
+        // dry run on an identity chain to obtain the level structure
+        std::vector<double> Ad((size_t)ch.N * b2, 0.0), Bs((size_t)ch.N * b2, 0.0);
+        for (int i = 0; i < ch.N; ++i)
+            for (int a = 0; a < bs; ++a) Ad[(size_t)i * b2 + a * bs + a] = 1.0;
+        std::vector<ChainLevelDesc> lv;
+        std::vector<double> fac;
+        int scr = 0;
+        factor_chain_levels(bs, H.radix, ch.N, Ad, Bs, lv, fac, scr);
+        ch.level_begin = (int32_t)H.levels.size();
+        ch.n_levels = (int32_t)lv.size();
+        const int32_t node_base = (int32_t)(H.fac.size() / (size_t)(4 * b2));
+        for (auto& L : lv) {
+            L.data_off += node_base;
+            H.levels.push_back(L);
+        }
+        H.fac_off.push_back((int64_t)H.fac.size());
+        H.fac.resize(H.fac.size() + fac.size(), 0.0);
+        ch.scratch_off = (int32_t)H.scratch_nodes;
+        ch.scratch_nodes = scr;
+        H.scratch_nodes += scr;
+        H.max_chain_scratch = std::max(H.max_chain_scratch, scr);
+    }
+    // Jacobi columns + work list (problem-major: chains, then Jacobi blocks)
+    size_t ci = 0;
+    for (int p = 0; p < count; ++p) {
+        while (ci < H.chains.size() && H.chains[ci].prob == p) {
+            H.prec_work.push_back(PrecWork{0, (int32_t)ci, 0, p});
+            ++ci;
+        }
+        const size_t d_first = H.diag_cols.size();
+        for (int64_t c = H.xoff[p]; c < H.xoff[p + 1]; ++c)
+            if (!in_chain[c]) {
+                H.diag_cols.push_back((int32_t)c);
+                H.diag_kpos.push_back(find_in_row(H.K, c, (int32_t)c));
+            }
+        for (size_t e = d_first; e < H.diag_cols.size(); e += 1024)
+            H.prec_work.push_back(PrecWork{1, (int32_t)e, (int32_t)std::min<size_t>(1024, H.diag_cols.size() - e), p});
+        H.prec_part_ptr[p + 1] = (int32_t)H.prec_work.size();
+    }
+    H.dinv.assign(H.diag_cols.size(), 1.0);
+    // algorithmic bytes of one K-apply per problem: 12 B per nonzero (fp64 value
+    // + int32 column), 4 B per row pointer, vector p read once, w written once
+    H.kkt_bytes.assign(count, 0.0);
+    for (int p = 0; p < count; ++p) {
+        const double nnz = (double)(H.K.ptr[H.xoff[p + 1]] - H.K.ptr[H.xoff[p]]);
+        const double n = (double)(H.xoff[p + 1] - H.xoff[p]);
+        H.kkt_bytes[p] = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
+    }
+    for (int p = 0; p < count; ++p) refresh_rho(H, p);
+}
+
+}  // namespace score

@@ -1,0 +1,115 @@
+"""Multi-GPU execution of independent SCORE problems (Monte-Carlo trials).
+
+``solve_score`` has no cross-problem state (score/solve_score.py:54-86), so a
+set of factor graphs shards embarrassingly: one process per GPU
+(``torch.distributed``; backend "nccl" is RCCL over xGMI on ROCm, "gloo" on
+CPU), problem i goes to one rank (longest-processing-time assignment by
+problem size), every rank solves its share as ONE lock-step batch on its own
+device, and a single all_gather of fixed-stride float64 records returns the
+estimates.  There is no collective on the data path.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import compat
+from .solve_score import solve_score_batch
+
+_HDR = 8  # status, iters, cg_iters, pobj, res_pri, res_dual, solve_ms, n_values
+
+
+def shard_assignment(costs: Sequence[float], world_size: int) -> List[List[int]]:
+    """Longest-processing-time-first assignment; deterministic."""
+    order = sorted(range(len(costs)), key=lambda i: (-float(costs[i]), i))
+    loads = [0.0] * world_size
+    shards: List[List[int]] = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda k: (loads[k], k))
+        shards[r].append(i)
+        loads[r] += float(costs[i])
+    return [sorted(s) for s in shards]
+
+
+def problem_cost(data) -> float:
+    return float(sum(len(c) for c in data.pose_variables) * 6 + 3 * len(data.range_measurements))
+
+
+def _pack(res: compat.SolverResults, data) -> np.ndarray:
+    names = [p.name for chain in data.pose_variables for p in chain]
+    vals = [res.poses[n].ravel() for n in names]
+    vals += [np.asarray(res.landmarks[l.name]).ravel() for l in data.landmark_variables]
+    v = np.concatenate(vals) if vals else np.zeros(0)
+    info = res.info or {}
+    hdr = np.array([
+        float(info.get("status", 1 if res.solved else 0)), float(info.get("iters", 0)), float(info.get("cg_iters", 0)),
+        float(info.get("pobj", np.nan)), float(info.get("res_pri", np.nan)), float(info.get("res_dual", np.nan)),
+        float(info.get("solve_ms", res.total_time * 1e3)), float(v.size),
+    ])
+    return np.concatenate([hdr, v])
+
+
+def _unpack(rec: np.ndarray, data) -> compat.SolverResults:
+    d = data.dimension
+    nv = int(rec[7])
+    v = rec[_HDR : _HDR + nv]
+    names = [p.name for chain in data.pose_variables for p in chain]
+    k = (d + 1) * (d + 1)
+    poses = {n: v[i * k : (i + 1) * k].reshape(d + 1, d + 1).copy() for i, n in enumerate(names)}
+    off = len(names) * k
+    lms = {l.name: v[off + i * d : off + (i + 1) * d].copy() for i, l in enumerate(data.landmark_variables)}
+    info = dict(status=int(rec[0]), iters=int(rec[1]), cg_iters=int(rec[2]), pobj=float(rec[3]),
+                res_pri=float(rec[4]), res_dual=float(rec[5]), solve_ms=float(rec[6]))
+    return compat.SolverResults(
+        variables=compat.VariableValues(d, poses, lms, None), total_time=info["solve_ms"] * 1e-3,
+        solved=info["status"] == 1, pose_chain_names=data.get_pose_chain_names(), solver_cost=info["pobj"], info=info,
+    )
+
+
+def record_stride(datas: Sequence) -> int:
+    worst = 0
+    for data in datas:
+        d = data.dimension
+        worst = max(worst, sum(len(c) for c in data.pose_variables) * (d + 1) ** 2 + len(data.landmark_variables) * d)
+    return _HDR + worst
+
+
+def solve_score_sharded(
+    datas: Sequence, relaxation_type: str = "QCQP", solver_settings: Optional[dict] = None,
+    lib_path: Optional[str] = None, device: Optional[int] = None,
+) -> List[compat.SolverResults]:
+    """Every rank passes the SAME list of factor graphs and gets ALL results."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return solve_score_batch(datas, relaxation_type, solver_settings=solver_settings, lib_path=lib_path)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    shards = shard_assignment([problem_cost(d) for d in datas], world)
+    mine = shards[rank]
+    settings = dict(solver_settings or {})
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    settings.setdefault("device", device)
+    results = solve_score_batch([datas[i] for i in mine], relaxation_type, solver_settings=settings,
+                                lib_path=lib_path) if mine else []
+    stride = record_stride(datas)
+    per_rank = max(len(s) for s in shards)
+    buf = np.zeros((per_rank, stride))
+    for slot, (i, res) in enumerate(zip(mine, results)):
+        rec = _pack(res, datas[i])
+        buf[slot, : rec.size] = rec
+    use_cuda = dist.get_backend() == "nccl"
+    t = torch.from_numpy(buf)
+    if use_cuda:
+        t = t.to(f"cuda:{device}")
+    gathered = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    out: List[Optional[compat.SolverResults]] = [None] * len(datas)
+    for r in range(world):
+        g = gathered[r].cpu().numpy()
+        for slot, i in enumerate(shards[r]):
+            out[i] = _unpack(g[slot], datas[i])
+    return out  # type: ignore[return-value]

@@ -1,0 +1,55 @@
+"""SO(d) rounding of the relaxed rotation blocks.
+
+Counterpart of ``round_to_special_orthogonal`` (score/utils/matrix_utils.py:
+59-79) as used by ``VariableCollection.get_variable_values``
+(score/utils/gurobi_utils.py:115-125): R = U V^T from the SVD, with the last
+singular direction flipped when det(U V^T) < 0, followed by the reference's
+validity check (matrix_utils.py:293-318, rtol = atol = 1e-3).  Batched over
+all poses (one LAPACK call) instead of one Python call per pose.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def get_matrix_determinant(mat: np.ndarray) -> float:
+    """matrix_utils.py:46-56."""
+    mat = np.asarray(mat)
+    assert mat.shape[0] == mat.shape[1], "matrix must be square"
+    return float(np.linalg.det(mat))
+
+
+def check_rotation_matrix(R: np.ndarray, assert_test: bool = True) -> None:
+    """matrix_utils.py:293-318."""
+    d = R.shape[-1]
+    RRt = R @ np.swapaxes(R, -1, -2)
+    if not np.allclose(RRt, np.eye(d), rtol=1e-3, atol=1e-3):
+        if assert_test:
+            raise ValueError(f"R is not orthogonal {RRt}")
+    det = np.linalg.det(R)
+    if np.any(np.abs(det - 1) >= 1e-3):
+        if assert_test:
+            raise ValueError(f"R det incorrect {det}")
+
+
+def round_to_special_orthogonal(mat: np.ndarray) -> np.ndarray:
+    """Round one (d, d) matrix or a (N, d, d) stack onto SO(d)."""
+    mat = np.asarray(mat, dtype=np.float64)
+    single = mat.ndim == 2
+    M = mat[None] if single else mat
+    if M.shape[-1] != M.shape[-2]:
+        raise AssertionError("matrix must be square")
+    try:
+        if not np.all(np.isfinite(M)):
+            raise ValueError("non-finite entries")
+        U, _, Vh = np.linalg.svd(M)
+        R = U @ Vh
+        neg = np.linalg.det(R) < 0
+        if np.any(neg):
+            Uf = U.copy()
+            Uf[neg, :, -1] *= -1.0  # U diag(1,..,1,-1) V^T
+            R = np.where(neg[:, None, None], Uf @ Vh, R)
+        check_rotation_matrix(R, assert_test=True)
+    except (ValueError, np.linalg.LinAlgError):
+        raise ValueError(f"Could not round matrix to special orthogonal form: {mat}")
+    return R[0] if single else R

@@ -1,0 +1,204 @@
+"""Drop-in ``solve_score`` for the SCORE convex relaxation on MI355X.
+
+Mirrors ``score/solve_score.py:54-86`` of the reference:
+
+    solve_score(data: FactorGraphData, relaxation_type: str = "QCQP") -> SolverResults
+
+check the graph (:28-32) -> build the model (gurobi_utils.py:173-187; here
+``score_amd.assemble``) -> optimise (here: the HIP ADMM solver behind the C ABI
+of include/score_hip.h instead of ``model.optimize()``) -> extract results with
+SO(d)-rounded rotations (gurobi_utils.py:114-136, :190-203).
+
+Relaxations.  "SOCP" and "QCQP" are the same convex program after minimising
+out the per-range auxiliary variable (min_{d>=|D|} w(d-dist)^2 =
+w*max(0,|D|-dist)^2 = min_{|r|<=1} w|D - dist*r|^2), so they
+share their optimal poses and landmarks.  By default a "QCQP" request is
+solved through that equivalent SOCP and the optimal ``r_ij`` are reconstructed
+in closed form (r = D / max(|D|, dist)); ``qcqp_mode="direct"`` hands the QCQP
+cone program itself to the solver.
+"""
+from __future__ import annotations
+
+import logging
+import time
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import compat
+from .assemble import (
+    ACCEPTABLE_RELAXATIONS,
+    QCQP_RELAXATION,
+    SOCP_RELAXATION,
+    ScoreModel,
+    assemble,
+    check_valid_relaxation,
+)
+from .rounding import round_to_special_orthogonal
+from .solver import ConicSolver
+
+logger = logging.getLogger(__name__)
+
+DEFAULT_SOLVER_SETTINGS = dict(eps_abs=1e-7, eps_rel=1e-7, max_iters=20000)
+
+
+def _check_factor_graph(data) -> None:
+    """score/solve_score.py:28-32."""
+    unconnected_variables = data.unconnected_variable_names
+    assert len(unconnected_variables) == 0, f"Found {unconnected_variables} unconnected variables. "
+
+
+def _qcqp_dists_from_socp(model: ScoreModel, x_model: np.ndarray, data) -> np.ndarray:
+    """Optimal QCQP range directions for fixed translations: r = D / max(|D|, dist)."""
+    d = model.dim
+    out = np.zeros((len(model.range_keys), d))
+    poses = model.pose_blocks(x_model)
+    lms = model.landmark_block(x_model)
+    pidx = {n: i for i, n in enumerate(model.pose_names)}
+    lidx = {n: i for i, n in enumerate(model.landmark_names)}
+
+    def trans(name):
+        return poses[pidx[name], :, d] if name in pidx else lms[lidx[name]]
+
+    for r, (m, key) in enumerate(zip(data.range_measurements, model.range_keys)):
+        delta = trans(key[0]) - trans(key[1])
+        den = max(float(np.linalg.norm(delta)), float(m.dist))
+        if den > 0:
+            out[r] = delta / den
+    return out
+
+
+def extract_solver_results(
+    model: ScoreModel, x_solver: np.ndarray, data, total_time: float, solved: bool,
+    requested_relaxation: str, info: Optional[dict] = None,
+) -> compat.SolverResults:
+    """gurobi_utils.py:190-203 + VariableCollection.get_variable_values (:114-136)."""
+    d = model.dim
+    xm = model.expand(x_solver)
+    blocks = model.pose_blocks(xm)  # (Np, d, d+1)
+    R = round_to_special_orthogonal(blocks[:, :, :d])
+    T = np.tile(np.eye(d + 1), (blocks.shape[0], 1, 1))
+    T[:, :d, :d] = R
+    T[:, :d, d] = blocks[:, :, d]
+    poses = {nm: T[i] for i, nm in enumerate(model.pose_names)}
+    lm = model.landmark_block(xm)
+    landmarks = {nm: lm[i].copy() for i, nm in enumerate(model.landmark_names)}
+    if requested_relaxation == model.relaxation:
+        rb = model.range_block(xm)
+        dists = {k: rb[i].copy() for i, k in enumerate(model.range_keys)}
+    else:  # QCQP answered through the SOCP
+        rq = _qcqp_dists_from_socp(model, xm, data)
+        dists = {k: rq[i] for i, k in enumerate(model.range_keys)}
+    values = compat.VariableValues(d, poses, landmarks, dists)
+    return compat.SolverResults(
+        variables=values, total_time=total_time, solved=solved,
+        pose_chain_names=data.get_pose_chain_names(), solver_cost=(info or {}).get("pobj"), info=info,
+    )
+
+
+def _resolve_args(args, relaxation_type):
+    """Accept both the reference signature ``solve_score(data, relaxation)`` and
+    the stale example's ``solve_score(data, solver_params, relaxation)``
+    (examples/solve_goats_example_score.py:42-44)."""
+    params = None
+    for a in args:
+        if isinstance(a, str):
+            relaxation_type = a
+        elif a is not None:
+            params = a
+    return params, relaxation_type
+
+
+def _model_for(data, relaxation_type: str, qcqp_mode: str) -> ScoreModel:
+    if relaxation_type == QCQP_RELAXATION and qcqp_mode == "via_socp":
+        return assemble(data, SOCP_RELAXATION)
+    return assemble(data, relaxation_type)
+
+
+def solve_score(
+    data, *args, relaxation_type: str = QCQP_RELAXATION, qcqp_mode: str = "via_socp",
+    solver_settings: Optional[dict] = None, lib_path: Optional[str] = None,
+) -> compat.SolverResults:
+    """MLE estimate of poses and landmarks from the SCORE relaxation.
+
+    args:
+        data (FactorGraphData): the data describing the problem
+        relaxation_type (str): "QCQP" (default, as the reference) or "SOCP"
+    returns:
+        SolverResults: poses are homogeneous (d+1)x(d+1) matrices with rotations
+        rounded to SO(d); ``solved`` is False when the solver did not reach its
+        tolerances (no exception, as in the reference).
+    """
+    _params, relaxation_type = _resolve_args(args, relaxation_type)
+    return solve_score_batch([data], relaxation_type=relaxation_type, qcqp_mode=qcqp_mode,
+                             solver_settings=solver_settings, lib_path=lib_path)[0]
+
+
+def solve_score_batch(
+    datas: Sequence, relaxation_type: str = QCQP_RELAXATION, qcqp_mode: str = "via_socp",
+    solver_settings: Optional[dict] = None, lib_path: Optional[str] = None,
+) -> List[compat.SolverResults]:
+    """Independent factor graphs solved in lock-step by one set of launches."""
+    check_valid_relaxation(relaxation_type)
+    if qcqp_mode not in ("via_socp", "direct"):
+        raise ValueError(f"qcqp_mode {qcqp_mode} is not supported")
+    models = []
+    for data in datas:
+        _check_factor_graph(data)
+        models.append(_model_for(data, relaxation_type, qcqp_mode))
+    settings = dict(DEFAULT_SOLVER_SETTINGS)
+    if any(len(d.loop_closure_measurements) for d in datas):
+        # loop closures are stiff couplings outside the per-robot chains the
+        # preconditioner captures: start with more PCG iterations per KKT solve
+        settings.update(cg_iters=16, cg_target=0.1)
+    if relaxation_type == QCQP_RELAXATION and qcqp_mode == "direct":
+        settings.update(cg_iters=8, adaptive_rho=0)
+    settings.update(solver_settings or {})
+    solver = ConicSolver([m.qp for m in models], settings, lib_path=lib_path)
+    try:
+        sols = solver.solve()
+    finally:
+        solver.close()
+    out = []
+    for data, model, sol in zip(datas, models, sols):
+        if not sol.solved:
+            logger.warning("SCORE solve did not converge: %s", sol.info)
+        out.append(extract_solver_results(
+            model, sol.x, data, total_time=sol.info["solve_ms"] * 1e-3, solved=sol.solved,
+            requested_relaxation=relaxation_type, info=sol.info,
+        ))
+    return out
+
+
+def solve_problem_with_intermediate_iterates(
+    data, relaxation_type: str = QCQP_RELAXATION, every: int = 25, qcqp_mode: str = "via_socp",
+    solver_settings: Optional[dict] = None, lib_path: Optional[str] = None, max_snapshots: int = 400,
+) -> List[compat.SolverResults]:
+    """score/solve_score.py:89-116: one ``SolverResults`` per iteration cap.  The
+    reference restarts the barrier solver with BarIterLimit = 0, 1, 2, ...; here a
+    single run is paused every ``every`` ADMM iterations."""
+    check_valid_relaxation(relaxation_type)
+    _check_factor_graph(data)
+    model = _model_for(data, relaxation_type, qcqp_mode)
+    settings = dict(DEFAULT_SOLVER_SETTINGS)
+    settings.update(solver_settings or {})
+    solver = ConicSolver([model.qp], settings, lib_path=lib_path)
+    iterates = []
+    try:
+        solver.reset()
+        t0 = time.time()
+        for _ in range(max_snapshots):
+            sol = solver.steps(every)[0]
+            finished = sol.info["res_pri"] <= settings["eps_abs"] * 10 and sol.info["res_dual"] <= settings["eps_abs"] * 1e3
+            try:
+                iterates.append(extract_solver_results(
+                    model, sol.x, data, total_time=time.time() - t0, solved=bool(finished),
+                    requested_relaxation=relaxation_type, info=sol.info,
+                ))
+            except ValueError:
+                pass  # an early iterate whose rotation block cannot be rounded yet
+            if finished or sol.info["iters"] >= settings["max_iters"]:
+                break
+    finally:
+        solver.close()
+    return iterates

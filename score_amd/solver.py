@@ -1,0 +1,235 @@
+"""ctypes binding of the C ABI in include/score_hip.h.
+
+``ConicSolver`` loads ``score_amd/csrc/libscore_hip.so`` (the HIP/gfx950
+library).  There is no CPU fallback on the product path: if the library is
+missing or no HIP device is usable, construction raises.  (Tests may point
+``lib_path`` at the oracle's CPU twin, which implements the same ABI.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB = os.path.join(_HERE, "csrc", "libscore_hip.so")
+
+_i32p = C.POINTER(C.c_int32)
+_f64p = C.POINTER(C.c_double)
+
+
+class ScoreProblem(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("m", C.c_int32),
+        ("P_rowptr", _i32p), ("P_col", _i32p), ("P_val", _f64p),
+        ("q", _f64p), ("c0", C.c_double),
+        ("A_rowptr", _i32p), ("A_col", _i32p), ("A_val", _f64p),
+        ("b", _f64p),
+        ("z", C.c_int32), ("n_soc", C.c_int32), ("soc_dims", _i32p),
+        ("block_size", C.c_int32), ("n_chains", C.c_int32),
+        ("chain_ptr", _i32p), ("node_first_col", _i32p),
+    ]
+
+
+class ScoreSettings(C.Structure):
+    _fields_ = [
+        ("eps_abs", C.c_double), ("eps_rel", C.c_double),
+        ("max_iters", C.c_int32), ("check_interval", C.c_int32),
+        ("rho", C.c_double), ("sigma", C.c_double), ("alpha", C.c_double),
+        ("scale_iters", C.c_int32), ("cg_iters", C.c_int32),
+        ("adaptive_cg", C.c_int32), ("max_cg_iters", C.c_int32), ("cg_target", C.c_double),
+        ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
+        ("adaptive_rho_tol", C.c_double),
+        ("chain_radix", C.c_int32), ("device", C.c_int32),
+        ("use_graph", C.c_int32), ("verbose", C.c_int32),
+    ]
+
+
+class ScoreInfo(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("iters", C.c_int32), ("cg_iters", C.c_int32), ("rho_updates", C.c_int32),
+        ("rho", C.c_double), ("pobj", C.c_double), ("dobj", C.c_double),
+        ("res_pri", C.c_double), ("res_dual", C.c_double), ("gap", C.c_double),
+        ("setup_ms", C.c_double), ("solve_ms", C.c_double), ("kkt_bytes", C.c_double),
+    ]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+STATUS_NAMES = {0: "unsolved", 1: "solved", 2: "max_iters", 3: "numerical"}
+
+# every symbol include/score_hip.h declares
+ABI_SYMBOLS = [
+    "score_default_settings", "score_create", "score_create_batch", "score_dims", "score_solve",
+    "score_reset", "score_solve_steps", "score_time_kkt_apply", "score_debug_get", "score_destroy",
+    "score_last_error", "score_backend",
+]
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    path = path or HIP_LIB
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+            "The SCORE solver has no CPU fallback."
+        )
+    lib = C.CDLL(path)
+    lib.score_default_settings.argtypes = [C.POINTER(ScoreSettings)]
+    lib.score_default_settings.restype = None
+    lib.score_create.argtypes = [C.POINTER(ScoreProblem), C.POINTER(ScoreSettings), C.POINTER(C.c_void_p)]
+    lib.score_create_batch.argtypes = [C.POINTER(ScoreProblem), C.c_int32, C.POINTER(ScoreSettings), C.POINTER(C.c_void_p)]
+    lib.score_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
+    lib.score_solve.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, C.POINTER(ScoreInfo)]
+    lib.score_reset.argtypes = [C.c_void_p]
+    lib.score_solve_steps.argtypes = [C.c_void_p, C.c_int32, _f64p, _f64p, _f64p, C.POINTER(ScoreInfo)]
+    lib.score_time_kkt_apply.argtypes = [C.c_void_p, C.c_int32, _f64p, _f64p]
+    lib.score_debug_get.argtypes = [C.c_void_p, C.c_char_p, _f64p, C.c_int64]
+    lib.score_debug_get.restype = C.c_int64
+    lib.score_destroy.argtypes = [C.c_void_p]
+    lib.score_destroy.restype = None
+    lib.score_last_error.restype = C.c_char_p
+    lib.score_backend.restype = C.c_char_p
+    return lib
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _ptr(a: np.ndarray, typ):
+    return a.ctypes.data_as(typ)
+
+
+@dataclass
+class ConicSolution:
+    x: np.ndarray
+    y: np.ndarray
+    s: np.ndarray
+    info: dict
+
+    @property
+    def solved(self) -> bool:
+        return self.info["status"] == 1
+
+
+class ConicSolver:
+    """A batch of conic QPs (``score_amd.assemble.ConicQP``) resident on one GPU."""
+
+    def __init__(self, qps: Sequence, settings: Optional[dict] = None, lib_path: Optional[str] = None):
+        if not isinstance(qps, (list, tuple)):
+            qps = [qps]
+        self.lib = load_library(lib_path)
+        self.count = len(qps)
+        self.ns = [int(qp.n) for qp in qps]
+        self.ms = [int(qp.m) for qp in qps]
+        st = ScoreSettings()
+        self.lib.score_default_settings(C.byref(st))
+        for k, v in (settings or {}).items():
+            if not hasattr(st, k):
+                raise ValueError(f"unknown solver setting {k}")
+            setattr(st, k, v)
+        self.settings = st
+        self._keep = []  # borrowed arrays must outlive score_create
+        probs = (ScoreProblem * self.count)()
+        for i, qp in enumerate(qps):
+            P = qp.P.tocsr()
+            A = qp.A.tocsr()
+            if not P.has_sorted_indices:
+                P = P.sorted_indices()
+            if not A.has_sorted_indices:
+                A = A.sorted_indices()
+            arrs = dict(
+                Pp=_i32(P.indptr), Pc=_i32(P.indices), Pv=_f64(P.data), q=_f64(qp.q),
+                Ap=_i32(A.indptr), Ac=_i32(A.indices), Av=_f64(A.data), b=_f64(qp.b),
+                soc=_i32(qp.soc_dims), cp=_i32(qp.chain_ptr), nc=_i32(qp.node_cols[:: max(1, qp.block_size)] if qp.block_size else qp.node_cols),
+            )
+            if qp.block_size:
+                nodes = np.asarray(qp.node_cols).reshape(-1, qp.block_size)
+                if nodes.size and not np.all(np.diff(nodes, axis=1) == 1):
+                    raise ValueError("chain nodes must own consecutive columns")
+            self._keep.append(arrs)
+            p = probs[i]
+            p.n, p.m = qp.n, qp.m
+            p.P_rowptr, p.P_col, p.P_val = _ptr(arrs["Pp"], _i32p), _ptr(arrs["Pc"], _i32p), _ptr(arrs["Pv"], _f64p)
+            p.q, p.c0 = _ptr(arrs["q"], _f64p), float(qp.c0)
+            p.A_rowptr, p.A_col, p.A_val = _ptr(arrs["Ap"], _i32p), _ptr(arrs["Ac"], _i32p), _ptr(arrs["Av"], _f64p)
+            p.b = _ptr(arrs["b"], _f64p)
+            p.z, p.n_soc, p.soc_dims = int(qp.z), int(len(qp.soc_dims)), _ptr(arrs["soc"], _i32p)
+            nch = int(len(qp.chain_ptr) - 1) if qp.block_size else 0
+            p.block_size, p.n_chains = int(qp.block_size), nch
+            p.chain_ptr, p.node_first_col = _ptr(arrs["cp"], _i32p), _ptr(arrs["nc"], _i32p)
+        self._h = C.c_void_p()
+        rc = self.lib.score_create_batch(probs, self.count, C.byref(st), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise RuntimeError(f"score_create_batch failed: {self.lib.score_last_error().decode()}")
+        self._keep.clear()
+        self.n_total, self.m_total = sum(self.ns), sum(self.ms)
+
+    @property
+    def backend(self) -> str:
+        return self.lib.score_backend().decode()
+
+    def _split(self, x, y, s, infos) -> List[ConicSolution]:
+        out, xo, ro = [], 0, 0
+        for i in range(self.count):
+            out.append(ConicSolution(
+                x[xo : xo + self.ns[i]].copy(), y[ro : ro + self.ms[i]].copy(), s[ro : ro + self.ms[i]].copy(),
+                infos[i].as_dict(),
+            ))
+            xo += self.ns[i]
+            ro += self.ms[i]
+        return out
+
+    def solve(self) -> List[ConicSolution]:
+        x = np.empty(self.n_total); y = np.empty(self.m_total); s = np.empty(self.m_total)
+        infos = (ScoreInfo * self.count)()
+        rc = self.lib.score_solve(self._h, _ptr(x, _f64p), _ptr(y, _f64p), _ptr(s, _f64p), infos)
+        if rc != 0:
+            raise RuntimeError(f"score_solve failed: {self.lib.score_last_error().decode()}")
+        return self._split(x, y, s, infos)
+
+    def reset(self) -> None:
+        if self.lib.score_reset(self._h) != 0:
+            raise RuntimeError(self.lib.score_last_error().decode())
+
+    def steps(self, iters: int) -> List[ConicSolution]:
+        x = np.empty(self.n_total); y = np.empty(self.m_total); s = np.empty(self.m_total)
+        infos = (ScoreInfo * self.count)()
+        rc = self.lib.score_solve_steps(self._h, int(iters), _ptr(x, _f64p), _ptr(y, _f64p), _ptr(s, _f64p), infos)
+        if rc != 0:
+            raise RuntimeError(f"score_solve_steps failed: {self.lib.score_last_error().decode()}")
+        return self._split(x, y, s, infos)
+
+    def time_kkt_apply(self, reps: int = 200):
+        ms, by = C.c_double(), C.c_double()
+        if self.lib.score_time_kkt_apply(self._h, int(reps), C.byref(ms), C.byref(by)) != 0:
+            raise RuntimeError(self.lib.score_last_error().decode())
+        return ms.value, by.value
+
+    def debug_get(self, name: str) -> np.ndarray:
+        sz = self.lib.score_debug_get(self._h, name.encode(), None, 0)
+        if sz < 0:
+            raise KeyError(name)
+        out = np.empty(sz)
+        self.lib.score_debug_get(self._h, name.encode(), _ptr(out, _f64p), sz)
+        return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.score_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,186 @@
+"""CPU tests: the oracle against its anchors, and the product assembler against
+the oracle's literal restatement of score/utils/gurobi_utils.py."""
+import numpy as np
+import pytest
+
+from conftest import SYNTH, graph_by_name, load_golden
+from oracle import score_oracle as so
+from score_amd import compat
+from score_amd.assemble import assemble
+from score_amd.manhattan import make_manhattan
+
+
+def _random_values(mdl, rng):
+    """A random model-space point that satisfies the pin, as named containers."""
+    d = mdl.dim
+    xs = rng.normal(size=mdl.qp.n)
+    xm = mdl.expand(xs)
+    vals = {
+        "poses": {nm: mdl.pose_blocks(xm)[i] for i, nm in enumerate(mdl.pose_names)},
+        "landmarks": {nm: mdl.landmark_block(xm)[i] for i, nm in enumerate(mdl.landmark_names)},
+        "dists": {k: mdl.range_block(xm)[i] for i, k in enumerate(mdl.range_keys)},
+    }
+    return xs, vals
+
+
+def _graph_3d(seed=5, n=12, n_lm=3):
+    """Small 3-D graph (one chain + landmarks + ranges + a prior + a loop closure)."""
+    rng = np.random.default_rng(seed)
+    fg = compat.FactorGraphData(dimension=3)
+    fg.pose_variables = [[compat.PoseVariable3D(f"A{i}", tuple(rng.normal(size=3))) for i in range(n)]]
+    fg.landmark_variables = [compat.LandmarkVariable3D(f"L{i}", tuple(rng.normal(size=3) * 5)) for i in range(n_lm)]
+
+    def rot():
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, -1] *= -1
+        return q
+
+    fg.odom_measurements = [[
+        compat.PoseMeasurement3D(f"A{i}", f"A{i+1}", rng.normal(size=3), rot(), 100.0 + i, 400.0 + i) for i in range(n - 1)
+    ]]
+    fg.loop_closure_measurements = [compat.PoseMeasurement3D("A2", "A9", rng.normal(size=3), rot(), 50.0, 70.0)]
+    for i in range(0, n, 2):
+        fg.range_measurements.append(compat.FGRangeMeasurement((f"A{i}", f"L{i % n_lm}"), float(rng.uniform(1, 6)), 0.5))
+    fg.landmark_priors = [compat.LandmarkPrior3D("L1", (1.0, -2.0, 0.5), 3.0)]
+    return fg
+
+
+@pytest.mark.parametrize("relax", ["SOCP", "QCQP"])
+@pytest.mark.parametrize("name", ["manhattan", "goats", "synth_b", "3d"])
+def test_assembler_matches_literal_model(name, relax, fixtures):
+    fg = _graph_3d() if name == "3d" else graph_by_name(name, fixtures)
+    mdl = assemble(fg, relax)
+    lit = so.LiteralModel(fg, relax)
+    rng = np.random.default_rng(1)
+    for _ in range(3):
+        xs, vals = _random_values(mdl, rng)
+        direct = lit.direct_cost(vals)
+        assert lit.pin_violation(vals) == 0.0
+        assert mdl.qp.objective(xs) == pytest.approx(direct, rel=1e-11)
+        # cone rows: s = b - A x must be (d_ij, t_i - t_j) resp. (1, r_ij)
+        s = (mdl.qp.b - mdl.qp.A @ xs).reshape(-1, mdl.dim + 1)
+        for r, key in enumerate(mdl.range_keys[:50]):
+            if relax == "SOCP":
+                diff = lit.translation(vals, key[0]) - lit.translation(vals, key[1])
+                np.testing.assert_allclose(s[r], np.concatenate([vals["dists"][key], diff]), atol=1e-12)
+            else:
+                np.testing.assert_allclose(s[r], np.concatenate([[1.0], vals["dists"][key]]), atol=1e-12)
+
+
+def test_fixture_statistics(fixtures):
+    """Counts of the reference's shipped data files."""
+    m, g = fixtures["manhattan"], fixtures["goats"]
+    assert (m.num_poses, m.num_landmarks, len(m.range_measurements)) == (1600, 6, 1160)
+    assert sum(len(c) for c in m.odom_measurements) == 1596 and len(m.pose_priors) == 1
+    assert (g.num_poses, g.num_landmarks, len(g.range_measurements)) == (679, 4, 1558)
+    assert g.range_measurements[0].precision == pytest.approx(1.0 / 0.75 ** 2)
+    ms = assemble(m, "SOCP").qp
+    assert (ms.n, ms.m) == (10772 - 6, 3 * 1160)  # pinned pose eliminated; lb rows implied by the cone
+    assert assemble(m, "QCQP").qp.n == 11932 - 6
+    assert assemble(g, "SOCP").qp.n == 5640 - 6 and assemble(g, "QCQP").qp.n == 7198 - 6
+
+
+@pytest.mark.parametrize("name", ["manhattan", "goats", "synth_a", "synth_b", "synth_c"])
+def test_newton_oracle_reproduces_golden(name, fixtures):
+    fg = graph_by_name(name, fixtures)
+    gold = load_golden(name)
+    rp, u, info = so.newton_solve(fg, tol=1e-13, max_iter=300)
+    vals = so.reduced_to_values(rp, u, "SOCP")
+    obj = so.LiteralModel(fg, "SOCP").direct_cost(vals)
+    assert obj == pytest.approx(float(gold["objective"]), rel=1e-8, abs=1e-9)
+    P = np.stack([vals["poses"][str(n)] for n in gold["pose_names"]])
+    det = gold["pose_determined"]
+    np.testing.assert_allclose(P[det], gold["poses"][det], atol=1e-6 * max(1.0, np.abs(gold["poses"]).max()))
+
+
+def test_survey_anchor_values():
+    """Survey-time anchors: 33.66585 and 330.487."""
+    assert float(load_golden("manhattan")["objective"]) == pytest.approx(33.66585, abs=2e-5)
+    assert float(load_golden("goats")["objective"]) == pytest.approx(330.487, abs=1e-3)
+
+
+@pytest.mark.parametrize("name", ["manhattan", "synth_c"])
+def test_oracle_optimum_certified_on_product_matrices(name, fixtures):
+    """Solver-independent certificate: the Newton optimum, with the multipliers the
+    reduced problem implies, satisfies the KKT conditions of the conic program the
+    PRODUCT assembler built -- for both relaxations (they share poses/landmarks)."""
+    fg = graph_by_name(name, fixtures)
+    rp, u, _ = so.newton_solve(fg, tol=1e-13)
+    for relax in ("SOCP", "QCQP"):
+        mdl = assemble(fg, relax)
+        vals = so.reduced_to_values(rp, u, relax)
+        lit = so.LiteralModel(fg, relax)
+        assert lit.cone_violation(vals) < 1e-9
+        d = mdl.dim
+        xm = np.zeros(mdl.n_model)
+        for i, nm in enumerate(mdl.pose_names):
+            xm[i * d * (d + 1) : (i + 1) * d * (d + 1)] = vals["poses"][nm].ravel()
+        for i, nm in enumerate(mdl.landmark_names):
+            xm[mdl.lm_base + i * d : mdl.lm_base + (i + 1) * d] = vals["landmarks"][nm]
+        for i, k in enumerate(mdl.range_keys):
+            xm[mdl.rng_base + i * mdl.rng_width : mdl.rng_base + (i + 1) * mdl.rng_width] = vals["dists"][k]
+        x = mdl.reduce(xm)
+        dl = rp.deltas(u)
+        rho = np.linalg.norm(dl, axis=1)
+        uh = np.where(rho[:, None] > 0, dl / np.maximum(rho, 1e-300)[:, None], 0.0)
+        ex = np.maximum(0.0, rho - rp.dist)
+        y = np.zeros((rp.nr, d + 1))
+        if relax == "SOCP":  # y = 2w max(0,|D|-dist) (1, -u)
+            y[:, 0] = 2 * rp.wr * ex
+            y[:, 1:] = -(2 * rp.wr * ex)[:, None] * uh
+        else:  # y_vec = -2 w dist (D - dist r), y_0 = |y_vec|
+            rr = np.stack([vals["dists"][k] for k in mdl.range_keys])
+            yv = -2 * (rp.wr * rp.dist)[:, None] * (dl - rp.dist[:, None] * rr)
+            y[:, 1:] = yv
+            y[:, 0] = np.linalg.norm(yv, axis=1)
+        cert = so.kkt_certificate(mdl.qp.P, mdl.qp.q, mdl.qp.A, mdl.qp.b, 0, mdl.qp.soc_dims, x, y.ravel())
+        scale = max(1.0, np.abs(mdl.qp.q).max())
+        assert cert["dual_res_inf"] < 1e-9 * scale, cert
+        assert cert["s_cone_dist"] < 1e-9 and cert["y_cone_dist"] < 1e-9, cert
+        assert cert["complementarity"] < 1e-7 * scale, cert
+
+
+def test_relaxations_share_poses(fixtures):
+    """SOCP / QCQP equivalence: same reduced problem, so one Newton
+    solve serves both; the literal costs of the two expansions agree."""
+    fg = fixtures["manhattan"]
+    rp, u, _ = so.newton_solve(fg, tol=1e-13)
+    c_socp = so.LiteralModel(fg, "SOCP").direct_cost(so.reduced_to_values(rp, u, "SOCP"))
+    c_qcqp = so.LiteralModel(fg, "QCQP").direct_cost(so.reduced_to_values(rp, u, "QCQP"))
+    assert c_socp == pytest.approx(c_qcqp, rel=1e-10)
+
+
+def test_input_validation(fixtures):
+    fg = make_manhattan(n_robots=1, n_poses=5, n_beacons=1, seed=0, p_range=1.0)
+    with pytest.raises(ValueError, match="not supported"):
+        assemble(fg, "SDP")
+    fg.dimension = 4
+    with pytest.raises(ValueError, match="not 2 or 3"):
+        assemble(fg, "SOCP")
+    fg.dimension = 2
+    fg.landmark_variables.append(compat.LandmarkVariable2D("A1"))
+    with pytest.raises(ValueError, match="already exists"):
+        assemble(fg, "SOCP")
+    fg.landmark_variables.pop()
+    fg.range_measurements.append(fg.range_measurements[0])
+    with pytest.raises(ValueError, match="already exists in distance_vars"):
+        assemble(fg, "SOCP")
+
+
+def test_generator_statistics():
+    """The synthetic generator reproduces the shipped fixture's statistics."""
+    fg = make_manhattan(n_robots=4, n_poses=400, n_beacons=6, seed=3)
+    assert fg.unconnected_variable_names == []
+    n_pb = sum(1 for m in fg.range_measurements if m.second_key.startswith("L"))
+    n_rr = len(fg.range_measurements) - n_pb
+    assert 0.08 < n_pb / (4 * 400 * 6) < 0.12 and 0.07 < n_rr / (6 * 400) < 0.13
+    th = np.array([m.theta for c in fg.odom_measurements for m in c])
+    turn = np.mean(np.abs(th) > 0.5)
+    assert 0.12 < turn < 0.30
+    assert all(m.dist >= 0 for m in fg.range_measurements)
+    p0 = fg.pose_variables[0][0]
+    assert p0.true_position == (0.0, 0.0) and p0.true_theta == 0.0
+    a = make_manhattan(n_robots=2, n_poses=30, n_beacons=2, seed=9)
+    b = make_manhattan(n_robots=2, n_poses=30, n_beacons=2, seed=9)
+    assert [m.dist for m in a.range_measurements] == [m.dist for m in b.range_measurements]
