@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SOCP (ADMM) iterations/s and problems/s of the SCORE
+relaxation on the 20-robot / 4-beacon Manhattan RA-SLAM workload
+(BASELINE.json configs[3]), with the HBM roofline of the KKT SpMV and a CPU
+baseline timed on the same box.
+
+A "step" = one cold-start solve to tolerance of one synthetic factor graph per
+GPU (per rank: its own Monte-Carlo trial, weak scaling; no data-path
+collective).  Problem data are assembled and resident in HBM before the timed
+region.  One JSON line on stdout (rank 0).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--robots", type=int, default=20)
+    ap.add_argument("--poses", type=int, default=1000)
+    ap.add_argument("--beacons", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=1, help="independent trials per GPU solved in lock-step")
+    ap.add_argument("--relaxation", default="SOCP")
+    ap.add_argument("--eps", type=float, default=1e-7)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline time budget")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--kkt-reps", type=int, default=2000)
+    return ap.parse_args()
+
+
+def make_workload(args, rank: int):
+    from score_amd.assemble import assemble
+    from score_amd.manhattan import make_manhattan
+
+    models = []
+    for j in range(args.batch):
+        trial = rank * args.batch + j
+        fg = make_manhattan(n_robots=args.robots, n_poses=args.poses, n_beacons=args.beacons, seed=3000 + trial)
+        models.append(assemble(fg, args.relaxation))
+    return models
+
+
+def cpu_baseline(args, models):
+    """The oracle's CPU twin (same algorithm, OpenMP loops) on a bounded sample of
+    the same workload: a fixed number of cold-start ADMM iterations."""
+    import __graft_entry__ as g
+    from score_amd.solver import ConicSolver
+
+    lib = g.build_oracle()
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    sol = ConicSolver([m.qp for m in models[:1]], dict(eps_abs=args.eps, eps_rel=args.eps), lib_path=lib)
+    sol.reset()
+    t0 = time.perf_counter()
+    sol.steps(25)
+    per25 = max(1e-4, time.perf_counter() - t0)
+    n_it = int(max(25, min(5000, (args.cpu_seconds / per25) * 25)) // 25 * 25)
+    sol.reset()
+    t0 = time.perf_counter()
+    out = sol.steps(n_it)[0]
+    dt = time.perf_counter() - t0
+    sol.close()
+    return {
+        "value": n_it / dt, "unit": "iters/s", "cores": int(os.environ.get("OMP_NUM_THREADS", cores)), "kind": "port",
+        "sample": f"{n_it} cold-start ADMM iterations of trial 0 of the same workload "
+                  f"(oracle/cpu_twin, OpenMP, {out.info['cg_iters']} PCG iterations)",
+        "seconds": dt,
+    }
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    workload = (f"manhattan RA-SLAM, {args.robots} robots x {args.poses} poses, {args.beacons} beacons, "
+                f"{args.relaxation} relaxation, {args.batch} trial(s)/GPU")
+    models = make_workload(args, rank)
+
+    if args.cpu_baseline_only:
+        print(json.dumps({"cpu_baseline": cpu_baseline(args, models), "config": {"workload": workload}}))
+        return
+
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    from score_amd.solver import ConicSolver
+
+    settings = dict(eps_abs=args.eps, eps_rel=args.eps, device=local_rank)
+    solver = ConicSolver([m.qp for m in models], settings)  # HIP library; fails loudly without it
+    assert solver.backend == "hip-gfx950"
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        solver.solve()
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    cg = 0
+    solved = 0
+    last = None
+    for _ in range(args.steps):
+        last = solver.solve()
+        iters += sum(s.info["iters"] for s in last)
+        cg += sum(s.info["cg_iters"] for s in last)
+        solved += sum(1 for s in last if s.solved)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    kkt_ms, kkt_bytes = solver.time_kkt_apply(args.kkt_reps)
+    stats = torch.tensor([dt, float(iters), float(args.steps * args.batch), float(solved), float(cg)], dtype=torch.float64)
+    if world > 1:
+        stats = stats.cuda()
+        tmax = stats[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tot = stats[1:].clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        dt_max, tot = float(tmax.item()), tot.cpu().tolist()
+    else:
+        dt_max, tot = dt, stats[1:].tolist()
+    if rank == 0:
+        info = last[0].info
+        achieved = kkt_bytes / (kkt_ms * 1e-3) / 1e9
+        rec = {
+            "metric": "socp_iters_per_sec", "value": tot[0] / dt_max, "unit": "iters/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt_max / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "n": int(models[0].qp.n), "m": int(models[0].qp.m),
+                       "nnz_P": int(models[0].qp.P.nnz), "eps": args.eps, "parallelism": f"independent x{world}"},
+            "problems_per_sec": tot[1] / dt_max, "problems_solved": int(tot[2]), "problems_total": int(tot[1]),
+            "admm_iters_per_solve": tot[0] / max(1.0, tot[1]), "pcg_iters_per_admm_iter": tot[3] / max(1.0, tot[0]),
+            "final": {"pobj": info["pobj"], "res_pri": info["res_pri"], "res_dual": info["res_dual"], "rho": info["rho"]},
+            "roofline": {"bound": "hbm", "kernel": "k_spmv<KP> (w = K p, KKT operator)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": kkt_bytes, "us_per_launch": kkt_ms * 1e3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            rec["cpu_baseline"] = cpu_baseline(args, models)
+            rec["speedup_vs_cpu_baseline"] = rec["value"] / rec["cpu_baseline"]["value"]
+        print(json.dumps(rec), flush=True)
+    solver.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -101,7 +101,10 @@ struct Solver {
                 continue;
             }
             const double pn = std::max(std::max(r.ax_u, r.s_u), H.bnorm_u[p]);
-            const double dn = std::max(std::max(r.px_u, r.aty_u), H.qnorm_u[p]);
+            // dual scale: the constraint forces only.  |Px| and |q| carry the stiff
+            // pinned-pose constants (1e5..1e6) that cancel in Px + q and would make a
+            // relative test vacuous.
+            const double dn = r.aty_u;
             const bool ok_p = r.rp_u <= st.eps_abs + st.eps_rel * pn;
             const bool ok_d = r.rd_u <= st.eps_abs + st.eps_rel * dn;
             const bool ok_g = I.gap <= st.eps_abs + st.eps_rel * std::max(std::fabs(I.pobj), std::fabs(I.dobj));

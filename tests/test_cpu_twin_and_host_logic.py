@@ -1,0 +1,172 @@
+"""CPU tests of everything that does not need a GPU: the shared host-side setup
+(equilibration, KKT assembly, multi-level chain factorisation) and the ADMM
+driver, executed through the oracle's CPU twin of the C ABI; the Python API
+(solve_score and friends) on top of it."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+from conftest import compare_with_golden, graph_by_name, load_golden
+from score_amd import compat
+from score_amd.assemble import assemble
+from score_amd.manhattan import make_manhattan
+from score_amd.solve_score import (
+    solve_problem_with_intermediate_iterates,
+    solve_score,
+    solve_score_batch,
+)
+from score_amd.solver import ConicSolver
+
+
+@pytest.mark.parametrize("name", ["manhattan", "synth_a", "synth_b", "synth_c"])
+@pytest.mark.parametrize("relax", ["SOCP", "QCQP"])
+def test_twin_solve_score_matches_golden(name, relax, fixtures, twin_lib):
+    fg = graph_by_name(name, fixtures)
+    gold = load_golden(name)
+    res = solve_score(fg, relax, lib_path=twin_lib)
+    assert res.solved, res.info
+    assert res.info["pobj"] == pytest.approx(float(gold["objective"]), rel=1e-5, abs=1e-6)
+    compare_with_golden(res, gold)
+    assert res.pose_chain_names == fg.get_pose_chain_names()
+    d = fg.dimension
+    key = (fg.range_measurements[0].first_key, fg.range_measurements[0].second_key) if fg.range_measurements else None
+    if key is not None:
+        assert res.distances[key].shape == ((1,) if relax == "SOCP" else (d,))
+        if relax == "QCQP":
+            assert max(np.linalg.norm(v) for v in res.distances.values()) <= 1 + 1e-9
+    T = res.poses[fg.pose_variables[0][0].name]
+    np.testing.assert_allclose(T, np.eye(d + 1), atol=1e-12)  # the pinned pose
+
+
+def test_twin_goats(fixtures, twin_lib):
+    """BASELINE config 0: the GOATS AUV data set (CPU plumbing case)."""
+    res = solve_score(fixtures["goats"], lib_path=twin_lib)  # default relaxation = QCQP
+    gold = load_golden("goats")
+    assert res.solved
+    assert res.info["pobj"] == pytest.approx(float(gold["objective"]), rel=1e-6)
+    compare_with_golden(res, gold)
+
+
+def test_qcqp_direct_equals_via_socp(fixtures, twin_lib):
+    fg = fixtures["manhattan"]
+    a = solve_score(fg, "QCQP", lib_path=twin_lib)
+    b = solve_score(fg, "QCQP", qcqp_mode="direct", lib_path=twin_lib)
+    assert a.solved and b.solved
+    assert a.info["pobj"] == pytest.approx(b.info["pobj"], rel=1e-6)
+    for nm in a.poses:
+        np.testing.assert_allclose(a.poses[nm], b.poses[nm], atol=2e-4)
+    # r_ij agree wherever the measured distance is not (numerically) zero
+    for m in fg.range_measurements:
+        if m.dist > 1e-6:
+            k = (m.first_key, m.second_key)
+            np.testing.assert_allclose(a.distances[k], b.distances[k], atol=5e-4)
+
+
+def test_batch_equals_individual(twin_lib):
+    graphs = [make_manhattan(n_robots=2, n_poses=40 + 10 * i, n_beacons=2, seed=100 + i) for i in range(3)]
+    batch = solve_score_batch(graphs, "SOCP", lib_path=twin_lib)
+    for g, rb in zip(graphs, batch):
+        ri = solve_score(g, "SOCP", lib_path=twin_lib)
+        assert rb.solved and ri.solved
+        assert rb.info["iters"] == ri.info["iters"]
+        for nm in ri.poses:
+            np.testing.assert_allclose(rb.poses[nm], ri.poses[nm], atol=1e-9)
+
+
+def test_intermediate_iterates(twin_lib):
+    fg = make_manhattan(n_robots=2, n_poses=40, n_beacons=2, seed=4)
+    its = solve_problem_with_intermediate_iterates(fg, "SOCP", every=25, lib_path=twin_lib)
+    assert len(its) >= 2 and its[-1].solved
+    iters = [r.info["iters"] for r in its]
+    assert iters == sorted(iters) and iters[0] == 25
+    final = solve_score(fg, "SOCP", lib_path=twin_lib)
+    for nm in final.poses:
+        np.testing.assert_allclose(its[-1].poses[nm], final.poses[nm], atol=1e-4)
+
+
+def test_api_errors(twin_lib):
+    fg = make_manhattan(n_robots=1, n_poses=6, n_beacons=1, seed=0, p_range=1.0)
+    with pytest.raises(ValueError, match="not supported"):
+        solve_score(fg, "LP", lib_path=twin_lib)
+    fg.landmark_variables.append(compat.LandmarkVariable2D("L9"))
+    with pytest.raises(AssertionError, match="unconnected"):
+        solve_score(fg, lib_path=twin_lib)
+    fg.landmark_variables.pop()
+    # stale example call shape: solve_score(data, solver_params, relaxation)
+    res = solve_score(fg, object(), "SOCP", lib_path=twin_lib)
+    assert res.solved
+    # non-convergence is reported through solved=False, not an exception
+    res = solve_score(fg, "SOCP", solver_settings=dict(max_iters=25, eps_abs=1e-14, eps_rel=1e-14), lib_path=twin_lib)
+    assert res.solved is False and res.info["status"] == 2
+
+
+def test_no_ranges_and_single_pose_chain(twin_lib):
+    """Edge cases: m = 0 (no cones at all) and a robot with a single pose."""
+    fg = make_manhattan(n_robots=1, n_poses=30, n_beacons=0, seed=2)
+    assert assemble(fg, "SOCP").qp.m == 0
+    res = solve_score(fg, "SOCP", lib_path=twin_lib)
+    assert res.solved and res.info["pobj"] == pytest.approx(0.0, abs=1e-6)
+    # odometry alone: the estimate composes the measurements
+    T = np.eye(3)
+    for m in fg.odom_measurements[0]:
+        step = np.eye(3); step[:2, :2] = m.rotation_matrix; step[:2, 2] = m.translation_vector
+        T = T @ step
+    np.testing.assert_allclose(res.poses["A29"][:2, 2], T[:2, 2], atol=1e-5)
+    fg2 = make_manhattan(n_robots=2, n_poses=20, n_beacons=2, seed=3, p_range=0.5)
+    fg2.pose_variables[1] = fg2.pose_variables[1][:1]  # robot B keeps one pose
+    fg2.odom_measurements[1] = []
+    names = {p.name for c in fg2.pose_variables for p in c} | {l.name for l in fg2.landmark_variables}
+    fg2.range_measurements = [m for m in fg2.range_measurements if m.first_key in names and m.second_key in names]
+    assert "B0" in {m.first_key for m in fg2.range_measurements} | {m.second_key for m in fg2.range_measurements}
+    assert solve_score(fg2, "SOCP", lib_path=twin_lib).solved
+
+
+def test_abi_rejects_bad_problems(twin_lib):
+    fg = make_manhattan(n_robots=1, n_poses=8, n_beacons=1, seed=0, p_range=1.0)
+    qp = assemble(fg, "SOCP").qp
+    bad = assemble(fg, "SOCP").qp
+    bad.soc_dims = bad.soc_dims.copy(); bad.soc_dims[0] = 2  # z + sum(dims) != m
+    with pytest.raises(RuntimeError, match="soc_dims"):
+        ConicSolver(bad, lib_path=twin_lib)
+    bad = assemble(fg, "SOCP").qp
+    bad.A = sp.csr_matrix((bad.A.data, bad.A.indices + 10**6, bad.A.indptr), shape=(bad.m, bad.n + 10**6 + 1))[:, : bad.n + 10**6 + 1]
+    bad.A._shape = (qp.m, qp.n)
+    with pytest.raises(RuntimeError, match="out of range"):
+        ConicSolver(bad, lib_path=twin_lib)
+    with pytest.raises(ValueError, match="unknown solver setting"):
+        ConicSolver(qp, dict(no_such=1), lib_path=twin_lib)
+
+
+@pytest.mark.parametrize("radix", [2, 3, 4, 8])
+def test_chain_preconditioner_is_the_exact_chain_inverse(radix, twin_lib):
+    """With a problem that consists ONLY of chains (odometry, no ranges) the
+    multi-level factorisation is an exact solver for K, so one PCG step gives the
+    exact KKT solution: a single ADMM iteration must reproduce the direct solve."""
+    fg = make_manhattan(n_robots=3, n_poses=37, n_beacons=0, seed=21, p_range=0.0)
+    qp = assemble(fg, "SOCP").qp
+    assert qp.m == 0
+    st = dict(scale_iters=0, cg_iters=1, adaptive_cg=0, adaptive_rho=0, sigma=1e-3, alpha=1.0, chain_radix=radix)
+    sol = ConicSolver(qp, st, lib_path=twin_lib)
+    sol.reset()
+    out = sol.steps(1)[0]
+    x_direct = spla.spsolve((qp.P + 1e-3 * sp.identity(qp.n)).tocsc(), -qp.q)
+    np.testing.assert_allclose(out.x, x_direct, rtol=1e-8, atol=1e-8 * np.abs(x_direct).max())
+
+
+def test_equilibration_and_kkt_values(fixtures, twin_lib):
+    """Host logic: D, E > 0 with one scale per cone, and K = D(P)D + sigma I + rho (EAD)'(EAD)."""
+    mdl = assemble(fixtures["manhattan"], "SOCP")
+    qp = mdl.qp
+    sol = ConicSolver(qp, dict(rho=0.37, sigma=1e-6), lib_path=twin_lib)
+    D, E, Kval = sol.debug_get("D"), sol.debug_get("E"), sol.debug_get("Kval")
+    assert D.min() > 0 and E.min() > 0
+    Ec = E.reshape(-1, 3)
+    assert np.all(Ec == Ec[:, :1])
+    Ps = sp.diags(D) @ qp.P @ sp.diags(D)
+    As = sp.diags(E) @ qp.A @ sp.diags(D)
+    K = (Ps + 1e-6 * sp.identity(qp.n) + 0.37 * (As.T @ As)).tocsr()
+    K.sort_indices()
+    assert abs(K).max(axis=0).toarray().max() < 1e3  # equilibrated (unscaled: 5e5)
+    assert Kval.size >= K.nnz
+    assert np.isclose(Kval.sum(), K.data.sum(), rtol=1e-10)
