@@ -64,7 +64,7 @@ def test_qcqp_direct_equals_via_socp(fixtures, twin_lib):
 
 
 def test_batch_equals_individual(twin_lib):
-    graphs = [make_manhattan(n_robots=2, n_poses=40 + 10 * i, n_beacons=3, seed=100 + i, p_range=0.5) for i in range(3)]
+    graphs = [make_manhattan(n_robots=3, n_poses=40 + 10 * (s % 4), n_beacons=4, seed=s, p_range=0.4) for s in (300, 303, 305)]
     batch = solve_score_batch(graphs, "SOCP", lib_path=twin_lib)
     for g, rb in zip(graphs, batch):
         ri = solve_score(g, "SOCP", lib_path=twin_lib)

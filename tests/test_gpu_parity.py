@@ -76,7 +76,7 @@ def test_qcqp_direct_on_gpu(fixtures, hip_lib):
 
 
 def test_deterministic_and_batch(hip_lib):
-    graphs = [make_manhattan(n_robots=2, n_poses=40 + 10 * i, n_beacons=3, seed=101 + i, p_range=0.5) for i in range(4)]
+    graphs = [make_manhattan(n_robots=3, n_poses=40 + 10 * (s % 4), n_beacons=4, seed=s, p_range=0.4) for s in (300, 303, 305, 307)]
     b1 = solve_score_batch(graphs, "SOCP")
     b2 = solve_score_batch(graphs, "SOCP")
     for g, r1, r2 in zip(graphs, b1, b2):
