@@ -89,7 +89,7 @@ typedef struct score_settings {
     int32_t adaptive_rho;      /* 0/1                                        */
     int32_t adaptive_rho_interval; /* in ADMM iterations (multiple of check_interval) */
     double  adaptive_rho_tol;  /* refactor when rho changes by this factor   */
-    int32_t chain_radix;       /* partition radix of the chain solver (2..8) */
+    int32_t chain_radix;       /* partition radix of the chain solver (2..4) */
     int32_t device;            /* HIP device ordinal                         */
     int32_t use_graph;         /* replay iterations from a hipGraph          */
     int32_t verbose;

@@ -8,31 +8,13 @@
 //   repeat cg_iters times:
 //     k_spmv<KP>   w  = K p ; partial p'w                      CSR-stream SpMV
 //     k_prec<STEP> a = r'z / p'w ; xt += a p ; r -= a w ; z = M^-1 r ; partial r'z
-//     k_pupdate    p  = z + (r'z_new / r'z_old) p
+//     k_spmv<KPB>  p  = z + (r'z_new / r'z_old) p fused into the next w = K p
 //   (the last CG iteration replaces STEP/pupdate by k_xupdate:
 //                  xt += a p ; x = alpha xt + (1 - alpha) x)
 //   k_cone         v = alpha (b - A xt) + (1 - alpha) s ; s = Proj_K(v - y/rho) ;
 //                  y += rho (s - v) ; u = rho (b - s) - y      one cone per lane
 //
-// Kernel design notes (gfx950):
-//  * The SpMV is HBM/L2-bandwidth work (12 B per nonzero, 2 flop): each
-//    256-thread workgroup owns a tile of <= 256 rows / <= 3072 nonzeros, reads
-//    values and column indices with fully coalesced 8/4-byte loads (12
-//    independent loads per lane in flight before the first use), gathers the
-//    vector, stages the products in LDS and lets one lane per row add its
-//    segment in CSR order -- so the result is bitwise independent of the
-//    launch geometry.  Rows longer than 48 nonzeros (landmarks) get a
-//    workgroup of their own and a shuffle/LDS tree reduction.
-//  * Dot products are never atomics: every workgroup writes one partial, and
-//    each consumer workgroup re-reduces the partials of its problem in a fixed
-//    order (a few KiB from L2) -- deterministic and one launch shorter than a
-//    separate finalise kernel.
-//  * The preconditioner is a direct solve of the per-robot block-tridiagonal
-//    part of K, factored on the host as a radix-p nested dissection: one
-//    workgroup per chain, one lane per run of p-1 nodes (bs x bs blocks in
-//    registers), coarse levels in LDS, O(p log_p N) dependent steps instead of
-//    2N.
-//  * No MFMA anywhere: nothing here is a dense contraction.
+// Kernels and their design notes: score_kernels.hpp.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -41,6 +23,7 @@
 #include <vector>
 
 #include "score_driver.hpp"
+#include "score_kernels.hpp"
 
 namespace {
 
@@ -54,597 +37,6 @@ thread_local std::string g_err;
         if (_e != hipSuccess)                                                                    \
             throw std::runtime_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));  \
     } while (0)
-
-constexpr int kThreads = 256;
-constexpr int kUnroll = kTileNnz / kThreads;  // 12 nonzeros per lane
-
-// ---------------------------------------------------------------------------
-// device helpers
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
-    return v;
-}
-// Sum over the 256-thread block, result in every thread.  `red` >= 4 doubles.
-__device__ __forceinline__ double block_sum(double v, double* red) {
-    v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return (red[0] + red[1]) + (red[2] + red[3]);
-}
-__device__ __forceinline__ double block_max(double v, double* red) {
-    v = wave_max(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
-}
-// NaN-propagating max for residual norms
-__device__ __forceinline__ double nanmax(double a, double b) { return (a != a || b != b) ? (a + b) : fmax(a, b); }
-
-// Fixed-order re-reduction of per-workgroup partials [lo, hi).
-__device__ __forceinline__ double reduce_partials(const double* __restrict__ part, int lo, int hi, double* red) {
-    double acc = 0.0;
-    for (int i = lo + (int)threadIdx.x; i < hi; i += kThreads) acc += part[i];
-    return block_sum(acc, red);
-}
-
-struct CsrDev {
-    const int32_t* ptr;
-    const int32_t* col;
-    const double* val;
-    const int32_t* first_row;  // row blocks
-    const int32_t* blk_prob;
-    const int32_t* split;      // G2 only
-    int nblocks;
-};
-
-struct SpmvArgs {
-    CsrDev M;
-    const double* xin;      // gathered vector
-    const int32_t* done;
-    // RHS
-    const double* x;        // current x (same buffer as xy)
-    const double* q;
-    double* r;
-    double sigma;
-    // KP
-    const double* p;
-    double* w;
-    double* pw_part;
-    // DRES
-    const double* invD;
-    double* dres_part;      // 8 per block
-};
-
-enum { MODE_RHS = 0, MODE_KP = 1, MODE_DRES = 2 };
-
-// ---------------------------------------------------------------------------
-// CSR-stream SpMV with fused epilogues
-// ---------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
-    __shared__ double prod[kTileNnz];
-    __shared__ double red[8];
-    const int b = blockIdx.x;
-    const int prob = a.M.blk_prob[b];
-    if (a.done[prob]) return;
-    const int t = threadIdx.x;
-    const int r0 = a.M.first_row[b], r1 = a.M.first_row[b + 1];
-    const int k0 = a.M.ptr[r0], k1 = a.M.ptr[r1];
-    const int nn = k1 - k0;
-    const double* __restrict__ val = a.M.val;
-    const int32_t* __restrict__ col = a.M.col;
-    const double* __restrict__ xin = a.xin;
-
-    int row = r0 + t;
-    bool has_row = false;
-    double sum = 0.0, sum2 = 0.0;  // sum2: A' part (MODE_DRES)
-
-    if (r1 - r0 == 1 && nn > kLongRow) {
-        // one long row: strided partial sums + tree reduction
-        double acc = 0.0, acc2 = 0.0;
-        const int split = (MODE == MODE_DRES) ? a.M.split[r0] : k1;
-        for (int k = k0 + t; k < k1; k += kThreads) {
-            const double v = val[k] * xin[col[k]];
-            if (MODE == MODE_DRES && k >= split) acc2 += v; else acc += v;
-        }
-        sum = block_sum(acc, red);
-        if (MODE == MODE_DRES) sum2 = block_sum(acc2, red);
-        has_row = (t == 0);
-        row = r0;
-    } else {
-        int32_t c[kUnroll];
-        double v[kUnroll];
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int k = t + u * kThreads;
-            if (k < nn) {
-                c[u] = col[k0 + k];
-                v[u] = val[k0 + k];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const int k = t + u * kThreads;
-            if (k < nn) prod[k] = v[u] * xin[c[u]];
-        }
-        __syncthreads();
-        if (row < r1) {
-            has_row = true;
-            const int a0 = a.M.ptr[row] - k0, a1 = a.M.ptr[row + 1] - k0;
-            if (MODE == MODE_DRES) {
-                const int sp = a.M.split[row] - k0;
-                for (int k = a0; k < sp; ++k) sum += prod[k];
-                for (int k = sp; k < a1; ++k) sum2 += prod[k];
-            } else {
-                for (int k = a0; k < a1; ++k) sum += prod[k];
-            }
-        }
-    }
-
-    if (MODE == MODE_RHS) {
-        if (has_row) a.r[row] = a.sigma * a.x[row] - a.q[row] + sum;
-    } else if (MODE == MODE_KP) {
-        double local = 0.0;
-        if (has_row) {
-            a.w[row] = sum;
-            local = a.p[row] * sum;
-        }
-        const double tot = block_sum(local, red);
-        if (t == 0) a.pw_part[b] = tot;
-    } else {  // MODE_DRES: sum = (P x)_i, sum2 = (A'y)_i ; xin = [x ; y]
-        double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, s0 = 0, s1 = 0;
-        if (has_row) {
-            const double qi = a.q[row];
-            const double dr = sum + qi + sum2;
-            const double id = a.invD[row];
-            m0 = fabs(dr) * id; m1 = fabs(sum) * id; m2 = fabs(sum2) * id;
-            m3 = fabs(dr); m4 = fabs(sum); m5 = fabs(sum2);
-            if (dr != dr) { m0 = dr; m3 = dr; }
-            const double xi = xin[row];
-            s0 = xi * sum;
-            s1 = qi * xi;
-        }
-        // NaN-safe: a NaN anywhere makes the sums NaN, which the host checks
-        const double nanflag = block_sum((m0 != m0) ? 1.0 : 0.0, red);
-        m0 = block_max(m0 != m0 ? 0.0 : m0, red); m1 = block_max(m1, red); m2 = block_max(m2, red);
-        m3 = block_max(m3 != m3 ? 0.0 : m3, red); m4 = block_max(m4, red); m5 = block_max(m5, red);
-        s0 = block_sum(s0, red); s1 = block_sum(s1, red);
-        if (t == 0) {
-            double* o = a.dres_part + (size_t)b * 8;
-            const double bad = nanflag > 0.0 ? __builtin_nan("") : 0.0;
-            o[0] = m0 + bad; o[1] = m1; o[2] = m2; o[3] = m3 + bad; o[4] = m4; o[5] = m5; o[6] = s0; o[7] = s1;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------
-// preconditioner: multi-level block-tridiagonal chain solve + Jacobi
-// ---------------------------------------------------------------------------
-struct PrecArgs {
-    const PrecWork* work;
-    const ChainDesc* chains;
-    const ChainLevelDesc* levels;
-    const double* fac;
-    const int32_t* node_col;
-    const int32_t* diag_cols;
-    const double* dinv;
-    const int32_t* done;
-    const int32_t* prec_part_ptr;  // per problem: range of prec work items
-    const int32_t* kblk_part_ptr;  // per problem: range of K row blocks
-    double* r;
-    double* z;
-    double* p;
-    const double* w;
-    double* xt;
-    const double* rz_in;   // partials of the previous r'z   (STEP)
-    const double* pw_part; // partials of p'w                (STEP)
-    double* rz_out;        // one partial per work item
-};
-
-enum { PREC_INIT = 0, PREC_STEP = 1 };
-
-template <int BS>
-__device__ __forceinline__ void matvec_sub(const double* __restrict__ M, const double (&v)[BS], double (&out)[BS]) {
-    // out -= M v   (M row-major BS x BS)
-#pragma unroll
-    for (int c = 0; c < BS; ++c) {
-        double s = out[c];
-#pragma unroll
-        for (int k = 0; k < BS; ++k) s -= M[c * BS + k] * v[k];
-        out[c] = s;
-    }
-}
-template <int BS>
-__device__ __forceinline__ void matvec_t_sub(const double* __restrict__ M, const double (&v)[BS], double (&out)[BS]) {
-    // out -= M' v
-#pragma unroll
-    for (int c = 0; c < BS; ++c) {
-        double s = out[c];
-#pragma unroll
-        for (int k = 0; k < BS; ++k) s -= M[k * BS + c] * v[k];
-        out[c] = s;
-    }
-}
-
-template <int BS, int RMAX, int MODE>
-__global__ __launch_bounds__(kThreads) void k_prec(PrecArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];  // [0,8): reductions, then chain scratch
-    double* red = lds;
-    double* scr = lds + 8;
-    const PrecWork wk = a.work[blockIdx.x];
-    const int prob = wk.prob;
-    if (a.done[prob]) return;
-    const int t = threadIdx.x;
-    double alpha = 0.0;
-    if (MODE == PREC_STEP) {
-        const double rz = reduce_partials(a.rz_in, a.prec_part_ptr[prob], a.prec_part_ptr[prob + 1], red);
-        const double pw = reduce_partials(a.pw_part, a.kblk_part_ptr[prob], a.kblk_part_ptr[prob + 1], red);
-        alpha = pw > 0.0 ? rz / pw : 0.0;
-    }
-    double local = 0.0;
-    if (wk.kind == 1) {
-        for (int e = wk.index + t; e < wk.index + wk.count; e += kThreads) {
-            const int col = a.diag_cols[e];
-            double rv = a.r[col];
-            if (MODE == PREC_STEP) {
-                a.xt[col] += alpha * a.p[col];
-                rv -= alpha * a.w[col];
-                a.r[col] = rv;
-            }
-            const double zv = rv * a.dinv[e];
-            a.z[col] = zv;
-            if (MODE == PREC_INIT) a.p[col] = zv;
-            local += rv * zv;
-        }
-    } else {
-        constexpr int B2 = BS * BS;
-        const ChainDesc ch = a.chains[wk.index];
-        const ChainLevelDesc* __restrict__ lv = a.levels + ch.level_begin;
-        const int32_t* __restrict__ nc = a.node_col + ch.node_begin;
-        const double* __restrict__ fac = a.fac;
-        if (MODE == PREC_STEP) {
-            for (int idx = t; idx < ch.N * BS; idx += kThreads) {
-                const int col = nc[idx / BS] + idx % BS;
-                a.xt[col] += alpha * a.p[col];
-                a.r[col] -= alpha * a.w[col];
-            }
-            __syncthreads();
-        }
-        for (int l = 0; l < ch.n_levels; ++l) {
-            const ChainLevelDesc L = lv[l];
-            const bool last = (L.p == 0);
-            const int nsep = last ? 0 : L.N / L.p;
-            const double* __restrict__ rec = fac + (size_t)L.data_off * 4 * B2;
-            for (int j = t; j <= nsep; j += kThreads) {
-                const int lo = last ? 0 : j * L.p;
-                const int hi = last ? L.N : min(j * L.p + L.p - 1, L.N);
-                if (lo >= hi) continue;
-                double y[RMAX][BS];
-                // forward substitution
-#pragma unroll
-                for (int q = 0; q < RMAX; ++q) {
-                    const int i = lo + q;
-                    if (i < hi) {
-                        if (l == 0) {
-                            const int col = nc[i];
-#pragma unroll
-                            for (int c = 0; c < BS; ++c) y[q][c] = a.r[col + c];
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < BS; ++c) y[q][c] = scr[(size_t)(L.vec_off + i) * BS + c];
-                        }
-                        if (q > 0) matvec_sub<BS>(rec + ((size_t)i * 4 + 0) * B2, y[q - 1], y[q]);
-                    }
-                }
-                // diagonal solve + backward substitution
-#pragma unroll
-                for (int q = RMAX - 1; q >= 0; --q) {
-                    const int i = lo + q;
-                    if (i < hi) {
-                        double tmp[BS];
-#pragma unroll
-                        for (int c = 0; c < BS; ++c) tmp[c] = 0.0;
-                        const double* __restrict__ Di = rec + ((size_t)i * 4 + 1) * B2;
-#pragma unroll
-                        for (int c = 0; c < BS; ++c) {
-                            double s = 0.0;
-#pragma unroll
-                            for (int k = 0; k < BS; ++k) s += Di[c * BS + k] * y[q][k];
-                            tmp[c] = s;
-                        }
-                        if (q + 1 < RMAX) {
-                            if (i + 1 < hi) matvec_t_sub<BS>(rec + ((size_t)(i + 1) * 4 + 0) * B2, y[q + 1], tmp);
-                        }
-#pragma unroll
-                        for (int c = 0; c < BS; ++c) y[q][c] = tmp[c];
-                        if (l == 0) {
-                            const int col = nc[i];
-#pragma unroll
-                            for (int c = 0; c < BS; ++c) a.z[col + c] = tmp[c];
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < BS; ++c) scr[(size_t)(L.vec_off + i) * BS + c] = tmp[c];
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            if (last) break;
-            const ChainLevelDesc Ln = lv[l + 1];
-            for (int j = t; j < nsep; j += kThreads) {
-                const int s = j * L.p + L.p - 1;
-                double v[BS], ym[BS], yp[BS];
-                if (l == 0) {
-                    const int cs = nc[s], cm = nc[s - 1];
-#pragma unroll
-                    for (int c = 0; c < BS; ++c) { v[c] = a.r[cs + c]; ym[c] = a.z[cm + c]; }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < BS; ++c) {
-                        v[c] = scr[(size_t)(L.vec_off + s) * BS + c];
-                        ym[c] = scr[(size_t)(L.vec_off + s - 1) * BS + c];
-                    }
-                }
-                matvec_sub<BS>(rec + ((size_t)s * 4 + 0) * B2, ym, v);
-                if (s + 1 < L.N) {
-                    if (l == 0) {
-                        const int cp = nc[s + 1];
-#pragma unroll
-                        for (int c = 0; c < BS; ++c) yp[c] = a.z[cp + c];
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < BS; ++c) yp[c] = scr[(size_t)(L.vec_off + s + 1) * BS + c];
-                    }
-                    matvec_sub<BS>(rec + ((size_t)s * 4 + 1) * B2, yp, v);
-                }
-                // the separator's own slot on this level is not read again until
-                // back-substitution, so the reduced right-hand side goes to level l+1
-#pragma unroll
-                for (int c = 0; c < BS; ++c) scr[(size_t)(Ln.vec_off + j) * BS + c] = v[c];
-            }
-            __syncthreads();
-        }
-        // back-substitution, coarse to fine
-        for (int l = ch.n_levels - 2; l >= 0; --l) {
-            const ChainLevelDesc L = lv[l];
-            const ChainLevelDesc Ln = lv[l + 1];
-            const int nsep = L.N / L.p;
-            const double* __restrict__ rec = fac + (size_t)L.data_off * 4 * B2;
-            for (int i = t; i < L.N; i += kThreads) {
-                const int j = i / L.p;
-                double v[BS];
-                const bool is_sep = (i % L.p == L.p - 1) && (j < nsep);
-                if (is_sep) {
-#pragma unroll
-                    for (int c = 0; c < BS; ++c) v[c] = scr[(size_t)(Ln.vec_off + j) * BS + c];
-                } else {
-                    if (l == 0) {
-                        const int col = nc[i];
-#pragma unroll
-                        for (int c = 0; c < BS; ++c) v[c] = a.z[col + c];
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < BS; ++c) v[c] = scr[(size_t)(L.vec_off + i) * BS + c];
-                    }
-                    if (j >= 1) {
-                        double ul[BS];
-#pragma unroll
-                        for (int c = 0; c < BS; ++c) ul[c] = scr[(size_t)(Ln.vec_off + j - 1) * BS + c];
-                        matvec_sub<BS>(rec + ((size_t)i * 4 + 2) * B2, ul, v);
-                    }
-                    if (j < nsep) {
-                        double ur[BS];
-#pragma unroll
-                        for (int c = 0; c < BS; ++c) ur[c] = scr[(size_t)(Ln.vec_off + j) * BS + c];
-                        matvec_sub<BS>(rec + ((size_t)i * 4 + 3) * B2, ur, v);
-                    }
-                }
-                if (l == 0) {
-                    const int col = nc[i];
-#pragma unroll
-                    for (int c = 0; c < BS; ++c) {
-                        a.z[col + c] = v[c];
-                        if (MODE == PREC_INIT) a.p[col + c] = v[c];
-                        local += a.r[col + c] * v[c];
-                    }
-                } else {
-#pragma unroll
-                    for (int c = 0; c < BS; ++c) scr[(size_t)(L.vec_off + i) * BS + c] = v[c];
-                }
-            }
-            __syncthreads();
-        }
-        if (ch.n_levels == 1) {
-            // single-level chain: finish p and the dot product here
-            for (int i = t; i < ch.N; i += kThreads) {
-                const int col = nc[i];
-#pragma unroll
-                for (int c = 0; c < BS; ++c) {
-                    const double zv = a.z[col + c];
-                    if (MODE == PREC_INIT) a.p[col + c] = zv;
-                    local += a.r[col + c] * zv;
-                }
-            }
-        }
-    }
-    const double tot = block_sum(local, red);
-    if (t == 0) a.rz_out[blockIdx.x] = tot;
-}
-
-// ---------------------------------------------------------------------------
-// vector updates (grid = K row blocks, so the problem of a block is known)
-// ---------------------------------------------------------------------------
-struct VecArgs {
-    const int32_t* first_row;
-    const int32_t* blk_prob;
-    const int32_t* done;
-    const int32_t* prec_part_ptr;
-    const int32_t* kblk_part_ptr;
-    const double* rz_new;
-    const double* rz_old;
-    const double* pw_part;
-    const double* z;
-    double* p;
-    double* xt;
-    double* x;
-    double alpha_relax;
-    int apply_alpha;  // 0: xt already holds the final CG iterate
-};
-
-__global__ __launch_bounds__(kThreads) void k_pupdate(VecArgs a) {
-    __shared__ double red[8];
-    const int b = blockIdx.x;
-    const int prob = a.blk_prob[b];
-    if (a.done[prob]) return;
-    const double rzn = reduce_partials(a.rz_new, a.prec_part_ptr[prob], a.prec_part_ptr[prob + 1], red);
-    const double rzo = reduce_partials(a.rz_old, a.prec_part_ptr[prob], a.prec_part_ptr[prob + 1], red);
-    const double beta = rzo > 0.0 ? rzn / rzo : 0.0;
-    const int row = a.first_row[b] + threadIdx.x;
-    if (row < a.first_row[b + 1]) a.p[row] = a.z[row] + beta * a.p[row];
-}
-
-__global__ __launch_bounds__(kThreads) void k_xupdate(VecArgs a) {
-    __shared__ double red[8];
-    const int b = blockIdx.x;
-    const int prob = a.blk_prob[b];
-    if (a.done[prob]) return;
-    double alpha = 0.0;
-    if (a.apply_alpha) {
-        const double rz = reduce_partials(a.rz_old, a.prec_part_ptr[prob], a.prec_part_ptr[prob + 1], red);
-        const double pw = reduce_partials(a.pw_part, a.kblk_part_ptr[prob], a.kblk_part_ptr[prob + 1], red);
-        alpha = pw > 0.0 ? rz / pw : 0.0;
-    }
-    const int row = a.first_row[b] + threadIdx.x;
-    if (row < a.first_row[b + 1]) {
-        const double xt = a.xt[row] + alpha * a.p[row];
-        a.xt[row] = xt;
-        a.x[row] = a.alpha_relax * xt + (1.0 - a.alpha_relax) * a.x[row];
-    }
-}
-
-// ---------------------------------------------------------------------------
-// cones: one cone per lane
-// ---------------------------------------------------------------------------
-struct ConeArgs {
-    const int32_t* A_ptr;
-    const int32_t* A_col;
-    const double* A_val;
-    const int32_t* cone_row;
-    const int32_t* cone_dim;
-    const int32_t* cone_type;
-    const int32_t* block_first;
-    const int32_t* block_prob;
-    const int32_t* done;
-    const double* rho;
-    const double* b;
-    const double* xt;   // gathered (xt for the iteration, x for residuals)
-    double* s;
-    double* y;
-    double* u;
-    double alpha_relax;
-    const double* invE;
-    double* pres_part;  // 7 per block
-};
-
-__device__ __forceinline__ double a_row_dot(const ConeArgs& a, int i, const double* __restrict__ v) {
-    double acc = 0.0;
-    for (int k = a.A_ptr[i]; k < a.A_ptr[i + 1]; ++k) acc += a.A_val[k] * v[a.A_col[k]];
-    return acc;
-}
-
-__global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
-    const int b = blockIdx.x;
-    const int prob = a.block_prob[b];
-    if (a.done[prob]) return;
-    const int c = a.block_first[b] + threadIdx.x;
-    if (c >= a.block_first[b + 1]) return;
-    const int row = a.cone_row[c], dim = a.cone_dim[c];
-    const double rho = a.rho[prob], irho = 1.0 / rho, al = a.alpha_relax;
-    double t0 = 0.0, nz2 = 0.0;
-    for (int k = 0; k < dim; ++k) {
-        const int i = row + k;
-        const double tt = a_row_dot(a, i, a.xt);
-        const double v = al * (a.b[i] - tt) + (1.0 - al) * a.s[i];
-        const double wv = v - a.y[i] * irho;
-        a.u[i] = v;   // stash v
-        a.s[i] = wv;  // stash the point to project
-        if (k == 0) t0 = wv; else nz2 += wv * wv;
-    }
-    double head, tail;  // s+ = (head, tail * w_tail)
-    if (a.cone_type[c] == 0) {
-        head = 0.0; tail = 0.0;
-    } else {
-        const double nz = sqrt(nz2);
-        if (nz <= t0) { head = t0; tail = 1.0; }
-        else if (nz <= -t0) { head = 0.0; tail = 0.0; }
-        else { const double m = 0.5 * (t0 + nz); head = m; tail = m / nz; }
-    }
-    for (int k = 0; k < dim; ++k) {
-        const int i = row + k;
-        const double sn = (k == 0) ? head : tail * a.s[i];
-        const double v = a.u[i];
-        const double yn = a.y[i] + rho * (sn - v);
-        a.s[i] = sn;
-        a.y[i] = yn;
-        a.u[i] = rho * (a.b[i] - sn) - yn;
-    }
-}
-
-// u = rho (b - s) - y   (after a penalty update)
-__global__ __launch_bounds__(kThreads) void k_refresh_u(ConeArgs a) {
-    const int b = blockIdx.x;
-    const int prob = a.block_prob[b];
-    const int c = a.block_first[b] + threadIdx.x;
-    if (c >= a.block_first[b + 1]) return;
-    const int row = a.cone_row[c], dim = a.cone_dim[c];
-    const double rho = a.rho[prob];
-    for (int k = 0; k < dim; ++k) {
-        const int i = row + k;
-        a.u[i] = rho * (a.b[i] - a.s[i]) - a.y[i];
-    }
-}
-
-// primal residual norms; a.xt points at x here
-__global__ __launch_bounds__(kThreads) void k_pres(ConeArgs a) {
-    __shared__ double red[8];
-    const int b = blockIdx.x;
-    const int prob = a.block_prob[b];
-    if (a.done[prob]) return;
-    const int c = a.block_first[b] + threadIdx.x;
-    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, sby = 0, bad = 0;
-    if (c < a.block_first[b + 1]) {
-        const int row = a.cone_row[c], dim = a.cone_dim[c];
-        for (int k = 0; k < dim; ++k) {
-            const int i = row + k;
-            const double tt = a_row_dot(a, i, a.xt);
-            const double si = a.s[i];
-            const double pr = tt + si - a.b[i];
-            const double ie = a.invE[i];
-            if (pr != pr) bad = 1.0;
-            m0 = fmax(m0, fabs(pr) * ie); m1 = fmax(m1, fabs(tt) * ie); m2 = fmax(m2, fabs(si) * ie);
-            m3 = fmax(m3, fabs(pr)); m4 = fmax(m4, fabs(tt)); m5 = fmax(m5, fabs(si));
-            sby += a.b[i] * a.y[i];
-        }
-    }
-    bad = block_sum(bad, red);
-    m0 = block_max(m0, red); m1 = block_max(m1, red); m2 = block_max(m2, red);
-    m3 = block_max(m3, red); m4 = block_max(m4, red); m5 = block_max(m5, red);
-    sby = block_sum(sby, red);
-    if (threadIdx.x == 0) {
-        double* o = a.pres_part + (size_t)b * 8;
-        const double nanv = bad > 0.0 ? __builtin_nan("") : 0.0;
-        o[0] = m0 + nanv; o[1] = m1; o[2] = m2; o[3] = m3 + nanv; o[4] = m4; o[5] = m5; o[6] = sby; o[7] = 0.0;
-    }
-}
 
 // ---------------------------------------------------------------------------
 // backend
@@ -706,13 +98,15 @@ struct HipBackend {
     DevBuf<PrecWork> prec_work;
     DevBuf<ChainDesc> chains;
     DevBuf<ChainLevelDesc> levels;
-    DevBuf<double> xtu, xy, s, r, z, p, w;
+    DevBuf<double> xtu, xy, s, r, z, p, p2, w;
     DevBuf<double> pw_part, rz_part0, rz_part1, rz_meas0, rz_meas1, pres_part, dres_part;
     int cg_iters = 2;
     double* h_pres = nullptr;  // pinned
     double* h_dres = nullptr;
     int n_cone_blocks = 0, n_prec = 0;
     size_t prec_lds = 0;
+    bool prec_lds0 = true;
+    static bool n_prec_chains(const HostSystem& h) { return !h.chains.empty(); }
 
     ~HipBackend() {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -753,10 +147,23 @@ struct HipBackend {
         prec_part_ptr.upload(h.prec_part_ptr); kblk_part_ptr.upload(h.rbK.part_ptr);
         prec_work.upload(h.prec_work); chains.upload(h.chains); levels.upload(h.levels);
         n_prec = (int)h.prec_work.size();
-        prec_lds = (8 + (size_t)h.max_chain_scratch * std::max(1, h.bs)) * sizeof(double);
-        if (prec_lds > 64 * 1024) throw std::runtime_error("chain too long for the LDS-resident chain solver");
+        // chain vectors in LDS: level 0 (N nodes) when it fits, always the coarse levels
+        int max_nodes = 0, max_all = 0;
+        for (const auto& ch : h.chains) {
+            max_nodes = std::max(max_nodes, ch.scratch_nodes);
+            max_all = std::max(max_all, ch.scratch_nodes + ch.N);
+        }
+        const size_t lds_all = (8 + (size_t)max_all * std::max(1, h.bs)) * sizeof(double);
+        const size_t lds_up = (8 + (size_t)max_nodes * std::max(1, h.bs)) * sizeof(double);
+        prec_lds0 = lds_all <= 144 * 1024;
+        prec_lds = prec_lds0 ? lds_all : lds_up;
+        if (prec_lds > 144 * 1024) throw std::runtime_error("chain too long for the LDS-resident chain solver");
+        if (prec_lds > 48 * 1024 && n_prec_chains(h)) {
+            if (h.bs <= 1) allow_big_lds<1>(); else if (h.bs == 2) allow_big_lds<2>();
+            else if (h.bs == 3) allow_big_lds<3>(); else allow_big_lds<4>();
+        }
         xtu.alloc(h.n_tot + h.m_tot); xy.alloc(h.n_tot + h.m_tot); s.alloc(h.m_tot);
-        r.alloc(h.n_tot); z.alloc(h.n_tot); p.alloc(h.n_tot); w.alloc(h.n_tot);
+        r.alloc(h.n_tot); z.alloc(h.n_tot); p.alloc(h.n_tot); p2.alloc(h.n_tot); w.alloc(h.n_tot);
         pw_part.alloc(K.nblocks); rz_part0.alloc(n_prec); rz_part1.alloc(n_prec);
         rz_meas0.alloc(n_prec); rz_meas1.alloc(n_prec);
         cg_iters = st.cg_iters;
@@ -807,7 +214,7 @@ struct HipBackend {
 
     void reset() {
         xtu.zero(stream); xy.zero(stream); s.zero(stream);
-        r.zero(stream); z.zero(stream); p.zero(stream); w.zero(stream);
+        r.zero(stream); z.zero(stream); p.zero(stream); p2.zero(stream); w.zero(stream);
         pw_part.zero(stream); rz_part0.zero(stream); rz_part1.zero(stream);
         rz_meas0.zero(stream); rz_meas1.zero(stream);
         if (n_cone_blocks) {
@@ -821,14 +228,24 @@ struct HipBackend {
     void launch_prec(const PrecArgs& pa) {
         if (n_prec == 0) return;
         const int bs = H->bs;
-        const bool wide = H->radix > 4;
-#define SCORE_LAUNCH_PREC(BS, RMAX)                                                                         \
-    hipLaunchKernelGGL((k_prec<BS, RMAX, MODE>), dim3(n_prec), dim3(kThreads), prec_lds, stream, pa)
-        if (bs <= 1) { if (wide) SCORE_LAUNCH_PREC(1, 7); else SCORE_LAUNCH_PREC(1, 3); }
-        else if (bs == 2) { if (wide) SCORE_LAUNCH_PREC(2, 7); else SCORE_LAUNCH_PREC(2, 3); }
-        else if (bs == 3) { if (wide) SCORE_LAUNCH_PREC(3, 7); else SCORE_LAUNCH_PREC(3, 3); }
-        else { if (wide) SCORE_LAUNCH_PREC(4, 7); else SCORE_LAUNCH_PREC(4, 3); }
+#define SCORE_LAUNCH_PREC(BS)                                                                                  \
+    do {                                                                                                       \
+        if (prec_lds0)                                                                                         \
+            hipLaunchKernelGGL((k_prec<BS, 3, MODE, true>), dim3(n_prec), dim3(kThreads), prec_lds, stream, pa); \
+        else                                                                                                   \
+            hipLaunchKernelGGL((k_prec<BS, 3, MODE, false>), dim3(n_prec), dim3(kThreads), prec_lds, stream, pa); \
+    } while (0)
+        if (bs <= 1) SCORE_LAUNCH_PREC(1);
+        else if (bs == 2) SCORE_LAUNCH_PREC(2);
+        else if (bs == 3) SCORE_LAUNCH_PREC(3);
+        else SCORE_LAUNCH_PREC(4);
 #undef SCORE_LAUNCH_PREC
+    }
+
+    template <int BS>
+    void allow_big_lds() {
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_INIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prec_lds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_STEP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prec_lds));
     }
 
     SpmvArgs spmv_args(const CsrBufs& M, const double* xin) {
@@ -836,12 +253,22 @@ struct HipBackend {
         a.M = M.dev(); a.xin = xin; a.done = done.d;
         a.x = xy.d; a.q = q.d; a.r = r.d; a.sigma = H->sigma;
         a.p = p.d; a.w = w.d; a.pw_part = pw_part.d;
+        a.prec_part_ptr = prec_part_ptr.d;
         a.invD = invD.d; a.dres_part = dres_part.d;
         return a;
     }
 
-    void launch_kp() {
-        hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, stream, spmv_args(K, p.d));
+    // w = K p
+    void launch_kp(const double* pdir) {
+        SpmvArgs a = spmv_args(K, pdir);
+        a.p = pdir;
+        hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
+    }
+    // p_new = z + beta p_old ; w = K p_new
+    void launch_kpb(const double* p_old, double* p_new, const double* rz_new, const double* rz_old) {
+        SpmvArgs a = spmv_args(K, p_old);
+        a.p = p_old; a.z = z.d; a.p_out = p_new; a.rz_new = rz_new; a.rz_old = rz_old;
+        hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
     }
 
     void set_cg_iters(int k) {
@@ -876,32 +303,30 @@ struct HipBackend {
         pa.r = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d;
         pa.pw_part = pw_part.d;
         double* rz_cur = measure ? rz_meas0.d : rz_part0.d;
-        pa.rz_in = nullptr; pa.rz_out = rz_cur;
+        double* p_cur = p.d;
+        double* p_oth = p2.d;
+        pa.p = p_cur; pa.rz_in = nullptr; pa.rz_out = rz_cur;
         launch_prec<PREC_INIT>(pa);
+        launch_kp(p_cur);
+        for (int j = 2; j <= cg_iters; ++j) {
+            double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
+            pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_nxt;
+            launch_prec<PREC_STEP>(pa);
+            launch_kpb(p_cur, p_oth, rz_nxt, rz_cur);
+            std::swap(p_cur, p_oth);
+            rz_cur = rz_nxt;
+        }
         VecArgs va{};
         va.first_row = K.first_row.d; va.blk_prob = K.blk_prob.d; va.done = done.d;
         va.prec_part_ptr = prec_part_ptr.d; va.kblk_part_ptr = kblk_part_ptr.d;
-        va.pw_part = pw_part.d; va.z = z.d; va.p = p.d; va.xt = xtu.d; va.x = xy.d;
-        va.alpha_relax = st.alpha; va.apply_alpha = 1;
-        for (int j = 1; j <= cg_iters; ++j) {
-            launch_kp();
-            if (j < cg_iters) {
-                double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
-                pa.rz_in = rz_cur; pa.rz_out = rz_nxt;
-                launch_prec<PREC_STEP>(pa);
-                va.rz_new = rz_nxt; va.rz_old = rz_cur;
-                hipLaunchKernelGGL(k_pupdate, dim3(K.nblocks), dim3(kThreads), 0, stream, va);
-                rz_cur = rz_nxt;
-            } else if (measure) {
-                pa.rz_in = rz_cur; pa.rz_out = rz_meas1.d;
-                launch_prec<PREC_STEP>(pa);  // also applies xt += a p, r -= a w
-                va.rz_old = rz_cur; va.rz_new = rz_cur; va.apply_alpha = 0;
-                hipLaunchKernelGGL(k_xupdate, dim3(K.nblocks), dim3(kThreads), 0, stream, va);
-            } else {
-                va.rz_old = rz_cur; va.rz_new = rz_cur;
-                hipLaunchKernelGGL(k_xupdate, dim3(K.nblocks), dim3(kThreads), 0, stream, va);
-            }
+        va.pw_part = pw_part.d; va.p = p_cur; va.xt = xtu.d; va.x = xy.d;
+        va.alpha_relax = st.alpha; va.rz_old = rz_cur; va.apply_alpha = 1;
+        if (measure) {
+            pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_meas1.d;
+            launch_prec<PREC_STEP>(pa);  // also applies xt += a p, r -= a w
+            va.apply_alpha = 0;
         }
+        hipLaunchKernelGGL(k_xupdate, dim3(K.nblocks), dim3(kThreads), 0, stream, va);
         if (n_cone_blocks)
             hipLaunchKernelGGL(k_cone, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xtu.d));
     }
@@ -1012,10 +437,10 @@ struct HipBackend {
         std::vector<int32_t> zero(h.count, 0), keep(h.count);
         HIP_CHECK(hipMemcpy(keep.data(), done.d, keep.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
         HIP_CHECK(hipMemcpy(done.d, zero.data(), zero.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        for (int i = 0; i < 10; ++i) launch_kp();
+        for (int i = 0; i < 10; ++i) launch_kp(p.d);
         HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipEventRecord(ev0, stream));
-        for (int i = 0; i < reps; ++i) launch_kp();
+        for (int i = 0; i < reps; ++i) launch_kp(p.d);
         HIP_CHECK(hipEventRecord(ev1, stream));
         HIP_CHECK(hipEventSynchronize(ev1));
         float t = 0;

@@ -48,11 +48,21 @@ struct RowBlocks {
     int nb() const { return (int)prob.size(); }
 };
 
+// One level of a chain's nested-dissection factorisation.  The factor blocks are
+// stored structure-of-arrays so that the lanes of a wavefront (= consecutive
+// runs, separators or nodes) read consecutive doubles:
+//   R (run phase)        Lf, Dinv : fac[offR + ((slot*b2 + e)*P + q)*nruns + j]
+//                                   slot 0/1, block entry e, position q in run j
+//   S (separator phase)  Cl, Cr   : fac[offS + (slot*b2 + e)*nsep + j]
+//   B (back-substitution) V, W    : fac[offB + (slot*b2 + e)*N + i]
 struct ChainLevelDesc {
-    int32_t N;         // nodes on this level
-    int32_t p;         // radix (0 = last level: one sequential run)
-    int32_t data_off;  // first node of this level in `fac` (units of nodes)
-    int32_t vec_off;   // first node of this level in the chain's scratch (level >= 1)
+    int32_t N;        // nodes on this level
+    int32_t p;        // radix (0 = last level: one sequential run)
+    int32_t nruns;    // runs on this level (last level: 1)
+    int32_t P;        // node positions per run (p - 1; last level: N)
+    int32_t nsep;     // separators (N / p; last level: 0)
+    int32_t vec_off;  // first node of this level in the chain's scratch (level >= 1)
+    int64_t offR, offS, offB;  // offsets into `fac`, in doubles
 };
 
 struct ChainDesc {
@@ -142,18 +152,20 @@ inline void factor_chain_levels(int bs, int radix, int N0, const std::vector<dou
     std::vector<double> curA = Ad, curB = Bs;
     int N = N0, vec_off = 0;
     double D[16], T1[16], T2[16];
+    std::vector<double> aos;  // node records [Lf|Cl, Dinv|Cr, V, W] of the current level
     for (int lvl = 0;; ++lvl) {
-        ChainLevelDesc L;
+        ChainLevelDesc L{};
         L.N = N;
-        L.data_off = (int32_t)(fac.size() / (size_t)(4 * b2));
         L.vec_off = (lvl == 0) ? -1 : vec_off;
         if (lvl > 0) vec_off += N;
-        const size_t base = fac.size();
-        fac.resize(base + (size_t)N * 4 * b2, 0.0);
-        auto nd = [&](int i, int slot) { return &fac[base + ((size_t)i * 4 + slot) * b2]; };
-        const bool last = (N <= radix);
+        aos.assign((size_t)N * 4 * b2, 0.0);
+        auto nd = [&](int i, int slot) { return &aos[((size_t)i * 4 + slot) * b2]; };
+        const bool last = (N <= radix - 1);  // the closing run must fit a lane's register tile (radix - 1 nodes)
         L.p = last ? 0 : radix;
         const int nsep = last ? 0 : N / radix;
+        L.nsep = nsep;
+        L.nruns = nsep + 1;
+        L.P = last ? N : radix - 1;
         std::vector<double> nA((size_t)nsep * b2, 0.0), nB((size_t)nsep * b2, 0.0);
         for (int j = 0; j <= nsep; ++j) {
             const int lo = last ? 0 : j * radix;
@@ -216,6 +228,30 @@ inline void factor_chain_levels(int bs, int radix, int N0, const std::vector<dou
                 for (int k = 0; k < b2; ++k) nB[(size_t)j * b2 + k] = -T1[k];
             }
         }
+        // pack the node records into the lane-coalesced layout
+        L.offR = (int64_t)fac.size();
+        fac.resize(fac.size() + (size_t)2 * b2 * L.P * L.nruns, 0.0);
+        L.offS = (int64_t)fac.size();
+        fac.resize(fac.size() + (size_t)2 * b2 * nsep, 0.0);
+        L.offB = (int64_t)fac.size();
+        fac.resize(fac.size() + (size_t)2 * b2 * N, 0.0);
+        for (int j = 0; j < L.nruns; ++j) {
+            const int lo = last ? 0 : j * radix;
+            const int hi = last ? N : std::min(j * radix + radix - 1, N);
+            for (int i = lo; i < hi; ++i)
+                for (int slot = 0; slot < 2; ++slot)
+                    for (int e = 0; e < b2; ++e)
+                        fac[L.offR + ((size_t)(slot * b2 + e) * L.P + (i - lo)) * L.nruns + j] = nd(i, slot)[e];
+        }
+        for (int j = 0; j < nsep; ++j) {
+            const int s = j * radix + radix - 1;
+            for (int slot = 0; slot < 2; ++slot)
+                for (int e = 0; e < b2; ++e) fac[L.offS + (size_t)(slot * b2 + e) * nsep + j] = nd(s, slot)[e];
+        }
+        if (!last)
+            for (int i = 0; i < N; ++i)
+                for (int slot = 0; slot < 2; ++slot)
+                    for (int e = 0; e < b2; ++e) fac[L.offB + (size_t)(slot * b2 + e) * N + i] = nd(i, 2 + slot)[e];
         levels.push_back(L);
         if (last) break;
         curA.swap(nA);
@@ -232,45 +268,39 @@ inline void chain_solve_host(const ChainDesc& ch, const ChainLevelDesc* levels, 
                              const int32_t* node_col, int bs, const double* r, double* z, double* scr) {
     const int b2 = bs * bs;
     const int32_t* nc = node_col + ch.node_begin;
-    auto rec = [&](const ChainLevelDesc& L, int i, int slot) {
-        return fac + ((size_t)(L.data_off + i) * 4 + slot) * b2;
-    };
     for (int lvl = 0; lvl < ch.n_levels; ++lvl) {
         const ChainLevelDesc& L = levels[ch.level_begin + lvl];
         const bool last = (L.p == 0);
-        const int nsep = last ? 0 : L.N / L.p;
+        const int nsep = L.nsep;
+        auto Rb = [&](int slot, int e, int q, int j) { return fac[L.offR + ((size_t)(slot * b2 + e) * L.P + q) * L.nruns + j]; };
+        auto Sb = [&](int slot, int e, int j) { return fac[L.offS + (size_t)(slot * b2 + e) * nsep + j]; };
         auto in = [&](int i, int c) { return lvl == 0 ? r[nc[i] + c] : scr[(size_t)(L.vec_off + i) * bs + c]; };
         auto out = [&](int i, int c) -> double& {
             return lvl == 0 ? z[nc[i] + c] : scr[(size_t)(L.vec_off + i) * bs + c];
         };
-        for (int j = 0; j <= nsep; ++j) {
+        for (int j = 0; j < L.nruns; ++j) {
             const int lo = last ? 0 : j * L.p;
             const int hi = last ? L.N : std::min(j * L.p + L.p - 1, L.N);
             if (lo >= hi) continue;
             double prev[kMaxBs], cur[kMaxBs];
             for (int i = lo; i < hi; ++i) {  // forward
                 for (int c = 0; c < bs; ++c) cur[c] = in(i, c);
-                if (i > lo) {
-                    const double* Lf = rec(L, i, 0);
+                if (i > lo)
                     for (int c = 0; c < bs; ++c)
-                        for (int k = 0; k < bs; ++k) cur[c] -= Lf[c * bs + k] * prev[k];
-                }
+                        for (int k = 0; k < bs; ++k) cur[c] -= Rb(0, c * bs + k, i - lo, j) * prev[k];
                 for (int c = 0; c < bs; ++c) { out(i, c) = cur[c]; prev[c] = cur[c]; }
             }
             for (int i = hi - 1; i >= lo; --i) {  // diagonal + backward
-                const double* Di = rec(L, i, 1);
                 double a[kMaxBs];
                 for (int c = 0; c < bs; ++c) a[c] = out(i, c);
                 for (int c = 0; c < bs; ++c) {
                     double s = 0;
-                    for (int k = 0; k < bs; ++k) s += Di[c * bs + k] * a[k];
+                    for (int k = 0; k < bs; ++k) s += Rb(1, c * bs + k, i - lo, j) * a[k];
                     cur[c] = s;
                 }
-                if (i + 1 < hi) {
-                    const double* Lf = rec(L, i + 1, 0);
+                if (i + 1 < hi)
                     for (int c = 0; c < bs; ++c)
-                        for (int k = 0; k < bs; ++k) cur[c] -= Lf[k * bs + c] * prev[k];
-                }
+                        for (int k = 0; k < bs; ++k) cur[c] -= Rb(0, k * bs + c, i + 1 - lo, j) * prev[k];
                 for (int c = 0; c < bs; ++c) { out(i, c) = cur[c]; prev[c] = cur[c]; }
             }
         }
@@ -278,13 +308,11 @@ inline void chain_solve_host(const ChainDesc& ch, const ChainLevelDesc* levels, 
         const ChainLevelDesc& Ln = levels[ch.level_begin + lvl + 1];
         for (int j = 0; j < nsep; ++j) {
             const int s = j * L.p + L.p - 1;
-            const double* Cl = rec(L, s, 0);
-            const double* Cr = rec(L, s, 1);
             for (int c = 0; c < bs; ++c) {
                 double v = in(s, c);
-                for (int k = 0; k < bs; ++k) v -= Cl[c * bs + k] * out(s - 1, k);
+                for (int k = 0; k < bs; ++k) v -= Sb(0, c * bs + k, j) * out(s - 1, k);
                 if (s + 1 < L.N)
-                    for (int k = 0; k < bs; ++k) v -= Cr[c * bs + k] * out(s + 1, k);
+                    for (int k = 0; k < bs; ++k) v -= Sb(1, c * bs + k, j) * out(s + 1, k);
                 scr[(size_t)(Ln.vec_off + j) * bs + c] = v;
             }
         }
@@ -292,7 +320,8 @@ inline void chain_solve_host(const ChainDesc& ch, const ChainLevelDesc* levels, 
     for (int lvl = ch.n_levels - 2; lvl >= 0; --lvl) {
         const ChainLevelDesc& L = levels[ch.level_begin + lvl];
         const ChainLevelDesc& Ln = levels[ch.level_begin + lvl + 1];
-        const int nsep = L.N / L.p;
+        const int nsep = L.nsep;
+        auto Bb = [&](int slot, int e, int i) { return fac[L.offB + (size_t)(slot * b2 + e) * L.N + i]; };
         auto out = [&](int i, int c) -> double& {
             return lvl == 0 ? z[nc[i] + c] : scr[(size_t)(L.vec_off + i) * bs + c];
         };
@@ -302,14 +331,12 @@ inline void chain_solve_host(const ChainDesc& ch, const ChainLevelDesc* levels, 
                 for (int c = 0; c < bs; ++c) out(i, c) = scr[(size_t)(Ln.vec_off + j) * bs + c];
                 continue;
             }
-            const double* V = rec(L, i, 2);
-            const double* W = rec(L, i, 3);
             for (int c = 0; c < bs; ++c) {
                 double v = out(i, c);
                 if (j >= 1)
-                    for (int k = 0; k < bs; ++k) v -= V[c * bs + k] * scr[(size_t)(Ln.vec_off + j - 1) * bs + k];
+                    for (int k = 0; k < bs; ++k) v -= Bb(0, c * bs + k, i) * scr[(size_t)(Ln.vec_off + j - 1) * bs + k];
                 if (j < nsep)
-                    for (int k = 0; k < bs; ++k) v -= W[c * bs + k] * scr[(size_t)(Ln.vec_off + j) * bs + k];
+                    for (int k = 0; k < bs; ++k) v -= Bb(1, c * bs + k, i) * scr[(size_t)(Ln.vec_off + j) * bs + k];
                 out(i, c) = v;
             }
         }
@@ -629,7 +656,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     H = HostSystem();
     H.count = count;
     H.sigma = st.sigma;
-    H.radix = std::min(8, std::max(2, st.chain_radix));
+    H.radix = std::min(4, std::max(2, st.chain_radix));
     H.xoff.assign(count + 1, 0);
     H.roff.assign(count + 1, 0);
     int bs = 0;
@@ -735,12 +762,14 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         factor_chain_levels(bs, H.radix, ch.N, Ad, Bs, lv, fac, scr);
         ch.level_begin = (int32_t)H.levels.size();
         ch.n_levels = (int32_t)lv.size();
-        const int32_t node_base = (int32_t)(H.fac.size() / (size_t)(4 * b2));
+        const int64_t dbl_base = (int64_t)H.fac.size();
         for (auto& L : lv) {
-            L.data_off += node_base;
+            L.offR += dbl_base;
+            L.offS += dbl_base;
+            L.offB += dbl_base;
             H.levels.push_back(L);
         }
-        H.fac_off.push_back((int64_t)H.fac.size());
+        H.fac_off.push_back(dbl_base);
         H.fac.resize(H.fac.size() + fac.size(), 0.0);
         ch.scratch_off = (int32_t)H.scratch_nodes;
         ch.scratch_nodes = scr;

@@ -1,0 +1,655 @@
+// score_kernels.hpp -- gfx950 device kernels of the SCORE conic solver.
+//
+// Kernel design notes:
+//  * k_spmv: the KKT operator is HBM/L2-bandwidth work (12 B per nonzero,
+//    2 flop).  Each 256-thread workgroup owns a tile of <= 256 rows / <= 3072
+//    nonzeros, reads values and column indices with fully coalesced loads (12
+//    independent loads per lane in flight before the first use), gathers the
+//    vector, stages the products in LDS and lets one lane per row add its
+//    segment in CSR order, so results do not depend on the launch geometry.
+//    Rows longer than 48 nonzeros (landmarks) get a workgroup of their own, an
+//    8-way unrolled strided sweep and a shuffle/LDS tree reduction.
+//  * dot products are never atomics: every workgroup writes one partial and
+//    each consumer workgroup re-reduces the partials of its problem in a fixed
+//    order (a few KiB from L2) -- deterministic, and one launch shorter than a
+//    separate finalise kernel.
+//  * k_prec: direct solve with the per-robot block-tridiagonal part of K,
+//    factored on the host as a radix-p nested dissection.  One workgroup per
+//    chain; the chain's vector lives in LDS; one lane per run of p-1 nodes with
+//    the bs x bs blocks in registers; factor blocks are stored structure-of-
+//    arrays so a wavefront's loads are 512 contiguous bytes; O(p log_p N)
+//    dependent steps instead of 2N.
+//  * k_cone: one cone per lane (cones have 3 or 4 rows; a wavefront per cone
+//    would idle 60 lanes), rows kept in registers.
+//  * no MFMA anywhere: nothing here is a dense contraction.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "score_host.hpp"
+
+namespace score {
+
+constexpr int kThreads = 256;
+constexpr int kUnroll = kTileNnz / kThreads;  // 12 nonzeros per lane
+constexpr int kLongUnroll = 8;
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+    return v;
+}
+// Sum over the 256-thread block, result in every thread.  `red` >= 4 doubles.
+__device__ __forceinline__ double block_sum(double v, double* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+__device__ __forceinline__ double block_max(double v, double* red) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+// Fixed-order re-reduction of per-workgroup partials [lo, hi).
+__device__ __forceinline__ double reduce_partials(const double* __restrict__ part, int lo, int hi, double* red) {
+    double acc = 0.0;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += kThreads) acc += part[i];
+    return block_sum(acc, red);
+}
+
+struct CsrDev {
+    const int32_t* ptr;
+    const int32_t* col;
+    const double* val;
+    const int32_t* first_row;  // row blocks
+    const int32_t* blk_prob;
+    const int32_t* split;      // G2 only
+    int nblocks;
+};
+
+struct SpmvArgs {
+    CsrDev M;
+    const double* xin;      // gathered vector
+    const int32_t* done;
+    // RHS
+    const double* x;
+    const double* q;
+    double* r;
+    double sigma;
+    // KP / KPB
+    const double* p;        // KP: direction (== xin).  KPB: previous direction
+    const double* z;        // KPB: preconditioned residual
+    double* p_out;          // KPB: new direction p = z + beta p_old (own rows)
+    double* w;
+    double* pw_part;
+    const double* rz_new;   // KPB: partials of r'z (new, old)
+    const double* rz_old;
+    const int32_t* prec_part_ptr;
+    // DRES
+    const double* invD;
+    double* dres_part;      // 8 per block
+};
+
+// RHS : r = sigma x - q + M xin                        (M = [-K | A'], xin = [xt ; u])
+// KP  : w = M p, partial p'w                           (M = K)
+// KPB : p_new = z + beta p_old (beta from partials), w = M p_new, partial p_new'w
+// DRES: dual residual norms                            (M = [P | A'], xin = [x ; y])
+enum { MODE_RHS = 0, MODE_KP = 1, MODE_DRES = 2, MODE_KPB = 3 };
+
+template <int MODE>
+__global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
+    __shared__ double prod[kTileNnz];
+    __shared__ double red[8];
+    const int b = blockIdx.x;
+    const int prob = a.M.blk_prob[b];
+    if (a.done[prob]) return;
+    const int t = threadIdx.x;
+    const int r0 = a.M.first_row[b], r1 = a.M.first_row[b + 1];
+    const int k0 = a.M.ptr[r0], k1 = a.M.ptr[r1];
+    const int nn = k1 - k0;
+    const double* __restrict__ val = a.M.val;
+    const int32_t* __restrict__ col = a.M.col;
+    const double* __restrict__ xin = a.xin;
+
+    double beta = 0.0;
+    if (MODE == MODE_KPB) {
+        const double rzn = reduce_partials(a.rz_new, a.prec_part_ptr[prob], a.prec_part_ptr[prob + 1], red);
+        const double rzo = reduce_partials(a.rz_old, a.prec_part_ptr[prob], a.prec_part_ptr[prob + 1], red);
+        beta = rzo > 0.0 ? rzn / rzo : 0.0;
+    }
+    // value of the gathered vector at column c
+    auto gather = [&](int c) -> double {
+        if (MODE == MODE_KPB) return a.z[c] + beta * a.p[c];
+        return xin[c];
+    };
+
+    int row = r0 + t;
+    bool has_row = false;
+    double sum = 0.0, sum2 = 0.0;  // sum2: A' part (MODE_DRES)
+
+    if (r1 - r0 == 1 && nn > kLongRow) {
+        // one long row: unrolled strided partial sums + tree reduction
+        double acc = 0.0, acc2 = 0.0;
+        const int split = (MODE == MODE_DRES) ? a.M.split[r0] : k1;
+        for (int kb = k0 + t; kb < k1; kb += kThreads * kLongUnroll) {
+            int32_t c[kLongUnroll];
+            double v[kLongUnroll];
+#pragma unroll
+            for (int u = 0; u < kLongUnroll; ++u) {
+                const int k = kb + u * kThreads;
+                if (k < k1) { c[u] = col[k]; v[u] = val[k]; }
+            }
+#pragma unroll
+            for (int u = 0; u < kLongUnroll; ++u) {
+                const int k = kb + u * kThreads;
+                if (k < k1) {
+                    const double pr = v[u] * gather(c[u]);
+                    if (MODE == MODE_DRES && k >= split) acc2 += pr; else acc += pr;
+                }
+            }
+        }
+        sum = block_sum(acc, red);
+        if (MODE == MODE_DRES) sum2 = block_sum(acc2, red);
+        has_row = (t == 0);
+        row = r0;
+    } else {
+        int32_t c[kUnroll];
+        double v[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int k = t + u * kThreads;
+            if (k < nn) {
+                c[u] = col[k0 + k];
+                v[u] = val[k0 + k];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int k = t + u * kThreads;
+            if (k < nn) prod[k] = v[u] * gather(c[u]);
+        }
+        __syncthreads();
+        if (row < r1) {
+            has_row = true;
+            const int a0 = a.M.ptr[row] - k0, a1 = a.M.ptr[row + 1] - k0;
+            if (MODE == MODE_DRES) {
+                const int sp = a.M.split[row] - k0;
+                for (int k = a0; k < sp; ++k) sum += prod[k];
+                for (int k = sp; k < a1; ++k) sum2 += prod[k];
+            } else {
+                for (int k = a0; k < a1; ++k) sum += prod[k];
+            }
+        }
+    }
+
+    if (MODE == MODE_RHS) {
+        if (has_row) a.r[row] = a.sigma * a.x[row] - a.q[row] + sum;
+    } else if (MODE == MODE_KP || MODE == MODE_KPB) {
+        double local = 0.0;
+        if (has_row) {
+            a.w[row] = sum;
+            double pi;
+            if (MODE == MODE_KPB) {
+                pi = a.z[row] + beta * a.p[row];
+                a.p_out[row] = pi;
+            } else {
+                pi = a.p[row];
+            }
+            local = pi * sum;
+        }
+        const double tot = block_sum(local, red);
+        if (t == 0) a.pw_part[b] = tot;
+    } else {  // MODE_DRES: sum = (P x)_i, sum2 = (A'y)_i ; xin = [x ; y]
+        double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, s0 = 0, s1 = 0, bad = 0;
+        if (has_row) {
+            const double qi = a.q[row];
+            const double dr = sum + qi + sum2;
+            const double id = a.invD[row];
+            if (dr != dr) bad = 1.0;
+            m0 = fabs(dr) * id; m1 = fabs(sum) * id; m2 = fabs(sum2) * id;
+            m3 = fabs(dr); m4 = fabs(sum); m5 = fabs(sum2);
+            const double xi = xin[row];
+            s0 = xi * sum;
+            s1 = qi * xi;
+        }
+        bad = block_sum(bad, red);
+        m0 = block_max(m0, red); m1 = block_max(m1, red); m2 = block_max(m2, red);
+        m3 = block_max(m3, red); m4 = block_max(m4, red); m5 = block_max(m5, red);
+        s0 = block_sum(s0, red); s1 = block_sum(s1, red);
+        if (t == 0) {
+            double* o = a.dres_part + (size_t)b * 8;
+            const double nanv = bad > 0.0 ? __builtin_nan("") : 0.0;
+            o[0] = m0 + nanv; o[1] = m1; o[2] = m2; o[3] = m3 + nanv; o[4] = m4; o[5] = m5; o[6] = s0; o[7] = s1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// preconditioner: multi-level block-tridiagonal chain solve + Jacobi
+// ---------------------------------------------------------------------------
+struct PrecArgs {
+    const PrecWork* work;
+    const ChainDesc* chains;
+    const ChainLevelDesc* levels;
+    const double* fac;
+    const int32_t* node_col;
+    const int32_t* diag_cols;
+    const double* dinv;
+    const int32_t* done;
+    const int32_t* prec_part_ptr;  // per problem: range of prec work items
+    const int32_t* kblk_part_ptr;  // per problem: range of K row blocks
+    double* r;
+    double* z;
+    double* p;             // INIT: receives p = z.  STEP: the direction of the last K p
+    const double* w;
+    double* xt;
+    const double* rz_in;   // partials of the previous r'z   (STEP)
+    const double* pw_part; // partials of p'w                (STEP)
+    double* rz_out;        // one partial per work item
+};
+
+enum { PREC_INIT = 0, PREC_STEP = 1 };
+
+// BS: block size, RMAX: radix - 1 (nodes per run), LDS0: level-0 vector in LDS
+template <int BS, int RMAX, int MODE, bool LDS0>
+__global__ __launch_bounds__(kThreads) void k_prec(PrecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // [0,8): reductions, then vectors
+    double* red = lds;
+    const PrecWork wk = a.work[blockIdx.x];
+    const int prob = wk.prob;
+    if (a.done[prob]) return;
+    const int t = threadIdx.x;
+    double alpha = 0.0;
+    if (MODE == PREC_STEP) {
+        const double rz = reduce_partials(a.rz_in, a.prec_part_ptr[prob], a.prec_part_ptr[prob + 1], red);
+        const double pw = reduce_partials(a.pw_part, a.kblk_part_ptr[prob], a.kblk_part_ptr[prob + 1], red);
+        alpha = pw > 0.0 ? rz / pw : 0.0;
+    }
+    double local = 0.0;
+    if (wk.kind == 1) {
+        for (int e = wk.index + t; e < wk.index + wk.count; e += kThreads) {
+            const int col = a.diag_cols[e];
+            double rv = a.r[col];
+            if (MODE == PREC_STEP) {
+                a.xt[col] += alpha * a.p[col];
+                rv -= alpha * a.w[col];
+                a.r[col] = rv;
+            }
+            const double zv = rv * a.dinv[e];
+            a.z[col] = zv;
+            if (MODE == PREC_INIT) a.p[col] = zv;
+            local += rv * zv;
+        }
+    } else {
+        constexpr int B2 = BS * BS;
+        const ChainDesc ch = a.chains[wk.index];
+        const ChainLevelDesc* __restrict__ lv = a.levels + ch.level_begin;
+        const int32_t* __restrict__ nc = a.node_col + ch.node_begin;
+        const double* __restrict__ fac = a.fac;
+        const int N = ch.N;
+        double* v0 = lds + 8;                                      // level-0 vector (LDS0)
+        double* vup = lds + 8 + (LDS0 ? (size_t)N * BS : (size_t)0);  // levels >= 1
+        // ---- load (and, for STEP, update) the chain's residual ----
+        for (int idx = t; idx < N * BS; idx += kThreads) {
+            const int node = idx / BS;
+            const int col = nc[node] + (idx - node * BS);
+            double rv = a.r[col];
+            if (MODE == PREC_STEP) {
+                a.xt[col] += alpha * a.p[col];
+                rv -= alpha * a.w[col];
+                a.r[col] = rv;
+            }
+            if (LDS0) v0[idx] = rv;
+        }
+        __syncthreads();
+        // level-l vector element (node i, component c): load / store
+        auto vld = [&](int l, const ChainLevelDesc& L, int i, int c, bool input) -> double {
+            if (l == 0) {
+                if (LDS0) return v0[i * BS + c];
+                return input ? a.r[nc[i] + c] : a.z[nc[i] + c];
+            }
+            return vup[(size_t)(L.vec_off + i) * BS + c];
+        };
+        auto vst = [&](int l, const ChainLevelDesc& L, int i, int c, double val) {
+            if (l == 0) {
+                if (LDS0) v0[i * BS + c] = val; else a.z[nc[i] + c] = val;
+            } else {
+                vup[(size_t)(L.vec_off + i) * BS + c] = val;
+            }
+        };
+        for (int l = 0; l < ch.n_levels; ++l) {
+            const ChainLevelDesc L = lv[l];
+            const bool last = (L.p == 0);
+            const int nsep = L.nsep;
+            const double* __restrict__ R = fac + L.offR;
+            for (int j = t; j < L.nruns; j += kThreads) {
+                const int lo = last ? 0 : j * L.p;
+                const int hi = last ? L.N : min(j * L.p + L.p - 1, L.N);
+                if (lo >= hi) continue;
+                double Lf[RMAX][B2], Dv[RMAX][B2], y[RMAX][BS];
+                // all factor loads of the run are issued before the recurrence starts
+#pragma unroll
+                for (int q = 0; q < RMAX; ++q)
+                    if (lo + q < hi) {
+#pragma unroll
+                        for (int e = 0; e < B2; ++e) {
+                            Lf[q][e] = R[((size_t)(0 * B2 + e) * L.P + q) * L.nruns + j];
+                            Dv[q][e] = R[((size_t)(1 * B2 + e) * L.P + q) * L.nruns + j];
+                        }
+#pragma unroll
+                        for (int c = 0; c < BS; ++c) y[q][c] = vld(l, L, lo + q, c, true);
+                    }
+                // forward substitution
+#pragma unroll
+                for (int q = 1; q < RMAX; ++q)
+                    if (lo + q < hi) {
+#pragma unroll
+                        for (int c = 0; c < BS; ++c) {
+                            double s = y[q][c];
+#pragma unroll
+                            for (int k = 0; k < BS; ++k) s -= Lf[q][c * BS + k] * y[q - 1][k];
+                            y[q][c] = s;
+                        }
+                    }
+                // diagonal solve + backward substitution
+#pragma unroll
+                for (int q = RMAX - 1; q >= 0; --q)
+                    if (lo + q < hi) {
+                        double tmp[BS];
+#pragma unroll
+                        for (int c = 0; c < BS; ++c) {
+                            double s = 0.0;
+#pragma unroll
+                            for (int k = 0; k < BS; ++k) s += Dv[q][c * BS + k] * y[q][k];
+                            tmp[c] = s;
+                        }
+                        if (q + 1 < RMAX) {
+                            if (lo + q + 1 < hi) {
+#pragma unroll
+                                for (int c = 0; c < BS; ++c) {
+                                    double s = tmp[c];
+#pragma unroll
+                                    for (int k = 0; k < BS; ++k) s -= Lf[q + 1][k * BS + c] * y[q + 1][k];
+                                    tmp[c] = s;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int c = 0; c < BS; ++c) {
+                            y[q][c] = tmp[c];
+                            vst(l, L, lo + q, c, tmp[c]);
+                        }
+                    }
+            }
+            __syncthreads();
+            if (last) break;
+            const ChainLevelDesc Ln = lv[l + 1];
+            const double* __restrict__ S = fac + L.offS;
+            for (int j = t; j < nsep; j += kThreads) {
+                const int s = j * L.p + L.p - 1;
+                double v[BS], ym[BS], yp[BS];
+                const bool has_right = (s + 1 < L.N);
+#pragma unroll
+                for (int c = 0; c < BS; ++c) {
+                    v[c] = vld(l, L, s, c, true);
+                    ym[c] = vld(l, L, s - 1, c, false);
+                    yp[c] = has_right ? vld(l, L, s + 1, c, false) : 0.0;
+                }
+#pragma unroll
+                for (int c = 0; c < BS; ++c) {
+                    double acc = v[c];
+#pragma unroll
+                    for (int k = 0; k < BS; ++k) {
+                        acc -= S[(size_t)(0 * B2 + c * BS + k) * nsep + j] * ym[k];
+                        acc -= S[(size_t)(1 * B2 + c * BS + k) * nsep + j] * yp[k];  // Cr = 0 without a right run
+                    }
+                    vup[(size_t)(Ln.vec_off + j) * BS + c] = acc;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- back-substitution, coarse to fine ----
+        for (int l = ch.n_levels - 2; l >= 0; --l) {
+            const ChainLevelDesc L = lv[l];
+            const ChainLevelDesc Ln = lv[l + 1];
+            const int nsep = L.nsep;
+            const double* __restrict__ Bk = fac + L.offB;
+            for (int i = t; i < L.N; i += kThreads) {
+                const int j = i / L.p;
+                double v[BS];
+                const bool is_sep = (i - j * L.p == L.p - 1) && (j < nsep);
+                if (is_sep) {
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) v[c] = vup[(size_t)(Ln.vec_off + j) * BS + c];
+                } else {
+                    double ul[BS], ur[BS];
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) {
+                        v[c] = vld(l, L, i, c, false);
+                        ul[c] = (j >= 1) ? vup[(size_t)(Ln.vec_off + j - 1) * BS + c] : 0.0;
+                        ur[c] = (j < nsep) ? vup[(size_t)(Ln.vec_off + j) * BS + c] : 0.0;
+                    }
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) {
+                        double acc = v[c];
+#pragma unroll
+                        for (int k = 0; k < BS; ++k) {
+                            acc -= Bk[(size_t)(0 * B2 + c * BS + k) * L.N + i] * ul[k];  // V = 0 without a left separator
+                            acc -= Bk[(size_t)(1 * B2 + c * BS + k) * L.N + i] * ur[k];
+                        }
+                        v[c] = acc;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < BS; ++c) vst(l, L, i, c, v[c]);
+            }
+            __syncthreads();
+        }
+        // ---- write z (LDS0), p (INIT) and accumulate r'z ----
+        for (int idx = t; idx < N * BS; idx += kThreads) {
+            const int node = idx / BS;
+            const int col = nc[node] + (idx - node * BS);
+            double zv;
+            if (LDS0) { zv = v0[idx]; a.z[col] = zv; } else { zv = a.z[col]; }
+            if (MODE == PREC_INIT) a.p[col] = zv;
+            local += a.r[col] * zv;
+        }
+    }
+    const double tot = block_sum(local, red);
+    if (t == 0) a.rz_out[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------
+// vector update at the end of the PCG sweep (grid = K row blocks)
+// ---------------------------------------------------------------------------
+struct VecArgs {
+    const int32_t* first_row;
+    const int32_t* blk_prob;
+    const int32_t* done;
+    const int32_t* prec_part_ptr;
+    const int32_t* kblk_part_ptr;
+    const double* rz_old;
+    const double* pw_part;
+    const double* p;
+    double* xt;
+    double* x;
+    double alpha_relax;
+    int apply_alpha;  // 0: xt already holds the final CG iterate
+};
+
+__global__ __launch_bounds__(kThreads) void k_xupdate(VecArgs a) {
+    __shared__ double red[8];
+    const int b = blockIdx.x;
+    const int prob = a.blk_prob[b];
+    if (a.done[prob]) return;
+    double alpha = 0.0;
+    if (a.apply_alpha) {
+        const double rz = reduce_partials(a.rz_old, a.prec_part_ptr[prob], a.prec_part_ptr[prob + 1], red);
+        const double pw = reduce_partials(a.pw_part, a.kblk_part_ptr[prob], a.kblk_part_ptr[prob + 1], red);
+        alpha = pw > 0.0 ? rz / pw : 0.0;
+    }
+    const int row = a.first_row[b] + threadIdx.x;
+    if (row < a.first_row[b + 1]) {
+        const double xt = a.xt[row] + alpha * a.p[row];
+        a.xt[row] = xt;
+        a.x[row] = a.alpha_relax * xt + (1.0 - a.alpha_relax) * a.x[row];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// cones: one cone per lane
+// ---------------------------------------------------------------------------
+struct ConeArgs {
+    const int32_t* A_ptr;
+    const int32_t* A_col;
+    const double* A_val;
+    const int32_t* cone_row;
+    const int32_t* cone_dim;
+    const int32_t* cone_type;
+    const int32_t* block_first;
+    const int32_t* block_prob;
+    const int32_t* done;
+    const double* rho;
+    const double* b;
+    const double* xt;   // gathered (xt for the iteration, x for residuals)
+    double* s;
+    double* y;
+    double* u;
+    double alpha_relax;
+    const double* invE;
+    double* pres_part;  // 8 per block
+};
+
+__device__ __forceinline__ double a_row_dot(const ConeArgs& a, int i, const double* __restrict__ v) {
+    double acc = 0.0;
+    for (int k = a.A_ptr[i]; k < a.A_ptr[i + 1]; ++k) acc += a.A_val[k] * v[a.A_col[k]];
+    return acc;
+}
+
+__device__ __forceinline__ void soc_scales(int type, double t0, double nz2, double& head, double& tail) {
+    if (type == 0) {  // zero cone
+        head = 0.0; tail = 0.0;
+        return;
+    }
+    const double nz = sqrt(nz2);
+    if (nz <= t0) { head = t0; tail = 1.0; }
+    else if (nz <= -t0) { head = 0.0; tail = 0.0; }
+    else { const double m = 0.5 * (t0 + nz); head = m; tail = m / nz; }
+}
+
+constexpr int kSmallCone = 4;
+
+__global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
+    const int b = blockIdx.x;
+    const int prob = a.block_prob[b];
+    if (a.done[prob]) return;
+    const int c = a.block_first[b] + threadIdx.x;
+    if (c >= a.block_first[b + 1]) return;
+    const int row = a.cone_row[c], dim = a.cone_dim[c], type = a.cone_type[c];
+    const double rho = a.rho[prob], irho = 1.0 / rho, al = a.alpha_relax;
+    double t0 = 0.0, nz2 = 0.0, head, tail;
+    if (dim <= kSmallCone) {
+        // SCORE's cones (d + 1 = 3 or 4 rows): everything stays in registers
+        double v[kSmallCone], wv[kSmallCone], yv[kSmallCone], bv[kSmallCone];
+#pragma unroll
+        for (int k = 0; k < kSmallCone; ++k)
+            if (k < dim) {
+                const int i = row + k;
+                bv[k] = a.b[i];
+                yv[k] = a.y[i];
+                const double tt = a_row_dot(a, i, a.xt);
+                v[k] = al * (bv[k] - tt) + (1.0 - al) * a.s[i];
+                wv[k] = v[k] - yv[k] * irho;
+                if (k == 0) t0 = wv[k]; else nz2 += wv[k] * wv[k];
+            }
+        soc_scales(type, t0, nz2, head, tail);
+#pragma unroll
+        for (int k = 0; k < kSmallCone; ++k)
+            if (k < dim) {
+                const int i = row + k;
+                const double sn = (k == 0) ? head : tail * wv[k];
+                const double yn = yv[k] + rho * (sn - v[k]);
+                a.s[i] = sn;
+                a.y[i] = yn;
+                a.u[i] = rho * (bv[k] - sn) - yn;
+            }
+        return;
+    }
+    for (int k = 0; k < dim; ++k) {
+        const int i = row + k;
+        const double tt = a_row_dot(a, i, a.xt);
+        const double v = al * (a.b[i] - tt) + (1.0 - al) * a.s[i];
+        const double wv = v - a.y[i] * irho;
+        a.u[i] = v;   // stash v
+        a.s[i] = wv;  // stash the point to project
+        if (k == 0) t0 = wv; else nz2 += wv * wv;
+    }
+    soc_scales(type, t0, nz2, head, tail);
+    for (int k = 0; k < dim; ++k) {
+        const int i = row + k;
+        const double sn = (k == 0) ? head : tail * a.s[i];
+        const double v = a.u[i];
+        const double yn = a.y[i] + rho * (sn - v);
+        a.s[i] = sn;
+        a.y[i] = yn;
+        a.u[i] = rho * (a.b[i] - sn) - yn;
+    }
+}
+
+// u = rho (b - s) - y   (after a penalty update)
+__global__ __launch_bounds__(kThreads) void k_refresh_u(ConeArgs a) {
+    const int b = blockIdx.x;
+    const int prob = a.block_prob[b];
+    const int c = a.block_first[b] + threadIdx.x;
+    if (c >= a.block_first[b + 1]) return;
+    const int row = a.cone_row[c], dim = a.cone_dim[c];
+    const double rho = a.rho[prob];
+    for (int k = 0; k < dim; ++k) {
+        const int i = row + k;
+        a.u[i] = rho * (a.b[i] - a.s[i]) - a.y[i];
+    }
+}
+
+// primal residual norms; a.xt points at x here
+__global__ __launch_bounds__(kThreads) void k_pres(ConeArgs a) {
+    __shared__ double red[8];
+    const int b = blockIdx.x;
+    const int prob = a.block_prob[b];
+    if (a.done[prob]) return;
+    const int c = a.block_first[b] + threadIdx.x;
+    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, sby = 0, bad = 0;
+    if (c < a.block_first[b + 1]) {
+        const int row = a.cone_row[c], dim = a.cone_dim[c];
+        for (int k = 0; k < dim; ++k) {
+            const int i = row + k;
+            const double tt = a_row_dot(a, i, a.xt);
+            const double si = a.s[i];
+            const double pr = tt + si - a.b[i];
+            const double ie = a.invE[i];
+            if (pr != pr) bad = 1.0;
+            m0 = fmax(m0, fabs(pr) * ie); m1 = fmax(m1, fabs(tt) * ie); m2 = fmax(m2, fabs(si) * ie);
+            m3 = fmax(m3, fabs(pr)); m4 = fmax(m4, fabs(tt)); m5 = fmax(m5, fabs(si));
+            sby += a.b[i] * a.y[i];
+        }
+    }
+    bad = block_sum(bad, red);
+    m0 = block_max(m0, red); m1 = block_max(m1, red); m2 = block_max(m2, red);
+    m3 = block_max(m3, red); m4 = block_max(m4, red); m5 = block_max(m5, red);
+    sby = block_sum(sby, red);
+    if (threadIdx.x == 0) {
+        double* o = a.pres_part + (size_t)b * 8;
+        const double nanv = bad > 0.0 ? __builtin_nan("") : 0.0;
+        o[0] = m0 + nanv; o[1] = m1; o[2] = m2; o[3] = m3 + nanv; o[4] = m4; o[5] = m5; o[6] = sby; o[7] = 0.0;
+    }
+}
+
+}  // namespace score

@@ -138,7 +138,7 @@ def test_abi_rejects_bad_problems(twin_lib):
         ConicSolver(qp, dict(no_such=1), lib_path=twin_lib)
 
 
-@pytest.mark.parametrize("radix", [2, 3, 4, 8])
+@pytest.mark.parametrize("radix", [2, 3, 4])
 def test_chain_preconditioner_is_the_exact_chain_inverse(radix, twin_lib):
     """With a problem that consists ONLY of chains (odometry, no ranges) the
     multi-level factorisation is an exact solver for K, so one PCG step gives the
