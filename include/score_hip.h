@@ -148,6 +148,12 @@ int  score_solve_steps(score_handle* h, int32_t iters, double* x, double* y, dou
 int  score_time_kkt_apply(score_handle* h, int32_t reps, double* ms_per_apply,
                           double* bytes_per_apply);
 
+/* Debug: average milliseconds of `reps` back-to-back launches of one kernel of the
+ * iteration ("rhs", "prec_init", "prec_step", "kp", "kpb", "xupdate", "cone"),
+ * HIP events on the handle's stream.  Leaves the iterates in an undefined state
+ * (call score_reset afterwards).                                              */
+int  score_debug_time(score_handle* h, const char* kernel, int32_t reps, double* ms);
+
 /* Debug/test access to an internal device vector by name ("x", "xt", "s", "y",
  * "u", "r", "z", "p", "w"); copies min(len, size) doubles, returns the size. */
 int64_t score_debug_get(score_handle* h, const char* name, double* out, int64_t len);

@@ -330,6 +330,10 @@ int score_time_kkt_apply(score_handle* h, int32_t reps, double* ms, double* byte
     try { h->solver.be.time_kkt(reps, ms, bytes); return 0; }
     catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
+int score_debug_time(score_handle*, const char*, int32_t, double* ms) {
+    if (ms) *ms = 0.0;  // the twin has no kernels to time
+    return 0;
+}
 int64_t score_debug_get(score_handle* h, const char* name, double* out, int64_t len) {
     return h->solver.be.get_vec(name, out, len);
 }

@@ -153,8 +153,8 @@ struct HipBackend {
             max_nodes = std::max(max_nodes, ch.scratch_nodes);
             max_all = std::max(max_all, ch.scratch_nodes + ch.N);
         }
-        const size_t lds_all = (8 + (size_t)max_all * std::max(1, h.bs)) * sizeof(double);
-        const size_t lds_up = (8 + (size_t)max_nodes * std::max(1, h.bs)) * sizeof(double);
+        const size_t lds_all = (16 + (size_t)max_all * std::max(1, h.bs)) * sizeof(double);
+        const size_t lds_up = (16 + (size_t)max_nodes * std::max(1, h.bs)) * sizeof(double);
         prec_lds0 = lds_all <= 144 * 1024;
         prec_lds = prec_lds0 ? lds_all : lds_up;
         if (prec_lds > 144 * 1024) throw std::runtime_error("chain too long for the LDS-resident chain solver");
@@ -231,9 +231,9 @@ struct HipBackend {
 #define SCORE_LAUNCH_PREC(BS)                                                                                  \
     do {                                                                                                       \
         if (prec_lds0)                                                                                         \
-            hipLaunchKernelGGL((k_prec<BS, 3, MODE, true>), dim3(n_prec), dim3(kThreads), prec_lds, stream, pa); \
+            hipLaunchKernelGGL((k_prec<BS, 3, MODE, true>), dim3(n_prec), dim3(kPrecThreads), prec_lds, stream, pa); \
         else                                                                                                   \
-            hipLaunchKernelGGL((k_prec<BS, 3, MODE, false>), dim3(n_prec), dim3(kThreads), prec_lds, stream, pa); \
+            hipLaunchKernelGGL((k_prec<BS, 3, MODE, false>), dim3(n_prec), dim3(kPrecThreads), prec_lds, stream, pa); \
     } while (0)
         if (bs <= 1) SCORE_LAUNCH_PREC(1);
         else if (bs == 2) SCORE_LAUNCH_PREC(2);
@@ -409,7 +409,7 @@ struct HipBackend {
         else if (nm == "s") { src = s.d; sz = h.m_tot; }
         else if (nm == "r") { src = r.d; sz = h.n_tot; }
         else if (nm == "z") { src = z.d; sz = h.n_tot; }
-        else if (nm == "p") { src = p.d; sz = h.n_tot; }
+        else if (nm == "p") { src = (cg_iters % 2 == 1) ? p.d : p2.d; sz = h.n_tot; }  // last PCG direction
         else if (nm == "w") { src = w.d; sz = h.n_tot; }
         else if (nm == "D") { src = h.D.data(); sz = h.n_tot; host = true; }
         else if (nm == "E") { src = h.E.data(); sz = h.m_tot; host = true; }
@@ -424,6 +424,40 @@ struct HipBackend {
             }
         }
         return sz;
+    }
+
+    void time_kernel(const std::string& which, int reps, double* ms) {
+        PrecArgs pa{};
+        pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = fac.d;
+        pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = done.d;
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d;
+        pa.r = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d;
+        pa.pw_part = pw_part.d; pa.rz_in = rz_part0.d; pa.rz_out = rz_part1.d;
+        VecArgs va{};
+        va.first_row = K.first_row.d; va.blk_prob = K.blk_prob.d; va.done = done.d;
+        va.prec_part_ptr = prec_part_ptr.d; va.kblk_part_ptr = kblk_part_ptr.d;
+        va.pw_part = pw_part.d; va.p = p.d; va.xt = xtu.d; va.x = xy.d;
+        va.alpha_relax = st.alpha; va.rz_old = rz_part0.d; va.apply_alpha = 1;
+        auto once = [&]() {
+            if (which == "rhs") hipLaunchKernelGGL(k_spmv<MODE_RHS>, dim3(G1.nblocks), dim3(kThreads), 0, stream, spmv_args(G1, xtu.d));
+            else if (which.rfind("prec_init:", 0) == 0) { pa.debug_skip = std::atoi(which.c_str() + 10); launch_prec<PREC_INIT>(pa); }
+            else if (which == "prec_init") launch_prec<PREC_INIT>(pa);
+            else if (which == "prec_step") launch_prec<PREC_STEP>(pa);
+            else if (which == "kp") launch_kp(p.d);
+            else if (which == "kpb") launch_kpb(p.d, p2.d, rz_part1.d, rz_part0.d);
+            else if (which == "xupdate") hipLaunchKernelGGL(k_xupdate, dim3(K.nblocks), dim3(kThreads), 0, stream, va);
+            else if (which == "cone") { if (n_cone_blocks) hipLaunchKernelGGL(k_cone, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xtu.d)); }
+            else throw std::runtime_error("unknown kernel name");
+        };
+        for (int i = 0; i < 5; ++i) once();
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipEventRecord(ev0, stream));
+        for (int i = 0; i < reps; ++i) once();
+        HIP_CHECK(hipEventRecord(ev1, stream));
+        HIP_CHECK(hipEventSynchronize(ev1));
+        float t = 0;
+        HIP_CHECK(hipEventElapsedTime(&t, ev0, ev1));
+        *ms = (double)t / std::max(1, reps);
     }
 
     // roofline probe: average launch duration of the KKT SpMV (w = K p), HIP
@@ -515,6 +549,13 @@ int score_time_kkt_apply(score_handle* h, int32_t reps, double* ms, double* byte
     try {
         if (!h) throw std::runtime_error("null handle");
         h->solver.be.time_kkt(reps, ms, bytes);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_debug_time(score_handle* h, const char* kernel, int32_t reps, double* ms) {
+    try {
+        if (!h || !kernel || !ms) throw std::runtime_error("null argument");
+        h->solver.be.time_kernel(kernel, reps, ms);
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }

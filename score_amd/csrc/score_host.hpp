@@ -72,7 +72,8 @@ struct ChainDesc {
     int32_t N;           // level-0 nodes
     int32_t scratch_off; // first scratch node (global scratch, units of nodes)
     int32_t scratch_nodes;
-    int32_t pad;
+    int32_t col0;        // first column of node 0
+    int32_t col_stride;  // node_col[i] == col0 + i * col_stride for every node (0 = irregular)
 };
 
 // Work item of the preconditioner kernel: a chain, or a block of Jacobi columns.
@@ -745,6 +746,15 @@ inline void build_system(const score_problem* probs, int count, const score_sett
                             H.pos_sub.push_back(-1);
                         }
                     }
+            }
+            ch.col0 = H.node_col[ch.node_begin];
+            ch.col_stride = 0;
+            if (ch.N >= 2) {
+                const int32_t st0 = H.node_col[ch.node_begin + 1] - H.node_col[ch.node_begin];
+                bool even = st0 > 0;
+                for (int i = 2; i < ch.N && even; ++i)
+                    even = (H.node_col[ch.node_begin + i] - H.node_col[ch.node_begin + i - 1]) == st0;
+                if (even) ch.col_stride = st0;
             }
             H.chains.push_back(ch);
         }

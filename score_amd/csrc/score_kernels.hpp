@@ -65,6 +65,24 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ par
     for (int i = lo + (int)threadIdx.x; i < hi; i += kThreads) acc += part[i];
     return block_sum(acc, red);
 }
+// The same for workgroups of NW wavefronts (the preconditioner uses 8).  `red` >= NW doubles.
+template <int NW>
+__device__ __forceinline__ double block_sum_n(double v, double* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) tot += red[i];
+    return tot;
+}
+template <int NW>
+__device__ __forceinline__ double reduce_partials_n(const double* __restrict__ part, int lo, int hi, double* red) {
+    double acc = 0.0;
+    for (int i = lo + (int)threadIdx.x; i < hi; i += NW * 64) acc += part[i];
+    return block_sum_n<NW>(acc, red);
+}
 
 struct CsrDev {
     const int32_t* ptr;
@@ -142,19 +160,20 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         const int split = (MODE == MODE_DRES) ? a.M.split[r0] : k1;
         for (int kb = k0 + t; kb < k1; kb += kThreads * kLongUnroll) {
             int32_t c[kLongUnroll];
-            double v[kLongUnroll];
+            double v[kLongUnroll], g[kLongUnroll];
 #pragma unroll
             for (int u = 0; u < kLongUnroll; ++u) {
-                const int k = kb + u * kThreads;
-                if (k < k1) { c[u] = col[k]; v[u] = val[k]; }
+                const int k = min(kb + u * kThreads, k1 - 1);
+                c[u] = col[k];
+                v[u] = val[k];
             }
 #pragma unroll
+            for (int u = 0; u < kLongUnroll; ++u) g[u] = gather(c[u]);
+#pragma unroll
             for (int u = 0; u < kLongUnroll; ++u) {
                 const int k = kb + u * kThreads;
-                if (k < k1) {
-                    const double pr = v[u] * gather(c[u]);
-                    if (MODE == MODE_DRES && k >= split) acc2 += pr; else acc += pr;
-                }
+                const double pr = (k < k1) ? v[u] * g[u] : 0.0;
+                if (MODE == MODE_DRES && k >= split) acc2 += pr; else acc += pr;
             }
         }
         sum = block_sum(acc, red);
@@ -162,20 +181,23 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         has_row = (t == 0);
         row = r0;
     } else {
+        // Loads are unconditional on clamped indices (a predicated load becomes a branch
+        // and serialises the memory pipeline); only the LDS stores are predicated.
         int32_t c[kUnroll];
-        double v[kUnroll];
+        double v[kUnroll], g[kUnroll];
+        const int klast = max(nn - 1, 0);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            const int k = t + u * kThreads;
-            if (k < nn) {
-                c[u] = col[k0 + k];
-                v[u] = val[k0 + k];
-            }
+            const int k = min(t + u * kThreads, klast);
+            c[u] = col[k0 + k];
+            v[u] = val[k0 + k];
         }
 #pragma unroll
+        for (int u = 0; u < kUnroll; ++u) g[u] = gather(c[u]);
+#pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const int k = t + u * kThreads;
-            if (k < nn) prod[k] = v[u] * gather(c[u]);
+            if (k < nn) prod[k] = v[u] * g[u];
         }
         __syncthreads();
         if (row < r1) {
@@ -255,14 +277,19 @@ struct PrecArgs {
     const double* rz_in;   // partials of the previous r'z   (STEP)
     const double* pw_part; // partials of p'w                (STEP)
     double* rz_out;        // one partial per work item
+    int debug_skip;        // timing experiments only: 1 run, 2 separator, 4 back-subst, 8 head, 16 tail
 };
 
 enum { PREC_INIT = 0, PREC_STEP = 1 };
 
+constexpr int kPrecThreads = 512;
+constexpr int kPrecWaves = kPrecThreads / 64;
+constexpr int kPrecChunk = 6;  // entries per lane whose loads are issued together
+
 // BS: block size, RMAX: radix - 1 (nodes per run), LDS0: level-0 vector in LDS
 template <int BS, int RMAX, int MODE, bool LDS0>
-__global__ __launch_bounds__(kThreads) void k_prec(PrecArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];  // [0,8): reductions, then vectors
+__global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // [0,16): reductions, then vectors
     double* red = lds;
     const PrecWork wk = a.work[blockIdx.x];
     const int prob = wk.prob;
@@ -270,24 +297,41 @@ __global__ __launch_bounds__(kThreads) void k_prec(PrecArgs a) {
     const int t = threadIdx.x;
     double alpha = 0.0;
     if (MODE == PREC_STEP) {
-        const double rz = reduce_partials(a.rz_in, a.prec_part_ptr[prob], a.prec_part_ptr[prob + 1], red);
-        const double pw = reduce_partials(a.pw_part, a.kblk_part_ptr[prob], a.kblk_part_ptr[prob + 1], red);
+        const double rz = reduce_partials_n<kPrecWaves>(a.rz_in, a.prec_part_ptr[prob], a.prec_part_ptr[prob + 1], red);
+        const double pw = reduce_partials_n<kPrecWaves>(a.pw_part, a.kblk_part_ptr[prob], a.kblk_part_ptr[prob + 1], red);
         alpha = pw > 0.0 ? rz / pw : 0.0;
     }
     double local = 0.0;
     if (wk.kind == 1) {
-        for (int e = wk.index + t; e < wk.index + wk.count; e += kThreads) {
-            const int col = a.diag_cols[e];
-            double rv = a.r[col];
-            if (MODE == PREC_STEP) {
-                a.xt[col] += alpha * a.p[col];
-                rv -= alpha * a.w[col];
-                a.r[col] = rv;
+        // Jacobi columns.  Every load is unconditional on a clamped index so that the
+        // whole chunk is in flight at once; only the stores are predicated.
+        const int e_end = wk.index + wk.count;
+        for (int base = wk.index + t; base < e_end; base += kPrecThreads * kPrecChunk) {
+            int cols[kPrecChunk];
+            double rv[kPrecChunk], dv[kPrecChunk], pv[kPrecChunk], wv[kPrecChunk], xv[kPrecChunk];
+#pragma unroll
+            for (int u = 0; u < kPrecChunk; ++u) cols[u] = a.diag_cols[min(base + u * kPrecThreads, e_end - 1)];
+#pragma unroll
+            for (int u = 0; u < kPrecChunk; ++u) {
+                rv[u] = a.r[cols[u]];
+                dv[u] = a.dinv[min(base + u * kPrecThreads, e_end - 1)];
+                if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt[cols[u]]; }
             }
-            const double zv = rv * a.dinv[e];
-            a.z[col] = zv;
-            if (MODE == PREC_INIT) a.p[col] = zv;
-            local += rv * zv;
+#pragma unroll
+            for (int u = 0; u < kPrecChunk; ++u) {
+                if (base + u * kPrecThreads < e_end) {
+                    double r_ = rv[u];
+                    if (MODE == PREC_STEP) {
+                        a.xt[cols[u]] = xv[u] + alpha * pv[u];
+                        r_ -= alpha * wv[u];
+                        a.r[cols[u]] = r_;
+                    }
+                    const double zv = r_ * dv[u];
+                    a.z[cols[u]] = zv;
+                    if (MODE == PREC_INIT) a.p[cols[u]] = zv;
+                    local += r_ * zv;
+                }
+            }
         }
     } else {
         constexpr int B2 = BS * BS;
@@ -296,32 +340,53 @@ __global__ __launch_bounds__(kThreads) void k_prec(PrecArgs a) {
         const int32_t* __restrict__ nc = a.node_col + ch.node_begin;
         const double* __restrict__ fac = a.fac;
         const int N = ch.N;
-        double* v0 = lds + 8;                                      // level-0 vector (LDS0)
-        double* vup = lds + 8 + (LDS0 ? (size_t)N * BS : (size_t)0);  // levels >= 1
+        const int NB = N * BS;
+        const int stride = ch.col_stride, col0 = ch.col0;
+        // column of a level-0 node: arithmetic for evenly spaced chains, else the index array
+        auto colof = [&](int node) -> int { return stride ? col0 + node * stride : nc[node]; };
+        double* v0 = lds + 16;                                      // level-0 vector (LDS0)
+        double* vup = lds + 16 + (LDS0 ? (size_t)NB : (size_t)0);  // levels >= 1
         // ---- load (and, for STEP, update) the chain's residual ----
-        for (int idx = t; idx < N * BS; idx += kThreads) {
-            const int node = idx / BS;
-            const int col = nc[node] + (idx - node * BS);
-            double rv = a.r[col];
-            if (MODE == PREC_STEP) {
-                a.xt[col] += alpha * a.p[col];
-                rv -= alpha * a.w[col];
-                a.r[col] = rv;
+        for (int base = t; base < NB && !(a.debug_skip & 8); base += kPrecThreads * kPrecChunk) {
+            int cols[kPrecChunk];
+            double rv[kPrecChunk], pv[kPrecChunk], wv[kPrecChunk], xv[kPrecChunk];
+#pragma unroll
+            for (int u = 0; u < kPrecChunk; ++u) {
+                const int idx = min(base + u * kPrecThreads, NB - 1);
+                const int node = idx / BS;
+                cols[u] = colof(node) + (idx - node * BS);
             }
-            if (LDS0) v0[idx] = rv;
+#pragma unroll
+            for (int u = 0; u < kPrecChunk; ++u) {
+                rv[u] = a.r[cols[u]];
+                if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt[cols[u]]; }
+            }
+#pragma unroll
+            for (int u = 0; u < kPrecChunk; ++u) {
+                const int idx = base + u * kPrecThreads;
+                if (idx < NB) {
+                    double r_ = rv[u];
+                    if (MODE == PREC_STEP) {
+                        a.xt[cols[u]] = xv[u] + alpha * pv[u];
+                        r_ -= alpha * wv[u];
+                        a.r[cols[u]] = r_;
+                    }
+                    if (LDS0) v0[idx] = r_;
+                }
+            }
         }
         __syncthreads();
         // level-l vector element (node i, component c): load / store
         auto vld = [&](int l, const ChainLevelDesc& L, int i, int c, bool input) -> double {
             if (l == 0) {
                 if (LDS0) return v0[i * BS + c];
-                return input ? a.r[nc[i] + c] : a.z[nc[i] + c];
+                return input ? a.r[colof(i) + c] : a.z[colof(i) + c];
             }
             return vup[(size_t)(L.vec_off + i) * BS + c];
         };
         auto vst = [&](int l, const ChainLevelDesc& L, int i, int c, double val) {
             if (l == 0) {
-                if (LDS0) v0[i * BS + c] = val; else a.z[nc[i] + c] = val;
+                if (LDS0) v0[i * BS + c] = val; else a.z[colof(i) + c] = val;
             } else {
                 vup[(size_t)(L.vec_off + i) * BS + c] = val;
             }
@@ -331,87 +396,91 @@ __global__ __launch_bounds__(kThreads) void k_prec(PrecArgs a) {
             const bool last = (L.p == 0);
             const int nsep = L.nsep;
             const double* __restrict__ R = fac + L.offR;
-            for (int j = t; j < L.nruns; j += kThreads) {
+            const size_t eP = (size_t)L.P * L.nruns;  // stride between block entries
+            for (int j = t; j < L.nruns && !(a.debug_skip & 1); j += kPrecThreads) {
                 const int lo = last ? 0 : j * L.p;
                 const int hi = last ? L.N : min(j * L.p + L.p - 1, L.N);
-                if (lo >= hi) continue;
+                const int len = hi - lo;
+                if (len <= 0) continue;
                 double Lf[RMAX][B2], Dv[RMAX][B2], y[RMAX][BS];
-                // all factor loads of the run are issued before the recurrence starts
+                // every factor load of the run is issued (unconditionally, on a clamped
+                // position) before the recurrence starts
 #pragma unroll
-                for (int q = 0; q < RMAX; ++q)
-                    if (lo + q < hi) {
+                for (int q = 0; q < RMAX; ++q) {
+                    const int qq = min(q, len - 1);
+                    const double* __restrict__ Rq = R + (size_t)qq * L.nruns + j;
 #pragma unroll
-                        for (int e = 0; e < B2; ++e) {
-                            Lf[q][e] = R[((size_t)(0 * B2 + e) * L.P + q) * L.nruns + j];
-                            Dv[q][e] = R[((size_t)(1 * B2 + e) * L.P + q) * L.nruns + j];
-                        }
-#pragma unroll
-                        for (int c = 0; c < BS; ++c) y[q][c] = vld(l, L, lo + q, c, true);
+                    for (int e = 0; e < B2; ++e) {
+                        Lf[q][e] = Rq[(size_t)e * eP];
+                        Dv[q][e] = Rq[(size_t)(B2 + e) * eP];
                     }
-                // forward substitution
 #pragma unroll
-                for (int q = 1; q < RMAX; ++q)
-                    if (lo + q < hi) {
+                    for (int c = 0; c < BS; ++c) y[q][c] = vld(l, L, lo + qq, c, true);
+                }
+                // forward substitution (positions >= len compute garbage that is never used)
 #pragma unroll
-                        for (int c = 0; c < BS; ++c) {
-                            double s = y[q][c];
+                for (int q = 1; q < RMAX; ++q) {
 #pragma unroll
-                            for (int k = 0; k < BS; ++k) s -= Lf[q][c * BS + k] * y[q - 1][k];
-                            y[q][c] = s;
-                        }
+                    for (int c = 0; c < BS; ++c) {
+                        double s_ = y[q][c];
+#pragma unroll
+                        for (int k = 0; k < BS; ++k) s_ -= Lf[q][c * BS + k] * y[q - 1][k];
+                        y[q][c] = s_;
                     }
+                }
                 // diagonal solve + backward substitution
 #pragma unroll
-                for (int q = RMAX - 1; q >= 0; --q)
-                    if (lo + q < hi) {
-                        double tmp[BS];
+                for (int q = RMAX - 1; q >= 0; --q) {
+                    double tmp[BS];
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) {
+                        double s_ = 0.0;
+#pragma unroll
+                        for (int k = 0; k < BS; ++k) s_ += Dv[q][c * BS + k] * y[q][k];
+                        tmp[c] = s_;
+                    }
+                    if (q + 1 < RMAX) {
+                        const bool has_next = (q + 1 < len);
 #pragma unroll
                         for (int c = 0; c < BS; ++c) {
-                            double s = 0.0;
+                            double s_ = 0.0;
 #pragma unroll
-                            for (int k = 0; k < BS; ++k) s += Dv[q][c * BS + k] * y[q][k];
-                            tmp[c] = s;
-                        }
-                        if (q + 1 < RMAX) {
-                            if (lo + q + 1 < hi) {
-#pragma unroll
-                                for (int c = 0; c < BS; ++c) {
-                                    double s = tmp[c];
-#pragma unroll
-                                    for (int k = 0; k < BS; ++k) s -= Lf[q + 1][k * BS + c] * y[q + 1][k];
-                                    tmp[c] = s;
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int c = 0; c < BS; ++c) {
-                            y[q][c] = tmp[c];
-                            vst(l, L, lo + q, c, tmp[c]);
+                            for (int k = 0; k < BS; ++k) s_ += Lf[q + 1][k * BS + c] * y[q + 1][k];
+                            tmp[c] = has_next ? tmp[c] - s_ : tmp[c];
                         }
                     }
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) y[q][c] = tmp[c];
+                    if (q < len) {
+#pragma unroll
+                        for (int c = 0; c < BS; ++c) vst(l, L, lo + q, c, tmp[c]);
+                    }
+                }
             }
             __syncthreads();
             if (last) break;
             const ChainLevelDesc Ln = lv[l + 1];
             const double* __restrict__ S = fac + L.offS;
-            for (int j = t; j < nsep; j += kThreads) {
+            for (int j = t; j < nsep && !(a.debug_skip & 2); j += kPrecThreads) {
                 const int s = j * L.p + L.p - 1;
-                double v[BS], ym[BS], yp[BS];
-                const bool has_right = (s + 1 < L.N);
+                double Cl[B2], Cr[B2], v[BS], ym[BS], yp[BS];
+                const int sr = min(s + 1, L.N - 1);  // Cr is zero when there is no right run
+#pragma unroll
+                for (int e = 0; e < B2; ++e) {
+                    Cl[e] = S[(size_t)e * nsep + j];
+                    Cr[e] = S[(size_t)(B2 + e) * nsep + j];
+                }
 #pragma unroll
                 for (int c = 0; c < BS; ++c) {
                     v[c] = vld(l, L, s, c, true);
                     ym[c] = vld(l, L, s - 1, c, false);
-                    yp[c] = has_right ? vld(l, L, s + 1, c, false) : 0.0;
+                    yp[c] = vld(l, L, sr, c, false);
                 }
 #pragma unroll
                 for (int c = 0; c < BS; ++c) {
                     double acc = v[c];
 #pragma unroll
-                    for (int k = 0; k < BS; ++k) {
-                        acc -= S[(size_t)(0 * B2 + c * BS + k) * nsep + j] * ym[k];
-                        acc -= S[(size_t)(1 * B2 + c * BS + k) * nsep + j] * yp[k];  // Cr = 0 without a right run
-                    }
+                    for (int k = 0; k < BS; ++k) acc -= Cl[c * BS + k] * ym[k] + Cr[c * BS + k] * yp[k];
                     vup[(size_t)(Ln.vec_off + j) * BS + c] = acc;
                 }
             }
@@ -423,48 +492,62 @@ __global__ __launch_bounds__(kThreads) void k_prec(PrecArgs a) {
             const ChainLevelDesc Ln = lv[l + 1];
             const int nsep = L.nsep;
             const double* __restrict__ Bk = fac + L.offB;
-            for (int i = t; i < L.N; i += kThreads) {
+            for (int i = t; i < L.N && !(a.debug_skip & 4); i += kPrecThreads) {
                 const int j = i / L.p;
-                double v[BS];
                 const bool is_sep = (i - j * L.p == L.p - 1) && (j < nsep);
-                if (is_sep) {
+                // V is zero without a left separator, W without a right one: clamp and load
+                const int jl = max(j - 1, 0), jr = min(j, max(nsep - 1, 0));
+                double V[B2], W[B2], v[BS], ul[BS], ur[BS];
 #pragma unroll
-                    for (int c = 0; c < BS; ++c) v[c] = vup[(size_t)(Ln.vec_off + j) * BS + c];
-                } else {
-                    double ul[BS], ur[BS];
-#pragma unroll
-                    for (int c = 0; c < BS; ++c) {
-                        v[c] = vld(l, L, i, c, false);
-                        ul[c] = (j >= 1) ? vup[(size_t)(Ln.vec_off + j - 1) * BS + c] : 0.0;
-                        ur[c] = (j < nsep) ? vup[(size_t)(Ln.vec_off + j) * BS + c] : 0.0;
-                    }
-#pragma unroll
-                    for (int c = 0; c < BS; ++c) {
-                        double acc = v[c];
-#pragma unroll
-                        for (int k = 0; k < BS; ++k) {
-                            acc -= Bk[(size_t)(0 * B2 + c * BS + k) * L.N + i] * ul[k];  // V = 0 without a left separator
-                            acc -= Bk[(size_t)(1 * B2 + c * BS + k) * L.N + i] * ur[k];
-                        }
-                        v[c] = acc;
-                    }
+                for (int e = 0; e < B2; ++e) {
+                    V[e] = Bk[(size_t)e * L.N + i];
+                    W[e] = Bk[(size_t)(B2 + e) * L.N + i];
                 }
 #pragma unroll
-                for (int c = 0; c < BS; ++c) vst(l, L, i, c, v[c]);
+                for (int c = 0; c < BS; ++c) {
+                    v[c] = vld(l, L, i, c, false);
+                    ul[c] = vup[(size_t)(Ln.vec_off + jl) * BS + c];
+                    ur[c] = vup[(size_t)(Ln.vec_off + jr) * BS + c];
+                }
+#pragma unroll
+                for (int c = 0; c < BS; ++c) {
+                    double acc = v[c];
+#pragma unroll
+                    for (int k = 0; k < BS; ++k) acc -= V[c * BS + k] * ul[k] + W[c * BS + k] * ur[k];
+                    // a separator takes the coarse solution (== ur when j < nsep)
+                    vst(l, L, i, c, is_sep ? ur[c] : acc);
+                }
             }
             __syncthreads();
         }
         // ---- write z (LDS0), p (INIT) and accumulate r'z ----
-        for (int idx = t; idx < N * BS; idx += kThreads) {
-            const int node = idx / BS;
-            const int col = nc[node] + (idx - node * BS);
-            double zv;
-            if (LDS0) { zv = v0[idx]; a.z[col] = zv; } else { zv = a.z[col]; }
-            if (MODE == PREC_INIT) a.p[col] = zv;
-            local += a.r[col] * zv;
+        for (int base = t; base < NB && !(a.debug_skip & 16); base += kPrecThreads * kPrecChunk) {
+            int cols[kPrecChunk];
+            double rv[kPrecChunk], zz[kPrecChunk];
+#pragma unroll
+            for (int u = 0; u < kPrecChunk; ++u) {
+                const int idx = min(base + u * kPrecThreads, NB - 1);
+                const int node = idx / BS;
+                cols[u] = colof(node) + (idx - node * BS);
+            }
+#pragma unroll
+            for (int u = 0; u < kPrecChunk; ++u) {
+                const int idx = min(base + u * kPrecThreads, NB - 1);
+                rv[u] = a.r[cols[u]];
+                zz[u] = LDS0 ? v0[idx] : a.z[cols[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < kPrecChunk; ++u) {
+                const int idx = base + u * kPrecThreads;
+                if (idx < NB) {
+                    if (LDS0) a.z[cols[u]] = zz[u];
+                    if (MODE == PREC_INIT) a.p[cols[u]] = zz[u];
+                    local += rv[u] * zz[u];
+                }
+            }
         }
     }
-    const double tot = block_sum(local, red);
+    const double tot = block_sum_n<kPrecWaves>(local, red);
     if (t == 0) a.rz_out[blockIdx.x] = tot;
 }
 

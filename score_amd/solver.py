@@ -65,7 +65,7 @@ STATUS_NAMES = {0: "unsolved", 1: "solved", 2: "max_iters", 3: "numerical"}
 # every symbol include/score_hip.h declares
 ABI_SYMBOLS = [
     "score_default_settings", "score_create", "score_create_batch", "score_dims", "score_solve",
-    "score_reset", "score_solve_steps", "score_time_kkt_apply", "score_debug_get", "score_destroy",
+    "score_reset", "score_solve_steps", "score_time_kkt_apply", "score_debug_time", "score_debug_get", "score_destroy",
     "score_last_error", "score_backend",
 ]
 
@@ -87,6 +87,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.score_reset.argtypes = [C.c_void_p]
     lib.score_solve_steps.argtypes = [C.c_void_p, C.c_int32, _f64p, _f64p, _f64p, C.POINTER(ScoreInfo)]
     lib.score_time_kkt_apply.argtypes = [C.c_void_p, C.c_int32, _f64p, _f64p]
+    lib.score_debug_time.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, _f64p]
     lib.score_debug_get.argtypes = [C.c_void_p, C.c_char_p, _f64p, C.c_int64]
     lib.score_debug_get.restype = C.c_int64
     lib.score_destroy.argtypes = [C.c_void_p]
@@ -214,6 +215,12 @@ class ConicSolver:
         if self.lib.score_time_kkt_apply(self._h, int(reps), C.byref(ms), C.byref(by)) != 0:
             raise RuntimeError(self.lib.score_last_error().decode())
         return ms.value, by.value
+
+    def debug_time(self, kernel: str, reps: int = 200) -> float:
+        ms = C.c_double()
+        if self.lib.score_debug_time(self._h, kernel.encode(), int(reps), C.byref(ms)) != 0:
+            raise RuntimeError(self.lib.score_last_error().decode())
+        return ms.value
 
     def debug_get(self, name: str) -> np.ndarray:
         sz = self.lib.score_debug_get(self._h, name.encode(), None, 0)
