@@ -53,6 +53,19 @@ def make_workload(args, rank: int):
     return models
 
 
+def pmc_traffic(n: int, nnz_p: int):
+    """HBM bytes per launch of the KKT SpMV from the committed PMC run
+    (profiles/kkt_traffic.json: separate --pmc FETCH_SIZE / WRITE_SIZE passes,
+    gfx950 FETCH correction applied) -- only when it was taken on this workload."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "kkt_traffic.json")))
+        if rec["workload"]["n"] == n and rec["workload"]["nnz_P"] == nnz_p:
+            return float(rec["traffic_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(args, models):
     """The oracle's CPU twin (same algorithm, OpenMP loops) on a bounded sample of
     the same workload: a fixed number of cold-start ADMM iterations."""
@@ -172,7 +185,8 @@ def main():
             "admm_iters_per_solve": tot[0] / max(1.0, tot[1]), "pcg_iters_per_admm_iter": tot[3] / max(1.0, tot[0]),
             "final": {"pobj": info["pobj"], "res_pri": info["res_pri"], "res_dual": info["res_dual"], "rho": info["rho"]},
             "roofline": {"bound": "hbm", "kernel": "k_spmv<KP> (w = K p, KKT operator)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": pmc_traffic(int(models[0].qp.n), int(models[0].qp.P.nnz)) if args.batch == 1 else None,
                          "bytes_per_launch": kkt_bytes, "us_per_launch": kkt_ms * 1e3},
         }
         if world == 1 and not args.no_cpu_baseline:

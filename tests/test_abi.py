@@ -61,3 +61,19 @@ def test_product_package_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src, f
+
+
+def test_score_import_shim_matches_reference_paths():
+    """`from score.solve_score import solve_score` etc. keep working (drop-in)."""
+    from score.solve_score import solve_problem_with_intermediate_iterates, solve_score  # noqa: F401
+    from score.utils.gurobi_utils import ACCEPTABLE_RELAXATIONS, QCQP_RELAXATION, SOCP_RELAXATION
+    from score.utils.matrix_utils import round_to_special_orthogonal  # noqa: F401
+    from score.utils.solver_utils import ScoreSolverParams
+
+    assert (SOCP_RELAXATION, QCQP_RELAXATION) == ("SOCP", "QCQP") and len(ACCEPTABLE_RELAXATIONS) == 2
+    assert ScoreSolverParams(solver="gurobi", verbose=True, save_results=True, init_technique="none",
+                             custom_init_file=None).init_technique == "none"
+    import inspect
+
+    sig = inspect.signature(solve_score)
+    assert list(sig.parameters)[0] == "data" and sig.parameters["relaxation_type"].default == "QCQP"
