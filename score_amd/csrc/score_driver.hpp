@@ -48,7 +48,7 @@ struct Solver {
         if (st.cg_iters < 1) st.cg_iters = 1;
         if (st.adaptive_rho_interval < st.check_interval) st.adaptive_rho_interval = st.check_interval;
         if (st.max_cg_iters < st.cg_iters) st.max_cg_iters = st.cg_iters;
-        if (!(st.cg_target > 0.0 && st.cg_target < 1.0)) st.cg_target = 0.3;
+        if (!(st.cg_target > 0.0 && st.cg_target < 1.0)) st.cg_target = 0.5;
         cg_now = st.cg_iters;
         build_system(probs, count, st, H);
         be.init(H, st);
@@ -221,7 +221,7 @@ inline void default_settings(score_settings* s) {
     s->cg_iters = 2;
     s->adaptive_cg = 1;
     s->max_cg_iters = 64;
-    s->cg_target = 0.3;
+    s->cg_target = 0.5;
     s->adaptive_rho = 1;
     s->adaptive_rho_interval = 100;
     s->adaptive_rho_tol = 5.0;

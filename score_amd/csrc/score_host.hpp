@@ -772,6 +772,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         factor_chain_levels(bs, H.radix, ch.N, Ad, Bs, lv, fac, scr);
         ch.level_begin = (int32_t)H.levels.size();
         ch.n_levels = (int32_t)lv.size();
+        if (ch.n_levels > 20) throw std::runtime_error("chain too long: more than 20 partition levels");
         const int64_t dbl_base = (int64_t)H.fac.size();
         for (auto& L : lv) {
             L.offR += dbl_base;

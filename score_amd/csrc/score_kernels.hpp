@@ -284,25 +284,63 @@ enum { PREC_INIT = 0, PREC_STEP = 1 };
 
 constexpr int kPrecThreads = 512;
 constexpr int kPrecWaves = kPrecThreads / 64;
-constexpr int kPrecChunk = 6;  // entries per lane whose loads are issued together
+constexpr int kPrecChunk = 6;   // entries per lane whose loads are issued together
+constexpr int kMaxLevels = 20;  // radix 2 .. 4: chains of up to 2^20 nodes (the host checks)
 
-// BS: block size, RMAX: radix - 1 (nodes per run), LDS0: level-0 vector in LDS
+// Factor blocks of one run (thread j of level L): all loads unconditional on a
+// clamped position so that they are issued back to back.
+template <int BS, int RMAX>
+__device__ __forceinline__ void load_run(const double* __restrict__ fac, const ChainLevelDesc& L, int j,
+                                         double (&Lf)[RMAX][BS * BS], double (&Dv)[RMAX][BS * BS]) {
+    constexpr int B2 = BS * BS;
+    const bool last = (L.p == 0);
+    const int lo = last ? 0 : j * L.p;
+    const int hi = last ? L.N : min(j * L.p + L.p - 1, L.N);
+    const int len = max(hi - lo, 1);
+    const size_t eP = (size_t)L.P * L.nruns;
+    const double* __restrict__ R = fac + L.offR;
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+        const double* __restrict__ Rq = R + (size_t)min(q, len - 1) * L.nruns + j;
+#pragma unroll
+        for (int e = 0; e < B2; ++e) {
+            Lf[q][e] = Rq[(size_t)e * eP];
+            Dv[q][e] = Rq[(size_t)(B2 + e) * eP];
+        }
+    }
+}
+
+// BS: block size, RMAX: radix - 1 (nodes per run), LDS0: level-0 vector in LDS.
+// Phases of one level: (run) every run of <= RMAX nodes is solved by one lane;
+// (sep) reduced right-hand sides of the separators go to the next level;
+// afterwards (back) the levels are back-substituted coarse to fine.  The factor
+// blocks of a phase never depend on vector data, so they are requested BEFORE the
+// barrier that ends the previous phase and arrive while it drains.
 template <int BS, int RMAX, int MODE, bool LDS0>
 __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];  // [0,16): reductions, then vectors
+    extern __shared__ __attribute__((aligned(16))) double lds[];  // [0,16) reductions, [16,16+6*kMaxLevels) level table, vectors
+    __shared__ ChainLevelDesc sLv[kMaxLevels];
     double* red = lds;
     const PrecWork wk = a.work[blockIdx.x];
     const int prob = wk.prob;
     if (a.done[prob]) return;
     const int t = threadIdx.x;
-    double alpha = 0.0;
+    // partial sums for alpha = r'z / p'w: loads first, reduction after the phase-0 loads are out
+    double acc_rz = 0.0, acc_pw = 0.0;
     if (MODE == PREC_STEP) {
-        const double rz = reduce_partials_n<kPrecWaves>(a.rz_in, a.prec_part_ptr[prob], a.prec_part_ptr[prob + 1], red);
-        const double pw = reduce_partials_n<kPrecWaves>(a.pw_part, a.kblk_part_ptr[prob], a.kblk_part_ptr[prob + 1], red);
-        alpha = pw > 0.0 ? rz / pw : 0.0;
+        const int l0 = a.prec_part_ptr[prob], l1 = a.prec_part_ptr[prob + 1];
+        const int k0 = a.kblk_part_ptr[prob], k1 = a.kblk_part_ptr[prob + 1];
+        for (int i = l0 + t; i < l1; i += kPrecThreads) acc_rz += a.rz_in[i];
+        for (int i = k0 + t; i < k1; i += kPrecThreads) acc_pw += a.pw_part[i];
     }
+    double alpha = 0.0;
     double local = 0.0;
     if (wk.kind == 1) {
+        if (MODE == PREC_STEP) {
+            const double rz = block_sum_n<kPrecWaves>(acc_rz, red);
+            const double pw = block_sum_n<kPrecWaves>(acc_pw, red);
+            alpha = pw > 0.0 ? rz / pw : 0.0;
+        }
         // Jacobi columns.  Every load is unconditional on a clamped index so that the
         // whole chunk is in flight at once; only the stores are predicated.
         const int e_end = wk.index + wk.count;
@@ -341,182 +379,246 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
         const double* __restrict__ fac = a.fac;
         const int N = ch.N;
         const int NB = N * BS;
+        const int nl = ch.n_levels;
         const int stride = ch.col_stride, col0 = ch.col0;
-        // column of a level-0 node: arithmetic for evenly spaced chains, else the index array
         auto colof = [&](int node) -> int { return stride ? col0 + node * stride : nc[node]; };
         double* v0 = lds + 16;                                      // level-0 vector (LDS0)
         double* vup = lds + 16 + (LDS0 ? (size_t)NB : (size_t)0);  // levels >= 1
-        // ---- load (and, for STEP, update) the chain's residual ----
-        for (int base = t; base < NB && !(a.debug_skip & 8); base += kPrecThreads * kPrecChunk) {
+        // level table -> LDS (read by every phase; one batch of loads instead of one per level)
+        if (t < nl) sLv[t] = lv[t];
+        ChainLevelDesc L = lv[0];
+        // level-0 run factors requested before anything else is waited for
+        double Lf[RMAX][B2], Dv[RMAX][B2];
+        const bool wave_has_run0 = ((t & ~63) < L.nruns);
+        if (wave_has_run0) load_run<BS, RMAX>(fac, L, min(t, L.nruns - 1), Lf, Dv);
+        // ---- residual: loads of the first chunk out, then alpha (uniform code, every
+        //      lane joins the reduction), then the update; further chunks only for long chains
+        {
             int cols[kPrecChunk];
             double rv[kPrecChunk], pv[kPrecChunk], wv[kPrecChunk], xv[kPrecChunk];
+            auto chunk_load = [&](int base) {
 #pragma unroll
-            for (int u = 0; u < kPrecChunk; ++u) {
-                const int idx = min(base + u * kPrecThreads, NB - 1);
-                const int node = idx / BS;
-                cols[u] = colof(node) + (idx - node * BS);
-            }
-#pragma unroll
-            for (int u = 0; u < kPrecChunk; ++u) {
-                rv[u] = a.r[cols[u]];
-                if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt[cols[u]]; }
-            }
-#pragma unroll
-            for (int u = 0; u < kPrecChunk; ++u) {
-                const int idx = base + u * kPrecThreads;
-                if (idx < NB) {
-                    double r_ = rv[u];
-                    if (MODE == PREC_STEP) {
-                        a.xt[cols[u]] = xv[u] + alpha * pv[u];
-                        r_ -= alpha * wv[u];
-                        a.r[cols[u]] = r_;
-                    }
-                    if (LDS0) v0[idx] = r_;
+                for (int u = 0; u < kPrecChunk; ++u) {
+                    const int idx = min(base + u * kPrecThreads, NB - 1);
+                    const int node = idx / BS;
+                    cols[u] = colof(node) + (idx - node * BS);
                 }
+#pragma unroll
+                for (int u = 0; u < kPrecChunk; ++u) {
+                    rv[u] = a.r[cols[u]];
+                    if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt[cols[u]]; }
+                }
+            };
+            auto chunk_apply = [&](int base) {
+#pragma unroll
+                for (int u = 0; u < kPrecChunk; ++u) {
+                    const int idx = base + u * kPrecThreads;
+                    if (idx < NB) {
+                        double r_ = rv[u];
+                        if (MODE == PREC_STEP) {
+                            a.xt[cols[u]] = xv[u] + alpha * pv[u];
+                            r_ -= alpha * wv[u];
+                            a.r[cols[u]] = r_;
+                        }
+                        if (LDS0) v0[idx] = r_;
+                    }
+                }
+            };
+            chunk_load(t);
+            if (MODE == PREC_STEP) {
+                const double rz = block_sum_n<kPrecWaves>(acc_rz, red);
+                const double pw = block_sum_n<kPrecWaves>(acc_pw, red);
+                alpha = pw > 0.0 ? rz / pw : 0.0;
+            }
+            chunk_apply(t);
+            for (int base = t + kPrecThreads * kPrecChunk; base < NB; base += kPrecThreads * kPrecChunk) {
+                chunk_load(base);
+                chunk_apply(base);
             }
         }
         __syncthreads();
-        // level-l vector element (node i, component c): load / store
-        auto vld = [&](int l, const ChainLevelDesc& L, int i, int c, bool input) -> double {
+        auto vld = [&](int l, const ChainLevelDesc& Lx, int i, int c, bool input) -> double {
             if (l == 0) {
                 if (LDS0) return v0[i * BS + c];
                 return input ? a.r[colof(i) + c] : a.z[colof(i) + c];
             }
-            return vup[(size_t)(L.vec_off + i) * BS + c];
+            return vup[(size_t)(Lx.vec_off + i) * BS + c];
         };
-        auto vst = [&](int l, const ChainLevelDesc& L, int i, int c, double val) {
+        auto vst = [&](int l, const ChainLevelDesc& Lx, int i, int c, double val) {
             if (l == 0) {
                 if (LDS0) v0[i * BS + c] = val; else a.z[colof(i) + c] = val;
             } else {
-                vup[(size_t)(L.vec_off + i) * BS + c] = val;
+                vup[(size_t)(Lx.vec_off + i) * BS + c] = val;
             }
         };
-        for (int l = 0; l < ch.n_levels; ++l) {
-            const ChainLevelDesc L = lv[l];
-            const bool last = (L.p == 0);
-            const int nsep = L.nsep;
-            const double* __restrict__ R = fac + L.offR;
-            const size_t eP = (size_t)L.P * L.nruns;  // stride between block entries
-            for (int j = t; j < L.nruns && !(a.debug_skip & 1); j += kPrecThreads) {
-                const int lo = last ? 0 : j * L.p;
-                const int hi = last ? L.N : min(j * L.p + L.p - 1, L.N);
-                const int len = hi - lo;
-                if (len <= 0) continue;
-                double Lf[RMAX][B2], Dv[RMAX][B2], y[RMAX][BS];
-                // every factor load of the run is issued (unconditionally, on a clamped
-                // position) before the recurrence starts
+        // solves run j of level l with the blocks in (Lf, Dv)
+        auto run_compute = [&](int l, const ChainLevelDesc& Lx, int j, const double (&Lfx)[RMAX][B2],
+                               const double (&Dvx)[RMAX][B2]) {
+            const bool last = (Lx.p == 0);
+            const int lo = last ? 0 : j * Lx.p;
+            const int hi = last ? Lx.N : min(j * Lx.p + Lx.p - 1, Lx.N);
+            const int len = hi - lo;
+            if (len <= 0) return;
+            double y[RMAX][BS];
 #pragma unroll
-                for (int q = 0; q < RMAX; ++q) {
-                    const int qq = min(q, len - 1);
-                    const double* __restrict__ Rq = R + (size_t)qq * L.nruns + j;
+            for (int q = 0; q < RMAX; ++q) {
+                const int qq = min(q, len - 1);
 #pragma unroll
-                    for (int e = 0; e < B2; ++e) {
-                        Lf[q][e] = Rq[(size_t)e * eP];
-                        Dv[q][e] = Rq[(size_t)(B2 + e) * eP];
-                    }
+                for (int c = 0; c < BS; ++c) y[q][c] = vld(l, Lx, lo + qq, c, true);
+            }
 #pragma unroll
-                    for (int c = 0; c < BS; ++c) y[q][c] = vld(l, L, lo + qq, c, true);
+            for (int q = 1; q < RMAX; ++q) {
+#pragma unroll
+                for (int c = 0; c < BS; ++c) {
+                    double s_ = y[q][c];
+#pragma unroll
+                    for (int k = 0; k < BS; ++k) s_ -= Lfx[q][c * BS + k] * y[q - 1][k];
+                    y[q][c] = s_;
                 }
-                // forward substitution (positions >= len compute garbage that is never used)
+            }
 #pragma unroll
-                for (int q = 1; q < RMAX; ++q) {
+            for (int q = RMAX - 1; q >= 0; --q) {
+                double tmp[BS];
 #pragma unroll
-                    for (int c = 0; c < BS; ++c) {
-                        double s_ = y[q][c];
+                for (int c = 0; c < BS; ++c) {
+                    double s_ = 0.0;
 #pragma unroll
-                        for (int k = 0; k < BS; ++k) s_ -= Lf[q][c * BS + k] * y[q - 1][k];
-                        y[q][c] = s_;
-                    }
+                    for (int k = 0; k < BS; ++k) s_ += Dvx[q][c * BS + k] * y[q][k];
+                    tmp[c] = s_;
                 }
-                // diagonal solve + backward substitution
-#pragma unroll
-                for (int q = RMAX - 1; q >= 0; --q) {
-                    double tmp[BS];
+                if (q + 1 < RMAX) {
+                    const bool has_next = (q + 1 < len);
 #pragma unroll
                     for (int c = 0; c < BS; ++c) {
                         double s_ = 0.0;
 #pragma unroll
-                        for (int k = 0; k < BS; ++k) s_ += Dv[q][c * BS + k] * y[q][k];
-                        tmp[c] = s_;
-                    }
-                    if (q + 1 < RMAX) {
-                        const bool has_next = (q + 1 < len);
-#pragma unroll
-                        for (int c = 0; c < BS; ++c) {
-                            double s_ = 0.0;
-#pragma unroll
-                            for (int k = 0; k < BS; ++k) s_ += Lf[q + 1][k * BS + c] * y[q + 1][k];
-                            tmp[c] = has_next ? tmp[c] - s_ : tmp[c];
-                        }
-                    }
-#pragma unroll
-                    for (int c = 0; c < BS; ++c) y[q][c] = tmp[c];
-                    if (q < len) {
-#pragma unroll
-                        for (int c = 0; c < BS; ++c) vst(l, L, lo + q, c, tmp[c]);
+                        for (int k = 0; k < BS; ++k) s_ += Lfx[q + 1][k * BS + c] * y[q + 1][k];
+                        tmp[c] = has_next ? tmp[c] - s_ : tmp[c];
                     }
                 }
+#pragma unroll
+                for (int c = 0; c < BS; ++c) y[q][c] = tmp[c];
+                if (q < len) {
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) vst(l, Lx, lo + q, c, tmp[c]);
+                }
             }
-            __syncthreads();
-            if (last) break;
-            const ChainLevelDesc Ln = lv[l + 1];
-            const double* __restrict__ S = fac + L.offS;
-            for (int j = t; j < nsep && !(a.debug_skip & 2); j += kPrecThreads) {
-                const int s = j * L.p + L.p - 1;
-                double Cl[B2], Cr[B2], v[BS], ym[BS], yp[BS];
-                const int sr = min(s + 1, L.N - 1);  // Cr is zero when there is no right run
+        };
+        for (int l = 0; l < nl; ++l) {
+            const bool last = (L.p == 0);
+            const int nsep = L.nsep;
+            // separator blocks of this level: requested now, used after the barrier
+            double Cl[B2], Cr[B2];
+            constexpr bool kPrefetchSep = (BS <= 3);  // 4x4 blocks: the register file is full already
+            const bool wave_has_sep = kPrefetchSep && !last && ((t & ~63) < nsep);
+            if (wave_has_sep) {
+                const double* __restrict__ S = fac + L.offS;
+                const int j = min(t, nsep - 1);
 #pragma unroll
                 for (int e = 0; e < B2; ++e) {
                     Cl[e] = S[(size_t)e * nsep + j];
                     Cr[e] = S[(size_t)(B2 + e) * nsep + j];
                 }
-#pragma unroll
-                for (int c = 0; c < BS; ++c) {
-                    v[c] = vld(l, L, s, c, true);
-                    ym[c] = vld(l, L, s - 1, c, false);
-                    yp[c] = vld(l, L, sr, c, false);
-                }
-#pragma unroll
-                for (int c = 0; c < BS; ++c) {
-                    double acc = v[c];
-#pragma unroll
-                    for (int k = 0; k < BS; ++k) acc -= Cl[c * BS + k] * ym[k] + Cr[c * BS + k] * yp[k];
-                    vup[(size_t)(Ln.vec_off + j) * BS + c] = acc;
+            }
+            // ---- run phase ----
+            if (!(a.debug_skip & 1)) {
+                for (int j = t; j < L.nruns; j += kPrecThreads) {
+                    if (j != t) load_run<BS, RMAX>(fac, L, j, Lf, Dv);  // long chains only: not prefetched
+                    run_compute(l, L, j, Lf, Dv);
                 }
             }
             __syncthreads();
+            if (last) break;
+            const ChainLevelDesc Ln = sLv[l + 1];
+            // next level's run blocks: requested before the separator arithmetic
+            if ((t & ~63) < Ln.nruns) load_run<BS, RMAX>(fac, Ln, min(t, Ln.nruns - 1), Lf, Dv);
+            // ---- separator phase ----
+            if (!(a.debug_skip & 2)) {
+                for (int j = t; j < nsep; j += kPrecThreads) {
+                    if (j >= kPrecThreads || !kPrefetchSep) {  // not prefetched
+                        const double* __restrict__ S = fac + L.offS;
+#pragma unroll
+                        for (int e = 0; e < B2; ++e) {
+                            Cl[e] = S[(size_t)e * nsep + j];
+                            Cr[e] = S[(size_t)(B2 + e) * nsep + j];
+                        }
+                    }
+                    const int s = j * L.p + L.p - 1;
+                    const int sr = min(s + 1, L.N - 1);  // Cr is zero when there is no right run
+                    double v[BS], ym[BS], yp[BS];
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) {
+                        v[c] = vld(l, L, s, c, true);
+                        ym[c] = vld(l, L, s - 1, c, false);
+                        yp[c] = vld(l, L, sr, c, false);
+                    }
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) {
+                        double acc = v[c];
+#pragma unroll
+                        for (int k = 0; k < BS; ++k) acc -= Cl[c * BS + k] * ym[k] + Cr[c * BS + k] * yp[k];
+                        vup[(size_t)(Ln.vec_off + j) * BS + c] = acc;
+                    }
+                }
+            }
+            __syncthreads();
+            L = Ln;
         }
-        // ---- back-substitution, coarse to fine ----
-        for (int l = ch.n_levels - 2; l >= 0; --l) {
-            const ChainLevelDesc L = lv[l];
-            const ChainLevelDesc Ln = lv[l + 1];
-            const int nsep = L.nsep;
-            const double* __restrict__ Bk = fac + L.offB;
-            for (int i = t; i < L.N && !(a.debug_skip & 4); i += kPrecThreads) {
-                const int j = i / L.p;
-                const bool is_sep = (i - j * L.p == L.p - 1) && (j < nsep);
-                // V is zero without a left separator, W without a right one: clamp and load
-                const int jl = max(j - 1, 0), jr = min(j, max(nsep - 1, 0));
-                double V[B2], W[B2], v[BS], ul[BS], ur[BS];
+        // ---- back-substitution, coarse to fine; spikes of the next batch are requested
+        //      before the barrier of the current one ----
+        double V[B2], W[B2];
+        auto load_spikes = [&](const ChainLevelDesc& Lx, int i) {
+            const double* __restrict__ Bk = fac + Lx.offB;
 #pragma unroll
-                for (int e = 0; e < B2; ++e) {
-                    V[e] = Bk[(size_t)e * L.N + i];
-                    W[e] = Bk[(size_t)(B2 + e) * L.N + i];
+            for (int e = 0; e < B2; ++e) {
+                V[e] = Bk[(size_t)e * Lx.N + i];
+                W[e] = Bk[(size_t)(B2 + e) * Lx.N + i];
+            }
+        };
+        bool have_spikes = false;  // V/W hold this lane's spikes of the level about to be processed
+        if (nl >= 2) {
+            const ChainLevelDesc Lb = sLv[nl - 2];
+            if ((t & ~63) < Lb.N) load_spikes(Lb, min(t, Lb.N - 1));
+            have_spikes = true;
+        }
+        for (int l = nl - 2; l >= 0; --l) {
+            const ChainLevelDesc Lb = sLv[l];
+            const ChainLevelDesc Ln = sLv[l + 1];
+            const int nsep = Lb.nsep;
+            const bool single_batch = (Lb.N <= kPrecThreads);
+            if (!(a.debug_skip & 4)) {
+                for (int i = t; i < Lb.N; i += kPrecThreads) {
+                    if (i >= kPrecThreads || !have_spikes) load_spikes(Lb, i);
+                    const int j = i / Lb.p;
+                    const bool is_sep = (i - j * Lb.p == Lb.p - 1) && (j < nsep);
+                    // V is zero without a left separator, W without a right one: clamp and use
+                    const int jl = max(j - 1, 0), jr = min(j, max(nsep - 1, 0));
+                    double v[BS], ul[BS], ur[BS];
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) {
+                        v[c] = vld(l, Lb, i, c, false);
+                        ul[c] = vup[(size_t)(Ln.vec_off + jl) * BS + c];
+                        ur[c] = vup[(size_t)(Ln.vec_off + jr) * BS + c];
+                    }
+                    double outv[BS];
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) {
+                        double acc = v[c];
+#pragma unroll
+                        for (int k = 0; k < BS; ++k) acc -= V[c * BS + k] * ul[k] + W[c * BS + k] * ur[k];
+                        outv[c] = is_sep ? ur[c] : acc;  // a separator takes the coarse solution
+                    }
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) vst(l, Lb, i, c, outv[c]);
                 }
-#pragma unroll
-                for (int c = 0; c < BS; ++c) {
-                    v[c] = vld(l, L, i, c, false);
-                    ul[c] = vup[(size_t)(Ln.vec_off + jl) * BS + c];
-                    ur[c] = vup[(size_t)(Ln.vec_off + jr) * BS + c];
-                }
-#pragma unroll
-                for (int c = 0; c < BS; ++c) {
-                    double acc = v[c];
-#pragma unroll
-                    for (int k = 0; k < BS; ++k) acc -= V[c * BS + k] * ul[k] + W[c * BS + k] * ur[k];
-                    // a separator takes the coarse solution (== ur when j < nsep)
-                    vst(l, L, i, c, is_sep ? ur[c] : acc);
-                }
+            }
+            // this lane's spikes of the finer level are requested before the barrier; valid only
+            // if this level was a single batch (otherwise V/W were reused above)
+            have_spikes = false;
+            if (l > 0 && single_batch) {
+                const ChainLevelDesc Lf_ = sLv[l - 1];
+                if ((t & ~63) < Lf_.N) load_spikes(Lf_, min(t, Lf_.N - 1));
+                have_spikes = true;
             }
             __syncthreads();
         }
