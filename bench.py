@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--kkt-reps", type=int, default=2000)
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even for one rank (testing)")
     return ap.parse_args()
 
 
@@ -130,7 +131,10 @@ def main():
     import torch
     import torch.distributed as dist
 
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
     from score_amd.solver import ConicSolver
@@ -140,7 +144,7 @@ def main():
     assert solver.backend == "hip-gfx950"
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -162,7 +166,7 @@ def main():
 
     kkt_ms, kkt_bytes = solver.time_kkt_apply(args.kkt_reps)
     stats = torch.tensor([dt, float(iters), float(args.steps * args.batch), float(solved), float(cg)], dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         stats = stats.cuda()
         tmax = stats[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -194,7 +198,7 @@ def main():
             rec["speedup_vs_cpu_baseline"] = rec["value"] / rec["cpu_baseline"]["value"]
         print(json.dumps(rec), flush=True)
     solver.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
