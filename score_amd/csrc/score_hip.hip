@@ -67,6 +67,7 @@ struct DevBuf {
 
 struct CsrBufs {
     DevBuf<int32_t> ptr, col, first_row, blk_prob, split;
+    DevBuf<int4> blk_meta;
     DevBuf<double> val;
     int nblocks = 0;
     void upload(const Csr& M, const RowBlocks& rb, const std::vector<int32_t>* sp = nullptr) {
@@ -75,10 +76,14 @@ struct CsrBufs {
         val.upload(M.val);
         first_row.upload(rb.first_row);
         blk_prob.upload(rb.prob);
+        std::vector<int4> meta(rb.nb());
+        for (int b = 0; b < rb.nb(); ++b)
+            meta[b] = make_int4(rb.first_row[b], rb.first_row[b + 1], M.ptr[rb.first_row[b]], M.ptr[rb.first_row[b + 1]]);
+        blk_meta.upload(meta);
         if (sp) split.upload(*sp);
         nblocks = rb.nb();
     }
-    CsrDev dev() const { return CsrDev{ptr.d, col.d, val.d, first_row.d, blk_prob.d, split.d, nblocks}; }
+    CsrDev dev() const { return CsrDev{ptr.d, col.d, val.d, first_row.d, blk_prob.d, blk_meta.d, split.d, nblocks}; }
 };
 
 struct HipBackend {

@@ -90,6 +90,7 @@ struct CsrDev {
     const double* val;
     const int32_t* first_row;  // row blocks
     const int32_t* blk_prob;
+    const int4* blk_meta;      // per block {first row, end row, first nonzero, end nonzero}: one load
     const int32_t* split;      // G2 only
     int nblocks;
 };
@@ -127,27 +128,35 @@ template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     __shared__ double prod[kTileNnz];
     __shared__ double red[8];
+    __shared__ int32_t srow[kRowsPerBlock + 1];  // row pointers of the tile, relative to k0
     const int b = blockIdx.x;
-    const int prob = a.M.blk_prob[b];
-    if (a.done[prob]) return;
     const int t = threadIdx.x;
-    const int r0 = a.M.first_row[b], r1 = a.M.first_row[b + 1];
-    const int k0 = a.M.ptr[r0], k1 = a.M.ptr[r1];
+    // one 16-byte load gives the whole tile geometry; the frozen-problem flag and the
+    // tile's row pointers are requested together with it
+    const int4 meta = a.M.blk_meta[b];
+    const int prob = a.M.blk_prob[b];
+    const int r0 = meta.x, r1 = meta.y, k0 = meta.z, k1 = meta.w;
     const int nn = k1 - k0;
+    const int my_ptr = a.M.ptr[min(r0 + t, r1)];
+    const int end_ptr = (t == 0) ? k1 : 0;
+    if (a.done[prob]) return;
     const double* __restrict__ val = a.M.val;
     const int32_t* __restrict__ col = a.M.col;
     const double* __restrict__ xin = a.xin;
 
-    double beta = 0.0;
+    // KPB: beta = r'z_new / r'z_old.  The partial sums are requested here, but reduced
+    // (two barriers) only after the matrix and vector loads of the tile are in flight.
+    double beta = 0.0, acc_n = 0.0, acc_o = 0.0;
     if (MODE == MODE_KPB) {
-        const double rzn = reduce_partials(a.rz_new, a.prec_part_ptr[prob], a.prec_part_ptr[prob + 1], red);
-        const double rzo = reduce_partials(a.rz_old, a.prec_part_ptr[prob], a.prec_part_ptr[prob + 1], red);
-        beta = rzo > 0.0 ? rzn / rzo : 0.0;
+        const int l0 = a.prec_part_ptr[prob], l1 = a.prec_part_ptr[prob + 1];
+        for (int i = l0 + t; i < l1; i += kThreads) { acc_n += a.rz_new[i]; acc_o += a.rz_old[i]; }
     }
-    // value of the gathered vector at column c
-    auto gather = [&](int c) -> double {
-        if (MODE == MODE_KPB) return a.z[c] + beta * a.p[c];
-        return xin[c];
+    auto finish_beta = [&]() {
+        if (MODE == MODE_KPB) {
+            const double rzn = block_sum(acc_n, red);
+            const double rzo = block_sum(acc_o, red);
+            beta = rzo > 0.0 ? rzn / rzo : 0.0;
+        }
     };
 
     int row = r0 + t;
@@ -158,9 +167,10 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         // one long row: unrolled strided partial sums + tree reduction
         double acc = 0.0, acc2 = 0.0;
         const int split = (MODE == MODE_DRES) ? a.M.split[r0] : k1;
+        finish_beta();  // uniform: lanes beyond the row's end never enter the sweep
         for (int kb = k0 + t; kb < k1; kb += kThreads * kLongUnroll) {
             int32_t c[kLongUnroll];
-            double v[kLongUnroll], g[kLongUnroll];
+            double v[kLongUnroll], g[kLongUnroll], g2[kLongUnroll];
 #pragma unroll
             for (int u = 0; u < kLongUnroll; ++u) {
                 const int k = min(kb + u * kThreads, k1 - 1);
@@ -168,10 +178,13 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
                 v[u] = val[k];
             }
 #pragma unroll
-            for (int u = 0; u < kLongUnroll; ++u) g[u] = gather(c[u]);
+            for (int u = 0; u < kLongUnroll; ++u) {
+                if (MODE == MODE_KPB) { g[u] = a.z[c[u]]; g2[u] = a.p[c[u]]; } else { g[u] = xin[c[u]]; }
+            }
 #pragma unroll
             for (int u = 0; u < kLongUnroll; ++u) {
                 const int k = kb + u * kThreads;
+                if (MODE == MODE_KPB) g[u] += beta * g2[u];
                 const double pr = (k < k1) ? v[u] * g[u] : 0.0;
                 if (MODE == MODE_DRES && k >= split) acc2 += pr; else acc += pr;
             }
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         // Loads are unconditional on clamped indices (a predicated load becomes a branch
         // and serialises the memory pipeline); only the LDS stores are predicated.
         int32_t c[kUnroll];
-        double v[kUnroll], g[kUnroll];
+        double v[kUnroll], g[kUnroll], g2[kUnroll];
         const int klast = max(nn - 1, 0);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
@@ -193,16 +206,22 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
             v[u] = val[k0 + k];
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) g[u] = gather(c[u]);
+        for (int u = 0; u < kUnroll; ++u) {
+            if (MODE == MODE_KPB) { g[u] = a.z[c[u]]; g2[u] = a.p[c[u]]; } else { g[u] = xin[c[u]]; }
+        }
+        finish_beta();
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const int k = t + u * kThreads;
+            if (MODE == MODE_KPB) g[u] += beta * g2[u];
             if (k < nn) prod[k] = v[u] * g[u];
         }
+        if (r0 + t <= r1) srow[t] = my_ptr - k0;
+        if (t == 0) srow[r1 - r0] = end_ptr - k0;
         __syncthreads();
         if (row < r1) {
             has_row = true;
-            const int a0 = a.M.ptr[row] - k0, a1 = a.M.ptr[row + 1] - k0;
+            const int a0 = srow[t], a1 = srow[t + 1];
             if (MODE == MODE_DRES) {
                 const int sp = a.M.split[row] - k0;
                 for (int k = a0; k < sp; ++k) sum += prod[k];
@@ -731,7 +750,8 @@ __device__ __forceinline__ void soc_scales(int type, double t0, double nz2, doub
     else { const double m = 0.5 * (t0 + nz); head = m; tail = m / nz; }
 }
 
-constexpr int kSmallCone = 4;
+constexpr int kSmallCone = 4;    // rows
+constexpr int kConeRowNnz = 2;   // entries per row handled by the register path
 
 __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
     const int b = blockIdx.x;
@@ -742,20 +762,48 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
     const int row = a.cone_row[c], dim = a.cone_dim[c], type = a.cone_type[c];
     const double rho = a.rho[prob], irho = 1.0 / rho, al = a.alpha_relax;
     double t0 = 0.0, nz2 = 0.0, head, tail;
-    if (dim <= kSmallCone) {
-        // SCORE's cones (d + 1 = 3 or 4 rows): everything stays in registers
-        double v[kSmallCone], wv[kSmallCone], yv[kSmallCone], bv[kSmallCone];
+    // SCORE's cones have d + 1 = 3 or 4 rows with at most 2 entries each: row pointers,
+    // then every column/value, then every gathered x are requested as three batches of
+    // unconditional loads (clamped indices) instead of a dependent chain per entry.
+    int ptrs[kSmallCone + 1];
+    bool small = (dim <= kSmallCone);
+    if (small) {
+#pragma unroll
+        for (int k = 0; k <= kSmallCone; ++k) ptrs[k] = a.A_ptr[row + min(k, dim)];
+#pragma unroll
+        for (int k = 0; k < kSmallCone; ++k) small = small && (ptrs[k + 1] - ptrs[k] <= kConeRowNnz);
+    }
+    if (small) {
+        double v[kSmallCone], wv[kSmallCone], yv[kSmallCone], bv[kSmallCone], sv[kSmallCone];
+        int cc[kSmallCone][kConeRowNnz];
+        double av[kSmallCone][kConeRowNnz], xv[kSmallCone][kConeRowNnz];
+        const int last_nz = max(ptrs[kSmallCone] - 1, 0);
+#pragma unroll
+        for (int k = 0; k < kSmallCone; ++k) {
+            const int i = row + min(k, dim - 1);
+            bv[k] = a.b[i];
+            yv[k] = a.y[i];
+            sv[k] = a.s[i];
+#pragma unroll
+            for (int e = 0; e < kConeRowNnz; ++e) {
+                const int idx = min(ptrs[k] + e, last_nz);
+                cc[k][e] = a.A_col[idx];
+                av[k][e] = a.A_val[idx];
+            }
+        }
 #pragma unroll
         for (int k = 0; k < kSmallCone; ++k)
-            if (k < dim) {
-                const int i = row + k;
-                bv[k] = a.b[i];
-                yv[k] = a.y[i];
-                const double tt = a_row_dot(a, i, a.xt);
-                v[k] = al * (bv[k] - tt) + (1.0 - al) * a.s[i];
-                wv[k] = v[k] - yv[k] * irho;
-                if (k == 0) t0 = wv[k]; else nz2 += wv[k] * wv[k];
-            }
+#pragma unroll
+            for (int e = 0; e < kConeRowNnz; ++e) xv[k][e] = a.xt[cc[k][e]];
+#pragma unroll
+        for (int k = 0; k < kSmallCone; ++k) {
+            double tt = 0.0;
+#pragma unroll
+            for (int e = 0; e < kConeRowNnz; ++e) tt += (ptrs[k] + e < ptrs[k + 1]) ? av[k][e] * xv[k][e] : 0.0;
+            v[k] = al * (bv[k] - tt) + (1.0 - al) * sv[k];
+            wv[k] = v[k] - yv[k] * irho;
+            if (k == 0) t0 = wv[k]; else if (k < dim) nz2 += wv[k] * wv[k];
+        }
         soc_scales(type, t0, nz2, head, tail);
 #pragma unroll
         for (int k = 0; k < kSmallCone; ++k)
