@@ -216,7 +216,7 @@ inline void default_settings(score_settings* s) {
     s->check_interval = 25;
     s->rho = 0.1;
     s->sigma = 1e-6;
-    s->alpha = 1.6;
+    s->alpha = 1.8;
     s->scale_iters = 10;
     s->cg_iters = 2;
     s->adaptive_cg = 1;
