@@ -31,7 +31,7 @@ thread_local std::string g_err;
 struct CpuBackend {
     const HostSystem* H = nullptr;
     score_settings st{};
-    std::vector<double> xtu, xy, s, r, z, p, w;  // xtu = [xt | u], xy = [x | y]
+    std::vector<double> xtu, xy, s, r, z, p, w, kx;  // xtu = [xt | u], xy = [x | y], kx = K xt
     std::vector<double> scr;
     std::vector<int> done;
     std::vector<double> cg_red;  // last measured sqrt(r'z_final / r'z_init) per problem
@@ -50,6 +50,7 @@ struct CpuBackend {
         z.assign(h.n_tot, 0.0);
         p.assign(h.n_tot, 0.0);
         w.assign(h.n_tot, 0.0);
+        kx.assign(h.n_tot, 0.0);
         scr.assign((size_t)std::max<int64_t>(1, h.scratch_nodes) * std::max(1, h.bs), 0.0);
         done.assign(h.count, 0);
         cg_red.assign(h.count, 0.0);
@@ -57,6 +58,8 @@ struct CpuBackend {
         reset();
     }
     void upload_rho(const HostSystem& h) {
+        // K changed: the carried product kx = K xt is recomputed once
+        for (int64_t i = 0; i < h.n_tot; ++i) kx[i] = row_dot(h.K, i, xtu.data());
         // u = rho (b - s) - y depends on rho
         for (int pi = 0; pi < h.count; ++pi)
             for (int64_t i = h.roff[pi]; i < h.roff[pi + 1]; ++i)
@@ -71,6 +74,7 @@ struct CpuBackend {
         std::fill(z.begin(), z.end(), 0.0);
         std::fill(p.begin(), p.end(), 0.0);
         std::fill(w.begin(), w.end(), 0.0);
+        std::fill(kx.begin(), kx.end(), 0.0);
         upload_rho(*H);
     }
 
@@ -115,9 +119,9 @@ struct CpuBackend {
         double* x = xy.data();
         double* u = xtu.data() + h.n_tot;
         double* y = xy.data() + h.n_tot;
-        // r = sigma x - q + [-K | A'] [xt ; u]
+        // r = sigma x - q + A'u - K xt   (K xt carried incrementally in kx)
 #pragma omp parallel for schedule(static)
-        for (int64_t i = x0; i < x1; ++i) r[i] = sigma * x[i] - h.q[i] + row_dot(h.G1, i, xtu.data());
+        for (int64_t i = x0; i < x1; ++i) r[i] = sigma * x[i] - h.q[i] + row_dot(h.G1, i, xtu.data()) - kx[i];
         double rz = 0;
         precond(pi, rz);
         const double rz_init = rz;
@@ -133,6 +137,7 @@ struct CpuBackend {
 #pragma omp parallel for schedule(static)
             for (int64_t i = x0; i < x1; ++i) {
                 xt[i] += a * p[i];
+                kx[i] += a * w[i];
                 r[i] -= a * w[i];
             }
             if (j == cg_iters && measure) {
@@ -253,6 +258,7 @@ struct CpuBackend {
         else if (nm == "z") { src = z.data(); sz = h.n_tot; }
         else if (nm == "p") { src = p.data(); sz = h.n_tot; }
         else if (nm == "w") { src = w.data(); sz = h.n_tot; }
+        else if (nm == "kx") { src = kx.data(); sz = h.n_tot; }
         else if (nm == "D") { src = h.D.data(); sz = h.n_tot; }
         else if (nm == "E") { src = h.E.data(); sz = h.m_tot; }
         else if (nm == "Kval") { src = h.K.val.data(); sz = (int64_t)h.K.val.size(); }

@@ -103,7 +103,7 @@ struct HipBackend {
     DevBuf<PrecWork> prec_work;
     DevBuf<ChainDesc> chains;
     DevBuf<ChainLevelDesc> levels;
-    DevBuf<double> xtu, xy, s, r, z, p, p2, w;
+    DevBuf<double> xtu, xy, s, r, z, p, p2, w, kx;
     DevBuf<double> pw_part, rz_part0, rz_part1, rz_meas0, rz_meas1, pres_part, dres_part;
     int cg_iters = 2;
     double* h_pres = nullptr;  // pinned
@@ -168,7 +168,7 @@ struct HipBackend {
             else if (h.bs == 3) allow_big_lds<3>(); else allow_big_lds<4>();
         }
         xtu.alloc(h.n_tot + h.m_tot); xy.alloc(h.n_tot + h.m_tot); s.alloc(h.m_tot);
-        r.alloc(h.n_tot); z.alloc(h.n_tot); p.alloc(h.n_tot); p2.alloc(h.n_tot); w.alloc(h.n_tot);
+        r.alloc(h.n_tot); z.alloc(h.n_tot); p.alloc(h.n_tot); p2.alloc(h.n_tot); w.alloc(h.n_tot); kx.alloc(h.n_tot);
         pw_part.alloc(K.nblocks); rz_part0.alloc(n_prec); rz_part1.alloc(n_prec);
         rz_meas0.alloc(n_prec); rz_meas1.alloc(n_prec);
         cg_iters = st.cg_iters;
@@ -184,7 +184,6 @@ struct HipBackend {
 
     void upload_rho_values(const HostSystem& h) {
         K.val.upload(h.K.val);
-        G1.val.upload(h.G1.val);
         fac.upload(h.fac);
         dinv.upload(h.dinv);
         rho.upload(h.rho);
@@ -204,6 +203,12 @@ struct HipBackend {
     void upload_rho(const HostSystem& h) {
         HIP_CHECK(hipStreamSynchronize(stream));
         upload_rho_values(h);
+        {   // K changed: the carried product kx = K xt is recomputed once
+            SpmvArgs a = spmv_args(K, xtu.d);
+            a.p = xtu.d; a.w = kx.d;
+            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
+            HIP_CHECK(hipGetLastError());
+        }
         if (n_cone_blocks) {
             hipLaunchKernelGGL(k_refresh_u, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xtu.d));
             HIP_CHECK(hipGetLastError());
@@ -219,7 +224,7 @@ struct HipBackend {
 
     void reset() {
         xtu.zero(stream); xy.zero(stream); s.zero(stream);
-        r.zero(stream); z.zero(stream); p.zero(stream); p2.zero(stream); w.zero(stream);
+        r.zero(stream); z.zero(stream); p.zero(stream); p2.zero(stream); w.zero(stream); kx.zero(stream);
         pw_part.zero(stream); rz_part0.zero(stream); rz_part1.zero(stream);
         rz_meas0.zero(stream); rz_meas1.zero(stream);
         if (n_cone_blocks) {
@@ -256,7 +261,7 @@ struct HipBackend {
     SpmvArgs spmv_args(const CsrBufs& M, const double* xin) {
         SpmvArgs a{};
         a.M = M.dev(); a.xin = xin; a.done = done.d;
-        a.x = xy.d; a.q = q.d; a.r = r.d; a.sigma = H->sigma;
+        a.x = xy.d; a.q = q.d; a.kx = kx.d; a.r = r.d; a.sigma = H->sigma;
         a.p = p.d; a.w = w.d; a.pw_part = pw_part.d;
         a.prec_part_ptr = prec_part_ptr.d;
         a.invD = invD.d; a.dres_part = dres_part.d;
@@ -305,7 +310,7 @@ struct HipBackend {
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = done.d;
         pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d;
-        pa.r = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d;
+        pa.r = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d;
         pa.pw_part = pw_part.d;
         double* rz_cur = measure ? rz_meas0.d : rz_part0.d;
         double* p_cur = p.d;
@@ -324,7 +329,7 @@ struct HipBackend {
         VecArgs va{};
         va.first_row = K.first_row.d; va.blk_prob = K.blk_prob.d; va.done = done.d;
         va.prec_part_ptr = prec_part_ptr.d; va.kblk_part_ptr = kblk_part_ptr.d;
-        va.pw_part = pw_part.d; va.p = p_cur; va.xt = xtu.d; va.x = xy.d;
+        va.pw_part = pw_part.d; va.p = p_cur; va.w = w.d; va.kx = kx.d; va.xt = xtu.d; va.x = xy.d;
         va.alpha_relax = st.alpha; va.rz_old = rz_cur; va.apply_alpha = 1;
         if (measure) {
             pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_meas1.d;
@@ -416,6 +421,7 @@ struct HipBackend {
         else if (nm == "z") { src = z.d; sz = h.n_tot; }
         else if (nm == "p") { src = (cg_iters % 2 == 1) ? p.d : p2.d; sz = h.n_tot; }  // last PCG direction
         else if (nm == "w") { src = w.d; sz = h.n_tot; }
+        else if (nm == "kx") { src = kx.d; sz = h.n_tot; }
         else if (nm == "D") { src = h.D.data(); sz = h.n_tot; host = true; }
         else if (nm == "E") { src = h.E.data(); sz = h.m_tot; host = true; }
         else if (nm == "Kval") { src = K.val.d; sz = (int64_t)h.K.val.size(); }
@@ -436,12 +442,12 @@ struct HipBackend {
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = done.d;
         pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d;
-        pa.r = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d;
+        pa.r = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d;
         pa.pw_part = pw_part.d; pa.rz_in = rz_part0.d; pa.rz_out = rz_part1.d;
         VecArgs va{};
         va.first_row = K.first_row.d; va.blk_prob = K.blk_prob.d; va.done = done.d;
         va.prec_part_ptr = prec_part_ptr.d; va.kblk_part_ptr = kblk_part_ptr.d;
-        va.pw_part = pw_part.d; va.p = p.d; va.xt = xtu.d; va.x = xy.d;
+        va.pw_part = pw_part.d; va.p = p.d; va.w = w.d; va.kx = kx.d; va.xt = xtu.d; va.x = xy.d;
         va.alpha_relax = st.alpha; va.rz_old = rz_part0.d; va.apply_alpha = 1;
         auto once = [&]() {
             if (which == "rhs") hipLaunchKernelGGL(k_spmv<MODE_RHS>, dim3(G1.nblocks), dim3(kThreads), 0, stream, spmv_args(G1, xtu.d));

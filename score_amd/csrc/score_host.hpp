@@ -5,7 +5,8 @@
 //   * Ruiz equilibration of [[P, A'], [A, 0]] with one scale per cone,
 //   * the KKT operator K = P + sigma*I + rho*A'A on a fixed sparsity pattern
 //     (values K0 + rho*K1), and the two "wide" operators
-//       G1 = [-K | A']  applied to [xt ; u]   (KKT right-hand side / residual)
+//       G1 = [ 0 | A']  applied to [xt ; u]   (A'u of the KKT right-hand side; K xt is
+//                                              carried incrementally, see kx)
 //       G2 = [ P | A']  applied to [x  ; y]   (dual residual),
 //   * the row-block tiling the CSR-stream SpMV kernel consumes,
 //   * the multi-level (radix-p nested-dissection) factorisation of the
@@ -368,7 +369,6 @@ struct HostSystem {
     Csr K;
     std::vector<double> K0, K1;
     Csr G1;
-    std::vector<int32_t> g1_kidx;
     Csr G2;
     std::vector<int32_t> g2_split;  // per row: first entry of the A' part
     RowBlocks rbK, rbG1, rbG2;
@@ -588,17 +588,10 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
             H.K1.push_back(acc1[j]);
         }
         H.K.ptr.push_back((int32_t)H.K.col.size());
-        // G1 row = [-K | A']
-        const int32_t kbase = H.K.ptr[H.K.ptr.size() - 2];
-        for (size_t c = 0; c < cols.size(); ++c) {
-            H.G1.col.push_back((int32_t)(xo + cols[c]));
-            H.G1.val.push_back(0.0);
-            H.g1_kidx.push_back(kbase + (int32_t)c);
-        }
+        // G1 row = [0 | A'] (columns address the contiguous buffer [xt ; u])
         for (int t = atp[i]; t < atp[i + 1]; ++t) {
             H.G1.col.push_back((int32_t)(H.n_tot + ro + atr[t]));
             H.G1.val.push_back(atv[t]);
-            H.g1_kidx.push_back(-1);
         }
         H.G1.ptr.push_back((int32_t)H.G1.col.size());
         // G2 row = [P | A']
@@ -621,8 +614,6 @@ inline void refresh_rho(HostSystem& H, int pi) {
     const double rho = H.rho[pi];
     const int64_t r0 = H.xoff[pi], r1 = H.xoff[pi + 1];
     for (int64_t k = H.K.ptr[r0]; k < H.K.ptr[r1]; ++k) H.K.val[k] = H.K0[k] + rho * H.K1[k];
-    for (int64_t k = H.G1.ptr[r0]; k < H.G1.ptr[r1]; ++k)
-        if (H.g1_kidx[k] >= 0) H.G1.val[k] = -H.K.val[H.g1_kidx[k]];
     const int bs = H.bs, b2 = bs * bs;
     for (size_t ci = 0; ci < H.chains.size(); ++ci) {
         ChainDesc& ch = H.chains[ci];

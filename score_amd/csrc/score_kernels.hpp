@@ -102,6 +102,7 @@ struct SpmvArgs {
     // RHS
     const double* x;
     const double* q;
+    const double* kx;       // K xt, carried incrementally by the PCG updates
     double* r;
     double sigma;
     // KP / KPB
@@ -118,7 +119,7 @@ struct SpmvArgs {
     double* dres_part;      // 8 per block
 };
 
-// RHS : r = sigma x - q + M xin                        (M = [-K | A'], xin = [xt ; u])
+// RHS : r = sigma x - q + M xin - kx                   (M = [0 | A'], xin = [xt ; u], kx = K xt)
 // KP  : w = M p, partial p'w                           (M = K)
 // KPB : p_new = z + beta p_old (beta from partials), w = M p_new, partial p_new'w
 // DRES: dual residual norms                            (M = [P | A'], xin = [x ; y])
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     }
 
     if (MODE == MODE_RHS) {
-        if (has_row) a.r[row] = a.sigma * a.x[row] - a.q[row] + sum;
+        if (has_row) a.r[row] = a.sigma * a.x[row] - a.q[row] + sum - a.kx[row];
     } else if (MODE == MODE_KP || MODE == MODE_KPB) {
         double local = 0.0;
         if (has_row) {
@@ -293,6 +294,7 @@ struct PrecArgs {
     double* p;             // INIT: receives p = z.  STEP: the direction of the last K p
     const double* w;
     double* xt;
+    double* kx;            // K xt: kx += alpha w whenever xt += alpha p
     const double* rz_in;   // partials of the previous r'z   (STEP)
     const double* pw_part; // partials of p'w                (STEP)
     double* rz_out;        // one partial per work item
@@ -365,14 +367,14 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
         const int e_end = wk.index + wk.count;
         for (int base = wk.index + t; base < e_end; base += kPrecThreads * kPrecChunk) {
             int cols[kPrecChunk];
-            double rv[kPrecChunk], dv[kPrecChunk], pv[kPrecChunk], wv[kPrecChunk], xv[kPrecChunk];
+            double rv[kPrecChunk], dv[kPrecChunk], pv[kPrecChunk], wv[kPrecChunk], xv[kPrecChunk], kv[kPrecChunk];
 #pragma unroll
             for (int u = 0; u < kPrecChunk; ++u) cols[u] = a.diag_cols[min(base + u * kPrecThreads, e_end - 1)];
 #pragma unroll
             for (int u = 0; u < kPrecChunk; ++u) {
                 rv[u] = a.r[cols[u]];
                 dv[u] = a.dinv[min(base + u * kPrecThreads, e_end - 1)];
-                if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt[cols[u]]; }
+                if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt[cols[u]]; kv[u] = a.kx[cols[u]]; }
             }
 #pragma unroll
             for (int u = 0; u < kPrecChunk; ++u) {
@@ -380,6 +382,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
                     double r_ = rv[u];
                     if (MODE == PREC_STEP) {
                         a.xt[cols[u]] = xv[u] + alpha * pv[u];
+                        a.kx[cols[u]] = kv[u] + alpha * wv[u];
                         r_ -= alpha * wv[u];
                         a.r[cols[u]] = r_;
                     }
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
         //      lane joins the reduction), then the update; further chunks only for long chains
         {
             int cols[kPrecChunk];
-            double rv[kPrecChunk], pv[kPrecChunk], wv[kPrecChunk], xv[kPrecChunk];
+            double rv[kPrecChunk], pv[kPrecChunk], wv[kPrecChunk], xv[kPrecChunk], kv[kPrecChunk];
             auto chunk_load = [&](int base) {
 #pragma unroll
                 for (int u = 0; u < kPrecChunk; ++u) {
@@ -425,7 +428,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
 #pragma unroll
                 for (int u = 0; u < kPrecChunk; ++u) {
                     rv[u] = a.r[cols[u]];
-                    if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt[cols[u]]; }
+                    if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt[cols[u]]; kv[u] = a.kx[cols[u]]; }
                 }
             };
             auto chunk_apply = [&](int base) {
@@ -436,6 +439,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
                         double r_ = rv[u];
                         if (MODE == PREC_STEP) {
                             a.xt[cols[u]] = xv[u] + alpha * pv[u];
+                            a.kx[cols[u]] = kv[u] + alpha * wv[u];
                             r_ -= alpha * wv[u];
                             a.r[cols[u]] = r_;
                         }
@@ -684,6 +688,8 @@ struct VecArgs {
     const double* rz_old;
     const double* pw_part;
     const double* p;
+    const double* w;
+    double* kx;
     double* xt;
     double* x;
     double alpha_relax;
@@ -705,6 +711,7 @@ __global__ __launch_bounds__(kThreads) void k_xupdate(VecArgs a) {
     if (row < a.first_row[b + 1]) {
         const double xt = a.xt[row] + alpha * a.p[row];
         a.xt[row] = xt;
+        if (a.apply_alpha) a.kx[row] += alpha * a.w[row];
         a.x[row] = a.alpha_relax * xt + (1.0 - a.alpha_relax) * a.x[row];
     }
 }

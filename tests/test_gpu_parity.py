@@ -17,7 +17,7 @@ from score_amd.solver import ConicSolver
 
 pytestmark = pytest.mark.gpu
 
-VECS = ["x", "xt", "s", "y", "u", "r", "z", "p", "w"]
+VECS = ["x", "xt", "s", "y", "u", "r", "z", "p", "w", "kx"]
 
 
 def _hip_only(hip_lib):
