@@ -329,23 +329,18 @@ def assemble(data, relaxation: str = QCQP_RELAXATION) -> ScoreModel:
     chain_ptr = [0]
     node_cols = []
     base = 0
+    j_ar = np.arange(D1)
     for chain in data.pose_variables:
         L = len(chain)
+        idx = base + np.arange(L)
+        # the pinned pose is not an unknown: a chain that contains it is cut there
+        pieces = [idx] if not (base <= p0 < base + L) else [idx[idx < p0], idx[idx > p0]]
         for k in range(d):
-            cnt = 0
-            for i in range(L):
-                p = base + i
-                if p == p0:
-                    # the pinned pose is not an unknown; a chain that contains it
-                    # simply starts after it
-                    if cnt:
-                        chain_ptr.append(chain_ptr[-1] + cnt)
-                        cnt = 0
+            for piece in pieces:
+                if piece.size == 0:
                     continue
-                node_cols.append(new_of_model[p * PB + k * D1 + np.arange(D1)])
-                cnt += 1
-            if cnt:
-                chain_ptr.append(chain_ptr[-1] + cnt)
+                node_cols.append(new_of_model[piece[:, None] * PB + k * D1 + j_ar[None, :]].ravel())
+                chain_ptr.append(chain_ptr[-1] + piece.size)
         base += L
     qp = ConicQP(
         P=P, q=np.ascontiguousarray(q), c0=c0, A=A, b=np.ascontiguousarray(b), z=0,
