@@ -165,6 +165,9 @@ def main():
     dt = time.perf_counter() - t0
 
     kkt_ms, kkt_bytes = solver.time_kkt_apply(args.kkt_reps)
+    # back-to-back duration of every kernel of the iteration (HIP events, solver's stream)
+    kernel_us = {k: 1e3 * solver.debug_time(k, 200) for k in
+                 ("rhs", "prec_init", "kp", "prec_step", "kpb", "xupdate", "cone")}
     stats = torch.tensor([dt, float(iters), float(args.steps * args.batch), float(solved), float(cg)], dtype=torch.float64)
     if use_dist:
         stats = stats.cuda()
@@ -192,6 +195,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": pmc_traffic(int(models[0].qp.n), int(models[0].qp.P.nnz)) if args.batch == 1 else None,
                          "bytes_per_launch": kkt_bytes, "us_per_launch": kkt_ms * 1e3},
+            "kernel_us_back_to_back": kernel_us,
         }
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args, models)
