@@ -103,9 +103,11 @@ struct HipBackend {
     DevBuf<PrecWork> prec_work;
     DevBuf<ChainDesc> chains;
     DevBuf<ChainLevelDesc> levels;
-    DevBuf<double> xtu, xy, s, r, z, p, p2, w, kx;
+    DevBuf<double> xtu, xy, s, r, z, p, p2, w, kx, step;
     DevBuf<double> pw_part, rz_part0, rz_part1, rz_meas0, rz_meas1, pres_part, dres_part;
     int cg_iters = 2;
+    const double* last_rz = nullptr;  // r'z partials / direction of the pending end-of-PCG update
+    const double* last_p = nullptr;
     double* h_pres = nullptr;  // pinned
     double* h_dres = nullptr;
     int n_cone_blocks = 0, n_prec = 0;
@@ -168,7 +170,7 @@ struct HipBackend {
             else if (h.bs == 3) allow_big_lds<3>(); else allow_big_lds<4>();
         }
         xtu.alloc(h.n_tot + h.m_tot); xy.alloc(h.n_tot + h.m_tot); s.alloc(h.m_tot);
-        r.alloc(h.n_tot); z.alloc(h.n_tot); p.alloc(h.n_tot); p2.alloc(h.n_tot); w.alloc(h.n_tot); kx.alloc(h.n_tot);
+        r.alloc(h.n_tot); z.alloc(h.n_tot); p.alloc(h.n_tot); p2.alloc(h.n_tot); w.alloc(h.n_tot); kx.alloc(h.n_tot); step.alloc(h.count);
         pw_part.alloc(K.nblocks); rz_part0.alloc(n_prec); rz_part1.alloc(n_prec);
         rz_meas0.alloc(n_prec); rz_meas1.alloc(n_prec);
         cg_iters = st.cg_iters;
@@ -197,6 +199,8 @@ struct HipBackend {
         a.done = done.d; a.rho = rho.d; a.b = b.d; a.xt = gathered;
         a.s = s.d; a.y = xy.d + H->n_tot; a.u = xtu.d + H->n_tot;
         a.alpha_relax = st.alpha; a.invE = invE.d; a.pres_part = pres_part.d;
+        a.apply_alpha = 0; a.pfin = p.d; a.pw_in = pw_part.d; a.rz_in = rz_part0.d;
+        a.prec_part_ptr = prec_part_ptr.d; a.kblk_part_ptr = kblk_part_ptr.d; a.step_out = step.d;
         return a;
     }
 
@@ -224,7 +228,7 @@ struct HipBackend {
 
     void reset() {
         xtu.zero(stream); xy.zero(stream); s.zero(stream);
-        r.zero(stream); z.zero(stream); p.zero(stream); p2.zero(stream); w.zero(stream); kx.zero(stream);
+        r.zero(stream); z.zero(stream); p.zero(stream); p2.zero(stream); w.zero(stream); kx.zero(stream); step.zero(stream);
         pw_part.zero(stream); rz_part0.zero(stream); rz_part1.zero(stream);
         rz_meas0.zero(stream); rz_meas1.zero(stream);
         if (n_cone_blocks) {
@@ -263,7 +267,9 @@ struct HipBackend {
         a.M = M.dev(); a.xin = xin; a.done = done.d;
         a.x = xy.d; a.q = q.d; a.kx = kx.d; a.r = r.d; a.sigma = H->sigma;
         a.p = p.d; a.w = w.d; a.pw_part = pw_part.d;
-        a.prec_part_ptr = prec_part_ptr.d;
+        a.prec_part_ptr = prec_part_ptr.d; a.kblk_part_ptr = kblk_part_ptr.d;
+        a.apply_update = 0; a.pfin = p.d; a.wfin = w.d; a.xt_rw = xtu.d; a.kx_rw = kx.d; a.x_rw = xy.d;
+        a.alpha_relax = st.alpha; a.step_in = step.d;
         a.invD = invD.d; a.dres_part = dres_part.d;
         return a;
     }
@@ -304,8 +310,17 @@ struct HipBackend {
 
     // enqueue one ADMM iteration on `stream`; a measuring iteration additionally
     // leaves r'z before and after the PCG sweep in rz_meas0 / rz_meas1
-    void enqueue_iteration(bool measure) {
-        hipLaunchKernelGGL(k_spmv<MODE_RHS>, dim3(G1.nblocks), dim3(kThreads), 0, stream, spmv_args(G1, xtu.d));
+    // The end-of-PCG update of an iteration (xt += a p, kx += a w, x relaxed) is applied by
+    // the NEXT iteration's right-hand-side kernel on its own rows, and on the fly by the cone
+    // kernel's gather; only a measuring iteration (the last of a launch graph) finalises it
+    // itself, so the first iteration of a graph has nothing pending (`first`).
+    void enqueue_iteration(bool measure, bool first) {
+        {
+            SpmvArgs ra = spmv_args(G1, xtu.d);
+            ra.apply_update = first ? 0 : 1;
+            ra.pfin = last_p;
+            hipLaunchKernelGGL(k_spmv<MODE_RHS>, dim3(G1.nblocks), dim3(kThreads), 0, stream, ra);
+        }
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = done.d;
@@ -326,26 +341,30 @@ struct HipBackend {
             std::swap(p_cur, p_oth);
             rz_cur = rz_nxt;
         }
-        VecArgs va{};
-        va.first_row = K.first_row.d; va.blk_prob = K.blk_prob.d; va.done = done.d;
-        va.prec_part_ptr = prec_part_ptr.d; va.kblk_part_ptr = kblk_part_ptr.d;
-        va.pw_part = pw_part.d; va.p = p_cur; va.w = w.d; va.kx = kx.d; va.xt = xtu.d; va.x = xy.d;
-        va.alpha_relax = st.alpha; va.rz_old = rz_cur; va.apply_alpha = 1;
+        ConeArgs ca = cone_args(xtu.d);
         if (measure) {
             pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_meas1.d;
-            launch_prec<PREC_STEP>(pa);  // also applies xt += a p, r -= a w
-            va.apply_alpha = 0;
+            launch_prec<PREC_STEP>(pa);  // also applies xt += a p, kx += a w, r -= a w
+            VecArgs va{};
+            va.first_row = K.first_row.d; va.blk_prob = K.blk_prob.d; va.done = done.d;
+            va.prec_part_ptr = prec_part_ptr.d; va.kblk_part_ptr = kblk_part_ptr.d;
+            va.pw_part = pw_part.d; va.p = p_cur; va.w = w.d; va.kx = kx.d; va.xt = xtu.d; va.x = xy.d;
+            va.alpha_relax = st.alpha; va.rz_old = rz_cur; va.apply_alpha = 0;
+            hipLaunchKernelGGL(k_xupdate, dim3(K.nblocks), dim3(kThreads), 0, stream, va);
+        } else {
+            ca.apply_alpha = 1; ca.pfin = p_cur; ca.rz_in = rz_cur;
+            last_rz = rz_cur;  // what the next iteration's right-hand-side kernel has to apply
+            last_p = p_cur;
         }
-        hipLaunchKernelGGL(k_xupdate, dim3(K.nblocks), dim3(kThreads), 0, stream, va);
         if (n_cone_blocks)
-            hipLaunchKernelGGL(k_cone, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xtu.d));
+            hipLaunchKernelGGL(k_cone, dim3(n_cone_blocks), dim3(kThreads), 0, stream, ca);
     }
 
     void build_graph(int iters) {
         if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
         hipGraph_t g = nullptr;
         HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        for (int i = 0; i < iters; ++i) enqueue_iteration(i == iters - 1);
+        for (int i = 0; i < iters; ++i) enqueue_iteration(i == iters - 1, i == 0);
         HIP_CHECK(hipStreamEndCapture(stream, &g));
         HIP_CHECK(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
@@ -357,7 +376,7 @@ struct HipBackend {
             if (!graph_exec || graph_iters != iters) build_graph(iters);
             HIP_CHECK(hipGraphLaunch(graph_exec, stream));
         } else {
-            for (int i = 0; i < iters; ++i) enqueue_iteration(i == iters - 1);
+            for (int i = 0; i < iters; ++i) enqueue_iteration(i == iters - 1, i == 0);
             HIP_CHECK(hipGetLastError());
         }
     }
@@ -450,14 +469,14 @@ struct HipBackend {
         va.pw_part = pw_part.d; va.p = p.d; va.w = w.d; va.kx = kx.d; va.xt = xtu.d; va.x = xy.d;
         va.alpha_relax = st.alpha; va.rz_old = rz_part0.d; va.apply_alpha = 1;
         auto once = [&]() {
-            if (which == "rhs") hipLaunchKernelGGL(k_spmv<MODE_RHS>, dim3(G1.nblocks), dim3(kThreads), 0, stream, spmv_args(G1, xtu.d));
+            if (which == "rhs") { SpmvArgs ra = spmv_args(G1, xtu.d); ra.apply_update = 1; hipLaunchKernelGGL(k_spmv<MODE_RHS>, dim3(G1.nblocks), dim3(kThreads), 0, stream, ra); }
             else if (which.rfind("prec_init:", 0) == 0) { pa.debug_skip = std::atoi(which.c_str() + 10); launch_prec<PREC_INIT>(pa); }
             else if (which == "prec_init") launch_prec<PREC_INIT>(pa);
             else if (which == "prec_step") launch_prec<PREC_STEP>(pa);
             else if (which == "kp") launch_kp(p.d);
             else if (which == "kpb") launch_kpb(p.d, p2.d, rz_part1.d, rz_part0.d);
             else if (which == "xupdate") hipLaunchKernelGGL(k_xupdate, dim3(K.nblocks), dim3(kThreads), 0, stream, va);
-            else if (which == "cone") { if (n_cone_blocks) hipLaunchKernelGGL(k_cone, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xtu.d)); }
+            else if (which == "cone") { if (n_cone_blocks) { ConeArgs ca = cone_args(xtu.d); ca.apply_alpha = 1; hipLaunchKernelGGL(k_cone, dim3(n_cone_blocks), dim3(kThreads), 0, stream, ca); } }
             else throw std::runtime_error("unknown kernel name");
         };
         for (int i = 0; i < 5; ++i) once();

@@ -59,6 +59,16 @@ __device__ __forceinline__ double block_max(double v, double* red) {
     __syncthreads();
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
+// Two sums with one pair of barriers.  `red` >= 8 doubles.
+__device__ __forceinline__ void block_sum2(double& v1, double& v2, double* red) {
+    v1 = wave_sum(v1);
+    v2 = wave_sum(v2);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = v1; red[4 + (threadIdx.x >> 6)] = v2; }
+    __syncthreads();
+    v1 = (red[0] + red[1]) + (red[2] + red[3]);
+    v2 = (red[4] + red[5]) + (red[6] + red[7]);
+}
 // Fixed-order re-reduction of per-workgroup partials [lo, hi).
 __device__ __forceinline__ double reduce_partials(const double* __restrict__ part, int lo, int hi, double* red) {
     double acc = 0.0;
@@ -76,6 +86,18 @@ __device__ __forceinline__ double block_sum_n(double v, double* red) {
 #pragma unroll
     for (int i = 0; i < NW; ++i) tot += red[i];
     return tot;
+}
+template <int NW>
+__device__ __forceinline__ void block_sum2_n(double& v1, double& v2, double* red) {  // `red` >= 2 NW doubles
+    v1 = wave_sum(v1);
+    v2 = wave_sum(v2);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = v1; red[NW + (threadIdx.x >> 6)] = v2; }
+    __syncthreads();
+    double t1 = 0.0, t2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) { t1 += red[i]; t2 += red[NW + i]; }
+    v1 = t1; v2 = t2;
 }
 template <int NW>
 __device__ __forceinline__ double reduce_partials_n(const double* __restrict__ part, int lo, int hi, double* red) {
@@ -114,6 +136,16 @@ struct SpmvArgs {
     const double* rz_new;   // KPB: partials of r'z (new, old)
     const double* rz_old;
     const int32_t* prec_part_ptr;
+    // RHS with the fused end-of-PCG update of the previous iteration
+    int apply_update;       // 1: xt += a p, kx += a w (a = r'z / p'w of the last PCG step), x relaxed
+    const double* pfin;     // last PCG direction
+    const double* wfin;     // K * pfin
+    double* xt_rw;
+    double* kx_rw;
+    double* x_rw;
+    double alpha_relax;
+    const double* step_in;  // per problem: step length of the last PCG step (written by k_cone)
+    const int32_t* kblk_part_ptr;
     // DRES
     const double* invD;
     double* dres_part;      // 8 per block
@@ -152,11 +184,12 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         const int l0 = a.prec_part_ptr[prob], l1 = a.prec_part_ptr[prob + 1];
         for (int i = l0 + t; i < l1; i += kThreads) { acc_n += a.rz_new[i]; acc_o += a.rz_old[i]; }
     }
+    // RHS: the step length of the last PCG step was published by the cone kernel
+    if (MODE == MODE_RHS && a.apply_update) beta = a.step_in[prob];
     auto finish_beta = [&]() {
         if (MODE == MODE_KPB) {
-            const double rzn = block_sum(acc_n, red);
-            const double rzo = block_sum(acc_o, red);
-            beta = rzo > 0.0 ? rzn / rzo : 0.0;
+            block_sum2(acc_n, acc_o, red);
+            beta = acc_o > 0.0 ? acc_n / acc_o : 0.0;
         }
     };
 
@@ -234,7 +267,19 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     }
 
     if (MODE == MODE_RHS) {
-        if (has_row) a.r[row] = a.sigma * a.x[row] - a.q[row] + sum - a.kx[row];
+        if (has_row) {
+            double kxv = a.kx[row];
+            double xv = a.x[row];
+            if (a.apply_update) {
+                const double xt = a.xt_rw[row] + beta * a.pfin[row];
+                kxv += beta * a.wfin[row];
+                xv = a.alpha_relax * xt + (1.0 - a.alpha_relax) * xv;
+                a.xt_rw[row] = xt;
+                a.kx_rw[row] = kxv;
+                a.x_rw[row] = xv;
+            }
+            a.r[row] = a.sigma * xv - a.q[row] + sum - kxv;
+        }
     } else if (MODE == MODE_KP || MODE == MODE_KPB) {
         double local = 0.0;
         if (has_row) {
@@ -358,9 +403,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
     double local = 0.0;
     if (wk.kind == 1) {
         if (MODE == PREC_STEP) {
-            const double rz = block_sum_n<kPrecWaves>(acc_rz, red);
-            const double pw = block_sum_n<kPrecWaves>(acc_pw, red);
-            alpha = pw > 0.0 ? rz / pw : 0.0;
+            block_sum2_n<kPrecWaves>(acc_rz, acc_pw, red);
+            alpha = acc_pw > 0.0 ? acc_rz / acc_pw : 0.0;
         }
         // Jacobi columns.  Every load is unconditional on a clamped index so that the
         // whole chunk is in flight at once; only the stores are predicated.
@@ -449,9 +493,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
             };
             chunk_load(t);
             if (MODE == PREC_STEP) {
-                const double rz = block_sum_n<kPrecWaves>(acc_rz, red);
-                const double pw = block_sum_n<kPrecWaves>(acc_pw, red);
-                alpha = pw > 0.0 ? rz / pw : 0.0;
+                block_sum2_n<kPrecWaves>(acc_rz, acc_pw, red);
+                alpha = acc_pw > 0.0 ? acc_rz / acc_pw : 0.0;
             }
             chunk_apply(t);
             for (int base = t + kPrecThreads * kPrecChunk; base < NB; base += kPrecThreads * kPrecChunk) {
@@ -738,6 +781,14 @@ struct ConeArgs {
     double alpha_relax;
     const double* invE;
     double* pres_part;  // 8 per block
+    // fused end-of-PCG update: the gathered vector is xt + a * pfin
+    int apply_alpha;
+    const double* pfin;
+    const double* pw_in;
+    const double* rz_in;
+    const int32_t* prec_part_ptr;
+    const int32_t* kblk_part_ptr;
+    double* step_out;   // per problem
 };
 
 __device__ __forceinline__ double a_row_dot(const ConeArgs& a, int i, const double* __restrict__ v) {
@@ -761,9 +812,20 @@ constexpr int kSmallCone = 4;    // rows
 constexpr int kConeRowNnz = 2;   // entries per row handled by the register path
 
 __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
+    __shared__ double red[8];
     const int b = blockIdx.x;
     const int prob = a.block_prob[b];
     if (a.done[prob]) return;
+    double step = 0.0;  // step length of the last PCG step (its xt update is applied on the fly)
+    if (a.apply_alpha) {
+        double rz = 0.0, pw = 0.0;
+        for (int i = a.prec_part_ptr[prob] + (int)threadIdx.x; i < a.prec_part_ptr[prob + 1]; i += kThreads) rz += a.rz_in[i];
+        for (int i = a.kblk_part_ptr[prob] + (int)threadIdx.x; i < a.kblk_part_ptr[prob + 1]; i += kThreads) pw += a.pw_in[i];
+        block_sum2(rz, pw, red);
+        step = pw > 0.0 ? rz / pw : 0.0;
+        // every block of the problem computes the same value; the next right-hand-side kernel reads it
+        if (threadIdx.x == 0) a.step_out[prob] = step;
+    }
     const int c = a.block_first[b] + threadIdx.x;
     if (c >= a.block_first[b + 1]) return;
     const int row = a.cone_row[c], dim = a.cone_dim[c], type = a.cone_type[c];
@@ -801,7 +863,10 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
 #pragma unroll
         for (int k = 0; k < kSmallCone; ++k)
 #pragma unroll
-            for (int e = 0; e < kConeRowNnz; ++e) xv[k][e] = a.xt[cc[k][e]];
+            for (int e = 0; e < kConeRowNnz; ++e) {
+                xv[k][e] = a.xt[cc[k][e]];
+                if (a.apply_alpha) xv[k][e] += step * a.pfin[cc[k][e]];
+            }
 #pragma unroll
         for (int k = 0; k < kSmallCone; ++k) {
             double tt = 0.0;
@@ -826,7 +891,8 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
     }
     for (int k = 0; k < dim; ++k) {
         const int i = row + k;
-        const double tt = a_row_dot(a, i, a.xt);
+        double tt = a_row_dot(a, i, a.xt);
+        if (a.apply_alpha) tt += step * a_row_dot(a, i, a.pfin);
         const double v = al * (a.b[i] - tt) + (1.0 - al) * a.s[i];
         const double wv = v - a.y[i] * irho;
         a.u[i] = v;   // stash v
