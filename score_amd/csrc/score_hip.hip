@@ -477,6 +477,9 @@ struct HipBackend {
             else if (which == "kpb") launch_kpb(p.d, p2.d, rz_part1.d, rz_part0.d);
             else if (which == "xupdate") hipLaunchKernelGGL(k_xupdate, dim3(K.nblocks), dim3(kThreads), 0, stream, va);
             else if (which == "cone") { if (n_cone_blocks) { ConeArgs ca = cone_args(xtu.d); ca.apply_alpha = 1; hipLaunchKernelGGL(k_cone, dim3(n_cone_blocks), dim3(kThreads), 0, stream, ca); } }
+            else if (which == "nop") hipLaunchKernelGGL(k_nop, dim3(K.nblocks), dim3(kThreads), 0, stream, (int*)nullptr);
+            else if (which == "nop1") hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, stream, (int*)nullptr);
+            else if (which == "nop_load") hipLaunchKernelGGL(k_nop_load, dim3(K.nblocks), dim3(kThreads), 0, stream, K.blk_prob.d, done.d, (int*)nullptr);
             else throw std::runtime_error("unknown kernel name");
         };
         for (int i = 0; i < 5; ++i) once();

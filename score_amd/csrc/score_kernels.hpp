@@ -958,4 +958,11 @@ __global__ __launch_bounds__(kThreads) void k_pres(ConeArgs a) {
     }
 }
 
+// launch-overhead probes (debug timing only)
+__global__ void k_nop(int* sink) { if (sink && threadIdx.x == 9999) sink[0] = 1; }
+__global__ void k_nop_load(const int32_t* a, const int32_t* b2, int* sink) {
+    const int p = a[blockIdx.x % 7];
+    if (b2[p & 1] == 12345 && sink) sink[0] = 1;
+}
+
 }  // namespace score
