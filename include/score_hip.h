@@ -92,6 +92,9 @@ typedef struct score_settings {
     int32_t chain_radix;       /* partition radix of the chain solver (2..4) */
     int32_t device;            /* HIP device ordinal                         */
     int32_t use_graph;         /* replay iterations from a hipGraph          */
+    int32_t polish;            /* 0/1: semismooth-Newton polish once ADMM is close (single problems whose
+                                  cones have private head variables, i.e. the SCORE SOCP form)          */
+    double  polish_start;      /* start it when both relative residuals are below this                  */
     int32_t verbose;
 } score_settings;
 
@@ -116,6 +119,8 @@ typedef struct score_info {
     double  setup_ms;          /* score_create time                          */
     double  solve_ms;          /* wall time of the last score_solve          */
     double  kkt_bytes;         /* algorithmic bytes of one K-apply (this problem) */
+    int32_t newton_iters;      /* Newton iterations of the polish (0 = not run) */
+    int32_t newton_cg_iters;   /* PCG iterations spent inside the polish     */
 } score_info;
 
 typedef struct score_handle score_handle;

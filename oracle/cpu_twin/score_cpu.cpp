@@ -38,6 +38,7 @@ struct CpuBackend {
     int cg_iters = 2;
 
     void set_cg_iters(int k) { cg_iters = k; }
+    bool polish(const HostSystem&, const score_settings&, int*, int*) { return false; }  // HIP backend only
     void cg_reduction(std::vector<double>& out) { out = cg_red; }
 
     void init(const HostSystem& h, const score_settings& s_) {
@@ -216,6 +217,7 @@ struct CpuBackend {
                 a.ax_s = std::max(a.ax_s, std::fabs(t));
                 a.s_s = std::max(a.s_s, std::fabs(s[i]));
                 a.by += h.b[i] * y[i];
+                a.sy_yrp += y[i] * (s[i] - pr);
                 if (pr != pr) a.rp_u = pr;
             }
             for (int64_t i = h.xoff[pi]; i < h.xoff[pi + 1]; ++i) {
@@ -232,6 +234,7 @@ struct CpuBackend {
                 a.aty_s = std::max(a.aty_s, std::fabs(aty));
                 a.xPx += x[i] * px;
                 a.qx += h.q[i] * x[i];
+                a.xrd += x[i] * dr;
                 if (dr != dr) a.rd_u = dr;
             }
             R[pi] = a;

@@ -22,6 +22,8 @@ struct ResidualSums {  // per problem, filled by the backend
     double rp_u = 0, ax_u = 0, s_u = 0, rp_s = 0, ax_s = 0, s_s = 0, by = 0;
     // dual side (G2 SpMV): inf-norms of Px+q+A'y, Px, A'y (unscaled, scaled), x'Px, q'x
     double rd_u = 0, px_u = 0, aty_u = 0, rd_s = 0, px_s = 0, aty_s = 0, xPx = 0, qx = 0;
+    // duality gap in its cancellation-free form: pobj - dobj = x'r_d + s'y - y'r_p
+    double xrd = 0, sy_yrp = 0;
 };
 
 inline double now_ms() {
@@ -39,6 +41,7 @@ struct Solver {
     int iters_done = 0;
     int cg_now = 2;       // PCG iterations per ADMM iteration currently in use
     int64_t cg_total = 0; // PCG iterations performed since reset
+    int next_polish = 0;  // earliest iteration of the next polish attempt
     double setup_ms = 0;
 
     void create(const score_problem* probs, int count, const score_settings& s) {
@@ -69,6 +72,7 @@ struct Solver {
         be.reset();
         if (cg_now != st.cg_iters) { cg_now = st.cg_iters; be.set_cg_iters(cg_now); }
         cg_total = 0;
+        next_polish = 0;
         iters_done = 0;
         std::fill(done.begin(), done.end(), 0);
         be.set_done(done);
@@ -90,8 +94,10 @@ struct Solver {
             I.res_pri = r.rp_u;
             I.res_dual = r.rd_u;
             I.pobj = 0.5 * r.xPx + r.qx + H.c0[p];
-            I.dobj = -0.5 * r.xPx - r.by + H.c0[p];
-            I.gap = std::fabs(I.pobj - I.dobj);
+            // x'Px + q'x + b'y evaluated as x'r_d + s'y - y'r_p: every factor is small near the
+            // optimum, whereas the textbook form cancels sums of magnitude 1e5..1e6
+            I.gap = std::fabs(r.xrd + r.sy_yrp);
+            I.dobj = I.pobj - (r.xrd + r.sy_yrp);
             I.kkt_bytes = H.kkt_bytes[p];
             const bool finite = std::isfinite(r.rp_u) && std::isfinite(r.rd_u) && std::isfinite(I.pobj);
             if (!finite) {
@@ -172,6 +178,19 @@ struct Solver {
             iters_done += k;
             cg_total += (int64_t)k * cg_now;
             all = check(true);
+            if (!all && st.polish && iters_done >= next_polish && H.count == 1) {
+                // Newton is globally convergent here (convex, line search), so by default it starts
+                // right after the first launch graph; polish_start can demand a closer ADMM iterate.
+                const score_info& I = infos[0];
+                if (std::max(I.res_pri, I.res_dual) <= st.polish_start) {
+                    int nit = 0, ncg = 0;
+                    const bool ok = be.polish(H, st, &nit, &ncg);
+                    infos[0].newton_iters += nit;
+                    infos[0].newton_cg_iters += ncg;
+                    if (ok) all = check(false);
+                    next_polish = iters_done + 20 * st.check_interval;  // a failed attempt is retried later
+                }
+            }
         }
         finish(x, y, s, out, t0);
         return 0;
@@ -228,6 +247,8 @@ inline void default_settings(score_settings* s) {
     s->chain_radix = 4;
     s->device = 0;
     s->use_graph = 1;
+    s->polish = 1;
+    s->polish_start = 1e30;
     s->verbose = 0;
 }
 

@@ -24,6 +24,7 @@
 
 #include "score_driver.hpp"
 #include "score_kernels.hpp"
+#include "score_polish.hpp"
 
 namespace {
 
@@ -105,6 +106,15 @@ struct HipBackend {
     DevBuf<ChainLevelDesc> levels;
     DevBuf<double> xtu, xy, s, r, z, p, p2, w, kx, step;
     DevBuf<double> pw_part, rz_part0, rz_part1, rz_meas0, rz_meas1, pres_part, dres_part;
+    // ---- semismooth-Newton polish (score_polish*.hpp) ----
+    PolishData Q;
+    CsrBufs Hm;
+    DevBuf<double> q_Pon, q_ccoef, q_Bbuf, q_fpart, q_X0, q_X1, q_g, q_delta, q_fac, q_dinv, q_work, q_dummy, q_gd, q_pw;
+    DevBuf<double> q_aabs, q_ck, q_theta, q_xstar;
+    DevBuf<int32_t> q_cptr, q_ccone, q_cab, q_head, q_ishead, q_posd, q_poss, q_diagpos, q_hblk_part;
+    double* h_newton = nullptr;  // pinned scratch for partial sums
+    size_t h_newton_n = 0;
+
     int cg_iters = 2;
     const double* last_rz = nullptr;  // r'z partials / direction of the pending end-of-PCG update
     const double* last_p = nullptr;
@@ -121,6 +131,7 @@ struct HipBackend {
         if (ev1) (void)hipEventDestroy(ev1);
         if (h_pres) (void)hipHostFree(h_pres);
         if (h_dres) (void)hipHostFree(h_dres);
+        if (h_newton) (void)hipHostFree(h_newton);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -174,13 +185,14 @@ struct HipBackend {
         pw_part.alloc(K.nblocks); rz_part0.alloc(n_prec); rz_part1.alloc(n_prec);
         rz_meas0.alloc(n_prec); rz_meas1.alloc(n_prec);
         cg_iters = st.cg_iters;
-        pres_part.alloc((size_t)std::max(1, n_cone_blocks) * 8);
-        dres_part.alloc((size_t)G2.nblocks * 8);
+        pres_part.alloc((size_t)std::max(1, n_cone_blocks) * kPartStride);
+        dres_part.alloc((size_t)G2.nblocks * kPartStride);
         HIP_CHECK(hipHostMalloc((void**)&h_pres, pres_part.n * sizeof(double)));
         HIP_CHECK(hipHostMalloc((void**)&h_dres, dres_part.n * sizeof(double)));
         std::vector<int32_t> dz(h.count, 0);
         done.upload(dz);
         upload_rho_values(h);
+        if (st.polish) init_polish(h);
         reset();
     }
 
@@ -394,21 +406,22 @@ struct HipBackend {
         for (int pi = 0; pi < h.count; ++pi) {
             ResidualSums a;
             for (int bl = h.cone_part_ptr[pi]; bl < h.cone_part_ptr[pi + 1]; ++bl) {
-                const double* o = h_pres + (size_t)bl * 8;
+                const double* o = h_pres + (size_t)bl * kPartStride;
                 a.rp_u = (o[0] != o[0]) ? o[0] : std::max(a.rp_u, o[0]);
                 a.ax_u = std::max(a.ax_u, o[1]); a.s_u = std::max(a.s_u, o[2]);
                 a.rp_s = (o[3] != o[3]) ? o[3] : std::max(a.rp_s, o[3]);
                 a.ax_s = std::max(a.ax_s, o[4]); a.s_s = std::max(a.s_s, o[5]);
                 a.by += o[6];
+                a.sy_yrp += o[7];
                 if (a.rp_u != a.rp_u) break;
             }
             for (int bl = h.rbG2.part_ptr[pi]; bl < h.rbG2.part_ptr[pi + 1]; ++bl) {
-                const double* o = h_dres + (size_t)bl * 8;
+                const double* o = h_dres + (size_t)bl * kPartStride;
                 a.rd_u = (o[0] != o[0]) ? o[0] : std::max(a.rd_u, o[0]);
                 a.px_u = std::max(a.px_u, o[1]); a.aty_u = std::max(a.aty_u, o[2]);
                 a.rd_s = (o[3] != o[3]) ? o[3] : std::max(a.rd_s, o[3]);
                 a.px_s = std::max(a.px_s, o[4]); a.aty_s = std::max(a.aty_s, o[5]);
-                a.xPx += o[6]; a.qx += o[7];
+                a.xPx += o[6]; a.qx += o[7]; a.xrd += o[8];
                 if (a.rd_u != a.rd_u) break;
             }
             R[pi] = a;
@@ -454,6 +467,220 @@ struct HipBackend {
             }
         }
         return sz;
+    }
+
+    void init_polish(const HostSystem& h) {
+        build_polish(h, Q);
+        if (!Q.available || h.count != 1) { Q.available = false; return; }
+        Hm.upload(Q.Hm, Q.rbH);
+        q_Pon.upload(Q.Pon); q_ccoef.upload(Q.ccoef); q_cptr.upload(Q.cptr); q_ccone.upload(Q.ccone); q_cab.upload(Q.cab);
+        q_head.upload(Q.head_col); q_ishead.upload(Q.is_head); q_aabs.upload(Q.a_abs); q_ck.upload(Q.ck);
+        q_theta.upload(Q.theta); q_xstar.upload(Q.xstar);
+        q_posd.upload(Q.pos_diag); q_poss.upload(Q.pos_sub); q_diagpos.upload(Q.diag_pos);
+        q_hblk_part.upload(Q.rbH.part_ptr);
+        const size_t nc = h.cone_row.size();
+        q_Bbuf.alloc(nc * Q.T * Q.T);
+        q_fpart.alloc((nc + kThreads - 1) / kThreads);
+        q_X0.alloc(h.n_tot + h.m_tot); q_X1.alloc(h.n_tot + h.m_tot);
+        q_g.alloc(h.n_tot); q_delta.alloc(h.n_tot); q_dummy.alloc(h.n_tot);
+        q_fac.alloc(h.fac.size()); q_dinv.alloc(h.dinv.size());
+        q_fac.zero(stream);  // separator slots of the spike region are never written (nor used)
+        q_work.alloc((size_t)std::max<int64_t>(1, h.scratch_nodes) * 2 * std::max(1, h.bs * h.bs));
+        q_gd.alloc((h.n_tot + kThreads - 1) / kThreads);
+        q_pw.alloc(Hm.nblocks);
+        h_newton_n = std::max<size_t>(std::max<size_t>(q_fpart.n, q_gd.n), std::max<size_t>((size_t)n_prec, 8)) + 8;
+        HIP_CHECK(hipHostMalloc((void**)&h_newton, h_newton_n * sizeof(double)));
+        // the diagonal regularisation keeps H positive definite along flat directions
+        // (landmarks all of whose cones are slack, gauge modes of robots no active cone ties down)
+        std::vector<double> pon = Q.Pon;
+        for (int64_t i = 0; i < h.n_tot; ++i) {
+            const int pd = find_in_row(Q.Hm, i, (int32_t)i);
+            if (pd >= 0 && !Q.is_head[i]) pon[pd] += 1e-9;
+        }
+        q_Pon.upload(pon);
+    }
+
+    PolishArgs polish_args(double* X) {
+        PolishArgs a{};
+        const HostSystem& h = *H;
+        a.ncones = (int)h.cone_row.size(); a.T = Q.T;
+        a.cone_row = cone_row.d; a.head_col = q_head.d; a.a_abs = q_aabs.d; a.ck = q_ck.d; a.theta = q_theta.d; a.xstar = q_xstar.d;
+        a.A_ptr = A_ptr.d; a.A_col = A_col.d; a.A_val = A_val.d; a.b = b.d;
+        a.u = X; a.nu = X + h.n_tot; a.Bbuf = q_Bbuf.d; a.fpart = q_fpart.d; a.n_tot = h.n_tot;
+        return a;
+    }
+
+    // F, |grad|_inf (unscaled) at the point stored in X = [u | .]; leaves nu in X, B blocks in
+    // q_Bbuf, the gradient in q_g and its negative in r
+    void newton_eval(double* X, double* F, double* gnorm) {
+        const HostSystem& h = *H;
+        PolishArgs pa = polish_args(X);
+        const int ncb = (int)q_fpart.n;
+        hipLaunchKernelGGL(k_newton_cone, dim3(ncb), dim3(kThreads), 0, stream, pa);
+        SpmvArgs ga = spmv_args(G2, X);
+        ga.is_head = q_ishead.d; ga.gout = q_g.d;
+        hipLaunchKernelGGL(k_spmv<MODE_GRAD>, dim3(G2.nblocks), dim3(kThreads), 0, stream, ga);
+        HIP_CHECK(hipMemcpyAsync(h_newton, q_fpart.d, ncb * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(h_dres, dres_part.d, dres_part.n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipGetLastError());
+        double f = 0.0, gmax = 0.0;
+        for (int i = 0; i < ncb; ++i) f += h_newton[i];
+        for (int bl = 0; bl < G2.nblocks; ++bl) {
+            const double* o = h_dres + (size_t)bl * kPartStride;
+            gmax = (o[0] != o[0]) ? o[0] : std::max(gmax, o[0]);
+            f += o[2];
+        }
+        (void)h;
+        *F = f;
+        *gnorm = gmax;
+    }
+
+    // Solve H delta = -g (r holds -g) with PCG on the device-factored chain preconditioner.
+    int newton_pcg(double rel_tol, int max_cg) {
+        const HostSystem& h = *H;
+        q_delta.zero(stream);
+        PrecArgs pa{};
+        pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = q_fac.d;
+        pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = done.d;
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d;
+        pa.r = r.d; pa.z = z.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d; pa.pw_part = q_pw.d;
+        double* rz_cur = rz_part0.d;
+        double* p_cur = p.d;
+        double* p_oth = p2.d;
+        pa.p = p_cur; pa.rz_in = nullptr; pa.rz_out = rz_cur;
+        launch_prec<PREC_INIT>(pa);
+        auto launch_hp = [&](const double* pd) {
+            SpmvArgs a = spmv_args(Hm, pd);
+            a.p = pd; a.pw_part = q_pw.d;
+            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, a);
+        };
+        auto launch_hpb = [&](const double* p_old, double* p_new, const double* rzn, const double* rzo) {
+            SpmvArgs a = spmv_args(Hm, p_old);
+            a.p = p_old; a.z = z.d; a.p_out = p_new; a.rz_new = rzn; a.rz_old = rzo; a.pw_part = q_pw.d;
+            hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, a);
+        };
+        launch_hp(p_cur);
+        auto sum_rz = [&](const double* dev) {
+            HIP_CHECK(hipMemcpyAsync(h_newton, dev, n_prec * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            double sacc = 0.0;
+            for (int i = 0; i < n_prec; ++i) sacc += h_newton[i];
+            return sacc;
+        };
+        const double rz0 = sum_rz(rz_cur);
+        if (!(rz0 > 0.0)) return 0;
+        int done_cg = 0;
+        while (done_cg < max_cg) {
+            const int chunk = 8;
+            for (int j = 0; j < chunk; ++j) {
+                double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
+                pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_nxt;
+                launch_prec<PREC_STEP>(pa);   // delta += a p ; r -= a w ; z = M^-1 r
+                launch_hpb(p_cur, p_oth, rz_nxt, rz_cur);
+                std::swap(p_cur, p_oth);
+                rz_cur = rz_nxt;
+            }
+            done_cg += chunk;
+            const double rzk = sum_rz(rz_cur);
+            if (!(rzk == rzk)) throw std::runtime_error("polish: NaN in PCG");
+            if (std::sqrt(std::max(0.0, rzk) / rz0) <= rel_tol) break;
+        }
+        (void)h;
+        return done_cg;
+    }
+
+    bool polish(const HostSystem& h, const score_settings& s_, int* newton_iters, int* cg_used) {
+        *newton_iters = 0; *cg_used = 0;
+        if (!Q.available || h.count != 1) return false;
+        HIP_CHECK(hipStreamSynchronize(stream));
+        const int nb_n = (int)q_gd.n;
+        double* X = q_X0.d;
+        double* Xt = q_X1.d;
+        NewtonVecArgs va{};
+        va.n = h.n_tot; va.is_head = q_ishead.d; va.g = q_g.d; va.part = q_gd.d;
+        // start from the ADMM iterate x (head variables are eliminated: kept at zero)
+        HIP_CHECK(hipMemsetAsync(q_g.d, 0, q_g.n * sizeof(double), stream));
+        va.u = xy.d; va.delta = xy.d; va.step = 0.0; va.out = X;
+        hipLaunchKernelGGL(k_newton_trial, dim3(nb_n), dim3(kThreads), 0, stream, va);
+        double F = 0, gn = 0;
+        newton_eval(X, &F, &gn);
+        const double tol = std::max(1e-12, 0.1 * s_.eps_abs);
+        const int bs = h.bs;
+        int it = 0, cg_tot = 0;
+        bool ok = true;
+        for (; it < 50 && gn > tol; ++it) {
+            // Hessian at X, its Jacobi diagonal and chain factors
+            HAsmArgs ha{};
+            ha.nnz = (int64_t)Q.Hm.col.size(); ha.Pon = q_Pon.d; ha.cptr = q_cptr.d; ha.ccone = q_ccone.d; ha.cab = q_cab.d;
+            ha.ccoef = q_ccoef.d; ha.Bbuf = q_Bbuf.d; ha.T2 = Q.T * Q.T; ha.Hval = Hm.val.d;
+            ha.ndiag = (int)h.diag_cols.size(); ha.diag_pos = q_diagpos.d; ha.dinv = q_dinv.d;
+            hipLaunchKernelGGL(k_hassemble, dim3((unsigned)((ha.nnz + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, ha);
+            if (ha.ndiag) hipLaunchKernelGGL(k_hdiag, dim3((ha.ndiag + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, ha);
+            if (n_prec && !h.chains.empty()) {
+                FactorArgs fa{};
+                fa.work = prec_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = Hm.val.d;
+                fa.pos_diag = q_posd.d; fa.pos_sub = q_poss.d; fa.fac = q_fac.d; fa.work_mat = q_work.d;
+                if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
+                else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
+                else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
+                else hipLaunchKernelGGL(k_factor<4>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
+            }
+            // inexact Newton: the linear residual only has to shrink superlinearly with |g|
+            const double eta = std::min(1e-2, std::max(1e-8, std::sqrt(gn)));
+            cg_tot += newton_pcg(eta, 400);
+            // backtracking on F (accept on the gradient when the decrease drowns in rounding)
+            double step = 1.0;
+            bool accepted = false;
+            double gd = 0.0;
+            for (int ls = 0; ls < 40; ++ls) {
+                va.u = X; va.delta = q_delta.d; va.step = step; va.out = Xt;
+                hipLaunchKernelGGL(k_newton_trial, dim3(nb_n), dim3(kThreads), 0, stream, va);
+                if (ls == 0) {
+                    HIP_CHECK(hipMemcpyAsync(h_newton, q_gd.d, nb_n * sizeof(double), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    for (int i = 0; i < nb_n; ++i) gd += h_newton[i];
+                }
+                double Ft = 0, gt = 0;
+                newton_eval(Xt, &Ft, &gt);   // note: overwrites q_g / r / B with the trial point's
+                const bool armijo = Ft <= F + 1e-4 * step * gd;
+                const bool tiny = std::fabs(step * gd) <= 1e-13 * std::max(1.0, std::fabs(F));
+                if ((Ft == Ft) && (armijo || (tiny && gt < gn))) {
+                    std::swap(X, Xt);
+                    F = Ft; gn = gt;
+                    accepted = true;
+                    break;
+                }
+                step *= 0.5;
+                // the gradient buffer now belongs to the rejected trial: restore it for the next g'delta
+                if (ls == 0) { /* gd already taken */ }
+            }
+            if (st.verbose) std::fprintf(stderr, "[score] newton it %d F %.12g |g| %.3e step %.3g cg %d\n", it + 1, F, gn, step, cg_tot);
+            if (!accepted) {
+                double Fx = 0, gx = 0;
+                newton_eval(X, &Fx, &gx);  // re-establish nu / B / g of the accepted point
+                ok = gn <= 10 * tol;
+                break;
+            }
+        }
+        *newton_iters = it;
+        *cg_used = cg_tot;
+        // hand the polished point to the ADMM state: x, x~, s, y, then u and K x~
+        va.u = X; va.delta = X; va.step = 0.0; va.out = Xt;
+        hipLaunchKernelGGL(k_polish_copy_x, dim3(nb_n), dim3(kThreads), 0, stream, va, xy.d, xtu.d);
+        FinishArgs fa2{};
+        fa2.P = polish_args(X);
+        fa2.x = xy.d; fa2.xt = xtu.d; fa2.s = this->s.d; fa2.y = xy.d + h.n_tot;
+        hipLaunchKernelGGL(k_polish_finish, dim3((unsigned)q_fpart.n), dim3(kThreads), 0, stream, fa2);
+        if (n_cone_blocks) hipLaunchKernelGGL(k_refresh_u, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xtu.d));
+        {
+            SpmvArgs a = spmv_args(K, xtu.d);
+            a.p = xtu.d; a.w = kx.d;
+            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
+        }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipGetLastError());
+        return ok;
     }
 
     void time_kernel(const std::string& which, int reps, double* ms) {

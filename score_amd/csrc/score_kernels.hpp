@@ -33,6 +33,7 @@ namespace score {
 constexpr int kThreads = 256;
 constexpr int kUnroll = kTileNnz / kThreads;  // 12 nonzeros per lane
 constexpr int kLongUnroll = 8;
+constexpr int kPartStride = 12;  // doubles per workgroup in the residual partial arrays
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -146,6 +147,9 @@ struct SpmvArgs {
     double alpha_relax;
     const double* step_in;  // per problem: step length of the last PCG step (written by k_cone)
     const int32_t* kblk_part_ptr;
+    // GRAD
+    const int32_t* is_head;
+    double* gout;           // gradient (r receives its negative)
     // DRES
     const double* invD;
     double* dres_part;      // 8 per block
@@ -155,7 +159,8 @@ struct SpmvArgs {
 // KP  : w = M p, partial p'w                           (M = K)
 // KPB : p_new = z + beta p_old (beta from partials), w = M p_new, partial p_new'w
 // DRES: dual residual norms                            (M = [P | A'], xin = [x ; y])
-enum { MODE_RHS = 0, MODE_KP = 1, MODE_DRES = 2, MODE_KPB = 3 };
+// GRAD: gradient of the reduced (head-eliminated) problem, M = [P | A'], xin = [u ; nu]
+enum { MODE_RHS = 0, MODE_KP = 1, MODE_DRES = 2, MODE_KPB = 3, MODE_GRAD = 4 };
 
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     if (r1 - r0 == 1 && nn > kLongRow) {
         // one long row: unrolled strided partial sums + tree reduction
         double acc = 0.0, acc2 = 0.0;
-        const int split = (MODE == MODE_DRES) ? a.M.split[r0] : k1;
+        const int split = (MODE == MODE_DRES || MODE == MODE_GRAD) ? a.M.split[r0] : k1;
         finish_beta();  // uniform: lanes beyond the row's end never enter the sweep
         for (int kb = k0 + t; kb < k1; kb += kThreads * kLongUnroll) {
             int32_t c[kLongUnroll];
@@ -220,11 +225,11 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
                 const int k = kb + u * kThreads;
                 if (MODE == MODE_KPB) g[u] += beta * g2[u];
                 const double pr = (k < k1) ? v[u] * g[u] : 0.0;
-                if (MODE == MODE_DRES && k >= split) acc2 += pr; else acc += pr;
+                if ((MODE == MODE_DRES || MODE == MODE_GRAD) && k >= split) acc2 += pr; else acc += pr;
             }
         }
         sum = block_sum(acc, red);
-        if (MODE == MODE_DRES) sum2 = block_sum(acc2, red);
+        if (MODE == MODE_DRES || MODE == MODE_GRAD) sum2 = block_sum(acc2, red);
         has_row = (t == 0);
         row = r0;
     } else {
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         if (row < r1) {
             has_row = true;
             const int a0 = srow[t], a1 = srow[t + 1];
-            if (MODE == MODE_DRES) {
+            if (MODE == MODE_DRES || MODE == MODE_GRAD) {
                 const int sp = a.M.split[row] - k0;
                 for (int k = a0; k < sp; ++k) sum += prod[k];
                 for (int k = sp; k < a1; ++k) sum2 += prod[k];
@@ -295,8 +300,30 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         }
         const double tot = block_sum(local, red);
         if (t == 0) a.pw_part[b] = tot;
+    } else if (MODE == MODE_GRAD) {  // sum = (P u)_i, sum2 = (A'nu)_i ; xin = [u ; nu]
+        double m0 = 0, m1 = 0, s0 = 0, bad = 0;
+        if (has_row) {
+            const bool head = a.is_head[row] != 0;
+            const double qi = a.q[row];
+            const double g = head ? 0.0 : sum + qi + sum2;
+            if (g != g) bad = 1.0;
+            a.gout[row] = g;
+            a.r[row] = -g;
+            m0 = fabs(g) * a.invD[row];
+            m1 = fabs(g);
+            const double xi = xin[row];
+            s0 = head ? 0.0 : xi * (0.5 * sum + qi);
+        }
+        bad = block_sum(bad, red);
+        m0 = block_max(m0, red); m1 = block_max(m1, red);
+        s0 = block_sum(s0, red);
+        if (t == 0) {
+            double* o = a.dres_part + (size_t)b * kPartStride;
+            const double nanv = bad > 0.0 ? __builtin_nan("") : 0.0;
+            o[0] = m0 + nanv; o[1] = m1; o[2] = s0;
+        }
     } else {  // MODE_DRES: sum = (P x)_i, sum2 = (A'y)_i ; xin = [x ; y]
-        double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, s0 = 0, s1 = 0, bad = 0;
+        double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, s0 = 0, s1 = 0, s2 = 0, bad = 0;
         if (has_row) {
             const double qi = a.q[row];
             const double dr = sum + qi + sum2;
@@ -307,15 +334,16 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
             const double xi = xin[row];
             s0 = xi * sum;
             s1 = qi * xi;
+            s2 = xi * dr;  // x'r_d: a cancellation-free piece of the duality gap
         }
         bad = block_sum(bad, red);
         m0 = block_max(m0, red); m1 = block_max(m1, red); m2 = block_max(m2, red);
         m3 = block_max(m3, red); m4 = block_max(m4, red); m5 = block_max(m5, red);
-        s0 = block_sum(s0, red); s1 = block_sum(s1, red);
+        s0 = block_sum(s0, red); s1 = block_sum(s1, red); s2 = block_sum(s2, red);
         if (t == 0) {
-            double* o = a.dres_part + (size_t)b * 8;
+            double* o = a.dres_part + (size_t)b * kPartStride;
             const double nanv = bad > 0.0 ? __builtin_nan("") : 0.0;
-            o[0] = m0 + nanv; o[1] = m1; o[2] = m2; o[3] = m3 + nanv; o[4] = m4; o[5] = m5; o[6] = s0; o[7] = s1;
+            o[0] = m0 + nanv; o[1] = m1; o[2] = m2; o[3] = m3 + nanv; o[4] = m4; o[5] = m5; o[6] = s0; o[7] = s1; o[8] = s2;
         }
     }
 }
@@ -932,7 +960,7 @@ __global__ __launch_bounds__(kThreads) void k_pres(ConeArgs a) {
     const int prob = a.block_prob[b];
     if (a.done[prob]) return;
     const int c = a.block_first[b] + threadIdx.x;
-    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, sby = 0, bad = 0;
+    double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, sby = 0, sgap = 0, bad = 0;
     if (c < a.block_first[b + 1]) {
         const int row = a.cone_row[c], dim = a.cone_dim[c];
         for (int k = 0; k < dim; ++k) {
@@ -945,16 +973,18 @@ __global__ __launch_bounds__(kThreads) void k_pres(ConeArgs a) {
             m0 = fmax(m0, fabs(pr) * ie); m1 = fmax(m1, fabs(tt) * ie); m2 = fmax(m2, fabs(si) * ie);
             m3 = fmax(m3, fabs(pr)); m4 = fmax(m4, fabs(tt)); m5 = fmax(m5, fabs(si));
             sby += a.b[i] * a.y[i];
+            sgap += a.y[i] * (si - pr);  // s'y - y'r_p
         }
     }
     bad = block_sum(bad, red);
     m0 = block_max(m0, red); m1 = block_max(m1, red); m2 = block_max(m2, red);
     m3 = block_max(m3, red); m4 = block_max(m4, red); m5 = block_max(m5, red);
     sby = block_sum(sby, red);
+    sgap = block_sum(sgap, red);
     if (threadIdx.x == 0) {
-        double* o = a.pres_part + (size_t)b * 8;
+        double* o = a.pres_part + (size_t)b * kPartStride;
         const double nanv = bad > 0.0 ? __builtin_nan("") : 0.0;
-        o[0] = m0 + nanv; o[1] = m1; o[2] = m2; o[3] = m3 + nanv; o[4] = m4; o[5] = m5; o[6] = sby; o[7] = 0.0;
+        o[0] = m0 + nanv; o[1] = m1; o[2] = m2; o[3] = m3 + nanv; o[4] = m4; o[5] = m5; o[6] = sby; o[7] = sgap;
     }
 }
 

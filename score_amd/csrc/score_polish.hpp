@@ -1,0 +1,394 @@
+// score_polish.hpp -- device kernels of the semismooth-Newton polish (see
+// score_polish_host.hpp for the mathematics).  These kernels run a handful of
+// times per solve; they are written for clarity, the hot kernels (SpMV, chain
+// solve) are shared with the ADMM loop.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "score_kernels.hpp"
+#include "score_polish_host.hpp"
+
+namespace score {
+
+struct PolishArgs {
+    // cones
+    int ncones;
+    int T;
+    const int32_t* cone_row;
+    const int32_t* head_col;
+    const double* a_abs;
+    const double* ck;
+    const double* theta;
+    const double* xstar;
+    const int32_t* A_ptr;
+    const int32_t* A_col;
+    const double* A_val;
+    const double* b;
+    // vectors
+    const double* u;      // [u | nu] buffer: Newton iterate (head entries zero) followed by nu (m)
+    double* nu;           // = u + n_tot
+    double* Bbuf;         // T*T per cone
+    double* fpart;        // per cone block: partial sum of the cone terms of F
+    int64_t n_tot;
+};
+
+// Per cone: t = b_tail - A_tail u, multiplier nu = -c max(0,|t|-theta) t/|t|, Hessian block.
+__global__ __launch_bounds__(kThreads) void k_newton_cone(PolishArgs a) {
+    __shared__ double red[8];
+    const int k = blockIdx.x * kThreads + threadIdx.x;
+    double phi = 0.0;
+    if (k < a.ncones) {
+        const int T = a.T;
+        const int r0 = a.cone_row[k];
+        double t[kPolishMaxTail];
+        double rho2 = 0.0;
+        for (int c = 0; c < T; ++c) {
+            const int r = r0 + 1 + c;
+            double acc = a.b[r];
+            for (int e = a.A_ptr[r]; e < a.A_ptr[r + 1]; ++e) acc -= a.A_val[e] * a.u[a.A_col[e]];
+            t[c] = acc;
+            rho2 += acc * acc;
+        }
+        const double rho = sqrt(rho2);
+        const double th = a.theta[k], ck = a.ck[k];
+        const double ex = rho > th ? rho - th : 0.0;
+        phi = 0.5 * ck * ex * ex;
+        const bool act = ex > 0.0 && rho > 0.0;
+        const double ir = act ? 1.0 / rho : 0.0;
+        a.nu[r0] = 0.0;
+        for (int c = 0; c < T; ++c) a.nu[r0 + 1 + c] = act ? -ck * ex * t[c] * ir : 0.0;
+        // B = c [ (1 - theta/rho)(I - uu') + uu' ]  on active cones, 0 otherwise
+        const double w1 = act ? ck * (1.0 - th * ir) : 0.0;
+        const double w2 = act ? ck * th * ir : 0.0;  // coefficient of uu' beyond w1: c - w1 = c*theta/rho
+        for (int c = 0; c < T; ++c)
+            for (int d = 0; d < T; ++d)
+                a.Bbuf[(size_t)k * T * T + c * T + d] = (c == d ? w1 : 0.0) + w2 * (t[c] * ir) * (t[d] * ir);
+    }
+    const double tot = block_sum(phi, red);
+    if (threadIdx.x == 0) a.fpart[blockIdx.x] = tot;
+}
+
+struct HAsmArgs {
+    int64_t nnz;
+    const double* Pon;
+    const int32_t* cptr;
+    const int32_t* ccone;
+    const int32_t* cab;
+    const double* ccoef;
+    const double* Bbuf;
+    int T2;
+    double* Hval;
+    // Jacobi part
+    int ndiag;
+    const int32_t* diag_pos;
+    double* dinv;
+};
+
+__global__ __launch_bounds__(kThreads) void k_hassemble(HAsmArgs a) {
+    const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (p >= a.nnz) return;
+    double v = a.Pon[p];
+    for (int c = a.cptr[p]; c < a.cptr[p + 1]; ++c) v += a.ccoef[c] * a.Bbuf[(size_t)a.ccone[c] * a.T2 + a.cab[c]];
+    a.Hval[p] = v;
+}
+__global__ __launch_bounds__(kThreads) void k_hdiag(HAsmArgs a) {
+    const int e = blockIdx.x * kThreads + threadIdx.x;
+    if (e < a.ndiag) a.dinv[e] = 1.0 / a.Hval[a.diag_pos[e]];
+}
+
+// ---------------------------------------------------------------------------
+// device-side multi-level factorisation of the chains of H (mirror of
+// factor_chain_levels in score_host.hpp; one 256-thread workgroup per chain)
+// ---------------------------------------------------------------------------
+template <int BS>
+struct SmallMat {
+    static constexpr int B2 = BS * BS;
+    __device__ static void mul(const double* A, const double* B, double* C) {
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < BS; ++k) s += A[i * BS + k] * B[k * BS + j];
+                C[i * BS + j] = s;
+            }
+    }
+    __device__ static void mul_bt(const double* A, const double* B, double* C) {  // A B'
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < BS; ++k) s += A[i * BS + k] * B[j * BS + k];
+                C[i * BS + j] = s;
+            }
+    }
+    __device__ static void mul_at(const double* A, const double* B, double* C) {  // A' B
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < BS; ++k) s += A[k * BS + i] * B[k * BS + j];
+                C[i * BS + j] = s;
+            }
+    }
+    // Gauss-Jordan without pivoting: the blocks are SPD Schur complements
+    __device__ static void inv(const double* A, double* Ai) {
+        double M[BS][2 * BS];
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) { M[i][j] = A[i * BS + j]; M[i][BS + j] = (i == j) ? 1.0 : 0.0; }
+#pragma unroll
+        for (int c = 0; c < BS; ++c) {
+            const double ip = 1.0 / M[c][c];
+#pragma unroll
+            for (int j = 0; j < 2 * BS; ++j) M[c][j] *= ip;
+#pragma unroll
+            for (int r = 0; r < BS; ++r) {
+                if (r == c) continue;
+                const double f = M[r][c];
+#pragma unroll
+                for (int j = 0; j < 2 * BS; ++j) M[r][j] -= f * M[c][j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BS; ++i)
+#pragma unroll
+            for (int j = 0; j < BS; ++j) Ai[i * BS + j] = M[i][BS + j];
+    }
+};
+
+struct FactorArgs {
+    const PrecWork* work;      // only kind == 0 items are processed
+    const ChainDesc* chains;
+    const ChainLevelDesc* levels;
+    const double* Hval;
+    const int32_t* pos_diag;   // per level-0 node, bs*bs positions in Hval
+    const int32_t* pos_sub;
+    double* fac;               // output, same layout as the ADMM factor
+    double* work_mat;          // level >= 1 matrices: 2*bs*bs doubles per scratch node
+};
+
+template <int BS>
+__global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
+    constexpr int B2 = BS * BS;
+    using SM = SmallMat<BS>;
+    const PrecWork wk = a.work[blockIdx.x];
+    if (wk.kind != 0) return;
+    const ChainDesc ch = a.chains[wk.index];
+    const ChainLevelDesc* lv = a.levels + ch.level_begin;
+    const int t = threadIdx.x;
+    // block accessors: level 0 gathers from H through the position tables, levels >= 1 read
+    // the Schur complements written by the previous level
+    auto loadA = [&](int l, const ChainLevelDesc& L, int i, double* out) {
+        if (l == 0) {
+            const int32_t* pd = a.pos_diag + (size_t)(ch.node_begin + i) * B2;
+            for (int e = 0; e < B2; ++e) out[e] = pd[e] >= 0 ? a.Hval[pd[e]] : 0.0;
+        } else {
+            const double* src = a.work_mat + ((size_t)(ch.scratch_off + L.vec_off + i) * 2 + 0) * B2;
+            for (int e = 0; e < B2; ++e) out[e] = src[e];
+        }
+    };
+    auto loadB = [&](int l, const ChainLevelDesc& L, int i, double* out) {  // T[i, i-1]
+        if (l == 0) {
+            const int32_t* ps = a.pos_sub + (size_t)(ch.node_begin + i) * B2;
+            for (int e = 0; e < B2; ++e) out[e] = (i > 0 && ps[e] >= 0) ? a.Hval[ps[e]] : 0.0;
+        } else {
+            const double* src = a.work_mat + ((size_t)(ch.scratch_off + L.vec_off + i) * 2 + 1) * B2;
+            for (int e = 0; e < B2; ++e) out[e] = src[e];
+        }
+    };
+    for (int l = 0; l < ch.n_levels; ++l) {
+        const ChainLevelDesc L = lv[l];
+        const bool last = (L.p == 0);
+        const int nsep = L.nsep;
+        double* R = a.fac + L.offR;
+        double* S = a.fac + L.offS;
+        double* Bk = a.fac + L.offB;
+        const size_t eP = (size_t)L.P * L.nruns;
+        auto Rst = [&](int slot, int q, int j, const double* M) {
+            for (int e = 0; e < B2; ++e) R[((size_t)(slot * B2 + e) * L.P + q) * L.nruns + j] = M[e];
+        };
+        auto Rld = [&](int slot, int q, int j, double* M) {
+            for (int e = 0; e < B2; ++e) M[e] = R[((size_t)(slot * B2 + e) * L.P + q) * L.nruns + j];
+        };
+        auto Bst = [&](int slot, int i, const double* M) {
+            for (int e = 0; e < B2; ++e) Bk[(size_t)(slot * B2 + e) * L.N + i] = M[e];
+        };
+        auto Bld = [&](int slot, int i, double* M) {
+            for (int e = 0; e < B2; ++e) M[e] = Bk[(size_t)(slot * B2 + e) * L.N + i];
+        };
+        (void)eP;
+        // ---- runs: block LDL' and the two spikes ----
+        for (int j = t; j < L.nruns; j += kThreads) {
+            const int lo = last ? 0 : j * L.p;
+            const int hi = last ? L.N : min(j * L.p + L.p - 1, L.N);
+            const int len = hi - lo;
+            if (len <= 0) continue;
+            double Ai[B2], Bi[B2], D[B2], Dinv_prev[B2], Lf[B2], T1[B2];
+            for (int q = 0; q < len; ++q) {
+                loadA(l, L, lo + q, Ai);
+                if (q == 0) {
+                    for (int e = 0; e < B2; ++e) { D[e] = Ai[e]; Lf[e] = 0.0; }
+                } else {
+                    loadB(l, L, lo + q, Bi);
+                    SM::mul(Bi, Dinv_prev, Lf);   // Lf = B Dinv_prev
+                    SM::mul_bt(Lf, Bi, T1);       // Lf B'
+                    for (int e = 0; e < B2; ++e) D[e] = Ai[e] - T1[e];
+                }
+                SM::inv(D, Dinv_prev);
+                Rst(0, q, j, Lf);
+                Rst(1, q, j, Dinv_prev);
+            }
+            if (last) continue;
+            const bool hasL = (j >= 1), hasR = (j < nsep);
+            for (int side = 0; side < 2; ++side) {
+                double Y[kMaxBs - 1][B2];  // run length <= radix - 1 <= 3
+                const bool on = (side == 0) ? hasL : hasR;
+                for (int q = 0; q < len; ++q)
+                    for (int e = 0; e < B2; ++e) Y[q][e] = 0.0;
+                if (on) {
+                    // right-hand side block: V: B[lo] at q = 0;  W: B[hi]' at q = len - 1
+                    if (side == 0) {
+                        loadB(l, L, lo, Y[0]);
+                    } else {
+                        loadB(l, L, hi, Bi);
+                        for (int r = 0; r < BS; ++r)
+                            for (int c = 0; c < BS; ++c) Y[len - 1][r * BS + c] = Bi[c * BS + r];
+                    }
+                    for (int q = 1; q < len; ++q) {  // forward: a_q -= Lf_q a_{q-1}
+                        Rld(0, q, j, Lf);
+                        SM::mul(Lf, Y[q - 1], T1);
+                        for (int e = 0; e < B2; ++e) Y[q][e] -= T1[e];
+                    }
+                    for (int q = len - 1; q >= 0; --q) {  // y_q = Dinv_q a_q - Lf_{q+1}' y_{q+1}
+                        Rld(1, q, j, D);
+                        SM::mul(D, Y[q], T1);
+                        if (q + 1 < len) {
+                            Rld(0, q + 1, j, Lf);
+                            double T2[B2];
+                            SM::mul_at(Lf, Y[q + 1], T2);
+                            for (int e = 0; e < B2; ++e) T1[e] -= T2[e];
+                        }
+                        for (int e = 0; e < B2; ++e) Y[q][e] = T1[e];
+                    }
+                }
+                for (int q = 0; q < len; ++q) Bst(side, lo + q, Y[q]);
+            }
+        }
+        __syncthreads();
+        if (last) break;
+        // ---- separators: coupling blocks and the Schur complement = next level's matrix ----
+        const ChainLevelDesc Ln = lv[l + 1];
+        for (int j = t; j < nsep; j += kThreads) {
+            const int s = j * L.p + L.p - 1;
+            double Cl[B2], Cr[B2], As[B2], M1[B2], T1[B2];
+            loadB(l, L, s, Cl);  // T[s, s-1]
+            loadA(l, L, s, As);
+            for (int e = 0; e < B2; ++e) Cr[e] = 0.0;
+            Bld(1, s - 1, M1);   // W_{s-1}
+            SM::mul(Cl, M1, T1);
+            for (int e = 0; e < B2; ++e) As[e] -= T1[e];
+            if (s + 1 < L.N) {
+                double Bn[B2];
+                loadB(l, L, s + 1, Bn);
+                for (int r = 0; r < BS; ++r)
+                    for (int c = 0; c < BS; ++c) Cr[r * BS + c] = Bn[c * BS + r];
+                Bld(0, s + 1, M1);  // V_{s+1}
+                SM::mul(Cr, M1, T1);
+                for (int e = 0; e < B2; ++e) As[e] -= T1[e];
+            }
+            for (int e = 0; e < B2; ++e) {
+                S[(size_t)(0 * B2 + e) * nsep + j] = Cl[e];
+                S[(size_t)(1 * B2 + e) * nsep + j] = Cr[e];
+            }
+            double* dstA = a.work_mat + ((size_t)(ch.scratch_off + Ln.vec_off + j) * 2 + 0) * B2;
+            double* dstB = a.work_mat + ((size_t)(ch.scratch_off + Ln.vec_off + j) * 2 + 1) * B2;
+            for (int e = 0; e < B2; ++e) dstA[e] = As[e];
+            if (j >= 1) {
+                Bld(0, s - 1, M1);  // V_{s-1}
+                SM::mul(Cl, M1, T1);
+                for (int e = 0; e < B2; ++e) dstB[e] = -T1[e];
+            } else {
+                for (int e = 0; e < B2; ++e) dstB[e] = 0.0;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// small vector kernels of the Newton loop
+// ---------------------------------------------------------------------------
+struct NewtonVecArgs {
+    int64_t n;
+    const int32_t* is_head;
+    const double* u;
+    const double* delta;
+    double step;
+    double* out;          // trial point / accepted point (head entries stay 0)
+    const double* g;      // gradient (= -r)
+    double* part;         // per block: partial g'delta
+};
+
+__global__ __launch_bounds__(kThreads) void k_newton_trial(NewtonVecArgs a) {
+    __shared__ double red[8];
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    double gd = 0.0;
+    if (i < a.n) {
+        const bool head = a.is_head[i] != 0;
+        const double d = head ? 0.0 : a.delta[i];
+        a.out[i] = head ? 0.0 : a.u[i] + a.step * d;
+        gd = a.g[i] * d;
+    }
+    const double tot = block_sum(gd, red);
+    if (threadIdx.x == 0) a.part[blockIdx.x] = tot;
+}
+
+struct FinishArgs {
+    PolishArgs P;        // P.u = accepted Newton iterate (+ nu after it)
+    double* x;           // ADMM x (n)  -- receives u with the head variables filled in
+    double* xt;          // ADMM x~
+    double* s;
+    double* y;
+};
+
+// copy the non-head entries
+__global__ __launch_bounds__(kThreads) void k_polish_copy_x(NewtonVecArgs a, double* x, double* xt) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < a.n && !a.is_head[i]) { x[i] = a.u[i]; xt[i] = a.u[i]; }
+}
+// per cone: head variable, s = b - A x, y = (|nu_tail|, nu_tail)
+__global__ __launch_bounds__(kThreads) void k_polish_finish(FinishArgs f) {
+    const PolishArgs& a = f.P;
+    const int k = blockIdx.x * kThreads + threadIdx.x;
+    if (k >= a.ncones) return;
+    const int T = a.T;
+    const int r0 = a.cone_row[k];
+    double rho2 = 0.0, y2 = 0.0;
+    for (int c = 0; c < T; ++c) {
+        const int r = r0 + 1 + c;
+        double acc = a.b[r];
+        for (int e = a.A_ptr[r]; e < a.A_ptr[r + 1]; ++e) acc -= a.A_val[e] * a.u[a.A_col[e]];
+        f.s[r] = acc;
+        rho2 += acc * acc;
+        const double yv = a.nu[r];
+        f.y[r] = yv;
+        y2 += yv * yv;
+    }
+    const double rho = sqrt(rho2);
+    const double xh = fmax(a.xstar[k], rho / a.a_abs[k]);
+    const int h = a.head_col[k];
+    f.x[h] = xh;
+    f.xt[h] = xh;
+    f.s[r0] = a.a_abs[k] * xh;  // b_head = 0, A[head, h] = -a_abs
+    f.y[r0] = sqrt(y2);
+}
+
+}  // namespace score

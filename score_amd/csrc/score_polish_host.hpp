@@ -1,0 +1,147 @@
+// score_polish_host.hpp -- host-side setup of the semismooth-Newton polish.
+//
+// Structure exploited (detected from the conic data, no extra ABI): every cone is
+// a second-order cone whose HEAD variable h is private -- it appears in exactly
+// one row of A (its own head row, coefficient a < 0, b_head = 0) and only on the
+// diagonal of P.  That is the SCORE "SOCP" relaxation (score/utils/gurobi_utils.py
+// :289-294 distance variable, :345-352 cone, :486-487 cost).  Minimising over the
+// head variables in closed form leaves the unconstrained, C^1, piecewise-quadratic
+//
+//     F(u) = 1/2 u'P u + q'u + sum_k 1/2 c_k max(0, |t_k(u)| - theta_k)^2 ,
+//     t_k(u) = b_tail,k - A_tail,k u ,  c_k = P_hh / a^2 ,  theta_k = |a| (-q_h / P_hh)
+//
+// (everything in the equilibrated variables).  Its generalised Hessian is
+// P + A_tail' B A_tail with one (dim-1)x(dim-1) block per ACTIVE cone, i.e. a
+// sparse SPD matrix on a fixed superset pattern "H".  The Newton systems are
+// solved by the same PCG + chain-preconditioner kernels as the ADMM KKT systems.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <vector>
+
+#include "score_host.hpp"
+
+namespace score {
+
+constexpr int kPolishMaxTail = 3;  // tail dimension d of SOC(d + 1), d in {2, 3}
+
+struct PolishData {
+    bool available = false;
+    int T = 0;  // tail dimension (uniform over the batch)
+    // per cone (same order as HostSystem::cone_row)
+    std::vector<int32_t> head_col;
+    std::vector<double> a_abs, ck, theta, xstar;
+    std::vector<int32_t> is_head;  // per column
+    // Newton matrix pattern, P on that pattern, contribution lists
+    Csr Hm;
+    std::vector<double> Pon;
+    std::vector<int32_t> cptr, ccone, cab;
+    std::vector<double> ccoef;
+    RowBlocks rbH;
+    // chain / Jacobi positions in Hm.val
+    std::vector<int32_t> pos_diag, pos_sub, diag_pos;
+};
+
+inline void build_polish(const HostSystem& H, PolishData& Q) {
+    Q = PolishData();
+    const int64_t n = H.n_tot, m = H.m_tot;
+    const size_t ncones = H.cone_row.size();
+    if (ncones == 0 || m == 0) return;
+    // ---- structure detection ----
+    int T = H.cone_dim[0] - 1;
+    if (T < 1 || T > kPolishMaxTail) return;
+    Q.head_col.assign(ncones, -1);
+    Q.a_abs.assign(ncones, 0.0); Q.ck.assign(ncones, 0.0); Q.theta.assign(ncones, 0.0); Q.xstar.assign(ncones, 0.0);
+    Q.is_head.assign(n, 0);
+    std::vector<int32_t> cone_of_row(m, -1);
+    for (size_t k = 0; k < ncones; ++k) {
+        if (H.cone_type[k] != 1 || H.cone_dim[k] - 1 != T) return;
+        const int r0 = H.cone_row[k];
+        for (int a = 0; a <= T; ++a) cone_of_row[r0 + a] = (int32_t)k;
+        if (H.A.ptr[r0 + 1] - H.A.ptr[r0] != 1) return;
+        const int32_t h = H.A.col[H.A.ptr[r0]];
+        const double a = H.A.val[H.A.ptr[r0]];
+        if (!(a < 0.0) || H.b[r0] != 0.0) return;
+        // column h: a single entry in A (this one) and a positive diagonal-only row in P
+        if (H.G2.ptr[h + 1] - H.g2_split[h] != 1) return;
+        if (H.g2_split[h] - H.G2.ptr[h] != 1 || H.G2.col[H.G2.ptr[h]] != h) return;
+        const double phh = H.G2.val[H.G2.ptr[h]];
+        if (!(phh > 0.0)) return;
+        Q.head_col[k] = h;
+        Q.is_head[h] = 1;
+        Q.a_abs[k] = -a;
+        Q.ck[k] = phh / (a * a);
+        Q.xstar[k] = -H.q[h] / phh;
+        Q.theta[k] = -a * Q.xstar[k];
+    }
+    Q.T = T;
+    // ---- Newton matrix pattern + contribution lists ----
+    struct Contrib { int32_t j, cone, ab; double coef; };
+    std::vector<Contrib> rowc;
+    Q.Hm.nrows = Q.Hm.ncols = n;
+    Q.Hm.ptr.assign(1, 0);
+    Q.cptr.assign(1, 0);
+    for (int64_t i = 0; i < n; ++i) {
+        rowc.clear();
+        if (Q.is_head[i]) {  // decoupled: unit diagonal, the Newton step leaves it alone
+            Q.Hm.col.push_back((int32_t)i);
+            Q.Pon.push_back(1.0);
+            Q.cptr.push_back((int32_t)Q.ccone.size());
+            Q.Hm.ptr.push_back((int32_t)Q.Hm.col.size());
+            continue;
+        }
+        for (int k = H.G2.ptr[i]; k < H.g2_split[i]; ++k)  // P row (cone = -1 marks a P entry)
+            rowc.push_back(Contrib{H.G2.col[k], -1, 0, H.G2.val[k]});
+        bool has_diag = false;
+        for (const auto& c : rowc) has_diag = has_diag || (c.j == i);
+        if (!has_diag) rowc.push_back(Contrib{(int32_t)i, -1, 0, 0.0});
+        for (int t = H.g2_split[i]; t < H.G2.ptr[i + 1]; ++t) {  // rows of A that contain column i
+            const int r = H.G2.col[t] - (int32_t)n;
+            const double vi = H.G2.val[t];
+            const int cone = cone_of_row[r];
+            const int r0 = H.cone_row[cone];
+            const int a = r - r0 - 1;  // tail index of row r
+            if (a < 0) continue;       // (head rows only hold the head column)
+            for (int b = 0; b < T; ++b) {
+                const int rb = r0 + 1 + b;
+                for (int kk = H.A.ptr[rb]; kk < H.A.ptr[rb + 1]; ++kk)
+                    rowc.push_back(Contrib{H.A.col[kk], cone, a * T + b, vi * H.A.val[kk]});
+            }
+        }
+        std::stable_sort(rowc.begin(), rowc.end(), [](const Contrib& x, const Contrib& y) { return x.j < y.j; });
+        size_t e = 0;
+        while (e < rowc.size()) {
+            const int32_t j = rowc[e].j;
+            double pval = 0.0;
+            for (; e < rowc.size() && rowc[e].j == j; ++e) {
+                if (rowc[e].cone < 0) pval += rowc[e].coef;
+                else { Q.ccone.push_back(rowc[e].cone); Q.cab.push_back(rowc[e].ab); Q.ccoef.push_back(rowc[e].coef); }
+            }
+            Q.Hm.col.push_back(j);
+            Q.Pon.push_back(pval);
+            Q.cptr.push_back((int32_t)Q.ccone.size());
+        }
+        Q.Hm.ptr.push_back((int32_t)Q.Hm.col.size());
+    }
+    Q.Hm.val.assign(Q.Hm.col.size(), 0.0);
+    Q.rbH = make_rowblocks(Q.Hm, H.xoff);
+    // ---- chain block / Jacobi positions in H ----
+    const int bs = H.bs;
+    Q.pos_diag.clear(); Q.pos_sub.clear();
+    for (const auto& ch : H.chains)
+        for (int i = 0; i < ch.N; ++i) {
+            const int32_t col = H.node_col[ch.node_begin + i];
+            for (int a = 0; a < bs; ++a)
+                for (int b = 0; b < bs; ++b) {
+                    Q.pos_diag.push_back(find_in_row(Q.Hm, col + a, col + b));
+                    if (i > 0) Q.pos_sub.push_back(find_in_row(Q.Hm, col + a, H.node_col[ch.node_begin + i - 1] + b));
+                    else Q.pos_sub.push_back(-1);
+                }
+        }
+    Q.diag_pos.clear();
+    for (int32_t c : H.diag_cols) Q.diag_pos.push_back(find_in_row(Q.Hm, c, c));
+    Q.available = true;
+}
+
+}  // namespace score

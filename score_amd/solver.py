@@ -44,7 +44,7 @@ class ScoreSettings(C.Structure):
         ("adaptive_rho", C.c_int32), ("adaptive_rho_interval", C.c_int32),
         ("adaptive_rho_tol", C.c_double),
         ("chain_radix", C.c_int32), ("device", C.c_int32),
-        ("use_graph", C.c_int32), ("verbose", C.c_int32),
+        ("use_graph", C.c_int32), ("polish", C.c_int32), ("polish_start", C.c_double), ("verbose", C.c_int32),
     ]
 
 
@@ -54,6 +54,7 @@ class ScoreInfo(C.Structure):
         ("rho", C.c_double), ("pobj", C.c_double), ("dobj", C.c_double),
         ("res_pri", C.c_double), ("res_dual", C.c_double), ("gap", C.c_double),
         ("setup_ms", C.c_double), ("solve_ms", C.c_double), ("kkt_bytes", C.c_double),
+        ("newton_iters", C.c_int32), ("newton_cg_iters", C.c_int32),
     ]
 
     def as_dict(self) -> dict:
