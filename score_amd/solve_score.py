@@ -136,10 +136,23 @@ def solve_score(
 
 def solve_score_batch(
     datas: Sequence, relaxation_type: str = QCQP_RELAXATION, qcqp_mode: str = "via_socp",
-    solver_settings: Optional[dict] = None, lib_path: Optional[str] = None,
+    solver_settings: Optional[dict] = None, lib_path: Optional[str] = None, lockstep: Optional[bool] = None,
 ) -> List[compat.SolverResults]:
-    """Independent factor graphs solved in lock-step by one set of launches."""
+    """Independent factor graphs on one GPU.
+
+    ``lockstep=True``: all graphs advance through the same kernel launches (ADMM
+    only; per-problem penalties and termination) -- best device utilisation per
+    iteration.  ``lockstep=False``: one after another, each with the
+    semismooth-Newton polish (5-20x fewer milliseconds per problem than ADMM
+    alone).  Default: sequential whenever the polish applies (SOCP form, polish
+    not disabled), lock-step otherwise."""
     check_valid_relaxation(relaxation_type)
+    if lockstep is None:
+        direct_qcqp = relaxation_type == QCQP_RELAXATION and qcqp_mode == "direct"
+        lockstep = direct_qcqp or not (solver_settings or {}).get("polish", 1)
+    if not lockstep and len(datas) > 1:
+        return [solve_score_batch([d], relaxation_type, qcqp_mode, solver_settings, lib_path, lockstep=True)[0]
+                for d in datas]
     if qcqp_mode not in ("via_socp", "direct"):
         raise ValueError(f"qcqp_mode {qcqp_mode} is not supported")
     models = []

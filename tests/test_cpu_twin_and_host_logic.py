@@ -65,7 +65,7 @@ def test_qcqp_direct_equals_via_socp(fixtures, twin_lib):
 
 def test_batch_equals_individual(twin_lib):
     graphs = [make_manhattan(n_robots=3, n_poses=40 + 10 * (s % 4), n_beacons=4, seed=s, p_range=0.4) for s in (300, 303, 305)]
-    batch = solve_score_batch(graphs, "SOCP", lib_path=twin_lib)
+    batch = solve_score_batch(graphs, "SOCP", lib_path=twin_lib, lockstep=True)
     for g, rb in zip(graphs, batch):
         ri = solve_score(g, "SOCP", lib_path=twin_lib)
         assert rb.solved and ri.solved

@@ -77,8 +77,8 @@ def test_qcqp_direct_on_gpu(fixtures, hip_lib):
 
 def test_deterministic_and_batch(hip_lib):
     graphs = [make_manhattan(n_robots=3, n_poses=40 + 10 * (s % 4), n_beacons=4, seed=s, p_range=0.4) for s in (300, 303, 305, 307)]
-    b1 = solve_score_batch(graphs, "SOCP")
-    b2 = solve_score_batch(graphs, "SOCP")
+    b1 = solve_score_batch(graphs, "SOCP", lockstep=True)
+    b2 = solve_score_batch(graphs, "SOCP", lockstep=True)
     for g, r1, r2 in zip(graphs, b1, b2):
         ri = solve_score(g, "SOCP", solver_settings=dict(polish=0))  # batches run without the polish
         assert r1.solved and ri.solved and r1.info["iters"] == ri.info["iters"]
@@ -191,7 +191,9 @@ def test_newton_polish_on_degenerate_and_unsupported_cases(hip_lib):
     assert res.info["pobj"] == pytest.approx(info["objective"], rel=1e-7, abs=1e-9)
     # batches and cone programs without the private-head structure simply skip the polish
     graphs = [make_manhattan(n_robots=3, n_poses=40 + 10 * (s % 4), n_beacons=4, seed=s, p_range=0.4) for s in (300, 303)]
-    for r in solve_score_batch(graphs, "SOCP"):
+    for r in solve_score_batch(graphs, "SOCP", lockstep=True):
         assert r.solved and r.info["newton_iters"] == 0
+    for r in solve_score_batch(graphs, "SOCP"):  # default: one after another, polished
+        assert r.solved and r.info["newton_iters"] > 0
     rd = solve_score(graphs[0], "QCQP", qcqp_mode="direct")
     assert rd.solved and rd.info["newton_iters"] == 0
