@@ -111,7 +111,8 @@ struct HipBackend {
     CsrBufs Hm;
     DevBuf<double> q_Pon, q_ccoef, q_Bbuf, q_fpart, q_X0, q_X1, q_g, q_delta, q_fac, q_dinv, q_work, q_dummy, q_gd, q_pw;
     DevBuf<double> q_aabs, q_ck, q_theta, q_xstar;
-    DevBuf<int32_t> q_cptr, q_ccone, q_cab, q_head, q_ishead, q_posd, q_poss, q_diagpos, q_hblk_part;
+    DevBuf<int32_t> q_cptr, q_ccone, q_cab, q_head, q_ishead, q_posd, q_poss, q_diagpos, q_hblk_part, q_long;
+    int n_long = 0;
     double* h_newton = nullptr;  // pinned scratch for partial sums
     size_t h_newton_n = 0;
 
@@ -478,6 +479,13 @@ struct HipBackend {
         q_theta.upload(Q.theta); q_xstar.upload(Q.xstar);
         q_posd.upload(Q.pos_diag); q_poss.upload(Q.pos_sub); q_diagpos.upload(Q.diag_pos);
         q_hblk_part.upload(Q.rbH.part_ptr);
+        {
+            std::vector<int32_t> longs;
+            for (size_t e = 0; e + 1 < Q.cptr.size(); ++e)
+                if (Q.cptr[e + 1] - Q.cptr[e] > kLongContrib) longs.push_back((int32_t)e);
+            n_long = (int)longs.size();
+            q_long.upload(longs);
+        }
         const size_t nc = h.cone_row.size();
         q_Bbuf.alloc(nc * Q.T * Q.T);
         q_fpart.alloc((nc + kThreads - 1) / kThreads);
@@ -605,7 +613,7 @@ struct HipBackend {
         hipLaunchKernelGGL(k_newton_trial, dim3(nb_n), dim3(kThreads), 0, stream, va);
         double F = 0, gn = 0;
         newton_eval(X, &F, &gn);
-        const double tol = std::max(1e-12, 0.1 * s_.eps_abs);
+        const double tol = std::max(1e-12, 0.3 * s_.eps_abs);
         const int bs = h.bs;
         int it = 0, cg_tot = 0;
         bool ok = true;
@@ -616,6 +624,7 @@ struct HipBackend {
             ha.ccoef = q_ccoef.d; ha.Bbuf = q_Bbuf.d; ha.T2 = Q.T * Q.T; ha.Hval = Hm.val.d;
             ha.ndiag = (int)h.diag_cols.size(); ha.diag_pos = q_diagpos.d; ha.dinv = q_dinv.d;
             hipLaunchKernelGGL(k_hassemble, dim3((unsigned)((ha.nnz + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, ha);
+            if (n_long) hipLaunchKernelGGL(k_hassemble_long, dim3(n_long), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d);
             if (ha.ndiag) hipLaunchKernelGGL(k_hdiag, dim3((ha.ndiag + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, ha);
             if (n_prec && !h.chains.empty()) {
                 FactorArgs fa{};
@@ -659,7 +668,7 @@ struct HipBackend {
             if (!accepted) {
                 double Fx = 0, gx = 0;
                 newton_eval(X, &Fx, &gx);  // re-establish nu / B / g of the accepted point
-                ok = gn <= 10 * tol;
+                ok = true;  // stalled in rounding: the residual test of the driver decides
                 break;
             }
         }

@@ -85,12 +85,27 @@ struct HAsmArgs {
     double* dinv;
 };
 
+constexpr int kLongContrib = 64;  // entries with more contributions get a workgroup of their own
+
 __global__ __launch_bounds__(kThreads) void k_hassemble(HAsmArgs a) {
     const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (p >= a.nnz) return;
+    const int c0 = a.cptr[p], c1 = a.cptr[p + 1];
+    if (c1 - c0 > kLongContrib) return;  // k_hassemble_long
     double v = a.Pon[p];
-    for (int c = a.cptr[p]; c < a.cptr[p + 1]; ++c) v += a.ccoef[c] * a.Bbuf[(size_t)a.ccone[c] * a.T2 + a.cab[c]];
+    for (int c = c0; c < c1; ++c) v += a.ccoef[c] * a.Bbuf[(size_t)a.ccone[c] * a.T2 + a.cab[c]];
     a.Hval[p] = v;
+}
+// landmark entries collect a contribution from every cone that touches the landmark (thousands):
+// strided partial sums + a fixed-order tree instead of one serial lane
+__global__ __launch_bounds__(kThreads) void k_hassemble_long(HAsmArgs a, const int32_t* long_entries) {
+    __shared__ double red[8];
+    const int64_t p = long_entries[blockIdx.x];
+    const int c0 = a.cptr[p], c1 = a.cptr[p + 1];
+    double v = 0.0;
+    for (int c = c0 + (int)threadIdx.x; c < c1; c += kThreads) v += a.ccoef[c] * a.Bbuf[(size_t)a.ccone[c] * a.T2 + a.cab[c]];
+    v = block_sum(v, red);
+    if (threadIdx.x == 0) a.Hval[p] = a.Pon[p] + v;
 }
 __global__ __launch_bounds__(kThreads) void k_hdiag(HAsmArgs a) {
     const int e = blockIdx.x * kThreads + threadIdx.x;
