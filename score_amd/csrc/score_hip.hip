@@ -113,6 +113,8 @@ struct HipBackend {
     DevBuf<double> q_aabs, q_ck, q_theta, q_xstar;
     DevBuf<int32_t> q_cptr, q_ccone, q_cab, q_head, q_ishead, q_posd, q_poss, q_diagpos, q_hblk_part, q_long;
     int n_long = 0;
+    double newton_eta_max = 1e-1;  // inexact Newton: linear residual <= min(eta_max, sqrt|g|)
+    int newton_chunk = 4;         // PCG iterations between two convergence reads
     double* h_newton = nullptr;  // pinned scratch for partial sums
     size_t h_newton_n = 0;
 
@@ -472,6 +474,8 @@ struct HipBackend {
 
     void init_polish(const HostSystem& h) {
         build_polish(h, Q);
+        if (const char* e = std::getenv("SCORE_NEWTON_ETA")) newton_eta_max = std::atof(e);
+        if (const char* e = std::getenv("SCORE_NEWTON_CHUNK")) newton_chunk = std::max(1, std::atoi(e));
         if (!Q.available || h.count != 1) { Q.available = false; return; }
         Hm.upload(Q.Hm, Q.rbH);
         q_Pon.upload(Q.Pon); q_ccoef.upload(Q.ccoef); q_cptr.upload(Q.cptr); q_ccone.upload(Q.ccone); q_cab.upload(Q.cab);
@@ -580,7 +584,7 @@ struct HipBackend {
         if (!(rz0 > 0.0)) return 0;
         int done_cg = 0;
         while (done_cg < max_cg) {
-            const int chunk = 8;
+            const int chunk = newton_chunk;
             for (int j = 0; j < chunk; ++j) {
                 double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
                 pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_nxt;
@@ -636,7 +640,7 @@ struct HipBackend {
                 else hipLaunchKernelGGL(k_factor<4>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
             }
             // inexact Newton: the linear residual only has to shrink superlinearly with |g|
-            const double eta = std::min(1e-2, std::max(1e-8, std::sqrt(gn)));
+            const double eta = std::min(newton_eta_max, std::max(1e-8, std::sqrt(gn)));
             cg_tot += newton_pcg(eta, 400);
             // backtracking on F (accept on the gradient when the decrease drowns in rounding)
             double step = 1.0;
