@@ -722,6 +722,12 @@ struct HipBackend {
             else if (which == "nop_load") hipLaunchKernelGGL(k_nop_load, dim3(K.nblocks), dim3(kThreads), 0, stream, K.blk_prob.d, done.d, (int*)nullptr);
             else throw std::runtime_error("unknown kernel name");
         };
+        // problems that have converged are skipped by every kernel: time them as active
+        const HostSystem& h = *H;
+        std::vector<int32_t> zero(h.count, 0), keep(h.count);
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipMemcpy(keep.data(), done.d, keep.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpy(done.d, zero.data(), zero.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         for (int i = 0; i < 5; ++i) once();
         HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipEventRecord(ev0, stream));
@@ -731,6 +737,7 @@ struct HipBackend {
         float t = 0;
         HIP_CHECK(hipEventElapsedTime(&t, ev0, ev1));
         *ms = (double)t / std::max(1, reps);
+        HIP_CHECK(hipMemcpy(done.d, keep.data(), keep.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
 
     // roofline probe: average launch duration of the KKT SpMV (w = K p), HIP

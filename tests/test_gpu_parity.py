@@ -197,3 +197,31 @@ def test_newton_polish_on_degenerate_and_unsupported_cases(hip_lib):
         assert r.solved and r.info["newton_iters"] > 0
     rd = solve_score(graphs[0], "QCQP", qcqp_mode="direct")
     assert rd.solved and rd.info["newton_iters"] == 0
+
+
+def test_random_graphs_against_the_oracle(hip_lib):
+    """Randomised sweep: 24 small graphs of varying shape (1-4 robots, with and
+    without beacons / loop closures, sparse and dense ranging).  The full GPU solver
+    must reproduce the oracle's optimum: objective to 1e-7 relative, the pinned
+    robot's trajectory to 1e-5 relative."""
+    rng = np.random.default_rng(2024)
+    worst_obj, worst_pose = 0.0, 0.0
+    for trial in range(24):
+        kw = dict(
+            n_robots=int(rng.integers(1, 5)), n_poses=int(rng.integers(20, 90)), n_beacons=int(rng.integers(0, 5)),
+            seed=1000 + trial, p_range=float(rng.choice([0.1, 0.2, 0.4])), n_loop_closures=int(rng.choice([0, 0, 3])),
+        )
+        fg = make_manhattan(**kw)
+        if fg.unconnected_variable_names:
+            continue
+        res = solve_score(fg, "SOCP")
+        assert res.solved, (kw, res.info)
+        rp, u, info = so.newton_solve(fg, tol=1e-13, max_iter=300)
+        ref = so.reduced_to_values(rp, u, "SOCP")
+        obj = so.LiteralModel(fg, "SOCP").direct_cost(ref)
+        worst_obj = max(worst_obj, abs(res.info["pobj"] - obj) / max(1.0, abs(obj)))
+        scale = max(1.0, max(np.abs(X[:, 2]).max() for X in ref["poses"].values()))
+        for p in fg.pose_variables[0]:
+            worst_pose = max(worst_pose, float(np.abs(res.poses[p.name][:2, 2] - ref["poses"][p.name][:, 2]).max()) / scale)
+    assert worst_obj < 1e-7, worst_obj
+    assert worst_pose < 1e-5, worst_pose
