@@ -42,6 +42,10 @@ thread_local std::string g_err;
 // ---------------------------------------------------------------------------
 // backend
 // ---------------------------------------------------------------------------
+// Uploads go through the calling handle's stream (never the legacy stream): several host
+// threads may drive different handles while one of them is capturing a graph.
+thread_local hipStream_t tl_copy_stream = nullptr;
+
 template <class T>
 struct DevBuf {
     T* d = nullptr;
@@ -53,7 +57,10 @@ struct DevBuf {
     }
     void upload(const std::vector<T>& h) {
         if (h.size() != n || !d) alloc(h.size());
-        if (!h.empty()) HIP_CHECK(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+        if (!h.empty()) {
+            HIP_CHECK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
+            HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
+        }
     }
     void zero(hipStream_t st) {
         if (n) HIP_CHECK(hipMemsetAsync(d, 0, n * sizeof(T), st));
@@ -147,7 +154,8 @@ struct HipBackend {
             throw std::runtime_error("no HIP device available (the SCORE solver has no CPU fallback)");
         if (st.device < 0 || st.device >= ndev) throw std::runtime_error("score_settings.device out of range");
         HIP_CHECK(hipSetDevice(st.device));
-        HIP_CHECK(hipStreamCreate(&stream));
+        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        tl_copy_stream = stream;
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
         if (h.bs != 0 && h.bs != 3 && h.bs != 4 && h.bs != 1 && h.bs != 2)
@@ -220,6 +228,7 @@ struct HipBackend {
     }
 
     void upload_rho(const HostSystem& h) {
+        tl_copy_stream = stream;
         HIP_CHECK(hipStreamSynchronize(stream));
         upload_rho_values(h);
         {   // K changed: the carried product kx = K xt is recomputed once
@@ -238,7 +247,8 @@ struct HipBackend {
     void set_done(const std::vector<int>& d) {
         HIP_CHECK(hipStreamSynchronize(stream));
         std::vector<int32_t> v(d.begin(), d.end());
-        HIP_CHECK(hipMemcpy(done.d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(done.d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
     }
 
     void reset() {
@@ -314,8 +324,10 @@ struct HipBackend {
         if (n_prec == 0) return;
         HIP_CHECK(hipStreamSynchronize(stream));
         std::vector<double> a(n_prec), b2(n_prec);
-        HIP_CHECK(hipMemcpy(a.data(), rz_meas0.d, sizeof(double) * n_prec, hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(b2.data(), rz_meas1.d, sizeof(double) * n_prec, hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpyAsync(a.data(), rz_meas0.d, sizeof(double) * n_prec, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipMemcpyAsync(b2.data(), rz_meas1.d, sizeof(double) * n_prec, hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
         for (int pi = 0; pi < h.count; ++pi) {
             double s0 = 0, s1 = 0;
             for (int i = h.prec_part_ptr[pi]; i < h.prec_part_ptr[pi + 1]; ++i) { s0 += a[i]; s1 += b2[i]; }
@@ -434,8 +446,10 @@ struct HipBackend {
     void download(const HostSystem& h, double* x, double* y, double* s_out) {
         HIP_CHECK(hipStreamSynchronize(stream));
         std::vector<double> hx(h.n_tot + h.m_tot), hs(h.m_tot);
-        HIP_CHECK(hipMemcpy(hx.data(), xy.d, hx.size() * sizeof(double), hipMemcpyDeviceToHost));
-        if (h.m_tot) HIP_CHECK(hipMemcpy(hs.data(), s.d, hs.size() * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_CHECK(hipMemcpyAsync(hx.data(), xy.d, hx.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (h.m_tot) HIP_CHECK(hipMemcpyAsync(hs.data(), s.d, hs.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
         if (x) for (int64_t i = 0; i < h.n_tot; ++i) x[i] = hx[i] * h.D[i];
         if (y) for (int64_t i = 0; i < h.m_tot; ++i) y[i] = hx[h.n_tot + i] * h.E[i];
         if (s_out) for (int64_t i = 0; i < h.m_tot; ++i) s_out[i] = hs[i] / h.E[i];
@@ -466,7 +480,8 @@ struct HipBackend {
             if (host) std::memcpy(out, src, bytes);
             else {
                 if (hipStreamSynchronize(stream) != hipSuccess) return -2;
-                if (hipMemcpy(out, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return -2;
+                if (hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return -2;
+                if (hipStreamSynchronize(stream) != hipSuccess) return -2;
             }
         }
         return sz;
@@ -726,8 +741,10 @@ struct HipBackend {
         const HostSystem& h = *H;
         std::vector<int32_t> zero(h.count, 0), keep(h.count);
         HIP_CHECK(hipStreamSynchronize(stream));
-        HIP_CHECK(hipMemcpy(keep.data(), done.d, keep.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(done.d, zero.data(), zero.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(keep.data(), done.d, keep.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipMemcpyAsync(done.d, zero.data(), zero.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
         for (int i = 0; i < 5; ++i) once();
         HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipEventRecord(ev0, stream));
@@ -737,7 +754,8 @@ struct HipBackend {
         float t = 0;
         HIP_CHECK(hipEventElapsedTime(&t, ev0, ev1));
         *ms = (double)t / std::max(1, reps);
-        HIP_CHECK(hipMemcpy(done.d, keep.data(), keep.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(done.d, keep.data(), keep.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
     }
 
     // roofline probe: average launch duration of the KKT SpMV (w = K p), HIP
@@ -747,10 +765,13 @@ struct HipBackend {
         std::vector<double> hp(h.n_tot);
         for (int64_t i = 0; i < h.n_tot; ++i) hp[i] = 1.0 + 1e-3 * (double)(i % 7);
         HIP_CHECK(hipStreamSynchronize(stream));
-        HIP_CHECK(hipMemcpy(p.d, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(p.d, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
         std::vector<int32_t> zero(h.count, 0), keep(h.count);
-        HIP_CHECK(hipMemcpy(keep.data(), done.d, keep.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
-        HIP_CHECK(hipMemcpy(done.d, zero.data(), zero.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(keep.data(), done.d, keep.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipMemcpyAsync(done.d, zero.data(), zero.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
         for (int i = 0; i < 10; ++i) launch_kp(p.d);
         HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipEventRecord(ev0, stream));
@@ -763,7 +784,8 @@ struct HipBackend {
         double bsum = 0;
         for (double v : h.kkt_bytes) bsum += v;
         *bytes = bsum;
-        HIP_CHECK(hipMemcpy(done.d, keep.data(), keep.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpyAsync(done.d, keep.data(), keep.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
     }
 };
 

@@ -137,6 +137,7 @@ def solve_score(
 def solve_score_batch(
     datas: Sequence, relaxation_type: str = QCQP_RELAXATION, qcqp_mode: str = "via_socp",
     solver_settings: Optional[dict] = None, lib_path: Optional[str] = None, lockstep: Optional[bool] = None,
+    workers: int = 4,
 ) -> List[compat.SolverResults]:
     """Independent factor graphs on one GPU.
 
@@ -144,15 +145,24 @@ def solve_score_batch(
     only; per-problem penalties and termination) -- best device utilisation per
     iteration.  ``lockstep=False``: one after another, each with the
     semismooth-Newton polish (5-20x fewer milliseconds per problem than ADMM
-    alone).  Default: sequential whenever the polish applies (SOCP form, polish
-    not disabled), lock-step otherwise."""
+    alone), from a pool of ``workers`` host threads: every problem gets its own
+    handle and HIP stream, so host-side setup (``score_create``) and the kernels of
+    different problems overlap.  Default: per-problem whenever the polish applies
+    (SOCP form, polish not disabled), lock-step otherwise."""
     check_valid_relaxation(relaxation_type)
     if lockstep is None:
         direct_qcqp = relaxation_type == QCQP_RELAXATION and qcqp_mode == "direct"
         lockstep = direct_qcqp or not (solver_settings or {}).get("polish", 1)
     if not lockstep and len(datas) > 1:
-        return [solve_score_batch([d], relaxation_type, qcqp_mode, solver_settings, lib_path, lockstep=True)[0]
-                for d in datas]
+        def one(d):
+            return solve_score_batch([d], relaxation_type, qcqp_mode, solver_settings, lib_path, lockstep=True)[0]
+
+        if workers <= 1:
+            return [one(d) for d in datas]
+        from concurrent.futures import ThreadPoolExecutor
+
+        with ThreadPoolExecutor(max_workers=min(workers, len(datas))) as pool:
+            return list(pool.map(one, datas))
     if qcqp_mode not in ("via_socp", "direct"):
         raise ValueError(f"qcqp_mode {qcqp_mode} is not supported")
     models = []
