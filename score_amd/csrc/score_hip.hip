@@ -62,6 +62,14 @@ struct DevBuf {
             HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
         }
     }
+    // copy into the existing allocation (which may be larger: padded), never re-allocating
+    void upload_into(const std::vector<T>& h) {
+        if (!d || h.size() > n) throw std::runtime_error("upload_into: buffer too small");
+        if (!h.empty()) {
+            HIP_CHECK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
+            HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
+        }
+    }
     void zero(hipStream_t st) {
         if (n) HIP_CHECK(hipMemsetAsync(d, 0, n * sizeof(T), st));
     }
@@ -80,8 +88,15 @@ struct CsrBufs {
     int nblocks = 0;
     void upload(const Csr& M, const RowBlocks& rb, const std::vector<int32_t>* sp = nullptr) {
         ptr.upload(M.ptr);
-        col.upload(M.col);
-        val.upload(M.val);
+        // The SpMV issues its loads unconditionally on clamped indices; for an empty tile at the
+        // very end of the matrix the clamp lands one past the last nonzero.  Pad with harmless
+        // entries (column 0, value 0) so that such a read stays in bounds and gathers x[0].
+        std::vector<int32_t> colp(M.col);
+        std::vector<double> valp(M.val);
+        colp.resize(M.col.size() + 64, 0);
+        valp.resize(M.val.size() + 64, 0.0);
+        col.upload(colp);
+        val.upload(valp);
         first_row.upload(rb.first_row);
         blk_prob.upload(rb.prob);
         std::vector<int4> meta(rb.nb());
@@ -163,7 +178,12 @@ struct HipBackend {
         K.upload(h.K, h.rbK);
         G1.upload(h.G1, h.rbG1);
         G2.upload(h.G2, h.rbG2, &h.g2_split);
-        A_ptr.upload(h.A.ptr); A_col.upload(h.A.col); A_val.upload(h.A.val);
+        A_ptr.upload(h.A.ptr);
+        {   // padded like the SpMV matrices: the cone kernel clamps its unconditional loads
+            std::vector<int32_t> ac(h.A.col); std::vector<double> av(h.A.val);
+            ac.resize(ac.size() + 64, 0); av.resize(av.size() + 64, 0.0);
+            A_col.upload(ac); A_val.upload(av);
+        }
         q.upload(h.q); b.upload(h.b);
         std::vector<double> iD(h.D.size()), iE(h.E.size());
         for (size_t i = 0; i < iD.size(); ++i) iD[i] = 1.0 / h.D[i];
@@ -208,7 +228,7 @@ struct HipBackend {
     }
 
     void upload_rho_values(const HostSystem& h) {
-        K.val.upload(h.K.val);
+        K.val.upload_into(h.K.val);  // keeps the padded allocation (and the pointer the launch graph holds)
         fac.upload(h.fac);
         dinv.upload(h.dinv);
         rho.upload(h.rho);

@@ -225,3 +225,19 @@ def test_random_graphs_against_the_oracle(hip_lib):
             worst_pose = max(worst_pose, float(np.abs(res.poses[p.name][:2, 2] - ref["poses"][p.name][:, 2]).max()) / scale)
     assert worst_obj < 1e-7, worst_obj
     assert worst_pose < 1e-5, worst_pose
+
+
+def test_handles_from_a_thread_pool_and_empty_tiles(hip_lib):
+    """Regression: (1) several host threads drive their own handles while others capture launch
+    graphs; (2) a problem without any cone (empty A, empty trailing tiles) solved after other
+    handles were freed -- the clamped unconditional loads must stay inside padded arrays."""
+    graphs = [make_manhattan(n_robots=3, n_poses=40 + 10 * (s % 4), n_beacons=4, seed=s, p_range=0.4) for s in (300, 303, 305, 307, 309, 310)]
+    seq = solve_score_batch(graphs, "SOCP", workers=1)
+    par = solve_score_batch(graphs, "SOCP", workers=6)
+    for a, b in zip(seq, par):
+        assert a.solved and b.solved
+        for nm in a.poses:
+            assert np.array_equal(a.poses[nm], b.poses[nm])
+    for seed in range(3):
+        fg = make_manhattan(n_robots=1, n_poses=50 + 17 * seed, n_beacons=0, seed=seed, p_range=0.0)
+        assert solve_score(fg, "SOCP").solved
