@@ -509,8 +509,6 @@ struct HipBackend {
 
     void init_polish(const HostSystem& h) {
         build_polish(h, Q);
-        if (const char* e = std::getenv("SCORE_NEWTON_ETA")) newton_eta_max = std::atof(e);
-        if (const char* e = std::getenv("SCORE_NEWTON_CHUNK")) newton_chunk = std::max(1, std::atoi(e));
         if (!Q.available || h.count != 1) { Q.available = false; return; }
         Hm.upload(Q.Hm, Q.rbH);
         q_Pon.upload(Q.Pon); q_ccoef.upload(Q.ccoef); q_cptr.upload(Q.cptr); q_ccone.upload(Q.ccone); q_cab.upload(Q.cab);
@@ -584,7 +582,7 @@ struct HipBackend {
     }
 
     // Solve H delta = -g (r holds -g) with PCG on the device-factored chain preconditioner.
-    int newton_pcg(double rel_tol, int max_cg) {
+    int newton_pcg(double rel_tol, int max_cg, int first_chunk) {
         const HostSystem& h = *H;
         q_delta.zero(stream);
         PrecArgs pa{};
@@ -619,7 +617,7 @@ struct HipBackend {
         if (!(rz0 > 0.0)) return 0;
         int done_cg = 0;
         while (done_cg < max_cg) {
-            const int chunk = newton_chunk;
+            const int chunk = (done_cg == 0) ? std::max(newton_chunk, first_chunk) : newton_chunk;
             for (int j = 0; j < chunk; ++j) {
                 double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
                 pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_nxt;
@@ -637,7 +635,20 @@ struct HipBackend {
         return done_cg;
     }
 
+    // Any failure inside the polish (NaN, HIP error) leaves the ADMM state untouched -- the Newton
+    // loop only writes scratch vectors until its final hand-over -- and ADMM simply continues.
     bool polish(const HostSystem& h, const score_settings& s_, int* newton_iters, int* cg_used) {
+        try {
+            return polish_impl(h, s_, newton_iters, cg_used);
+        } catch (const std::exception& e) {
+            if (st.verbose) std::fprintf(stderr, "[score] polish abandoned: %s\n", e.what());
+            (void)hipStreamSynchronize(stream);
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+
+    bool polish_impl(const HostSystem& h, const score_settings& s_, int* newton_iters, int* cg_used) {
         *newton_iters = 0; *cg_used = 0;
         if (!Q.available || h.count != 1) return false;
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -654,7 +665,7 @@ struct HipBackend {
         newton_eval(X, &F, &gn);
         const double tol = std::max(1e-12, 0.3 * s_.eps_abs);
         const int bs = h.bs;
-        int it = 0, cg_tot = 0;
+        int it = 0, cg_tot = 0, last_cg = 0;
         bool ok = true;
         for (; it < 50 && gn > tol; ++it) {
             // Hessian at X, its Jacobi diagonal and chain factors
@@ -676,7 +687,10 @@ struct HipBackend {
             }
             // inexact Newton: the linear residual only has to shrink superlinearly with |g|
             const double eta = std::min(newton_eta_max, std::max(1e-8, std::sqrt(gn)));
-            cg_tot += newton_pcg(eta, 400);
+            // the previous Newton step's PCG count predicts this one's: fewer convergence reads
+            const int used = newton_pcg(eta, 400, std::max(0, last_cg - 2 * newton_chunk));
+            last_cg = used;
+            cg_tot += used;
             // backtracking on F (accept on the gradient when the decrease drowns in rounding)
             double step = 1.0;
             bool accepted = false;
