@@ -35,6 +35,13 @@ QCQP_RELAXATION = "QCQP"
 ACCEPTABLE_RELAXATIONS = [SOCP_RELAXATION, QCQP_RELAXATION]
 
 
+def _dot(a: np.ndarray, b: np.ndarray) -> float:
+    """Inner product that stays out of BLAS.  A threaded BLAS wakes its whole worker pool for a
+    long vector, and those workers then spin for ~100 ms on the cores the native setup threads
+    of the next `score_create` want (measured on the MI355X host: +80..130 ms per problem)."""
+    return float(np.einsum("i,i->", a, b))
+
+
 def check_valid_relaxation(relaxation: str) -> None:
     """gurobi_utils.py:139-144."""
     if relaxation not in ACCEPTABLE_RELAXATIONS:
@@ -78,7 +85,7 @@ class ConicQP:
         return self.A.shape[0]
 
     def objective(self, x: np.ndarray) -> float:
-        return float(0.5 * x @ (self.P @ x) + self.q @ x + self.c0)
+        return 0.5 * _dot(x, self.P @ x) + _dot(self.q, x) + float(self.c0)
 
 
 @dataclass
@@ -139,9 +146,20 @@ def _pose_meas_arrays(meas: list, pose_idx: Dict[str, int], d: int):
     tau = np.fromiter((m.rotation_precision for m in meas), dtype=np.float64, count=ne)
     tm = np.empty((ne, d))
     Rm = np.empty((ne, d, d))
-    for e, m in enumerate(meas):
-        tm[e] = m.translation_vector
-        Rm[e] = m.rotation_matrix
+    m0 = meas[0]
+    if d == 2 and all(hasattr(m0, a) for a in ("x", "y", "theta")):
+        # PyFactorGraph's PoseMeasurement2D stores (x, y, theta); translation_vector and
+        # rotation_matrix are properties derived from them -- derive them for all edges at once
+        tm[:, 0] = np.fromiter((m.x for m in meas), dtype=np.float64, count=ne)
+        tm[:, 1] = np.fromiter((m.y for m in meas), dtype=np.float64, count=ne)
+        th = np.fromiter((m.theta for m in meas), dtype=np.float64, count=ne)
+        cs, sn = np.cos(th), np.sin(th)
+        Rm[:, 0, 0] = cs; Rm[:, 0, 1] = -sn
+        Rm[:, 1, 0] = sn; Rm[:, 1, 1] = cs
+    else:
+        for e, m in enumerate(meas):
+            tm[e] = m.translation_vector
+            Rm[e] = m.rotation_matrix
     return bi, tj, kap, tau, tm, Rm
 
 
@@ -177,14 +195,16 @@ def assemble(data, relaxation: str = QCQP_RELAXATION) -> ScoreModel:
     rw = 1 if relaxation == SOCP_RELAXATION else d
     n_model = rng_base + Nr * rw
 
-    def tcols(name: str) -> int:
-        """first translation column (k = 0) and stride to the next k
-        (VariableCollection.get_translation_var, gurobi_utils.py:103-109)."""
-        if name in pose_idx:
-            return pose_idx[name] * PB + d, D1
-        if name in lm_idx:
-            return lm_base + lm_idx[name] * d, 1
-        raise ValueError(f"Variable name {name} not found")
+    # first translation column (k = 0) and stride to the next k of every variable that has a
+    # translation (VariableCollection.get_translation_var, gurobi_utils.py:103-109: poses first)
+    tmap = {nm: (lm_base + i * d, 1) for nm, i in lm_idx.items()}
+    tmap.update((nm, (i * PB + d, D1)) for nm, i in pose_idx.items())
+
+    def tcols(name: str):
+        try:
+            return tmap[name]
+        except KeyError:
+            raise ValueError(f"Variable name {name} not found") from None
 
     rows, cols, vals = [], [], []  # residual Jacobian J (COO)
     cvec, wvec = [], []
@@ -224,11 +244,8 @@ def assemble(data, relaxation: str = QCQP_RELAXATION) -> ScoreModel:
 
     # ---- range costs (:449-501) ------------------------------------------
     if Nr:
-        ta = np.empty(Nr, np.int64); sa = np.empty(Nr, np.int64)
-        tb = np.empty(Nr, np.int64); sb = np.empty(Nr, np.int64)
-        for r, (ka, kb) in enumerate(range_keys):
-            ta[r], sa[r] = tcols(ka)
-            tb[r], sb[r] = tcols(kb)
+        ends = np.array([tcols(ka) + tcols(kb) for ka, kb in range_keys], dtype=np.int64).reshape(Nr, 4)
+        ta, sa, tb, sb = ends[:, 0], ends[:, 1], ends[:, 2], ends[:, 3]
         dist = np.fromiter((m.dist for m in data.range_measurements), dtype=np.float64, count=Nr)
         wr = np.fromiter((m.precision for m in data.range_measurements), dtype=np.float64, count=Nr)
         if relaxation == SOCP_RELAXATION:
@@ -258,21 +275,47 @@ def assemble(data, relaxation: str = QCQP_RELAXATION) -> ScoreModel:
         wvec.append(np.full(d, float(prior.translation_precision)))
         nrow += d
 
+    # ---- pin the first pose of the first chain to [I | 0] (:181-183, :316-333):
+    # x = (x_free, x_fixed), so J x - c = J_free x_free - (c - J_fixed x_fixed) and the pinned
+    # columns never enter a matrix product
+    first = data.pose_variables[0][0].name
+    p0 = pose_idx[first]
+    fixed_cols = p0 * PB + np.arange(PB)
+    fixed_vals = np.hstack([np.eye(d), np.zeros((d, 1))]).ravel()
+    mask = np.ones(n_model, dtype=bool)
+    mask[fixed_cols] = False
+    free_cols = np.nonzero(mask)[0]
+    n_free = free_cols.size
+    xc = np.zeros(n_model)
+    xc[fixed_cols] = fixed_vals
+    new_of_model = -np.ones(n_model, dtype=np.int64)
+    new_of_model[free_cols] = np.arange(n_free)
+
+    def reduced(r, cidx, v, nrows, const):
+        """CSR on the free columns; the pinned part goes into `const -= M_fixed x_fixed`."""
+        pinned = ~mask[cidx]
+        if pinned.any():
+            const = const - np.bincount(r[pinned], weights=v[pinned] * xc[cidx[pinned]], minlength=nrows)
+            keep = ~pinned
+            r, cidx, v = r[keep], cidx[keep], v[keep]
+        M = sp.csr_matrix((v, (r, new_of_model[cidx])), shape=(nrows, n_free))
+        return M, const
+
     if nrow:
-        J = sp.csr_matrix(
-            (np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))),
-            shape=(nrow, n_model),
-        )
         c = np.concatenate(cvec)
         w = np.concatenate(wvec)
+        J, c = reduced(np.concatenate(rows), np.concatenate(cols), np.concatenate(vals), nrow, c)
+        WJ = J.copy()
+        WJ.data *= np.repeat(w, np.diff(J.indptr))
+        Jt = J.T.tocsr()
+        P = (Jt @ WJ).tocsr()
+        P.data *= 2.0
+        q = -2.0 * (Jt @ (w * c))
+        c0 = _dot(c, w * c)
     else:
-        J = sp.csr_matrix((0, n_model))
-        c = np.zeros(0)
-        w = np.zeros(0)
-    JW = J.T.multiply(w).tocsr()  # J' W
-    P_full = (2.0 * (JW @ J)).tocsr()
-    q_full = -2.0 * (JW @ c)
-    c0 = float(c @ (w * c))
+        P = sp.csr_matrix((n_free, n_free))
+        q = np.zeros(n_free)
+        c0 = 0.0
 
     # ---- cones (:336-352) --------------------------------------------------
     m = Nr * D1
@@ -296,36 +339,14 @@ def assemble(data, relaxation: str = QCQP_RELAXATION) -> ScoreModel:
             av = [-np.ones(Nr * d)]
             b = np.zeros(m)
             b[np.arange(Nr) * D1] = 1.0
-        A_full = sp.csr_matrix(
-            (np.concatenate(av), (np.concatenate(ar), np.concatenate(ac))), shape=(m, n_model)
-        )
+        A, b = reduced(np.concatenate(ar), np.concatenate(ac), np.concatenate(av), m, b)
     else:
-        A_full = sp.csr_matrix((0, n_model))
+        A = sp.csr_matrix((0, n_free))
         b = np.zeros(0)
-    A_full.sum_duplicates()
-
-    # ---- pin the first pose of the first chain to [I | 0] (:181-183, :316-333)
-    first = data.pose_variables[0][0].name
-    p0 = pose_idx[first]
-    fixed_cols = p0 * PB + np.arange(PB)
-    fixed_vals = np.hstack([np.eye(d), np.zeros((d, 1))]).ravel()
-    mask = np.ones(n_model, dtype=bool)
-    mask[fixed_cols] = False
-    free_cols = np.nonzero(mask)[0]
-    xc = np.zeros(n_model)
-    xc[fixed_cols] = fixed_vals
-    Pxc = P_full @ xc
-    P = P_full[free_cols][:, free_cols].tocsr()
-    q = (q_full + Pxc)[free_cols]
-    c0 = c0 + float(0.5 * xc @ Pxc + q_full @ xc)
-    A = A_full[:, free_cols].tocsr()
-    b = b - A_full @ xc
     P.sum_duplicates(); P.sort_indices()
-    A.sort_indices()
+    A.sum_duplicates(); A.sort_indices()
 
     # ---- block-tridiagonal hint: one chain per (robot chain, matrix row k) ----
-    new_of_model = -np.ones(n_model, dtype=np.int64)
-    new_of_model[free_cols] = np.arange(free_cols.size)
     chain_ptr = [0]
     node_cols = []
     base = 0

@@ -62,6 +62,14 @@ struct DevBuf {
             HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
         }
     }
+    // upload into an allocation with `pad` extra zeroed elements at the end
+    void upload_padded(const std::vector<T>& h, size_t pad) {
+        if (h.size() + pad != n || !d) alloc(h.size() + pad);
+        HIP_CHECK(hipMemsetAsync(d + h.size(), 0, pad * sizeof(T), tl_copy_stream));
+        if (!h.empty())
+            HIP_CHECK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
+        HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
+    }
     // copy into the existing allocation (which may be larger: padded), never re-allocating
     void upload_into(const std::vector<T>& h) {
         if (!d || h.size() > n) throw std::runtime_error("upload_into: buffer too small");
@@ -86,17 +94,19 @@ struct CsrBufs {
     DevBuf<int4> blk_meta;
     DevBuf<double> val;
     int nblocks = 0;
-    void upload(const Csr& M, const RowBlocks& rb, const std::vector<int32_t>* sp = nullptr) {
+    // values = false: the value array is only allocated (zeroed); a kernel fills it
+    void upload(const Csr& M, const RowBlocks& rb, const std::vector<int32_t>* sp = nullptr, bool values = true) {
         ptr.upload(M.ptr);
         // The SpMV issues its loads unconditionally on clamped indices; for an empty tile at the
         // very end of the matrix the clamp lands one past the last nonzero.  Pad with harmless
         // entries (column 0, value 0) so that such a read stays in bounds and gathers x[0].
-        std::vector<int32_t> colp(M.col);
-        std::vector<double> valp(M.val);
-        colp.resize(M.col.size() + 64, 0);
-        valp.resize(M.val.size() + 64, 0.0);
-        col.upload(colp);
-        val.upload(valp);
+        col.upload_padded(M.col, 64);
+        if (values) {
+            val.upload_padded(M.val, 64);
+        } else {
+            val.alloc(M.col.size() + 64);
+            HIP_CHECK(hipMemsetAsync(val.d, 0, val.n * sizeof(double), tl_copy_stream));
+        }
         first_row.upload(rb.first_row);
         blk_prob.upload(rb.prob);
         std::vector<int4> meta(rb.nb());
@@ -163,6 +173,7 @@ struct HipBackend {
     void init(const HostSystem& h, const score_settings& s_) {
         H = &h;
         st = s_;
+        PhaseTimer pt(st.verbose != 0);
         int ndev = 0;
         hipError_t e = hipGetDeviceCount(&ndev);
         if (e != hipSuccess || ndev <= 0)
@@ -173,17 +184,15 @@ struct HipBackend {
         tl_copy_stream = stream;
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
+        pt.mark("device + stream");
         if (h.bs != 0 && h.bs != 3 && h.bs != 4 && h.bs != 1 && h.bs != 2)
             throw std::runtime_error("unsupported block size");
         K.upload(h.K, h.rbK);
         G1.upload(h.G1, h.rbG1);
         G2.upload(h.G2, h.rbG2, &h.g2_split);
         A_ptr.upload(h.A.ptr);
-        {   // padded like the SpMV matrices: the cone kernel clamps its unconditional loads
-            std::vector<int32_t> ac(h.A.col); std::vector<double> av(h.A.val);
-            ac.resize(ac.size() + 64, 0); av.resize(av.size() + 64, 0.0);
-            A_col.upload(ac); A_val.upload(av);
-        }
+        // padded like the SpMV matrices: the cone kernel clamps its unconditional loads
+        A_col.upload_padded(h.A.col, 64); A_val.upload_padded(h.A.val, 64);
         q.upload(h.q); b.upload(h.b);
         std::vector<double> iD(h.D.size()), iE(h.E.size());
         for (size_t i = 0; i < iD.size(); ++i) iD[i] = 1.0 / h.D[i];
@@ -196,6 +205,7 @@ struct HipBackend {
         prec_part_ptr.upload(h.prec_part_ptr); kblk_part_ptr.upload(h.rbK.part_ptr);
         prec_work.upload(h.prec_work); chains.upload(h.chains); levels.upload(h.levels);
         n_prec = (int)h.prec_work.size();
+        pt.mark("uploads");
         // chain vectors in LDS: level 0 (N nodes) when it fits, always the coarse levels
         int max_nodes = 0, max_all = 0;
         for (const auto& ch : h.chains) {
@@ -222,9 +232,12 @@ struct HipBackend {
         HIP_CHECK(hipHostMalloc((void**)&h_dres, dres_part.n * sizeof(double)));
         std::vector<int32_t> dz(h.count, 0);
         done.upload(dz);
-        upload_rho_values(h);
+        fac.upload(h.fac); dinv.upload(h.dinv); rho.upload(h.rho);  // (K.val went up with K)
+        pt.mark("allocations + rho data");
         if (st.polish) init_polish(h);
+        pt.mark("polish setup");
         reset();
+        pt.mark("reset");
     }
 
     void upload_rho_values(const HostSystem& h) {
@@ -410,12 +423,14 @@ struct HipBackend {
     void build_graph(int iters) {
         if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
         hipGraph_t g = nullptr;
+        PhaseTimer pt(st.verbose != 0);
         HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
         for (int i = 0; i < iters; ++i) enqueue_iteration(i == iters - 1, i == 0);
         HIP_CHECK(hipStreamEndCapture(stream, &g));
         HIP_CHECK(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
         graph_iters = iters;
+        pt.mark("graph capture + instantiate");
     }
 
     void run(int iters) {
@@ -508,9 +523,11 @@ struct HipBackend {
     }
 
     void init_polish(const HostSystem& h) {
+        PhaseTimer pt(st.verbose != 0);
         build_polish(h, Q);
+        pt.mark("  polish: host structures");
         if (!Q.available || h.count != 1) { Q.available = false; return; }
-        Hm.upload(Q.Hm, Q.rbH);
+        Hm.upload(Q.Hm, Q.rbH, nullptr, false);
         q_Pon.upload(Q.Pon); q_ccoef.upload(Q.ccoef); q_cptr.upload(Q.cptr); q_ccone.upload(Q.ccone); q_cab.upload(Q.cab);
         q_head.upload(Q.head_col); q_ishead.upload(Q.is_head); q_aabs.upload(Q.a_abs); q_ck.upload(Q.ck);
         q_theta.upload(Q.theta); q_xstar.upload(Q.xstar);
@@ -535,14 +552,6 @@ struct HipBackend {
         q_pw.alloc(Hm.nblocks);
         h_newton_n = std::max<size_t>(std::max<size_t>(q_fpart.n, q_gd.n), std::max<size_t>((size_t)n_prec, 8)) + 8;
         HIP_CHECK(hipHostMalloc((void**)&h_newton, h_newton_n * sizeof(double)));
-        // the diagonal regularisation keeps H positive definite along flat directions
-        // (landmarks all of whose cones are slack, gauge modes of robots no active cone ties down)
-        std::vector<double> pon = Q.Pon;
-        for (int64_t i = 0; i < h.n_tot; ++i) {
-            const int pd = find_in_row(Q.Hm, i, (int32_t)i);
-            if (pd >= 0 && !Q.is_head[i]) pon[pd] += 1e-9;
-        }
-        q_Pon.upload(pon);
     }
 
     PolishArgs polish_args(double* X) {

@@ -17,12 +17,19 @@
 #pragma once
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
 #include <string>
+#include <thread>
+
+#include <sched.h>
+#include <sys/resource.h>
 #include <vector>
 
 #include "../../include/score_hip.h"
@@ -34,6 +41,56 @@ constexpr int kTileNnz = 2048;      // products staged in LDS per workgroup (16 
 constexpr int kLongRow = 48;        // rows longer than this get a workgroup of their own
 constexpr int kConesPerBlock = 256;
 constexpr int kMaxBs = 4;
+
+// Setup work (equilibration, K = P + sigma I + rho A'A, chain factorisations) is split into
+// contiguous index ranges over a few host threads.  Every range computes exactly what the serial
+// loop would, so results do not depend on the thread count.
+inline int host_threads() {
+    static const int n = [] {
+        unsigned h = std::thread::hardware_concurrency();
+        cpu_set_t set;  // the CPUs this process may actually run on (containers, taskset)
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) h = std::min<unsigned>(h, (unsigned)CPU_COUNT(&set));
+        return (int)std::min(8u, std::max(1u, h));
+    }();
+    return n;
+}
+
+template <class F>
+inline void parallel_ranges(int64_t n, int64_t min_per_thread, F&& fn) {  // fn(part, begin, end)
+    int T = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
+    if (T <= 1) { fn(0, (int64_t)0, n); return; }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(T);
+    for (int t = 0; t < T; ++t)
+        th.emplace_back([&, t] {
+            try { fn(t, n * t / T, n * (t + 1) / T); } catch (...) { err[t] = std::current_exception(); }
+        });
+    for (auto& x : th) x.join();
+    for (auto& e : err) if (e) std::rethrow_exception(e);
+}
+inline int parallel_parts(int64_t n, int64_t min_per_thread) {
+    return (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
+}
+
+// Sense-reversing barrier for a team started by one parallel_ranges call: lets a thread keep
+// "its" rows in its own cache across the passes of an iterative setup step.
+struct TeamBarrier {
+    explicit TeamBarrier(int n) : T(n) {}
+    void wait() {
+        if (T <= 1) return;
+        const int g = gen.load(std::memory_order_acquire);
+        if (count.fetch_add(1, std::memory_order_acq_rel) == T - 1) {
+            count.store(0, std::memory_order_relaxed);
+            gen.store(g + 1, std::memory_order_release);
+        } else {
+            int spins = 0;
+            while (gen.load(std::memory_order_acquire) == g)
+                if (++spins > 4096) std::this_thread::yield();
+        }
+    }
+    int T;
+    std::atomic<int> count{0}, gen{0};
+};
 
 struct Csr {
     int64_t nrows = 0, ncols = 0;
@@ -450,34 +507,58 @@ inline void ruiz_scale(const score_problem& p, int iters, ProblemScaled& out) {
     out.D.assign(n, 1.0);
     out.E.assign(m, 1.0);
     std::vector<double> cn(n), rn(m), d(n), e(m);
-    for (int it = 0; it < iters; ++it) {
-        std::fill(cn.begin(), cn.end(), 0.0);
-        std::fill(rn.begin(), rn.end(), 0.0);
-        for (int i = 0; i < n; ++i)
-            for (int k = out.P.ptr[i]; k < out.P.ptr[i + 1]; ++k)
-                cn[out.P.col[k]] = std::max(cn[out.P.col[k]], std::fabs(out.P.val[k]));
-        for (int r = 0; r < m; ++r)
-            for (int k = out.A.ptr[r]; k < out.A.ptr[r + 1]; ++k) {
-                double v = std::fabs(out.A.val[k]);
-                cn[out.A.col[k]] = std::max(cn[out.A.col[k]], v);
-                rn[r] = std::max(rn[r], v);
+    // P is symmetric (the ABI takes the full matrix): its column norms are its row norms.  One
+    // team runs all passes; each member owns a row range of P and, per pass, scales it and takes
+    // the row norms of the result (the next pass's input) in one sweep.  Member 0 also does the
+    // (much smaller) A side.
+    TeamBarrier bar(parallel_parts(n, 16384));
+    if (iters > 0)
+        parallel_ranges(n, 16384, [&](int t, int64_t i0, int64_t i1) {
+            for (int64_t i = i0; i < i1; ++i) {
+                double mx = 0.0;
+                for (int k = out.P.ptr[i]; k < out.P.ptr[i + 1]; ++k) mx = std::max(mx, std::fabs(out.P.val[k]));
+                cn[i] = mx;
             }
-        int row = p.z;
-        for (int c = 0; c < p.n_soc; ++c) {  // one scale per cone
-            double mx = 0;
-            for (int k = 0; k < p.soc_dims[c]; ++k) mx = std::max(mx, rn[row + k]);
-            for (int k = 0; k < p.soc_dims[c]; ++k) rn[row + k] = mx;
-            row += p.soc_dims[c];
-        }
-        for (int j = 0; j < n; ++j) d[j] = cn[j] > 1e-12 ? 1.0 / std::sqrt(cn[j]) : 1.0;
-        for (int r = 0; r < m; ++r) e[r] = rn[r] > 1e-12 ? 1.0 / std::sqrt(rn[r]) : 1.0;
-        for (int i = 0; i < n; ++i)
-            for (int k = out.P.ptr[i]; k < out.P.ptr[i + 1]; ++k) out.P.val[k] *= d[i] * d[out.P.col[k]];
-        for (int r = 0; r < m; ++r)
-            for (int k = out.A.ptr[r]; k < out.A.ptr[r + 1]; ++k) out.A.val[k] *= e[r] * d[out.A.col[k]];
-        for (int j = 0; j < n; ++j) out.D[j] *= d[j];
-        for (int r = 0; r < m; ++r) out.E[r] *= e[r];
-    }
+            for (int it = 0; it < iters; ++it) {
+                bar.wait();  // cn holds the row norms of P
+                if (t == 0) {
+                    for (int r = 0; r < m; ++r) {
+                        double mx = 0.0;
+                        for (int k = out.A.ptr[r]; k < out.A.ptr[r + 1]; ++k) {
+                            double v = std::fabs(out.A.val[k]);
+                            cn[out.A.col[k]] = std::max(cn[out.A.col[k]], v);
+                            mx = std::max(mx, v);
+                        }
+                        rn[r] = mx;
+                    }
+                    int row = p.z;
+                    for (int c = 0; c < p.n_soc; ++c) {  // one scale per cone
+                        double mx = 0;
+                        for (int k = 0; k < p.soc_dims[c]; ++k) mx = std::max(mx, rn[row + k]);
+                        for (int k = 0; k < p.soc_dims[c]; ++k) rn[row + k] = mx;
+                        row += p.soc_dims[c];
+                    }
+                    for (int r = 0; r < m; ++r) e[r] = rn[r] > 1e-12 ? 1.0 / std::sqrt(rn[r]) : 1.0;
+                }
+                bar.wait();  // cn complete
+                for (int64_t j = i0; j < i1; ++j) d[j] = cn[j] > 1e-12 ? 1.0 / std::sqrt(cn[j]) : 1.0;
+                bar.wait();  // d complete
+                for (int64_t i = i0; i < i1; ++i) {
+                    double mx = 0.0;
+                    for (int k = out.P.ptr[i]; k < out.P.ptr[i + 1]; ++k) {
+                        out.P.val[k] *= d[i] * d[out.P.col[k]];
+                        mx = std::max(mx, std::fabs(out.P.val[k]));
+                    }
+                    cn[i] = mx;
+                    out.D[i] *= d[i];
+                }
+                if (t == 0) {
+                    for (int r = 0; r < m; ++r)
+                        for (int k = out.A.ptr[r]; k < out.A.ptr[r + 1]; ++k) out.A.val[k] *= e[r] * d[out.A.col[k]];
+                    for (int r = 0; r < m; ++r) out.E[r] *= e[r];
+                }
+            }
+        });
     out.q.resize(n);
     out.b.resize(m);
     for (int j = 0; j < n; ++j) out.q[j] = p.q[j] * out.D[j];
@@ -525,8 +606,35 @@ inline void validate_problem(const score_problem& p) {
     }
 }
 
+// wall-clock marks of the setup phases, printed when settings.verbose is set
+struct PhaseTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    long flt = 0, csw = 0;
+    static void usage(long& f, long& c) {
+        struct rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        f = ru.ru_minflt;
+        c = ru.ru_nvcsw + ru.ru_nivcsw;
+    }
+    explicit PhaseTimer(bool enabled) : on(enabled), t(std::chrono::steady_clock::now()) {
+        if (on) usage(flt, csw);
+    }
+    void mark(const char* what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        long f, c;
+        usage(f, c);
+        std::fprintf(stderr, "[score setup] %-28s %8.2f ms  (%ld page faults, %ld context switches)\n", what,
+                     std::chrono::duration<double, std::milli>(now - t).count(), f - flt, c - csw);
+        t = std::chrono::steady_clock::now();
+        flt = f;
+        csw = c;
+    }
+};
+
 // Append problem `b` (already scaled) to the batch: A, K (pattern + K0/K1), G1, G2.
-inline void append_problem(HostSystem& H, int pi, const score_problem& p, const ProblemScaled& S) {
+inline void append_problem(HostSystem& H, int pi, const score_problem& p, const ProblemScaled& S, PhaseTimer& pt) {
     const int n = p.n, m = p.m;
     const int64_t xo = H.xoff[pi], ro = H.roff[pi];
     // ---- A (global indices) ----
@@ -551,61 +659,95 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
                 atv[pos] = S.A.val[k];
             }
     }
-    // ---- K rows via a sparse accumulator (Gustavson) ----
-    std::vector<double> acc0(n, 0.0), acc1(n, 0.0);
-    std::vector<int32_t> mark(n, -1), cols;
+    pt.mark("  append: A, A'");
+    // ---- K = P + sigma I + rho A'A, kept as K0 + rho K1 on the union pattern ----
+    // A row of K has a few dozen entries: it is gathered into a small buffer, ordered by column
+    // (stable, so equal columns are summed in the order they were met) and merged.  Pass 1 counts
+    // the merged entries per row, pass 2 writes them in place; both run over row ranges in parallel
+    // and touch no O(n) scratch.
+    struct Ent { int32_t j; double v0, v1; };
+    auto gather_row = [&](int64_t i, std::vector<Ent>& buf) {
+        buf.clear();
+        buf.push_back(Ent{(int32_t)i, H.sigma, 0.0});
+        for (int k = S.P.ptr[i]; k < S.P.ptr[i + 1]; ++k) buf.push_back(Ent{S.P.col[k], S.P.val[k], 0.0});
+        for (int t2 = atp[i]; t2 < atp[i + 1]; ++t2) {
+            const int r = atr[t2];
+            const double a = atv[t2];
+            for (int k = S.A.ptr[r]; k < S.A.ptr[r + 1]; ++k) buf.push_back(Ent{S.A.col[k], 0.0, a * S.A.val[k]});
+        }
+        // insertion sort: short, mostly ordered input; stable
+        for (size_t x = 1; x < buf.size(); ++x) {
+            const Ent e = buf[x];
+            size_t y = x;
+            while (y > 0 && buf[y - 1].j > e.j) { buf[y] = buf[y - 1]; --y; }
+            buf[y] = e;
+        }
+    };
     const size_t k_row0 = H.K.ptr.size() - 1;  // == xo
-    (void)k_row0;
+    const int32_t k_base = H.K.ptr.back();
+    H.K.ptr.resize(k_row0 + 1 + n);
+    parallel_ranges(n, 8192, [&](int, int64_t i0, int64_t i1) {
+        std::vector<Ent> buf;
+        for (int64_t i = i0; i < i1; ++i) {
+            gather_row(i, buf);
+            int32_t cnt = 0;
+            for (size_t x = 0; x < buf.size(); ++x)
+                if (x == 0 || buf[x].j != buf[x - 1].j) ++cnt;
+            H.K.ptr[k_row0 + 1 + i] = cnt;
+        }
+    });
+    pt.mark("  append: K count");
+    for (int i = 0; i < n; ++i) H.K.ptr[k_row0 + 1 + i] += H.K.ptr[k_row0 + i];
+    const size_t k_end = (size_t)H.K.ptr[k_row0 + n];
+    (void)k_base;
+    H.K.col.resize(k_end); H.K0.resize(k_end); H.K1.resize(k_end);
+    pt.mark("  append: K resize");
+    parallel_ranges(n, 8192, [&](int, int64_t i0, int64_t i1) {
+        std::vector<Ent> buf;
+        for (int64_t i = i0; i < i1; ++i) {
+            gather_row(i, buf);
+            size_t o = (size_t)H.K.ptr[k_row0 + i];
+            size_t x = 0;
+            while (x < buf.size()) {
+                const int32_t j = buf[x].j;
+                double a0 = 0.0, a1 = 0.0;
+                for (; x < buf.size() && buf[x].j == j; ++x) { a0 += buf[x].v0; a1 += buf[x].v1; }
+                H.K.col[o] = (int32_t)(xo + j);
+                H.K0[o] = a0;
+                H.K1[o] = a1;
+                ++o;
+            }
+        }
+    });
+    pt.mark("  append: K fill");
+    // ---- G1 = [0 | A'] and G2 = [P | A'] (columns address the contiguous buffer [xt ; u]) ----
+    const size_t g1_base = H.G1.col.size(), g2_base = H.G2.col.size();
+    const size_t g1_row0 = H.G1.ptr.size(), g2_row0 = H.G2.ptr.size(), sp_row0 = H.g2_split.size();
+    H.G1.ptr.resize(g1_row0 + n); H.G2.ptr.resize(g2_row0 + n); H.g2_split.resize(sp_row0 + n);
     for (int i = 0; i < n; ++i) {
-        cols.clear();
-        auto touch = [&](int j) {
-            if (mark[j] != i) {
-                mark[j] = i;
-                acc0[j] = 0.0;
-                acc1[j] = 0.0;
-                cols.push_back(j);
-            }
-        };
-        touch(i);
-        acc0[i] += H.sigma;
-        for (int k = S.P.ptr[i]; k < S.P.ptr[i + 1]; ++k) {
-            touch(S.P.col[k]);
-            acc0[S.P.col[k]] += S.P.val[k];
-        }
-        for (int t = atp[i]; t < atp[i + 1]; ++t) {
-            const int r = atr[t];
-            const double a = atv[t];
-            for (int k = S.A.ptr[r]; k < S.A.ptr[r + 1]; ++k) {
-                touch(S.A.col[k]);
-                acc1[S.A.col[k]] += a * S.A.val[k];
-            }
-        }
-        std::sort(cols.begin(), cols.end());
-        // K row
-        for (int j : cols) {
-            H.K.col.push_back((int32_t)(xo + j));
-            H.K0.push_back(acc0[j]);
-            H.K1.push_back(acc1[j]);
-        }
-        H.K.ptr.push_back((int32_t)H.K.col.size());
-        // G1 row = [0 | A'] (columns address the contiguous buffer [xt ; u])
-        for (int t = atp[i]; t < atp[i + 1]; ++t) {
-            H.G1.col.push_back((int32_t)(H.n_tot + ro + atr[t]));
-            H.G1.val.push_back(atv[t]);
-        }
-        H.G1.ptr.push_back((int32_t)H.G1.col.size());
-        // G2 row = [P | A']
-        for (int k = S.P.ptr[i]; k < S.P.ptr[i + 1]; ++k) {
-            H.G2.col.push_back((int32_t)(xo + S.P.col[k]));
-            H.G2.val.push_back(S.P.val[k]);
-        }
-        H.g2_split.push_back((int32_t)H.G2.col.size());
-        for (int t = atp[i]; t < atp[i + 1]; ++t) {
-            H.G2.col.push_back((int32_t)(H.n_tot + ro + atr[t]));
-            H.G2.val.push_back(atv[t]);
-        }
-        H.G2.ptr.push_back((int32_t)H.G2.col.size());
+        H.G1.ptr[g1_row0 + i] = (int32_t)(g1_base + atp[i + 1]);
+        H.g2_split[sp_row0 + i] = (int32_t)(g2_base + S.P.ptr[i + 1] + atp[i]);
+        H.G2.ptr[g2_row0 + i] = (int32_t)(g2_base + S.P.ptr[i + 1] + atp[i + 1]);
     }
+    H.G1.col.resize(g1_base + atr.size()); H.G1.val.resize(g1_base + atr.size());
+    H.G2.col.resize(g2_base + S.P.col.size() + atr.size()); H.G2.val.resize(g2_base + S.P.col.size() + atr.size());
+    pt.mark("  append: G resize");
+    const int32_t ucol0 = (int32_t)(H.n_tot + ro);
+    parallel_ranges(n, 16384, [&](int, int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+            size_t o1 = g1_base + atp[i], o2 = g2_base + S.P.ptr[i] + atp[i];
+            for (int k = S.P.ptr[i]; k < S.P.ptr[i + 1]; ++k, ++o2) {
+                H.G2.col[o2] = (int32_t)(xo + S.P.col[k]);
+                H.G2.val[o2] = S.P.val[k];
+            }
+            for (int t2 = atp[i]; t2 < atp[i + 1]; ++t2, ++o1, ++o2) {
+                H.G1.col[o1] = ucol0 + atr[t2];
+                H.G1.val[o1] = atv[t2];
+                H.G2.col[o2] = ucol0 + atr[t2];
+                H.G2.val[o2] = atv[t2];
+            }
+        }
+    });
 }
 
 // (Re)compute everything that depends on rho for problem `pi`: K values, G1
@@ -613,29 +755,38 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
 inline void refresh_rho(HostSystem& H, int pi) {
     const double rho = H.rho[pi];
     const int64_t r0 = H.xoff[pi], r1 = H.xoff[pi + 1];
-    for (int64_t k = H.K.ptr[r0]; k < H.K.ptr[r1]; ++k) H.K.val[k] = H.K0[k] + rho * H.K1[k];
+    const int64_t k0 = H.K.ptr[r0], k1 = H.K.ptr[r1];
+    parallel_ranges(k1 - k0, 1 << 17, [&](int, int64_t a, int64_t b) {
+        for (int64_t k = k0 + a; k < k0 + b; ++k) H.K.val[k] = H.K0[k] + rho * H.K1[k];
+    });
     const int bs = H.bs, b2 = bs * bs;
-    for (size_t ci = 0; ci < H.chains.size(); ++ci) {
-        ChainDesc& ch = H.chains[ci];
-        if (ch.prob != pi) continue;
-        std::vector<double> Ad((size_t)ch.N * b2), Bs((size_t)ch.N * b2, 0.0);
-        for (int i = 0; i < ch.N; ++i) {
-            const size_t g = (size_t)(ch.node_begin + i) * b2;
-            for (int k = 0; k < b2; ++k) {
-                int pd = H.pos_diag[g + k];
-                Ad[(size_t)i * b2 + k] = pd >= 0 ? H.K.val[pd] : 0.0;
-                int ps = H.pos_sub[g + k];
-                Bs[(size_t)i * b2 + k] = (i > 0 && ps >= 0) ? H.K.val[ps] : 0.0;
-            }
-        }
+    std::vector<int32_t> mine;
+    for (size_t ci = 0; ci < H.chains.size(); ++ci)
+        if (H.chains[ci].prob == pi) mine.push_back((int32_t)ci);
+    parallel_ranges((int64_t)mine.size(), 1, [&](int, int64_t c0, int64_t c1) {
+        std::vector<double> Ad, Bs, fac;
         std::vector<ChainLevelDesc> lv;
-        std::vector<double> fac;
-        int scr = 0;
-        factor_chain_levels(bs, H.radix, ch.N, Ad, Bs, lv, fac, scr);
-        // level structure depends only on (N, radix): it was laid out at setup
-        const int64_t off = H.fac_off[ci];
-        std::memcpy(&H.fac[off], fac.data(), sizeof(double) * fac.size());
-    }
+        for (int64_t c = c0; c < c1; ++c) {
+            const size_t ci = mine[c];
+            const ChainDesc& ch = H.chains[ci];
+            Ad.assign((size_t)ch.N * b2, 0.0);
+            Bs.assign((size_t)ch.N * b2, 0.0);
+            for (int i = 0; i < ch.N; ++i) {
+                const size_t g = (size_t)(ch.node_begin + i) * b2;
+                for (int k = 0; k < b2; ++k) {
+                    int pd = H.pos_diag[g + k];
+                    Ad[(size_t)i * b2 + k] = pd >= 0 ? H.K.val[pd] : 0.0;
+                    int ps = H.pos_sub[g + k];
+                    Bs[(size_t)i * b2 + k] = (i > 0 && ps >= 0) ? H.K.val[ps] : 0.0;
+                }
+            }
+            lv.clear(); fac.clear();
+            int scr = 0;
+            factor_chain_levels(bs, H.radix, ch.N, Ad, Bs, lv, fac, scr);
+            // level structure depends only on (N, radix): it was laid out at setup
+            std::memcpy(&H.fac[H.fac_off[ci]], fac.data(), sizeof(double) * fac.size());
+        }
+    });
     for (size_t e = 0; e < H.diag_cols.size(); ++e) {
         int32_t c = H.diag_cols[e];
         if (c < r0 || c >= r1) continue;
@@ -645,6 +796,7 @@ inline void refresh_rho(HostSystem& H, int pi) {
 
 inline void build_system(const score_problem* probs, int count, const score_settings& st, HostSystem& H) {
     if (count <= 0) throw std::runtime_error("score_create: count must be positive");
+    PhaseTimer pt(st.verbose != 0);
     H = HostSystem();
     H.count = count;
     H.sigma = st.sigma;
@@ -654,6 +806,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     int bs = 0;
     for (int p = 0; p < count; ++p) {
         validate_problem(probs[p]);
+        pt.mark("validate");
         H.xoff[p + 1] = H.xoff[p] + probs[p].n;
         H.roff[p + 1] = H.roff[p] + probs[p].m;
         if (probs[p].n_chains > 0) {
@@ -677,6 +830,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         const score_problem& pr = probs[p];
         ProblemScaled S;
         ruiz_scale(pr, std::max(0, st.scale_iters), S);
+        pt.mark("ruiz");
         H.D.insert(H.D.end(), S.D.begin(), S.D.end());
         H.E.insert(H.E.end(), S.E.begin(), S.E.end());
         H.q.insert(H.q.end(), S.q.begin(), S.q.end());
@@ -686,7 +840,8 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         for (int j = 0; j < pr.n; ++j) { qu = std::max(qu, std::fabs(pr.q[j])); qs = std::max(qs, std::fabs(S.q[j])); }
         for (int r = 0; r < pr.m; ++r) { bu = std::max(bu, std::fabs(pr.b[r])); bsn = std::max(bsn, std::fabs(S.b[r])); }
         H.qnorm_u.push_back(qu); H.bnorm_u.push_back(bu); H.qnorm_s.push_back(qs); H.bnorm_s.push_back(bsn);
-        append_problem(H, p, pr, S);
+        append_problem(H, p, pr, S, pt);
+        pt.mark("append (K, G1, G2)");
         // cones, in blocks of kConesPerBlock that never straddle problems
         const size_t c_first = H.cone_row.size();
         for (int r = 0; r < pr.z; ++r) {
@@ -708,6 +863,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     H.rbK = make_rowblocks(H.K, H.xoff);
     H.rbG1 = make_rowblocks(H.G1, H.xoff);
     H.rbG2 = make_rowblocks(H.G2, H.xoff);
+    pt.mark("row blocks");
 
     // ---- preconditioner layout ----
     const int b2 = bs * bs;
@@ -750,21 +906,37 @@ inline void build_system(const score_problem* probs, int count, const score_sett
             H.chains.push_back(ch);
         }
     }
+    pt.mark("chain positions");
     // level layout (structure only) + storage
     H.fac_off.clear();
+    struct Layout { int N; std::vector<ChainLevelDesc> lv; size_t fac_size; int scr; };
+    size_t fac_total = H.fac.size();
+    std::vector<Layout> layouts;  // the level structure depends only on (N, radix): one dry run per length
     for (auto& ch : H.chains) {
-        // dry run on an identity chain to obtain the level structure
-        std::vector<double> Ad((size_t)ch.N * b2, 0.0), Bs((size_t)ch.N * b2, 0.0);
-        for (int i = 0; i < ch.N; ++i)
-            for (int a = 0; a < bs; ++a) Ad[(size_t)i * b2 + a * bs + a] = 1.0;
-        std::vector<ChainLevelDesc> lv;
-        std::vector<double> fac;
-        int scr = 0;
-        factor_chain_levels(bs, H.radix, ch.N, Ad, Bs, lv, fac, scr);
+        const Layout* lay = nullptr;
+        for (const auto& L : layouts)
+            if (L.N == ch.N) lay = &L;
+        if (!lay) {
+            // dry run on an identity chain to obtain the level structure
+            std::vector<double> Ad((size_t)ch.N * b2, 0.0), Bs((size_t)ch.N * b2, 0.0);
+            for (int i = 0; i < ch.N; ++i)
+                for (int a = 0; a < bs; ++a) Ad[(size_t)i * b2 + a * bs + a] = 1.0;
+            Layout L;
+            L.N = ch.N;
+            std::vector<double> f;
+            L.scr = 0;
+            factor_chain_levels(bs, H.radix, ch.N, Ad, Bs, L.lv, f, L.scr);
+            L.fac_size = f.size();
+            layouts.push_back(std::move(L));
+            lay = &layouts.back();
+        }
+        std::vector<ChainLevelDesc> lv = lay->lv;
+        const size_t fac_size = lay->fac_size;
+        const int scr = lay->scr;
         ch.level_begin = (int32_t)H.levels.size();
         ch.n_levels = (int32_t)lv.size();
         if (ch.n_levels > 20) throw std::runtime_error("chain too long: more than 20 partition levels");
-        const int64_t dbl_base = (int64_t)H.fac.size();
+        const int64_t dbl_base = (int64_t)fac_total;
         for (auto& L : lv) {
             L.offR += dbl_base;
             L.offS += dbl_base;
@@ -772,12 +944,14 @@ inline void build_system(const score_problem* probs, int count, const score_sett
             H.levels.push_back(L);
         }
         H.fac_off.push_back(dbl_base);
-        H.fac.resize(H.fac.size() + fac.size(), 0.0);
+        fac_total += fac_size;
         ch.scratch_off = (int32_t)H.scratch_nodes;
         ch.scratch_nodes = scr;
         H.scratch_nodes += scr;
         H.max_chain_scratch = std::max(H.max_chain_scratch, scr);
     }
+    H.fac.assign(fac_total, 0.0);
+    pt.mark("level layout (dry run)");
     // Jacobi columns + work list (problem-major: chains, then Jacobi blocks)
     size_t ci = 0;
     for (int p = 0; p < count; ++p) {
@@ -804,7 +978,9 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         const double n = (double)(H.xoff[p + 1] - H.xoff[p]);
         H.kkt_bytes[p] = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
     }
+    pt.mark("jacobi + work list");
     for (int p = 0; p < count; ++p) refresh_rho(H, p);
+    pt.mark("refresh_rho (factor)");
 }
 
 }  // namespace score

@@ -25,6 +25,9 @@
 namespace score {
 
 constexpr int kPolishMaxTail = 3;  // tail dimension d of SOC(d + 1), d in {2, 3}
+// added to the diagonal of the non-head rows: keeps H positive definite along flat directions
+// (landmarks all of whose cones are slack, gauge modes of robots no active cone ties down)
+constexpr double kPolishDiagReg = 1e-9;
 
 struct PolishData {
     bool available = false;
@@ -78,67 +81,103 @@ inline void build_polish(const HostSystem& H, PolishData& Q) {
     Q.T = T;
     // ---- Newton matrix pattern + contribution lists ----
     struct Contrib { int32_t j, cone, ab; double coef; };
-    std::vector<Contrib> rowc;
+    struct Part {  // rows [i0, i1) of H, built by one host thread
+        std::vector<int32_t> col, row_len, ent_len, ccone, cab;
+        std::vector<double> pon, ccoef;
+    };
+    std::vector<Part> parts(parallel_parts(n, 8192));
+    parallel_ranges(n, 8192, [&](int t, int64_t i0, int64_t i1) {
+        Part& W = parts[t];
+        std::vector<Contrib> rowc;
+        {   // reserve (virtual) room for the worst case so that the buffers never re-allocate
+            size_t ub_ent = 0, ub_con = 0;
+            for (int64_t i = i0; i < i1; ++i) {
+                ub_ent += (size_t)(H.g2_split[i] - H.G2.ptr[i]) + 1;
+                ub_con += (size_t)(H.G2.ptr[i + 1] - H.g2_split[i]) * T * 2;
+            }
+            ub_ent += ub_con;
+            W.col.reserve(ub_ent); W.pon.reserve(ub_ent); W.ent_len.reserve(ub_ent);
+            W.ccone.reserve(ub_con); W.cab.reserve(ub_con); W.ccoef.reserve(ub_con);
+            W.row_len.reserve(i1 - i0);
+        }
+        for (int64_t i = i0; i < i1; ++i) {
+            rowc.clear();
+            if (Q.is_head[i]) {  // decoupled: unit diagonal, the Newton step leaves it alone
+                W.col.push_back((int32_t)i);
+                W.pon.push_back(1.0);
+                W.ent_len.push_back(0);
+                W.row_len.push_back(1);
+                continue;
+            }
+            for (int k = H.G2.ptr[i]; k < H.g2_split[i]; ++k)  // P row (cone = -1 marks a P entry)
+                rowc.push_back(Contrib{H.G2.col[k], -1, 0, H.G2.val[k]});
+            bool has_diag = false;
+            for (const auto& c : rowc) has_diag = has_diag || (c.j == i);
+            if (!has_diag) rowc.push_back(Contrib{(int32_t)i, -1, 0, 0.0});
+            for (int t2 = H.g2_split[i]; t2 < H.G2.ptr[i + 1]; ++t2) {  // rows of A that contain column i
+                const int r = H.G2.col[t2] - (int32_t)n;
+                const double vi = H.G2.val[t2];
+                const int cone = cone_of_row[r];
+                const int r0 = H.cone_row[cone];
+                const int a = r - r0 - 1;  // tail index of row r
+                if (a < 0) continue;       // (head rows only hold the head column)
+                for (int b = 0; b < T; ++b) {
+                    const int rb = r0 + 1 + b;
+                    for (int kk = H.A.ptr[rb]; kk < H.A.ptr[rb + 1]; ++kk)
+                        rowc.push_back(Contrib{H.A.col[kk], cone, a * T + b, vi * H.A.val[kk]});
+                }
+            }
+            std::stable_sort(rowc.begin(), rowc.end(), [](const Contrib& x, const Contrib& y) { return x.j < y.j; });
+            size_t e = 0;
+            int32_t nent = 0;
+            while (e < rowc.size()) {
+                const int32_t j = rowc[e].j;
+                double pval = 0.0;
+                int32_t nc = 0;
+                for (; e < rowc.size() && rowc[e].j == j; ++e) {
+                    if (rowc[e].cone < 0) pval += rowc[e].coef;
+                    else { W.ccone.push_back(rowc[e].cone); W.cab.push_back(rowc[e].ab); W.ccoef.push_back(rowc[e].coef); ++nc; }
+                }
+                W.col.push_back(j);
+                W.pon.push_back(j == i ? pval + kPolishDiagReg : pval);
+                W.ent_len.push_back(nc);
+                ++nent;
+            }
+            W.row_len.push_back(nent);
+        }
+    });
     Q.Hm.nrows = Q.Hm.ncols = n;
     Q.Hm.ptr.assign(1, 0);
     Q.cptr.assign(1, 0);
-    for (int64_t i = 0; i < n; ++i) {
-        rowc.clear();
-        if (Q.is_head[i]) {  // decoupled: unit diagonal, the Newton step leaves it alone
-            Q.Hm.col.push_back((int32_t)i);
-            Q.Pon.push_back(1.0);
-            Q.cptr.push_back((int32_t)Q.ccone.size());
-            Q.Hm.ptr.push_back((int32_t)Q.Hm.col.size());
-            continue;
-        }
-        for (int k = H.G2.ptr[i]; k < H.g2_split[i]; ++k)  // P row (cone = -1 marks a P entry)
-            rowc.push_back(Contrib{H.G2.col[k], -1, 0, H.G2.val[k]});
-        bool has_diag = false;
-        for (const auto& c : rowc) has_diag = has_diag || (c.j == i);
-        if (!has_diag) rowc.push_back(Contrib{(int32_t)i, -1, 0, 0.0});
-        for (int t = H.g2_split[i]; t < H.G2.ptr[i + 1]; ++t) {  // rows of A that contain column i
-            const int r = H.G2.col[t] - (int32_t)n;
-            const double vi = H.G2.val[t];
-            const int cone = cone_of_row[r];
-            const int r0 = H.cone_row[cone];
-            const int a = r - r0 - 1;  // tail index of row r
-            if (a < 0) continue;       // (head rows only hold the head column)
-            for (int b = 0; b < T; ++b) {
-                const int rb = r0 + 1 + b;
-                for (int kk = H.A.ptr[rb]; kk < H.A.ptr[rb + 1]; ++kk)
-                    rowc.push_back(Contrib{H.A.col[kk], cone, a * T + b, vi * H.A.val[kk]});
-            }
-        }
-        std::stable_sort(rowc.begin(), rowc.end(), [](const Contrib& x, const Contrib& y) { return x.j < y.j; });
-        size_t e = 0;
-        while (e < rowc.size()) {
-            const int32_t j = rowc[e].j;
-            double pval = 0.0;
-            for (; e < rowc.size() && rowc[e].j == j; ++e) {
-                if (rowc[e].cone < 0) pval += rowc[e].coef;
-                else { Q.ccone.push_back(rowc[e].cone); Q.cab.push_back(rowc[e].ab); Q.ccoef.push_back(rowc[e].coef); }
-            }
-            Q.Hm.col.push_back(j);
-            Q.Pon.push_back(pval);
-            Q.cptr.push_back((int32_t)Q.ccone.size());
-        }
-        Q.Hm.ptr.push_back((int32_t)Q.Hm.col.size());
+    for (const Part& W : parts) {
+        Q.Hm.col.insert(Q.Hm.col.end(), W.col.begin(), W.col.end());
+        Q.Pon.insert(Q.Pon.end(), W.pon.begin(), W.pon.end());
+        Q.ccone.insert(Q.ccone.end(), W.ccone.begin(), W.ccone.end());
+        Q.cab.insert(Q.cab.end(), W.cab.begin(), W.cab.end());
+        Q.ccoef.insert(Q.ccoef.end(), W.ccoef.begin(), W.ccoef.end());
+        for (int32_t l : W.row_len) Q.Hm.ptr.push_back(Q.Hm.ptr.back() + l);
+        for (int32_t l : W.ent_len) Q.cptr.push_back(Q.cptr.back() + l);
     }
-    Q.Hm.val.assign(Q.Hm.col.size(), 0.0);
     Q.rbH = make_rowblocks(Q.Hm, H.xoff);
     // ---- chain block / Jacobi positions in H ----
     const int bs = H.bs;
-    Q.pos_diag.clear(); Q.pos_sub.clear();
+    const int b2 = bs * bs;
+    Q.pos_diag.assign(H.node_col.size() * b2, -1);
+    Q.pos_sub.assign(H.node_col.size() * b2, -1);
+    std::vector<int32_t> prev_col(H.node_col.size(), -1);  // column of the chain predecessor
     for (const auto& ch : H.chains)
-        for (int i = 0; i < ch.N; ++i) {
-            const int32_t col = H.node_col[ch.node_begin + i];
+        for (int i = 1; i < ch.N; ++i) prev_col[ch.node_begin + i] = H.node_col[ch.node_begin + i - 1];
+    parallel_ranges((int64_t)H.node_col.size(), 2048, [&](int, int64_t g0, int64_t g1) {
+        for (int64_t g = g0; g < g1; ++g) {
+            const int32_t col = H.node_col[g];
+            size_t o = (size_t)g * b2;
             for (int a = 0; a < bs; ++a)
-                for (int b = 0; b < bs; ++b) {
-                    Q.pos_diag.push_back(find_in_row(Q.Hm, col + a, col + b));
-                    if (i > 0) Q.pos_sub.push_back(find_in_row(Q.Hm, col + a, H.node_col[ch.node_begin + i - 1] + b));
-                    else Q.pos_sub.push_back(-1);
+                for (int b = 0; b < bs; ++b, ++o) {
+                    Q.pos_diag[o] = find_in_row(Q.Hm, col + a, col + b);
+                    if (prev_col[g] >= 0) Q.pos_sub[o] = find_in_row(Q.Hm, col + a, prev_col[g] + b);
                 }
         }
+    });
     Q.diag_pos.clear();
     for (int32_t c : H.diag_cols) Q.diag_pos.push_back(find_in_row(Q.Hm, c, c));
     Q.available = true;
