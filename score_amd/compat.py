@@ -226,17 +226,13 @@ class FactorGraphData:
         """Variables no factor that SCORE uses touches (solve_score.py:28-32)."""
         touched = set()
         for chain in self.odom_measurements:
-            for m in chain:
-                touched.add(m.base_pose)
-                touched.add(m.to_pose)
-        for m in self.loop_closure_measurements:
-            touched.add(m.base_pose)
-            touched.add(m.to_pose)
+            touched.update(m.base_pose for m in chain)
+            touched.update(m.to_pose for m in chain)
+        touched.update(m.base_pose for m in self.loop_closure_measurements)
+        touched.update(m.to_pose for m in self.loop_closure_measurements)
         for m in self.range_measurements:
-            touched.add(m.first_key)
-            touched.add(m.second_key)
-        for p in self.landmark_priors:
-            touched.add(p.name)
+            touched.update(m.association)
+        touched.update(p.name for p in self.landmark_priors)
         return [n for n in self.all_variable_names if n not in touched]
 
     def get_pose_chain_names(self) -> List[List[str]]:

@@ -158,6 +158,7 @@ struct HipBackend {
     int n_cone_blocks = 0, n_prec = 0;
     size_t prec_lds = 0;
     bool prec_lds0 = true;
+    bool prec_pre = false;  // every chain fits the lane budget of k_prec_pre
     static bool n_prec_chains(const HostSystem& h) { return !h.chains.empty(); }
 
     ~HipBackend() {
@@ -216,6 +217,28 @@ struct HipBackend {
         const size_t lds_up = (16 + (size_t)max_nodes * std::max(1, h.bs)) * sizeof(double);
         prec_lds0 = lds_all <= 144 * 1024;
         prec_lds = prec_lds0 ? lds_all : lds_up;
+        // k_prec_pre (level 0 in registers, coarser levels staged into LDS): every chain needs
+        // <= 256 level-0 runs, its vector in one chunk of loads, coarse factors that fit the
+        // staging registers, and everything within the LDS budget
+        prec_pre = h.bs >= 1 && h.bs <= 3 && !h.chains.empty();
+        size_t lds_pre = 0;
+        for (const auto& ch : h.chains) {
+            const ChainLevelDesc* lv = &h.levels[ch.level_begin];
+            int64_t deep = 0;
+            if (ch.n_levels >= 2) {
+                const ChainLevelDesc& Lz = lv[ch.n_levels - 1];
+                deep = Lz.offB + (int64_t)2 * h.bs * h.bs * Lz.N - lv[1].offR;
+            }
+            const int ng = std::max(8 * h.bs * h.bs, 32);
+            if (lv[0].nruns > kPreRunLanes || (ch.n_levels >= 2 && lv[1].N > kPrecThreads - kPreRunLanes) || (int64_t)ch.N * h.bs > (int64_t)kPrecChunk * kPrecThreads ||
+                deep > (int64_t)ng * (kPrecThreads - kPreRunLanes))
+                prec_pre = false;
+            const ChainLevelDesc& Lend = lv[ch.n_levels - 1];
+            const size_t vec_doubles = (size_t)Lend.lds_off + (size_t)Lend.N * h.bs + 1;
+            lds_pre = std::max(lds_pre, (16 + vec_doubles + (size_t)(lv[0].nruns + 1) * h.bs + (size_t)deep) * sizeof(double));
+        }
+        if (lds_pre > 144 * 1024) prec_pre = false;
+        if (prec_pre) { prec_lds0 = true; prec_lds = lds_pre; }
         if (prec_lds > 144 * 1024) throw std::runtime_error("chain too long for the LDS-resident chain solver");
         if (prec_lds > 48 * 1024 && n_prec_chains(h)) {
             if (h.bs <= 1) allow_big_lds<1>(); else if (h.bs == 2) allow_big_lds<2>();
@@ -302,7 +325,9 @@ struct HipBackend {
         const int bs = H->bs;
 #define SCORE_LAUNCH_PREC(BS)                                                                                  \
     do {                                                                                                       \
-        if (prec_lds0)                                                                                         \
+        if (prec_pre && BS <= 3)                                                                               \
+            hipLaunchKernelGGL((k_prec_pre<(BS <= 3 ? BS : 3), MODE>), dim3(n_prec), dim3(kPrecThreads), prec_lds, stream, pa); \
+        else if (prec_lds0)                                                                                    \
             hipLaunchKernelGGL((k_prec<BS, 3, MODE, true>), dim3(n_prec), dim3(kPrecThreads), prec_lds, stream, pa); \
         else                                                                                                   \
             hipLaunchKernelGGL((k_prec<BS, 3, MODE, false>), dim3(n_prec), dim3(kPrecThreads), prec_lds, stream, pa); \
@@ -318,6 +343,9 @@ struct HipBackend {
     void allow_big_lds() {
         HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_INIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prec_lds));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_STEP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prec_lds));
+        constexpr int BP = BS <= 3 ? BS : 3;
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_INIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prec_lds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prec_lds));
     }
 
     SpmvArgs spmv_args(const CsrBufs& M, const double* xin) {
@@ -770,6 +798,7 @@ struct HipBackend {
             if (which == "rhs") { SpmvArgs ra = spmv_args(G1, xtu.d); ra.apply_update = 1; hipLaunchKernelGGL(k_spmv<MODE_RHS>, dim3(G1.nblocks), dim3(kThreads), 0, stream, ra); }
             else if (which.rfind("prec_init:", 0) == 0) { pa.debug_skip = std::atoi(which.c_str() + 10); launch_prec<PREC_INIT>(pa); }
             else if (which == "prec_init") launch_prec<PREC_INIT>(pa);
+            else if (which.rfind("prec_step:", 0) == 0) { pa.debug_skip = std::atoi(which.c_str() + 10); launch_prec<PREC_STEP>(pa); }
             else if (which == "prec_step") launch_prec<PREC_STEP>(pa);
             else if (which == "kp") launch_kp(p.d);
             else if (which == "kpb") launch_kpb(p.d, p2.d, rz_part1.d, rz_part0.d);

@@ -120,6 +120,10 @@ struct ChainLevelDesc {
     int32_t P;        // node positions per run (p - 1; last level: N)
     int32_t nsep;     // separators (N / p; last level: 0)
     int32_t vec_off;  // first node of this level in the chain's scratch (level >= 1)
+    // bank-conflict-free vector layout of k_prec_pre: component c of node i of this level lives at
+    // lds_off + i * bs + i / p + c (one padding double per run + separator), all levels back to back
+    int32_t lds_off;
+    uint32_t inv_p;   // 2^20 / p + 1: i / p == (i * inv_p) >> 20 for i < 2^18
     int64_t offR, offS, offB;  // offsets into `fac`, in doubles
 };
 
@@ -209,7 +213,7 @@ inline void factor_chain_levels(int bs, int radix, int N0, const std::vector<dou
                                 std::vector<double>& fac, int& scratch_nodes) {
     const int b2 = bs * bs;
     std::vector<double> curA = Ad, curB = Bs;
-    int N = N0, vec_off = 0;
+    int N = N0, vec_off = 0, lds_off = 0;
     double D[16], T1[16], T2[16];
     std::vector<double> aos;  // node records [Lf|Cl, Dinv|Cr, V, W] of the current level
     for (int lvl = 0;; ++lvl) {
@@ -221,6 +225,9 @@ inline void factor_chain_levels(int bs, int radix, int N0, const std::vector<dou
         auto nd = [&](int i, int slot) { return &aos[((size_t)i * 4 + slot) * b2]; };
         const bool last = (N <= radix - 1);  // the closing run must fit a lane's register tile (radix - 1 nodes)
         L.p = last ? 0 : radix;
+        L.inv_p = last ? 0u : ((1u << 20) / (uint32_t)radix + 1u);
+        L.lds_off = lds_off;
+        lds_off += N * bs + (last ? 0 : N / radix) + 1;
         const int nsep = last ? 0 : N / radix;
         L.nsep = nsep;
         L.nruns = nsep + 1;

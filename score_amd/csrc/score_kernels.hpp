@@ -24,6 +24,8 @@
 //  * no MFMA anywhere: nothing here is a dense contraction.
 #pragma once
 
+#include <type_traits>
+
 #include <hip/hip_runtime.h>
 
 #include "score_host.hpp"
@@ -404,6 +406,50 @@ __device__ __forceinline__ void load_run(const double* __restrict__ fac, const C
     }
 }
 
+// Jacobi work item (columns outside every chain): z = r / diag(K), with the PCG step folded in.
+template <int MODE>
+__device__ __forceinline__ double prec_jacobi_item(const PrecArgs& a, const PrecWork& wk, double acc_rz, double acc_pw,
+                                                   double* red) {
+    const int t = threadIdx.x;
+    double alpha = 0.0, local = 0.0;
+    if (MODE == PREC_STEP) {
+        block_sum2_n<kPrecWaves>(acc_rz, acc_pw, red);
+        alpha = acc_pw > 0.0 ? acc_rz / acc_pw : 0.0;
+    }
+    // Jacobi columns.  Every load is unconditional on a clamped index so that the
+    // whole chunk is in flight at once; only the stores are predicated.
+    const int e_end = wk.index + wk.count;
+    for (int base = wk.index + t; base < e_end; base += kPrecThreads * kPrecChunk) {
+        int cols[kPrecChunk];
+        double rv[kPrecChunk], dv[kPrecChunk], pv[kPrecChunk], wv[kPrecChunk], xv[kPrecChunk], kv[kPrecChunk];
+#pragma unroll
+        for (int u = 0; u < kPrecChunk; ++u) cols[u] = a.diag_cols[min(base + u * kPrecThreads, e_end - 1)];
+#pragma unroll
+        for (int u = 0; u < kPrecChunk; ++u) {
+            rv[u] = a.r[cols[u]];
+            dv[u] = a.dinv[min(base + u * kPrecThreads, e_end - 1)];
+            if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt[cols[u]]; kv[u] = a.kx[cols[u]]; }
+        }
+#pragma unroll
+        for (int u = 0; u < kPrecChunk; ++u) {
+            if (base + u * kPrecThreads < e_end) {
+                double r_ = rv[u];
+                if (MODE == PREC_STEP) {
+                    a.xt[cols[u]] = xv[u] + alpha * pv[u];
+                    a.kx[cols[u]] = kv[u] + alpha * wv[u];
+                    r_ -= alpha * wv[u];
+                    a.r[cols[u]] = r_;
+                }
+                const double zv = r_ * dv[u];
+                a.z[cols[u]] = zv;
+                if (MODE == PREC_INIT) a.p[cols[u]] = zv;
+                local += r_ * zv;
+            }
+        }
+    }
+    return local;
+}
+
 // BS: block size, RMAX: radix - 1 (nodes per run), LDS0: level-0 vector in LDS.
 // Phases of one level: (run) every run of <= RMAX nodes is solved by one lane;
 // (sep) reduced right-hand sides of the separators go to the next level;
@@ -430,41 +476,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
     double alpha = 0.0;
     double local = 0.0;
     if (wk.kind == 1) {
-        if (MODE == PREC_STEP) {
-            block_sum2_n<kPrecWaves>(acc_rz, acc_pw, red);
-            alpha = acc_pw > 0.0 ? acc_rz / acc_pw : 0.0;
-        }
-        // Jacobi columns.  Every load is unconditional on a clamped index so that the
-        // whole chunk is in flight at once; only the stores are predicated.
-        const int e_end = wk.index + wk.count;
-        for (int base = wk.index + t; base < e_end; base += kPrecThreads * kPrecChunk) {
-            int cols[kPrecChunk];
-            double rv[kPrecChunk], dv[kPrecChunk], pv[kPrecChunk], wv[kPrecChunk], xv[kPrecChunk], kv[kPrecChunk];
-#pragma unroll
-            for (int u = 0; u < kPrecChunk; ++u) cols[u] = a.diag_cols[min(base + u * kPrecThreads, e_end - 1)];
-#pragma unroll
-            for (int u = 0; u < kPrecChunk; ++u) {
-                rv[u] = a.r[cols[u]];
-                dv[u] = a.dinv[min(base + u * kPrecThreads, e_end - 1)];
-                if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt[cols[u]]; kv[u] = a.kx[cols[u]]; }
-            }
-#pragma unroll
-            for (int u = 0; u < kPrecChunk; ++u) {
-                if (base + u * kPrecThreads < e_end) {
-                    double r_ = rv[u];
-                    if (MODE == PREC_STEP) {
-                        a.xt[cols[u]] = xv[u] + alpha * pv[u];
-                        a.kx[cols[u]] = kv[u] + alpha * wv[u];
-                        r_ -= alpha * wv[u];
-                        a.r[cols[u]] = r_;
-                    }
-                    const double zv = r_ * dv[u];
-                    a.z[cols[u]] = zv;
-                    if (MODE == PREC_INIT) a.p[cols[u]] = zv;
-                    local += r_ * zv;
-                }
-            }
-        }
+        local = prec_jacobi_item<MODE>(a, wk, acc_rz, acc_pw, red);
     } else {
         constexpr int B2 = BS * BS;
         const ChainDesc ch = a.chains[wk.index];
@@ -740,6 +752,462 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
                     if (MODE == PREC_INIT) a.p[cols[u]] = zz[u];
                     local += rv[u] * zz[u];
                 }
+            }
+        }
+    }
+    const double tot = block_sum_n<kPrecWaves>(local, red);
+    if (t == 0) a.rz_out[blockIdx.x] = tot;
+}
+
+// ---------------------------------------------------------------------------
+// k_prec_pre: the same solve with every factor block requested up front.
+//
+// A phase of k_prec is a few dozen FMAs between two barriers -- far shorter than
+// a trip to L2/HBM -- so requesting a phase's blocks one phase ahead still exposes
+// most of the latency once per phase (measured: ~3 us per level).  Here nothing
+// is requested inside the level loop:
+//   * level 0 (3/4 of the data) lives in registers: lane j < 256 holds run j and
+//     separator j for the whole kernel.  The level-0 spikes are not read at all: the
+//     back-substitution re-solves each run against the separator couplings, which the
+//     lane already holds (144 instead of 324 bytes per node);
+//   * the factors of ALL coarser levels (contiguous in `fac`) are staged into LDS by
+//     lanes 256..511 while lanes 0..255 fetch level 0, so the coarse phases only
+//     touch LDS.
+// Every load of the kernel is therefore in flight before the first barrier, apart
+// from the operands of the fused xt / kx update, which are requested many phases
+// before their use.  The host selects this kernel when every
+// chain fits (HipBackend::init: <= 256 level-0 runs, coarse factors fit the
+// staging registers and LDS); otherwise k_prec runs.
+// ---------------------------------------------------------------------------
+// orders the LDS traffic of one wavefront: what its lanes wrote before is visible to all of them after
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kPreRunLanes = 256;
+template <int BS>
+struct PreTile {
+    static constexpr int B2 = BS * BS;
+    static constexpr int NG = (8 * B2 > 32) ? 8 * B2 : 32;  // run (6 B2) + separator (2 B2) blocks | staging
+};
+
+template <int BS, int MODE>
+__global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
+    constexpr int RMAX = 3;
+    constexpr int B2 = BS * BS;
+    constexpr int NG = PreTile<BS>::NG;
+    constexpr int oCl = 2 * RMAX * B2, oCr = oCl + B2;
+    constexpr int kStageLanes = kPrecThreads - kPreRunLanes;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ ChainLevelDesc sLv[kMaxLevels];
+    double* red = lds;
+    const PrecWork wk = a.work[blockIdx.x];
+    const int prob = wk.prob;
+    if (a.done[prob]) return;
+    const int t = threadIdx.x;
+    double acc_rz = 0.0, acc_pw = 0.0;
+    if (MODE == PREC_STEP) {
+        const int l0 = a.prec_part_ptr[prob], l1 = a.prec_part_ptr[prob + 1];
+        const int k0 = a.kblk_part_ptr[prob], k1 = a.kblk_part_ptr[prob + 1];
+        for (int i = l0 + t; i < l1; i += kPrecThreads) acc_rz += a.rz_in[i];
+        for (int i = k0 + t; i < k1; i += kPrecThreads) acc_pw += a.pw_part[i];
+    }
+    double local = 0.0;
+    if (wk.kind == 1) {
+        local = prec_jacobi_item<MODE>(a, wk, acc_rz, acc_pw, red);
+    } else {
+        const ChainDesc ch = a.chains[wk.index];
+        const ChainLevelDesc* __restrict__ lv = a.levels + ch.level_begin;
+        const int32_t* __restrict__ nc = a.node_col + ch.node_begin;
+        const double* __restrict__ fac = a.fac;
+        const int N = ch.N;
+        const int NB = N * BS;
+        const int nl = ch.n_levels;
+        const int stride = ch.col_stride, col0 = ch.col0;
+        auto colof = [&](int node) -> int { return stride ? col0 + node * stride : nc[node]; };
+        // vectors of all levels, padded (see ChainLevelDesc::lds_off): node i, component c of level
+        // L at vb[L.lds_off + i * BS + i / L.p + c]
+        double* vb = lds + 16;
+        double* v0 = vb;  // level 0
+        if (t < nl) sLv[t] = lv[t];
+        const ChainLevelDesc L0 = lv[0];
+        const ChainLevelDesc Lz = lv[nl - 1];
+        double* lfac = vb + Lz.lds_off + Lz.N * BS + 1;  // factors of the levels >= 1
+        auto pad = [](const ChainLevelDesc& L, int i) -> int { return (int)(((uint32_t)i * L.inv_p) >> 20); };  // i / p (0 on the last level)
+        auto nodep = [&](const ChainLevelDesc& L, int i) -> double* { return vb + L.lds_off + i * BS + pad(L, i); };
+        int64_t deep_base = 0;
+        int deep_cnt = 0;
+        if (nl >= 2) {
+            deep_base = lv[1].offR;
+            deep_cnt = (int)(Lz.offB + (int64_t)2 * B2 * Lz.N - deep_base);
+        }
+        double* xch = lfac + deep_cnt;  // coupling terms handed from a separator to the run on its right
+        // ---- vector loads (only r and w feed the solve; the operands of the xt / kx update
+        //      are requested later: the register file is full here) ----
+        int cols[kPrecChunk];
+        double rv[kPrecChunk], wv[kPrecChunk];
+#pragma unroll
+        for (int u = 0; u < kPrecChunk; ++u) {
+            const int idx = min(t + u * kPrecThreads, NB - 1);
+            const int node = idx / BS;
+            cols[u] = colof(node) + (idx - node * BS);
+        }
+#pragma unroll
+        for (int u = 0; u < kPrecChunk; ++u) {
+            rv[u] = a.r[cols[u]];
+            if (MODE == PREC_STEP) wv[u] = a.w[cols[u]];
+        }
+        // ---- factor loads: level 0 -> registers (lanes < 256), coarser levels -> staging ----
+        double G[NG];
+        const bool l0_last = (L0.p == 0);
+        if (t < kPreRunLanes) {
+            if ((t & ~63) < L0.nruns && !(a.debug_skip & 1)) {
+                const int j = min(t, L0.nruns - 1);
+                const int lo = l0_last ? 0 : j * L0.p;
+                const int hi = l0_last ? L0.N : min(j * L0.p + L0.p - 1, L0.N);
+                const int len = max(hi - lo, 1);
+                const size_t eP = (size_t)L0.P * L0.nruns;
+                const double* __restrict__ R = fac + L0.offR;
+#pragma unroll
+                for (int q = 0; q < RMAX; ++q) {
+                    const double* __restrict__ Rq = R + (size_t)min(q, len - 1) * L0.nruns + j;
+#pragma unroll
+                    for (int e = 0; e < B2; ++e) {
+                        G[q * B2 + e] = Rq[(size_t)e * eP];
+                        G[(RMAX + q) * B2 + e] = Rq[(size_t)(B2 + e) * eP];
+                    }
+                }
+                if (L0.nsep > 0) {
+                    const double* __restrict__ S = fac + L0.offS;
+                    const int js = min(t, L0.nsep - 1);
+#pragma unroll
+                    for (int e = 0; e < B2; ++e) {
+                        G[oCl + e] = S[(size_t)e * L0.nsep + js];
+                        G[oCr + e] = S[(size_t)(B2 + e) * L0.nsep + js];
+                    }
+                }
+            }
+        } else if (deep_cnt > 0 && !(a.debug_skip & 2)) {
+            const double* __restrict__ src = fac + deep_base;
+            const int lane = t - kPreRunLanes;
+#pragma unroll
+            for (int k0 = 0; k0 < NG; k0 += 8) {
+                if (k0 * kStageLanes < deep_cnt) {  // uniform
+#pragma unroll
+                    for (int k = k0; k < k0 + 8; ++k) G[k] = src[min(lane + k * kStageLanes, deep_cnt - 1)];
+                }
+            }
+        }
+        // ---- alpha (every lane joins the reduction), then the vector update into LDS ----
+        double alpha = 0.0;
+        if (MODE == PREC_STEP) {
+            block_sum2_n<kPrecWaves>(acc_rz, acc_pw, red);
+            alpha = acc_pw > 0.0 ? acc_rz / acc_pw : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kPrecChunk; ++u) {
+            const int idx = t + u * kPrecThreads;
+            if (idx < NB) {
+                double r_ = rv[u];
+                if (MODE == PREC_STEP) {
+                    r_ -= alpha * wv[u];
+                    a.r[cols[u]] = r_;
+                }
+                v0[idx + pad(L0, idx / BS)] = r_;
+                rv[u] = r_;
+            }
+        }
+        if (t >= kPreRunLanes) {
+            if (deep_cnt > 0 && !(a.debug_skip & 2)) {
+                const int lane = t - kPreRunLanes;
+#pragma unroll
+                for (int k0 = 0; k0 < NG; k0 += 8) {
+                    if (k0 * kStageLanes < deep_cnt) {
+#pragma unroll
+                        for (int k = k0; k < k0 + 8; ++k) {
+                            const int idx = lane + k * kStageLanes;
+                            if (idx < deep_cnt) lfac[idx] = G[k];
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // in-place solve with the diagonal block of a level-0 run: y <- T_run^-1 y (first len nodes)
+        auto run_solve0 = [&](double (&y)[RMAX][BS], int len) {
+#pragma unroll
+            for (int q = 1; q < RMAX; ++q) {
+#pragma unroll
+                for (int c = 0; c < BS; ++c) {
+                    double s_ = y[q][c];
+#pragma unroll
+                    for (int k = 0; k < BS; ++k) s_ -= G[q * B2 + c * BS + k] * y[q - 1][k];
+                    y[q][c] = s_;
+                }
+            }
+#pragma unroll
+            for (int q = RMAX - 1; q >= 0; --q) {
+                double tmp[BS];
+#pragma unroll
+                for (int c = 0; c < BS; ++c) {
+                    double s_ = 0.0;
+#pragma unroll
+                    for (int k = 0; k < BS; ++k) s_ += G[(RMAX + q) * B2 + c * BS + k] * y[q][k];
+                    tmp[c] = s_;
+                }
+                if (q + 1 < RMAX) {
+                    const bool has_next = (q + 1 < len);
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) {
+                        double s_ = 0.0;
+#pragma unroll
+                        for (int k = 0; k < BS; ++k) s_ += G[(q + 1) * B2 + k * BS + c] * y[q + 1][k];
+                        tmp[c] = has_next ? tmp[c] - s_ : tmp[c];
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < BS; ++c) y[q][c] = tmp[c];
+            }
+        };
+        // ---- level 0, run phase (registers) ----
+        const bool dbg_nophase = (a.debug_skip & 4) != 0;
+        if (t < L0.nruns && !dbg_nophase) {
+            const int j = t;
+            const int lo = l0_last ? 0 : j * L0.p;
+            const int hi = l0_last ? L0.N : min(j * L0.p + L0.p - 1, L0.N);
+            const int len = hi - lo;
+            const int jpad = l0_last ? 0 : j;
+            if (len > 0) {
+                double y[RMAX][BS];
+#pragma unroll
+                for (int q = 0; q < RMAX; ++q) {
+                    const double* src = v0 + (lo + min(q, len - 1)) * BS + jpad;
+#pragma unroll
+                    for (int c = 0; c < BS; ++c) y[q][c] = src[c];
+                }
+                run_solve0(y, len);
+#pragma unroll
+                for (int q = 0; q < RMAX; ++q) {
+                    if (q < len) {
+                        double* dst = v0 + (lo + q) * BS + jpad;
+#pragma unroll
+                        for (int c = 0; c < BS; ++c) dst[c] = y[q][c];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (nl >= 2 && !dbg_nophase) {
+            // ---- level 0, separator phase (registers) ----
+            const ChainLevelDesc L1 = sLv[1];
+            if (t < L0.nsep) {
+                const int s = t * L0.p + L0.p - 1;
+                const bool has_r = (s + 1 < L0.N);  // Cr is zero when there is no right run
+                const double* pv_ = v0 + s * BS + t;
+                const double* pm = v0 + (s - 1) * BS + t;
+                const double* pp = has_r ? v0 + (s + 1) * BS + t + 1 : pv_;
+                double v[BS], ym[BS], yp[BS];
+#pragma unroll
+                for (int c = 0; c < BS; ++c) { v[c] = pv_[c]; ym[c] = pm[c]; yp[c] = pp[c]; }
+#pragma unroll
+                for (int c = 0; c < BS; ++c) {
+                    double acc = v[c];
+#pragma unroll
+                    for (int k = 0; k < BS; ++k) acc -= G[oCl + c * BS + k] * ym[k] + G[oCr + c * BS + k] * yp[k];
+                    nodep(L1, t)[c] = acc;
+                }
+            }
+            __syncthreads();
+        }
+        // The step's xt += alpha p, kx += alpha w in two halves (the run blocks stay in registers,
+        // there is no room for all operands at once): the first half is in flight during the coarse
+        // levels, the second during the level-0 back-substitution.
+        constexpr int kHalf = kPrecChunk / 2;
+        double pv[kHalf], wq[kHalf], xv[kHalf], kv[kHalf];
+        auto upd_load = [&](auto half) {
+            constexpr int u0 = decltype(half)::value * kHalf;
+#pragma unroll
+            for (int u = 0; u < kHalf; ++u) {
+                pv[u] = a.p[cols[u0 + u]]; wq[u] = a.w[cols[u0 + u]]; xv[u] = a.xt[cols[u0 + u]]; kv[u] = a.kx[cols[u0 + u]];
+            }
+        };
+        auto upd_store = [&](auto half) {
+            constexpr int u0 = decltype(half)::value * kHalf;
+#pragma unroll
+            for (int u = 0; u < kHalf; ++u) {
+                if (t + (u0 + u) * kPrecThreads < NB) {
+                    a.xt[cols[u0 + u]] = xv[u] + alpha * pv[u];
+                    a.kx[cols[u0 + u]] = kv[u] + alpha * wq[u];
+                }
+            }
+        };
+        using H0 = std::integral_constant<int, 0>;
+        using H1 = std::integral_constant<int, 1>;
+        if (MODE == PREC_STEP) upd_load(H0());
+        // ---- coarser levels: factors and vectors in LDS.  Lanes 256..511 do this work: their
+        //      register tile G is free (the staging is over), so each phase first pulls all its
+        //      blocks from LDS into G and only then starts the dependent arithmetic ----
+        const int dt = t - kPreRunLanes;
+        for (int l = 1; l < nl && !dbg_nophase; ++l) {
+            const ChainLevelDesc L = sLv[l];
+            const bool last = (L.p == 0);
+            if (dt >= 0 && dt < L.nruns) {
+                const int j = dt;
+                const int lo = last ? 0 : j * L.p;
+                const int hi = last ? L.N : min(j * L.p + L.p - 1, L.N);
+                const int len = hi - lo;
+                if (len > 0) {
+                    const int eP = L.P * L.nruns;
+                    const double* R = lfac + (L.offR - deep_base);
+#pragma unroll
+                    for (int q = 0; q < RMAX; ++q) {
+                        const double* Rq = R + min(q, len - 1) * L.nruns + j;
+#pragma unroll
+                        for (int e = 0; e < B2; ++e) {
+                            G[q * B2 + e] = Rq[e * eP];
+                            G[(RMAX + q) * B2 + e] = Rq[(B2 + e) * eP];
+                        }
+                    }
+                    double* vr = vb + L.lds_off + lo * BS + (last ? 0 : j);
+                    double y[RMAX][BS];
+#pragma unroll
+                    for (int q = 0; q < RMAX; ++q)
+#pragma unroll
+                        for (int c = 0; c < BS; ++c) y[q][c] = vr[min(q, len - 1) * BS + c];
+                    run_solve0(y, len);
+#pragma unroll
+                    for (int q = 0; q < RMAX; ++q) {
+                        if (q < len) {
+#pragma unroll
+                            for (int c = 0; c < BS; ++c) vr[q * BS + c] = y[q][c];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (last) break;
+            const ChainLevelDesc Ln = sLv[l + 1];
+            if (dt >= 0 && dt < L.nsep) {
+                const int js = dt;
+                const double* S = lfac + (L.offS - deep_base);
+#pragma unroll
+                for (int e = 0; e < B2; ++e) {
+                    G[oCl + e] = S[e * L.nsep + js];
+                    G[oCr + e] = S[(B2 + e) * L.nsep + js];
+                }
+                const int s = js * L.p + L.p - 1;
+                const bool has_r = (s + 1 < L.N);
+                const double* pv_ = vb + L.lds_off + s * BS + js;
+                const double* pm = vb + L.lds_off + (s - 1) * BS + js;
+                const double* pp = has_r ? vb + L.lds_off + (s + 1) * BS + js + 1 : pv_;
+                double v[BS], ym[BS], yp[BS];
+#pragma unroll
+                for (int c = 0; c < BS; ++c) { v[c] = pv_[c]; ym[c] = pm[c]; yp[c] = pp[c]; }
+                double* dst = nodep(Ln, js);
+#pragma unroll
+                for (int c = 0; c < BS; ++c) {
+                    double acc = v[c];
+#pragma unroll
+                    for (int k = 0; k < BS; ++k) acc -= G[oCl + c * BS + k] * ym[k] + G[oCr + c * BS + k] * yp[k];
+                    dst[c] = acc;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- back-substitution of the coarser levels (LDS), coarse to fine ----
+        for (int l = nl - 2; l >= 1 && !dbg_nophase; --l) {
+            const ChainLevelDesc Lb = sLv[l];
+            const ChainLevelDesc Ln = sLv[l + 1];
+            if (dt >= 0 && dt < Lb.N) {
+                const int i = dt;
+                const double* Bk = lfac + (Lb.offB - deep_base);
+#pragma unroll
+                for (int e = 0; e < 2 * B2; ++e) G[e] = Bk[e * Lb.N + i];
+                const int nsep = Lb.nsep;
+                const int j = pad(Lb, i);
+                const bool is_sep = (i - j * Lb.p == Lb.p - 1) && (j < nsep);
+                const int jl = max(j - 1, 0), jr = min(j, max(nsep - 1, 0));
+                double* pvx = vb + Lb.lds_off + i * BS + j;
+                const double* pul = nodep(Ln, jl);
+                const double* pur = nodep(Ln, jr);
+                double v[BS], ul[BS], ur[BS];
+#pragma unroll
+                for (int c = 0; c < BS; ++c) { v[c] = pvx[c]; ul[c] = pul[c]; ur[c] = pur[c]; }
+#pragma unroll
+                for (int c = 0; c < BS; ++c) {
+                    double acc = v[c];
+#pragma unroll
+                    for (int k = 0; k < BS; ++k) acc -= G[c * BS + k] * ul[k] + G[B2 + c * BS + k] * ur[k];
+                    pvx[c] = is_sep ? ur[c] : acc;
+                }
+            }
+            __syncthreads();
+        }
+        if (MODE == PREC_STEP) { upd_store(H0()); upd_load(H1()); }
+        // ---- back-substitution of level 0.  No spikes are stored for this level: with the run
+        //      blocks still in registers, x_run = y_run - T_run^-1 (e_first Cr_left' x_left +
+        //      e_last Cl_right' x_right) costs one more run solve and no memory traffic ----
+        if (nl >= 2 && !dbg_nophase) {
+            const ChainLevelDesc L1 = sLv[1];
+            const int nsep = L0.nsep;
+            double c_last[BS];
+#pragma unroll
+            for (int c = 0; c < BS; ++c) c_last[c] = 0.0;
+            if (t < nsep) {  // separator t: takes the coarse solution; couplings to both neighbours
+                const int s = t * L0.p + L0.p - 1;
+                double xs[BS];
+#pragma unroll
+                for (int c = 0; c < BS; ++c) xs[c] = nodep(L1, t)[c];
+#pragma unroll
+                for (int c = 0; c < BS; ++c) {
+                    double sl = 0.0, sr = 0.0;
+#pragma unroll
+                    for (int k = 0; k < BS; ++k) { sl += G[oCl + k * BS + c] * xs[k]; sr += G[oCr + k * BS + c] * xs[k]; }
+                    c_last[c] = sl;                       // Cl' x_s: last node of run t (this lane)
+                    xch[(size_t)(t + 1) * BS + c] = sr;   // Cr' x_s: first node of run t + 1
+                    v0[s * BS + t + c] = xs[c];
+                }
+            }
+            __syncthreads();
+            if (t < L0.nruns) {
+                const int lo = t * L0.p;
+                const int hi = min(t * L0.p + L0.p - 1, L0.N);
+                const int len = hi - lo;
+                if (len > 0) {
+                    double y[RMAX][BS];
+#pragma unroll
+                    for (int q = 0; q < RMAX; ++q)
+#pragma unroll
+                        for (int c = 0; c < BS; ++c) {
+                            double v = (q == len - 1) ? c_last[c] : 0.0;
+                            if (q == 0 && t >= 1) v += xch[(size_t)t * BS + c];
+                            y[q][c] = v;
+                        }
+                    run_solve0(y, len);
+#pragma unroll
+                    for (int q = 0; q < RMAX; ++q) {
+                        if (q < len) {
+                            double* dst = v0 + (lo + q) * BS + t;
+#pragma unroll
+                            for (int c = 0; c < BS; ++c) dst[c] -= y[q][c];
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        // ---- write z, p (INIT), the rest of the step's xt / kx, and accumulate r'z ----
+        if (MODE == PREC_STEP) upd_store(H1());
+#pragma unroll
+        for (int u = 0; u < kPrecChunk; ++u) {
+            const int idx = t + u * kPrecThreads;
+            if (idx < NB) {
+                const double zz = v0[idx + pad(L0, idx / BS)];
+                a.z[cols[u]] = zz;
+                if (MODE == PREC_INIT) a.p[cols[u]] = zz;
+                local += rv[u] * zz;
             }
         }
     }

@@ -5,7 +5,12 @@ Counterpart of ``round_to_special_orthogonal`` (score/utils/matrix_utils.py:
 (score/utils/gurobi_utils.py:115-125): R = U V^T from the SVD, with the last
 singular direction flipped when det(U V^T) < 0, followed by the reference's
 validity check (matrix_utils.py:293-318, rtol = atol = 1e-3).  Batched over
-all poses (one LAPACK call) instead of one Python call per pose.
+all poses instead of one Python call per pose.  For d = 2 the maximiser of
+tr(R^T M) over SO(2) -- which is what U diag(1, det(U V^T)) V^T computes -- has
+the closed form R(theta), theta = atan2(M10 - M01, M00 + M11); only the inputs
+for which that maximiser is not unique (M00 + M11 = M10 - M01 = 0: zero and
+scaled-reflection matrices, where the reference returns whatever its SVD
+picks) go through the SVD.
 """
 from __future__ import annotations
 
@@ -32,6 +37,33 @@ def check_rotation_matrix(R: np.ndarray, assert_test: bool = True) -> None:
             raise ValueError(f"R det incorrect {det}")
 
 
+def _svd_round(M: np.ndarray) -> np.ndarray:
+    U, _, Vh = np.linalg.svd(M)
+    R = U @ Vh
+    neg = np.linalg.det(R) < 0
+    if np.any(neg):
+        Uf = U.copy()
+        Uf[neg, :, -1] *= -1.0  # U diag(1,..,1,-1) V^T
+        R = np.where(neg[:, None, None], Uf @ Vh, R)
+    return R
+
+
+def _closed_form_round_2d(M: np.ndarray) -> np.ndarray:
+    cx = M[:, 0, 0] + M[:, 1, 1]
+    sx = M[:, 1, 0] - M[:, 0, 1]
+    h = np.hypot(cx, sx)
+    scale = np.abs(M).sum(axis=(1, 2))
+    degenerate = ~(h > 1e-9 * scale)  # also catches M = 0
+    hs = np.where(degenerate, 1.0, h)
+    c, s_ = cx / hs, sx / hs
+    R = np.empty_like(M)
+    R[:, 0, 0] = c; R[:, 0, 1] = -s_
+    R[:, 1, 0] = s_; R[:, 1, 1] = c
+    if np.any(degenerate):
+        R[degenerate] = _svd_round(M[degenerate])
+    return R
+
+
 def round_to_special_orthogonal(mat: np.ndarray) -> np.ndarray:
     """Round one (d, d) matrix or a (N, d, d) stack onto SO(d)."""
     mat = np.asarray(mat, dtype=np.float64)
@@ -42,13 +74,7 @@ def round_to_special_orthogonal(mat: np.ndarray) -> np.ndarray:
     try:
         if not np.all(np.isfinite(M)):
             raise ValueError("non-finite entries")
-        U, _, Vh = np.linalg.svd(M)
-        R = U @ Vh
-        neg = np.linalg.det(R) < 0
-        if np.any(neg):
-            Uf = U.copy()
-            Uf[neg, :, -1] *= -1.0  # U diag(1,..,1,-1) V^T
-            R = np.where(neg[:, None, None], Uf @ Vh, R)
+        R = _closed_form_round_2d(M) if (M.shape[-1] == 2 and not single) else _svd_round(M)
         check_rotation_matrix(R, assert_test=True)
     except (ValueError, np.linalg.LinAlgError):
         raise ValueError(f"Could not round matrix to special orthogonal form: {mat}")
