@@ -786,6 +786,15 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Block barrier for phases that only exchange data through LDS: __syncthreads() also waits for
+// every outstanding global load and store (vmcnt(0)), which would serialise the prefetches this
+// kernel keeps in flight across its phases.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 constexpr int kPreRunLanes = 256;
 template <int BS>
 struct PreTile {
@@ -934,7 +943,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         // in-place solve with the diagonal block of a level-0 run: y <- T_run^-1 y (first len nodes)
         auto run_solve0 = [&](double (&y)[RMAX][BS], int len) {
 #pragma unroll
@@ -998,7 +1007,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (nl >= 2 && !dbg_nophase) {
             // ---- level 0, separator phase (registers) ----
             const ChainLevelDesc L1 = sLv[1];
@@ -1019,7 +1028,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                     nodep(L1, t)[c] = acc;
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
         // The step's xt += alpha p, kx += alpha w in two halves (the run blocks stay in registers,
         // there is no room for all operands at once): the first half is in flight during the coarse
@@ -1086,7 +1095,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             if (last) break;
             const ChainLevelDesc Ln = sLv[l + 1];
             if (dt >= 0 && dt < L.nsep) {
@@ -1114,7 +1123,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                     dst[c] = acc;
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
         // ---- back-substitution of the coarser levels (LDS), coarse to fine ----
         for (int l = nl - 2; l >= 1 && !dbg_nophase; --l) {
@@ -1143,7 +1152,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                     pvx[c] = is_sep ? ur[c] : acc;
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
         if (MODE == PREC_STEP) { upd_store(H0()); upd_load(H1()); }
         // ---- back-substitution of level 0.  No spikes are stored for this level: with the run
@@ -1170,7 +1179,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                     v0[s * BS + t + c] = xs[c];
                 }
             }
-            __syncthreads();
+            lds_barrier();
             if (t < L0.nruns) {
                 const int lo = t * L0.p;
                 const int hi = min(t * L0.p + L0.p - 1, L0.N);
@@ -1196,7 +1205,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
         // ---- write z, p (INIT), the rest of the step's xt / kx, and accumulate r'z ----
         if (MODE == PREC_STEP) upd_store(H1());
