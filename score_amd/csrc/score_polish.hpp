@@ -240,61 +240,104 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
             for (int e = 0; e < B2; ++e) M[e] = Bk[(size_t)(slot * B2 + e) * L.N + i];
         };
         (void)eP;
-        // ---- runs: block LDL' and the two spikes ----
+        // ---- runs: block LDL' and the two spikes.  Everything a run needs (its <= 3 diagonal and
+        //      sub-diagonal blocks and the block coupling it to the right separator) is requested
+        //      first; the factors then stay in registers -- no store -> load round trips ----
+        constexpr int RM = kMaxBs - 1;  // nodes per run <= radix - 1 <= 3
+        double Vl[B2], Wl[B2];          // spikes of the last node of this lane's (first) run
         for (int j = t; j < L.nruns; j += kThreads) {
             const int lo = last ? 0 : j * L.p;
             const int hi = last ? L.N : min(j * L.p + L.p - 1, L.N);
             const int len = hi - lo;
             if (len <= 0) continue;
-            double Ai[B2], Bi[B2], D[B2], Dinv_prev[B2], Lf[B2], T1[B2];
-            for (int q = 0; q < len; ++q) {
-                loadA(l, L, lo + q, Ai);
+            const bool hasL = !last && (j >= 1), hasR = !last && (j < nsep);
+            double Aq[RM][B2], Bq[RM][B2], Bhi[B2];
+#pragma unroll
+            for (int q = 0; q < RM; ++q) {
+                loadA(l, L, lo + min(q, len - 1), Aq[q]);
+                loadB(l, L, lo + min(q, len - 1), Bq[q]);
+            }
+            loadB(l, L, hasR ? hi : lo, Bhi);
+            double Lfq[RM][B2], Diq[RM][B2];
+#pragma unroll
+            for (int q = 0; q < RM; ++q) {
+                double D[B2], T1[B2];
                 if (q == 0) {
-                    for (int e = 0; e < B2; ++e) { D[e] = Ai[e]; Lf[e] = 0.0; }
+#pragma unroll
+                    for (int e = 0; e < B2; ++e) { D[e] = Aq[0][e]; Lfq[0][e] = 0.0; }
                 } else {
-                    loadB(l, L, lo + q, Bi);
-                    SM::mul(Bi, Dinv_prev, Lf);   // Lf = B Dinv_prev
-                    SM::mul_bt(Lf, Bi, T1);       // Lf B'
-                    for (int e = 0; e < B2; ++e) D[e] = Ai[e] - T1[e];
+                    SM::mul(Bq[q], Diq[q - 1], Lfq[q]);  // Lf = B Dinv_prev
+                    SM::mul_bt(Lfq[q], Bq[q], T1);       // Lf B'
+#pragma unroll
+                    for (int e = 0; e < B2; ++e) D[e] = Aq[q][e] - T1[e];
                 }
-                SM::inv(D, Dinv_prev);
-                Rst(0, q, j, Lf);
-                Rst(1, q, j, Dinv_prev);
+                SM::inv(D, Diq[q]);
+                if (q < len) {
+                    Rst(0, q, j, Lfq[q]);
+                    Rst(1, q, j, Diq[q]);
+                }
             }
             if (last) continue;
-            const bool hasL = (j >= 1), hasR = (j < nsep);
+#pragma unroll
             for (int side = 0; side < 2; ++side) {
-                double Y[kMaxBs - 1][B2];  // run length <= radix - 1 <= 3
+                double Y[RM][B2];
                 const bool on = (side == 0) ? hasL : hasR;
-                for (int q = 0; q < len; ++q)
+#pragma unroll
+                for (int q = 0; q < RM; ++q)
+#pragma unroll
                     for (int e = 0; e < B2; ++e) Y[q][e] = 0.0;
                 if (on) {
                     // right-hand side block: V: B[lo] at q = 0;  W: B[hi]' at q = len - 1
                     if (side == 0) {
-                        loadB(l, L, lo, Y[0]);
+#pragma unroll
+                        for (int e = 0; e < B2; ++e) Y[0][e] = Bq[0][e];
                     } else {
-                        loadB(l, L, hi, Bi);
-                        for (int r = 0; r < BS; ++r)
-                            for (int c = 0; c < BS; ++c) Y[len - 1][r * BS + c] = Bi[c * BS + r];
+#pragma unroll
+                        for (int q = 0; q < RM; ++q)
+                            if (q == len - 1) {
+#pragma unroll
+                                for (int r = 0; r < BS; ++r)
+#pragma unroll
+                                    for (int c = 0; c < BS; ++c) Y[q][r * BS + c] = Bhi[c * BS + r];
+                            }
                     }
-                    for (int q = 1; q < len; ++q) {  // forward: a_q -= Lf_q a_{q-1}
-                        Rld(0, q, j, Lf);
-                        SM::mul(Lf, Y[q - 1], T1);
-                        for (int e = 0; e < B2; ++e) Y[q][e] -= T1[e];
-                    }
-                    for (int q = len - 1; q >= 0; --q) {  // y_q = Dinv_q a_q - Lf_{q+1}' y_{q+1}
-                        Rld(1, q, j, D);
-                        SM::mul(D, Y[q], T1);
-                        if (q + 1 < len) {
-                            Rld(0, q + 1, j, Lf);
-                            double T2[B2];
-                            SM::mul_at(Lf, Y[q + 1], T2);
-                            for (int e = 0; e < B2; ++e) T1[e] -= T2[e];
+#pragma unroll
+                    for (int q = 1; q < RM; ++q) {  // forward: a_q -= Lf_q a_{q-1}
+                        if (q < len) {
+                            double T1[B2];
+                            SM::mul(Lfq[q], Y[q - 1], T1);
+#pragma unroll
+                            for (int e = 0; e < B2; ++e) Y[q][e] -= T1[e];
                         }
-                        for (int e = 0; e < B2; ++e) Y[q][e] = T1[e];
+                    }
+#pragma unroll
+                    for (int q = RM - 1; q >= 0; --q) {  // y_q = Dinv_q a_q - Lf_{q+1}' y_{q+1}
+                        if (q < len) {
+                            double T1[B2];
+                            SM::mul(Diq[q], Y[q], T1);
+                            if (q + 1 < RM) {
+                                if (q + 1 < len) {
+                                    double T2[B2];
+                                    SM::mul_at(Lfq[q + 1], Y[q + 1], T2);
+#pragma unroll
+                                    for (int e = 0; e < B2; ++e) T1[e] -= T2[e];
+                                }
+                            }
+#pragma unroll
+                            for (int e = 0; e < B2; ++e) Y[q][e] = T1[e];
+                        }
                     }
                 }
-                for (int q = 0; q < len; ++q) Bst(side, lo + q, Y[q]);
+#pragma unroll
+                for (int q = 0; q < RM; ++q) {
+                    if (q < len) Bst(side, lo + q, Y[q]);
+                    if (q == len - 1 && j == t) {
+#pragma unroll
+                        for (int e = 0; e < B2; ++e) {
+                            if (side == 0) Vl[e] = Y[q][e]; else Wl[e] = Y[q][e];
+                        }
+                    }
+                }
             }
         }
         __syncthreads();
@@ -307,7 +350,11 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
             loadB(l, L, s, Cl);  // T[s, s-1]
             loadA(l, L, s, As);
             for (int e = 0; e < B2; ++e) Cr[e] = 0.0;
-            Bld(1, s - 1, M1);   // W_{s-1}
+            if (j == t) {        // W_{s-1}: last node of this lane's own run
+                for (int e = 0; e < B2; ++e) M1[e] = Wl[e];
+            } else {
+                Bld(1, s - 1, M1);
+            }
             SM::mul(Cl, M1, T1);
             for (int e = 0; e < B2; ++e) As[e] -= T1[e];
             if (s + 1 < L.N) {
@@ -327,7 +374,11 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
             double* dstB = a.work_mat + ((size_t)(ch.scratch_off + Ln.vec_off + j) * 2 + 1) * B2;
             for (int e = 0; e < B2; ++e) dstA[e] = As[e];
             if (j >= 1) {
-                Bld(0, s - 1, M1);  // V_{s-1}
+                if (j == t) {       // V_{s-1}
+                    for (int e = 0; e < B2; ++e) M1[e] = Vl[e];
+                } else {
+                    Bld(0, s - 1, M1);
+                }
                 SM::mul(Cl, M1, T1);
                 for (int e = 0; e < B2; ++e) dstB[e] = -T1[e];
             } else {
