@@ -237,7 +237,7 @@ struct HipBackend {
             const size_t vec_doubles = (size_t)Lend.lds_off + (size_t)Lend.N * h.bs + 1;
             lds_pre = std::max(lds_pre, (16 + vec_doubles + (size_t)(lv[0].nruns + 1) * h.bs + (size_t)deep) * sizeof(double));
         }
-        if (lds_pre > 144 * 1024) prec_pre = false;
+        if (lds_pre > 158 * 1024) prec_pre = false;  // 160 KiB per CU, minus the static level table and slack
         if (prec_pre) { prec_lds0 = true; prec_lds = lds_pre; }
         if (prec_lds > 144 * 1024) throw std::runtime_error("chain too long for the LDS-resident chain solver");
         if (prec_lds > 48 * 1024 && n_prec_chains(h)) {

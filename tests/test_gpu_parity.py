@@ -121,6 +121,26 @@ def test_long_chain_and_3d_blocks(hip_lib, twin_lib):
     assert a.info["pobj"] == pytest.approx(so.LiteralModel(fg3, "SOCP").direct_cost(so.reduced_to_values(rp, u, "SOCP")), rel=1e-5, abs=1e-6)
 
 
+@pytest.mark.parametrize("n_poses", [255, 1023, 1024])
+def test_both_chain_kernels_match_the_twin(n_poses, hip_lib, twin_lib):
+    """Chains of up to 1023 poses run the register/LDS-resident chain kernel (k_prec_pre), longer
+    ones (and radix != 4) the streaming one (k_prec): same preconditioner, same iterates.  A fixed
+    number of ADMM iterations is compared with the CPU twin on both sides of the boundary, and the
+    two kernels with each other on the same chain (radix 2 forces the streaming kernel)."""
+    fg = make_manhattan(n_robots=2, n_poses=n_poses, n_beacons=3, seed=21)
+    qp = assemble(fg, "SOCP").qp
+    outs = {}
+    for name, lib, extra in (("hip", None, {}), ("twin", twin_lib, {}), ("hip_r2", None, dict(chain_radix=2)),
+                             ("twin_r2", twin_lib, dict(chain_radix=2))):
+        sol = ConicSolver(qp, dict(polish=0, adaptive_rho=0, adaptive_cg=0, **extra), lib_path=lib)
+        outs[name] = sol.steps(50)[0]
+        sol.close()
+    for a, b in (("hip", "twin"), ("hip_r2", "twin_r2")):
+        scale = np.abs(outs[b].x).max()
+        np.testing.assert_allclose(outs[a].x, outs[b].x, atol=1e-7 * scale)
+        assert outs[a].info["pobj"] == pytest.approx(outs[b].info["pobj"], rel=1e-8)
+
+
 @pytest.mark.parametrize("index", [1, 2, 3])
 def test_full_size_configs_are_certified(index, hip_lib):
     """BASELINE.json's full sizes (1x500, 4x1000, 20x1000 poses): the oracle's
