@@ -17,6 +17,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -190,6 +192,46 @@ def montecarlo(args, rank, world, local_rank):
         dist.destroy_process_group()
 
 
+def chain_factor_doubles(N: int, bs: int, radix: int = 4):
+    """Doubles of chain-factor data one preconditioner application reads for a chain of N nodes:
+    level 0 run + separator blocks (its spikes are not read by k_prec_pre), every block of the
+    coarser levels (layout of score_host.hpp factor_chain_levels)."""
+    b2 = bs * bs
+    total, level = 0, 0
+    while True:
+        last = N <= radix - 1
+        nsep = 0 if last else N // radix
+        nruns = nsep + 1
+        P = N if last else radix - 1
+        total += 2 * b2 * P * nruns + 2 * b2 * nsep
+        if level > 0 and not last:
+            total += 2 * b2 * N
+        if last:
+            return total
+        N, level = nsep, level + 1
+
+
+def algorithmic_bytes(qp, kkt_bytes: float):
+    """Algorithmic HBM bytes per launch of the six kernels of one ADMM iteration."""
+    n, m, nnzA = int(qp.n), int(qp.m), int(qp.A.nnz)
+    bs = int(qp.block_size)
+    cp = np.asarray(qp.chain_ptr)
+    lens = np.diff(cp)
+    fac = 8.0 * sum(chain_factor_doubles(int(L), bs) for L in lens if L > 0)
+    n_chain = int(lens.sum()) * bs
+    n_jac = n - n_chain
+    prec_init = fac + 24.0 * n_chain + 32.0 * n_jac            # r in, z and p out (+ 1/diag for Jacobi columns)
+    prec_step = fac + 72.0 * n_chain + 80.0 * n_jac            # + w, p, xt, kx in; r, xt, kx out
+    return {
+        "rhs": 12.0 * nnzA + 8.0 * (9 * n + m),
+        "prec_init": prec_init,
+        "kp": float(kkt_bytes),
+        "prec_step": prec_step,
+        "kpb": float(kkt_bytes) + 24.0 * n,
+        "cone": 12.0 * nnzA + 56.0 * m,
+    }
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -266,6 +308,7 @@ def main():
         ps.close()
 
     kkt_ms, kkt_bytes = solver.time_kkt_apply(args.kkt_reps)
+    alg_bytes = algorithmic_bytes(models[0].qp, kkt_bytes / args.batch)
     # back-to-back duration of every kernel of the iteration (HIP events, solver's stream)
     kernel_us = {k: 1e3 * solver.debug_time(k, 200) for k in
                  ("rhs", "prec_init", "kp", "prec_step", "kpb", "xupdate", "cone")}
@@ -299,6 +342,18 @@ def main():
             "kernel_us_back_to_back": kernel_us,
             "full_solver_with_newton_polish": polished,
         }
+        # every kernel of the iteration against the same HBM roofline (algorithmic bytes as in
+        # DESIGN.md section 4, back-to-back duration), and the whole iteration in the loop
+        per_kernel = {}
+        for k, b in alg_bytes.items():
+            gbs = args.batch * b / (kernel_us[k] * 1e-6) / 1e9
+            per_kernel[k] = {"bytes": args.batch * b, "us": kernel_us[k], "GB/s": gbs, "frac": gbs / HBM_PEAK_GBS}
+        rec["roofline_by_kernel"] = per_kernel
+        it_bytes = args.batch * sum(alg_bytes.values())
+        it_us = 1e6 * dt_max / max(1.0, tot[0] / world) * args.batch
+        rec["roofline_iteration"] = {"bytes": it_bytes, "us": it_us, "GB/s": it_bytes / (it_us * 1e-6) / 1e9,
+                                     "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                     "note": "six kernels of one ADMM iteration (2 PCG iterations), time in the launch graph incl. convergence checks"}
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args, models)
             rec["speedup_vs_cpu_baseline"] = rec["value"] / rec["cpu_baseline"]["value"]
