@@ -284,8 +284,26 @@ def assemble(data, relaxation: str = QCQP_RELAXATION) -> ScoreModel:
     fixed_vals = np.hstack([np.eye(d), np.zeros((d, 1))]).ravel()
     mask = np.ones(n_model, dtype=bool)
     mask[fixed_cols] = False
-    free_cols = np.nonzero(mask)[0]
+    # Solver-space column order: pose columns chain by chain and, within a chain, matrix row by
+    # matrix row -- [R(k,:) t(k)] of all poses of robot r for k = 0, then k = 1, ... -- so that each
+    # block-tridiagonal chain of the preconditioner (one per robot and row k; the d rows of a pose
+    # are decoupled in P) owns a CONTIGUOUS range of unknowns: its vector loads in the chain kernel
+    # are fully coalesced and the KKT matrix is banded per chain.  Landmarks and range variables
+    # follow in model order.  (Model space keeps the Gurobi layout; expand()/reduce() map.)
+    pieces_free = []
+    base = 0
+    j_ar = np.arange(D1)
+    for chain in data.pose_variables:
+        L = len(chain)
+        idx = base + np.arange(L)
+        idx = idx[idx != p0]
+        for k in range(d):
+            pieces_free.append((idx[:, None] * PB + k * D1 + j_ar[None, :]).ravel())
+        base += L
+    pieces_free.append(np.arange(lm_base, n_model))
+    free_cols = np.concatenate(pieces_free)
     n_free = free_cols.size
+    assert n_free == n_model - PB
     xc = np.zeros(n_model)
     xc[fixed_cols] = fixed_vals
     new_of_model = -np.ones(n_model, dtype=np.int64)
