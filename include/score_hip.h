@@ -95,6 +95,7 @@ typedef struct score_settings {
     int32_t polish;            /* 0/1: semismooth-Newton polish once ADMM is close (single problems whose
                                   cones have private head variables, i.e. the SCORE SOCP form)          */
     double  polish_start;      /* start it when both relative residuals are below this                  */
+    int32_t polish_warmup;     /* ADMM iterations before the first polish attempt (0: one check_interval) */
     int32_t verbose;
 } score_settings;
 

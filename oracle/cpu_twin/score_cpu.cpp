@@ -39,6 +39,7 @@ struct CpuBackend {
 
     void set_cg_iters(int k) { cg_iters = k; }
     bool polish(const HostSystem&, const score_settings&, int*, int*) { return false; }  // HIP backend only
+    bool polish_available() const { return false; }
     void cg_reduction(std::vector<double>& out) { out = cg_red; }
 
     void init(const HostSystem& h, const score_settings& s_) {

@@ -42,6 +42,7 @@ struct Solver {
     int cg_now = 2;       // PCG iterations per ADMM iteration currently in use
     int64_t cg_total = 0; // PCG iterations performed since reset
     int next_polish = 0;  // earliest iteration of the next polish attempt
+    int next_rho = 0;     // earliest iteration of the next rho adaptation
     double setup_ms = 0;
 
     void create(const score_problem* probs, int count, const score_settings& s) {
@@ -73,6 +74,7 @@ struct Solver {
         if (cg_now != st.cg_iters) { cg_now = st.cg_iters; be.set_cg_iters(cg_now); }
         cg_total = 0;
         next_polish = 0;
+        next_rho = st.adaptive_rho_interval;
         iters_done = 0;
         std::fill(done.begin(), done.end(), 0);
         be.set_done(done);
@@ -126,7 +128,7 @@ struct Solver {
                 continue;
             }
             all = false;
-            if (allow_rho && st.adaptive_rho && iters_done % st.adaptive_rho_interval == 0) {
+            if (allow_rho && st.adaptive_rho && iters_done >= next_rho) {
                 const double tiny = 1e-30;
                 const double pns = std::max(std::max(std::max(r.ax_s, r.s_s), H.bnorm_s[p]), tiny);
                 const double dns = std::max(std::max(std::max(r.px_s, r.aty_s), H.qnorm_s[p]), tiny);
@@ -140,6 +142,7 @@ struct Solver {
                 }
             }
         }
+        if (allow_rho && st.adaptive_rho && iters_done >= next_rho) next_rho = iters_done + st.adaptive_rho_interval;
         if (any_rho) be.upload_rho(H);
         if (newly_done) be.set_done(done);
         if (allow_rho && st.adaptive_cg && !all) {
@@ -174,8 +177,12 @@ struct Solver {
         const double t0 = now_ms();
         reset();
         bool all = false;
+        // with the polish on, the first block is shorter: Newton is globally convergent, a rough
+        // ADMM iterate is all it needs (measured: 15 iterations beat 25 by ~8 % of the solve time)
+        const bool can_polish = st.polish && H.count == 1 && be.polish_available();
         while (!all && iters_done < st.max_iters) {
-            const int k = std::min(st.check_interval, st.max_iters - iters_done);
+            int k = std::min(st.check_interval, st.max_iters - iters_done);
+            if (iters_done == 0 && can_polish && st.polish_warmup > 0) k = std::min(k, st.polish_warmup);
             be.run(k);
             iters_done += k;
             cg_total += (int64_t)k * cg_now;
@@ -253,6 +260,7 @@ inline void default_settings(score_settings* s) {
     s->use_graph = 1;
     s->polish = 1;
     s->polish_start = 1e30;
+    s->polish_warmup = 15;
     s->verbose = 0;
 }
 

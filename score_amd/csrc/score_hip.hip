@@ -674,6 +674,8 @@ struct HipBackend {
 
     // Any failure inside the polish (NaN, HIP error) leaves the ADMM state untouched -- the Newton
     // loop only writes scratch vectors until its final hand-over -- and ADMM simply continues.
+    bool polish_available() const { return Q.available; }
+
     bool polish(const HostSystem& h, const score_settings& s_, int* newton_iters, int* cg_used) {
         try {
             return polish_impl(h, s_, newton_iters, cg_used);
