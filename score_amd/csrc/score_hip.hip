@@ -46,14 +46,50 @@ thread_local std::string g_err;
 // threads may drive different handles while one of them is capturing a graph.
 thread_local hipStream_t tl_copy_stream = nullptr;
 
+// Device memory of one handle comes from a few large allocations: ~70 hipMalloc / hipFree pairs per
+// handle cost ~20 ms (hipFree synchronises the device), a handful cost ~1 ms.
+struct DevArena {
+    std::vector<void*> chunks;
+    char* cur = nullptr;
+    size_t left = 0, next_chunk = (size_t)8 << 20;
+    void* take(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes > left) {
+            const size_t sz = std::max(bytes, next_chunk);
+            next_chunk = std::min<size_t>(next_chunk * 2, (size_t)64 << 20);
+            void* p = nullptr;
+            HIP_CHECK(hipMalloc(&p, sz));
+            chunks.push_back(p);
+            cur = (char*)p;
+            left = sz;
+        }
+        void* r = cur;
+        cur += bytes;
+        left -= bytes;
+        return r;
+    }
+    ~DevArena() {
+        for (void* p : chunks) (void)hipFree(p);
+    }
+};
+thread_local DevArena* tl_arena = nullptr;  // set while a handle is being initialised on this thread
+
 template <class T>
 struct DevBuf {
     T* d = nullptr;
     size_t n = 0;
+    bool owned = false;  // allocated with hipMalloc (not from the handle's arena)
     void alloc(size_t count) {
         release();
         n = count;
-        HIP_CHECK(hipMalloc((void**)&d, std::max<size_t>(1, count) * sizeof(T)));
+        const size_t bytes = std::max<size_t>(1, count) * sizeof(T);
+        if (tl_arena) {
+            d = (T*)tl_arena->take(bytes);
+            owned = false;
+        } else {
+            HIP_CHECK(hipMalloc((void**)&d, bytes));
+            owned = true;
+        }
     }
     void upload(const std::vector<T>& h) {
         if (h.size() != n || !d) alloc(h.size());
@@ -82,9 +118,10 @@ struct DevBuf {
         if (n) HIP_CHECK(hipMemsetAsync(d, 0, n * sizeof(T), st));
     }
     void release() {
-        if (d) (void)hipFree(d);
+        if (d && owned) (void)hipFree(d);
         d = nullptr;
         n = 0;
+        owned = false;
     }
     ~DevBuf() { release(); }
 };
@@ -126,6 +163,7 @@ struct HipBackend {
     hipGraphExec_t graph_exec = nullptr;
     int graph_iters = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    DevArena arena;  // declared before every buffer: destroyed after them
 
     CsrBufs K, G1, G2;
     DevBuf<int32_t> A_ptr, A_col;
@@ -183,6 +221,10 @@ struct HipBackend {
         HIP_CHECK(hipSetDevice(st.device));
         HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         tl_copy_stream = stream;
+        struct ArenaScope {  // buffers allocated during init come from this handle's arena
+            explicit ArenaScope(DevArena* a) { tl_arena = a; }
+            ~ArenaScope() { tl_arena = nullptr; }
+        } arena_scope(&arena);
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
         pt.mark("device + stream");
@@ -552,7 +594,7 @@ struct HipBackend {
 
     void init_polish(const HostSystem& h) {
         PhaseTimer pt(st.verbose != 0);
-        build_polish(h, Q);
+        build_polish(h, Q, st.verbose != 0);
         pt.mark("  polish: host structures");
         if (!Q.available || h.count != 1) { Q.available = false; return; }
         Hm.upload(Q.Hm, Q.rbH, nullptr, false);

@@ -50,7 +50,7 @@ inline int host_threads() {
         unsigned h = std::thread::hardware_concurrency();
         cpu_set_t set;  // the CPUs this process may actually run on (containers, taskset)
         if (sched_getaffinity(0, sizeof(set), &set) == 0) h = std::min<unsigned>(h, (unsigned)CPU_COUNT(&set));
-        return (int)std::min(8u, std::max(1u, h));
+        return (int)std::min(16u, std::max(1u, h));
     }();
     return n;
 }
@@ -669,9 +669,8 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
     pt.mark("  append: A, A'");
     // ---- K = P + sigma I + rho A'A, kept as K0 + rho K1 on the union pattern ----
     // A row of K has a few dozen entries: it is gathered into a small buffer, ordered by column
-    // (stable, so equal columns are summed in the order they were met) and merged.  Pass 1 counts
-    // the merged entries per row, pass 2 writes them in place; both run over row ranges in parallel
-    // and touch no O(n) scratch.
+    // (stable, so equal columns are summed in the order they were met) and merged; row ranges run
+    // in parallel and touch no O(n) scratch.
     struct Ent { int32_t j; double v0, v1; };
     auto gather_row = [&](int64_t i, std::vector<Ent>& buf) {
         buf.clear();
@@ -691,39 +690,49 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
         }
     };
     const size_t k_row0 = H.K.ptr.size() - 1;  // == xo
-    const int32_t k_base = H.K.ptr.back();
     H.K.ptr.resize(k_row0 + 1 + n);
-    parallel_ranges(n, 8192, [&](int, int64_t i0, int64_t i1) {
+    // one sweep: every thread merges its rows into its own buffers (reserved for the worst case, so
+    // they never re-allocate), the row lengths are prefix-summed, the buffers copied into place
+    struct KPart { std::vector<int32_t> col; std::vector<double> k0, k1; int64_t i0 = 0, i1 = 0; };
+    std::vector<KPart> kparts(parallel_parts(n, 8192));
+    parallel_ranges(n, 8192, [&](int t, int64_t i0, int64_t i1) {
+        KPart& Q = kparts[t];
+        Q.i0 = i0; Q.i1 = i1;
+        size_t ub = 0;
+        for (int64_t i = i0; i < i1; ++i) {
+            ub += 1 + (size_t)(S.P.ptr[i + 1] - S.P.ptr[i]);
+            for (int t2 = atp[i]; t2 < atp[i + 1]; ++t2) ub += (size_t)(S.A.ptr[atr[t2] + 1] - S.A.ptr[atr[t2]]);
+        }
+        Q.col.reserve(ub); Q.k0.reserve(ub); Q.k1.reserve(ub);
         std::vector<Ent> buf;
         for (int64_t i = i0; i < i1; ++i) {
             gather_row(i, buf);
             int32_t cnt = 0;
-            for (size_t x = 0; x < buf.size(); ++x)
-                if (x == 0 || buf[x].j != buf[x - 1].j) ++cnt;
-            H.K.ptr[k_row0 + 1 + i] = cnt;
-        }
-    });
-    pt.mark("  append: K count");
-    for (int i = 0; i < n; ++i) H.K.ptr[k_row0 + 1 + i] += H.K.ptr[k_row0 + i];
-    const size_t k_end = (size_t)H.K.ptr[k_row0 + n];
-    (void)k_base;
-    H.K.col.resize(k_end); H.K0.resize(k_end); H.K1.resize(k_end);
-    pt.mark("  append: K resize");
-    parallel_ranges(n, 8192, [&](int, int64_t i0, int64_t i1) {
-        std::vector<Ent> buf;
-        for (int64_t i = i0; i < i1; ++i) {
-            gather_row(i, buf);
-            size_t o = (size_t)H.K.ptr[k_row0 + i];
             size_t x = 0;
             while (x < buf.size()) {
                 const int32_t j = buf[x].j;
                 double a0 = 0.0, a1 = 0.0;
                 for (; x < buf.size() && buf[x].j == j; ++x) { a0 += buf[x].v0; a1 += buf[x].v1; }
-                H.K.col[o] = (int32_t)(xo + j);
-                H.K0[o] = a0;
-                H.K1[o] = a1;
-                ++o;
+                Q.col.push_back((int32_t)(xo + j));
+                Q.k0.push_back(a0);
+                Q.k1.push_back(a1);
+                ++cnt;
             }
+            H.K.ptr[k_row0 + 1 + i] = cnt;
+        }
+    });
+    pt.mark("  append: K rows");
+    for (int i = 0; i < n; ++i) H.K.ptr[k_row0 + 1 + i] += H.K.ptr[k_row0 + i];
+    const size_t k_end = (size_t)H.K.ptr[k_row0 + n];
+    H.K.col.resize(k_end); H.K0.resize(k_end); H.K1.resize(k_end);
+    parallel_ranges((int64_t)kparts.size(), 1, [&](int, int64_t p0, int64_t p1) {
+        for (int64_t pi2 = p0; pi2 < p1; ++pi2) {
+            const KPart& Q = kparts[pi2];
+            if (Q.col.empty()) continue;
+            const size_t o = (size_t)H.K.ptr[k_row0 + Q.i0];
+            std::memcpy(&H.K.col[o], Q.col.data(), Q.col.size() * sizeof(int32_t));
+            std::memcpy(&H.K0[o], Q.k0.data(), Q.k0.size() * sizeof(double));
+            std::memcpy(&H.K1[o], Q.k1.data(), Q.k1.size() * sizeof(double));
         }
     });
     pt.mark("  append: K fill");
@@ -875,6 +884,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     // ---- preconditioner layout ----
     const int b2 = bs * bs;
     std::vector<char> in_chain(H.n_tot, 0);
+    std::vector<int32_t> node_prev;  // column of each chain node's predecessor (-1: first of its chain)
     const int max_nodes = 1 << 20;
     for (int p = 0; p < count; ++p) {
         const score_problem& pr = probs[p];
@@ -889,17 +899,8 @@ inline void build_system(const score_problem* probs, int count, const score_sett
             for (int j = nb; j < ne; ++j) {
                 const int32_t col = (int32_t)(H.xoff[p] + pr.node_first_col[j]);
                 H.node_col.push_back(col);
+                node_prev.push_back(j > nb ? (int32_t)(H.xoff[p] + pr.node_first_col[j - 1]) : -1);
                 for (int a = 0; a < bs; ++a) in_chain[col + a] = 1;
-                for (int a = 0; a < bs; ++a)
-                    for (int bcol = 0; bcol < bs; ++bcol) {
-                        H.pos_diag.push_back(find_in_row(H.K, col + a, col + bcol));
-                        if (j > nb) {
-                            const int32_t pc = (int32_t)(H.xoff[p] + pr.node_first_col[j - 1]);
-                            H.pos_sub.push_back(find_in_row(H.K, col + a, pc + bcol));
-                        } else {
-                            H.pos_sub.push_back(-1);
-                        }
-                    }
             }
             ch.col0 = H.node_col[ch.node_begin];
             ch.col_stride = 0;
@@ -913,6 +914,20 @@ inline void build_system(const score_problem* probs, int count, const score_sett
             H.chains.push_back(ch);
         }
     }
+    // K.val positions of the diagonal / sub-diagonal block entries of every chain node
+    H.pos_diag.assign(H.node_col.size() * b2, -1);
+    H.pos_sub.assign(H.node_col.size() * b2, -1);
+    parallel_ranges((int64_t)H.node_col.size(), 2048, [&](int, int64_t g0, int64_t g1) {
+        for (int64_t g = g0; g < g1; ++g) {
+            const int32_t col = H.node_col[g], pc = node_prev[g];
+            size_t o = (size_t)g * b2;
+            for (int a = 0; a < bs; ++a)
+                for (int bcol = 0; bcol < bs; ++bcol, ++o) {
+                    H.pos_diag[o] = find_in_row(H.K, col + a, col + bcol);
+                    if (pc >= 0) H.pos_sub[o] = find_in_row(H.K, col + a, pc + bcol);
+                }
+        }
+    });
     pt.mark("chain positions");
     // level layout (structure only) + storage
     H.fac_off.clear();

@@ -46,8 +46,9 @@ struct PolishData {
     std::vector<int32_t> pos_diag, pos_sub, diag_pos;
 };
 
-inline void build_polish(const HostSystem& H, PolishData& Q) {
+inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = false) {
     Q = PolishData();
+    PhaseTimer pt(verbose);
     const int64_t n = H.n_tot, m = H.m_tot;
     const size_t ncones = H.cone_row.size();
     if (ncones == 0 || m == 0) return;
@@ -79,6 +80,7 @@ inline void build_polish(const HostSystem& H, PolishData& Q) {
         Q.theta[k] = -a * Q.xstar[k];
     }
     Q.T = T;
+    pt.mark("    polish: structure check");
     // ---- Newton matrix pattern + contribution lists ----
     struct Contrib { int32_t j, cone, ab; double coef; };
     struct Part {  // rows [i0, i1) of H, built by one host thread
@@ -146,19 +148,38 @@ inline void build_polish(const HostSystem& H, PolishData& Q) {
             W.row_len.push_back(nent);
         }
     });
+    pt.mark("    polish: rows");
     Q.Hm.nrows = Q.Hm.ncols = n;
     Q.Hm.ptr.assign(1, 0);
     Q.cptr.assign(1, 0);
-    for (const Part& W : parts) {
-        Q.Hm.col.insert(Q.Hm.col.end(), W.col.begin(), W.col.end());
-        Q.Pon.insert(Q.Pon.end(), W.pon.begin(), W.pon.end());
-        Q.ccone.insert(Q.ccone.end(), W.ccone.begin(), W.ccone.end());
-        Q.cab.insert(Q.cab.end(), W.cab.begin(), W.cab.end());
-        Q.ccoef.insert(Q.ccoef.end(), W.ccoef.begin(), W.ccoef.end());
-        for (int32_t l : W.row_len) Q.Hm.ptr.push_back(Q.Hm.ptr.back() + l);
-        for (int32_t l : W.ent_len) Q.cptr.push_back(Q.cptr.back() + l);
+    {   // sizes, then every part is copied into place by its own thread
+        std::vector<size_t> eoff(parts.size() + 1, 0), coff(parts.size() + 1, 0), roff(parts.size() + 1, 0);
+        for (size_t k = 0; k < parts.size(); ++k) {
+            eoff[k + 1] = eoff[k] + parts[k].col.size();
+            coff[k + 1] = coff[k] + parts[k].ccone.size();
+            roff[k + 1] = roff[k] + parts[k].row_len.size();
+        }
+        Q.Hm.col.resize(eoff.back()); Q.Pon.resize(eoff.back());
+        Q.ccone.resize(coff.back()); Q.cab.resize(coff.back()); Q.ccoef.resize(coff.back());
+        Q.Hm.ptr.resize(n + 1); Q.cptr.resize(eoff.back() + 1);
+        parallel_ranges((int64_t)parts.size(), 1, [&](int, int64_t k0, int64_t k1) {
+            for (int64_t k = k0; k < k1; ++k) {
+                const Part& W = parts[k];
+                std::copy(W.col.begin(), W.col.end(), Q.Hm.col.begin() + eoff[k]);
+                std::copy(W.pon.begin(), W.pon.end(), Q.Pon.begin() + eoff[k]);
+                std::copy(W.ccone.begin(), W.ccone.end(), Q.ccone.begin() + coff[k]);
+                std::copy(W.cab.begin(), W.cab.end(), Q.cab.begin() + coff[k]);
+                std::copy(W.ccoef.begin(), W.ccoef.end(), Q.ccoef.begin() + coff[k]);
+                int32_t acc = (int32_t)eoff[k];
+                for (size_t r = 0; r < W.row_len.size(); ++r) { acc += W.row_len[r]; Q.Hm.ptr[roff[k] + r + 1] = acc; }
+                int32_t cacc = (int32_t)coff[k];
+                for (size_t e = 0; e < W.ent_len.size(); ++e) { cacc += W.ent_len[e]; Q.cptr[eoff[k] + e + 1] = cacc; }
+            }
+        });
     }
+    pt.mark("    polish: concatenate");
     Q.rbH = make_rowblocks(Q.Hm, H.xoff);
+    pt.mark("    polish: row blocks");
     // ---- chain block / Jacobi positions in H ----
     const int bs = H.bs;
     const int b2 = bs * bs;
@@ -180,6 +201,7 @@ inline void build_polish(const HostSystem& H, PolishData& Q) {
     });
     Q.diag_pos.clear();
     for (int32_t c : H.diag_cols) Q.diag_pos.push_back(find_in_row(Q.Hm, c, c));
+    pt.mark("    polish: positions");
     Q.available = true;
 }
 
