@@ -226,12 +226,8 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
         double* R = a.fac + L.offR;
         double* S = a.fac + L.offS;
         double* Bk = a.fac + L.offB;
-        const size_t eP = (size_t)L.P * L.nruns;
         auto Rst = [&](int slot, int q, int j, const double* M) {
             for (int e = 0; e < B2; ++e) R[((size_t)(slot * B2 + e) * L.P + q) * L.nruns + j] = M[e];
-        };
-        auto Rld = [&](int slot, int q, int j, double* M) {
-            for (int e = 0; e < B2; ++e) M[e] = R[((size_t)(slot * B2 + e) * L.P + q) * L.nruns + j];
         };
         auto Bst = [&](int slot, int i, const double* M) {
             for (int e = 0; e < B2; ++e) Bk[(size_t)(slot * B2 + e) * L.N + i] = M[e];
@@ -239,7 +235,6 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
         auto Bld = [&](int slot, int i, double* M) {
             for (int e = 0; e < B2; ++e) M[e] = Bk[(size_t)(slot * B2 + e) * L.N + i];
         };
-        (void)eP;
         // ---- runs: block LDL' and the two spikes.  Everything a run needs (its <= 3 diagonal and
         //      sub-diagonal blocks and the block coupling it to the right separator) is requested
         //      first; the factors then stay in registers -- no store -> load round trips ----
