@@ -403,14 +403,16 @@ struct HipBackend {
     }
 
     // w = K p
-    void launch_kp(const double* pdir) {
+    void launch_kp(const double* pdir, unsigned long long* ts = nullptr) {
         SpmvArgs a = spmv_args(K, pdir);
-        a.p = pdir;
+        a.p = pdir; a.tstamp = ts;
         hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
     }
     // p_new = z + beta p_old ; w = K p_new
-    void launch_kpb(const double* p_old, double* p_new, const double* rz_new, const double* rz_old) {
+    void launch_kpb(const double* p_old, double* p_new, const double* rz_new, const double* rz_old,
+                    unsigned long long* ts = nullptr) {
         SpmvArgs a = spmv_args(K, p_old);
+        a.tstamp = ts;
         a.p = p_old; a.z = z.d; a.p_out = p_new; a.rz_new = rz_new; a.rz_old = rz_old;
         hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
     }
@@ -444,9 +446,13 @@ struct HipBackend {
     // the NEXT iteration's right-hand-side kernel on its own rows, and on the fly by the cone
     // kernel's gather; only a measuring iteration (the last of a launch graph) finalises it
     // itself, so the first iteration of a graph has nothing pending (`first`).
-    void enqueue_iteration(bool measure, bool first) {
+    // `ts` (score_time_iteration only): device slots, ts_stride per kernel of the iteration (KernelStamp)
+    size_t ts_stride = 0;
+    void enqueue_iteration(bool measure, bool first, unsigned long long* ts = nullptr) {
+        auto slot = [&](int k) -> unsigned long long* { return ts ? ts + ts_stride * k : nullptr; };
         {
             SpmvArgs ra = spmv_args(G1, xtu.d);
+            ra.tstamp = slot(0);
             ra.apply_update = first ? 0 : 1;
             ra.pfin = last_p;
             hipLaunchKernelGGL(k_spmv<MODE_RHS>, dim3(G1.nblocks), dim3(kThreads), 0, stream, ra);
@@ -461,18 +467,21 @@ struct HipBackend {
         double* p_cur = p.d;
         double* p_oth = p2.d;
         pa.p = p_cur; pa.rz_in = nullptr; pa.rz_out = rz_cur;
+        pa.tstamp = slot(1);
         launch_prec<PREC_INIT>(pa);
-        launch_kp(p_cur);
+        launch_kp(p_cur, slot(2));
         for (int j = 2; j <= cg_iters; ++j) {
             double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
             pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_nxt;
+            pa.tstamp = (j == 2) ? slot(3) : nullptr;
             launch_prec<PREC_STEP>(pa);
-            launch_kpb(p_cur, p_oth, rz_nxt, rz_cur);
+            launch_kpb(p_cur, p_oth, rz_nxt, rz_cur, (j == 2) ? slot(4) : nullptr);
             std::swap(p_cur, p_oth);
             rz_cur = rz_nxt;
         }
         ConeArgs ca = cone_args(xtu.d);
         if (measure) {
+            pa.tstamp = nullptr;
             pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_meas1.d;
             launch_prec<PREC_STEP>(pa);  // also applies xt += a p, kx += a w, r -= a w
             VecArgs va{};
@@ -486,8 +495,47 @@ struct HipBackend {
             last_rz = rz_cur;  // what the next iteration's right-hand-side kernel has to apply
             last_p = p_cur;
         }
+        ca.tstamp = slot(5);
         if (n_cone_blocks)
             hipLaunchKernelGGL(k_cone, dim3(n_cone_blocks), dim3(kThreads), 0, stream, ca);
+    }
+
+    // in-loop duration of the six kernels of an iteration (see score_time_iteration)
+    void time_iteration(int warmup, int iters, double* us) {
+        if (cg_iters != 2) throw std::runtime_error("score_time_iteration: needs cg_iters == 2");
+        iters = std::max(1, iters);
+        const HostSystem& h = *H;
+        int khz = 0;
+        HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, st.device));
+        if (khz <= 0) throw std::runtime_error("score_time_iteration: no wall clock rate");
+        std::vector<int32_t> zero(h.count, 0);
+        reset();
+        HIP_CHECK(hipMemcpyAsync(done.d, zero.data(), zero.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        const int maxb = std::max(std::max(G1.nblocks, K.nblocks), std::max(n_prec, n_cone_blocks));
+        ts_stride = (size_t)2 * maxb;
+        const size_t per_iter = 6 * ts_stride, nslot = per_iter * iters;
+        std::vector<unsigned long long> hts(nslot);
+        for (size_t i = 0; i < nslot; i += 2) { hts[i] = ~0ull; hts[i + 1] = 0ull; }
+        unsigned long long* dts = nullptr;
+        HIP_CHECK(hipMalloc((void**)&dts, nslot * sizeof(unsigned long long)));
+        HIP_CHECK(hipMemcpyAsync(dts, hts.data(), nslot * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for (int i = 0; i < warmup; ++i) enqueue_iteration(false, i == 0);
+        for (int i = 0; i < iters; ++i) enqueue_iteration(false, warmup == 0 && i == 0, dts + per_iter * i);
+        hipError_t e1 = hipMemcpyAsync(hts.data(), dts, nslot * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream);
+        hipError_t e2 = hipStreamSynchronize(stream);
+        (void)hipFree(dts);
+        HIP_CHECK(e1);
+        HIP_CHECK(e2);
+        HIP_CHECK(hipGetLastError());
+        for (int k = 0; k < 6; ++k) us[k] = 0.0;
+        for (int i = 0; i < iters; ++i)
+            for (int k = 0; k < 6; ++k) {
+                const unsigned long long* p = &hts[per_iter * i + ts_stride * k];
+                unsigned long long t0 = ~0ull, t1 = 0ull;
+                for (int b = 0; b < maxb; ++b) { t0 = std::min(t0, p[2 * b]); t1 = std::max(t1, p[2 * b + 1]); }
+                if (t1 > t0) us[k] += (double)(t1 - t0) * 1e3 / (double)khz / iters;
+            }
     }
 
     void build_graph(int iters) {
@@ -967,6 +1015,13 @@ int score_time_kkt_apply(score_handle* h, int32_t reps, double* ms, double* byte
     try {
         if (!h) throw std::runtime_error("null handle");
         h->solver.be.time_kkt(reps, ms, bytes);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_time_iteration(score_handle* h, int32_t warmup, int32_t iters, double* us) {
+    try {
+        if (!h || !us) throw std::runtime_error("null argument");
+        h->solver.be.time_iteration(warmup, iters, us);
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }

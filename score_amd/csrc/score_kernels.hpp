@@ -120,6 +120,22 @@ struct CsrDev {
     int nblocks;
 };
 
+// Optional device-side timing of one launch (score_time_iteration): the first lane of every
+// workgroup stores the wall clock at entry / exit into its own slot ts[2 b], ts[2 b + 1]; the host
+// takes min / max over the workgroups.  This is what a profiler reports as the kernel's duration
+// and, unlike HIP events, adds no command between two kernels of the loop (and, unlike atomics
+// on one address, no serialisation between workgroups).  ts == nullptr (always, outside that
+// probe): one uniform branch.
+struct KernelStamp {
+    unsigned long long* ts;
+    __device__ explicit KernelStamp(unsigned long long* p) : ts(p) {
+        if (ts && threadIdx.x == 0) ts[2 * blockIdx.x] = (unsigned long long)wall_clock64();
+    }
+    __device__ ~KernelStamp() {
+        if (ts && threadIdx.x == 0) ts[2 * blockIdx.x + 1] = (unsigned long long)wall_clock64();
+    }
+};
+
 struct SpmvArgs {
     CsrDev M;
     const double* xin;      // gathered vector
@@ -155,6 +171,7 @@ struct SpmvArgs {
     // DRES
     const double* invD;
     double* dres_part;      // 8 per block
+    unsigned long long* tstamp;  // see KernelStamp
 };
 
 // RHS : r = sigma x - q + M xin - kx                   (M = [0 | A'], xin = [xt ; u], kx = K xt)
@@ -166,6 +183,7 @@ enum { MODE_RHS = 0, MODE_KP = 1, MODE_DRES = 2, MODE_KPB = 3, MODE_GRAD = 4 };
 
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
+    KernelStamp stamp(a.tstamp);
     __shared__ double prod[kTileNnz];
     __shared__ double red[8];
     __shared__ int32_t srow[kRowsPerBlock + 1];  // row pointers of the tile, relative to k0
@@ -373,6 +391,7 @@ struct PrecArgs {
     const double* rz_in;   // partials of the previous r'z   (STEP)
     const double* pw_part; // partials of p'w                (STEP)
     double* rz_out;        // one partial per work item
+    unsigned long long* tstamp;  // see KernelStamp
     int debug_skip;        // timing experiments only: 1 run, 2 separator, 4 back-subst, 8 head, 16 tail
 };
 
@@ -458,6 +477,7 @@ __device__ __forceinline__ double prec_jacobi_item(const PrecArgs& a, const Prec
 // barrier that ends the previous phase and arrive while it drains.
 template <int BS, int RMAX, int MODE, bool LDS0>
 __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
+    KernelStamp stamp(a.tstamp);
     extern __shared__ __attribute__((aligned(16))) double lds[];  // [0,16) reductions, [16,16+6*kMaxLevels) level table, vectors
     __shared__ ChainLevelDesc sLv[kMaxLevels];
     double* red = lds;
@@ -804,6 +824,7 @@ struct PreTile {
 
 template <int BS, int MODE>
 __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
+    KernelStamp stamp(a.tstamp);
     constexpr int RMAX = 3;
     constexpr int B2 = BS * BS;
     constexpr int NG = PreTile<BS>::NG;
@@ -1294,6 +1315,7 @@ struct ConeArgs {
     const int32_t* prec_part_ptr;
     const int32_t* kblk_part_ptr;
     double* step_out;   // per problem
+    unsigned long long* tstamp;  // see KernelStamp
 };
 
 __device__ __forceinline__ double a_row_dot(const ConeArgs& a, int i, const double* __restrict__ v) {
@@ -1317,6 +1339,7 @@ constexpr int kSmallCone = 4;    // rows
 constexpr int kConeRowNnz = 2;   // entries per row handled by the register path
 
 __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
+    KernelStamp stamp(a.tstamp);
     __shared__ double red[8];
     const int b = blockIdx.x;
     const int prob = a.block_prob[b];

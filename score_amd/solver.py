@@ -67,7 +67,7 @@ STATUS_NAMES = {0: "unsolved", 1: "solved", 2: "max_iters", 3: "numerical"}
 # every symbol include/score_hip.h declares
 ABI_SYMBOLS = [
     "score_default_settings", "score_create", "score_create_batch", "score_dims", "score_solve",
-    "score_reset", "score_solve_steps", "score_time_kkt_apply", "score_debug_time", "score_debug_get", "score_destroy",
+    "score_reset", "score_solve_steps", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
     "score_last_error", "score_backend",
 ]
 
@@ -90,6 +90,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.score_solve_steps.argtypes = [C.c_void_p, C.c_int32, _f64p, _f64p, _f64p, C.POINTER(ScoreInfo)]
     lib.score_time_kkt_apply.argtypes = [C.c_void_p, C.c_int32, _f64p, _f64p]
     lib.score_debug_time.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, _f64p]
+    lib.score_time_iteration.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f64p]
+    lib.score_time_iteration.restype = C.c_int
     lib.score_debug_get.argtypes = [C.c_void_p, C.c_char_p, _f64p, C.c_int64]
     lib.score_debug_get.restype = C.c_int64
     lib.score_destroy.argtypes = [C.c_void_p]
@@ -217,6 +219,16 @@ class ConicSolver:
         if self.lib.score_time_kkt_apply(self._h, int(reps), C.byref(ms), C.byref(by)) != 0:
             raise RuntimeError(self.lib.score_last_error().decode())
         return ms.value, by.value
+
+    ITERATION_KERNELS = ("rhs", "prec_init", "kp", "prec_step", "kpb", "cone")
+
+    def time_iteration(self, warmup: int = 50, iters: int = 200) -> dict:
+        """In-loop microseconds of the six kernels of one ADMM iteration (device wall clock, first
+        workgroup in to last workgroup out).  Resets and advances the iterates."""
+        us = np.zeros(6)
+        if self.lib.score_time_iteration(self._h, int(warmup), int(iters), _ptr(us, _f64p)) != 0:
+            raise RuntimeError(self.lib.score_last_error().decode())
+        return dict(zip(self.ITERATION_KERNELS, us.tolist()))
 
     def debug_time(self, kernel: str, reps: int = 200) -> float:
         ms = C.c_double()
