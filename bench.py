@@ -73,6 +73,18 @@ def pmc_traffic(n: int, nnz_p: int):
     return None
 
 
+def profiler_kkt_us(n: int, nnz_p: int):
+    """Average duration of the KKT SpMV in the committed rocprofv3 kernel trace of this command
+    (profiles/kkt_traffic.json carries it) -- only when it was taken on this workload."""
+    try:
+        rec = json.load(open(os.path.join(ROOT, "profiles", "kkt_traffic.json")))
+        if rec["workload"]["n"] == n and rec["workload"]["nnz_P"] == nnz_p:
+            return float(rec["rocprofv3_kernel_trace"]["average_us"])
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(args, models):
     """The oracle's CPU twin (same algorithm, OpenMP loops) on a bounded sample of
     the same workload: a fixed number of cold-start ADMM iterations."""
@@ -345,6 +357,7 @@ def main():
                          "bytes_per_launch": kkt_bytes, "us_per_launch": inloop_us["kp"],
                          "timing": "in the ADMM loop: device wall clock, first workgroup in to last workgroup "
                                    "out, averaged over 200 iterations (what rocprofv3 --kernel-trace reports)",
+                         "rocprofv3_average_us": profiler_kkt_us(int(models[0].qp.n), int(models[0].qp.P.nnz)) if args.batch == 1 else None,
                          "back_to_back": {"us_per_launch": kkt_ms * 1e3, "achieved": achieved_b2b,
                                           "frac": achieved_b2b / HBM_PEAK_GBS,
                                           "note": "500 consecutive launches of this kernel alone: K stays in the XCD L2s"}},
