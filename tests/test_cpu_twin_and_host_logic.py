@@ -170,3 +170,37 @@ def test_equilibration_and_kkt_values(fixtures, twin_lib):
     assert abs(K).max(axis=0).toarray().max() < 1e3  # equilibrated (unscaled: 5e5)
     assert Kval.size >= K.nnz
     assert np.isclose(Kval.sum(), K.data.sum(), rtol=1e-10)
+
+
+def test_host_setup_does_not_depend_on_the_thread_count(twin_lib, tmp_path):
+    """score_create spreads equilibration, the KKT pattern and the chain factorisations over host
+    threads; every thread computes what the serial loop would, so the scaled problem -- and with
+    OMP_NUM_THREADS=1 the whole iterate sequence of the twin -- must be bitwise the same on one
+    CPU (affinity mask of a child process) and on all of them."""
+    import os
+    import subprocess
+    import sys
+
+    script = tmp_path / "run.py"
+    script.write_text(
+        "import sys, os\n"
+        "if sys.argv[2] == 'one': os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})\n"
+        f"sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})\n"
+        "import numpy as np\n"
+        "from score_amd.manhattan import make_manhattan\n"
+        "from score_amd.assemble import assemble\n"
+        "from score_amd.solver import ConicSolver\n"
+        "qp = assemble(make_manhattan(n_robots=6, n_poses=3000, n_beacons=3, seed=4), 'SOCP').qp\n"
+        "s = ConicSolver(qp, dict(polish=0), lib_path=sys.argv[1])\n"
+        "out = s.steps(30)[0]\n"
+        "np.save(sys.argv[3], np.concatenate([out.x, out.y, out.s]))\n"
+    )
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    outs = []
+    for mode in ("one", "all"):
+        f = str(tmp_path / f"{mode}.npy")
+        subprocess.run([sys.executable, str(script), twin_lib, mode, f], check=True, env=env, timeout=600)
+        outs.append(np.load(f))
+    if len(os.sched_getaffinity(0)) < 2:
+        pytest.skip("single-CPU machine: nothing to compare")
+    assert np.array_equal(outs[0], outs[1])

@@ -261,3 +261,23 @@ def test_handles_from_a_thread_pool_and_empty_tiles(hip_lib):
     for seed in range(3):
         fg = make_manhattan(n_robots=1, n_poses=50 + 17 * seed, n_beacons=0, seed=seed, p_range=0.0)
         assert solve_score(fg, "SOCP").solved
+
+
+def test_polish_warmup_and_in_loop_timing_probe(hip_lib):
+    """polish_warmup sets the length of the first ADMM block; score_time_iteration returns a
+    positive device-clock duration for each of the six kernels of the iteration and leaves the
+    handle usable."""
+    qp = assemble(make_manhattan(n_robots=3, n_poses=200, n_beacons=3, seed=6), "SOCP").qp
+    for warm, expect in ((15, 15), (0, 25), (40, 25)):
+        sol = ConicSolver(qp, dict(polish_warmup=warm))
+        out = sol.solve()[0]
+        sol.close()
+        assert out.solved and out.info["newton_iters"] > 0 and out.info["iters"] == expect, out.info
+    sol = ConicSolver(qp, dict(polish=0))
+    ref = sol.solve()[0]
+    us = sol.time_iteration(warmup=5, iters=20)
+    assert list(us) == ["rhs", "prec_init", "kp", "prec_step", "kpb", "cone"]
+    assert all(0.5 < v < 500.0 for v in us.values()), us
+    again = sol.solve()[0]  # solve() resets the iterates: the probe leaves no trace
+    np.testing.assert_array_equal(ref.x, again.x)
+    sol.close()
