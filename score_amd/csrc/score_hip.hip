@@ -170,6 +170,7 @@ struct HipBackend {
     DevBuf<double> A_val;
     DevBuf<double> q, b, invD, invE, rho, fac, dinv;
     DevBuf<int32_t> done, cone_row, cone_dim, cone_type, cone_block_first, cone_block_prob;
+    DevBuf<int4> cone_meta;
     DevBuf<int32_t> node_col, diag_cols, prec_part_ptr, kblk_part_ptr;
     DevBuf<PrecWork> prec_work;
     DevBuf<ChainDesc> chains;
@@ -243,6 +244,16 @@ struct HipBackend {
         invD.upload(iD); invE.upload(iE);
         cone_row.upload(h.cone_row); cone_dim.upload(h.cone_dim); cone_type.upload(h.cone_type);
         cone_block_first.upload(h.cone_block_first); cone_block_prob.upload(h.cone_block_prob);
+        {
+            std::vector<int4> meta(2 * h.cone_row.size());
+            for (size_t c = 0; c < h.cone_row.size(); ++c) {
+                const int row = h.cone_row[c], dim = h.cone_dim[c];
+                auto ptr = [&](int k) { return h.A.ptr[row + std::min(k, dim)]; };
+                meta[2 * c] = make_int4(row, dim, h.cone_type[c], ptr(0));
+                meta[2 * c + 1] = make_int4(ptr(1), ptr(2), ptr(3), ptr(4));
+            }
+            cone_meta.upload(meta);
+        }
         n_cone_blocks = (int)h.cone_block_prob.size();
         node_col.upload(h.node_col); diag_cols.upload(h.diag_cols);
         prec_part_ptr.upload(h.prec_part_ptr); kblk_part_ptr.upload(h.rbK.part_ptr);
@@ -315,7 +326,7 @@ struct HipBackend {
     ConeArgs cone_args(const double* gathered) {
         ConeArgs a{};
         a.A_ptr = A_ptr.d; a.A_col = A_col.d; a.A_val = A_val.d;
-        a.cone_row = cone_row.d; a.cone_dim = cone_dim.d; a.cone_type = cone_type.d;
+        a.cone_row = cone_row.d; a.cone_dim = cone_dim.d; a.cone_type = cone_type.d; a.cone_meta = cone_meta.d;
         a.block_first = cone_block_first.d; a.block_prob = cone_block_prob.d;
         a.done = done.d; a.rho = rho.d; a.b = b.d; a.xt = gathered;
         a.s = s.d; a.y = xy.d + H->n_tot; a.u = xtu.d + H->n_tot;

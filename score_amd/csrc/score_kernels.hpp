@@ -1295,6 +1295,7 @@ struct ConeArgs {
     const int32_t* cone_row;
     const int32_t* cone_dim;
     const int32_t* cone_type;
+    const int4* cone_meta;  // per cone: {row, dim, type, ptr[row]}, {ptr[row+1..row+4]} (clamped at row+dim)
     const int32_t* block_first;
     const int32_t* block_prob;
     const int32_t* done;
@@ -1344,36 +1345,44 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
     const int b = blockIdx.x;
     const int prob = a.block_prob[b];
     if (a.done[prob]) return;
-    double step = 0.0;  // step length of the last PCG step (its xt update is applied on the fly)
+    // Partial sums of the last PCG step's r'z and p'w: requested now, reduced (two barriers) only
+    // after the cone's own loads are in flight.
+    double rz = 0.0, pw = 0.0;
     if (a.apply_alpha) {
-        double rz = 0.0, pw = 0.0;
         for (int i = a.prec_part_ptr[prob] + (int)threadIdx.x; i < a.prec_part_ptr[prob + 1]; i += kThreads) rz += a.rz_in[i];
         for (int i = a.kblk_part_ptr[prob] + (int)threadIdx.x; i < a.kblk_part_ptr[prob + 1]; i += kThreads) pw += a.pw_in[i];
-        block_sum2(rz, pw, red);
-        step = pw > 0.0 ? rz / pw : 0.0;
-        // every block of the problem computes the same value; the next right-hand-side kernel reads it
-        if (threadIdx.x == 0) a.step_out[prob] = step;
     }
+    double step = 0.0;  // step length of the last PCG step (its xt update is applied on the fly)
+    auto finish_step = [&]() {
+        if (a.apply_alpha) {
+            block_sum2(rz, pw, red);
+            step = pw > 0.0 ? rz / pw : 0.0;
+            // every block of the problem computes the same value; the next right-hand-side kernel reads it
+            if (threadIdx.x == 0) a.step_out[prob] = step;
+        }
+    };
+    const int c_end = a.block_first[b + 1];
     const int c = a.block_first[b] + threadIdx.x;
-    if (c >= a.block_first[b + 1]) return;
-    const int row = a.cone_row[c], dim = a.cone_dim[c], type = a.cone_type[c];
+    // one 32-byte record per cone (first row, dimension, type, the row pointers of its first four
+    // rows) instead of the chain cone_row -> A_ptr; loaded on a clamped index by every lane
+    const int cl = min(c, c_end - 1);
+    const int4 m0 = a.cone_meta[2 * cl], m1 = a.cone_meta[2 * cl + 1];
+    const int row = m0.x, dim = m0.y, type = m0.z;
+    const int ptrs[kSmallCone + 1] = {m0.w, m1.x, m1.y, m1.z, m1.w};
     const double rho = a.rho[prob], irho = 1.0 / rho, al = a.alpha_relax;
     double t0 = 0.0, nz2 = 0.0, head, tail;
-    // SCORE's cones have d + 1 = 3 or 4 rows with at most 2 entries each: row pointers,
-    // then every column/value, then every gathered x are requested as three batches of
-    // unconditional loads (clamped indices) instead of a dependent chain per entry.
-    int ptrs[kSmallCone + 1];
+    // SCORE's cones have d + 1 = 3 or 4 rows with at most 2 entries each: every column/value,
+    // then every gathered x are requested as batches of unconditional loads (clamped indices)
+    // instead of a dependent chain per entry.
     bool small = (dim <= kSmallCone);
-    if (small) {
 #pragma unroll
-        for (int k = 0; k <= kSmallCone; ++k) ptrs[k] = a.A_ptr[row + min(k, dim)];
-#pragma unroll
-        for (int k = 0; k < kSmallCone; ++k) small = small && (ptrs[k + 1] - ptrs[k] <= kConeRowNnz);
-    }
+    for (int k = 0; k < kSmallCone; ++k) small = small && (ptrs[k + 1] - ptrs[k] <= kConeRowNnz);
+    // (uniform decision per block would need a vote; lanes simply take their own path after the
+    //  block-wide reduction below)
+    double v[kSmallCone], wv[kSmallCone], yv[kSmallCone], bv[kSmallCone], sv[kSmallCone];
+    int cc[kSmallCone][kConeRowNnz];
+    double av[kSmallCone][kConeRowNnz], xv[kSmallCone][kConeRowNnz], pvv[kSmallCone][kConeRowNnz];
     if (small) {
-        double v[kSmallCone], wv[kSmallCone], yv[kSmallCone], bv[kSmallCone], sv[kSmallCone];
-        int cc[kSmallCone][kConeRowNnz];
-        double av[kSmallCone][kConeRowNnz], xv[kSmallCone][kConeRowNnz];
         const int last_nz = max(ptrs[kSmallCone] - 1, 0);
 #pragma unroll
         for (int k = 0; k < kSmallCone; ++k) {
@@ -1393,13 +1402,18 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
 #pragma unroll
             for (int e = 0; e < kConeRowNnz; ++e) {
                 xv[k][e] = a.xt[cc[k][e]];
-                if (a.apply_alpha) xv[k][e] += step * a.pfin[cc[k][e]];
+                pvv[k][e] = a.apply_alpha ? a.pfin[cc[k][e]] : 0.0;
             }
+    }
+    finish_step();
+    if (c >= c_end) return;
+    if (small) {
 #pragma unroll
         for (int k = 0; k < kSmallCone; ++k) {
             double tt = 0.0;
 #pragma unroll
-            for (int e = 0; e < kConeRowNnz; ++e) tt += (ptrs[k] + e < ptrs[k + 1]) ? av[k][e] * xv[k][e] : 0.0;
+            for (int e = 0; e < kConeRowNnz; ++e)
+                tt += (ptrs[k] + e < ptrs[k + 1]) ? av[k][e] * (xv[k][e] + step * pvv[k][e]) : 0.0;
             v[k] = al * (bv[k] - tt) + (1.0 - al) * sv[k];
             wv[k] = v[k] - yv[k] * irho;
             if (k == 0) t0 = wv[k]; else if (k < dim) nz2 += wv[k] * wv[k];
@@ -1421,18 +1435,18 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
         const int i = row + k;
         double tt = a_row_dot(a, i, a.xt);
         if (a.apply_alpha) tt += step * a_row_dot(a, i, a.pfin);
-        const double v = al * (a.b[i] - tt) + (1.0 - al) * a.s[i];
-        const double wv = v - a.y[i] * irho;
-        a.u[i] = v;   // stash v
-        a.s[i] = wv;  // stash the point to project
-        if (k == 0) t0 = wv; else nz2 += wv * wv;
+        const double v_ = al * (a.b[i] - tt) + (1.0 - al) * a.s[i];
+        const double w_ = v_ - a.y[i] * irho;
+        a.u[i] = v_;   // stash v
+        a.s[i] = w_;  // stash the point to project
+        if (k == 0) t0 = w_; else nz2 += w_ * w_;
     }
     soc_scales(type, t0, nz2, head, tail);
     for (int k = 0; k < dim; ++k) {
         const int i = row + k;
         const double sn = (k == 0) ? head : tail * a.s[i];
-        const double v = a.u[i];
-        const double yn = a.y[i] + rho * (sn - v);
+        const double v_ = a.u[i];
+        const double yn = a.y[i] + rho * (sn - v_);
         a.s[i] = sn;
         a.y[i] = yn;
         a.u[i] = rho * (a.b[i] - sn) - yn;
