@@ -105,6 +105,10 @@ class ScoreModel:
     lm_base: int
     rng_base: int
     rng_width: int  # 1 (SOCP) or d (QCQP)
+    # per range measurement: first translation column / stride of both end points (model space)
+    # and the measured distance
+    range_ends: Optional[np.ndarray] = None  # (Nr, 4) int64: ta, sa, tb, sb
+    range_dist: Optional[np.ndarray] = None
 
     def expand(self, x_solver: np.ndarray) -> np.ndarray:
         """solver space -> model space (re-inserts the pinned pose)."""
@@ -393,4 +397,5 @@ def assemble(data, relaxation: str = QCQP_RELAXATION) -> ScoreModel:
         fixed_cols=fixed_cols, fixed_vals=fixed_vals, pose_names=pose_names,
         landmark_names=landmark_names, range_keys=range_keys, lm_base=lm_base,
         rng_base=rng_base, rng_width=rw,
+        range_ends=(ends if Nr else None), range_dist=(dist if Nr else None),
     )

@@ -51,20 +51,15 @@ def _check_factor_graph(data) -> None:
 def _qcqp_dists_from_socp(model: ScoreModel, x_model: np.ndarray, data) -> np.ndarray:
     """Optimal QCQP range directions for fixed translations: r = D / max(|D|, dist)."""
     d = model.dim
-    out = np.zeros((len(model.range_keys), d))
-    poses = model.pose_blocks(x_model)
-    lms = model.landmark_block(x_model)
-    pidx = {n: i for i, n in enumerate(model.pose_names)}
-    lidx = {n: i for i, n in enumerate(model.landmark_names)}
-
-    def trans(name):
-        return poses[pidx[name], :, d] if name in pidx else lms[lidx[name]]
-
-    for r, (m, key) in enumerate(zip(data.range_measurements, model.range_keys)):
-        delta = trans(key[0]) - trans(key[1])
-        den = max(float(np.linalg.norm(delta)), float(m.dist))
-        if den > 0:
-            out[r] = delta / den
+    nr = len(model.range_keys)
+    if nr == 0:
+        return np.zeros((0, d))
+    k = np.arange(d)
+    e = model.range_ends
+    delta = x_model[e[:, 0:1] + e[:, 1:2] * k] - x_model[e[:, 2:3] + e[:, 3:4] * k]
+    den = np.maximum(np.sqrt(np.einsum("ij,ij->i", delta, delta)), model.range_dist)
+    out = np.zeros((nr, d))
+    np.divide(delta, den[:, None], out=out, where=den[:, None] > 0)
     return out
 
 
@@ -80,15 +75,13 @@ def extract_solver_results(
     T = np.tile(np.eye(d + 1), (blocks.shape[0], 1, 1))
     T[:, :d, :d] = R
     T[:, :d, d] = blocks[:, :, d]
-    poses = {nm: T[i] for i, nm in enumerate(model.pose_names)}
-    lm = model.landmark_block(xm)
-    landmarks = {nm: lm[i].copy() for i, nm in enumerate(model.landmark_names)}
+    # (rows of freshly built arrays: iterating a 2-D/3-D array yields one view per entry)
+    poses = dict(zip(model.pose_names, T))
+    landmarks = dict(zip(model.landmark_names, model.landmark_block(xm).copy()))
     if requested_relaxation == model.relaxation:
-        rb = model.range_block(xm)
-        dists = {k: rb[i].copy() for i, k in enumerate(model.range_keys)}
+        dists = dict(zip(model.range_keys, model.range_block(xm).copy()))
     else:  # QCQP answered through the SOCP
-        rq = _qcqp_dists_from_socp(model, xm, data)
-        dists = {k: rq[i] for i, k in enumerate(model.range_keys)}
+        dists = dict(zip(model.range_keys, _qcqp_dists_from_socp(model, xm, data)))
     values = compat.VariableValues(d, poses, landmarks, dists)
     return compat.SolverResults(
         variables=values, total_time=total_time, solved=solved,
