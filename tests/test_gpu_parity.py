@@ -281,3 +281,32 @@ def test_polish_warmup_and_in_loop_timing_probe(hip_lib):
     again = sol.solve()[0]  # solve() resets the iterates: the probe leaves no trace
     np.testing.assert_array_equal(ref.x, again.x)
     sol.close()
+
+
+def test_chain_length_sweep_against_the_twin(hip_lib, twin_lib):
+    """Chain lengths around every structural boundary of the chain kernels (last-level runs of
+    1..3 nodes, one/two/three levels, 64/256 runs per level, the k_prec_pre / k_prec switch), with
+    random robot / beacon / loop-closure counts: 40 ADMM iterations must reproduce the CPU twin's
+    iterates, and the full solver must return a certified optimum."""
+    rng = np.random.default_rng(123)
+    for trial, n_poses in enumerate([2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 63, 64, 65, 255, 256, 257]):
+        nrob, nb = int(rng.integers(1, 4)), int(rng.integers(0, 4))
+        nlc = int(rng.integers(0, 3)) if n_poses > 8 else 0
+        if nrob == 1 and nb == 0:
+            nb = 1
+        fg = make_manhattan(n_robots=nrob, n_poses=n_poses, n_beacons=nb, seed=1000 + trial, n_loop_closures=nlc,
+                            p_range=float(rng.uniform(0.05, 0.6)))
+        qp = assemble(fg, "SOCP").qp
+        outs = []
+        for lib in (None, twin_lib):
+            sol = ConicSolver(qp, dict(polish=0, adaptive_rho=0, adaptive_cg=0), lib_path=lib)
+            outs.append(sol.steps(40)[0])
+            sol.close()
+        scale = max(1.0, np.abs(outs[1].x).max())
+        np.testing.assert_allclose(outs[0].x, outs[1].x, atol=1e-7 * scale, err_msg=f"n_poses={n_poses}")
+        sol = ConicSolver(qp, {})
+        full = sol.solve()[0]
+        sol.close()
+        assert full.solved, (n_poses, full.info)
+        cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, full.x, full.y, full.s)
+        assert cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4, (n_poses, cert)
