@@ -292,8 +292,8 @@ struct HipBackend {
         }
         if (lds_pre > 158 * 1024) prec_pre = false;  // 160 KiB per CU, minus the static level table and slack
         if (prec_pre) { prec_lds0 = true; prec_lds = lds_pre; }
-        if (prec_lds > 144 * 1024) throw std::runtime_error("chain too long for the LDS-resident chain solver");
-        if (prec_lds > 48 * 1024 && n_prec_chains(h)) {
+        if (!prec_pre && prec_lds > 144 * 1024) throw std::runtime_error("chain too long for the LDS-resident chain solver");
+        if (n_prec_chains(h)) {
             if (h.bs <= 1) allow_big_lds<1>(); else if (h.bs == 2) allow_big_lds<2>();
             else if (h.bs == 3) allow_big_lds<3>(); else allow_big_lds<4>();
         }
@@ -392,13 +392,19 @@ struct HipBackend {
 #undef SCORE_LAUNCH_PREC
     }
 
+    // The attribute is per kernel function, i.e. shared by every handle of the process: always
+    // raise it to the same ceiling, never to what this handle happens to need (a later, smaller
+    // handle would otherwise lower it under a live larger one).
     template <int BS>
     void allow_big_lds() {
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_INIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prec_lds));
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_STEP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prec_lds));
+        constexpr int kCeil = 158 * 1024;
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_INIT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_STEP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_INIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_STEP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
         constexpr int BP = BS <= 3 ? BS : 3;
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_INIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prec_lds));
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prec_lds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_INIT>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
     }
 
     SpmvArgs spmv_args(const CsrBufs& M, const double* xin) {

@@ -310,3 +310,17 @@ def test_chain_length_sweep_against_the_twin(hip_lib, twin_lib):
         assert full.solved, (n_poses, full.info)
         cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, full.x, full.y, full.s)
         assert cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4, (n_poses, cert)
+
+
+def test_live_handles_of_different_sizes(hip_lib):
+    """The dynamic-LDS ceiling of the chain kernels is a per-function attribute shared by every
+    handle of the process: creating a smaller handle must not lower it under a larger live one."""
+    qps = [assemble(make_manhattan(n_robots=2, n_poses=n, n_beacons=3, seed=n), "SOCP").qp for n in (1000, 500, 120)]
+    sols = [ConicSolver(qp, {}) for qp in qps]  # largest first
+    ref = [s.solve()[0] for s in sols]
+    for _ in range(2):
+        for s, r in zip(sols, ref):
+            out = s.solve()[0]
+            assert out.solved and out.info["pobj"] == r.info["pobj"]
+    for s in sols:
+        s.close()
