@@ -44,7 +44,9 @@ def parse_args():
     ap.add_argument("--montecarlo", type=int, default=0, metavar="TRIALS",
                     help="BASELINE config 4: TRIALS independent 4-robot x 1000-pose trials sharded over the ranks; "
                          "reports problems/s of the full solver with every problem resident in HBM")
-    ap.add_argument("--mc-threads", type=int, default=8, help="host threads driving handles concurrently (montecarlo)")
+    ap.add_argument("--mc-threads", type=int, default=4, help="host threads driving handles concurrently (montecarlo)")
+    ap.add_argument("--mc-batch", type=int, default=16,
+                    help="montecarlo: trials per handle (>1: lock-step batches, one launch serves the whole batch)")
     return ap.parse_args()
 
 
@@ -134,9 +136,10 @@ def cpu_baseline(args, models):
 
 
 def montecarlo(args, rank, world, local_rank):
-    """Config 4: independent Monte-Carlo trials, trial i on rank i % world, every trial its own
-    handle (own stream); the timed region solves all of a rank's trials `steps` times from a
-    pool of host threads (full solver: ADMM warm-up + Newton polish)."""
+    """Config 5: independent Monte-Carlo trials, trial i on rank i % world; a rank's trials are
+    grouped into lock-step handles of --mc-batch trials (own stream each); the timed region solves
+    all of them `steps` times from a pool of host threads (full solver: ADMM warm-up + Newton
+    polish)."""
     from concurrent.futures import ThreadPoolExecutor
 
     import torch
@@ -153,10 +156,10 @@ def montecarlo(args, rank, world, local_rank):
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
     mine = [t for t in range(args.montecarlo) if t % world == rank]
-    solvers = []
-    for t in mine:
-        fg = make_manhattan(n_robots=4, n_poses=1000, n_beacons=4, seed=4000 + t)
-        solvers.append(ConicSolver([assemble(fg, "SOCP").qp], dict(eps_abs=args.eps, eps_rel=args.eps, device=local_rank)))
+    qps = [assemble(make_manhattan(n_robots=4, n_poses=1000, n_beacons=4, seed=4000 + t), "SOCP").qp for t in mine]
+    nb = max(1, args.mc_batch)
+    solvers = [ConicSolver(qps[i : i + nb], dict(eps_abs=args.eps, eps_rel=args.eps, device=local_rank))
+               for i in range(0, len(qps), nb)]
 
     def barrier():
         if use_dist:
@@ -164,7 +167,7 @@ def montecarlo(args, rank, world, local_rank):
         torch.cuda.synchronize()
 
     def sweep(pool):
-        return list(pool.map(lambda s: s.solve()[0], solvers))
+        return [r for rs in pool.map(lambda s: s.solve(), solvers) for r in rs]
 
     with ThreadPoolExecutor(max_workers=max(1, args.mc_threads)) as pool:
         for _ in range(args.warmup):
@@ -192,7 +195,8 @@ def montecarlo(args, rank, world, local_rank):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.montecarlo} Monte-Carlo trials, manhattan RA-SLAM 4 robots x 1000 poses, 4 beacons, "
-                                   f"SOCP, full solver (ADMM warm-up + Newton polish), {args.mc_threads} host threads/GPU",
+                                   f"SOCP, full solver (ADMM warm-up + Newton polish), {args.mc_threads} host threads/GPU, "
+                                   f"{nb} trial(s) per handle" + (" (lock-step)" if nb > 1 else ""),
                        "eps": args.eps, "parallelism": f"trials sharded x{world}"},
             "problems_solved_last_sweep": int(tot[1]), "admm_iters_last_sweep": int(tot[2]),
             "newton_iters_last_sweep": int(tot[3]),

@@ -38,7 +38,7 @@ struct CpuBackend {
     int cg_iters = 2;
 
     void set_cg_iters(int k) { cg_iters = k; }
-    bool polish(const HostSystem&, const score_settings&, int*, int*) { return false; }  // HIP backend only
+    bool polish(const HostSystem&, const score_settings&, const std::vector<int>&, int*, int*) { return false; }  // HIP backend only
     bool polish_available() const { return false; }
     void cg_reduction(std::vector<double>& out) { out = cg_red; }
 

@@ -179,7 +179,7 @@ struct Solver {
         bool all = false;
         // with the polish on, the first block is shorter: Newton is globally convergent, a rough
         // ADMM iterate is all it needs (measured: 15 iterations beat 25 by ~8 % of the solve time)
-        const bool can_polish = st.polish && H.count == 1 && be.polish_available();
+        const bool can_polish = st.polish && be.polish_available();
         while (!all && iters_done < st.max_iters) {
             int k = std::min(st.check_interval, st.max_iters - iters_done);
             if (iters_done == 0 && can_polish && st.polish_warmup > 0) k = std::min(k, st.polish_warmup);
@@ -187,15 +187,17 @@ struct Solver {
             iters_done += k;
             cg_total += (int64_t)k * cg_now;
             all = check(true);
-            if (!all && st.polish && iters_done >= next_polish && H.count == 1) {
+            if (!all && can_polish && iters_done >= next_polish) {
                 // Newton is globally convergent here (convex, line search), so by default it starts
                 // right after the first launch graph; polish_start can demand a closer ADMM iterate.
-                const score_info& I = infos[0];
-                if (std::max(I.res_pri, I.res_dual) <= st.polish_start) {
+                double worst = 0.0;  // over the problems still running
+                for (int p = 0; p < H.count; ++p)
+                    if (!done[p]) worst = std::max(worst, std::max(infos[p].res_pri, infos[p].res_dual));
+                if (worst <= st.polish_start) {
                     int nit = 0, ncg = 0;
-                    const bool ran = be.polish(H, st, &nit, &ncg);
-                    infos[0].newton_iters += nit;
-                    infos[0].newton_cg_iters += ncg;
+                    const bool ran = be.polish(H, st, done, &nit, &ncg);
+                    for (int p = 0; p < H.count; ++p)
+                        if (!done[p]) { infos[p].newton_iters += nit; infos[p].newton_cg_iters += ncg; }
                     // whether Newton converged to its own tolerance or stalled in rounding, the point
                     // it hands back is a consistent ADMM state: let the ordinary residual test decide
                     if (ran) all = check(false);

@@ -184,6 +184,10 @@ struct HipBackend {
     DevBuf<double> q_aabs, q_ck, q_theta, q_xstar;
     DevBuf<int32_t> q_cptr, q_ccone, q_cab, q_head, q_ishead, q_posd, q_poss, q_diagpos, q_hblk_part, q_long;
     int n_long = 0;
+    // lock-step polish of a batch (count > 1)
+    DevBuf<int32_t> q_skip;
+    DevBuf<double> q_step;
+    DevBuf<int64_t> q_seg_begin, q_seg_end;
     double newton_eta_max = 1e-1;  // inexact Newton: linear residual <= min(eta_max, sqrt|g|)
     int newton_chunk = 4;         // PCG iterations between two convergence reads
     double* h_newton = nullptr;  // pinned scratch for partial sums
@@ -661,7 +665,7 @@ struct HipBackend {
         PhaseTimer pt(st.verbose != 0);
         build_polish(h, Q, st.verbose != 0);
         pt.mark("  polish: host structures");
-        if (!Q.available || h.count != 1) { Q.available = false; return; }
+        if (!Q.available) return;
         Hm.upload(Q.Hm, Q.rbH, nullptr, false);
         q_Pon.upload(Q.Pon); q_ccoef.upload(Q.ccoef); q_cptr.upload(Q.cptr); q_ccone.upload(Q.ccone); q_cab.upload(Q.cab);
         q_head.upload(Q.head_col); q_ishead.upload(Q.is_head); q_aabs.upload(Q.a_abs); q_ck.upload(Q.ck);
@@ -677,14 +681,23 @@ struct HipBackend {
         }
         const size_t nc = h.cone_row.size();
         q_Bbuf.alloc(nc * Q.T * Q.T);
-        q_fpart.alloc((nc + kThreads - 1) / kThreads);
+        q_fpart.alloc(std::max<size_t>((nc + kThreads - 1) / kThreads, (size_t)n_cone_blocks));
         q_X0.alloc(h.n_tot + h.m_tot); q_X1.alloc(h.n_tot + h.m_tot);
         q_g.alloc(h.n_tot); q_delta.alloc(h.n_tot); q_dummy.alloc(h.n_tot);
         q_fac.alloc(h.fac.size()); q_dinv.alloc(h.dinv.size());
         q_fac.zero(stream);  // separator slots of the spike region are never written (nor used)
         q_work.alloc((size_t)std::max<int64_t>(1, h.scratch_nodes) * 2 * std::max(1, h.bs * h.bs));
-        q_gd.alloc((h.n_tot + kThreads - 1) / kThreads);
+        q_gd.alloc(std::max<size_t>((h.n_tot + kThreads - 1) / kThreads, (size_t)Hm.nblocks));
         q_pw.alloc(Hm.nblocks);
+        if (h.count > 1) {
+            q_skip.alloc(h.count); q_step.alloc(h.count);
+            std::vector<int64_t> sb(2 * h.count), se(2 * h.count);
+            for (int p = 0; p < h.count; ++p) {
+                sb[2 * p] = h.xoff[p]; se[2 * p] = h.xoff[p + 1];
+                sb[2 * p + 1] = h.n_tot + h.roff[p]; se[2 * p + 1] = h.n_tot + h.roff[p + 1];
+            }
+            q_seg_begin.upload(sb); q_seg_end.upload(se);
+        }
         h_newton_n = std::max<size_t>(std::max<size_t>(q_fpart.n, q_gd.n), std::max<size_t>((size_t)n_prec, 8)) + 8;
         HIP_CHECK(hipHostMalloc((void**)&h_newton, h_newton_n * sizeof(double)));
     }
@@ -783,8 +796,10 @@ struct HipBackend {
     // loop only writes scratch vectors until its final hand-over -- and ADMM simply continues.
     bool polish_available() const { return Q.available; }
 
-    bool polish(const HostSystem& h, const score_settings& s_, int* newton_iters, int* cg_used) {
+    bool polish(const HostSystem& h, const score_settings& s_, const std::vector<int>& done_host, int* newton_iters,
+                int* cg_used) {
         try {
+            if (h.count > 1) return polish_batch_impl(h, s_, done_host, newton_iters, cg_used);
             return polish_impl(h, s_, newton_iters, cg_used);
         } catch (const std::exception& e) {
             if (st.verbose) std::fprintf(stderr, "[score] polish abandoned: %s\n", e.what());
@@ -792,6 +807,244 @@ struct HipBackend {
             (void)hipGetLastError();
             return false;
         }
+    }
+
+    // ---- lock-step polish of a batch: every live problem takes its Newton step through the same
+    //      launches; per-problem F, |g|, step length and state live on the host, the kernels read
+    //      per-problem step lengths and skip flags from device arrays ----
+    BatchTables batch_tables() const {
+        BatchTables bt{};
+        bt.cone_block_first = cone_block_first.d; bt.cone_block_prob = cone_block_prob.d;
+        bt.row_first = Hm.first_row.d; bt.row_prob = Hm.blk_prob.d;
+        bt.skip = q_skip.d; bt.step = q_step.d;
+        return bt;
+    }
+    void upload_skip(const std::vector<char>& live) {  // skip = !live
+        std::vector<int32_t> v(live.size());
+        for (size_t i = 0; i < live.size(); ++i) v[i] = live[i] ? 0 : 1;
+        HIP_CHECK(hipMemcpyAsync(q_skip.d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
+    // F and |grad|_inf of the problems not skipped, at the point stored in Xbuf
+    void newton_eval_batch(double* Xbuf, const std::vector<char>& which, std::vector<double>& F, std::vector<double>& gn) {
+        const HostSystem& h = *H;
+        PolishArgs pa = polish_args(Xbuf);
+        hipLaunchKernelGGL(k_newton_cone_b, dim3(n_cone_blocks), dim3(kThreads), 0, stream, pa, batch_tables());
+        SpmvArgs ga = spmv_args(G2, Xbuf);
+        ga.is_head = q_ishead.d; ga.gout = q_g.d; ga.done = q_skip.d;
+        hipLaunchKernelGGL(k_spmv<MODE_GRAD>, dim3(G2.nblocks), dim3(kThreads), 0, stream, ga);
+        HIP_CHECK(hipMemcpyAsync(h_newton, q_fpart.d, n_cone_blocks * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(h_dres, dres_part.d, dres_part.n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipGetLastError());
+        for (int p = 0; p < h.count; ++p) {
+            if (!which[p]) continue;
+            double f = 0.0, gmax = 0.0;
+            for (int b = h.cone_part_ptr[p]; b < h.cone_part_ptr[p + 1]; ++b) f += h_newton[b];
+            for (int bl = h.rbG2.part_ptr[p]; bl < h.rbG2.part_ptr[p + 1]; ++bl) {
+                const double* o = h_dres + (size_t)bl * kPartStride;
+                gmax = (o[0] != o[0]) ? o[0] : std::max(gmax, o[0]);
+                f += o[2];
+            }
+            F[p] = f;
+            gn[p] = gmax;
+        }
+    }
+    // PCG on H delta = -g for the problems in `live`, each to its own relative tolerance
+    int newton_pcg_batch(const std::vector<char>& live, const std::vector<double>& eta, int max_cg) {
+        const HostSystem& h = *H;
+        q_delta.zero(stream);
+        upload_skip(live);
+        PrecArgs pa{};
+        pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = q_fac.d;
+        pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = q_skip.d;
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d;
+        pa.r = r.d; pa.z = z.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d; pa.pw_part = q_pw.d;
+        double* rz_cur = rz_part0.d;
+        double* p_cur = p.d;
+        double* p_oth = p2.d;
+        pa.p = p_cur; pa.rz_in = nullptr; pa.rz_out = rz_cur;
+        launch_prec<PREC_INIT>(pa);
+        auto launch_hp = [&](const double* pd) {
+            SpmvArgs a = spmv_args(Hm, pd);
+            a.p = pd; a.pw_part = q_pw.d; a.done = q_skip.d;
+            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, a);
+        };
+        auto launch_hpb = [&](const double* p_old, double* p_new, const double* rzn, const double* rzo) {
+            SpmvArgs a = spmv_args(Hm, p_old);
+            a.p = p_old; a.z = z.d; a.p_out = p_new; a.rz_new = rzn; a.rz_old = rzo; a.pw_part = q_pw.d; a.done = q_skip.d;
+            hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, a);
+        };
+        launch_hp(p_cur);
+        std::vector<double> rz(h.count, 0.0), rz0(h.count, 0.0);
+        auto sum_rz = [&](const double* dev, std::vector<double>& out, const std::vector<char>& which) {
+            HIP_CHECK(hipMemcpyAsync(h_newton, dev, n_prec * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            for (int p = 0; p < h.count; ++p) {
+                if (!which[p]) continue;
+                double sacc = 0.0;
+                for (int i = h.prec_part_ptr[p]; i < h.prec_part_ptr[p + 1]; ++i) sacc += h_newton[i];
+                out[p] = sacc;
+            }
+        };
+        std::vector<char> run = live;
+        sum_rz(rz_cur, rz0, run);
+        bool any = false, changed = false;
+        for (int p = 0; p < h.count; ++p) {
+            if (run[p] && !(rz0[p] > 0.0)) { run[p] = 0; changed = true; }
+            any = any || run[p];
+        }
+        if (changed) upload_skip(run);
+        int done_cg = 0;
+        while (any && done_cg < max_cg) {
+            for (int j = 0; j < newton_chunk; ++j) {
+                double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
+                pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_nxt;
+                launch_prec<PREC_STEP>(pa);   // delta += a p ; r -= a w ; z = M^-1 r
+                launch_hpb(p_cur, p_oth, rz_nxt, rz_cur);
+                std::swap(p_cur, p_oth);
+                rz_cur = rz_nxt;
+            }
+            done_cg += newton_chunk;
+            sum_rz(rz_cur, rz, run);
+            any = false; changed = false;
+            for (int p = 0; p < h.count; ++p) {
+                if (!run[p]) continue;
+                if (!(rz[p] == rz[p])) throw std::runtime_error("polish: NaN in PCG");
+                if (std::sqrt(std::max(0.0, rz[p]) / rz0[p]) <= eta[p]) { run[p] = 0; changed = true; }
+                any = any || run[p];
+            }
+            // a frozen problem keeps its rz partials of this read: the ping-pong buffers are only
+            // rewritten by the problems still running
+            if (changed && any) upload_skip(run);
+        }
+        return done_cg;
+    }
+
+    bool polish_batch_impl(const HostSystem& h, const score_settings& s_, const std::vector<int>& done_host,
+                           int* newton_iters, int* cg_used) {
+        *newton_iters = 0; *cg_used = 0;
+        if (!Q.available) return false;
+        HIP_CHECK(hipStreamSynchronize(stream));
+        const int count = h.count, nbh = Hm.nblocks;
+        double* X = q_X0.d;   // current point [u | nu]
+        double* Xt = q_X1.d;  // trial point
+        std::vector<char> part(count), all(count, 1);
+        bool any = false;
+        for (int p = 0; p < count; ++p) { part[p] = done_host[p] ? 0 : 1; any = any || part[p]; }
+        if (!any) return false;
+        NewtonVecArgs va{};
+        va.n = h.n_tot; va.is_head = q_ishead.d; va.g = q_g.d; va.part = q_gd.d;
+        // start from the ADMM iterate x of every problem (head variables eliminated: kept at zero)
+        HIP_CHECK(hipMemsetAsync(q_g.d, 0, q_g.n * sizeof(double), stream));
+        va.u = xy.d; va.delta = xy.d; va.step = 0.0; va.out = X;
+        hipLaunchKernelGGL(k_newton_trial, dim3((unsigned)((h.n_tot + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, va);
+        std::vector<double> F(count, 0.0), gn(count, 0.0), Ft(count, 0.0), gt(count, 0.0), eta(count, 0.0);
+        std::vector<double> step(count, 1.0), gd(count, 0.0);
+        upload_skip(part);
+        newton_eval_batch(X, part, F, gn);
+        const double tol = std::max(1e-12, 0.3 * s_.eps_abs);
+        const int bs = h.bs;
+        std::vector<char> live(count), stalled(count, 0);
+        int it = 0, cg_tot = 0;
+        for (; it < 50; ++it) {
+            any = false;
+            for (int p = 0; p < count; ++p) { live[p] = part[p] && !stalled[p] && gn[p] > tol; any = any || live[p]; }
+            if (!any) break;
+            // Hessians (all problems: the blocks of a frozen problem are simply re-derived), factors
+            HAsmArgs ha{};
+            ha.nnz = (int64_t)Q.Hm.col.size(); ha.Pon = q_Pon.d; ha.cptr = q_cptr.d; ha.ccone = q_ccone.d; ha.cab = q_cab.d;
+            ha.ccoef = q_ccoef.d; ha.Bbuf = q_Bbuf.d; ha.T2 = Q.T * Q.T; ha.Hval = Hm.val.d;
+            ha.ndiag = (int)h.diag_cols.size(); ha.diag_pos = q_diagpos.d; ha.dinv = q_dinv.d;
+            hipLaunchKernelGGL(k_hassemble, dim3((unsigned)((ha.nnz + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, ha);
+            if (n_long) hipLaunchKernelGGL(k_hassemble_long, dim3(n_long), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d);
+            if (ha.ndiag) hipLaunchKernelGGL(k_hdiag, dim3((ha.ndiag + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, ha);
+            if (n_prec && !h.chains.empty()) {
+                FactorArgs fa{};
+                fa.work = prec_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = Hm.val.d;
+                fa.pos_diag = q_posd.d; fa.pos_sub = q_poss.d; fa.fac = q_fac.d; fa.work_mat = q_work.d;
+                if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
+                else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
+                else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
+                else hipLaunchKernelGGL(k_factor<4>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
+            }
+            for (int p = 0; p < count; ++p) eta[p] = std::min(newton_eta_max, std::max(1e-8, std::sqrt(gn[p])));
+            cg_tot += newton_pcg_batch(live, eta, 400);
+            // backtracking per problem; a problem leaves the search when its step is accepted
+            std::vector<char> ls = live, accepted(count, 0);
+            for (int p = 0; p < count; ++p) step[p] = 1.0;
+            for (int k = 0; k < 40; ++k) {
+                upload_skip(ls);
+                HIP_CHECK(hipMemcpyAsync(q_step.d, step.data(), count * sizeof(double), hipMemcpyHostToDevice, stream));
+                va.u = X; va.delta = q_delta.d; va.step = 0.0; va.out = Xt;
+                hipLaunchKernelGGL(k_newton_trial_b, dim3(nbh), dim3(kThreads), 0, stream, va, batch_tables());
+                if (k == 0) {
+                    HIP_CHECK(hipMemcpyAsync(h_newton, q_gd.d, nbh * sizeof(double), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    for (int p = 0; p < count; ++p) {
+                        gd[p] = 0.0;
+                        if (!ls[p]) continue;
+                        for (int b = Q.rbH.part_ptr[p]; b < Q.rbH.part_ptr[p + 1]; ++b) gd[p] += h_newton[b];
+                    }
+                }
+                newton_eval_batch(Xt, ls, Ft, gt);  // overwrites nu / B / g of the problems searched
+                std::vector<int32_t> acc_now(count, 0);
+                bool any_acc = false, any_ls = false;
+                for (int p = 0; p < count; ++p) {
+                    if (!ls[p]) continue;
+                    const bool armijo = Ft[p] <= F[p] + 1e-4 * step[p] * gd[p];
+                    const bool tiny = std::fabs(step[p] * gd[p]) <= 1e-13 * std::max(1.0, std::fabs(F[p]));
+                    if ((Ft[p] == Ft[p]) && (armijo || (tiny && gt[p] < gn[p]))) {
+                        F[p] = Ft[p]; gn[p] = gt[p];
+                        accepted[p] = 1; acc_now[p] = 1; any_acc = true;
+                        ls[p] = 0;
+                    } else {
+                        step[p] *= 0.5;
+                        any_ls = true;
+                    }
+                }
+                if (any_acc) {  // X <- Xt on the segments (unknowns and cone rows) of the accepted problems
+                    HIP_CHECK(hipMemcpyAsync(q_skip.d, acc_now.data(), count * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+                    hipLaunchKernelGGL(k_copy_segments, dim3(64, 2 * count), dim3(kThreads), 0, stream, X, (const double*)Xt,
+                                       (const int64_t*)q_seg_begin.d, (const int64_t*)q_seg_end.d, (const int32_t*)q_skip.d);
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                }
+                if (!any_ls) break;
+            }
+            bool any_stalled = false;
+            for (int p = 0; p < count; ++p)
+                if (live[p] && !accepted[p]) { stalled[p] = 1; any_stalled = true; }
+            if (st.verbose) {
+                for (int p = 0; p < count; ++p)
+                    if (live[p]) std::fprintf(stderr, "[score] newton it %d prob %d F %.12g |g| %.3e step %.3g%s\n", it + 1, p, F[p], gn[p], step[p], stalled[p] ? " (stalled)" : "");
+            }
+            if (any_stalled) {  // re-establish nu / B / g of the current point of the stalled problems
+                std::vector<char> sv(stalled.begin(), stalled.end());
+                for (int p = 0; p < count; ++p) sv[p] = sv[p] && live[p];
+                upload_skip(sv);
+                std::vector<double> fx(count), gx(count);
+                newton_eval_batch(X, sv, fx, gx);
+            }
+        }
+        *newton_iters = it;
+        *cg_used = cg_tot;
+        // hand the polished points to the ADMM state of the problems that took part
+        upload_skip(part);
+        va.u = X; va.delta = X; va.step = 0.0; va.out = Xt;
+        hipLaunchKernelGGL(k_polish_copy_x_b, dim3(nbh), dim3(kThreads), 0, stream, va, xy.d, xtu.d, batch_tables());
+        FinishArgs fa2{};
+        fa2.P = polish_args(X);
+        fa2.x = xy.d; fa2.xt = xtu.d; fa2.s = this->s.d; fa2.y = xy.d + h.n_tot;
+        hipLaunchKernelGGL(k_polish_finish_b, dim3(n_cone_blocks), dim3(kThreads), 0, stream, fa2, batch_tables());
+        if (n_cone_blocks) hipLaunchKernelGGL(k_refresh_u, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xtu.d));
+        {
+            SpmvArgs a = spmv_args(K, xtu.d);
+            a.p = xtu.d; a.w = kx.d; a.done = q_skip.d;
+            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
+        }
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipGetLastError());
+        return true;
     }
 
     bool polish_impl(const HostSystem& h, const score_settings& s_, int* newton_iters, int* cg_used) {

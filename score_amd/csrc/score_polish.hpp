@@ -452,4 +452,120 @@ __global__ __launch_bounds__(kThreads) void k_polish_finish(FinishArgs f) {
     f.y[r0] = sqrt(y2);
 }
 
+// ---------------------------------------------------------------------------
+// lock-step variants for a batch of problems (one Newton iteration advances every live problem
+// through the same launches): grids follow the per-problem partitions of the ADMM kernels (cone
+// blocks, row blocks of H), per-problem scalars come from device arrays, and `skip[prob] != 0`
+// freezes a problem (converged, line search finished, PCG converged).
+// ---------------------------------------------------------------------------
+struct BatchTables {
+    const int32_t* cone_block_first;  // per cone block (+1)
+    const int32_t* cone_block_prob;
+    const int32_t* row_first;         // row blocks of H (+1)
+    const int32_t* row_prob;
+    const int32_t* skip;              // per problem
+    const double* step;               // per problem
+};
+
+__global__ __launch_bounds__(kThreads) void k_newton_cone_b(PolishArgs a, BatchTables bt) {
+    __shared__ double red[8];
+    const int b = blockIdx.x;
+    if (bt.skip[bt.cone_block_prob[b]]) return;
+    const int k = bt.cone_block_first[b] + threadIdx.x;
+    double phi = 0.0;
+    if (k < bt.cone_block_first[b + 1]) {
+        const int T = a.T;
+        const int r0 = a.cone_row[k];
+        double t[kPolishMaxTail];
+        double rho2 = 0.0;
+        for (int c = 0; c < T; ++c) {
+            const int r = r0 + 1 + c;
+            double acc = a.b[r];
+            for (int e = a.A_ptr[r]; e < a.A_ptr[r + 1]; ++e) acc -= a.A_val[e] * a.u[a.A_col[e]];
+            t[c] = acc;
+            rho2 += acc * acc;
+        }
+        const double rho = sqrt(rho2);
+        const double th = a.theta[k], ck = a.ck[k];
+        const double ex = rho > th ? rho - th : 0.0;
+        phi = 0.5 * ck * ex * ex;
+        const bool act = ex > 0.0 && rho > 0.0;
+        const double ir = act ? 1.0 / rho : 0.0;
+        a.nu[r0] = 0.0;
+        for (int c = 0; c < T; ++c) a.nu[r0 + 1 + c] = act ? -ck * ex * t[c] * ir : 0.0;
+        const double w1 = act ? ck * (1.0 - th * ir) : 0.0;
+        const double w2 = act ? ck * th * ir : 0.0;
+        for (int c = 0; c < T; ++c)
+            for (int d = 0; d < T; ++d)
+                a.Bbuf[(size_t)k * T * T + c * T + d] = (c == d ? w1 : 0.0) + w2 * (t[c] * ir) * (t[d] * ir);
+    }
+    const double tot = block_sum(phi, red);
+    if (threadIdx.x == 0) a.fpart[b] = tot;
+}
+
+// out = u + step[prob] * delta on the rows of the live problems; partial g'delta per row block
+__global__ __launch_bounds__(kThreads) void k_newton_trial_b(NewtonVecArgs a, BatchTables bt) {
+    __shared__ double red[8];
+    const int b = blockIdx.x;
+    const int prob = bt.row_prob[b];
+    if (bt.skip[prob]) return;
+    const double step = bt.step[prob];
+    const int64_t i = (int64_t)bt.row_first[b] + threadIdx.x;
+    double gd = 0.0;
+    if (i < bt.row_first[b + 1]) {
+        const bool head = a.is_head[i] != 0;
+        const double d = head ? 0.0 : a.delta[i];
+        a.out[i] = head ? 0.0 : a.u[i] + step * d;
+        gd = a.g[i] * d;
+    }
+    const double tot = block_sum(gd, red);
+    if (threadIdx.x == 0) a.part[b] = tot;
+}
+
+// dst[seg] = src[seg] for every flagged problem: segments 2 p (unknowns) and 2 p + 1 (cone rows,
+// shifted by n_tot) of the [u | nu] buffers
+__global__ __launch_bounds__(kThreads) void k_copy_segments(double* dst, const double* src, const int64_t* seg_begin,
+                                                            const int64_t* seg_end, const int32_t* flag) {
+    const int sgm = blockIdx.y;
+    if (!flag[sgm >> 1]) return;
+    const int64_t e = seg_end[sgm];
+    for (int64_t i = seg_begin[sgm] + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < e; i += (int64_t)gridDim.x * kThreads)
+        dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(kThreads) void k_polish_copy_x_b(NewtonVecArgs a, double* x, double* xt, BatchTables bt) {
+    const int b = blockIdx.x;
+    if (bt.skip[bt.row_prob[b]]) return;
+    const int64_t i = (int64_t)bt.row_first[b] + threadIdx.x;
+    if (i < bt.row_first[b + 1] && !a.is_head[i]) { x[i] = a.u[i]; xt[i] = a.u[i]; }
+}
+
+__global__ __launch_bounds__(kThreads) void k_polish_finish_b(FinishArgs f, BatchTables bt) {
+    const PolishArgs& a = f.P;
+    const int b = blockIdx.x;
+    if (bt.skip[bt.cone_block_prob[b]]) return;
+    const int k = bt.cone_block_first[b] + threadIdx.x;
+    if (k >= bt.cone_block_first[b + 1]) return;
+    const int T = a.T;
+    const int r0 = a.cone_row[k];
+    double rho2 = 0.0, y2 = 0.0;
+    for (int c = 0; c < T; ++c) {
+        const int r = r0 + 1 + c;
+        double acc = a.b[r];
+        for (int e = a.A_ptr[r]; e < a.A_ptr[r + 1]; ++e) acc -= a.A_val[e] * a.u[a.A_col[e]];
+        f.s[r] = acc;
+        rho2 += acc * acc;
+        const double yv = a.nu[r];
+        f.y[r] = yv;
+        y2 += yv * yv;
+    }
+    const double rho = sqrt(rho2);
+    const double xh = fmax(a.xstar[k], rho / a.a_abs[k]);
+    const int h = a.head_col[k];
+    f.x[h] = xh;
+    f.xt[h] = xh;
+    f.s[r0] = a.a_abs[k] * xh;
+    f.y[r0] = sqrt(y2);
+}
+
 }  // namespace score

@@ -77,10 +77,10 @@ def test_qcqp_direct_on_gpu(fixtures, hip_lib):
 
 def test_deterministic_and_batch(hip_lib):
     graphs = [make_manhattan(n_robots=3, n_poses=40 + 10 * (s % 4), n_beacons=4, seed=s, p_range=0.4) for s in (300, 303, 305, 307)]
-    b1 = solve_score_batch(graphs, "SOCP", lockstep=True)
-    b2 = solve_score_batch(graphs, "SOCP", lockstep=True)
+    b1 = solve_score_batch(graphs, "SOCP", lockstep=True, solver_settings=dict(polish=0))
+    b2 = solve_score_batch(graphs, "SOCP", lockstep=True, solver_settings=dict(polish=0))
     for g, r1, r2 in zip(graphs, b1, b2):
-        ri = solve_score(g, "SOCP", solver_settings=dict(polish=0))  # batches run without the polish
+        ri = solve_score(g, "SOCP", solver_settings=dict(polish=0))  # ADMM alone: lock-step == one by one
         assert r1.solved and ri.solved and r1.info["iters"] == ri.info["iters"]
         for nm in ri.poses:
             assert np.array_equal(r1.poses[nm], r2.poses[nm])  # bitwise reproducible
@@ -209,12 +209,14 @@ def test_newton_polish_on_degenerate_and_unsupported_cases(hip_lib):
     assert res.solved and res.info["newton_iters"] > 0, res.info
     rp, u, info = so.newton_solve(fg, tol=1e-13)
     assert res.info["pobj"] == pytest.approx(info["objective"], rel=1e-7, abs=1e-9)
-    # batches and cone programs without the private-head structure simply skip the polish
+    # batches are polished in lock-step or one after another; cone programs without the
+    # private-head structure (the direct QCQP form) simply skip the polish
     graphs = [make_manhattan(n_robots=3, n_poses=40 + 10 * (s % 4), n_beacons=4, seed=s, p_range=0.4) for s in (300, 303)]
-    for r in solve_score_batch(graphs, "SOCP", lockstep=True):
-        assert r.solved and r.info["newton_iters"] == 0
-    for r in solve_score_batch(graphs, "SOCP"):  # default: one after another, polished
-        assert r.solved and r.info["newton_iters"] > 0
+    lock = solve_score_batch(graphs, "SOCP", lockstep=True)
+    pool = solve_score_batch(graphs, "SOCP", lockstep=False)
+    for a, b in zip(lock, pool):
+        assert a.solved and b.solved and a.info["newton_iters"] > 0 and b.info["newton_iters"] > 0
+        assert a.info["pobj"] == pytest.approx(b.info["pobj"], rel=1e-8, abs=1e-9)
     rd = solve_score(graphs[0], "QCQP", qcqp_mode="direct")
     assert rd.solved and rd.info["newton_iters"] == 0
 
@@ -324,3 +326,28 @@ def test_live_handles_of_different_sizes(hip_lib):
             assert out.solved and out.info["pobj"] == r.info["pobj"]
     for s in sols:
         s.close()
+
+
+def test_lockstep_batch_polish_matches_individual_solves(hip_lib):
+    """A batch handle advances all its problems through the same launches, ADMM warm-up and Newton
+    polish alike (per-problem step lengths, line searches and PCG tolerances): every problem must
+    end where its own single-problem solve ends, whatever its neighbours in the batch need."""
+    specs = [(2, 150, 3, 1), (1, 400, 2, 2), (3, 80, 3, 3), (4, 1000, 4, 4), (2, 37, 0, 5), (1, 12, 1, 6), (1, 30, 0, 7),
+             (3, 300, 2, 8)]
+    qps = [assemble(make_manhattan(n_robots=r, n_poses=n, n_beacons=b, seed=s), "SOCP").qp for r, n, b, s in specs]
+    single = []
+    for qp in qps:
+        sol = ConicSolver(qp, {})
+        single.append(sol.solve()[0])
+        sol.close()
+    sol = ConicSolver(qps, {})
+    batch = sol.solve()
+    again = sol.solve()
+    sol.close()
+    assert any(o.info["newton_iters"] > 0 for o in batch)
+    for qp, a, b, c in zip(qps, single, batch, again):
+        assert a.solved and b.solved, (a.info, b.info)
+        assert b.info["pobj"] == pytest.approx(a.info["pobj"], rel=1e-7, abs=1e-8)
+        cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, b.x, b.y, b.s)
+        assert cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4, cert
+        np.testing.assert_array_equal(b.x, c.x)  # deterministic
