@@ -18,6 +18,7 @@
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
+#include <mutex>
 #endif
 
 #include "../../score_amd/csrc/score_driver.hpp"
@@ -298,6 +299,16 @@ void score_default_settings(score_settings* s) { score::default_settings(s); }
 
 int score_create_batch(const score_problem* p, int32_t count, const score_settings* s, score_handle** out) {
     try {
+#ifdef _OPENMP
+        // Default team of the twin: at most 16 threads.  Its loops are short (a test problem has a
+        // few hundred rows); on a 256-thread host the default team makes every parallel region
+        // cost milliseconds.  Set once: a caller that sizes the team itself (bench.py's cpu_baseline
+        // calibrates it with omp_set_num_threads) is not overridden afterwards.
+        static std::once_flag team_once;
+        std::call_once(team_once, [] {
+            if (omp_get_max_threads() > 16) omp_set_num_threads(16);
+        });
+#endif
         score_settings st;
         if (s) st = *s; else score::default_settings(&st);
         auto* h = new score_handle();
