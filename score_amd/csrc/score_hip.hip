@@ -188,6 +188,9 @@ struct HipBackend {
     DevBuf<int32_t> q_skip;
     DevBuf<double> q_step;
     DevBuf<int64_t> q_seg_begin, q_seg_end;
+    static constexpr int kFlagSlots = 16;
+    int32_t* h_flags = nullptr;  // pinned
+    int flag_slot = 0;
     double newton_eta_max = 1e-1;  // inexact Newton: linear residual <= min(eta_max, sqrt|g|)
     int newton_chunk = 4;         // PCG iterations between two convergence reads
     double* h_newton = nullptr;  // pinned scratch for partial sums
@@ -211,6 +214,7 @@ struct HipBackend {
         if (h_pres) (void)hipHostFree(h_pres);
         if (h_dres) (void)hipHostFree(h_dres);
         if (h_newton) (void)hipHostFree(h_newton);
+        if (h_flags) (void)hipHostFree(h_flags);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -819,11 +823,23 @@ struct HipBackend {
         bt.skip = q_skip.d; bt.step = q_step.d;
         return bt;
     }
-    void upload_skip(const std::vector<char>& live) {  // skip = !live
-        std::vector<int32_t> v(live.size());
-        for (size_t i = 0; i < live.size(); ++i) v[i] = live[i] ? 0 : 1;
-        HIP_CHECK(hipMemcpyAsync(q_skip.d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+    // skip = !live.  Stream-ordered, no host synchronisation: the flags go through a small ring of
+    // pinned slots (every evaluation of F synchronises the stream, long before the ring wraps).
+    int32_t* next_flag_slot(size_t c) {
+        if (!h_flags) HIP_CHECK(hipHostMalloc((void**)&h_flags, kFlagSlots * c * sizeof(int32_t)));
+        flag_slot = (flag_slot + 1) % kFlagSlots;
+        return h_flags + (size_t)flag_slot * c;
+    }
+    void upload_skip(const std::vector<char>& live) {
+        const size_t c = live.size();
+        int32_t* v = next_flag_slot(c);
+        for (size_t i = 0; i < c; ++i) v[i] = live[i] ? 0 : 1;
+        HIP_CHECK(hipMemcpyAsync(q_skip.d, v, c * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    }
+    void upload_flags(const std::vector<int32_t>& f) {  // nonzero = selected
+        int32_t* v = next_flag_slot(f.size());
+        std::copy(f.begin(), f.end(), v);
+        HIP_CHECK(hipMemcpyAsync(q_skip.d, v, f.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     }
     // F and |grad|_inf of the problems not skipped, at the point stored in Xbuf
     void newton_eval_batch(double* Xbuf, const std::vector<char>& which, std::vector<double>& F, std::vector<double>& gn) {
@@ -1004,10 +1020,9 @@ struct HipBackend {
                     }
                 }
                 if (any_acc) {  // X <- Xt on the segments (unknowns and cone rows) of the accepted problems
-                    HIP_CHECK(hipMemcpyAsync(q_skip.d, acc_now.data(), count * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+                    upload_flags(acc_now);
                     hipLaunchKernelGGL(k_copy_segments, dim3(64, 2 * count), dim3(kThreads), 0, stream, X, (const double*)Xt,
                                        (const int64_t*)q_seg_begin.d, (const int64_t*)q_seg_end.d, (const int32_t*)q_skip.d);
-                    HIP_CHECK(hipStreamSynchronize(stream));
                 }
                 if (!any_ls) break;
             }
