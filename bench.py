@@ -135,6 +135,37 @@ def cpu_baseline(args, models):
     }
 
 
+def montecarlo_summary(eps: float, device: int, trials: int = 64, per_handle: int = 16, threads: int = 4, sweeps: int = 3):
+    """BASELINE config 5 on this GPU, as an extra figure of the default single-GPU run: `trials`
+    four-robot Monte-Carlo problems in lock-step handles of `per_handle`, full solver."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import torch
+
+    from score_amd.assemble import assemble
+    from score_amd.manhattan import make_manhattan
+    from score_amd.solver import ConicSolver
+
+    qps = [assemble(make_manhattan(n_robots=4, n_poses=1000, n_beacons=4, seed=4000 + t), "SOCP").qp for t in range(trials)]
+    solvers = [ConicSolver(qps[i : i + per_handle], dict(eps_abs=eps, eps_rel=eps, device=device))
+               for i in range(0, trials, per_handle)]
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        def sweep():
+            return [r for rs in pool.map(lambda s: s.solve(), solvers) for r in rs]
+        sweep()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(sweeps):
+            last = sweep()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    for s in solvers:
+        s.close()
+    return {"problems_per_sec": trials * sweeps / dt, "trials": trials, "trials_per_handle": per_handle,
+            "host_threads": threads, "solved_last_sweep": int(sum(1 for r in last if r.solved)),
+            "workload": "4 robots x 1000 poses, 4 beacons, SOCP, full solver (ADMM warm-up + Newton polish in lock-step)"}
+
+
 def montecarlo(args, rank, world, local_rank):
     """Config 5: independent Monte-Carlo trials, trial i on rank i % world; a rank's trials are
     grouped into lock-step handles of --mc-batch trials (own stream each); the timed region solves
@@ -381,6 +412,8 @@ def main():
         rec["roofline_iteration"] = {"bytes": it_bytes, "us": it_us, "GB/s": it_bytes / (it_us * 1e-6) / 1e9,
                                      "frac": it_bytes / (it_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                      "note": "six kernels of one ADMM iteration (2 PCG iterations), time in the launch graph incl. convergence checks"}
+        if world == 1 and not args.no_cpu_baseline and args.batch == 1:
+            rec["montecarlo_64_trials_this_gpu"] = montecarlo_summary(args.eps, local_rank)
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline(args, models)
             rec["speedup_vs_cpu_baseline"] = rec["value"] / rec["cpu_baseline"]["value"]
