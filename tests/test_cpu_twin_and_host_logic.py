@@ -74,6 +74,22 @@ def test_batch_equals_individual(twin_lib):
             np.testing.assert_allclose(rb.poses[nm], ri.poses[nm], atol=1e-9)
 
 
+def test_batch_grouping_keeps_order_and_results(twin_lib):
+    """solve_score_batch's default policy splits the graphs into lock-step groups (one handle per
+    group, groups driven from a thread pool): results come back in input order and equal the
+    one-by-one solves, whatever the grouping."""
+    graphs = [make_manhattan(n_robots=2, n_poses=20 + 3 * i, n_beacons=4, seed=800 + i, p_range=0.8) for i in range(5)]
+    ref = [solve_score(g, "SOCP", lib_path=twin_lib) for g in graphs]
+    for kw in (dict(workers=2), dict(lockstep=False, workers=3)):
+        out = solve_score_batch(graphs, "SOCP", lib_path=twin_lib, **kw)
+        assert len(out) == len(graphs)
+        for g, a, b in zip(graphs, out, ref):
+            assert a.solved and a.pose_chain_names == g.get_pose_chain_names()
+            assert a.info["pobj"] == pytest.approx(b.info["pobj"], rel=1e-6, abs=1e-8)
+            last = g.pose_variables[0][-1].name
+            np.testing.assert_allclose(a.poses[last], b.poses[last], atol=1e-6)
+
+
 def test_intermediate_iterates(twin_lib):
     fg = make_manhattan(n_robots=2, n_poses=40, n_beacons=2, seed=4)
     its = solve_problem_with_intermediate_iterates(fg, "SOCP", every=25, lib_path=twin_lib)
