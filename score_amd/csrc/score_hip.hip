@@ -813,6 +813,29 @@ struct HipBackend {
         }
     }
 
+    // Generalised Hessian from the cone blocks of the last evaluation (q_Bbuf), the Jacobi diagonal
+    // and the chain factors of the Newton preconditioner (device-side factorisation)
+    void newton_hessian() {
+        const HostSystem& h = *H;
+        const int bs = h.bs;
+        HAsmArgs ha{};
+        ha.nnz = (int64_t)Q.Hm.col.size(); ha.Pon = q_Pon.d; ha.cptr = q_cptr.d; ha.ccone = q_ccone.d; ha.cab = q_cab.d;
+        ha.ccoef = q_ccoef.d; ha.Bbuf = q_Bbuf.d; ha.T2 = Q.T * Q.T; ha.Hval = Hm.val.d;
+        ha.ndiag = (int)h.diag_cols.size(); ha.diag_pos = q_diagpos.d; ha.dinv = q_dinv.d;
+        hipLaunchKernelGGL(k_hassemble, dim3((unsigned)((ha.nnz + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, ha);
+        if (n_long) hipLaunchKernelGGL(k_hassemble_long, dim3(n_long), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d);
+        if (ha.ndiag) hipLaunchKernelGGL(k_hdiag, dim3((ha.ndiag + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, ha);
+        if (n_prec && !h.chains.empty()) {
+            FactorArgs fa{};
+            fa.work = prec_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = Hm.val.d;
+            fa.pos_diag = q_posd.d; fa.pos_sub = q_poss.d; fa.fac = q_fac.d; fa.work_mat = q_work.d;
+            if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
+            else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
+            else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
+            else hipLaunchKernelGGL(k_factor<4>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
+        }
+    }
+
     // ---- lock-step polish of a batch: every live problem takes its Newton step through the same
     //      launches; per-problem F, |g|, step length and state live on the host, the kernels read
     //      per-problem step lengths and skip flags from device arrays ----
@@ -960,30 +983,13 @@ struct HipBackend {
         upload_skip(part);
         newton_eval_batch(X, part, F, gn);
         const double tol = std::max(1e-12, 0.3 * s_.eps_abs);
-        const int bs = h.bs;
         std::vector<char> live(count), stalled(count, 0);
         int it = 0, cg_tot = 0;
         for (; it < 50; ++it) {
             any = false;
             for (int p = 0; p < count; ++p) { live[p] = part[p] && !stalled[p] && gn[p] > tol; any = any || live[p]; }
             if (!any) break;
-            // Hessians (all problems: the blocks of a frozen problem are simply re-derived), factors
-            HAsmArgs ha{};
-            ha.nnz = (int64_t)Q.Hm.col.size(); ha.Pon = q_Pon.d; ha.cptr = q_cptr.d; ha.ccone = q_ccone.d; ha.cab = q_cab.d;
-            ha.ccoef = q_ccoef.d; ha.Bbuf = q_Bbuf.d; ha.T2 = Q.T * Q.T; ha.Hval = Hm.val.d;
-            ha.ndiag = (int)h.diag_cols.size(); ha.diag_pos = q_diagpos.d; ha.dinv = q_dinv.d;
-            hipLaunchKernelGGL(k_hassemble, dim3((unsigned)((ha.nnz + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, ha);
-            if (n_long) hipLaunchKernelGGL(k_hassemble_long, dim3(n_long), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d);
-            if (ha.ndiag) hipLaunchKernelGGL(k_hdiag, dim3((ha.ndiag + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, ha);
-            if (n_prec && !h.chains.empty()) {
-                FactorArgs fa{};
-                fa.work = prec_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = Hm.val.d;
-                fa.pos_diag = q_posd.d; fa.pos_sub = q_poss.d; fa.fac = q_fac.d; fa.work_mat = q_work.d;
-                if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
-                else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
-                else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
-                else hipLaunchKernelGGL(k_factor<4>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
-            }
+            newton_hessian();  // all problems: the blocks of a frozen problem are simply re-derived
             for (int p = 0; p < count; ++p) eta[p] = std::min(newton_eta_max, std::max(1e-8, std::sqrt(gn[p])));
             cg_tot += newton_pcg_batch(live, eta, 400);
             // backtracking per problem; a problem leaves the search when its step is accepted
@@ -1078,27 +1084,10 @@ struct HipBackend {
         double F = 0, gn = 0;
         newton_eval(X, &F, &gn);
         const double tol = std::max(1e-12, 0.3 * s_.eps_abs);
-        const int bs = h.bs;
         int it = 0, cg_tot = 0, last_cg = 0;
         bool ok = true;
         for (; it < 50 && gn > tol; ++it) {
-            // Hessian at X, its Jacobi diagonal and chain factors
-            HAsmArgs ha{};
-            ha.nnz = (int64_t)Q.Hm.col.size(); ha.Pon = q_Pon.d; ha.cptr = q_cptr.d; ha.ccone = q_ccone.d; ha.cab = q_cab.d;
-            ha.ccoef = q_ccoef.d; ha.Bbuf = q_Bbuf.d; ha.T2 = Q.T * Q.T; ha.Hval = Hm.val.d;
-            ha.ndiag = (int)h.diag_cols.size(); ha.diag_pos = q_diagpos.d; ha.dinv = q_dinv.d;
-            hipLaunchKernelGGL(k_hassemble, dim3((unsigned)((ha.nnz + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, ha);
-            if (n_long) hipLaunchKernelGGL(k_hassemble_long, dim3(n_long), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d);
-            if (ha.ndiag) hipLaunchKernelGGL(k_hdiag, dim3((ha.ndiag + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, ha);
-            if (n_prec && !h.chains.empty()) {
-                FactorArgs fa{};
-                fa.work = prec_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = Hm.val.d;
-                fa.pos_diag = q_posd.d; fa.pos_sub = q_poss.d; fa.fac = q_fac.d; fa.work_mat = q_work.d;
-                if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
-                else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
-                else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
-                else hipLaunchKernelGGL(k_factor<4>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
-            }
+            newton_hessian();  // Hessian at X, its Jacobi diagonal and chain factors
             // inexact Newton: the linear residual only has to shrink superlinearly with |g|
             const double eta = std::min(newton_eta_max, std::max(1e-8, std::sqrt(gn)));
             // the previous Newton step's PCG count predicts this one's: fewer convergence reads
