@@ -968,7 +968,7 @@ struct HipBackend {
         const int count = h.count, nbh = Hm.nblocks;
         double* X = q_X0.d;   // current point [u | nu]
         double* Xt = q_X1.d;  // trial point
-        std::vector<char> part(count), all(count, 1);
+        std::vector<char> part(count);
         bool any = false;
         for (int p = 0; p < count; ++p) { part[p] = done_host[p] ? 0 : 1; any = any || part[p]; }
         if (!any) return false;
