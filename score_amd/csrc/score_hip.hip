@@ -815,7 +815,7 @@ struct HipBackend {
 
     // Generalised Hessian from the cone blocks of the last evaluation (q_Bbuf), the Jacobi diagonal
     // and the chain factors of the Newton preconditioner (device-side factorisation)
-    void newton_hessian() {
+    void newton_hessian(const int32_t* skip = nullptr) {
         const HostSystem& h = *H;
         const int bs = h.bs;
         HAsmArgs ha{};
@@ -828,7 +828,7 @@ struct HipBackend {
         if (n_prec && !h.chains.empty()) {
             FactorArgs fa{};
             fa.work = prec_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = Hm.val.d;
-            fa.pos_diag = q_posd.d; fa.pos_sub = q_poss.d; fa.fac = q_fac.d; fa.work_mat = q_work.d;
+            fa.pos_diag = q_posd.d; fa.pos_sub = q_poss.d; fa.fac = q_fac.d; fa.work_mat = q_work.d; fa.skip = skip;
             if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
             else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
             else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
@@ -989,7 +989,8 @@ struct HipBackend {
             any = false;
             for (int p = 0; p < count; ++p) { live[p] = part[p] && !stalled[p] && gn[p] > tol; any = any || live[p]; }
             if (!any) break;
-            newton_hessian();  // all problems: the blocks of a frozen problem are simply re-derived
+            upload_skip(live);
+            newton_hessian(q_skip.d);  // (the matrix entries of a frozen problem are simply re-derived)
             for (int p = 0; p < count; ++p) eta[p] = std::min(newton_eta_max, std::max(1e-8, std::sqrt(gn[p])));
             cg_tot += newton_pcg_batch(live, eta, 400);
             // backtracking per problem; a problem leaves the search when its step is accepted

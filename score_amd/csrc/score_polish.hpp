@@ -188,6 +188,7 @@ struct FactorArgs {
     const int32_t* pos_sub;
     double* fac;               // output, same layout as the ADMM factor
     double* work_mat;          // level >= 1 matrices: 2*bs*bs doubles per scratch node
+    const int32_t* skip;       // optional, per problem: chains of a frozen problem keep their factors
 };
 
 template <int BS>
@@ -196,6 +197,7 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
     using SM = SmallMat<BS>;
     const PrecWork wk = a.work[blockIdx.x];
     if (wk.kind != 0) return;
+    if (a.skip && a.skip[wk.prob]) return;
     const ChainDesc ch = a.chains[wk.index];
     const ChainLevelDesc* lv = a.levels + ch.level_begin;
     const int t = threadIdx.x;
