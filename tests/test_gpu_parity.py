@@ -1,6 +1,8 @@
 """GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the
 C ABI of include/score_hip.h into the HIP library; the oracle (CPU twin, Newton
 solve, golden fixtures, KKT certificate) is only the checker."""
+import os
+
 import numpy as np
 import pytest
 
@@ -351,3 +353,22 @@ def test_lockstep_batch_polish_matches_individual_solves(hip_lib):
         cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, b.x, b.y, b.s)
         assert cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4, cert
         np.testing.assert_array_equal(b.x, c.x)  # deterministic
+
+
+def test_bench_montecarlo_mode_reports_a_contract_line(hip_lib):
+    """bench.py --montecarlo (BASELINE config 5): lock-step groups, one JSON line with the contract keys."""
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--montecarlo", "4", "--mc-batch", "2", "--mc-threads", "2",
+         "--steps", "1", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config"):
+        assert key in rec
+    assert rec["metric"] == "problems_per_sec" and rec["value"] > 0 and rec["problems_solved_last_sweep"] == 4
