@@ -154,14 +154,19 @@ int  score_solve_steps(score_handle* h, int32_t iters, double* x, double* y, dou
 int  score_time_kkt_apply(score_handle* h, int32_t reps, double* ms_per_apply,
                           double* bytes_per_apply);
 
-/* Time the six kernels of the ADMM iteration IN THE LOOP: resets the iterates, runs `warmup` +
- * `iters` iterations (2 PCG iterations each: rhs, prec_init, kp, prec_step, kpb, cone) on the
- * handle's stream and returns each kernel's average duration in microseconds in us[0..5] (same
- * order).  The duration is taken on the device -- first workgroup in to last workgroup out, on
- * the constant-rate wall clock -- i.e. what a profiler's kernel trace reports; no command is
- * inserted between two kernels.  Unlike back-to-back launches of one kernel, every kernel finds
- * the caches as the loop leaves them.  Requires cg_iters == 2; leaves the iterates advanced.   */
-int  score_time_iteration(score_handle* h, int32_t warmup, int32_t iters, double* us);
+/* Time the six kernels of the ADMM iteration IN THE LOOP: resets the solver (iterates, penalties,
+ * PCG count), runs `warmup` + `iters` iterations (2 PCG iterations each: rhs, prec_init, kp,
+ * prec_step, kpb, cone) on the handle's stream and returns each kernel's average duration in
+ * microseconds (same order):
+ *   us[0..5]   on the device -- first workgroup in to last workgroup out, constant-rate wall clock;
+ *              no command is inserted between two kernels;
+ *   us[6..11]  (with_events != 0; a second pass over further iterations) begin to end of each
+ *              DISPATCH as the runtime records it: start/stop HIP events bound to the launch itself
+ *              (hipExtLaunchKernel) on the handle's stream -- the interval a profiler's kernel trace
+ *              (rocprofv3 --kernel-trace) reports for the same launches; zeros otherwise.
+ * Unlike back-to-back launches of one kernel, every kernel finds the caches as the loop leaves
+ * them.  Requires settings.cg_iters == 2; leaves the iterates advanced.  `us` holds 12 doubles.  */
+int  score_time_iteration(score_handle* h, int32_t warmup, int32_t iters, double* us, int32_t with_events);
 
 /* Debug: average milliseconds of `reps` back-to-back launches of one kernel of the
  * iteration ("rhs", "prec_init", "prec_step", "kp", "kpb", "xupdate", "cone"),

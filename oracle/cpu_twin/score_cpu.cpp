@@ -351,8 +351,8 @@ int score_time_kkt_apply(score_handle* h, int32_t reps, double* ms, double* byte
     try { h->solver.be.time_kkt(reps, ms, bytes); return 0; }
     catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
-int score_time_iteration(score_handle*, int32_t, int32_t, double* us) {
-    if (us) for (int k = 0; k < 6; ++k) us[k] = 0.0;  // the twin has no kernels to time
+int score_time_iteration(score_handle*, int32_t, int32_t, double* us, int32_t) {
+    if (us) for (int k = 0; k < 12; ++k) us[k] = 0.0;  // the twin has no kernels to time
     return 0;
 }
 int score_debug_time(score_handle*, const char*, int32_t, double* ms) {

@@ -90,6 +90,7 @@ struct Solver {
             if (done[p]) continue;
             const ResidualSums& r = R[p];
             score_info& I = infos[p];
+            I.status = SCORE_STATUS_UNSOLVED;  // re-evaluated below (steps() un-latches a problem that had passed)
             I.iters = iters_done;
             I.cg_iters = (int32_t)std::min<int64_t>(cg_total, 2147483647);
             I.rho = H.rho[p];

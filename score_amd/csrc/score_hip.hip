@@ -16,6 +16,7 @@
 //
 // Kernels and their design notes: score_kernels.hpp.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdio>
 #include <cstring>
@@ -38,6 +39,27 @@ thread_local std::string g_err;
         if (_e != hipSuccess)                                                                    \
             throw std::runtime_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));  \
     } while (0)
+
+// Every entry point that takes a handle runs with the handle's device current and restores the
+// caller's device on exit: a host thread that never called hipSetDevice (a pool worker on a rank
+// with LOCAL_RANK > 0) would otherwise capture / launch / allocate on device 0 while the handle's
+// stream lives on device N.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) {
+            HIP_CHECK(hipSetDevice(dev));
+            switched = true;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 // ---------------------------------------------------------------------------
 // backend
@@ -380,18 +402,31 @@ struct HipBackend {
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 
+    // Launch on the handle's stream.  Inside score_time_iteration (tev != nullptr, slot >= 0) the
+    // launch carries a start/stop event pair: the runtime then reports the dispatch's own begin/end
+    // timestamps (what a profiler's kernel trace shows) without inserting a command between two
+    // kernels of the loop.
+    hipEvent_t* tev = nullptr;
+    template <class Kern, class... Args>
+    void launch_on_stream(Kern kernel, dim3 grid, dim3 block, size_t lds_bytes, int slot, Args... args) {
+        if (tev && slot >= 0)
+            hipExtLaunchKernelGGL(kernel, grid, block, (unsigned)lds_bytes, stream, tev[2 * slot], tev[2 * slot + 1], 0, args...);
+        else
+            hipLaunchKernelGGL(kernel, grid, block, lds_bytes, stream, args...);
+    }
+
     template <int MODE>
-    void launch_prec(const PrecArgs& pa) {
+    void launch_prec(const PrecArgs& pa, int slot = -1) {
         if (n_prec == 0) return;
         const int bs = H->bs;
 #define SCORE_LAUNCH_PREC(BS)                                                                                  \
     do {                                                                                                       \
         if (prec_pre && BS <= 3)                                                                               \
-            hipLaunchKernelGGL((k_prec_pre<(BS <= 3 ? BS : 3), MODE>), dim3(n_prec), dim3(kPrecThreads), prec_lds, stream, pa); \
+            launch_on_stream((k_prec_pre<(BS <= 3 ? BS : 3), MODE>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa); \
         else if (prec_lds0)                                                                                    \
-            hipLaunchKernelGGL((k_prec<BS, 3, MODE, true>), dim3(n_prec), dim3(kPrecThreads), prec_lds, stream, pa); \
+            launch_on_stream((k_prec<BS, 3, MODE, true>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa); \
         else                                                                                                   \
-            hipLaunchKernelGGL((k_prec<BS, 3, MODE, false>), dim3(n_prec), dim3(kPrecThreads), prec_lds, stream, pa); \
+            launch_on_stream((k_prec<BS, 3, MODE, false>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa); \
     } while (0)
         if (bs <= 1) SCORE_LAUNCH_PREC(1);
         else if (bs == 2) SCORE_LAUNCH_PREC(2);
@@ -428,18 +463,18 @@ struct HipBackend {
     }
 
     // w = K p
-    void launch_kp(const double* pdir, unsigned long long* ts = nullptr) {
+    void launch_kp(const double* pdir, unsigned long long* ts = nullptr, int slot = -1) {
         SpmvArgs a = spmv_args(K, pdir);
         a.p = pdir; a.tstamp = ts;
-        hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
+        launch_on_stream(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, slot, a);
     }
     // p_new = z + beta p_old ; w = K p_new
     void launch_kpb(const double* p_old, double* p_new, const double* rz_new, const double* rz_old,
-                    unsigned long long* ts = nullptr) {
+                    unsigned long long* ts = nullptr, int slot = -1) {
         SpmvArgs a = spmv_args(K, p_old);
         a.tstamp = ts;
         a.p = p_old; a.z = z.d; a.p_out = p_new; a.rz_new = rz_new; a.rz_old = rz_old;
-        hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
+        launch_on_stream(k_spmv<MODE_KPB>, dim3(K.nblocks), dim3(kThreads), 0, slot, a);
     }
 
     void set_cg_iters(int k) {
@@ -480,7 +515,7 @@ struct HipBackend {
             ra.tstamp = slot(0);
             ra.apply_update = first ? 0 : 1;
             ra.pfin = last_p;
-            hipLaunchKernelGGL(k_spmv<MODE_RHS>, dim3(G1.nblocks), dim3(kThreads), 0, stream, ra);
+            launch_on_stream(k_spmv<MODE_RHS>, dim3(G1.nblocks), dim3(kThreads), 0, 0, ra);
         }
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = fac.d;
@@ -493,14 +528,14 @@ struct HipBackend {
         double* p_oth = p2.d;
         pa.p = p_cur; pa.rz_in = nullptr; pa.rz_out = rz_cur;
         pa.tstamp = slot(1);
-        launch_prec<PREC_INIT>(pa);
-        launch_kp(p_cur, slot(2));
+        launch_prec<PREC_INIT>(pa, 1);
+        launch_kp(p_cur, slot(2), 2);
         for (int j = 2; j <= cg_iters; ++j) {
             double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
             pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_nxt;
             pa.tstamp = (j == 2) ? slot(3) : nullptr;
-            launch_prec<PREC_STEP>(pa);
-            launch_kpb(p_cur, p_oth, rz_nxt, rz_cur, (j == 2) ? slot(4) : nullptr);
+            launch_prec<PREC_STEP>(pa, (j == 2) ? 3 : -1);
+            launch_kpb(p_cur, p_oth, rz_nxt, rz_cur, (j == 2) ? slot(4) : nullptr, (j == 2) ? 4 : -1);
             std::swap(p_cur, p_oth);
             rz_cur = rz_nxt;
         }
@@ -522,44 +557,67 @@ struct HipBackend {
         }
         ca.tstamp = slot(5);
         if (n_cone_blocks)
-            hipLaunchKernelGGL(k_cone, dim3(n_cone_blocks), dim3(kThreads), 0, stream, ca);
+            launch_on_stream(k_cone, dim3(n_cone_blocks), dim3(kThreads), 0, 5, ca);
     }
 
-    // in-loop duration of the six kernels of an iteration (see score_time_iteration)
-    void time_iteration(int warmup, int iters, double* us) {
+    // in-loop duration of the six kernels of an iteration (see score_time_iteration):
+    //   us[0..5]   device wall clock, first workgroup in -> last workgroup out
+    //   us[6..11]  begin -> end of the dispatch as the runtime records it (start/stop events bound to
+    //              the launch itself: the interval rocprofv3 --kernel-trace reports); 0 when with_events == 0
+    // The two are taken in separate passes over the same iterations (the per-launch events make
+    // the runtime wait for each dispatch's completion signal, which the plain pass does not).
+    void time_iteration(int warmup, int iters, double* us, int with_events) {
         if (cg_iters != 2) throw std::runtime_error("score_time_iteration: needs cg_iters == 2");
         iters = std::max(1, iters);
         const HostSystem& h = *H;
         int khz = 0;
         HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, st.device));
         if (khz <= 0) throw std::runtime_error("score_time_iteration: no wall clock rate");
-        std::vector<int32_t> zero(h.count, 0);
-        reset();
-        HIP_CHECK(hipMemcpyAsync(done.d, zero.data(), zero.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        for (int k = 0; k < 12; ++k) us[k] = 0.0;
         const int maxb = std::max(std::max(G1.nblocks, K.nblocks), std::max(n_prec, n_cone_blocks));
         ts_stride = (size_t)2 * maxb;
         const size_t per_iter = 6 * ts_stride, nslot = per_iter * iters;
-        std::vector<unsigned long long> hts(nslot);
-        for (size_t i = 0; i < nslot; i += 2) { hts[i] = ~0ull; hts[i + 1] = 0ull; }
-        unsigned long long* dts = nullptr;
-        HIP_CHECK(hipMalloc((void**)&dts, nslot * sizeof(unsigned long long)));
-        HIP_CHECK(hipMemcpyAsync(dts, hts.data(), nslot * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+        {
+            std::vector<unsigned long long> hts(nslot);
+            for (size_t i = 0; i < nslot; i += 2) { hts[i] = ~0ull; hts[i + 1] = 0ull; }
+            DevBuf<unsigned long long> dts;  // (tl_arena is null outside init: a plain hipMalloc on the handle's device)
+            dts.alloc(nslot);
+            HIP_CHECK(hipMemcpyAsync(dts.d, hts.data(), nslot * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            for (int i = 0; i < warmup; ++i) enqueue_iteration(false, i == 0);
+            for (int i = 0; i < iters; ++i) enqueue_iteration(false, warmup == 0 && i == 0, dts.d + per_iter * i);
+            HIP_CHECK(hipMemcpyAsync(hts.data(), dts.d, nslot * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(hipGetLastError());
+            for (int i = 0; i < iters; ++i)
+                for (int k = 0; k < 6; ++k) {
+                    const unsigned long long* p = &hts[per_iter * i + ts_stride * k];
+                    unsigned long long t0 = ~0ull, t1 = 0ull;
+                    for (int b = 0; b < maxb; ++b) { t0 = std::min(t0, p[2 * b]); t1 = std::max(t1, p[2 * b + 1]); }
+                    if (t1 > t0) us[k] += (double)(t1 - t0) * 1e3 / (double)khz / iters;
+                }
+        }
+        if (!with_events) return;
+        std::vector<hipEvent_t> evs((size_t)12 * iters, nullptr);
+        struct EvFree {
+            std::vector<hipEvent_t>& v;
+            ~EvFree() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
+        } ev_free{evs};
+        for (auto& e : evs) HIP_CHECK(hipEventCreate(&e));
+        for (int i = 0; i < warmup; ++i) enqueue_iteration(false, false);
+        for (int i = 0; i < iters; ++i) {
+            tev = evs.data() + (size_t)12 * i;
+            enqueue_iteration(false, false);
+        }
+        tev = nullptr;
         HIP_CHECK(hipStreamSynchronize(stream));
-        for (int i = 0; i < warmup; ++i) enqueue_iteration(false, i == 0);
-        for (int i = 0; i < iters; ++i) enqueue_iteration(false, warmup == 0 && i == 0, dts + per_iter * i);
-        hipError_t e1 = hipMemcpyAsync(hts.data(), dts, nslot * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream);
-        hipError_t e2 = hipStreamSynchronize(stream);
-        (void)hipFree(dts);
-        HIP_CHECK(e1);
-        HIP_CHECK(e2);
         HIP_CHECK(hipGetLastError());
-        for (int k = 0; k < 6; ++k) us[k] = 0.0;
         for (int i = 0; i < iters; ++i)
             for (int k = 0; k < 6; ++k) {
-                const unsigned long long* p = &hts[per_iter * i + ts_stride * k];
-                unsigned long long t0 = ~0ull, t1 = 0ull;
-                for (int b = 0; b < maxb; ++b) { t0 = std::min(t0, p[2 * b]); t1 = std::max(t1, p[2 * b + 1]); }
-                if (t1 > t0) us[k] += (double)(t1 - t0) * 1e3 / (double)khz / iters;
+                if (k == 5 && !n_cone_blocks) continue;
+                float ms = 0.f;
+                HIP_CHECK(hipEventElapsedTime(&ms, evs[(size_t)12 * i + 2 * k], evs[(size_t)12 * i + 2 * k + 1]));
+                us[6 + k] += 1e3 * (double)ms / iters;
             }
     }
 
@@ -1243,6 +1301,11 @@ int score_create_batch(const score_problem* p, int32_t count, const score_settin
         if (!p || !out) throw std::runtime_error("null argument");
         score_settings st;
         if (s) st = *s; else score::default_settings(&st);
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            throw std::runtime_error("no HIP device available (the SCORE solver has no CPU fallback)");
+        if (st.device < 0 || st.device >= ndev) throw std::runtime_error("score_settings.device out of range");
+        DeviceGuard guard(st.device);
         auto* h = new score_handle();
         try {
             h->solver.create(p, count, st);
@@ -1270,12 +1333,14 @@ int score_dims(const score_handle* h, int64_t* n_total, int64_t* m_total, int32_
 int score_solve(score_handle* h, double* x, double* y, double* s, score_info* infos) {
     try {
         if (!h) throw std::runtime_error("null handle");
+        DeviceGuard guard(h->solver.st.device);
         return h->solver.solve(x, y, s, infos);
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 int score_reset(score_handle* h) {
     try {
         if (!h) throw std::runtime_error("null handle");
+        DeviceGuard guard(h->solver.st.device);
         h->solver.reset();
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
@@ -1283,35 +1348,52 @@ int score_reset(score_handle* h) {
 int score_solve_steps(score_handle* h, int32_t iters, double* x, double* y, double* s, score_info* infos) {
     try {
         if (!h) throw std::runtime_error("null handle");
+        DeviceGuard guard(h->solver.st.device);
         return h->solver.steps(iters, x, y, s, infos);
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 int score_time_kkt_apply(score_handle* h, int32_t reps, double* ms, double* bytes) {
     try {
         if (!h) throw std::runtime_error("null handle");
+        DeviceGuard guard(h->solver.st.device);
         h->solver.be.time_kkt(reps, ms, bytes);
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
-int score_time_iteration(score_handle* h, int32_t warmup, int32_t iters, double* us) {
+int score_time_iteration(score_handle* h, int32_t warmup, int32_t iters, double* us, int32_t with_events) {
     try {
         if (!h || !us) throw std::runtime_error("null argument");
-        h->solver.be.time_iteration(warmup, iters, us);
+        DeviceGuard guard(h->solver.st.device);
+        // the driver's reset: iterates, penalties AND the PCG count an adaptive solve may have raised
+        h->solver.reset();
+        h->solver.be.time_iteration(warmup, iters, us, with_events);
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 int score_debug_time(score_handle* h, const char* kernel, int32_t reps, double* ms) {
     try {
         if (!h || !kernel || !ms) throw std::runtime_error("null argument");
+        DeviceGuard guard(h->solver.st.device);
         h->solver.be.time_kernel(kernel, reps, ms);
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 int64_t score_debug_get(score_handle* h, const char* name, double* out, int64_t len) {
     if (!h || !name) return -1;
-    return h->solver.be.get_vec(name, out, len);
+    try {
+        DeviceGuard guard(h->solver.st.device);
+        return h->solver.be.get_vec(name, out, len);
+    } catch (const std::exception& e) { g_err = e.what(); return -2; }
 }
-void score_destroy(score_handle* h) { delete h; }
+void score_destroy(score_handle* h) {
+    if (!h) return;
+    try {
+        DeviceGuard guard(h->solver.st.device);
+        delete h;
+    } catch (...) {
+        delete h;
+    }
+}
 const char* score_last_error(void) { return g_err.c_str(); }
 const char* score_backend(void) { return "hip-gfx950"; }
 }

@@ -80,7 +80,13 @@ def solve_score_sharded(
     datas: Sequence, relaxation_type: str = "QCQP", solver_settings: Optional[dict] = None,
     lib_path: Optional[str] = None, device: Optional[int] = None,
 ) -> List[compat.SolverResults]:
-    """Every rank passes the SAME list of factor graphs and gets ALL results."""
+    """Every rank passes the SAME list of factor graphs and gets ALL results.
+
+    (Monte-Carlo graphs are generated from seeds, so holding the whole list on every rank costs
+    nothing and spares a broadcast of problem data; a rank only ASSEMBLES and solves its own
+    shard.  The gathered record carries the rounded poses, landmarks and solver statistics --
+    what ``SolverResults`` exposes -- not the raw conic iterates x / y / s.)  If any problem fails
+    anywhere, every rank raises after the collective; no rank is left waiting."""
     import torch
     import torch.distributed as dist
 
@@ -93,14 +99,32 @@ def solve_score_sharded(
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
     settings.setdefault("device", device)
-    results = solve_score_batch([datas[i] for i in mine], relaxation_type, solver_settings=settings,
-                                lib_path=lib_path) if mine else []
     stride = record_stride(datas)
     per_rank = max(len(s) for s in shards)
     buf = np.zeros((per_rank, stride))
+    # Whatever happens on this rank (score_create / score_solve failing, a graph whose estimate
+    # cannot be packed), it must still reach the all_gather below -- the other ranks are waiting in
+    # it.  A failed slot travels as a failure record (status 3 = numerical, NaN values); the error
+    # is raised on every rank AFTER the collective.
+    failure = None
+    try:
+        results = solve_score_batch([datas[i] for i in mine], relaxation_type, solver_settings=settings,
+                                    lib_path=lib_path) if mine else []
+    except Exception as exc:  # noqa: BLE001 - re-raised after the collective
+        failure = f"rank {rank}: {type(exc).__name__}: {exc}"
+        results = [None] * len(mine)
     for slot, (i, res) in enumerate(zip(mine, results)):
-        rec = _pack(res, datas[i])
-        buf[slot, : rec.size] = rec
+        try:
+            if res is None:
+                raise RuntimeError("no result")
+            rec = _pack(res, datas[i])
+            buf[slot, : rec.size] = rec
+        except Exception as exc:  # noqa: BLE001
+            if failure is None:
+                failure = f"rank {rank}, problem {i}: {type(exc).__name__}: {exc}"
+            buf[slot, :] = np.nan
+            buf[slot, 0] = 3.0   # status: numerical
+            buf[slot, 7] = -1.0  # no values
     use_cuda = dist.get_backend() == "nccl"
     t = torch.from_numpy(buf)
     if use_cuda:
@@ -108,8 +132,14 @@ def solve_score_sharded(
     gathered = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(gathered, t)
     out: List[Optional[compat.SolverResults]] = [None] * len(datas)
+    failed = []
     for r in range(world):
         g = gathered[r].cpu().numpy()
         for slot, i in enumerate(shards[r]):
+            if g[slot, 7] < 0:
+                failed.append(i)
+                continue
             out[i] = _unpack(g[slot], datas[i])
+    if failed or failure:
+        raise RuntimeError(f"solve_score_sharded: problems {failed} failed" + (f" ({failure})" if failure else ""))
     return out  # type: ignore[return-value]

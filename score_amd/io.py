@@ -71,8 +71,18 @@ class _PyfgUnpickler(pickle.Unpickler):
         if (module, name) in _ALLOWED_PYFG:
             return type(name, (_Raw,), {"_kind": name})
         if (module, name) in _ALLOWED_OTHER:
-            if module == "numpy.core.multiarray":
-                module = "numpy._core.multiarray"
+            if module in ("numpy.core.multiarray", "numpy._core.multiarray"):
+                # numpy 2 moved numpy.core to numpy._core (pickles carry either name); import
+                # whichever this numpy provides
+                import importlib.util
+
+                for cand in ("numpy._core.multiarray", "numpy.core.multiarray"):
+                    try:
+                        if importlib.util.find_spec(cand) is not None:
+                            module = cand
+                            break
+                    except ModuleNotFoundError:
+                        continue
             return super().find_class(module, name)
         raise pickle.UnpicklingError(f"global {module}.{name} is not allowed")
 

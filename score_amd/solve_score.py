@@ -143,20 +143,43 @@ def solve_score_batch(
     different groups overlap (measured on 64 four-robot trials: 2490 problems/s in groups of 16
     on 4 threads, 770 problems/s with one handle per graph)."""
     check_valid_relaxation(relaxation_type)
+    if len(datas) == 0:
+        return []
     order = list(range(len(datas)))
+
+    def size_of(i):
+        return sum(len(c) for c in datas[i].pose_variables) + len(datas[i].range_measurements)
+
     if lockstep is None and len(datas) > 1:
-        # graphs of similar size share a group: a lock-step group runs as long as its slowest member
-        order.sort(key=lambda i: sum(len(c) for c in datas[i].pose_variables) + len(datas[i].range_measurements))
+        # a lock-step handle needs one block size (2-D and 3-D graphs never share a group); within a
+        # dimension, graphs of similar size share a group: it runs as long as its slowest member
+        chunks = []
         group = max(1, min(16, -(-len(datas) // max(1, workers))))
-        chunks = [order[i : i + group] for i in range(0, len(order), group)]
+        for dim in sorted({int(datas[i].dimension) for i in order}):
+            sub = sorted((i for i in order if int(datas[i].dimension) == dim), key=size_of)
+            chunks += [sub[i : i + group] for i in range(0, len(sub), group)]
     elif not lockstep and len(datas) > 1:
         chunks = [[i] for i in order]
+    elif len({int(d.dimension) for d in datas}) > 1:
+        # lockstep=True was asked for a mixed 2-D / 3-D list: one handle per dimension
+        chunks = [[i for i in order if int(datas[i].dimension) == dim] for dim in sorted({int(d.dimension) for d in datas})]
     else:
         chunks = None
-    if chunks is not None and len(chunks) > 1:
+    if chunks is not None and (len(chunks) > 1 or len(chunks[0]) != len(datas)):
+        first_error = []
+
         def one(idx):
-            return solve_score_batch([datas[i] for i in idx], relaxation_type, qcqp_mode, solver_settings, lib_path,
-                                     lockstep=True)
+            try:
+                return solve_score_batch([datas[i] for i in idx], relaxation_type, qcqp_mode, solver_settings, lib_path,
+                                         lockstep=True)
+            except ValueError as exc:  # keep what the other graphs of this group produced
+                partial = getattr(exc, "partial_results", None)
+                if partial is None:
+                    if len(idx) > 1:
+                        raise
+                    partial = [None]
+                first_error.append(exc)
+                return partial
 
         if workers <= 1:
             parts = [one(c) for c in chunks]
@@ -169,6 +192,11 @@ def solve_score_batch(
         for idx, rs in zip(chunks, parts):
             for i, r in zip(idx, rs):
                 out[i] = r
+        if first_error:
+            bad = [i for i, r in enumerate(out) if r is None]
+            err = ValueError(f"graphs {bad} could not be extracted (first error: {first_error[0]})")
+            err.partial_results = out  # type: ignore[attr-defined]
+            raise err
         return out
     if qcqp_mode not in ("via_socp", "direct"):
         raise ValueError(f"qcqp_mode {qcqp_mode} is not supported")
@@ -190,13 +218,27 @@ def solve_score_batch(
     finally:
         solver.close()
     out = []
-    for data, model, sol in zip(datas, models, sols):
+    errors = []
+    for k, (data, model, sol) in enumerate(zip(datas, models, sols)):
         if not sol.solved:
             logger.warning("SCORE solve did not converge: %s", sol.info)
-        out.append(extract_solver_results(
-            model, sol.x, data, total_time=sol.info["solve_ms"] * 1e-3, solved=sol.solved,
-            requested_relaxation=relaxation_type, info=sol.info,
-        ))
+        try:
+            out.append(extract_solver_results(
+                model, sol.x, data, total_time=sol.info["solve_ms"] * 1e-3, solved=sol.solved,
+                requested_relaxation=relaxation_type, info=sol.info,
+            ))
+        except ValueError as exc:
+            # an estimate that cannot be rounded (NaN iterate, non-converged rotation block): as in
+            # the reference, one graph's failure is that graph's -- the rest of the batch is kept
+            if len(datas) == 1:
+                raise
+            errors.append((k, exc))
+            out.append(None)
+    if errors:
+        k, exc = errors[0]
+        err = ValueError(f"{len(errors)} of {len(datas)} graphs could not be extracted (first: #{k}: {exc})")
+        err.partial_results = out  # type: ignore[attr-defined]
+        raise err
     return out
 
 

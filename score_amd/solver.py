@@ -90,7 +90,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.score_solve_steps.argtypes = [C.c_void_p, C.c_int32, _f64p, _f64p, _f64p, C.POINTER(ScoreInfo)]
     lib.score_time_kkt_apply.argtypes = [C.c_void_p, C.c_int32, _f64p, _f64p]
     lib.score_debug_time.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, _f64p]
-    lib.score_time_iteration.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f64p]
+    lib.score_time_iteration.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_int32]
     lib.score_time_iteration.restype = C.c_int
     lib.score_debug_get.argtypes = [C.c_void_p, C.c_char_p, _f64p, C.c_int64]
     lib.score_debug_get.restype = C.c_int64
@@ -222,13 +222,18 @@ class ConicSolver:
 
     ITERATION_KERNELS = ("rhs", "prec_init", "kp", "prec_step", "kpb", "cone")
 
-    def time_iteration(self, warmup: int = 50, iters: int = 200) -> dict:
-        """In-loop microseconds of the six kernels of one ADMM iteration (device wall clock, first
-        workgroup in to last workgroup out).  Resets and advances the iterates."""
-        us = np.zeros(6)
-        if self.lib.score_time_iteration(self._h, int(warmup), int(iters), _ptr(us, _f64p)) != 0:
+    def time_iteration(self, warmup: int = 50, iters: int = 200, dispatch: bool = False):
+        """In-loop microseconds of the six kernels of one ADMM iteration on the device wall clock
+        (first workgroup in to last workgroup out).  With ``dispatch=True`` a second dict holds the
+        begin-to-end time of each DISPATCH (start/stop HIP events bound to the launches on the
+        handle's stream: what ``rocprofv3 --kernel-trace`` reports).  Resets and advances the iterates."""
+        us = np.zeros(12)
+        if self.lib.score_time_iteration(self._h, int(warmup), int(iters), _ptr(us, _f64p), 1 if dispatch else 0) != 0:
             raise RuntimeError(self.lib.score_last_error().decode())
-        return dict(zip(self.ITERATION_KERNELS, us.tolist()))
+        dev = dict(zip(self.ITERATION_KERNELS, us[:6].tolist()))
+        if not dispatch:
+            return dev
+        return dev, dict(zip(self.ITERATION_KERNELS, us[6:].tolist()))
 
     def debug_time(self, kernel: str, reps: int = 200) -> float:
         ms = C.c_double()

@@ -17,5 +17,65 @@ def test_bench_cpu_baseline_leg_runs_and_reports(twin_lib):
     )
     assert out.returncode == 0, out.stderr[-2000:]
     rec = json.loads(out.stdout.strip().splitlines()[-1])
-    assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["value"] > 0
-    assert rec["cpu_baseline"]["cores"] >= 1 and "sample" in rec["cpu_baseline"]
+    cb = rec["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0
+    assert cb["cores"] >= 1 and "sample" in cb
+    # C1 (SciPy direct-KKT ADMM, 1 thread) and C2 (C++ twin, 1 thread / best team),
+    # each with seconds to eps on the same problem
+    assert set(cb["entries"]) == {"C1_scipy_direct_kkt_admm", "C2_twin_1_thread", "C2_twin_best_team"}
+    for e in cb["entries"].values():
+        assert e["kind"] == "port" and e["seconds_to_eps"] > 0 and e["cores"] >= 1
+    objs = [e["pobj"] for e in cb["entries"].values()]
+    assert max(objs) - min(objs) < 1e-4 * max(1.0, abs(objs[0]))  # the three baselines solve the same program
+
+
+CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config")
+
+
+def test_bench_gpus_flag_launches_that_many_ranks(twin_lib):
+    """`python bench.py --gpus 2` must start two ranks by itself (no torchrun) and report n_gpus = 2
+    on BASELINE configs[4] (Monte-Carlo trials sharded i mod N).  Run here on gloo + the oracle's CPU
+    twin (--test-cpu-twin); on the GPU box the same launcher starts RCCL ranks."""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--test-cpu-twin", "--montecarlo", "5",
+         "--mc-robots", "2", "--mc-poses", "30", "--mc-batch", "2", "--mc-threads", "1", "--steps", "1", "--warmup", "0"],
+        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env,
+    )
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout  # ONE json line, from rank 0
+    rec = json.loads(lines[0])
+    for key in CONTRACT_KEYS:
+        assert key in rec
+    assert rec["n_gpus"] == 2 and rec["metric"] == "problems_per_sec" and rec["scaling"] == "strong"
+    assert rec["problems_total_per_step"] == 5 and rec["problems_solved_last_sweep"] == 5  # 3 trials on rank 0, 2 on rank 1
+    assert "test_mode" in rec
+
+
+def test_bench_is_one_of_the_ranks_under_a_launcher(twin_lib):
+    """With RANK / WORLD_SIZE already in the environment (torch.distributed.run) bench.py must not
+    spawn anything: world size 1 here, process group forced on."""
+    env = dict(os.environ, OMP_NUM_THREADS="2", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29533")
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--test-cpu-twin", "--force-dist", "--montecarlo", "2",
+         "--mc-robots", "1", "--mc-poses", "30", "--mc-beacons", "2", "--steps", "1", "--warmup", "0"],
+        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env,
+    )
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["problems_solved_last_sweep"] == 2
+
+
+def test_montecarlo_group_sizes():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.mc_groups(64, 16, 4) == [16, 16, 16, 16]
+    assert bench.mc_groups(0, 16, 4) == []
+    for n in (1, 2, 3, 8, 9, 32, 33, 100):
+        g = bench.mc_groups(n, 16, 4)
+        assert sum(g) == n and max(g) <= 16 and min(g) >= 1 and max(g) - min(g) <= 1

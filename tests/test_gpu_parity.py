@@ -279,9 +279,12 @@ def test_polish_warmup_and_in_loop_timing_probe(hip_lib):
         assert out.solved and out.info["newton_iters"] > 0 and out.info["iters"] == expect, out.info
     sol = ConicSolver(qp, dict(polish=0))
     ref = sol.solve()[0]
-    us = sol.time_iteration(warmup=5, iters=20)
-    assert list(us) == ["rhs", "prec_init", "kp", "prec_step", "kpb", "cone"]
+    us, disp = sol.time_iteration(warmup=5, iters=20, dispatch=True)
+    assert list(us) == list(disp) == ["rhs", "prec_init", "kp", "prec_step", "kpb", "cone"]
     assert all(0.5 < v < 500.0 for v in us.values()), us
+    # begin-to-end of a dispatch (start/stop events bound to the launch) contains the interval
+    # first workgroup in -> last workgroup out
+    assert all(0.5 < disp[k] < 500.0 and disp[k] > 0.8 * us[k] for k in us), (us, disp)
     again = sol.solve()[0]  # solve() resets the iterates: the probe leaves no trace
     np.testing.assert_array_equal(ref.x, again.x)
     sol.close()
@@ -353,6 +356,40 @@ def test_lockstep_batch_polish_matches_individual_solves(hip_lib):
         cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, b.x, b.y, b.s)
         assert cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4, cert
         np.testing.assert_array_equal(b.x, c.x)  # deterministic
+
+
+def test_config5_all_64_trials_are_certified(hip_lib):
+    """BASELINE configs[4] at its full size: 64 four-robot x 1000-pose Monte-Carlo trials, solved
+    the way bench.py solves them (lock-step handles of 16, product default solver).  EVERY trial
+    must carry a solver-independent KKT certificate, and four of them are compared pose by pose
+    with the oracle's Newton solve (north_star: 1e-4 relative)."""
+    import bench
+
+    args = bench.parse_args([])
+    mc = bench.MonteCarlo(args, range(64), 0, None)
+    assert mc.group_sizes == [16, 16, 16, 16]
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        sols = mc.sweep(pool)
+    mc.close()
+    assert len(sols) == 64 and all(o.solved for o in sols)
+    for t, (mdl, out) in enumerate(zip(mc.models, sols)):
+        qp = mdl.qp
+        cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, out.x, out.y, out.s)
+        assert cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4, (t, cert)
+        assert cert["s_cone_dist"] < 1e-9 and cert["y_cone_dist"] < 1e-9, (t, cert)
+        assert cert["gap"] < 1e-4 * max(1.0, abs(out.info["pobj"])), (t, cert)
+    for t in (0, 21, 42, 63):
+        fg = make_manhattan(n_robots=4, n_poses=1000, n_beacons=4, seed=bench.MC_SEED0 + t)
+        rp, u, info = so.newton_solve(fg, tol=1e-12)
+        assert sols[t].info["pobj"] == pytest.approx(info["objective"], rel=1e-6)
+        ref = so.reduced_to_values(rp, u, "SOCP")
+        mdl = mc.models[t]
+        blocks = mdl.pose_blocks(mdl.expand(sols[t].x))
+        scale = max(np.abs(v[:, 2]).max() for v in ref["poses"].values())
+        worst = max(np.abs(blocks[i] - ref["poses"][nm]).max() for i, nm in enumerate(mdl.pose_names))
+        assert worst / scale < 1e-4, (t, worst / scale)
 
 
 def test_bench_montecarlo_mode_reports_a_contract_line(hip_lib):
