@@ -139,6 +139,13 @@ struct DevBuf {
     void zero(hipStream_t st) {
         if (n) HIP_CHECK(hipMemsetAsync(d, 0, n * sizeof(T), st));
     }
+    // a window into somebody else's allocation
+    void view(T* ptr, size_t count) {
+        release();
+        d = ptr;
+        n = count;
+        owned = false;
+    }
     void release() {
         if (d && owned) (void)hipFree(d);
         d = nullptr;
@@ -210,13 +217,29 @@ struct HipBackend {
     DevBuf<int32_t> q_skip;
     DevBuf<double> q_step;
     DevBuf<int64_t> q_seg_begin, q_seg_end;
-    static constexpr int kFlagSlots = 16;
-    int32_t* h_flags = nullptr;  // pinned
+    static constexpr int kFlagSlots = 32;
+    char* h_ring = nullptr;      // pinned ring of upload slots
+    size_t ring_slot_bytes = 0;
     int flag_slot = 0;
-    double newton_eta_max = 1e-1;  // inexact Newton: linear residual <= min(eta_max, sqrt|g|)
-    int newton_chunk = 4;         // PCG iterations between two convergence reads
-    double* h_newton = nullptr;  // pinned scratch for partial sums
-    size_t h_newton_n = 0;
+    DevBuf<double> q_negg;                   // -gradient of the last evaluation (right-hand side of the next PCG)
+    DevBuf<double> q_gate_tol2, q_gate_ref;  // device-side PCG termination (pcg_gate)
+    DevBuf<int32_t> q_gate_used;
+    int32_t* h_gate = nullptr;   // [gate flags | iterations used]          } windows into h_rep
+    double* h_gd = nullptr;      // partials of g'delta                      }
+    // Everything the host reads back between launches lives in ONE device allocation, mirrored by
+    // one pinned host buffer, so that a convergence check (ADMM) or a Newton iteration costs a
+    // single device-to-host copy:  [pres | dres | fpart | gd | gate flags, gate counts]
+    DevBuf<double> rep;
+    double* h_rep = nullptr;
+    size_t rep_dres_off = 0;     // doubles
+    size_t n_fpart = 0, n_gd = 0;
+    // ... and everything the host tells the kernels per problem in one upload: [step | tol2 | skip]
+    DevBuf<double> ctl;
+    DevBuf<int32_t> q_pcgdone;   // window into rep: raised by pcg_gate
+    int pcg_used_total = 0;
+    double newton_eta_max = 1e-1;  // inexact Newton: linear residual <= min(eta_max, coef * |g|^pow)
+    double newton_eta_coef = 1.0, newton_eta_pow = 0.5;
+    double* h_newton = nullptr;  // window into h_rep: partials of the cone part of F
 
     int cg_iters = 2;
     const double* last_rz = nullptr;  // r'z partials / direction of the pending end-of-PCG update
@@ -233,10 +256,8 @@ struct HipBackend {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
-        if (h_pres) (void)hipHostFree(h_pres);
-        if (h_dres) (void)hipHostFree(h_dres);
-        if (h_newton) (void)hipHostFree(h_newton);
-        if (h_flags) (void)hipHostFree(h_flags);
+        if (h_rep) (void)hipHostFree(h_rep);
+        if (h_ring) (void)hipHostFree(h_ring);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -332,16 +353,36 @@ struct HipBackend {
         pw_part.alloc(K.nblocks); rz_part0.alloc(n_prec); rz_part1.alloc(n_prec);
         rz_meas0.alloc(n_prec); rz_meas1.alloc(n_prec);
         cg_iters = st.cg_iters;
-        pres_part.alloc((size_t)std::max(1, n_cone_blocks) * kPartStride);
-        dres_part.alloc((size_t)G2.nblocks * kPartStride);
-        HIP_CHECK(hipHostMalloc((void**)&h_pres, pres_part.n * sizeof(double)));
-        HIP_CHECK(hipHostMalloc((void**)&h_dres, dres_part.n * sizeof(double)));
         std::vector<int32_t> dz(h.count, 0);
         done.upload(dz);
         fac.upload(h.fac); dinv.upload(h.dinv); rho.upload(h.rho);  // (K.val went up with K)
         pt.mark("allocations + rho data");
         if (st.polish) init_polish(h);
         pt.mark("polish setup");
+        {   // the report arena (see `rep`) and the control block (see `ctl`)
+            const size_t n_pres = (size_t)std::max(1, n_cone_blocks) * kPartStride, n_dres = (size_t)G2.nblocks * kPartStride;
+            const size_t n_int = (2 * (size_t)h.count + 1) / 2;  // 2 * count int32
+            rep.alloc(n_pres + n_dres + n_fpart + n_gd + n_int);
+            rep.zero(stream);
+            HIP_CHECK(hipHostMalloc((void**)&h_rep, rep.n * sizeof(double)));
+            std::memset(h_rep, 0, rep.n * sizeof(double));
+            rep_dres_off = n_pres;
+            pres_part.view(rep.d, n_pres);
+            dres_part.view(rep.d + n_pres, n_dres);
+            q_fpart.view(rep.d + n_pres + n_dres, n_fpart);
+            q_gd.view(rep.d + n_pres + n_dres + n_fpart, n_gd);
+            q_pcgdone.view((int32_t*)(rep.d + n_pres + n_dres + n_fpart + n_gd), h.count);
+            q_gate_used.view(q_pcgdone.d + h.count, h.count);
+            h_pres = h_rep;
+            h_dres = h_rep + n_pres;
+            h_newton = h_rep + n_pres + n_dres;
+            h_gd = h_rep + n_pres + n_dres + n_fpart;
+            h_gate = (int32_t*)(h_rep + n_pres + n_dres + n_fpart + n_gd);
+            ctl.alloc(2 * (size_t)h.count + ((size_t)h.count + 1) / 2);
+            q_step.view(ctl.d, h.count);
+            q_gate_tol2.view(ctl.d + h.count, h.count);
+            q_skip.view((int32_t*)(ctl.d + 2 * (size_t)h.count), h.count);
+        }
         reset();
         pt.mark("reset");
     }
@@ -521,7 +562,7 @@ struct HipBackend {
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = done.d;
         pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d;
-        pa.r = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d;
+        pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d;
         pa.pw_part = pw_part.d;
         double* rz_cur = measure ? rz_meas0.d : rz_part0.d;
         double* p_cur = p.d;
@@ -646,12 +687,11 @@ struct HipBackend {
 
     void residuals(std::vector<ResidualSums>& R) {
         const HostSystem& h = *H;
-        if (n_cone_blocks) {
+        if (n_cone_blocks)
             hipLaunchKernelGGL(k_pres, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xy.d));
-            HIP_CHECK(hipMemcpyAsync(h_pres, pres_part.d, pres_part.n * sizeof(double), hipMemcpyDeviceToHost, stream));
-        }
         hipLaunchKernelGGL(k_spmv<MODE_DRES>, dim3(G2.nblocks), dim3(kThreads), 0, stream, spmv_args(G2, xy.d));
-        HIP_CHECK(hipMemcpyAsync(h_dres, dres_part.d, dres_part.n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        // [pres | dres] are adjacent in the report arena: one copy
+        HIP_CHECK(hipMemcpyAsync(h_rep, rep.d, (pres_part.n + dres_part.n) * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipGetLastError());
         for (int pi = 0; pi < h.count; ++pi) {
@@ -725,6 +765,9 @@ struct HipBackend {
 
     void init_polish(const HostSystem& h) {
         PhaseTimer pt(st.verbose != 0);
+        if (const char* e = std::getenv("SCORE_NEWTON_ETA_MAX")) newton_eta_max = std::atof(e);
+        if (const char* e = std::getenv("SCORE_NEWTON_ETA_COEF")) newton_eta_coef = std::atof(e);
+        if (const char* e = std::getenv("SCORE_NEWTON_ETA_POW")) newton_eta_pow = std::atof(e);
         build_polish(h, Q, st.verbose != 0);
         pt.mark("  polish: host structures");
         if (!Q.available) return;
@@ -743,16 +786,16 @@ struct HipBackend {
         }
         const size_t nc = h.cone_row.size();
         q_Bbuf.alloc(nc * Q.T * Q.T);
-        q_fpart.alloc(std::max<size_t>((nc + kThreads - 1) / kThreads, (size_t)n_cone_blocks));
+        n_fpart = std::max<size_t>((nc + kThreads - 1) / kThreads, (size_t)n_cone_blocks);
         q_X0.alloc(h.n_tot + h.m_tot); q_X1.alloc(h.n_tot + h.m_tot);
-        q_g.alloc(h.n_tot); q_delta.alloc(h.n_tot); q_dummy.alloc(h.n_tot);
+        q_g.alloc(h.n_tot); q_delta.alloc(h.n_tot); q_dummy.alloc(h.n_tot); q_negg.alloc(h.n_tot);
         q_fac.alloc(h.fac.size()); q_dinv.alloc(h.dinv.size());
         q_fac.zero(stream);  // separator slots of the spike region are never written (nor used)
         q_work.alloc((size_t)std::max<int64_t>(1, h.scratch_nodes) * 2 * std::max(1, h.bs * h.bs));
-        q_gd.alloc(std::max<size_t>((h.n_tot + kThreads - 1) / kThreads, (size_t)Hm.nblocks));
+        n_gd = std::max<size_t>((h.n_tot + kThreads - 1) / kThreads, (size_t)Hm.nblocks);
         q_pw.alloc(Hm.nblocks);
-        if (h.count > 1) {
-            q_skip.alloc(h.count); q_step.alloc(h.count);
+        {
+            q_gate_ref.alloc(h.count);
             std::vector<int64_t> sb(2 * h.count), se(2 * h.count);
             for (int p = 0; p < h.count; ++p) {
                 sb[2 * p] = h.xoff[p]; se[2 * p] = h.xoff[p + 1];
@@ -760,8 +803,6 @@ struct HipBackend {
             }
             q_seg_begin.upload(sb); q_seg_end.upload(se);
         }
-        h_newton_n = std::max<size_t>(std::max<size_t>(q_fpart.n, q_gd.n), std::max<size_t>((size_t)n_prec, 8)) + 8;
-        HIP_CHECK(hipHostMalloc((void**)&h_newton, h_newton_n * sizeof(double)));
     }
 
     PolishArgs polish_args(double* X) {
@@ -774,86 +815,6 @@ struct HipBackend {
         return a;
     }
 
-    // F, |grad|_inf (unscaled) at the point stored in X = [u | .]; leaves nu in X, B blocks in
-    // q_Bbuf, the gradient in q_g and its negative in r
-    void newton_eval(double* X, double* F, double* gnorm) {
-        const HostSystem& h = *H;
-        PolishArgs pa = polish_args(X);
-        const int ncb = (int)q_fpart.n;
-        hipLaunchKernelGGL(k_newton_cone, dim3(ncb), dim3(kThreads), 0, stream, pa);
-        SpmvArgs ga = spmv_args(G2, X);
-        ga.is_head = q_ishead.d; ga.gout = q_g.d;
-        hipLaunchKernelGGL(k_spmv<MODE_GRAD>, dim3(G2.nblocks), dim3(kThreads), 0, stream, ga);
-        HIP_CHECK(hipMemcpyAsync(h_newton, q_fpart.d, ncb * sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(h_dres, dres_part.d, dres_part.n * sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        HIP_CHECK(hipGetLastError());
-        double f = 0.0, gmax = 0.0;
-        for (int i = 0; i < ncb; ++i) f += h_newton[i];
-        for (int bl = 0; bl < G2.nblocks; ++bl) {
-            const double* o = h_dres + (size_t)bl * kPartStride;
-            gmax = (o[0] != o[0]) ? o[0] : std::max(gmax, o[0]);
-            f += o[2];
-        }
-        (void)h;
-        *F = f;
-        *gnorm = gmax;
-    }
-
-    // Solve H delta = -g (r holds -g) with PCG on the device-factored chain preconditioner.
-    int newton_pcg(double rel_tol, int max_cg, int first_chunk) {
-        const HostSystem& h = *H;
-        q_delta.zero(stream);
-        PrecArgs pa{};
-        pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = q_fac.d;
-        pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = done.d;
-        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d;
-        pa.r = r.d; pa.z = z.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d; pa.pw_part = q_pw.d;
-        double* rz_cur = rz_part0.d;
-        double* p_cur = p.d;
-        double* p_oth = p2.d;
-        pa.p = p_cur; pa.rz_in = nullptr; pa.rz_out = rz_cur;
-        launch_prec<PREC_INIT>(pa);
-        auto launch_hp = [&](const double* pd) {
-            SpmvArgs a = spmv_args(Hm, pd);
-            a.p = pd; a.pw_part = q_pw.d;
-            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, a);
-        };
-        auto launch_hpb = [&](const double* p_old, double* p_new, const double* rzn, const double* rzo) {
-            SpmvArgs a = spmv_args(Hm, p_old);
-            a.p = p_old; a.z = z.d; a.p_out = p_new; a.rz_new = rzn; a.rz_old = rzo; a.pw_part = q_pw.d;
-            hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, a);
-        };
-        launch_hp(p_cur);
-        auto sum_rz = [&](const double* dev) {
-            HIP_CHECK(hipMemcpyAsync(h_newton, dev, n_prec * sizeof(double), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
-            double sacc = 0.0;
-            for (int i = 0; i < n_prec; ++i) sacc += h_newton[i];
-            return sacc;
-        };
-        const double rz0 = sum_rz(rz_cur);
-        if (!(rz0 > 0.0)) return 0;
-        int done_cg = 0;
-        while (done_cg < max_cg) {
-            const int chunk = (done_cg == 0) ? std::max(newton_chunk, first_chunk) : newton_chunk;
-            for (int j = 0; j < chunk; ++j) {
-                double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
-                pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_nxt;
-                launch_prec<PREC_STEP>(pa);   // delta += a p ; r -= a w ; z = M^-1 r
-                launch_hpb(p_cur, p_oth, rz_nxt, rz_cur);
-                std::swap(p_cur, p_oth);
-                rz_cur = rz_nxt;
-            }
-            done_cg += chunk;
-            const double rzk = sum_rz(rz_cur);
-            if (!(rzk == rzk)) throw std::runtime_error("polish: NaN in PCG");
-            if (std::sqrt(std::max(0.0, rzk) / rz0) <= rel_tol) break;
-        }
-        (void)h;
-        return done_cg;
-    }
-
     // Any failure inside the polish (NaN, HIP error) leaves the ADMM state untouched -- the Newton
     // loop only writes scratch vectors until its final hand-over -- and ADMM simply continues.
     bool polish_available() const { return Q.available; }
@@ -861,8 +822,7 @@ struct HipBackend {
     bool polish(const HostSystem& h, const score_settings& s_, const std::vector<int>& done_host, int* newton_iters,
                 int* cg_used) {
         try {
-            if (h.count > 1) return polish_batch_impl(h, s_, done_host, newton_iters, cg_used);
-            return polish_impl(h, s_, newton_iters, cg_used);
+            return polish_lockstep(h, s_, done_host, newton_iters, cg_used);
         } catch (const std::exception& e) {
             if (st.verbose) std::fprintf(stderr, "[score] polish abandoned: %s\n", e.what());
             (void)hipStreamSynchronize(stream);
@@ -894,9 +854,13 @@ struct HipBackend {
         }
     }
 
-    // ---- lock-step polish of a batch: every live problem takes its Newton step through the same
-    //      launches; per-problem F, |g|, step length and state live on the host, the kernels read
-    //      per-problem step lengths and skip flags from device arrays ----
+    // ---- Newton polish, all problems of the handle in lock-step (a single problem is a batch of
+    //      one): every live problem takes its Newton step through the same launches; per-problem
+    //      F, |g|, step length and state live on the host, the kernels read per-problem step lengths
+    //      and skip flags from device arrays.  The PCG solves terminate ON THE DEVICE (pcg_gate in
+    //      score_kernels.hpp): the host queues as many PCG iterations as the previous Newton step
+    //      needed plus a margin, then the trial point and its evaluation, and synchronises ONCE per
+    //      Newton iteration to read F, |g|, g'delta and the PCG flags together. ----
     BatchTables batch_tables() const {
         BatchTables bt{};
         bt.cone_block_first = cone_block_first.d; bt.cone_block_prob = cone_block_prob.d;
@@ -904,36 +868,56 @@ struct HipBackend {
         bt.skip = q_skip.d; bt.step = q_step.d;
         return bt;
     }
-    // skip = !live.  Stream-ordered, no host synchronisation: the flags go through a small ring of
-    // pinned slots (every evaluation of F synchronises the stream, long before the ring wraps).
-    int32_t* next_flag_slot(size_t c) {
-        if (!h_flags) HIP_CHECK(hipHostMalloc((void**)&h_flags, kFlagSlots * c * sizeof(int32_t)));
+    // Stream-ordered uploads of small per-problem arrays without a host synchronisation: the data
+    // go through a ring of pinned slots (every evaluation of F synchronises the stream, long
+    // before the ring wraps).
+    char* next_ring_slot(size_t bytes) {
+        const size_t need = (bytes + 63) & ~(size_t)63;
+        if (need > ring_slot_bytes) {
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (h_ring) (void)hipHostFree(h_ring);
+            h_ring = nullptr;
+            ring_slot_bytes = std::max<size_t>(need, 256);
+            HIP_CHECK(hipHostMalloc((void**)&h_ring, kFlagSlots * ring_slot_bytes));
+        }
         flag_slot = (flag_slot + 1) % kFlagSlots;
-        return h_flags + (size_t)flag_slot * c;
+        return h_ring + (size_t)flag_slot * ring_slot_bytes;
     }
-    void upload_skip(const std::vector<char>& live) {
-        const size_t c = live.size();
-        int32_t* v = next_flag_slot(c);
-        for (size_t i = 0; i < c; ++i) v[i] = live[i] ? 0 : 1;
-        HIP_CHECK(hipMemcpyAsync(q_skip.d, v, c * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    // one upload of the per-problem control block [step | tol2 | skip]
+    std::vector<double> c_step, c_tol2;
+    std::vector<int32_t> c_skip;
+    void upload_control() {
+        const size_t c = c_skip.size();
+        char* v = next_ring_slot(ctl.n * sizeof(double));
+        std::memcpy(v, c_step.data(), c * sizeof(double));
+        std::memcpy(v + c * sizeof(double), c_tol2.data(), c * sizeof(double));
+        std::memcpy(v + 2 * c * sizeof(double), c_skip.data(), c * sizeof(int32_t));
+        HIP_CHECK(hipMemcpyAsync(ctl.d, v, 2 * c * sizeof(double) + c * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    }
+    void upload_skip(const std::vector<char>& live) {  // skip = !live
+        for (size_t i = 0; i < live.size(); ++i) c_skip[i] = live[i] ? 0 : 1;
+        upload_control();
     }
     void upload_flags(const std::vector<int32_t>& f) {  // nonzero = selected
-        int32_t* v = next_flag_slot(f.size());
-        std::copy(f.begin(), f.end(), v);
-        HIP_CHECK(hipMemcpyAsync(q_skip.d, v, f.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        c_skip = f;
+        upload_control();
     }
-    // F and |grad|_inf of the problems not skipped, at the point stored in Xbuf
-    void newton_eval_batch(double* Xbuf, const std::vector<char>& which, std::vector<double>& F, std::vector<double>& gn) {
-        const HostSystem& h = *H;
+
+    // queue the evaluation of F and the gradient at Xbuf for the problems not skipped
+    void newton_eval_enqueue(double* Xbuf) {
         PolishArgs pa = polish_args(Xbuf);
         hipLaunchKernelGGL(k_newton_cone_b, dim3(n_cone_blocks), dim3(kThreads), 0, stream, pa, batch_tables());
         SpmvArgs ga = spmv_args(G2, Xbuf);
-        ga.is_head = q_ishead.d; ga.gout = q_g.d; ga.done = q_skip.d;
+        // -g goes to its own buffer, not to the PCG residual r: an unfinished PCG solve can then be
+        // resumed after the evaluation of a trial point
+        ga.is_head = q_ishead.d; ga.gout = q_g.d; ga.r = q_negg.d; ga.done = q_skip.d;
         hipLaunchKernelGGL(k_spmv<MODE_GRAD>, dim3(G2.nblocks), dim3(kThreads), 0, stream, ga);
-        HIP_CHECK(hipMemcpyAsync(h_newton, q_fpart.d, n_cone_blocks * sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(h_dres, dres_part.d, dres_part.n * sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        HIP_CHECK(hipGetLastError());
+        // [dres | fpart | gd | gate flags and counts]: adjacent in the report arena, one copy
+        HIP_CHECK(hipMemcpyAsync(h_dres, dres_part.d, (rep.n - rep_dres_off) * sizeof(double), hipMemcpyDeviceToHost, stream));
+    }
+    // after the synchronisation: F and |grad|_inf of the problems in `which`
+    void newton_eval_collect(const std::vector<char>& which, std::vector<double>& F, std::vector<double>& gn) {
+        const HostSystem& h = *H;
         for (int p = 0; p < h.count; ++p) {
             if (!which[p]) continue;
             double f = 0.0, gmax = 0.0;
@@ -947,82 +931,74 @@ struct HipBackend {
             gn[p] = gmax;
         }
     }
-    // PCG on H delta = -g for the problems in `live`, each to its own relative tolerance
-    int newton_pcg_batch(const std::vector<char>& live, const std::vector<double>& eta, int max_cg) {
+    void newton_eval_batch(double* Xbuf, const std::vector<char>& which, std::vector<double>& F, std::vector<double>& gn) {
+        newton_eval_enqueue(Xbuf);
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipGetLastError());
+        newton_eval_collect(which, F, gn);
+    }
+
+    // Queue PCG iterations on H delta = -g for the problems in `live`, each to its own relative
+    // tolerance eta[p]; a problem's launches turn into no-ops once its gate has fired (q_skip[p] is
+    // raised by the device).  No host synchronisation.  `resume`: continue the solve the previous
+    // call left unfinished (its state -- delta, r, z, p, w, the r'z partials -- is intact because a
+    // gate that has not fired has not frozen anything).
+    double* pcg_rz_cur = nullptr;
+    double* pcg_p_cur = nullptr;
+    double* pcg_p_oth = nullptr;
+    void newton_pcg_enqueue(const std::vector<char>& live, const std::vector<double>& eta, int n_iters, bool resume) {
         const HostSystem& h = *H;
-        q_delta.zero(stream);
-        upload_skip(live);
+        if (!resume)
+            for (int p = 0; p < h.count; ++p) c_tol2[p] = eta[p] * eta[p];
+        upload_skip(live);  // (uploads the tolerances too)
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = q_fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = q_skip.d;
         pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d;
-        pa.r = r.d; pa.z = z.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d; pa.pw_part = q_pw.d;
-        double* rz_cur = rz_part0.d;
-        double* p_cur = p.d;
-        double* p_oth = p2.d;
-        pa.p = p_cur; pa.rz_in = nullptr; pa.rz_out = rz_cur;
-        launch_prec<PREC_INIT>(pa);
-        auto launch_hp = [&](const double* pd) {
-            SpmvArgs a = spmv_args(Hm, pd);
-            a.p = pd; a.pw_part = q_pw.d; a.done = q_skip.d;
+        pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d; pa.pw_part = q_pw.d;
+        pa.gate_used = q_gate_used.d;
+        if (!resume) {
+            // the right-hand side is read where the evaluation left it (-g in q_negg) and the solution
+            // starts from zero without a memset: the first STEP writes r and delta
+            pcg_rz_cur = rz_part0.d; pcg_p_cur = p.d; pcg_p_oth = p2.d;
+            pa.p = pcg_p_cur; pa.rz_in = nullptr; pa.rz_out = pcg_rz_cur;
+            pa.r_in = q_negg.d;
+            pa.gate_init = q_pcgdone.d;  // gate flags start as the host's skip flags
+            launch_prec<PREC_INIT>(pa);
+            pa.gate_init = nullptr;
+            SpmvArgs a = spmv_args(Hm, pcg_p_cur);
+            a.p = pcg_p_cur; a.pw_part = q_pw.d; a.done = q_skip.d;
             hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, a);
-        };
-        auto launch_hpb = [&](const double* p_old, double* p_new, const double* rzn, const double* rzo) {
-            SpmvArgs a = spmv_args(Hm, p_old);
-            a.p = p_old; a.z = z.d; a.p_out = p_new; a.rz_new = rzn; a.rz_old = rzo; a.pw_part = q_pw.d; a.done = q_skip.d;
+        } else {
+            // flags of the problems that go on: lowered again (their gates had not fired; the host's skip
+            // flags now hold exactly the resumed set)
+            HIP_CHECK(hipMemcpyAsync(q_pcgdone.d, q_skip.d, h.count * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+        }
+        pa.done = q_pcgdone.d;
+        pa.gate_flag = q_pcgdone.d; pa.gate_tol2 = q_gate_tol2.d; pa.gate_ref = q_gate_ref.d;
+        for (int j = 0; j < n_iters; ++j) {
+            double* rz_nxt = (pcg_rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
+            const bool first = !resume && j == 0;
+            pa.p = pcg_p_cur; pa.rz_in = pcg_rz_cur; pa.rz_out = rz_nxt;
+            pa.gate_first = first ? 1 : 0;
+            pa.r_in = first ? q_negg.d : r.d;
+            pa.xt_zero = first ? 1 : 0;
+            launch_prec<PREC_STEP>(pa);   // delta += a p ; r -= a w ; z = M^-1 r   (or: gate fires, nothing happens)
+            SpmvArgs a = spmv_args(Hm, pcg_p_cur);
+            a.p = pcg_p_cur; a.z = z.d; a.p_out = pcg_p_oth; a.rz_new = rz_nxt; a.rz_old = pcg_rz_cur; a.pw_part = q_pw.d; a.done = q_pcgdone.d;
             hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, a);
-        };
-        launch_hp(p_cur);
-        std::vector<double> rz(h.count, 0.0), rz0(h.count, 0.0);
-        auto sum_rz = [&](const double* dev, std::vector<double>& out, const std::vector<char>& which) {
-            HIP_CHECK(hipMemcpyAsync(h_newton, dev, n_prec * sizeof(double), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
-            for (int p = 0; p < h.count; ++p) {
-                if (!which[p]) continue;
-                double sacc = 0.0;
-                for (int i = h.prec_part_ptr[p]; i < h.prec_part_ptr[p + 1]; ++i) sacc += h_newton[i];
-                out[p] = sacc;
-            }
-        };
-        std::vector<char> run = live;
-        sum_rz(rz_cur, rz0, run);
-        bool any = false, changed = false;
-        for (int p = 0; p < h.count; ++p) {
-            if (run[p] && !(rz0[p] > 0.0)) { run[p] = 0; changed = true; }
-            any = any || run[p];
+            std::swap(pcg_p_cur, pcg_p_oth);
+            pcg_rz_cur = rz_nxt;
         }
-        if (changed) upload_skip(run);
-        int done_cg = 0;
-        while (any && done_cg < max_cg) {
-            for (int j = 0; j < newton_chunk; ++j) {
-                double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
-                pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_nxt;
-                launch_prec<PREC_STEP>(pa);   // delta += a p ; r -= a w ; z = M^-1 r
-                launch_hpb(p_cur, p_oth, rz_nxt, rz_cur);
-                std::swap(p_cur, p_oth);
-                rz_cur = rz_nxt;
-            }
-            done_cg += newton_chunk;
-            sum_rz(rz_cur, rz, run);
-            any = false; changed = false;
-            for (int p = 0; p < h.count; ++p) {
-                if (!run[p]) continue;
-                if (!(rz[p] == rz[p])) throw std::runtime_error("polish: NaN in PCG");
-                if (std::sqrt(std::max(0.0, rz[p]) / rz0[p]) <= eta[p]) { run[p] = 0; changed = true; }
-                any = any || run[p];
-            }
-            // a frozen problem keeps its rz partials of this read: the ping-pong buffers are only
-            // rewritten by the problems still running
-            if (changed && any) upload_skip(run);
-        }
-        return done_cg;
     }
 
-    bool polish_batch_impl(const HostSystem& h, const score_settings& s_, const std::vector<int>& done_host,
-                           int* newton_iters, int* cg_used) {
+    bool polish_lockstep(const HostSystem& h, const score_settings& s_, const std::vector<int>& done_host,
+                         int* newton_iters, int* cg_used) {
         *newton_iters = 0; *cg_used = 0;
+        pcg_used_total = 0;
+        const double t_start = now_ms();
+        c_step.assign(h.count, 1.0); c_tol2.assign(h.count, 0.0); c_skip.assign(h.count, 0);
         if (!Q.available) return false;
-        HIP_CHECK(hipStreamSynchronize(stream));
         const int count = h.count, nbh = Hm.nblocks;
         double* X = q_X0.d;   // current point [u | nu]
         double* Xt = q_X1.d;  // trial point
@@ -1042,33 +1018,73 @@ struct HipBackend {
         newton_eval_batch(X, part, F, gn);
         const double tol = std::max(1e-12, 0.3 * s_.eps_abs);
         std::vector<char> live(count), stalled(count, 0);
-        int it = 0, cg_tot = 0;
+        int it = 0;
+        int n_pcg = 12;  // PCG iterations queued for the first Newton step
+        int used_prev = 0;
+        std::vector<double> eta_prev(count, 0.0);
         for (; it < 50; ++it) {
             any = false;
             for (int p = 0; p < count; ++p) { live[p] = part[p] && !stalled[p] && gn[p] > tol; any = any || live[p]; }
             if (!any) break;
             upload_skip(live);
             newton_hessian(q_skip.d);  // (the matrix entries of a frozen problem are simply re-derived)
-            for (int p = 0; p < count; ++p) eta[p] = std::min(newton_eta_max, std::max(1e-8, std::sqrt(gn[p])));
-            cg_tot += newton_pcg_batch(live, eta, 400);
+            // inexact Newton: the linear residual only has to shrink superlinearly with |g|
+            // (and never more digits than the step needs to land below the tolerance)
+            for (int p = 0; p < count; ++p) {
+                const double superlinear = std::max(1e-8, newton_eta_coef * std::pow(gn[p], newton_eta_pow));
+                const double enough = gn[p] > 0.0 ? 0.1 * tol / gn[p] : 1.0;
+                eta[p] = std::min(newton_eta_max, std::max(superlinear, enough));
+            }
+            // PCG iterations to queue: what the previous Newton step needed, scaled by the digits this
+            // one asks for (PCG converges linearly), plus a margin; skipped launches cost ~2 us each
+            if (it > 0 && used_prev > 0) {
+                double scale = 1.0;
+                for (int p = 0; p < count; ++p)
+                    if (live[p] && eta_prev[p] > 0.0 && eta_prev[p] < 1.0 && eta[p] < 1.0)
+                        scale = std::max(scale, std::log(eta[p]) / std::log(eta_prev[p]));
+                n_pcg = std::min(400, (int)std::ceil(used_prev * std::min(scale, 4.0)) + 3);
+            }
+            newton_pcg_enqueue(live, eta, n_pcg, false);
+            eta_prev = eta;
+            int used_now = 0;
             // backtracking per problem; a problem leaves the search when its step is accepted
             std::vector<char> ls = live, accepted(count, 0);
             for (int p = 0; p < count; ++p) step[p] = 1.0;
             for (int k = 0; k < 40; ++k) {
-                upload_skip(ls);
-                HIP_CHECK(hipMemcpyAsync(q_step.d, step.data(), count * sizeof(double), hipMemcpyHostToDevice, stream));
+                c_step = step;
+                upload_skip(ls);  // (uploads the step lengths too)
                 va.u = X; va.delta = q_delta.d; va.step = 0.0; va.out = Xt;
                 hipLaunchKernelGGL(k_newton_trial_b, dim3(nbh), dim3(kThreads), 0, stream, va, batch_tables());
+                newton_eval_enqueue(Xt);  // overwrites nu / B / g of the problems searched; copies gd and the gate words too
+                HIP_CHECK(hipStreamSynchronize(stream));  // the one synchronisation of a Newton iteration (step 1 accepted)
+                HIP_CHECK(hipGetLastError());
                 if (k == 0) {
-                    HIP_CHECK(hipMemcpyAsync(h_newton, q_gd.d, nbh * sizeof(double), hipMemcpyDeviceToHost, stream));
-                    HIP_CHECK(hipStreamSynchronize(stream));
+                    // a problem whose queue ran dry before its gate fired resumes its PCG (state intact);
+                    // the trial point and its evaluation are then redone
+                    std::vector<char> more(count, 0);
+                    bool any_more = false;
+                    used_now = 0;
                     for (int p = 0; p < count; ++p) {
-                        gd[p] = 0.0;
-                        if (!ls[p]) continue;
-                        for (int b = Q.rbH.part_ptr[p]; b < Q.rbH.part_ptr[p + 1]; ++b) gd[p] += h_newton[b];
+                        if (!live[p]) continue;
+                        used_now = std::max(used_now, (int)h_gate[count + p]);
+                        if (!h_gate[p] && h_gate[count + p] < 400) { more[p] = 1; any_more = true; }
+                    }
+                    if (any_more) {
+                        newton_pcg_enqueue(more, eta, std::max(4, used_now / 2), true);
+                        --k;  // same step length again
+                        continue;
                     }
                 }
-                newton_eval_batch(Xt, ls, Ft, gt);  // overwrites nu / B / g of the problems searched
+                newton_eval_collect(ls, Ft, gt);
+                if (k == 0) {
+                    for (int p = 0; p < count; ++p) {
+                        gd[p] = 0.0;
+                        if (!live[p]) continue;
+                        for (int b = Q.rbH.part_ptr[p]; b < Q.rbH.part_ptr[p + 1]; ++b) gd[p] += h_gd[b];
+                    }
+                    pcg_used_total += used_now;
+                    used_prev = used_now;
+                }
                 std::vector<int32_t> acc_now(count, 0);
                 bool any_acc = false, any_ls = false;
                 for (int p = 0; p < count; ++p) {
@@ -1084,10 +1100,24 @@ struct HipBackend {
                         any_ls = true;
                     }
                 }
-                if (any_acc) {  // X <- Xt on the segments (unknowns and cone rows) of the accepted problems
-                    upload_flags(acc_now);
-                    hipLaunchKernelGGL(k_copy_segments, dim3(64, 2 * count), dim3(kThreads), 0, stream, X, (const double*)Xt,
-                                       (const int64_t*)q_seg_begin.d, (const int64_t*)q_seg_end.d, (const int32_t*)q_skip.d);
+                if (any_acc) {
+                    if (!any_ls && k == 0) {
+                        std::swap(X, Xt);  // every live problem accepted its full step: trade the buffers ...
+                        // ... and keep the points of the problems that did not move
+                        bool others = false;
+                        std::vector<int32_t> keep(count, 0);
+                        for (int p = 0; p < count; ++p)
+                            if (!live[p]) { keep[p] = 1; others = true; }
+                        if (others && count > 1) {
+                            upload_flags(keep);
+                            hipLaunchKernelGGL(k_copy_segments, dim3(64, 2 * count), dim3(kThreads), 0, stream, X, (const double*)Xt,
+                                               (const int64_t*)q_seg_begin.d, (const int64_t*)q_seg_end.d, (const int32_t*)q_skip.d);
+                        }
+                    } else {  // X <- Xt on the segments (unknowns and cone rows) of the accepted problems
+                        upload_flags(acc_now);
+                        hipLaunchKernelGGL(k_copy_segments, dim3(64, 2 * count), dim3(kThreads), 0, stream, X, (const double*)Xt,
+                                           (const int64_t*)q_seg_begin.d, (const int64_t*)q_seg_end.d, (const int32_t*)q_skip.d);
+                    }
                 }
                 if (!any_ls) break;
             }
@@ -1096,7 +1126,7 @@ struct HipBackend {
                 if (live[p] && !accepted[p]) { stalled[p] = 1; any_stalled = true; }
             if (st.verbose) {
                 for (int p = 0; p < count; ++p)
-                    if (live[p]) std::fprintf(stderr, "[score] newton it %d prob %d F %.12g |g| %.3e step %.3g%s\n", it + 1, p, F[p], gn[p], step[p], stalled[p] ? " (stalled)" : "");
+                    if (live[p]) std::fprintf(stderr, "[score] newton it %d prob %d F %.12g |g| %.3e step %.3g pcg %d (conv %d, queued next %d) t %.3f ms%s\n", it + 1, p, F[p], gn[p], step[p], h_gate[count + p], h_gate[p], n_pcg, now_ms() - t_start, stalled[p] ? " (stalled)" : "");
             }
             if (any_stalled) {  // re-establish nu / B / g of the current point of the stalled problems
                 std::vector<char> sv(stalled.begin(), stalled.end());
@@ -1107,7 +1137,8 @@ struct HipBackend {
             }
         }
         *newton_iters = it;
-        *cg_used = cg_tot;
+        *cg_used = pcg_used_total;
+        pcg_used_total = 0;
         // hand the polished points to the ADMM state of the problems that took part
         upload_skip(part);
         va.u = X; va.delta = X; va.step = 0.0; va.out = Xt;
@@ -1127,92 +1158,12 @@ struct HipBackend {
         return true;
     }
 
-    bool polish_impl(const HostSystem& h, const score_settings& s_, int* newton_iters, int* cg_used) {
-        *newton_iters = 0; *cg_used = 0;
-        if (!Q.available || h.count != 1) return false;
-        HIP_CHECK(hipStreamSynchronize(stream));
-        const int nb_n = (int)q_gd.n;
-        double* X = q_X0.d;
-        double* Xt = q_X1.d;
-        NewtonVecArgs va{};
-        va.n = h.n_tot; va.is_head = q_ishead.d; va.g = q_g.d; va.part = q_gd.d;
-        // start from the ADMM iterate x (head variables are eliminated: kept at zero)
-        HIP_CHECK(hipMemsetAsync(q_g.d, 0, q_g.n * sizeof(double), stream));
-        va.u = xy.d; va.delta = xy.d; va.step = 0.0; va.out = X;
-        hipLaunchKernelGGL(k_newton_trial, dim3(nb_n), dim3(kThreads), 0, stream, va);
-        double F = 0, gn = 0;
-        newton_eval(X, &F, &gn);
-        const double tol = std::max(1e-12, 0.3 * s_.eps_abs);
-        int it = 0, cg_tot = 0, last_cg = 0;
-        bool ok = true;
-        for (; it < 50 && gn > tol; ++it) {
-            newton_hessian();  // Hessian at X, its Jacobi diagonal and chain factors
-            // inexact Newton: the linear residual only has to shrink superlinearly with |g|
-            const double eta = std::min(newton_eta_max, std::max(1e-8, std::sqrt(gn)));
-            // the previous Newton step's PCG count predicts this one's: fewer convergence reads
-            const int used = newton_pcg(eta, 400, std::max(0, last_cg - 2 * newton_chunk));
-            last_cg = used;
-            cg_tot += used;
-            // backtracking on F (accept on the gradient when the decrease drowns in rounding)
-            double step = 1.0;
-            bool accepted = false;
-            double gd = 0.0;
-            for (int ls = 0; ls < 40; ++ls) {
-                va.u = X; va.delta = q_delta.d; va.step = step; va.out = Xt;
-                hipLaunchKernelGGL(k_newton_trial, dim3(nb_n), dim3(kThreads), 0, stream, va);
-                if (ls == 0) {
-                    HIP_CHECK(hipMemcpyAsync(h_newton, q_gd.d, nb_n * sizeof(double), hipMemcpyDeviceToHost, stream));
-                    HIP_CHECK(hipStreamSynchronize(stream));
-                    for (int i = 0; i < nb_n; ++i) gd += h_newton[i];
-                }
-                double Ft = 0, gt = 0;
-                newton_eval(Xt, &Ft, &gt);   // note: overwrites q_g / r / B with the trial point's
-                const bool armijo = Ft <= F + 1e-4 * step * gd;
-                const bool tiny = std::fabs(step * gd) <= 1e-13 * std::max(1.0, std::fabs(F));
-                if ((Ft == Ft) && (armijo || (tiny && gt < gn))) {
-                    std::swap(X, Xt);
-                    F = Ft; gn = gt;
-                    accepted = true;
-                    break;
-                }
-                step *= 0.5;
-                // the gradient buffer now belongs to the rejected trial: restore it for the next g'delta
-                if (ls == 0) { /* gd already taken */ }
-            }
-            if (st.verbose) std::fprintf(stderr, "[score] newton it %d F %.12g |g| %.3e step %.3g cg %d\n", it + 1, F, gn, step, cg_tot);
-            if (!accepted) {
-                double Fx = 0, gx = 0;
-                newton_eval(X, &Fx, &gx);  // re-establish nu / B / g of the accepted point
-                ok = true;  // stalled in rounding: the residual test of the driver decides
-                break;
-            }
-        }
-        *newton_iters = it;
-        *cg_used = cg_tot;
-        // hand the polished point to the ADMM state: x, x~, s, y, then u and K x~
-        va.u = X; va.delta = X; va.step = 0.0; va.out = Xt;
-        hipLaunchKernelGGL(k_polish_copy_x, dim3(nb_n), dim3(kThreads), 0, stream, va, xy.d, xtu.d);
-        FinishArgs fa2{};
-        fa2.P = polish_args(X);
-        fa2.x = xy.d; fa2.xt = xtu.d; fa2.s = this->s.d; fa2.y = xy.d + h.n_tot;
-        hipLaunchKernelGGL(k_polish_finish, dim3((unsigned)q_fpart.n), dim3(kThreads), 0, stream, fa2);
-        if (n_cone_blocks) hipLaunchKernelGGL(k_refresh_u, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xtu.d));
-        {
-            SpmvArgs a = spmv_args(K, xtu.d);
-            a.p = xtu.d; a.w = kx.d;
-            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
-        }
-        HIP_CHECK(hipStreamSynchronize(stream));
-        HIP_CHECK(hipGetLastError());
-        return ok;
-    }
-
     void time_kernel(const std::string& which, int reps, double* ms) {
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = done.d;
         pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d;
-        pa.r = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d;
+        pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d;
         pa.pw_part = pw_part.d; pa.rz_in = rz_part0.d; pa.rz_out = rz_part1.d;
         VecArgs va{};
         va.first_row = K.first_row.d; va.blk_prob = K.blk_prob.d; va.done = done.d;

@@ -393,9 +393,46 @@ struct PrecArgs {
     double* rz_out;        // one partial per work item
     unsigned long long* tstamp;  // see KernelStamp
     int debug_skip;        // timing experiments only: 1 run, 2 separator, 4 back-subst, 8 head, 16 tail
+    // Device-side termination of a PCG solve (the Newton polish; null in the ADMM loop, whose PCG
+    // count is fixed).  The first STEP of a solve (gate_first) turns r'z_0 into the problem's
+    // threshold tol2[prob] * r'z_0; every later STEP compares the r'z it is about to use with it
+    // and, once below, raises done[prob] -- the flag every kernel of the loop tests on entry -- and
+    // leaves without touching anything: the launches still queued for that problem become no-ops,
+    // and the host reads one flag at its next synchronisation instead of polling r'z every few
+    // iterations.  All workgroups of a problem reduce the same partials in the same order, so they
+    // take the same decision.
+    const double* r_in;    // residual as it stands at entry (== r, except for the first kernels of a Newton PCG solve,
+                           // which read the right-hand side -g where the evaluation left it); r receives updates
+    int xt_zero;           // STEP: treat xt as zero on entry (first step of a solve: no memset of the solution)
+    int32_t* gate_init;    // INIT: per problem, copy done[prob] here and clear gate_used (start of a gated solve)
+    int32_t* gate_flag;        // == done (writable)
+    const double* gate_tol2;   // per problem: (relative tolerance)^2
+    double* gate_ref;          // per problem: threshold
+    int32_t* gate_used;        // per problem: STEPs executed
+    int gate_first;
 };
 
 enum { PREC_INIT = 0, PREC_STEP = 1 };
+
+// returns true when the problem's PCG has converged (uniform over the workgroup)
+__device__ __forceinline__ bool pcg_gate(const PrecArgs& a, int prob, double rz, double ref_loaded) {
+    if (!a.gate_flag) return false;
+    const bool lead = (threadIdx.x == 0) && ((int)blockIdx.x == a.prec_part_ptr[prob]);
+    if (a.gate_first) {
+        if (!(rz > 0.0)) {
+            if (lead) a.gate_flag[prob] = 1;
+            return true;
+        }
+        if (lead) { a.gate_ref[prob] = rz * a.gate_tol2[prob]; a.gate_used[prob] = 1; }
+        return false;
+    }
+    if (!(rz > ref_loaded)) {  // converged (or NaN: stop, the host sees it in F)
+        if (lead) a.gate_flag[prob] = 1;
+        return true;
+    }
+    if (lead) a.gate_used[prob] += 1;
+    return false;
+}
 
 constexpr int kPrecThreads = 512;
 constexpr int kPrecWaves = kPrecThreads / 64;
@@ -428,12 +465,15 @@ __device__ __forceinline__ void load_run(const double* __restrict__ fac, const C
 // Jacobi work item (columns outside every chain): z = r / diag(K), with the PCG step folded in.
 template <int MODE>
 __device__ __forceinline__ double prec_jacobi_item(const PrecArgs& a, const PrecWork& wk, double acc_rz, double acc_pw,
-                                                   double* red) {
+                                                   double* red, bool& stop) {
     const int t = threadIdx.x;
     double alpha = 0.0, local = 0.0;
+    stop = false;
     if (MODE == PREC_STEP) {
+        const double gref = (a.gate_flag && !a.gate_first) ? a.gate_ref[wk.prob] : 0.0;
         block_sum2_n<kPrecWaves>(acc_rz, acc_pw, red);
         alpha = acc_pw > 0.0 ? acc_rz / acc_pw : 0.0;
+        if (pcg_gate(a, wk.prob, acc_rz, gref)) { stop = true; return 0.0; }
     }
     // Jacobi columns.  Every load is unconditional on a clamped index so that the
     // whole chunk is in flight at once; only the stores are predicated.
@@ -445,9 +485,9 @@ __device__ __forceinline__ double prec_jacobi_item(const PrecArgs& a, const Prec
         for (int u = 0; u < kPrecChunk; ++u) cols[u] = a.diag_cols[min(base + u * kPrecThreads, e_end - 1)];
 #pragma unroll
         for (int u = 0; u < kPrecChunk; ++u) {
-            rv[u] = a.r[cols[u]];
+            rv[u] = a.r_in[cols[u]];
             dv[u] = a.dinv[min(base + u * kPrecThreads, e_end - 1)];
-            if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt[cols[u]]; kv[u] = a.kx[cols[u]]; }
+            if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt_zero ? 0.0 : a.xt[cols[u]]; kv[u] = a.kx[cols[u]]; }
         }
 #pragma unroll
         for (int u = 0; u < kPrecChunk; ++u) {
@@ -483,6 +523,10 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
     double* red = lds;
     const PrecWork wk = a.work[blockIdx.x];
     const int prob = wk.prob;
+    if (MODE == PREC_INIT && a.gate_init && threadIdx.x == 0 && (int)blockIdx.x == a.prec_part_ptr[prob]) {
+        a.gate_init[prob] = a.done[prob];
+        a.gate_used[prob] = 0;
+    }
     if (a.done[prob]) return;
     const int t = threadIdx.x;
     // partial sums for alpha = r'z / p'w: loads first, reduction after the phase-0 loads are out
@@ -496,9 +540,12 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
     double alpha = 0.0;
     double local = 0.0;
     if (wk.kind == 1) {
-        local = prec_jacobi_item<MODE>(a, wk, acc_rz, acc_pw, red);
+        bool stop;
+        local = prec_jacobi_item<MODE>(a, wk, acc_rz, acc_pw, red, stop);
+        if (stop) return;
     } else {
         constexpr int B2 = BS * BS;
+        const double gref = (MODE == PREC_STEP && a.gate_flag && !a.gate_first) ? a.gate_ref[prob] : 0.0;
         const ChainDesc ch = a.chains[wk.index];
         const ChainLevelDesc* __restrict__ lv = a.levels + ch.level_begin;
         const int32_t* __restrict__ nc = a.node_col + ch.node_begin;
@@ -508,6 +555,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
         const int nl = ch.n_levels;
         const int stride = ch.col_stride, col0 = ch.col0;
         auto colof = [&](int node) -> int { return stride ? col0 + node * stride : nc[node]; };
+        // the residual after this kernel's own update: STEP writes it to r, INIT leaves it where it was
+        const double* __restrict__ rcur = (MODE == PREC_INIT) ? a.r_in : a.r;
         double* v0 = lds + 16;                                      // level-0 vector (LDS0)
         double* vup = lds + 16 + (LDS0 ? (size_t)NB : (size_t)0);  // levels >= 1
         // level table -> LDS (read by every phase; one batch of loads instead of one per level)
@@ -531,8 +580,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
                 }
 #pragma unroll
                 for (int u = 0; u < kPrecChunk; ++u) {
-                    rv[u] = a.r[cols[u]];
-                    if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt[cols[u]]; kv[u] = a.kx[cols[u]]; }
+                    rv[u] = a.r_in[cols[u]];
+                    if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt_zero ? 0.0 : a.xt[cols[u]]; kv[u] = a.kx[cols[u]]; }
                 }
             };
             auto chunk_apply = [&](int base) {
@@ -555,6 +604,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
             if (MODE == PREC_STEP) {
                 block_sum2_n<kPrecWaves>(acc_rz, acc_pw, red);
                 alpha = acc_pw > 0.0 ? acc_rz / acc_pw : 0.0;
+                if (pcg_gate(a, prob, acc_rz, gref)) return;
             }
             chunk_apply(t);
             for (int base = t + kPrecThreads * kPrecChunk; base < NB; base += kPrecThreads * kPrecChunk) {
@@ -566,7 +616,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
         auto vld = [&](int l, const ChainLevelDesc& Lx, int i, int c, bool input) -> double {
             if (l == 0) {
                 if (LDS0) return v0[i * BS + c];
-                return input ? a.r[colof(i) + c] : a.z[colof(i) + c];
+                return input ? rcur[colof(i) + c] : a.z[colof(i) + c];
             }
             return vup[(size_t)(Lx.vec_off + i) * BS + c];
         };
@@ -761,7 +811,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
 #pragma unroll
             for (int u = 0; u < kPrecChunk; ++u) {
                 const int idx = min(base + u * kPrecThreads, NB - 1);
-                rv[u] = a.r[cols[u]];
+                rv[u] = rcur[cols[u]];
                 zz[u] = LDS0 ? v0[idx] : a.z[cols[u]];
             }
 #pragma unroll
@@ -835,6 +885,10 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
     double* red = lds;
     const PrecWork wk = a.work[blockIdx.x];
     const int prob = wk.prob;
+    if (MODE == PREC_INIT && a.gate_init && threadIdx.x == 0 && (int)blockIdx.x == a.prec_part_ptr[prob]) {
+        a.gate_init[prob] = a.done[prob];
+        a.gate_used[prob] = 0;
+    }
     if (a.done[prob]) return;
     const int t = threadIdx.x;
     double acc_rz = 0.0, acc_pw = 0.0;
@@ -846,8 +900,11 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
     }
     double local = 0.0;
     if (wk.kind == 1) {
-        local = prec_jacobi_item<MODE>(a, wk, acc_rz, acc_pw, red);
+        bool stop;
+        local = prec_jacobi_item<MODE>(a, wk, acc_rz, acc_pw, red, stop);
+        if (stop) return;
     } else {
+        const double gref = (MODE == PREC_STEP && a.gate_flag && !a.gate_first) ? a.gate_ref[prob] : 0.0;
         const ChainDesc ch = a.chains[wk.index];
         const ChainLevelDesc* __restrict__ lv = a.levels + ch.level_begin;
         const int32_t* __restrict__ nc = a.node_col + ch.node_begin;
@@ -886,7 +943,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < kPrecChunk; ++u) {
-            rv[u] = a.r[cols[u]];
+            rv[u] = a.r_in[cols[u]];
             if (MODE == PREC_STEP) wv[u] = a.w[cols[u]];
         }
         // ---- factor loads: level 0 -> registers (lanes < 256), coarser levels -> staging ----
@@ -935,6 +992,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         if (MODE == PREC_STEP) {
             block_sum2_n<kPrecWaves>(acc_rz, acc_pw, red);
             alpha = acc_pw > 0.0 ? acc_rz / acc_pw : 0.0;
+            if (pcg_gate(a, prob, acc_rz, gref)) return;
         }
 #pragma unroll
         for (int u = 0; u < kPrecChunk; ++u) {
@@ -1060,7 +1118,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             constexpr int u0 = decltype(half)::value * kHalf;
 #pragma unroll
             for (int u = 0; u < kHalf; ++u) {
-                pv[u] = a.p[cols[u0 + u]]; wq[u] = a.w[cols[u0 + u]]; xv[u] = a.xt[cols[u0 + u]]; kv[u] = a.kx[cols[u0 + u]];
+                pv[u] = a.p[cols[u0 + u]]; wq[u] = a.w[cols[u0 + u]]; xv[u] = a.xt_zero ? 0.0 : a.xt[cols[u0 + u]]; kv[u] = a.kx[cols[u0 + u]];
             }
         };
         auto upd_store = [&](auto half) {
