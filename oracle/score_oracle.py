@@ -359,6 +359,113 @@ def newton_solve(data, tol: float = 1e-11, max_iter: int = 200, verbose: bool = 
     return rp, u, info
 
 
+def gauge_basis(rp: ReducedProblem) -> np.ndarray:
+    """A basis (n x k, dense) of the null space of the ODOMETRY part of the objective, which
+    contains the null space of the whole generalised Hessian: the directions along which the
+    relative-pose costs (gurobi_utils.py:504-526) do not change.  For every pose chain whose first
+    pose is free, perturbing that pose by (dR_0, dt_0) and propagating dR_{i+1} = dR_i Rm_i,
+    dt_{i+1} = dt_i + dR_i tm_i along the chain leaves every odometry residual unchanged
+    (d^2 + d directions per chain; none for the chain that holds the pinned pose, and the
+    remainder of a chain cut by the pin starts at a fixed pose).  Every landmark coordinate is a
+    direction of its own (landmarks appear in no odometry term)."""
+    d = rp.dim
+    cols = []
+    for chain, odo in zip(rp.data.pose_variables, rp.data.odom_measurements):
+        names = [p.name for p in chain]
+        if rp.first_pose in names and names[0] == rp.first_pose:
+            continue  # rooted at the pinned pose
+        if rp.first_pose in names:
+            raise NotImplementedError("pinned pose in the interior of a chain")
+        by_edge = {(m.base_pose, m.to_pose): m for m in odo}
+        for a in range(d):
+            for b in range(d + 1):  # unit perturbation of entry (a, b) of [R_0 | t_0]
+                v = np.zeros(rp.n)
+                dR = np.zeros((d, d)); dt = np.zeros(d)
+                if b < d:
+                    dR[a, b] = 1.0
+                else:
+                    dt[a] = 1.0
+                for i, nm in enumerate(names):
+                    c = rp.col[nm]
+                    blk = np.hstack([dR, dt[:, None]])
+                    v[c : c + d * (d + 1)] = blk.ravel()
+                    if i + 1 < len(names):
+                        m = by_edge[(nm, names[i + 1])]
+                        dt = dt + dR @ np.asarray(m.translation_vector, dtype=float)
+                        dR = dR @ np.asarray(m.rotation_matrix, dtype=float)
+                cols.append(v)
+    for nm in rp.landmark_names:
+        for k in range(d):
+            v = np.zeros(rp.n)
+            v[rp.col[nm] + k] = 1.0
+            cols.append(v)
+    return np.stack(cols, axis=1) if cols else np.zeros((rp.n, 0))
+
+
+def determined_masks(rp: ReducedProblem, u: np.ndarray, rel_tol: float = 1e-9, active_tol: float = 1e-8):
+    """Which poses / landmarks does the optimum determine uniquely?  Computed from the oracle's own
+    objects only (no second solver).  F is convex and piecewise quadratic, so near an optimum u the
+    optimal set is u + {v : H v = 0} with H the generalised Hessian at u (cones strictly active /
+    strictly slack).  null(H) lies inside the span of gauge_basis(); restricted to that small basis
+    N the test is an eigen-decomposition of N'HN.  A variable is determined iff its entries vanish in
+    every null direction.  Returns (pose_mask, landmark_mask, info)."""
+    d = rp.dim
+    # generalised Hessian with STRICTLY active cones only: a cone whose excess is zero to rounding
+    # (the iterate sits on the boundary of a slack region) does not pin anything -- the variable may
+    # move inwards at no cost
+    H = rp.H0
+    if rp.nr:
+        dl = rp.deltas(u)
+        rho = np.linalg.norm(dl, axis=1)
+        act = (rho - rp.dist) > active_tol * max(1.0, float(np.abs(u).max()))
+        uh = np.zeros_like(dl)
+        nz = rho > 0
+        uh[nz] = dl[nz] / rho[nz, None]
+        a = np.where(act & nz, 1.0 - rp.dist / np.where(nz, rho, 1.0), 0.0)
+        uu = uh[:, :, None] * uh[:, None, :]
+        blocks = 2.0 * rp.wr[:, None, None] * np.where(act[:, None, None], a[:, None, None] * (np.eye(d)[None] - uu) + uu, 0.0)
+        B = sp.block_diag(list(blocks), format="csr")
+        H = (rp.H0 + rp.D.T @ B @ rp.D).tocsc()
+    N = gauge_basis(rp)
+    if N.shape[1] == 0:
+        return np.ones(len(rp.pose_names), bool), np.ones(len(rp.landmark_names), bool), {"null_dim": 0, "basis": 0}
+    # scale the basis columns: propagated translations grow along a chain
+    N = N / np.maximum(1e-300, np.abs(N).max(axis=0))
+    G = N.T @ (H @ N)
+    G = 0.5 * (G + G.T)
+    w, V = np.linalg.eigh(G)
+    top = max(float(w.max()), 1e-300)
+    null = V[:, w <= rel_tol * top]
+    Z = N @ null  # n x null_dim
+    zmax = np.abs(Z).max() if Z.size else 0.0
+    pose_mask = np.ones(len(rp.pose_names), bool)
+    for i, nm in enumerate(rp.pose_names):
+        if nm == rp.first_pose or Z.shape[1] == 0:
+            continue
+        c = rp.col[nm]
+        pose_mask[i] = np.abs(Z[c : c + d * (d + 1)]).max() <= 1e-7 * max(1.0, zmax)
+    lm_mask = np.ones(len(rp.landmark_names), bool)
+    for i, nm in enumerate(rp.landmark_names):
+        if Z.shape[1] == 0:
+            continue
+        c = rp.col[nm]
+        lm_mask[i] = np.abs(Z[c : c + d]).max() <= 1e-7 * max(1.0, zmax)
+    return pose_mask, lm_mask, {"null_dim": int(Z.shape[1]), "basis": int(N.shape[1]),
+                                "eigs": w.tolist()}
+
+
+def optimal_residuals(rp: ReducedProblem, u: np.ndarray):
+    """Quantities every optimum shares even where the poses themselves are not unique: F is a
+    strictly convex function of the residual vector, so the weighted relative-pose residuals J u - c
+    and the range excesses max(0, |D u + e| - dist) are the same at every minimiser."""
+    res = rp.J @ u - rp.c
+    if rp.nr:
+        ex = np.maximum(0.0, np.linalg.norm(rp.deltas(u), axis=1) - rp.dist)
+    else:
+        ex = np.zeros(0)
+    return res, ex
+
+
 def reduced_to_values(rp: ReducedProblem, u: np.ndarray, relaxation: str):
     """Expand the reduced optimum to the reference's variables: SOCP
     d_ij = max(|D|, dist); QCQP r_ij = D / max(|D|, dist)  (SURVEY.md 3.3)."""

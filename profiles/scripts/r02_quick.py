@@ -1,6 +1,6 @@
 """Quick timing of the product default solver (ADMM warm-up + Newton polish) on the BASELINE sizes,
 and of BASELINE configs[4] on one GPU.  python profiles/scripts/r02_quick.py [mc]"""
-import sys, time; sys.path.insert(0, '.')
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from score_amd.assemble import assemble
 from score_amd.manhattan import make_manhattan

@@ -287,6 +287,9 @@ class SolverResults:
     pose_chain_names: Optional[list] = None
     solver_cost: Optional[float] = None
     info: Optional[dict] = None  # ADMM statistics (not in the reference type)
+    # the relaxation's own variables before SO(d) rounding (not in the reference type): the d x (d+1)
+    # blocks [R | t] the convex program returned, for diagnostics and parity checks
+    relaxed_poses: Optional[dict] = None
 
     @property
     def poses(self):

@@ -218,9 +218,9 @@ struct HipBackend {
     DevBuf<double> q_step;
     DevBuf<int64_t> q_seg_begin, q_seg_end;
     static constexpr int kFlagSlots = 32;
-    char* h_ring = nullptr;      // pinned ring of upload slots
+    char* h_ring = nullptr;      // pinned (host-mapped) ring of upload slots
     size_t ring_slot_bytes = 0;
-    int flag_slot = 0;
+    int flag_slot = 0, ring_used = 0;
     DevBuf<double> q_negg;                   // -gradient of the last evaluation (right-hand side of the next PCG)
     DevBuf<double> q_gate_tol2, q_gate_ref;  // device-side PCG termination (pcg_gate)
     DevBuf<int32_t> q_gate_used;
@@ -229,9 +229,20 @@ struct HipBackend {
     // Everything the host reads back between launches lives in ONE device allocation, mirrored by
     // one pinned host buffer, so that a convergence check (ADMM) or a Newton iteration costs a
     // single device-to-host copy:  [pres | dres | fpart | gd | gate flags, gate counts]
-    DevBuf<double> rep;
+    DevBuf<double> rep;          // window: the device address of h_rep (host-mapped pinned memory)
     double* h_rep = nullptr;
     size_t rep_dres_off = 0;     // doubles
+    // Kernels write their per-workgroup partials straight into that host-mapped memory; small device
+    // arrays the device itself reads (r'z measurements, PCG gate words) are pushed there by k_push,
+    // which then publishes a sequence number the host spins on: no copy command, no stream
+    // synchronisation on the path of a convergence check or a Newton iteration.
+    unsigned long long* h_seq = nullptr;   // [0]: last published sequence number (host-mapped)
+    unsigned long long* d_seq = nullptr;
+    unsigned long long seq_next = 0;
+    double* h_meas = nullptr;    // [rz_meas0 | rz_meas1] as pushed
+    double* d_meas = nullptr;
+    int32_t* d_gate_host = nullptr;  // device address of h_gate
+    char* d_ring = nullptr;      // device address of h_ring
     size_t n_fpart = 0, n_gd = 0;
     // ... and everything the host tells the kernels per problem in one upload: [step | tol2 | skip]
     DevBuf<double> ctl;
@@ -362,22 +373,26 @@ struct HipBackend {
         {   // the report arena (see `rep`) and the control block (see `ctl`)
             const size_t n_pres = (size_t)std::max(1, n_cone_blocks) * kPartStride, n_dres = (size_t)G2.nblocks * kPartStride;
             const size_t n_int = (2 * (size_t)h.count + 1) / 2;  // 2 * count int32
-            rep.alloc(n_pres + n_dres + n_fpart + n_gd + n_int);
-            rep.zero(stream);
-            HIP_CHECK(hipHostMalloc((void**)&h_rep, rep.n * sizeof(double)));
-            std::memset(h_rep, 0, rep.n * sizeof(double));
+            const size_t n_meas = 2 * (size_t)std::max(1, n_prec);
+            const size_t total = n_pres + n_dres + n_fpart + n_gd + n_meas + n_int + 1;
+            HIP_CHECK(hipHostMalloc((void**)&h_rep, total * sizeof(double), hipHostMallocMapped));
+            std::memset(h_rep, 0, total * sizeof(double));
+            double* d_rep = nullptr;
+            HIP_CHECK(hipHostGetDevicePointer((void**)&d_rep, h_rep, 0));
+            rep.view(d_rep, total);
             rep_dres_off = n_pres;
-            pres_part.view(rep.d, n_pres);
-            dres_part.view(rep.d + n_pres, n_dres);
-            q_fpart.view(rep.d + n_pres + n_dres, n_fpart);
-            q_gd.view(rep.d + n_pres + n_dres + n_fpart, n_gd);
-            q_pcgdone.view((int32_t*)(rep.d + n_pres + n_dres + n_fpart + n_gd), h.count);
+            size_t o = 0;
+            pres_part.view(d_rep + o, n_pres); h_pres = h_rep + o; o += n_pres;
+            dres_part.view(d_rep + o, n_dres); h_dres = h_rep + o; o += n_dres;
+            q_fpart.view(d_rep + o, n_fpart); h_newton = h_rep + o; o += n_fpart;
+            q_gd.view(d_rep + o, n_gd); h_gd = h_rep + o; o += n_gd;
+            h_meas = h_rep + o; d_meas = d_rep + o; o += n_meas;
+            h_gate = (int32_t*)(h_rep + o); d_gate_host = (int32_t*)(d_rep + o); o += n_int;
+            h_seq = (unsigned long long*)(h_rep + o); d_seq = (unsigned long long*)(d_rep + o);
+            // device-resident words the kernels read: gate flags and counts, control block
+            q_pcgdone.alloc(2 * (size_t)h.count);
+            q_pcgdone.zero(stream);
             q_gate_used.view(q_pcgdone.d + h.count, h.count);
-            h_pres = h_rep;
-            h_dres = h_rep + n_pres;
-            h_newton = h_rep + n_pres + n_dres;
-            h_gd = h_rep + n_pres + n_dres + n_fpart;
-            h_gate = (int32_t*)(h_rep + n_pres + n_dres + n_fpart + n_gd);
             ctl.alloc(2 * (size_t)h.count + ((size_t)h.count + 1) / 2);
             q_step.view(ctl.d, h.count);
             q_gate_tol2.view(ctl.d + h.count, h.count);
@@ -424,11 +439,61 @@ struct HipBackend {
         HIP_CHECK(hipStreamSynchronize(stream));
     }
 
+    // Stream-ordered uploads of small per-problem arrays without a host synchronisation and without
+    // the copy engine: the words go through a ring of host-mapped pinned slots and a one-workgroup
+    // kernel fetches them (every wait_published() drains the stream long before the ring wraps).
+    char* next_ring_slot(size_t bytes) {
+        const size_t need = (bytes + 63) & ~(size_t)63;
+        if (need > ring_slot_bytes) {
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (h_ring) (void)hipHostFree(h_ring);
+            h_ring = nullptr;
+            ring_slot_bytes = std::max<size_t>(need, 256);
+            HIP_CHECK(hipHostMalloc((void**)&h_ring, kFlagSlots * ring_slot_bytes, hipHostMallocMapped));
+            HIP_CHECK(hipHostGetDevicePointer((void**)&d_ring, h_ring, 0));
+            ring_used = 0;
+        }
+        if (++ring_used >= kFlagSlots) {  // about to reuse a slot a queued fetch may not have read yet
+            HIP_CHECK(hipStreamSynchronize(stream));
+            ring_used = 1;
+        }
+        flag_slot = (flag_slot + 1) % kFlagSlots;
+        return h_ring + (size_t)flag_slot * ring_slot_bytes;
+    }
+    void fetch_words(int32_t* dev_dst, const char* slot, int n_words) {
+        const int32_t* src = (const int32_t*)(d_ring + (slot - h_ring));
+        hipLaunchKernelGGL(k_fetch, dim3(1), dim3(kThreads), 0, stream, src, dev_dst, n_words);
+    }
     void set_done(const std::vector<int>& d) {
-        HIP_CHECK(hipStreamSynchronize(stream));
-        std::vector<int32_t> v(d.begin(), d.end());
-        HIP_CHECK(hipMemcpyAsync(done.d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+        int32_t* v = (int32_t*)next_ring_slot(d.size() * sizeof(int32_t));
+        for (size_t i = 0; i < d.size(); ++i) v[i] = d[i];
+        fetch_words(done.d, (const char*)v, (int)d.size());
+    }
+    // Publish: push up to three small device arrays into the host-mapped arena and raise the
+    // sequence number; wait: spin on it (falls back to a stream synchronisation, which also surfaces
+    // device errors, when it does not arrive within 2 s).
+    unsigned long long publish(const void* s0 = nullptr, void* d0 = nullptr, size_t w0 = 0, const void* s1 = nullptr, void* d1 = nullptr,
+                               size_t w1 = 0, const void* s2 = nullptr, void* d2 = nullptr, size_t w2 = 0) {
+        PushArgs a{};
+        a.src[0] = (const unsigned long long*)s0; a.dst[0] = (unsigned long long*)d0; a.n[0] = (int)w0;
+        a.src[1] = (const unsigned long long*)s1; a.dst[1] = (unsigned long long*)d1; a.n[1] = (int)w1;
+        a.src[2] = (const unsigned long long*)s2; a.dst[2] = (unsigned long long*)d2; a.n[2] = (int)w2;
+        a.flag = d_seq; a.seq = ++seq_next;
+        hipLaunchKernelGGL(k_push, dim3(1), dim3(kThreads), 0, stream, a);
+        return a.seq;
+    }
+    void wait_published(unsigned long long seq) {
+        HIP_CHECK(hipGetLastError());
+        const auto t0 = std::chrono::steady_clock::now();
+        int spins = 0;
+        while (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) < seq) {
+            if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+                HIP_CHECK(hipStreamSynchronize(stream));
+                if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) < seq) throw std::runtime_error("device did not publish its results");
+                break;
+            }
+        }
+        ring_used = 0;  // everything queued before the publish has run: all ring slots are free again
     }
 
     void reset() {
@@ -528,12 +593,9 @@ struct HipBackend {
         const HostSystem& h = *H;
         out.assign(h.count, 0.0);
         if (n_prec == 0) return;
-        HIP_CHECK(hipStreamSynchronize(stream));
-        std::vector<double> a(n_prec), b2(n_prec);
-        HIP_CHECK(hipMemcpyAsync(a.data(), rz_meas0.d, sizeof(double) * n_prec, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        HIP_CHECK(hipMemcpyAsync(b2.data(), rz_meas1.d, sizeof(double) * n_prec, hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+        // (pushed into the host-mapped arena by the last residuals() call)
+        const double* a = h_meas;
+        const double* b2 = h_meas + n_prec;
         for (int pi = 0; pi < h.count; ++pi) {
             double s0 = 0, s1 = 0;
             for (int i = h.prec_part_ptr[pi]; i < h.prec_part_ptr[pi + 1]; ++i) { s0 += a[i]; s1 += b2[i]; }
@@ -690,10 +752,9 @@ struct HipBackend {
         if (n_cone_blocks)
             hipLaunchKernelGGL(k_pres, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xy.d));
         hipLaunchKernelGGL(k_spmv<MODE_DRES>, dim3(G2.nblocks), dim3(kThreads), 0, stream, spmv_args(G2, xy.d));
-        // [pres | dres] are adjacent in the report arena: one copy
-        HIP_CHECK(hipMemcpyAsync(h_rep, rep.d, (pres_part.n + dres_part.n) * sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        HIP_CHECK(hipGetLastError());
+        // the partials land in host-mapped memory as the kernels write them; the r'z measurements of the
+        // last iteration of the launch graph are pushed there, then the sequence number
+        wait_published(publish(rz_meas0.d, d_meas, (size_t)n_prec, rz_meas1.d, d_meas + n_prec, (size_t)n_prec));
         for (int pi = 0; pi < h.count; ++pi) {
             ResidualSums a;
             for (int bl = h.cone_part_ptr[pi]; bl < h.cone_part_ptr[pi + 1]; ++bl) {
@@ -868,21 +929,6 @@ struct HipBackend {
         bt.skip = q_skip.d; bt.step = q_step.d;
         return bt;
     }
-    // Stream-ordered uploads of small per-problem arrays without a host synchronisation: the data
-    // go through a ring of pinned slots (every evaluation of F synchronises the stream, long
-    // before the ring wraps).
-    char* next_ring_slot(size_t bytes) {
-        const size_t need = (bytes + 63) & ~(size_t)63;
-        if (need > ring_slot_bytes) {
-            HIP_CHECK(hipStreamSynchronize(stream));
-            if (h_ring) (void)hipHostFree(h_ring);
-            h_ring = nullptr;
-            ring_slot_bytes = std::max<size_t>(need, 256);
-            HIP_CHECK(hipHostMalloc((void**)&h_ring, kFlagSlots * ring_slot_bytes));
-        }
-        flag_slot = (flag_slot + 1) % kFlagSlots;
-        return h_ring + (size_t)flag_slot * ring_slot_bytes;
-    }
     // one upload of the per-problem control block [step | tol2 | skip]
     std::vector<double> c_step, c_tol2;
     std::vector<int32_t> c_skip;
@@ -892,7 +938,7 @@ struct HipBackend {
         std::memcpy(v, c_step.data(), c * sizeof(double));
         std::memcpy(v + c * sizeof(double), c_tol2.data(), c * sizeof(double));
         std::memcpy(v + 2 * c * sizeof(double), c_skip.data(), c * sizeof(int32_t));
-        HIP_CHECK(hipMemcpyAsync(ctl.d, v, 2 * c * sizeof(double) + c * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+        fetch_words((int32_t*)ctl.d, v, (int)(4 * c + c));
     }
     void upload_skip(const std::vector<char>& live) {  // skip = !live
         for (size_t i = 0; i < live.size(); ++i) c_skip[i] = live[i] ? 0 : 1;
@@ -912,9 +958,11 @@ struct HipBackend {
         // resumed after the evaluation of a trial point
         ga.is_head = q_ishead.d; ga.gout = q_g.d; ga.r = q_negg.d; ga.done = q_skip.d;
         hipLaunchKernelGGL(k_spmv<MODE_GRAD>, dim3(G2.nblocks), dim3(kThreads), 0, stream, ga);
-        // [dres | fpart | gd | gate flags and counts]: adjacent in the report arena, one copy
-        HIP_CHECK(hipMemcpyAsync(h_dres, dres_part.d, (rep.n - rep_dres_off) * sizeof(double), hipMemcpyDeviceToHost, stream));
+        // F and gradient partials land in host-mapped memory as the kernels write them; the PCG gate
+        // words (device-resident: the kernels read them) are pushed, then the sequence number
+        eval_seq = publish(q_pcgdone.d, d_gate_host, ((size_t)2 * H->count + 1) / 2);
     }
+    unsigned long long eval_seq = 0;
     // after the synchronisation: F and |grad|_inf of the problems in `which`
     void newton_eval_collect(const std::vector<char>& which, std::vector<double>& F, std::vector<double>& gn) {
         const HostSystem& h = *H;
@@ -933,8 +981,7 @@ struct HipBackend {
     }
     void newton_eval_batch(double* Xbuf, const std::vector<char>& which, std::vector<double>& F, std::vector<double>& gn) {
         newton_eval_enqueue(Xbuf);
-        HIP_CHECK(hipStreamSynchronize(stream));
-        HIP_CHECK(hipGetLastError());
+        wait_published(eval_seq);
         newton_eval_collect(which, F, gn);
     }
 
@@ -972,7 +1019,7 @@ struct HipBackend {
         } else {
             // flags of the problems that go on: lowered again (their gates had not fired; the host's skip
             // flags now hold exactly the resumed set)
-            HIP_CHECK(hipMemcpyAsync(q_pcgdone.d, q_skip.d, h.count * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+            hipLaunchKernelGGL(k_fetch, dim3(1), dim3(kThreads), 0, stream, (const int32_t*)q_skip.d, q_pcgdone.d, h.count);
         }
         pa.done = q_pcgdone.d;
         pa.gate_flag = q_pcgdone.d; pa.gate_tol2 = q_gate_tol2.d; pa.gate_ref = q_gate_ref.d;
@@ -1056,8 +1103,7 @@ struct HipBackend {
                 va.u = X; va.delta = q_delta.d; va.step = 0.0; va.out = Xt;
                 hipLaunchKernelGGL(k_newton_trial_b, dim3(nbh), dim3(kThreads), 0, stream, va, batch_tables());
                 newton_eval_enqueue(Xt);  // overwrites nu / B / g of the problems searched; copies gd and the gate words too
-                HIP_CHECK(hipStreamSynchronize(stream));  // the one synchronisation of a Newton iteration (step 1 accepted)
-                HIP_CHECK(hipGetLastError());
+                wait_published(eval_seq);  // the one wait of a Newton iteration (step 1 accepted)
                 if (k == 0) {
                     // a problem whose queue ran dry before its gate fired resumes its PCG (state intact);
                     // the trial point and its evaluation are then redone

@@ -1560,6 +1560,36 @@ __global__ __launch_bounds__(kThreads) void k_pres(ConeArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// host <-> device words without the copy engine.  A hipMemcpyAsync between two kernels of a stream
+// costs the copy kernel plus 10..50 us of cross-queue signalling (measured, rocprofv3 timeline);
+// these one-workgroup kernels run in the stream's own queue instead.
+//   k_push : up to 3 small device arrays -> host-mapped pinned memory, then a sequence number the
+//            host spins on (everything earlier in the stream -- including partials that kernels wrote
+//            straight into host-mapped memory -- has completed before this kernel starts)
+//   k_fetch: host-mapped pinned memory -> a small device array (control words)
+// ---------------------------------------------------------------------------
+struct PushArgs {
+    const unsigned long long* src[3];
+    unsigned long long* dst[3];
+    int n[3];                       // 8-byte words
+    unsigned long long* flag;       // host-mapped
+    unsigned long long seq;
+};
+__global__ __launch_bounds__(kThreads) void k_push(PushArgs a) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        for (int i = threadIdx.x; i < a.n[k]; i += kThreads) a.dst[k][i] = a.src[k][i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(a.flag, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+__global__ __launch_bounds__(kThreads) void k_fetch(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int n_words) {
+    for (int i = threadIdx.x; i < n_words; i += kThreads) dst[i] = src[i];
+}
+
 // launch-overhead probes (debug timing only)
 __global__ void k_nop(int* sink) { if (sink && threadIdx.x == 9999) sink[0] = 1; }
 __global__ void k_nop_load(const int32_t* a, const int32_t* b2, int* sink) {

@@ -86,6 +86,7 @@ def extract_solver_results(
     return compat.SolverResults(
         variables=values, total_time=total_time, solved=solved,
         pose_chain_names=data.get_pose_chain_names(), solver_cost=(info or {}).get("pobj"), info=info,
+        relaxed_poses=dict(zip(model.pose_names, blocks.copy())),
     )
 
 

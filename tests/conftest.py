@@ -83,10 +83,44 @@ def load_golden(name):
 
 
 SYNTH = {
-    "synth_a": dict(n_robots=1, n_poses=60, n_beacons=2, seed=11),
+    # one robot densely ranged to three beacons: 34 of 119 cones active, every landmark determined
+    "synth_a": dict(n_robots=1, n_poses=60, n_beacons=3, seed=11, p_range=0.6),
+    # three robots with loop closures: the two unpinned robots keep gauge freedom, no landmark is determined
     "synth_b": dict(n_robots=3, n_poses=50, n_beacons=3, seed=12, n_loop_closures=4),
+    # no beacons: robot-robot ranges only
     "synth_c": dict(n_robots=2, n_poses=120, n_beacons=0, seed=13, p_range=0.3),
+    # two robots, both determined through active cones; one of three landmarks is not
+    "synth_d": dict(n_robots=2, n_poses=50, n_beacons=3, seed=14, p_range=0.5),
 }
+GOLDEN_NAMES = ["manhattan", "goats", "synth_a", "synth_b", "synth_c", "synth_d", "graph3d"]
+
+
+def graph_3d(seed=5, n=12, n_lm=3):
+    """Small 3-D graph (one chain + landmarks + ranges + a prior + a loop closure)."""
+    import numpy as np
+
+    from score_amd import compat
+
+    rng = np.random.default_rng(seed)
+    fg = compat.FactorGraphData(dimension=3)
+    fg.pose_variables = [[compat.PoseVariable3D(f"A{i}", tuple(rng.normal(size=3))) for i in range(n)]]
+    fg.landmark_variables = [compat.LandmarkVariable3D(f"L{i}", tuple(rng.normal(size=3) * 5)) for i in range(n_lm)]
+
+    def rot():
+        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
+        if np.linalg.det(q) < 0:
+            q[:, -1] *= -1
+        return q
+
+    fg.odom_measurements = [[
+        compat.PoseMeasurement3D(f"A{i}", f"A{i+1}", rng.normal(size=3), rot(), 100.0 + i, 400.0 + i) for i in range(n - 1)
+    ]]
+    fg.loop_closure_measurements = [compat.PoseMeasurement3D("A2", "A9", rng.normal(size=3), rot(), 50.0, 70.0)]
+    for i in range(0, n, 2):
+        fg.range_measurements.append(compat.FGRangeMeasurement((f"A{i}", f"L{i % n_lm}"), float(rng.uniform(1, 6)), 0.5))
+    fg.landmark_priors = [compat.LandmarkPrior3D("L1", (1.0, -2.0, 0.5), 3.0)]
+    return fg
+
 
 
 def graph_by_name(name, fixtures):
@@ -94,6 +128,9 @@ def graph_by_name(name, fixtures):
 
     if name in fixtures:
         return fixtures[name]
+    if name == "graph3d":
+        # 3-D poses (gurobi_utils.py:37-50): chain + landmarks + ranges + a landmark prior (:433-446) + a loop closure
+        return graph_3d(n=40)
     return make_manhattan(**SYNTH[name])
 
 
@@ -124,3 +161,32 @@ def compare_with_golden(res, gold, pose_tol=1e-4, check_landmarks=True):
                 err = float(np.max(np.abs(res.landmarks[str(nm)] - gold["landmarks"][i]))) / scale
                 assert err < pose_tol, f"landmark {nm} differs by {err:.3e}"
     return worst_t, worst_R
+
+
+def compare_residuals_with_golden(res, fg, gold, tol=1e-4):
+    """What every optimum shares, also where poses are not unique (robots with gauge freedom,
+    landmarks behind slack cones): the relative-pose residuals and the range excesses.  Evaluated
+    with the ORACLE's restatement of the measurement model on the solver's relaxed (unrounded)
+    variables; relative to the coordinate scale like the pose comparison."""
+    import numpy as np
+
+    from oracle import score_oracle as so
+
+    if "quad_residuals" not in gold.files:
+        return
+    rp = so.ReducedProblem(fg)
+    d = rp.dim
+    u = np.zeros(rp.n)
+    for nm in rp.pose_names:
+        if nm != rp.first_pose:
+            u[rp.col[nm] : rp.col[nm] + d * (d + 1)] = np.asarray(res.relaxed_poses[nm]).ravel()
+    for nm in rp.landmark_names:
+        u[rp.col[nm] : rp.col[nm] + d] = res.landmarks[nm]
+    r, ex = so.optimal_residuals(rp, u)
+    scale = max(1.0, float(np.max(np.abs(gold["poses"][:, :, d]))))
+    sw = np.sqrt(gold["quad_weights"])
+    # weighted residuals (the cost's own units): sqrt(w) * residual, relative to sqrt(w) * scale
+    worst_r = float(np.max(np.abs(sw * (r - gold["quad_residuals"])) / (sw * scale))) if r.size else 0.0
+    worst_e = float(np.max(np.abs(ex - gold["range_excess"]))) / scale if ex.size else 0.0
+    assert worst_r < tol, f"relative-pose residuals differ by {worst_r:.3e} (relative)"
+    assert worst_e < tol, f"range excesses differ by {worst_e:.3e} (relative)"

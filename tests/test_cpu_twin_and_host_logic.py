@@ -7,7 +7,7 @@ import pytest
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
-from conftest import compare_with_golden, graph_by_name, load_golden
+from conftest import compare_residuals_with_golden, compare_with_golden, graph_by_name, load_golden
 from score_amd import compat
 from score_amd.assemble import assemble
 from score_amd.manhattan import make_manhattan
@@ -19,7 +19,7 @@ from score_amd.solve_score import (
 from score_amd.solver import ConicSolver
 
 
-@pytest.mark.parametrize("name", ["manhattan", "synth_a", "synth_b", "synth_c"])
+@pytest.mark.parametrize("name", ["manhattan", "synth_a", "synth_b", "synth_c", "synth_d", "graph3d"])
 @pytest.mark.parametrize("relax", ["SOCP", "QCQP"])
 def test_twin_solve_score_matches_golden(name, relax, fixtures, twin_lib):
     fg = graph_by_name(name, fixtures)
@@ -28,6 +28,7 @@ def test_twin_solve_score_matches_golden(name, relax, fixtures, twin_lib):
     assert res.solved, res.info
     assert res.info["pobj"] == pytest.approx(float(gold["objective"]), rel=1e-5, abs=1e-6)
     compare_with_golden(res, gold)
+    compare_residuals_with_golden(res, fg, gold)  # also where the poses are not unique
     assert res.pose_chain_names == fg.get_pose_chain_names()
     d = fg.dimension
     key = (fg.range_measurements[0].first_key, fg.range_measurements[0].second_key) if fg.range_measurements else None
@@ -46,6 +47,7 @@ def test_twin_goats(fixtures, twin_lib):
     assert res.solved
     assert res.info["pobj"] == pytest.approx(float(gold["objective"]), rel=1e-6)
     compare_with_golden(res, gold)
+    compare_residuals_with_golden(res, fixtures["goats"], gold)
 
 
 def test_qcqp_direct_equals_via_socp(fixtures, twin_lib):

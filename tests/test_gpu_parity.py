@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import compare_with_golden, graph_by_name, load_golden
+from conftest import GOLDEN_NAMES, compare_residuals_with_golden, compare_with_golden, graph_by_name, load_golden
 from oracle import score_oracle as so
 from score_amd.assemble import assemble
 from score_amd.manhattan import make_config, make_manhattan
@@ -58,14 +58,19 @@ def test_iterates_match_cpu_twin(name, radix, cg, fixtures, hip_lib, twin_lib):
 
 
 @pytest.mark.parametrize("relax", ["SOCP", "QCQP"])
-@pytest.mark.parametrize("name", ["manhattan", "goats", "synth_a", "synth_b", "synth_c"])
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_solve_score_matches_golden(name, relax, fixtures, hip_lib):
+    """Product default path against the oracle-only goldens (2-D fixtures of the reference, four
+    synthetic graphs, one 3-D graph): objective, every pose / landmark the optimum determines, and --
+    where robots keep gauge freedom -- the residuals and range excesses every optimum shares."""
     _hip_only(hip_lib)
-    res = solve_score(graph_by_name(name, fixtures), relax)  # default library = HIP
+    fg = graph_by_name(name, fixtures)
+    res = solve_score(fg, relax)  # default library = HIP
     gold = load_golden(name)
     assert res.solved, res.info
     assert res.info["pobj"] == pytest.approx(float(gold["objective"]), rel=1e-5, abs=1e-6)
     compare_with_golden(res, gold, pose_tol=1e-4)  # north_star: 1e-4 relative
+    compare_residuals_with_golden(res, fg, gold, tol=1e-4)
 
 
 def test_qcqp_direct_on_gpu(fixtures, hip_lib):
@@ -183,7 +188,7 @@ def test_full_size_configs_are_certified(index, hip_lib):
         assert worst / scale < 1e-4
 
 
-@pytest.mark.parametrize("name", ["manhattan", "goats", "synth_b", "synth_c"])
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_newton_polish_matches_golden(name, fixtures, hip_lib):
     """Full solver (ADMM warm-up + semismooth-Newton polish on the GPU): tighter
     than ADMM alone -- objective to 1e-8 relative, poses to 1e-6, primal residual
@@ -199,6 +204,7 @@ def test_newton_polish_matches_golden(name, fixtures, hip_lib):
     assert res.info["pobj"] == pytest.approx(float(gold["objective"]), rel=1e-8, abs=1e-8)
     assert res.info["res_pri"] <= 1e-9
     compare_with_golden(res, gold, pose_tol=1e-6)
+    compare_residuals_with_golden(res, fg, gold, tol=1e-6)
     rq = solve_score(fg, "QCQP", solver_settings=dict(polish=1))  # QCQP answered through the polished SOCP
     assert rq.solved
     compare_with_golden(rq, gold, pose_tol=1e-6)

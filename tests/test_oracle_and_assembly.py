@@ -3,7 +3,7 @@ the oracle's literal restatement of score/utils/gurobi_utils.py."""
 import numpy as np
 import pytest
 
-from conftest import SYNTH, graph_by_name, load_golden
+from conftest import GOLDEN_NAMES, SYNTH, graph_by_name, load_golden
 from oracle import score_oracle as so
 from score_amd import compat
 from score_amd.assemble import assemble
@@ -23,27 +23,7 @@ def _random_values(mdl, rng):
     return xs, vals
 
 
-def _graph_3d(seed=5, n=12, n_lm=3):
-    """Small 3-D graph (one chain + landmarks + ranges + a prior + a loop closure)."""
-    rng = np.random.default_rng(seed)
-    fg = compat.FactorGraphData(dimension=3)
-    fg.pose_variables = [[compat.PoseVariable3D(f"A{i}", tuple(rng.normal(size=3))) for i in range(n)]]
-    fg.landmark_variables = [compat.LandmarkVariable3D(f"L{i}", tuple(rng.normal(size=3) * 5)) for i in range(n_lm)]
-
-    def rot():
-        q, _ = np.linalg.qr(rng.normal(size=(3, 3)))
-        if np.linalg.det(q) < 0:
-            q[:, -1] *= -1
-        return q
-
-    fg.odom_measurements = [[
-        compat.PoseMeasurement3D(f"A{i}", f"A{i+1}", rng.normal(size=3), rot(), 100.0 + i, 400.0 + i) for i in range(n - 1)
-    ]]
-    fg.loop_closure_measurements = [compat.PoseMeasurement3D("A2", "A9", rng.normal(size=3), rot(), 50.0, 70.0)]
-    for i in range(0, n, 2):
-        fg.range_measurements.append(compat.FGRangeMeasurement((f"A{i}", f"L{i % n_lm}"), float(rng.uniform(1, 6)), 0.5))
-    fg.landmark_priors = [compat.LandmarkPrior3D("L1", (1.0, -2.0, 0.5), 3.0)]
-    return fg
+from conftest import graph_3d as _graph_3d  # noqa: E402  (shared with tests/golden/make_fixture_golden.py)
 
 
 @pytest.mark.parametrize("relax", ["SOCP", "QCQP"])
@@ -81,7 +61,7 @@ def test_fixture_statistics(fixtures):
     assert assemble(g, "SOCP").qp.n == 5640 - 6 and assemble(g, "QCQP").qp.n == 7198 - 6
 
 
-@pytest.mark.parametrize("name", ["manhattan", "goats", "synth_a", "synth_b", "synth_c"])
+@pytest.mark.parametrize("name", GOLDEN_NAMES)
 def test_newton_oracle_reproduces_golden(name, fixtures):
     fg = graph_by_name(name, fixtures)
     gold = load_golden(name)
@@ -92,6 +72,38 @@ def test_newton_oracle_reproduces_golden(name, fixtures):
     P = np.stack([vals["poses"][str(n)] for n in gold["pose_names"]])
     det = gold["pose_determined"]
     np.testing.assert_allclose(P[det], gold["poses"][det], atol=1e-6 * max(1.0, np.abs(gold["poses"]).max()))
+    # the masks come from the oracle alone: null space of the generalised Hessian at the optimum
+    pm, lm, ninfo = so.determined_masks(rp, u)
+    assert np.array_equal(pm, gold["pose_determined"]) and np.array_equal(lm, gold["landmark_determined"])
+    res, ex = so.optimal_residuals(rp, u)
+    np.testing.assert_allclose(res, gold["quad_residuals"], atol=1e-7)
+    np.testing.assert_allclose(ex, gold["range_excess"], atol=1e-7)
+
+
+def test_determined_masks_follow_the_null_space():
+    """A direction the analysis calls free must leave the objective unchanged, and the variables it
+    calls determined must not move along it; moving a determined variable must raise the objective."""
+    fg = graph_by_name("synth_b", {})
+    rp, u, _ = so.newton_solve(fg, tol=1e-13, max_iter=300)
+    pm, lm, ninfo = so.determined_masks(rp, u)
+    assert ninfo["null_dim"] > 0 and not pm.all() and pm[: len(fg.pose_variables[0])].all()
+    _, H = rp.grad_hess(u)
+    N = so.gauge_basis(rp)
+    d = rp.dim
+    n_odo = sum(len(c) for c in fg.odom_measurements) * (d + d * d)  # odometry rows come first in J (loop closures follow)
+    assert np.abs((rp.J @ N)[:n_odo]).max() < 1e-9  # odometry residuals are blind to the gauge directions
+    G = N.T @ (H @ N)
+    w, V = np.linalg.eigh(0.5 * (G + G.T))
+    z = N @ V[:, 0]
+    z /= np.abs(z).max()
+    f0 = rp.value(u)
+    assert abs(rp.value(u + 1e-3 * z) - f0) < 1e-9 * max(1.0, f0)  # flat along a null direction
+    for i, nm in enumerate(rp.pose_names):
+        if pm[i] and nm != rp.first_pose:
+            assert np.abs(z[rp.col[nm] : rp.col[nm] + d * (d + 1)]).max() < 1e-6
+    e = np.zeros(rp.n)
+    e[rp.col[rp.pose_names[5]] + d] = 1.0  # translation of a determined pose of the pinned robot
+    assert rp.value(u + 1e-3 * e) > f0 + 1e-6
 
 
 def test_survey_anchor_values():
