@@ -30,6 +30,7 @@ using namespace score;
 thread_local std::string g_err;
 
 struct CpuBackend {
+    static constexpr bool kFactorOnHost = true;
     const HostSystem* H = nullptr;
     score_settings st{};
     std::vector<double> xtu, xy, s, r, z, p, w, kx;  // xtu = [xt | u], xy = [x | y], kx = K xt

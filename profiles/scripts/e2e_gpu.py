@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0,'.')
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from score_amd.manhattan import make_config
 from score_amd import solve_score as ss

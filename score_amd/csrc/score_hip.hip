@@ -186,6 +186,9 @@ struct CsrBufs {
 };
 
 struct HipBackend {
+    // K's values, the chain factors and the Jacobi diagonal are derived on the device from K0, K1 and
+    // rho (derive_rho_data): the host neither factors nor uploads anything when a penalty changes
+    static constexpr bool kFactorOnHost = false;
     const HostSystem* H = nullptr;
     score_settings st{};
     hipStream_t stream = nullptr;
@@ -197,7 +200,8 @@ struct HipBackend {
     CsrBufs K, G1, G2;
     DevBuf<int32_t> A_ptr, A_col;
     DevBuf<double> A_val;
-    DevBuf<double> q, b, invD, invE, rho, fac, dinv;
+    DevBuf<double> q, b, invD, invE, rho, fac, dinv, K0d, K1d;
+    DevBuf<int32_t> kposd, kposs, kdiagpos;  // K.val positions of the chain blocks / Jacobi diagonals
     DevBuf<int32_t> done, cone_row, cone_dim, cone_type, cone_block_first, cone_block_prob;
     DevBuf<int4> cone_meta;
     DevBuf<int32_t> node_col, diag_cols, prec_part_ptr, kblk_part_ptr;
@@ -366,8 +370,13 @@ struct HipBackend {
         cg_iters = st.cg_iters;
         std::vector<int32_t> dz(h.count, 0);
         done.upload(dz);
-        fac.upload(h.fac); dinv.upload(h.dinv); rho.upload(h.rho);  // (K.val went up with K)
-        pt.mark("allocations + rho data");
+        K0d.upload_padded(h.K0, 64); K1d.upload_padded(h.K1, 64);
+        kposd.upload(h.pos_diag); kposs.upload(h.pos_sub); kdiagpos.upload(h.diag_kpos);
+        fac.alloc(h.fac.size()); fac.zero(stream);  // separator slots of the spike region are never written (nor used)
+        dinv.alloc(h.dinv.size()); rho.upload(h.rho);
+        q_work.alloc((size_t)std::max<int64_t>(1, h.scratch_nodes) * 2 * std::max(1, h.bs * h.bs));
+        derive_rho_data(false);
+        pt.mark("allocations + rho data (device)");
         if (st.polish) init_polish(h);
         pt.mark("polish setup");
         {   // the report arena (see `rep`) and the control block (see `ctl`)
@@ -402,12 +411,33 @@ struct HipBackend {
         pt.mark("reset");
     }
 
-    void upload_rho_values(const HostSystem& h) {
-        K.val.upload_into(h.K.val);  // keeps the padded allocation (and the pointer the launch graph holds)
-        fac.upload(h.fac);
-        dinv.upload(h.dinv);
-        rho.upload(h.rho);
+    // Everything that depends on the penalties, on the device and in stream order: K = K0 + rho K1 on
+    // the fixed pattern, the nested-dissection factors of the chains of K (the same k_factor the Newton
+    // polish uses for its Hessian) and the reciprocal Jacobi diagonal.
+    void derive_rho_data(bool upload_penalties) {
+        const HostSystem& h = *H;
+        if (upload_penalties) {
+            double* v = (double*)next_ring_slot(h.count * sizeof(double));
+            for (int p = 0; p < h.count; ++p) v[p] = h.rho[p];
+            fetch_words((int32_t*)rho.d, (const char*)v, 2 * h.count);
+        }
+        hipLaunchKernelGGL(k_kval, dim3(K.nblocks), dim3(kThreads), 0, stream, K.dev(), (const double*)K0d.d, (const double*)K1d.d,
+                           (const double*)rho.d, K.val.d, (const int32_t*)nullptr);
+        if (n_prec_items()) {
+            FactorArgs fa{};
+            fa.work = prec_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = K.val.d;
+            fa.pos_diag = kposd.d; fa.pos_sub = kposs.d; fa.fac = fac.d; fa.work_mat = q_work.d; fa.skip = nullptr;
+            fa.diag_pos = kdiagpos.d; fa.dinv = dinv.d;
+            const int np = n_prec_items();
+            const int bs = h.bs;
+            if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(np), dim3(kThreads), 0, stream, fa);
+            else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(np), dim3(kThreads), 0, stream, fa);
+            else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(np), dim3(kThreads), 0, stream, fa);
+            else hipLaunchKernelGGL(k_factor<4>, dim3(np), dim3(kThreads), 0, stream, fa);
+        }
+        HIP_CHECK(hipGetLastError());
     }
+    int n_prec_items() const { return (int)H->prec_work.size(); }
 
     ConeArgs cone_args(const double* gathered) {
         ConeArgs a{};
@@ -423,9 +453,8 @@ struct HipBackend {
     }
 
     void upload_rho(const HostSystem& h) {
-        tl_copy_stream = stream;
-        HIP_CHECK(hipStreamSynchronize(stream));
-        upload_rho_values(h);
+        (void)h;
+        derive_rho_data(true);
         {   // K changed: the carried product kx = K xt is recomputed once
             SpmvArgs a = spmv_args(K, xtu.d);
             a.p = xtu.d; a.w = kx.d;
@@ -436,7 +465,6 @@ struct HipBackend {
             hipLaunchKernelGGL(k_refresh_u, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xtu.d));
             HIP_CHECK(hipGetLastError());
         }
-        HIP_CHECK(hipStreamSynchronize(stream));
     }
 
     // Stream-ordered uploads of small per-problem arrays without a host synchronisation and without
@@ -811,6 +839,74 @@ struct HipBackend {
         else if (nm == "D") { src = h.D.data(); sz = h.n_tot; host = true; }
         else if (nm == "E") { src = h.E.data(); sz = h.m_tot; host = true; }
         else if (nm == "Kval") { src = K.val.d; sz = (int64_t)h.K.val.size(); }
+        else if (nm == "fac") { src = fac.d; sz = (int64_t)h.fac.size(); }
+        // ---- kernel-level checks of the Newton polish (tests/test_gpu_parity.py) ----
+        else if (nm == "polish_assemble_at_x") {
+            // evaluate F, gradient, generalised Hessian and its chain factors at the current ADMM
+            // iterate x (what the first Newton iteration does); returns F
+            if (!Q.available) return -1;
+            if (out && len > 0) {
+                try {
+                    c_step.assign(h.count, 1.0); c_tol2.assign(h.count, 0.0); c_skip.assign(h.count, 0);
+                    std::vector<char> all(h.count, 1);
+                    NewtonVecArgs va{};
+                    va.n = h.n_tot; va.is_head = q_ishead.d; va.g = q_g.d; va.part = q_gd.d;
+                    HIP_CHECK(hipMemsetAsync(q_g.d, 0, q_g.n * sizeof(double), stream));
+                    va.u = xy.d; va.delta = xy.d; va.step = 0.0; va.out = q_X0.d;
+                    hipLaunchKernelGGL(k_newton_trial, dim3((unsigned)((h.n_tot + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, va);
+                    upload_skip(all);
+                    std::vector<double> F(h.count), gn(h.count);
+                    newton_eval_batch(q_X0.d, all, F, gn);
+                    newton_hessian(q_skip.d);
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    out[0] = F[0];
+                } catch (const std::exception&) { return -2; }
+            }
+            return 1;
+        }
+        else if (nm == "polish_prec_of_negg") {
+            // z = M^-1 (-g) with the Newton preconditioner as factored on the device (k_factor), applied by
+            // the chain kernel the PCG uses
+            if (!Q.available) return -1;
+            if (out && len > 0) {
+                PrecArgs pa{};
+                pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = q_fac.d;
+                pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = q_skip.d;
+                pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d;
+                pa.r = r.d; pa.r_in = q_negg.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d;
+                pa.pw_part = q_pw.d; pa.rz_in = nullptr; pa.rz_out = rz_part0.d;
+                launch_prec<PREC_INIT>(pa);
+            }
+            src = z.d; sz = h.n_tot;
+        }
+        else if (nm == "polish_g") { src = q_g.d; sz = Q.available ? h.n_tot : 0; }
+        else if (nm == "Hval") { src = Hm.val.d; sz = Q.available ? (int64_t)Q.Hm.col.size() : 0; }
+        else if (nm == "Hcol" || nm == "Hptr" || nm == "is_head" || nm == "chain_of_col") {
+            if (!Q.available) return -1;
+            std::vector<double> tmp;
+            if (nm == "Hcol") tmp.assign(Q.Hm.col.begin(), Q.Hm.col.end());
+            else if (nm == "Hptr") tmp.assign(Q.Hm.ptr.begin(), Q.Hm.ptr.end());
+            else if (nm == "is_head") tmp.assign(Q.is_head.begin(), Q.is_head.end());
+            else {  // per column: chain node index (global numbering over all chains) or -1
+                tmp.assign(h.n_tot, -1.0);
+                for (size_t ci = 0; ci < h.chains.size(); ++ci)
+                    for (int i = 0; i < h.chains[ci].N; ++i)
+                        for (int c = 0; c < h.bs; ++c) tmp[h.node_col[h.chains[ci].node_begin + i] + c] = (double)(h.chains[ci].node_begin + i) + 1e-3 * 0;
+                // chain boundaries: encode the chain id in a second pass through "chain_id_of_col"
+            }
+            sz = (int64_t)tmp.size();
+            if (out && len > 0) std::memcpy(out, tmp.data(), sizeof(double) * (size_t)std::min(len, sz));
+            return sz;
+        }
+        else if (nm == "chain_id_of_col") {
+            std::vector<double> tmp(h.n_tot, -1.0);
+            for (size_t ci = 0; ci < h.chains.size(); ++ci)
+                for (int i = 0; i < h.chains[ci].N; ++i)
+                    for (int c = 0; c < h.bs; ++c) tmp[h.node_col[h.chains[ci].node_begin + i] + c] = (double)ci;
+            sz = (int64_t)tmp.size();
+            if (out && len > 0) std::memcpy(out, tmp.data(), sizeof(double) * (size_t)std::min(len, sz));
+            return sz;
+        }
         else return -1;
         if (out && len > 0) {
             const size_t bytes = sizeof(double) * (size_t)std::min(len, sz);
@@ -852,7 +948,6 @@ struct HipBackend {
         q_g.alloc(h.n_tot); q_delta.alloc(h.n_tot); q_dummy.alloc(h.n_tot); q_negg.alloc(h.n_tot);
         q_fac.alloc(h.fac.size()); q_dinv.alloc(h.dinv.size());
         q_fac.zero(stream);  // separator slots of the spike region are never written (nor used)
-        q_work.alloc((size_t)std::max<int64_t>(1, h.scratch_nodes) * 2 * std::max(1, h.bs * h.bs));
         n_gd = std::max<size_t>((h.n_tot + kThreads - 1) / kThreads, (size_t)Hm.nblocks);
         q_pw.alloc(Hm.nblocks);
         {
@@ -901,13 +996,13 @@ struct HipBackend {
         ha.nnz = (int64_t)Q.Hm.col.size(); ha.Pon = q_Pon.d; ha.cptr = q_cptr.d; ha.ccone = q_ccone.d; ha.cab = q_cab.d;
         ha.ccoef = q_ccoef.d; ha.Bbuf = q_Bbuf.d; ha.T2 = Q.T * Q.T; ha.Hval = Hm.val.d;
         ha.ndiag = (int)h.diag_cols.size(); ha.diag_pos = q_diagpos.d; ha.dinv = q_dinv.d;
-        hipLaunchKernelGGL(k_hassemble, dim3((unsigned)((ha.nnz + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, ha);
-        if (n_long) hipLaunchKernelGGL(k_hassemble_long, dim3(n_long), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d);
-        if (ha.ndiag) hipLaunchKernelGGL(k_hdiag, dim3((ha.ndiag + kThreads - 1) / kThreads), dim3(kThreads), 0, stream, ha);
-        if (n_prec && !h.chains.empty()) {
+        const int base_blocks = (int)((ha.nnz + kThreads - 1) / kThreads);
+        hipLaunchKernelGGL(k_hassemble, dim3((unsigned)(base_blocks + n_long)), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d, base_blocks);
+        if (n_prec) {  // chain factors and the reciprocal Jacobi diagonal, one launch
             FactorArgs fa{};
             fa.work = prec_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = Hm.val.d;
             fa.pos_diag = q_posd.d; fa.pos_sub = q_poss.d; fa.fac = q_fac.d; fa.work_mat = q_work.d; fa.skip = skip;
+            fa.diag_pos = q_diagpos.d; fa.dinv = q_dinv.d;
             if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
             else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
             else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
@@ -995,9 +1090,9 @@ struct HipBackend {
     double* pcg_p_oth = nullptr;
     void newton_pcg_enqueue(const std::vector<char>& live, const std::vector<double>& eta, int n_iters, bool resume) {
         const HostSystem& h = *H;
-        if (!resume)
-            for (int p = 0; p < h.count; ++p) c_tol2[p] = eta[p] * eta[p];
-        upload_skip(live);  // (uploads the tolerances too)
+        // (a fresh solve finds its control words -- skip flags, tolerances -- uploaded by the caller)
+        if (resume) upload_skip(live);
+        (void)eta;
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = q_fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = q_skip.d;
@@ -1073,8 +1168,6 @@ struct HipBackend {
             any = false;
             for (int p = 0; p < count; ++p) { live[p] = part[p] && !stalled[p] && gn[p] > tol; any = any || live[p]; }
             if (!any) break;
-            upload_skip(live);
-            newton_hessian(q_skip.d);  // (the matrix entries of a frozen problem are simply re-derived)
             // inexact Newton: the linear residual only has to shrink superlinearly with |g|
             // (and never more digits than the step needs to land below the tolerance)
             for (int p = 0; p < count; ++p) {
@@ -1091,15 +1184,24 @@ struct HipBackend {
                         scale = std::max(scale, std::log(eta[p]) / std::log(eta_prev[p]));
                 n_pcg = std::min(400, (int)std::ceil(used_prev * std::min(scale, 4.0)) + 3);
             }
+            // ONE upload of the control words serves the whole iteration: skip = !live for the Hessian,
+            // the PCG solve and the first trial point; the PCG tolerances; unit step lengths
+            for (int p = 0; p < count; ++p) { c_tol2[p] = eta[p] * eta[p]; c_step[p] = 1.0; }
+            upload_skip(live);
+            newton_hessian(q_skip.d);  // (the matrix entries of a frozen problem are simply re-derived)
             newton_pcg_enqueue(live, eta, n_pcg, false);
             eta_prev = eta;
+            bool control_stale = false;
             int used_now = 0;
             // backtracking per problem; a problem leaves the search when its step is accepted
             std::vector<char> ls = live, accepted(count, 0);
             for (int p = 0; p < count; ++p) step[p] = 1.0;
             for (int k = 0; k < 40; ++k) {
-                c_step = step;
-                upload_skip(ls);  // (uploads the step lengths too)
+                if (k > 0 || control_stale) {
+                    c_step = step;
+                    upload_skip(ls);  // (uploads the step lengths too)
+                    control_stale = false;
+                }
                 va.u = X; va.delta = q_delta.d; va.step = 0.0; va.out = Xt;
                 hipLaunchKernelGGL(k_newton_trial_b, dim3(nbh), dim3(kThreads), 0, stream, va, batch_tables());
                 newton_eval_enqueue(Xt);  // overwrites nu / B / g of the problems searched; copies gd and the gate words too
@@ -1117,6 +1219,7 @@ struct HipBackend {
                     }
                     if (any_more) {
                         newton_pcg_enqueue(more, eta, std::max(4, used_now / 2), true);
+                        control_stale = true;  // the skip flags now describe the resumed set
                         --k;  // same step length again
                         continue;
                     }

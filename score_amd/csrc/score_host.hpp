@@ -454,6 +454,12 @@ struct HostSystem {
     std::vector<double> kkt_bytes; // per problem: algorithmic bytes of one K-apply
 
     std::vector<int64_t> fac_off;  // per chain: offset of its records in `fac` (doubles)
+
+    // true: K's values, the chain factorisation and the Jacobi diagonal are computed here, on the
+    // host, whenever a penalty changes (the CPU twin).  false: the backend derives them on the
+    // device from K0 / K1 / rho (the HIP backend: k_kval + k_factor) -- nothing rho-dependent is
+    // computed or uploaded by the host.
+    bool factor_on_host = true;
 };
 
 inline int find_in_row(const Csr& M, int64_t row, int32_t col) {
@@ -769,6 +775,7 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
 // (Re)compute everything that depends on rho for problem `pi`: K values, G1
 // values, the chain factorisation and the Jacobi diagonal.
 inline void refresh_rho(HostSystem& H, int pi) {
+    if (!H.factor_on_host) return;
     const double rho = H.rho[pi];
     const int64_t r0 = H.xoff[pi], r1 = H.xoff[pi + 1];
     const int64_t k0 = H.K.ptr[r0], k1 = H.K.ptr[r1];
@@ -810,10 +817,12 @@ inline void refresh_rho(HostSystem& H, int pi) {
     }
 }
 
-inline void build_system(const score_problem* probs, int count, const score_settings& st, HostSystem& H) {
+inline void build_system(const score_problem* probs, int count, const score_settings& st, HostSystem& H,
+                         bool factor_on_host = true) {
     if (count <= 0) throw std::runtime_error("score_create: count must be positive");
     PhaseTimer pt(st.verbose != 0);
     H = HostSystem();
+    H.factor_on_host = factor_on_host;
     H.count = count;
     H.sigma = st.sigma;
     H.radix = std::min(4, std::max(2, st.chain_radix));

@@ -1590,6 +1590,17 @@ __global__ __launch_bounds__(kThreads) void k_fetch(const int32_t* __restrict__ 
     for (int i = threadIdx.x; i < n_words; i += kThreads) dst[i] = src[i];
 }
 
+// K = K0 + rho[prob] * K1 on the fixed pattern (grid = K row blocks; one tile of <= kTileNnz entries each,
+// or one long row)
+__global__ __launch_bounds__(kThreads) void k_kval(CsrDev M, const double* __restrict__ K0, const double* __restrict__ K1,
+                                                   const double* __restrict__ rho, double* __restrict__ val, const int32_t* skip) {
+    const int4 meta = M.blk_meta[blockIdx.x];
+    const int prob = M.blk_prob[blockIdx.x];
+    if (skip && skip[prob]) return;
+    const double r = rho[prob];
+    for (int k = meta.z + (int)threadIdx.x; k < meta.w; k += kThreads) val[k] = K0[k] + r * K1[k];
+}
+
 // launch-overhead probes (debug timing only)
 __global__ void k_nop(int* sink) { if (sink && threadIdx.x == 9999) sink[0] = 1; }
 __global__ void k_nop_load(const int32_t* a, const int32_t* b2, int* sink) {

@@ -87,7 +87,18 @@ struct HAsmArgs {
 
 constexpr int kLongContrib = 64;  // entries with more contributions get a workgroup of their own
 
-__global__ __launch_bounds__(kThreads) void k_hassemble(HAsmArgs a) {
+// grid = ceil(nnz / 256) entry blocks followed by one block per long entry (k_hassemble_long's work)
+__global__ __launch_bounds__(kThreads) void k_hassemble(HAsmArgs a, const int32_t* long_entries, int first_long_block) {
+    if ((int)blockIdx.x >= first_long_block) {
+        __shared__ double red[8];
+        const int64_t pl = long_entries[blockIdx.x - first_long_block];
+        const int c0 = a.cptr[pl], c1 = a.cptr[pl + 1];
+        double v = 0.0;
+        for (int c = c0 + (int)threadIdx.x; c < c1; c += kThreads) v += a.ccoef[c] * a.Bbuf[(size_t)a.ccone[c] * a.T2 + a.cab[c]];
+        v = block_sum(v, red);
+        if (threadIdx.x == 0) a.Hval[pl] = a.Pon[pl] + v;
+        return;
+    }
     const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
     if (p >= a.nnz) return;
     const int c0 = a.cptr[p], c1 = a.cptr[p + 1];
@@ -96,21 +107,8 @@ __global__ __launch_bounds__(kThreads) void k_hassemble(HAsmArgs a) {
     for (int c = c0; c < c1; ++c) v += a.ccoef[c] * a.Bbuf[(size_t)a.ccone[c] * a.T2 + a.cab[c]];
     a.Hval[p] = v;
 }
-// landmark entries collect a contribution from every cone that touches the landmark (thousands):
-// strided partial sums + a fixed-order tree instead of one serial lane
-__global__ __launch_bounds__(kThreads) void k_hassemble_long(HAsmArgs a, const int32_t* long_entries) {
-    __shared__ double red[8];
-    const int64_t p = long_entries[blockIdx.x];
-    const int c0 = a.cptr[p], c1 = a.cptr[p + 1];
-    double v = 0.0;
-    for (int c = c0 + (int)threadIdx.x; c < c1; c += kThreads) v += a.ccoef[c] * a.Bbuf[(size_t)a.ccone[c] * a.T2 + a.cab[c]];
-    v = block_sum(v, red);
-    if (threadIdx.x == 0) a.Hval[p] = a.Pon[p] + v;
-}
-__global__ __launch_bounds__(kThreads) void k_hdiag(HAsmArgs a) {
-    const int e = blockIdx.x * kThreads + threadIdx.x;
-    if (e < a.ndiag) a.dinv[e] = 1.0 / a.Hval[a.diag_pos[e]];
-}
+// (landmark entries collect a contribution from every cone that touches the landmark -- thousands:
+//  strided partial sums + a fixed-order tree instead of one serial lane: the long-entry blocks above)
 
 // ---------------------------------------------------------------------------
 // device-side multi-level factorisation of the chains of H (mirror of
@@ -189,6 +187,9 @@ struct FactorArgs {
     double* fac;               // output, same layout as the ADMM factor
     double* work_mat;          // level >= 1 matrices: 2*bs*bs doubles per scratch node
     const int32_t* skip;       // optional, per problem: chains of a frozen problem keep their factors
+    // Jacobi work items (columns outside every chain): dinv[e] = 1 / H[diag_pos[e]]
+    const int32_t* diag_pos;
+    double* dinv;
 };
 
 template <int BS>
@@ -196,8 +197,11 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
     constexpr int B2 = BS * BS;
     using SM = SmallMat<BS>;
     const PrecWork wk = a.work[blockIdx.x];
-    if (wk.kind != 0) return;
     if (a.skip && a.skip[wk.prob]) return;
+    if (wk.kind != 0) {  // Jacobi block: reciprocal diagonal
+        for (int e = wk.index + (int)threadIdx.x; e < wk.index + wk.count; e += kThreads) a.dinv[e] = 1.0 / a.Hval[a.diag_pos[e]];
+        return;
+    }
     const ChainDesc ch = a.chains[wk.index];
     const ChainLevelDesc* lv = a.levels + ch.level_begin;
     const int t = threadIdx.x;

@@ -364,6 +364,81 @@ def test_lockstep_batch_polish_matches_individual_solves(hip_lib):
         np.testing.assert_array_equal(b.x, c.x)  # deterministic
 
 
+@pytest.mark.parametrize("name", ["manhattan", "graph3d"])
+def test_newton_kernels_against_the_oracle(name, fixtures, hip_lib):
+    """Kernel-level parity of the semismooth-Newton polish: the gradient (k_newton_cone + k_spmv<GRAD>), the
+    generalised Hessian the device assembles (k_hassemble on the host-built pattern) and the chain
+    factorisation (k_factor, applied through the chain kernel) are compared, entry by entry, with the
+    oracle's ReducedProblem.grad_hess at the same point -- an ADMM iterate, far from the optimum, with a
+    mixed set of active and slack cones."""
+    import scipy.sparse as sp
+
+    fg = graph_by_name(name, fixtures)
+    mdl = assemble(fg, "SOCP")
+    d = mdl.dim
+    sol = ConicSolver(mdl.qp, dict(adaptive_rho=0))
+    sol.reset()
+    sol.steps(15)
+    assert sol.debug_get("polish_assemble_at_x").size == 1
+    D = sol.debug_get("D")
+    xhat = sol.debug_get("x")
+    n = mdl.qp.n
+    Hm = sp.csr_matrix((sol.debug_get("Hval"), sol.debug_get("Hcol").astype(np.int64), sol.debug_get("Hptr").astype(np.int64)), shape=(n, n))
+    g = sol.debug_get("polish_g")
+    head = sol.debug_get("is_head") > 0
+    # the same point in the oracle's variables
+    rp = so.ReducedProblem(fg)
+    xm = mdl.expand(xhat * D)
+    u = np.zeros(rp.n)
+    omap = -np.ones(mdl.n_model, dtype=np.int64)  # model column -> oracle column
+    PB = d * (d + 1)
+    for i, nm in enumerate(mdl.pose_names):
+        if nm != rp.first_pose:
+            omap[i * PB : (i + 1) * PB] = rp.col[nm] + np.arange(PB)
+    for i, nm in enumerate(mdl.landmark_names):
+        omap[mdl.lm_base + i * d : mdl.lm_base + (i + 1) * d] = rp.col[nm] + np.arange(d)
+    sel = omap >= 0
+    u[omap[sel]] = xm[sel]
+    go, Ho = rp.grad_hess(u)
+    dl = rp.deltas(u)
+    n_active = int((np.linalg.norm(dl, axis=1) > rp.dist).sum())
+    assert 0 < n_active < rp.nr  # a genuinely mixed active set
+    oc = omap[mdl.free_cols]  # solver column -> oracle column (-1: range variable = eliminated head)
+    assert np.array_equal(oc < 0, head)
+    nh = np.nonzero(~head)[0]
+    # gradient: g_product = D g_oracle
+    np.testing.assert_allclose(g[nh], D[nh] * go[oc[nh]], rtol=0, atol=1e-9 * np.abs(go).max() * D.max())
+    assert np.all(g[head] == 0.0)
+    # Hessian: H_product = D H_oracle D (+ the 1e-9 diagonal regularisation) on the non-head block
+    Hd = Hm[nh][:, nh].toarray() if len(nh) <= 4000 else None
+    Ho_perm = Ho.tocsr()[oc[nh]][:, oc[nh]]
+    ref = sp.diags(D[nh]) @ Ho_perm @ sp.diags(D[nh])
+    diff = (Hm[nh][:, nh] - ref - 1e-9 * sp.identity(len(nh))).tocsr()
+    scale = abs(ref).max()
+    assert abs(diff).max() <= 1e-10 * scale, (abs(diff).max(), scale)
+    del Hd
+    # head rows are decoupled unit rows
+    Hh = Hm[np.nonzero(head)[0]]
+    assert Hh.nnz == int(head.sum()) and np.all(Hh.data == 1.0)
+    # chain factorisation: z = M^-1 (-g) must solve the block-tridiagonal chain part T of the SAME H exactly,
+    # and be the Jacobi quotient on the other columns
+    z = sol.debug_get("polish_prec_of_negg")
+    chain = sol.debug_get("chain_id_of_col").astype(np.int64)
+    bs = mdl.qp.block_size
+    coo = Hm.tocoo()
+    first = np.full(chain.max() + 2, n, dtype=np.int64)
+    np.minimum.at(first, chain[chain >= 0], np.nonzero(chain >= 0)[0])
+    node = np.where(chain >= 0, (np.arange(n) - first[np.maximum(chain, 0)]) // bs, -1)
+    keep = (chain[coo.row] >= 0) & (chain[coo.row] == chain[coo.col]) & (np.abs(node[coo.row] - node[coo.col]) <= 1)
+    T = sp.csr_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=(n, n))
+    inchain = chain >= 0
+    resid = (T @ z + g)[inchain]
+    assert np.abs(resid).max() <= 1e-9 * max(1.0, np.abs(g).max()), np.abs(resid).max()
+    other = ~inchain
+    np.testing.assert_allclose(z[other], -g[other] / Hm.diagonal()[other], rtol=1e-12, atol=1e-300)
+    sol.close()
+
+
 def test_config5_all_64_trials_are_certified(hip_lib):
     """BASELINE configs[4] at its full size: 64 four-robot x 1000-pose Monte-Carlo trials, solved
     the way bench.py solves them (lock-step handles of 16, product default solver).  EVERY trial
