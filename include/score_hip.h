@@ -180,6 +180,49 @@ int64_t score_debug_get(score_handle* h, const char* name, double* out, int64_t 
 
 void score_destroy(score_handle* h);
 
+/* ---------------------------------------------------------------------------
+ * Native model construction: the factor graph as flat arrays -> the conic program above.
+ * Replaces, for the same path, the reference's `initialize_model`
+ * (score/utils/gurobi_utils.py:173-187: variables :221-310, pinned first pose :316-333, cones
+ * :336-352, objective :358-526), which the Python host otherwise performs in
+ * score_amd/assemble.py.  Poses are numbered chain by chain (chain 0 first); the first pose of
+ * chain 0 is the pinned one.  Range endpoints are variable ids: 0..n_poses-1 = poses,
+ * n_poses..n_poses+n_landmarks-1 = landmarks.  Column layout of the result: see
+ * score_amd/csrc/score_assemble.hpp (identical to score_amd/assemble.py).
+ * ------------------------------------------------------------------------- */
+typedef struct score_graph {
+    int32_t dim;                /* 2 or 3                                      */
+    int32_t relaxation;         /* 0 = "SOCP", 1 = "QCQP" (gurobi_utils.py:139-144) */
+    int32_t n_chains;
+    const int32_t* chain_len;   /* poses per chain                             */
+    int32_t n_landmarks;
+    int64_t n_rel;              /* relative-pose measurements: odometry, then loop closures */
+    const int32_t* rel_base;    /* pose index of base_pose / to_pose           */
+    const int32_t* rel_to;
+    const double*  rel_t;       /* n_rel * dim   translation_vector            */
+    const double*  rel_R;       /* n_rel * dim * dim  rotation_matrix, row-major */
+    const double*  rel_kappa;   /* translation_precision                       */
+    const double*  rel_tau;     /* rotation_precision                          */
+    int64_t n_rng;              /* range measurements                          */
+    const int32_t* rng_a;       /* variable id of first_key / second_key       */
+    const int32_t* rng_b;
+    const double*  rng_dist;
+    const double*  rng_prec;    /* precision = 1 / stddev^2                    */
+    int64_t n_lprior;           /* landmark priors (gurobi_utils.py:433-446)   */
+    const int32_t* lprior_lm;   /* landmark index                              */
+    const double*  lprior_t;    /* n_lprior * dim                              */
+    const double*  lprior_prec;
+} score_graph;
+
+typedef struct score_assembled score_assembled;
+
+/* Build the program (host memory owned by *out).  Inputs are borrowed for the call. */
+int  score_assemble(const score_graph* g, score_assembled** out);
+/* Fill `view` with pointers into the assembled program (valid until score_assembled_free);
+ * pass it to score_create / score_create_batch like any other score_problem.   */
+int  score_assembled_view(const score_assembled* a, score_problem* view);
+void score_assembled_free(score_assembled* a);
+
 const char* score_last_error(void);
 const char* score_backend(void);   /* "hip-gfx950" or "cpu-twin"             */
 

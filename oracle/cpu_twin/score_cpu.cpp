@@ -22,6 +22,7 @@
 #endif
 
 #include "../../score_amd/csrc/score_driver.hpp"
+#include "../../score_amd/csrc/score_assemble.hpp"
 
 namespace {
 
@@ -290,6 +291,10 @@ struct CpuBackend {
 
 }  // namespace
 
+struct score_assembled {
+    score::AssembledQP qp;
+};
+
 struct score_handle {
     score::Solver<CpuBackend> solver;
 };
@@ -364,6 +369,26 @@ int64_t score_debug_get(score_handle* h, const char* name, double* out, int64_t 
     return h->solver.be.get_vec(name, out, len);
 }
 void score_destroy(score_handle* h) { delete h; }
+int score_assemble(const score_graph* g, score_assembled** out) {
+    try {
+        if (!g || !out) throw std::runtime_error("null argument");
+        auto* a = new score_assembled();
+        try {
+            score::assemble_graph(*g, a->qp);
+        } catch (...) {
+            delete a;
+            throw;
+        }
+        *out = a;
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_assembled_view(const score_assembled* a, score_problem* view) {
+    if (!a || !view) { g_err = "null argument"; return -1; }
+    a->qp.view(view);
+    return 0;
+}
+void score_assembled_free(score_assembled* a) { delete a; }
 const char* score_last_error(void) { return g_err.c_str(); }
 const char* score_backend(void) { return "cpu-twin"; }
 }

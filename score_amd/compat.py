@@ -26,6 +26,7 @@ path only uses the attributes above (duck typing), never ``isinstance``.
 """
 from __future__ import annotations
 
+from collections.abc import Mapping
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -258,6 +259,54 @@ class FactorGraphData:
 # ---------------------------------------------------------------------------
 # results (py_factor_graph.utils.solver_utils counterparts)
 # ---------------------------------------------------------------------------
+class ArrayDict(Mapping):
+    """A read-only ``dict``-like view ``name -> array[i]`` over one stacked array.  Building 20 000
+    small arrays and a real dict for every solve costs more than the solve itself; the name index
+    is built on the first lookup, rows are views into the stacked array (``dict(view)`` gives a
+    plain dict where one is wanted)."""
+
+    __slots__ = ("_names", "_array", "_index")
+
+    def __init__(self, names, array):
+        self._names = names
+        self._array = array
+        self._index = None
+
+    def _idx(self):
+        if self._index is None:
+            self._index = {nm: i for i, nm in enumerate(self._names)}
+        return self._index
+
+    def __getitem__(self, key):
+        return self._array[self._idx()[key]]
+
+    def __iter__(self):
+        return iter(self._names)
+
+    def __len__(self):
+        return len(self._names)
+
+    def __contains__(self, key):
+        return key in self._idx()
+
+    def items(self):
+        return zip(self._names, self._array)
+
+    def values(self):
+        return iter(self._array)
+
+    def keys(self):
+        return list(self._names)
+
+    @property
+    def array(self) -> np.ndarray:
+        """The stacked values, in ``keys()`` order."""
+        return self._array
+
+    def __repr__(self):
+        return f"ArrayDict({len(self._names)} entries, item shape {self._array.shape[1:]})"
+
+
 @dataclass
 class VariableValues:
     dim: int

@@ -1,0 +1,312 @@
+// score_assemble.hpp -- native model construction: FactorGraphData (flat arrays) -> conic QP.
+//
+// The C++ counterpart of score_amd/assemble.py, i.e. of the reference's
+// `initialize_model` (score/utils/gurobi_utils.py:173-187): variables (:221-310), the
+// pinned first pose (:181-183, :316-333; eliminated from the unknowns), second-order cones
+// (:336-352), relative-pose costs (:380-430, :504-526), range costs (:449-501) and landmark
+// priors (:433-446), written straight into the standard form the solver consumes
+//
+//     minimise 1/2 x'Px + q'x + c0   s.t.  A x + s = b,  s in SOC(d+1)^Nr
+//
+// without going through a residual Jacobian: every measurement adds its (d+1)x(d+1) blocks to P
+// analytically.  Python model construction was the end-to-end bottleneck once the solve takes
+// milliseconds (SURVEY.md hard part 8: ~45 ms per 20-robot graph, and serialised by the GIL over
+// a batch); this runs in a few milliseconds and releases the GIL.
+//
+// Column layout (identical to assemble.py, so ScoreModel.expand()/reduce() apply unchanged):
+//   solver space = for every pose chain, for every matrix row k = 0..d-1, the (d+1) entries
+//   [R(k,:) t(k)] of every pose of the chain except the pinned one (chain-major: each
+//   block-tridiagonal preconditioner chain is contiguous); then the landmarks (d each); then the
+//   range variables (1 each for SOCP, d each for QCQP).
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+#include "score_host.hpp"
+
+namespace score {
+
+struct AssembledQP {
+    int32_t n = 0, m = 0, dim = 0, relaxation = 0;
+    std::vector<int32_t> P_ptr, P_col, A_ptr, A_col, soc_dims, chain_ptr, node_first_col;
+    std::vector<double> P_val, q, A_val, b;
+    double c0 = 0.0;
+    int32_t block_size = 0;
+
+    void view(score_problem* p) const {
+        std::memset(p, 0, sizeof(*p));
+        p->n = n; p->m = m;
+        p->P_rowptr = P_ptr.data(); p->P_col = P_col.data(); p->P_val = P_val.data();
+        p->q = q.data(); p->c0 = c0;
+        p->A_rowptr = A_ptr.data(); p->A_col = A_col.data(); p->A_val = A_val.data(); p->b = b.data();
+        p->z = 0; p->n_soc = (int32_t)soc_dims.size(); p->soc_dims = soc_dims.data();
+        p->block_size = block_size; p->n_chains = (int32_t)chain_ptr.size() - 1;
+        p->chain_ptr = chain_ptr.data(); p->node_first_col = node_first_col.data();
+    }
+};
+
+namespace detail {
+struct Trip { int32_t col; double val; };
+}
+
+inline void assemble_graph(const score_graph& g, AssembledQP& out) {
+    const int d = g.dim;
+    if (d != 2 && d != 3) throw std::runtime_error("score_graph: dim must be 2 or 3");
+    if (g.relaxation != 0 && g.relaxation != 1) throw std::runtime_error("score_graph: relaxation must be 0 (SOCP) or 1 (QCQP)");
+    if (g.n_chains <= 0 || !g.chain_len) throw std::runtime_error("score_graph: no pose chains");
+    const int D1 = d + 1;
+    int64_t Np = 0;
+    for (int c = 0; c < g.n_chains; ++c) {
+        if (g.chain_len[c] < 0) throw std::runtime_error("score_graph: negative chain length");
+        Np += g.chain_len[c];
+    }
+    if (Np == 0 || g.chain_len[0] == 0) throw std::runtime_error("factor graph has no pose variables");
+    const int64_t Nl = g.n_landmarks, Nr = g.n_rng;
+    const int rw = g.relaxation == 0 ? 1 : d;
+    const int64_t n_pose_cols = (Np - 1) * d * D1;
+    const int64_t lm_base = n_pose_cols, rng_base = lm_base + Nl * d;
+    const int64_t n = rng_base + Nr * rw;
+    if (n >= ((int64_t)1 << 31)) throw std::runtime_error("score_graph: too many unknowns");
+    // solver column of entry (k, j) of pose p: pose_col[p] + k * stride[p] + j ; -1 for the pinned pose
+    // (pose 0 of chain 0).  Within a chain the poses (minus the pin) are consecutive nodes.
+    std::vector<int64_t> pose_col(Np), pose_kstride(Np);
+    out = AssembledQP();
+    out.dim = d; out.relaxation = g.relaxation;
+    out.chain_ptr.assign(1, 0);
+    {
+        int64_t p = 0, col = 0;
+        for (int c = 0; c < g.n_chains; ++c) {
+            const int64_t L = g.chain_len[c];
+            const int64_t Lfree = L - (c == 0 ? 1 : 0);
+            for (int64_t i = 0; i < L; ++i, ++p) {
+                if (c == 0 && i == 0) { pose_col[p] = -1; pose_kstride[p] = 0; continue; }
+                const int64_t node = i - (c == 0 ? 1 : 0);
+                pose_col[p] = col + node * D1;   // k = 0 block; row k adds k * Lfree * D1
+                pose_kstride[p] = Lfree * D1;
+            }
+            for (int k = 0; k < d; ++k) {
+                if (Lfree > 0) {
+                    for (int64_t node = 0; node < Lfree; ++node) out.node_first_col.push_back((int32_t)(col + k * Lfree * D1 + node * D1));
+                    out.chain_ptr.push_back(out.chain_ptr.back() + (int32_t)Lfree);
+                }
+            }
+            col += Lfree * d * D1;
+        }
+    }
+    out.block_size = D1;
+    auto pcol = [&](int64_t p, int k, int j) -> int64_t { return pose_col[p] < 0 ? -1 : pose_col[p] + k * pose_kstride[p] + j; };
+    // translation column k of a variable id (pose or landmark); -1 for the pinned pose (value 0)
+    auto tcol = [&](int64_t v, int k) -> int64_t {
+        if (v < 0 || v >= Np + Nl) throw std::runtime_error("score_graph: range endpoint out of range");
+        if (v < Np) return pcol(v, k, d);
+        return lm_base + (v - Np) * d + k;
+    };
+    // ---- P, q, c0.  The measurement loops run twice over the same code: a counting pass sizes every
+    //      row, a filling pass writes (column, value) pairs into one flat array; rows are then sorted
+    //      and merged in parallel (rows are short: a few (d+1)-blocks each). ----
+    out.q.assign((size_t)n, 0.0);
+    double c0 = 0.0;
+    std::vector<int32_t> cnt((size_t)n + 1, 0);
+    std::vector<int32_t> tcols;
+    std::vector<double> tvals;
+    std::vector<int32_t> fill;
+    bool filling = false;
+    auto addP = [&](int64_t r, int64_t c, double v) {
+        if (!filling) { ++cnt[(size_t)r + 1]; return; }
+        const int32_t pos = fill[(size_t)r]++;
+        tcols[(size_t)pos] = (int32_t)c;
+        tvals[(size_t)pos] = v;
+    };
+    auto measurements = [&]() {
+        // relative-pose terms.  Per matrix row k (the d rows of a pose are decoupled and share their blocks):
+        //   residual = u_j - G u_i,  u = (R[k,0..d-1], t[k]),  G[c][l] = Rm[l][c] (c < d), G[d][l] = tm[l], G[d][d] = 1,
+        //   weights W = diag(tau, ..., tau, kappa).   cost = res' W res.
+        for (int64_t e = 0; e < g.n_rel; ++e) {
+            const int64_t i = g.rel_base[e], j = g.rel_to[e];
+            if (i < 0 || i >= Np || j < 0 || j >= Np) throw std::runtime_error("score_graph: relative-pose endpoint out of range");
+            const double* tm = g.rel_t + e * d;
+            const double* Rm = g.rel_R + e * d * d;
+            const double kap = g.rel_kappa[e], tau = g.rel_tau[e];
+            double G[4][4] = {{0}}, W[4];
+            for (int c = 0; c < d; ++c) {
+                for (int l = 0; l < d; ++l) G[c][l] = Rm[l * d + c];
+                W[c] = tau;
+            }
+            for (int l = 0; l < d; ++l) G[d][l] = tm[l];
+            G[d][d] = 1.0;
+            W[d] = kap;
+            double GtWG[4][4], GtW[4][4];
+            for (int a = 0; a < D1; ++a)
+                for (int b2 = 0; b2 < D1; ++b2) {
+                    GtW[a][b2] = G[b2][a] * W[b2];
+                    double s_ = 0;
+                    for (int c = 0; c < D1; ++c) s_ += G[c][a] * W[c] * G[c][b2];
+                    GtWG[a][b2] = s_;
+                }
+            for (int k = 0; k < d; ++k) {
+                const int64_t ci = pcol(i, k, 0), cj = pcol(j, k, 0);
+                double ui[4] = {0, 0, 0, 0}, uj[4] = {0, 0, 0, 0};  // pinned pose: [I | 0]
+                ui[k] = 1.0; uj[k] = 1.0;
+                if (cj >= 0) {
+                    for (int a = 0; a < D1; ++a) addP(cj + a, cj + a, 2.0 * W[a]);
+                    if (ci >= 0) {
+                        for (int a = 0; a < D1; ++a)
+                            for (int b2 = 0; b2 < D1; ++b2) {
+                                const double v = -2.0 * GtW[a][b2];  // block (i, j) = -2 G'W ; (j, i) its transpose
+                                if (G[b2][a] != 0.0) { addP(ci + a, cj + b2, v); addP(cj + b2, ci + a, v); }
+                            }
+                    } else if (filling) {  // u_i fixed: cost (u_j - G u_i)' W (u_j - G u_i)
+                        for (int a = 0; a < D1; ++a) {
+                            double gu = 0;
+                            for (int l = 0; l < D1; ++l) gu += G[a][l] * ui[l];
+                            out.q[(size_t)(cj + a)] += -2.0 * W[a] * gu;
+                            c0 += W[a] * gu * gu;
+                        }
+                    }
+                }
+                if (ci >= 0) {
+                    for (int a = 0; a < D1; ++a)
+                        for (int b2 = 0; b2 < D1; ++b2) addP(ci + a, ci + b2, 2.0 * GtWG[a][b2]);
+                    if (cj < 0 && filling) {  // u_j fixed
+                        for (int a = 0; a < D1; ++a) {
+                            double s_ = 0;
+                            for (int c = 0; c < D1; ++c) s_ += GtW[a][c] * uj[c];
+                            out.q[(size_t)(ci + a)] += -2.0 * s_;
+                        }
+                        for (int c = 0; c < D1; ++c) c0 += W[c] * uj[c] * uj[c];
+                    }
+                }
+                if (ci < 0 && cj < 0 && filling) {
+                    for (int a = 0; a < D1; ++a) {
+                        double gu = 0;
+                        for (int l = 0; l < D1; ++l) gu += G[a][l] * ui[l];
+                        c0 += W[a] * (uj[a] - gu) * (uj[a] - gu);
+                    }
+                }
+            }
+        }
+        // range costs
+        for (int64_t r = 0; r < Nr; ++r) {
+            const double w = g.rng_prec[r], dist = g.rng_dist[r];
+            if (g.relaxation == 0) {  // w (d_ij - dist)^2    (:487)
+                const int64_t c = rng_base + r;
+                addP(c, c, 2.0 * w);
+                if (filling) {
+                    out.q[(size_t)c] += -2.0 * w * dist;
+                    c0 += w * dist * dist;
+                }
+            } else {  // w || t_a - t_b - dist r ||^2    (:489-496)
+                for (int k = 0; k < d; ++k) {
+                    const int64_t cs[3] = {tcol(g.rng_a[r], k), tcol(g.rng_b[r], k), rng_base + r * d + k};
+                    const double cf[3] = {1.0, -1.0, -dist};
+                    for (int a = 0; a < 3; ++a)
+                        for (int b2 = 0; b2 < 3; ++b2)
+                            if (cs[a] >= 0 && cs[b2] >= 0) addP(cs[a], cs[b2], 2.0 * w * cf[a] * cf[b2]);
+                    // (a pinned translation is zero: no linear or constant term)
+                }
+            }
+        }
+        // landmark priors  w (l[k] - tv[k])^2    (:433-446)
+        for (int64_t e = 0; e < g.n_lprior; ++e) {
+            const int64_t l = g.lprior_lm[e];
+            if (l < 0 || l >= Nl) throw std::runtime_error("score_graph: landmark prior out of range");
+            const double w = g.lprior_prec[e];
+            for (int k = 0; k < d; ++k) {
+                const int64_t c = lm_base + l * d + k;
+                const double tv = g.lprior_t[e * d + k];
+                addP(c, c, 2.0 * w);
+                if (filling) {
+                    out.q[(size_t)c] += -2.0 * w * tv;
+                    c0 += w * tv * tv;
+                }
+            }
+        }
+    };
+    measurements();  // counting pass
+    for (int64_t i = 0; i < n; ++i) cnt[(size_t)i + 1] += cnt[(size_t)i];
+    tcols.resize((size_t)cnt[(size_t)n]);
+    tvals.resize((size_t)cnt[(size_t)n]);
+    fill.assign(cnt.begin(), cnt.end() - 1);
+    filling = true;
+    measurements();  // filling pass
+    out.c0 = c0;
+    // sort + merge every row (stable: equal columns are summed in the order they were met)
+    out.n = (int32_t)n;
+    out.P_ptr.assign((size_t)n + 1, 0);
+    {
+        const int T = parallel_parts(n, 8192);
+        std::vector<std::vector<int32_t>> pc(T);
+        std::vector<std::vector<double>> pv(T);
+        parallel_ranges(n, 8192, [&](int t, int64_t i0, int64_t i1) {
+            pc[t].reserve((size_t)(cnt[(size_t)i1] - cnt[(size_t)i0]));
+            pv[t].reserve((size_t)(cnt[(size_t)i1] - cnt[(size_t)i0]));
+            std::vector<detail::Trip> L;
+            for (int64_t i = i0; i < i1; ++i) {
+                L.clear();
+                for (int32_t k = cnt[(size_t)i]; k < cnt[(size_t)i + 1]; ++k) L.push_back(detail::Trip{tcols[(size_t)k], tvals[(size_t)k]});
+                // insertion sort: short, stable
+                for (size_t x = 1; x < L.size(); ++x) {
+                    const detail::Trip e = L[x];
+                    size_t y = x;
+                    while (y > 0 && L[y - 1].col > e.col) { L[y] = L[y - 1]; --y; }
+                    L[y] = e;
+                }
+                int32_t c_ = 0;
+                size_t x = 0;
+                while (x < L.size()) {
+                    const int32_t c = L[x].col;
+                    double s_ = 0;
+                    for (; x < L.size() && L[x].col == c; ++x) s_ += L[x].val;
+                    pc[t].push_back(c); pv[t].push_back(s_);
+                    ++c_;
+                }
+                out.P_ptr[(size_t)i + 1] = c_;
+            }
+        });
+        for (int64_t i = 0; i < n; ++i) out.P_ptr[(size_t)i + 1] += out.P_ptr[(size_t)i];
+        out.P_col.resize((size_t)out.P_ptr[(size_t)n]);
+        out.P_val.resize((size_t)out.P_ptr[(size_t)n]);
+        for (int t = 0; t < T; ++t) {
+            if (pc[t].empty()) continue;
+            const int64_t i0 = n * t / T;  // the ranges of parallel_ranges are contiguous and ordered
+            std::memcpy(&out.P_col[(size_t)out.P_ptr[(size_t)i0]], pc[t].data(), pc[t].size() * sizeof(int32_t));
+            std::memcpy(&out.P_val[(size_t)out.P_ptr[(size_t)i0]], pv[t].data(), pv[t].size() * sizeof(double));
+        }
+    }
+    // ---- cones (:336-352): s = b - A x ----
+    const int64_t m = Nr * D1;
+    out.m = (int32_t)m;
+    out.b.assign((size_t)m, 0.0);
+    out.A_ptr.assign(1, 0);
+    out.soc_dims.assign((size_t)Nr, D1);
+    for (int64_t r = 0; r < Nr; ++r) {
+        if (g.relaxation == 0) {
+            // (d_ij, t_a - t_b) in SOC: A = -[e_d ; e_ta - e_tb], b = 0
+            out.A_col.push_back((int32_t)(rng_base + r)); out.A_val.push_back(-1.0);
+            out.A_ptr.push_back((int32_t)out.A_col.size());
+            for (int k = 0; k < d; ++k) {
+                int64_t ca = tcol(g.rng_a[r], k), cb = tcol(g.rng_b[r], k);
+                double va = -1.0, vb = 1.0;
+                if (ca >= 0 && cb >= 0 && ca == cb) throw std::runtime_error("score_graph: range between a variable and itself");
+                if (ca >= 0 && cb >= 0 && cb < ca) { std::swap(ca, cb); std::swap(va, vb); }
+                if (ca >= 0) { out.A_col.push_back((int32_t)ca); out.A_val.push_back(va); }
+                if (cb >= 0) { out.A_col.push_back((int32_t)cb); out.A_val.push_back(vb); }
+                out.A_ptr.push_back((int32_t)out.A_col.size());
+            }
+        } else {
+            // (1, r_ij) in SOC: A = -[0 ; I], b = (1, 0..0)
+            out.b[(size_t)(r * D1)] = 1.0;
+            out.A_ptr.push_back((int32_t)out.A_col.size());
+            for (int k = 0; k < d; ++k) {
+                out.A_col.push_back((int32_t)(rng_base + r * d + k)); out.A_val.push_back(-1.0);
+                out.A_ptr.push_back((int32_t)out.A_col.size());
+            }
+        }
+    }
+}
+
+}  // namespace score

@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "score_driver.hpp"
+#include "score_assemble.hpp"
 #include "score_kernels.hpp"
 #include "score_polish.hpp"
 
@@ -372,7 +373,7 @@ struct HipBackend {
         done.upload(dz);
         K0d.upload_padded(h.K0, 64); K1d.upload_padded(h.K1, 64);
         kposd.upload(h.pos_diag); kposs.upload(h.pos_sub); kdiagpos.upload(h.diag_kpos);
-        fac.alloc(h.fac.size()); fac.zero(stream);  // separator slots of the spike region are never written (nor used)
+        fac.alloc(h.fac_doubles); fac.zero(stream);  // separator slots of the spike region are never written (nor used)
         dinv.alloc(h.dinv.size()); rho.upload(h.rho);
         q_work.alloc((size_t)std::max<int64_t>(1, h.scratch_nodes) * 2 * std::max(1, h.bs * h.bs));
         derive_rho_data(false);
@@ -839,7 +840,7 @@ struct HipBackend {
         else if (nm == "D") { src = h.D.data(); sz = h.n_tot; host = true; }
         else if (nm == "E") { src = h.E.data(); sz = h.m_tot; host = true; }
         else if (nm == "Kval") { src = K.val.d; sz = (int64_t)h.K.val.size(); }
-        else if (nm == "fac") { src = fac.d; sz = (int64_t)h.fac.size(); }
+        else if (nm == "fac") { src = fac.d; sz = (int64_t)h.fac_doubles; }
         // ---- kernel-level checks of the Newton polish (tests/test_gpu_parity.py) ----
         else if (nm == "polish_assemble_at_x") {
             // evaluate F, gradient, generalised Hessian and its chain factors at the current ADMM
@@ -946,7 +947,7 @@ struct HipBackend {
         n_fpart = std::max<size_t>((nc + kThreads - 1) / kThreads, (size_t)n_cone_blocks);
         q_X0.alloc(h.n_tot + h.m_tot); q_X1.alloc(h.n_tot + h.m_tot);
         q_g.alloc(h.n_tot); q_delta.alloc(h.n_tot); q_dummy.alloc(h.n_tot); q_negg.alloc(h.n_tot);
-        q_fac.alloc(h.fac.size()); q_dinv.alloc(h.dinv.size());
+        q_fac.alloc(h.fac_doubles); q_dinv.alloc(h.dinv.size());
         q_fac.zero(stream);  // separator slots of the spike region are never written (nor used)
         n_gd = std::max<size_t>((h.n_tot + kThreads - 1) / kThreads, (size_t)Hm.nblocks);
         q_pw.alloc(Hm.nblocks);
@@ -1388,6 +1389,10 @@ struct HipBackend {
 
 }  // namespace
 
+struct score_assembled {
+    score::AssembledQP qp;
+};
+
 struct score_handle {
     score::Solver<HipBackend> solver;
 };
@@ -1494,6 +1499,26 @@ void score_destroy(score_handle* h) {
         delete h;
     }
 }
+int score_assemble(const score_graph* g, score_assembled** out) {
+    try {
+        if (!g || !out) throw std::runtime_error("null argument");
+        auto* a = new score_assembled();
+        try {
+            score::assemble_graph(*g, a->qp);
+        } catch (...) {
+            delete a;
+            throw;
+        }
+        *out = a;
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_assembled_view(const score_assembled* a, score_problem* view) {
+    if (!a || !view) { g_err = "null argument"; return -1; }
+    a->qp.view(view);
+    return 0;
+}
+void score_assembled_free(score_assembled* a) { delete a; }
 const char* score_last_error(void) { return g_err.c_str(); }
 const char* score_backend(void) { return "hip-gfx950"; }
 }

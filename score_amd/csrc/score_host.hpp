@@ -327,6 +327,39 @@ inline void factor_chain_levels(int bs, int radix, int N0, const std::vector<dou
     scratch_nodes = vec_off;
 }
 
+// The level structure of factor_chain_levels() for a chain of N0 nodes (it depends on nothing else):
+// descriptors with offsets relative to the chain's first factor double, total doubles, scratch nodes.
+inline void chain_level_layout(int bs, int radix, int N0, std::vector<ChainLevelDesc>& levels, size_t& fac_size,
+                               int& scratch_nodes) {
+    const int b2 = bs * bs;
+    int N = N0, vec_off = 0, lds_off = 0;
+    size_t off = 0;
+    levels.clear();
+    for (int lvl = 0;; ++lvl) {
+        ChainLevelDesc L{};
+        L.N = N;
+        L.vec_off = (lvl == 0) ? -1 : vec_off;
+        if (lvl > 0) vec_off += N;
+        const bool last = (N <= radix - 1);
+        L.p = last ? 0 : radix;
+        L.inv_p = last ? 0u : ((1u << 20) / (uint32_t)radix + 1u);
+        L.lds_off = lds_off;
+        lds_off += N * bs + (last ? 0 : N / radix) + 1;
+        const int nsep = last ? 0 : N / radix;
+        L.nsep = nsep;
+        L.nruns = nsep + 1;
+        L.P = last ? N : radix - 1;
+        L.offR = (int64_t)off; off += (size_t)2 * b2 * L.P * L.nruns;
+        L.offS = (int64_t)off; off += (size_t)2 * b2 * nsep;
+        L.offB = (int64_t)off; off += (size_t)2 * b2 * N;
+        levels.push_back(L);
+        if (last) break;
+        N = nsep;
+    }
+    fac_size = off;
+    scratch_nodes = vec_off;
+}
+
 // Reference (host) application of the factorisation: z = M^{-1} r for one chain.
 // r/z are indexed by column (level 0 gathers through node_col); `scr` holds the
 // level >= 1 vectors.  The HIP kernel performs exactly these operations.
@@ -443,6 +476,7 @@ struct HostSystem {
     std::vector<ChainDesc> chains;
     std::vector<ChainLevelDesc> levels;
     std::vector<double> fac;
+    size_t fac_doubles = 0;  // size of the factor storage (== fac.size() when the host holds it)
     int64_t scratch_nodes = 0;
     int max_chain_scratch = 0;
     std::vector<int32_t> diag_cols, diag_kpos;
@@ -948,16 +982,10 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         for (const auto& L : layouts)
             if (L.N == ch.N) lay = &L;
         if (!lay) {
-            // dry run on an identity chain to obtain the level structure
-            std::vector<double> Ad((size_t)ch.N * b2, 0.0), Bs((size_t)ch.N * b2, 0.0);
-            for (int i = 0; i < ch.N; ++i)
-                for (int a = 0; a < bs; ++a) Ad[(size_t)i * b2 + a * bs + a] = 1.0;
             Layout L;
             L.N = ch.N;
-            std::vector<double> f;
             L.scr = 0;
-            factor_chain_levels(bs, H.radix, ch.N, Ad, Bs, L.lv, f, L.scr);
-            L.fac_size = f.size();
+            chain_level_layout(bs, H.radix, ch.N, L.lv, L.fac_size, L.scr);
             layouts.push_back(std::move(L));
             lay = &layouts.back();
         }
@@ -981,8 +1009,10 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         H.scratch_nodes += scr;
         H.max_chain_scratch = std::max(H.max_chain_scratch, scr);
     }
-    H.fac.assign(fac_total, 0.0);
-    pt.mark("level layout (dry run)");
+    // (the factors themselves live on the device when the backend derives them there)
+    H.fac.assign(H.factor_on_host ? fac_total : 0, 0.0);
+    H.fac_doubles = fac_total;
+    pt.mark("level layout");
     // Jacobi columns + work list (problem-major: chains, then Jacobi blocks)
     size_t ci = 0;
     for (int p = 0; p < count; ++p) {

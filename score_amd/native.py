@@ -1,0 +1,259 @@
+"""Native (C++) model construction through the C ABI: ``score_assemble``.
+
+``assemble_native(data, relaxation)`` is a drop-in for ``score_amd.assemble.assemble`` -- it
+returns a ``ScoreModel`` with the same column layout and read-back maps -- but the conic program
+(P, q, A, b, cones, chain hint) is built by ``score_amd/csrc/score_assemble.hpp`` from flat
+measurement arrays instead of SciPy sparse algebra: a few milliseconds per 20-robot graph, with
+the GIL released (model construction is what bounds ``solve_score_batch`` once the solve takes
+milliseconds; reference: score/utils/gurobi_utils.py:173-187 ``initialize_model``).
+
+The assembled program lives in the library's host memory; ``NativeQP`` hands its ``score_problem``
+view to ``score_create[_batch]`` directly and only materialises SciPy matrices when a caller asks
+for ``.P`` / ``.A`` (tests, the oracle's certificate).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import scipy.sparse as sp
+
+from .assemble import (
+    QCQP_RELAXATION,
+    SOCP_RELAXATION,
+    ScoreModel,
+    _check_unique,
+    _pose_meas_arrays,
+    check_dimension,
+    check_valid_relaxation,
+)
+from .solver import ScoreProblem, _f64p, _i32p, load_library
+
+
+class ScoreGraph(C.Structure):
+    _fields_ = [
+        ("dim", C.c_int32), ("relaxation", C.c_int32), ("n_chains", C.c_int32), ("chain_len", _i32p),
+        ("n_landmarks", C.c_int32),
+        ("n_rel", C.c_int64), ("rel_base", _i32p), ("rel_to", _i32p), ("rel_t", _f64p), ("rel_R", _f64p),
+        ("rel_kappa", _f64p), ("rel_tau", _f64p),
+        ("n_rng", C.c_int64), ("rng_a", _i32p), ("rng_b", _i32p), ("rng_dist", _f64p), ("rng_prec", _f64p),
+        ("n_lprior", C.c_int64), ("lprior_lm", _i32p), ("lprior_t", _f64p), ("lprior_prec", _f64p),
+    ]
+
+
+def _bind(lib: C.CDLL) -> None:
+    if getattr(lib, "_score_assemble_bound", False):
+        return
+    lib.score_assemble.argtypes = [C.POINTER(ScoreGraph), C.POINTER(C.c_void_p)]
+    lib.score_assembled_view.argtypes = [C.c_void_p, C.POINTER(ScoreProblem)]
+    lib.score_assembled_free.argtypes = [C.c_void_p]
+    lib.score_assembled_free.restype = None
+    lib._score_assemble_bound = True
+
+
+def graph_arrays(data) -> Dict[str, np.ndarray]:
+    """FactorGraphData -> the flat arrays of ``score_graph`` (the only per-measurement Python work
+    left on the path: attribute reads).  Raises the reference's errors for duplicate / unknown
+    variable names (gurobi_utils.py:62-80, :103-109)."""
+    d = data.dimension
+    check_dimension(d)
+    pose_names = [p.name for chain in data.pose_variables for p in chain]
+    landmark_names = [l.name for l in data.landmark_variables]
+    _check_unique(pose_names, "pose_vars")
+    _check_unique(landmark_names, "landmark_vars")
+    pose_idx = {nm: i for i, nm in enumerate(pose_names)}
+    for nm in landmark_names:
+        if nm in pose_idx:
+            raise ValueError(f"Variable name {nm} already exists in pose_vars")
+    Np = len(pose_names)
+    if Np == 0:
+        raise ValueError("factor graph has no pose variables")
+    var_idx = dict(pose_idx)
+    var_idx.update((nm, Np + i) for i, nm in enumerate(landmark_names))
+    range_keys = [(m.first_key, m.second_key) for m in data.range_measurements]
+    if len(set(range_keys)) != len(range_keys):
+        seen = set()
+        for k in range_keys:
+            if k in seen:
+                raise ValueError(f"Variable name {k} already exists in distance_vars")
+            seen.add(k)
+    meas = [m for chain in data.odom_measurements for m in chain]
+    meas += list(data.loop_closure_measurements)
+    ne = len(meas)
+    if ne:
+        bi, tj, kap, tau, tm, Rm = _pose_meas_arrays(meas, pose_idx, d)
+    else:
+        bi = tj = np.zeros(0, np.int64); kap = tau = np.zeros(0); tm = np.zeros((0, d)); Rm = np.zeros((0, d, d))
+    nr = len(range_keys)
+
+    def vid(name):
+        try:
+            return var_idx[name]
+        except KeyError:
+            raise ValueError(f"Variable name {name} not found") from None
+
+    ra = np.fromiter((vid(a) for a, _ in range_keys), dtype=np.int32, count=nr)
+    rb = np.fromiter((vid(b) for _, b in range_keys), dtype=np.int32, count=nr)
+    dist = np.fromiter((m.dist for m in data.range_measurements), dtype=np.float64, count=nr)
+    prec = np.fromiter((m.precision for m in data.range_measurements), dtype=np.float64, count=nr)
+    lm_idx = {nm: i for i, nm in enumerate(landmark_names)}
+    pri = list(data.landmark_priors)
+    for p in pri:
+        if p.name not in lm_idx and p.name not in pose_idx:
+            raise ValueError(f"Variable name {p.name} not found")
+        if p.name not in lm_idx:
+            raise ValueError(f"landmark prior on {p.name}: not a landmark")
+    return dict(
+        dim=d, pose_names=pose_names, landmark_names=landmark_names, range_keys=range_keys,
+        chain_len=np.array([len(c) for c in data.pose_variables], dtype=np.int32),
+        rel_base=bi.astype(np.int32), rel_to=tj.astype(np.int32), rel_t=np.ascontiguousarray(tm, dtype=np.float64),
+        rel_R=np.ascontiguousarray(Rm, dtype=np.float64), rel_kappa=np.ascontiguousarray(kap, dtype=np.float64),
+        rel_tau=np.ascontiguousarray(tau, dtype=np.float64),
+        rng_a=ra, rng_b=rb, rng_dist=dist, rng_prec=prec,
+        lprior_lm=np.array([lm_idx[p.name] for p in pri], dtype=np.int32),
+        lprior_t=np.array([np.asarray(p.translation_vector, dtype=np.float64) for p in pri], dtype=np.float64).reshape(-1, d),
+        lprior_prec=np.array([float(p.translation_precision) for p in pri], dtype=np.float64),
+    )
+
+
+class NativeQP:
+    """The assembled conic program held by the native library (duck-types ``assemble.ConicQP``)."""
+
+    def __init__(self, lib: C.CDLL, handle: C.c_void_p):
+        self._lib, self._h = lib, handle
+        self.problem = ScoreProblem()
+        if lib.score_assembled_view(handle, C.byref(self.problem)) != 0:
+            raise RuntimeError(lib.score_last_error().decode())
+        p = self.problem
+        self.n, self.m, self.z = int(p.n), int(p.m), int(p.z)
+        self.c0 = float(p.c0)
+        self.block_size = int(p.block_size)
+        self._cache = {}
+
+    def _arr(self, ptr, count, dtype):
+        if count == 0:
+            return np.zeros(0, dtype=dtype)
+        return np.ctypeslib.as_array(ptr, shape=(count,)).copy()
+
+    def _get(self, key, fn):
+        if key not in self._cache:
+            self._cache[key] = fn()
+        return self._cache[key]
+
+    @property
+    def P(self) -> sp.csr_matrix:
+        def build():
+            p = self.problem
+            ptr = self._arr(p.P_rowptr, self.n + 1, np.int32)
+            return sp.csr_matrix((self._arr(p.P_val, int(ptr[-1]), np.float64), self._arr(p.P_col, int(ptr[-1]), np.int32), ptr),
+                                 shape=(self.n, self.n))
+        return self._get("P", build)
+
+    @property
+    def A(self) -> sp.csr_matrix:
+        def build():
+            p = self.problem
+            ptr = self._arr(p.A_rowptr, self.m + 1, np.int32)
+            return sp.csr_matrix((self._arr(p.A_val, int(ptr[-1]), np.float64), self._arr(p.A_col, int(ptr[-1]), np.int32), ptr),
+                                 shape=(self.m, self.n))
+        return self._get("A", build)
+
+    @property
+    def q(self) -> np.ndarray:
+        return self._get("q", lambda: self._arr(self.problem.q, self.n, np.float64))
+
+    @property
+    def b(self) -> np.ndarray:
+        return self._get("b", lambda: self._arr(self.problem.b, self.m, np.float64))
+
+    @property
+    def soc_dims(self) -> np.ndarray:
+        return self._get("soc", lambda: self._arr(self.problem.soc_dims, int(self.problem.n_soc), np.int32))
+
+    @property
+    def chain_ptr(self) -> np.ndarray:
+        return self._get("cp", lambda: self._arr(self.problem.chain_ptr, int(self.problem.n_chains) + 1, np.int32))
+
+    @property
+    def node_cols(self) -> np.ndarray:
+        def build():
+            first = self._arr(self.problem.node_first_col, int(self.chain_ptr[-1]), np.int32)
+            return (first[:, None] + np.arange(self.block_size, dtype=np.int32)[None, :]).ravel()
+        return self._get("nc", build)
+
+    def objective(self, x: np.ndarray) -> float:
+        return 0.5 * float(np.einsum("i,i->", x, self.P @ x)) + float(np.einsum("i,i->", self.q, x)) + self.c0
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.score_assembled_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def assemble_native(data, relaxation: str = QCQP_RELAXATION, lib_path: Optional[str] = None, arrays: Optional[dict] = None) -> ScoreModel:
+    check_valid_relaxation(relaxation)
+    lib = load_library(lib_path)
+    _bind(lib)
+    a = arrays if arrays is not None else graph_arrays(data)
+    d = int(a["dim"])
+    g = ScoreGraph()
+    g.dim, g.relaxation = d, (0 if relaxation == SOCP_RELAXATION else 1)
+    g.n_chains, g.chain_len = len(a["chain_len"]), a["chain_len"].ctypes.data_as(_i32p)
+    g.n_landmarks = len(a["landmark_names"])
+    g.n_rel = len(a["rel_base"])
+    g.rel_base, g.rel_to = a["rel_base"].ctypes.data_as(_i32p), a["rel_to"].ctypes.data_as(_i32p)
+    g.rel_t, g.rel_R = a["rel_t"].ctypes.data_as(_f64p), a["rel_R"].ctypes.data_as(_f64p)
+    g.rel_kappa, g.rel_tau = a["rel_kappa"].ctypes.data_as(_f64p), a["rel_tau"].ctypes.data_as(_f64p)
+    g.n_rng = len(a["rng_a"])
+    g.rng_a, g.rng_b = a["rng_a"].ctypes.data_as(_i32p), a["rng_b"].ctypes.data_as(_i32p)
+    g.rng_dist, g.rng_prec = a["rng_dist"].ctypes.data_as(_f64p), a["rng_prec"].ctypes.data_as(_f64p)
+    g.n_lprior = len(a["lprior_lm"])
+    g.lprior_lm, g.lprior_t = a["lprior_lm"].ctypes.data_as(_i32p), a["lprior_t"].ctypes.data_as(_f64p)
+    g.lprior_prec = a["lprior_prec"].ctypes.data_as(_f64p)
+    h = C.c_void_p()
+    if lib.score_assemble(C.byref(g), C.byref(h)) != 0:
+        raise ValueError(lib.score_last_error().decode())
+    qp = NativeQP(lib, h)
+    # read-back maps: the same formulas as assemble.py (model space keeps the Gurobi layout)
+    D1, PB = d + 1, d * (d + 1)
+    Np, Nl, Nr = len(a["pose_names"]), len(a["landmark_names"]), len(a["range_keys"])
+    rw = 1 if relaxation == SOCP_RELAXATION else d
+    lm_base = Np * PB
+    rng_base = lm_base + Nl * d
+    n_model = rng_base + Nr * rw
+    pieces, base = [], 0
+    j_ar = np.arange(D1)
+    for L in a["chain_len"]:
+        idx = base + np.arange(int(L))
+        idx = idx[idx != 0]
+        for k in range(d):
+            pieces.append((idx[:, None] * PB + k * D1 + j_ar[None, :]).ravel())
+        base += int(L)
+    pieces.append(np.arange(lm_base, n_model))
+    free_cols = np.concatenate(pieces)
+    assert free_cols.size == qp.n, (free_cols.size, qp.n)
+    ends = dist = None
+    if Nr:
+        va, vb = a["rng_a"].astype(np.int64), a["rng_b"].astype(np.int64)
+
+        def tcol(v):
+            pose = v < Np
+            return np.where(pose, v * PB + d, lm_base + (v - Np) * d), np.where(pose, D1, 1)
+
+        ta, sa = tcol(va)
+        tb, sb = tcol(vb)
+        ends = np.stack([ta, sa, tb, sb], axis=1)
+        dist = a["rng_dist"]
+    return ScoreModel(
+        dim=d, relaxation=relaxation, qp=qp, n_model=n_model, free_cols=free_cols,
+        fixed_cols=np.arange(PB), fixed_vals=np.hstack([np.eye(d), np.zeros((d, 1))]).ravel(),
+        pose_names=a["pose_names"], landmark_names=a["landmark_names"], range_keys=a["range_keys"],
+        lm_base=lm_base, rng_base=rng_base, rng_width=rw, range_ends=ends, range_dist=dist,
+    )

@@ -75,18 +75,18 @@ def extract_solver_results(
     T = np.tile(np.eye(d + 1), (blocks.shape[0], 1, 1))
     T[:, :d, :d] = R
     T[:, :d, d] = blocks[:, :, d]
-    # (rows of freshly built arrays: iterating a 2-D/3-D array yields one view per entry)
-    poses = dict(zip(model.pose_names, T))
-    landmarks = dict(zip(model.landmark_names, model.landmark_block(xm).copy()))
+    # dict-like views over the stacked arrays (compat.ArrayDict): no per-pose Python objects
+    poses = compat.ArrayDict(model.pose_names, T)
+    landmarks = compat.ArrayDict(model.landmark_names, model.landmark_block(xm).copy())
     if requested_relaxation == model.relaxation:
-        dists = dict(zip(model.range_keys, model.range_block(xm).copy()))
+        dists = compat.ArrayDict(model.range_keys, model.range_block(xm).copy())
     else:  # QCQP answered through the SOCP
-        dists = dict(zip(model.range_keys, _qcqp_dists_from_socp(model, xm, data)))
+        dists = compat.ArrayDict(model.range_keys, _qcqp_dists_from_socp(model, xm, data))
     values = compat.VariableValues(d, poses, landmarks, dists)
     return compat.SolverResults(
         variables=values, total_time=total_time, solved=solved,
         pose_chain_names=data.get_pose_chain_names(), solver_cost=(info or {}).get("pobj"), info=info,
-        relaxed_poses=dict(zip(model.pose_names, blocks.copy())),
+        relaxed_poses=compat.ArrayDict(model.pose_names, blocks.copy()),
     )
 
 
@@ -103,15 +103,23 @@ def _resolve_args(args, relaxation_type):
     return params, relaxation_type
 
 
-def _model_for(data, relaxation_type: str, qcqp_mode: str) -> ScoreModel:
-    if relaxation_type == QCQP_RELAXATION and qcqp_mode == "via_socp":
-        return assemble(data, SOCP_RELAXATION)
-    return assemble(data, relaxation_type)
+def _model_for(data, relaxation_type: str, qcqp_mode: str, lib_path: Optional[str] = None, assembler: str = "native") -> ScoreModel:
+    """Model construction (gurobi_utils.py:173-187).  ``assembler="native"`` (default): the C++
+    assembler behind the C ABI (score_assemble, score_amd/native.py); ``"python"``: the NumPy/SciPy
+    one (score_amd/assemble.py) -- same program, same column layout."""
+    relax = SOCP_RELAXATION if (relaxation_type == QCQP_RELAXATION and qcqp_mode == "via_socp") else relaxation_type
+    if assembler == "native":
+        from .native import assemble_native
+
+        return assemble_native(data, relax, lib_path=lib_path)
+    if assembler != "python":
+        raise ValueError(f"assembler {assembler} is not supported")
+    return assemble(data, relax)
 
 
 def solve_score(
     data, *args, relaxation_type: str = QCQP_RELAXATION, qcqp_mode: str = "via_socp",
-    solver_settings: Optional[dict] = None, lib_path: Optional[str] = None,
+    solver_settings: Optional[dict] = None, lib_path: Optional[str] = None, assembler: str = "native",
 ) -> compat.SolverResults:
     """MLE estimate of poses and landmarks from the SCORE relaxation.
 
@@ -125,13 +133,13 @@ def solve_score(
     """
     _params, relaxation_type = _resolve_args(args, relaxation_type)
     return solve_score_batch([data], relaxation_type=relaxation_type, qcqp_mode=qcqp_mode,
-                             solver_settings=solver_settings, lib_path=lib_path)[0]
+                             solver_settings=solver_settings, lib_path=lib_path, assembler=assembler)[0]
 
 
 def solve_score_batch(
     datas: Sequence, relaxation_type: str = QCQP_RELAXATION, qcqp_mode: str = "via_socp",
     solver_settings: Optional[dict] = None, lib_path: Optional[str] = None, lockstep: Optional[bool] = None,
-    workers: int = 4,
+    workers: int = 4, assembler: str = "native",
 ) -> List[compat.SolverResults]:
     """Independent factor graphs on one GPU.
 
@@ -172,7 +180,7 @@ def solve_score_batch(
         def one(idx):
             try:
                 return solve_score_batch([datas[i] for i in idx], relaxation_type, qcqp_mode, solver_settings, lib_path,
-                                         lockstep=True)
+                                         lockstep=True, assembler=assembler)
             except ValueError as exc:  # keep what the other graphs of this group produced
                 partial = getattr(exc, "partial_results", None)
                 if partial is None:
@@ -204,7 +212,7 @@ def solve_score_batch(
     models = []
     for data in datas:
         _check_factor_graph(data)
-        models.append(_model_for(data, relaxation_type, qcqp_mode))
+        models.append(_model_for(data, relaxation_type, qcqp_mode, lib_path, assembler))
     settings = dict(DEFAULT_SOLVER_SETTINGS)
     if any(len(d.loop_closure_measurements) for d in datas):
         # loop closures are stiff couplings outside the per-robot chains the
@@ -252,7 +260,7 @@ def solve_problem_with_intermediate_iterates(
     single run is paused every ``every`` ADMM iterations."""
     check_valid_relaxation(relaxation_type)
     _check_factor_graph(data)
-    model = _model_for(data, relaxation_type, qcqp_mode)
+    model = _model_for(data, relaxation_type, qcqp_mode, lib_path)
     settings = dict(DEFAULT_SOLVER_SETTINGS)
     settings.update(solver_settings or {})
     solver = ConicSolver([model.qp], settings, lib_path=lib_path)

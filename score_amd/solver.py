@@ -66,6 +66,7 @@ STATUS_NAMES = {0: "unsolved", 1: "solved", 2: "max_iters", 3: "numerical"}
 
 # every symbol include/score_hip.h declares
 ABI_SYMBOLS = [
+    "score_assemble", "score_assembled_view", "score_assembled_free",
     "score_default_settings", "score_create", "score_create_batch", "score_dims", "score_solve",
     "score_reset", "score_solve_steps", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
     "score_last_error", "score_backend",
@@ -145,6 +146,12 @@ class ConicSolver:
         self._keep = []  # borrowed arrays must outlive score_create
         probs = (ScoreProblem * self.count)()
         for i, qp in enumerate(qps):
+            native = getattr(qp, "problem", None)
+            if isinstance(native, ScoreProblem):
+                # assembled by the library itself (score_amd.native): hand its view over as it is
+                C.memmove(C.byref(probs[i]), C.byref(native), C.sizeof(ScoreProblem))
+                self._keep.append(qp)
+                continue
             P = qp.P.tocsr()
             A = qp.A.tocsr()
             if not P.has_sorted_indices:

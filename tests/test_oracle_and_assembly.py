@@ -196,3 +196,51 @@ def test_generator_statistics():
     a = make_manhattan(n_robots=2, n_poses=30, n_beacons=2, seed=9)
     b = make_manhattan(n_robots=2, n_poses=30, n_beacons=2, seed=9)
     assert [m.dist for m in a.range_measurements] == [m.dist for m in b.range_measurements]
+
+
+@pytest.mark.parametrize("relax", ["SOCP", "QCQP"])
+@pytest.mark.parametrize("name", ["manhattan", "goats", "synth_b", "graph3d"])
+def test_native_assembler_equals_the_python_one(name, relax, fixtures, twin_lib):
+    """score_assemble (C++, behind the C ABI) builds the same conic program as score_amd/assemble.py --
+    same column layout, P / q / c0 / A / b / cones / chain hint -- on the reference's two data sets, a
+    graph with loop closures and a 3-D graph with a landmark prior; and hence the same literal objective
+    (gurobi_utils.py:358-526) as the oracle."""
+    from score_amd.native import assemble_native
+
+    fg = graph_by_name(name, fixtures)
+    a, b = assemble(fg, relax), assemble_native(fg, relax, lib_path=twin_lib)
+    qa, qb = a.qp, b.qp
+    assert (qa.n, qa.m, qa.z, qa.block_size) == (qb.n, qb.m, qb.z, qb.block_size)
+    scale = abs(qa.P).max()
+    assert abs(qa.P - qb.P).max() <= 1e-13 * scale
+    np.testing.assert_allclose(qb.q, qa.q, rtol=0, atol=1e-13 * max(1.0, np.abs(qa.q).max()))
+    assert qb.c0 == pytest.approx(qa.c0, rel=1e-12, abs=1e-9)
+    if qa.m:
+        assert abs(qa.A - qb.A).max() == 0.0 and np.array_equal(qa.b, qb.b)
+        assert qb.A.has_sorted_indices and qb.P.has_sorted_indices
+    assert np.array_equal(qa.soc_dims, qb.soc_dims)
+    assert np.array_equal(qa.chain_ptr, qb.chain_ptr) and np.array_equal(qa.node_cols, qb.node_cols)
+    assert np.array_equal(a.free_cols, b.free_cols) and a.n_model == b.n_model
+    assert a.pose_names == b.pose_names and a.range_keys == b.range_keys
+    if a.range_ends is not None:
+        assert np.array_equal(a.range_ends, b.range_ends)
+    rng = np.random.default_rng(3)
+    xs, vals = _random_values(b, rng)
+    assert qb.objective(xs) == pytest.approx(so.LiteralModel(fg, relax).direct_cost(vals), rel=1e-11)
+
+
+def test_native_assembler_errors(twin_lib):
+    from score_amd import compat
+    from score_amd.manhattan import make_manhattan
+    from score_amd.native import assemble_native
+
+    fg = make_manhattan(n_robots=1, n_poses=5, n_beacons=1, seed=1, p_range=1.0)
+    with pytest.raises(ValueError, match="not supported"):
+        assemble_native(fg, "LP", lib_path=twin_lib)
+    fg.range_measurements.append(compat.FGRangeMeasurement(("A1", "nope"), 1.0, 1.0))
+    with pytest.raises(ValueError, match="Variable name nope not found"):
+        assemble_native(fg, "SOCP", lib_path=twin_lib)
+    fg.range_measurements.pop()
+    fg.pose_variables[0].append(compat.PoseVariable2D("A1", (0.0, 0.0), 0.0))
+    with pytest.raises(ValueError, match="already exists in pose_vars"):
+        assemble_native(fg, "SOCP", lib_path=twin_lib)
