@@ -20,6 +20,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -69,9 +70,64 @@ struct DeviceGuard {
 // threads may drive different handles while one of them is capturing a graph.
 thread_local hipStream_t tl_copy_stream = nullptr;
 
+// Handles come and go at a high rate in Monte-Carlo use (one per lock-step group of trials), and
+// hipMalloc / hipFree / hipHostMalloc / hipHostFree cost milliseconds each (hipFree synchronises the
+// device): freed blocks are parked in a small process-wide cache, per device and size class (powers
+// of two), and handed to the next handle that asks.  Bounded: at most kMaxCachedBytes stay parked.
+struct BlockCache {
+    struct Block { void* p; size_t bytes; int dev; bool host; };
+    std::mutex mu;
+    std::vector<Block> free_blocks;
+    size_t cached = 0;
+    static constexpr size_t kMaxCachedBytes = (size_t)4 << 30;
+    static size_t round_up(size_t b) {
+        size_t r = 4096;
+        while (r < b) r <<= 1;
+        return r;
+    }
+    void* take(size_t& bytes, int dev, bool host) {
+        bytes = round_up(bytes);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < free_blocks.size(); ++i)
+                if (free_blocks[i].bytes == bytes && free_blocks[i].dev == dev && free_blocks[i].host == host) {
+                    void* p = free_blocks[i].p;
+                    cached -= bytes;
+                    free_blocks[i] = free_blocks.back();
+                    free_blocks.pop_back();
+                    return p;
+                }
+        }
+        void* p = nullptr;
+        if (host) HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocMapped));
+        else HIP_CHECK(hipMalloc(&p, bytes));
+        return p;
+    }
+    void give(void* p, size_t bytes, int dev, bool host) {
+        if (!p) return;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            if (cached + bytes <= kMaxCachedBytes) {
+                free_blocks.push_back(Block{p, bytes, dev, host});
+                cached += bytes;
+                return;
+            }
+        }
+        if (host) (void)hipHostFree(p); else (void)hipFree(p);
+    }
+    ~BlockCache() {  // process exit: the runtime may already be gone, leave the blocks to it
+    }
+};
+inline BlockCache& block_cache() {
+    static BlockCache* c = new BlockCache();  // intentionally leaked (see ~BlockCache)
+    return *c;
+}
+
 // Device memory of one handle comes from a few large allocations: ~70 hipMalloc / hipFree pairs per
 // handle cost ~20 ms (hipFree synchronises the device), a handful cost ~1 ms.
 struct DevArena {
+    int dev = 0;
+    std::vector<size_t> chunk_bytes;
     std::vector<void*> chunks;
     char* cur = nullptr;
     size_t left = 0, next_chunk = (size_t)8 << 20;
@@ -80,11 +136,12 @@ struct DevArena {
         if (bytes > left) {
             const size_t sz = std::max(bytes, next_chunk);
             next_chunk = std::min<size_t>(next_chunk * 2, (size_t)64 << 20);
-            void* p = nullptr;
-            HIP_CHECK(hipMalloc(&p, sz));
+            size_t got = sz;
+            void* p = block_cache().take(got, dev, false);
             chunks.push_back(p);
+            chunk_bytes.push_back(got);
             cur = (char*)p;
-            left = sz;
+            left = got;
         }
         void* r = cur;
         cur += bytes;
@@ -92,7 +149,8 @@ struct DevArena {
         return r;
     }
     ~DevArena() {
-        for (void* p : chunks) (void)hipFree(p);
+        // (the owner has synchronised its stream: nothing in flight touches these blocks)
+        for (size_t i = 0; i < chunks.size(); ++i) block_cache().give(chunks[i], chunk_bytes[i], dev, false);
     }
 };
 thread_local DevArena* tl_arena = nullptr;  // set while a handle is being initialised on this thread
@@ -236,6 +294,7 @@ struct HipBackend {
     // single device-to-host copy:  [pres | dres | fpart | gd | gate flags, gate counts]
     DevBuf<double> rep;          // window: the device address of h_rep (host-mapped pinned memory)
     double* h_rep = nullptr;
+    size_t h_rep_bytes = 0, h_ring_bytes = 0;
     size_t rep_dres_off = 0;     // doubles
     // Kernels write their per-workgroup partials straight into that host-mapped memory; small device
     // arrays the device itself reads (r'z measurements, PCG gate words) are pushed there by k_push,
@@ -272,8 +331,9 @@ struct HipBackend {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
-        if (h_rep) (void)hipHostFree(h_rep);
-        if (h_ring) (void)hipHostFree(h_ring);
+        if (stream) (void)hipStreamSynchronize(stream);
+        block_cache().give(h_rep, h_rep_bytes, st.device, true);
+        block_cache().give(h_ring, h_ring_bytes, st.device, true);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -287,6 +347,7 @@ struct HipBackend {
             throw std::runtime_error("no HIP device available (the SCORE solver has no CPU fallback)");
         if (st.device < 0 || st.device >= ndev) throw std::runtime_error("score_settings.device out of range");
         HIP_CHECK(hipSetDevice(st.device));
+        arena.dev = st.device;
         HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         tl_copy_stream = stream;
         struct ArenaScope {  // buffers allocated during init come from this handle's arena
@@ -385,7 +446,8 @@ struct HipBackend {
             const size_t n_int = (2 * (size_t)h.count + 1) / 2;  // 2 * count int32
             const size_t n_meas = 2 * (size_t)std::max(1, n_prec);
             const size_t total = n_pres + n_dres + n_fpart + n_gd + n_meas + n_int + 1;
-            HIP_CHECK(hipHostMalloc((void**)&h_rep, total * sizeof(double), hipHostMallocMapped));
+            h_rep_bytes = total * sizeof(double);
+            h_rep = (double*)block_cache().take(h_rep_bytes, st.device, true);
             std::memset(h_rep, 0, total * sizeof(double));
             double* d_rep = nullptr;
             HIP_CHECK(hipHostGetDevicePointer((void**)&d_rep, h_rep, 0));
@@ -475,10 +537,11 @@ struct HipBackend {
         const size_t need = (bytes + 63) & ~(size_t)63;
         if (need > ring_slot_bytes) {
             HIP_CHECK(hipStreamSynchronize(stream));
-            if (h_ring) (void)hipHostFree(h_ring);
+            block_cache().give(h_ring, h_ring_bytes, st.device, true);
             h_ring = nullptr;
             ring_slot_bytes = std::max<size_t>(need, 256);
-            HIP_CHECK(hipHostMalloc((void**)&h_ring, kFlagSlots * ring_slot_bytes, hipHostMallocMapped));
+            h_ring_bytes = kFlagSlots * ring_slot_bytes;
+            h_ring = (char*)block_cache().take(h_ring_bytes, st.device, true);
             HIP_CHECK(hipHostGetDevicePointer((void**)&d_ring, h_ring, 0));
             ring_used = 0;
         }

@@ -117,6 +117,20 @@ def graph_arrays(data) -> Dict[str, np.ndarray]:
     )
 
 
+def unconnected_variable_names(a: Dict[str, np.ndarray]):
+    """``FactorGraphData.unconnected_variable_names`` (score/solve_score.py:28-32) from the flat arrays:
+    variables that no odometry / loop-closure / range measurement and no landmark prior touches."""
+    Np, Nl = len(a["pose_names"]), len(a["landmark_names"])
+    touched = np.zeros(Np + Nl, dtype=bool)
+    for key in ("rel_base", "rel_to", "rng_a", "rng_b"):
+        touched[a[key]] = True
+    touched[Np + a["lprior_lm"]] = True
+    if touched.all():
+        return []
+    names = list(a["pose_names"]) + list(a["landmark_names"])
+    return [names[i] for i in np.nonzero(~touched)[0]]
+
+
 class NativeQP:
     """The assembled conic program held by the native library (duck-types ``assemble.ConicQP``)."""
 

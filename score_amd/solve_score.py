@@ -109,9 +109,13 @@ def _model_for(data, relaxation_type: str, qcqp_mode: str, lib_path: Optional[st
     one (score_amd/assemble.py) -- same program, same column layout."""
     relax = SOCP_RELAXATION if (relaxation_type == QCQP_RELAXATION and qcqp_mode == "via_socp") else relaxation_type
     if assembler == "native":
-        from .native import assemble_native
+        from .native import assemble_native, graph_arrays, unconnected_variable_names
 
-        return assemble_native(data, relax, lib_path=lib_path)
+        arrays = graph_arrays(data)
+        # score/solve_score.py:28-32, evaluated on the arrays just extracted (one pass over the graph objects)
+        unconnected_variables = unconnected_variable_names(arrays)
+        assert len(unconnected_variables) == 0, f"Found {unconnected_variables} unconnected variables. "
+        return assemble_native(data, relax, lib_path=lib_path, arrays=arrays)
     if assembler != "python":
         raise ValueError(f"assembler {assembler} is not supported")
     return assemble(data, relax)
@@ -211,7 +215,8 @@ def solve_score_batch(
         raise ValueError(f"qcqp_mode {qcqp_mode} is not supported")
     models = []
     for data in datas:
-        _check_factor_graph(data)
+        if assembler != "native":
+            _check_factor_graph(data)  # (the native path checks on its flat arrays)
         models.append(_model_for(data, relaxation_type, qcqp_mode, lib_path, assembler))
     settings = dict(DEFAULT_SOLVER_SETTINGS)
     if any(len(d.loop_closure_measurements) for d in datas):
@@ -259,7 +264,6 @@ def solve_problem_with_intermediate_iterates(
     reference restarts the barrier solver with BarIterLimit = 0, 1, 2, ...; here a
     single run is paused every ``every`` ADMM iterations."""
     check_valid_relaxation(relaxation_type)
-    _check_factor_graph(data)
     model = _model_for(data, relaxation_type, qcqp_mode, lib_path)
     settings = dict(DEFAULT_SOLVER_SETTINGS)
     settings.update(solver_settings or {})
