@@ -20,6 +20,7 @@
 
 #include <cstdio>
 #include <cstring>
+#include <malloc.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -118,6 +119,37 @@ struct BlockCache {
     ~BlockCache() {  // process exit: the runtime may already be gone, leave the blocks to it
     }
 };
+// idle HIP streams, per device: hipStreamCreate / hipStreamDestroy cost 3-4 ms each
+struct StreamPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> idle;
+    hipStream_t take(int dev) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < idle.size(); ++i)
+                if (idle[i].first == dev) {
+                    hipStream_t s = idle[i].second;
+                    idle[i] = idle.back();
+                    idle.pop_back();
+                    return s;
+                }
+        }
+        hipStream_t s = nullptr;
+        HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        return s;
+    }
+    void give(int dev, hipStream_t s) {
+        if (!s) return;
+        std::lock_guard<std::mutex> lk(mu);
+        if (idle.size() < 64) idle.emplace_back(dev, s);
+        else (void)hipStreamDestroy(s);
+    }
+};
+inline StreamPool& stream_pool() {
+    static StreamPool* p = new StreamPool();  // leaked on purpose, like the block cache
+    return *p;
+}
+
 inline BlockCache& block_cache() {
     static BlockCache* c = new BlockCache();  // intentionally leaked (see ~BlockCache)
     return *c;
@@ -328,13 +360,18 @@ struct HipBackend {
     static bool n_prec_chains(const HostSystem& h) { return !h.chains.empty(); }
 
     ~HipBackend() {
+        PhaseTimer pt(st.verbose != 0);
+        if (stream) (void)hipStreamSynchronize(stream);
+        pt.mark("destroy: sync");
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        pt.mark("destroy: graph");
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
-        if (stream) (void)hipStreamSynchronize(stream);
         block_cache().give(h_rep, h_rep_bytes, st.device, true);
         block_cache().give(h_ring, h_ring_bytes, st.device, true);
-        if (stream) (void)hipStreamDestroy(stream);
+        pt.mark("destroy: events, pinned blocks");
+        stream_pool().give(st.device, stream);  // (drained above)
+        pt.mark("destroy: stream");
     }
 
     void init(const HostSystem& h, const score_settings& s_) {
@@ -348,7 +385,7 @@ struct HipBackend {
         if (st.device < 0 || st.device >= ndev) throw std::runtime_error("score_settings.device out of range");
         HIP_CHECK(hipSetDevice(st.device));
         arena.dev = st.device;
-        HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        stream = stream_pool().take(st.device);
         tl_copy_stream = stream;
         struct ArenaScope {  // buffers allocated during init come from this handle's arena
             explicit ArenaScope(DevArena* a) { tl_arena = a; }
@@ -1464,8 +1501,21 @@ extern "C" {
 
 void score_default_settings(score_settings* s) { score::default_settings(s); }
 
+// Setup builds (and teardown frees) a few hundred megabytes of host vectors per handle.  With glibc's
+// default thresholds each of them is an mmap / munmap pair with fresh page faults; raising the
+// thresholds once keeps that memory in the process heap, where the next handle finds it again.
+static void tune_host_allocator_once() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (std::getenv("SCORE_KEEP_MALLOC_DEFAULTS")) return;
+        mallopt(M_MMAP_THRESHOLD, 1 << 30);
+        mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    });
+}
+
 int score_create_batch(const score_problem* p, int32_t count, const score_settings* s, score_handle** out) {
     try {
+        tune_host_allocator_once();
         if (!p || !out) throw std::runtime_error("null argument");
         score_settings st;
         if (s) st = *s; else score::default_settings(&st);
@@ -1557,7 +1607,9 @@ void score_destroy(score_handle* h) {
     if (!h) return;
     try {
         DeviceGuard guard(h->solver.st.device);
+        score::PhaseTimer pt(h->solver.st.verbose != 0);
         delete h;
+        pt.mark("destroy: total");
     } catch (...) {
         delete h;
     }
