@@ -147,6 +147,12 @@ int  score_reset(score_handle* h);
 int  score_solve_steps(score_handle* h, int32_t iters, double* x, double* y, double* s,
                        score_info* infos);
 
+/* The same for the second phase of the default solver: at most `iters` semismooth-Newton iterations
+ * of the polish from the current iterate (a backend or problem without the polish leaves the
+ * iterate alone), then the report.  score_info.newton_iters accumulates.               */
+int  score_newton_steps(score_handle* h, int32_t iters, double* x, double* y, double* s,
+                        score_info* infos);
+
 /* Time `reps` applications of the KKT operator w = K p on the handle's stream
  * with HIP events (the roofline probe bench.py reports); returns the average
  * milliseconds per launch in *ms_per_apply and the algorithmic bytes of one

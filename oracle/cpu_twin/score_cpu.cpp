@@ -41,8 +41,9 @@ struct CpuBackend {
     int cg_iters = 2;
 
     void set_cg_iters(int k) { cg_iters = k; }
-    bool polish(const HostSystem&, const score_settings&, const std::vector<int>&, int*, int*) { return false; }  // HIP backend only
+    bool polish(const HostSystem&, const score_settings&, const std::vector<int>&, int*, int*, const std::vector<double>*) { return false; }  // HIP backend only
     bool polish_available() const { return false; }
+    void set_newton_limit(int) {}
     void cg_reduction(std::vector<double>& out) { out = cg_red; }
 
     void init(const HostSystem& h, const score_settings& s_) {
@@ -352,6 +353,12 @@ int score_reset(score_handle* h) {
 int score_solve_steps(score_handle* h, int32_t iters, double* x, double* y, double* s, score_info* infos) {
     try { return h->solver.steps(iters, x, y, s, infos); }
     catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_newton_steps(score_handle* h, int32_t iters, double* x, double* y, double* s, score_info* infos) {
+    try {
+        if (!h) throw std::runtime_error("null handle");
+        return h->solver.newton_steps(iters, x, y, s, infos);
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 int score_time_kkt_apply(score_handle* h, int32_t reps, double* ms, double* bytes) {
     try { h->solver.be.time_kkt(reps, ms, bytes); return 0; }

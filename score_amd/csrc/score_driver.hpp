@@ -44,6 +44,7 @@ struct Solver {
     int next_polish = 0;  // earliest iteration of the next polish attempt
     int next_rho = 0;     // earliest iteration of the next rho adaptation
     double setup_ms = 0;
+    std::vector<double> dual_scale;  // per problem: |A'y|_inf of the last residual test (scale of the dual test)
 
     void create(const score_problem* probs, int count, const score_settings& s) {
         const double t0 = now_ms();
@@ -58,6 +59,7 @@ struct Solver {
         be.init(H, st);
         infos.assign(count, score_info{});
         done.assign(count, 0);
+        dual_scale.assign(count, 0.0);
         setup_ms = now_ms() - t0;
     }
 
@@ -114,6 +116,7 @@ struct Solver {
             // pinned-pose constants (1e5..1e6) that cancel in Px + q and would make a
             // relative test vacuous.
             const double dn = r.aty_u;
+            dual_scale[p] = dn;
             const bool ok_p = r.rp_u <= st.eps_abs + st.eps_rel * pn;
             const bool ok_d = r.rd_u <= st.eps_abs + st.eps_rel * dn;
             // gap scale as in SCS: the magnitudes of the terms it is made of (|x'r_d| alone is up to
@@ -195,19 +198,42 @@ struct Solver {
                 for (int p = 0; p < H.count; ++p)
                     if (!done[p]) worst = std::max(worst, std::max(infos[p].res_pri, infos[p].res_dual));
                 if (worst <= st.polish_start) {
-                    int nit = 0, ncg = 0;
-                    const bool ran = be.polish(H, st, done, &nit, &ncg);
-                    for (int p = 0; p < H.count; ++p)
-                        if (!done[p]) { infos[p].newton_iters += nit; infos[p].newton_cg_iters += ncg; }
-                    // whether Newton converged to its own tolerance or stalled in rounding, the point
-                    // it hands back is a consistent ADMM state: let the ordinary residual test decide
-                    if (ran) all = check(false);
+                    // First to the tolerance the residual test below will apply -- its dual test is relative
+                    // to |A'y|, known from the last check -- and only if that test then fails (the scale
+                    // moved) on to Newton's own, absolute, tolerance: a Newton iteration costs ten times a
+                    // residual test.  Whether Newton converged or stalled in rounding, the point it hands
+                    // back is a consistent ADMM state: the ordinary residual test decides.
+                    for (int pass = 0; pass < 2 && !all; ++pass) {
+                        int nit = 0, ncg = 0;
+                        const bool ran = be.polish(H, st, done, &nit, &ncg, pass == 0 ? &dual_scale : nullptr);
+                        for (int p = 0; p < H.count; ++p)
+                            if (!done[p]) { infos[p].newton_iters += nit; infos[p].newton_cg_iters += ncg; }
+                        if (!ran) break;
+                        all = check(false);
+                    }
                     next_polish = iters_done + 20 * st.check_interval;  // a failed attempt is retried later
                 }
             }
         }
         finish(x, y, s, out, t0);
         return 0;
+    }
+
+    // Intermediate iterates of the PRODUCT's default trajectory: after the ADMM warm-up the solver
+    // switches to Newton's method on the reduced problem; this runs at most `iters` Newton iterations
+    // from the current iterate and reports like steps().  Backends without the polish do nothing.
+    int newton_steps(int iters, double* x, double* y, double* s, score_info* out) {
+        const double t0 = now_ms();
+        if (iters > 0 && be.polish_available()) {
+            int nit = 0, ncg = 0;
+            const std::vector<int> none(H.count, 0);
+            be.set_newton_limit(iters);
+            const bool ran = be.polish(H, st, none, &nit, &ncg, nullptr);
+            be.set_newton_limit(0);
+            if (ran)
+                for (int p = 0; p < H.count; ++p) { infos[p].newton_iters += nit; infos[p].newton_cg_iters += ncg; }
+        }
+        return report(x, y, s, out, t0);
     }
 
     int steps(int iters, double* x, double* y, double* s, score_info* out) {
@@ -220,6 +246,11 @@ struct Solver {
             cg_total += (int64_t)k * cg_now;
             left -= k;
         }
+        return report(x, y, s, out, t0);
+    }
+
+    // residual test + snapshot of the current iterate without latching any problem
+    int report(double* x, double* y, double* s, score_info* out, double t0) {
         std::vector<int> keep = done;
         check(false);
         for (int p = 0; p < H.count; ++p) {

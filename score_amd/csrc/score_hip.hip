@@ -1075,11 +1075,13 @@ struct HipBackend {
     // Any failure inside the polish (NaN, HIP error) leaves the ADMM state untouched -- the Newton
     // loop only writes scratch vectors until its final hand-over -- and ADMM simply continues.
     bool polish_available() const { return Q.available; }
+    int newton_limit = 0;  // > 0: at most this many Newton iterations per polish call (intermediate iterates)
+    void set_newton_limit(int k) { newton_limit = k; }
 
     bool polish(const HostSystem& h, const score_settings& s_, const std::vector<int>& done_host, int* newton_iters,
-                int* cg_used) {
+                int* cg_used, const std::vector<double>* dual_scale) {
         try {
-            return polish_lockstep(h, s_, done_host, newton_iters, cg_used);
+            return polish_lockstep(h, s_, done_host, newton_iters, cg_used, dual_scale);
         } catch (const std::exception& e) {
             if (st.verbose) std::fprintf(stderr, "[score] polish abandoned: %s\n", e.what());
             (void)hipStreamSynchronize(stream);
@@ -1235,8 +1237,10 @@ struct HipBackend {
         }
     }
 
+    // dual_scale (optional): per problem |A'y|_inf -- Newton then stops at half the tolerance the
+    // driver's dual residual test will apply, eps_abs + eps_rel |A'y|, instead of its own absolute one
     bool polish_lockstep(const HostSystem& h, const score_settings& s_, const std::vector<int>& done_host,
-                         int* newton_iters, int* cg_used) {
+                         int* newton_iters, int* cg_used, const std::vector<double>* dual_scale) {
         *newton_iters = 0; *cg_used = 0;
         pcg_used_total = 0;
         const double t_start = now_ms();
@@ -1260,20 +1264,24 @@ struct HipBackend {
         upload_skip(part);
         newton_eval_batch(X, part, F, gn);
         const double tol = std::max(1e-12, 0.3 * s_.eps_abs);
+        std::vector<double> tolp(count, tol);
+        if (dual_scale)
+            for (int p = 0; p < count; ++p) tolp[p] = std::max(tol, 0.5 * (s_.eps_abs + s_.eps_rel * (*dual_scale)[p]));
         std::vector<char> live(count), stalled(count, 0);
         int it = 0;
         int n_pcg = 12;  // PCG iterations queued for the first Newton step
         int used_prev = 0;
         std::vector<double> eta_prev(count, 0.0);
-        for (; it < 50; ++it) {
+        const int it_max = newton_limit > 0 ? std::min(50, newton_limit) : 50;
+        for (; it < it_max; ++it) {
             any = false;
-            for (int p = 0; p < count; ++p) { live[p] = part[p] && !stalled[p] && gn[p] > tol; any = any || live[p]; }
+            for (int p = 0; p < count; ++p) { live[p] = part[p] && !stalled[p] && gn[p] > tolp[p]; any = any || live[p]; }
             if (!any) break;
             // inexact Newton: the linear residual only has to shrink superlinearly with |g|
             // (and never more digits than the step needs to land below the tolerance)
             for (int p = 0; p < count; ++p) {
                 const double superlinear = std::max(1e-8, newton_eta_coef * std::pow(gn[p], newton_eta_pow));
-                const double enough = gn[p] > 0.0 ? 0.1 * tol / gn[p] : 1.0;
+                const double enough = gn[p] > 0.0 ? 0.1 * tolp[p] / gn[p] : 1.0;
                 eta[p] = std::min(newton_eta_max, std::max(superlinear, enough));
             }
             // PCG iterations to queue: what the previous Newton step needed, scaled by the digits this
@@ -1568,6 +1576,13 @@ int score_solve_steps(score_handle* h, int32_t iters, double* x, double* y, doub
         if (!h) throw std::runtime_error("null handle");
         DeviceGuard guard(h->solver.st.device);
         return h->solver.steps(iters, x, y, s, infos);
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_newton_steps(score_handle* h, int32_t iters, double* x, double* y, double* s, score_info* infos) {
+    try {
+        if (!h) throw std::runtime_error("null handle");
+        DeviceGuard guard(h->solver.st.device);
+        return h->solver.newton_steps(iters, x, y, s, infos);
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 int score_time_kkt_apply(score_handle* h, int32_t reps, double* ms, double* bytes) {

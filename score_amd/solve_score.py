@@ -257,32 +257,60 @@ def solve_score_batch(
 
 
 def solve_problem_with_intermediate_iterates(
-    data, relaxation_type: str = QCQP_RELAXATION, every: int = 25, qcqp_mode: str = "via_socp",
+    data, relaxation_type: str = QCQP_RELAXATION, every: int = 5, qcqp_mode: str = "via_socp",
     solver_settings: Optional[dict] = None, lib_path: Optional[str] = None, max_snapshots: int = 400,
 ) -> List[compat.SolverResults]:
-    """score/solve_score.py:89-116: one ``SolverResults`` per iteration cap.  The
-    reference restarts the barrier solver with BarIterLimit = 0, 1, 2, ...; here a
-    single run is paused every ``every`` ADMM iterations."""
+    """score/solve_score.py:89-116: one ``SolverResults`` per iteration cap.  The reference restarts
+    Gurobi's barrier solver with BarIterLimit = 0, 1, 2, ... until it reports OPTIMAL; here ONE run of
+    the product's default solver is paused along its own trajectory: every ``every`` ADMM iterations
+    during the warm-up (``polish_warmup`` iterations, 15 by default), then after every semismooth-Newton
+    iteration of the polish.  Where the polish does not apply (the direct QCQP form, polish=0) the run
+    continues with ADMM snapshots.  ``solved`` is the solver's own verdict (its three termination tests,
+    the counterpart of ``model.status == GRB.OPTIMAL``, gurobi_utils.py:195); the list ends with the
+    first solved iterate."""
     check_valid_relaxation(relaxation_type)
     model = _model_for(data, relaxation_type, qcqp_mode, lib_path)
     settings = dict(DEFAULT_SOLVER_SETTINGS)
+    if len(data.loop_closure_measurements):
+        settings.update(cg_iters=16, cg_target=0.1)
+    if relaxation_type == QCQP_RELAXATION and qcqp_mode == "direct":
+        settings.update(cg_iters=8, adaptive_rho=0)
     settings.update(solver_settings or {})
+    every = max(1, int(every))
     solver = ConicSolver([model.qp], settings, lib_path=lib_path)
+    warmup = int(solver.settings.polish_warmup) if solver.settings.polish else 0
     iterates = []
     try:
         solver.reset()
         t0 = time.time()
-        for _ in range(max_snapshots):
-            sol = solver.steps(every)[0]
-            finished = sol.info["res_pri"] <= settings["eps_abs"] * 10 and sol.info["res_dual"] <= settings["eps_abs"] * 1e3
+
+        def snapshot(sol) -> bool:
             try:
                 iterates.append(extract_solver_results(
-                    model, sol.x, data, total_time=time.time() - t0, solved=bool(finished),
+                    model, sol.x, data, total_time=time.time() - t0, solved=sol.solved,
                     requested_relaxation=relaxation_type, info=sol.info,
                 ))
             except ValueError:
                 pass  # an early iterate whose rotation block cannot be rounded yet
-            if finished or sol.info["iters"] >= settings["max_iters"]:
+            return sol.solved
+
+        done, admm = False, 0
+        while not done and admm < warmup and len(iterates) < max_snapshots:
+            k = min(every, warmup - admm)
+            done = snapshot(solver.steps(k)[0])
+            admm += k
+        newton_possible = warmup > 0
+        while not done and len(iterates) < max_snapshots:
+            if newton_possible:
+                sol = solver.newton_steps(1)[0]
+                if sol.info["newton_iters"] == (iterates[-1].info["newton_iters"] if iterates else 0):
+                    newton_possible = False  # no polish for this program / backend, or Newton has stalled: ADMM goes on
+                    continue
+            else:
+                sol = solver.steps(every)[0]
+                admm += every
+            done = snapshot(sol)
+            if admm >= settings["max_iters"]:
                 break
     finally:
         solver.close()

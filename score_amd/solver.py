@@ -68,7 +68,7 @@ STATUS_NAMES = {0: "unsolved", 1: "solved", 2: "max_iters", 3: "numerical"}
 ABI_SYMBOLS = [
     "score_assemble", "score_assembled_view", "score_assembled_free",
     "score_default_settings", "score_create", "score_create_batch", "score_dims", "score_solve",
-    "score_reset", "score_solve_steps", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
+    "score_reset", "score_solve_steps", "score_newton_steps", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
     "score_last_error", "score_backend",
 ]
 
@@ -89,6 +89,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.score_solve.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, C.POINTER(ScoreInfo)]
     lib.score_reset.argtypes = [C.c_void_p]
     lib.score_solve_steps.argtypes = [C.c_void_p, C.c_int32, _f64p, _f64p, _f64p, C.POINTER(ScoreInfo)]
+    lib.score_newton_steps.argtypes = [C.c_void_p, C.c_int32, _f64p, _f64p, _f64p, C.POINTER(ScoreInfo)]
     lib.score_time_kkt_apply.argtypes = [C.c_void_p, C.c_int32, _f64p, _f64p]
     lib.score_debug_time.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, _f64p]
     lib.score_time_iteration.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_int32]
@@ -219,6 +220,15 @@ class ConicSolver:
         rc = self.lib.score_solve_steps(self._h, int(iters), _ptr(x, _f64p), _ptr(y, _f64p), _ptr(s, _f64p), infos)
         if rc != 0:
             raise RuntimeError(f"score_solve_steps failed: {self.lib.score_last_error().decode()}")
+        return self._split(x, y, s, infos)
+
+    def newton_steps(self, iters: int) -> List[ConicSolution]:
+        """At most ``iters`` Newton iterations of the polish from the current iterate, then a snapshot."""
+        x = np.empty(self.n_total); y = np.empty(self.m_total); s = np.empty(self.m_total)
+        infos = (ScoreInfo * self.count)()
+        rc = self.lib.score_newton_steps(self._h, int(iters), _ptr(x, _f64p), _ptr(y, _f64p), _ptr(s, _f64p), infos)
+        if rc != 0:
+            raise RuntimeError(f"score_newton_steps failed: {self.lib.score_last_error().decode()}")
         return self._split(x, y, s, infos)
 
     def time_kkt_apply(self, reps: int = 200):
