@@ -97,6 +97,10 @@ typedef struct score_settings {
     double  polish_start;      /* start it when both relative residuals are below this                  */
     int32_t polish_warmup;     /* ADMM iterations before the first polish attempt (0: one check_interval) */
     int32_t verbose;
+    int32_t chain_split;       /* chain preconditioner: 0 = one workgroup per chain (default); 1 = split every long
+                                  chain over 2-4 workgroups (k_prec_wave) when the whole launch fits the device at
+                                  once -- correct and tested, measured 10-15 % SLOWER than the default on the
+                                  headline problem, kept as an option                      */
 } score_settings;
 
 enum {

@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0,'.')
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from score_amd.manhattan import make_config
 from score_amd.assemble import assemble
 from score_amd.solver import ConicSolver

@@ -296,6 +296,7 @@ inline void default_settings(score_settings* s) {
     s->polish_start = 1e30;
     s->polish_warmup = 15;
     s->verbose = 0;
+    s->chain_split = 0;
 }
 
 }  // namespace score

@@ -29,6 +29,7 @@
 #include "score_assemble.hpp"
 #include "score_kernels.hpp"
 #include "score_polish.hpp"
+#include "score_prec_wave.hpp"
 
 namespace {
 
@@ -353,7 +354,18 @@ struct HipBackend {
     const double* last_p = nullptr;
     double* h_pres = nullptr;  // pinned
     double* h_dres = nullptr;
-    int n_cone_blocks = 0, n_prec = 0;
+    int n_cone_blocks = 0, n_prec = 0;  // n_prec: work items of the ACTIVE preconditioner launch (split or not)
+    // split chain kernel (score_split.hpp / score_prec_wave.hpp)
+    SplitSystem split;
+    std::vector<int32_t> active_part_ptr;   // host copy of the active per-problem work ranges
+    DevBuf<PrecWork> split_work;
+    DevBuf<SplitItem> split_items;
+    DevBuf<SplitPlan> split_plans;
+    DevBuf<int32_t> split_stage;
+    DevBuf<double> split_xbuf;
+    DevBuf<unsigned int> split_xflag, split_epoch;
+    size_t split_lds = 0;
+    unsigned long long split_poll_limit = 0;
     size_t prec_lds = 0;
     bool prec_lds0 = true;
     bool prec_pre = false;  // every chain fits the lane budget of k_prec_pre
@@ -421,9 +433,43 @@ struct HipBackend {
         }
         n_cone_blocks = (int)h.cone_block_prob.size();
         node_col.upload(h.node_col); diag_cols.upload(h.diag_cols);
-        prec_part_ptr.upload(h.prec_part_ptr); kblk_part_ptr.upload(h.rbK.part_ptr);
+        kblk_part_ptr.upload(h.rbK.part_ptr);
         prec_work.upload(h.prec_work); chains.upload(h.chains); levels.upload(h.levels);
         n_prec = (int)h.prec_work.size();
+        active_part_ptr = h.prec_part_ptr;
+        {   // split chain kernel: only when the whole launch is resident at once (one workgroup per CU)
+            int cus = 0;
+            HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st.device));
+            const bool off = st.chain_split <= 0 || std::getenv("SCORE_NO_CHAIN_SPLIT") != nullptr;
+            if (!off && cus > 0) build_split_system(h, cus, split);
+            if (split.active && split.stage_rel.size() > 0) {
+                for (const auto& pl : split.plans)
+                    if (pl.n_stage > kWaveThreads * kWaveStage || (pl.lv[0].n + 1) * 3 > kWaveThreads * kWaveVec) split.active = false;
+            }
+            if (split.active) {
+                n_prec = (int)split.work.size();
+                active_part_ptr = split.part_ptr;
+                split_work.upload(split.work); split_items.upload(split.items); split_plans.upload(split.plans);
+                split_stage.upload(split.stage_rel.empty() ? std::vector<int32_t>(1, -1) : split.stage_rel);
+                split_xbuf.alloc((size_t)std::max(1, split.n_slots) * kSplitMaxParts * kSplitSlotDoubles); split_xbuf.zero(stream);
+                split_xflag.alloc((size_t)std::max(1, split.n_slots) * kSplitMaxParts); split_xflag.zero(stream);
+                split_epoch.alloc(split.work.size()); split_epoch.zero(stream);
+                // more than half of a CU's LDS: at most one of these workgroups per CU (the hand-off between the
+                // parts of a chain is sized and measured for that)
+                split_lds = std::max<size_t>(split.max_lds_doubles * sizeof(double), (size_t)84 * 1024);
+                HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_wave<PREC_INIT>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+                HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_wave<PREC_STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+                int khz = 0;
+                HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, st.device));
+                split_poll_limit = (unsigned long long)std::max(1, khz) * 50ull;  // 50 ms
+                if (split.max_lds_doubles * sizeof(double) > (size_t)150 * 1024) split.active = false;
+            }
+            if (!split.active) { n_prec = (int)h.prec_work.size(); active_part_ptr = h.prec_part_ptr; }
+        }
+        prec_part_ptr.upload(active_part_ptr);
+        if (st.verbose)
+            std::fprintf(stderr, "[score setup] chain preconditioner: %s, %d work items (%zu chains)\n",
+                         split.active ? "split (one wavefront per chain part)" : "one workgroup per chain", n_prec, h.chains.size());
         pt.mark("uploads");
         // chain vectors in LDS: level 0 (N nodes) when it fits, always the coarse levels
         int max_nodes = 0, max_all = 0;
@@ -653,6 +699,15 @@ struct HipBackend {
     template <int MODE>
     void launch_prec(const PrecArgs& pa, int slot = -1) {
         if (n_prec == 0) return;
+        if (split.active) {
+            WaveArgs wa{};
+            wa.p = pa;
+            wa.p.work = split_work.d;
+            wa.items = split_items.d; wa.plans = split_plans.d; wa.stage_rel = split_stage.d;
+            wa.xbuf = split_xbuf.d; wa.xflag = split_xflag.d; wa.epoch = split_epoch.d; wa.poll_limit = split_poll_limit;
+            launch_on_stream(k_prec_wave<MODE>, dim3(n_prec), dim3(kWaveThreads), split_lds, slot, wa);
+            return;
+        }
         const int bs = H->bs;
 #define SCORE_LAUNCH_PREC(BS)                                                                                  \
     do {                                                                                                       \
@@ -727,7 +782,7 @@ struct HipBackend {
         const double* b2 = h_meas + n_prec;
         for (int pi = 0; pi < h.count; ++pi) {
             double s0 = 0, s1 = 0;
-            for (int i = h.prec_part_ptr[pi]; i < h.prec_part_ptr[pi + 1]; ++i) { s0 += a[i]; s1 += b2[i]; }
+            for (int i = active_part_ptr[pi]; i < active_part_ptr[pi + 1]; ++i) { s0 += a[i]; s1 += b2[i]; }
             out[pi] = s0 > 0 ? std::sqrt(std::max(0.0, s1) / s0) : 0.0;
         }
     }
@@ -1101,15 +1156,15 @@ struct HipBackend {
         ha.ndiag = (int)h.diag_cols.size(); ha.diag_pos = q_diagpos.d; ha.dinv = q_dinv.d;
         const int base_blocks = (int)((ha.nnz + kThreads - 1) / kThreads);
         hipLaunchKernelGGL(k_hassemble, dim3((unsigned)(base_blocks + n_long)), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d, base_blocks);
-        if (n_prec) {  // chain factors and the reciprocal Jacobi diagonal, one launch
+        if (n_prec_items()) {  // chain factors and the reciprocal Jacobi diagonal, one launch
             FactorArgs fa{};
             fa.work = prec_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = Hm.val.d;
             fa.pos_diag = q_posd.d; fa.pos_sub = q_poss.d; fa.fac = q_fac.d; fa.work_mat = q_work.d; fa.skip = skip;
             fa.diag_pos = q_diagpos.d; fa.dinv = q_dinv.d;
-            if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
-            else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
-            else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
-            else hipLaunchKernelGGL(k_factor<4>, dim3(n_prec), dim3(kThreads), 0, stream, fa);
+            if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(n_prec_items()), dim3(kThreads), 0, stream, fa);
+            else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(n_prec_items()), dim3(kThreads), 0, stream, fa);
+            else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(n_prec_items()), dim3(kThreads), 0, stream, fa);
+            else hipLaunchKernelGGL(k_factor<4>, dim3(n_prec_items()), dim3(kThreads), 0, stream, fa);
         }
     }
 

@@ -489,6 +489,29 @@ def test_goats_example_script_runs_on_the_pickle(hip_lib, tmp_path):
     assert est.shape == load_tum(os.path.join(GOLDEN, "gt_traj_A.tum")).shape
 
 
+@pytest.mark.parametrize("n_poses", [255, 300, 640, 1000, 1023])
+def test_split_chain_kernel_matches_the_twin(n_poses, hip_lib, twin_lib):
+    """chain_split=1: every chain of >= 256 poses is cut at the nodes of its last nested-dissection level
+    into 2-4 parts, each solved by its own workgroup (k_prec_wave) with one in-kernel exchange; shorter
+    chains run the same kernel as a single part.  Same factor, same operator: 40 ADMM iterations must
+    reproduce the CPU twin's iterates, the default (unsplit) kernel's, and the full solver must agree."""
+    fg = make_manhattan(n_robots=3, n_poses=n_poses, n_beacons=3, seed=31 + n_poses)
+    qp = assemble(fg, "SOCP").qp
+    outs = {}
+    for name, lib, extra in (("split", None, dict(chain_split=1)), ("plain", None, dict(chain_split=0)), ("twin", twin_lib, {})):
+        sol = ConicSolver(qp, dict(polish=0, adaptive_rho=0, adaptive_cg=0, **extra), lib_path=lib)
+        outs[name] = sol.steps(40)[0]
+        sol.close()
+    scale = np.abs(outs["twin"].x).max()
+    np.testing.assert_allclose(outs["split"].x, outs["twin"].x, atol=1e-7 * scale)
+    np.testing.assert_allclose(outs["split"].x, outs["plain"].x, atol=1e-9 * scale)
+    a = ConicSolver(qp, dict(chain_split=1)); ra = a.solve()[0]; a.close()
+    b = ConicSolver(qp, dict(chain_split=0)); rb = b.solve()[0]; b.close()
+    assert ra.solved and rb.solved and ra.info["pobj"] == pytest.approx(rb.info["pobj"], rel=1e-9)
+    cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, ra.x, ra.y, ra.s)
+    assert cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4, cert
+
+
 def test_config5_all_64_trials_are_certified(hip_lib):
     """BASELINE configs[4] at its full size: 64 four-robot x 1000-pose Monte-Carlo trials, solved
     the way bench.py solves them (lock-step handles of 16, product default solver).  EVERY trial
