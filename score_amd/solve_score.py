@@ -109,9 +109,9 @@ def _model_for(data, relaxation_type: str, qcqp_mode: str, lib_path: Optional[st
     one (score_amd/assemble.py) -- same program, same column layout."""
     relax = SOCP_RELAXATION if (relaxation_type == QCQP_RELAXATION and qcqp_mode == "via_socp") else relaxation_type
     if assembler == "native":
-        from .native import assemble_native, graph_arrays, unconnected_variable_names
+        from .native import ArrayGraph, assemble_native, graph_arrays, unconnected_variable_names
 
-        arrays = graph_arrays(data)
+        arrays = data.arrays if isinstance(data, ArrayGraph) else graph_arrays(data)
         # score/solve_score.py:28-32, evaluated on the arrays just extracted (one pass over the graph objects)
         unconnected_variables = unconnected_variable_names(arrays)
         assert len(unconnected_variables) == 0, f"Found {unconnected_variables} unconnected variables. "
@@ -161,7 +161,10 @@ def solve_score_batch(
     order = list(range(len(datas)))
 
     def size_of(i):
-        return sum(len(c) for c in datas[i].pose_variables) + len(datas[i].range_measurements)
+        d_ = datas[i]
+        if hasattr(d_, "arrays"):  # native.ArrayGraph
+            return d_.num_poses + d_.num_ranges
+        return sum(len(c) for c in d_.pose_variables) + len(d_.range_measurements)
 
     if lockstep is None and len(datas) > 1:
         # a lock-step handle needs one block size (2-D and 3-D graphs never share a group); within a
@@ -219,7 +222,7 @@ def solve_score_batch(
             _check_factor_graph(data)  # (the native path checks on its flat arrays)
         models.append(_model_for(data, relaxation_type, qcqp_mode, lib_path, assembler))
     settings = dict(DEFAULT_SOLVER_SETTINGS)
-    if any(len(d.loop_closure_measurements) for d in datas):
+    if any((d.n_loop_closures if hasattr(d, "arrays") else len(d.loop_closure_measurements)) for d in datas):
         # loop closures are stiff couplings outside the per-robot chains the
         # preconditioner captures: start with more PCG iterations per KKT solve
         settings.update(cg_iters=16, cg_target=0.1)

@@ -222,3 +222,19 @@ def test_host_setup_does_not_depend_on_the_thread_count(twin_lib, tmp_path):
     if len(os.sched_getaffinity(0)) < 2:
         pytest.skip("single-CPU machine: nothing to compare")
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_array_graph_input_equals_object_input(twin_lib):
+    """native.ArrayGraph (a factor graph that already is flat arrays) goes through the same path as a
+    FactorGraphData, minus the per-measurement attribute reads."""
+    from score_amd.manhattan import make_manhattan
+    from score_amd.native import ArrayGraph, graph_arrays
+
+    gs = [make_manhattan(n_robots=2, n_poses=30, n_beacons=2, seed=60 + i, p_range=0.4, n_loop_closures=i) for i in range(3)]
+    a = solve_score_batch(gs, "SOCP", lib_path=twin_lib)
+    b = solve_score_batch([ArrayGraph(graph_arrays(g)) for g in gs], "SOCP", lib_path=twin_lib)
+    for x, y in zip(a, b):
+        assert x.solved and y.solved and x.info["iters"] == y.info["iters"] and x.pose_chain_names == y.pose_chain_names
+        for nm in x.poses:
+            np.testing.assert_allclose(x.poses[nm], y.poses[nm], atol=1e-9)
+        assert list(x.distances.keys()) == list(y.distances.keys())
