@@ -885,11 +885,22 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     H.cone_part_ptr.assign(count + 1, 0);
     H.prec_part_ptr.assign(count + 1, 0);
     H.rho.assign(count, st.rho);
+    // Equilibration is independent per problem: a batch of small problems (each below the row count
+    // at which ruiz_scale splits its own passes over threads) is scaled one problem per thread.
+    std::vector<ProblemScaled> scaled((size_t)count);
+    if (count > 1) {
+        parallel_ranges(count, 1, [&](int, int64_t p0, int64_t p1) {
+            for (int64_t p = p0; p < p1; ++p) ruiz_scale(probs[p], std::max(0, st.scale_iters), scaled[(size_t)p]);
+        });
+        pt.mark("ruiz (all problems)");
+    }
     for (int p = 0; p < count; ++p) {
         const score_problem& pr = probs[p];
-        ProblemScaled S;
-        ruiz_scale(pr, std::max(0, st.scale_iters), S);
-        pt.mark("ruiz");
+        if (count == 1) {
+            ruiz_scale(pr, std::max(0, st.scale_iters), scaled[0]);
+            pt.mark("ruiz");
+        }
+        ProblemScaled S = std::move(scaled[(size_t)p]);
         H.D.insert(H.D.end(), S.D.begin(), S.D.end());
         H.E.insert(H.E.end(), S.E.begin(), S.E.end());
         H.q.insert(H.q.end(), S.q.begin(), S.q.end());

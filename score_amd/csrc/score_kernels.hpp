@@ -184,7 +184,10 @@ enum { MODE_RHS = 0, MODE_KP = 1, MODE_DRES = 2, MODE_KPB = 3, MODE_GRAD = 4 };
 template <int MODE>
 __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     KernelStamp stamp(a.tstamp);
-    __shared__ double prod[kTileNnz];
+    // products of the tile, padded by one double per 8: the row sums read consecutive 8-entry segments from
+    // consecutive lanes (stride 8 doubles = 16 banks -> 16-way conflicts unpadded, 2-way with stride 9)
+    __shared__ double prod[kTileNnz + kTileNnz / 8];
+    auto kpad = [](int k) -> int { return k + (k >> 3); };
     __shared__ double red[8];
     __shared__ int32_t srow[kRowsPerBlock + 1];  // row pointers of the tile, relative to k0
     const int b = blockIdx.x;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         for (int u = 0; u < kUnroll; ++u) {
             const int k = t + u * kThreads;
             if (MODE == MODE_KPB) g[u] += beta * g2[u];
-            if (k < nn) prod[k] = v[u] * g[u];
+            if (k < nn) prod[kpad(k)] = v[u] * g[u];
         }
         if (r0 + t <= r1) srow[t] = my_ptr - k0;
         if (t == 0) srow[r1 - r0] = end_ptr - k0;
@@ -283,10 +286,10 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
             const int a0 = srow[t], a1 = srow[t + 1];
             if (MODE == MODE_DRES || MODE == MODE_GRAD) {
                 const int sp = a.M.split[row] - k0;
-                for (int k = a0; k < sp; ++k) sum += prod[k];
-                for (int k = sp; k < a1; ++k) sum2 += prod[k];
+                for (int k = a0; k < sp; ++k) sum += prod[kpad(k)];
+                for (int k = sp; k < a1; ++k) sum2 += prod[kpad(k)];
             } else {
-                for (int k = a0; k < a1; ++k) sum += prod[k];
+                for (int k = a0; k < a1; ++k) sum += prod[kpad(k)];
             }
         }
     }
