@@ -1,8 +1,8 @@
-import sys, time; sys.path.insert(0,'.')
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from score_amd.manhattan import make_manhattan
 from score_amd.assemble import assemble
 from score_amd.solver import ConicSolver
-for B in (1, 2, 4, 8, 16):
+for B in (1, 4, 16):
     qps = [assemble(make_manhattan(n_robots=20, n_poses=1000, n_beacons=4, seed=3000+i),'SOCP').qp for i in range(B)]
     s = ConicSolver(qps, dict(polish=0, max_iters=100)); s.solve()
     ms, by = s.time_kkt_apply(300)

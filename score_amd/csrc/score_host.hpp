@@ -894,6 +894,63 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         });
         pt.mark("ruiz (all problems)");
     }
+    // The per-problem pieces of A, K (pattern + K0 / K1), G1 and G2 do not depend on each other: in a
+    // batch they are built one problem per thread into private mini-systems -- global column indices
+    // (the offsets are known up front), local row pointers -- and stitched together below, each piece
+    // copied into its own range.  A single problem is appended in place (its row loops are split over
+    // threads inside append_problem).  Either way the arrays come out identical.
+    std::vector<HostSystem> pieces;
+    if (count > 1) {
+        pieces.resize((size_t)count);
+        parallel_ranges(count, 1, [&](int, int64_t p0, int64_t p1) {
+            PhaseTimer quiet(false);
+            for (int64_t p = p0; p < p1; ++p) {
+                HostSystem& Q = pieces[(size_t)p];
+                Q.count = 1;
+                Q.sigma = H.sigma;
+                Q.n_tot = H.n_tot; Q.m_tot = H.m_tot;
+                Q.xoff.assign(1, H.xoff[p]); Q.roff.assign(1, H.roff[p]);
+                Q.A.ptr.assign(1, 0); Q.K.ptr.assign(1, 0); Q.G1.ptr.assign(1, 0); Q.G2.ptr.assign(1, 0);
+                append_problem(Q, 0, probs[p], scaled[(size_t)p], quiet);
+            }
+        });
+        pt.mark("append (K, G1, G2), all problems");
+        // sizes, then parallel copies into place
+        std::vector<size_t> oA(count + 1, 0), oK(count + 1, 0), oG1(count + 1, 0), oG2(count + 1, 0);
+        for (int p = 0; p < count; ++p) {
+            oA[p + 1] = oA[p] + pieces[p].A.col.size();
+            oK[p + 1] = oK[p] + pieces[p].K.col.size();
+            oG1[p + 1] = oG1[p] + pieces[p].G1.col.size();
+            oG2[p + 1] = oG2[p] + pieces[p].G2.col.size();
+        }
+        H.A.col.resize(oA[count]); H.A.val.resize(oA[count]); H.A.ptr.resize((size_t)H.m_tot + 1);
+        H.K.col.resize(oK[count]); H.K0.resize(oK[count]); H.K1.resize(oK[count]); H.K.ptr.resize((size_t)H.n_tot + 1);
+        H.G1.col.resize(oG1[count]); H.G1.val.resize(oG1[count]); H.G1.ptr.resize((size_t)H.n_tot + 1);
+        H.G2.col.resize(oG2[count]); H.G2.val.resize(oG2[count]); H.G2.ptr.resize((size_t)H.n_tot + 1);
+        H.g2_split.resize((size_t)H.n_tot);
+        parallel_ranges(count, 1, [&](int, int64_t p0, int64_t p1) {
+            for (int64_t p = p0; p < p1; ++p) {
+                HostSystem& Q = pieces[(size_t)p];
+                const size_t n = (size_t)probs[p].n, m = (size_t)probs[p].m;
+                const size_t xo = (size_t)H.xoff[p], ro = (size_t)H.roff[p];
+                auto copy = [](auto& dst, size_t off, const auto& src) { if (!src.empty()) std::memcpy(&dst[off], src.data(), src.size() * sizeof(src[0])); };
+                copy(H.A.col, oA[p], Q.A.col); copy(H.A.val, oA[p], Q.A.val);
+                for (size_t r = 0; r < m; ++r) H.A.ptr[ro + r + 1] = (int32_t)(oA[p] + (size_t)Q.A.ptr[r + 1]);
+                copy(H.K.col, oK[p], Q.K.col); copy(H.K0, oK[p], Q.K0); copy(H.K1, oK[p], Q.K1);
+                copy(H.G1.col, oG1[p], Q.G1.col); copy(H.G1.val, oG1[p], Q.G1.val);
+                copy(H.G2.col, oG2[p], Q.G2.col); copy(H.G2.val, oG2[p], Q.G2.val);
+                for (size_t i = 0; i < n; ++i) {
+                    H.K.ptr[xo + i + 1] = (int32_t)(oK[p] + (size_t)Q.K.ptr[i + 1]);
+                    H.G1.ptr[xo + i + 1] = (int32_t)(oG1[p] + (size_t)Q.G1.ptr[i + 1]);
+                    H.G2.ptr[xo + i + 1] = (int32_t)(oG2[p] + (size_t)Q.G2.ptr[i + 1]);
+                    H.g2_split[xo + i] = (int32_t)(oG2[p] + (size_t)Q.g2_split[i]);
+                }
+                Q = HostSystem();  // release the piece
+            }
+        });
+        H.A.ptr[0] = 0; H.K.ptr[0] = 0; H.G1.ptr[0] = 0; H.G2.ptr[0] = 0;
+        pt.mark("stitch");
+    }
     for (int p = 0; p < count; ++p) {
         const score_problem& pr = probs[p];
         if (count == 1) {
@@ -910,8 +967,10 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         for (int j = 0; j < pr.n; ++j) { qu = std::max(qu, std::fabs(pr.q[j])); qs = std::max(qs, std::fabs(S.q[j])); }
         for (int r = 0; r < pr.m; ++r) { bu = std::max(bu, std::fabs(pr.b[r])); bsn = std::max(bsn, std::fabs(S.b[r])); }
         H.qnorm_u.push_back(qu); H.bnorm_u.push_back(bu); H.qnorm_s.push_back(qs); H.bnorm_s.push_back(bsn);
-        append_problem(H, p, pr, S, pt);
-        pt.mark("append (K, G1, G2)");
+        if (count == 1) {
+            append_problem(H, p, pr, S, pt);
+            pt.mark("append (K, G1, G2)");
+        }
         // cones, in blocks of kConesPerBlock that never straddle problems
         const size_t c_first = H.cone_row.size();
         for (int r = 0; r < pr.z; ++r) {
