@@ -520,6 +520,7 @@ struct HipBackend {
         fac.alloc(h.fac_doubles); fac.zero(stream);  // separator slots of the spike region are never written (nor used)
         dinv.alloc(h.dinv.size()); rho.upload(h.rho);
         q_work.alloc((size_t)std::max<int64_t>(1, h.scratch_nodes) * 2 * std::max(1, h.bs * h.bs));
+        plan_factor_lds();
         derive_rho_data(false);
         pt.mark("allocations + rho data (device)");
         if (st.polish) init_polish(h);
@@ -574,16 +575,43 @@ struct HipBackend {
             fa.work = prec_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = K.val.d;
             fa.pos_diag = kposd.d; fa.pos_sub = kposs.d; fa.fac = fac.d; fa.work_mat = q_work.d; fa.skip = nullptr;
             fa.diag_pos = kdiagpos.d; fa.dinv = dinv.d;
-            const int np = n_prec_items();
-            const int bs = h.bs;
-            if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(np), dim3(kThreads), 0, stream, fa);
-            else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(np), dim3(kThreads), 0, stream, fa);
-            else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(np), dim3(kThreads), 0, stream, fa);
-            else hipLaunchKernelGGL(k_factor<4>, dim3(np), dim3(kThreads), 0, stream, fa);
+            launch_factor(fa);
         }
         HIP_CHECK(hipGetLastError());
     }
     int n_prec_items() const { return (int)H->prec_work.size(); }
+    // k_factor keeps the level-to-level matrices in LDS when the longest chain fits
+    int factor_lds_wmat = 0;
+    size_t factor_lds_bytes = 0;
+    void plan_factor_lds() {
+        const HostSystem& h = *H;
+        const int b2 = std::max(1, h.bs * h.bs);
+        int max_scr = 0, max_runs = 0;
+        for (const auto& ch : h.chains) {
+            max_scr = std::max(max_scr, ch.scratch_nodes);
+            max_runs = std::max(max_runs, h.levels[ch.level_begin].nruns);
+        }
+        const size_t wm = (size_t)max_scr * 2 * b2, vx = (size_t)(max_runs + 2) * b2;
+        factor_lds_wmat = 0; factor_lds_bytes = 0;
+        if (!h.chains.empty() && max_runs <= kThreads && (wm + vx) * sizeof(double) <= (size_t)150 * 1024) {
+            factor_lds_wmat = (int)std::max<size_t>(wm, 1);
+            factor_lds_bytes = (wm + vx + 2) * sizeof(double);
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_factor<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_factor<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_factor<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_factor<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
+        }
+    }
+    void launch_factor(FactorArgs fa) {
+        const int np = n_prec_items();
+        if (np == 0) return;
+        fa.lds_wmat = factor_lds_wmat;
+        const int bs = H->bs;
+        if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
+        else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
+        else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
+        else hipLaunchKernelGGL(k_factor<4>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
+    }
 
     ConeArgs cone_args(const double* gathered) {
         ConeArgs a{};
@@ -1149,7 +1177,6 @@ struct HipBackend {
     // and the chain factors of the Newton preconditioner (device-side factorisation)
     void newton_hessian(const int32_t* skip = nullptr) {
         const HostSystem& h = *H;
-        const int bs = h.bs;
         HAsmArgs ha{};
         ha.nnz = (int64_t)Q.Hm.col.size(); ha.Pon = q_Pon.d; ha.cptr = q_cptr.d; ha.ccone = q_ccone.d; ha.cab = q_cab.d;
         ha.ccoef = q_ccoef.d; ha.Bbuf = q_Bbuf.d; ha.T2 = Q.T * Q.T; ha.Hval = Hm.val.d;
@@ -1161,10 +1188,7 @@ struct HipBackend {
             fa.work = prec_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = Hm.val.d;
             fa.pos_diag = q_posd.d; fa.pos_sub = q_poss.d; fa.fac = q_fac.d; fa.work_mat = q_work.d; fa.skip = skip;
             fa.diag_pos = q_diagpos.d; fa.dinv = q_dinv.d;
-            if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(n_prec_items()), dim3(kThreads), 0, stream, fa);
-            else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(n_prec_items()), dim3(kThreads), 0, stream, fa);
-            else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(n_prec_items()), dim3(kThreads), 0, stream, fa);
-            else hipLaunchKernelGGL(k_factor<4>, dim3(n_prec_items()), dim3(kThreads), 0, stream, fa);
+            launch_factor(fa);
         }
     }
 

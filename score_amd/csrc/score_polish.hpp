@@ -190,12 +190,19 @@ struct FactorArgs {
     // Jacobi work items (columns outside every chain): dinv[e] = 1 / H[diag_pos[e]]
     const int32_t* diag_pos;
     double* dinv;
+    // > 0: the Schur complements handed from one level to the next (and the spike blocks a separator
+    // needs from the run on its right) stay in dynamic LDS -- lds_wmat doubles for the matrices, the
+    // spike exchange behind them -- instead of making a round trip through global memory between the
+    // phases of every level (the host enables it when the longest chain of the launch fits)
+    int lds_wmat;
 };
 
 template <int BS>
 __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
     constexpr int B2 = BS * BS;
     using SM = SmallMat<BS>;
+    extern __shared__ __attribute__((aligned(16))) double fl[];
+    const bool in_lds = a.lds_wmat > 0;
     const PrecWork wk = a.work[blockIdx.x];
     if (a.skip && a.skip[wk.prob]) return;
     if (wk.kind != 0) {  // Jacobi block: reciprocal diagonal
@@ -209,19 +216,38 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
     // the Schur complements written by the previous level
     auto loadA = [&](int l, const ChainLevelDesc& L, int i, double* out) {
         if (l == 0) {
+            // (unconditional loads on clamped positions, selected afterwards: a predicated load compiles to a
+            //  branch with its own wait and serialises the gathers)
             const int32_t* pd = a.pos_diag + (size_t)(ch.node_begin + i) * B2;
-            for (int e = 0; e < B2; ++e) out[e] = pd[e] >= 0 ? a.Hval[pd[e]] : 0.0;
+            int32_t ix[B2];
+#pragma unroll
+            for (int e = 0; e < B2; ++e) ix[e] = pd[e];
+            double v[B2];
+#pragma unroll
+            for (int e = 0; e < B2; ++e) v[e] = a.Hval[max(ix[e], 0)];
+#pragma unroll
+            for (int e = 0; e < B2; ++e) out[e] = ix[e] >= 0 ? v[e] : 0.0;
         } else {
-            const double* src = a.work_mat + ((size_t)(ch.scratch_off + L.vec_off + i) * 2 + 0) * B2;
+            const double* src = in_lds ? fl + ((size_t)(L.vec_off + i) * 2 + 0) * B2
+                                       : a.work_mat + ((size_t)(ch.scratch_off + L.vec_off + i) * 2 + 0) * B2;
             for (int e = 0; e < B2; ++e) out[e] = src[e];
         }
     };
+    double* vx = fl + a.lds_wmat;  // (in_lds) V of the first node of every run of the current level
     auto loadB = [&](int l, const ChainLevelDesc& L, int i, double* out) {  // T[i, i-1]
         if (l == 0) {
             const int32_t* ps = a.pos_sub + (size_t)(ch.node_begin + i) * B2;
-            for (int e = 0; e < B2; ++e) out[e] = (i > 0 && ps[e] >= 0) ? a.Hval[ps[e]] : 0.0;
+            int32_t ix[B2];
+#pragma unroll
+            for (int e = 0; e < B2; ++e) ix[e] = ps[e];
+            double v[B2];
+#pragma unroll
+            for (int e = 0; e < B2; ++e) v[e] = a.Hval[max(ix[e], 0)];
+#pragma unroll
+            for (int e = 0; e < B2; ++e) out[e] = (i > 0 && ix[e] >= 0) ? v[e] : 0.0;
         } else {
-            const double* src = a.work_mat + ((size_t)(ch.scratch_off + L.vec_off + i) * 2 + 1) * B2;
+            const double* src = in_lds ? fl + ((size_t)(L.vec_off + i) * 2 + 1) * B2
+                                       : a.work_mat + ((size_t)(ch.scratch_off + L.vec_off + i) * 2 + 1) * B2;
             for (int e = 0; e < B2; ++e) out[e] = src[e];
         }
     };
@@ -246,6 +272,16 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
         //      first; the factors then stay in registers -- no store -> load round trips ----
         constexpr int RM = kMaxBs - 1;  // nodes per run <= radix - 1 <= 3
         double Vl[B2], Wl[B2];          // spikes of the last node of this lane's (first) run
+        // the blocks of this lane's separator (T[s, s-1], T[s, s], T[s+1, s]) are requested together with its
+        // run's: at level 0 they are gathers through the position tables, two dependent trips to memory
+        double pCl[B2], pAs[B2], pBn[B2];
+        const bool pre = !last && t < nsep;
+        if (pre) {
+            const int s = t * L.p + L.p - 1;
+            loadB(l, L, s, pCl);
+            loadA(l, L, s, pAs);
+            loadB(l, L, min(s + 1, L.N - 1), pBn);
+        }
         for (int j = t; j < L.nruns; j += kThreads) {
             const int lo = last ? 0 : j * L.p;
             const int hi = last ? L.N : min(j * L.p + L.p - 1, L.N);
@@ -332,6 +368,10 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
 #pragma unroll
                 for (int q = 0; q < RM; ++q) {
                     if (q < len) Bst(side, lo + q, Y[q]);
+                    if (in_lds && side == 0 && q == 0) {
+#pragma unroll
+                        for (int e = 0; e < B2; ++e) vx[(size_t)j * B2 + e] = Y[0][e];
+                    }
                     if (q == len - 1 && j == t) {
 #pragma unroll
                         for (int e = 0; e < B2; ++e) {
@@ -348,8 +388,12 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
         for (int j = t; j < nsep; j += kThreads) {
             const int s = j * L.p + L.p - 1;
             double Cl[B2], Cr[B2], As[B2], M1[B2], T1[B2];
-            loadB(l, L, s, Cl);  // T[s, s-1]
-            loadA(l, L, s, As);
+            if (pre && j == t) {
+                for (int e = 0; e < B2; ++e) { Cl[e] = pCl[e]; As[e] = pAs[e]; }
+            } else {
+                loadB(l, L, s, Cl);  // T[s, s-1]
+                loadA(l, L, s, As);
+            }
             for (int e = 0; e < B2; ++e) Cr[e] = 0.0;
             if (j == t) {        // W_{s-1}: last node of this lane's own run
                 for (int e = 0; e < B2; ++e) M1[e] = Wl[e];
@@ -360,10 +404,18 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
             for (int e = 0; e < B2; ++e) As[e] -= T1[e];
             if (s + 1 < L.N) {
                 double Bn[B2];
-                loadB(l, L, s + 1, Bn);
+                if (pre && j == t) {
+                    for (int e = 0; e < B2; ++e) Bn[e] = pBn[e];
+                } else {
+                    loadB(l, L, s + 1, Bn);
+                }
                 for (int r = 0; r < BS; ++r)
                     for (int c = 0; c < BS; ++c) Cr[r * BS + c] = Bn[c * BS + r];
-                Bld(0, s + 1, M1);  // V_{s+1}
+                if (in_lds) {   // V_{s+1}: first node of the run on the right
+                    for (int e = 0; e < B2; ++e) M1[e] = vx[(size_t)(j + 1) * B2 + e];
+                } else {
+                    Bld(0, s + 1, M1);
+                }
                 SM::mul(Cr, M1, T1);
                 for (int e = 0; e < B2; ++e) As[e] -= T1[e];
             }
@@ -371,8 +423,10 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
                 S[(size_t)(0 * B2 + e) * nsep + j] = Cl[e];
                 S[(size_t)(1 * B2 + e) * nsep + j] = Cr[e];
             }
-            double* dstA = a.work_mat + ((size_t)(ch.scratch_off + Ln.vec_off + j) * 2 + 0) * B2;
-            double* dstB = a.work_mat + ((size_t)(ch.scratch_off + Ln.vec_off + j) * 2 + 1) * B2;
+            double* dstA = in_lds ? fl + ((size_t)(Ln.vec_off + j) * 2 + 0) * B2
+                                  : a.work_mat + ((size_t)(ch.scratch_off + Ln.vec_off + j) * 2 + 0) * B2;
+            double* dstB = in_lds ? fl + ((size_t)(Ln.vec_off + j) * 2 + 1) * B2
+                                  : a.work_mat + ((size_t)(ch.scratch_off + Ln.vec_off + j) * 2 + 1) * B2;
             for (int e = 0; e < B2; ++e) dstA[e] = As[e];
             if (j >= 1) {
                 if (j == t) {       // V_{s-1}
