@@ -77,6 +77,7 @@ def test_montecarlo_group_sizes():
 
     assert bench.mc_groups(64, 16, 4) == [16, 16, 16, 16]
     assert bench.mc_groups(0, 16, 4) == []
+    assert bench.mc_groups(8, 16, 4) == [4, 4] and bench.mc_groups(16, 16, 4) == [4, 4, 4, 4] and bench.mc_groups(32, 16, 4) == [8] * 4
     for n in (1, 2, 3, 8, 9, 32, 33, 100):
         g = bench.mc_groups(n, 16, 4)
         assert sum(g) == n and max(g) <= 16 and min(g) >= 1 and max(g) - min(g) <= 1
