@@ -143,20 +143,22 @@ def _check_unique(names: List[str], what: str) -> None:
 
 
 def _pose_meas_arrays(meas: list, pose_idx: Dict[str, int], d: int):
+    from operator import attrgetter
+
     ne = len(meas)
-    bi = np.fromiter((pose_idx[m.base_pose] for m in meas), dtype=np.int64, count=ne)
-    tj = np.fromiter((pose_idx[m.to_pose] for m in meas), dtype=np.int64, count=ne)
-    kap = np.fromiter((m.translation_precision for m in meas), dtype=np.float64, count=ne)
-    tau = np.fromiter((m.rotation_precision for m in meas), dtype=np.float64, count=ne)
+    bi = np.fromiter(map(pose_idx.__getitem__, map(attrgetter("base_pose"), meas)), dtype=np.int64, count=ne)
+    tj = np.fromiter(map(pose_idx.__getitem__, map(attrgetter("to_pose"), meas)), dtype=np.int64, count=ne)
+    kap = np.fromiter(map(attrgetter("translation_precision"), meas), dtype=np.float64, count=ne)
+    tau = np.fromiter(map(attrgetter("rotation_precision"), meas), dtype=np.float64, count=ne)
     tm = np.empty((ne, d))
     Rm = np.empty((ne, d, d))
     m0 = meas[0]
     if d == 2 and all(hasattr(m0, a) for a in ("x", "y", "theta")):
         # PyFactorGraph's PoseMeasurement2D stores (x, y, theta); translation_vector and
         # rotation_matrix are properties derived from them -- derive them for all edges at once
-        tm[:, 0] = np.fromiter((m.x for m in meas), dtype=np.float64, count=ne)
-        tm[:, 1] = np.fromiter((m.y for m in meas), dtype=np.float64, count=ne)
-        th = np.fromiter((m.theta for m in meas), dtype=np.float64, count=ne)
+        tm[:, 0] = np.fromiter(map(attrgetter("x"), meas), dtype=np.float64, count=ne)
+        tm[:, 1] = np.fromiter(map(attrgetter("y"), meas), dtype=np.float64, count=ne)
+        th = np.fromiter(map(attrgetter("theta"), meas), dtype=np.float64, count=ne)
         cs, sn = np.cos(th), np.sin(th)
         Rm[:, 0, 0] = cs; Rm[:, 0, 1] = -sn
         Rm[:, 1, 0] = sn; Rm[:, 1, 1] = cs

@@ -553,43 +553,52 @@ inline void ruiz_scale(const score_problem& p, int iters, ProblemScaled& out) {
     out.A.val.assign(p.A_val, p.A_val + p.A_rowptr[m]);
     out.D.assign(n, 1.0);
     out.E.assign(m, 1.0);
-    std::vector<double> cn(n), rn(m), d(n), e(m);
-    // P is symmetric (the ABI takes the full matrix): its column norms are its row norms.  One
-    // team runs all passes; each member owns a row range of P and, per pass, scales it and takes
-    // the row norms of the result (the next pass's input) in one sweep.  Member 0 also does the
-    // (much smaller) A side.
-    TeamBarrier bar(parallel_parts(n, 16384));
+    std::vector<double> cn(n), d(n), e(m);
+    // P is symmetric (the ABI takes the full matrix): its column norms are its row norms.  One team
+    // runs all passes; each member owns a row range of P (= a column range of the KKT matrix) and a
+    // range of cone groups of A (a zero-cone row is a group of its own; the rows of one cone share a
+    // scale), and per pass takes norms and scales in one sweep each.  Column norms of A are taken
+    // column-wise through a position map (A' built once), so no member ever updates another's entry.
+    const int64_t nnzA = p.A_rowptr[m];
+    std::vector<int32_t> atp(n + 1, 0), atpos((size_t)nnzA);
+    for (int64_t k = 0; k < nnzA; ++k) atp[out.A.col[k] + 1]++;
+    for (int j = 0; j < n; ++j) atp[j + 1] += atp[j];
+    {
+        std::vector<int32_t> fill(atp.begin(), atp.end() - 1);
+        for (int64_t k = 0; k < nnzA; ++k) atpos[(size_t)fill[out.A.col[k]]++] = (int32_t)k;
+    }
+    const int64_t ngroups = (int64_t)p.z + p.n_soc;
+    std::vector<int32_t> gstart((size_t)ngroups + 1);
+    for (int r = 0; r < p.z; ++r) gstart[r] = r;
+    {
+        int row = p.z;
+        for (int c = 0; c < p.n_soc; ++c) { gstart[(size_t)p.z + c] = row; row += p.soc_dims[c]; }
+        gstart[(size_t)ngroups] = row;
+    }
+    const int T = parallel_parts(n, 16384);
+    TeamBarrier bar(T);
     if (iters > 0)
         parallel_ranges(n, 16384, [&](int t, int64_t i0, int64_t i1) {
+            const int64_t g0 = ngroups * t / T, g1 = ngroups * (t + 1) / T;
             for (int64_t i = i0; i < i1; ++i) {
                 double mx = 0.0;
                 for (int k = out.P.ptr[i]; k < out.P.ptr[i + 1]; ++k) mx = std::max(mx, std::fabs(out.P.val[k]));
                 cn[i] = mx;
             }
             for (int it = 0; it < iters; ++it) {
-                bar.wait();  // cn holds the row norms of P
-                if (t == 0) {
-                    for (int r = 0; r < m; ++r) {
-                        double mx = 0.0;
-                        for (int k = out.A.ptr[r]; k < out.A.ptr[r + 1]; ++k) {
-                            double v = std::fabs(out.A.val[k]);
-                            cn[out.A.col[k]] = std::max(cn[out.A.col[k]], v);
-                            mx = std::max(mx, v);
-                        }
-                        rn[r] = mx;
-                    }
-                    int row = p.z;
-                    for (int c = 0; c < p.n_soc; ++c) {  // one scale per cone
-                        double mx = 0;
-                        for (int k = 0; k < p.soc_dims[c]; ++k) mx = std::max(mx, rn[row + k]);
-                        for (int k = 0; k < p.soc_dims[c]; ++k) rn[row + k] = mx;
-                        row += p.soc_dims[c];
-                    }
-                    for (int r = 0; r < m; ++r) e[r] = rn[r] > 1e-12 ? 1.0 / std::sqrt(rn[r]) : 1.0;
+                // norms: own columns (P row norm already in cn, A column-wise), own cone groups
+                for (int64_t j = i0; j < i1; ++j) {
+                    double mx = cn[j];
+                    for (int k = atp[j]; k < atp[j + 1]; ++k) mx = std::max(mx, std::fabs(out.A.val[atpos[(size_t)k]]));
+                    d[j] = mx > 1e-12 ? 1.0 / std::sqrt(mx) : 1.0;
                 }
-                bar.wait();  // cn complete
-                for (int64_t j = i0; j < i1; ++j) d[j] = cn[j] > 1e-12 ? 1.0 / std::sqrt(cn[j]) : 1.0;
-                bar.wait();  // d complete
+                for (int64_t g = g0; g < g1; ++g) {
+                    double mx = 0.0;
+                    for (int k = out.A.ptr[gstart[(size_t)g]]; k < out.A.ptr[gstart[(size_t)g + 1]]; ++k) mx = std::max(mx, std::fabs(out.A.val[k]));
+                    const double eg = mx > 1e-12 ? 1.0 / std::sqrt(mx) : 1.0;
+                    for (int r = gstart[(size_t)g]; r < gstart[(size_t)g + 1]; ++r) e[r] = eg;
+                }
+                bar.wait();  // d, e complete
                 for (int64_t i = i0; i < i1; ++i) {
                     double mx = 0.0;
                     for (int k = out.P.ptr[i]; k < out.P.ptr[i + 1]; ++k) {
@@ -599,11 +608,11 @@ inline void ruiz_scale(const score_problem& p, int iters, ProblemScaled& out) {
                     cn[i] = mx;
                     out.D[i] *= d[i];
                 }
-                if (t == 0) {
-                    for (int r = 0; r < m; ++r)
-                        for (int k = out.A.ptr[r]; k < out.A.ptr[r + 1]; ++k) out.A.val[k] *= e[r] * d[out.A.col[k]];
-                    for (int r = 0; r < m; ++r) out.E[r] *= e[r];
+                for (int r = gstart[(size_t)g0]; r < gstart[(size_t)g1]; ++r) {
+                    for (int k = out.A.ptr[r]; k < out.A.ptr[r + 1]; ++k) out.A.val[k] *= e[r] * d[out.A.col[k]];
+                    out.E[r] *= e[r];
                 }
+                bar.wait();  // A scaled: the next pass reads it column-wise
             }
         });
     out.q.resize(n);

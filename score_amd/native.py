@@ -14,6 +14,7 @@ for ``.P`` / ``.A`` (tests, the oracle's certificate).
 from __future__ import annotations
 
 import ctypes as C
+from operator import attrgetter
 from typing import Dict, Optional
 
 import numpy as np
@@ -71,7 +72,10 @@ def graph_arrays(data) -> Dict[str, np.ndarray]:
         raise ValueError("factor graph has no pose variables")
     var_idx = dict(pose_idx)
     var_idx.update((nm, Np + i) for i, nm in enumerate(landmark_names))
-    range_keys = [(m.first_key, m.second_key) for m in data.range_measurements]
+    if data.range_measurements and hasattr(data.range_measurements[0], "association"):
+        range_keys = [tuple(a) for a in map(attrgetter("association"), data.range_measurements)]
+    else:
+        range_keys = [(m.first_key, m.second_key) for m in data.range_measurements]
     if len(set(range_keys)) != len(range_keys):
         seen = set()
         for k in range_keys:
@@ -87,16 +91,18 @@ def graph_arrays(data) -> Dict[str, np.ndarray]:
         bi = tj = np.zeros(0, np.int64); kap = tau = np.zeros(0); tm = np.zeros((0, d)); Rm = np.zeros((0, d, d))
     nr = len(range_keys)
 
-    def vid(name):
-        try:
-            return var_idx[name]
-        except KeyError:
-            raise ValueError(f"Variable name {name} not found") from None
-
-    ra = np.fromiter((vid(a) for a, _ in range_keys), dtype=np.int32, count=nr)
-    rb = np.fromiter((vid(b) for _, b in range_keys), dtype=np.int32, count=nr)
-    dist = np.fromiter((m.dist for m in data.range_measurements), dtype=np.float64, count=nr)
-    prec = np.fromiter((m.precision for m in data.range_measurements), dtype=np.float64, count=nr)
+    try:  # (dict lookups in C: itemgetter over all keys at once)
+        ra = np.fromiter(map(var_idx.__getitem__, (k[0] for k in range_keys)), dtype=np.int32, count=nr)
+        rb = np.fromiter(map(var_idx.__getitem__, (k[1] for k in range_keys)), dtype=np.int32, count=nr)
+    except KeyError as exc:
+        raise ValueError(f"Variable name {exc.args[0]} not found") from None
+    rm = data.range_measurements
+    dist = np.fromiter(map(attrgetter("dist"), rm), dtype=np.float64, count=nr)
+    if nr and hasattr(rm[0], "stddev"):  # PyFactorGraph stores stddev; precision = 1 / stddev^2 is a derived property
+        std = np.fromiter(map(attrgetter("stddev"), rm), dtype=np.float64, count=nr)
+        prec = 1.0 / (std * std)
+    else:
+        prec = np.fromiter(map(attrgetter("precision"), rm), dtype=np.float64, count=nr)
     lm_idx = {nm: i for i, nm in enumerate(landmark_names)}
     pri = list(data.landmark_priors)
     for p in pri:
