@@ -233,6 +233,17 @@ int  score_assemble(const score_graph* g, score_assembled** out);
 int  score_assembled_view(const score_assembled* a, score_problem* view);
 void score_assembled_free(score_assembled* a);
 
+/* SO(d) rounding of the relaxed rotation blocks: replaces the per-pose
+ * round_to_special_orthogonal(...) calls of VariableCollection.get_variable_values
+ * (score/utils/gurobi_utils.py:115-125; score/utils/matrix_utils.py:59-79).
+ * `blocks`, `rotations`: n row-major dim x dim matrices (host memory); rotations[i] is the
+ * maximiser of tr(R' blocks[i]) over SO(dim) -- what the reference's SVD + determinant fix
+ * computes.  degenerate[i] = 1 where that maximiser is not unique (rank-deficient or
+ * reflection-like input, NaN): rotations[i] is then the identity and the caller decides
+ * (score_amd falls back to the reference's SVD formula for those blocks).  dim = 2 or 3. */
+int  score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rotations,
+                       int32_t* degenerate, int32_t device);
+
 const char* score_last_error(void);
 const char* score_backend(void);   /* "hip-gfx950" or "cpu-twin"             */
 

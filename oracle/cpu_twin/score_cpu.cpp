@@ -23,6 +23,7 @@
 
 #include "../../score_amd/csrc/score_driver.hpp"
 #include "../../score_amd/csrc/score_assemble.hpp"
+#include "../../score_amd/csrc/score_round.hpp"
 
 namespace {
 
@@ -396,6 +397,15 @@ int score_assembled_view(const score_assembled* a, score_problem* view) {
     return 0;
 }
 void score_assembled_free(score_assembled* a) { delete a; }
+int score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rotations, int32_t* degenerate, int32_t /*device*/) {
+    if (dim != 2 && dim != 3) { g_err = "score_round_to_so: dim must be 2 or 3"; return -1; }
+    if (n < 0 || (n > 0 && (!blocks || !rotations || !degenerate))) { g_err = "score_round_to_so: null argument"; return -1; }
+    for (int64_t i = 0; i < n; ++i) {  // the same per-block function the HIP kernel runs per lane
+        if (dim == 2) score::round_so2(blocks + 4 * i, rotations + 4 * i, degenerate + i);
+        else score::round_so3(blocks + 9 * i, rotations + 9 * i, degenerate + i);
+    }
+    return 0;
+}
 const char* score_last_error(void) { return g_err.c_str(); }
 const char* score_backend(void) { return "cpu-twin"; }
 }

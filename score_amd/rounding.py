@@ -11,6 +11,11 @@ the closed form R(theta), theta = atan2(M10 - M01, M00 + M11); only the inputs
 for which that maximiser is not unique (M00 + M11 = M10 - M01 = 0: zero and
 scaled-reflection matrices, where the reference returns whatever its SVD
 picks) go through the SVD.
+
+``lib`` given (the loaded C-ABI library, ``score_amd.solver.load_library``): the stack is rounded by
+``score_round_to_so`` -- on the GPU for the HIP library, one block per lane (closed form for d = 2,
+Horn's quaternion eigenvector for d = 3; csrc/score_round.hpp) -- and only the blocks it flags as
+degenerate go through the SVD here.  20 000 3-D poses: 65 ms of batched NumPy SVD otherwise.
 """
 from __future__ import annotations
 
@@ -64,7 +69,29 @@ def _closed_form_round_2d(M: np.ndarray) -> np.ndarray:
     return R
 
 
-def round_to_special_orthogonal(mat: np.ndarray) -> np.ndarray:
+def _native_round(M: np.ndarray, lib, device: int) -> np.ndarray:
+    import ctypes as C
+
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    R = np.empty_like(M)
+    flags = np.empty(len(M), dtype=np.int32)
+    f64p = C.POINTER(C.c_double)
+    rc = lib.score_round_to_so(M.shape[-1], len(M), M.ctypes.data_as(f64p), R.ctypes.data_as(f64p),
+                               flags.ctypes.data_as(C.POINTER(C.c_int32)), int(device))
+    if rc != 0:
+        raise RuntimeError(f"score_round_to_so failed: {lib.score_last_error().decode()}")
+    # non-degenerate blocks are rotations by construction (cos/sin pair, unit quaternion) for finite
+    # input, which the caller has checked; only the SVD fallback needs the reference's validity check
+    degenerate = flags != 0
+    if np.any(degenerate):
+        R[degenerate] = _svd_round(M[degenerate])
+        check_rotation_matrix(R[degenerate], assert_test=True)
+    if not np.all(np.isfinite(R)):
+        raise ValueError("non-finite rotation")
+    return R
+
+
+def round_to_special_orthogonal(mat: np.ndarray, lib=None, device: int = 0) -> np.ndarray:
     """Round one (d, d) matrix or a (N, d, d) stack onto SO(d)."""
     mat = np.asarray(mat, dtype=np.float64)
     single = mat.ndim == 2
@@ -74,8 +101,11 @@ def round_to_special_orthogonal(mat: np.ndarray) -> np.ndarray:
     try:
         if not np.all(np.isfinite(M)):
             raise ValueError("non-finite entries")
-        R = _closed_form_round_2d(M) if (M.shape[-1] == 2 and not single) else _svd_round(M)
-        check_rotation_matrix(R, assert_test=True)
+        if lib is not None and not single and M.shape[-1] in (2, 3) and len(M):
+            R = _native_round(M, lib, device)
+        else:
+            R = _closed_form_round_2d(M) if (M.shape[-1] == 2 and not single) else _svd_round(M)
+            check_rotation_matrix(R, assert_test=True)
     except (ValueError, np.linalg.LinAlgError):
         raise ValueError(f"Could not round matrix to special orthogonal form: {mat}")
     return R[0] if single else R

@@ -65,13 +65,13 @@ def _qcqp_dists_from_socp(model: ScoreModel, x_model: np.ndarray, data) -> np.nd
 
 def extract_solver_results(
     model: ScoreModel, x_solver: np.ndarray, data, total_time: float, solved: bool,
-    requested_relaxation: str, info: Optional[dict] = None,
+    requested_relaxation: str, info: Optional[dict] = None, lib=None, device: int = 0,
 ) -> compat.SolverResults:
     """gurobi_utils.py:190-203 + VariableCollection.get_variable_values (:114-136)."""
     d = model.dim
     xm = model.expand(x_solver)
     blocks = model.pose_blocks(xm)  # (Np, d, d+1)
-    R = round_to_special_orthogonal(blocks[:, :, :d])
+    R = round_to_special_orthogonal(blocks[:, :, :d], lib=lib, device=device)  # lib: on the device
     T = np.tile(np.eye(d + 1), (blocks.shape[0], 1, 1))
     T[:, :d, :d] = R
     T[:, :d, d] = blocks[:, :, d]
@@ -230,6 +230,7 @@ def solve_score_batch(
         settings.update(cg_iters=8, adaptive_rho=0)
     settings.update(solver_settings or {})
     solver = ConicSolver([m.qp for m in models], settings, lib_path=lib_path)
+    lib, device = solver.lib, int(solver.settings.device)
     try:
         sols = solver.solve()
     finally:
@@ -242,7 +243,7 @@ def solve_score_batch(
         try:
             out.append(extract_solver_results(
                 model, sol.x, data, total_time=sol.info["solve_ms"] * 1e-3, solved=sol.solved,
-                requested_relaxation=relaxation_type, info=sol.info,
+                requested_relaxation=relaxation_type, info=sol.info, lib=lib, device=device,
             ))
         except ValueError as exc:
             # an estimate that cannot be rounded (NaN iterate, non-converged rotation block): as in
@@ -291,7 +292,7 @@ def solve_problem_with_intermediate_iterates(
             try:
                 iterates.append(extract_solver_results(
                     model, sol.x, data, total_time=time.time() - t0, solved=sol.solved,
-                    requested_relaxation=relaxation_type, info=sol.info,
+                    requested_relaxation=relaxation_type, info=sol.info, lib=solver.lib, device=int(solver.settings.device),
                 ))
             except ValueError:
                 pass  # an early iterate whose rotation block cannot be rounded yet

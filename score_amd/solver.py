@@ -66,7 +66,7 @@ STATUS_NAMES = {0: "unsolved", 1: "solved", 2: "max_iters", 3: "numerical"}
 
 # every symbol include/score_hip.h declares
 ABI_SYMBOLS = [
-    "score_assemble", "score_assembled_view", "score_assembled_free",
+    "score_assemble", "score_assembled_view", "score_assembled_free", "score_round_to_so",
     "score_default_settings", "score_create", "score_create_batch", "score_dims", "score_solve",
     "score_reset", "score_solve_steps", "score_newton_steps", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
     "score_last_error", "score_backend",
@@ -98,6 +98,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.score_debug_get.restype = C.c_int64
     lib.score_destroy.argtypes = [C.c_void_p]
     lib.score_destroy.restype = None
+    lib.score_round_to_so.argtypes = [C.c_int32, C.c_int64, _f64p, _f64p, C.POINTER(C.c_int32), C.c_int32]
+    lib.score_round_to_so.restype = C.c_int
     lib.score_last_error.restype = C.c_char_p
     lib.score_backend.restype = C.c_char_p
     return lib

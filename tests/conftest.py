@@ -7,6 +7,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The CPU twin (test infrastructure) is an OpenMP program and the suite's problems are tiny: a full team
+# per Python worker thread on the 8 test-container CPUs spends its time in barriers (measured: a
+# 3-graph batch 26 s with 8 threads, 0.3 s with 2).  Tests that study thread counts set them explicitly.
+os.environ.setdefault("OMP_NUM_THREADS", "2")
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 HIP_LIB = os.path.join(ROOT, "score_amd", "csrc", "libscore_hip.so")
 TWIN_LIB = os.path.join(ROOT, "oracle", "cpu_twin", "libscore_cpu.so")

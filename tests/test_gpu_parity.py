@@ -563,3 +563,38 @@ def test_bench_montecarlo_mode_reports_a_contract_line(hip_lib):
                 "vs_baseline", "dtype", "data", "config"):
         assert key in rec
     assert rec["metric"] == "problems_per_sec" and rec["value"] > 0 and rec["problems_solved_last_sweep"] == 4
+
+
+@pytest.mark.parametrize("d", [2, 3])
+def test_device_rounding_matches_reference_vectors_and_the_twin(d, hip_lib, twin_lib):
+    """k_round_so through score_round_to_so: the reference-generated golden vectors, then a 50 000-block
+    stack against the CPU twin's loop over the same per-block function (fp64: reassociation only) and,
+    on the well-conditioned blocks, against the oracle's SVD restatement."""
+    from conftest import GOLDEN
+    from score_amd.rounding import round_to_special_orthogonal
+    from score_amd.solver import load_library
+
+    _hip_only(hip_lib)
+    hip, twin = load_library(hip_lib), load_library(twin_lib)
+    z = np.load(os.path.join(GOLDEN, "rounding_golden.npz"))
+    M, R = z[f"in_{d}d"], z[f"out_{d}d"]
+    full_rank = np.abs(z[f"det_{d}d"]) > 1e-6
+    got = round_to_special_orthogonal(M, lib=hip)
+    np.testing.assert_allclose(got[full_rank], R[full_rank], atol=1e-10)
+    rng = np.random.default_rng(40 + d)
+    big = rng.normal(size=(50000, d, d))
+    q, _ = np.linalg.qr(rng.normal(size=(20000, d, d)))
+    big[:20000] = q + 1e-3 * rng.normal(size=(20000, d, d))
+    big[20000:22000] *= 10.0 ** rng.uniform(-6, 6, size=(2000, 1, 1))
+    g_hip, g_twin = round_to_special_orthogonal(big, lib=hip), round_to_special_orthogonal(big, lib=twin)
+    sv = np.linalg.svd(big, compute_uv=False)
+    det = np.linalg.det(big)
+    margin = np.where(det > 0, sv[:, -1] + sv[:, -2], sv[:, -2] - sv[:, -1]) / sv[:, 0]
+    ok = margin > 1e-3
+    np.testing.assert_allclose(g_hip[ok], g_twin[ok], atol=1e-11)
+    np.testing.assert_allclose(g_hip @ np.swapaxes(g_hip, 1, 2), np.tile(np.eye(d), (len(big), 1, 1)), atol=1e-9)
+    idx = np.flatnonzero(ok)[:3000]
+    ref = np.stack([so.round_to_special_orthogonal(m) for m in big[idx]])
+    np.testing.assert_allclose(g_hip[idx], ref, atol=1e-9)
+    with pytest.raises(ValueError, match="Could not round"):
+        round_to_special_orthogonal(np.full((3, d, d), np.nan), lib=hip)
