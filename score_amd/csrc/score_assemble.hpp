@@ -21,6 +21,7 @@
 #pragma once
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -108,6 +109,8 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
     // ---- P, q, c0.  The measurement loops run twice over the same code: a counting pass sizes every
     //      row, a filling pass writes (column, value) pairs into one flat array; rows are then sorted
     //      and merged in parallel (rows are short: a few (d+1)-blocks each). ----
+    PhaseTimer pt(std::getenv("SCORE_ASSEMBLE_VERBOSE") != nullptr);  // phase marks on stderr
+    pt.mark("assemble: layout");
     out.q.assign((size_t)n, 0.0);
     double c0 = 0.0;
     std::vector<int32_t> cnt((size_t)n + 1, 0);
@@ -227,12 +230,14 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
         }
     };
     measurements();  // counting pass
+    pt.mark("assemble: counting pass");
     for (int64_t i = 0; i < n; ++i) cnt[(size_t)i + 1] += cnt[(size_t)i];
     tcols.resize((size_t)cnt[(size_t)n]);
     tvals.resize((size_t)cnt[(size_t)n]);
     fill.assign(cnt.begin(), cnt.end() - 1);
     filling = true;
     measurements();  // filling pass
+    pt.mark("assemble: filling pass");
     out.c0 = c0;
     // sort + merge every row (stable: equal columns are summed in the order they were met)
     out.n = (int32_t)n;
@@ -242,18 +247,27 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
         std::vector<std::vector<int32_t>> pc(T);
         std::vector<std::vector<double>> pv(T);
         parallel_ranges(n, 8192, [&](int t, int64_t i0, int64_t i1) {
-            pc[t].reserve((size_t)(cnt[(size_t)i1] - cnt[(size_t)i0]));
-            pv[t].reserve((size_t)(cnt[(size_t)i1] - cnt[(size_t)i0]));
+            // thread-local buffers, handed over at the end: the headers of pc[t] / pv[t] share cache lines
+            // with their neighbours', and every push_back writes the header (measured: the 16-thread phase
+            // was slower than one thread)
+            std::vector<int32_t> lc;
+            std::vector<double> lv;
+            lc.reserve((size_t)(cnt[(size_t)i1] - cnt[(size_t)i0]));
+            lv.reserve((size_t)(cnt[(size_t)i1] - cnt[(size_t)i0]));
             std::vector<detail::Trip> L;
             for (int64_t i = i0; i < i1; ++i) {
                 L.clear();
                 for (int32_t k = cnt[(size_t)i]; k < cnt[(size_t)i + 1]; ++k) L.push_back(detail::Trip{tcols[(size_t)k], tvals[(size_t)k]});
-                // insertion sort: short, stable
-                for (size_t x = 1; x < L.size(); ++x) {
-                    const detail::Trip e = L[x];
-                    size_t y = x;
-                    while (y > 0 && L[y - 1].col > e.col) { L[y] = L[y - 1]; --y; }
-                    L[y] = e;
+                // stable order by column: insertion sort for the usual short rows
+                if (L.size() > 64) {
+                    std::stable_sort(L.begin(), L.end(), [](const detail::Trip& x, const detail::Trip& y) { return x.col < y.col; });
+                } else {
+                    for (size_t x = 1; x < L.size(); ++x) {
+                        const detail::Trip e = L[x];
+                        size_t y = x;
+                        while (y > 0 && L[y - 1].col > e.col) { L[y] = L[y - 1]; --y; }
+                        L[y] = e;
+                    }
                 }
                 int32_t c_ = 0;
                 size_t x = 0;
@@ -261,22 +275,29 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
                     const int32_t c = L[x].col;
                     double s_ = 0;
                     for (; x < L.size() && L[x].col == c; ++x) s_ += L[x].val;
-                    pc[t].push_back(c); pv[t].push_back(s_);
+                    lc.push_back(c); lv.push_back(s_);
                     ++c_;
                 }
                 out.P_ptr[(size_t)i + 1] = c_;
             }
+            pc[t] = std::move(lc);
+            pv[t] = std::move(lv);
         });
+        pt.mark("assemble:   rows (parallel)");
         for (int64_t i = 0; i < n; ++i) out.P_ptr[(size_t)i + 1] += out.P_ptr[(size_t)i];
         out.P_col.resize((size_t)out.P_ptr[(size_t)n]);
         out.P_val.resize((size_t)out.P_ptr[(size_t)n]);
-        for (int t = 0; t < T; ++t) {
-            if (pc[t].empty()) continue;
-            const int64_t i0 = n * t / T;  // the ranges of parallel_ranges are contiguous and ordered
-            std::memcpy(&out.P_col[(size_t)out.P_ptr[(size_t)i0]], pc[t].data(), pc[t].size() * sizeof(int32_t));
-            std::memcpy(&out.P_val[(size_t)out.P_ptr[(size_t)i0]], pv[t].data(), pv[t].size() * sizeof(double));
-        }
+        parallel_ranges(T, 1, [&](int, int64_t t0, int64_t t1) {
+            for (int64_t t = t0; t < t1; ++t) {
+                if (pc[(size_t)t].empty()) continue;
+                const int64_t i0 = n * t / T;  // the ranges of parallel_ranges are contiguous and ordered
+                std::memcpy(&out.P_col[(size_t)out.P_ptr[(size_t)i0]], pc[(size_t)t].data(), pc[(size_t)t].size() * sizeof(int32_t));
+                std::memcpy(&out.P_val[(size_t)out.P_ptr[(size_t)i0]], pv[(size_t)t].data(), pv[(size_t)t].size() * sizeof(double));
+            }
+        });
+        pt.mark("assemble:   concatenate");
     }
+    pt.mark("assemble: sort + merge rows");
     // ---- cones (:336-352): s = b - A x ----
     const int64_t m = Nr * D1;
     out.m = (int32_t)m;
@@ -307,6 +328,7 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
             }
         }
     }
+    pt.mark("assemble: cones");
 }
 
 }  // namespace score

@@ -27,7 +27,11 @@
 #include <stdexcept>
 #include <string>
 #include <thread>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 
+#include <pthread.h>
 #include <sched.h>
 #include <sys/resource.h>
 #include <vector>
@@ -55,18 +59,135 @@ inline int host_threads() {
     return n;
 }
 
+// A team of host threads that outlives the call: starting and joining 16 std::threads costs 0.3-0.4 ms
+// on the MI355X host, and score_create alone has ~17 parallel phases.  One parallel region at a time owns
+// the team (`gate`); a region that finds it busy (several handles being created from different host
+// threads) starts its own threads as before.  Part 0 runs on the calling thread; every part of a region
+// runs concurrently (TeamBarrier relies on that).  The team is leaked at exit on purpose and rebuilt
+// lazily in a forked child (its threads do not exist there).
+struct HostTeam {
+    std::mutex gate;
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> workers;
+    const std::function<void(int)>* job = nullptr;
+    int job_parts = 0;
+    uint64_t gen = 0;
+    int remaining = 0;
+    explicit HostTeam(int n_workers) {
+        for (int w = 0; w < n_workers; ++w) workers.emplace_back([this, w] { loop(w + 1); });
+    }
+    void loop(int part) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)>* j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return gen != seen; });
+                seen = gen;
+                if (part >= job_parts) continue;
+                j = job;
+            }
+            (*j)(part);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (--remaining == 0) cv_done.notify_one();
+            }
+        }
+    }
+    void run(int parts, const std::function<void(int)>& f) {  // caller holds `gate`; parts - 1 <= workers.size()
+        {
+            std::lock_guard<std::mutex> lk(m);
+            job = &f;
+            job_parts = parts;
+            remaining = parts - 1;
+            ++gen;
+        }
+        cv_work.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return remaining == 0; });
+        job = nullptr;
+    }
+};
+inline std::atomic<HostTeam*>& host_team_slot() {
+    static std::atomic<HostTeam*> slot{nullptr};
+    return slot;
+}
+inline HostTeam* host_team() {
+    static std::mutex make;
+    static std::once_flag fork_hook;
+    HostTeam* t = host_team_slot().load(std::memory_order_acquire);
+    if (t) return t;
+    std::lock_guard<std::mutex> lk(make);
+    t = host_team_slot().load(std::memory_order_acquire);
+    if (!t) {
+        std::call_once(fork_hook, [] { pthread_atfork(nullptr, nullptr, [] { host_team_slot().store(nullptr); }); });
+        t = new HostTeam(host_threads() - 1);
+        host_team_slot().store(t, std::memory_order_release);
+    }
+    return t;
+}
+
+inline bool& tl_in_parallel_region() {
+    static thread_local bool v = false;
+    return v;
+}
+
+// fn(part, begin, end) for part = 0..T-1 over the boundaries `bound` (T + 1 entries), all parts concurrently
+template <class F>
+inline void run_parts(const std::vector<int64_t>& bound, F&& fn) {
+    const int T = (int)bound.size() - 1;
+    if (T <= 1) { fn(0, bound[0], bound[(size_t)T]); return; }
+    std::vector<std::exception_ptr> err((size_t)T);
+    bool& in_region = tl_in_parallel_region();  // a part that opens a region of its own never touches the gate
+    const bool nested = in_region;
+    const std::function<void(int)> body = [&](int t) {
+        bool& mine = tl_in_parallel_region();  // (this thread's flag: parts run on other threads)
+        const bool was = mine;
+        mine = true;
+        try { fn(t, bound[(size_t)t], bound[(size_t)t + 1]); } catch (...) { err[(size_t)t] = std::current_exception(); }
+        mine = was;
+    };
+    HostTeam* team = (!nested && host_threads() > 1) ? host_team() : nullptr;
+    if (team && T - 1 <= (int)team->workers.size() && team->gate.try_lock()) {
+        std::lock_guard<std::mutex> own(team->gate, std::adopt_lock);
+        team->run(T, body);
+    } else {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back([&body, t] { body(t); });
+        body(0);
+        for (auto& x : th) x.join();
+    }
+    for (auto& e : err) if (e) std::rethrow_exception(e);
+}
+
 template <class F>
 inline void parallel_ranges(int64_t n, int64_t min_per_thread, F&& fn) {  // fn(part, begin, end)
-    int T = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
+    const int T = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
     if (T <= 1) { fn(0, (int64_t)0, n); return; }
-    std::vector<std::thread> th;
-    std::vector<std::exception_ptr> err(T);
-    for (int t = 0; t < T; ++t)
-        th.emplace_back([&, t] {
-            try { fn(t, n * t / T, n * (t + 1) / T); } catch (...) { err[t] = std::current_exception(); }
-        });
-    for (auto& x : th) x.join();
-    for (auto& e : err) if (e) std::rethrow_exception(e);
+    std::vector<int64_t> bound((size_t)T + 1);
+    for (int t = 0; t <= T; ++t) bound[(size_t)t] = n * t / T;
+    run_parts(bound, fn);
+}
+// The same with part boundaries chosen so that every part carries about the same total weight
+// (weight(i) >= 0: the work of index i).  Parts stay contiguous and ordered; a few very heavy indices
+// (a landmark seen by thousands of ranges) no longer land in one part.  fn(part, begin, end).
+template <class W, class F>
+inline void parallel_ranges_balanced(int64_t n, int64_t min_per_thread, W&& weight, F&& fn) {
+    const int T = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
+    if (T <= 1) { fn(0, (int64_t)0, n); return; }
+    std::vector<double> pre((size_t)n + 1, 0.0);
+    for (int64_t i = 0; i < n; ++i) pre[(size_t)i + 1] = pre[(size_t)i] + 1.0 + (double)weight(i);
+    std::vector<int64_t> bound((size_t)T + 1, n);
+    bound[0] = 0;
+    for (int t = 1; t < T; ++t) {
+        const double target = pre[(size_t)n] * t / T;
+        bound[(size_t)t] = std::max<int64_t>(bound[(size_t)t - 1],
+                                             std::lower_bound(pre.begin(), pre.end(), target) - pre.begin());
+        bound[(size_t)t] = std::min<int64_t>(bound[(size_t)t], n);
+    }
+    run_parts(bound, fn);
 }
 inline int parallel_parts(int64_t n, int64_t min_per_thread) {
     return (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
@@ -730,12 +851,18 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
             const double a = atv[t2];
             for (int k = S.A.ptr[r]; k < S.A.ptr[r + 1]; ++k) buf.push_back(Ent{S.A.col[k], 0.0, a * S.A.val[k]});
         }
-        // insertion sort: short, mostly ordered input; stable
-        for (size_t x = 1; x < buf.size(); ++x) {
-            const Ent e = buf[x];
-            size_t y = x;
-            while (y > 0 && buf[y - 1].j > e.j) { buf[y] = buf[y - 1]; --y; }
-            buf[y] = e;
+        // stable order by column.  Typical rows hold a few dozen mostly ordered entries (insertion sort);
+        // a landmark seen by thousands of ranges gathers thousands, alternating between its own column and
+        // the other endpoint's -- quadratic for an insertion sort (8 such rows were 7 of the 8 ms of this phase)
+        if (buf.size() > 64) {
+            std::stable_sort(buf.begin(), buf.end(), [](const Ent& x, const Ent& y) { return x.j < y.j; });
+        } else {
+            for (size_t x = 1; x < buf.size(); ++x) {
+                const Ent e = buf[x];
+                size_t y = x;
+                while (y > 0 && buf[y - 1].j > e.j) { buf[y] = buf[y - 1]; --y; }
+                buf[y] = e;
+            }
         }
     };
     const size_t k_row0 = H.K.ptr.size() - 1;  // == xo
@@ -744,8 +871,12 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
     // they never re-allocate), the row lengths are prefix-summed, the buffers copied into place
     struct KPart { std::vector<int32_t> col; std::vector<double> k0, k1; int64_t i0 = 0, i1 = 0; };
     std::vector<KPart> kparts(parallel_parts(n, 8192));
-    parallel_ranges(n, 8192, [&](int t, int64_t i0, int64_t i1) {
-        KPart& Q = kparts[t];
+    auto k_row_weight = [&](int64_t i) {  // entries gathered for row i; long rows cost n log n in the sort
+        const double g = (double)(S.P.ptr[i + 1] - S.P.ptr[i]) + 2.0 * (double)(atp[i + 1] - atp[i]);
+        return g > 64.0 ? 4.0 * g : g;
+    };
+    parallel_ranges_balanced(n, 8192, k_row_weight, [&](int t, int64_t i0, int64_t i1) {
+        KPart Q;  // thread-local (no cache line shared with a neighbour's vector headers), handed over at the end
         Q.i0 = i0; Q.i1 = i1;
         size_t ub = 0;
         for (int64_t i = i0; i < i1; ++i) {
@@ -769,6 +900,7 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
             }
             H.K.ptr[k_row0 + 1 + i] = cnt;
         }
+        kparts[t] = std::move(Q);
     });
     pt.mark("  append: K rows");
     for (int i = 0; i < n; ++i) H.K.ptr[k_row0 + 1 + i] += H.K.ptr[k_row0 + i];

@@ -88,8 +88,12 @@ inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = fals
         std::vector<double> pon, ccoef;
     };
     std::vector<Part> parts(parallel_parts(n, 8192));
-    parallel_ranges(n, 8192, [&](int t, int64_t i0, int64_t i1) {
-        Part& W = parts[t];
+    auto h_row_weight = [&](int64_t i) {  // contributions gathered for row i (sorted: long rows cost n log n)
+        const double g = (double)(H.g2_split[i] - H.G2.ptr[i]) + 2.0 * T * (double)(H.G2.ptr[i + 1] - H.g2_split[i]);
+        return g > 64.0 ? 4.0 * g : g;
+    };
+    parallel_ranges_balanced(n, 8192, h_row_weight, [&](int t, int64_t i0, int64_t i1) {
+        Part W;  // thread-local, handed over at the end (neighbouring parts' vector headers share cache lines)
         std::vector<Contrib> rowc;
         {   // reserve (virtual) room for the worst case so that the buffers never re-allocate
             size_t ub_ent = 0, ub_con = 0;
@@ -147,6 +151,7 @@ inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = fals
             }
             W.row_len.push_back(nent);
         }
+        parts[t] = std::move(W);
     });
     pt.mark("    polish: rows");
     Q.Hm.nrows = Q.Hm.ncols = n;
