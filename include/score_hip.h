@@ -244,6 +244,20 @@ void score_assembled_free(score_assembled* a);
 int  score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rotations,
                        int32_t* degenerate, int32_t device);
 
+/* Linear mode: the handle's chain-preconditioned PCG as a solver for symmetric positive definite
+ * systems K x = rhs -- the sparse solves inside the local refinement that follows SCORE (the reference's
+ * README.md:63-67 hands the SCORE estimate to GTSAM; score_amd/refine.py runs Gauss-Newton /
+ * Levenberg-Marquardt on SE(2) and solves its damped normal equations here).
+ * score_linear_create: `pattern` carries n, the CSR pattern of K in P_rowptr / P_col (columns strictly
+ * increasing, every row holds its diagonal), the chain hint (one chain per robot, one node per pose,
+ * block_size = 3 for SE(2)), and m = 0; values are not read.  score_linear_solve: `values` on that
+ * pattern; K is factored along the chains on the device (k_factor), PCG runs until
+ * r'M^-1 r <= rel_tol^2 r0'M^-1 r0 (tested on the device) or max_iters.  Returns 0 converged, 1 iteration
+ * cap, < 0 error; rel_residual (optional) = |rhs - K x|_2 / |rhs|_2.  Free with score_destroy.      */
+int  score_linear_create(const score_problem* pattern, const score_settings* s, score_handle** out);
+int  score_linear_solve(score_handle* h, const double* values, const double* rhs, double* x, double rel_tol,
+                        int32_t max_iters, int32_t* iters_used, double* rel_residual);
+
 const char* score_last_error(void);
 const char* score_backend(void);   /* "hip-gfx950" or "cpu-twin"             */
 

@@ -118,6 +118,36 @@ struct CpuBackend {
         rz = acc;
     }
 
+    // linear mode: the same PCG as the loop above (precond() + row_dot), run to r'M^-1 r <= tol^2 r0'M^-1 r0
+    bool linear_solve(const HostSystem& h, const double* rhs, double* x, double rel_tol, int max_iters, int* used_out) {
+        const int64_t n = h.n_tot;
+        std::vector<double> xs((size_t)n, 0.0);
+        for (int64_t i = 0; i < n; ++i) r[i] = rhs[i];
+        double rz = 0.0;
+        precond(0, rz);
+        for (int64_t i = 0; i < n; ++i) p[i] = z[i];
+        const double ref = rz * rel_tol * rel_tol;
+        int used = 0;
+        bool ok = !(rz > 0.0);
+        while (!ok) {
+            if (used > 0 && !(rz > ref)) { ok = true; break; }  // the test the device gate makes before a STEP
+            if (used >= max_iters) break;
+            double pw = 0.0;
+            for (int64_t i = 0; i < n; ++i) { w[i] = row_dot(h.K, i, p.data()); pw += p[i] * w[i]; }
+            const double a = pw > 0.0 ? rz / pw : 0.0;
+            for (int64_t i = 0; i < n; ++i) { xs[i] += a * p[i]; r[i] -= a * w[i]; }
+            ++used;
+            double rz_new = 0.0;
+            precond(0, rz_new);
+            const double beta = rz > 0.0 ? rz_new / rz : 0.0;
+            for (int64_t i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
+            rz = rz_new;
+        }
+        for (int64_t i = 0; i < n; ++i) x[i] = xs[i];
+        if (used_out) *used_out = used;
+        return ok;
+    }
+
     void iterate_problem(int pi, bool measure) {
         const HostSystem& h = *H;
         const int64_t x0 = h.xoff[pi], x1 = h.xoff[pi + 1];
@@ -359,6 +389,34 @@ int score_newton_steps(score_handle* h, int32_t iters, double* x, double* y, dou
     try {
         if (!h) throw std::runtime_error("null handle");
         return h->solver.newton_steps(iters, x, y, s, infos);
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_linear_create(const score_problem* pattern, const score_settings* s, score_handle** out) {
+    try {
+        if (!pattern || !out) throw std::runtime_error("null argument");
+        score::LinearPattern L;
+        score::make_linear_pattern(*pattern, s, L);
+        score_handle* h = nullptr;
+        if (score_create_batch(&L.prob, 1, &L.st, &h) != 0) return -1;
+        auto& S = h->solver;
+        if ((int64_t)S.H.K0.size() != (int64_t)pattern->P_rowptr[pattern->n]) {
+            score_destroy(h);
+            throw std::runtime_error("score_linear_create: internal pattern differs from the given one");
+        }
+        S.linear_mode = true;
+        S.linear_nnz = (int64_t)S.H.K0.size();
+        *out = h;
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_linear_solve(score_handle* h, const double* values, const double* rhs, double* x, double rel_tol,
+                       int32_t max_iters, int32_t* iters_used, double* rel_residual) {
+    try {
+        if (!h) throw std::runtime_error("null handle");
+        int used = 0;
+        const int rc = h->solver.linear_solve(values, rhs, x, rel_tol, max_iters, &used, rel_residual);
+        if (iters_used) *iters_used = used;
+        return rc;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 int score_time_kkt_apply(score_handle* h, int32_t reps, double* ms, double* bytes) {

@@ -236,6 +236,42 @@ struct Solver {
         return report(x, y, s, out, t0);
     }
 
+    // ---- linear mode (score_linear_create / score_linear_solve): the handle is a chain-preconditioned
+    //      PCG solver for SPD systems on the sparsity pattern it was created with ----
+    bool linear_mode = false;
+    int64_t linear_nnz = 0;
+    // K x = rhs with the values of K given on the creation pattern; returns 0 converged, 1 iteration cap
+    int linear_solve(const double* values, const double* rhs, double* x, double rel_tol, int max_iters,
+                     int* iters_used, double* rel_residual) {
+        if (!linear_mode) throw std::runtime_error("score_linear_solve: handle was not made by score_linear_create");
+        if (!values || !rhs || !x) throw std::runtime_error("score_linear_solve: null argument");
+        if (!(rel_tol > 0.0) || max_iters < 1) throw std::runtime_error("score_linear_solve: bad tolerance / iteration cap");
+        bool zero_rhs = true;
+        for (int64_t i = 0; i < H.n_tot && zero_rhs; ++i) zero_rhs = (rhs[i] == 0.0);
+        if (zero_rhs) {
+            std::fill(x, x + H.n_tot, 0.0);
+            if (iters_used) *iters_used = 0;
+            if (rel_residual) *rel_residual = 0.0;
+            return 0;
+        }
+        std::copy(values, values + linear_nnz, H.K0.begin());  // K1 = 0 (no constraints): K = K0
+        for (int p = 0; p < H.count; ++p) refresh_rho(H, p);     // (host factorisation: CPU twin only)
+        int used = 0;
+        const bool ok = be.linear_solve(H, rhs, x, rel_tol, max_iters, &used);
+        if (iters_used) *iters_used = used;
+        if (rel_residual) {  // |rhs - K x|_2 / |rhs|_2 on the host
+            double rr = 0.0, bb = 0.0;
+            for (int64_t i = 0; i < H.n_tot; ++i) {
+                double acc = rhs[i];
+                for (int k = H.K.ptr[i]; k < H.K.ptr[i + 1]; ++k) acc -= H.K0[k] * x[H.K.col[k]];
+                rr += acc * acc;
+                bb += rhs[i] * rhs[i];
+            }
+            *rel_residual = bb > 0.0 ? std::sqrt(rr / bb) : std::sqrt(rr);
+        }
+        return ok ? 0 : 1;
+    }
+
     int steps(int iters, double* x, double* y, double* s, score_info* out) {
         const double t0 = now_ms();
         int left = iters;
@@ -298,5 +334,45 @@ inline void default_settings(score_settings* s) {
     s->verbose = 0;
     s->chain_split = 0;
 }
+
+// score_linear_create: the pattern problem behind a linear-mode handle.  `pat` gives the sparsity pattern
+// of an SPD matrix (CSR, columns strictly increasing, every row holds its diagonal) and the chain hint;
+// the placeholder values are the identity, so that the handle is valid before the first solve.
+struct LinearPattern {
+    std::vector<double> val, q, none_d{0.0};
+    std::vector<int32_t> a_ptr{0}, none_i{0};
+    score_problem prob{};
+    score_settings st{};
+};
+inline void make_linear_pattern(const score_problem& pat, const score_settings* s, LinearPattern& L) {
+    if (pat.n <= 0 || !pat.P_rowptr || !pat.P_col) throw std::runtime_error("score_linear_create: empty pattern");
+    if (pat.m != 0 || pat.n_soc != 0 || pat.z != 0) throw std::runtime_error("score_linear_create: the pattern problem must have no constraints (m = 0)");
+    const int64_t nnz = pat.P_rowptr[pat.n];
+    L.val.assign((size_t)nnz, 0.0);
+    for (int i = 0; i < pat.n; ++i) {
+        bool diag = false;
+        for (int k = pat.P_rowptr[i]; k < pat.P_rowptr[i + 1]; ++k) {
+            const int j = pat.P_col[k];
+            if (j < 0 || j >= pat.n) throw std::runtime_error("score_linear_create: column out of range");
+            if (k > pat.P_rowptr[i] && pat.P_col[k - 1] >= j) throw std::runtime_error("score_linear_create: columns of a row must be strictly increasing");
+            if (j == i) { diag = true; L.val[(size_t)k] = 1.0; }
+        }
+        if (!diag) throw std::runtime_error("score_linear_create: every row must hold its diagonal entry");
+    }
+    L.q.assign((size_t)pat.n, 0.0);
+    L.prob = pat;
+    L.prob.P_val = L.val.data();
+    L.prob.q = L.q.data();
+    L.prob.c0 = 0.0;
+    L.prob.m = 0; L.prob.z = 0; L.prob.n_soc = 0;
+    L.prob.A_rowptr = L.a_ptr.data(); L.prob.A_col = L.none_i.data(); L.prob.A_val = L.none_d.data();
+    L.prob.b = L.none_d.data(); L.prob.soc_dims = L.none_i.data();
+    if (s) L.st = *s; else default_settings(&L.st);
+    L.st.scale_iters = 0;  // the caller's values are used as they are
+    L.st.polish = 0;
+    L.st.adaptive_rho = 0;
+    L.st.use_graph = 0;
+}
+
 
 }  // namespace score

@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "score_driver.hpp"
+#include <future>
 #include "score_assemble.hpp"
 #include "score_round.hpp"
 #include "score_kernels.hpp"
@@ -305,6 +306,7 @@ struct HipBackend {
     DevBuf<double> pw_part, rz_part0, rz_part1, rz_meas0, rz_meas1, pres_part, dres_part;
     // ---- semismooth-Newton polish (score_polish*.hpp) ----
     PolishData Q;
+    std::future<void> polish_build;  // build_polish runs beside the uploads of init()
     CsrBufs Hm;
     DevBuf<double> q_Pon, q_ccoef, q_Bbuf, q_fpart, q_X0, q_X1, q_g, q_delta, q_fac, q_dinv, q_work, q_dummy, q_gd, q_pw;
     DevBuf<double> q_aabs, q_ck, q_theta, q_xstar;
@@ -409,6 +411,13 @@ struct HipBackend {
         pt.mark("device + stream");
         if (h.bs != 0 && h.bs != 3 && h.bs != 4 && h.bs != 1 && h.bs != 2)
             throw std::runtime_error("unsupported block size");
+        struct JoinPolish {  // an exception below must not leave the builder running against a dying handle
+            std::future<void>& f;
+            ~JoinPolish() { if (f.valid()) f.wait(); }
+        } join_polish{polish_build};
+        // the Newton matrix pattern and its contribution lists only read the finished host system:
+        // built on another thread while this one uploads (4.3 ms beside 2.4 ms of uploads / allocations)
+        if (st.polish) polish_build = std::async(std::launch::async, [this, &h] { build_polish(h, Q, st.verbose != 0); });
         K.upload(h.K, h.rbK);
         G1.upload(h.G1, h.rbG1);
         G2.upload(h.G2, h.rbG2, &h.g2_split);
@@ -1105,13 +1114,78 @@ struct HipBackend {
         return sz;
     }
 
+    // ---- linear mode: K x = rhs by the chain-preconditioned PCG of the ADMM loop (k_prec_pre / k_prec +
+    //      k_spmv), K factored on the device (k_factor), termination on the device (pcg_gate):
+    //      r'M^-1 r <= rel_tol^2 r0'M^-1 r0.  The host looks at one flag per chunk of iterations. ----
+    DevBuf<double> lin_rhs, lin_tol2, lin_ref;
+    DevBuf<int32_t> lin_flag;  // [gate flag | STEPs executed] per problem
+    bool linear_solve(const HostSystem& h, const double* rhs, double* x, double rel_tol, int max_iters, int* used_out) {
+        if (h.m_tot != 0 || h.count != 1) throw std::runtime_error("linear mode: one unconstrained pattern per handle");
+        const size_t n = (size_t)h.n_tot;
+        if (!lin_flag.d) {
+            lin_rhs.alloc(n); lin_tol2.alloc(1); lin_ref.alloc(1); lin_flag.alloc(2);
+        }
+        // values -> K0 (K1 = 0), K = K0 and its chain factors / Jacobi inverses on the device
+        HIP_CHECK(hipMemcpyAsync(K0d.d, h.K0.data(), h.K0.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        derive_rho_data(false);
+        const double tol2 = rel_tol * rel_tol;
+        HIP_CHECK(hipMemcpyAsync(lin_rhs.d, rhs, n * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(lin_tol2.d, &tol2, sizeof(double), hipMemcpyHostToDevice, stream));
+        HIP_CHECK(hipMemsetAsync(lin_flag.d, 0, 2 * sizeof(int32_t), stream));
+        PrecArgs pa{};
+        pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = fac.d;
+        pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = lin_flag.d;
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d;
+        pa.r = r.d; pa.r_in = lin_rhs.d; pa.z = z.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d; pa.pw_part = pw_part.d;
+        pa.gate_used = lin_flag.d + 1;
+        double* rz_cur = rz_part0.d;
+        double* p_cur = p.d;
+        double* p_oth = p2.d;
+        pa.p = p_cur; pa.rz_in = nullptr; pa.rz_out = rz_cur;
+        launch_prec<PREC_INIT>(pa);  // z = M^-1 rhs, p = z
+        {
+            SpmvArgs a = spmv_args(K, p_cur);
+            a.p = p_cur; a.done = lin_flag.d;
+            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
+        }
+        pa.gate_flag = lin_flag.d; pa.gate_tol2 = lin_tol2.d; pa.gate_ref = lin_ref.d;
+        int32_t state[2] = {0, 0};
+        int queued = 0;
+        bool first = true;
+        while (!state[0] && queued < max_iters) {
+            const int chunk = std::min(max_iters - queued, queued == 0 ? 16 : 32);
+            for (int j = 0; j < chunk; ++j) {
+                double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
+                pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_nxt;
+                pa.gate_first = first ? 1 : 0;
+                pa.r_in = first ? lin_rhs.d : r.d;
+                pa.xt_zero = first ? 1 : 0;
+                launch_prec<PREC_STEP>(pa);  // x += a p ; r -= a w ; z = M^-1 r   (or the gate fires)
+                SpmvArgs a = spmv_args(K, p_cur);
+                a.p = p_cur; a.z = z.d; a.p_out = p_oth; a.rz_new = rz_nxt; a.rz_old = rz_cur; a.done = lin_flag.d;
+                hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
+                std::swap(p_cur, p_oth);
+                rz_cur = rz_nxt;
+                first = false;
+            }
+            queued += chunk;
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(state, lin_flag.d, sizeof(state), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+        }
+        HIP_CHECK(hipMemcpyAsync(x, xtu.d, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (used_out) *used_out = state[1];
+        return state[0] != 0;
+    }
+
     void init_polish(const HostSystem& h) {
         PhaseTimer pt(st.verbose != 0);
         if (const char* e = std::getenv("SCORE_NEWTON_ETA_MAX")) newton_eta_max = std::atof(e);
         if (const char* e = std::getenv("SCORE_NEWTON_ETA_COEF")) newton_eta_coef = std::atof(e);
         if (const char* e = std::getenv("SCORE_NEWTON_ETA_POW")) newton_eta_pow = std::atof(e);
-        build_polish(h, Q, st.verbose != 0);
-        pt.mark("  polish: host structures");
+        polish_build.get();  // (rethrows what build_polish threw)
+        pt.mark("  polish: host structures (wait)");
         if (!Q.available) return;
         Hm.upload(Q.Hm, Q.rbH, nullptr, false);
         q_Pon.upload(Q.Pon); q_ccoef.upload(Q.ccoef); q_cptr.upload(Q.cptr); q_ccone.upload(Q.ccone); q_cab.upload(Q.cab);
@@ -1679,6 +1753,35 @@ int score_newton_steps(score_handle* h, int32_t iters, double* x, double* y, dou
         if (!h) throw std::runtime_error("null handle");
         DeviceGuard guard(h->solver.st.device);
         return h->solver.newton_steps(iters, x, y, s, infos);
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_linear_create(const score_problem* pattern, const score_settings* s, score_handle** out) {
+    try {
+        if (!pattern || !out) throw std::runtime_error("null argument");
+        score::LinearPattern L;
+        score::make_linear_pattern(*pattern, s, L);
+        score_handle* h = nullptr;
+        if (score_create_batch(&L.prob, 1, &L.st, &h) != 0) return -1;
+        auto& S = h->solver;
+        if ((int64_t)S.H.K0.size() != (int64_t)pattern->P_rowptr[pattern->n]) {
+            score_destroy(h);
+            throw std::runtime_error("score_linear_create: internal pattern differs from the given one");
+        }
+        S.linear_mode = true;
+        S.linear_nnz = (int64_t)S.H.K0.size();
+        *out = h;
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_linear_solve(score_handle* h, const double* values, const double* rhs, double* x, double rel_tol,
+                       int32_t max_iters, int32_t* iters_used, double* rel_residual) {
+    try {
+        if (!h) throw std::runtime_error("null handle");
+        DeviceGuard guard(h->solver.st.device);
+        int used = 0;
+        const int rc = h->solver.linear_solve(values, rhs, x, rel_tol, max_iters, &used, rel_residual);
+        if (iters_used) *iters_used = used;
+        return rc;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 int score_time_kkt_apply(score_handle* h, int32_t reps, double* ms, double* bytes) {

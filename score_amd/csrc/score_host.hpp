@@ -1130,9 +1130,13 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     }
     H.cone_block_first.push_back((int32_t)H.cone_row.size());
     H.K.val.assign(H.K.col.size(), 0.0);
-    H.rbK = make_rowblocks(H.K, H.xoff);
-    H.rbG1 = make_rowblocks(H.G1, H.xoff);
-    H.rbG2 = make_rowblocks(H.G2, H.xoff);
+    parallel_ranges(3, 1, [&](int, int64_t k0, int64_t k1) {  // three independent serial scans
+        for (int64_t k = k0; k < k1; ++k) {
+            if (k == 0) H.rbK = make_rowblocks(H.K, H.xoff);
+            else if (k == 1) H.rbG1 = make_rowblocks(H.G1, H.xoff);
+            else H.rbG2 = make_rowblocks(H.G2, H.xoff);
+        }
+    });
     pt.mark("row blocks");
 
     // ---- preconditioner layout ----

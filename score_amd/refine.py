@@ -10,10 +10,13 @@ gurobi_utils.py:504-526; ranges :449-501; landmark priors :433-446):
     F(theta, t, l) = sum_rel  kappa |t_j - t_i - R(theta_i) t_ij|^2 + tau |R(theta_j) - R(theta_i) R_ij|_F^2
                    + sum_rng  w (|p_a - p_b| - d_ab)^2  +  sum_prior w |l - l0|^2
 
-Host-side (NumPy / SciPy sparse): the Jacobian is assembled vectorised, the normal equations are solved
-by sparse Cholesky-like LU.  The GPU path of this round stops at the SCORE estimate; the normal
-equations here have the structure of the polish's Newton systems (block-tridiagonal pose chains + range
-couplings), so they are the next candidate for the chain-preconditioned PCG on the device.
+The residuals and the sparse Jacobian are assembled vectorised on the host (NumPy / SciPy); the damped
+normal equations (J'J + lambda I) step = -J'r -- block-tridiagonal 3 x 3 pose chains along every
+robot's odometry, plus loop-closure and range couplings -- are solved on the GPU by the solver's
+chain-preconditioned PCG through the C ABI (``score_linear_create`` / ``score_linear_solve``:
+``k_factor`` factors the chains of J'J, ``k_prec_pre`` + ``k_spmv`` run the PCG, termination on the
+device).  ``linear_solver="scipy"`` keeps the sparse-LU solve on the host: the reference the tests
+compare the device path with, not a fallback (the default path raises without the HIP library).
 """
 from __future__ import annotations
 
@@ -159,10 +162,71 @@ def _initial_point(prob: _Problem, results) -> np.ndarray:
     return prob.pack(th, t, lm)
 
 
-def refine_estimate(data, results, max_iters: int = 50, tol: float = 1e-10, verbose: bool = False):
+class _DeviceNormalEquations:
+    """(J'J + lambda I) step = rhs on the GPU.  The pattern of J'J is fixed by the graph: it is taken once
+    from the all-ones Jacobian (no cancellation can remove an entry), a linear-mode handle is created on it
+    with one chain per robot (node = pose: theta, x, y), and every solve maps the current values onto it."""
+
+    def __init__(self, prob: _Problem, J: sp.csr_matrix, lib_path: Optional[str], settings: Optional[dict]):
+        from .solver import LinearSolver
+
+        ones = J.copy()
+        ones.data[:] = 1.0
+        pat = (ones.T @ ones + sp.identity(prob.n, format="csr")).tocsr()
+        pat.sort_indices()
+        self.n = prob.n
+        self.indptr, self.indices = pat.indptr.astype(np.int64), pat.indices.astype(np.int64)
+        rows = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(self.indptr))
+        self.keys = rows * self.n + self.indices  # ascending: CSR with sorted indices
+        self.diag = np.searchsorted(self.keys, np.arange(self.n, dtype=np.int64) * (self.n + 1))
+        lens = np.asarray(prob.a["chain_len"], dtype=np.int64).copy()
+        lens[0] -= 1  # the pinned pose is not an unknown
+        lens = lens[lens > 0]
+        chain_ptr = np.concatenate([[0], np.cumsum(lens)])
+        node_first_col = 3 * np.arange(prob.Np - 1, dtype=np.int64)
+        self.solver = LinearSolver(pat, chain_ptr, node_first_col, 3, settings=settings, lib_path=lib_path)
+        self._cache = None  # (indptr, indices) of the last J'J and its positions in the pattern
+        self.pcg_iters = 0
+        self.solves = 0
+
+    def values(self, H: sp.csr_matrix) -> np.ndarray:
+        c = self._cache
+        if c is None or c[0].shape != H.indptr.shape or c[1].shape != H.indices.shape or \
+                not (np.array_equal(c[0], H.indptr) and np.array_equal(c[1], H.indices)):
+            rows = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(H.indptr))
+            pos = np.searchsorted(self.keys, rows * self.n + H.indices.astype(np.int64))
+            if pos.size and (pos.max() >= self.keys.size or not np.array_equal(self.keys[pos], rows * self.n + H.indices)):
+                raise RuntimeError("refine: J'J left its sparsity pattern")
+            self._cache = c = (H.indptr.copy(), H.indices.copy(), pos)
+        v = np.zeros(self.keys.size)
+        if H.has_canonical_format:
+            v[c[2]] = H.data
+        else:
+            np.add.at(v, c[2], H.data)  # duplicates summed
+        return v
+
+    def solve(self, H: sp.csr_matrix, lam: float, rhs: np.ndarray, rel_tol: float) -> np.ndarray:
+        v = self.values(H)
+        v[self.diag] += lam
+        x, info = self.solver.solve(v, rhs, rel_tol=rel_tol, max_iters=4000)
+        self.pcg_iters += info["iters"]
+        self.solves += 1
+        if not np.all(np.isfinite(x)):
+            raise RuntimeError("refine: the device PCG returned a non-finite step")
+        return x
+
+    def close(self) -> None:
+        self.solver.close()
+
+
+def refine_estimate(data, results, max_iters: int = 50, tol: float = 1e-10, verbose: bool = False,
+                    linear_solver: str = "device", lib_path: Optional[str] = None, solver_settings: Optional[dict] = None,
+                    pcg_rel_tol: float = 1e-9):
     """Refine a SCORE estimate (``SolverResults``) to a local minimiser of the RA-SLAM maximum-likelihood
-    cost.  Returns ``(refined SolverResults, info)``; ``info`` holds the cost before / after, iterations and
-    the final gradient norm."""
+    cost.  Returns ``(refined SolverResults, info)``; ``info`` holds the cost before / after, iterations,
+    the final gradient norm and (device path) the PCG iterations spent in the linear solves."""
+    if linear_solver not in ("device", "scipy"):
+        raise ValueError("linear_solver must be 'device' or 'scipy'")
     prob = _Problem(data)
     u = _initial_point(prob, results)
     res, J = prob.residuals(u, jac=True)
@@ -171,16 +235,42 @@ def refine_estimate(data, results, max_iters: int = 50, tol: float = 1e-10, verb
     lam = 1e-6
     it = 0
     gnorm = np.inf
+    dev = _DeviceNormalEquations(prob, J, lib_path, solver_settings) if (linear_solver == "device" and prob.n > 0) else None
+    try:
+        u, f, it, gnorm = _lm_loop(prob, u, res, J, f, lam, max_iters, tol, verbose, dev, pcg_rel_tol)
+    finally:
+        pcg = (dev.pcg_iters, dev.solves) if dev else (0, 0)
+        if dev:
+            dev.close()
+    th, t, lm = prob.split(u)
+    c, s = np.cos(th), np.sin(th)
+    T = np.tile(np.eye(3), (prob.Np, 1, 1))
+    T[:, 0, 0] = c; T[:, 0, 1] = -s; T[:, 1, 0] = s; T[:, 1, 1] = c
+    T[:, :2, 2] = t
+    values = compat.VariableValues(2, compat.ArrayDict(prob.a["pose_names"], T), compat.ArrayDict(prob.a["landmark_names"], lm.copy()), None)
+    out = compat.SolverResults(variables=values, total_time=results.total_time, solved=True,
+                               pose_chain_names=results.pose_chain_names, solver_cost=f, info=dict(results.info or {}))
+    info = {"cost_initial": f0, "cost_final": f, "iterations": it, "grad_inf": gnorm, "linear_solver": linear_solver,
+            "pcg_iters": pcg[0], "linear_solves": pcg[1]}
+    return out, info
+
+
+def _lm_loop(prob, u, res, J, f, lam, max_iters, tol, verbose, dev, pcg_rel_tol):
+    it = 0
+    gnorm = np.inf
     for it in range(1, max_iters + 1):
         g = J.T @ res
         gnorm = float(np.abs(g).max()) if g.size else 0.0
         if gnorm <= tol * max(1.0, f):
             break
-        H = (J.T @ J).tocsc()
+        H = (J.T @ J).tocsr() if dev else (J.T @ J).tocsc()
         accepted = False
         for _ in range(12):
             try:
-                step = spla.splu((H + lam * sp.identity(prob.n, format="csc")).tocsc()).solve(-g)
+                if dev:
+                    step = dev.solve(H, lam, -g, pcg_rel_tol)
+                else:
+                    step = spla.splu((H + lam * sp.identity(prob.n, format="csc")).tocsc()).solve(-g)
             except RuntimeError:
                 lam *= 10.0
                 continue
@@ -200,13 +290,4 @@ def refine_estimate(data, results, max_iters: int = 50, tol: float = 1e-10, verb
             print(f"  refine it {it}: cost {f:.9g} |g| {gnorm:.3e} lambda {lam:.1e}")
         if dec <= 1e-14 * max(1.0, f):
             break
-    th, t, lm = prob.split(u)
-    c, s = np.cos(th), np.sin(th)
-    T = np.tile(np.eye(3), (prob.Np, 1, 1))
-    T[:, 0, 0] = c; T[:, 0, 1] = -s; T[:, 1, 0] = s; T[:, 1, 1] = c
-    T[:, :2, 2] = t
-    values = compat.VariableValues(2, compat.ArrayDict(prob.a["pose_names"], T), compat.ArrayDict(prob.a["landmark_names"], lm.copy()), None)
-    out = compat.SolverResults(variables=values, total_time=results.total_time, solved=True,
-                               pose_chain_names=results.pose_chain_names, solver_cost=f, info=dict(results.info or {}))
-    info = {"cost_initial": f0, "cost_final": f, "iterations": it, "grad_inf": gnorm}
-    return out, info
+    return u, f, it, gnorm

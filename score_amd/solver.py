@@ -68,7 +68,7 @@ STATUS_NAMES = {0: "unsolved", 1: "solved", 2: "max_iters", 3: "numerical"}
 ABI_SYMBOLS = [
     "score_assemble", "score_assembled_view", "score_assembled_free", "score_round_to_so",
     "score_default_settings", "score_create", "score_create_batch", "score_dims", "score_solve",
-    "score_reset", "score_solve_steps", "score_newton_steps", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
+    "score_reset", "score_solve_steps", "score_newton_steps", "score_linear_create", "score_linear_solve", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
     "score_last_error", "score_backend",
 ]
 
@@ -98,6 +98,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.score_debug_get.restype = C.c_int64
     lib.score_destroy.argtypes = [C.c_void_p]
     lib.score_destroy.restype = None
+    lib.score_linear_create.argtypes = [C.POINTER(ScoreProblem), C.POINTER(ScoreSettings), C.POINTER(C.c_void_p)]
+    lib.score_linear_solve.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, C.c_double, C.c_int32, C.POINTER(C.c_int32), _f64p]
     lib.score_round_to_so.argtypes = [C.c_int32, C.c_int64, _f64p, _f64p, C.POINTER(C.c_int32), C.c_int32]
     lib.score_round_to_so.restype = C.c_int
     lib.score_last_error.restype = C.c_char_p
@@ -267,6 +269,74 @@ class ConicSolver:
         out = np.empty(sz)
         self.lib.score_debug_get(self._h, name.encode(), _ptr(out, _f64p), sz)
         return out
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self.lib.score_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class LinearSolver:
+    """Chain-preconditioned PCG on the GPU for SPD systems on a fixed sparsity pattern
+    (``score_linear_create`` / ``score_linear_solve``): the linear solves of the local refinement that
+    follows SCORE (score_amd/refine.py).  ``pattern``: scipy CSR with sorted indices and a full diagonal;
+    ``chain_ptr`` / ``node_first_col`` / ``block_size``: the block-tridiagonal hint (one chain per robot,
+    one node per pose)."""
+
+    def __init__(self, pattern, chain_ptr, node_first_col, block_size: int, settings: Optional[dict] = None,
+                 lib_path: Optional[str] = None):
+        self.lib = load_library(lib_path)
+        P = pattern.tocsr()
+        if not P.has_sorted_indices:
+            P = P.sorted_indices()
+        self.n = int(P.shape[0])
+        self.nnz = int(P.nnz)
+        self.indptr, self.indices = _i32(P.indptr), _i32(P.indices)
+        st = ScoreSettings()
+        self.lib.score_default_settings(C.byref(st))
+        for k, v in (settings or {}).items():
+            if not hasattr(st, k):
+                raise ValueError(f"unknown solver setting {k}")
+            setattr(st, k, v)
+        self.settings = st
+        cp, nc = _i32(chain_ptr), _i32(node_first_col)
+        zero_i, zero_d = np.zeros(1, np.int32), np.zeros(1)
+        p = ScoreProblem()
+        p.n, p.m = self.n, 0
+        p.P_rowptr, p.P_col, p.P_val = _ptr(self.indptr, _i32p), _ptr(self.indices, _i32p), None
+        p.q, p.c0 = None, 0.0
+        p.A_rowptr, p.A_col, p.A_val, p.b = _ptr(zero_i, _i32p), _ptr(zero_i, _i32p), _ptr(zero_d, _f64p), _ptr(zero_d, _f64p)
+        p.z, p.n_soc, p.soc_dims = 0, 0, _ptr(zero_i, _i32p)
+        p.block_size, p.n_chains = int(block_size), int(len(cp) - 1)
+        p.chain_ptr, p.node_first_col = _ptr(cp, _i32p), _ptr(nc, _i32p)
+        self._h = C.c_void_p()
+        rc = self.lib.score_linear_create(C.byref(p), C.byref(st), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise RuntimeError(f"score_linear_create failed: {self.lib.score_last_error().decode()}")
+
+    def solve(self, values, rhs, rel_tol: float = 1e-8, max_iters: int = 500, residual: bool = False):
+        """x with K x = rhs; returns (x, info) with info = {converged, iters[, rel_residual]}."""
+        v, b = _f64(values), _f64(rhs)
+        if v.shape != (self.nnz,) or b.shape != (self.n,):
+            raise ValueError("values / rhs do not match the pattern")
+        x = np.empty(self.n)
+        used = C.c_int32(0)
+        rr = C.c_double(0.0)
+        rc = self.lib.score_linear_solve(self._h, _ptr(v, _f64p), _ptr(b, _f64p), _ptr(x, _f64p), float(rel_tol), int(max_iters),
+                                         C.byref(used), C.byref(rr) if residual else None)
+        if rc < 0:
+            raise RuntimeError(f"score_linear_solve failed: {self.lib.score_last_error().decode()}")
+        info = {"converged": rc == 0, "iters": int(used.value)}
+        if residual:
+            info["rel_residual"] = float(rr.value)
+        return x, info
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -1,6 +1,8 @@
-"""Local refinement after SCORE (reference README.md:63-67), on the CPU: Gauss-Newton /
-Levenberg-Marquardt on SE(2) from the SCORE estimate, checked against SciPy's least_squares run on the
-same residual function (an independent trust-region solver with a finite-difference Jacobian check)."""
+"""Local refinement after SCORE (reference README.md:63-67): Gauss-Newton /
+Levenberg-Marquardt on SE(2) from the SCORE estimate, its normal equations solved through the C ABI's
+linear mode (here: the CPU twin's implementation of it; the HIP one in tests/test_gpu_parity.py), checked
+against SciPy's least_squares run on the same residual function (an independent trust-region solver with a
+finite-difference Jacobian check) and against the sparse-LU variant of the same loop."""
 import numpy as np
 import pytest
 from scipy.optimize import least_squares
@@ -32,7 +34,12 @@ def test_refinement_reaches_the_least_squares_optimum(twin_lib):
     fg = _graph()
     res = solve_score(fg, "SOCP", lib_path=twin_lib)
     assert res.solved
-    refined, info = refine_estimate(fg, res)
+    refined, info = refine_estimate(fg, res, lib_path=twin_lib)  # normal equations through score_linear_solve
+    assert info["linear_solver"] == "device" and info["linear_solves"] >= 1 and info["pcg_iters"] >= 1
+    by_lu, info_lu = refine_estimate(fg, res, linear_solver="scipy")
+    assert info["cost_final"] == pytest.approx(info_lu["cost_final"], rel=1e-9)
+    for nm in refined.poses:
+        np.testing.assert_allclose(refined.poses[nm], by_lu.poses[nm], atol=1e-5)
     assert info["cost_final"] <= info["cost_initial"] + 1e-12 and info["grad_inf"] < 1e-5 * max(1.0, info["cost_final"])
     prob = _Problem(fg)
     u0 = _initial_point(prob, res)
@@ -57,3 +64,47 @@ def test_refinement_reaches_the_least_squares_optimum(twin_lib):
         err = [np.linalg.norm(r.poses[p.name][:2, 2] - np.asarray(p.true_position)) for chain in fg.pose_variables for p in chain]
         return float(np.sqrt(np.mean(np.square(err))))
     assert rmse(refined) <= rmse(res) + 1e-9
+
+
+def test_linear_mode_solves_the_normal_equations(twin_lib):
+    """score_linear_create / score_linear_solve on the damped normal equations of a graph with loop closures
+    and ranges: the solution equals SciPy's sparse direct solve; new values on the same handle; errors."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    from score_amd.refine import _DeviceNormalEquations
+    from score_amd.solver import LinearSolver
+
+    fg = make_manhattan(n_robots=3, n_poses=40, n_beacons=2, seed=5, p_range=0.4, n_loop_closures=4)
+    res = solve_score(fg, "SOCP", lib_path=twin_lib)
+    prob = _Problem(fg)
+    u = _initial_point(prob, res)
+    r, J = prob.residuals(u, jac=True)
+    dev = _DeviceNormalEquations(prob, J, twin_lib, None)
+    try:
+        H = (J.T @ J).tocsr()
+        g = J.T @ r
+        for lam in (1e-6, 1e-2):
+            step = dev.solve(H, lam, -g, 1e-11)
+            ref = spla.spsolve((H + lam * sp.identity(prob.n)).tocsc(), -g)
+            np.testing.assert_allclose(step, ref, atol=1e-8 * max(1.0, np.abs(ref).max()))
+        assert dev.pcg_iters > 0
+        v = dev.values(H)
+        v[dev.diag] += 1e-3
+        x, info = dev.solver.solve(v, np.zeros(prob.n))
+        assert info["converged"] and info["iters"] == 0 and not np.any(x)
+        x, info = dev.solver.solve(v, -g, rel_tol=1e-10, max_iters=3, residual=True)  # iteration cap is reported
+        assert not info["converged"] and info["iters"] == 3 and info["rel_residual"] > 1e-10
+        with pytest.raises(ValueError):
+            dev.solver.solve(v[:-1], -g)
+    finally:
+        dev.close()
+    # pattern checks of score_linear_create
+    n = 6
+    good = sp.identity(n, format="csr")
+    with pytest.raises(RuntimeError, match="diagonal"):
+        LinearSolver(sp.csr_matrix(([1.0], ([0], [1])), shape=(n, n)), [0, 2], [0, 3], 3, lib_path=twin_lib)
+    ls = LinearSolver(good, [0, 2], [0, 3], 3, lib_path=twin_lib)
+    x, info = ls.solve(np.full(n, 4.0), np.arange(1.0, n + 1))
+    np.testing.assert_allclose(x, np.arange(1.0, n + 1) / 4.0, rtol=1e-12)
+    ls.close()
