@@ -258,6 +258,23 @@ int  score_linear_create(const score_problem* pattern, const score_settings* s, 
 int  score_linear_solve(score_handle* h, const double* values, const double* rhs, double* x, double rel_tol,
                         int32_t max_iters, int32_t* iters_used, double* rel_residual);
 
+/* Local refinement after SCORE, whole loop behind the ABI: Gauss-Newton / Levenberg-Marquardt on SE(2)
+ * from a given estimate (README.md:63-67 of the reference: "SCORE's estimate initialises a local solver").
+ * The graph is the score_graph of score_assemble (dim = 2; `relaxation` is not read).  Per-measurement
+ * Jacobian blocks, J'J / J'r on a fixed pattern and trial points are device kernels; the damped normal
+ * equations run in linear mode (above).  poses: n_poses x (theta, x, y) in chain order, pose 0 stays
+ * fixed; landmarks: n_landmarks x (x, y).  tol: stop when |J'r|_inf <= tol * max(1, cost).            */
+typedef struct score_refine score_refine;
+typedef struct score_refine_info {
+    double  cost_initial, cost_final, grad_inf;
+    int32_t iterations, linear_solves, pcg_iters;
+    double  setup_ms, solve_ms;
+} score_refine_info;
+int  score_refine_create(const score_graph* g, const score_settings* s, score_refine** out);
+int  score_refine_run(score_refine* r, const double* poses_in, const double* landmarks_in, int32_t max_iters,
+                      double tol, double* poses_out, double* landmarks_out, score_refine_info* info);
+void score_refine_destroy(score_refine* r);
+
 const char* score_last_error(void);
 const char* score_backend(void);   /* "hip-gfx950" or "cpu-twin"             */
 

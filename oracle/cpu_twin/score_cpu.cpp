@@ -23,6 +23,7 @@
 
 #include "../../score_amd/csrc/score_driver.hpp"
 #include "../../score_amd/csrc/score_assemble.hpp"
+#include "../../score_amd/csrc/score_gn.hpp"
 #include "../../score_amd/csrc/score_round.hpp"
 
 namespace {
@@ -331,6 +332,72 @@ struct score_handle {
     score::Solver<CpuBackend> solver;
 };
 
+// Local refinement (score_gn.hpp) with every kernel restated as a loop; the damped normal equations go
+// through this library's linear mode.
+struct score_refine {
+    score::GnProblem P;
+    score_handle* lin = nullptr;
+    double setup_ms = 0;
+    std::vector<double> u, ut, step, hblk, gblk, rhs, vals;
+    ~score_refine();
+    void create(const score_graph& g, const score_settings* s);
+    double eval_at(const std::vector<double>& w, bool with_blocks) {
+        const double* uu = w.data();
+        double f = 0.0;
+        for (int64_t m = 0; m < P.n_rel(); ++m) {
+            double thi, xi, yi, thj, xj, yj;
+            score::gn_pose(uu, P.pin, P.rel_i[m], thi, xi, yi);
+            score::gn_pose(uu, P.pin, P.rel_j[m], thj, xj, yj);
+            f += score::gn_rel_block(thi, xi, yi, thj, xj, yj, &P.rel_t[2 * m], &P.rel_R[4 * m], P.rel_kappa[m], P.rel_tau[m],
+                                     with_blocks ? &hblk[36 * m] : nullptr, with_blocks ? &gblk[6 * m] : nullptr);
+        }
+        const int64_t hb = 36 * P.n_rel(), gb = 6 * P.n_rel();
+        for (int64_t r = 0; r < P.n_rng(); ++r) {
+            double xa, ya, xb, yb;
+            score::gn_point(uu, P.pin, P.Np, P.rng_a[r], xa, ya);
+            score::gn_point(uu, P.pin, P.Np, P.rng_b[r], xb, yb);
+            f += score::gn_range_block(xa, ya, xb, yb, P.rng_dist[r], P.rng_prec[r], with_blocks ? &hblk[hb + 16 * r] : nullptr,
+                                       with_blocks ? &gblk[gb + 4 * r] : nullptr);
+        }
+        const int64_t hp = hb + 16 * P.n_rng(), gp = gb + 4 * P.n_rng();
+        for (int64_t e = 0; e < P.n_pri(); ++e) {
+            const double* l = uu + 3 * (P.Np - 1) + 2 * (int64_t)P.pri_l[e];
+            f += score::gn_prior_block(l[0], l[1], &P.pri_t[2 * e], P.pri_prec[e], with_blocks ? &hblk[hp + 2 * e] : nullptr,
+                                       with_blocks ? &gblk[gp + 2 * e] : nullptr);
+        }
+        return f;
+    }
+    double eval_current(bool with_blocks) { return eval_at(u, with_blocks); }
+    double eval_trial() {
+        for (int64_t i = 0; i < P.n; ++i) ut[i] = u[i] + step[i];
+        return eval_at(ut, false);
+    }
+    void accept() { u.swap(ut); }
+    double assemble() {
+        double m = 0.0;
+        for (int64_t i = 0; i < P.n; ++i) {
+            double acc = 0.0;
+            for (int32_t c = P.gc_ptr[i]; c < P.gc_ptr[i + 1]; ++c) acc += gblk[P.gc_slot[c]];
+            rhs[i] = -acc;
+            m = std::max(m, acc == acc ? std::fabs(acc) : INFINITY);
+        }
+        return m;
+    }
+    bool solve(double lambda, double rel_tol, int* used);
+    void run(const double* poses_in, const double* lms_in, int max_iters, double tol, double* poses_out, double* lms_out,
+             score::GnInfo& info) {
+        for (int k = 0; k < 3; ++k) P.pin[k] = poses_in[k];
+        for (int64_t p = 1; p < P.Np; ++p)
+            for (int k = 0; k < 3; ++k) u[3 * (p - 1) + k] = poses_in[3 * p + k];
+        for (int64_t l = 0; l < 2 * P.Nl; ++l) u[3 * (P.Np - 1) + l] = lms_in[l];
+        score::gn_levenberg_marquardt(*this, max_iters, tol, 1e-9, info);
+        for (int k = 0; k < 3; ++k) poses_out[k] = poses_in[k];
+        for (int64_t p = 1; p < P.Np; ++p)
+            for (int k = 0; k < 3; ++k) poses_out[3 * p + k] = u[3 * (p - 1) + k];
+        for (int64_t l = 0; l < 2 * P.Nl; ++l) lms_out[l] = u[3 * (P.Np - 1) + l];
+    }
+};
+
 extern "C" {
 
 void score_default_settings(score_settings* s) { score::default_settings(s); }
@@ -466,4 +533,67 @@ int score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rota
 }
 const char* score_last_error(void) { return g_err.c_str(); }
 const char* score_backend(void) { return "cpu-twin"; }
+}
+
+score_refine::~score_refine() { if (lin) score_destroy(lin); }
+void score_refine::create(const score_graph& g, const score_settings* s) {
+    const double t0 = score::now_ms();
+    score::gn_build(g, P);
+    score_problem pat{};
+    pat.n = (int32_t)P.n; pat.m = 0;
+    pat.P_rowptr = P.hptr.data(); pat.P_col = P.hcol.data();
+    pat.block_size = 3; pat.n_chains = (int32_t)P.chain_ptr.size() - 1;
+    pat.chain_ptr = P.chain_ptr.data(); pat.node_first_col = P.node_first_col.data();
+    if (score_linear_create(&pat, s, &lin) != 0) throw std::runtime_error(g_err);
+    u.assign((size_t)P.n, 0.0); ut = u; step = u; rhs = u;
+    hblk.assign((size_t)std::max<int64_t>(1, P.hblk_size()), 0.0);
+    gblk.assign((size_t)std::max<int64_t>(1, P.gblk_size()), 0.0);
+    vals.assign(P.hcol.size(), 0.0);
+    setup_ms = score::now_ms() - t0;
+}
+bool score_refine::solve(double lambda, double rel_tol, int* used) {
+    for (size_t k = 0; k < P.hcol.size(); ++k) {
+        double acc = 0.0;
+        for (int32_t c = P.hc_ptr[k]; c < P.hc_ptr[k + 1]; ++c) acc += hblk[P.hc_slot[c]];
+        vals[k] = acc;
+    }
+    for (int64_t i = 0; i < P.n; ++i) vals[(size_t)P.diag_pos[(size_t)i]] += lambda;
+    int32_t it = 0;
+    const int rc = score_linear_solve(lin, vals.data(), rhs.data(), step.data(), rel_tol, 4000, &it, nullptr);
+    if (rc < 0) throw std::runtime_error(g_err);
+    if (used) *used = it;
+    return rc == 0;
+}
+
+extern "C" {
+int score_refine_create(const score_graph* g, const score_settings* s, score_refine** out) {
+    try {
+        if (!g || !out) throw std::runtime_error("null argument");
+        auto* r = new score_refine();
+        try {
+            r->create(*g, s);
+        } catch (...) {
+            delete r;
+            throw;
+        }
+        *out = r;
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_refine_run(score_refine* r, const double* poses_in, const double* landmarks_in, int32_t max_iters, double tol,
+                     double* poses_out, double* landmarks_out, score_refine_info* info) {
+    try {
+        if (!r || !poses_in || !poses_out || (r->P.Nl > 0 && (!landmarks_in || !landmarks_out))) throw std::runtime_error("null argument");
+        const double t0 = score::now_ms();
+        score::GnInfo gi;
+        r->run(poses_in, landmarks_in, max_iters, tol, poses_out, landmarks_out, gi);
+        if (info) {
+            info->cost_initial = gi.cost_initial; info->cost_final = gi.cost_final; info->grad_inf = gi.grad_inf;
+            info->iterations = gi.iterations; info->linear_solves = gi.linear_solves; info->pcg_iters = gi.pcg_iters;
+            info->setup_ms = r->setup_ms; info->solve_ms = score::now_ms() - t0;
+        }
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+void score_refine_destroy(score_refine* r) { delete r; }
 }

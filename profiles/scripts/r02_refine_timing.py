@@ -10,9 +10,11 @@ from score_amd.solve_score import solve_score
 for (r, n, b) in ((4, 1000, 4), (20, 1000, 4)):
     fg = make_manhattan(n_robots=r, n_poses=n, n_beacons=b, seed=3000)
     res = solve_score(fg, "SOCP")
-    for which in ("device", "device", "scipy"):
-        t = time.perf_counter(); out, info = refine_estimate(fg, res, linear_solver=which); dt = time.perf_counter() - t
-        print(f"{r}x{n} {which:6s}: {dt*1e3:8.1f} ms  LM its {info['iterations']}  cost {info['cost_initial']:.6f} -> {info['cost_final']:.6f}  "
+    for which, eng in (("device", "native"), ("device", "native"), ("device", "python"), ("scipy", "python")):
+        t = time.perf_counter(); out, info = refine_estimate(fg, res, linear_solver=which, engine=eng); dt = time.perf_counter() - t
+        if eng == "native":
+            print(f"     (native: create {info['setup_ms']:.1f} ms, run {info['solve_ms']:.1f} ms)")
+        print(f"{r}x{n} {which:6s} {eng:6s}: {dt*1e3:8.1f} ms  LM its {info['iterations']}  cost {info['cost_initial']:.6f} -> {info['cost_final']:.6f}  "
               f"|g| {info['grad_inf']:.2e}  linear solves {info['linear_solves']}  PCG its {info['pcg_iters']}", flush=True)
     prob = _Problem(fg); u = _initial_point(prob, res); rr, J = prob.residuals(u, jac=True)
     dev = _DeviceNormalEquations(prob, J, None, None)

@@ -1,0 +1,102 @@
+// score_gn_kernels.hpp -- device side of the local refinement (score_gn.hpp): per-measurement blocks,
+// the gathers that turn them into J'J / J'r on the handle's pattern, trial points.
+// All are small streaming kernels (one measurement / matrix entry / unknown per lane); the work that
+// matters -- the damped normal equations -- runs in the solver's own k_factor / k_prec_pre / k_spmv.
+#pragma once
+
+#include "score_gn.hpp"
+#include "score_kernels.hpp"
+
+namespace score {
+
+struct GnDev {
+    int64_t Np, Nl, n, n_rel, n_rng, n_pri;
+    const int32_t *rel_i, *rel_j, *rng_a, *rng_b, *pri_l;
+    const double *rel_t, *rel_R, *rel_kappa, *rel_tau, *rng_dist, *rng_prec, *pri_t, *pri_prec;
+    const double* pin;  // theta, x, y of the fixed pose
+};
+
+// one measurement per lane: cost (block partial sums) and, with_blocks, its J'J / J'r block
+__global__ __launch_bounds__(kThreads) void k_gn_blocks(GnDev d, const double* __restrict__ u, double* __restrict__ hblk,
+                                                        double* __restrict__ gblk, double* __restrict__ cost_part, int with_blocks) {
+    __shared__ double red[8];
+    const int64_t m = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    double cost = 0.0;
+    if (m < d.n_rel) {
+        double thi, xi, yi, thj, xj, yj;
+        gn_pose(u, d.pin, d.rel_i[m], thi, xi, yi);
+        gn_pose(u, d.pin, d.rel_j[m], thj, xj, yj);
+        double H[36], g[6];
+        cost = gn_rel_block(thi, xi, yi, thj, xj, yj, d.rel_t + 2 * m, d.rel_R + 4 * m, d.rel_kappa[m], d.rel_tau[m],
+                            with_blocks ? H : nullptr, g);
+        if (with_blocks) {
+#pragma unroll
+            for (int k = 0; k < 36; ++k) hblk[36 * m + k] = H[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) gblk[6 * m + k] = g[k];
+        }
+    } else if (m < d.n_rel + d.n_rng) {
+        const int64_t r = m - d.n_rel;
+        double xa, ya, xb, yb;
+        gn_point(u, d.pin, d.Np, d.rng_a[r], xa, ya);
+        gn_point(u, d.pin, d.Np, d.rng_b[r], xb, yb);
+        double H[16], g[4];
+        cost = gn_range_block(xa, ya, xb, yb, d.rng_dist[r], d.rng_prec[r], with_blocks ? H : nullptr, g);
+        if (with_blocks) {
+            double* ho = hblk + 36 * d.n_rel + 16 * r;
+            double* go = gblk + 6 * d.n_rel + 4 * r;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) ho[k] = H[k];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) go[k] = g[k];
+        }
+    } else if (m < d.n_rel + d.n_rng + d.n_pri) {
+        const int64_t e = m - d.n_rel - d.n_rng;
+        const double* l = u + 3 * (d.Np - 1) + 2 * (int64_t)d.pri_l[e];
+        double H[2], g[2];
+        cost = gn_prior_block(l[0], l[1], d.pri_t + 2 * e, d.pri_prec[e], with_blocks ? H : nullptr, g);
+        if (with_blocks) {
+            double* ho = hblk + 36 * d.n_rel + 16 * d.n_rng + 2 * e;
+            double* go = gblk + 6 * d.n_rel + 4 * d.n_rng + 2 * e;
+            ho[0] = H[0]; ho[1] = H[1]; go[0] = g[0]; go[1] = g[1];
+        }
+    }
+    const double tot = block_sum(cost, red);
+    if (threadIdx.x == 0) cost_part[blockIdx.x] = tot;
+}
+
+// one entry of H per lane: the sum of its block slots in list order (+ lambda on the diagonal)
+__global__ __launch_bounds__(kThreads) void k_gn_gather_h(const int32_t* __restrict__ hc_ptr, const int32_t* __restrict__ hc_slot,
+                                                          const double* __restrict__ hblk, const int32_t* __restrict__ is_diag,
+                                                          double lambda, double* __restrict__ out, int64_t nnz) {
+    const int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (k >= nnz) return;
+    double acc = 0.0;
+    for (int32_t c = hc_ptr[k]; c < hc_ptr[k + 1]; ++c) acc += hblk[hc_slot[c]];
+    out[k] = is_diag[k] ? acc + lambda : acc;
+}
+
+// one unknown per lane: g = J'r, rhs = -g, block partial of |g|_inf
+__global__ __launch_bounds__(kThreads) void k_gn_gather_g(const int32_t* __restrict__ gc_ptr, const int32_t* __restrict__ gc_slot,
+                                                          const double* __restrict__ gblk, double* __restrict__ rhs,
+                                                          double* __restrict__ gmax_part, int64_t n) {
+    __shared__ double red[8];
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    double a = 0.0;
+    if (i < n) {
+        double acc = 0.0;
+        for (int32_t c = gc_ptr[i]; c < gc_ptr[i + 1]; ++c) acc += gblk[gc_slot[c]];
+        rhs[i] = -acc;
+        a = acc == acc ? fabs(acc) : INFINITY;
+    }
+    const double mx = block_max(a, red);
+    if (threadIdx.x == 0) gmax_part[blockIdx.x] = mx;
+}
+
+__global__ __launch_bounds__(kThreads) void k_gn_trial(const double* __restrict__ u, const double* __restrict__ step,
+                                                       double* __restrict__ ut, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < n) ut[i] = u[i] + step[i];
+}
+
+}  // namespace score

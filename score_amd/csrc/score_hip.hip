@@ -28,6 +28,7 @@
 #include "score_driver.hpp"
 #include <future>
 #include "score_assemble.hpp"
+#include "score_gn_kernels.hpp"
 #include "score_round.hpp"
 #include "score_kernels.hpp"
 #include "score_polish.hpp"
@@ -1119,24 +1120,35 @@ struct HipBackend {
     //      r'M^-1 r <= rel_tol^2 r0'M^-1 r0.  The host looks at one flag per chunk of iterations. ----
     DevBuf<double> lin_rhs, lin_tol2, lin_ref;
     DevBuf<int32_t> lin_flag;  // [gate flag | STEPs executed] per problem
-    bool linear_solve(const HostSystem& h, const double* rhs, double* x, double rel_tol, int max_iters, int* used_out) {
+    void linear_buffers(const HostSystem& h) {
         if (h.m_tot != 0 || h.count != 1) throw std::runtime_error("linear mode: one unconstrained pattern per handle");
-        const size_t n = (size_t)h.n_tot;
         if (!lin_flag.d) {
-            lin_rhs.alloc(n); lin_tol2.alloc(1); lin_ref.alloc(1); lin_flag.alloc(2);
+            lin_rhs.alloc((size_t)h.n_tot); lin_tol2.alloc(1); lin_ref.alloc(1); lin_flag.alloc(2);
         }
-        // values -> K0 (K1 = 0), K = K0 and its chain factors / Jacobi inverses on the device
+    }
+    bool linear_solve(const HostSystem& h, const double* rhs, double* x, double rel_tol, int max_iters, int* used_out) {
+        linear_buffers(h);
+        const size_t n = (size_t)h.n_tot;
+        // values -> K0 (K1 = 0)
         HIP_CHECK(hipMemcpyAsync(K0d.d, h.K0.data(), h.K0.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-        derive_rho_data(false);
-        const double tol2 = rel_tol * rel_tol;
         HIP_CHECK(hipMemcpyAsync(lin_rhs.d, rhs, n * sizeof(double), hipMemcpyHostToDevice, stream));
+        const bool ok = linear_solve_core(h, lin_rhs.d, rel_tol, max_iters, used_out);
+        HIP_CHECK(hipMemcpyAsync(x, xtu.d, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return ok;
+    }
+    // K0d holds the values and rhs_dev the right-hand side, both on the device; the solution is left in xtu
+    bool linear_solve_core(const HostSystem& h, const double* rhs_dev, double rel_tol, int max_iters, int* used_out) {
+        linear_buffers(h);
+        derive_rho_data(false);  // K = K0 and its chain factors / Jacobi inverses on the device
+        const double tol2 = rel_tol * rel_tol;
         HIP_CHECK(hipMemcpyAsync(lin_tol2.d, &tol2, sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemsetAsync(lin_flag.d, 0, 2 * sizeof(int32_t), stream));
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = lin_flag.d;
         pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d;
-        pa.r = r.d; pa.r_in = lin_rhs.d; pa.z = z.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d; pa.pw_part = pw_part.d;
+        pa.r = r.d; pa.r_in = rhs_dev; pa.z = z.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d; pa.pw_part = pw_part.d;
         pa.gate_used = lin_flag.d + 1;
         double* rz_cur = rz_part0.d;
         double* p_cur = p.d;
@@ -1158,7 +1170,7 @@ struct HipBackend {
                 double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
                 pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_nxt;
                 pa.gate_first = first ? 1 : 0;
-                pa.r_in = first ? lin_rhs.d : r.d;
+                pa.r_in = first ? rhs_dev : r.d;
                 pa.xt_zero = first ? 1 : 0;
                 launch_prec<PREC_STEP>(pa);  // x += a p ; r -= a w ; z = M^-1 r   (or the gate fires)
                 SpmvArgs a = spmv_args(K, p_cur);
@@ -1173,8 +1185,6 @@ struct HipBackend {
             HIP_CHECK(hipMemcpyAsync(state, lin_flag.d, sizeof(state), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
         }
-        HIP_CHECK(hipMemcpyAsync(x, xtu.d, n * sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
         if (used_out) *used_out = state[1];
         return state[0] != 0;
     }
@@ -1675,6 +1685,112 @@ struct score_handle {
     score::Solver<HipBackend> solver;
 };
 
+// Local refinement after SCORE on the device (score_gn.hpp): state, blocks and gathers here, the damped
+// normal equations through the linear-mode handle `lin` (its K0 values and right-hand side are written
+// in place by the gather kernels; the step is read from its solution vector).
+struct score_refine {
+    score::GnProblem P;
+    score_handle* lin = nullptr;
+    int device = 0;
+    double setup_ms = 0;
+    DevBuf<int32_t> rel_i, rel_j, rng_a, rng_b, pri_l, hc_ptr, hc_slot, gc_ptr, gc_slot, is_diag;
+    DevBuf<double> rel_t, rel_R, rel_kappa, rel_tau, rng_dist, rng_prec, pri_t, pri_prec, pin;
+    DevBuf<double> u, ut, hblk, gblk, rhs, cost_part, gmax_part;
+    int n_mblocks = 0, n_ublocks = 0, n_hblocks = 0;
+    std::vector<double> part_host;
+
+    HipBackend& be() { return lin->solver.be; }
+    hipStream_t stream() { return lin->solver.be.stream; }
+    score::GnDev dev() const {
+        score::GnDev d{};
+        d.Np = P.Np; d.Nl = P.Nl; d.n = P.n; d.n_rel = P.n_rel(); d.n_rng = P.n_rng(); d.n_pri = P.n_pri();
+        d.rel_i = rel_i.d; d.rel_j = rel_j.d; d.rng_a = rng_a.d; d.rng_b = rng_b.d; d.pri_l = pri_l.d;
+        d.rel_t = rel_t.d; d.rel_R = rel_R.d; d.rel_kappa = rel_kappa.d; d.rel_tau = rel_tau.d;
+        d.rng_dist = rng_dist.d; d.rng_prec = rng_prec.d; d.pri_t = pri_t.d; d.pri_prec = pri_prec.d; d.pin = pin.d;
+        return d;
+    }
+    void create(const score_graph& g, const score_settings* s) {
+        const double t0 = score::now_ms();
+        score::gn_build(g, P);
+        score_problem pat{};
+        pat.n = (int32_t)P.n; pat.m = 0;
+        pat.P_rowptr = P.hptr.data(); pat.P_col = P.hcol.data();
+        pat.block_size = 3; pat.n_chains = (int32_t)P.chain_ptr.size() - 1;
+        pat.chain_ptr = P.chain_ptr.data(); pat.node_first_col = P.node_first_col.data();
+        if (score_linear_create(&pat, s, &lin) != 0) throw std::runtime_error(g_err);
+        device = lin->solver.st.device;
+        tl_copy_stream = stream();
+        rel_i.upload(P.rel_i); rel_j.upload(P.rel_j); rng_a.upload(P.rng_a); rng_b.upload(P.rng_b); pri_l.upload(P.pri_l);
+        rel_t.upload(P.rel_t); rel_R.upload(P.rel_R); rel_kappa.upload(P.rel_kappa); rel_tau.upload(P.rel_tau);
+        rng_dist.upload(P.rng_dist); rng_prec.upload(P.rng_prec); pri_t.upload(P.pri_t); pri_prec.upload(P.pri_prec);
+        hc_ptr.upload(P.hc_ptr); hc_slot.upload(P.hc_slot); gc_ptr.upload(P.gc_ptr); gc_slot.upload(P.gc_slot);
+        std::vector<int32_t> dg(P.hcol.size(), 0);
+        for (int64_t i = 0; i < P.n; ++i) dg[(size_t)P.diag_pos[(size_t)i]] = 1;
+        is_diag.upload(dg);
+        pin.alloc(3); u.alloc((size_t)P.n); ut.alloc((size_t)P.n); rhs.alloc((size_t)P.n);
+        hblk.alloc((size_t)std::max<int64_t>(1, P.hblk_size())); gblk.alloc((size_t)std::max<int64_t>(1, P.gblk_size()));
+        n_mblocks = (int)std::max<int64_t>(1, (P.n_meas() + kThreads - 1) / kThreads);
+        n_ublocks = (int)std::max<int64_t>(1, (P.n + kThreads - 1) / kThreads);
+        n_hblocks = (int)std::max<int64_t>(1, ((int64_t)P.hcol.size() + kThreads - 1) / kThreads);
+        cost_part.alloc((size_t)n_mblocks); gmax_part.alloc((size_t)n_ublocks);
+        be().linear_buffers(lin->solver.H);
+        setup_ms = score::now_ms() - t0;
+    }
+    ~score_refine() { if (lin) score_destroy(lin); }
+
+    // ---- the backend concept of gn_levenberg_marquardt ----
+    double eval_at(const double* where, bool with_blocks) {
+        hipLaunchKernelGGL(score::k_gn_blocks, dim3(n_mblocks), dim3(kThreads), 0, stream(), dev(), where, hblk.d, gblk.d,
+                           cost_part.d, with_blocks ? 1 : 0);
+        part_host.resize((size_t)n_mblocks);
+        HIP_CHECK(hipMemcpyAsync(part_host.data(), cost_part.d, (size_t)n_mblocks * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
+        double f = 0.0;
+        for (double v : part_host) f += v;
+        return f;
+    }
+    double eval_current(bool with_blocks) { return eval_at(u.d, with_blocks); }
+    double eval_trial() {
+        hipLaunchKernelGGL(score::k_gn_trial, dim3(n_ublocks), dim3(kThreads), 0, stream(), (const double*)u.d,
+                           (const double*)be().xtu.d, ut.d, (int64_t)P.n);
+        return eval_at(ut.d, false);
+    }
+    void accept() { std::swap(u.d, ut.d); }
+    double assemble() {  // g = J'r (rhs = -g) from the blocks of the current point; returns |g|_inf
+        hipLaunchKernelGGL(score::k_gn_gather_g, dim3(n_ublocks), dim3(kThreads), 0, stream(), (const int32_t*)gc_ptr.d,
+                           (const int32_t*)gc_slot.d, (const double*)gblk.d, rhs.d, gmax_part.d, (int64_t)P.n);
+        part_host.resize((size_t)n_ublocks);
+        HIP_CHECK(hipMemcpyAsync(part_host.data(), gmax_part.d, (size_t)n_ublocks * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
+        double m = 0.0;
+        for (double v : part_host) m = std::max(m, v);
+        return m;
+    }
+    bool solve(double lambda, double rel_tol, int* used) {  // (J'J + lambda I) step = -g, step left in the handle's xtu
+        hipLaunchKernelGGL(score::k_gn_gather_h, dim3(n_hblocks), dim3(kThreads), 0, stream(), (const int32_t*)hc_ptr.d,
+                           (const int32_t*)hc_slot.d, (const double*)hblk.d, (const int32_t*)is_diag.d, lambda, be().K0d.d,
+                           (int64_t)P.hcol.size());
+        return be().linear_solve_core(lin->solver.H, rhs.d, rel_tol, 4000, used);
+    }
+    void run(const double* poses_in, const double* lms_in, int max_iters, double tol, double* poses_out, double* lms_out,
+             score::GnInfo& info) {
+        std::vector<double> u0((size_t)P.n);
+        for (int64_t p = 1; p < P.Np; ++p)
+            for (int k = 0; k < 3; ++k) u0[(size_t)(3 * (p - 1) + k)] = poses_in[3 * p + k];
+        for (int64_t l = 0; l < 2 * P.Nl; ++l) u0[(size_t)(3 * (P.Np - 1) + l)] = lms_in[l];
+        HIP_CHECK(hipMemcpyAsync(u.d, u0.data(), u0.size() * sizeof(double), hipMemcpyHostToDevice, stream()));
+        HIP_CHECK(hipMemcpyAsync(pin.d, poses_in, 3 * sizeof(double), hipMemcpyHostToDevice, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
+        score::gn_levenberg_marquardt(*this, max_iters, tol, 1e-9, info);
+        HIP_CHECK(hipMemcpyAsync(u0.data(), u.d, u0.size() * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        HIP_CHECK(hipStreamSynchronize(stream()));
+        for (int k = 0; k < 3; ++k) poses_out[k] = poses_in[k];
+        for (int64_t p = 1; p < P.Np; ++p)
+            for (int k = 0; k < 3; ++k) poses_out[3 * p + k] = u0[(size_t)(3 * (p - 1) + k)];
+        for (int64_t l = 0; l < 2 * P.Nl; ++l) lms_out[l] = u0[(size_t)(3 * (P.Np - 1) + l)];
+    }
+};
+
 extern "C" {
 
 void score_default_settings(score_settings* s) { score::default_settings(s); }
@@ -1848,6 +1964,44 @@ int score_assembled_view(const score_assembled* a, score_problem* view) {
     return 0;
 }
 void score_assembled_free(score_assembled* a) { delete a; }
+int score_refine_create(const score_graph* g, const score_settings* s, score_refine** out) {
+    try {
+        if (!g || !out) throw std::runtime_error("null argument");
+        auto* r = new score_refine();
+        try {
+            r->create(*g, s);
+        } catch (...) {
+            delete r;
+            throw;
+        }
+        *out = r;
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_refine_run(score_refine* r, const double* poses_in, const double* landmarks_in, int32_t max_iters, double tol,
+                     double* poses_out, double* landmarks_out, score_refine_info* info) {
+    try {
+        if (!r || !poses_in || !poses_out || (r->P.Nl > 0 && (!landmarks_in || !landmarks_out))) throw std::runtime_error("null argument");
+        DeviceGuard guard(r->device);
+        const double t0 = score::now_ms();
+        score::GnInfo gi;
+        r->run(poses_in, landmarks_in, max_iters, tol, poses_out, landmarks_out, gi);
+        if (info) {
+            info->cost_initial = gi.cost_initial; info->cost_final = gi.cost_final; info->grad_inf = gi.grad_inf;
+            info->iterations = gi.iterations; info->linear_solves = gi.linear_solves; info->pcg_iters = gi.pcg_iters;
+            info->setup_ms = r->setup_ms; info->solve_ms = score::now_ms() - t0;
+        }
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+void score_refine_destroy(score_refine* r) {
+    if (!r) return;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    (void)hipSetDevice(r->device);
+    delete r;
+    if (prev >= 0) (void)hipSetDevice(prev);
+}
 int score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rotations, int32_t* degenerate, int32_t device) {
     try {
         if (dim != 2 && dim != 3) throw std::runtime_error("score_round_to_so: dim must be 2 or 3");

@@ -247,14 +247,10 @@ class NativeQP:
             pass
 
 
-def assemble_native(data, relaxation: str = QCQP_RELAXATION, lib_path: Optional[str] = None, arrays: Optional[dict] = None) -> ScoreModel:
-    check_valid_relaxation(relaxation)
-    lib = load_library(lib_path)
-    _bind(lib)
-    a = arrays if arrays is not None else graph_arrays(data)
-    d = int(a["dim"])
+def score_graph_struct(a: Dict[str, np.ndarray], relaxation: int = 0) -> ScoreGraph:
+    """``struct score_graph`` over the flat arrays of ``graph_arrays`` (borrowed: keep ``a`` alive)."""
     g = ScoreGraph()
-    g.dim, g.relaxation = d, (0 if relaxation == SOCP_RELAXATION else 1)
+    g.dim, g.relaxation = int(a["dim"]), int(relaxation)
     g.n_chains, g.chain_len = len(a["chain_len"]), a["chain_len"].ctypes.data_as(_i32p)
     g.n_landmarks = len(a["landmark_names"])
     g.n_rel = len(a["rel_base"])
@@ -267,6 +263,16 @@ def assemble_native(data, relaxation: str = QCQP_RELAXATION, lib_path: Optional[
     g.n_lprior = len(a["lprior_lm"])
     g.lprior_lm, g.lprior_t = a["lprior_lm"].ctypes.data_as(_i32p), a["lprior_t"].ctypes.data_as(_f64p)
     g.lprior_prec = a["lprior_prec"].ctypes.data_as(_f64p)
+    return g
+
+
+def assemble_native(data, relaxation: str = QCQP_RELAXATION, lib_path: Optional[str] = None, arrays: Optional[dict] = None) -> ScoreModel:
+    check_valid_relaxation(relaxation)
+    lib = load_library(lib_path)
+    _bind(lib)
+    a = arrays if arrays is not None else graph_arrays(data)
+    d = int(a["dim"])
+    g = score_graph_struct(a, 0 if relaxation == SOCP_RELAXATION else 1)
     h = C.c_void_p()
     if lib.score_assemble(C.byref(g), C.byref(h)) != 0:
         raise ValueError(lib.score_last_error().decode())

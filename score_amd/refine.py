@@ -17,6 +17,11 @@ chain-preconditioned PCG through the C ABI (``score_linear_create`` / ``score_li
 ``k_factor`` factors the chains of J'J, ``k_prec_pre`` + ``k_spmv`` run the PCG, termination on the
 device).  ``linear_solver="scipy"`` keeps the sparse-LU solve on the host: the reference the tests
 compare the device path with, not a fallback (the default path raises without the HIP library).
+
+``engine="native"`` (default) runs the WHOLE loop behind the C ABI (``score_refine_create`` /
+``score_refine_run``, csrc/score_gn.hpp): per-measurement Jacobian blocks, J'J / J'r on a fixed pattern
+and trial points are device kernels too, the host only steers the Levenberg-Marquardt iteration.
+``engine="python"`` is the loop below (host Jacobians), kept as the readable twin the tests compare with.
 """
 from __future__ import annotations
 
@@ -219,16 +224,60 @@ class _DeviceNormalEquations:
         self.solver.close()
 
 
+def _refine_native(prob: _Problem, u0: np.ndarray, max_iters: int, tol: float, lib_path: Optional[str],
+                   solver_settings: Optional[dict]):
+    """The whole LM loop behind the C ABI (score_refine_*).  Returns (u, info dict)."""
+    import ctypes as C
+
+    from .native import score_graph_struct
+    from .solver import ScoreRefineInfo, ScoreSettings, _f64p, load_library
+
+    lib = load_library(lib_path)
+    st = ScoreSettings()
+    lib.score_default_settings(C.byref(st))
+    for k, v in (solver_settings or {}).items():
+        if not hasattr(st, k):
+            raise ValueError(f"unknown solver setting {k}")
+        setattr(st, k, v)
+    g = score_graph_struct(prob.a)
+    h = C.c_void_p()
+    if lib.score_refine_create(C.byref(g), C.byref(st), C.byref(h)) != 0:
+        raise RuntimeError(f"score_refine_create failed: {lib.score_last_error().decode()}")
+    try:
+        th, t, lm = prob.split(u0)
+        poses_in = np.ascontiguousarray(np.column_stack([th, t]), dtype=np.float64)
+        lms_in = np.ascontiguousarray(lm, dtype=np.float64).reshape(-1, 2)
+        poses_out, lms_out = np.empty_like(poses_in), np.empty((max(1, len(lms_in)), 2))
+        info = ScoreRefineInfo()
+        rc = lib.score_refine_run(h, poses_in.ctypes.data_as(_f64p), lms_in.ctypes.data_as(_f64p) if len(lms_in) else None,
+                                  int(max_iters), float(tol), poses_out.ctypes.data_as(_f64p), lms_out.ctypes.data_as(_f64p),
+                                  C.byref(info))
+        if rc != 0:
+            raise RuntimeError(f"score_refine_run failed: {lib.score_last_error().decode()}")
+    finally:
+        lib.score_refine_destroy(h)
+    u = prob.pack(poses_out[:, 0], poses_out[:, 1:3], lms_out[: len(lms_in)])
+    return u, info.as_dict()
+
+
 def refine_estimate(data, results, max_iters: int = 50, tol: float = 1e-10, verbose: bool = False,
                     linear_solver: str = "device", lib_path: Optional[str] = None, solver_settings: Optional[dict] = None,
-                    pcg_rel_tol: float = 1e-9):
+                    pcg_rel_tol: float = 1e-9, engine: str = "native"):
     """Refine a SCORE estimate (``SolverResults``) to a local minimiser of the RA-SLAM maximum-likelihood
     cost.  Returns ``(refined SolverResults, info)``; ``info`` holds the cost before / after, iterations,
     the final gradient norm and (device path) the PCG iterations spent in the linear solves."""
     if linear_solver not in ("device", "scipy"):
         raise ValueError("linear_solver must be 'device' or 'scipy'")
+    if engine not in ("native", "python"):
+        raise ValueError("engine must be 'native' or 'python'")
     prob = _Problem(data)
     u = _initial_point(prob, results)
+    if engine == "native" and linear_solver == "device" and prob.n > 0:
+        u, ni = _refine_native(prob, u, max_iters, tol, lib_path, solver_settings)
+        info = {"cost_initial": ni["cost_initial"], "cost_final": ni["cost_final"], "iterations": ni["iterations"],
+                "grad_inf": ni["grad_inf"], "linear_solver": "device", "engine": "native", "pcg_iters": ni["pcg_iters"],
+                "linear_solves": ni["linear_solves"], "setup_ms": ni["setup_ms"], "solve_ms": ni["solve_ms"]}
+        return _as_results(prob, u, results, ni["cost_final"]), info
     res, J = prob.residuals(u, jac=True)
     f = float(res @ res)
     f0 = f
@@ -242,17 +291,21 @@ def refine_estimate(data, results, max_iters: int = 50, tol: float = 1e-10, verb
         pcg = (dev.pcg_iters, dev.solves) if dev else (0, 0)
         if dev:
             dev.close()
+    out = _as_results(prob, u, results, f)
+    info = {"cost_initial": f0, "cost_final": f, "iterations": it, "grad_inf": gnorm, "linear_solver": linear_solver,
+            "engine": "python", "pcg_iters": pcg[0], "linear_solves": pcg[1]}
+    return out, info
+
+
+def _as_results(prob: _Problem, u: np.ndarray, results, cost: float):
     th, t, lm = prob.split(u)
     c, s = np.cos(th), np.sin(th)
     T = np.tile(np.eye(3), (prob.Np, 1, 1))
     T[:, 0, 0] = c; T[:, 0, 1] = -s; T[:, 1, 0] = s; T[:, 1, 1] = c
     T[:, :2, 2] = t
     values = compat.VariableValues(2, compat.ArrayDict(prob.a["pose_names"], T), compat.ArrayDict(prob.a["landmark_names"], lm.copy()), None)
-    out = compat.SolverResults(variables=values, total_time=results.total_time, solved=True,
-                               pose_chain_names=results.pose_chain_names, solver_cost=f, info=dict(results.info or {}))
-    info = {"cost_initial": f0, "cost_final": f, "iterations": it, "grad_inf": gnorm, "linear_solver": linear_solver,
-            "pcg_iters": pcg[0], "linear_solves": pcg[1]}
-    return out, info
+    return compat.SolverResults(variables=values, total_time=results.total_time, solved=True,
+                                pose_chain_names=results.pose_chain_names, solver_cost=cost, info=dict(results.info or {}))
 
 
 def _lm_loop(prob, u, res, J, f, lam, max_iters, tol, verbose, dev, pcg_rel_tol):

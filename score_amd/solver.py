@@ -49,6 +49,17 @@ class ScoreSettings(C.Structure):
     ]
 
 
+class ScoreRefineInfo(C.Structure):
+    _fields_ = [
+        ("cost_initial", C.c_double), ("cost_final", C.c_double), ("grad_inf", C.c_double),
+        ("iterations", C.c_int32), ("linear_solves", C.c_int32), ("pcg_iters", C.c_int32),
+        ("setup_ms", C.c_double), ("solve_ms", C.c_double),
+    ]
+
+    def as_dict(self) -> dict:
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 class ScoreInfo(C.Structure):
     _fields_ = [
         ("status", C.c_int32), ("iters", C.c_int32), ("cg_iters", C.c_int32), ("rho_updates", C.c_int32),
@@ -68,7 +79,7 @@ STATUS_NAMES = {0: "unsolved", 1: "solved", 2: "max_iters", 3: "numerical"}
 ABI_SYMBOLS = [
     "score_assemble", "score_assembled_view", "score_assembled_free", "score_round_to_so",
     "score_default_settings", "score_create", "score_create_batch", "score_dims", "score_solve",
-    "score_reset", "score_solve_steps", "score_newton_steps", "score_linear_create", "score_linear_solve", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
+    "score_reset", "score_solve_steps", "score_newton_steps", "score_linear_create", "score_linear_solve", "score_refine_create", "score_refine_run", "score_refine_destroy", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
     "score_last_error", "score_backend",
 ]
 
@@ -100,6 +111,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.score_destroy.restype = None
     lib.score_linear_create.argtypes = [C.POINTER(ScoreProblem), C.POINTER(ScoreSettings), C.POINTER(C.c_void_p)]
     lib.score_linear_solve.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, C.c_double, C.c_int32, C.POINTER(C.c_int32), _f64p]
+    lib.score_refine_create.argtypes = [C.c_void_p, C.POINTER(ScoreSettings), C.POINTER(C.c_void_p)]
+    lib.score_refine_run.argtypes = [C.c_void_p, _f64p, _f64p, C.c_int32, C.c_double, _f64p, _f64p, C.POINTER(ScoreRefineInfo)]
+    lib.score_refine_destroy.argtypes = [C.c_void_p]
+    lib.score_refine_destroy.restype = None
     lib.score_round_to_so.argtypes = [C.c_int32, C.c_int64, _f64p, _f64p, C.POINTER(C.c_int32), C.c_int32]
     lib.score_round_to_so.restype = C.c_int
     lib.score_last_error.restype = C.c_char_p

@@ -632,10 +632,18 @@ def test_linear_mode_and_refinement_on_the_gpu(hip_lib, twin_lib):
     np.testing.assert_allclose(out["hip"][2], out["twin"][2], atol=1e-8 * scale)
     ref = spla.spsolve((H + 1e-4 * sp.identity(prob.n)).tocsc(), -g)
     np.testing.assert_allclose(out["hip"][2], ref, atol=1e-7 * max(1.0, np.abs(ref).max()))
-    refined, info = refine_estimate(fg, res, lib_path=hip_lib)
+    refined, info = refine_estimate(fg, res, lib_path=hip_lib)  # whole loop on the device (score_refine_run)
+    by_twin, info_twin = refine_estimate(fg, res, lib_path=twin_lib)  # the same loop, kernels as CPU loops
+    by_py, info_py = refine_estimate(fg, res, lib_path=hip_lib, engine="python")  # host Jacobians, device solves
     by_lu, info_lu = refine_estimate(fg, res, linear_solver="scipy")
-    assert info["linear_solver"] == "device" and info["pcg_iters"] > 0
-    assert info["cost_final"] == pytest.approx(info_lu["cost_final"], rel=1e-8)
+    assert info["engine"] == "native" and info["pcg_iters"] > 0
+    assert info["iterations"] == info_twin["iterations"] == info_py["iterations"]
+    assert info["cost_initial"] == pytest.approx(info_twin["cost_initial"], rel=1e-13)
+    for other in (info_twin, info_py, info_lu):
+        assert info["cost_final"] == pytest.approx(other["cost_final"], rel=1e-8)
+    for nm in refined.poses:
+        np.testing.assert_allclose(refined.poses[nm], by_twin.poses[nm], atol=1e-6)
+        np.testing.assert_allclose(refined.poses[nm], by_lu.poses[nm], atol=1e-4)
     assert info["cost_final"] <= info["cost_initial"]
     # BASELINE size (configs[3]): residual bound of one damped solve
     big = make_config(3) if False else make_manhattan(n_robots=20, n_poses=1000, n_beacons=4, seed=3000)
