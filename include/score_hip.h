@@ -101,6 +101,10 @@ typedef struct score_settings {
                                   chain over 2-4 workgroups (k_prec_wave) when the whole launch fits the device at
                                   once -- correct and tested, measured 10-15 % SLOWER than the default on the
                                   headline problem, kept as an option                      */
+    int32_t fac_fp32;          /* 1 (default): the chain factors are kept to float precision (rounded after every
+                                  factorisation) and the LDS-resident chain kernel reads them as 4-byte values --
+                                  half the bytes of the kernel that owns the iteration; M^-1 stays a fixed linear
+                                  operator, PCG converges to the same tolerances.  0: double throughout.          */
 } score_settings;
 
 enum {

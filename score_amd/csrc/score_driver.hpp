@@ -333,6 +333,7 @@ inline void default_settings(score_settings* s) {
     s->polish_warmup = 15;
     s->verbose = 0;
     s->chain_split = 0;
+    s->fac_fp32 = 1;
 }
 
 // score_linear_create: the pattern problem behind a linear-mode handle.  `pat` gives the sparsity pattern

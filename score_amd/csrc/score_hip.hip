@@ -306,6 +306,8 @@ struct HipBackend {
     DevBuf<double> xtu, xy, s, r, z, p, p2, w, kx, step;
     DevBuf<double> pw_part, rz_part0, rz_part1, rz_meas0, rz_meas1, pres_part, dres_part;
     // ---- semismooth-Newton polish (score_polish*.hpp) ----
+    DevBuf<float> fac32, q_fac32;  // float copies of the chain factors (ADMM / Newton), see k_fac_round
+    bool use_fac32 = false;
     PolishData Q;
     std::future<void> polish_build;  // build_polish runs beside the uploads of init()
     CsrBufs Hm;
@@ -529,6 +531,8 @@ struct HipBackend {
         K0d.upload_padded(h.K0, 64); K1d.upload_padded(h.K1, 64);
         kposd.upload(h.pos_diag); kposs.upload(h.pos_sub); kdiagpos.upload(h.diag_kpos);
         fac.alloc(h.fac_doubles); fac.zero(stream);  // separator slots of the spike region are never written (nor used)
+        use_fac32 = st.fac_fp32 != 0;
+        if (use_fac32) { fac32.alloc(h.fac_doubles); fac32.zero(stream); }
         dinv.alloc(h.dinv.size()); rho.upload(h.rho);
         q_work.alloc((size_t)std::max<int64_t>(1, h.scratch_nodes) * 2 * std::max(1, h.bs * h.bs));
         plan_factor_lds();
@@ -622,6 +626,11 @@ struct HipBackend {
         else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
         else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
         else hipLaunchKernelGGL(k_factor<4>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
+        if (use_fac32 && H->fac_doubles > 0) {
+            float* shadow = (fa.fac == q_fac.d) ? q_fac32.d : fac32.d;
+            const int64_t nf = (int64_t)H->fac_doubles;
+            hipLaunchKernelGGL(k_fac_round, dim3((unsigned)((nf + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, fa.fac, shadow, nf);
+        }
     }
 
     ConeArgs cone_args(const double* gathered) {
@@ -736,8 +745,10 @@ struct HipBackend {
     }
 
     template <int MODE>
-    void launch_prec(const PrecArgs& pa, int slot = -1) {
+    void launch_prec(const PrecArgs& pa_in, int slot = -1) {
         if (n_prec == 0) return;
+        PrecArgs pa = pa_in;
+        pa.fac32 = (pa.fac == q_fac.d) ? q_fac32.d : fac32.d;  // the float copy of whichever factor set is applied
         if (split.active) {
             WaveArgs wa{};
             wa.p = pa;
@@ -750,8 +761,10 @@ struct HipBackend {
         const int bs = H->bs;
 #define SCORE_LAUNCH_PREC(BS)                                                                                  \
     do {                                                                                                       \
-        if (prec_pre && BS <= 3)                                                                               \
-            launch_on_stream((k_prec_pre<(BS <= 3 ? BS : 3), MODE>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa); \
+        if (prec_pre && BS <= 3 && use_fac32)                                                                  \
+            launch_on_stream((k_prec_pre<(BS <= 3 ? BS : 3), MODE, float>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa); \
+        else if (prec_pre && BS <= 3)                                                                          \
+            launch_on_stream((k_prec_pre<(BS <= 3 ? BS : 3), MODE, double>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa); \
         else if (prec_lds0)                                                                                    \
             launch_on_stream((k_prec<BS, 3, MODE, true>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa); \
         else                                                                                                   \
@@ -775,8 +788,10 @@ struct HipBackend {
         HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_INIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_STEP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
         constexpr int BP = BS <= 3 ? BS : 3;
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_INIT>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_INIT, double>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_STEP, double>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_INIT, float>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_STEP, float>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
     }
 
     SpmvArgs spmv_args(const CsrBufs& M, const double* xin) {
@@ -1217,6 +1232,7 @@ struct HipBackend {
         q_g.alloc(h.n_tot); q_delta.alloc(h.n_tot); q_dummy.alloc(h.n_tot); q_negg.alloc(h.n_tot);
         q_fac.alloc(h.fac_doubles); q_dinv.alloc(h.dinv.size());
         q_fac.zero(stream);  // separator slots of the spike region are never written (nor used)
+        if (use_fac32) { q_fac32.alloc(h.fac_doubles); q_fac32.zero(stream); }
         n_gd = std::max<size_t>((h.n_tot + kThreads - 1) / kThreads, (size_t)Hm.nblocks);
         q_pw.alloc(Hm.nblocks);
         {

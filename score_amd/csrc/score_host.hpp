@@ -615,6 +615,7 @@ struct HostSystem {
     // device from K0 / K1 / rho (the HIP backend: k_kval + k_factor) -- nothing rho-dependent is
     // computed or uploaded by the host.
     bool factor_on_host = true;
+    bool fac_fp32 = true;   // chain factors kept to float precision (score_settings.fac_fp32)
 };
 
 inline int find_in_row(const Csr& M, int64_t row, int32_t col) {
@@ -982,6 +983,8 @@ inline void refresh_rho(HostSystem& H, int pi) {
             int scr = 0;
             factor_chain_levels(bs, H.radix, ch.N, Ad, Bs, lv, fac, scr);
             // level structure depends only on (N, radix): it was laid out at setup
+            if (H.fac_fp32)  // what the device keeps: the factors to float precision (k_fac_round)
+                for (double& v : fac) v = (double)(float)v;
             std::memcpy(&H.fac[H.fac_off[ci]], fac.data(), sizeof(double) * fac.size());
         }
     });
@@ -998,6 +1001,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     PhaseTimer pt(st.verbose != 0);
     H = HostSystem();
     H.factor_on_host = factor_on_host;
+    H.fac_fp32 = st.fac_fp32 != 0;
     H.count = count;
     H.sigma = st.sigma;
     H.radix = std::min(4, std::max(2, st.chain_radix));

@@ -379,6 +379,7 @@ struct PrecArgs {
     const ChainDesc* chains;
     const ChainLevelDesc* levels;
     const double* fac;
+    const float* fac32;    // the same factors as 4-byte values (k_fac_round); read by k_prec_pre<.., float>
     const int32_t* node_col;
     const int32_t* diag_cols;
     const double* dinv;
@@ -875,7 +876,7 @@ struct PreTile {
     static constexpr int NG = (8 * B2 > 32) ? 8 * B2 : 32;  // run (6 B2) + separator (2 B2) blocks | staging
 };
 
-template <int BS, int MODE>
+template <int BS, int MODE, typename FT = double>
 __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
     KernelStamp stamp(a.tstamp);
     constexpr int RMAX = 3;
@@ -911,7 +912,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         const ChainDesc ch = a.chains[wk.index];
         const ChainLevelDesc* __restrict__ lv = a.levels + ch.level_begin;
         const int32_t* __restrict__ nc = a.node_col + ch.node_begin;
-        const double* __restrict__ fac = a.fac;
+        // factor stream: 8-byte values, or their float copies (half the bytes through this CU; converted on arrival)
+        const FT* __restrict__ fac = sizeof(FT) == 4 ? (const FT*)(const void*)a.fac32 : (const FT*)(const void*)a.fac;
         const int N = ch.N;
         const int NB = N * BS;
         const int nl = ch.n_levels;
@@ -950,7 +952,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             if (MODE == PREC_STEP) wv[u] = a.w[cols[u]];
         }
         // ---- factor loads: level 0 -> registers (lanes < 256), coarser levels -> staging ----
-        double G[NG];
+        FT Gr[NG];  // as loaded (converted to double once they have arrived: after the vector update below)
         const bool l0_last = (L0.p == 0);
         if (t < kPreRunLanes) {
             if ((t & ~63) < L0.nruns && !(a.debug_skip & 1)) {
@@ -959,34 +961,34 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                 const int hi = l0_last ? L0.N : min(j * L0.p + L0.p - 1, L0.N);
                 const int len = max(hi - lo, 1);
                 const size_t eP = (size_t)L0.P * L0.nruns;
-                const double* __restrict__ R = fac + L0.offR;
+                const FT* __restrict__ R = fac + L0.offR;
 #pragma unroll
                 for (int q = 0; q < RMAX; ++q) {
-                    const double* __restrict__ Rq = R + (size_t)min(q, len - 1) * L0.nruns + j;
+                    const FT* __restrict__ Rq = R + (size_t)min(q, len - 1) * L0.nruns + j;
 #pragma unroll
                     for (int e = 0; e < B2; ++e) {
-                        G[q * B2 + e] = Rq[(size_t)e * eP];
-                        G[(RMAX + q) * B2 + e] = Rq[(size_t)(B2 + e) * eP];
+                        Gr[q * B2 + e] = Rq[(size_t)e * eP];
+                        Gr[(RMAX + q) * B2 + e] = Rq[(size_t)(B2 + e) * eP];
                     }
                 }
                 if (L0.nsep > 0) {
-                    const double* __restrict__ S = fac + L0.offS;
+                    const FT* __restrict__ S = fac + L0.offS;
                     const int js = min(t, L0.nsep - 1);
 #pragma unroll
                     for (int e = 0; e < B2; ++e) {
-                        G[oCl + e] = S[(size_t)e * L0.nsep + js];
-                        G[oCr + e] = S[(size_t)(B2 + e) * L0.nsep + js];
+                        Gr[oCl + e] = S[(size_t)e * L0.nsep + js];
+                        Gr[oCr + e] = S[(size_t)(B2 + e) * L0.nsep + js];
                     }
                 }
             }
         } else if (deep_cnt > 0 && !(a.debug_skip & 2)) {
-            const double* __restrict__ src = fac + deep_base;
+            const FT* __restrict__ src = fac + deep_base;
             const int lane = t - kPreRunLanes;
 #pragma unroll
             for (int k0 = 0; k0 < NG; k0 += 8) {
                 if (k0 * kStageLanes < deep_cnt) {  // uniform
 #pragma unroll
-                    for (int k = k0; k < k0 + 8; ++k) G[k] = src[min(lane + k * kStageLanes, deep_cnt - 1)];
+                    for (int k = k0; k < k0 + 8; ++k) Gr[k] = src[min(lane + k * kStageLanes, deep_cnt - 1)];
                 }
             }
         }
@@ -1019,12 +1021,15 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
 #pragma unroll
                         for (int k = k0; k < k0 + 8; ++k) {
                             const int idx = lane + k * kStageLanes;
-                            if (idx < deep_cnt) lfac[idx] = G[k];
+                            if (idx < deep_cnt) lfac[idx] = (double)Gr[k];
                         }
                     }
                 }
             }
         }
+        double G[NG];
+#pragma unroll
+        for (int k = 0; k < NG; ++k) G[k] = (double)Gr[k];
         lds_barrier();
         // in-place solve with the diagonal block of a level-0 run: y <- T_run^-1 y (first len nodes)
         auto run_solve0 = [&](double (&y)[RMAX][BS], int len) {
@@ -1605,6 +1610,16 @@ __global__ __launch_bounds__(kThreads) void k_kval(CsrDev M, const double* __res
 }
 
 // launch-overhead probes (debug timing only)
+// after a factorisation: keep the factors to float precision (in place, so every reader sees the same
+// operator) and write the 4-byte copy the LDS-resident chain kernel streams
+__global__ __launch_bounds__(kThreads) void k_fac_round(double* __restrict__ fac, float* __restrict__ fac32, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i >= n) return;
+    const float f = (float)fac[i];
+    fac32[i] = f;
+    fac[i] = (double)f;
+}
+
 __global__ void k_nop(int* sink) { if (sink && threadIdx.x == 9999) sink[0] = 1; }
 __global__ void k_nop_load(const int32_t* a, const int32_t* b2, int* sink) {
     const int p = a[blockIdx.x % 7];

@@ -45,7 +45,7 @@ class ScoreSettings(C.Structure):
         ("adaptive_rho_tol", C.c_double),
         ("chain_radix", C.c_int32), ("device", C.c_int32),
         ("use_graph", C.c_int32), ("polish", C.c_int32), ("polish_start", C.c_double),
-        ("polish_warmup", C.c_int32), ("verbose", C.c_int32), ("chain_split", C.c_int32),
+        ("polish_warmup", C.c_int32), ("verbose", C.c_int32), ("chain_split", C.c_int32), ("fac_fp32", C.c_int32),
     ]
 
 

@@ -164,12 +164,16 @@ def test_chain_preconditioner_is_the_exact_chain_inverse(radix, twin_lib):
     fg = make_manhattan(n_robots=3, n_poses=37, n_beacons=0, seed=21, p_range=0.0)
     qp = assemble(fg, "SOCP").qp
     assert qp.m == 0
-    st = dict(scale_iters=0, cg_iters=1, adaptive_cg=0, adaptive_rho=0, sigma=1e-3, alpha=1.0, chain_radix=radix)
-    sol = ConicSolver(qp, st, lib_path=twin_lib)
-    sol.reset()
-    out = sol.steps(1)[0]
     x_direct = spla.spsolve((qp.P + 1e-3 * sp.identity(qp.n)).tocsc(), -qp.q)
-    np.testing.assert_allclose(out.x, x_direct, rtol=1e-8, atol=1e-8 * np.abs(x_direct).max())
+    # fac_fp32 = 0: factors in double -- exact to rounding; 1 (default): factors kept to float precision, the
+    # inverse is exact to float eps times the conditioning of the chains
+    for fp32, tol in ((0, 1e-8), (1, 2e-4)):
+        st = dict(scale_iters=0, cg_iters=1, adaptive_cg=0, adaptive_rho=0, sigma=1e-3, alpha=1.0, chain_radix=radix, fac_fp32=fp32)
+        sol = ConicSolver(qp, st, lib_path=twin_lib)
+        sol.reset()
+        out = sol.steps(1)[0]
+        sol.close()
+        np.testing.assert_allclose(out.x, x_direct, rtol=tol, atol=tol * np.abs(x_direct).max())
 
 
 def test_equilibration_and_kkt_values(fixtures, twin_lib):

@@ -30,15 +30,21 @@ def _hip_only(hip_lib):
     assert lib.score_backend().decode() == "hip-gfx950"
 
 
+@pytest.mark.parametrize("fp32", [0, 1])
 @pytest.mark.parametrize("radix,cg", [(4, 2), (2, 1), (4, 3), (3, 4)])
 @pytest.mark.parametrize("name", ["manhattan", "synth_b"])
-def test_iterates_match_cpu_twin(name, radix, cg, fixtures, hip_lib, twin_lib):
+def test_iterates_match_cpu_twin(name, radix, cg, fp32, fixtures, hip_lib, twin_lib):
     """Kernel-level parity: after k ADMM iterations every internal vector of the
     HIP solver equals the CPU twin's (same algorithm, loops instead of kernels).
-    Differences are pure floating-point reassociation."""
+    fac_fp32 = 0 (chain factors in double): differences are pure floating-point reassociation, 1e-9.
+    fac_fp32 = 1 (the default: factors kept to float precision on both sides, the LDS-resident chain
+    kernel streams the 4-byte copies): host and device factorisations round a few entries to
+    neighbouring floats, so the iterates agree to float eps times the conditioning of the chain blocks:
+    2e-5 on the iterates (x itself to 1e-6), 1e-4 on the PCG internals."""
     _hip_only(hip_lib)
     qp = assemble(graph_by_name(name, fixtures), "SOCP").qp
-    st = dict(chain_radix=radix, cg_iters=cg, adaptive_cg=0, adaptive_rho=0, check_interval=5)
+    st = dict(chain_radix=radix, cg_iters=cg, adaptive_cg=0, adaptive_rho=0, check_interval=5, fac_fp32=fp32)
+    tol = 2e-5 if fp32 else 1e-9
     for use_graph in (0, 1):
         gpu = ConicSolver(qp, dict(use_graph=use_graph, **st), lib_path=hip_lib)
         cpu = ConicSolver(qp, st, lib_path=twin_lib)
@@ -49,11 +55,13 @@ def test_iterates_match_cpu_twin(name, radix, cg, fixtures, hip_lib, twin_lib):
             for v in VECS:
                 ga, gb = gpu.debug_get(v), cpu.debug_get(v)
                 scale = max(1.0, np.abs(gb).max())
-                assert np.abs(ga - gb).max() <= 1e-9 * scale, (v, k, use_graph, np.abs(ga - gb).max(), scale)
-            np.testing.assert_allclose(a.x, b.x, rtol=0, atol=1e-9 * max(1.0, np.abs(b.x).max()))
-            assert a.info["res_pri"] == pytest.approx(b.info["res_pri"], rel=1e-6, abs=1e-12)
-            assert a.info["res_dual"] == pytest.approx(b.info["res_dual"], rel=1e-6, abs=1e-9)
-            assert a.info["pobj"] == pytest.approx(b.info["pobj"], rel=1e-9, abs=1e-9)
+                # (fp32 factors: the PCG internals r, z, p, w are small differences of large terms -- 1e-4)
+                vtol = 1e-4 if (fp32 and v in ("r", "z", "p", "w")) else tol
+                assert np.abs(ga - gb).max() <= vtol * scale, (v, k, use_graph, np.abs(ga - gb).max(), scale)
+            np.testing.assert_allclose(a.x, b.x, rtol=0, atol=(1e-6 if fp32 else 1e-9) * max(1.0, np.abs(b.x).max()))
+            assert a.info["res_pri"] == pytest.approx(b.info["res_pri"], rel=1e-2 if fp32 else 1e-6, abs=1e-12)
+            assert a.info["res_dual"] == pytest.approx(b.info["res_dual"], rel=1e-2 if fp32 else 1e-6, abs=1e-2 if fp32 else 1e-9)
+            assert a.info["pobj"] == pytest.approx(b.info["pobj"], rel=tol, abs=tol)
         gpu.close(); cpu.close()
 
 
@@ -374,7 +382,7 @@ def test_newton_kernels_against_the_oracle(name, fixtures, hip_lib):
     fg = graph_by_name(name, fixtures)
     mdl = assemble(fg, "SOCP")
     d = mdl.dim
-    sol = ConicSolver(mdl.qp, dict(adaptive_rho=0))
+    sol = ConicSolver(mdl.qp, dict(adaptive_rho=0, fac_fp32=0))  # factors in double: the chain solve is exact
     sol.reset()
     sol.steps(15)
     assert sol.debug_get("polish_assemble_at_x").size == 1
@@ -435,6 +443,17 @@ def test_newton_kernels_against_the_oracle(name, fixtures, hip_lib):
     other = ~inchain
     np.testing.assert_allclose(z[other], -g[other] / Hm.diagonal()[other], rtol=1e-12, atol=1e-300)
     sol.close()
+    # the default (factors kept to float precision, 4-byte factor stream in the chain kernel): the same solve to
+    # float eps times the conditioning of the chain blocks
+    sol = ConicSolver(mdl.qp, dict(adaptive_rho=0))
+    sol.reset()
+    sol.steps(15)
+    assert sol.debug_get("polish_assemble_at_x").size == 1
+    z32, g32 = sol.debug_get("polish_prec_of_negg"), sol.debug_get("polish_g")
+    sol.close()
+    zs = np.abs(z[inchain]).max()
+    assert np.abs(z32 - z)[inchain].max() <= 1e-3 * zs, (np.abs(z32 - z)[inchain].max(), zs)
+    assert np.abs((T @ z32 + g32)[inchain]).max() <= 1e-4 * max(1.0, np.abs(g32).max())
 
 
 @pytest.mark.parametrize("name", ["manhattan", "synth_a"])
@@ -460,8 +479,9 @@ def test_intermediate_iterates_on_the_default_trajectory(name, fixtures, hip_lib
     for r in admm:
         b = cpu.steps(5)[0]
         assert b.info["iters"] == r.info["iters"]
-        assert r.info["pobj"] == pytest.approx(b.info["pobj"], rel=1e-9, abs=1e-9)
-        assert r.info["res_pri"] == pytest.approx(b.info["res_pri"], rel=1e-6, abs=1e-12)
+        # (default settings: chain factors kept to float precision on both sides -> float-eps agreement)
+        assert r.info["pobj"] == pytest.approx(b.info["pobj"], rel=1e-6, abs=1e-6)
+        assert r.info["res_pri"] == pytest.approx(b.info["res_pri"], rel=1e-3, abs=1e-9)
     cpu.close()
     # Newton snapshots: exactly feasible points whose objective decreases to the optimum
     obj = [r.info["pobj"] for r in newton]
