@@ -1983,6 +1983,13 @@ void score_assembled_free(score_assembled* a) { delete a; }
 int score_refine_create(const score_graph* g, const score_settings* s, score_refine** out) {
     try {
         if (!g || !out) throw std::runtime_error("null argument");
+        score_settings st;
+        if (s) st = *s; else score::default_settings(&st);
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            throw std::runtime_error("no HIP device available (the SCORE solver has no CPU fallback)");
+        if (st.device < 0 || st.device >= ndev) throw std::runtime_error("score_settings.device out of range");
+        DeviceGuard guard(st.device);  // the refinement's own buffers live on the handle's device too
         auto* r = new score_refine();
         try {
             r->create(*g, s);
