@@ -676,3 +676,10 @@ def test_linear_mode_and_refinement_on_the_gpu(hip_lib, twin_lib):
     x, info = dev.solver.solve(v, -(J.T @ r), rel_tol=1e-8, max_iters=4000, residual=True)
     dev.close()
     assert info["converged"] and info["rel_residual"] < 1e-5 and np.all(np.isfinite(x))
+
+
+def test_refinement_edge_cases_on_the_gpu(hip_lib):
+    from test_refine import check_refinement_edge_cases
+
+    _hip_only(hip_lib)
+    check_refinement_edge_cases(hip_lib)

@@ -153,3 +153,34 @@ def _noisy_truth(fg, seed=0):
     vals = compat.VariableValues(2, compat.ArrayDict(names, T), compat.ArrayDict([l.name for l in fg.landmark_variables], lms), None)
     return compat.SolverResults(variables=vals, total_time=0.0, solved=True, pose_chain_names=fg.get_pose_chain_names(),
                                 solver_cost=0.0, info={})
+
+
+def check_refinement_edge_cases(lib):
+    """No ranges at all; a two-pose graph; a single (pinned) pose with one landmark (no chain nodes: the
+    preconditioner is Jacobi only); linear mode without a chain hint."""
+    import scipy.sparse as sp
+
+    from score_amd.solver import LinearSolver
+
+    fg = make_manhattan(n_robots=2, n_poses=15, n_beacons=0, seed=1, p_range=0.0, n_loop_closures=2)
+    res = _noisy_truth(fg)
+    a, ia = refine_estimate(fg, res, lib_path=lib)
+    b, ib = refine_estimate(fg, res, linear_solver="scipy")
+    assert ia["cost_final"] == pytest.approx(ib["cost_final"], rel=1e-9) and ia["iterations"] == ib["iterations"]
+    fg = make_manhattan(n_robots=1, n_poses=2, n_beacons=1, seed=2, p_range=1.0)
+    a, ia = refine_estimate(fg, _noisy_truth(fg), lib_path=lib)
+    assert ia["cost_final"] < 1e-18
+    fg = make_manhattan(n_robots=1, n_poses=1, n_beacons=1, seed=3, p_range=1.0)
+    assert len(fg.range_measurements) == 1
+    a, ia = refine_estimate(fg, _noisy_truth(fg), lib_path=lib)
+    assert ia["cost_final"] < 1e-18 and ia["linear_solves"] >= 1
+    K = sp.csr_matrix(np.array([[4.0, 1, 0], [1, 3, 0], [0, 0, 2]]))
+    ls = LinearSolver(K, [0], [], 0, lib_path=lib)
+    x, info = ls.solve(K.data, np.array([1.0, 2, 3]), rel_tol=1e-12)
+    ls.close()
+    assert info["converged"]
+    np.testing.assert_allclose(x, np.linalg.solve(K.toarray(), [1.0, 2, 3]), rtol=1e-10)
+
+
+def test_refinement_edge_cases(twin_lib):
+    check_refinement_edge_cases(twin_lib)
