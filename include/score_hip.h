@@ -101,10 +101,12 @@ typedef struct score_settings {
                                   chain over 2-4 workgroups (k_prec_wave) when the whole launch fits the device at
                                   once -- correct and tested, measured 10-15 % SLOWER than the default on the
                                   headline problem, kept as an option                      */
-    int32_t fac_fp32;          /* 1 (default): the chain factors are kept to float precision (rounded after every
-                                  factorisation) and the LDS-resident chain kernel reads them as 4-byte values --
-                                  half the bytes of the kernel that owns the iteration; M^-1 stays a fixed linear
-                                  operator, PCG converges to the same tolerances.  0: double throughout.          */
+    int32_t fac_fp32;          /* chain factors kept to float precision (rounded after every factorisation) and
+                                  streamed as 4-byte values by the LDS-resident chain kernel -- half the bytes of the
+                                  kernel that owns the iteration; M^-1 stays a fixed linear operator, PCG converges
+                                  to the same tolerances.  1 (default): the ADMM loop's factors (of K);  2: the Newton
+                                  polish's too (same iteration counts on the BASELINE sizes, ~10 % more Newton PCG
+                                  iterations on small ill-conditioned graphs);  0: double throughout.            */
 } score_settings;
 
 enum {

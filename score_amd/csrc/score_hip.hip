@@ -307,7 +307,8 @@ struct HipBackend {
     DevBuf<double> pw_part, rz_part0, rz_part1, rz_meas0, rz_meas1, pres_part, dres_part;
     // ---- semismooth-Newton polish (score_polish*.hpp) ----
     DevBuf<float> fac32, q_fac32;  // float copies of the chain factors (ADMM / Newton), see k_fac_round
-    bool use_fac32 = false;
+    bool use_fac32 = false;     // ADMM-loop factors (K)
+    bool newton_fac32 = false;  // Newton-polish factors (H): fac_fp32 = 2 only, see DESIGN.md section 4
     PolishData Q;
     std::future<void> polish_build;  // build_polish runs beside the uploads of init()
     CsrBufs Hm;
@@ -532,6 +533,7 @@ struct HipBackend {
         kposd.upload(h.pos_diag); kposs.upload(h.pos_sub); kdiagpos.upload(h.diag_kpos);
         fac.alloc(h.fac_doubles); fac.zero(stream);  // separator slots of the spike region are never written (nor used)
         use_fac32 = st.fac_fp32 != 0;
+        newton_fac32 = st.fac_fp32 >= 2;
         if (use_fac32) { fac32.alloc(h.fac_doubles); fac32.zero(stream); }
         dinv.alloc(h.dinv.size()); rho.upload(h.rho);
         q_work.alloc((size_t)std::max<int64_t>(1, h.scratch_nodes) * 2 * std::max(1, h.bs * h.bs));
@@ -626,8 +628,9 @@ struct HipBackend {
         else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
         else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
         else hipLaunchKernelGGL(k_factor<4>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
-        if (use_fac32 && H->fac_doubles > 0) {
-            float* shadow = (fa.fac == q_fac.d) ? q_fac32.d : fac32.d;
+        const bool newton_set = (fa.fac == q_fac.d) && q_fac.d;
+        if ((newton_set ? newton_fac32 : use_fac32) && H->fac_doubles > 0) {
+            float* shadow = newton_set ? q_fac32.d : fac32.d;
             const int64_t nf = (int64_t)H->fac_doubles;
             hipLaunchKernelGGL(k_fac_round, dim3((unsigned)((nf + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, fa.fac, shadow, nf);
         }
@@ -748,7 +751,9 @@ struct HipBackend {
     void launch_prec(const PrecArgs& pa_in, int slot = -1) {
         if (n_prec == 0) return;
         PrecArgs pa = pa_in;
-        pa.fac32 = (pa.fac == q_fac.d) ? q_fac32.d : fac32.d;  // the float copy of whichever factor set is applied
+        const bool newton_set = (pa.fac == q_fac.d) && q_fac.d;
+        pa.fac32 = newton_set ? q_fac32.d : fac32.d;  // the float copy of whichever factor set is applied
+        const bool use_fac32 = newton_set ? newton_fac32 : this->use_fac32;
         if (split.active) {
             WaveArgs wa{};
             wa.p = pa;
@@ -1232,7 +1237,7 @@ struct HipBackend {
         q_g.alloc(h.n_tot); q_delta.alloc(h.n_tot); q_dummy.alloc(h.n_tot); q_negg.alloc(h.n_tot);
         q_fac.alloc(h.fac_doubles); q_dinv.alloc(h.dinv.size());
         q_fac.zero(stream);  // separator slots of the spike region are never written (nor used)
-        if (use_fac32) { q_fac32.alloc(h.fac_doubles); q_fac32.zero(stream); }
+        if (newton_fac32) { q_fac32.alloc(h.fac_doubles); q_fac32.zero(stream); }
         n_gd = std::max<size_t>((h.n_tot + kThreads - 1) / kThreads, (size_t)Hm.nblocks);
         q_pw.alloc(Hm.nblocks);
         {

@@ -443,9 +443,9 @@ def test_newton_kernels_against_the_oracle(name, fixtures, hip_lib):
     other = ~inchain
     np.testing.assert_allclose(z[other], -g[other] / Hm.diagonal()[other], rtol=1e-12, atol=1e-300)
     sol.close()
-    # the default (factors kept to float precision, 4-byte factor stream in the chain kernel): the same solve to
-    # float eps times the conditioning of the chain blocks
-    sol = ConicSolver(mdl.qp, dict(adaptive_rho=0))
+    # fac_fp32 = 2 (Newton factors kept to float precision too, 4-byte factor stream in the chain kernel): the same
+    # solve to float eps times the conditioning of the chain blocks
+    sol = ConicSolver(mdl.qp, dict(adaptive_rho=0, fac_fp32=2))
     sol.reset()
     sol.steps(15)
     assert sol.debug_get("polish_assemble_at_x").size == 1
