@@ -26,6 +26,7 @@
 #include <vector>
 
 #include "../../include/score_hip.h"
+#include "score_host.hpp"
 
 #if defined(__HIPCC__)
 #define SCORE_GN_HD __host__ __device__ __forceinline__
@@ -176,63 +177,136 @@ inline void gn_build(const score_graph& g, GnProblem& P) {
     for (int64_t e = 0; e < g.n_lprior; ++e)
         if (P.pri_l[e] < 0 || P.pri_l[e] >= P.Nl) throw std::runtime_error("score_refine: landmark prior out of range");
 
-    // (row, col, slot) triplets of every block entry that lands on two unknowns
-    struct Trip { int32_t row, col, slot; };
-    std::vector<Trip> trips;
-    trips.reserve((size_t)(36 * g.n_rel + 16 * g.n_rng + 2 * g.n_lprior + P.n));
-    std::vector<std::vector<int32_t>> glist((size_t)P.n);
-    for (int64_t e = 0; e < g.n_rel; ++e) {
-        const int64_t ci = P.pose_col(P.rel_i[e]), cj = P.pose_col(P.rel_j[e]);
-        int64_t L[6];
-        for (int a = 0; a < 3; ++a) { L[a] = ci < 0 ? -1 : ci + a; L[3 + a] = cj < 0 ? -1 : cj + a; }
-        for (int a = 0; a < 6; ++a) {
-            if (L[a] < 0) continue;
-            glist[(size_t)L[a]].push_back((int32_t)(6 * e + a));
-            for (int b = 0; b < 6; ++b)
-                if (L[b] >= 0) trips.push_back(Trip{(int32_t)L[a], (int32_t)L[b], (int32_t)(36 * e + a * 6 + b)});
-        }
-    }
+    // Every block entry that lands on two unknowns is a (row, col, slot) triplet.  The measurement loops run
+    // twice over the same code -- a counting pass sizes every row, a filling pass writes (col, slot) pairs in
+    // measurement order -- then the rows are ordered by column and merged in parallel (stable: an entry sums
+    // its slots in measurement order on every backend).  Gradient lists: the same without columns.
     const int64_t hb_rng = 36 * g.n_rel, gb_rng = 6 * g.n_rel;
-    for (int64_t r = 0; r < g.n_rng; ++r) {
-        const int64_t ca = P.point_col(P.rng_a[r]), cb = P.point_col(P.rng_b[r]);
-        const int64_t L[4] = {ca < 0 ? -1 : ca, ca < 0 ? -1 : ca + 1, cb < 0 ? -1 : cb, cb < 0 ? -1 : cb + 1};
-        for (int a = 0; a < 4; ++a) {
-            if (L[a] < 0) continue;
-            glist[(size_t)L[a]].push_back((int32_t)(gb_rng + 4 * r + a));
-            for (int b = 0; b < 4; ++b)
-                if (L[b] >= 0) trips.push_back(Trip{(int32_t)L[a], (int32_t)L[b], (int32_t)(hb_rng + 16 * r + a * 4 + b)});
-        }
-    }
     const int64_t hb_pri = hb_rng + 16 * g.n_rng, gb_pri = gb_rng + 4 * g.n_rng;
-    for (int64_t e = 0; e < g.n_lprior; ++e) {
-        const int64_t c = 3 * (P.Np - 1) + 2 * (int64_t)P.pri_l[e];
-        for (int a = 0; a < 2; ++a) {
-            glist[(size_t)(c + a)].push_back((int32_t)(gb_pri + 2 * e + a));
-            trips.push_back(Trip{(int32_t)(c + a), (int32_t)(c + a), (int32_t)(hb_pri + 2 * e + a)});
+    std::vector<int32_t> hcnt((size_t)P.n + 1, 0), gcnt((size_t)P.n + 1, 0), hfill, gfill, tcol, tslot;
+    bool filling = false;
+    auto addH = [&](int64_t row, int64_t col, int64_t slot) {
+        if (!filling) { ++hcnt[(size_t)row + 1]; return; }
+        const int32_t pos = hfill[(size_t)row]++;
+        tcol[(size_t)pos] = (int32_t)col;
+        tslot[(size_t)pos] = (int32_t)slot;
+    };
+    auto addG = [&](int64_t row, int64_t slot) {
+        if (!filling) { ++gcnt[(size_t)row + 1]; return; }
+        P.gc_slot[(size_t)gfill[(size_t)row]++] = (int32_t)slot;
+    };
+    auto measurements = [&]() {
+        for (int64_t e = 0; e < g.n_rel; ++e) {
+            const int64_t ci = P.pose_col(P.rel_i[e]), cj = P.pose_col(P.rel_j[e]);
+            int64_t L[6];
+            for (int a = 0; a < 3; ++a) { L[a] = ci < 0 ? -1 : ci + a; L[3 + a] = cj < 0 ? -1 : cj + a; }
+            for (int a = 0; a < 6; ++a) {
+                if (L[a] < 0) continue;
+                addG(L[a], 6 * e + a);
+                for (int b = 0; b < 6; ++b)
+                    if (L[b] >= 0) addH(L[a], L[b], 36 * e + a * 6 + b);
+            }
         }
-    }
-    for (int64_t i = 0; i < P.n; ++i) trips.push_back(Trip{(int32_t)i, (int32_t)i, -1});  // the diagonal always exists
-    std::stable_sort(trips.begin(), trips.end(), [](const Trip& x, const Trip& y) {
-        return x.row != y.row ? x.row < y.row : x.col < y.col;
-    });
-    P.hptr.assign((size_t)P.n + 1, 0);
-    P.hcol.clear(); P.hc_ptr.assign(1, 0); P.hc_slot.clear();
+        for (int64_t r = 0; r < g.n_rng; ++r) {
+            const int64_t ca = P.point_col(P.rng_a[r]), cb = P.point_col(P.rng_b[r]);
+            const int64_t L[4] = {ca < 0 ? -1 : ca, ca < 0 ? -1 : ca + 1, cb < 0 ? -1 : cb, cb < 0 ? -1 : cb + 1};
+            for (int a = 0; a < 4; ++a) {
+                if (L[a] < 0) continue;
+                addG(L[a], gb_rng + 4 * r + a);
+                for (int b = 0; b < 4; ++b)
+                    if (L[b] >= 0) addH(L[a], L[b], hb_rng + 16 * r + a * 4 + b);
+            }
+        }
+        for (int64_t e = 0; e < g.n_lprior; ++e) {
+            const int64_t c = 3 * (P.Np - 1) + 2 * (int64_t)P.pri_l[e];
+            for (int a = 0; a < 2; ++a) {
+                addG(c + a, gb_pri + 2 * e + a);
+                addH(c + a, c + a, hb_pri + 2 * e + a);
+            }
+        }
+        for (int64_t i = 0; i < P.n; ++i) addH(i, i, -1);  // the diagonal always exists
+    };
+    measurements();  // counting pass
+    for (int64_t i = 0; i < P.n; ++i) { hcnt[(size_t)i + 1] += hcnt[(size_t)i]; gcnt[(size_t)i + 1] += gcnt[(size_t)i]; }
+    tcol.resize((size_t)hcnt[(size_t)P.n]); tslot.resize((size_t)hcnt[(size_t)P.n]);
+    P.gc_ptr = gcnt;
+    P.gc_slot.assign((size_t)gcnt[(size_t)P.n], 0);
+    hfill.assign(hcnt.begin(), hcnt.end() - 1);
+    gfill.assign(gcnt.begin(), gcnt.end() - 1);
+    filling = true;
+    measurements();  // filling pass
+    // rows -> pattern + contribution lists, part by part
+    struct Part { std::vector<int32_t> col, ent_len, slot, row_len; int64_t i0 = 0; };
+    const int T = parallel_parts(P.n, 4096);
+    std::vector<Part> parts((size_t)std::max(1, T));
     P.diag_pos.assign((size_t)P.n, -1);
-    size_t k = 0;
-    while (k < trips.size()) {
-        const int32_t row = trips[k].row, col = trips[k].col;
-        if (row == col) P.diag_pos[(size_t)row] = (int32_t)P.hcol.size();
-        P.hcol.push_back(col);
-        for (; k < trips.size() && trips[k].row == row && trips[k].col == col; ++k)
-            if (trips[k].slot >= 0) P.hc_slot.push_back(trips[k].slot);
-        P.hc_ptr.push_back((int32_t)P.hc_slot.size());
-        P.hptr[(size_t)row + 1] = (int32_t)P.hcol.size();
-    }
-    for (int64_t i = 0; i < P.n; ++i) P.hptr[(size_t)i + 1] = std::max(P.hptr[(size_t)i + 1], P.hptr[(size_t)i]);
-    P.gc_ptr.assign(1, 0); P.gc_slot.clear();
-    for (int64_t i = 0; i < P.n; ++i) {
-        P.gc_slot.insert(P.gc_slot.end(), glist[(size_t)i].begin(), glist[(size_t)i].end());
-        P.gc_ptr.push_back((int32_t)P.gc_slot.size());
+    std::vector<int32_t> diag_rel((size_t)P.n, -1);  // position of the diagonal within its part
+    auto row_weight = [&](int64_t i) {
+        const double w = (double)(hcnt[(size_t)i + 1] - hcnt[(size_t)i]);
+        return w > 64.0 ? 4.0 * w : w;
+    };
+    parallel_ranges_balanced(P.n, 4096, row_weight, [&](int t, int64_t i0, int64_t i1) {
+        Part W;
+        W.i0 = i0;
+        W.col.reserve((size_t)(hcnt[(size_t)i1] - hcnt[(size_t)i0]));
+        W.slot.reserve((size_t)(hcnt[(size_t)i1] - hcnt[(size_t)i0]));
+        struct Ent { int32_t col, slot; };
+        std::vector<Ent> L;
+        for (int64_t i = i0; i < i1; ++i) {
+            L.clear();
+            for (int32_t k = hcnt[(size_t)i]; k < hcnt[(size_t)i + 1]; ++k) L.push_back(Ent{tcol[(size_t)k], tslot[(size_t)k]});
+            if (L.size() > 64) {
+                std::stable_sort(L.begin(), L.end(), [](const Ent& x, const Ent& y) { return x.col < y.col; });
+            } else {
+                for (size_t x = 1; x < L.size(); ++x) {
+                    const Ent e = L[x];
+                    size_t y = x;
+                    while (y > 0 && L[y - 1].col > e.col) { L[y] = L[y - 1]; --y; }
+                    L[y] = e;
+                }
+            }
+            int32_t nent = 0;
+            size_t k = 0;
+            while (k < L.size()) {
+                const int32_t col = L[k].col;
+                int32_t ns = 0;
+                if (col == (int32_t)i) diag_rel[(size_t)i] = (int32_t)W.col.size();
+                for (; k < L.size() && L[k].col == col; ++k)
+                    if (L[k].slot >= 0) { W.slot.push_back(L[k].slot); ++ns; }
+                W.col.push_back(col);
+                W.ent_len.push_back(ns);
+                ++nent;
+            }
+            W.row_len.push_back(nent);
+        }
+        parts[(size_t)t] = std::move(W);
+    });
+    {
+        std::vector<size_t> eoff(parts.size() + 1, 0), soff(parts.size() + 1, 0);
+        for (size_t k = 0; k < parts.size(); ++k) {
+            eoff[k + 1] = eoff[k] + parts[k].col.size();
+            soff[k + 1] = soff[k] + parts[k].slot.size();
+        }
+        P.hptr.assign((size_t)P.n + 1, 0);
+        P.hcol.resize(eoff.back());
+        P.hc_ptr.assign(eoff.back() + 1, 0);
+        P.hc_slot.resize(soff.back());
+        parallel_ranges((int64_t)parts.size(), 1, [&](int, int64_t k0, int64_t k1) {
+            for (int64_t k = k0; k < k1; ++k) {
+                const Part& W = parts[(size_t)k];
+                std::copy(W.col.begin(), W.col.end(), P.hcol.begin() + (std::ptrdiff_t)eoff[(size_t)k]);
+                std::copy(W.slot.begin(), W.slot.end(), P.hc_slot.begin() + (std::ptrdiff_t)soff[(size_t)k]);
+                int32_t acc = (int32_t)eoff[(size_t)k];
+                for (size_t r = 0; r < W.row_len.size(); ++r) {
+                    const int64_t i = W.i0 + (int64_t)r;
+                    P.diag_pos[(size_t)i] = (int32_t)eoff[(size_t)k] + diag_rel[(size_t)i];
+                    acc += W.row_len[r];
+                    P.hptr[(size_t)i + 1] = acc;
+                }
+                int32_t sacc = (int32_t)soff[(size_t)k];
+                for (size_t e = 0; e < W.ent_len.size(); ++e) { sacc += W.ent_len[e]; P.hc_ptr[eoff[(size_t)k] + e + 1] = sacc; }
+            }
+        });
     }
     // chain hint: one chain per robot, node = pose (theta, x, y); the pinned pose is not a node
     P.chain_ptr.assign(1, 0);

@@ -1732,13 +1732,16 @@ struct score_refine {
     }
     void create(const score_graph& g, const score_settings* s) {
         const double t0 = score::now_ms();
+        score::PhaseTimer pt(s && s->verbose != 0);
         score::gn_build(g, P);
+        pt.mark("refine: pattern + contribution lists");
         score_problem pat{};
         pat.n = (int32_t)P.n; pat.m = 0;
         pat.P_rowptr = P.hptr.data(); pat.P_col = P.hcol.data();
         pat.block_size = 3; pat.n_chains = (int32_t)P.chain_ptr.size() - 1;
         pat.chain_ptr = P.chain_ptr.data(); pat.node_first_col = P.node_first_col.data();
         if (score_linear_create(&pat, s, &lin) != 0) throw std::runtime_error(g_err);
+        pt.mark("refine: linear-mode handle");
         device = lin->solver.st.device;
         tl_copy_stream = stream();
         rel_i.upload(P.rel_i); rel_j.upload(P.rel_j); rng_a.upload(P.rng_a); rng_b.upload(P.rng_b); pri_l.upload(P.pri_l);
@@ -1755,6 +1758,7 @@ struct score_refine {
         n_hblocks = (int)std::max<int64_t>(1, ((int64_t)P.hcol.size() + kThreads - 1) / kThreads);
         cost_part.alloc((size_t)n_mblocks); gmax_part.alloc((size_t)n_ublocks);
         be().linear_buffers(lin->solver.H);
+        pt.mark("refine: uploads + buffers");
         setup_ms = score::now_ms() - t0;
     }
     ~score_refine() { if (lin) score_destroy(lin); }

@@ -154,15 +154,19 @@ class _Problem:
         return float(r @ r)
 
 
+def _stacked(mapping, names, shape):
+    """Values of ``mapping`` in the order of ``names`` as one array: without a Python loop when the mapping is
+    an ArrayDict over the same names (what solve_score returns)."""
+    if isinstance(mapping, compat.ArrayDict) and len(mapping) == len(names) and list(mapping.keys()) == list(names):
+        return np.asarray(mapping.array, dtype=np.float64).reshape((len(names),) + shape)
+    return np.array([np.asarray(mapping[nm], dtype=np.float64) for nm in names], dtype=np.float64).reshape((len(names),) + shape)
+
+
 def _initial_point(prob: _Problem, results) -> np.ndarray:
-    names = prob.a["pose_names"]
-    th = np.empty(prob.Np)
-    t = np.empty((prob.Np, 2))
-    for i, nm in enumerate(names):
-        T = results.poses[nm]
-        th[i] = np.arctan2(T[1, 0], T[0, 0])
-        t[i] = T[:2, 2]
-    lm = np.array([results.landmarks[nm] for nm in prob.a["landmark_names"]]).reshape(-1, 2)
+    T = _stacked(results.poses, prob.a["pose_names"], (3, 3))
+    th = np.arctan2(T[:, 1, 0], T[:, 0, 0])
+    t = T[:, :2, 2].copy()
+    lm = _stacked(results.landmarks, prob.a["landmark_names"], (2,))
     prob.pin = (float(th[0]), t[0].copy())
     return prob.pack(th, t, lm)
 
