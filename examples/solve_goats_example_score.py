@@ -13,6 +13,7 @@ from score.solve_score import solve_score  # noqa: E402
 from score.utils.gurobi_utils import QCQP_RELAXATION  # noqa: E402
 from score.utils.solver_utils import ScoreSolverParams  # noqa: E402
 from score_amd.io import load_fg_npz, load_pyfg_pickle, save_to_tum  # noqa: E402
+from score_amd.refine import refine_estimate  # noqa: E402
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
@@ -24,3 +25,9 @@ if __name__ == "__main__":
     print(f"solved={score_result.solved} objective={score_result.solver_cost:.6f} "
           f"iterations={score_result.info['iters']} time={score_result.total_time:.3f}s")
     print("trajectory written to", save_to_tum(score_result, "/tmp/goats_score"))
+    # the step the reference's README describes next (README.md:63-67): SCORE's estimate initialises a local
+    # maximum-likelihood refinement -- here Gauss-Newton on SE(2), on the same GPU
+    refined, info = refine_estimate(goats_pyfg, score_result)
+    print(f"refined: cost {info['cost_initial']:.4f} -> {info['cost_final']:.4f} in {info['iterations']} iterations "
+          f"({info['pcg_iters']} PCG iterations, {info['solve_ms']:.1f} ms)")
+    print("refined trajectory written to", save_to_tum(refined, "/tmp/goats_refined"))

@@ -507,6 +507,12 @@ def test_goats_example_script_runs_on_the_pickle(hip_lib, tmp_path):
     assert "solved=True" in out.stdout and "objective=330.48" in out.stdout, out.stdout
     est = load_tum("/tmp/goats_score_A.tum")
     assert est.shape == load_tum(os.path.join(GOLDEN, "gt_traj_A.tum")).shape
+    # ... followed by the local refinement on the same GPU, which can only lower the maximum-likelihood cost
+    line = [l for l in out.stdout.splitlines() if l.startswith("refined: cost")]
+    assert line, out.stdout
+    c0, c1 = (float(x) for x in line[0].split("cost")[1].split("in")[0].split("->"))
+    assert c1 <= c0
+    assert load_tum("/tmp/goats_refined_A.tum").shape == est.shape
 
 
 @pytest.mark.parametrize("n_poses", [255, 300, 640, 1000, 1023])
