@@ -129,12 +129,16 @@ struct CpuBackend {
         for (int64_t i = 0; i < n; ++i) p[i] = z[i];
         const double ref = rz * rel_tol * rel_tol;
         int used = 0;
+        double beta_prev = 0.0;
         bool ok = !(rz > 0.0);
         while (!ok) {
             if (used > 0 && !(rz > ref)) { ok = true; break; }  // the test the device gate makes before a STEP
             if (used >= max_iters) break;
             double pw = 0.0;
-            for (int64_t i = 0; i < n; ++i) { w[i] = row_dot(h.K, i, p.data()); pw += p[i] * w[i]; }
+            for (int64_t i = 0; i < n; ++i) {
+                w[i] = (used == 0) ? row_dot(h.K, i, p.data()) : row_dot(h.K, i, z.data()) + beta_prev * w[i];
+                pw += p[i] * w[i];
+            }
             const double a = pw > 0.0 ? rz / pw : 0.0;
             for (int64_t i = 0; i < n; ++i) { xs[i] += a * p[i]; r[i] -= a * w[i]; }
             ++used;
@@ -142,6 +146,7 @@ struct CpuBackend {
             precond(0, rz_new);
             const double beta = rz > 0.0 ? rz_new / rz : 0.0;
             for (int64_t i = 0; i < n; ++i) p[i] = z[i] + beta * p[i];
+            beta_prev = beta;
             rz = rz_new;
         }
         for (int64_t i = 0; i < n; ++i) x[i] = xs[i];
@@ -164,11 +169,14 @@ struct CpuBackend {
         precond(pi, rz);
         const double rz_init = rz;
         for (int64_t i = x0; i < x1; ++i) p[i] = z[i];
+        double beta_prev = 0.0;
         for (int j = 1; j <= cg_iters; ++j) {
             double pw = 0;
+            // first product of a solve: w = K p.  Later ones: K (z + beta p_old) = K z + beta w_old (what the KPB
+            // kernel computes: one gather per nonzero)
 #pragma omp parallel for reduction(+ : pw) schedule(static)
             for (int64_t i = x0; i < x1; ++i) {
-                w[i] = row_dot(h.K, i, p.data());
+                w[i] = (j == 1) ? row_dot(h.K, i, p.data()) : row_dot(h.K, i, z.data()) + beta_prev * w[i];
                 pw += p[i] * w[i];
             }
             const double a = pw > 0 ? rz / pw : 0.0;
@@ -189,6 +197,7 @@ struct CpuBackend {
                 const double beta = rz > 0 ? rz2 / rz : 0.0;
 #pragma omp parallel for schedule(static)
                 for (int64_t i = x0; i < x1; ++i) p[i] = z[i] + beta * p[i];
+                beta_prev = beta;
                 rz = rz2;
             }
         }

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         finish_beta();  // uniform: lanes beyond the row's end never enter the sweep
         for (int kb = k0 + t; kb < k1; kb += kThreads * kLongUnroll) {
             int32_t c[kLongUnroll];
-            double v[kLongUnroll], g[kLongUnroll], g2[kLongUnroll];
+            double v[kLongUnroll], g[kLongUnroll];
 #pragma unroll
             for (int u = 0; u < kLongUnroll; ++u) {
                 const int k = min(kb + u * kThreads, k1 - 1);
@@ -241,12 +241,11 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
             }
 #pragma unroll
             for (int u = 0; u < kLongUnroll; ++u) {
-                if (MODE == MODE_KPB) { g[u] = a.z[c[u]]; g2[u] = a.p[c[u]]; } else { g[u] = xin[c[u]]; }
+                if (MODE == MODE_KPB) g[u] = a.z[c[u]]; else g[u] = xin[c[u]];
             }
 #pragma unroll
             for (int u = 0; u < kLongUnroll; ++u) {
                 const int k = kb + u * kThreads;
-                if (MODE == MODE_KPB) g[u] += beta * g2[u];
                 const double pr = (k < k1) ? v[u] * g[u] : 0.0;
                 if ((MODE == MODE_DRES || MODE == MODE_GRAD) && k >= split) acc2 += pr; else acc += pr;
             }
@@ -259,7 +258,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         // Loads are unconditional on clamped indices (a predicated load becomes a branch
         // and serialises the memory pipeline); only the LDS stores are predicated.
         int32_t c[kUnroll];
-        double v[kUnroll], g[kUnroll], g2[kUnroll];
+        double v[kUnroll], g[kUnroll];
         const int klast = max(nn - 1, 0);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
@@ -269,13 +268,12 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            if (MODE == MODE_KPB) { g[u] = a.z[c[u]]; g2[u] = a.p[c[u]]; } else { g[u] = xin[c[u]]; }
+            if (MODE == MODE_KPB) g[u] = a.z[c[u]]; else g[u] = xin[c[u]];
         }
         finish_beta();
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const int k = t + u * kThreads;
-            if (MODE == MODE_KPB) g[u] += beta * g2[u];
             if (k < nn) prod[kpad(k)] = v[u] * g[u];
         }
         if (r0 + t <= r1) srow[t] = my_ptr - k0;
@@ -311,14 +309,17 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     } else if (MODE == MODE_KP || MODE == MODE_KPB) {
         double local = 0.0;
         if (has_row) {
-            a.w[row] = sum;
             double pi;
             if (MODE == MODE_KPB) {
+                // K (z + beta p) = K z + beta w_old: one gather (z) per nonzero instead of two; w_old = K p_old is this
+                // row's own entry.  (The first product of a solve is always the direct one, MODE_KP.)
+                sum += beta * a.w[row];
                 pi = a.z[row] + beta * a.p[row];
                 a.p_out[row] = pi;
             } else {
                 pi = a.p[row];
             }
+            a.w[row] = sum;
             local = pi * sum;
         }
         const double tot = block_sum(local, red);
