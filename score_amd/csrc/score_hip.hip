@@ -1744,6 +1744,10 @@ struct score_refine {
         pt.mark("refine: linear-mode handle");
         device = lin->solver.st.device;
         tl_copy_stream = stream();
+        struct ArenaScope {  // the refinement's buffers come from (and go back with) the handle's arena
+            explicit ArenaScope(DevArena* a) { tl_arena = a; }
+            ~ArenaScope() { tl_arena = nullptr; }
+        } arena_scope(&be().arena);
         rel_i.upload(P.rel_i); rel_j.upload(P.rel_j); rng_a.upload(P.rng_a); rng_b.upload(P.rng_b); pri_l.upload(P.pri_l);
         rel_t.upload(P.rel_t); rel_R.upload(P.rel_R); rel_kappa.upload(P.rel_kappa); rel_tau.upload(P.rel_tau);
         rng_dist.upload(P.rng_dist); rng_prec.upload(P.rng_prec); pri_t.upload(P.pri_t); pri_prec.upload(P.pri_prec);
