@@ -299,6 +299,8 @@ struct HipBackend {
     DevBuf<int32_t> kposd, kposs, kdiagpos;  // K.val positions of the chain blocks / Jacobi diagonals
     DevBuf<int32_t> done, cone_row, cone_dim, cone_type, cone_block_first, cone_block_prob;
     DevBuf<int4> cone_meta;
+    DevBuf<int32_t> cone_cols;  // 8 per cone (two int4)
+    DevBuf<double> cone_vals;   // 8 per cone (four double2)
     DevBuf<int32_t> node_col, diag_cols, prec_part_ptr, kblk_part_ptr;
     DevBuf<PrecWork> prec_work;
     DevBuf<ChainDesc> chains;
@@ -444,6 +446,25 @@ struct HipBackend {
                 meta[2 * c + 1] = make_int4(ptr(1), ptr(2), ptr(3), ptr(4));
             }
             cone_meta.upload(meta);
+            // the entries of the small cones again, by cone index (see ConeArgs::cone_cols)
+            std::vector<int32_t> pc(8 * h.cone_row.size(), 0);
+            std::vector<double> pv(8 * h.cone_row.size(), 0.0);
+            for (size_t c = 0; c < h.cone_row.size(); ++c) {
+                const int row = h.cone_row[c], dim = h.cone_dim[c];
+                bool small = dim <= kSmallCone;
+                for (int k = 0; k < std::min(dim, (int)kSmallCone) && small; ++k) small = (h.A.ptr[row + k + 1] - h.A.ptr[row + k]) <= kConeRowNnz;
+                int32_t safe = h.A.ptr[row] < h.A.ptr[row + dim] ? h.A.col[h.A.ptr[row]] : 0;  // any valid column
+                for (int k = 0; k < kSmallCone; ++k)
+                    for (int e = 0; e < kConeRowNnz; ++e) {
+                        const size_t o = 8 * c + (size_t)k * kConeRowNnz + e;
+                        pc[o] = safe;
+                        if (small && k < dim && h.A.ptr[row + k] + e < h.A.ptr[row + k + 1]) {
+                            pc[o] = h.A.col[h.A.ptr[row + k] + e];
+                            pv[o] = h.A.val[h.A.ptr[row + k] + e];
+                        }
+                    }
+            }
+            cone_cols.upload(pc); cone_vals.upload(pv);
         }
         n_cone_blocks = (int)h.cone_block_prob.size();
         node_col.upload(h.node_col); diag_cols.upload(h.diag_cols);
@@ -640,6 +661,8 @@ struct HipBackend {
         ConeArgs a{};
         a.A_ptr = A_ptr.d; a.A_col = A_col.d; a.A_val = A_val.d;
         a.cone_row = cone_row.d; a.cone_dim = cone_dim.d; a.cone_type = cone_type.d; a.cone_meta = cone_meta.d;
+        a.cone_cols = (const int4*)cone_cols.d; a.cone_vals = (const double2*)cone_vals.d;
+        a.uniform_cones = (H->count == 1) ? (int)H->cone_row.size() : 0;
         a.block_first = cone_block_first.d; a.block_prob = cone_block_prob.d;
         a.done = done.d; a.rho = rho.d; a.b = b.d; a.xt = gathered;
         a.s = s.d; a.y = xy.d + H->n_tot; a.u = xtu.d + H->n_tot;

@@ -1363,6 +1363,12 @@ struct ConeArgs {
     const int32_t* cone_dim;
     const int32_t* cone_type;
     const int4* cone_meta;  // per cone: {row, dim, type, ptr[row]}, {ptr[row+1..row+4]} (clamped at row+dim)
+    // small cones (<= kSmallCone rows of <= kConeRowNnz entries: every SCORE cone): the entries of A again, by cone
+    // index -- two int4 of columns (missing entries repeat a valid column) and four double2 of values (missing: 0),
+    // so that they are requested together with the cone record instead of after it
+    const int4* cone_cols;
+    const double2* cone_vals;
+    int uniform_cones;      // > 0: one problem, block b holds cones [b * kConesPerBlock, ...) of uniform_cones
     const int32_t* block_first;
     const int32_t* block_prob;
     const int32_t* done;
@@ -1428,12 +1434,15 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
             if (threadIdx.x == 0) a.step_out[prob] = step;
         }
     };
-    const int c_end = a.block_first[b + 1];
-    const int c = a.block_first[b] + threadIdx.x;
+    // (one problem: the block boundaries are arithmetic -- one dependent load less)
+    const int c_end = a.uniform_cones > 0 ? min((b + 1) * kConesPerBlock, a.uniform_cones) : a.block_first[b + 1];
+    const int c = (a.uniform_cones > 0 ? b * kConesPerBlock : a.block_first[b]) + threadIdx.x;
     // one 32-byte record per cone (first row, dimension, type, the row pointers of its first four
     // rows) instead of the chain cone_row -> A_ptr; loaded on a clamped index by every lane
     const int cl = min(c, c_end - 1);
     const int4 m0 = a.cone_meta[2 * cl], m1 = a.cone_meta[2 * cl + 1];
+    const int4 pc0 = a.cone_cols[2 * cl], pc1 = a.cone_cols[2 * cl + 1];
+    const double2 pv0 = a.cone_vals[4 * cl], pv1 = a.cone_vals[4 * cl + 1], pv2 = a.cone_vals[4 * cl + 2], pv3 = a.cone_vals[4 * cl + 3];
     const int row = m0.x, dim = m0.y, type = m0.z;
     const int ptrs[kSmallCone + 1] = {m0.w, m1.x, m1.y, m1.z, m1.w};
     const double rho = a.rho[prob], irho = 1.0 / rho, al = a.alpha_relax;
@@ -1450,19 +1459,17 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
     int cc[kSmallCone][kConeRowNnz];
     double av[kSmallCone][kConeRowNnz], xv[kSmallCone][kConeRowNnz], pvv[kSmallCone][kConeRowNnz];
     if (small) {
-        const int last_nz = max(ptrs[kSmallCone] - 1, 0);
+        static_assert(kSmallCone == 4 && kConeRowNnz == 2, "packed cone entries: 4 rows x 2 entries");
+        cc[0][0] = pc0.x; cc[0][1] = pc0.y; cc[1][0] = pc0.z; cc[1][1] = pc0.w;
+        cc[2][0] = pc1.x; cc[2][1] = pc1.y; cc[3][0] = pc1.z; cc[3][1] = pc1.w;
+        av[0][0] = pv0.x; av[0][1] = pv0.y; av[1][0] = pv1.x; av[1][1] = pv1.y;
+        av[2][0] = pv2.x; av[2][1] = pv2.y; av[3][0] = pv3.x; av[3][1] = pv3.y;
 #pragma unroll
         for (int k = 0; k < kSmallCone; ++k) {
             const int i = row + min(k, dim - 1);
             bv[k] = a.b[i];
             yv[k] = a.y[i];
             sv[k] = a.s[i];
-#pragma unroll
-            for (int e = 0; e < kConeRowNnz; ++e) {
-                const int idx = min(ptrs[k] + e, last_nz);
-                cc[k][e] = a.A_col[idx];
-                av[k][e] = a.A_val[idx];
-            }
         }
 #pragma unroll
         for (int k = 0; k < kSmallCone; ++k)
@@ -1479,7 +1486,7 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
         for (int k = 0; k < kSmallCone; ++k) {
             double tt = 0.0;
 #pragma unroll
-            for (int e = 0; e < kConeRowNnz; ++e)
+            for (int e = 0; e < kConeRowNnz; ++e)  // (same predicate as before the packing: a missing entry adds an exact 0)
                 tt += (ptrs[k] + e < ptrs[k + 1]) ? av[k][e] * (xv[k][e] + step * pvv[k][e]) : 0.0;
             v[k] = al * (bv[k] - tt) + (1.0 - al) * sv[k];
             wv[k] = v[k] - yv[k] * irho;
