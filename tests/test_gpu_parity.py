@@ -210,6 +210,11 @@ def test_newton_polish_matches_golden(name, fixtures, hip_lib):
     assert res.info["pobj"] == pytest.approx(float(gold["objective"]), rel=1e-8, abs=1e-8)
     assert res.info["res_pri"] <= 1e-9
     compare_with_golden(res, gold, pose_tol=1e-6)
+    # the other factor precisions (0: double throughout; 2: float stream for the Newton factors too) end at the same optimum
+    for mode in (0, 2):
+        alt = solve_score(fg, "SOCP", solver_settings=dict(fac_fp32=mode))
+        assert alt.solved and alt.info["pobj"] == pytest.approx(float(gold["objective"]), rel=1e-8, abs=1e-8), (mode, alt.info)
+        compare_with_golden(alt, gold, pose_tol=1e-6)
     compare_residuals_with_golden(res, fg, gold, tol=1e-6)
     rq = solve_score(fg, "QCQP", solver_settings=dict(polish=1))  # QCQP answered through the polished SOCP
     assert rq.solved
