@@ -33,7 +33,7 @@
 namespace score {
 
 constexpr int kThreads = 256;
-constexpr int kUnroll = kTileNnz / kThreads;  // 12 nonzeros per lane
+constexpr int kUnroll = kTileNnz / kThreads;  // 8 nonzeros per lane
 constexpr int kLongUnroll = 8;
 constexpr int kPartStride = 12;  // doubles per workgroup in the residual partial arrays
 
@@ -176,7 +176,7 @@ struct SpmvArgs {
 
 // RHS : r = sigma x - q + M xin - kx                   (M = [0 | A'], xin = [xt ; u], kx = K xt)
 // KP  : w = M p, partial p'w                           (M = K)
-// KPB : p_new = z + beta p_old (beta from partials), w = M p_new, partial p_new'w
+// KPB : p_new = z + beta p_old (beta from partials), w = M z + beta w_old (= M p_new: one gather per nonzero), partial p_new'w
 // DRES: dual residual norms                            (M = [P | A'], xin = [x ; y])
 // GRAD: gradient of the reduced (head-eliminated) problem, M = [P | A'], xin = [u ; nu]
 enum { MODE_RHS = 0, MODE_KP = 1, MODE_DRES = 2, MODE_KPB = 3, MODE_GRAD = 4 };
