@@ -694,3 +694,29 @@ def test_refinement_edge_cases_on_the_gpu(hip_lib):
 
     _hip_only(hip_lib)
     check_refinement_edge_cases(hip_lib)
+
+
+def test_random_3d_graphs_are_certified(hip_lib):
+    """3-D graphs (block size 4: the streaming chain kernel, SO(3) rounding on the device) of several lengths and
+    seeds: the product default solver returns an optimum the oracle certifies, and its objective equals the oracle's
+    Newton solve on the smaller ones."""
+    from conftest import graph_3d
+
+    _hip_only(hip_lib)
+    for seed, n, n_lm in ((1, 12, 3), (2, 25, 3), (3, 64, 5), (4, 130, 3), (5, 300, 5)):
+        fg = graph_3d(seed=seed, n=n, n_lm=n_lm)
+        mdl = assemble(fg, "SOCP")
+        qp = mdl.qp
+        sol = ConicSolver(qp, {})
+        out = sol.solve()[0]
+        sol.close()
+        assert out.solved, (seed, n, out.info)
+        cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, out.x, out.y, out.s)
+        assert cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4, (seed, n, cert)
+        res = solve_score(fg, "SOCP")
+        for T in res.poses.values():
+            R = T[:3, :3]
+            assert np.allclose(R @ R.T, np.eye(3), atol=1e-9) and np.linalg.det(R) == pytest.approx(1.0, abs=1e-9)
+        if n <= 64:
+            rp, u, info = so.newton_solve(fg, tol=1e-12)
+            assert out.info["pobj"] == pytest.approx(info["objective"], rel=1e-6, abs=1e-8)
