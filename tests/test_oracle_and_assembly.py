@@ -244,3 +244,37 @@ def test_native_assembler_errors(twin_lib):
     fg.pose_variables[0].append(compat.PoseVariable2D("A1", (0.0, 0.0), 0.0))
     with pytest.raises(ValueError, match="already exists in pose_vars"):
         assemble_native(fg, "SOCP", lib_path=twin_lib)
+
+
+def test_headline_config_golden_is_an_optimum_of_the_literal_model():
+    """tests/golden/config3_golden.npz (BASELINE configs[3], 20 robots x 1000 poses; produced offline by the oracle's
+    Newton method): the stored estimate belongs to the graph make_config(3) regenerates, satisfies the pin, evaluates
+    to the stored objective under the reference's objective taken literally (gurobi_utils.py:358-526), and the
+    gradient of the reduced problem vanishes there -- checked without running the solve again."""
+    from score_amd.manhattan import make_config
+
+    gold = load_golden("config3")
+    fg = make_config(3)
+    names = [p.name for chain in fg.pose_variables for p in chain]
+    assert names == [str(n) for n in gold["pose_names"]]
+    assert [l.name for l in fg.landmark_variables] == [str(n) for n in gold["landmark_names"]]
+    d = fg.dimension
+    P, L = gold["poses"], gold["landmarks"]
+    assert P.shape == (20000, d, d + 1)
+    assert np.array_equal(P[0], np.hstack([np.eye(d), np.zeros((d, 1))]))  # pinned pose (gurobi_utils.py:316-333)
+    rp = so.ReducedProblem(fg)
+    u = np.zeros(rp.n)
+    for i, nm in enumerate(names):
+        if nm != rp.first_pose:
+            u[rp.col[nm] : rp.col[nm] + d * (d + 1)] = P[i].ravel()
+    for i, l in enumerate(fg.landmark_variables):
+        u[rp.col[l.name] : rp.col[l.name] + d] = L[i]
+    g, _ = rp.grad_hess(u)
+    assert np.abs(g).max() <= 1e-8 * max(1.0, np.abs(rp.g0).max())
+    vals = so.reduced_to_values(rp, u, "SOCP")
+    lit = so.LiteralModel(fg, "SOCP")
+    assert lit.pin_violation(vals) == 0.0 and lit.cone_violation(vals) <= 1e-12
+    assert lit.direct_cost(vals) == pytest.approx(float(gold["objective"]), rel=1e-12)
+    res, ex = so.optimal_residuals(rp, u)
+    np.testing.assert_allclose(ex, gold["range_excess"], atol=1e-12)
+    assert int((ex > 1e-9).sum()) == 588
