@@ -71,6 +71,21 @@ typedef struct score_problem {
     int32_t        n_chains;
     const int32_t* chain_ptr;  /* n_chains + 1                               */
     const int32_t* node_first_col;
+    /* Optional row-replication hint (0 = none).  The SCORE model is a sum of terms in ONE row k of the
+     * pose matrices [R | t] at a time (gurobi_utils.py:504-526: row k of R_j - R_i R~ and of
+     * t_j - t_i - R_i t~ only holds row k of the variables), and only the cones couple the d rows
+     * (:345-352).  With the unknowns ordered replica by replica,
+     *     columns [k * rep_n, (k + 1) * rep_n), k = 0..rep_d-1  = the rep_n unknowns of matrix row k,
+     *     columns [rep_d * rep_n, n)                            = the remaining ("tail") unknowns,
+     * the quadratic part is P = I_{rep_d} (x) P_row (+ a tail block), every cone has rep_d + 1 rows --
+     * a head row that holds tail columns only and rep_d rows that hold the same entries, replica by
+     * replica -- and the chains come replica by replica as well.  The KKT operator then is
+     * K = I (x) K_row (+ tail): the solver stores and streams K_row ONCE and applies it to the rep_d
+     * right-hand sides together, and factors one set of chains for all replicas.  The hint is CHECKED
+     * at score_create (pattern and values, to 1e-12); a problem that does not have the structure is
+     * solved as a general one -- the hint never changes the result.                                   */
+    int32_t        rep_d;      /* replicas (SCORE: the dimension d); 0 or 1 = no hint */
+    int32_t        rep_n;      /* unknowns per replica                        */
 } score_problem;
 
 typedef struct score_settings {

@@ -34,6 +34,28 @@ thread_local std::string g_err;
 
 struct CpuBackend {
     static constexpr bool kFactorOnHost = true;
+    // By default the twin applies the full K the problem defines, whatever its row-replication hint says (and so checks
+    // the product's replicated kernels against an execution that knows nothing of the structure).  With
+    // SCORE_TWIN_REPLICATION set it runs the replicated host structures instead (K and G1 hold replica 0's rows, a
+    // replica's chain uses its owner's factors): the CPU-side test of that setup code.
+    static bool allow_rep() { return std::getenv("SCORE_TWIN_REPLICATION") != nullptr; }
+    // y[row (+ q rs)] = fn(M row . v[col + q rs_in]) over the rows M holds for problem pi
+    template <class F>
+    void for_rows(const Csr& M, int pi, int rs_in_fixed, F&& fn) const {
+        const HostSystem& h = *H;
+        const int64_t x0 = h.xoff[pi], x1 = h.xoff[pi + 1];
+        if (h.rep <= 1) {
+#pragma omp parallel for schedule(static)
+            for (int64_t i = x0; i < x1; ++i) fn(i, i, 0);
+            return;
+        }
+        const int64_t nr = h.rep_n[(size_t)pi];
+#pragma omp parallel for schedule(static)
+        for (int64_t i = x0; i < x0 + nr; ++i)
+            for (int q = 0; q < h.rep; ++q) fn(i, i + q * nr, (int64_t)q * (rs_in_fixed ? rs_in_fixed : nr));
+#pragma omp parallel for schedule(static)
+        for (int64_t i = x0 + (int64_t)h.rep * nr; i < x1; ++i) fn(i, i, 0);
+    }
     const HostSystem* H = nullptr;
     score_settings st{};
     std::vector<double> xtu, xy, s, r, z, p, w, kx;  // xtu = [xt | u], xy = [x | y], kx = K xt
@@ -67,7 +89,8 @@ struct CpuBackend {
     }
     void upload_rho(const HostSystem& h) {
         // K changed: the carried product kx = K xt is recomputed once
-        for (int64_t i = 0; i < h.n_tot; ++i) kx[i] = row_dot(h.K, i, xtu.data());
+        for (int pi = 0; pi < h.count; ++pi)
+            for_rows(h.K, pi, 0, [&](int64_t row, int64_t o, int64_t sh) { kx[o] = row_dot(h.K, row, xtu.data() + sh); });
         // u = rho (b - s) - y depends on rho
         for (int pi = 0; pi < h.count; ++pi)
             for (int64_t i = h.roff[pi]; i < h.roff[pi + 1]; ++i)
@@ -163,8 +186,9 @@ struct CpuBackend {
         double* u = xtu.data() + h.n_tot;
         double* y = xy.data() + h.n_tot;
         // r = sigma x - q + A'u - K xt   (K xt carried incrementally in kx)
-#pragma omp parallel for schedule(static)
-        for (int64_t i = x0; i < x1; ++i) r[i] = sigma * x[i] - h.q[i] + row_dot(h.G1, i, xtu.data()) - kx[i];
+        for_rows(h.G1, pi, 1, [&](int64_t row, int64_t o, int64_t sh) {
+            r[o] = sigma * x[o] - h.q[o] + row_dot(h.G1, row, xtu.data() + sh) - kx[o];
+        });
         double rz = 0;
         precond(pi, rz);
         const double rz_init = rz;
@@ -174,11 +198,11 @@ struct CpuBackend {
             double pw = 0;
             // first product of a solve: w = K p.  Later ones: K (z + beta p_old) = K z + beta w_old (what the KPB
             // kernel computes: one gather per nonzero)
+            for_rows(h.K, pi, 0, [&](int64_t row, int64_t o, int64_t sh) {
+                w[o] = (j == 1) ? row_dot(h.K, row, p.data() + sh) : row_dot(h.K, row, z.data() + sh) + beta_prev * w[o];
+            });
 #pragma omp parallel for reduction(+ : pw) schedule(static)
-            for (int64_t i = x0; i < x1; ++i) {
-                w[i] = (j == 1) ? row_dot(h.K, i, p.data()) : row_dot(h.K, i, z.data()) + beta_prev * w[i];
-                pw += p[i] * w[i];
-            }
+            for (int64_t i = x0; i < x1; ++i) pw += p[i] * w[i];
             const double a = pw > 0 ? rz / pw : 0.0;
 #pragma omp parallel for schedule(static)
             for (int64_t i = x0; i < x1; ++i) {
@@ -311,6 +335,11 @@ struct CpuBackend {
         else if (nm == "D") { src = h.D.data(); sz = h.n_tot; }
         else if (nm == "E") { src = h.E.data(); sz = h.m_tot; }
         else if (nm == "Kval") { src = h.K.val.data(); sz = (int64_t)h.K.val.size(); }
+        else if (nm == "rep") {
+            const double v[3] = {(double)h.rep, (double)h.K.col.size(), (double)h.G1.col.size()};
+            if (out && len > 0) std::memcpy(out, v, sizeof(double) * (size_t)std::min<int64_t>(len, 3));
+            return 3;
+        }
         else return -1;
         if (out) std::memcpy(out, src, sizeof(double) * (size_t)std::min(len, sz));
         return sz;
@@ -321,8 +350,8 @@ struct CpuBackend {
         for (int64_t i = 0; i < h.n_tot; ++i) p[i] = 1.0 + 1e-3 * (double)(i % 7);
         const double t0 = now_ms();
         for (int rep = 0; rep < reps; ++rep) {
-#pragma omp parallel for schedule(static)
-            for (int64_t i = 0; i < h.n_tot; ++i) w[i] = row_dot(h.K, i, p.data());
+            for (int pi = 0; pi < h.count; ++pi)
+                for_rows(h.K, pi, 0, [&](int64_t row, int64_t o, int64_t sh) { w[o] = row_dot(h.K, row, p.data() + sh); });
         }
         *ms = (now_ms() - t0) / std::max(1, reps);
         double bsum = 0;

@@ -75,6 +75,10 @@ class ConicQP:
     chain_ptr: np.ndarray = field(default_factory=lambda: np.zeros(1, np.int32))
     node_cols: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
     block_size: int = 0
+    # row-replication hint (include/score_hip.h, score_problem::rep_d / rep_n): the first rep_d * rep_n
+    # columns are rep_d replicas of rep_n unknowns that only the cones couple; 0 = no hint
+    rep_d: int = 0
+    rep_n: int = 0
 
     @property
     def n(self) -> int:
@@ -290,23 +294,29 @@ def assemble(data, relaxation: str = QCQP_RELAXATION) -> ScoreModel:
     fixed_vals = np.hstack([np.eye(d), np.zeros((d, 1))]).ravel()
     mask = np.ones(n_model, dtype=bool)
     mask[fixed_cols] = False
-    # Solver-space column order: pose columns chain by chain and, within a chain, matrix row by
-    # matrix row -- [R(k,:) t(k)] of all poses of robot r for k = 0, then k = 1, ... -- so that each
-    # block-tridiagonal chain of the preconditioner (one per robot and row k; the d rows of a pose
-    # are decoupled in P) owns a CONTIGUOUS range of unknowns: its vector loads in the chain kernel
-    # are fully coalesced and the KKT matrix is banded per chain.  Landmarks and range variables
-    # follow in model order.  (Model space keeps the Gurobi layout; expand()/reduce() map.)
+    # Solver-space column order: replica by replica, one replica per matrix row k of the poses [R | t]
+    # (the model only couples the entries of one row k at a time, except through the cones:
+    # gurobi_utils.py:504-526, :345-352).  Replica k = [R(k,:) t(k)] of all free poses, chain by chain
+    # (each block-tridiagonal chain of the preconditioner -- one per robot and row k -- owns a CONTIGUOUS
+    # range of unknowns), then coordinate k of every landmark, then (QCQP) component k of every range
+    # vector; the SOCP range variables form the tail.  P = I_d (x) P_row (+ tail) in this order: the
+    # structure the solver's row-replication hint announces.  (Model space keeps the Gurobi layout;
+    # expand()/reduce() map.)
     pieces_free = []
-    base = 0
     j_ar = np.arange(D1)
-    for chain in data.pose_variables:
-        L = len(chain)
-        idx = base + np.arange(L)
-        idx = idx[idx != p0]
-        for k in range(d):
+    for k in range(d):
+        base = 0
+        for chain in data.pose_variables:
+            L = len(chain)
+            idx = base + np.arange(L)
+            idx = idx[idx != p0]
             pieces_free.append((idx[:, None] * PB + k * D1 + j_ar[None, :]).ravel())
-        base += L
-    pieces_free.append(np.arange(lm_base, n_model))
+            base += L
+        pieces_free.append(lm_base + np.arange(Nl) * d + k)
+        if relaxation != SOCP_RELAXATION:
+            pieces_free.append(rng_base + np.arange(Nr) * d + k)
+    if relaxation == SOCP_RELAXATION:
+        pieces_free.append(rng_base + np.arange(Nr))
     free_cols = np.concatenate(pieces_free)
     n_free = free_cols.size
     assert n_free == n_model - PB
@@ -370,29 +380,30 @@ def assemble(data, relaxation: str = QCQP_RELAXATION) -> ScoreModel:
     P.sum_duplicates(); P.sort_indices()
     A.sum_duplicates(); A.sort_indices()
 
-    # ---- block-tridiagonal hint: one chain per (robot chain, matrix row k) ----
+    # ---- block-tridiagonal hint: one chain per (matrix row k, robot chain), replica by replica ----
     chain_ptr = [0]
     node_cols = []
-    base = 0
     j_ar = np.arange(D1)
-    for chain in data.pose_variables:
-        L = len(chain)
-        idx = base + np.arange(L)
-        # the pinned pose is not an unknown: a chain that contains it is cut there
-        pieces = [idx] if not (base <= p0 < base + L) else [idx[idx < p0], idx[idx > p0]]
-        for k in range(d):
+    for k in range(d):
+        base = 0
+        for chain in data.pose_variables:
+            L = len(chain)
+            idx = base + np.arange(L)
+            # the pinned pose is not an unknown: a chain that contains it is cut there
+            pieces = [idx] if not (base <= p0 < base + L) else [idx[idx < p0], idx[idx > p0]]
             for piece in pieces:
                 if piece.size == 0:
                     continue
                 node_cols.append(new_of_model[piece[:, None] * PB + k * D1 + j_ar[None, :]].ravel())
                 chain_ptr.append(chain_ptr[-1] + piece.size)
-        base += L
+            base += L
+    n_rep = (Np - 1) * D1 + Nl + (0 if relaxation == SOCP_RELAXATION else Nr)
     qp = ConicQP(
         P=P, q=np.ascontiguousarray(q), c0=c0, A=A, b=np.ascontiguousarray(b), z=0,
         soc_dims=np.full(Nr, D1, dtype=np.int32),
         chain_ptr=np.asarray(chain_ptr, dtype=np.int32),
         node_cols=(np.concatenate(node_cols).astype(np.int32) if node_cols else np.zeros(0, np.int32)),
-        block_size=D1,
+        block_size=D1, rep_d=d, rep_n=n_rep,
     )
     return ScoreModel(
         dim=d, relaxation=relaxation, qp=qp, n_model=n_model, free_cols=free_cols,

@@ -14,10 +14,15 @@
 // a batch); this runs in a few milliseconds and releases the GIL.
 //
 // Column layout (identical to assemble.py, so ScoreModel.expand()/reduce() apply unchanged):
-//   solver space = for every pose chain, for every matrix row k = 0..d-1, the (d+1) entries
-//   [R(k,:) t(k)] of every pose of the chain except the pinned one (chain-major: each
-//   block-tridiagonal preconditioner chain is contiguous); then the landmarks (d each); then the
-//   range variables (1 each for SOCP, d each for QCQP).
+//   solver space = replica by replica, one replica per matrix row k = 0..d-1 of the poses [R | t]:
+//     replica k = for every pose chain the (d+1) entries [R(k,:) t(k)] of every pose except the pinned one
+//                 (each block-tridiagonal preconditioner chain is contiguous), then coordinate k of every
+//                 landmark, then (QCQP) component k of every range vector r_ij;
+//   then the tail: (SOCP) the range variables d_ij.
+//   The model only couples the entries of ONE replica at a time, except through the cones
+//   (gurobi_utils.py:504-526, :345-352): P = I_d (x) P_row (+ the tail's diagonal), every cone has a head
+//   row on the tail and d identical rows, one per replica -- the structure score_problem::rep_d / rep_n
+//   announce, which lets the solver stream K_row once for all d right-hand sides.
 #pragma once
 
 #include <algorithm>
@@ -37,6 +42,7 @@ struct AssembledQP {
     std::vector<double> P_val, q, A_val, b;
     double c0 = 0.0;
     int32_t block_size = 0;
+    int32_t rep_n = 0;  // unknowns per replica (replicas = dim)
 
     void view(score_problem* p) const {
         std::memset(p, 0, sizeof(*p));
@@ -47,6 +53,7 @@ struct AssembledQP {
         p->z = 0; p->n_soc = (int32_t)soc_dims.size(); p->soc_dims = soc_dims.data();
         p->block_size = block_size; p->n_chains = (int32_t)chain_ptr.size() - 1;
         p->chain_ptr = chain_ptr.data(); p->node_first_col = node_first_col.data();
+        p->rep_d = dim; p->rep_n = rep_n;
     }
 };
 
@@ -67,45 +74,49 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
     }
     if (Np == 0 || g.chain_len[0] == 0) throw std::runtime_error("factor graph has no pose variables");
     const int64_t Nl = g.n_landmarks, Nr = g.n_rng;
-    const int rw = g.relaxation == 0 ? 1 : d;
-    const int64_t n_pose_cols = (Np - 1) * d * D1;
-    const int64_t lm_base = n_pose_cols, rng_base = lm_base + Nl * d;
-    const int64_t n = rng_base + Nr * rw;
+    const int64_t n_rep = (Np - 1) * D1 + Nl + (g.relaxation == 0 ? 0 : Nr);  // unknowns per replica
+    const int64_t lm_base = (Np - 1) * D1, rq_base = lm_base + Nl;          // within a replica
+    const int64_t rng_base = (int64_t)d * n_rep;                            // tail (SOCP range variables)
+    const int64_t n = rng_base + (g.relaxation == 0 ? Nr : 0);
     if (n >= ((int64_t)1 << 31)) throw std::runtime_error("score_graph: too many unknowns");
-    // solver column of entry (k, j) of pose p: pose_col[p] + k * stride[p] + j ; -1 for the pinned pose
+    // solver column of entry (k, j) of pose p: k * n_rep + pose_col[p] + j ; pose_col = -1 for the pinned pose
     // (pose 0 of chain 0).  Within a chain the poses (minus the pin) are consecutive nodes.
-    std::vector<int64_t> pose_col(Np), pose_kstride(Np);
+    std::vector<int64_t> pose_col(Np);
     out = AssembledQP();
     out.dim = d; out.relaxation = g.relaxation;
+    out.rep_n = (int32_t)n_rep;
     out.chain_ptr.assign(1, 0);
     {
         int64_t p = 0, col = 0;
+        std::vector<int64_t> chain_col, chain_free;
         for (int c = 0; c < g.n_chains; ++c) {
             const int64_t L = g.chain_len[c];
             const int64_t Lfree = L - (c == 0 ? 1 : 0);
             for (int64_t i = 0; i < L; ++i, ++p) {
-                if (c == 0 && i == 0) { pose_col[p] = -1; pose_kstride[p] = 0; continue; }
-                const int64_t node = i - (c == 0 ? 1 : 0);
-                pose_col[p] = col + node * D1;   // k = 0 block; row k adds k * Lfree * D1
-                pose_kstride[p] = Lfree * D1;
+                if (c == 0 && i == 0) { pose_col[p] = -1; continue; }
+                pose_col[p] = col + (i - (c == 0 ? 1 : 0)) * D1;
             }
-            for (int k = 0; k < d; ++k) {
-                if (Lfree > 0) {
-                    for (int64_t node = 0; node < Lfree; ++node) out.node_first_col.push_back((int32_t)(col + k * Lfree * D1 + node * D1));
-                    out.chain_ptr.push_back(out.chain_ptr.back() + (int32_t)Lfree);
-                }
-            }
-            col += Lfree * d * D1;
+            chain_col.push_back(col);
+            chain_free.push_back(Lfree);
+            col += Lfree * D1;
         }
+        for (int k = 0; k < d; ++k)  // chains replica by replica
+            for (int c = 0; c < g.n_chains; ++c) {
+                if (chain_free[(size_t)c] <= 0) continue;
+                for (int64_t node = 0; node < chain_free[(size_t)c]; ++node)
+                    out.node_first_col.push_back((int32_t)(k * n_rep + chain_col[(size_t)c] + node * D1));
+                out.chain_ptr.push_back(out.chain_ptr.back() + (int32_t)chain_free[(size_t)c]);
+            }
     }
     out.block_size = D1;
-    auto pcol = [&](int64_t p, int k, int j) -> int64_t { return pose_col[p] < 0 ? -1 : pose_col[p] + k * pose_kstride[p] + j; };
+    auto pcol = [&](int64_t p, int k, int j) -> int64_t { return pose_col[p] < 0 ? -1 : k * n_rep + pose_col[p] + j; };
     // translation column k of a variable id (pose or landmark); -1 for the pinned pose (value 0)
     auto tcol = [&](int64_t v, int k) -> int64_t {
         if (v < 0 || v >= Np + Nl) throw std::runtime_error("score_graph: range endpoint out of range");
         if (v < Np) return pcol(v, k, d);
-        return lm_base + (v - Np) * d + k;
+        return k * n_rep + lm_base + (v - Np);
     };
+    auto rqcol = [&](int64_t r, int k) -> int64_t { return k * n_rep + rq_base + r; };  // QCQP range vector component
     // ---- P, q, c0.  The measurement loops run twice over the same code: a counting pass sizes every
     //      row, a filling pass writes (column, value) pairs into one flat array; rows are then sorted
     //      and merged in parallel (rows are short: a few (d+1)-blocks each). ----
@@ -204,7 +215,7 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
                 }
             } else {  // w || t_a - t_b - dist r ||^2    (:489-496)
                 for (int k = 0; k < d; ++k) {
-                    const int64_t cs[3] = {tcol(g.rng_a[r], k), tcol(g.rng_b[r], k), rng_base + r * d + k};
+                    const int64_t cs[3] = {tcol(g.rng_a[r], k), tcol(g.rng_b[r], k), rqcol(r, k)};
                     const double cf[3] = {1.0, -1.0, -dist};
                     for (int a = 0; a < 3; ++a)
                         for (int b2 = 0; b2 < 3; ++b2)
@@ -219,7 +230,7 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
             if (l < 0 || l >= Nl) throw std::runtime_error("score_graph: landmark prior out of range");
             const double w = g.lprior_prec[e];
             for (int k = 0; k < d; ++k) {
-                const int64_t c = lm_base + l * d + k;
+                const int64_t c = k * n_rep + lm_base + l;
                 const double tv = g.lprior_t[e * d + k];
                 addP(c, c, 2.0 * w);
                 if (filling) {
@@ -323,7 +334,7 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
             out.b[(size_t)(r * D1)] = 1.0;
             out.A_ptr.push_back((int32_t)out.A_col.size());
             for (int k = 0; k < d; ++k) {
-                out.A_col.push_back((int32_t)(rng_base + r * d + k)); out.A_val.push_back(-1.0);
+                out.A_col.push_back((int32_t)rqcol(r, k)); out.A_val.push_back(-1.0);
                 out.A_ptr.push_back((int32_t)out.A_col.size());
             }
         }

@@ -251,10 +251,12 @@ struct DevBuf {
 };
 
 struct CsrBufs {
-    DevBuf<int32_t> ptr, col, first_row, blk_prob, split;
+    DevBuf<int32_t> ptr, col, first_row, blk_prob, blk_rs, split;
     DevBuf<int4> blk_meta;
     DevBuf<double> val;
     int nblocks = 0;
+    int rep = 1;     // right-hand sides per row of the replicated blocks (HostSystem::rep), 1 = plain rows only
+    int rs_in = 0;   // replicated blocks: operand stride between replicas (0 = the block's own replica stride)
     // values = false: the value array is only allocated (zeroed); a kernel fills it
     void upload(const Csr& M, const RowBlocks& rb, const std::vector<int32_t>* sp = nullptr, bool values = true) {
         ptr.upload(M.ptr);
@@ -270,20 +272,22 @@ struct CsrBufs {
         }
         first_row.upload(rb.first_row);
         blk_prob.upload(rb.prob);
+        blk_rs.upload(rb.rs);
         std::vector<int4> meta(rb.nb());
         for (int b = 0; b < rb.nb(); ++b)
-            meta[b] = make_int4(rb.first_row[b], rb.first_row[b + 1], M.ptr[rb.first_row[b]], M.ptr[rb.first_row[b + 1]]);
+            meta[b] = make_int4(rb.first_row[b], rb.end_row[b], M.ptr[rb.first_row[b]], M.ptr[rb.end_row[b]]);
         blk_meta.upload(meta);
         if (sp) split.upload(*sp);
         nblocks = rb.nb();
     }
-    CsrDev dev() const { return CsrDev{ptr.d, col.d, val.d, first_row.d, blk_prob.d, blk_meta.d, split.d, nblocks}; }
+    CsrDev dev() const { return CsrDev{ptr.d, col.d, val.d, first_row.d, blk_prob.d, blk_meta.d, blk_rs.d, split.d, nblocks}; }
 };
 
 struct HipBackend {
     // K's values, the chain factors and the Jacobi diagonal are derived on the device from K0, K1 and
     // rho (derive_rho_data): the host neither factors nor uploads anything when a penalty changes
     static constexpr bool kFactorOnHost = false;
+    static bool allow_rep() { return true; }  // replicated problems (HostSystem::rep): K_row streamed once for all replicas
     const HostSystem* H = nullptr;
     score_settings st{};
     hipStream_t stream = nullptr;
@@ -302,9 +306,11 @@ struct HipBackend {
     DevBuf<int32_t> cone_cols;  // 8 per cone (two int4)
     DevBuf<double> cone_vals;   // 8 per cone (four double2)
     DevBuf<int32_t> node_col, diag_cols, prec_part_ptr, kblk_part_ptr;
-    DevBuf<PrecWork> prec_work;
-    DevBuf<ChainDesc> chains;
-    DevBuf<ChainLevelDesc> levels;
+    DevBuf<PrecWork> prec_work, factor_work;   // factor_work: what a factorisation of K visits (HostSystem::factor_work)
+    DevBuf<ChainDesc> chains, chainsH;         // chainsH / levelsH: the same chains with factors of their own (Newton matrix)
+    DevBuf<ChainLevelDesc> levels, levelsH;
+    DevBuf<int32_t> vb_first, vb_end, vb_prob; // blocks of <= 256 vector entries per problem (k_xupdate)
+    int n_vblocks = 0;
     DevBuf<double> xtu, xy, s, r, z, p, p2, w, kx, step;
     DevBuf<double> pw_part, rz_part0, rz_part1, rz_meas0, rz_meas1, pres_part, dres_part;
     // ---- semismooth-Newton polish (score_polish*.hpp) ----
@@ -427,6 +433,19 @@ struct HipBackend {
         K.upload(h.K, h.rbK);
         G1.upload(h.G1, h.rbG1);
         G2.upload(h.G2, h.rbG2, &h.g2_split);
+        // replicated problems (HostSystem::rep): K and G1 = A' hold replica 0's rows; K's operands repeat with the
+        // block's replica stride, G1's are the consecutive tail rows of a cone
+        K.rep = h.rep; K.rs_in = 0;
+        G1.rep = h.rep; G1.rs_in = 1;
+        {
+            std::vector<int32_t> vf, ve, vp;
+            for (int p = 0; p < h.count; ++p)
+                for (int64_t r = h.xoff[p]; r < h.xoff[p + 1]; r += kThreads) {
+                    vf.push_back((int32_t)r); ve.push_back((int32_t)std::min<int64_t>(r + kThreads, h.xoff[p + 1])); vp.push_back(p);
+                }
+            n_vblocks = (int)vf.size();
+            vb_first.upload(vf); vb_end.upload(ve); vb_prob.upload(vp);
+        }
         A_ptr.upload(h.A.ptr);
         // padded like the SpMV matrices: the cone kernel clamps its unconditional loads
         A_col.upload_padded(h.A.col, 64); A_val.upload_padded(h.A.val, 64);
@@ -470,12 +489,15 @@ struct HipBackend {
         node_col.upload(h.node_col); diag_cols.upload(h.diag_cols);
         kblk_part_ptr.upload(h.rbK.part_ptr);
         prec_work.upload(h.prec_work); chains.upload(h.chains); levels.upload(h.levels);
+        factor_work.upload(h.factor_work);
+        if (h.rep > 1) { chainsH.upload(h.chainsH); levelsH.upload(h.levelsH); }
+        else { chainsH.view(chains.d, chains.n); levelsH.view(levels.d, levels.n); }
         n_prec = (int)h.prec_work.size();
         active_part_ptr = h.prec_part_ptr;
         {   // split chain kernel: only when the whole launch is resident at once (one workgroup per CU)
             int cus = 0;
             HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st.device));
-            const bool off = st.chain_split <= 0 || std::getenv("SCORE_NO_CHAIN_SPLIT") != nullptr;
+            const bool off = st.chain_split <= 0 || h.rep > 1 || std::getenv("SCORE_NO_CHAIN_SPLIT") != nullptr;
             if (!off && cus > 0) build_split_system(h, cus, split);
             if (split.active && split.stage_rel.size() > 0) {
                 for (const auto& pl : split.plans)
@@ -608,12 +630,12 @@ struct HipBackend {
         }
         hipLaunchKernelGGL(k_kval, dim3(K.nblocks), dim3(kThreads), 0, stream, K.dev(), (const double*)K0d.d, (const double*)K1d.d,
                            (const double*)rho.d, K.val.d, (const int32_t*)nullptr);
-        if (n_prec_items()) {
+        if (!h.factor_work.empty()) {
             FactorArgs fa{};
-            fa.work = prec_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = K.val.d;
+            fa.work = factor_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = K.val.d;
             fa.pos_diag = kposd.d; fa.pos_sub = kposs.d; fa.fac = fac.d; fa.work_mat = q_work.d; fa.skip = nullptr;
             fa.diag_pos = kdiagpos.d; fa.dinv = dinv.d;
-            launch_factor(fa);
+            launch_factor(fa, (int)h.factor_work.size(), false);
         }
         HIP_CHECK(hipGetLastError());
     }
@@ -640,8 +662,8 @@ struct HipBackend {
             HIP_CHECK(hipFuncSetAttribute((const void*)k_factor<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         }
     }
-    void launch_factor(FactorArgs fa) {
-        const int np = n_prec_items();
+    // newton_set: the factors of the Newton matrix (every chain its own: chainsH / levelsH / q_fac)
+    void launch_factor(FactorArgs fa, int np, bool newton_set) {
         if (np == 0) return;
         fa.lds_wmat = factor_lds_wmat;
         const int bs = H->bs;
@@ -649,10 +671,9 @@ struct HipBackend {
         else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
         else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
         else hipLaunchKernelGGL(k_factor<4>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
-        const bool newton_set = (fa.fac == q_fac.d) && q_fac.d;
-        if ((newton_set ? newton_fac32 : use_fac32) && H->fac_doubles > 0) {
+        const int64_t nf = (int64_t)(newton_set ? H->fac_doubles_H : H->fac_doubles);
+        if ((newton_set ? newton_fac32 : use_fac32) && nf > 0) {
             float* shadow = newton_set ? q_fac32.d : fac32.d;
-            const int64_t nf = (int64_t)H->fac_doubles;
             hipLaunchKernelGGL(k_fac_round, dim3((unsigned)((nf + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, fa.fac, shadow, nf);
         }
     }
@@ -678,7 +699,7 @@ struct HipBackend {
         {   // K changed: the carried product kx = K xt is recomputed once
             SpmvArgs a = spmv_args(K, xtu.d);
             a.p = xtu.d; a.w = kx.d;
-            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
+            launch_spmv<MODE_KP>(K, a);
             HIP_CHECK(hipGetLastError());
         }
         if (n_cone_blocks) {
@@ -822,9 +843,18 @@ struct HipBackend {
         HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_STEP, float>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
     }
 
+    // SpMV launch: matrices of a replicated problem (K, G1) run with rep right-hand sides per stored row
+    template <int MODE>
+    void launch_spmv(const CsrBufs& M, const SpmvArgs& a, int slot = -1) {
+        static_assert(MODE == MODE_RHS || MODE == MODE_KP || MODE == MODE_KPB, "the residual / gradient modes run on plain rows (G2, H)");
+        if (M.rep == 2) { launch_on_stream(k_spmv<MODE, 2>, dim3(M.nblocks), dim3(kThreads), 0, slot, a); return; }
+        if (M.rep == 3) { launch_on_stream(k_spmv<MODE, 3>, dim3(M.nblocks), dim3(kThreads), 0, slot, a); return; }
+        launch_on_stream(k_spmv<MODE, 1>, dim3(M.nblocks), dim3(kThreads), 0, slot, a);
+    }
+
     SpmvArgs spmv_args(const CsrBufs& M, const double* xin) {
         SpmvArgs a{};
-        a.M = M.dev(); a.xin = xin; a.done = done.d;
+        a.M = M.dev(); a.xin = xin; a.done = done.d; a.rs_in = M.rs_in;
         a.x = xy.d; a.q = q.d; a.kx = kx.d; a.r = r.d; a.sigma = H->sigma;
         a.p = p.d; a.w = w.d; a.pw_part = pw_part.d;
         a.prec_part_ptr = prec_part_ptr.d; a.kblk_part_ptr = kblk_part_ptr.d;
@@ -838,7 +868,7 @@ struct HipBackend {
     void launch_kp(const double* pdir, unsigned long long* ts = nullptr, int slot = -1) {
         SpmvArgs a = spmv_args(K, pdir);
         a.p = pdir; a.tstamp = ts;
-        launch_on_stream(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, slot, a);
+        launch_spmv<MODE_KP>(K, a, slot);
     }
     // p_new = z + beta p_old ; w = K p_new
     void launch_kpb(const double* p_old, double* p_new, const double* rz_new, const double* rz_old,
@@ -846,7 +876,7 @@ struct HipBackend {
         SpmvArgs a = spmv_args(K, p_old);
         a.tstamp = ts;
         a.p = p_old; a.z = z.d; a.p_out = p_new; a.rz_new = rz_new; a.rz_old = rz_old;
-        launch_on_stream(k_spmv<MODE_KPB>, dim3(K.nblocks), dim3(kThreads), 0, slot, a);
+        launch_spmv<MODE_KPB>(K, a, slot);
     }
 
     void set_cg_iters(int k) {
@@ -884,7 +914,7 @@ struct HipBackend {
             ra.tstamp = slot(0);
             ra.apply_update = first ? 0 : 1;
             ra.pfin = last_p;
-            launch_on_stream(k_spmv<MODE_RHS>, dim3(G1.nblocks), dim3(kThreads), 0, 0, ra);
+            launch_spmv<MODE_RHS>(G1, ra, 0);
         }
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = fac.d;
@@ -914,11 +944,11 @@ struct HipBackend {
             pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_meas1.d;
             launch_prec<PREC_STEP>(pa);  // also applies xt += a p, kx += a w, r -= a w
             VecArgs va{};
-            va.first_row = K.first_row.d; va.blk_prob = K.blk_prob.d; va.done = done.d;
+            va.first_row = vb_first.d; va.end_row = vb_end.d; va.blk_prob = vb_prob.d; va.done = done.d;
             va.prec_part_ptr = prec_part_ptr.d; va.kblk_part_ptr = kblk_part_ptr.d;
             va.pw_part = pw_part.d; va.p = p_cur; va.w = w.d; va.kx = kx.d; va.xt = xtu.d; va.x = xy.d;
             va.alpha_relax = st.alpha; va.rz_old = rz_cur; va.apply_alpha = 0;
-            hipLaunchKernelGGL(k_xupdate, dim3(K.nblocks), dim3(kThreads), 0, stream, va);
+            hipLaunchKernelGGL(k_xupdate, dim3(n_vblocks), dim3(kThreads), 0, stream, va);
         } else {
             ca.apply_alpha = 1; ca.pfin = p_cur; ca.rz_in = rz_cur;
             last_rz = rz_cur;  // what the next iteration's right-hand-side kernel has to apply
@@ -1077,6 +1107,11 @@ struct HipBackend {
         else if (nm == "D") { src = h.D.data(); sz = h.n_tot; host = true; }
         else if (nm == "E") { src = h.E.data(); sz = h.m_tot; host = true; }
         else if (nm == "Kval") { src = K.val.d; sz = (int64_t)h.K.val.size(); }
+        else if (nm == "rep") {  // [replicas the kernels run with (1 = general problem), nnz of the stored K, of the stored A']
+            const double v[3] = {(double)h.rep, (double)h.K.col.size(), (double)h.G1.col.size()};
+            if (out && len > 0) std::memcpy(out, v, sizeof(double) * (size_t)std::min<int64_t>(len, 3));
+            return 3;
+        }
         else if (nm == "fac") { src = fac.d; sz = (int64_t)h.fac_doubles; }
         // ---- kernel-level checks of the Newton polish (tests/test_gpu_parity.py) ----
         else if (nm == "polish_assemble_at_x") {
@@ -1108,7 +1143,7 @@ struct HipBackend {
             if (!Q.available) return -1;
             if (out && len > 0) {
                 PrecArgs pa{};
-                pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = q_fac.d;
+                pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.fac = q_fac.d;
                 pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = q_skip.d;
                 pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d;
                 pa.r = r.d; pa.r_in = q_negg.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d;
@@ -1201,7 +1236,7 @@ struct HipBackend {
         {
             SpmvArgs a = spmv_args(K, p_cur);
             a.p = p_cur; a.done = lin_flag.d;
-            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
+            launch_spmv<MODE_KP>(K, a);
         }
         pa.gate_flag = lin_flag.d; pa.gate_tol2 = lin_tol2.d; pa.gate_ref = lin_ref.d;
         int32_t state[2] = {0, 0};
@@ -1218,7 +1253,7 @@ struct HipBackend {
                 launch_prec<PREC_STEP>(pa);  // x += a p ; r -= a w ; z = M^-1 r   (or the gate fires)
                 SpmvArgs a = spmv_args(K, p_cur);
                 a.p = p_cur; a.z = z.d; a.p_out = p_oth; a.rz_new = rz_nxt; a.rz_old = rz_cur; a.done = lin_flag.d;
-                hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
+                launch_spmv<MODE_KPB>(K, a);
                 std::swap(p_cur, p_oth);
                 rz_cur = rz_nxt;
                 first = false;
@@ -1258,9 +1293,9 @@ struct HipBackend {
         n_fpart = std::max<size_t>((nc + kThreads - 1) / kThreads, (size_t)n_cone_blocks);
         q_X0.alloc(h.n_tot + h.m_tot); q_X1.alloc(h.n_tot + h.m_tot);
         q_g.alloc(h.n_tot); q_delta.alloc(h.n_tot); q_dummy.alloc(h.n_tot); q_negg.alloc(h.n_tot);
-        q_fac.alloc(h.fac_doubles); q_dinv.alloc(h.dinv.size());
+        q_fac.alloc(h.fac_doubles_H); q_dinv.alloc(h.dinv.size());
         q_fac.zero(stream);  // separator slots of the spike region are never written (nor used)
-        if (newton_fac32) { q_fac32.alloc(h.fac_doubles); q_fac32.zero(stream); }
+        if (newton_fac32) { q_fac32.alloc(h.fac_doubles_H); q_fac32.zero(stream); }
         n_gd = std::max<size_t>((h.n_tot + kThreads - 1) / kThreads, (size_t)Hm.nblocks);
         q_pw.alloc(Hm.nblocks);
         {
@@ -1314,10 +1349,10 @@ struct HipBackend {
         hipLaunchKernelGGL(k_hassemble, dim3((unsigned)(base_blocks + n_long)), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d, base_blocks);
         if (n_prec_items()) {  // chain factors and the reciprocal Jacobi diagonal, one launch
             FactorArgs fa{};
-            fa.work = prec_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = Hm.val.d;
+            fa.work = prec_work.d; fa.chains = chainsH.d; fa.levels = levelsH.d; fa.Hval = Hm.val.d;
             fa.pos_diag = q_posd.d; fa.pos_sub = q_poss.d; fa.fac = q_fac.d; fa.work_mat = q_work.d; fa.skip = skip;
             fa.diag_pos = q_diagpos.d; fa.dinv = q_dinv.d;
-            launch_factor(fa);
+            launch_factor(fa, n_prec_items(), true);
         }
     }
 
@@ -1405,7 +1440,7 @@ struct HipBackend {
         if (resume) upload_skip(live);
         (void)eta;
         PrecArgs pa{};
-        pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = q_fac.d;
+        pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.fac = q_fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = q_skip.d;
         pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d;
         pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d; pa.pw_part = q_pw.d;
@@ -1617,7 +1652,7 @@ struct HipBackend {
         {
             SpmvArgs a = spmv_args(K, xtu.d);
             a.p = xtu.d; a.w = kx.d; a.done = q_skip.d;
-            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(K.nblocks), dim3(kThreads), 0, stream, a);
+            launch_spmv<MODE_KP>(K, a);
         }
         HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipGetLastError());
@@ -1632,19 +1667,19 @@ struct HipBackend {
         pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d;
         pa.pw_part = pw_part.d; pa.rz_in = rz_part0.d; pa.rz_out = rz_part1.d;
         VecArgs va{};
-        va.first_row = K.first_row.d; va.blk_prob = K.blk_prob.d; va.done = done.d;
+        va.first_row = vb_first.d; va.end_row = vb_end.d; va.blk_prob = vb_prob.d; va.done = done.d;
         va.prec_part_ptr = prec_part_ptr.d; va.kblk_part_ptr = kblk_part_ptr.d;
         va.pw_part = pw_part.d; va.p = p.d; va.w = w.d; va.kx = kx.d; va.xt = xtu.d; va.x = xy.d;
         va.alpha_relax = st.alpha; va.rz_old = rz_part0.d; va.apply_alpha = 1;
         auto once = [&]() {
-            if (which == "rhs") { SpmvArgs ra = spmv_args(G1, xtu.d); ra.apply_update = 1; hipLaunchKernelGGL(k_spmv<MODE_RHS>, dim3(G1.nblocks), dim3(kThreads), 0, stream, ra); }
+            if (which == "rhs") { SpmvArgs ra = spmv_args(G1, xtu.d); ra.apply_update = 1; launch_spmv<MODE_RHS>(G1, ra); }
             else if (which.rfind("prec_init:", 0) == 0) { pa.debug_skip = std::atoi(which.c_str() + 10); launch_prec<PREC_INIT>(pa); }
             else if (which == "prec_init") launch_prec<PREC_INIT>(pa);
             else if (which.rfind("prec_step:", 0) == 0) { pa.debug_skip = std::atoi(which.c_str() + 10); launch_prec<PREC_STEP>(pa); }
             else if (which == "prec_step") launch_prec<PREC_STEP>(pa);
             else if (which == "kp") launch_kp(p.d);
             else if (which == "kpb") launch_kpb(p.d, p2.d, rz_part1.d, rz_part0.d);
-            else if (which == "xupdate") hipLaunchKernelGGL(k_xupdate, dim3(K.nblocks), dim3(kThreads), 0, stream, va);
+            else if (which == "xupdate") hipLaunchKernelGGL(k_xupdate, dim3(n_vblocks), dim3(kThreads), 0, stream, va);
             else if (which == "cone") { if (n_cone_blocks) { ConeArgs ca = cone_args(xtu.d); ca.apply_alpha = 1; hipLaunchKernelGGL(k_cone, dim3(n_cone_blocks), dim3(kThreads), 0, stream, ca); } }
             else if (which == "nop") hipLaunchKernelGGL(k_nop, dim3(K.nblocks), dim3(kThreads), 0, stream, (int*)nullptr);
             else if (which == "nop1") hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, stream, (int*)nullptr);

@@ -221,11 +221,16 @@ struct Csr {
 };
 
 struct RowBlocks {
-    std::vector<int32_t> first_row;  // nb + 1
+    std::vector<int32_t> first_row;  // nb (+ 1: the end of the last block)
+    std::vector<int32_t> end_row;    // nb: blocks of one problem need not be adjacent (replicated problems skip rows)
     std::vector<int32_t> prob;       // nb
+    std::vector<int32_t> rs;         // nb: replica stride of a block of replicated rows (see HostSystem::rep), 0 = plain rows
     std::vector<int32_t> part_ptr;   // count + 1 : block range of each problem
     int nb() const { return (int)prob.size(); }
 };
+// A contiguous range of matrix rows to be tiled: plain rows (rs == 0) or rows of replica 0 whose results
+// and operands repeat every rs entries for the other replicas.
+struct RowSegment { int64_t begin, end; int32_t prob, rs; };
 
 // One level of a chain's nested-dissection factorisation.  The factor blocks are
 // stored structure-of-arrays so that the lanes of a wavefront (= consecutive
@@ -610,6 +615,25 @@ struct HostSystem {
 
     std::vector<int64_t> fac_off;  // per chain: offset of its records in `fac` (doubles)
 
+    // ---- row replication (score_problem::rep_d / rep_n, checked by check_replication) ----
+    // rep > 1: every problem of the batch is  K = I_rep (x) K_row (+ tail).  Then K and G1 = A' hold the rows of
+    // replica 0 and of the tail only (a row's index is still its first column's address: the rows of the other
+    // replicas are empty), the SpMV kernels apply a replica-0 row to all rep right-hand sides (operands and results
+    // repeat every rep_n[p] entries), and a chain of replica k uses the factors of its replica-0 sibling
+    // (chain_owner): `levels` / `fac` hold one set per robot.  The Newton matrix of the polish is NOT of that form
+    // (active cones couple the rows): chainsH / levelsH / fac_doubles_H describe the same chains with factors of
+    // their own.  rep == 1: chainsH == chains, levelsH == levels.
+    int rep = 1;
+    std::vector<int64_t> rep_n;          // per problem
+    std::vector<int32_t> chain_owner;    // per chain
+    std::vector<PrecWork> factor_work;   // what a factorisation of K visits: owner chains + the Jacobi blocks
+    std::vector<ChainDesc> chainsH;
+    std::vector<ChainLevelDesc> levelsH;
+    size_t fac_doubles_H = 0;
+    bool stored_row(int p, int64_t local) const {  // does K / G1 hold a row for this unknown?
+        return rep <= 1 || local < rep_n[(size_t)p] || local >= (int64_t)rep * rep_n[(size_t)p];
+    }
+
     // true: K's values, the chain factorisation and the Jacobi diagonal are computed here, on the
     // host, whenever a penalty changes (the CPU twin).  false: the backend derives them on the
     // device from K0 / K1 / rho (the HIP backend: k_kval + k_factor) -- nothing rho-dependent is
@@ -626,19 +650,20 @@ inline int find_in_row(const Csr& M, int64_t row, int32_t col) {
     return -1;
 }
 
-inline RowBlocks make_rowblocks(const Csr& M, const std::vector<int64_t>& xoff) {
+inline RowBlocks make_rowblocks(const Csr& M, const std::vector<RowSegment>& segs, int count) {
     RowBlocks rb;
-    const int count = (int)xoff.size() - 1;
     rb.part_ptr.assign(count + 1, 0);
-    for (int p = 0; p < count; ++p) {
-        int64_t r = xoff[p];
-        const int64_t rend = xoff[p + 1];
+    for (const RowSegment& sg : segs) {
+        int64_t r = sg.begin;
+        const int64_t rend = sg.end;
         while (r < rend) {
             rb.first_row.push_back((int32_t)r);
-            rb.prob.push_back(p);
+            rb.prob.push_back(sg.prob);
+            rb.rs.push_back(sg.rs);
             int64_t len0 = M.ptr[r + 1] - M.ptr[r];
             if (len0 > kLongRow) {  // a long row is a block of its own
                 ++r;
+                rb.end_row.push_back((int32_t)r);
                 continue;
             }
             int64_t nn = 0, r1 = r;
@@ -649,11 +674,18 @@ inline RowBlocks make_rowblocks(const Csr& M, const std::vector<int64_t>& xoff) 
                 ++r1;
             }
             r = r1;
+            rb.end_row.push_back((int32_t)r);
         }
-        rb.part_ptr[p + 1] = (int32_t)rb.prob.size();
+        rb.part_ptr[sg.prob + 1] = (int32_t)rb.prob.size();  // (segments come problem by problem)
     }
-    rb.first_row.push_back((int32_t)xoff[count]);
+    for (int p = 0; p < count; ++p) rb.part_ptr[p + 1] = std::max(rb.part_ptr[p + 1], rb.part_ptr[p]);
+    rb.first_row.push_back(segs.empty() ? 0 : (int32_t)segs.back().end);
     return rb;
+}
+inline std::vector<RowSegment> plain_segments(const std::vector<int64_t>& xoff) {
+    std::vector<RowSegment> sg;
+    for (size_t p = 0; p + 1 < xoff.size(); ++p) sg.push_back(RowSegment{xoff[p], xoff[p + 1], (int32_t)p, 0});
+    return sg;
 }
 
 struct ProblemScaled {
@@ -741,6 +773,72 @@ inline void ruiz_scale(const score_problem& p, int iters, ProblemScaled& out) {
     out.b.resize(m);
     for (int j = 0; j < n; ++j) out.q[j] = p.q[j] * out.D[j];
     for (int r = 0; r < m; ++r) out.b[r] = p.b[r] * out.E[r];
+}
+
+// Does the problem have the row-replicated structure its hint claims (include/score_hip.h, score_problem::rep_d)?
+// Pattern and values, to a relative 1e-12 (assemblers that sum a row's terms in a different order per replica
+// differ in the last bits; the solver then uses replica 0's values for all of them -- a perturbation far below
+// the inexactness of its PCG solves, and the residual tests keep using the problem as given).
+inline bool check_replication(const score_problem& p) {
+    const int d = p.rep_d;
+    const int64_t nr = p.rep_n, n = p.n;
+    if (d < 2 || d > 3 || nr < 1 || (int64_t)d * nr > n) return false;
+    if (p.z != 0) return false;
+    const int64_t t0 = (int64_t)d * nr;
+    auto close = [](double a, double b) { return std::fabs(a - b) <= 1e-12 * std::max(std::fabs(a), std::fabs(b)); };
+    std::atomic<bool> ok{true};
+    parallel_ranges(nr, 8192, [&](int, int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1 && ok.load(std::memory_order_relaxed); ++i) {
+            const int a0 = p.P_rowptr[i], a1 = p.P_rowptr[i + 1];
+            for (int k = a0; k < a1; ++k)
+                if (p.P_col[k] >= nr) { ok = false; return; }
+            for (int rpl = 1; rpl < d; ++rpl) {
+                const int64_t ir = i + rpl * nr;
+                const int b0 = p.P_rowptr[ir];
+                if (p.P_rowptr[ir + 1] - b0 != a1 - a0) { ok = false; return; }
+                for (int k = 0; k < a1 - a0; ++k)
+                    if (p.P_col[b0 + k] != p.P_col[a0 + k] + rpl * nr || !close(p.P_val[b0 + k], p.P_val[a0 + k])) { ok = false; return; }
+            }
+        }
+    });
+    if (!ok) return false;
+    for (int64_t i = t0; i < n; ++i)
+        for (int k = p.P_rowptr[i]; k < p.P_rowptr[i + 1]; ++k)
+            if (p.P_col[k] < t0) return false;
+    // cones: head row on tail columns, then d rows that repeat replica by replica
+    int64_t row = 0;
+    for (int c = 0; c < p.n_soc; ++c) {
+        if (p.soc_dims[c] != d + 1) return false;
+        for (int k = p.A_rowptr[row]; k < p.A_rowptr[row + 1]; ++k)
+            if (p.A_col[k] < t0) return false;
+        const int a0 = p.A_rowptr[row + 1], a1 = p.A_rowptr[row + 2];
+        for (int k = a0; k < a1; ++k)
+            if (p.A_col[k] >= nr) return false;
+        for (int rpl = 1; rpl < d; ++rpl) {
+            const int b0 = p.A_rowptr[row + 1 + rpl];
+            if (p.A_rowptr[row + 2 + rpl] - b0 != a1 - a0) return false;
+            for (int k = 0; k < a1 - a0; ++k)
+                if (p.A_col[b0 + k] != p.A_col[a0 + k] + rpl * nr || !close(p.A_val[b0 + k], p.A_val[a0 + k])) return false;
+        }
+        row += d + 1;
+    }
+    // chains: replica by replica, each a shifted copy of replica 0's
+    if (p.n_chains > 0) {
+        if (p.n_chains % d != 0) return false;
+        const int nc0 = p.n_chains / d;
+        const int nodes0 = p.chain_ptr[nc0] - p.chain_ptr[0];
+        for (int rpl = 0; rpl < d; ++rpl)
+            for (int c = 0; c < nc0; ++c) {
+                const int cc = rpl * nc0 + c;
+                if (p.chain_ptr[cc] != p.chain_ptr[c] + rpl * nodes0 || p.chain_ptr[cc + 1] != p.chain_ptr[c + 1] + rpl * nodes0) return false;
+                for (int j = p.chain_ptr[c]; j < p.chain_ptr[c + 1]; ++j) {
+                    const int64_t col = p.node_first_col[j];
+                    if (rpl == 0 && (col < 0 || col + p.block_size > nr)) return false;
+                    if (p.node_first_col[j + rpl * nodes0] != col + rpl * nr) return false;
+                }
+            }
+    }
+    return true;
 }
 
 inline void validate_problem(const score_problem& p) {
@@ -872,7 +970,10 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
     // they never re-allocate), the row lengths are prefix-summed, the buffers copied into place
     struct KPart { std::vector<int32_t> col; std::vector<double> k0, k1; int64_t i0 = 0, i1 = 0; };
     std::vector<KPart> kparts(parallel_parts(n, 8192));
+    // (replicated problems: K holds the rows of replica 0 and of the tail only, see HostSystem::rep)
+    auto stored = [&](int64_t i) { return H.stored_row(pi, i); };
     auto k_row_weight = [&](int64_t i) {  // entries gathered for row i; long rows cost n log n in the sort
+        if (!stored(i)) return 0.0;
         const double g = (double)(S.P.ptr[i + 1] - S.P.ptr[i]) + 2.0 * (double)(atp[i + 1] - atp[i]);
         return g > 64.0 ? 4.0 * g : g;
     };
@@ -881,12 +982,14 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
         Q.i0 = i0; Q.i1 = i1;
         size_t ub = 0;
         for (int64_t i = i0; i < i1; ++i) {
+            if (!stored(i)) continue;
             ub += 1 + (size_t)(S.P.ptr[i + 1] - S.P.ptr[i]);
             for (int t2 = atp[i]; t2 < atp[i + 1]; ++t2) ub += (size_t)(S.A.ptr[atr[t2] + 1] - S.A.ptr[atr[t2]]);
         }
         Q.col.reserve(ub); Q.k0.reserve(ub); Q.k1.reserve(ub);
         std::vector<Ent> buf;
         for (int64_t i = i0; i < i1; ++i) {
+            if (!stored(i)) { H.K.ptr[k_row0 + 1 + i] = 0; continue; }
             gather_row(i, buf);
             int32_t cnt = 0;
             size_t x = 0;
@@ -922,25 +1025,31 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
     const size_t g1_base = H.G1.col.size(), g2_base = H.G2.col.size();
     const size_t g1_row0 = H.G1.ptr.size(), g2_row0 = H.G2.ptr.size(), sp_row0 = H.g2_split.size();
     H.G1.ptr.resize(g1_row0 + n); H.G2.ptr.resize(g2_row0 + n); H.g2_split.resize(sp_row0 + n);
+    std::vector<int32_t> g1p((size_t)n + 1, 0);  // G1 row starts (local): stored rows only
     for (int i = 0; i < n; ++i) {
-        H.G1.ptr[g1_row0 + i] = (int32_t)(g1_base + atp[i + 1]);
+        g1p[(size_t)i + 1] = g1p[(size_t)i] + (stored(i) ? atp[i + 1] - atp[i] : 0);
+        H.G1.ptr[g1_row0 + i] = (int32_t)(g1_base + g1p[(size_t)i + 1]);
         H.g2_split[sp_row0 + i] = (int32_t)(g2_base + S.P.ptr[i + 1] + atp[i]);
         H.G2.ptr[g2_row0 + i] = (int32_t)(g2_base + S.P.ptr[i + 1] + atp[i + 1]);
     }
-    H.G1.col.resize(g1_base + atr.size()); H.G1.val.resize(g1_base + atr.size());
+    H.G1.col.resize(g1_base + (size_t)g1p[(size_t)n]); H.G1.val.resize(g1_base + (size_t)g1p[(size_t)n]);
     H.G2.col.resize(g2_base + S.P.col.size() + atr.size()); H.G2.val.resize(g2_base + S.P.col.size() + atr.size());
     pt.mark("  append: G resize");
     const int32_t ucol0 = (int32_t)(H.n_tot + ro);
     parallel_ranges(n, 16384, [&](int, int64_t i0, int64_t i1) {
         for (int64_t i = i0; i < i1; ++i) {
-            size_t o1 = g1_base + atp[i], o2 = g2_base + S.P.ptr[i] + atp[i];
+            size_t o1 = g1_base + (size_t)g1p[(size_t)i], o2 = g2_base + S.P.ptr[i] + atp[i];
+            const bool st_ = stored(i);
             for (int k = S.P.ptr[i]; k < S.P.ptr[i + 1]; ++k, ++o2) {
                 H.G2.col[o2] = (int32_t)(xo + S.P.col[k]);
                 H.G2.val[o2] = S.P.val[k];
             }
-            for (int t2 = atp[i]; t2 < atp[i + 1]; ++t2, ++o1, ++o2) {
-                H.G1.col[o1] = ucol0 + atr[t2];
-                H.G1.val[o1] = atv[t2];
+            for (int t2 = atp[i]; t2 < atp[i + 1]; ++t2, ++o2) {
+                if (st_) {
+                    H.G1.col[o1] = ucol0 + atr[t2];
+                    H.G1.val[o1] = atv[t2];
+                    ++o1;
+                }
                 H.G2.col[o2] = ucol0 + atr[t2];
                 H.G2.val[o2] = atv[t2];
             }
@@ -959,9 +1068,9 @@ inline void refresh_rho(HostSystem& H, int pi) {
         for (int64_t k = k0 + a; k < k0 + b; ++k) H.K.val[k] = H.K0[k] + rho * H.K1[k];
     });
     const int bs = H.bs, b2 = bs * bs;
-    std::vector<int32_t> mine;
+    std::vector<int32_t> mine;  // (a replica's chain uses its owner's factors)
     for (size_t ci = 0; ci < H.chains.size(); ++ci)
-        if (H.chains[ci].prob == pi) mine.push_back((int32_t)ci);
+        if (H.chains[ci].prob == pi && H.chain_owner[ci] == (int32_t)ci) mine.push_back((int32_t)ci);
     parallel_ranges((int64_t)mine.size(), 1, [&](int, int64_t c0, int64_t c1) {
         std::vector<double> Ad, Bs, fac;
         std::vector<ChainLevelDesc> lv;
@@ -995,8 +1104,10 @@ inline void refresh_rho(HostSystem& H, int pi) {
     }
 }
 
+// allow_rep: the backend can run replicated problems (HostSystem::rep); the CPU twin cannot (and is the better
+// check for not doing so: it applies the full K the problem defines).
 inline void build_system(const score_problem* probs, int count, const score_settings& st, HostSystem& H,
-                         bool factor_on_host = true) {
+                         bool factor_on_host = true, bool allow_rep = false) {
     if (count <= 0) throw std::runtime_error("score_create: count must be positive");
     PhaseTimer pt(st.verbose != 0);
     H = HostSystem();
@@ -1022,6 +1133,16 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     H.bs = bs;
     H.n_tot = H.xoff[count];
     H.m_tot = H.roff[count];
+    {   // row replication: every problem of the batch must carry the same, verified, hint
+        int rep = (allow_rep && std::getenv("SCORE_NO_REPLICATION") == nullptr) ? probs[0].rep_d : 0;
+        for (int p = 0; p < count && rep > 1; ++p)
+            if (probs[p].rep_d != rep || !check_replication(probs[p])) rep = 0;
+        H.rep = rep > 1 ? rep : 1;
+        H.rep_n.assign((size_t)count, 0);
+        if (H.rep > 1)
+            for (int p = 0; p < count; ++p) H.rep_n[(size_t)p] = probs[p].rep_n;
+        pt.mark("replication check");
+    }
     if (H.n_tot + H.m_tot >= (int64_t)1 << 31) throw std::runtime_error("batch too large for 32-bit indices");
     H.A.nrows = H.m_tot; H.A.ncols = H.n_tot; H.A.ptr.assign(1, 0);
     H.K.nrows = H.K.ncols = H.n_tot; H.K.ptr.assign(1, 0);
@@ -1052,6 +1173,8 @@ inline void build_system(const score_problem* probs, int count, const score_sett
             for (int64_t p = p0; p < p1; ++p) {
                 HostSystem& Q = pieces[(size_t)p];
                 Q.count = 1;
+                Q.rep = H.rep;
+                Q.rep_n.assign(1, H.rep_n[(size_t)p]);
                 Q.sigma = H.sigma;
                 Q.n_tot = H.n_tot; Q.m_tot = H.m_tot;
                 Q.xoff.assign(1, H.xoff[p]); Q.roff.assign(1, H.roff[p]);
@@ -1136,9 +1259,20 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     H.K.val.assign(H.K.col.size(), 0.0);
     parallel_ranges(3, 1, [&](int, int64_t k0, int64_t k1) {  // three independent serial scans
         for (int64_t k = k0; k < k1; ++k) {
-            if (k == 0) H.rbK = make_rowblocks(H.K, H.xoff);
-            else if (k == 1) H.rbG1 = make_rowblocks(H.G1, H.xoff);
-            else H.rbG2 = make_rowblocks(H.G2, H.xoff);
+            // K and G1 of a replicated problem: the rows of replica 0 (applied to all replicas), then the tail
+            std::vector<RowSegment> sg;
+            if (k < 2 && H.rep > 1) {
+                for (int p = 0; p < count; ++p) {
+                    const int64_t nr = H.rep_n[(size_t)p];
+                    sg.push_back(RowSegment{H.xoff[p], H.xoff[p] + nr, p, (int32_t)nr});
+                    sg.push_back(RowSegment{H.xoff[p] + (int64_t)H.rep * nr, H.xoff[p + 1], p, 0});
+                }
+            } else {
+                sg = plain_segments(H.xoff);
+            }
+            if (k == 0) H.rbK = make_rowblocks(H.K, sg, count);
+            else if (k == 1) H.rbG1 = make_rowblocks(H.G1, sg, count);
+            else H.rbG2 = make_rowblocks(H.G2, sg, count);
         }
     });
     pt.mark("row blocks");
@@ -1175,12 +1309,27 @@ inline void build_system(const score_problem* probs, int count, const score_sett
             }
             H.chains.push_back(ch);
         }
+        // replicated problem: the chains come replica by replica (check_replication); replica k's chain c is
+        // replica 0's chain c shifted by k * rep_n and uses its factors
+        const size_t first = H.chain_owner.size(), mine = H.chains.size() - first;
+        const size_t per_rep = H.rep > 1 ? mine / (size_t)H.rep : mine;
+        for (size_t c = 0; c < mine; ++c) H.chain_owner.push_back((int32_t)(first + (per_rep ? c % per_rep : c)));
     }
+    for (size_t ci = 0; ci < H.chains.size(); ++ci) {
+        const ChainDesc& a = H.chains[ci];
+        const ChainDesc& o = H.chains[(size_t)H.chain_owner[ci]];
+        if (a.N != o.N || a.prob != o.prob) throw std::runtime_error("replicated chains do not line up");
+    }
+    std::vector<char> node_owned(H.node_col.size(), 1);  // nodes whose blocks are looked up in K
+    for (size_t ci = 0; ci < H.chains.size(); ++ci)
+        if (H.chain_owner[ci] != (int32_t)ci)
+            for (int i = 0; i < H.chains[ci].N; ++i) node_owned[(size_t)H.chains[ci].node_begin + i] = 0;
     // K.val positions of the diagonal / sub-diagonal block entries of every chain node
     H.pos_diag.assign(H.node_col.size() * b2, -1);
     H.pos_sub.assign(H.node_col.size() * b2, -1);
     parallel_ranges((int64_t)H.node_col.size(), 2048, [&](int, int64_t g0, int64_t g1) {
         for (int64_t g = g0; g < g1; ++g) {
+            if (!node_owned[(size_t)g]) continue;
             const int32_t col = H.node_col[g], pc = node_prev[g];
             size_t o = (size_t)g * b2;
             for (int a = 0; a < bs; ++a)
@@ -1196,7 +1345,11 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     struct Layout { int N; std::vector<ChainLevelDesc> lv; size_t fac_size; int scr; };
     size_t fac_total = H.fac.size();
     std::vector<Layout> layouts;  // the level structure depends only on (N, radix): one dry run per length
-    for (auto& ch : H.chains) {
+    size_t fac_total_H = 0;
+    int64_t scratch_H = 0;
+    H.chainsH = H.chains;
+    for (size_t ci = 0; ci < H.chains.size(); ++ci) {
+        ChainDesc& ch = H.chains[ci];
         const Layout* lay = nullptr;
         for (const auto& L : layouts)
             if (L.N == ch.N) lay = &L;
@@ -1211,23 +1364,43 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         std::vector<ChainLevelDesc> lv = lay->lv;
         const size_t fac_size = lay->fac_size;
         const int scr = lay->scr;
-        ch.level_begin = (int32_t)H.levels.size();
         ch.n_levels = (int32_t)lv.size();
         if (ch.n_levels > 20) throw std::runtime_error("chain too long: more than 20 partition levels");
-        const int64_t dbl_base = (int64_t)fac_total;
-        for (auto& L : lv) {
-            L.offR += dbl_base;
-            L.offS += dbl_base;
-            L.offB += dbl_base;
-            H.levels.push_back(L);
+        {   // the Newton matrix: every chain has factors of its own
+            ChainDesc& cH = H.chainsH[ci];
+            cH.level_begin = (int32_t)H.levelsH.size();
+            cH.n_levels = ch.n_levels;
+            for (auto L : lv) {
+                L.offR += (int64_t)fac_total_H; L.offS += (int64_t)fac_total_H; L.offB += (int64_t)fac_total_H;
+                H.levelsH.push_back(L);
+            }
+            fac_total_H += fac_size;
+            cH.scratch_off = (int32_t)scratch_H;
+            cH.scratch_nodes = scr;
+            scratch_H += scr;
         }
-        H.fac_off.push_back(dbl_base);
-        fac_total += fac_size;
+        if (H.chain_owner[ci] == (int32_t)ci) {
+            ch.level_begin = (int32_t)H.levels.size();
+            const int64_t dbl_base = (int64_t)fac_total;
+            for (auto& L : lv) {
+                L.offR += dbl_base;
+                L.offS += dbl_base;
+                L.offB += dbl_base;
+                H.levels.push_back(L);
+            }
+            H.fac_off.push_back(dbl_base);
+            fac_total += fac_size;
+        } else {  // (owners precede their replicas)
+            ch.level_begin = H.chains[(size_t)H.chain_owner[ci]].level_begin;
+            H.fac_off.push_back(H.fac_off[(size_t)H.chain_owner[ci]]);
+        }
         ch.scratch_off = (int32_t)H.scratch_nodes;
         ch.scratch_nodes = scr;
         H.scratch_nodes += scr;
         H.max_chain_scratch = std::max(H.max_chain_scratch, scr);
     }
+    H.fac_doubles_H = fac_total_H;
+    H.scratch_nodes = std::max(H.scratch_nodes, scratch_H);
     // (the factors themselves live on the device when the backend derives them there)
     H.fac.assign(H.factor_on_host ? fac_total : 0, 0.0);
     H.fac_doubles = fac_total;
@@ -1237,16 +1410,26 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     for (int p = 0; p < count; ++p) {
         while (ci < H.chains.size() && H.chains[ci].prob == p) {
             H.prec_work.push_back(PrecWork{0, (int32_t)ci, 0, p});
+            if (H.chain_owner[ci] == (int32_t)ci) H.factor_work.push_back(PrecWork{0, (int32_t)ci, 0, p});
             ++ci;
         }
         const size_t d_first = H.diag_cols.size();
         for (int64_t c = H.xoff[p]; c < H.xoff[p + 1]; ++c)
             if (!in_chain[c]) {
                 H.diag_cols.push_back((int32_t)c);
-                H.diag_kpos.push_back(find_in_row(H.K, c, (int32_t)c));
+                // (a column of replica k finds its diagonal in replica 0's row)
+                int64_t c0_ = c;
+                if (H.rep > 1) {
+                    const int64_t local = c - H.xoff[p], nr = H.rep_n[(size_t)p];
+                    if (local < (int64_t)H.rep * nr) c0_ = H.xoff[p] + local % nr;
+                }
+                H.diag_kpos.push_back(find_in_row(H.K, c0_, (int32_t)c0_));
             }
-        for (size_t e = d_first; e < H.diag_cols.size(); e += 1024)
-            H.prec_work.push_back(PrecWork{1, (int32_t)e, (int32_t)std::min<size_t>(1024, H.diag_cols.size() - e), p});
+        for (size_t e = d_first; e < H.diag_cols.size(); e += 1024) {
+            const PrecWork jw{1, (int32_t)e, (int32_t)std::min<size_t>(1024, H.diag_cols.size() - e), p};
+            H.prec_work.push_back(jw);
+            H.factor_work.push_back(jw);
+        }
         H.prec_part_ptr[p + 1] = (int32_t)H.prec_work.size();
     }
     H.dinv.assign(H.diag_cols.size(), 1.0);
@@ -1254,9 +1437,11 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     // + int32 column), 4 B per row pointer, vector p read once, w written once
     H.kkt_bytes.assign(count, 0.0);
     for (int p = 0; p < count; ++p) {
+        // (a replicated problem streams K_row and the tail once: the rows K holds; p and w are whole vectors)
         const double nnz = (double)(H.K.ptr[H.xoff[p + 1]] - H.K.ptr[H.xoff[p]]);
         const double n = (double)(H.xoff[p + 1] - H.xoff[p]);
-        H.kkt_bytes[p] = 12.0 * nnz + 4.0 * (n + 1) + 16.0 * n;
+        const double rows = H.rep > 1 ? n - (double)(H.rep - 1) * (double)H.rep_n[(size_t)p] : n;
+        H.kkt_bytes[p] = 12.0 * nnz + 4.0 * (rows + 1) + 16.0 * n;
     }
     pt.mark("jacobi + work list");
     for (int p = 0; p < count; ++p) refresh_rho(H, p);

@@ -116,6 +116,7 @@ struct CsrDev {
     const int32_t* first_row;  // row blocks
     const int32_t* blk_prob;
     const int4* blk_meta;      // per block {first row, end row, first nonzero, end nonzero}: one load
+    const int32_t* blk_rs;     // per block: replica stride (rows of replica 0 applied to NR right-hand sides), 0 = plain rows
     const int32_t* split;      // G2 only
     int nblocks;
 };
@@ -140,6 +141,9 @@ struct SpmvArgs {
     CsrDev M;
     const double* xin;      // gathered vector
     const int32_t* done;
+    // replicated rows (blk_rs[b] > 0): replica k gathers xin[col + k * rs_in] (rs_in == 0: the block's own stride)
+    // and owns the vector entries row + k * blk_rs[b]
+    int rs_in;
     // RHS
     const double* x;
     const double* q;
@@ -181,29 +185,26 @@ struct SpmvArgs {
 // GRAD: gradient of the reduced (head-eliminated) problem, M = [P | A'], xin = [u ; nu]
 enum { MODE_RHS = 0, MODE_KP = 1, MODE_DRES = 2, MODE_KPB = 3, MODE_GRAD = 4 };
 
-template <int MODE>
-__global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
-    KernelStamp stamp(a.tstamp);
-    // products of the tile, padded by one double per 8: the row sums read consecutive 8-entry segments from
-    // consecutive lanes (stride 8 doubles = 16 banks -> 16-way conflicts unpadded, 2-way with stride 9)
-    __shared__ double prod[kTileNnz + kTileNnz / 8];
+constexpr int kMaxRep = 3;
+constexpr int kProdPlane = kTileNnz + kTileNnz / 8;  // products of one right-hand side, padded by one double per 8
+
+// One tile (row block) of the SpMV with NR right-hand sides per matrix row.  NR == 1: plain CSR rows.  NR > 1: the
+// rows of replica 0 of a problem whose operator is I_NR (x) K_row -- the matrix stream (12 B per nonzero) is read
+// once, the gathers and the LDS products are per replica; sums are per replica in CSR order, so every replica gets
+// exactly what a plain SpMV on its own copy of the rows would give.
+template <int MODE, int NR>
+__device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int4 meta, const int prob, const int my_ptr, const int end_ptr,
+                                          const int rs_out, double* __restrict__ prod, double* red, int32_t* srow) {
+    static_assert(NR == 1 || (MODE != MODE_DRES && MODE != MODE_GRAD), "residual / gradient modes run on plain rows");
     auto kpad = [](int k) -> int { return k + (k >> 3); };
-    __shared__ double red[8];
-    __shared__ int32_t srow[kRowsPerBlock + 1];  // row pointers of the tile, relative to k0
     const int b = blockIdx.x;
     const int t = threadIdx.x;
-    // one 16-byte load gives the whole tile geometry; the frozen-problem flag and the
-    // tile's row pointers are requested together with it
-    const int4 meta = a.M.blk_meta[b];
-    const int prob = a.M.blk_prob[b];
     const int r0 = meta.x, r1 = meta.y, k0 = meta.z, k1 = meta.w;
     const int nn = k1 - k0;
-    const int my_ptr = a.M.ptr[min(r0 + t, r1)];
-    const int end_ptr = (t == 0) ? k1 : 0;
-    if (a.done[prob]) return;
+    const int rs_in = (NR > 1) ? (a.rs_in ? a.rs_in : rs_out) : 0;
     const double* __restrict__ val = a.M.val;
     const int32_t* __restrict__ col = a.M.col;
-    const double* __restrict__ xin = a.xin;
+    const double* __restrict__ xin = (MODE == MODE_KPB) ? a.z : a.xin;
 
     // KPB: beta = r'z_new / r'z_old.  The partial sums are requested here, but reduced
     // (two barriers) only after the matrix and vector loads of the tile are in flight.
@@ -223,16 +224,41 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
 
     int row = r0 + t;
     bool has_row = false;
-    double sum = 0.0, sum2 = 0.0;  // sum2: A' part (MODE_DRES)
+    double sum[NR], sum2 = 0.0;  // sum2: A' part (MODE_DRES / MODE_GRAD, NR == 1)
+#pragma unroll
+    for (int q = 0; q < NR; ++q) sum[q] = 0.0;
+    // The frozen-problem flag and the operands of the epilogue (this lane's own vector entries) are requested together
+    // with the matrix entries, on a clamped row: every trip to memory the tile needs is then in flight before the
+    // first wait -- tile record -> {matrix, row pointers, own entries, flag} -> gathers -- instead of five dependent trips.
+    const int dn = a.done[prob];
+    const bool one_long = (r1 - r0 == 1 && nn > kLongRow);
+    const int ro = one_long ? r0 : min(row, max(r1 - 1, r0));
+    double e0[NR], e1[NR], e2[NR], e3[NR], e4[NR], e5[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int o = ro + q * rs_out;
+        e0[q] = e1[q] = e2[q] = e3[q] = e4[q] = e5[q] = 0.0;
+        if (MODE == MODE_RHS) {
+            e0[q] = a.kx[o]; e1[q] = a.x[o]; e2[q] = a.q[o];
+            if (a.apply_update) { e3[q] = a.xt_rw[o]; e4[q] = a.pfin[o]; e5[q] = a.wfin[o]; }
+        } else if (MODE == MODE_KP) {
+            e0[q] = a.p[o];
+        } else if (MODE == MODE_KPB) {
+            e0[q] = a.w[o]; e1[q] = a.z[o]; e2[q] = a.p[o];
+        }
+    }
 
-    if (r1 - r0 == 1 && nn > kLongRow) {
+    if (one_long) {
         // one long row: unrolled strided partial sums + tree reduction
-        double acc = 0.0, acc2 = 0.0;
+        double acc[NR], acc2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) acc[q] = 0.0;
         const int split = (MODE == MODE_DRES || MODE == MODE_GRAD) ? a.M.split[r0] : k1;
+        if (dn) return;  // (uniform over the workgroup)
         finish_beta();  // uniform: lanes beyond the row's end never enter the sweep
         for (int kb = k0 + t; kb < k1; kb += kThreads * kLongUnroll) {
             int32_t c[kLongUnroll];
-            double v[kLongUnroll], g[kLongUnroll];
+            double v[kLongUnroll], g[kLongUnroll][NR];
 #pragma unroll
             for (int u = 0; u < kLongUnroll; ++u) {
                 const int k = min(kb + u * kThreads, k1 - 1);
@@ -241,16 +267,21 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
             }
 #pragma unroll
             for (int u = 0; u < kLongUnroll; ++u) {
-                if (MODE == MODE_KPB) g[u] = a.z[c[u]]; else g[u] = xin[c[u]];
+#pragma unroll
+                for (int q = 0; q < NR; ++q) g[u][q] = xin[c[u] + q * rs_in];
             }
 #pragma unroll
             for (int u = 0; u < kLongUnroll; ++u) {
                 const int k = kb + u * kThreads;
-                const double pr = (k < k1) ? v[u] * g[u] : 0.0;
-                if ((MODE == MODE_DRES || MODE == MODE_GRAD) && k >= split) acc2 += pr; else acc += pr;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const double pr = (k < k1) ? v[u] * g[u][q] : 0.0;
+                    if ((MODE == MODE_DRES || MODE == MODE_GRAD) && k >= split) acc2 += pr; else acc[q] += pr;
+                }
             }
         }
-        sum = block_sum(acc, red);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) sum[q] = block_sum(acc[q], red);
         if (MODE == MODE_DRES || MODE == MODE_GRAD) sum2 = block_sum(acc2, red);
         has_row = (t == 0);
         row = r0;
@@ -258,7 +289,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         // Loads are unconditional on clamped indices (a predicated load becomes a branch
         // and serialises the memory pipeline); only the LDS stores are predicated.
         int32_t c[kUnroll];
-        double v[kUnroll], g[kUnroll];
+        double v[kUnroll], g[kUnroll][NR];
         const int klast = max(nn - 1, 0);
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
@@ -268,13 +299,18 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            if (MODE == MODE_KPB) g[u] = a.z[c[u]]; else g[u] = xin[c[u]];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) g[u][q] = xin[c[u] + q * rs_in];
         }
+        if (dn) return;  // (uniform over the workgroup; nothing has been written)
         finish_beta();
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
             const int k = t + u * kThreads;
-            if (k < nn) prod[kpad(k)] = v[u] * g[u];
+            if (k < nn) {
+#pragma unroll
+                for (int q = 0; q < NR; ++q) prod[q * kProdPlane + kpad(k)] = v[u] * g[u][q];
+            }
         }
         if (r0 + t <= r1) srow[t] = my_ptr - k0;
         if (t == 0) srow[r1 - r0] = end_ptr - k0;
@@ -284,43 +320,54 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
             const int a0 = srow[t], a1 = srow[t + 1];
             if (MODE == MODE_DRES || MODE == MODE_GRAD) {
                 const int sp = a.M.split[row] - k0;
-                for (int k = a0; k < sp; ++k) sum += prod[kpad(k)];
+                for (int k = a0; k < sp; ++k) sum[0] += prod[kpad(k)];
                 for (int k = sp; k < a1; ++k) sum2 += prod[kpad(k)];
             } else {
-                for (int k = a0; k < a1; ++k) sum += prod[kpad(k)];
+                for (int k = a0; k < a1; ++k) {
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) sum[q] += prod[q * kProdPlane + kpad(k)];
+                }
             }
         }
     }
 
     if (MODE == MODE_RHS) {
         if (has_row) {
-            double kxv = a.kx[row];
-            double xv = a.x[row];
-            if (a.apply_update) {
-                const double xt = a.xt_rw[row] + beta * a.pfin[row];
-                kxv += beta * a.wfin[row];
-                xv = a.alpha_relax * xt + (1.0 - a.alpha_relax) * xv;
-                a.xt_rw[row] = xt;
-                a.kx_rw[row] = kxv;
-                a.x_rw[row] = xv;
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int o = row + q * rs_out;
+                double kxv = e0[q];
+                double xv = e1[q];
+                if (a.apply_update) {
+                    const double xt = e3[q] + beta * e4[q];
+                    kxv += beta * e5[q];
+                    xv = a.alpha_relax * xt + (1.0 - a.alpha_relax) * xv;
+                    a.xt_rw[o] = xt;
+                    a.kx_rw[o] = kxv;
+                    a.x_rw[o] = xv;
+                }
+                a.r[o] = a.sigma * xv - e2[q] + sum[q] - kxv;
             }
-            a.r[row] = a.sigma * xv - a.q[row] + sum - kxv;
         }
     } else if (MODE == MODE_KP || MODE == MODE_KPB) {
         double local = 0.0;
         if (has_row) {
-            double pi;
-            if (MODE == MODE_KPB) {
-                // K (z + beta p) = K z + beta w_old: one gather (z) per nonzero instead of two; w_old = K p_old is this
-                // row's own entry.  (The first product of a solve is always the direct one, MODE_KP.)
-                sum += beta * a.w[row];
-                pi = a.z[row] + beta * a.p[row];
-                a.p_out[row] = pi;
-            } else {
-                pi = a.p[row];
+#pragma unroll
+            for (int q = 0; q < NR; ++q) {
+                const int o = row + q * rs_out;
+                double pi, sq = sum[q];
+                if (MODE == MODE_KPB) {
+                    // K (z + beta p) = K z + beta w_old: one gather (z) per nonzero instead of two; w_old = K p_old is this
+                    // row's own entry.  (The first product of a solve is always the direct one, MODE_KP.)
+                    sq += beta * e0[q];
+                    pi = e1[q] + beta * e2[q];
+                    a.p_out[o] = pi;
+                } else {
+                    pi = e0[q];
+                }
+                a.w[o] = sq;
+                local += pi * sq;
             }
-            a.w[row] = sum;
-            local = pi * sum;
         }
         const double tot = block_sum(local, red);
         if (t == 0) a.pw_part[b] = tot;
@@ -329,14 +376,14 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         if (has_row) {
             const bool head = a.is_head[row] != 0;
             const double qi = a.q[row];
-            const double g = head ? 0.0 : sum + qi + sum2;
+            const double g = head ? 0.0 : sum[0] + qi + sum2;
             if (g != g) bad = 1.0;
             a.gout[row] = g;
             a.r[row] = -g;
             m0 = fabs(g) * a.invD[row];
             m1 = fabs(g);
             const double xi = xin[row];
-            s0 = head ? 0.0 : xi * (0.5 * sum + qi);
+            s0 = head ? 0.0 : xi * (0.5 * sum[0] + qi);
         }
         bad = block_sum(bad, red);
         m0 = block_max(m0, red); m1 = block_max(m1, red);
@@ -350,13 +397,13 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
         double m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0, m5 = 0, s0 = 0, s1 = 0, s2 = 0, bad = 0;
         if (has_row) {
             const double qi = a.q[row];
-            const double dr = sum + qi + sum2;
+            const double dr = sum[0] + qi + sum2;
             const double id = a.invD[row];
             if (dr != dr) bad = 1.0;
-            m0 = fabs(dr) * id; m1 = fabs(sum) * id; m2 = fabs(sum2) * id;
-            m3 = fabs(dr); m4 = fabs(sum); m5 = fabs(sum2);
+            m0 = fabs(dr) * id; m1 = fabs(sum[0]) * id; m2 = fabs(sum2) * id;
+            m3 = fabs(dr); m4 = fabs(sum[0]); m5 = fabs(sum2);
             const double xi = xin[row];
-            s0 = xi * sum;
+            s0 = xi * sum[0];
             s1 = qi * xi;
             s2 = xi * dr;  // x'r_d: a cancellation-free piece of the duality gap
         }
@@ -370,6 +417,28 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
             o[0] = m0 + nanv; o[1] = m1; o[2] = m2; o[3] = m3 + nanv; o[4] = m4; o[5] = m5; o[6] = s0; o[7] = s1; o[8] = s2;
         }
     }
+}
+
+// NR: right-hand sides per row of the replicated blocks of this launch (1: every block holds plain rows)
+template <int MODE, int NR = 1>
+__global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
+    KernelStamp stamp(a.tstamp);
+    // products of the tile, one padded plane per right-hand side: the row sums read consecutive 8-entry segments from
+    // consecutive lanes (stride 8 doubles = 16 banks -> 16-way conflicts unpadded, 2-way with stride 9)
+    __shared__ double prod[NR * kProdPlane];
+    __shared__ double red[8];
+    __shared__ int32_t srow[kRowsPerBlock + 1];  // row pointers of the tile, relative to k0
+    const int b = blockIdx.x;
+    const int t = threadIdx.x;
+    // one 16-byte load gives the whole tile geometry; the frozen-problem flag and the
+    // tile's row pointers are requested together with it
+    const int4 meta = a.M.blk_meta[b];
+    const int prob = a.M.blk_prob[b];
+    const int rs = (NR > 1) ? a.M.blk_rs[b] : 0;
+    const int my_ptr = a.M.ptr[min(meta.x + t, meta.y)];
+    const int end_ptr = (t == 0) ? meta.w : 0;
+    if (NR > 1 && rs > 0) spmv_tile<MODE, NR>(a, meta, prob, my_ptr, end_ptr, rs, prod, red, srow);
+    else spmv_tile<MODE, 1>(a, meta, prob, my_ptr, end_ptr, 0, prod, red, srow);
 }
 
 // ---------------------------------------------------------------------------
@@ -1313,10 +1382,11 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// vector update at the end of the PCG sweep (grid = K row blocks)
+// vector update at the end of the PCG sweep (grid = vector blocks)
 // ---------------------------------------------------------------------------
 struct VecArgs {
-    const int32_t* first_row;
+    const int32_t* first_row;   // blocks of <= 256 consecutive vector entries of one problem (not the K row blocks:
+    const int32_t* end_row;     //  a replicated K holds replica 0's rows only)
     const int32_t* blk_prob;
     const int32_t* done;
     const int32_t* prec_part_ptr;
@@ -1344,7 +1414,7 @@ __global__ __launch_bounds__(kThreads) void k_xupdate(VecArgs a) {
         alpha = pw > 0.0 ? rz / pw : 0.0;
     }
     const int row = a.first_row[b] + threadIdx.x;
-    if (row < a.first_row[b + 1]) {
+    if (row < a.end_row[b]) {
         const double xt = a.xt[row] + alpha * a.p[row];
         a.xt[row] = xt;
         if (a.apply_alpha) a.kx[row] += alpha * a.w[row];

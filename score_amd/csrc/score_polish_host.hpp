@@ -183,7 +183,7 @@ inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = fals
         });
     }
     pt.mark("    polish: concatenate");
-    Q.rbH = make_rowblocks(Q.Hm, H.xoff);
+    Q.rbH = make_rowblocks(Q.Hm, plain_segments(H.xoff), H.count);
     pt.mark("    polish: row blocks");
     // ---- chain block / Jacobi positions in H ----
     const int bs = H.bs;

@@ -76,6 +76,26 @@ def record_stride(datas: Sequence) -> int:
     return _HDR + worst
 
 
+def all_gather_records(buf: np.ndarray, device: Optional[int] = None) -> List[np.ndarray]:
+    """One all_gather of a rank's fixed-shape float64 record block; returns every rank's block (rank order).
+    Backend "nccl" (= RCCL over xGMI on ROCm): the block travels through this rank's GPU; "gloo": host memory.
+    Without an initialised process group: [buf] -- the single-process case takes the same code path."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return [np.asarray(buf)]
+    world = dist.get_world_size()
+    t = torch.from_numpy(np.ascontiguousarray(buf, dtype=np.float64))
+    if dist.get_backend() == "nccl":
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        t = t.to(f"cuda:{device}")
+    gathered = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(gathered, t)
+    return [g.cpu().numpy() for g in gathered]
+
+
 def solve_score_sharded(
     datas: Sequence, relaxation_type: str = "QCQP", solver_settings: Optional[dict] = None,
     lib_path: Optional[str] = None, device: Optional[int] = None,
@@ -87,7 +107,6 @@ def solve_score_sharded(
     shard.  The gathered record carries the rounded poses, landmarks and solver statistics --
     what ``SolverResults`` exposes -- not the raw conic iterates x / y / s.)  If any problem fails
     anywhere, every rank raises after the collective; no rank is left waiting."""
-    import torch
     import torch.distributed as dist
 
     if not (dist.is_available() and dist.is_initialized()):
@@ -125,16 +144,11 @@ def solve_score_sharded(
             buf[slot, :] = np.nan
             buf[slot, 0] = 3.0   # status: numerical
             buf[slot, 7] = -1.0  # no values
-    use_cuda = dist.get_backend() == "nccl"
-    t = torch.from_numpy(buf)
-    if use_cuda:
-        t = t.to(f"cuda:{device}")
-    gathered = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(gathered, t)
+    gathered = all_gather_records(buf, device)
     out: List[Optional[compat.SolverResults]] = [None] * len(datas)
     failed = []
     for r in range(world):
-        g = gathered[r].cpu().numpy()
+        g = gathered[r]
         for slot, i in enumerate(shards[r]):
             if g[slot, 7] < 0:
                 failed.append(i)

@@ -179,6 +179,7 @@ class NativeQP:
         self.n, self.m, self.z = int(p.n), int(p.m), int(p.z)
         self.c0 = float(p.c0)
         self.block_size = int(p.block_size)
+        self.rep_d, self.rep_n = int(p.rep_d), int(p.rep_n)
         self._cache = {}
 
     def _arr(self, ptr, count, dtype):
@@ -284,15 +285,20 @@ def assemble_native(data, relaxation: str = QCQP_RELAXATION, lib_path: Optional[
     lm_base = Np * PB
     rng_base = lm_base + Nl * d
     n_model = rng_base + Nr * rw
-    pieces, base = [], 0
+    pieces = []
     j_ar = np.arange(D1)
-    for L in a["chain_len"]:
-        idx = base + np.arange(int(L))
-        idx = idx[idx != 0]
-        for k in range(d):
+    for k in range(d):  # replica by replica (score_assemble.hpp / assemble.py: the same order)
+        base = 0
+        for L in a["chain_len"]:
+            idx = base + np.arange(int(L))
+            idx = idx[idx != 0]
             pieces.append((idx[:, None] * PB + k * D1 + j_ar[None, :]).ravel())
-        base += int(L)
-    pieces.append(np.arange(lm_base, n_model))
+            base += int(L)
+        pieces.append(lm_base + np.arange(Nl) * d + k)
+        if relaxation != SOCP_RELAXATION:
+            pieces.append(rng_base + np.arange(Nr) * d + k)
+    if relaxation == SOCP_RELAXATION:
+        pieces.append(rng_base + np.arange(Nr))
     free_cols = np.concatenate(pieces)
     assert free_cols.size == qp.n, (free_cols.size, qp.n)
     ends = dist = None

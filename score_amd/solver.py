@@ -31,6 +31,7 @@ class ScoreProblem(C.Structure):
         ("z", C.c_int32), ("n_soc", C.c_int32), ("soc_dims", _i32p),
         ("block_size", C.c_int32), ("n_chains", C.c_int32),
         ("chain_ptr", _i32p), ("node_first_col", _i32p),
+        ("rep_d", C.c_int32), ("rep_n", C.c_int32),
     ]
 
 
@@ -198,6 +199,7 @@ class ConicSolver:
             nch = int(len(qp.chain_ptr) - 1) if qp.block_size else 0
             p.block_size, p.n_chains = int(qp.block_size), nch
             p.chain_ptr, p.node_first_col = _ptr(arrs["cp"], _i32p), _ptr(arrs["nc"], _i32p)
+            p.rep_d, p.rep_n = int(getattr(qp, "rep_d", 0)), int(getattr(qp, "rep_n", 0))
         self._h = C.c_void_p()
         rc = self.lib.score_create_batch(probs, self.count, C.byref(st), C.byref(self._h))
         if rc != 0:

@@ -35,14 +35,16 @@ CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
 
 
 def test_bench_gpus_flag_launches_that_many_ranks(twin_lib):
-    """`python bench.py --gpus 2` must start two ranks by itself (no torchrun) and report n_gpus = 2
-    on BASELINE configs[4] (Monte-Carlo trials sharded i mod N).  Run here on gloo + the oracle's CPU
-    twin (--test-cpu-twin); on the GPU box the same launcher starts RCCL ranks."""
+    """`python bench.py --gpus 2` must start two ranks by itself (no torchrun) and report n_gpus = 2 with the SAME
+    primary metric as one rank (SOCP iterations/s, every rank its own headline problem: weak scaling), plus BASELINE
+    configs[4] sharded t mod N with ONE all_gather of the result records per sweep.  Run here on gloo + the oracle's
+    CPU twin (--test-cpu-twin); on the GPU box the same launcher starts RCCL ranks."""
     env = dict(os.environ, OMP_NUM_THREADS="2")
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
     out = subprocess.run(
-        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--test-cpu-twin", "--montecarlo", "5",
-         "--mc-robots", "2", "--mc-poses", "30", "--mc-batch", "2", "--mc-threads", "1", "--steps", "1", "--warmup", "0"],
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--test-cpu-twin", "--robots", "2", "--poses", "30",
+         "--montecarlo", "5", "--mc-robots", "2", "--mc-poses", "30", "--mc-batch", "2", "--mc-threads", "1", "--steps", "1",
+         "--warmup", "0"],
         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env,
     )
     assert out.returncode == 0, out.stderr[-3000:]
@@ -51,24 +53,47 @@ def test_bench_gpus_flag_launches_that_many_ranks(twin_lib):
     rec = json.loads(lines[0])
     for key in CONTRACT_KEYS:
         assert key in rec
-    assert rec["n_gpus"] == 2 and rec["metric"] == "problems_per_sec" and rec["scaling"] == "strong"
-    assert rec["problems_total_per_step"] == 5 and rec["problems_solved_last_sweep"] == 5  # 3 trials on rank 0, 2 on rank 1
+    assert rec["n_gpus"] == 2 and rec["metric"] == "socp_iters_per_sec" and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["timed_region"]["problems_total"] == 2 and rec["timed_region"]["problems_solved"] == 2  # one per rank
+    c5 = rec["config5_montecarlo"]
+    assert c5["n_gpus"] == 2 and c5["scaling"] == "strong" and c5["trials"] == 5 and c5["problems_per_sec"] > 0
+    assert c5["results_gathered"] == 5 and c5["solved_last_sweep"] == 5  # 3 trials on rank 0, 2 on rank 1, all records on rank 0
+    assert "gloo" in c5["gather"]
     assert "test_mode" in rec
 
 
 def test_bench_is_one_of_the_ranks_under_a_launcher(twin_lib):
     """With RANK / WORLD_SIZE already in the environment (torch.distributed.run) bench.py must not
-    spawn anything: world size 1 here, process group forced on."""
+    spawn anything: world size 1 here, process group forced on (the gather then runs as a 1-rank collective)."""
     env = dict(os.environ, OMP_NUM_THREADS="2", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT="29533")
     out = subprocess.run(
-        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--test-cpu-twin", "--force-dist", "--montecarlo", "2",
-         "--mc-robots", "1", "--mc-poses", "30", "--mc-beacons", "2", "--steps", "1", "--warmup", "0"],
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--test-cpu-twin", "--force-dist", "--robots", "1",
+         "--poses", "30", "--beacons", "2", "--montecarlo", "2", "--mc-robots", "1", "--mc-poses", "30", "--mc-beacons", "2",
+         "--steps", "1", "--warmup", "0"],
         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env,
     )
     assert out.returncode == 0, out.stderr[-3000:]
     rec = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
-    assert rec["n_gpus"] == 1 and rec["problems_solved_last_sweep"] == 2
+    assert rec["n_gpus"] == 1 and rec["metric"] == "socp_iters_per_sec"
+    assert rec["config5_montecarlo"]["solved_last_sweep"] == 2 and rec["config5_montecarlo"]["results_gathered"] == 2
+
+
+def test_a_failing_rank_takes_the_launch_down_promptly(twin_lib):
+    """The launcher polls every child: a rank that dies (here: an impossible workload on every rank) ends the whole
+    launch with a non-zero code at once -- no rank is left waiting in a collective for the backend's timeout."""
+    import time
+
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+    t0 = time.time()
+    out = subprocess.run(
+        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--test-cpu-twin", "--robots", "0", "--poses", "30",
+         "--steps", "1", "--warmup", "0"],
+        capture_output=True, text=True, timeout=300, cwd=ROOT, env=env,
+    )
+    assert out.returncode != 0 and time.time() - t0 < 120
+    assert "exited with code" in out.stderr
 
 
 def test_montecarlo_group_sizes():

@@ -7,7 +7,7 @@ import pytest
 import scipy.sparse as sp
 import scipy.sparse.linalg as spla
 
-from conftest import compare_residuals_with_golden, compare_with_golden, graph_by_name, load_golden
+from conftest import GOLDEN_NAMES, compare_residuals_with_golden, compare_with_golden, graph_by_name, load_golden
 from score_amd import compat
 from score_amd.assemble import assemble
 from score_amd.manhattan import make_manhattan
@@ -243,3 +243,52 @@ def test_array_graph_input_equals_object_input(twin_lib):
         for nm in x.poses:  # (two ADMM runs of the OpenMP twin stop within the tolerance of each other, not bitwise)
             np.testing.assert_allclose(x.poses[nm], y.poses[nm], atol=1e-3)
         assert list(x.distances.keys()) == list(y.distances.keys())
+
+
+@pytest.mark.parametrize("name,relax", [("manhattan", "SOCP"), ("synth_b", "SOCP"), ("graph3d", "SOCP"), ("synth_d", "QCQP")])
+def test_row_replicated_setup_equals_the_general_one(name, relax, fixtures, twin_lib, monkeypatch):
+    """The model couples one row k of the pose matrices at a time (gurobi_utils.py:504-526); only the cones couple the
+    rows (:345-352).  Both assemblers order the unknowns replica by replica and announce it (score_problem::rep_d);
+    the solver then keeps K_row once: K and A' hold replica 0's rows, a replica's chain uses its owner's factors.
+    Here the host side of that: the twin run on the replicated structures (SCORE_TWIN_REPLICATION) must walk through
+    the same iterates as the twin run on the full K (3-D: three replicas; QCQP: no tail; loop closures)."""
+    fg = graph_by_name(name, fixtures)
+    direct = relax == "QCQP"
+    mdl = assemble(fg, relax)
+    qp = mdl.qp
+    d = fg.dimension
+    assert qp.rep_d == d and qp.rep_n * d + (0 if direct else len(mdl.range_keys)) == qp.n
+    # the structure itself, on the assembled matrices: P = I_d (x) P_row (+ tail), no coupling between the replicas
+    nr = qp.rep_n
+    P = qp.P.tocsr()
+    P0 = P[:nr, :nr]
+    for k in range(1, d):
+        assert abs(P[k * nr : (k + 1) * nr, k * nr : (k + 1) * nr] - P0).max() == 0.0
+    off = P[: d * nr, : d * nr].copy().tolil()
+    for k in range(d):
+        off[k * nr : (k + 1) * nr, k * nr : (k + 1) * nr] = 0
+    assert off.tocsr().count_nonzero() == 0
+    outs = {}
+    for mode in ("general", "replicated"):
+        if mode == "replicated":
+            monkeypatch.setenv("SCORE_TWIN_REPLICATION", "1")
+        else:
+            monkeypatch.delenv("SCORE_TWIN_REPLICATION", raising=False)
+        sol = ConicSolver(qp, dict(polish=0, adaptive_rho=0, adaptive_cg=0, fac_fp32=0), lib_path=twin_lib)
+        outs[mode] = (sol.steps(60)[0], sol.debug_get("Kval"), sol.debug_get("z"), sol.debug_get("kx"))
+        sol.close()
+    (a, Ka, za, kxa), (b, Kb, zb, kxb) = outs["general"], outs["replicated"]
+    # the replicated K holds replica 0's rows and the tail's: fewer values, same entries
+    assert Kb.size < Ka.size and np.isclose(Kb.sum() * 1.0, Kb.sum())
+    scale = np.abs(a.x).max()
+    np.testing.assert_allclose(b.x, a.x, atol=1e-9 * scale)
+    np.testing.assert_allclose(b.y, a.y, atol=1e-9 * max(1.0, np.abs(a.y).max()))
+    np.testing.assert_allclose(zb, za, atol=1e-9 * max(1e-300, np.abs(za).max()))
+    np.testing.assert_allclose(kxb, kxa, atol=1e-9 * max(1e-300, np.abs(kxa).max()))
+    assert b.info["pobj"] == pytest.approx(a.info["pobj"], rel=1e-7)  # (sums of terms of magnitude 1e5: x to 1e-9)
+    # a full solve on the replicated structures ends at the golden optimum
+    monkeypatch.setenv("SCORE_TWIN_REPLICATION", "1")
+    res = solve_score(fg, relax, qcqp_mode="direct" if direct else "via_socp", solver_settings=dict(max_iters=30000), lib_path=twin_lib)
+    assert res.solved
+    if name in GOLDEN_NAMES:
+        compare_with_golden(res, load_golden(name), pose_tol=1e-4)

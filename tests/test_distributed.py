@@ -57,3 +57,48 @@ def test_two_rank_gloo_matches_single_process(twin_lib, tmp_path):
     single = [solve_score(g, "SOCP", lib_path=twin_lib) for g in graphs]
     flat = np.concatenate([np.concatenate([r.poses[n].ravel() for n in sorted(r.poses)]) for r in single])
     np.testing.assert_allclose(r0, flat, atol=1e-6)
+
+
+_NCCL_CHILD = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np
+import torch
+import torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT={port!r}, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+from score_amd.distributed import solve_score_sharded
+from score_amd.manhattan import make_manhattan
+from score_amd.solve_score import solve_score_batch
+graphs = [make_manhattan(n_robots=2, n_poses=30 + 7 * i, n_beacons=2, seed=51 + i) for i in range(5)]
+assert dist.get_backend() == "nccl"
+res = solve_score_sharded(graphs, "SOCP", device=0)          # solve on this GPU, records through ONE RCCL all_gather
+ref = solve_score_batch(graphs, "SOCP", solver_settings=dict(device=0))
+worst = 0.0
+for a, b in zip(res, ref):
+    assert a.solved and b.solved
+    for n in b.poses:
+        worst = max(worst, float(np.abs(a.poses[n] - b.poses[n]).max()))
+    for n in b.landmarks:
+        worst = max(worst, float(np.abs(a.landmarks[n] - b.landmarks[n]).max()))
+assert worst <= 1e-9, worst
+dist.barrier()
+dist.destroy_process_group()
+print("NCCL_SHARDED_OK", worst)
+"""
+
+
+@pytest.mark.gpu
+def test_sharded_solve_under_rccl_equals_the_batch_solve(hip_lib):
+    """The N > 1 path on real hardware as far as one GPU allows: solve_score_sharded in a process group with backend
+    "nccl" (= RCCL) and world size 1 -- device binding, the product's HIP solves, and the all_gather of the result
+    records through the GPU -- equals solve_score_batch.  Runs in a child process started before this one has a
+    process group (never a re-exec of a GPU-initialised process)."""
+    import subprocess
+
+    code = _NCCL_CHILD.format(root=ROOT, port=str(_free_port()))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
+    assert "NCCL_SHARDED_OK" in out.stdout

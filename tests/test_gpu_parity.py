@@ -49,6 +49,9 @@ def test_iterates_match_cpu_twin(name, radix, cg, fp32, fixtures, hip_lib, twin_
         gpu = ConicSolver(qp, dict(use_graph=use_graph, **st), lib_path=hip_lib)
         cpu = ConicSolver(qp, st, lib_path=twin_lib)
         assert gpu.backend == "hip-gfx950" and cpu.backend == "cpu-twin"
+        # the product runs the problem row-replicated (K_row streamed once for both rows of the pose matrices);
+        # the twin applies the full K the problem defines
+        assert gpu.debug_get("rep")[0] == 2 and cpu.debug_get("rep")[0] == 1
         gpu.reset(); cpu.reset()
         for k in (1, 5, 9):
             a, b = gpu.steps(k)[0], cpu.steps(k)[0]
@@ -63,6 +66,48 @@ def test_iterates_match_cpu_twin(name, radix, cg, fp32, fixtures, hip_lib, twin_
             assert a.info["res_dual"] == pytest.approx(b.info["res_dual"], rel=1e-2 if fp32 else 1e-6, abs=1e-2 if fp32 else 1e-9)
             assert a.info["pobj"] == pytest.approx(b.info["pobj"], rel=tol, abs=tol)
         gpu.close(); cpu.close()
+
+
+@pytest.mark.parametrize("name,relax,rep", [("manhattan", "SOCP", 2), ("graph3d", "SOCP", 3), ("synth_d", "QCQP", 2), ("synth_b", "SOCP", 2)])
+def test_replicated_kernels_match_the_general_ones(name, relax, rep, fixtures, hip_lib, twin_lib, monkeypatch):
+    """K = I_d (x) K_row (+ tail) for every SCORE model (the cost couples one row of the pose matrices at a time,
+    gurobi_utils.py:504-526; only the cones couple rows, :345-352).  The product streams K_row once and applies it to
+    the d right-hand sides (k_spmv<MODE, NR>), factors one set of chains per robot and lets the d chains of a robot
+    share it.  Against the same library with the structure switched off (SCORE_NO_REPLICATION: the general kernels on
+    the full K) and against the CPU twin: every internal vector after k ADMM iterations, in 2-D, 3-D (three
+    replicas), for the direct QCQP form (no tail unknowns) and with loop closures."""
+    _hip_only(hip_lib)
+    qp = assemble(graph_by_name(name, fixtures), relax).qp
+    st = dict(adaptive_cg=0, adaptive_rho=0, check_interval=5, fac_fp32=0, polish=0)
+    monkeypatch.delenv("SCORE_NO_REPLICATION", raising=False)
+    fast = ConicSolver(qp, st, lib_path=hip_lib)
+    monkeypatch.setenv("SCORE_NO_REPLICATION", "1")
+    plain = ConicSolver(qp, st, lib_path=hip_lib)
+    monkeypatch.delenv("SCORE_NO_REPLICATION", raising=False)
+    cpu = ConicSolver(qp, st, lib_path=twin_lib)
+    ri, rp = fast.debug_get("rep"), plain.debug_get("rep")
+    assert ri[0] == rep and rp[0] == 1 and cpu.debug_get("rep")[0] == 1
+    n_tail = qp.n - rep * qp.rep_n
+    assert ri[1] * rep - (rep - 1) * n_tail == rp[1]  # stored K: replica 0's rows + the (diagonal) tail rows
+    for s_ in (fast, plain, cpu):
+        s_.reset()
+    for k in (1, 6, 13):
+        outs = [s_.steps(k)[0] for s_ in (fast, plain, cpu)]
+        for v in VECS:
+            ga, gb, gc = fast.debug_get(v), plain.debug_get(v), cpu.debug_get(v)
+            scale = max(1.0, np.abs(gc).max())
+            assert np.abs(ga - gb).max() <= 1e-10 * scale, (v, k, np.abs(ga - gb).max(), scale)
+            assert np.abs(ga - gc).max() <= 1e-9 * scale, (v, k, np.abs(ga - gc).max(), scale)
+        assert outs[0].info["res_dual"] == pytest.approx(outs[1].info["res_dual"], rel=1e-6, abs=1e-9)
+    # a penalty change re-derives K_row, its factors and the carried product K xt on the device
+    a = ConicSolver(qp, dict(polish=0, fac_fp32=0, rho=300.0), lib_path=hip_lib).solve()[0]
+    monkeypatch.setenv("SCORE_NO_REPLICATION", "1")
+    b = ConicSolver(qp, dict(polish=0, fac_fp32=0, rho=300.0), lib_path=hip_lib).solve()[0]
+    assert a.solved and b.solved and a.info["iters"] == b.info["iters"] and a.info["rho_updates"] == b.info["rho_updates"]
+    assert a.info["rho_updates"] > 0 or name != "manhattan"
+    np.testing.assert_allclose(a.x, b.x, atol=1e-8 * max(1.0, np.abs(b.x).max()))
+    for s_ in (fast, plain, cpu):
+        s_.close()
 
 
 @pytest.mark.parametrize("relax", ["SOCP", "QCQP"])
