@@ -569,6 +569,7 @@ int score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rota
     }
     return 0;
 }
+int64_t score_trim_caches(void) { return 0; }  // the twin parks nothing
 const char* score_last_error(void) { return g_err.c_str(); }
 const char* score_backend(void) { return "cpu-twin"; }
 }

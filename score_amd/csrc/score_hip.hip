@@ -84,41 +84,85 @@ struct BlockCache {
     std::mutex mu;
     std::vector<Block> free_blocks;
     size_t cached = 0;
-    static constexpr size_t kMaxCachedBytes = (size_t)4 << 30;
+    static size_t max_cached_bytes() {  // SCORE_CACHE_MB: cap of the parked bytes (0 = park nothing)
+        static const size_t v = [] {
+            const char* e = std::getenv("SCORE_CACHE_MB");
+            return e ? (size_t)std::max(0L, std::atol(e)) << 20 : (size_t)4 << 30;
+        }();
+        return v;
+    }
+    // size classes: powers of two up to 1 MiB, multiples of 2 MiB above (a 65 MiB request parks 66 MiB, not 128)
     static size_t round_up(size_t b) {
-        size_t r = 4096;
-        while (r < b) r <<= 1;
-        return r;
+        if (b <= ((size_t)1 << 20)) {
+            size_t r = 4096;
+            while (r < b) r <<= 1;
+            return r;
+        }
+        const size_t g = (size_t)2 << 20;
+        return (b + g - 1) / g * g;
+    }
+    static hipError_t raw_alloc(void** p, size_t bytes, bool host) {
+        return host ? hipHostMalloc(p, bytes, hipHostMallocMapped) : hipMalloc(p, bytes);
     }
     void* take(size_t& bytes, int dev, bool host) {
         bytes = round_up(bytes);
         {
             std::lock_guard<std::mutex> lk(mu);
-            for (size_t i = 0; i < free_blocks.size(); ++i)
-                if (free_blocks[i].bytes == bytes && free_blocks[i].dev == dev && free_blocks[i].host == host) {
-                    void* p = free_blocks[i].p;
-                    cached -= bytes;
-                    free_blocks[i] = free_blocks.back();
-                    free_blocks.pop_back();
-                    return p;
-                }
+            // same class first; failing that, a parked block of the same kind at most half as large again
+            size_t best = free_blocks.size();
+            for (size_t i = 0; i < free_blocks.size(); ++i) {
+                const Block& b = free_blocks[i];
+                if (b.dev != dev || b.host != host || b.bytes < bytes || b.bytes > bytes + bytes / 2) continue;
+                if (best == free_blocks.size() || b.bytes < free_blocks[best].bytes) best = i;
+            }
+            if (best != free_blocks.size()) {
+                void* p = free_blocks[best].p;
+                bytes = free_blocks[best].bytes;
+                cached -= bytes;
+                free_blocks[best] = free_blocks.back();
+                free_blocks.pop_back();
+                return p;
+            }
         }
         void* p = nullptr;
-        if (host) HIP_CHECK(hipHostMalloc(&p, bytes, hipHostMallocMapped));
-        else HIP_CHECK(hipMalloc(&p, bytes));
+        hipError_t e = raw_alloc(&p, bytes, host);
+        if (e != hipSuccess) {
+            // out of device or locked memory: what this cache holds back (other size classes, devices, kinds) is the
+            // first thing to give up -- release every parked block and try once more
+            (void)hipGetLastError();
+            trim();
+            e = raw_alloc(&p, bytes, host);
+        }
+        if (e != hipSuccess)
+            throw std::runtime_error(std::string(host ? "hipHostMalloc" : "hipMalloc") + " of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
         return p;
     }
     void give(void* p, size_t bytes, int dev, bool host) {
         if (!p) return;
         {
             std::lock_guard<std::mutex> lk(mu);
-            if (cached + bytes <= kMaxCachedBytes) {
+            if (cached + bytes <= max_cached_bytes()) {
                 free_blocks.push_back(Block{p, bytes, dev, host});
                 cached += bytes;
                 return;
             }
         }
         if (host) (void)hipHostFree(p); else (void)hipFree(p);
+    }
+    // release every parked block (score_trim_caches; also the retry path of take()); returns the bytes freed
+    size_t trim() {
+        std::vector<Block> all;
+        size_t freed = 0;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            all.swap(free_blocks);
+            freed = cached;
+            cached = 0;
+        }
+        for (const Block& b : all) {
+            if (b.host) (void)hipHostFree(b.p); else (void)hipFree(b.p);
+        }
+        return freed;
     }
     ~BlockCache() {  // process exit: the runtime may already be gone, leave the blocks to it
     }
@@ -147,6 +191,14 @@ struct StreamPool {
         std::lock_guard<std::mutex> lk(mu);
         if (idle.size() < 64) idle.emplace_back(dev, s);
         else (void)hipStreamDestroy(s);
+    }
+    void trim() {
+        std::vector<std::pair<int, hipStream_t>> all;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            all.swap(idle);
+        }
+        for (auto& e : all) (void)hipStreamDestroy(e.second);
     }
 };
 inline StreamPool& stream_pool() {
@@ -256,6 +308,7 @@ struct CsrBufs {
     DevBuf<double> val;
     int nblocks = 0;
     int rep = 1;     // right-hand sides per row of the replicated blocks (HostSystem::rep), 1 = plain rows only
+    int unroll = kUnroll;  // nonzeros per lane of a tile (HostSystem::tile_nnz / 256)
     int rs_in = 0;   // replicated blocks: operand stride between replicas (0 = the block's own replica stride)
     // values = false: the value array is only allocated (zeroed); a kernel fills it
     void upload(const Csr& M, const RowBlocks& rb, const std::vector<int32_t>* sp = nullptr, bool values = true) {
@@ -303,6 +356,8 @@ struct HipBackend {
     DevBuf<int32_t> kposd, kposs, kdiagpos;  // K.val positions of the chain blocks / Jacobi diagonals
     DevBuf<int32_t> done, cone_row, cone_dim, cone_type, cone_block_first, cone_block_prob;
     DevBuf<int4> cone_meta;
+    DevBuf<int2> cone_large;    // {cone, problem} of the cones with more than kWaveCone rows (k_cone_wave)
+    int n_large_cones = 0;
     DevBuf<int32_t> cone_cols;  // 8 per cone (two int4)
     DevBuf<double> cone_vals;   // 8 per cone (four double2)
     DevBuf<int32_t> node_col, diag_cols, prec_part_ptr, kblk_part_ptr;
@@ -437,6 +492,7 @@ struct HipBackend {
         // block's replica stride, G1's are the consecutive tail rows of a cone
         K.rep = h.rep; K.rs_in = 0;
         G1.rep = h.rep; G1.rs_in = 1;
+        K.unroll = G1.unroll = (h.rep > 1) ? h.tile_nnz / kThreads : kUnroll;
         {
             std::vector<int32_t> vf, ve, vp;
             for (int p = 0; p < h.count; ++p)
@@ -486,6 +542,14 @@ struct HipBackend {
             cone_cols.upload(pc); cone_vals.upload(pv);
         }
         n_cone_blocks = (int)h.cone_block_prob.size();
+        {
+            std::vector<int2> lg;
+            for (int bl = 0; bl < n_cone_blocks; ++bl)
+                for (int c = h.cone_block_first[bl]; c < h.cone_block_first[bl + 1]; ++c)
+                    if (h.cone_dim[c] > kWaveCone) lg.push_back(make_int2(c, h.cone_block_prob[bl]));
+            n_large_cones = (int)lg.size();
+            if (n_large_cones) cone_large.upload(lg);
+        }
         node_col.upload(h.node_col); diag_cols.upload(h.diag_cols);
         kblk_part_ptr.upload(h.rbK.part_ptr);
         prec_work.upload(h.prec_work); chains.upload(h.chains); levels.upload(h.levels);
@@ -690,6 +754,7 @@ struct HipBackend {
         a.alpha_relax = st.alpha; a.invE = invE.d; a.pres_part = pres_part.d;
         a.apply_alpha = 0; a.pfin = p.d; a.pw_in = pw_part.d; a.rz_in = rz_part0.d;
         a.prec_part_ptr = prec_part_ptr.d; a.kblk_part_ptr = kblk_part_ptr.d; a.step_out = step.d;
+        a.skip_large = n_large_cones > 0 ? 1 : 0;
         return a;
     }
 
@@ -847,6 +912,9 @@ struct HipBackend {
     template <int MODE>
     void launch_spmv(const CsrBufs& M, const SpmvArgs& a, int slot = -1) {
         static_assert(MODE == MODE_RHS || MODE == MODE_KP || MODE == MODE_KPB, "the residual / gradient modes run on plain rows (G2, H)");
+        const bool half = (M.unroll == kUnroll / 2);
+        if (M.rep == 2 && half) { launch_on_stream(k_spmv<MODE, 2, kUnroll / 2>, dim3(M.nblocks), dim3(kThreads), 0, slot, a); return; }
+        if (M.rep == 3 && half) { launch_on_stream(k_spmv<MODE, 3, kUnroll / 2>, dim3(M.nblocks), dim3(kThreads), 0, slot, a); return; }
         if (M.rep == 2) { launch_on_stream(k_spmv<MODE, 2>, dim3(M.nblocks), dim3(kThreads), 0, slot, a); return; }
         if (M.rep == 3) { launch_on_stream(k_spmv<MODE, 3>, dim3(M.nblocks), dim3(kThreads), 0, slot, a); return; }
         launch_on_stream(k_spmv<MODE, 1>, dim3(M.nblocks), dim3(kThreads), 0, slot, a);
@@ -957,6 +1025,11 @@ struct HipBackend {
         ca.tstamp = slot(5);
         if (n_cone_blocks)
             launch_on_stream(k_cone, dim3(n_cone_blocks), dim3(kThreads), 0, 5, ca);
+        if (n_large_cones) {  // (general conic programs only: a SCORE model has none)
+            ca.tstamp = nullptr;
+            hipLaunchKernelGGL(k_cone_wave, dim3((unsigned)((n_large_cones + 3) / 4)), dim3(kThreads), 0, stream, ca,
+                               (const int2*)cone_large.d, n_large_cones);
+        }
     }
 
     // in-loop duration of the six kernels of an iteration (see score_time_iteration):
@@ -2124,10 +2197,22 @@ int score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rota
             std::memcpy(rotations, stage + in_bytes, in_bytes);
             std::memcpy(degenerate, stage + 2 * in_bytes, flag_bytes);
         } catch (const std::exception& e) { g_err = e.what(); rc = -1; }
-        stream_pool().give(device, st);
-        block_cache().give(stage, cap, device, true);
+        // After an error the kernel may still be running on the staging block: hand block and stream back only once
+        // the stream has drained; if even that fails, drop them (a leak of one block beats a kernel writing into a
+        // block another handle has been given).
+        if (rc == 0 || hipStreamSynchronize(st) == hipSuccess) {
+            stream_pool().give(device, st);
+            block_cache().give(stage, cap, device, true);
+        } else {
+            (void)hipGetLastError();
+        }
         return rc;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int64_t score_trim_caches(void) {
+    const size_t freed = block_cache().trim();
+    stream_pool().trim();
+    return (int64_t)freed;
 }
 const char* score_last_error(void) { return g_err.c_str(); }
 const char* score_backend(void) { return "hip-gfx950"; }

@@ -624,6 +624,7 @@ struct HostSystem {
     // (active cones couple the rows): chainsH / levelsH / fac_doubles_H describe the same chains with factors of
     // their own.  rep == 1: chainsH == chains, levelsH == levels.
     int rep = 1;
+    int tile_nnz = kTileNnz;             // nonzeros per SpMV tile of K and G1 (kTileNnz, or half of it: see build_system)
     std::vector<int64_t> rep_n;          // per problem
     std::vector<int32_t> chain_owner;    // per chain
     std::vector<PrecWork> factor_work;   // what a factorisation of K visits: owner chains + the Jacobi blocks
@@ -650,7 +651,7 @@ inline int find_in_row(const Csr& M, int64_t row, int32_t col) {
     return -1;
 }
 
-inline RowBlocks make_rowblocks(const Csr& M, const std::vector<RowSegment>& segs, int count) {
+inline RowBlocks make_rowblocks(const Csr& M, const std::vector<RowSegment>& segs, int count, int tile_nnz = kTileNnz) {
     RowBlocks rb;
     rb.part_ptr.assign(count + 1, 0);
     for (const RowSegment& sg : segs) {
@@ -669,7 +670,7 @@ inline RowBlocks make_rowblocks(const Csr& M, const std::vector<RowSegment>& seg
             int64_t nn = 0, r1 = r;
             while (r1 < rend && r1 - r < kRowsPerBlock) {
                 int64_t len = M.ptr[r1 + 1] - M.ptr[r1];
-                if (len > kLongRow || nn + len > kTileNnz) break;
+                if (len > kLongRow || nn + len > tile_nnz) break;
                 nn += len;
                 ++r1;
             }
@@ -1257,6 +1258,14 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     }
     H.cone_block_first.push_back((int32_t)H.cone_row.size());
     H.K.val.assign(H.K.col.size(), 0.0);
+    // Tile size of K and G1 (SCORE_TILE_NNZ: 1024 / 2048 for replicated problems).  Measured on the headline problem,
+    // whose replicated K is 250 tiles of 2048 nonzeros -- one per CU: half-size tiles are SLOWER (kp 7.3 -> 7.8 us,
+    // kpb 7.8 -> 8.6 us): the SpMV of a single problem is a chain of dependent trips to memory, not a throughput loop.
+    H.tile_nnz = kTileNnz;
+    if (const char* e = std::getenv("SCORE_TILE_NNZ")) {
+        const int v = std::atoi(e);
+        if (H.rep > 1 && (v == kTileNnz || v == kTileNnz / 2)) H.tile_nnz = v;
+    }
     parallel_ranges(3, 1, [&](int, int64_t k0, int64_t k1) {  // three independent serial scans
         for (int64_t k = k0; k < k1; ++k) {
             // K and G1 of a replicated problem: the rows of replica 0 (applied to all replicas), then the tail
@@ -1270,8 +1279,8 @@ inline void build_system(const score_problem* probs, int count, const score_sett
             } else {
                 sg = plain_segments(H.xoff);
             }
-            if (k == 0) H.rbK = make_rowblocks(H.K, sg, count);
-            else if (k == 1) H.rbG1 = make_rowblocks(H.G1, sg, count);
+            if (k == 0) H.rbK = make_rowblocks(H.K, sg, count, H.tile_nnz);
+            else if (k == 1) H.rbG1 = make_rowblocks(H.G1, sg, count, H.tile_nnz);
             else H.rbG2 = make_rowblocks(H.G2, sg, count);
         }
     });

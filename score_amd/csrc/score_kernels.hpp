@@ -186,17 +186,17 @@ struct SpmvArgs {
 enum { MODE_RHS = 0, MODE_KP = 1, MODE_DRES = 2, MODE_KPB = 3, MODE_GRAD = 4 };
 
 constexpr int kMaxRep = 3;
-constexpr int kProdPlane = kTileNnz + kTileNnz / 8;  // products of one right-hand side, padded by one double per 8
 
 // One tile (row block) of the SpMV with NR right-hand sides per matrix row.  NR == 1: plain CSR rows.  NR > 1: the
 // rows of replica 0 of a problem whose operator is I_NR (x) K_row -- the matrix stream (12 B per nonzero) is read
 // once, the gathers and the LDS products are per replica; sums are per replica in CSR order, so every replica gets
 // exactly what a plain SpMV on its own copy of the rows would give.
-template <int MODE, int NR>
+template <int MODE, int NR, int UNR = kUnroll>
 __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int4 meta, const int prob, const int my_ptr, const int end_ptr,
                                           const int rs_out, double* __restrict__ prod, double* red, int32_t* srow) {
     static_assert(NR == 1 || (MODE != MODE_DRES && MODE != MODE_GRAD), "residual / gradient modes run on plain rows");
     auto kpad = [](int k) -> int { return k + (k >> 3); };
+    constexpr int kPlane = UNR * kThreads + UNR * kThreads / 8;  // one padded plane of products per right-hand side
     const int b = blockIdx.x;
     const int t = threadIdx.x;
     const int r0 = meta.x, r1 = meta.y, k0 = meta.z, k1 = meta.w;
@@ -288,28 +288,28 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int4 meta, co
     } else {
         // Loads are unconditional on clamped indices (a predicated load becomes a branch
         // and serialises the memory pipeline); only the LDS stores are predicated.
-        int32_t c[kUnroll];
-        double v[kUnroll], g[kUnroll][NR];
+        int32_t c[UNR];
+        double v[UNR], g[UNR][NR];
         const int klast = max(nn - 1, 0);
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < UNR; ++u) {
             const int k = min(t + u * kThreads, klast);
             c[u] = col[k0 + k];
             v[u] = val[k0 + k];
         }
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < UNR; ++u) {
 #pragma unroll
             for (int q = 0; q < NR; ++q) g[u][q] = xin[c[u] + q * rs_in];
         }
         if (dn) return;  // (uniform over the workgroup; nothing has been written)
         finish_beta();
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
+        for (int u = 0; u < UNR; ++u) {
             const int k = t + u * kThreads;
             if (k < nn) {
 #pragma unroll
-                for (int q = 0; q < NR; ++q) prod[q * kProdPlane + kpad(k)] = v[u] * g[u][q];
+                for (int q = 0; q < NR; ++q) prod[q * kPlane + kpad(k)] = v[u] * g[u][q];
             }
         }
         if (r0 + t <= r1) srow[t] = my_ptr - k0;
@@ -325,7 +325,7 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int4 meta, co
             } else {
                 for (int k = a0; k < a1; ++k) {
 #pragma unroll
-                    for (int q = 0; q < NR; ++q) sum[q] += prod[q * kProdPlane + kpad(k)];
+                    for (int q = 0; q < NR; ++q) sum[q] += prod[q * kPlane + kpad(k)];
                 }
             }
         }
@@ -419,13 +419,15 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int4 meta, co
     }
 }
 
-// NR: right-hand sides per row of the replicated blocks of this launch (1: every block holds plain rows)
-template <int MODE, int NR = 1>
+// NR: right-hand sides per row of the replicated blocks of this launch (1: every block holds plain rows).
+// UNR: nonzeros per lane of a tile (tiles of UNR * 256 nonzeros, HostSystem::tile_nnz): a single replicated problem
+// has half the matrix of a general one -- smaller tiles keep every CU busy.
+template <int MODE, int NR = 1, int UNR = kUnroll>
 __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     KernelStamp stamp(a.tstamp);
     // products of the tile, one padded plane per right-hand side: the row sums read consecutive 8-entry segments from
     // consecutive lanes (stride 8 doubles = 16 banks -> 16-way conflicts unpadded, 2-way with stride 9)
-    __shared__ double prod[NR * kProdPlane];
+    __shared__ double prod[NR * (UNR * kThreads + UNR * kThreads / 8)];
     __shared__ double red[8];
     __shared__ int32_t srow[kRowsPerBlock + 1];  // row pointers of the tile, relative to k0
     const int b = blockIdx.x;
@@ -437,8 +439,8 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     const int rs = (NR > 1) ? a.M.blk_rs[b] : 0;
     const int my_ptr = a.M.ptr[min(meta.x + t, meta.y)];
     const int end_ptr = (t == 0) ? meta.w : 0;
-    if (NR > 1 && rs > 0) spmv_tile<MODE, NR>(a, meta, prob, my_ptr, end_ptr, rs, prod, red, srow);
-    else spmv_tile<MODE, 1>(a, meta, prob, my_ptr, end_ptr, 0, prod, red, srow);
+    if (NR > 1 && rs > 0) spmv_tile<MODE, NR, UNR>(a, meta, prob, my_ptr, end_ptr, rs, prod, red, srow);
+    else spmv_tile<MODE, 1, UNR>(a, meta, prob, my_ptr, end_ptr, 0, prod, red, srow);
 }
 
 // ---------------------------------------------------------------------------
@@ -1460,6 +1462,7 @@ struct ConeArgs {
     const int32_t* kblk_part_ptr;
     double* step_out;   // per problem
     unsigned long long* tstamp;  // see KernelStamp
+    int skip_large;     // k_cone leaves cones with more than kWaveCone rows to k_cone_wave
 };
 
 __device__ __forceinline__ double a_row_dot(const ConeArgs& a, int i, const double* __restrict__ v) {
@@ -1481,6 +1484,7 @@ __device__ __forceinline__ void soc_scales(int type, double t0, double nz2, doub
 
 constexpr int kSmallCone = 4;    // rows
 constexpr int kConeRowNnz = 2;   // entries per row handled by the register path
+constexpr int kWaveCone = 32;    // cones with more rows than this are projected by one wavefront each (k_cone_wave)
 
 __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
     KernelStamp stamp(a.tstamp);
@@ -1575,6 +1579,7 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
             }
         return;
     }
+    if (a.skip_large && dim > kWaveCone) return;  // k_cone_wave projects it: one wavefront per cone
     for (int k = 0; k < dim; ++k) {
         const int i = row + k;
         double tt = a_row_dot(a, i, a.xt);
@@ -1587,6 +1592,55 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
     }
     soc_scales(type, t0, nz2, head, tail);
     for (int k = 0; k < dim; ++k) {
+        const int i = row + k;
+        const double sn = (k == 0) ? head : tail * a.s[i];
+        const double v_ = a.u[i];
+        const double yn = a.y[i] + rho * (sn - v_);
+        a.s[i] = sn;
+        a.y[i] = yn;
+        a.u[i] = rho * (a.b[i] - sn) - yn;
+    }
+}
+
+// Large cones (more than kWaveCone rows; none in a SCORE model, whose cones have d + 1 rows -- the C ABI takes any):
+// one WAVEFRONT per cone.  The lanes stride over the rows -- A-row products, relaxation, the point to project -- the
+// squared norm of the tail is reduced with wavefront shuffles, and the lanes apply the projection and the dual update to
+// the rows they hold.  Four cones per 256-thread workgroup; `large` lists {cone, problem} pairs.
+__global__ __launch_bounds__(kThreads) void k_cone_wave(ConeArgs a, const int2* __restrict__ large, int n_large) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (idx >= n_large) return;  // (whole wavefronts leave: no block-wide barrier below)
+    const int2 lc = large[idx];
+    const int prob = lc.y;
+    if (a.done[prob]) return;
+    double step = 0.0;
+    if (a.apply_alpha) {  // the step length of the last PCG step, as k_cone forms it (fixed order over the partials)
+        double rz = 0.0, pw = 0.0;
+        for (int i = a.prec_part_ptr[prob] + lane; i < a.prec_part_ptr[prob + 1]; i += 64) rz += a.rz_in[i];
+        for (int i = a.kblk_part_ptr[prob] + lane; i < a.kblk_part_ptr[prob + 1]; i += 64) pw += a.pw_in[i];
+        rz = wave_sum(rz); pw = wave_sum(pw);
+        rz = __shfl(rz, 0, 64); pw = __shfl(pw, 0, 64);
+        step = pw > 0.0 ? rz / pw : 0.0;
+    }
+    const int row = a.cone_row[lc.x], dim = a.cone_dim[lc.x], type = a.cone_type[lc.x];
+    const double rho = a.rho[prob], irho = 1.0 / rho, al = a.alpha_relax;
+    double t0 = 0.0, nz2 = 0.0;
+    for (int k = lane; k < dim; k += 64) {
+        const int i = row + k;
+        double tt = a_row_dot(a, i, a.xt);
+        if (a.apply_alpha) tt += step * a_row_dot(a, i, a.pfin);
+        const double v_ = al * (a.b[i] - tt) + (1.0 - al) * a.s[i];
+        const double w_ = v_ - a.y[i] * irho;
+        a.u[i] = v_;   // stash v (this lane reads it back below)
+        a.s[i] = w_;   // stash the point to project
+        if (k == 0) t0 = w_; else nz2 += w_ * w_;
+    }
+    nz2 = wave_sum(nz2);
+    nz2 = __shfl(nz2, 0, 64);
+    t0 = __shfl(t0, 0, 64);  // (lane 0 holds row 0)
+    double head, tail;
+    soc_scales(type, t0, nz2, head, tail);
+    for (int k = lane; k < dim; k += 64) {
         const int i = row + k;
         const double sn = (k == 0) ? head : tail * a.s[i];
         const double v_ = a.u[i];

@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "score_assemble", "score_assembled_view", "score_assembled_free", "score_round_to_so",
     "score_default_settings", "score_create", "score_create_batch", "score_dims", "score_solve",
     "score_reset", "score_solve_steps", "score_newton_steps", "score_linear_create", "score_linear_solve", "score_refine_create", "score_refine_run", "score_refine_destroy", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
-    "score_last_error", "score_backend",
+    "score_trim_caches", "score_last_error", "score_backend",
 ]
 
 
@@ -118,6 +118,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.score_refine_destroy.restype = None
     lib.score_round_to_so.argtypes = [C.c_int32, C.c_int64, _f64p, _f64p, C.POINTER(C.c_int32), C.c_int32]
     lib.score_round_to_so.restype = C.c_int
+    lib.score_trim_caches.argtypes = []
+    lib.score_trim_caches.restype = C.c_int64
     lib.score_last_error.restype = C.c_char_p
     lib.score_backend.restype = C.c_char_p
     return lib
@@ -145,6 +147,12 @@ class ConicSolution:
     @property
     def solved(self) -> bool:
         return self.info["status"] == 1
+
+
+def trim_caches(lib_path: Optional[str] = None) -> int:
+    """Release the device / pinned blocks and streams the library keeps parked between handles
+    (``score_trim_caches``); returns the bytes freed."""
+    return int(load_library(lib_path).score_trim_caches())
 
 
 class ConicSolver:

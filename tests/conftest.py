@@ -97,7 +97,9 @@ SYNTH = {
     # two robots, both determined through active cones; one of three landmarks is not
     "synth_d": dict(n_robots=2, n_poses=50, n_beacons=3, seed=14, p_range=0.5),
 }
-GOLDEN_NAMES = ["manhattan", "goats", "synth_a", "synth_b", "synth_c", "synth_d", "graph3d"]
+# two robots and three beacons with 2-D landmark priors (gurobi_utils.py:433-446) on two of them
+PRIOR_2D = dict(n_robots=2, n_poses=60, n_beacons=3, seed=15, p_range=0.4)
+GOLDEN_NAMES = ["manhattan", "goats", "synth_a", "synth_b", "synth_c", "synth_d", "graph3d", "prior2d"]
 
 
 def graph_3d(seed=5, n=12, n_lm=3):
@@ -133,6 +135,16 @@ def graph_by_name(name, fixtures):
 
     if name in fixtures:
         return fixtures[name]
+    if name == "prior2d":
+        from score_amd import compat
+
+        fg = make_manhattan(**PRIOR_2D)
+        lm = fg.landmark_variables
+        fg.landmark_priors = [
+            compat.LandmarkPrior2D(lm[0].name, (lm[0].true_position[0] + 0.3, lm[0].true_position[1] - 0.2), 4.0),
+            compat.LandmarkPrior2D(lm[2].name, (lm[2].true_position[0] - 0.1, lm[2].true_position[1] + 0.4), 0.25),
+        ]
+        return fg
     if name == "graph3d":
         # 3-D poses (gurobi_utils.py:37-50): chain + landmarks + ranges + a landmark prior (:433-446) + a loop closure
         return graph_3d(n=40)

@@ -39,7 +39,7 @@ from score_amd.solver import ConicSolver  # noqa: E402
 TWIN = os.path.join(ROOT, "oracle", "cpu_twin", "libscore_cpu.so")
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from conftest import SYNTH, graph_3d  # noqa: E402
+from conftest import SYNTH, graph_3d, graph_by_name  # noqa: E402
 
 
 def golden_for(name, fg):
@@ -90,3 +90,4 @@ if __name__ == "__main__":
     for name, kw in SYNTH.items():
         golden_for(name, make_manhattan(**kw))
     golden_for("graph3d", graph_3d(n=40))
+    golden_for("prior2d", graph_by_name("prior2d", {}))  # 2-D landmark priors (gurobi_utils.py:433-446)
