@@ -364,6 +364,7 @@ struct HipBackend {
     DevBuf<PrecWork> prec_work, factor_work;   // factor_work: what a factorisation of K visits (HostSystem::factor_work)
     DevBuf<ChainDesc> chains, chainsH;         // chainsH / levelsH: the same chains with factors of their own (Newton matrix)
     DevBuf<ChainLevelDesc> levels, levelsH;
+    DevBuf<PrecRecord> prec_rec, prec_recH;    // one record per work item: work + chain + level table (k_prec_pre)
     DevBuf<int32_t> vb_first, vb_end, vb_prob; // blocks of <= 256 vector entries per problem (k_xupdate)
     int n_vblocks = 0;
     DevBuf<double> xtu, xy, s, r, z, p, p2, w, kx, step;
@@ -556,6 +557,22 @@ struct HipBackend {
         factor_work.upload(h.factor_work);
         if (h.rep > 1) { chainsH.upload(h.chainsH); levelsH.upload(h.levelsH); }
         else { chainsH.view(chains.d, chains.n); levelsH.view(levels.d, levels.n); }
+        {   // the records k_prec_pre reads (PrecRecord), for the factors of K and for those of the Newton matrix
+            auto build = [&](const std::vector<ChainDesc>& cs, const std::vector<ChainLevelDesc>& ls) {
+                std::vector<PrecRecord> rec(h.prec_work.size());
+                std::memset((void*)rec.data(), 0, rec.size() * sizeof(PrecRecord));
+                for (size_t w = 0; w < rec.size(); ++w) {
+                    rec[w].wk = h.prec_work[w];
+                    if (rec[w].wk.kind != 0) continue;
+                    rec[w].ch = cs[(size_t)rec[w].wk.index];
+                    for (int l = 0; l < std::min<int>(rec[w].ch.n_levels, kRecLevels); ++l) rec[w].lv[l] = ls[(size_t)rec[w].ch.level_begin + l];
+                }
+                return rec;
+            };
+            prec_rec.upload(build(h.chains, h.levels));
+            if (h.rep > 1 && st.polish) prec_recH.upload(build(h.chainsH, h.levelsH));
+            else prec_recH.view(prec_rec.d, prec_rec.n);
+        }
         n_prec = (int)h.prec_work.size();
         active_part_ptr = h.prec_part_ptr;
         {   // split chain kernel: only when the whole launch is resident at once (one workgroup per CU)
@@ -615,7 +632,7 @@ struct HipBackend {
                 deep = Lz.offB + (int64_t)2 * h.bs * h.bs * Lz.N - lv[1].offR;
             }
             const int ng = std::max(8 * h.bs * h.bs, 32);
-            if (lv[0].nruns > kPreRunLanes || (ch.n_levels >= 2 && lv[1].N > kPrecThreads - kPreRunLanes) || (int64_t)ch.N * h.bs > (int64_t)kPrecChunk * kPrecThreads ||
+            if (ch.n_levels > kRecLevels || lv[0].nruns > kPreRunLanes || (ch.n_levels >= 2 && lv[1].N > kPrecThreads - kPreRunLanes) || (int64_t)ch.N * h.bs > (int64_t)kPrecChunk * kPrecThreads ||
                 deep > (int64_t)ng * (kPrecThreads - kPreRunLanes))
                 prec_pre = false;
             const ChainLevelDesc& Lend = lv[ch.n_levels - 1];
@@ -985,7 +1002,7 @@ struct HipBackend {
             launch_spmv<MODE_RHS>(G1, ra, 0);
         }
         PrecArgs pa{};
-        pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = fac.d;
+        pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.rec = prec_rec.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = done.d;
         pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d;
         pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d;
@@ -1216,7 +1233,7 @@ struct HipBackend {
             if (!Q.available) return -1;
             if (out && len > 0) {
                 PrecArgs pa{};
-                pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.fac = q_fac.d;
+                pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.rec = prec_recH.d; pa.fac = q_fac.d;
                 pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = q_skip.d;
                 pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d;
                 pa.r = r.d; pa.r_in = q_negg.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d;
@@ -1296,11 +1313,12 @@ struct HipBackend {
         HIP_CHECK(hipMemcpyAsync(lin_tol2.d, &tol2, sizeof(double), hipMemcpyHostToDevice, stream));
         HIP_CHECK(hipMemsetAsync(lin_flag.d, 0, 2 * sizeof(int32_t), stream));
         PrecArgs pa{};
-        pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = fac.d;
+        pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.rec = prec_rec.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = lin_flag.d;
         pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d;
         pa.r = r.d; pa.r_in = rhs_dev; pa.z = z.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d; pa.pw_part = pw_part.d;
         pa.gate_used = lin_flag.d + 1;
+        pa.early_done = 1;
         double* rz_cur = rz_part0.d;
         double* p_cur = p.d;
         double* p_oth = p2.d;
@@ -1326,6 +1344,7 @@ struct HipBackend {
                 launch_prec<PREC_STEP>(pa);  // x += a p ; r -= a w ; z = M^-1 r   (or the gate fires)
                 SpmvArgs a = spmv_args(K, p_cur);
                 a.p = p_cur; a.z = z.d; a.p_out = p_oth; a.rz_new = rz_nxt; a.rz_old = rz_cur; a.done = lin_flag.d;
+                a.early_done = 1;
                 launch_spmv<MODE_KPB>(K, a);
                 std::swap(p_cur, p_oth);
                 rz_cur = rz_nxt;
@@ -1513,11 +1532,12 @@ struct HipBackend {
         if (resume) upload_skip(live);
         (void)eta;
         PrecArgs pa{};
-        pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.fac = q_fac.d;
+        pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.rec = prec_recH.d; pa.fac = q_fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = q_skip.d;
         pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d;
         pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d; pa.pw_part = q_pw.d;
         pa.gate_used = q_gate_used.d;
+        pa.early_done = 1;  // launches queued beyond the gate are no-ops: keep them cheap
         if (!resume) {
             // the right-hand side is read where the evaluation left it (-g in q_negg) and the solution
             // starts from zero without a memset: the first STEP writes r and delta
@@ -1547,6 +1567,7 @@ struct HipBackend {
             launch_prec<PREC_STEP>(pa);   // delta += a p ; r -= a w ; z = M^-1 r   (or: gate fires, nothing happens)
             SpmvArgs a = spmv_args(Hm, pcg_p_cur);
             a.p = pcg_p_cur; a.z = z.d; a.p_out = pcg_p_oth; a.rz_new = rz_nxt; a.rz_old = pcg_rz_cur; a.pw_part = q_pw.d; a.done = q_pcgdone.d;
+            a.early_done = 1;
             hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, a);
             std::swap(pcg_p_cur, pcg_p_oth);
             pcg_rz_cur = rz_nxt;
@@ -1734,7 +1755,7 @@ struct HipBackend {
 
     void time_kernel(const std::string& which, int reps, double* ms) {
         PrecArgs pa{};
-        pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.fac = fac.d;
+        pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.rec = prec_rec.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = done.d;
         pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d;
         pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d;

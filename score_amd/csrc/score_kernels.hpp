@@ -141,6 +141,9 @@ struct SpmvArgs {
     CsrDev M;
     const double* xin;      // gathered vector
     const int32_t* done;
+    int early_done;         // 1: test the frozen-problem flag before anything else is requested (gated PCG solves queue
+                            //    launches that are MEANT to be no-ops once the gate has fired: they must stay cheap);
+                            // 0: the flag is requested with everything else and tested before the first write (ADMM loop)
     // replicated rows (blk_rs[b] > 0): replica k gathers xin[col + k * rs_in] (rs_in == 0: the block's own stride)
     // and owns the vector entries row + k * blk_rs[b]
     int rs_in;
@@ -231,6 +234,7 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int4 meta, co
     // with the matrix entries, on a clamped row: every trip to memory the tile needs is then in flight before the
     // first wait -- tile record -> {matrix, row pointers, own entries, flag} -> gathers -- instead of five dependent trips.
     const int dn = a.done[prob];
+    if (a.early_done && dn) return;
     const bool one_long = (r1 - r0 == 1 && nn > kLongRow);
     const int ro = one_long ? r0 : min(row, max(r1 - 1, r0));
     double e0[NR], e1[NR], e2[NR], e3[NR], e4[NR], e5[NR];
@@ -446,8 +450,21 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
 // ---------------------------------------------------------------------------
 // preconditioner: multi-level block-tridiagonal chain solve + Jacobi
 // ---------------------------------------------------------------------------
+// Everything k_prec_pre needs to know about its work item in ONE 512-byte record (work item, chain, level table):
+// a single trip to memory by 32 lanes instead of the chain work -> chain -> levels (three dependent trips before the
+// first factor or vector load could be requested).  Built by the backend from HostSystem::prec_work / chains / levels.
+constexpr int kRecLevels = 8;
+struct alignas(16) PrecRecord {
+    PrecWork wk;
+    ChainDesc ch;
+    int32_t pad_;
+    ChainLevelDesc lv[kRecLevels];
+};
+static_assert(sizeof(PrecRecord) == 512, "PrecRecord is read as 32 int4");
+
 struct PrecArgs {
     const PrecWork* work;
+    const PrecRecord* rec;     // k_prec_pre: one record per work item (see PrecRecord)
     const ChainDesc* chains;
     const ChainLevelDesc* levels;
     const double* fac;
@@ -480,6 +497,7 @@ struct PrecArgs {
     const double* r_in;    // residual as it stands at entry (== r, except for the first kernels of a Newton PCG solve,
                            // which read the right-hand side -g where the evaluation left it); r receives updates
     int xt_zero;           // STEP: treat xt as zero on entry (first step of a solve: no memset of the solution)
+    int early_done;        // as SpmvArgs::early_done
     int32_t* gate_init;    // INIT: per problem, copy done[prob] here and clear gate_used (start of a gated solve)
     int32_t* gate_flag;        // == done (writable)
     const double* gate_tol2;   // per problem: (relative tolerance)^2
@@ -489,6 +507,8 @@ struct PrecArgs {
 };
 
 enum { PREC_INIT = 0, PREC_STEP = 1 };
+
+
 
 // returns true when the problem's PCG has converged (uniform over the workgroup)
 __device__ __forceinline__ bool pcg_gate(const PrecArgs& a, int prob, double rz, double ref_loaded) {
@@ -957,16 +977,21 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
     constexpr int oCl = 2 * RMAX * B2, oCr = oCl + B2;
     constexpr int kStageLanes = kPrecThreads - kPreRunLanes;
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ ChainLevelDesc sLv[kMaxLevels];
+    __shared__ PrecRecord srec;
     double* red = lds;
-    const PrecWork wk = a.work[blockIdx.x];
+    const int t = threadIdx.x;
+    // trip 1: the work item's record.  Trip 2: everything else -- frozen flag, partial sums, vectors, factors.
+    if (t < 32) reinterpret_cast<int4*>(&srec)[t] = reinterpret_cast<const int4*>(a.rec + blockIdx.x)[t];
+    __syncthreads();
+    const PrecWork wk = srec.wk;
+    const ChainLevelDesc* sLv = srec.lv;
     const int prob = wk.prob;
+    const int dn = a.done[prob];  // (tested once the loads below are in flight; uniform over the workgroup)
+    if (a.early_done && dn) return;
     if (MODE == PREC_INIT && a.gate_init && threadIdx.x == 0 && (int)blockIdx.x == a.prec_part_ptr[prob]) {
-        a.gate_init[prob] = a.done[prob];
+        a.gate_init[prob] = dn;
         a.gate_used[prob] = 0;
     }
-    if (a.done[prob]) return;
-    const int t = threadIdx.x;
     double acc_rz = 0.0, acc_pw = 0.0;
     if (MODE == PREC_STEP) {
         const int l0 = a.prec_part_ptr[prob], l1 = a.prec_part_ptr[prob + 1];
@@ -976,13 +1001,13 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
     }
     double local = 0.0;
     if (wk.kind == 1) {
+        if (dn) return;
         bool stop;
         local = prec_jacobi_item<MODE>(a, wk, acc_rz, acc_pw, red, stop);
         if (stop) return;
     } else {
         const double gref = (MODE == PREC_STEP && a.gate_flag && !a.gate_first) ? a.gate_ref[prob] : 0.0;
-        const ChainDesc ch = a.chains[wk.index];
-        const ChainLevelDesc* __restrict__ lv = a.levels + ch.level_begin;
+        const ChainDesc ch = srec.ch;
         const int32_t* __restrict__ nc = a.node_col + ch.node_begin;
         // factor stream: 8-byte values, or their float copies (half the bytes through this CU; converted on arrival)
         const FT* __restrict__ fac = sizeof(FT) == 4 ? (const FT*)(const void*)a.fac32 : (const FT*)(const void*)a.fac;
@@ -995,16 +1020,15 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         // L at vb[L.lds_off + i * BS + i / L.p + c]
         double* vb = lds + 16;
         double* v0 = vb;  // level 0
-        if (t < nl) sLv[t] = lv[t];
-        const ChainLevelDesc L0 = lv[0];
-        const ChainLevelDesc Lz = lv[nl - 1];
+        const ChainLevelDesc L0 = sLv[0];
+        const ChainLevelDesc Lz = sLv[nl - 1];
         double* lfac = vb + Lz.lds_off + Lz.N * BS + 1;  // factors of the levels >= 1
         auto pad = [](const ChainLevelDesc& L, int i) -> int { return (int)(((uint32_t)i * L.inv_p) >> 20); };  // i / p (0 on the last level)
         auto nodep = [&](const ChainLevelDesc& L, int i) -> double* { return vb + L.lds_off + i * BS + pad(L, i); };
         int64_t deep_base = 0;
         int deep_cnt = 0;
         if (nl >= 2) {
-            deep_base = lv[1].offR;
+            deep_base = sLv[1].offR;
             deep_cnt = (int)(Lz.offB + (int64_t)2 * B2 * Lz.N - deep_base);
         }
         double* xch = lfac + deep_cnt;  // coupling terms handed from a separator to the run on its right
@@ -1065,6 +1089,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             }
         }
         // ---- alpha (every lane joins the reduction), then the vector update into LDS ----
+        if (dn) return;  // frozen problem (uniform): nothing has been written
         double alpha = 0.0;
         if (MODE == PREC_STEP) {
             block_sum2_n<kPrecWaves>(acc_rz, acc_pw, red);
