@@ -121,7 +121,10 @@ typedef struct score_settings {
                                   kernel that owns the iteration; M^-1 stays a fixed linear operator, PCG converges
                                   to the same tolerances.  1 (default): the ADMM loop's factors (of K);  2: the Newton
                                   polish's too (same iteration counts on the BASELINE sizes, ~10 % more Newton PCG
-                                  iterations on small ill-conditioned graphs);  0: double throughout.            */
+                                  iterations on small ill-conditioned graphs);  0: double throughout.
+                                  3-D problems (4 x 4 chain blocks): 1 covers the Newton factors as well -- the
+                                  LDS-resident chain kernel exists for the 4-byte stream only there, the streaming
+                                  kernel that double factors need is three times slower.                        */
 } score_settings;
 
 enum {

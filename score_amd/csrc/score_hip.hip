@@ -439,7 +439,8 @@ struct HipBackend {
     unsigned long long split_poll_limit = 0;
     size_t prec_lds = 0;
     bool prec_lds0 = true;
-    bool prec_pre = false;  // every chain fits the lane budget of k_prec_pre
+    bool prec_pre = false;  // every chain fits the lane budget of k_prec_pre (4 x 4 blocks: with the 4-byte factor stream only)
+    size_t prec_pre_lds = 0;
     static bool n_prec_chains(const HostSystem& h) { return !h.chains.empty(); }
 
     ~HipBackend() {
@@ -622,8 +623,10 @@ struct HipBackend {
         // k_prec_pre (level 0 in registers, coarser levels staged into LDS): every chain needs
         // <= 256 level-0 runs, its vector in one chunk of loads, coarse factors that fit the
         // staging registers, and everything within the LDS budget
-        prec_pre = h.bs >= 1 && h.bs <= 3 && !h.chains.empty();
+        prec_pre = h.bs >= 1 && h.bs <= 4 && !h.chains.empty();
         size_t lds_pre = 0;
+        const int pre_chunk = h.bs >= 4 ? 8 : kPrecChunk;          // PreTile<BS>::CH
+        const size_t deep_esz = h.bs >= 4 ? sizeof(float) : sizeof(double);  // coarse-level factors in LDS (k_prec_pre: LT)
         for (const auto& ch : h.chains) {
             const ChainLevelDesc* lv = &h.levels[ch.level_begin];
             int64_t deep = 0;
@@ -632,16 +635,19 @@ struct HipBackend {
                 deep = Lz.offB + (int64_t)2 * h.bs * h.bs * Lz.N - lv[1].offR;
             }
             const int ng = std::max(8 * h.bs * h.bs, 32);
-            if (ch.n_levels > kRecLevels || lv[0].nruns > kPreRunLanes || (ch.n_levels >= 2 && lv[1].N > kPrecThreads - kPreRunLanes) || (int64_t)ch.N * h.bs > (int64_t)kPrecChunk * kPrecThreads ||
+            if (ch.n_levels > kRecLevels || lv[0].nruns > kPreRunLanes || (ch.n_levels >= 2 && lv[1].N > kPrecThreads - kPreRunLanes) || (int64_t)ch.N * h.bs > (int64_t)pre_chunk * kPrecThreads ||
                 deep > (int64_t)ng * (kPrecThreads - kPreRunLanes))
                 prec_pre = false;
             const ChainLevelDesc& Lend = lv[ch.n_levels - 1];
             const size_t vec_doubles = (size_t)Lend.lds_off + (size_t)Lend.N * h.bs + 1;
-            lds_pre = std::max(lds_pre, (16 + vec_doubles + (size_t)(lv[0].nruns + 1) * h.bs + (size_t)deep) * sizeof(double));
+            lds_pre = std::max(lds_pre, (16 + vec_doubles + (size_t)(lv[0].nruns + 1) * h.bs) * sizeof(double) + (((size_t)deep + 1) & ~(size_t)1) * deep_esz);
         }
-        if (lds_pre > 158 * 1024) prec_pre = false;  // 160 KiB per CU, minus the static level table and slack
-        if (prec_pre) { prec_lds0 = true; prec_lds = lds_pre; }
-        if (!prec_pre && prec_lds > 144 * 1024) throw std::runtime_error("chain too long for the LDS-resident chain solver");
+        if (lds_pre > 158 * 1024) prec_pre = false;  // 160 KiB per CU, minus the static record and slack
+        prec_pre_lds = prec_pre ? lds_pre : 0;
+        {   // does any launch fall back to the streaming kernel (k_prec)?  4 x 4 blocks: every factor set kept in double
+            const bool fallback = !prec_pre || (h.bs >= 4 && st.fac_fp32 == 0);
+            if (fallback && prec_lds > 144 * 1024) throw std::runtime_error("chain too long for the LDS-resident chain solver");
+        }
         if (n_prec_chains(h)) {
             if (h.bs <= 1) allow_big_lds<1>(); else if (h.bs == 2) allow_big_lds<2>();
             else if (h.bs == 3) allow_big_lds<3>(); else allow_big_lds<4>();
@@ -657,7 +663,10 @@ struct HipBackend {
         kposd.upload(h.pos_diag); kposs.upload(h.pos_sub); kdiagpos.upload(h.diag_kpos);
         fac.alloc(h.fac_doubles); fac.zero(stream);  // separator slots of the spike region are never written (nor used)
         use_fac32 = st.fac_fp32 != 0;
-        newton_fac32 = st.fac_fp32 >= 2;
+        // 4 x 4 blocks (3-D problems): the LDS-resident chain kernel only exists for the 4-byte stream, and the streaming
+        // kernel is three times slower (22 / 30 us against 66 / 74 us per application on 1000-pose chains) -- the Newton
+        // factors follow the ADMM ones there (same Newton and PCG counts on the 3-D BASELINE-sized problems)
+        newton_fac32 = st.fac_fp32 >= 2 || (st.fac_fp32 == 1 && h.bs >= 4 && prec_pre);
         if (use_fac32) { fac32.alloc(h.fac_doubles); fac32.zero(stream); }
         dinv.alloc(h.dinv.size()); rho.upload(h.rho);
         q_work.alloc((size_t)std::max<int64_t>(1, h.scratch_nodes) * 2 * std::max(1, h.bs * h.bs));
@@ -890,22 +899,27 @@ struct HipBackend {
             return;
         }
         const int bs = H->bs;
-#define SCORE_LAUNCH_PREC(BS)                                                                                  \
-    do {                                                                                                       \
-        if (prec_pre && BS <= 3 && use_fac32)                                                                  \
-            launch_on_stream((k_prec_pre<(BS <= 3 ? BS : 3), MODE, float>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa); \
-        else if (prec_pre && BS <= 3)                                                                          \
-            launch_on_stream((k_prec_pre<(BS <= 3 ? BS : 3), MODE, double>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa); \
-        else if (prec_lds0)                                                                                    \
-            launch_on_stream((k_prec<BS, 3, MODE, true>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa); \
-        else                                                                                                   \
-            launch_on_stream((k_prec<BS, 3, MODE, false>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa); \
-    } while (0)
-        if (bs <= 1) SCORE_LAUNCH_PREC(1);
-        else if (bs == 2) SCORE_LAUNCH_PREC(2);
-        else if (bs == 3) SCORE_LAUNCH_PREC(3);
-        else SCORE_LAUNCH_PREC(4);
-#undef SCORE_LAUNCH_PREC
+        if (bs <= 1) launch_prec_bs<1, MODE>(pa, slot, use_fac32);
+        else if (bs == 2) launch_prec_bs<2, MODE>(pa, slot, use_fac32);
+        else if (bs == 3) launch_prec_bs<3, MODE>(pa, slot, use_fac32);
+        else launch_prec_bs<4, MODE>(pa, slot, use_fac32);
+    }
+    template <int BS, int MODE>
+    void launch_prec_bs(const PrecArgs& pa, int slot, bool use_fac32) {
+        // k_prec_pre (level 0 in registers, coarse levels in LDS) when every chain fits; 4 x 4 blocks (3-D problems) only
+        // with the 4-byte factor stream (score_settings.fac_fp32), otherwise the streaming kernel
+        if (prec_pre && use_fac32) {
+            launch_on_stream((k_prec_pre<BS, MODE, float>), dim3(n_prec), dim3(kPrecThreads), prec_pre_lds, slot, pa);
+            return;
+        }
+        if constexpr (BS <= 3) {
+            if (prec_pre) {
+                launch_on_stream((k_prec_pre<BS, MODE, double>), dim3(n_prec), dim3(kPrecThreads), prec_pre_lds, slot, pa);
+                return;
+            }
+        }
+        if (prec_lds0) launch_on_stream((k_prec<BS, 3, MODE, true>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa);
+        else launch_on_stream((k_prec<BS, 3, MODE, false>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa);
     }
 
     // The attribute is per kernel function, i.e. shared by every handle of the process: always
@@ -918,11 +932,12 @@ struct HipBackend {
         HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_STEP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_INIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_STEP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
-        constexpr int BP = BS <= 3 ? BS : 3;
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_INIT, double>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_STEP, double>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_INIT, float>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BP, PREC_STEP, float>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
+        if constexpr (BS <= 3) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BS, PREC_INIT, double>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BS, PREC_STEP, double>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
+        }
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BS, PREC_INIT, float>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BS, PREC_STEP, float>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
     }
 
     // SpMV launch: matrices of a replicated problem (K, G1) run with rep right-hand sides per stored row

@@ -966,6 +966,7 @@ template <int BS>
 struct PreTile {
     static constexpr int B2 = BS * BS;
     static constexpr int NG = (8 * B2 > 32) ? 8 * B2 : 32;  // run (6 B2) + separator (2 B2) blocks | staging
+    static constexpr int CH = (BS >= 4) ? 8 : kPrecChunk;    // vector entries per lane: chains of up to CH * 512 / BS nodes
 };
 
 template <int BS, int MODE, typename FT = double>
@@ -976,6 +977,11 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
     constexpr int NG = PreTile<BS>::NG;
     constexpr int oCl = 2 * RMAX * B2, oCr = oCl + B2;
     constexpr int kStageLanes = kPrecThreads - kPreRunLanes;
+    constexpr int CH = PreTile<BS>::CH;  // vector entries per lane
+    // 4 x 4 blocks (3-D): the level-0 tile stays in the factor stream's own type in registers and the coarse levels'
+    // factors in LDS likewise -- with the 4-byte stream (the only one this block size is launched with) that is 128
+    // registers and 84 KB instead of 256 and 169 KB; converted where used
+    using LT = typename std::conditional<(BS >= 4), FT, double>::type;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ PrecRecord srec;
     double* red = lds;
@@ -1022,7 +1028,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         double* v0 = vb;  // level 0
         const ChainLevelDesc L0 = sLv[0];
         const ChainLevelDesc Lz = sLv[nl - 1];
-        double* lfac = vb + Lz.lds_off + Lz.N * BS + 1;  // factors of the levels >= 1
+        LT* lfac = reinterpret_cast<LT*>(vb + Lz.lds_off + Lz.N * BS + 1);  // factors of the levels >= 1
         auto pad = [](const ChainLevelDesc& L, int i) -> int { return (int)(((uint32_t)i * L.inv_p) >> 20); };  // i / p (0 on the last level)
         auto nodep = [&](const ChainLevelDesc& L, int i) -> double* { return vb + L.lds_off + i * BS + pad(L, i); };
         int64_t deep_base = 0;
@@ -1031,21 +1037,23 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             deep_base = sLv[1].offR;
             deep_cnt = (int)(Lz.offB + (int64_t)2 * B2 * Lz.N - deep_base);
         }
-        double* xch = lfac + deep_cnt;  // coupling terms handed from a separator to the run on its right
+        double* xch = reinterpret_cast<double*>(lfac + ((deep_cnt + 1) & ~1));  // coupling terms handed from a separator to the run on its right
         // ---- vector loads (only r and w feed the solve; the operands of the xt / kx update
         //      are requested later: the register file is full here) ----
-        int cols[kPrecChunk];
-        double rv[kPrecChunk], wv[kPrecChunk];
+        int cols[CH];
+        double rv[CH], wv[CH];
 #pragma unroll
-        for (int u = 0; u < kPrecChunk; ++u) {
+        for (int u = 0; u < CH; ++u) {
             const int idx = min(t + u * kPrecThreads, NB - 1);
             const int node = idx / BS;
             cols[u] = colof(node) + (idx - node * BS);
         }
+        // (4 x 4 blocks: w is requested after the factor tile, just before its use -- the tile fills the register file)
+        constexpr bool kLateW = (BS >= 4);
 #pragma unroll
-        for (int u = 0; u < kPrecChunk; ++u) {
+        for (int u = 0; u < CH; ++u) {
             rv[u] = a.r_in[cols[u]];
-            if (MODE == PREC_STEP) wv[u] = a.w[cols[u]];
+            if (MODE == PREC_STEP && !kLateW) wv[u] = a.w[cols[u]];
         }
         // ---- factor loads: level 0 -> registers (lanes < 256), coarser levels -> staging ----
         FT Gr[NG];  // as loaded (converted to double once they have arrived: after the vector update below)
@@ -1096,8 +1104,12 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             alpha = acc_pw > 0.0 ? acc_rz / acc_pw : 0.0;
             if (pcg_gate(a, prob, acc_rz, gref)) return;
         }
+        if (MODE == PREC_STEP && kLateW) {
 #pragma unroll
-        for (int u = 0; u < kPrecChunk; ++u) {
+            for (int u = 0; u < CH; ++u) wv[u] = a.w[cols[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
             const int idx = t + u * kPrecThreads;
             if (idx < NB) {
                 double r_ = rv[u];
@@ -1118,15 +1130,15 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
 #pragma unroll
                         for (int k = k0; k < k0 + 8; ++k) {
                             const int idx = lane + k * kStageLanes;
-                            if (idx < deep_cnt) lfac[idx] = (double)Gr[k];
+                            if (idx < deep_cnt) lfac[idx] = (LT)Gr[k];
                         }
                     }
                 }
             }
         }
-        double G[NG];
+        LT G[NG];
 #pragma unroll
-        for (int k = 0; k < NG; ++k) G[k] = (double)Gr[k];
+        for (int k = 0; k < NG; ++k) G[k] = (LT)Gr[k];
         lds_barrier();
         // in-place solve with the diagonal block of a level-0 run: y <- T_run^-1 y (first len nodes)
         auto run_solve0 = [&](double (&y)[RMAX][BS], int len) {
@@ -1217,7 +1229,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         // The step's xt += alpha p, kx += alpha w in two halves (the run blocks stay in registers,
         // there is no room for all operands at once): the first half is in flight during the coarse
         // levels, the second during the level-0 back-substitution.
-        constexpr int kHalf = kPrecChunk / 2;
+        constexpr int kHalf = CH / 2;
         double pv[kHalf], wq[kHalf], xv[kHalf], kv[kHalf];
         auto upd_load = [&](auto half) {
             constexpr int u0 = decltype(half)::value * kHalf;
@@ -1238,7 +1250,9 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         };
         using H0 = std::integral_constant<int, 0>;
         using H1 = std::integral_constant<int, 1>;
-        if (MODE == PREC_STEP) upd_load(H0());
+        // (4 x 4 blocks: the register file holds the 128-entry factor tile; the update waits until the tile is dead)
+        constexpr bool kLateUpdate = (BS >= 4);
+        if (MODE == PREC_STEP && !kLateUpdate) upd_load(H0());
         // ---- coarser levels: factors and vectors in LDS.  Lanes 256..511 do this work: their
         //      register tile G is free (the staging is over), so each phase first pulls all its
         //      blocks from LDS into G and only then starts the dependent arithmetic ----
@@ -1253,10 +1267,10 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                 const int len = hi - lo;
                 if (len > 0) {
                     const int eP = L.P * L.nruns;
-                    const double* R = lfac + (L.offR - deep_base);
+                    const LT* R = lfac + (L.offR - deep_base);
 #pragma unroll
                     for (int q = 0; q < RMAX; ++q) {
-                        const double* Rq = R + min(q, len - 1) * L.nruns + j;
+                        const LT* Rq = R + min(q, len - 1) * L.nruns + j;
 #pragma unroll
                         for (int e = 0; e < B2; ++e) {
                             G[q * B2 + e] = Rq[e * eP];
@@ -1284,7 +1298,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             const ChainLevelDesc Ln = sLv[l + 1];
             if (dt >= 0 && dt < L.nsep) {
                 const int js = dt;
-                const double* S = lfac + (L.offS - deep_base);
+                const LT* S = lfac + (L.offS - deep_base);
 #pragma unroll
                 for (int e = 0; e < B2; ++e) {
                     G[oCl + e] = S[e * L.nsep + js];
@@ -1315,7 +1329,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             const ChainLevelDesc Ln = sLv[l + 1];
             if (dt >= 0 && dt < Lb.N) {
                 const int i = dt;
-                const double* Bk = lfac + (Lb.offB - deep_base);
+                const LT* Bk = lfac + (Lb.offB - deep_base);
 #pragma unroll
                 for (int e = 0; e < 2 * B2; ++e) G[e] = Bk[e * Lb.N + i];
                 const int nsep = Lb.nsep;
@@ -1338,7 +1352,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             }
             lds_barrier();
         }
-        if (MODE == PREC_STEP) { upd_store(H0()); upd_load(H1()); }
+        if (MODE == PREC_STEP && !kLateUpdate) { upd_store(H0()); upd_load(H1()); }
         // ---- back-substitution of level 0.  No spikes are stored for this level: with the run
         //      blocks still in registers, x_run = y_run - T_run^-1 (e_first Cr_left' x_left +
         //      e_last Cl_right' x_right) costs one more run solve and no memory traffic ----
@@ -1392,9 +1406,10 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             lds_barrier();
         }
         // ---- write z, p (INIT), the rest of the step's xt / kx, and accumulate r'z ----
-        if (MODE == PREC_STEP) upd_store(H1());
+        if (MODE == PREC_STEP && !kLateUpdate) upd_store(H1());
+        if (MODE == PREC_STEP && kLateUpdate) { upd_load(H0()); upd_store(H0()); upd_load(H1()); upd_store(H1()); }
 #pragma unroll
-        for (int u = 0; u < kPrecChunk; ++u) {
+        for (int u = 0; u < CH; ++u) {
             const int idx = t + u * kPrecThreads;
             if (idx < NB) {
                 const double zz = v0[idx + pad(L0, idx / BS)];

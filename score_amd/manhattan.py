@@ -155,6 +155,95 @@ def make_manhattan(
     return fg
 
 
+def _rotvec(v: np.ndarray) -> np.ndarray:
+    """Rotation matrix of the rotation vector v (Rodrigues)."""
+    th = float(np.linalg.norm(v))
+    if th < 1e-15:
+        return np.eye(3)
+    k = v / th
+    K = np.array([[0.0, -k[2], k[1]], [k[2], 0.0, -k[0]], [-k[1], k[0], 0.0]])
+    return np.eye(3) + np.sin(th) * K + (1.0 - np.cos(th)) * (K @ K)
+
+
+def make_manhattan_3d(
+    n_robots: int = 4,
+    n_poses: int = 400,
+    n_beacons: int = 6,
+    seed: int = 0,
+    side: int = 12,
+    p_range: float = 0.10,
+    sigma_t: float = 0.01,
+    sigma_theta: float = 0.002,
+    sigma_range: float = 1.0,
+    p_turn: float = 0.25,
+) -> compat.FactorGraphData:
+    """The 3-D counterpart of `make_manhattan` (the reference's model is dimension-generic,
+    gurobi_utils.py:37-50, :53-60; it ships no 3-D data): every robot walks the integer lattice of a cube of
+    the given side with an axis-aligned orientation -- one unit step along its body x axis per pose, a
+    quarter turn about its body z or y axis with probability p_turn (and whenever the step would leave the
+    cube) -- odometry = that motion in the base frame plus noise (translation sigma_t per axis, rotation a
+    random rotation vector of sigma_theta per axis), ranges to beacons and between robots at equal timestamps
+    with probability p_range each.  Same statistics and naming as the 2-D generator."""
+    rng = np.random.default_rng(seed)
+    letters = robot_letters(n_robots)
+    fg = compat.FactorGraphData(dimension=3)
+    quarter = [_rotvec(np.array(a) * (np.pi / 2)) for a in ((0, 0, 1), (0, 0, -1), (0, 1, 0), (0, -1, 0))]
+    quarter = [np.rint(q) for q in quarter]
+    all_pos = []
+    for r in range(n_robots):
+        pos = np.zeros(3) if r == 0 else rng.integers(0, side + 1, size=3).astype(np.float64)
+        R = np.eye(3)
+        if r > 0:
+            for _ in range(int(rng.integers(0, 6))):
+                R = R @ quarter[int(rng.integers(0, 4))]
+        P, Rs = [pos.copy()], [R.copy()]
+        for _ in range(n_poses - 1):
+            # the motion of this step in the base frame: one unit forward, then possibly a quarter turn
+            tries = 0
+            while True:
+                Rn = R @ quarter[int(rng.integers(0, 4))] if (rng.random() < p_turn or tries > 0) else R
+                nxt = pos + R[:, 0]
+                ahead = nxt + Rn[:, 0]  # the step after this one must stay inside as well
+                if np.all(nxt >= 0) and np.all(nxt <= side) and np.all(ahead >= 0) and np.all(ahead <= side):
+                    break
+                tries += 1
+                if tries > 64:  # boxed in along the current heading: turn in place first
+                    R = R @ quarter[int(rng.integers(0, 4))]
+                    tries = 1
+            pos, R = nxt, Rn
+            P.append(pos.copy()); Rs.append(R.copy())
+        P = np.stack(P); all_pos.append(P)
+        fg.pose_variables.append([
+            compat.PoseVariable3D(f"{letters[r]}{i}", tuple(float(x) for x in P[i]), Rs[i].copy()) for i in range(n_poses)])
+        odo = []
+        for i in range(n_poses - 1):
+            rel_R = Rs[i].T @ Rs[i + 1]
+            rel_t = Rs[i].T @ (P[i + 1] - P[i])
+            odo.append(compat.PoseMeasurement3D(
+                f"{letters[r]}{i}", f"{letters[r]}{i + 1}", rel_t + sigma_t * rng.standard_normal(3),
+                rel_R @ _rotvec(sigma_theta * rng.standard_normal(3)), 1.0 / sigma_t ** 2, 1.0 / sigma_theta ** 2))
+        fg.odom_measurements.append(odo)
+    beacons = rng.integers(0, side + 1, size=(n_beacons, 3)).astype(np.float64)
+    fg.landmark_variables = [compat.LandmarkVariable3D(f"L{i}", tuple(float(x) for x in b)) for i, b in enumerate(beacons)]
+    P = np.stack(all_pos)
+    for r in range(n_robots):
+        if n_beacons == 0:
+            break
+        ti, bi = np.nonzero(rng.random((n_poses, n_beacons)) < p_range)
+        true = np.linalg.norm(P[r, ti] - beacons[bi], axis=1)
+        meas = np.maximum(0.0, true + sigma_range * rng.standard_normal(true.size))
+        for t, b, dd in zip(ti, bi, meas):
+            fg.range_measurements.append(compat.FGRangeMeasurement((f"{letters[r]}{t}", f"L{b}"), float(dd), float(sigma_range)))
+    for a in range(n_robots):
+        for b in range(a + 1, n_robots):
+            ti = np.nonzero(rng.random(n_poses) < p_range)[0]
+            true = np.linalg.norm(P[a, ti] - P[b, ti], axis=1)
+            meas = np.maximum(0.0, true + sigma_range * rng.standard_normal(true.size))
+            for t, dd in zip(ti, meas):
+                fg.range_measurements.append(compat.FGRangeMeasurement((f"{letters[a]}{t}", f"{letters[b]}{t}"), float(dd), float(sigma_range)))
+    return fg
+
+
 # BASELINE.json configs (index -> generator arguments); seed = index*1000 + trial
 CONFIGS = {
     1: dict(n_robots=1, n_poses=500, n_beacons=2),

@@ -821,3 +821,36 @@ def test_large_cones_through_the_abi(dims, hip_lib, twin_lib):
         np.testing.assert_allclose(out.x, expect, atol=1e-6)
         np.testing.assert_allclose(out.s, expect, atol=1e-6)  # s = b - A x = x
         assert out.info["pobj"] == pytest.approx(0.5 * float((expect - c) @ (expect - c)), abs=1e-6)
+
+
+@pytest.mark.parametrize("n_poses", [40, 333, 1000])
+def test_3d_chain_kernels_match_the_twin(n_poses, hip_lib, twin_lib):
+    """3-D problems (gurobi_utils.py:37-50: dimension 3 -> 3 x 4 pose matrices, chains of 4 x 4 blocks, three replicas):
+    with the 4-byte factor stream (the default) the LDS-resident chain kernel k_prec_pre<4, ., float> runs -- level-0
+    tile and coarse-level factors kept as floats, converted where used -- with double factors the streaming kernel
+    k_prec<4>.  Both against the CPU twin after k ADMM iterations, and the full default solve against the oracle."""
+    from score_amd.manhattan import make_manhattan_3d
+
+    _hip_only(hip_lib)
+    fg = make_manhattan_3d(n_robots=2, n_poses=n_poses, n_beacons=3, seed=31, p_range=0.3)
+    qp = assemble(fg, "SOCP").qp
+    assert qp.block_size == 4 and qp.rep_d == 3
+    for fp32, tol in ((0, 1e-9), (1, 2e-5)):
+        st = dict(adaptive_cg=0, adaptive_rho=0, check_interval=5, fac_fp32=fp32, polish=0)
+        gpu = ConicSolver(qp, st, lib_path=hip_lib)
+        cpu = ConicSolver(qp, st, lib_path=twin_lib)
+        assert gpu.debug_get("rep")[0] == 3
+        gpu.reset(); cpu.reset()
+        for k in (1, 7):
+            a, b = gpu.steps(k)[0], cpu.steps(k)[0]
+            for v in VECS:
+                ga, gb = gpu.debug_get(v), cpu.debug_get(v)
+                scale = max(1.0, np.abs(gb).max())
+                vtol = 1e-4 if (fp32 and v in ("r", "z", "p", "w")) else tol
+                assert np.abs(ga - gb).max() <= vtol * scale, (v, k, fp32, np.abs(ga - gb).max(), scale)
+        gpu.close(); cpu.close()
+    if n_poses <= 333:
+        res = solve_score(fg, "SOCP")
+        rp, u, info = so.newton_solve(fg, tol=1e-12, max_iter=300)
+        assert res.solved and res.info["newton_iters"] > 0
+        assert res.info["pobj"] == pytest.approx(info["objective"], rel=1e-7, abs=1e-8)
