@@ -288,12 +288,16 @@ int  score_linear_create(const score_problem* pattern, const score_settings* s, 
 int  score_linear_solve(score_handle* h, const double* values, const double* rhs, double* x, double rel_tol,
                         int32_t max_iters, int32_t* iters_used, double* rel_residual);
 
-/* Local refinement after SCORE, whole loop behind the ABI: Gauss-Newton / Levenberg-Marquardt on SE(2)
+/* Local refinement after SCORE, whole loop behind the ABI: Gauss-Newton / Levenberg-Marquardt on SE(2) or SE(3)
  * from a given estimate (README.md:63-67 of the reference: "SCORE's estimate initialises a local solver").
- * The graph is the score_graph of score_assemble (dim = 2; `relaxation` is not read).  Per-measurement
+ * The graph is the score_graph of score_assemble (dim = 2 or 3; `relaxation` is not read).  Per-measurement
  * Jacobian blocks, J'J / J'r on a fixed pattern and trial points are device kernels; the damped normal
- * equations run in linear mode (above).  poses: n_poses x (theta, x, y) in chain order, pose 0 stays
- * fixed; landmarks: n_landmarks x (x, y).  tol: stop when |J'r|_inf <= tol * max(1, cost).            */
+ * equations run in linear mode (above).
+ *   dim 2: poses n_poses x (theta, x, y) in chain order; landmarks n_landmarks x (x, y);
+ *   dim 3: poses n_poses x 12 = [R (3 x 3, row-major) | t]; landmarks n_landmarks x 3; steps live in the tangent
+ *          space (R <- R Exp(omega), t <- t + v), the chains of the preconditioner are the omega blocks and the
+ *          v blocks of every robot (3 x 3).
+ * Pose 0 stays fixed.  tol: stop when |J'r|_inf <= tol * max(1, cost).                                        */
 typedef struct score_refine score_refine;
 typedef struct score_refine_info {
     double  cost_initial, cost_final, grad_inf;

@@ -380,6 +380,7 @@ struct score_refine {
     ~score_refine();
     void create(const score_graph& g, const score_settings* s);
     double eval_at(const std::vector<double>& w, bool with_blocks) {
+        if (P.dim == 3) return eval_at3(w, with_blocks);
         const double* uu = w.data();
         double f = 0.0;
         for (int64_t m = 0; m < P.n_rel(); ++m) {
@@ -405,9 +406,31 @@ struct score_refine {
         }
         return f;
     }
+    // 3-D: state X = [R | t] of every pose, then the landmarks (score_gn.hpp)
+    double eval_at3(const std::vector<double>& w, bool with_blocks) {
+        const double* X = w.data();
+        double f = 0.0;
+        for (int64_t m = 0; m < P.n_rel(); ++m)
+            f += score::gn_rel_block3(X + 12 * (int64_t)P.rel_i[m], X + 12 * (int64_t)P.rel_j[m], &P.rel_t[3 * m], &P.rel_R[9 * m],
+                                      P.rel_kappa[m], P.rel_tau[m], with_blocks ? &hblk[144 * m] : nullptr, with_blocks ? &gblk[12 * m] : nullptr);
+        const int64_t hb = 144 * P.n_rel(), gb = 12 * P.n_rel();
+        for (int64_t r = 0; r < P.n_rng(); ++r)
+            f += score::gn_range_block3(score::gn_point3(X, P.Np, P.rng_a[r]), score::gn_point3(X, P.Np, P.rng_b[r]), P.rng_dist[r],
+                                        P.rng_prec[r], with_blocks ? &hblk[hb + 36 * r] : nullptr, with_blocks ? &gblk[gb + 6 * r] : nullptr);
+        const int64_t hp = hb + 36 * P.n_rng(), gp = gb + 6 * P.n_rng();
+        for (int64_t e = 0; e < P.n_pri(); ++e)
+            f += score::gn_prior_block3(X + 12 * P.Np + 3 * (int64_t)P.pri_l[e], &P.pri_t[3 * e], P.pri_prec[e],
+                                        with_blocks ? &hblk[hp + 3 * e] : nullptr, with_blocks ? &gblk[gp + 3 * e] : nullptr);
+        return f;
+    }
     double eval_current(bool with_blocks) { return eval_at(u, with_blocks); }
     double eval_trial() {
-        for (int64_t i = 0; i < P.n; ++i) ut[i] = u[i] + step[i];
+        if (P.dim == 2) {
+            for (int64_t i = 0; i < P.n; ++i) ut[i] = u[i] + step[i];
+        } else {  // retraction: R <- R Exp(omega), t <- t + v; landmarks additive
+            for (int64_t p = 0; p < P.Np; ++p) score::gn_pose3_retract(&u[12 * p], p > 0 ? &step[6 * (p - 1)] : nullptr, &ut[12 * p]);
+            for (int64_t l = 0; l < 3 * P.Nl; ++l) ut[12 * P.Np + l] = u[12 * P.Np + l] + step[6 * (P.Np - 1) + l];
+        }
         return eval_at(ut, false);
     }
     void accept() { u.swap(ut); }
@@ -424,6 +447,14 @@ struct score_refine {
     bool solve(double lambda, double rel_tol, int* used);
     void run(const double* poses_in, const double* lms_in, int max_iters, double tol, double* poses_out, double* lms_out,
              score::GnInfo& info) {
+        if (P.dim == 3) {
+            std::copy(poses_in, poses_in + 12 * P.Np, u.begin());
+            if (P.Nl) std::copy(lms_in, lms_in + 3 * P.Nl, u.begin() + (std::ptrdiff_t)(12 * P.Np));
+            score::gn_levenberg_marquardt(*this, max_iters, tol, 1e-9, info);
+            std::copy(u.begin(), u.begin() + (std::ptrdiff_t)(12 * P.Np), poses_out);
+            if (P.Nl) std::copy(u.begin() + (std::ptrdiff_t)(12 * P.Np), u.begin() + (std::ptrdiff_t)(12 * P.Np + 3 * P.Nl), lms_out);
+            return;
+        }
         for (int k = 0; k < 3; ++k) P.pin[k] = poses_in[k];
         for (int64_t p = 1; p < P.Np; ++p)
             for (int k = 0; k < 3; ++k) u[3 * (p - 1) + k] = poses_in[3 * p + k];
@@ -584,7 +615,8 @@ void score_refine::create(const score_graph& g, const score_settings* s) {
     pat.block_size = 3; pat.n_chains = (int32_t)P.chain_ptr.size() - 1;
     pat.chain_ptr = P.chain_ptr.data(); pat.node_first_col = P.node_first_col.data();
     if (score_linear_create(&pat, s, &lin) != 0) throw std::runtime_error(g_err);
-    u.assign((size_t)P.n, 0.0); ut = u; step = u; rhs = u;
+    u.assign((size_t)P.state_size(), 0.0); ut = u;
+    step.assign((size_t)P.n, 0.0); rhs = step;
     hblk.assign((size_t)std::max<int64_t>(1, P.hblk_size()), 0.0);
     gblk.assign((size_t)std::max<int64_t>(1, P.gblk_size()), 0.0);
     vals.assign(P.hcol.size(), 0.0);

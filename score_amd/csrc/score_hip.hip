@@ -1884,7 +1884,7 @@ struct score_refine {
     DevBuf<int32_t> rel_i, rel_j, rng_a, rng_b, pri_l, hc_ptr, hc_slot, gc_ptr, gc_slot, is_diag;
     DevBuf<double> rel_t, rel_R, rel_kappa, rel_tau, rng_dist, rng_prec, pri_t, pri_prec, pin;
     DevBuf<double> u, ut, hblk, gblk, rhs, cost_part, gmax_part;
-    int n_mblocks = 0, n_ublocks = 0, n_hblocks = 0;
+    int n_mblocks = 0, n_ublocks = 0, n_hblocks = 0, n_sblocks = 0;
     std::vector<double> part_host;
 
     HipBackend& be() { return lin->solver.be; }
@@ -1922,10 +1922,12 @@ struct score_refine {
         std::vector<int32_t> dg(P.hcol.size(), 0);
         for (int64_t i = 0; i < P.n; ++i) dg[(size_t)P.diag_pos[(size_t)i]] = 1;
         is_diag.upload(dg);
-        pin.alloc(3); u.alloc((size_t)P.n); ut.alloc((size_t)P.n); rhs.alloc((size_t)P.n);
+        // state: 2-D the unknowns themselves (theta, x, y per free pose; landmarks); 3-D [R | t] of every pose, landmarks
+        pin.alloc(3); u.alloc((size_t)P.state_size()); ut.alloc((size_t)P.state_size()); rhs.alloc((size_t)P.n);
         hblk.alloc((size_t)std::max<int64_t>(1, P.hblk_size())); gblk.alloc((size_t)std::max<int64_t>(1, P.gblk_size()));
         n_mblocks = (int)std::max<int64_t>(1, (P.n_meas() + kThreads - 1) / kThreads);
         n_ublocks = (int)std::max<int64_t>(1, (P.n + kThreads - 1) / kThreads);
+        n_sblocks = (int)std::max<int64_t>(1, (P.Np + P.Nl + kThreads - 1) / kThreads);
         n_hblocks = (int)std::max<int64_t>(1, ((int64_t)P.hcol.size() + kThreads - 1) / kThreads);
         cost_part.alloc((size_t)n_mblocks); gmax_part.alloc((size_t)n_ublocks);
         be().linear_buffers(lin->solver.H);
@@ -1936,8 +1938,12 @@ struct score_refine {
 
     // ---- the backend concept of gn_levenberg_marquardt ----
     double eval_at(const double* where, bool with_blocks) {
-        hipLaunchKernelGGL(score::k_gn_blocks, dim3(n_mblocks), dim3(kThreads), 0, stream(), dev(), where, hblk.d, gblk.d,
-                           cost_part.d, with_blocks ? 1 : 0);
+        if (P.dim == 2)
+            hipLaunchKernelGGL(score::k_gn_blocks, dim3(n_mblocks), dim3(kThreads), 0, stream(), dev(), where, hblk.d, gblk.d,
+                               cost_part.d, with_blocks ? 1 : 0);
+        else
+            hipLaunchKernelGGL(score::k_gn_blocks3, dim3(n_mblocks), dim3(kThreads), 0, stream(), dev(), where, hblk.d, gblk.d,
+                               cost_part.d, with_blocks ? 1 : 0);
         part_host.resize((size_t)n_mblocks);
         HIP_CHECK(hipMemcpyAsync(part_host.data(), cost_part.d, (size_t)n_mblocks * sizeof(double), hipMemcpyDeviceToHost, stream()));
         HIP_CHECK(hipStreamSynchronize(stream()));
@@ -1947,8 +1953,12 @@ struct score_refine {
     }
     double eval_current(bool with_blocks) { return eval_at(u.d, with_blocks); }
     double eval_trial() {
-        hipLaunchKernelGGL(score::k_gn_trial, dim3(n_ublocks), dim3(kThreads), 0, stream(), (const double*)u.d,
-                           (const double*)be().xtu.d, ut.d, (int64_t)P.n);
+        if (P.dim == 2)
+            hipLaunchKernelGGL(score::k_gn_trial, dim3(n_ublocks), dim3(kThreads), 0, stream(), (const double*)u.d,
+                               (const double*)be().xtu.d, ut.d, (int64_t)P.n);
+        else  // retraction: R <- R Exp(omega), t <- t + v
+            hipLaunchKernelGGL(score::k_gn_trial3, dim3(n_sblocks), dim3(kThreads), 0, stream(), (const double*)u.d,
+                               (const double*)be().xtu.d, ut.d, (int64_t)P.Np, (int64_t)P.Nl);
         return eval_at(ut.d, false);
     }
     void accept() { std::swap(u.d, ut.d); }
@@ -1970,20 +1980,30 @@ struct score_refine {
     }
     void run(const double* poses_in, const double* lms_in, int max_iters, double tol, double* poses_out, double* lms_out,
              score::GnInfo& info) {
-        std::vector<double> u0((size_t)P.n);
-        for (int64_t p = 1; p < P.Np; ++p)
-            for (int k = 0; k < 3; ++k) u0[(size_t)(3 * (p - 1) + k)] = poses_in[3 * p + k];
-        for (int64_t l = 0; l < 2 * P.Nl; ++l) u0[(size_t)(3 * (P.Np - 1) + l)] = lms_in[l];
+        std::vector<double> u0((size_t)P.state_size());
+        if (P.dim == 2) {
+            for (int64_t p = 1; p < P.Np; ++p)
+                for (int k = 0; k < 3; ++k) u0[(size_t)(3 * (p - 1) + k)] = poses_in[3 * p + k];
+            for (int64_t l = 0; l < 2 * P.Nl; ++l) u0[(size_t)(3 * (P.Np - 1) + l)] = lms_in[l];
+            HIP_CHECK(hipMemcpyAsync(pin.d, poses_in, 3 * sizeof(double), hipMemcpyHostToDevice, stream()));
+        } else {  // the state is the input layout: [R | t] per pose, then the landmarks
+            std::copy(poses_in, poses_in + 12 * P.Np, u0.begin());
+            if (P.Nl) std::copy(lms_in, lms_in + 3 * P.Nl, u0.begin() + (std::ptrdiff_t)(12 * P.Np));
+        }
         HIP_CHECK(hipMemcpyAsync(u.d, u0.data(), u0.size() * sizeof(double), hipMemcpyHostToDevice, stream()));
-        HIP_CHECK(hipMemcpyAsync(pin.d, poses_in, 3 * sizeof(double), hipMemcpyHostToDevice, stream()));
         HIP_CHECK(hipStreamSynchronize(stream()));
         score::gn_levenberg_marquardt(*this, max_iters, tol, 1e-9, info);
         HIP_CHECK(hipMemcpyAsync(u0.data(), u.d, u0.size() * sizeof(double), hipMemcpyDeviceToHost, stream()));
         HIP_CHECK(hipStreamSynchronize(stream()));
-        for (int k = 0; k < 3; ++k) poses_out[k] = poses_in[k];
-        for (int64_t p = 1; p < P.Np; ++p)
-            for (int k = 0; k < 3; ++k) poses_out[3 * p + k] = u0[(size_t)(3 * (p - 1) + k)];
-        for (int64_t l = 0; l < 2 * P.Nl; ++l) lms_out[l] = u0[(size_t)(3 * (P.Np - 1) + l)];
+        if (P.dim == 2) {
+            for (int k = 0; k < 3; ++k) poses_out[k] = poses_in[k];
+            for (int64_t p = 1; p < P.Np; ++p)
+                for (int k = 0; k < 3; ++k) poses_out[3 * p + k] = u0[(size_t)(3 * (p - 1) + k)];
+            for (int64_t l = 0; l < 2 * P.Nl; ++l) lms_out[l] = u0[(size_t)(3 * (P.Np - 1) + l)];
+        } else {
+            std::copy(u0.begin(), u0.begin() + (std::ptrdiff_t)(12 * P.Np), poses_out);
+            if (P.Nl) std::copy(u0.begin() + (std::ptrdiff_t)(12 * P.Np), u0.end(), lms_out);
+        }
     }
 };
 

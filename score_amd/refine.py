@@ -2,8 +2,9 @@
 
 SCORE's convex relaxation gives an initial estimate; the reference's README hands it to a local
 nonlinear least-squares solver (GTSAM in the paper) for the maximum-likelihood estimate on the
-manifold.  This module is that next step for 2-D graphs: Gauss-Newton with Levenberg-Marquardt damping
-on SE(2)^N x R^(2 L), the first pose of the first chain held fixed (the gauge SCORE fixes too), over
+manifold.  This module is that next step, in 2-D and in 3-D: Gauss-Newton with Levenberg-Marquardt damping
+on SE(d)^N x R^(d L) (3-D: steps in the tangent space, retraction R <- R Exp(omega), t <- t + v; class
+``_Problem3D``), the first pose of the first chain held fixed (the gauge SCORE fixes too), over
 exactly the factors SCORE reads (relative-pose measurements with the reference's chordal rotation cost,
 gurobi_utils.py:504-526; ranges :449-501; landmark priors :433-446):
 
@@ -153,6 +154,151 @@ class _Problem:
         r = self.residuals(u)
         return float(r @ r)
 
+    def retract(self, u, step):
+        return u + step
+
+    def chains(self):
+        """One 3 x 3 chain per robot, node = pose (theta, x, y); the pinned pose is not an unknown."""
+        lens = np.asarray(self.a["chain_len"], dtype=np.int64).copy()
+        lens[0] -= 1
+        lens = lens[lens > 0]
+        return np.concatenate([[0], np.cumsum(lens)]), 3 * np.arange(self.Np - 1, dtype=np.int64)
+
+
+def _hat(v: np.ndarray) -> np.ndarray:
+    """[v]x for a stack of 3-vectors."""
+    K = np.zeros(v.shape[:-1] + (3, 3))
+    K[..., 0, 1], K[..., 0, 2] = -v[..., 2], v[..., 1]
+    K[..., 1, 0], K[..., 1, 2] = v[..., 2], -v[..., 0]
+    K[..., 2, 0], K[..., 2, 1] = -v[..., 1], v[..., 0]
+    return K
+
+
+def so3_exp(w: np.ndarray) -> np.ndarray:
+    """Rodrigues' formula for a stack of rotation vectors."""
+    th = np.linalg.norm(w, axis=-1)
+    K = _hat(w)
+    small = th < 1e-8
+    ths = np.where(small, 1.0, th)
+    A = np.where(small, 1.0 - th ** 2 / 6.0, np.sin(ths) / ths)
+    B = np.where(small, 0.5 - th ** 2 / 24.0, (1.0 - np.cos(ths)) / ths ** 2)
+    return np.eye(3) + A[..., None, None] * K + B[..., None, None] * (K @ K)
+
+
+class _Problem3D:
+    """The 3-D RA-SLAM least-squares problem on SE(3)^N x R^(3 L) (the reference's model is dimension-generic,
+    gurobi_utils.py:37-50).  The STATE is (R, t, lm): rotation matrices, translations, landmarks; a STEP lives in the
+    tangent space, (omega, v) per free pose and a 3-vector per landmark, applied by the retraction
+    R <- R Exp(omega), t <- t + v.  Columns of pose p >= 1: 6 (p - 1) .. +5 = [omega | v]; pose 0 is fixed."""
+
+    def __init__(self, data):
+        if data.dimension != 3:
+            raise ValueError("_Problem3D: 3-D graphs only")
+        a = graph_arrays(data)
+        self.a = a
+        self.Np, self.Nl = len(a["pose_names"]), len(a["landmark_names"])
+        self.n = 6 * (self.Np - 1) + 3 * self.Nl
+        self.bi, self.tj = a["rel_base"].astype(np.int64), a["rel_to"].astype(np.int64)
+        self.tm, self.Rm = a["rel_t"], a["rel_R"]
+        self.sk, self.st = np.sqrt(a["rel_kappa"]), np.sqrt(a["rel_tau"])
+        self.ra, self.rb = a["rng_a"].astype(np.int64), a["rng_b"].astype(np.int64)
+        self.dist, self.sw = a["rng_dist"], np.sqrt(a["rng_prec"])
+        self.pl, self.pt, self.spw = a["lprior_lm"].astype(np.int64), a["lprior_t"].reshape(-1, 3), np.sqrt(a["lprior_prec"])
+
+    def _point(self, v, t, lm):
+        pose = v < self.Np
+        out = np.empty((len(v), 3))
+        out[pose] = t[v[pose]]
+        out[~pose] = lm[v[~pose] - self.Np]
+        return out
+
+    def retract(self, state, step):
+        R, t, lm = state
+        w = step[: 6 * (self.Np - 1)].reshape(-1, 6)
+        Rn, tn = R.copy(), t.copy()
+        Rn[1:] = R[1:] @ so3_exp(w[:, :3])
+        tn[1:] = t[1:] + w[:, 3:]
+        return Rn, tn, lm + step[6 * (self.Np - 1):].reshape(-1, 3)
+
+    def residuals(self, state, jac: bool = False):
+        R, t, lm = state
+        bi, tj = self.bi, self.tj
+        ne = len(bi)
+        rt = t[tj] - t[bi] - np.einsum("eij,ej->ei", R[bi], self.tm)
+        rR = (R[tj] - R[bi] @ self.Rm).reshape(ne, 9)
+        pa, pb = self._point(self.ra, t, lm), self._point(self.rb, t, lm)
+        dv = pa - pb
+        rho = np.linalg.norm(dv, axis=1)
+        rp = lm[self.pl] - self.pt if len(self.pl) else np.zeros((0, 3))
+        res = np.concatenate([(self.sk[:, None] * rt).ravel(), (self.st[:, None] * rR).ravel(), self.sw * (rho - self.dist),
+                              (self.spw[:, None] * rp).ravel()])
+        if not jac:
+            return res
+        rows, cols, vals = [], [], []
+
+        def add(r, c, v):
+            r, c, v = np.broadcast_arrays(np.asarray(r), np.asarray(c), np.asarray(v))
+            r, c, v = r.ravel(), c.ravel(), v.ravel()
+            keep = c >= 0
+            rows.append(r[keep]); cols.append(c[keep]); vals.append(v[keep])
+
+        NEG = -(10 ** 9)
+        e = np.arange(ne)
+        ci, cj = np.where(bi > 0, 6 * (bi - 1), NEG), np.where(tj > 0, 6 * (tj - 1), NEG)
+        k3 = np.arange(3)
+        r_t = 3 * e[:, None] + k3[None, :]
+        add(r_t, cj[:, None] + 3 + k3[None, :], self.sk[:, None])
+        add(r_t, ci[:, None] + 3 + k3[None, :], -self.sk[:, None])
+        M = R[bi] @ _hat(self.tm)  # d r_t / d omega_i = R_i [tm]x
+        for a_ in range(3):
+            add(r_t, ci[:, None] + a_, self.sk[:, None] * M[:, :, a_])
+        base = 3 * ne
+        r_R = base + 9 * e[:, None] + np.arange(9)[None, :]
+        for a_ in range(3):
+            Ea = _hat(np.eye(3)[a_])
+            add(r_R, cj[:, None] + a_, self.st[:, None] * (R[tj] @ Ea).reshape(ne, 9))
+            add(r_R, ci[:, None] + a_, -self.st[:, None] * (R[bi] @ Ea @ self.Rm).reshape(ne, 9))
+        base += 9 * ne
+        nr = len(self.ra)
+        r = base + np.arange(nr)
+        g = dv / np.where(rho > 1e-12, rho, 1.0)[:, None]
+        g[rho <= 1e-12] = 0.0
+
+        def pcol(v):
+            pose = v < self.Np
+            return np.where(pose, np.where(v > 0, 6 * (v - 1) + 3, NEG), 6 * (self.Np - 1) + 3 * (v - self.Np))
+
+        add(r[:, None], pcol(self.ra)[:, None] + k3[None, :], self.sw[:, None] * g)
+        add(r[:, None], pcol(self.rb)[:, None] + k3[None, :], -self.sw[:, None] * g)
+        base += nr
+        npz = len(self.pl)
+        add(base + 3 * np.arange(npz)[:, None] + k3[None, :], 6 * (self.Np - 1) + 3 * self.pl[:, None] + k3[None, :], self.spw[:, None])
+        J = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(len(res), self.n))
+        return res, J
+
+    def cost(self, state) -> float:
+        r = self.residuals(state)
+        return float(r @ r)
+
+    def initial_state(self, results):
+        T = _stacked(results.poses, self.a["pose_names"], (4, 4))
+        lm = _stacked(results.landmarks, self.a["landmark_names"], (3,)) if self.Nl else np.zeros((0, 3))
+        return T[:, :3, :3].copy(), T[:, :3, 3].copy(), lm.copy()
+
+    def chains(self):
+        """3 x 3 chains of the preconditioner: per robot the omega blocks and the v blocks of its free poses."""
+        lens = np.asarray(self.a["chain_len"], dtype=np.int64)
+        ptr, first, p0 = [0], [], 0
+        for L in lens:
+            ps = np.arange(p0, p0 + L)
+            ps = ps[ps > 0]
+            for kind in range(2):
+                if ps.size:
+                    first.append(6 * (ps - 1) + 3 * kind)
+                    ptr.append(ptr[-1] + ps.size)
+            p0 += L
+        return np.asarray(ptr, dtype=np.int64), (np.concatenate(first) if first else np.zeros(0, np.int64))
+
 
 def _stacked(mapping, names, shape):
     """Values of ``mapping`` in the order of ``names`` as one array: without a Python loop when the mapping is
@@ -188,11 +334,7 @@ class _DeviceNormalEquations:
         rows = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(self.indptr))
         self.keys = rows * self.n + self.indices  # ascending: CSR with sorted indices
         self.diag = np.searchsorted(self.keys, np.arange(self.n, dtype=np.int64) * (self.n + 1))
-        lens = np.asarray(prob.a["chain_len"], dtype=np.int64).copy()
-        lens[0] -= 1  # the pinned pose is not an unknown
-        lens = lens[lens > 0]
-        chain_ptr = np.concatenate([[0], np.cumsum(lens)])
-        node_first_col = 3 * np.arange(prob.Np - 1, dtype=np.int64)
+        chain_ptr, node_first_col = prob.chains()
         self.solver = LinearSolver(pat, chain_ptr, node_first_col, 3, settings=settings, lib_path=lib_path)
         self._cache = None  # (indptr, indices) of the last J'J and its positions in the pattern
         self.pcg_iters = 0
@@ -248,10 +390,15 @@ def _refine_native(prob: _Problem, u0: np.ndarray, max_iters: int, tol: float, l
     if lib.score_refine_create(C.byref(g), C.byref(st), C.byref(h)) != 0:
         raise RuntimeError(f"score_refine_create failed: {lib.score_last_error().decode()}")
     try:
-        th, t, lm = prob.split(u0)
-        poses_in = np.ascontiguousarray(np.column_stack([th, t]), dtype=np.float64)
-        lms_in = np.ascontiguousarray(lm, dtype=np.float64).reshape(-1, 2)
-        poses_out, lms_out = np.empty_like(poses_in), np.empty((max(1, len(lms_in)), 2))
+        if isinstance(prob, _Problem3D):  # 3-D: [R (row-major) | t] per pose, landmarks x 3
+            R, t, lm = u0
+            poses_in = np.ascontiguousarray(np.concatenate([R.reshape(prob.Np, 9), t], axis=1), dtype=np.float64)
+            lms_in = np.ascontiguousarray(lm, dtype=np.float64).reshape(-1, 3)
+        else:
+            th, t, lm = prob.split(u0)
+            poses_in = np.ascontiguousarray(np.column_stack([th, t]), dtype=np.float64)
+            lms_in = np.ascontiguousarray(lm, dtype=np.float64).reshape(-1, 2)
+        poses_out, lms_out = np.empty_like(poses_in), np.empty((max(1, len(lms_in)), lms_in.shape[1]))
         info = ScoreRefineInfo()
         rc = lib.score_refine_run(h, poses_in.ctypes.data_as(_f64p), lms_in.ctypes.data_as(_f64p) if len(lms_in) else None,
                                   int(max_iters), float(tol), poses_out.ctypes.data_as(_f64p), lms_out.ctypes.data_as(_f64p),
@@ -260,6 +407,8 @@ def _refine_native(prob: _Problem, u0: np.ndarray, max_iters: int, tol: float, l
             raise RuntimeError(f"score_refine_run failed: {lib.score_last_error().decode()}")
     finally:
         lib.score_refine_destroy(h)
+    if isinstance(prob, _Problem3D):
+        return (poses_out[:, :9].reshape(-1, 3, 3).copy(), poses_out[:, 9:12].copy(), lms_out[: len(lms_in)].copy()), info.as_dict()
     u = prob.pack(poses_out[:, 0], poses_out[:, 1:3], lms_out[: len(lms_in)])
     return u, info.as_dict()
 
@@ -274,8 +423,12 @@ def refine_estimate(data, results, max_iters: int = 50, tol: float = 1e-10, verb
         raise ValueError("linear_solver must be 'device' or 'scipy'")
     if engine not in ("native", "python"):
         raise ValueError("engine must be 'native' or 'python'")
-    prob = _Problem(data)
-    u = _initial_point(prob, results)
+    if data.dimension == 3:
+        prob = _Problem3D(data)
+        u = prob.initial_state(results)
+    else:
+        prob = _Problem(data)
+        u = _initial_point(prob, results)
     if engine == "native" and linear_solver == "device" and prob.n > 0:
         u, ni = _refine_native(prob, u, max_iters, tol, lib_path, solver_settings)
         info = {"cost_initial": ni["cost_initial"], "cost_final": ni["cost_final"], "iterations": ni["iterations"],
@@ -301,7 +454,15 @@ def refine_estimate(data, results, max_iters: int = 50, tol: float = 1e-10, verb
     return out, info
 
 
-def _as_results(prob: _Problem, u: np.ndarray, results, cost: float):
+def _as_results(prob, u, results, cost: float):
+    if isinstance(prob, _Problem3D):
+        R, t, lm = u
+        T = np.tile(np.eye(4), (prob.Np, 1, 1))
+        T[:, :3, :3] = R
+        T[:, :3, 3] = t
+        values = compat.VariableValues(3, compat.ArrayDict(prob.a["pose_names"], T), compat.ArrayDict(prob.a["landmark_names"], np.array(lm, dtype=np.float64)), None)
+        return compat.SolverResults(variables=values, total_time=results.total_time, solved=True,
+                                    pose_chain_names=results.pose_chain_names, solver_cost=cost, info=dict(results.info or {}))
     th, t, lm = prob.split(u)
     c, s = np.cos(th), np.sin(th)
     T = np.tile(np.eye(3), (prob.Np, 1, 1))
@@ -331,7 +492,7 @@ def _lm_loop(prob, u, res, J, f, lam, max_iters, tol, verbose, dev, pcg_rel_tol)
             except RuntimeError:
                 lam *= 10.0
                 continue
-            un = u + step
+            un = prob.retract(u, step)
             fn = prob.cost(un)
             if fn < f:
                 accepted = True

@@ -854,3 +854,31 @@ def test_3d_chain_kernels_match_the_twin(n_poses, hip_lib, twin_lib):
         rp, u, info = so.newton_solve(fg, tol=1e-12, max_iter=300)
         assert res.solved and res.info["newton_iters"] > 0
         assert res.info["pobj"] == pytest.approx(info["objective"], rel=1e-7, abs=1e-8)
+
+
+def test_3d_refinement_on_the_gpu(hip_lib, twin_lib):
+    """f4 in 3-D: SE(3) Gauss-Newton / LM behind score_refine_run on the device (k_gn_blocks3: 12 x 12 relative-pose
+    blocks; k_gn_trial3: the retraction R Exp(omega), t + v; normal equations through the chain-preconditioned PCG
+    with the omega and v chains of every robot) -- against SciPy's least_squares / sparse LU (check_3d_refinement) and
+    against the CPU twin of the same loop; then on a larger graph: same LM iterations as the twin."""
+    from test_refine import _graph3, _noisy_truth3, check_3d_refinement
+
+    from score_amd.manhattan import make_manhattan_3d
+    from score_amd.refine import refine_estimate
+
+    _hip_only(hip_lib)
+    check_3d_refinement(hip_lib)
+    fg = _graph3()
+    res = _noisy_truth3(fg)
+    a, ia = refine_estimate(fg, res, lib_path=hip_lib)
+    b, ib = refine_estimate(fg, res, lib_path=twin_lib)
+    assert (ia["iterations"], ia["linear_solves"]) == (ib["iterations"], ib["linear_solves"])
+    assert ia["cost_final"] == pytest.approx(ib["cost_final"], rel=1e-8)
+    for nm in a.poses:
+        np.testing.assert_allclose(a.poses[nm], b.poses[nm], atol=1e-6)
+    fg = make_manhattan_3d(n_robots=3, n_poses=400, n_beacons=4, seed=47, p_range=0.2, sigma_t=0.05, sigma_theta=0.02)
+    res = _noisy_truth3(fg, seed=3)
+    a, ia = refine_estimate(fg, res, lib_path=hip_lib)
+    b, ib = refine_estimate(fg, res, lib_path=twin_lib)
+    assert ia["iterations"] == ib["iterations"] and ia["cost_final"] == pytest.approx(ib["cost_final"], rel=1e-7)
+    assert ia["cost_final"] < 0.05 * ia["cost_initial"] and ia["grad_inf"] < 1e-5 * max(1.0, ia["cost_final"])
