@@ -39,6 +39,7 @@ struct CpuBackend {
     // SCORE_TWIN_REPLICATION set it runs the replicated host structures instead (K and G1 hold replica 0's rows, a
     // replica's chain uses its owner's factors): the CPU-side test of that setup code.
     static bool allow_rep() { return std::getenv("SCORE_TWIN_REPLICATION") != nullptr; }
+    RuizOffload* ruiz_offload(const score_settings&) { return nullptr; }  // the twin equilibrates with the host loop
     // y[row (+ q rs)] = fn(M row . v[col + q rs_in]) over the rows M holds for problem pi
     template <class F>
     void for_rows(const Csr& M, int pi, int rs_in_fixed, F&& fn) const {

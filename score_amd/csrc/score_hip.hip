@@ -267,6 +267,11 @@ struct DevBuf {
             HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
         }
     }
+    // (no synchronisation: the caller waits for the stream before the source goes away)
+    void upload_from(const T* src, size_t count) {
+        if (count != n || !d) alloc(count);
+        if (count) HIP_CHECK(hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
+    }
     // upload into an allocation with `pad` extra zeroed elements at the end
     void upload_padded(const std::vector<T>& h, size_t pad) {
         if (h.size() + pad != n || !d) alloc(h.size() + pad);
@@ -336,11 +341,79 @@ struct CsrBufs {
     CsrDev dev() const { return CsrDev{ptr.d, col.d, val.d, first_row.d, blk_prob.d, blk_meta.d, blk_rs.d, split.d, nblocks}; }
 };
 
+// The passes of the Ruiz equilibration on the device (RuizOffload, score_host.hpp): the raw P and A of ONE problem go
+// up once, 3 small launches per pass run back to back, D and E come back.  The host loop it replaces is ten
+// barrier-separated sweeps of a 16-thread team -- 3 ms on a quiet host, several times that on a busy one; this is
+// ~1 ms either way.  Buffers and stream come from the process-wide caches and go back before it returns.
+struct RuizDevice : RuizOffload {
+    int device = 0;
+    bool passes(const score_problem& p, int iters, int rep, int64_t rep_n, const std::vector<int32_t>& atp,
+                const std::vector<int32_t>& atpos, const std::vector<int32_t>& arow, const std::vector<int32_t>& gstart,
+                double* D, double* E) override {
+        if (std::getenv("SCORE_NO_DEVICE_RUIZ")) return false;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return false;  // (score_create reports it)
+        DeviceGuard guard(device);
+        const int n = p.n, m = p.m;
+        const int64_t nnzP = p.P_rowptr[n], nnzA = p.A_rowptr[m];
+        const int64_t ngroups = (int64_t)gstart.size() - 1;
+        const int64_t n_act = rep > 1 ? n - (int64_t)(rep - 1) * rep_n : n;
+        hipStream_t st = stream_pool().take(device);
+        bool ok = true;
+        {
+            DevArena arena;
+            arena.dev = device;
+            struct Scope {
+                DevArena* a_; hipStream_t s_;
+                Scope(DevArena* a, hipStream_t s) : a_(tl_arena), s_(tl_copy_stream) { tl_arena = a; tl_copy_stream = s; }
+                ~Scope() { tl_arena = a_; tl_copy_stream = s_; }
+            } scope(&arena, st);
+            try {
+                DevBuf<int32_t> Pp, Pc, Ap, Ac, dat, dpos, drow, dg;
+                DevBuf<double> Pv, Av, dD, dE, dd, de;
+                Pp.upload_from(p.P_rowptr, (size_t)n + 1); Pc.upload_from(p.P_col, (size_t)nnzP); Pv.upload_from(p.P_val, (size_t)nnzP);
+                Ap.upload_from(p.A_rowptr, (size_t)m + 1); Ac.upload_from(p.A_col, (size_t)nnzA); Av.upload_from(p.A_val, (size_t)nnzA);
+                dat.upload_from(atp.data(), atp.size()); dpos.upload_from(atpos.data(), atpos.size());
+                drow.upload_from(arow.data(), arow.size()); dg.upload_from(gstart.data(), gstart.size());
+                dD.upload_from(D, (size_t)n); dE.upload_from(E, (size_t)m);  // (all ones)
+                dd.alloc((size_t)std::max<int64_t>(1, n_act)); de.alloc((size_t)std::max<int64_t>(1, ngroups));
+                RuizArgs a{};
+                a.P_ptr = Pp.d; a.P_col = Pc.d; a.P_val = Pv.d; a.A_ptr = Ap.d; a.A_col = Ac.d; a.A_val = Av.d;
+                a.atp = dat.d; a.atpos = dpos.d; a.arow = drow.d; a.gstart = dg.d;
+                a.D = dD.d; a.E = dE.d; a.d = dd.d; a.e = de.d;
+                a.n_act = n_act; a.nr = rep > 1 ? rep_n : 0; a.ngroups = ngroups; a.rep = rep;
+                const unsigned gc = (unsigned)((n_act + (kThreads / 64) - 1) / (kThreads / 64));
+                const unsigned gg = (unsigned)std::max<int64_t>(1, (ngroups + kThreads - 1) / kThreads);
+                const unsigned ga = (unsigned)std::max<int64_t>(1, (std::max(n_act, ngroups) + kThreads - 1) / kThreads);
+                for (int it = 0; it < iters; ++it) {
+                    if (n_act) hipLaunchKernelGGL(k_ruiz_cols, dim3(gc), dim3(kThreads), 0, st, a);
+                    if (ngroups) hipLaunchKernelGGL(k_ruiz_groups, dim3(gg), dim3(kThreads), 0, st, a);
+                    hipLaunchKernelGGL(k_ruiz_apply, dim3(ga), dim3(kThreads), 0, st, a);
+                }
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipMemcpyAsync(D, dD.d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
+                if (m) HIP_CHECK(hipMemcpyAsync(E, dE.d, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st));
+                HIP_CHECK(hipStreamSynchronize(st));
+            } catch (const std::exception&) {
+                (void)hipStreamSynchronize(st);
+                (void)hipGetLastError();
+                ok = false;  // the host loop takes over (D, E may be partly written: reset them)
+                std::fill(D, D + n, 1.0);
+                std::fill(E, E + m, 1.0);
+            }
+        }
+        stream_pool().give(device, st);
+        return ok;
+    }
+};
+
 struct HipBackend {
     // K's values, the chain factors and the Jacobi diagonal are derived on the device from K0, K1 and
     // rho (derive_rho_data): the host neither factors nor uploads anything when a penalty changes
     static constexpr bool kFactorOnHost = false;
     static bool allow_rep() { return true; }  // replicated problems (HostSystem::rep): K_row streamed once for all replicas
+    RuizDevice ruiz_dev;
+    RuizOffload* ruiz_offload(const score_settings& s_) { ruiz_dev.device = s_.device; return &ruiz_dev; }
     const HostSystem* H = nullptr;
     score_settings st{};
     hipStream_t stream = nullptr;

@@ -689,38 +689,63 @@ inline std::vector<RowSegment> plain_segments(const std::vector<int64_t>& xoff) 
     return sg;
 }
 
+// A CSR matrix whose pattern is borrowed from the caller's score_problem (valid for the duration of score_create)
+// and whose values are owned (the equilibrated ones).
+struct CsrScaled {
+    const int32_t* ptr = nullptr;
+    const int32_t* col = nullptr;
+    std::vector<double> val;
+    int64_t nnz = 0;
+};
 struct ProblemScaled {
-    Csr P, A;
+    CsrScaled P, A;
     std::vector<double> q, b, D, E;
+    // A' as a position map, built once for the equilibration and reused by append_problem: the entries of column j
+    // of A are atpos[atp[j] .. atp[j+1]) (indices into A's arrays, in row order); arow[k] = row of entry k
+    std::vector<int32_t> atp, atpos, arow;
 };
 
 // Ruiz equilibration of one problem; rows of one cone share a scale.
-inline void ruiz_scale(const score_problem& p, int iters, ProblemScaled& out) {
+//   D, E <- 1; per pass: d_j = 1 / sqrt(|column j of [[P, A'], [A, 0]] scaled by the current D, E|_inf),
+//   e_g likewise for the rows of cone group g (a zero-cone row is a group of its own); then D *= d, E *= e.
+// The matrix itself is NOT rescaled between passes: a pass is one read sweep that forms |v| D_i D_j on the fly
+// (P is symmetric -- the ABI takes the full matrix -- so its column norms are its row norms; A's columns go through
+// the position map), and the values are scaled once at the end.  One team runs all passes; each member owns a
+// range of columns and a range of cone groups, so no member ever updates another's entry.
+// rep > 1 (a verified row-replicated problem, HostSystem::rep): the columns of replicas >= 1 and the tail rows
+// >= 2 of every cone repeat replica 0's entries -- only replica 0 and the tail are swept, the others copy.
+struct PhaseTimer;
+inline void phase_mark(PhaseTimer* pt, const char* what);
+// The passes of the equilibration on a device (the HIP backend: k_ruiz_*): same formulas, same result as the host
+// loop below; returns false when it declines (then the host loop runs).  Everything it needs is in the problem and
+// in the position maps ruiz_scale builds first.
+struct RuizOffload {
+    virtual ~RuizOffload() = default;
+    virtual bool passes(const score_problem& p, int iters, int rep, int64_t rep_n, const std::vector<int32_t>& atp,
+                        const std::vector<int32_t>& atpos, const std::vector<int32_t>& arow, const std::vector<int32_t>& gstart,
+                        double* D, double* E) = 0;
+};
+inline void ruiz_scale(const score_problem& p, int iters, ProblemScaled& out, int rep = 1, int64_t rep_n = 0, PhaseTimer* pt = nullptr,
+                       RuizOffload* offload = nullptr) {
     const int n = p.n, m = p.m;
-    out.P.nrows = out.P.ncols = n;
-    out.P.ptr.assign(p.P_rowptr, p.P_rowptr + n + 1);
-    out.P.col.assign(p.P_col, p.P_col + p.P_rowptr[n]);
-    out.P.val.assign(p.P_val, p.P_val + p.P_rowptr[n]);
-    out.A.nrows = m;
-    out.A.ncols = n;
-    out.A.ptr.assign(p.A_rowptr, p.A_rowptr + m + 1);
-    out.A.col.assign(p.A_col, p.A_col + p.A_rowptr[m]);
-    out.A.val.assign(p.A_val, p.A_val + p.A_rowptr[m]);
+    const int64_t nnzP = p.P_rowptr[n], nnzA = p.A_rowptr[m];
+    out.P.ptr = p.P_rowptr; out.P.col = p.P_col; out.P.nnz = nnzP;
+    out.A.ptr = p.A_rowptr; out.A.col = p.A_col; out.A.nnz = nnzA;
     out.D.assign(n, 1.0);
     out.E.assign(m, 1.0);
-    std::vector<double> cn(n), d(n), e(m);
-    // P is symmetric (the ABI takes the full matrix): its column norms are its row norms.  One team
-    // runs all passes; each member owns a row range of P (= a column range of the KKT matrix) and a
-    // range of cone groups of A (a zero-cone row is a group of its own; the rows of one cone share a
-    // scale), and per pass takes norms and scales in one sweep each.  Column norms of A are taken
-    // column-wise through a position map (A' built once), so no member ever updates another's entry.
-    const int64_t nnzA = p.A_rowptr[m];
-    std::vector<int32_t> atp(n + 1, 0), atpos((size_t)nnzA);
-    for (int64_t k = 0; k < nnzA; ++k) atp[out.A.col[k] + 1]++;
+    out.atp.assign((size_t)n + 1, 0);
+    out.atpos.resize((size_t)nnzA);
+    out.arow.resize((size_t)nnzA);
+    std::vector<int32_t>& atp = out.atp;
+    for (int64_t k = 0; k < nnzA; ++k) atp[p.A_col[k] + 1]++;
     for (int j = 0; j < n; ++j) atp[j + 1] += atp[j];
     {
         std::vector<int32_t> fill(atp.begin(), atp.end() - 1);
-        for (int64_t k = 0; k < nnzA; ++k) atpos[(size_t)fill[out.A.col[k]]++] = (int32_t)k;
+        for (int r = 0; r < m; ++r)
+            for (int k = p.A_rowptr[r]; k < p.A_rowptr[r + 1]; ++k) {
+                out.atpos[(size_t)fill[p.A_col[k]]++] = (int32_t)k;
+                out.arow[(size_t)k] = r;
+            }
     }
     const int64_t ngroups = (int64_t)p.z + p.n_soc;
     std::vector<int32_t> gstart((size_t)ngroups + 1);
@@ -730,50 +755,80 @@ inline void ruiz_scale(const score_problem& p, int iters, ProblemScaled& out) {
         for (int c = 0; c < p.n_soc; ++c) { gstart[(size_t)p.z + c] = row; row += p.soc_dims[c]; }
         gstart[(size_t)ngroups] = row;
     }
-    const int T = parallel_parts(n, 16384);
+    phase_mark(pt, "  ruiz: A' map, groups");
+    const bool repl = rep > 1;
+    const int64_t nr = repl ? rep_n : 0;
+    const int64_t n_act = repl ? n - (int64_t)(rep - 1) * nr : n;   // columns swept: replica 0, then the tail
+    auto act_col = [&](int64_t a) -> int64_t { return (!repl || a < nr) ? a : a + (int64_t)(rep - 1) * nr; };
+    std::vector<double> d((size_t)n_act), e((size_t)ngroups);
+    const int T = parallel_parts(n_act, 4096);
     TeamBarrier bar(T);
-    if (iters > 0)
-        parallel_ranges(n, 16384, [&](int t, int64_t i0, int64_t i1) {
+    double* D = out.D.data();
+    double* E = out.E.data();
+    // (parts of equal WORK: a pose column carries a dozen entries, a range variable's two)
+    auto col_weight = [&](int64_t a) {
+        const int64_t j = act_col(a);
+        return (double)(p.P_rowptr[j + 1] - p.P_rowptr[j]) + 2.0 * (double)(atp[j + 1] - atp[j]);
+    };
+    const bool offloaded = iters > 0 && offload && offload->passes(p, iters, rep, nr, atp, out.atpos, out.arow, gstart, D, E);
+    if (iters > 0 && !offloaded)
+        parallel_ranges_balanced(n_act, 4096, col_weight, [&](int t, int64_t a0, int64_t a1) {
             const int64_t g0 = ngroups * t / T, g1 = ngroups * (t + 1) / T;
-            for (int64_t i = i0; i < i1; ++i) {
-                double mx = 0.0;
-                for (int k = out.P.ptr[i]; k < out.P.ptr[i + 1]; ++k) mx = std::max(mx, std::fabs(out.P.val[k]));
-                cn[i] = mx;
-            }
             for (int it = 0; it < iters; ++it) {
-                // norms: own columns (P row norm already in cn, A column-wise), own cone groups
-                for (int64_t j = i0; j < i1; ++j) {
-                    double mx = cn[j];
-                    for (int k = atp[j]; k < atp[j + 1]; ++k) mx = std::max(mx, std::fabs(out.A.val[atpos[(size_t)k]]));
-                    d[j] = mx > 1e-12 ? 1.0 / std::sqrt(mx) : 1.0;
+                for (int64_t a = a0; a < a1; ++a) {
+                    const int64_t j = act_col(a);
+                    double mx = 0.0;
+                    for (int k = p.P_rowptr[j]; k < p.P_rowptr[j + 1]; ++k) mx = std::max(mx, std::fabs(p.P_val[k]) * D[p.P_col[k]]);
+                    for (int k = atp[j]; k < atp[j + 1]; ++k) {
+                        const int32_t q = out.atpos[(size_t)k];
+                        mx = std::max(mx, std::fabs(p.A_val[q]) * E[out.arow[(size_t)q]]);
+                    }
+                    mx *= D[j];
+                    d[(size_t)a] = mx > 1e-12 ? 1.0 / std::sqrt(mx) : 1.0;
                 }
                 for (int64_t g = g0; g < g1; ++g) {
+                    const int r0 = gstart[(size_t)g];
+                    // (replicated: the head row and the first tail row stand for the whole cone)
+                    const int r1 = repl ? std::min(r0 + 2, gstart[(size_t)g + 1]) : gstart[(size_t)g + 1];
                     double mx = 0.0;
-                    for (int k = out.A.ptr[gstart[(size_t)g]]; k < out.A.ptr[gstart[(size_t)g + 1]]; ++k) mx = std::max(mx, std::fabs(out.A.val[k]));
-                    const double eg = mx > 1e-12 ? 1.0 / std::sqrt(mx) : 1.0;
-                    for (int r = gstart[(size_t)g]; r < gstart[(size_t)g + 1]; ++r) e[r] = eg;
+                    for (int k = p.A_rowptr[r0]; k < p.A_rowptr[r1]; ++k) mx = std::max(mx, std::fabs(p.A_val[k]) * D[p.A_col[k]]);
+                    mx *= E[r0];
+                    e[(size_t)g] = mx > 1e-12 ? 1.0 / std::sqrt(mx) : 1.0;
                 }
-                bar.wait();  // d, e complete
-                for (int64_t i = i0; i < i1; ++i) {
-                    double mx = 0.0;
-                    for (int k = out.P.ptr[i]; k < out.P.ptr[i + 1]; ++k) {
-                        out.P.val[k] *= d[i] * d[out.P.col[k]];
-                        mx = std::max(mx, std::fabs(out.P.val[k]));
-                    }
-                    cn[i] = mx;
-                    out.D[i] *= d[i];
+                bar.wait();  // d, e complete (everybody has read the old D, E)
+                for (int64_t a = a0; a < a1; ++a) {
+                    const int64_t j = act_col(a);
+                    const double v = D[j] * d[(size_t)a];
+                    D[j] = v;
+                    if (repl && a < nr)
+                        for (int q = 1; q < rep; ++q) D[j + q * nr] = v;
                 }
-                for (int r = gstart[(size_t)g0]; r < gstart[(size_t)g1]; ++r) {
-                    for (int k = out.A.ptr[r]; k < out.A.ptr[r + 1]; ++k) out.A.val[k] *= e[r] * d[out.A.col[k]];
-                    out.E[r] *= e[r];
-                }
-                bar.wait();  // A scaled: the next pass reads it column-wise
+                for (int64_t g = g0; g < g1; ++g)
+                    for (int r = gstart[(size_t)g]; r < gstart[(size_t)g + 1]; ++r) E[r] *= e[(size_t)g];
+                bar.wait();  // D, E updated: the next pass reads them
             }
         });
+    phase_mark(pt, "  ruiz: passes");
+    // the equilibrated values, once
+    out.P.val.resize((size_t)nnzP);
+    out.A.val.resize((size_t)nnzA);
     out.q.resize(n);
     out.b.resize(m);
-    for (int j = 0; j < n; ++j) out.q[j] = p.q[j] * out.D[j];
-    for (int r = 0; r < m; ++r) out.b[r] = p.b[r] * out.E[r];
+    parallel_ranges(n, 16384, [&](int, int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i) {
+            const double di = D[i];
+            for (int k = p.P_rowptr[i]; k < p.P_rowptr[i + 1]; ++k) out.P.val[(size_t)k] = p.P_val[k] * di * D[p.P_col[k]];
+            out.q[(size_t)i] = p.q[i] * di;
+        }
+    });
+    parallel_ranges(m, 16384, [&](int, int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
+            const double er = E[r];
+            for (int k = p.A_rowptr[r]; k < p.A_rowptr[r + 1]; ++k) out.A.val[(size_t)k] = p.A_val[k] * er * D[p.A_col[k]];
+            out.b[(size_t)r] = p.b[r] * er;
+        }
+    });
+    phase_mark(pt, "  ruiz: scaled values");
 }
 
 // Does the problem have the row-replicated structure its hint claims (include/score_hip.h, score_problem::rep_d)?
@@ -910,32 +965,36 @@ struct PhaseTimer {
     }
 };
 
+inline void phase_mark(PhaseTimer* pt, const char* what) { if (pt) pt->mark(what); }
+
 // Append problem `b` (already scaled) to the batch: A, K (pattern + K0/K1), G1, G2.
 inline void append_problem(HostSystem& H, int pi, const score_problem& p, const ProblemScaled& S, PhaseTimer& pt) {
     const int n = p.n, m = p.m;
     const int64_t xo = H.xoff[pi], ro = H.roff[pi];
     // ---- A (global indices) ----
-    for (int r = 0; r < m; ++r) {
-        for (int k = S.A.ptr[r]; k < S.A.ptr[r + 1]; ++k) {
-            H.A.col.push_back((int32_t)(xo + S.A.col[k]));
-            H.A.val.push_back(S.A.val[k]);
-        }
-        H.A.ptr.push_back((int32_t)H.A.col.size());
-    }
-    // ---- A' (local) ----
-    std::vector<int32_t> atp(n + 1, 0), atr(S.A.col.size());
-    std::vector<double> atv(S.A.col.size());
-    for (size_t k = 0; k < S.A.col.size(); ++k) atp[S.A.col[k] + 1]++;
-    for (int j = 0; j < n; ++j) atp[j + 1] += atp[j];
-    {
-        std::vector<int32_t> fill(atp.begin(), atp.end() - 1);
-        for (int r = 0; r < m; ++r)
+    const size_t a_base = H.A.col.size(), a_row0 = H.A.ptr.size();
+    H.A.col.resize(a_base + (size_t)S.A.nnz); H.A.val.resize(a_base + (size_t)S.A.nnz);
+    H.A.ptr.resize(a_row0 + (size_t)m);
+    parallel_ranges(m, 16384, [&](int, int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r) {
             for (int k = S.A.ptr[r]; k < S.A.ptr[r + 1]; ++k) {
-                int pos = fill[S.A.col[k]]++;
-                atr[pos] = r;
-                atv[pos] = S.A.val[k];
+                H.A.col[a_base + (size_t)k] = (int32_t)(xo + S.A.col[k]);
+                H.A.val[a_base + (size_t)k] = S.A.val[(size_t)k];
             }
-    }
+            H.A.ptr[a_row0 + (size_t)r] = (int32_t)(a_base + (size_t)S.A.ptr[r + 1]);
+        }
+    });
+    // ---- A' (local): the position map of the equilibration, with the scaled values ----
+    const std::vector<int32_t>& atp = S.atp;
+    std::vector<int32_t> atr((size_t)S.A.nnz);
+    std::vector<double> atv((size_t)S.A.nnz);
+    parallel_ranges(S.A.nnz, 65536, [&](int, int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; ++k) {
+            const int32_t q = S.atpos[(size_t)k];
+            atr[(size_t)k] = S.arow[(size_t)q];
+            atv[(size_t)k] = S.A.val[(size_t)q];
+        }
+    });
     pt.mark("  append: A, A'");
     // ---- K = P + sigma I + rho A'A, kept as K0 + rho K1 on the union pattern ----
     // A row of K has a few dozen entries: it is gathered into a small buffer, ordered by column
@@ -1034,7 +1093,7 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
         H.G2.ptr[g2_row0 + i] = (int32_t)(g2_base + S.P.ptr[i + 1] + atp[i + 1]);
     }
     H.G1.col.resize(g1_base + (size_t)g1p[(size_t)n]); H.G1.val.resize(g1_base + (size_t)g1p[(size_t)n]);
-    H.G2.col.resize(g2_base + S.P.col.size() + atr.size()); H.G2.val.resize(g2_base + S.P.col.size() + atr.size());
+    H.G2.col.resize(g2_base + (size_t)S.P.nnz + atr.size()); H.G2.val.resize(g2_base + (size_t)S.P.nnz + atr.size());
     pt.mark("  append: G resize");
     const int32_t ucol0 = (int32_t)(H.n_tot + ro);
     parallel_ranges(n, 16384, [&](int, int64_t i0, int64_t i1) {
@@ -1108,7 +1167,7 @@ inline void refresh_rho(HostSystem& H, int pi) {
 // allow_rep: the backend can run replicated problems (HostSystem::rep); the CPU twin cannot (and is the better
 // check for not doing so: it applies the full K the problem defines).
 inline void build_system(const score_problem* probs, int count, const score_settings& st, HostSystem& H,
-                         bool factor_on_host = true, bool allow_rep = false) {
+                         bool factor_on_host = true, bool allow_rep = false, RuizOffload* ruiz_offload = nullptr) {
     if (count <= 0) throw std::runtime_error("score_create: count must be positive");
     PhaseTimer pt(st.verbose != 0);
     H = HostSystem();
@@ -1157,7 +1216,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     std::vector<ProblemScaled> scaled((size_t)count);
     if (count > 1) {
         parallel_ranges(count, 1, [&](int, int64_t p0, int64_t p1) {
-            for (int64_t p = p0; p < p1; ++p) ruiz_scale(probs[p], std::max(0, st.scale_iters), scaled[(size_t)p]);
+            for (int64_t p = p0; p < p1; ++p) ruiz_scale(probs[p], std::max(0, st.scale_iters), scaled[(size_t)p], H.rep, H.rep_n[(size_t)p]);
         });
         pt.mark("ruiz (all problems)");
     }
@@ -1223,7 +1282,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     for (int p = 0; p < count; ++p) {
         const score_problem& pr = probs[p];
         if (count == 1) {
-            ruiz_scale(pr, std::max(0, st.scale_iters), scaled[0]);
+            ruiz_scale(pr, std::max(0, st.scale_iters), scaled[0], H.rep, H.rep_n[0], &pt, ruiz_offload);  // (one problem: the passes may run on the device)
             pt.mark("ruiz");
         }
         ProblemScaled S = std::move(scaled[(size_t)p]);

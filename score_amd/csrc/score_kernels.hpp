@@ -1781,6 +1781,68 @@ __global__ __launch_bounds__(kThreads) void k_kval(CsrDev M, const double* __res
     for (int k = meta.z + (int)threadIdx.x; k < meta.w; k += kThreads) val[k] = K0[k] + r * K1[k];
 }
 
+// ---------------------------------------------------------------------------
+// Ruiz equilibration passes on the device (ruiz_scale in score_host.hpp is the specification and the twin's path):
+//   k_ruiz_cols   one WAVEFRONT per swept column j (a landmark's column holds thousands of entries): the lanes stride
+//                 over row j of P (symmetric: = column j) and over column j of A through the position map,
+//                 |v| D[other] resp. |v| E[row], wavefront max, d_j = 1 / sqrt(D_j * max)
+//   k_ruiz_groups one lane per cone group: e_g from its rows (replicated problems: head row + first tail row)
+//   k_ruiz_apply  D *= d (copied to the other replicas), E *= e
+// Three launches per pass, nothing on the host between them.
+// ---------------------------------------------------------------------------
+struct RuizArgs {
+    const int32_t* P_ptr; const int32_t* P_col; const double* P_val;
+    const int32_t* A_ptr; const int32_t* A_col; const double* A_val;
+    const int32_t* atp; const int32_t* atpos; const int32_t* arow; const int32_t* gstart;
+    double* D; double* E; double* d; double* e;
+    int64_t n_act, nr, ngroups;
+    int rep;  // 1: plain problem (every column swept)
+};
+__device__ __forceinline__ int64_t ruiz_col(const RuizArgs& a, int64_t act) {
+    return (a.rep <= 1 || act < a.nr) ? act : act + (int64_t)(a.rep - 1) * a.nr;
+}
+__global__ __launch_bounds__(kThreads) void k_ruiz_cols(RuizArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t act = (int64_t)blockIdx.x * (kThreads / 64) + (threadIdx.x >> 6);
+    if (act >= a.n_act) return;
+    const int64_t j = ruiz_col(a, act);
+    double mx = 0.0;
+    for (int k = a.P_ptr[j] + lane; k < a.P_ptr[j + 1]; k += 64) mx = fmax(mx, fabs(a.P_val[k]) * a.D[a.P_col[k]]);
+    for (int k = a.atp[j] + lane; k < a.atp[j + 1]; k += 64) {
+        const int32_t q = a.atpos[k];
+        mx = fmax(mx, fabs(a.A_val[q]) * a.E[a.arow[q]]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) {
+        mx *= a.D[j];
+        a.d[act] = mx > 1e-12 ? 1.0 / sqrt(mx) : 1.0;
+    }
+}
+__global__ __launch_bounds__(kThreads) void k_ruiz_groups(RuizArgs a) {
+    const int64_t g = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (g >= a.ngroups) return;
+    const int r0 = a.gstart[g];
+    const int r1 = a.rep > 1 ? min(r0 + 2, a.gstart[g + 1]) : a.gstart[g + 1];
+    double mx = 0.0;
+    for (int k = a.A_ptr[r0]; k < a.A_ptr[r1]; ++k) mx = fmax(mx, fabs(a.A_val[k]) * a.D[a.A_col[k]]);
+    mx *= a.E[r0];
+    a.e[g] = mx > 1e-12 ? 1.0 / sqrt(mx) : 1.0;
+}
+__global__ __launch_bounds__(kThreads) void k_ruiz_apply(RuizArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < a.n_act) {
+        const int64_t j = ruiz_col(a, i);
+        const double v = a.D[j] * a.d[i];
+        a.D[j] = v;
+        if (a.rep > 1 && i < a.nr)
+            for (int q = 1; q < a.rep; ++q) a.D[j + q * a.nr] = v;
+    }
+    if (i < a.ngroups) {
+        const double eg = a.e[i];
+        for (int r = a.gstart[i]; r < a.gstart[i + 1]; ++r) a.E[r] *= eg;
+    }
+}
+
 // launch-overhead probes (debug timing only)
 // after a factorisation: keep the factors to float precision (in place, so every reader sees the same
 // operator) and write the 4-byte copy the LDS-resident chain kernel streams

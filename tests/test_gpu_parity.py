@@ -882,3 +882,27 @@ def test_3d_refinement_on_the_gpu(hip_lib, twin_lib):
     b, ib = refine_estimate(fg, res, lib_path=twin_lib)
     assert ia["iterations"] == ib["iterations"] and ia["cost_final"] == pytest.approx(ib["cost_final"], rel=1e-7)
     assert ia["cost_final"] < 0.05 * ia["cost_initial"] and ia["grad_inf"] < 1e-5 * max(1.0, ia["cost_final"])
+
+
+@pytest.mark.parametrize("name,relax", [("manhattan", "SOCP"), ("graph3d", "SOCP"), ("synth_d", "QCQP"), ("goats", "SOCP")])
+def test_device_equilibration_equals_the_host_loop(name, relax, fixtures, hip_lib, twin_lib, monkeypatch):
+    """f2: the passes of the Ruiz equilibration run on the device for a single problem (k_ruiz_cols: a wavefront per
+    column of [[P, A'], [A, 0]]; k_ruiz_groups: one scale per cone; k_ruiz_apply) -- the scales D, E must be the ones
+    the host loop computes (ruiz_scale, which the twin runs): same formulas, so equal to rounding; replicated problems
+    (2 and 3 replicas), the direct QCQP form, and the switch back to the host loop (SCORE_NO_DEVICE_RUIZ)."""
+    _hip_only(hip_lib)
+    qp = assemble(graph_by_name(name, fixtures), relax).qp
+    monkeypatch.delenv("SCORE_NO_DEVICE_RUIZ", raising=False)
+    dev = ConicSolver(qp, dict(polish=0), lib_path=hip_lib)
+    monkeypatch.setenv("SCORE_NO_DEVICE_RUIZ", "1")
+    host = ConicSolver(qp, dict(polish=0), lib_path=hip_lib)
+    monkeypatch.delenv("SCORE_NO_DEVICE_RUIZ", raising=False)
+    twin = ConicSolver(qp, dict(polish=0), lib_path=twin_lib)
+    for v in ("D", "E"):
+        a, b, c = dev.debug_get(v), host.debug_get(v), twin.debug_get(v)
+        assert a.min() > 0
+        np.testing.assert_allclose(a, b, rtol=1e-12, atol=0)
+        np.testing.assert_allclose(a, c, rtol=1e-12, atol=0)
+    np.testing.assert_allclose(dev.debug_get("Kval"), host.debug_get("Kval"), rtol=1e-11, atol=1e-300)
+    for s_ in (dev, host, twin):
+        s_.close()
