@@ -444,6 +444,10 @@ struct HipBackend {
     DevBuf<double> pw_part, rz_part0, rz_part1, rz_meas0, rz_meas1, pres_part, dres_part;
     // ---- semismooth-Newton polish (score_polish*.hpp) ----
     DevBuf<float> fac32, q_fac32;  // float copies of the chain factors (ADMM / Newton), see k_fac_round
+    DevBuf<float> deepK, deepH;    // lane-major copies of their coarse levels (k_deep_pack -> k_prec_pre<.., float, true>)
+    DevBuf<int32_t> deep_map;
+    bool prec_reg = false;         // every chain has a lane plan: the register-resident variant serves the 4-byte streams
+    size_t prec_reg_lds = 0;
     bool use_fac32 = false;     // ADMM-loop factors (K)
     bool newton_fac32 = false;  // Newton-polish factors (H): fac_fp32 = 2 only, see DESIGN.md section 4
     PolishData Q;
@@ -717,6 +721,18 @@ struct HipBackend {
         }
         if (lds_pre > 158 * 1024) prec_pre = false;  // 160 KiB per CU, minus the static record and slack
         prec_pre_lds = prec_pre ? lds_pre : 0;
+        // register-resident coarse levels (k_prec_pre<.., float, true>): LDS holds the vectors only
+        prec_reg = prec_pre && h.deep_ok && h.bs <= 3 && st.fac_fp32 != 0 && std::getenv("SCORE_NO_REGDEEP") == nullptr;
+        if (prec_reg) {
+            size_t lds_reg = 0;
+            for (const auto& ch : h.chains) {
+                const ChainLevelDesc* lv = &h.levels[ch.level_begin];
+                const ChainLevelDesc& Lend = lv[ch.n_levels - 1];
+                lds_reg = std::max(lds_reg, (16 + (size_t)Lend.lds_off + (size_t)Lend.N * h.bs + 1 + (size_t)(lv[0].nruns + 1) * h.bs) * sizeof(double));
+            }
+            prec_reg_lds = lds_reg;
+            deep_map.upload(h.deep_map);
+        }
         {   // does any launch fall back to the streaming kernel (k_prec)?  4 x 4 blocks: every factor set kept in double
             const bool fallback = !prec_pre || (h.bs >= 4 && st.fac_fp32 == 0);
             if (fallback && prec_lds > 144 * 1024) throw std::runtime_error("chain too long for the LDS-resident chain solver");
@@ -741,6 +757,7 @@ struct HipBackend {
         // factors follow the ADMM ones there (same Newton and PCG counts on the 3-D BASELINE-sized problems)
         newton_fac32 = st.fac_fp32 >= 2 || (st.fac_fp32 == 1 && h.bs >= 4 && prec_pre);
         if (use_fac32) { fac32.alloc(h.fac_doubles); fac32.zero(stream); }
+        if (use_fac32 && prec_reg) deepK.alloc((size_t)std::max<int64_t>(1, h.deep_floats));
         dinv.alloc(h.dinv.size()); rho.upload(h.rho);
         q_work.alloc((size_t)std::max<int64_t>(1, h.scratch_nodes) * 2 * std::max(1, h.bs * h.bs));
         plan_factor_lds();
@@ -838,6 +855,9 @@ struct HipBackend {
         if ((newton_set ? newton_fac32 : use_fac32) && nf > 0) {
             float* shadow = newton_set ? q_fac32.d : fac32.d;
             hipLaunchKernelGGL(k_fac_round, dim3((unsigned)((nf + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, fa.fac, shadow, nf);
+            if (prec_reg)  // ... and the lane-major copy of the coarse levels the register-resident chain kernel loads
+                hipLaunchKernelGGL(k_deep_pack, dim3((unsigned)(12 * bs * bs), (unsigned)np), dim3(kThreads), 0, stream, fa.work, fa.chains,
+                                   fa.levels, (const int32_t*)deep_map.d, (const float*)shadow, newton_set ? deepH.d : deepK.d, fa.skip);
         }
     }
 
@@ -961,6 +981,7 @@ struct HipBackend {
         PrecArgs pa = pa_in;
         const bool newton_set = (pa.fac == q_fac.d) && q_fac.d;
         pa.fac32 = newton_set ? q_fac32.d : fac32.d;  // the float copy of whichever factor set is applied
+        pa.deep = newton_set ? deepH.d : deepK.d;
         const bool use_fac32 = newton_set ? newton_fac32 : this->use_fac32;
         if (split.active) {
             WaveArgs wa{};
@@ -981,6 +1002,12 @@ struct HipBackend {
     void launch_prec_bs(const PrecArgs& pa, int slot, bool use_fac32) {
         // k_prec_pre (level 0 in registers, coarse levels in LDS) when every chain fits; 4 x 4 blocks (3-D problems) only
         // with the 4-byte factor stream (score_settings.fac_fp32), otherwise the streaming kernel
+        if constexpr (BS <= 3) {
+            if (prec_reg && use_fac32) {  // coarse-level factors in registers, vectors only in LDS
+                launch_on_stream((k_prec_pre<BS, MODE, float, true>), dim3(n_prec), dim3(kPrecThreads), prec_reg_lds, slot, pa);
+                return;
+            }
+        }
         if (prec_pre && use_fac32) {
             launch_on_stream((k_prec_pre<BS, MODE, float>), dim3(n_prec), dim3(kPrecThreads), prec_pre_lds, slot, pa);
             return;
@@ -1006,6 +1033,8 @@ struct HipBackend {
         HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_INIT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_prec<BS, 3, PREC_STEP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
         if constexpr (BS <= 3) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BS, PREC_INIT, float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BS, PREC_STEP, float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
             HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BS, PREC_INIT, double>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
             HIP_CHECK(hipFuncSetAttribute((const void*)k_prec_pre<BS, PREC_STEP, double>, hipFuncAttributeMaxDynamicSharedMemorySize, kCeil));
         }
@@ -1476,6 +1505,7 @@ struct HipBackend {
         q_fac.alloc(h.fac_doubles_H); q_dinv.alloc(h.dinv.size());
         q_fac.zero(stream);  // separator slots of the spike region are never written (nor used)
         if (newton_fac32) { q_fac32.alloc(h.fac_doubles_H); q_fac32.zero(stream); }
+        if (newton_fac32 && prec_reg) deepH.alloc((size_t)std::max<int64_t>(1, h.deep_floats_H));
         n_gd = std::max<size_t>((h.n_tot + kThreads - 1) / kThreads, (size_t)Hm.nblocks);
         q_pw.alloc(Hm.nblocks);
         {

@@ -251,6 +251,10 @@ struct ChainLevelDesc {
     int32_t lds_off;
     uint32_t inv_p;   // 2^20 / p + 1: i / p == (i * inv_p) >> 20 for i < 2^18
     int64_t offR, offS, offB;  // offsets into `fac`, in doubles
+    // register-resident coarse levels (k_prec_pre<.., REGDEEP>): the runs / nodes of level >= 1 are served by the staging
+    // lanes lane0 .. (disjoint ranges per level, chain_lane_plan); -1: the chain does not fit that kernel
+    int32_t lane0;
+    int32_t pad_;
 };
 
 struct ChainDesc {
@@ -262,6 +266,10 @@ struct ChainDesc {
     int32_t scratch_nodes;
     int32_t col0;        // first column of node 0
     int32_t col_stride;  // node_col[i] == col0 + i * col_stride for every node (0 = irregular)
+    // register-resident coarse levels: slot map of this chain's length class in HostSystem::deep_map (-1: not eligible)
+    // and the chain's block in the lane-major factor copy (floats; a replica's chain points at its owner's block)
+    int32_t deep_map_off;
+    int32_t deep_off;
 };
 
 // Work item of the preconditioner kernel: a chain, or a block of Jacobi columns.
@@ -486,6 +494,58 @@ inline void chain_level_layout(int bs, int radix, int N0, std::vector<ChainLevel
     scratch_nodes = vec_off;
 }
 
+// Lane plan of the register-resident coarse levels: level 1 on staging lanes 0 .. N_1 - 1 (its runs on the first
+// nruns_1 of them), every further level on a 64-aligned range of its own behind the previous one.  Returns false
+// (and leaves lane0 = -1) when the levels do not fit `lanes` staging lanes.
+inline bool chain_lane_plan(std::vector<ChainLevelDesc>& lv, int lanes) {
+    for (auto& L : lv) { L.lane0 = -1; L.pad_ = 0; }
+    if (lv.size() < 2) return true;  // a single level: nothing coarse
+    // level 1: node i (spike blocks, slots [0, 2 b2)) on lane i, run j on lane j.  Levels >= 2 keep their run and
+    // spike blocks in OTHER slots, so they share lanes with level 1's nodes -- but not with level 1's runs nor with
+    // each other: 64-aligned ranges behind the lanes of level 1's runs.
+    bool ok = lv[1].N <= lanes && lv[1].nruns <= lanes;
+    lv[1].lane0 = 0;
+    int next = (lv[1].nruns + 63) / 64 * 64;
+    for (size_t l = 2; l < lv.size() && ok; ++l) {
+        const int need = std::max(lv[l].N, lv[l].nruns);
+        if (next + need > lanes) { ok = false; break; }
+        lv[l].lane0 = next;
+        next = (next + need + 63) / 64 * 64;
+    }
+    if (!ok)
+        for (auto& L : lv) L.lane0 = -1;
+    return ok;
+}
+// Slot map of the lane-major copy of a chain's coarse-level factors (k_deep_pack -> k_prec_pre<.., REGDEEP>): staging lane
+// dt keeps in registers  [0, 2 b2): the spike blocks V, W of level-1 node dt;  [2 b2, 10 b2): the run (6 b2) and
+// separator (2 b2) blocks of the run it serves (whatever level);  [10 b2, 12 b2): the spike blocks of its own level's
+// node when that level is >= 2.  map[s * lanes + dt] = index into the chain's factor array (relative), -1 = unused.
+inline void chain_deep_map(int bs, const std::vector<ChainLevelDesc>& lv, int64_t fac_base, int lanes, std::vector<int32_t>& map) {
+    const int b2 = bs * bs, RMAX = 3;
+    map.assign((size_t)12 * b2 * lanes, -1);
+    auto put = [&](int slot, int dt, int64_t idx) { map[(size_t)slot * lanes + dt] = (int32_t)(idx - fac_base); };
+    for (size_t l = 1; l < lv.size(); ++l) {
+        const ChainLevelDesc& L = lv[l];
+        const bool last = (L.p == 0);
+        for (int j = 0; j < L.nruns; ++j) {
+            const int lo = last ? 0 : j * L.p;
+            const int hi = last ? L.N : std::min(j * L.p + L.p - 1, L.N);
+            const int len = std::max(hi - lo, 1);
+            for (int q = 0; q < RMAX; ++q)
+                for (int slot = 0; slot < 2; ++slot)
+                    for (int e = 0; e < b2; ++e)
+                        put(2 * b2 + (slot * RMAX + q) * b2 + e, L.lane0 + j,
+                            L.offR + ((int64_t)(slot * b2 + e) * L.P + std::min(q, len - 1)) * L.nruns + j);
+        }
+        for (int j = 0; j < L.nsep; ++j)
+            for (int slot = 0; slot < 2; ++slot)
+                for (int e = 0; e < b2; ++e) put(2 * b2 + (2 * RMAX + slot) * b2 + e, L.lane0 + j, L.offS + (int64_t)(slot * b2 + e) * L.nsep + j);
+        if (!last)
+            for (int i = 0; i < L.N; ++i)
+                for (int e = 0; e < 2 * b2; ++e) put((l == 1 ? 0 : 10 * b2) + e, L.lane0 + i, L.offB + (int64_t)e * L.N + i);
+    }
+}
+
 // Reference (host) application of the factorisation: z = M^{-1} r for one chain.
 // r/z are indexed by column (level 0 gathers through node_col); `scr` holds the
 // level >= 1 vectors.  The HIP kernel performs exactly these operations.
@@ -623,6 +683,11 @@ struct HostSystem {
     // (chain_owner): `levels` / `fac` hold one set per robot.  The Newton matrix of the polish is NOT of that form
     // (active cones couple the rows): chainsH / levelsH / fac_doubles_H describe the same chains with factors of
     // their own.  rep == 1: chainsH == chains, levelsH == levels.
+    // lane-major copies of the coarse-level factors (chain_deep_map): slot maps per chain length, sizes of the copies
+    // for the factors of K (owner chains) and of the Newton matrix (every chain)
+    std::vector<int32_t> deep_map;
+    int64_t deep_floats = 0, deep_floats_H = 0;
+    bool deep_ok = false;    // every chain has a lane plan (block size <= 3)
     int rep = 1;
     int tile_nnz = kTileNnz;             // nonzeros per SpMV tile of K and G1 (kTileNnz, or half of it: see build_system)
     std::vector<int64_t> rep_n;          // per problem
@@ -1410,7 +1475,9 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     pt.mark("chain positions");
     // level layout (structure only) + storage
     H.fac_off.clear();
-    struct Layout { int N; std::vector<ChainLevelDesc> lv; size_t fac_size; int scr; };
+    struct Layout { int N; std::vector<ChainLevelDesc> lv; size_t fac_size; int scr; int32_t map_off; };
+    constexpr int kDeepLanes = 256;
+    H.deep_ok = bs >= 1 && bs <= 3 && !H.chains.empty();
     size_t fac_total = H.fac.size();
     std::vector<Layout> layouts;  // the level structure depends only on (N, radix): one dry run per length
     size_t fac_total_H = 0;
@@ -1426,6 +1493,13 @@ inline void build_system(const score_problem* probs, int count, const score_sett
             L.N = ch.N;
             L.scr = 0;
             chain_level_layout(bs, H.radix, ch.N, L.lv, L.fac_size, L.scr);
+            L.map_off = -1;
+            if (bs >= 1 && bs <= 3 && chain_lane_plan(L.lv, kDeepLanes)) {  // (kPrecThreads - kPreRunLanes staging lanes)
+                std::vector<int32_t> mp;
+                chain_deep_map(bs, L.lv, 0, kDeepLanes, mp);
+                L.map_off = (int32_t)H.deep_map.size();
+                H.deep_map.insert(H.deep_map.end(), mp.begin(), mp.end());
+            }
             layouts.push_back(std::move(L));
             lay = &layouts.back();
         }
@@ -1434,8 +1508,14 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         const int scr = lay->scr;
         ch.n_levels = (int32_t)lv.size();
         if (ch.n_levels > 20) throw std::runtime_error("chain too long: more than 20 partition levels");
+        const int64_t deep_sz = (int64_t)12 * bs * bs * kDeepLanes;
+        ch.deep_map_off = lay->map_off;
+        if (lay->map_off < 0) H.deep_ok = false;
         {   // the Newton matrix: every chain has factors of its own
             ChainDesc& cH = H.chainsH[ci];
+            cH.deep_map_off = lay->map_off;
+            cH.deep_off = (int32_t)H.deep_floats_H;
+            H.deep_floats_H += deep_sz;
             cH.level_begin = (int32_t)H.levelsH.size();
             cH.n_levels = ch.n_levels;
             for (auto L : lv) {
@@ -1458,9 +1538,12 @@ inline void build_system(const score_problem* probs, int count, const score_sett
             }
             H.fac_off.push_back(dbl_base);
             fac_total += fac_size;
+            ch.deep_off = (int32_t)H.deep_floats;
+            H.deep_floats += deep_sz;
         } else {  // (owners precede their replicas)
             ch.level_begin = H.chains[(size_t)H.chain_owner[ci]].level_begin;
             H.fac_off.push_back(H.fac_off[(size_t)H.chain_owner[ci]]);
+            ch.deep_off = H.chains[(size_t)H.chain_owner[ci]].deep_off;
         }
         ch.scratch_off = (int32_t)H.scratch_nodes;
         ch.scratch_nodes = scr;
@@ -1476,11 +1559,16 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     // Jacobi columns + work list (problem-major: chains, then Jacobi blocks)
     size_t ci = 0;
     for (int p = 0; p < count; ++p) {
+        const size_t c_first = ci;
         while (ci < H.chains.size() && H.chains[ci].prob == p) {
-            H.prec_work.push_back(PrecWork{0, (int32_t)ci, 0, p});
             if (H.chain_owner[ci] == (int32_t)ci) H.factor_work.push_back(PrecWork{0, (int32_t)ci, 0, p});
             ++ci;
         }
+        // (Measured and not kept: dealing a replicated problem's work items in groups of 8 robots, replica after replica,
+        //  so that the chains sharing one factor set sit 8 items apart -- on one XCD's L2 under round-robin placement:
+        //  no change, 61.6 vs 62.5 us at 16 problems.  The chain kernel is bound by its dependent phases at one
+        //  workgroup per CU, not by where its factors come from.)
+        for (size_t c = c_first; c < ci; ++c) H.prec_work.push_back(PrecWork{0, (int32_t)c, 0, p});
         const size_t d_first = H.diag_cols.size();
         for (int64_t c = H.xoff[p]; c < H.xoff[p + 1]; ++c)
             if (!in_chain[c]) {

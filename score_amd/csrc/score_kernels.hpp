@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
 // Everything k_prec_pre needs to know about its work item in ONE 512-byte record (work item, chain, level table):
 // a single trip to memory by 32 lanes instead of the chain work -> chain -> levels (three dependent trips before the
 // first factor or vector load could be requested).  Built by the backend from HostSystem::prec_work / chains / levels.
-constexpr int kRecLevels = 8;
+constexpr int kRecLevels = 7;
 struct alignas(16) PrecRecord {
     PrecWork wk;
     ChainDesc ch;
@@ -469,6 +469,7 @@ struct PrecArgs {
     const ChainLevelDesc* levels;
     const double* fac;
     const float* fac32;    // the same factors as 4-byte values (k_fac_round); read by k_prec_pre<.., float>
+    const float* deep;     // lane-major copy of the coarse-level factors (k_deep_pack); read by k_prec_pre<.., float, true>
     const int32_t* node_col;
     const int32_t* diag_cols;
     const double* dinv;
@@ -969,19 +970,28 @@ struct PreTile {
     static constexpr int CH = (BS >= 4) ? 8 : kPrecChunk;    // vector entries per lane: chains of up to CH * 512 / BS nodes
 };
 
-template <int BS, int MODE, typename FT = double>
+// REGDEEP (4-byte stream, block size <= 3, every chain with a lane plan): the coarse levels' factors never touch LDS.
+// k_deep_pack has laid them out lane by lane -- staging lane dt: [0, 2 B2) spike blocks of level-1 node dt, [2 B2, 10 B2)
+// the run + separator blocks of the run it serves, [10 B2, 12 B2) the spike blocks of its own level's node (levels >= 2) --
+// so a lane loads its slots straight into registers (coalesced: slot-major) and every coarse phase starts its arithmetic
+// at once instead of pulling 18..72 values from LDS first.  LDS then holds vectors only (41 KB instead of 135 KB at
+// 1000 nodes): three chains per CU can be resident.  The level-0 tile is kept as floats too (converted where used).
+template <int BS, int MODE, typename FT = double, bool REGDEEP = false>
 __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
+    static_assert(!REGDEEP || (sizeof(FT) == 4 && BS <= 3), "register-resident coarse levels: 4-byte stream, blocks up to 3 x 3");
     KernelStamp stamp(a.tstamp);
     constexpr int RMAX = 3;
     constexpr int B2 = BS * BS;
-    constexpr int NG = PreTile<BS>::NG;
-    constexpr int oCl = 2 * RMAX * B2, oCr = oCl + B2;
+    constexpr int oRun = REGDEEP ? 2 * B2 : 0;                 // first register of a lane's run blocks
+    constexpr int oBk2 = 10 * B2;                              // REGDEEP: spike blocks of the lane's own level (>= 2)
+    constexpr int NG = REGDEEP ? 12 * B2 : PreTile<BS>::NG;
+    constexpr int oCl = oRun + 2 * RMAX * B2, oCr = oCl + B2;
     constexpr int kStageLanes = kPrecThreads - kPreRunLanes;
     constexpr int CH = PreTile<BS>::CH;  // vector entries per lane
     // 4 x 4 blocks (3-D): the level-0 tile stays in the factor stream's own type in registers and the coarse levels'
     // factors in LDS likewise -- with the 4-byte stream (the only one this block size is launched with) that is 128
     // registers and 84 KB instead of 256 and 169 KB; converted where used
-    using LT = typename std::conditional<(BS >= 4), FT, double>::type;
+    using LT = typename std::conditional<(BS >= 4 || REGDEEP), FT, double>::type;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ PrecRecord srec;
     double* red = lds;
@@ -1037,7 +1047,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             deep_base = sLv[1].offR;
             deep_cnt = (int)(Lz.offB + (int64_t)2 * B2 * Lz.N - deep_base);
         }
-        double* xch = reinterpret_cast<double*>(lfac + ((deep_cnt + 1) & ~1));  // coupling terms handed from a separator to the run on its right
+        // coupling terms handed from a separator to the run on its right (REGDEEP: no factors in LDS, they follow the vectors)
+        double* xch = REGDEEP ? vb + Lz.lds_off + Lz.N * BS + 1 : reinterpret_cast<double*>(lfac + ((deep_cnt + 1) & ~1));
         // ---- vector loads (only r and w feed the solve; the operands of the xt / kx update
         //      are requested later: the register file is full here) ----
         int cols[CH];
@@ -1071,8 +1082,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                     const FT* __restrict__ Rq = R + (size_t)min(q, len - 1) * L0.nruns + j;
 #pragma unroll
                     for (int e = 0; e < B2; ++e) {
-                        Gr[q * B2 + e] = Rq[(size_t)e * eP];
-                        Gr[(RMAX + q) * B2 + e] = Rq[(size_t)(B2 + e) * eP];
+                        Gr[oRun + q * B2 + e] = Rq[(size_t)e * eP];
+                        Gr[oRun + (RMAX + q) * B2 + e] = Rq[(size_t)(B2 + e) * eP];
                     }
                 }
                 if (L0.nsep > 0) {
@@ -1083,6 +1094,24 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                         Gr[oCl + e] = S[(size_t)e * L0.nsep + js];
                         Gr[oCr + e] = S[(size_t)(B2 + e) * L0.nsep + js];
                     }
+                }
+            }
+        } else if (REGDEEP) {
+            // this lane's slots of the lane-major copy; slot ranges no lane of the wavefront uses are skipped (uniform)
+            if (nl >= 2 && !(a.debug_skip & 2)) {
+                const float* __restrict__ src = a.deep + ch.deep_off + (t - kPreRunLanes);
+                const int w0 = (t - kPreRunLanes) & ~63;  // first staging lane of this wavefront
+                bool need_run = false, need_bk2 = false;
+                for (int l = 1; l < nl; ++l) {
+                    const ChainLevelDesc Lx = sLv[l];
+                    need_run = need_run || (Lx.lane0 < w0 + 64 && Lx.lane0 + Lx.nruns > w0);
+                    need_bk2 = need_bk2 || (l >= 2 && Lx.p != 0 && Lx.lane0 < w0 + 64 && Lx.lane0 + Lx.N > w0);
+                }
+                const bool need_bk1 = sLv[1].p != 0 && w0 < sLv[1].N;
+#pragma unroll
+                for (int k = 0; k < NG; ++k) {
+                    const bool need = k < 2 * B2 ? need_bk1 : (k < oBk2 ? need_run : need_bk2);
+                    Gr[k] = need ? (FT)src[(size_t)k * kStageLanes] : (FT)0;
                 }
             }
         } else if (deep_cnt > 0 && !(a.debug_skip & 2)) {
@@ -1121,7 +1150,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                 rv[u] = r_;
             }
         }
-        if (t >= kPreRunLanes) {
+        if (t >= kPreRunLanes && !REGDEEP) {
             if (deep_cnt > 0 && !(a.debug_skip & 2)) {
                 const int lane = t - kPreRunLanes;
 #pragma unroll
@@ -1148,7 +1177,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                 for (int c = 0; c < BS; ++c) {
                     double s_ = y[q][c];
 #pragma unroll
-                    for (int k = 0; k < BS; ++k) s_ -= G[q * B2 + c * BS + k] * y[q - 1][k];
+                    for (int k = 0; k < BS; ++k) s_ -= G[oRun + q * B2 + c * BS + k] * y[q - 1][k];
                     y[q][c] = s_;
                 }
             }
@@ -1159,7 +1188,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                 for (int c = 0; c < BS; ++c) {
                     double s_ = 0.0;
 #pragma unroll
-                    for (int k = 0; k < BS; ++k) s_ += G[(RMAX + q) * B2 + c * BS + k] * y[q][k];
+                    for (int k = 0; k < BS; ++k) s_ += G[oRun + (RMAX + q) * B2 + c * BS + k] * y[q][k];
                     tmp[c] = s_;
                 }
                 if (q + 1 < RMAX) {
@@ -1168,7 +1197,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                     for (int c = 0; c < BS; ++c) {
                         double s_ = 0.0;
 #pragma unroll
-                        for (int k = 0; k < BS; ++k) s_ += G[(q + 1) * B2 + k * BS + c] * y[q + 1][k];
+                        for (int k = 0; k < BS; ++k) s_ += G[oRun + (q + 1) * B2 + k * BS + c] * y[q + 1][k];
                         tmp[c] = has_next ? tmp[c] - s_ : tmp[c];
                     }
                 }
@@ -1260,21 +1289,26 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         for (int l = 1; l < nl && !dbg_nophase; ++l) {
             const ChainLevelDesc L = sLv[l];
             const bool last = (L.p == 0);
-            if (dt >= 0 && dt < L.nruns) {
-                const int j = dt;
+            // (REGDEEP: the level's runs / separators / nodes are served by the staging lanes lane0 .., whose registers
+            //  already hold the blocks)
+            const int dl = REGDEEP ? dt - L.lane0 : dt;
+            if (dt >= 0 && dl >= 0 && dl < L.nruns) {
+                const int j = dl;
                 const int lo = last ? 0 : j * L.p;
                 const int hi = last ? L.N : min(j * L.p + L.p - 1, L.N);
                 const int len = hi - lo;
                 if (len > 0) {
-                    const int eP = L.P * L.nruns;
-                    const LT* R = lfac + (L.offR - deep_base);
+                    if (!REGDEEP) {
+                        const int eP = L.P * L.nruns;
+                        const LT* R = lfac + (L.offR - deep_base);
 #pragma unroll
-                    for (int q = 0; q < RMAX; ++q) {
-                        const LT* Rq = R + min(q, len - 1) * L.nruns + j;
+                        for (int q = 0; q < RMAX; ++q) {
+                            const LT* Rq = R + min(q, len - 1) * L.nruns + j;
 #pragma unroll
-                        for (int e = 0; e < B2; ++e) {
-                            G[q * B2 + e] = Rq[e * eP];
-                            G[(RMAX + q) * B2 + e] = Rq[(B2 + e) * eP];
+                            for (int e = 0; e < B2; ++e) {
+                                G[q * B2 + e] = Rq[e * eP];
+                                G[(RMAX + q) * B2 + e] = Rq[(B2 + e) * eP];
+                            }
                         }
                     }
                     double* vr = vb + L.lds_off + lo * BS + (last ? 0 : j);
@@ -1296,13 +1330,15 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             lds_barrier();
             if (last) break;
             const ChainLevelDesc Ln = sLv[l + 1];
-            if (dt >= 0 && dt < L.nsep) {
-                const int js = dt;
-                const LT* S = lfac + (L.offS - deep_base);
+            if (dt >= 0 && dl >= 0 && dl < L.nsep) {
+                const int js = dl;
+                if (!REGDEEP) {
+                    const LT* S = lfac + (L.offS - deep_base);
 #pragma unroll
-                for (int e = 0; e < B2; ++e) {
-                    G[oCl + e] = S[e * L.nsep + js];
-                    G[oCr + e] = S[(B2 + e) * L.nsep + js];
+                    for (int e = 0; e < B2; ++e) {
+                        G[oCl + e] = S[e * L.nsep + js];
+                        G[oCr + e] = S[(B2 + e) * L.nsep + js];
+                    }
                 }
                 const int s = js * L.p + L.p - 1;
                 const bool has_r = (s + 1 < L.N);
@@ -1327,11 +1363,18 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         for (int l = nl - 2; l >= 1 && !dbg_nophase; --l) {
             const ChainLevelDesc Lb = sLv[l];
             const ChainLevelDesc Ln = sLv[l + 1];
-            if (dt >= 0 && dt < Lb.N) {
-                const int i = dt;
-                const LT* Bk = lfac + (Lb.offB - deep_base);
+            const int db = REGDEEP ? dt - Lb.lane0 : dt;
+            if (dt >= 0 && db >= 0 && db < Lb.N) {
+                const int i = db;
+                LT Vw[2 * B2];  // spike blocks V, W of node i
+                if (REGDEEP) {
 #pragma unroll
-                for (int e = 0; e < 2 * B2; ++e) G[e] = Bk[e * Lb.N + i];
+                    for (int e = 0; e < 2 * B2; ++e) Vw[e] = (l == 1) ? G[e] : G[oBk2 + e];
+                } else {
+                    const LT* Bk = lfac + (Lb.offB - deep_base);
+#pragma unroll
+                    for (int e = 0; e < 2 * B2; ++e) Vw[e] = Bk[e * Lb.N + i];
+                }
                 const int nsep = Lb.nsep;
                 const int j = pad(Lb, i);
                 const bool is_sep = (i - j * Lb.p == Lb.p - 1) && (j < nsep);
@@ -1346,7 +1389,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                 for (int c = 0; c < BS; ++c) {
                     double acc = v[c];
 #pragma unroll
-                    for (int k = 0; k < BS; ++k) acc -= G[c * BS + k] * ul[k] + G[B2 + c * BS + k] * ur[k];
+                    for (int k = 0; k < BS; ++k) acc -= Vw[c * BS + k] * ul[k] + Vw[B2 + c * BS + k] * ur[k];
                     pvx[c] = is_sep ? ur[c] : acc;
                 }
             }
@@ -1852,6 +1895,21 @@ __global__ __launch_bounds__(kThreads) void k_fac_round(double* __restrict__ fac
     const float f = (float)fac[i];
     fac32[i] = f;
     fac[i] = (double)f;
+}
+
+// Lane-major copy of the coarse-level factors of every chain of the work list (HostSystem::deep_map): block (s, w) fills
+// slot s of work item w's chain for the 256 staging lanes -- what k_prec_pre<.., float, true> loads straight into registers.
+__global__ __launch_bounds__(kThreads) void k_deep_pack(const PrecWork* __restrict__ work, const ChainDesc* __restrict__ chains,
+                                                        const ChainLevelDesc* __restrict__ levels, const int32_t* __restrict__ map,
+                                                        const float* __restrict__ fac32, float* __restrict__ deep, const int32_t* skip) {
+    const PrecWork wk = work[blockIdx.y];
+    if (wk.kind != 0 || (skip && skip[wk.prob])) return;
+    const ChainDesc ch = chains[wk.index];
+    if (ch.deep_map_off < 0) return;
+    const int64_t base = levels[ch.level_begin].offR;  // the chain's first factor entry
+    const int s = blockIdx.x, dt = threadIdx.x;
+    const int32_t idx = map[(size_t)ch.deep_map_off + (size_t)s * kThreads + dt];
+    deep[(size_t)ch.deep_off + (size_t)s * kThreads + dt] = idx >= 0 ? fac32[base + idx] : 0.0f;
 }
 
 __global__ void k_nop(int* sink) { if (sink && threadIdx.x == 9999) sink[0] = 1; }
