@@ -122,6 +122,8 @@ typedef struct score_settings {
                                   to the same tolerances.  1 (default): the ADMM loop's factors (of K);  2: the Newton
                                   polish's too (same iteration counts on the BASELINE sizes, ~10 % more Newton PCG
                                   iterations on small ill-conditioned graphs);  0: double throughout.
+                                  With 1 the Newton factors follow the 4-byte stream by themselves when every
+                                  chain has >= 256 nodes (same iteration counts there, 7 % faster default solve).
                                   3-D problems (4 x 4 chain blocks): 1 covers the Newton factors as well -- the
                                   LDS-resident chain kernel exists for the 4-byte stream only there, the streaming
                                   kernel that double factors need is three times slower.                        */

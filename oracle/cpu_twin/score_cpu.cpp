@@ -159,8 +159,10 @@ struct CpuBackend {
             if (used > 0 && !(rz > ref)) { ok = true; break; }  // the test the device gate makes before a STEP
             if (used >= max_iters) break;
             double pw = 0.0;
+            // (every 32nd product directly, as the device does: the recurrence K z + beta w_old drifts over a long solve)
+            const bool direct = (used == 0) || (used % 32 == 0);
             for (int64_t i = 0; i < n; ++i) {
-                w[i] = (used == 0) ? row_dot(h.K, i, p.data()) : row_dot(h.K, i, z.data()) + beta_prev * w[i];
+                w[i] = direct ? row_dot(h.K, i, p.data()) : row_dot(h.K, i, z.data()) + beta_prev * w[i];
                 pw += p[i] * w[i];
             }
             const double a = pw > 0.0 ? rz / pw : 0.0;

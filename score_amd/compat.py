@@ -289,14 +289,10 @@ class ArrayDict(Mapping):
     def __contains__(self, key):
         return key in self._idx()
 
-    def items(self):
-        return zip(self._names, self._array)
-
-    def values(self):
-        return iter(self._array)
-
-    def keys(self):
-        return list(self._names)
+    # keys() / items() / values() are Mapping's own views (sized, re-iterable, like a dict's): code written against
+    # the reference's Dict[str, ndarray] -- len(res.poses.values()), two passes over items() -- keeps working.  Rows
+    # are VIEWS into one stacked array: an in-place edit of a row edits the stack (dict(view) gives independent keys,
+    # {k: v.copy() ...} independent values).
 
     @property
     def array(self) -> np.ndarray:

@@ -755,7 +755,13 @@ struct HipBackend {
         // 4 x 4 blocks (3-D problems): the LDS-resident chain kernel only exists for the 4-byte stream, and the streaming
         // kernel is three times slower (22 / 30 us against 66 / 74 us per application on 1000-pose chains) -- the Newton
         // factors follow the ADMM ones there (same Newton and PCG counts on the 3-D BASELINE-sized problems)
-        newton_fac32 = st.fac_fp32 >= 2 || (st.fac_fp32 == 1 && h.bs >= 4 && prec_pre);
+        // Long chains (every chain >= 256 nodes: the BASELINE sizes) take the 4-byte stream for the Newton factors as well:
+        // same Newton and PCG counts there, and the register-resident chain kernel serves the Newton PCG too (headline
+        // default solve 6.1 -> 5.7 ms).  Short chains with stiff pinned-pose terms keep double Newton factors (+10 % PCG
+        // iterations with floats on the 144-graph sweep of round 2).
+        int min_chain = 1 << 30;
+        for (const auto& ch : h.chains) min_chain = std::min(min_chain, (int)ch.N);
+        newton_fac32 = st.fac_fp32 >= 2 || (st.fac_fp32 == 1 && prec_pre && (h.bs >= 4 || min_chain >= 256));
         if (use_fac32) { fac32.alloc(h.fac_doubles); fac32.zero(stream); }
         if (use_fac32 && prec_reg) deepK.alloc((size_t)std::max<int64_t>(1, h.deep_floats));
         dinv.alloc(h.dinv.size()); rho.upload(h.rho);
@@ -1405,6 +1411,7 @@ struct HipBackend {
     //      r'M^-1 r <= rel_tol^2 r0'M^-1 r0.  The host looks at one flag per chunk of iterations. ----
     DevBuf<double> lin_rhs, lin_tol2, lin_ref;
     DevBuf<int32_t> lin_flag;  // [gate flag | STEPs executed] per problem
+    static constexpr int kDirectEvery = 32;  // PCG: a direct product w = K p every so many recursive ones
     void linear_buffers(const HostSystem& h) {
         if (h.m_tot != 0 || h.count != 1) throw std::runtime_error("linear mode: one unconstrained pattern per handle");
         if (!lin_flag.d) {
@@ -1464,6 +1471,13 @@ struct HipBackend {
                 a.early_done = 1;
                 launch_spmv<MODE_KPB>(K, a);
                 std::swap(p_cur, p_oth);
+                if ((queued + j + 1) % kDirectEvery == 0) {
+                    // the recurrence w = K z + beta w_old accumulates rounding over a long solve: every kDirectEvery-th
+                    // product is recomputed directly, w = K p (and its p'w)
+                    SpmvArgs d = spmv_args(K, p_cur);
+                    d.p = p_cur; d.done = lin_flag.d; d.early_done = 1;
+                    launch_spmv<MODE_KP>(K, d);
+                }
                 rz_cur = rz_nxt;
                 first = false;
             }
@@ -1641,6 +1655,7 @@ struct HipBackend {
     // raised by the device).  No host synchronisation.  `resume`: continue the solve the previous
     // call left unfinished (its state -- delta, r, z, p, w, the r'z partials -- is intact because a
     // gate that has not fired has not frozen anything).
+    int pcg_steps_queued = 0;
     double* pcg_rz_cur = nullptr;
     double* pcg_p_cur = nullptr;
     double* pcg_p_oth = nullptr;
@@ -1660,6 +1675,7 @@ struct HipBackend {
             // the right-hand side is read where the evaluation left it (-g in q_negg) and the solution
             // starts from zero without a memset: the first STEP writes r and delta
             pcg_rz_cur = rz_part0.d; pcg_p_cur = p.d; pcg_p_oth = p2.d;
+            pcg_steps_queued = 0;
             pa.p = pcg_p_cur; pa.rz_in = nullptr; pa.rz_out = pcg_rz_cur;
             pa.r_in = q_negg.d;
             pa.gate_init = q_pcgdone.d;  // gate flags start as the host's skip flags
@@ -1688,6 +1704,11 @@ struct HipBackend {
             a.early_done = 1;
             hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, a);
             std::swap(pcg_p_cur, pcg_p_oth);
+            if (++pcg_steps_queued % kDirectEvery == 0) {  // (see linear_solve_core)
+                SpmvArgs d = spmv_args(Hm, pcg_p_cur);
+                d.p = pcg_p_cur; d.pw_part = q_pw.d; d.done = q_pcgdone.d; d.early_done = 1;
+                hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, d);
+            }
             pcg_rz_cur = rz_nxt;
         }
     }

@@ -275,7 +275,8 @@ def solve_problem_with_intermediate_iterates(
     check_valid_relaxation(relaxation_type)
     model = _model_for(data, relaxation_type, qcqp_mode, lib_path)
     settings = dict(DEFAULT_SOLVER_SETTINGS)
-    if len(data.loop_closure_measurements):
+    n_lc = int(data.n_loop_closures) if hasattr(data, "arrays") else len(data.loop_closure_measurements)  # (ArrayGraph or objects)
+    if n_lc:
         settings.update(cg_iters=16, cg_target=0.1)
     if relaxation_type == QCQP_RELAXATION and qcqp_mode == "direct":
         settings.update(cg_iters=8, adaptive_rho=0)
@@ -298,22 +299,27 @@ def solve_problem_with_intermediate_iterates(
                 pass  # an early iterate whose rotation block cannot be rounded yet
             return sol.solved
 
-        done, admm = False, 0
-        while not done and admm < warmup and len(iterates) < max_snapshots:
+        # (attempted snapshots are counted, not stored ones: an iterate that cannot be rounded yet still uses up a slot,
+        #  so the loops below end whatever extract_solver_results does)
+        done, admm, attempts, newton_seen = False, 0, 0, 0
+        while not done and admm < warmup and attempts < max_snapshots:
             k = min(every, warmup - admm)
             done = snapshot(solver.steps(k)[0])
             admm += k
+            attempts += 1
         newton_possible = warmup > 0
-        while not done and len(iterates) < max_snapshots:
+        while not done and attempts < max_snapshots:
             if newton_possible:
                 sol = solver.newton_steps(1)[0]
-                if sol.info["newton_iters"] == (iterates[-1].info["newton_iters"] if iterates else 0):
+                if sol.info["newton_iters"] == newton_seen:
                     newton_possible = False  # no polish for this program / backend, or Newton has stalled: ADMM goes on
                     continue
+                newton_seen = sol.info["newton_iters"]
             else:
                 sol = solver.steps(every)[0]
                 admm += every
             done = snapshot(sol)
+            attempts += 1
             if admm >= settings["max_iters"]:
                 break
     finally:

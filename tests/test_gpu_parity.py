@@ -753,6 +753,13 @@ def test_linear_mode_and_refinement_on_the_gpu(hip_lib, twin_lib):
     assert info["converged"] and info["rel_residual"] < 1e-5 and np.all(np.isfinite(x))
 
 
+def test_long_pcg_verdict_on_the_gpu(hip_lib):
+    from test_refine import check_long_pcg_verdict
+
+    _hip_only(hip_lib)
+    check_long_pcg_verdict(hip_lib)
+
+
 def test_refinement_edge_cases_on_the_gpu(hip_lib):
     from test_refine import check_refinement_edge_cases
 
