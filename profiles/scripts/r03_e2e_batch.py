@@ -1,0 +1,39 @@
+"""BASELINE configs[4] end to end from flat arrays: where a lock-step group's wall time goes (one thread,
+then the 4-thread sweep), and the Python profile of one group."""
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import cProfile, pstats
+import numpy as np
+from score_amd.manhattan import make_manhattan
+from score_amd import solve_score as ss
+from score_amd.native import ArrayGraph, graph_arrays, assemble_native
+from score_amd.solver import ConicSolver
+
+trials = [make_manhattan(n_robots=4, n_poses=1000, n_beacons=4, seed=5000 + t) for t in range(64)]
+flat = [ArrayGraph(graph_arrays(fg)) for fg in trials]
+st = dict(eps_abs=1e-7, eps_rel=1e-7)
+ss.solve_score_batch(flat[:16], "SOCP", solver_settings=st)
+for rep in range(2):
+    g = flat[:16]
+    t = time.perf_counter(); models = [ss._model_for(d, "SOCP", "via_socp") for d in g]; t_asm = time.perf_counter() - t
+    settings = dict(ss.DEFAULT_SOLVER_SETTINGS); settings.update(st)
+    t = time.perf_counter(); solver = ConicSolver([m.qp for m in models], settings); t_create = time.perf_counter() - t
+    t = time.perf_counter(); sols = solver.solve(); t_solve = time.perf_counter() - t
+    t = time.perf_counter()
+    out = [ss.extract_solver_results(m, s.x, d, total_time=0.0, solved=s.solved, requested_relaxation="SOCP", info=s.info,
+                                     lib=solver.lib, device=0) for d, m, s in zip(g, models, sols)]
+    t_extract = time.perf_counter() - t
+    t = time.perf_counter(); solver.close(); t_close = time.perf_counter() - t
+    print(f"group of 16, one thread: assemble {1e3*t_asm:.1f} ms  create {1e3*t_create:.1f} (setup_ms {sols[0].info['setup_ms']:.1f})  "
+          f"solve {1e3*t_solve:.1f} (solve_ms {sols[0].info['solve_ms']:.1f})  extract {1e3*t_extract:.1f}  close {1e3*t_close:.1f}", flush=True)
+for workers in (1, 4, 8):
+    ts = []
+    c0 = time.process_time()
+    for _ in range(6):
+        t = time.perf_counter(); r = ss.solve_score_batch(flat, "SOCP", solver_settings=st, workers=workers); ts.append(time.perf_counter() - t)
+    cpu = time.process_time() - c0
+    print(f"64 trials, workers {workers}: min {1e3*min(ts):.1f} ms = {64/min(ts):.0f} problems/s, median {1e3*sorted(ts)[3]:.1f} ms = {64/sorted(ts)[3]:.0f} problems/s, "
+          f"solved {sum(x.solved for x in r)}; CPU time / wall time = {cpu/sum(ts):.1f} ({1e3*cpu/6/64:.1f} core-ms per trial)", flush=True)
+pr = cProfile.Profile(); pr.enable()
+ss.solve_score_batch(flat[:16], "SOCP", solver_settings=st)
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)

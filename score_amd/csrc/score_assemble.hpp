@@ -62,6 +62,7 @@ struct Trip { int32_t col; double val; };
 }
 
 inline void assemble_graph(const score_graph& g, AssembledQP& out) {
+    BuildScope scope;
     const int d = g.dim;
     if (d != 2 && d != 3) throw std::runtime_error("score_graph: dim must be 2 or 3");
     if (g.relaxation != 0 && g.relaxation != 1) throw std::runtime_error("score_graph: relaxation must be 0 (SOCP) or 1 (QCQP)");

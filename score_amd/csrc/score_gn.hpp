@@ -295,6 +295,7 @@ struct GnProblem {
 };
 
 inline void gn_build(const score_graph& g, GnProblem& P) {
+    BuildScope scope;
     if (g.dim != 2 && g.dim != 3) throw std::runtime_error("score_refine: dim must be 2 or 3");
     if (g.n_chains <= 0 || !g.chain_len) throw std::runtime_error("score_refine: no pose chains");
     P.dim = g.dim;

@@ -2142,8 +2142,11 @@ static void tune_host_allocator_once() {
     static std::once_flag once;
     std::call_once(once, [] {
         if (std::getenv("SCORE_KEEP_MALLOC_DEFAULTS")) return;
-        mallopt(M_MMAP_THRESHOLD, 1 << 30);
+        // (glibc refuses an mmap threshold above HEAP_MAX_SIZE / 2 = 32 MiB and then keeps its default -- a
+        //  larger request here used to be a silent no-op)
+        mallopt(M_MMAP_THRESHOLD, 32 << 20);
         mallopt(M_TRIM_THRESHOLD, 1 << 30);
+        mallopt(M_TOP_PAD, 64 << 20);
     });
 }
 
@@ -2392,6 +2395,7 @@ int score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rota
 int64_t score_trim_caches(void) {
     const size_t freed = block_cache().trim();
     stream_pool().trim();
+    malloc_trim(0);  // the host heap kept by tune_host_allocator_once goes back to the system as well
     return (int64_t)freed;
 }
 const char* score_last_error(void) { return g_err.c_str(); }

@@ -54,19 +54,69 @@ inline int host_threads() {
         unsigned h = std::thread::hardware_concurrency();
         cpu_set_t set;  // the CPUs this process may actually run on (containers, taskset)
         if (sched_getaffinity(0, sizeof(set), &set) == 0) h = std::min<unsigned>(h, (unsigned)CPU_COUNT(&set));
+        // ... and the CPU time it may use: a cgroup bandwidth limit (cpu.max "quota period") stalls EVERY thread
+        // of the group for the rest of the period once the quota is spent, so more runnable threads than
+        // quota / period CPUs make setup slower, not faster (the MI355X boxes: 256 CPUs visible, 16 granted)
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            long long quota = 0, period = 0;
+            if (std::fscanf(f, "%lld %lld", &quota, &period) == 2 && quota > 0 && period > 0)
+                h = std::min<unsigned>(h, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+            std::fclose(f);
+        } else if (FILE* g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            long long quota = 0, period = 100000;
+            const bool ok = std::fscanf(g, "%lld", &quota) == 1;
+            std::fclose(g);
+            if (FILE* pf = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+                if (std::fscanf(pf, "%lld", &period) != 1) period = 100000;
+                std::fclose(pf);
+            }
+            if (ok && quota > 0 && period > 0) h = std::min<unsigned>(h, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+        }
+        if (const char* e = std::getenv("SCORE_HOST_THREADS")) h = (unsigned)std::max(1, std::atoi(e));
         return (int)std::min(16u, std::max(1u, h));
     }();
     return n;
 }
 
-// A team of host threads that outlives the call: starting and joining 16 std::threads costs 0.3-0.4 ms
-// on the MI355X host, and score_create alone has ~17 parallel phases.  One parallel region at a time owns
-// the team (`gate`); a region that finds it busy (several handles being created from different host
-// threads) starts its own threads as before.  Part 0 runs on the calling thread; every part of a region
-// runs concurrently (TeamBarrier relies on that).  The team is leaked at exit on purpose and rebuilt
-// lazily in a forked child (its threads do not exist there).
+// How many threads a parallel region opened by THIS thread may use.  Handles are created concurrently
+// (the lock-step groups of solve_score_batch, one host thread each; the polish structures of a handle on a
+// thread of their own): every such builder opens a BuildScope, which fixes its width for the duration --
+// host_threads() shared between the builders active at that moment -- so that the machine's thread budget
+// is not multiplied by the number of callers.  The width is constant inside a scope (parallel_parts() and the
+// region that follows must agree); a region opened from inside a part runs serially.
+inline std::atomic<int>& active_builders() {
+    static std::atomic<int> n{0};
+    return n;
+}
+inline int& tl_region_width() {
+    static thread_local int w = 0;  // 0 = no scope: the full width
+    return w;
+}
+struct BuildScope {
+    int saved;
+    bool counted;
+    BuildScope() : saved(tl_region_width()), counted(tl_region_width() == 0) {
+        if (!counted) return;  // nested scope on the same thread: keep the outer width
+        const int active = active_builders().fetch_add(1, std::memory_order_acq_rel) + 1;
+        tl_region_width() = std::max(1, host_threads() / std::max(1, active));
+    }
+    ~BuildScope() {
+        if (!counted) return;
+        active_builders().fetch_sub(1, std::memory_order_acq_rel);
+        tl_region_width() = saved;
+    }
+    BuildScope(const BuildScope&) = delete;
+    BuildScope& operator=(const BuildScope&) = delete;
+};
+
+// Teams of host threads that outlive the call: starting and joining 16 std::threads costs 0.3-0.4 ms
+// on the MI355X host, and score_create alone has ~17 parallel phases.  A parallel region borrows a whole
+// team for its duration (TeamLease); handles created concurrently from different host threads (the
+// lock-step groups of solve_score_batch) each get a team of their own, up to kMaxTeams -- beyond that a
+// region starts its own threads.  Part 0 runs on the calling thread; every part of a region runs
+// concurrently (TeamBarrier relies on that).  Teams are leaked at exit on purpose and rebuilt lazily in
+// a forked child (their threads do not exist there).
 struct HostTeam {
-    std::mutex gate;
     std::mutex m;
     std::condition_variable cv_work, cv_done;
     std::vector<std::thread> workers;
@@ -95,7 +145,7 @@ struct HostTeam {
             }
         }
     }
-    void run(int parts, const std::function<void(int)>& f) {  // caller holds `gate`; parts - 1 <= workers.size()
+    void run(int parts, const std::function<void(int)>& f) {  // caller holds the lease; parts - 1 <= workers.size()
         {
             std::lock_guard<std::mutex> lk(m);
             job = &f;
@@ -110,28 +160,58 @@ struct HostTeam {
         job = nullptr;
     }
 };
-inline std::atomic<HostTeam*>& host_team_slot() {
-    static std::atomic<HostTeam*> slot{nullptr};
+constexpr int kMaxTeams = 8;
+struct TeamPool {
+    std::mutex m;
+    std::vector<HostTeam*> idle;
+    int made = 0;
+};
+inline std::atomic<TeamPool*>& team_pool_slot() {
+    static std::atomic<TeamPool*> slot{nullptr};
     return slot;
 }
-inline HostTeam* host_team() {
+inline TeamPool* team_pool() {
     static std::mutex make;
     static std::once_flag fork_hook;
-    HostTeam* t = host_team_slot().load(std::memory_order_acquire);
+    TeamPool* t = team_pool_slot().load(std::memory_order_acquire);
     if (t) return t;
     std::lock_guard<std::mutex> lk(make);
-    t = host_team_slot().load(std::memory_order_acquire);
+    t = team_pool_slot().load(std::memory_order_acquire);
     if (!t) {
-        std::call_once(fork_hook, [] { pthread_atfork(nullptr, nullptr, [] { host_team_slot().store(nullptr); }); });
-        t = new HostTeam(host_threads() - 1);
-        host_team_slot().store(t, std::memory_order_release);
+        std::call_once(fork_hook, [] { pthread_atfork(nullptr, nullptr, [] { team_pool_slot().store(nullptr); }); });
+        t = new TeamPool();
+        team_pool_slot().store(t, std::memory_order_release);
     }
     return t;
 }
+// a team for the duration of one parallel region (team == nullptr: none free, the region starts threads)
+struct TeamLease {
+    TeamPool* pool = nullptr;
+    HostTeam* team = nullptr;
+    TeamLease() {
+        if (host_threads() <= 1) return;
+        pool = team_pool();
+        std::lock_guard<std::mutex> lk(pool->m);
+        if (!pool->idle.empty()) { team = pool->idle.back(); pool->idle.pop_back(); }
+        else if (pool->made < kMaxTeams) { ++pool->made; team = new HostTeam(host_threads() - 1); }
+    }
+    ~TeamLease() {
+        if (!team) return;
+        std::lock_guard<std::mutex> lk(pool->m);
+        pool->idle.push_back(team);
+    }
+    TeamLease(const TeamLease&) = delete;
+    TeamLease& operator=(const TeamLease&) = delete;
+};
 
 inline bool& tl_in_parallel_region() {
     static thread_local bool v = false;
     return v;
+}
+inline int region_width() {
+    if (tl_in_parallel_region()) return 1;
+    const int w = tl_region_width();
+    return w > 0 ? w : host_threads();
 }
 
 // fn(part, begin, end) for part = 0..T-1 over the boundaries `bound` (T + 1 entries), all parts concurrently
@@ -149,11 +229,15 @@ inline void run_parts(const std::vector<int64_t>& bound, F&& fn) {
         try { fn(t, bound[(size_t)t], bound[(size_t)t + 1]); } catch (...) { err[(size_t)t] = std::current_exception(); }
         mine = was;
     };
-    HostTeam* team = (!nested && host_threads() > 1) ? host_team() : nullptr;
-    if (team && T - 1 <= (int)team->workers.size() && team->gate.try_lock()) {
-        std::lock_guard<std::mutex> own(team->gate, std::adopt_lock);
-        team->run(T, body);
-    } else {
+    if (!nested) {
+        TeamLease lease;
+        if (lease.team && T - 1 <= (int)lease.team->workers.size()) {
+            lease.team->run(T, body);
+            for (auto& e : err) if (e) std::rethrow_exception(e);
+            return;
+        }
+    }
+    {
         std::vector<std::thread> th;
         for (int t = 1; t < T; ++t) th.emplace_back([&body, t] { body(t); });
         body(0);
@@ -164,7 +248,7 @@ inline void run_parts(const std::vector<int64_t>& bound, F&& fn) {
 
 template <class F>
 inline void parallel_ranges(int64_t n, int64_t min_per_thread, F&& fn) {  // fn(part, begin, end)
-    const int T = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
+    const int T = (int)std::min<int64_t>(region_width(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
     if (T <= 1) { fn(0, (int64_t)0, n); return; }
     std::vector<int64_t> bound((size_t)T + 1);
     for (int t = 0; t <= T; ++t) bound[(size_t)t] = n * t / T;
@@ -175,7 +259,7 @@ inline void parallel_ranges(int64_t n, int64_t min_per_thread, F&& fn) {  // fn(
 // (a landmark seen by thousands of ranges) no longer land in one part.  fn(part, begin, end).
 template <class W, class F>
 inline void parallel_ranges_balanced(int64_t n, int64_t min_per_thread, W&& weight, F&& fn) {
-    const int T = (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
+    const int T = (int)std::min<int64_t>(region_width(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
     if (T <= 1) { fn(0, (int64_t)0, n); return; }
     std::vector<double> pre((size_t)n + 1, 0.0);
     for (int64_t i = 0; i < n; ++i) pre[(size_t)i + 1] = pre[(size_t)i] + 1.0 + (double)weight(i);
@@ -190,7 +274,7 @@ inline void parallel_ranges_balanced(int64_t n, int64_t min_per_thread, W&& weig
     run_parts(bound, fn);
 }
 inline int parallel_parts(int64_t n, int64_t min_per_thread) {
-    return (int)std::min<int64_t>(host_threads(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
+    return (int)std::min<int64_t>(region_width(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
 }
 
 // Sense-reversing barrier for a team started by one parallel_ranges call: lets a thread keep
@@ -1234,6 +1318,7 @@ inline void refresh_rho(HostSystem& H, int pi) {
 inline void build_system(const score_problem* probs, int count, const score_settings& st, HostSystem& H,
                          bool factor_on_host = true, bool allow_rep = false, RuizOffload* ruiz_offload = nullptr) {
     if (count <= 0) throw std::runtime_error("score_create: count must be positive");
+    BuildScope scope;
     PhaseTimer pt(st.verbose != 0);
     H = HostSystem();
     H.factor_on_host = factor_on_host;

@@ -48,6 +48,7 @@ struct PolishData {
 
 inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = false) {
     Q = PolishData();
+    BuildScope scope;  // (built on a thread of its own next to the handle's uploads: shares the thread budget)
     PhaseTimer pt(verbose);
     const int64_t n = H.n_tot, m = H.m_tot;
     const size_t ncones = H.cone_row.size();

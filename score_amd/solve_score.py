@@ -143,7 +143,7 @@ def solve_score(
 def solve_score_batch(
     datas: Sequence, relaxation_type: str = QCQP_RELAXATION, qcqp_mode: str = "via_socp",
     solver_settings: Optional[dict] = None, lib_path: Optional[str] = None, lockstep: Optional[bool] = None,
-    workers: int = 4, assembler: str = "native",
+    workers: int = 4, assembler: str = "native", _models: Optional[list] = None,
 ) -> List[compat.SolverResults]:
     """Independent factor graphs on one GPU.
 
@@ -183,11 +183,20 @@ def solve_score_batch(
         chunks = None
     if chunks is not None and (len(chunks) > 1 or len(chunks[0]) != len(datas)):
         first_error = []
+        if qcqp_mode not in ("via_socp", "direct"):
+            raise ValueError(f"qcqp_mode {qcqp_mode} is not supported")
+        futs: dict = {}
+
+        def build(i):  # model construction, graph by graph (the native assembler releases the GIL)
+            if assembler != "native":
+                _check_factor_graph(datas[i])
+            return _model_for(datas[i], relaxation_type, qcqp_mode, lib_path, assembler)
 
         def one(idx):
             try:
+                models = [futs[i].result() if i in futs else build(i) for i in idx]
                 return solve_score_batch([datas[i] for i in idx], relaxation_type, qcqp_mode, solver_settings, lib_path,
-                                         lockstep=True, assembler=assembler)
+                                         lockstep=True, assembler=assembler, _models=models)
             except ValueError as exc:  # keep what the other graphs of this group produced
                 partial = getattr(exc, "partial_results", None)
                 if partial is None:
@@ -202,8 +211,12 @@ def solve_score_batch(
         else:
             from concurrent.futures import ThreadPoolExecutor
 
-            with ThreadPoolExecutor(max_workers=min(workers, len(chunks))) as pool:
-                parts = list(pool.map(one, chunks))
+            # every group's models are built by the whole pool (in group order: the first group's handle
+            # is being set up while the later groups' models are still under construction)
+            with ThreadPoolExecutor(max_workers=workers) as pool:
+                futs.update((i, pool.submit(build, i)) for c in chunks for i in c)
+                with ThreadPoolExecutor(max_workers=min(workers, len(chunks))) as gpool:
+                    parts = list(gpool.map(one, chunks))
         out = [None] * len(datas)
         for idx, rs in zip(chunks, parts):
             for i, r in zip(idx, rs):
@@ -216,8 +229,8 @@ def solve_score_batch(
         return out
     if qcqp_mode not in ("via_socp", "direct"):
         raise ValueError(f"qcqp_mode {qcqp_mode} is not supported")
-    models = []
-    for data in datas:
+    models = list(_models) if _models is not None else []
+    for data in datas if _models is None else ():
         if assembler != "native":
             _check_factor_graph(data)  # (the native path checks on its flat arrays)
         models.append(_model_for(data, relaxation_type, qcqp_mode, lib_path, assembler))
