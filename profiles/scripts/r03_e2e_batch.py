@@ -12,19 +12,21 @@ trials = [make_manhattan(n_robots=4, n_poses=1000, n_beacons=4, seed=5000 + t) f
 flat = [ArrayGraph(graph_arrays(fg)) for fg in trials]
 st = dict(eps_abs=1e-7, eps_rel=1e-7)
 ss.solve_score_batch(flat[:16], "SOCP", solver_settings=st)
-for rep in range(2):
+def timed(fn):
+    c, t = time.process_time(), time.perf_counter()
+    out = fn()
+    return out, 1e3 * (time.perf_counter() - t), 1e3 * (time.process_time() - c)
+for rep in range(3):
     g = flat[:16]
-    t = time.perf_counter(); models = [ss._model_for(d, "SOCP", "via_socp") for d in g]; t_asm = time.perf_counter() - t
+    models, t_asm, c_asm = timed(lambda: [ss._model_for(d, "SOCP", "via_socp") for d in g])
     settings = dict(ss.DEFAULT_SOLVER_SETTINGS); settings.update(st)
-    t = time.perf_counter(); solver = ConicSolver([m.qp for m in models], settings); t_create = time.perf_counter() - t
-    t = time.perf_counter(); sols = solver.solve(); t_solve = time.perf_counter() - t
-    t = time.perf_counter()
-    out = [ss.extract_solver_results(m, s.x, d, total_time=0.0, solved=s.solved, requested_relaxation="SOCP", info=s.info,
-                                     lib=solver.lib, device=0) for d, m, s in zip(g, models, sols)]
-    t_extract = time.perf_counter() - t
-    t = time.perf_counter(); solver.close(); t_close = time.perf_counter() - t
-    print(f"group of 16, one thread: assemble {1e3*t_asm:.1f} ms  create {1e3*t_create:.1f} (setup_ms {sols[0].info['setup_ms']:.1f})  "
-          f"solve {1e3*t_solve:.1f} (solve_ms {sols[0].info['solve_ms']:.1f})  extract {1e3*t_extract:.1f}  close {1e3*t_close:.1f}", flush=True)
+    solver, t_create, c_create = timed(lambda: ConicSolver([m.qp for m in models], settings))
+    sols, t_solve, c_solve = timed(solver.solve)
+    out, t_extract, c_extract = timed(lambda: [ss.extract_solver_results(m, s.x, d, total_time=0.0, solved=s.solved, requested_relaxation="SOCP",
+                                                                         info=s.info, lib=solver.lib, device=0) for d, m, s in zip(g, models, sols)])
+    _, t_close, c_close = timed(solver.close)
+    print(f"group of 16, one thread, wall ms (CPU ms of the whole process): assemble {t_asm:.1f} ({c_asm:.1f})  create {t_create:.1f} ({c_create:.1f})  "
+          f"solve {t_solve:.1f} ({c_solve:.1f})  extract {t_extract:.1f} ({c_extract:.1f})  close {t_close:.1f} ({c_close:.1f})", flush=True)
 for workers in (1, 4, 8):
     ts = []
     c0 = time.process_time()

@@ -458,7 +458,7 @@ struct HipBackend {
     DevBuf<int32_t> q_cptr, q_ccone, q_cab, q_head, q_ishead, q_posd, q_poss, q_diagpos, q_hblk_part, q_long;
     int n_long = 0;
     // lock-step polish of a batch (count > 1)
-    DevBuf<int32_t> q_skip;
+    DevBuf<int32_t> q_skip, q_reref, q_fskip, q_act;  // (q_skip, q_reref, q_fskip: views into ctl)
     DevBuf<double> q_step;
     DevBuf<int64_t> q_seg_begin, q_seg_end;
     static constexpr int kFlagSlots = 32;
@@ -795,10 +795,12 @@ struct HipBackend {
             q_pcgdone.alloc(2 * (size_t)h.count);
             q_pcgdone.zero(stream);
             q_gate_used.view(q_pcgdone.d + h.count, h.count);
-            ctl.alloc(2 * (size_t)h.count + ((size_t)h.count + 1) / 2);
+            ctl.alloc(2 * (size_t)h.count + (3 * (size_t)h.count + 1) / 2);  // [step | tol2 | skip, reref, fskip]
             q_step.view(ctl.d, h.count);
             q_gate_tol2.view(ctl.d + h.count, h.count);
             q_skip.view((int32_t*)(ctl.d + 2 * (size_t)h.count), h.count);
+            q_reref.view((int32_t*)(ctl.d + 2 * (size_t)h.count) + h.count, h.count);
+            q_fskip.view((int32_t*)(ctl.d + 2 * (size_t)h.count) + 2 * (size_t)h.count, h.count);
         }
         reset();
         pt.mark("reset");
@@ -1513,7 +1515,8 @@ struct HipBackend {
         }
         const size_t nc = h.cone_row.size();
         q_Bbuf.alloc(nc * Q.T * Q.T);
-        n_fpart = std::max<size_t>((nc + kThreads - 1) / kThreads, (size_t)n_cone_blocks);
+        q_act.alloc(nc); q_act.zero(stream);
+        n_fpart = 2 * std::max<size_t>((nc + kThreads - 1) / kThreads, (size_t)n_cone_blocks);  // F partials, then active-set flips
         q_X0.alloc(h.n_tot + h.m_tot); q_X1.alloc(h.n_tot + h.m_tot);
         q_g.alloc(h.n_tot); q_delta.alloc(h.n_tot); q_dummy.alloc(h.n_tot); q_negg.alloc(h.n_tot);
         q_fac.alloc(h.fac_doubles_H); q_dinv.alloc(h.dinv.size());
@@ -1540,6 +1543,7 @@ struct HipBackend {
         a.cone_row = cone_row.d; a.head_col = q_head.d; a.a_abs = q_aabs.d; a.ck = q_ck.d; a.theta = q_theta.d; a.xstar = q_xstar.d;
         a.A_ptr = A_ptr.d; a.A_col = A_col.d; a.A_val = A_val.d; a.b = b.d;
         a.u = X; a.nu = X + h.n_tot; a.Bbuf = q_Bbuf.d; a.fpart = q_fpart.d; a.n_tot = h.n_tot;
+        a.act = q_act.d; a.flip_part = q_fpart.d + n_fpart / 2; a.reref = q_reref.d;
         return a;
     }
 
@@ -1563,7 +1567,7 @@ struct HipBackend {
 
     // Generalised Hessian from the cone blocks of the last evaluation (q_Bbuf), the Jacobi diagonal
     // and the chain factors of the Newton preconditioner (device-side factorisation)
-    void newton_hessian(const int32_t* skip = nullptr) {
+    void newton_hessian(const int32_t* skip = nullptr, bool refactor = true) {
         const HostSystem& h = *H;
         HAsmArgs ha{};
         ha.nnz = (int64_t)Q.Hm.col.size(); ha.Pon = q_Pon.d; ha.cptr = q_cptr.d; ha.ccone = q_ccone.d; ha.cab = q_cab.d;
@@ -1571,7 +1575,7 @@ struct HipBackend {
         ha.ndiag = (int)h.diag_cols.size(); ha.diag_pos = q_diagpos.d; ha.dinv = q_dinv.d;
         const int base_blocks = (int)((ha.nnz + kThreads - 1) / kThreads);
         hipLaunchKernelGGL(k_hassemble, dim3((unsigned)(base_blocks + n_long)), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d, base_blocks);
-        if (n_prec_items()) {  // chain factors and the reciprocal Jacobi diagonal, one launch
+        if (n_prec_items() && refactor) {  // chain factors and the reciprocal Jacobi diagonal, one launch
             FactorArgs fa{};
             fa.work = prec_work.d; fa.chains = chainsH.d; fa.levels = levelsH.d; fa.Hval = Hm.val.d;
             fa.pos_diag = q_posd.d; fa.pos_sub = q_poss.d; fa.fac = q_fac.d; fa.work_mat = q_work.d; fa.skip = skip;
@@ -1594,16 +1598,22 @@ struct HipBackend {
         bt.skip = q_skip.d; bt.step = q_step.d;
         return bt;
     }
-    // one upload of the per-problem control block [step | tol2 | skip]
+    // one upload of the per-problem control block [step | tol2 | skip, reref, fskip]
+    //   reref: the problem's chain factors are recomputed in this Newton iteration (PolishArgs::reref);
+    //   fskip: ... are not (the skip flags of the factor kernels).  Both return to "no" after one upload.
     std::vector<double> c_step, c_tol2;
-    std::vector<int32_t> c_skip;
+    std::vector<int32_t> c_skip, c_reref;
     void upload_control() {
         const size_t c = c_skip.size();
+        if (c_reref.size() != c) c_reref.assign(c, 0);
         char* v = next_ring_slot(ctl.n * sizeof(double));
         std::memcpy(v, c_step.data(), c * sizeof(double));
         std::memcpy(v + c * sizeof(double), c_tol2.data(), c * sizeof(double));
-        std::memcpy(v + 2 * c * sizeof(double), c_skip.data(), c * sizeof(int32_t));
-        fetch_words((int32_t*)ctl.d, v, (int)(4 * c + c));
+        int32_t* w = (int32_t*)(v + 2 * c * sizeof(double));
+        std::memcpy(w, c_skip.data(), c * sizeof(int32_t));
+        for (size_t i = 0; i < c; ++i) { w[c + i] = c_reref[i]; w[2 * c + i] = c_reref[i] ? 0 : 1; }
+        fetch_words((int32_t*)ctl.d, v, (int)(4 * c + 3 * c));
+        std::fill(c_reref.begin(), c_reref.end(), 0);
     }
     void upload_skip(const std::vector<char>& live) {  // skip = !live
         for (size_t i = 0; i < live.size(); ++i) c_skip[i] = live[i] ? 0 : 1;
@@ -1628,13 +1638,17 @@ struct HipBackend {
         eval_seq = publish(q_pcgdone.d, d_gate_host, ((size_t)2 * H->count + 1) / 2);
     }
     unsigned long long eval_seq = 0;
+    std::vector<double> act_flips;  // per problem: cones whose activity differs from the last factorisation's (last evaluation)
     // after the synchronisation: F and |grad|_inf of the problems in `which`
     void newton_eval_collect(const std::vector<char>& which, std::vector<double>& F, std::vector<double>& gn) {
         const HostSystem& h = *H;
+        if ((int)act_flips.size() != h.count) act_flips.assign((size_t)h.count, 0.0);
         for (int p = 0; p < h.count; ++p) {
             if (!which[p]) continue;
             double f = 0.0, gmax = 0.0;
-            for (int b = h.cone_part_ptr[p]; b < h.cone_part_ptr[p + 1]; ++b) f += h_newton[b];
+            double fl = 0.0;
+            for (int b = h.cone_part_ptr[p]; b < h.cone_part_ptr[p + 1]; ++b) { f += h_newton[b]; fl += h_newton[n_fpart / 2 + b]; }
+            act_flips[p] = fl;
             for (int bl = h.rbG2.part_ptr[p]; bl < h.rbG2.part_ptr[p + 1]; ++bl) {
                 const double* o = h_dres + (size_t)bl * kPartStride;
                 gmax = (o[0] != o[0]) ? o[0] : std::max(gmax, o[0]);
@@ -1772,8 +1786,26 @@ struct HipBackend {
             // ONE upload of the control words serves the whole iteration: skip = !live for the Hessian,
             // the PCG solve and the first trial point; the PCG tolerances; unit step lengths
             for (int p = 0; p < count; ++p) { c_tol2[p] = eta[p] * eta[p]; c_step[p] = 1.0; }
+            // The chain factors of the preconditioner are recomputed only when the active set of a live problem has
+            // moved since they were last computed (act_flips, counted by the evaluation kernel): in the last Newton
+            // iterations the blocks of B change by the step alone and the factors of the previous iteration
+            // precondition as well (same PCG counts; k_factor + k_fac_round + k_deep_pack are 60-150 us a time).
+            static const double flip_tol = std::getenv("SCORE_REFACTOR_FLIPS") ? std::atof(std::getenv("SCORE_REFACTOR_FLIPS")) : 0.0;
+            // (decided problem by problem: what a problem computes never depends on its batch mates)
+            bool refactor = false;
+            c_reref.assign((size_t)count, 0);
+            for (int p = 0; p < count; ++p) {
+                c_reref[p] = live[p] && (it == 0 || flip_tol < 0.0 || act_flips[p] > flip_tol);
+                refactor = refactor || c_reref[p];
+            }
+            if (st.verbose) {
+                double mx = 0.0;
+                int nre = 0;
+                for (int p = 0; p < count; ++p) if (live[p]) { mx = std::max(mx, act_flips[p]); nre += c_reref[p]; }
+                std::fprintf(stderr, "[score] newton it %d: active-set flips since the last factorisation (max over live problems) %.0f -> %d problems refactor\n", it + 1, mx, nre);
+            }
             upload_skip(live);
-            newton_hessian(q_skip.d);  // (the matrix entries of a frozen problem are simply re-derived)
+            newton_hessian(q_fskip.d, refactor);  // (the matrix entries of a frozen problem are simply re-derived)
             newton_pcg_enqueue(live, eta, n_pcg, false);
             eta_prev = eta;
             bool control_stale = false;

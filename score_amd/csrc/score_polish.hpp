@@ -31,43 +31,15 @@ struct PolishArgs {
     double* Bbuf;         // T*T per cone
     double* fpart;        // per cone block: partial sum of the cone terms of F
     int64_t n_tot;
+    // active-set bookkeeping for the preconditioner (k_newton_cone_b): per cone, bit 0 = active when the chain
+    // factors of its problem were last computed, bit 1 = active at the last evaluation; flip_part[b] = cones of
+    // the block whose activity differs from bit 0.  The host refactors a problem only when its active set has
+    // moved (polish_lockstep) and says so in reref[prob]: the first evaluation after a factorisation then
+    // takes the previous evaluation's activity (the point the factors were built at) as the new reference.
+    int32_t* act;
+    double* flip_part;
+    const int32_t* reref;
 };
-
-// Per cone: t = b_tail - A_tail u, multiplier nu = -c max(0,|t|-theta) t/|t|, Hessian block.
-__global__ __launch_bounds__(kThreads) void k_newton_cone(PolishArgs a) {
-    __shared__ double red[8];
-    const int k = blockIdx.x * kThreads + threadIdx.x;
-    double phi = 0.0;
-    if (k < a.ncones) {
-        const int T = a.T;
-        const int r0 = a.cone_row[k];
-        double t[kPolishMaxTail];
-        double rho2 = 0.0;
-        for (int c = 0; c < T; ++c) {
-            const int r = r0 + 1 + c;
-            double acc = a.b[r];
-            for (int e = a.A_ptr[r]; e < a.A_ptr[r + 1]; ++e) acc -= a.A_val[e] * a.u[a.A_col[e]];
-            t[c] = acc;
-            rho2 += acc * acc;
-        }
-        const double rho = sqrt(rho2);
-        const double th = a.theta[k], ck = a.ck[k];
-        const double ex = rho > th ? rho - th : 0.0;
-        phi = 0.5 * ck * ex * ex;
-        const bool act = ex > 0.0 && rho > 0.0;
-        const double ir = act ? 1.0 / rho : 0.0;
-        a.nu[r0] = 0.0;
-        for (int c = 0; c < T; ++c) a.nu[r0 + 1 + c] = act ? -ck * ex * t[c] * ir : 0.0;
-        // B = c [ (1 - theta/rho)(I - uu') + uu' ]  on active cones, 0 otherwise
-        const double w1 = act ? ck * (1.0 - th * ir) : 0.0;
-        const double w2 = act ? ck * th * ir : 0.0;  // coefficient of uu' beyond w1: c - w1 = c*theta/rho
-        for (int c = 0; c < T; ++c)
-            for (int d = 0; d < T; ++d)
-                a.Bbuf[(size_t)k * T * T + c * T + d] = (c == d ? w1 : 0.0) + w2 * (t[c] * ir) * (t[d] * ir);
-    }
-    const double tot = block_sum(phi, red);
-    if (threadIdx.x == 0) a.fpart[blockIdx.x] = tot;
-}
 
 struct HAsmArgs {
     int64_t nnz;
@@ -527,12 +499,16 @@ struct BatchTables {
     const double* step;               // per problem
 };
 
+// Per cone: t = b_tail - A_tail u, multiplier nu = -c max(0,|t|-theta) t/|t|, Hessian block
+// B = c [ (1 - theta/rho)(I - uu') + uu' ] on active cones, 0 otherwise.
 __global__ __launch_bounds__(kThreads) void k_newton_cone_b(PolishArgs a, BatchTables bt) {
     __shared__ double red[8];
     const int b = blockIdx.x;
-    if (bt.skip[bt.cone_block_prob[b]]) return;
+    const int prob = bt.cone_block_prob[b];
+    if (bt.skip[prob]) return;
     const int k = bt.cone_block_first[b] + threadIdx.x;
-    double phi = 0.0;
+    const bool new_ref = a.reref[prob] != 0;
+    double phi = 0.0, flips = 0.0;
     if (k < bt.cone_block_first[b + 1]) {
         const int T = a.T;
         const int r0 = a.cone_row[k];
@@ -550,6 +526,12 @@ __global__ __launch_bounds__(kThreads) void k_newton_cone_b(PolishArgs a, BatchT
         const double ex = rho > th ? rho - th : 0.0;
         phi = 0.5 * ck * ex * ex;
         const bool act = ex > 0.0 && rho > 0.0;
+        {
+            const int32_t old = a.act[k];
+            const int32_t ref = new_ref ? (old >> 1) & 1 : old & 1;
+            flips = (ref != (int32_t)act) ? 1.0 : 0.0;
+            a.act[k] = ref | (act ? 2 : 0);
+        }
         const double ir = act ? 1.0 / rho : 0.0;
         a.nu[r0] = 0.0;
         for (int c = 0; c < T; ++c) a.nu[r0 + 1 + c] = act ? -ck * ex * t[c] * ir : 0.0;
@@ -559,8 +541,8 @@ __global__ __launch_bounds__(kThreads) void k_newton_cone_b(PolishArgs a, BatchT
             for (int d = 0; d < T; ++d)
                 a.Bbuf[(size_t)k * T * T + c * T + d] = (c == d ? w1 : 0.0) + w2 * (t[c] * ir) * (t[d] * ir);
     }
-    const double tot = block_sum(phi, red);
-    if (threadIdx.x == 0) a.fpart[b] = tot;
+    block_sum2(phi, flips, red);
+    if (threadIdx.x == 0) { a.fpart[b] = phi; a.flip_part[b] = flips; }
 }
 
 // out = u + step[prob] * delta on the rows of the live problems; partial g'delta per row block

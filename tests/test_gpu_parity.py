@@ -441,7 +441,7 @@ def test_lockstep_batch_polish_matches_individual_solves(hip_lib):
 
 @pytest.mark.parametrize("name", ["manhattan", "graph3d"])
 def test_newton_kernels_against_the_oracle(name, fixtures, hip_lib):
-    """Kernel-level parity of the semismooth-Newton polish: the gradient (k_newton_cone + k_spmv<GRAD>), the
+    """Kernel-level parity of the semismooth-Newton polish: the gradient (k_newton_cone_b + k_spmv<GRAD>), the
     generalised Hessian the device assembles (k_hassemble on the host-built pattern) and the chain
     factorisation (k_factor, applied through the chain kernel) are compared, entry by entry, with the
     oracle's ReducedProblem.grad_hess at the same point -- an ADMM iterate, far from the optimum, with a
