@@ -16,7 +16,7 @@ while len(qps) < 144:
         continue
     qps.append(assemble(fg, "SOCP").qp)
 for rep in range(2):
-    for wu in (10, 15, 20):
+    for wu in (4, 6, 8, 10, 15):
         tot = 0.0; out = []
         for qp in qps:
             s = ConicSolver(qp, dict(polish_warmup=wu)); o = s.solve()[0]; s.close()

@@ -180,9 +180,14 @@ struct Solver {
     int solve(double* x, double* y, double* s, score_info* out) {
         const double t0 = now_ms();
         reset();
+        auto mark = [&](const char* what) {
+            if (st.verbose) std::fprintf(stderr, "[score] solve timeline: %-28s t %.3f ms\n", what, now_ms() - t0);
+        };
+        mark("reset");
         bool all = false;
         // with the polish on, the first block is shorter: Newton is globally convergent, a rough
-        // ADMM iterate is all it needs (measured: 15 iterations beat 25 by ~8 % of the solve time)
+        // ADMM iterate is all it needs (measured: 6 iterations beat 15 by 9-13 % of the solve time on the
+        // BASELINE sizes and tie with 8-15 on 144 small random graphs; 15 had beaten 25 by ~8 %)
         const bool can_polish = st.polish && be.polish_available();
         while (!all && iters_done < st.max_iters) {
             int k = std::min(st.check_interval, st.max_iters - iters_done);
@@ -190,7 +195,9 @@ struct Solver {
             be.run(k);
             iters_done += k;
             cg_total += (int64_t)k * cg_now;
+            mark("ADMM block queued");
             all = check(true);
+            mark("residual test");
             if (!all && can_polish && iters_done >= next_polish) {
                 // Newton is globally convergent here (convex, line search), so by default it starts
                 // right after the first launch graph; polish_start can demand a closer ADMM iterate.
@@ -209,13 +216,16 @@ struct Solver {
                         for (int p = 0; p < H.count; ++p)
                             if (!done[p]) { infos[p].newton_iters += nit; infos[p].newton_cg_iters += ncg; }
                         if (!ran) break;
+                        mark("Newton polish");
                         all = check(false);
+                        mark("residual test");
                     }
                     next_polish = iters_done + 20 * st.check_interval;  // a failed attempt is retried later
                 }
             }
         }
         finish(x, y, s, out, t0);
+        mark("solution copied out");
         return 0;
     }
 
@@ -330,7 +340,7 @@ inline void default_settings(score_settings* s) {
     s->use_graph = 1;
     s->polish = 1;
     s->polish_start = 1e30;
-    s->polish_warmup = 15;
+    s->polish_warmup = 6;  // (measured round 3: 6-10 beat 15 now that a Newton iteration costs less; profiles/scripts/r03_warmup.py)
     s->verbose = 0;
     s->chain_split = 0;
     s->fac_fp32 = 1;

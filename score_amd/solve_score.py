@@ -280,7 +280,7 @@ def solve_problem_with_intermediate_iterates(
     """score/solve_score.py:89-116: one ``SolverResults`` per iteration cap.  The reference restarts
     Gurobi's barrier solver with BarIterLimit = 0, 1, 2, ... until it reports OPTIMAL; here ONE run of
     the product's default solver is paused along its own trajectory: every ``every`` ADMM iterations
-    during the warm-up (``polish_warmup`` iterations, 15 by default), then after every semismooth-Newton
+    during the warm-up (``polish_warmup`` iterations, 6 by default), then after every semismooth-Newton
     iteration of the polish.  Where the polish does not apply (the direct QCQP form, polish=0) the run
     continues with ADMM snapshots.  ``solved`` is the solver's own verdict (its three termination tests,
     the counterpart of ``model.status == GRB.OPTIMAL``, gurobi_utils.py:195); the list ends with the

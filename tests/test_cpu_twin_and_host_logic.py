@@ -97,7 +97,7 @@ def test_intermediate_iterates(twin_lib):
     its = solve_problem_with_intermediate_iterates(fg, "SOCP", every=25, lib_path=twin_lib)
     assert len(its) >= 2 and its[-1].solved
     iters = [r.info["iters"] for r in its]
-    assert iters == sorted(iters) and iters[0] == 15  # the warm-up (polish_warmup = 15) is one snapshot at every=25
+    assert iters == sorted(iters) and iters[0] == 6  # the warm-up (polish_warmup = 6) is one snapshot at every=25
     final = solve_score(fg, "SOCP", lib_path=twin_lib)
     for nm in final.poses:
         np.testing.assert_allclose(its[-1].poses[nm], final.poses[nm], atol=1e-4)

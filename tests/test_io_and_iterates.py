@@ -95,9 +95,10 @@ def test_intermediate_iterates_follow_the_solver(twin_lib):
     snapshots every `every` iterations, then every `every` more; `solved` is the solver's own status and
     the list ends with the first solved iterate, which is the optimum."""
     fg = graph_by_name("synth_a", {})
-    its = solve_problem_with_intermediate_iterates(fg, "SOCP", every=5, lib_path=twin_lib)
+    its = solve_problem_with_intermediate_iterates(fg, "SOCP", every=3, lib_path=twin_lib)
     counts = [r.info["iters"] for r in its]
-    assert counts == sorted(counts) and counts[:3] == [5, 10, 15] and len(set(counts)) == len(counts)
+    # (polish_warmup = 6 by default: two warm-up snapshots, then ADMM goes on in steps of `every`)
+    assert counts == sorted(counts) and counts[:3] == [3, 6, 9] and len(set(counts)) == len(counts)
     assert [r.solved for r in its[:-1]] == [False] * (len(its) - 1) and its[-1].solved
     assert all(r.info["status"] in (1, 2) for r in its)
     res_p = [r.info["res_pri"] for r in its]
@@ -105,5 +106,5 @@ def test_intermediate_iterates_follow_the_solver(twin_lib):
     compare_with_golden(its[-1], load_golden("synth_a"))
     ref = solve_score(fg, "SOCP", lib_path=twin_lib)
     # the same iteration, paused: the first solved snapshot comes no later than solve()'s own check
-    # (solve() tests every 25 iterations, the snapshots every 5)
-    assert ref.solved and its[-1].info["iters"] <= ref.info["iters"] + 5
+    # (solve() tests every 25 iterations, the snapshots every 3)
+    assert ref.solved and its[-1].info["iters"] <= ref.info["iters"] + 3
