@@ -438,6 +438,8 @@ struct HipBackend {
     DevBuf<ChainDesc> chains, chainsH;         // chainsH / levelsH: the same chains with factors of their own (Newton matrix)
     DevBuf<ChainLevelDesc> levels, levelsH;
     DevBuf<PrecRecord> prec_rec, prec_recH;    // one record per work item: work + chain + level table (k_prec_pre)
+    static constexpr int64_t kHelpEntries = (int64_t)kPrecThreads * kPrecChunk;  // vector entries per update helper
+    int n_help = 0;                            // update-helper records appended to prec_rec / prec_recH
     DevBuf<int32_t> vb_first, vb_end, vb_prob; // blocks of <= 256 vector entries per problem (k_xupdate)
     int n_vblocks = 0;
     DevBuf<double> xtu, xy, s, r, z, p, p2, w, kx, step;
@@ -645,8 +647,27 @@ struct HipBackend {
                     rec[w].ch = cs[(size_t)rec[w].wk.index];
                     for (int l = 0; l < std::min<int>(rec[w].ch.n_levels, kRecLevels); ++l) rec[w].lv[l] = ls[(size_t)rec[w].ch.level_begin + l];
                 }
+                // update helpers (PrecArgs::split_update): a single problem's chains occupy a fraction of the CUs for the
+                // whole launch, and a third of what each of them pulls through its CU is the xt / kx update.  Extra
+                // records after the problem's own hand that update, slice by slice, to workgroups on the idle CUs.
+                // (A batch fills the chip with chains: there the update stays fused.)
+                PrecRecord hr;
+                std::memset((void*)&hr, 0, sizeof(hr));
+                for (int i = 0; i < n_help; ++i) {
+                    const int64_t e0 = (int64_t)i * kHelpEntries;
+                    hr.wk = PrecWork{2, (int32_t)e0, (int32_t)std::min<int64_t>(kHelpEntries, h.n_tot - e0), 0};
+                    rec.push_back(hr);
+                }
                 return rec;
             };
+            {
+                int cus = 0;
+                HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st.device));
+                const int want = (int)((h.n_tot + kHelpEntries - 1) / kHelpEntries);
+                const bool on = h.count == 1 && std::getenv("SCORE_NO_UPDATE_HELPERS") == nullptr &&
+                                (int)h.prec_work.size() + want <= cus;  // the whole launch resident at once
+                n_help = on ? want : 0;
+            }
             prec_rec.upload(build(h.chains, h.levels));
             if (h.rep > 1 && st.polish) prec_recH.upload(build(h.chainsH, h.levelsH));
             else prec_recH.view(prec_rec.d, prec_rec.n);
@@ -1007,7 +1028,12 @@ struct HipBackend {
         else launch_prec_bs<4, MODE>(pa, slot, use_fac32);
     }
     template <int BS, int MODE>
-    void launch_prec_bs(const PrecArgs& pa, int slot, bool use_fac32) {
+    void launch_prec_bs(const PrecArgs& pa_in, int slot, bool use_fac32) {
+        // (the k_prec_pre launches of a STEP carry the update helpers of a single-problem handle, see the records)
+        PrecArgs pa = pa_in;
+        const bool help = MODE == PREC_STEP && n_help > 0 && pa.rec != nullptr && !pa.debug_skip;
+        const int n_prec = this->n_prec + (help ? n_help : 0);
+        pa.split_update = help ? 1 : 0;
         // k_prec_pre (level 0 in registers, coarse levels in LDS) when every chain fits; 4 x 4 blocks (3-D problems) only
         // with the 4-byte factor stream (score_settings.fac_fp32), otherwise the streaming kernel
         if constexpr (BS <= 3) {
@@ -1026,8 +1052,9 @@ struct HipBackend {
                 return;
             }
         }
-        if (prec_lds0) launch_on_stream((k_prec<BS, 3, MODE, true>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa);
-        else launch_on_stream((k_prec<BS, 3, MODE, false>), dim3(n_prec), dim3(kPrecThreads), prec_lds, slot, pa);
+        pa.split_update = 0;  // (the streaming kernel reads the plain work list: no helpers)
+        if (prec_lds0) launch_on_stream((k_prec<BS, 3, MODE, true>), dim3(this->n_prec), dim3(kPrecThreads), prec_lds, slot, pa);
+        else launch_on_stream((k_prec<BS, 3, MODE, false>), dim3(this->n_prec), dim3(kPrecThreads), prec_lds, slot, pa);
     }
 
     // The attribute is per kernel function, i.e. shared by every handle of the process: always

@@ -487,6 +487,8 @@ struct PrecArgs {
     double* rz_out;        // one partial per work item
     unsigned long long* tstamp;  // see KernelStamp
     int debug_skip;        // timing experiments only: 1 run, 2 separator, 4 back-subst, 8 head, 16 tail
+    int split_update;      // STEP of k_prec_pre: xt += alpha p, kx += alpha w are done by the helper items (kind 2) of this
+                           // launch, on CUs the chains leave idle, instead of by the chain / Jacobi workgroups themselves
     // Device-side termination of a PCG solve (the Newton polish; null in the ADMM loop, whose PCG
     // count is fixed).  The first STEP of a solve (gate_first) turns r'z_0 into the problem's
     // threshold tol2[prob] * r'z_0; every later STEP compares the r'z it is about to use with it
@@ -584,15 +586,21 @@ __device__ __forceinline__ double prec_jacobi_item(const PrecArgs& a, const Prec
         for (int u = 0; u < kPrecChunk; ++u) {
             rv[u] = a.r_in[cols[u]];
             dv[u] = a.dinv[min(base + u * kPrecThreads, e_end - 1)];
-            if (MODE == PREC_STEP) { pv[u] = a.p[cols[u]]; wv[u] = a.w[cols[u]]; xv[u] = a.xt_zero ? 0.0 : a.xt[cols[u]]; kv[u] = a.kx[cols[u]]; }
+            if (MODE == PREC_STEP) {
+                wv[u] = a.w[cols[u]];
+                if (!a.split_update) { pv[u] = a.p[cols[u]]; xv[u] = a.xt_zero ? 0.0 : a.xt[cols[u]]; kv[u] = a.kx[cols[u]]; }
+                else { pv[u] = 0.0; xv[u] = 0.0; kv[u] = 0.0; }
+            }
         }
 #pragma unroll
         for (int u = 0; u < kPrecChunk; ++u) {
             if (base + u * kPrecThreads < e_end) {
                 double r_ = rv[u];
                 if (MODE == PREC_STEP) {
-                    a.xt[cols[u]] = xv[u] + alpha * pv[u];
-                    a.kx[cols[u]] = kv[u] + alpha * wv[u];
+                    if (!a.split_update) {
+                        a.xt[cols[u]] = xv[u] + alpha * pv[u];
+                        a.kx[cols[u]] = kv[u] + alpha * wv[u];
+                    }
                     r_ -= alpha * wv[u];
                     a.r[cols[u]] = r_;
                 }
@@ -1016,6 +1024,32 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         for (int i = k0 + t; i < k1; i += kPrecThreads) acc_pw += a.pw_part[i];
     }
     double local = 0.0;
+    if (wk.kind == 2) {
+        // update helper (STEP with split_update; appended after the problem's own items, so never the gate's lead and
+        // outside the r'z partials): entries [index, index + count) of xt and kx.  alpha and the gate's verdict are
+        // derived from the same partial sums in the same order as in the chain workgroups -- the same bits.
+        if (MODE != PREC_STEP || dn) return;
+        const double gref = (a.gate_flag && !a.gate_first) ? a.gate_ref[prob] : 0.0;
+        const int e_end = wk.index + wk.count;
+        int idx[kPrecChunk];
+        double pv[kPrecChunk], wv[kPrecChunk], xv[kPrecChunk], kv[kPrecChunk];
+#pragma unroll
+        for (int u = 0; u < kPrecChunk; ++u) {
+            idx[u] = min(wk.index + t + u * kPrecThreads, e_end - 1);
+            pv[u] = a.p[idx[u]]; wv[u] = a.w[idx[u]]; xv[u] = a.xt_zero ? 0.0 : a.xt[idx[u]]; kv[u] = a.kx[idx[u]];
+        }
+        block_sum2_n<kPrecWaves>(acc_rz, acc_pw, red);
+        const double alpha = acc_pw > 0.0 ? acc_rz / acc_pw : 0.0;
+        if (a.gate_flag && (a.gate_first ? !(acc_rz > 0.0) : !(acc_rz > gref))) return;  // (pcg_gate's test, without its writes)
+#pragma unroll
+        for (int u = 0; u < kPrecChunk; ++u) {
+            if (wk.index + t + u * kPrecThreads < e_end) {
+                a.xt[idx[u]] = xv[u] + alpha * pv[u];
+                a.kx[idx[u]] = kv[u] + alpha * wv[u];
+            }
+        }
+        return;
+    }
     if (wk.kind == 1) {
         if (dn) return;
         bool stop;
@@ -1281,7 +1315,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         using H1 = std::integral_constant<int, 1>;
         // (4 x 4 blocks: the register file holds the 128-entry factor tile; the update waits until the tile is dead)
         constexpr bool kLateUpdate = (BS >= 4);
-        if (MODE == PREC_STEP && !kLateUpdate) upd_load(H0());
+        const bool own_update = (MODE == PREC_STEP) && !a.split_update;  // (uniform)
+        if (own_update && !kLateUpdate) upd_load(H0());
         // ---- coarser levels: factors and vectors in LDS.  Lanes 256..511 do this work: their
         //      register tile G is free (the staging is over), so each phase first pulls all its
         //      blocks from LDS into G and only then starts the dependent arithmetic ----
@@ -1395,7 +1430,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             }
             lds_barrier();
         }
-        if (MODE == PREC_STEP && !kLateUpdate) { upd_store(H0()); upd_load(H1()); }
+        if (own_update && !kLateUpdate) { upd_store(H0()); upd_load(H1()); }
         // ---- back-substitution of level 0.  No spikes are stored for this level: with the run
         //      blocks still in registers, x_run = y_run - T_run^-1 (e_first Cr_left' x_left +
         //      e_last Cl_right' x_right) costs one more run solve and no memory traffic ----
@@ -1449,8 +1484,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             lds_barrier();
         }
         // ---- write z, p (INIT), the rest of the step's xt / kx, and accumulate r'z ----
-        if (MODE == PREC_STEP && !kLateUpdate) upd_store(H1());
-        if (MODE == PREC_STEP && kLateUpdate) { upd_load(H0()); upd_store(H0()); upd_load(H1()); upd_store(H1()); }
+        if (own_update && !kLateUpdate) upd_store(H1());
+        if (own_update && kLateUpdate) { upd_load(H0()); upd_store(H0()); upd_load(H1()); upd_store(H1()); }
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             const int idx = t + u * kPrecThreads;

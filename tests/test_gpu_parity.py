@@ -68,6 +68,32 @@ def test_iterates_match_cpu_twin(name, radix, cg, fp32, fixtures, hip_lib, twin_
         gpu.close(); cpu.close()
 
 
+@pytest.mark.parametrize("name", ["manhattan", "graph3d"])
+def test_update_helpers_change_no_bit(name, fixtures, hip_lib, monkeypatch):
+    """A single-problem handle hands the PCG step's xt += alpha p, kx += alpha w to helper work items of the chain
+    kernel's launch (PrecArgs::split_update: workgroups on the CUs the chains leave idle) instead of doing them in
+    the chain / Jacobi workgroups.  Same alpha from the same partial sums, same operations: every internal vector,
+    the ADMM trajectory and the polished solution are bit-identical with the helpers switched off."""
+    _hip_only(hip_lib)
+    qp = assemble(graph_by_name(name, fixtures), "SOCP").qp
+    st = dict(adaptive_cg=0, check_interval=5)
+    monkeypatch.delenv("SCORE_NO_UPDATE_HELPERS", raising=False)
+    with_h = ConicSolver(qp, st, lib_path=hip_lib)
+    monkeypatch.setenv("SCORE_NO_UPDATE_HELPERS", "1")
+    without = ConicSolver(qp, st, lib_path=hip_lib)
+    monkeypatch.delenv("SCORE_NO_UPDATE_HELPERS", raising=False)
+    with_h.reset(); without.reset()
+    for k in (1, 4, 11):
+        a, b = with_h.steps(k)[0], without.steps(k)[0]
+        for v in VECS:
+            assert np.array_equal(with_h.debug_get(v), without.debug_get(v)), (v, k)
+        assert np.array_equal(a.x, b.x)
+    a, b = with_h.solve()[0], without.solve()[0]
+    assert a.solved and b.solved and a.info["newton_iters"] > 0
+    assert a.info["newton_cg_iters"] == b.info["newton_cg_iters"] and np.array_equal(a.x, b.x)
+    with_h.close(); without.close()
+
+
 @pytest.mark.parametrize("name,relax,rep", [("manhattan", "SOCP", 2), ("graph3d", "SOCP", 3), ("synth_d", "QCQP", 2), ("synth_b", "SOCP", 2)])
 def test_replicated_kernels_match_the_general_ones(name, relax, rep, fixtures, hip_lib, twin_lib, monkeypatch):
     """K = I_d (x) K_row (+ tail) for every SCORE model (the cost couples one row of the pose matrices at a time,
