@@ -1413,6 +1413,14 @@ struct HipBackend {
             if (out && len > 0) std::memcpy(out, tmp.data(), sizeof(double) * (size_t)std::min(len, sz));
             return sz;
         }
+        else if (nm == "Kcol" || nm == "Kptr") {  // pattern of the K the kernels stream (a replicated problem: replica 0 + tail rows)
+            std::vector<double> tmp;
+            if (nm == "Kcol") tmp.assign(h.K.col.begin(), h.K.col.end());
+            else tmp.assign(h.K.ptr.begin(), h.K.ptr.end());
+            sz = (int64_t)tmp.size();
+            if (out && len > 0) std::memcpy(out, tmp.data(), sizeof(double) * (size_t)std::min(len, sz));
+            return sz;
+        }
         else if (nm == "chain_id_of_col") {
             std::vector<double> tmp(h.n_tot, -1.0);
             for (size_t ci = 0; ci < h.chains.size(); ++ci)

@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 import pytest
+import scipy.sparse as sp
 
 from conftest import GOLDEN_NAMES, compare_residuals_with_golden, compare_with_golden, graph_by_name, load_golden
 from oracle import score_oracle as so
@@ -92,6 +93,45 @@ def test_update_helpers_change_no_bit(name, fixtures, hip_lib, monkeypatch):
     assert a.solved and b.solved and a.info["newton_iters"] > 0
     assert a.info["newton_cg_iters"] == b.info["newton_cg_iters"] and np.array_equal(a.x, b.x)
     with_h.close(); without.close()
+
+@pytest.mark.parametrize("name,relax", [("manhattan", "SOCP"), ("graph3d", "SOCP"), ("synth_d", "QCQP"), ("synth_b", "SOCP"), ("prior2d", "SOCP")])
+def test_device_setup_against_scipy(name, relax, fixtures, hip_lib):
+    """The setup the kernels run on, checked without any of the product's (or the twin's) host code: the scales D, E
+    and the stored KKT operator come back from the handle; SciPy rebuilds K = D P D + sigma I + rho (E A D)'(E A D)
+    from the problem data alone.  The stored rows (replica 0 of every pose row / landmark coordinate + the tail)
+    must hold exactly SciPy's rows, and SciPy's K must be I_d (x) K_row + tail -- the structure the replicated
+    kernels rely on (gurobi_utils.py:504-526: the cost couples one row of [R | t] at a time; :345-352: only the
+    cones couple rows, and K sees them through A'A, which is per coordinate)."""
+    _hip_only(hip_lib)
+    qp = assemble(graph_by_name(name, fixtures), relax).qp
+    rho, sigma = 0.37, 1e-6
+    sol = ConicSolver(qp, dict(rho=rho, sigma=sigma, adaptive_rho=0), lib_path=hip_lib)
+    D, E = sol.debug_get("D"), sol.debug_get("E")
+    Kval, Kcol, Kptr = sol.debug_get("Kval"), sol.debug_get("Kcol").astype(np.int64), sol.debug_get("Kptr").astype(np.int64)
+    rep, nr = int(sol.debug_get("rep")[0]), int(qp.rep_n)
+    sol.close()
+    assert rep == qp.rep_d and D.min() > 0 and E.min() > 0
+    n = qp.n
+    Ps = sp.diags(D) @ qp.P @ sp.diags(D)
+    As = sp.diags(E) @ qp.A @ sp.diags(D)
+    K = (Ps + sigma * sp.identity(n) + rho * (As.T @ As)).tocsr()
+    stored = sp.csr_matrix((Kval[: Kptr[-1]], Kcol[: Kptr[-1]], Kptr), shape=(n, n))
+    scale = abs(K).max()
+    # rows the handle stores: replica 0 and the tail; the other replicas' rows are empty there
+    rows = np.r_[np.arange(nr), np.arange(rep * nr, n)]
+    assert abs(stored[rows] - K[rows]).max() <= 1e-12 * scale
+    others = np.arange(nr, rep * nr)
+    assert stored[others].nnz == 0
+    # ... and what they would hold is replica 0's block again
+    Krow = K[:nr, :nr]
+    for k in range(1, rep):
+        blk = K[k * nr : (k + 1) * nr]
+        assert abs(blk[:, k * nr : (k + 1) * nr] - Krow).max() <= 1e-12 * scale
+        off = blk.copy().tolil()
+        off[:, k * nr : (k + 1) * nr] = 0
+        assert abs(off.tocsr()).max() == 0.0
+    assert abs(K[:nr, nr:]).max() == 0.0
+
 
 
 @pytest.mark.parametrize("name,relax,rep", [("manhattan", "SOCP", 2), ("graph3d", "SOCP", 3), ("synth_d", "QCQP", 2), ("synth_b", "SOCP", 2)])
