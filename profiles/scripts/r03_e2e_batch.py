@@ -27,13 +27,13 @@ for rep in range(3):
     _, t_close, c_close = timed(solver.close)
     print(f"group of 16, one thread, wall ms (CPU ms of the whole process): assemble {t_asm:.1f} ({c_asm:.1f})  create {t_create:.1f} ({c_create:.1f})  "
           f"solve {t_solve:.1f} ({c_solve:.1f})  extract {t_extract:.1f} ({c_extract:.1f})  close {t_close:.1f} ({c_close:.1f})", flush=True)
-for workers in (1, 4, 8):
+for workers, gsz in ((1, None), (4, None), (8, None), (8, 16), (6, 11), (12, 8), (16, 4)):
     ts = []
     c0 = time.process_time()
     for _ in range(6):
-        t = time.perf_counter(); r = ss.solve_score_batch(flat, "SOCP", solver_settings=st, workers=workers); ts.append(time.perf_counter() - t)
+        t = time.perf_counter(); r = ss.solve_score_batch(flat, "SOCP", solver_settings=st, workers=workers, group_size=gsz); ts.append(time.perf_counter() - t)
     cpu = time.process_time() - c0
-    print(f"64 trials, workers {workers}: min {1e3*min(ts):.1f} ms = {64/min(ts):.0f} problems/s, median {1e3*sorted(ts)[3]:.1f} ms = {64/sorted(ts)[3]:.0f} problems/s, "
+    print(f"64 trials, workers {workers}, group size {gsz}: min {1e3*min(ts):.1f} ms = {64/min(ts):.0f} problems/s, median {1e3*sorted(ts)[3]:.1f} ms = {64/sorted(ts)[3]:.0f} problems/s, "
           f"solved {sum(x.solved for x in r)}; CPU time / wall time = {cpu/sum(ts):.1f} ({1e3*cpu/6/64:.1f} core-ms per trial)", flush=True)
 pr = cProfile.Profile(); pr.enable()
 ss.solve_score_batch(flat[:16], "SOCP", solver_settings=st)

@@ -294,7 +294,7 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
             }
             pc[t] = std::move(lc);
             pv[t] = std::move(lv);
-        });
+        }, T);
         pt.mark("assemble:   rows (parallel)");
         for (int64_t i = 0; i < n; ++i) out.P_ptr[(size_t)i + 1] += out.P_ptr[(size_t)i];
         out.P_col.resize((size_t)out.P_ptr[(size_t)n]);

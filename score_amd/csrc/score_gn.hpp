@@ -436,7 +436,7 @@ inline void gn_build(const score_graph& g, GnProblem& P) {
             W.row_len.push_back(nent);
         }
         parts[(size_t)t] = std::move(W);
-    });
+    }, T);
     {
         std::vector<size_t> eoff(parts.size() + 1, 0), soff(parts.size() + 1, 0);
         for (size_t k = 0; k < parts.size(); ++k) {

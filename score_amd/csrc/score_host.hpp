@@ -78,33 +78,24 @@ inline int host_threads() {
     return n;
 }
 
-// How many threads a parallel region opened by THIS thread may use.  Handles are created concurrently
-// (the lock-step groups of solve_score_batch, one host thread each; the polish structures of a handle on a
-// thread of their own): every such builder opens a BuildScope, which fixes its width for the duration --
-// host_threads() shared between the builders active at that moment -- so that the machine's thread budget
-// is not multiplied by the number of callers.  The width is constant inside a scope (parallel_parts() and the
-// region that follows must agree); a region opened from inside a part runs serially.
+// The thread budget.  Handles are created concurrently (the lock-step groups of solve_score_batch, one host thread
+// each; the polish structures of a handle on a thread of their own; model construction on a pool): every such
+// builder opens a BuildScope for its duration, and every parallel region takes, at the moment it starts, what is
+// free -- host_threads() minus the builders' own threads minus the extra threads other regions are running -- and at
+// least its caller.  A builder in a serial phase leaves its share to the others; the machine's thread budget is not
+// multiplied by the number of callers.  A region opened from inside a part runs serially.  Where the number of parts
+// is planned ahead (parallel_parts) the region is started with that number (the `parts` argument).
 inline std::atomic<int>& active_builders() {
     static std::atomic<int> n{0};
     return n;
 }
-inline int& tl_region_width() {
-    static thread_local int w = 0;  // 0 = no scope: the full width
-    return w;
+inline std::atomic<int>& extra_threads_busy() {
+    static std::atomic<int> n{0};
+    return n;
 }
 struct BuildScope {
-    int saved;
-    bool counted;
-    BuildScope() : saved(tl_region_width()), counted(tl_region_width() == 0) {
-        if (!counted) return;  // nested scope on the same thread: keep the outer width
-        const int active = active_builders().fetch_add(1, std::memory_order_acq_rel) + 1;
-        tl_region_width() = std::max(1, host_threads() / std::max(1, active));
-    }
-    ~BuildScope() {
-        if (!counted) return;
-        active_builders().fetch_sub(1, std::memory_order_acq_rel);
-        tl_region_width() = saved;
-    }
+    BuildScope() { active_builders().fetch_add(1, std::memory_order_acq_rel); }
+    ~BuildScope() { active_builders().fetch_sub(1, std::memory_order_acq_rel); }
     BuildScope(const BuildScope&) = delete;
     BuildScope& operator=(const BuildScope&) = delete;
 };
@@ -210,8 +201,9 @@ inline bool& tl_in_parallel_region() {
 }
 inline int region_width() {
     if (tl_in_parallel_region()) return 1;
-    const int w = tl_region_width();
-    return w > 0 ? w : host_threads();
+    const int callers = std::max(1, active_builders().load(std::memory_order_acquire));
+    const int free_extra = host_threads() - callers - extra_threads_busy().load(std::memory_order_acquire);
+    return 1 + std::max(0, free_extra);
 }
 
 // fn(part, begin, end) for part = 0..T-1 over the boundaries `bound` (T + 1 entries), all parts concurrently
@@ -229,15 +221,20 @@ inline void run_parts(const std::vector<int64_t>& bound, F&& fn) {
         try { fn(t, bound[(size_t)t], bound[(size_t)t + 1]); } catch (...) { err[(size_t)t] = std::current_exception(); }
         mine = was;
     };
+    struct Busy {  // the extra threads of this region, for the budget of the others
+        int n;
+        explicit Busy(int k) : n(k) { extra_threads_busy().fetch_add(n, std::memory_order_acq_rel); }
+        ~Busy() { extra_threads_busy().fetch_sub(n, std::memory_order_acq_rel); }
+    } busy(T - 1);
+    bool ran = false;
     if (!nested) {
         TeamLease lease;
         if (lease.team && T - 1 <= (int)lease.team->workers.size()) {
             lease.team->run(T, body);
-            for (auto& e : err) if (e) std::rethrow_exception(e);
-            return;
+            ran = true;
         }
     }
-    {
+    if (!ran) {
         std::vector<std::thread> th;
         for (int t = 1; t < T; ++t) th.emplace_back([&body, t] { body(t); });
         body(0);
@@ -247,8 +244,8 @@ inline void run_parts(const std::vector<int64_t>& bound, F&& fn) {
 }
 
 template <class F>
-inline void parallel_ranges(int64_t n, int64_t min_per_thread, F&& fn) {  // fn(part, begin, end)
-    const int T = (int)std::min<int64_t>(region_width(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
+inline void parallel_ranges(int64_t n, int64_t min_per_thread, F&& fn, int parts = 0) {  // fn(part, begin, end)
+    const int T = parts > 0 ? parts : (int)std::min<int64_t>(region_width(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
     if (T <= 1) { fn(0, (int64_t)0, n); return; }
     std::vector<int64_t> bound((size_t)T + 1);
     for (int t = 0; t <= T; ++t) bound[(size_t)t] = n * t / T;
@@ -258,8 +255,8 @@ inline void parallel_ranges(int64_t n, int64_t min_per_thread, F&& fn) {  // fn(
 // (weight(i) >= 0: the work of index i).  Parts stay contiguous and ordered; a few very heavy indices
 // (a landmark seen by thousands of ranges) no longer land in one part.  fn(part, begin, end).
 template <class W, class F>
-inline void parallel_ranges_balanced(int64_t n, int64_t min_per_thread, W&& weight, F&& fn) {
-    const int T = (int)std::min<int64_t>(region_width(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
+inline void parallel_ranges_balanced(int64_t n, int64_t min_per_thread, W&& weight, F&& fn, int parts = 0) {
+    const int T = parts > 0 ? parts : (int)std::min<int64_t>(region_width(), std::max<int64_t>(1, n / std::max<int64_t>(1, min_per_thread)));
     if (T <= 1) { fn(0, (int64_t)0, n); return; }
     std::vector<double> pre((size_t)n + 1, 0.0);
     for (int64_t i = 0; i < n; ++i) pre[(size_t)i + 1] = pre[(size_t)i] + 1.0 + (double)weight(i);
@@ -921,7 +918,7 @@ inline void ruiz_scale(const score_problem& p, int iters, ProblemScaled& out, in
     };
     const bool offloaded = iters > 0 && offload && offload->passes(p, iters, rep, nr, atp, out.atpos, out.arow, gstart, D, E);
     if (iters > 0 && !offloaded)
-        parallel_ranges_balanced(n_act, 4096, col_weight, [&](int t, int64_t a0, int64_t a1) {
+        parallel_ranges_balanced(n_act, 4096, col_weight, [&, T](int t, int64_t a0, int64_t a1) {
             const int64_t g0 = ngroups * t / T, g1 = ngroups * (t + 1) / T;
             for (int it = 0; it < iters; ++it) {
                 for (int64_t a = a0; a < a1; ++a) {
@@ -956,7 +953,7 @@ inline void ruiz_scale(const score_problem& p, int iters, ProblemScaled& out, in
                     for (int r = gstart[(size_t)g]; r < gstart[(size_t)g + 1]; ++r) E[r] *= e[(size_t)g];
                 bar.wait();  // D, E updated: the next pass reads them
             }
-        });
+        }, T);
     phase_mark(pt, "  ruiz: passes");
     // the equilibrated values, once
     out.P.val.resize((size_t)nnzP);
@@ -1178,7 +1175,8 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
     // one sweep: every thread merges its rows into its own buffers (reserved for the worst case, so
     // they never re-allocate), the row lengths are prefix-summed, the buffers copied into place
     struct KPart { std::vector<int32_t> col; std::vector<double> k0, k1; int64_t i0 = 0, i1 = 0; };
-    std::vector<KPart> kparts(parallel_parts(n, 8192));
+    const int k_parts = parallel_parts(n, 8192);
+    std::vector<KPart> kparts((size_t)k_parts);
     // (replicated problems: K holds the rows of replica 0 and of the tail only, see HostSystem::rep)
     auto stored = [&](int64_t i) { return H.stored_row(pi, i); };
     auto k_row_weight = [&](int64_t i) {  // entries gathered for row i; long rows cost n log n in the sort
@@ -1214,7 +1212,7 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
             H.K.ptr[k_row0 + 1 + i] = cnt;
         }
         kparts[t] = std::move(Q);
-    });
+    }, k_parts);
     pt.mark("  append: K rows");
     for (int i = 0; i < n; ++i) H.K.ptr[k_row0 + 1 + i] += H.K.ptr[k_row0 + i];
     const size_t k_end = (size_t)H.K.ptr[k_row0 + n];

@@ -88,7 +88,8 @@ inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = fals
         std::vector<int32_t> col, row_len, ent_len, ccone, cab;
         std::vector<double> pon, ccoef;
     };
-    std::vector<Part> parts(parallel_parts(n, 8192));
+    const int n_parts = parallel_parts(n, 8192);
+    std::vector<Part> parts((size_t)n_parts);
     auto h_row_weight = [&](int64_t i) {  // contributions gathered for row i (sorted: long rows cost n log n)
         const double g = (double)(H.g2_split[i] - H.G2.ptr[i]) + 2.0 * T * (double)(H.G2.ptr[i + 1] - H.g2_split[i]);
         return g > 64.0 ? 4.0 * g : g;
@@ -153,7 +154,7 @@ inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = fals
             W.row_len.push_back(nent);
         }
         parts[t] = std::move(W);
-    });
+    }, n_parts);
     pt.mark("    polish: rows");
     Q.Hm.nrows = Q.Hm.ncols = n;
     Q.Hm.ptr.assign(1, 0);

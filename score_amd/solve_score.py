@@ -143,7 +143,7 @@ def solve_score(
 def solve_score_batch(
     datas: Sequence, relaxation_type: str = QCQP_RELAXATION, qcqp_mode: str = "via_socp",
     solver_settings: Optional[dict] = None, lib_path: Optional[str] = None, lockstep: Optional[bool] = None,
-    workers: int = 4, assembler: str = "native", _models: Optional[list] = None,
+    workers: int = 4, assembler: str = "native", _models: Optional[list] = None, group_size: Optional[int] = None,
 ) -> List[compat.SolverResults]:
     """Independent factor graphs on one GPU.
 
@@ -154,7 +154,8 @@ def solve_score_batch(
     driven from a pool of ``workers`` host threads.  Default: lock-step groups of up to 16 graphs,
     one group per worker thread, so that host-side setup (``score_create``) and the kernels of
     different groups overlap (measured on 64 four-robot trials: 2490 problems/s in groups of 16
-    on 4 threads, 770 problems/s with one handle per graph)."""
+    on 4 threads, 770 problems/s with one handle per graph).  ``group_size`` overrides the group length
+    (default: the graphs spread evenly over the workers, at most 16 per group)."""
     check_valid_relaxation(relaxation_type)
     if len(datas) == 0:
         return []
@@ -170,7 +171,7 @@ def solve_score_batch(
         # a lock-step handle needs one block size (2-D and 3-D graphs never share a group); within a
         # dimension, graphs of similar size share a group: it runs as long as its slowest member
         chunks = []
-        group = max(1, min(16, -(-len(datas) // max(1, workers))))
+        group = max(1, min(16, -(-len(datas) // max(1, workers)))) if group_size is None else max(1, int(group_size))
         for dim in sorted({int(datas[i].dimension) for i in order}):
             sub = sorted((i for i in order if int(datas[i].dimension) == dim), key=size_of)
             chunks += [sub[i : i + group] for i in range(0, len(sub), group)]
