@@ -1078,15 +1078,26 @@ struct HipBackend {
     }
 
     // SpMV launch: matrices of a replicated problem (K, G1) run with rep right-hand sides per stored row
+    // XCD-aware tile order (SpmvArgs::xcd_chunk): returns the grid size.  Measured: KKT SpMV of a 16-problem batch
+    // 48.0 -> 45.6 us (3.06 -> 3.23 TB/s), single problem 8.2 -> 7.8 us; kpb and rhs gain 2-3 %.
+    bool xcd_spmv = std::getenv("SCORE_NO_XCD_SPMV") == nullptr;
+    unsigned xcd_grid(SpmvArgs& a, int nblocks) const {
+        if (!xcd_spmv || nblocks < 16) { a.xcd_chunk = 0; a.n_tiles = nblocks; return (unsigned)nblocks; }
+        a.xcd_chunk = (nblocks + 7) / 8;
+        a.n_tiles = nblocks;
+        return (unsigned)(8 * a.xcd_chunk);
+    }
     template <int MODE>
-    void launch_spmv(const CsrBufs& M, const SpmvArgs& a, int slot = -1) {
+    void launch_spmv(const CsrBufs& M, const SpmvArgs& a_in, int slot = -1) {
         static_assert(MODE == MODE_RHS || MODE == MODE_KP || MODE == MODE_KPB, "the residual / gradient modes run on plain rows (G2, H)");
+        SpmvArgs a = a_in;
+        const unsigned grid = xcd_grid(a, M.nblocks);
         const bool half = (M.unroll == kUnroll / 2);
-        if (M.rep == 2 && half) { launch_on_stream(k_spmv<MODE, 2, kUnroll / 2>, dim3(M.nblocks), dim3(kThreads), 0, slot, a); return; }
-        if (M.rep == 3 && half) { launch_on_stream(k_spmv<MODE, 3, kUnroll / 2>, dim3(M.nblocks), dim3(kThreads), 0, slot, a); return; }
-        if (M.rep == 2) { launch_on_stream(k_spmv<MODE, 2>, dim3(M.nblocks), dim3(kThreads), 0, slot, a); return; }
-        if (M.rep == 3) { launch_on_stream(k_spmv<MODE, 3>, dim3(M.nblocks), dim3(kThreads), 0, slot, a); return; }
-        launch_on_stream(k_spmv<MODE, 1>, dim3(M.nblocks), dim3(kThreads), 0, slot, a);
+        if (M.rep == 2 && half) { launch_on_stream(k_spmv<MODE, 2, kUnroll / 2>, dim3(grid), dim3(kThreads), 0, slot, a); return; }
+        if (M.rep == 3 && half) { launch_on_stream(k_spmv<MODE, 3, kUnroll / 2>, dim3(grid), dim3(kThreads), 0, slot, a); return; }
+        if (M.rep == 2) { launch_on_stream(k_spmv<MODE, 2>, dim3(grid), dim3(kThreads), 0, slot, a); return; }
+        if (M.rep == 3) { launch_on_stream(k_spmv<MODE, 3>, dim3(grid), dim3(kThreads), 0, slot, a); return; }
+        launch_on_stream(k_spmv<MODE, 1>, dim3(grid), dim3(kThreads), 0, slot, a);
     }
 
     SpmvArgs spmv_args(const CsrBufs& M, const double* xin) {
@@ -1215,7 +1226,7 @@ struct HipBackend {
         HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, st.device));
         if (khz <= 0) throw std::runtime_error("score_time_iteration: no wall clock rate");
         for (int k = 0; k < 12; ++k) us[k] = 0.0;
-        const int maxb = std::max(std::max(G1.nblocks, K.nblocks), std::max(n_prec, n_cone_blocks));
+        const int maxb = std::max(std::max(G1.nblocks, K.nblocks) + 8, std::max(n_prec + n_help, n_cone_blocks));  // (grids: XCD rounding, update helpers)
         ts_stride = (size_t)2 * maxb;
         const size_t per_iter = 6 * ts_stride, nslot = per_iter * iters;
         {
@@ -1732,7 +1743,8 @@ struct HipBackend {
             pa.gate_init = nullptr;
             SpmvArgs a = spmv_args(Hm, pcg_p_cur);
             a.p = pcg_p_cur; a.pw_part = q_pw.d; a.done = q_skip.d;
-            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, a);
+            const unsigned grid = xcd_grid(a, Hm.nblocks);  // (sets a.xcd_chunk: before the launch copies `a`)
+            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(grid), dim3(kThreads), 0, stream, a);
         } else {
             // flags of the problems that go on: lowered again (their gates had not fired; the host's skip
             // flags now hold exactly the resumed set)
@@ -1751,12 +1763,14 @@ struct HipBackend {
             SpmvArgs a = spmv_args(Hm, pcg_p_cur);
             a.p = pcg_p_cur; a.z = z.d; a.p_out = pcg_p_oth; a.rz_new = rz_nxt; a.rz_old = pcg_rz_cur; a.pw_part = q_pw.d; a.done = q_pcgdone.d;
             a.early_done = 1;
-            hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, a);
+            const unsigned grid = xcd_grid(a, Hm.nblocks);
+            hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(grid), dim3(kThreads), 0, stream, a);
             std::swap(pcg_p_cur, pcg_p_oth);
             if (++pcg_steps_queued % kDirectEvery == 0) {  // (see linear_solve_core)
                 SpmvArgs d = spmv_args(Hm, pcg_p_cur);
                 d.p = pcg_p_cur; d.pw_part = q_pw.d; d.done = q_pcgdone.d; d.early_done = 1;
-                hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(Hm.nblocks), dim3(kThreads), 0, stream, d);
+                const unsigned dgrid = xcd_grid(d, Hm.nblocks);
+                hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(dgrid), dim3(kThreads), 0, stream, d);
             }
             pcg_rz_cur = rz_nxt;
         }

@@ -141,6 +141,10 @@ struct SpmvArgs {
     CsrDev M;
     const double* xin;      // gathered vector
     const int32_t* done;
+    int xcd_chunk;          // > 0: tiles are dealt to the XCDs in contiguous runs of this many (workgroup i runs on XCD i % 8 and
+                            //      takes tile (i % 8) * xcd_chunk + i / 8): the tiles of one problem of a batch, and neighbouring
+                            //      tiles of one problem, gather through the same L2.  Grid = 8 * xcd_chunk; 0 = tile i on workgroup i
+    int n_tiles;            // (tiles beyond this exit: the grid is rounded up to 8 * xcd_chunk)
     int early_done;         // 1: test the frozen-problem flag before anything else is requested (gated PCG solves queue
                             //    launches that are MEANT to be no-ops once the gate has fired: they must stay cheap);
                             // 0: the flag is requested with everything else and tested before the first write (ADMM loop)
@@ -195,12 +199,11 @@ constexpr int kMaxRep = 3;
 // once, the gathers and the LDS products are per replica; sums are per replica in CSR order, so every replica gets
 // exactly what a plain SpMV on its own copy of the rows would give.
 template <int MODE, int NR, int UNR = kUnroll>
-__device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int4 meta, const int prob, const int my_ptr, const int end_ptr,
+__device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b, const int4 meta, const int prob, const int my_ptr, const int end_ptr,
                                           const int rs_out, double* __restrict__ prod, double* red, int32_t* srow) {
     static_assert(NR == 1 || (MODE != MODE_DRES && MODE != MODE_GRAD), "residual / gradient modes run on plain rows");
     auto kpad = [](int k) -> int { return k + (k >> 3); };
     constexpr int kPlane = UNR * kThreads + UNR * kThreads / 8;  // one padded plane of products per right-hand side
-    const int b = blockIdx.x;
     const int t = threadIdx.x;
     const int r0 = meta.x, r1 = meta.y, k0 = meta.z, k1 = meta.w;
     const int nn = k1 - k0;
@@ -434,7 +437,8 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     __shared__ double prod[NR * (UNR * kThreads + UNR * kThreads / 8)];
     __shared__ double red[8];
     __shared__ int32_t srow[kRowsPerBlock + 1];  // row pointers of the tile, relative to k0
-    const int b = blockIdx.x;
+    const int b = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (a.xcd_chunk > 0 && b >= a.n_tiles) return;
     const int t = threadIdx.x;
     // one 16-byte load gives the whole tile geometry; the frozen-problem flag and the
     // tile's row pointers are requested together with it
@@ -443,8 +447,8 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     const int rs = (NR > 1) ? a.M.blk_rs[b] : 0;
     const int my_ptr = a.M.ptr[min(meta.x + t, meta.y)];
     const int end_ptr = (t == 0) ? meta.w : 0;
-    if (NR > 1 && rs > 0) spmv_tile<MODE, NR, UNR>(a, meta, prob, my_ptr, end_ptr, rs, prod, red, srow);
-    else spmv_tile<MODE, 1, UNR>(a, meta, prob, my_ptr, end_ptr, 0, prod, red, srow);
+    if (NR > 1 && rs > 0) spmv_tile<MODE, NR, UNR>(a, b, meta, prob, my_ptr, end_ptr, rs, prod, red, srow);
+    else spmv_tile<MODE, 1, UNR>(a, b, meta, prob, my_ptr, end_ptr, 0, prod, red, srow);
 }
 
 // ---------------------------------------------------------------------------
