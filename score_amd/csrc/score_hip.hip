@@ -1203,8 +1203,12 @@ struct HipBackend {
             last_p = p_cur;
         }
         ca.tstamp = slot(5);
-        if (n_cone_blocks)
-            launch_on_stream(k_cone, dim3(n_cone_blocks), dim3(kThreads), 0, 5, ca);
+        if (n_cone_blocks) {
+            unsigned cgrid = (unsigned)n_cone_blocks;
+            if (xcd_spmv && n_cone_blocks >= 16) { ca.xcd_chunk = (n_cone_blocks + 7) / 8; ca.n_blocks = n_cone_blocks; cgrid = 8u * (unsigned)ca.xcd_chunk; }
+            launch_on_stream(k_cone, dim3(cgrid), dim3(kThreads), 0, 5, ca);
+            ca.xcd_chunk = 0;
+        }
         if (n_large_cones) {  // (general conic programs only: a SCORE model has none)
             ca.tstamp = nullptr;
             hipLaunchKernelGGL(k_cone_wave, dim3((unsigned)((n_large_cones + 3) / 4)), dim3(kThreads), 0, stream, ca,
@@ -1226,7 +1230,7 @@ struct HipBackend {
         HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, st.device));
         if (khz <= 0) throw std::runtime_error("score_time_iteration: no wall clock rate");
         for (int k = 0; k < 12; ++k) us[k] = 0.0;
-        const int maxb = std::max(std::max(G1.nblocks, K.nblocks) + 8, std::max(n_prec + n_help, n_cone_blocks));  // (grids: XCD rounding, update helpers)
+        const int maxb = std::max(std::max(G1.nblocks, K.nblocks) + 8, std::max(n_prec + n_help, n_cone_blocks + 8));  // (grids: XCD rounding, update helpers)
         ts_stride = (size_t)2 * maxb;
         const size_t per_iter = 6 * ts_stride, nslot = per_iter * iters;
         {

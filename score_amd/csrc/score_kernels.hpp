@@ -1550,6 +1550,7 @@ __global__ __launch_bounds__(kThreads) void k_xupdate(VecArgs a) {
 // cones: one cone per lane
 // ---------------------------------------------------------------------------
 struct ConeArgs {
+    int xcd_chunk, n_blocks;  // see SpmvArgs::xcd_chunk (0: block i on workgroup i)
     const int32_t* A_ptr;
     const int32_t* A_col;
     const double* A_val;
@@ -1611,7 +1612,9 @@ constexpr int kWaveCone = 32;    // cones with more rows than this are projected
 __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
     KernelStamp stamp(a.tstamp);
     __shared__ double red[8];
-    const int b = blockIdx.x;
+    // (XCD-aware block order as in k_spmv: the cone blocks of one problem of a batch project through one L2)
+    const int b = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (a.xcd_chunk > 0 && b >= a.n_blocks) return;
     const int prob = a.block_prob[b];
     if (a.done[prob]) return;
     // Partial sums of the last PCG step's r'z and p'w: requested now, reduced (two barriers) only
