@@ -1682,7 +1682,8 @@ struct HipBackend {
         // -g goes to its own buffer, not to the PCG residual r: an unfinished PCG solve can then be
         // resumed after the evaluation of a trial point
         ga.is_head = q_ishead.d; ga.gout = q_g.d; ga.r = q_negg.d; ga.done = q_skip.d;
-        hipLaunchKernelGGL(k_spmv<MODE_GRAD>, dim3(G2.nblocks), dim3(kThreads), 0, stream, ga);
+        const unsigned ggrid = xcd_grid(ga, G2.nblocks);
+        hipLaunchKernelGGL(k_spmv<MODE_GRAD>, dim3(ggrid), dim3(kThreads), 0, stream, ga);
         // F and gradient partials land in host-mapped memory as the kernels write them; the PCG gate
         // words (device-resident: the kernels read them) are pushed, then the sequence number
         eval_seq = publish(q_pcgdone.d, d_gate_host, ((size_t)2 * H->count + 1) / 2);
