@@ -94,6 +94,32 @@ def test_update_helpers_change_no_bit(name, fixtures, hip_lib, monkeypatch):
     assert a.info["newton_cg_iters"] == b.info["newton_cg_iters"] and np.array_equal(a.x, b.x)
     with_h.close(); without.close()
 
+def test_xcd_aware_tile_order_changes_no_bit(fixtures, hip_lib, monkeypatch):
+    """k_spmv / k_cone deal their tiles to the XCDs in contiguous runs (workgroup i takes tile (i % 8) * chunk + i / 8;
+    the grid is rounded up and the surplus workgroups leave).  Which workgroup computes a tile changes nothing in
+    what is computed: a lock-step batch of three different graphs (tile counts that are no multiple of 8) gives
+    bit-identical iterates, partial sums and polished solutions with the plain order (SCORE_NO_XCD_SPMV)."""
+    _hip_only(hip_lib)
+    qps = [assemble(make_manhattan(n_robots=3, n_poses=700 + 130 * k, n_beacons=3, seed=40 + k), "SOCP").qp for k in range(3)]
+    st = dict(adaptive_cg=0, check_interval=5)
+    monkeypatch.delenv("SCORE_NO_XCD_SPMV", raising=False)
+    aware = ConicSolver(qps, st, lib_path=hip_lib)
+    monkeypatch.setenv("SCORE_NO_XCD_SPMV", "1")
+    plain = ConicSolver(qps, st, lib_path=hip_lib)
+    monkeypatch.delenv("SCORE_NO_XCD_SPMV", raising=False)
+    aware.reset(); plain.reset()
+    for k in (1, 7):
+        a, b = aware.steps(k), plain.steps(k)
+        for v in VECS:
+            assert np.array_equal(aware.debug_get(v), plain.debug_get(v)), (v, k)
+        for x, y in zip(a, b):
+            assert np.array_equal(x.x, y.x) and x.info["res_dual"] == y.info["res_dual"]
+    a, b = aware.solve(), plain.solve()
+    for x, y in zip(a, b):
+        assert x.solved and y.solved and x.info["newton_cg_iters"] == y.info["newton_cg_iters"] and np.array_equal(x.x, y.x)
+    aware.close(); plain.close()
+
+
 @pytest.mark.parametrize("name,relax", [("manhattan", "SOCP"), ("graph3d", "SOCP"), ("synth_d", "QCQP"), ("synth_b", "SOCP"), ("prior2d", "SOCP")])
 def test_device_setup_against_scipy(name, relax, fixtures, hip_lib):
     """The setup the kernels run on, checked without any of the product's (or the twin's) host code: the scales D, E
