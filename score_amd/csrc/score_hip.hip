@@ -733,7 +733,8 @@ struct HipBackend {
                 deep = Lz.offB + (int64_t)2 * h.bs * h.bs * Lz.N - lv[1].offR;
             }
             const int ng = std::max(8 * h.bs * h.bs, 32);
-            if (ch.n_levels > kRecLevels || lv[0].nruns > kPreRunLanes || (ch.n_levels >= 2 && lv[1].N > kPrecThreads - kPreRunLanes) || (int64_t)ch.N * h.bs > (int64_t)pre_chunk * kPrecThreads ||
+            // (k_prec_pre computes a node's column as col0 + node * stride: chains with irregular columns take k_prec)
+            if (ch.col_stride == 0 || ch.n_levels > kRecLevels || lv[0].nruns > kPreRunLanes || (ch.n_levels >= 2 && lv[1].N > kPrecThreads - kPreRunLanes) || (int64_t)ch.N * h.bs > (int64_t)pre_chunk * kPrecThreads ||
                 deep > (int64_t)ng * (kPrecThreads - kPreRunLanes))
                 prec_pre = false;
             const ChainLevelDesc& Lend = lv[ch.n_levels - 1];
@@ -885,7 +886,7 @@ struct HipBackend {
             float* shadow = newton_set ? q_fac32.d : fac32.d;
             hipLaunchKernelGGL(k_fac_round, dim3((unsigned)((nf + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, fa.fac, shadow, nf);
             if (prec_reg)  // ... and the lane-major copy of the coarse levels the register-resident chain kernel loads
-                hipLaunchKernelGGL(k_deep_pack, dim3((unsigned)(12 * bs * bs), (unsigned)np), dim3(kThreads), 0, stream, fa.work, fa.chains,
+                hipLaunchKernelGGL(k_deep_pack, dim3((unsigned)(12 * bs * bs), (unsigned)np), dim3(kThreads), 0, stream, fa.work, fa.chains,  // (grid.x / 12 = bs^2: the kernel derives the packet layout from it)
                                    fa.levels, (const int32_t*)deep_map.d, (const float*)shadow, newton_set ? deepH.d : deepK.d, fa.skip);
         }
     }

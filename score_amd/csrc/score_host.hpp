@@ -593,10 +593,35 @@ inline bool chain_lane_plan(std::vector<ChainLevelDesc>& lv, int lanes) {
         lv[l].lane0 = next;
         next = (next + need + 63) / 64 * 64;
     }
-    if (!ok)
+    if (!ok) {
         for (auto& L : lv) L.lane0 = -1;
+        return ok;
+    }
+    // which slot groups each 64-lane wavefront of the staging lanes has to load (k_prec_pre reads lv[0].pad_ instead of
+    // walking the level table): bit w = level-1 spike blocks, bit 4 + w = run / separator blocks, bit 8 + w = the spike
+    // blocks of a level >= 2, for wavefront w (lanes 64 w .. 64 w + 63)
+    int mask = 0;
+    for (int w = 0; w * 64 < lanes && w < 4; ++w) {
+        const int w0 = 64 * w;
+        if (lv[1].p != 0 && w0 < lv[1].N) mask |= 1 << w;
+        for (size_t l = 1; l < lv.size(); ++l) {
+            if (lv[l].lane0 < w0 + 64 && lv[l].lane0 + lv[l].nruns > w0) mask |= 1 << (4 + w);
+            if (l >= 2 && lv[l].p != 0 && lv[l].lane0 < w0 + 64 && lv[l].lane0 + lv[l].N > w0) mask |= 1 << (8 + w);
+        }
+    }
+    lv[0].pad_ = mask;
     return ok;
 }
+// Layout of the lane-major copy (k_deep_pack -> k_prec_pre<.., REGDEEP>): the three slot groups of a lane -- [0, 2 b2)
+// level-1 spikes, [2 b2, 10 b2) run + separator, [10 b2, 12 b2) own-level spikes -- each padded to a multiple of 4 and
+// stored as 16-byte packets, packet q of lane dt at float 4 (q * lanes + dt): a lane fetches a group with a few
+// 16-byte loads (27 + 1 padding packet per lane at 3 x 3 blocks) instead of one 4-byte load per value.
+inline int deep_group_pad(int bs) { return ((2 * bs * bs + 3) & ~3) - 2 * bs * bs; }
+inline int deep_padded_slot(int bs, int slot) {
+    const int b2 = bs * bs, pad = deep_group_pad(bs);
+    return slot < 2 * b2 ? slot : (slot < 10 * b2 ? slot + pad : slot + 2 * pad);
+}
+inline int deep_padded_slots(int bs) { return 12 * bs * bs + 2 * deep_group_pad(bs); }
 // Slot map of the lane-major copy of a chain's coarse-level factors (k_deep_pack -> k_prec_pre<.., REGDEEP>): staging lane
 // dt keeps in registers  [0, 2 b2): the spike blocks V, W of level-1 node dt;  [2 b2, 10 b2): the run (6 b2) and
 // separator (2 b2) blocks of the run it serves (whatever level);  [10 b2, 12 b2): the spike blocks of its own level's
@@ -1591,7 +1616,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         const int scr = lay->scr;
         ch.n_levels = (int32_t)lv.size();
         if (ch.n_levels > 20) throw std::runtime_error("chain too long: more than 20 partition levels");
-        const int64_t deep_sz = (int64_t)12 * bs * bs * kDeepLanes;
+        const int64_t deep_sz = (int64_t)deep_padded_slots(bs) * kDeepLanes;
         ch.deep_map_off = lay->map_off;
         if (lay->map_off < 0) H.deep_ok = false;
         {   // the Newton matrix: every chain has factors of its own

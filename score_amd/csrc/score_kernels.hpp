@@ -1014,10 +1014,17 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
     const PrecWork wk = srec.wk;
     const ChainLevelDesc* sLv = srec.lv;
     const int prob = wk.prob;
-    const int dn = a.done[prob];  // (tested once the loads below are in flight; uniform over the workgroup)
-    if (a.early_done && dn) return;
+    // The frozen-problem flag.  Gated PCG solves (early_done) test it before anything else: their queue holds launches
+    // that are meant to be no-ops.  The ADMM loop requests it here and tests it where the first write would happen --
+    // waiting for it now would put one more round trip to memory in front of every load below.
+    int dn = 0;
+    if (a.early_done) {
+        dn = a.done[prob];
+        if (dn) return;
+    }
+    const int dn_late = a.early_done ? 0 : a.done[prob];
     if (MODE == PREC_INIT && a.gate_init && threadIdx.x == 0 && (int)blockIdx.x == a.prec_part_ptr[prob]) {
-        a.gate_init[prob] = dn;
+        a.gate_init[prob] = a.early_done ? dn : dn_late;
         a.gate_used[prob] = 0;
     }
     double acc_rz = 0.0, acc_pw = 0.0;
@@ -1032,7 +1039,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         // update helper (STEP with split_update; appended after the problem's own items, so never the gate's lead and
         // outside the r'z partials): entries [index, index + count) of xt and kx.  alpha and the gate's verdict are
         // derived from the same partial sums in the same order as in the chain workgroups -- the same bits.
-        if (MODE != PREC_STEP || dn) return;
+        if (MODE != PREC_STEP || dn || dn_late) return;
         const double gref = (a.gate_flag && !a.gate_first) ? a.gate_ref[prob] : 0.0;
         const int e_end = wk.index + wk.count;
         int idx[kPrecChunk];
@@ -1055,21 +1062,21 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         return;
     }
     if (wk.kind == 1) {
-        if (dn) return;
+        if (dn || dn_late) return;
         bool stop;
         local = prec_jacobi_item<MODE>(a, wk, acc_rz, acc_pw, red, stop);
         if (stop) return;
     } else {
         const double gref = (MODE == PREC_STEP && a.gate_flag && !a.gate_first) ? a.gate_ref[prob] : 0.0;
         const ChainDesc ch = srec.ch;
-        const int32_t* __restrict__ nc = a.node_col + ch.node_begin;
         // factor stream: 8-byte values, or their float copies (half the bytes through this CU; converted on arrival)
         const FT* __restrict__ fac = sizeof(FT) == 4 ? (const FT*)(const void*)a.fac32 : (const FT*)(const void*)a.fac;
         const int N = ch.N;
         const int NB = N * BS;
         const int nl = ch.n_levels;
         const int stride = ch.col_stride, col0 = ch.col0;
-        auto colof = [&](int node) -> int { return stride ? col0 + node * stride : nc[node]; };
+        // (regular chains only -- the backend checks: no trip to node_col in front of the vector loads)
+        auto colof = [&](int node) -> int { return col0 + node * stride; };
         // vectors of all levels, padded (see ChainLevelDesc::lds_off): node i, component c of level
         // L at vb[L.lds_off + i * BS + i / L.p + c]
         double* vb = lds + 16;
@@ -1135,21 +1142,36 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                 }
             }
         } else if (REGDEEP) {
-            // this lane's slots of the lane-major copy; slot ranges no lane of the wavefront uses are skipped (uniform)
+            // this lane's slots of the lane-major copy, as 16-byte packets; slot groups no lane of the wavefront uses are
+            // skipped (scalar branches: the host has put the wavefront's needs into lv[0].pad_, chain_lane_plan)
             if (nl >= 2 && !(a.debug_skip & 2)) {
-                const float* __restrict__ src = a.deep + ch.deep_off + (t - kPreRunLanes);
-                const int w0 = (t - kPreRunLanes) & ~63;  // first staging lane of this wavefront
-                bool need_run = false, need_bk2 = false;
-                for (int l = 1; l < nl; ++l) {
-                    const ChainLevelDesc Lx = sLv[l];
-                    need_run = need_run || (Lx.lane0 < w0 + 64 && Lx.lane0 + Lx.nruns > w0);
-                    need_bk2 = need_bk2 || (l >= 2 && Lx.p != 0 && Lx.lane0 < w0 + 64 && Lx.lane0 + Lx.N > w0);
+                constexpr int kPad = ((2 * B2 + 3) & ~3) - 2 * B2;    // padding of a spike group (deep_group_pad)
+                constexpr int P1 = 2 * B2 + kPad;                      // packets [0, P1 / 4): level-1 spikes
+                constexpr int NQ = (12 * B2 + 2 * kPad) / 4;           // packets per lane
+                const float4* __restrict__ src = reinterpret_cast<const float4*>(a.deep + ch.deep_off) + (t - kPreRunLanes);
+                const int wv_ = __builtin_amdgcn_readfirstlane((t - kPreRunLanes) >> 6);
+                const int mask = __builtin_amdgcn_readfirstlane(L0.pad_);
+                const bool need_bk1 = (mask >> wv_) & 1, need_run = (mask >> (4 + wv_)) & 1, need_bk2 = (mask >> (8 + wv_)) & 1;
+                float4 pk[NQ];
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) pk[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (need_bk1) {
+#pragma unroll
+                    for (int q = 0; q < P1 / 4; ++q) pk[q] = src[(size_t)q * kStageLanes];
                 }
-                const bool need_bk1 = sLv[1].p != 0 && w0 < sLv[1].N;
+                if (need_run) {
+#pragma unroll
+                    for (int q = P1 / 4; q < P1 / 4 + 2 * B2; ++q) pk[q] = src[(size_t)q * kStageLanes];
+                }
+                if (need_bk2) {
+#pragma unroll
+                    for (int q = P1 / 4 + 2 * B2; q < NQ; ++q) pk[q] = src[(size_t)q * kStageLanes];
+                }
 #pragma unroll
                 for (int k = 0; k < NG; ++k) {
-                    const bool need = k < 2 * B2 ? need_bk1 : (k < oBk2 ? need_run : need_bk2);
-                    Gr[k] = need ? (FT)src[(size_t)k * kStageLanes] : (FT)0;
+                    const int g = k < 2 * B2 ? k : (k < 10 * B2 ? k + kPad : k + 2 * kPad);
+                    const float4 v = pk[g >> 2];
+                    Gr[k] = (FT)((g & 3) == 0 ? v.x : (g & 3) == 1 ? v.y : (g & 3) == 2 ? v.z : v.w);
                 }
             }
         } else if (deep_cnt > 0 && !(a.debug_skip & 2)) {
@@ -1164,7 +1186,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             }
         }
         // ---- alpha (every lane joins the reduction), then the vector update into LDS ----
-        if (dn) return;  // frozen problem (uniform): nothing has been written
+        if (dn_late) return;  // frozen problem (uniform): nothing has been written
         double alpha = 0.0;
         if (MODE == PREC_STEP) {
             block_sum2_n<kPrecWaves>(acc_rz, acc_pw, red);
@@ -1951,7 +1973,11 @@ __global__ __launch_bounds__(kThreads) void k_deep_pack(const PrecWork* __restri
     const int64_t base = levels[ch.level_begin].offR;  // the chain's first factor entry
     const int s = blockIdx.x, dt = threadIdx.x;
     const int32_t idx = map[(size_t)ch.deep_map_off + (size_t)s * kThreads + dt];
-    deep[(size_t)ch.deep_off + (size_t)s * kThreads + dt] = idx >= 0 ? fac32[base + idx] : 0.0f;
+    // 16-byte packets, slot groups padded to multiples of 4 (deep_padded_slot, score_host.hpp)
+    const int b2 = (int)gridDim.x / 12;
+    const int pad = ((2 * b2 + 3) & ~3) - 2 * b2;
+    const int g = s < 2 * b2 ? s : (s < 10 * b2 ? s + pad : s + 2 * pad);
+    deep[(size_t)ch.deep_off + 4 * ((size_t)(g >> 2) * kThreads + dt) + (g & 3)] = idx >= 0 ? fac32[base + idx] : 0.0f;
 }
 
 __global__ void k_nop(int* sink) { if (sink && threadIdx.x == 9999) sink[0] = 1; }
