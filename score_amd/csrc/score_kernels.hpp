@@ -311,13 +311,14 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b, const 
         }
         if (dn) return;  // (uniform over the workgroup; nothing has been written)
         finish_beta();
+        // (every lane stores all its products: slots beyond the tile's last nonzero hold copies of the last product and
+        //  are never read -- a row adds the slots of its own nonzeros only -- and a predicated store is an exec-mask
+        //  branch per product)
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int k = t + u * kThreads;
-            if (k < nn) {
 #pragma unroll
-                for (int q = 0; q < NR; ++q) prod[q * kPlane + kpad(k)] = v[u] * g[u][q];
-            }
+            for (int q = 0; q < NR; ++q) prod[q * kPlane + kpad(k)] = v[u] * g[u][q];
         }
         if (r0 + t <= r1) srow[t] = my_ptr - k0;
         if (t == 0) srow[r1 - r0] = end_ptr - k0;
@@ -330,9 +331,25 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b, const 
                 for (int k = a0; k < sp; ++k) sum[0] += prod[kpad(k)];
                 for (int k = sp; k < a1; ++k) sum2 += prod[kpad(k)];
             } else {
-                for (int k = a0; k < a1; ++k) {
+                // four slots per trip (clamped reads, the surplus ones add an exact zero -- the order of the additions is
+                // the CSR order, as before): one LDS wait per four nonzeros instead of one per nonzero
+                for (int k = a0; k < a1; k += 4) {
+                    const int k1_ = min(k + 1, a1 - 1), k2_ = min(k + 2, a1 - 1), k3_ = min(k + 3, a1 - 1);
+                    double p0[NR], p1[NR], p2[NR], p3[NR];
 #pragma unroll
-                    for (int q = 0; q < NR; ++q) sum[q] += prod[q * kPlane + kpad(k)];
+                    for (int q = 0; q < NR; ++q) {
+                        p0[q] = prod[q * kPlane + kpad(k)];
+                        p1[q] = prod[q * kPlane + kpad(k1_)];
+                        p2[q] = prod[q * kPlane + kpad(k2_)];
+                        p3[q] = prod[q * kPlane + kpad(k3_)];
+                    }
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) {
+                        sum[q] += p0[q];
+                        sum[q] += (k + 1 < a1) ? p1[q] : 0.0;
+                        sum[q] += (k + 2 < a1) ? p2[q] : 0.0;
+                        sum[q] += (k + 3 < a1) ? p3[q] : 0.0;
+                    }
                 }
             }
         }
