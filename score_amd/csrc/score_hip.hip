@@ -903,6 +903,7 @@ struct HipBackend {
         a.alpha_relax = st.alpha; a.invE = invE.d; a.pres_part = pres_part.d;
         a.apply_alpha = 0; a.pfin = p.d; a.pw_in = pw_part.d; a.rz_in = rz_part0.d;
         a.prec_part_ptr = prec_part_ptr.d; a.kblk_part_ptr = kblk_part_ptr.d; a.step_out = step.d;
+        a.uni = uni_for(K.nblocks);
         a.skip_large = n_large_cones > 0 ? 1 : 0;
         return a;
     }
@@ -1088,6 +1089,16 @@ struct HipBackend {
         a.n_tiles = nblocks;
         return (unsigned)(8 * a.xcd_chunk);
     }
+    // partial-sum ranges by value for single-problem handles (UniRanges, score_kernels.hpp); kblocks = row blocks of the
+    // matrix whose p'w partials the launch reads (K in the ADMM loop, H in the Newton PCG)
+    bool uni_ranges = std::getenv("SCORE_NO_UNI_RANGES") == nullptr;
+    UniRanges uni_for(int kblocks) const {
+        UniRanges u{};
+        u.on = (uni_ranges && H->count == 1 && active_part_ptr.size() == 2) ? 1 : 0;
+        u.l0 = 0; u.l1 = u.on ? active_part_ptr[1] : 0;
+        u.k0 = 0; u.k1 = kblocks;
+        return u;
+    }
     template <int MODE>
     void launch_spmv(const CsrBufs& M, const SpmvArgs& a_in, int slot = -1) {
         static_assert(MODE == MODE_RHS || MODE == MODE_KP || MODE == MODE_KPB, "the residual / gradient modes run on plain rows (G2, H)");
@@ -1107,6 +1118,7 @@ struct HipBackend {
         a.x = xy.d; a.q = q.d; a.kx = kx.d; a.r = r.d; a.sigma = H->sigma;
         a.p = p.d; a.w = w.d; a.pw_part = pw_part.d;
         a.prec_part_ptr = prec_part_ptr.d; a.kblk_part_ptr = kblk_part_ptr.d;
+        a.uni = uni_for(K.nblocks);
         a.apply_update = 0; a.pfin = p.d; a.wfin = w.d; a.xt_rw = xtu.d; a.kx_rw = kx.d; a.x_rw = xy.d;
         a.alpha_relax = st.alpha; a.step_in = step.d;
         a.invD = invD.d; a.dres_part = dres_part.d;
@@ -1168,7 +1180,7 @@ struct HipBackend {
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.rec = prec_rec.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = done.d;
-        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d;
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d; pa.uni = uni_for(K.nblocks);
         pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d;
         pa.pw_part = pw_part.d;
         double* rz_cur = measure ? rz_meas0.d : rz_part0.d;
@@ -1403,7 +1415,7 @@ struct HipBackend {
                 PrecArgs pa{};
                 pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.rec = prec_recH.d; pa.fac = q_fac.d;
                 pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = q_skip.d;
-                pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d;
+                pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d; pa.uni = uni_for(Hm.nblocks);
                 pa.r = r.d; pa.r_in = q_negg.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d;
                 pa.pw_part = q_pw.d; pa.rz_in = nullptr; pa.rz_out = rz_part0.d;
                 launch_prec<PREC_INIT>(pa);
@@ -1492,7 +1504,7 @@ struct HipBackend {
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.rec = prec_rec.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = lin_flag.d;
-        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d;
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d; pa.uni = uni_for(K.nblocks);
         pa.r = r.d; pa.r_in = rhs_dev; pa.z = z.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d; pa.pw_part = pw_part.d;
         pa.gate_used = lin_flag.d + 1;
         pa.early_done = 1;
@@ -1733,7 +1745,7 @@ struct HipBackend {
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.rec = prec_recH.d; pa.fac = q_fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = q_skip.d;
-        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d;
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d; pa.uni = uni_for(Hm.nblocks);
         pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d; pa.pw_part = q_pw.d;
         pa.gate_used = q_gate_used.d;
         pa.early_done = 1;  // launches queued beyond the gate are no-ops: keep them cheap
@@ -1983,7 +1995,7 @@ struct HipBackend {
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.rec = prec_rec.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = done.d;
-        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d;
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d; pa.uni = uni_for(K.nblocks);
         pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d;
         pa.pw_part = pw_part.d; pa.rz_in = rz_part0.d; pa.rz_out = rz_part1.d;
         VecArgs va{};

@@ -137,7 +137,19 @@ struct KernelStamp {
     }
 };
 
+// Single-problem handles: the ranges of the per-workgroup partial sums (r'z over the preconditioner's work items, p'w over
+// the K row blocks) are launch constants, and the problem index is 0 -- passed by value, the kernels request the
+// partials (and the frozen flag, rho, the published step length) in their FIRST trip to memory instead of behind
+// block -> problem -> range (two dependent trips in front of every alpha / beta reduction).  on == 0: a batch, the
+// kernels look the ranges up.
+struct UniRanges {
+    int on;
+    int l0, l1;  // prec_part_ptr[0], prec_part_ptr[1]
+    int k0, k1;  // kblk_part_ptr[0], kblk_part_ptr[1]
+};
+
 struct SpmvArgs {
+    UniRanges uni;
     CsrDev M;
     const double* xin;      // gathered vector
     const int32_t* done;
@@ -216,7 +228,7 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b, const 
     // (two barriers) only after the matrix and vector loads of the tile are in flight.
     double beta = 0.0, acc_n = 0.0, acc_o = 0.0;
     if (MODE == MODE_KPB) {
-        const int l0 = a.prec_part_ptr[prob], l1 = a.prec_part_ptr[prob + 1];
+        const int l0 = a.uni.on ? a.uni.l0 : a.prec_part_ptr[prob], l1 = a.uni.on ? a.uni.l1 : a.prec_part_ptr[prob + 1];
         for (int i = l0 + t; i < l1; i += kThreads) { acc_n += a.rz_new[i]; acc_o += a.rz_old[i]; }
     }
     // RHS: the step length of the last PCG step was published by the cone kernel
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     // one 16-byte load gives the whole tile geometry; the frozen-problem flag and the
     // tile's row pointers are requested together with it
     const int4 meta = a.M.blk_meta[b];
-    const int prob = a.M.blk_prob[b];
+    const int prob = a.uni.on ? 0 : a.M.blk_prob[b];
     const int rs = (NR > 1) ? a.M.blk_rs[b] : 0;
     const int my_ptr = a.M.ptr[min(meta.x + t, meta.y)];
     const int end_ptr = (t == 0) ? meta.w : 0;
@@ -497,6 +509,7 @@ struct PrecArgs {
     const int32_t* done;
     const int32_t* prec_part_ptr;  // per problem: range of prec work items
     const int32_t* kblk_part_ptr;  // per problem: range of K row blocks
+    UniRanges uni;                 // (k_prec_pre) single-problem handles: those ranges by value
     double* r;
     double* z;
     double* p;             // INIT: receives p = z.  STEP: the direction of the last K p
@@ -1025,7 +1038,13 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
     __shared__ PrecRecord srec;
     double* red = lds;
     const int t = threadIdx.x;
-    // trip 1: the work item's record.  Trip 2: everything else -- frozen flag, partial sums, vectors, factors.
+    // trip 1: the work item's record (and, for a single-problem handle, the partial sums of alpha: their ranges are launch
+    // constants).  Trip 2: everything else -- frozen flag, partial sums of a batch, vectors, factors.
+    double acc_rz = 0.0, acc_pw = 0.0;
+    if (MODE == PREC_STEP && a.uni.on) {
+        for (int i = a.uni.l0 + t; i < a.uni.l1; i += kPrecThreads) acc_rz += a.rz_in[i];
+        for (int i = a.uni.k0 + t; i < a.uni.k1; i += kPrecThreads) acc_pw += a.pw_part[i];
+    }
     if (t < 32) reinterpret_cast<int4*>(&srec)[t] = reinterpret_cast<const int4*>(a.rec + blockIdx.x)[t];
     __syncthreads();
     const PrecWork wk = srec.wk;
@@ -1044,8 +1063,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
         a.gate_init[prob] = a.early_done ? dn : dn_late;
         a.gate_used[prob] = 0;
     }
-    double acc_rz = 0.0, acc_pw = 0.0;
-    if (MODE == PREC_STEP) {
+    if (MODE == PREC_STEP && !a.uni.on) {
         const int l0 = a.prec_part_ptr[prob], l1 = a.prec_part_ptr[prob + 1];
         const int k0 = a.kblk_part_ptr[prob], k1 = a.kblk_part_ptr[prob + 1];
         for (int i = l0 + t; i < l1; i += kPrecThreads) acc_rz += a.rz_in[i];
@@ -1590,6 +1608,7 @@ __global__ __launch_bounds__(kThreads) void k_xupdate(VecArgs a) {
 // ---------------------------------------------------------------------------
 struct ConeArgs {
     int xcd_chunk, n_blocks;  // see SpmvArgs::xcd_chunk (0: block i on workgroup i)
+    UniRanges uni;
     const int32_t* A_ptr;
     const int32_t* A_col;
     const double* A_val;
@@ -1654,14 +1673,16 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
     // (XCD-aware block order as in k_spmv: the cone blocks of one problem of a batch project through one L2)
     const int b = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (a.xcd_chunk > 0 && b >= a.n_blocks) return;
-    const int prob = a.block_prob[b];
+    const int prob = a.uni.on ? 0 : a.block_prob[b];
     if (a.done[prob]) return;
     // Partial sums of the last PCG step's r'z and p'w: requested now, reduced (two barriers) only
     // after the cone's own loads are in flight.
     double rz = 0.0, pw = 0.0;
     if (a.apply_alpha) {
-        for (int i = a.prec_part_ptr[prob] + (int)threadIdx.x; i < a.prec_part_ptr[prob + 1]; i += kThreads) rz += a.rz_in[i];
-        for (int i = a.kblk_part_ptr[prob] + (int)threadIdx.x; i < a.kblk_part_ptr[prob + 1]; i += kThreads) pw += a.pw_in[i];
+        const int l0 = a.uni.on ? a.uni.l0 : a.prec_part_ptr[prob], l1 = a.uni.on ? a.uni.l1 : a.prec_part_ptr[prob + 1];
+        const int k0 = a.uni.on ? a.uni.k0 : a.kblk_part_ptr[prob], k1 = a.uni.on ? a.uni.k1 : a.kblk_part_ptr[prob + 1];
+        for (int i = l0 + (int)threadIdx.x; i < l1; i += kThreads) rz += a.rz_in[i];
+        for (int i = k0 + (int)threadIdx.x; i < k1; i += kThreads) pw += a.pw_in[i];
     }
     double step = 0.0;  // step length of the last PCG step (its xt update is applied on the fly)
     auto finish_step = [&]() {
