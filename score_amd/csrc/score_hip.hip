@@ -573,7 +573,8 @@ struct HipBackend {
         // block's replica stride, G1's are the consecutive tail rows of a cone
         K.rep = h.rep; K.rs_in = 0;
         G1.rep = h.rep; G1.rs_in = 1;
-        K.unroll = G1.unroll = (h.rep > 1) ? h.tile_nnz / kThreads : kUnroll;
+        K.unroll = (h.rep > 1) ? h.tile_nnz / kThreads : kUnroll;
+        G1.unroll = (h.rep > 1) ? kUnroll / 2 : kUnroll;  // (tiles of at most kTileNnz / 2 nonzeros, see build_system)
         {
             std::vector<int32_t> vf, ve, vp;
             for (int p = 0; p < h.count; ++p)

@@ -1511,8 +1511,11 @@ inline void build_system(const score_problem* probs, int count, const score_sett
             } else {
                 sg = plain_segments(H.xoff);
             }
+            // (G1 = A' has one or two entries per row: its tiles are bounded by their 256 rows, far below 1024 nonzeros --
+            //  a replicated problem runs it with 4 instead of 8 nonzero slots per lane: half the issued loads and LDS
+            //  planes; measured rhs 6.7 -> 6.2 us on the headline problem, 55.9 -> 47.6 us in the batch of 16)
             if (k == 0) H.rbK = make_rowblocks(H.K, sg, count, H.tile_nnz);
-            else if (k == 1) H.rbG1 = make_rowblocks(H.G1, sg, count, H.tile_nnz);
+            else if (k == 1) H.rbG1 = make_rowblocks(H.G1, sg, count, H.rep > 1 ? kTileNnz / 2 : H.tile_nnz);
             else H.rbG2 = make_rowblocks(H.G2, sg, count);
         }
     });
