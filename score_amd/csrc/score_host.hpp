@@ -1692,8 +1692,10 @@ inline void build_system(const score_problem* probs, int count, const score_sett
                 }
                 H.diag_kpos.push_back(find_in_row(H.K, c0_, (int32_t)c0_));
             }
-        for (size_t e = d_first; e < H.diag_cols.size(); e += 1024) {
-            const PrecWork jw{1, (int32_t)e, (int32_t)std::min<size_t>(1024, H.diag_cols.size() - e), p};
+        // (one Jacobi item = what a 512-thread workgroup requests in one batch of loads: 6 entries per lane)
+        constexpr size_t kJacobiItem = 3072;
+        for (size_t e = d_first; e < H.diag_cols.size(); e += kJacobiItem) {
+            const PrecWork jw{1, (int32_t)e, (int32_t)std::min<size_t>(kJacobiItem, H.diag_cols.size() - e), p};
             H.prec_work.push_back(jw);
             H.factor_work.push_back(jw);
         }
