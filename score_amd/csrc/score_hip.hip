@@ -887,8 +887,8 @@ struct HipBackend {
             float* shadow = newton_set ? q_fac32.d : fac32.d;
             hipLaunchKernelGGL(k_fac_round, dim3((unsigned)((nf + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, fa.fac, shadow, nf);
             if (prec_reg)  // ... and the lane-major copy of the coarse levels the register-resident chain kernel loads
-                hipLaunchKernelGGL(k_deep_pack, dim3((unsigned)(12 * bs * bs), (unsigned)np), dim3(kThreads), 0, stream, fa.work, fa.chains,  // (grid.x / 12 = bs^2: the kernel derives the packet layout from it)
-                                   fa.levels, (const int32_t*)deep_map.d, (const float*)shadow, newton_set ? deepH.d : deepK.d, fa.skip);
+                hipLaunchKernelGGL(k_deep_pack, dim3((unsigned)(deep_padded_slots(bs) / 4), (unsigned)np), dim3(kThreads), 0, stream, fa.work, fa.chains,
+                                   fa.levels, (const int32_t*)deep_map.d, (const float*)shadow, newton_set ? deepH.d : deepK.d, fa.skip, bs * bs);
         }
     }
 

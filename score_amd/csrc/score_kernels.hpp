@@ -1999,23 +1999,32 @@ __global__ __launch_bounds__(kThreads) void k_fac_round(double* __restrict__ fac
     fac[i] = (double)f;
 }
 
-// Lane-major copy of the coarse-level factors of every chain of the work list (HostSystem::deep_map): block (s, w) fills
-// slot s of work item w's chain for the 256 staging lanes -- what k_prec_pre<.., float, true> loads straight into registers.
+// Lane-major copy of the coarse-level factors of every chain of the work list (HostSystem::deep_map): block (q, w) fills
+// 16-byte packet q of work item w's chain for the 256 staging lanes -- what k_prec_pre<.., float, true> loads straight into
+// registers.  Slot groups are padded to multiples of 4 (deep_padded_slot, score_host.hpp); b2 = block size squared.
 __global__ __launch_bounds__(kThreads) void k_deep_pack(const PrecWork* __restrict__ work, const ChainDesc* __restrict__ chains,
                                                         const ChainLevelDesc* __restrict__ levels, const int32_t* __restrict__ map,
-                                                        const float* __restrict__ fac32, float* __restrict__ deep, const int32_t* skip) {
+                                                        const float* __restrict__ fac32, float* __restrict__ deep, const int32_t* skip, int b2) {
     const PrecWork wk = work[blockIdx.y];
     if (wk.kind != 0 || (skip && skip[wk.prob])) return;
     const ChainDesc ch = chains[wk.index];
     if (ch.deep_map_off < 0) return;
     const int64_t base = levels[ch.level_begin].offR;  // the chain's first factor entry
-    const int s = blockIdx.x, dt = threadIdx.x;
-    const int32_t idx = map[(size_t)ch.deep_map_off + (size_t)s * kThreads + dt];
-    // 16-byte packets, slot groups padded to multiples of 4 (deep_padded_slot, score_host.hpp)
-    const int b2 = (int)gridDim.x / 12;
-    const int pad = ((2 * b2 + 3) & ~3) - 2 * b2;
-    const int g = s < 2 * b2 ? s : (s < 10 * b2 ? s + pad : s + 2 * pad);
-    deep[(size_t)ch.deep_off + 4 * ((size_t)(g >> 2) * kThreads + dt) + (g & 3)] = idx >= 0 ? fac32[base + idx] : 0.0f;
+    const int q = blockIdx.x, dt = threadIdx.x;
+    const int pad = ((2 * b2 + 3) & ~3) - 2 * b2, p1 = 2 * b2 + pad;
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int g = 4 * q + c;
+        // padded position -> slot (or a padding position: zero)
+        int s = -1;
+        if (g < p1) s = g < 2 * b2 ? g : -1;
+        else if (g < p1 + 8 * b2) s = g - pad;
+        else s = (g - 2 * pad < 12 * b2) ? g - 2 * pad : -1;
+        const int32_t idx = s >= 0 ? map[(size_t)ch.deep_map_off + (size_t)s * kThreads + dt] : -1;
+        v[c] = idx >= 0 ? fac32[base + idx] : 0.0f;
+    }
+    reinterpret_cast<float4*>(deep + ch.deep_off)[(size_t)q * kThreads + dt] = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 __global__ void k_nop(int* sink) { if (sink && threadIdx.x == 9999) sink[0] = 1; }
