@@ -1015,7 +1015,7 @@ struct PreTile {
 // REGDEEP (4-byte stream, block size <= 3, every chain with a lane plan): the coarse levels' factors never touch LDS.
 // k_deep_pack has laid them out lane by lane -- staging lane dt: [0, 2 B2) spike blocks of level-1 node dt, [2 B2, 10 B2)
 // the run + separator blocks of the run it serves, [10 B2, 12 B2) the spike blocks of its own level's node (levels >= 2) --
-// so a lane loads its slots straight into registers (coalesced: slot-major) and every coarse phase starts its arithmetic
+// so a lane loads its slots straight into registers (16-byte packets, packet-major: coalesced) and every coarse phase starts its arithmetic
 // at once instead of pulling 18..72 values from LDS first.  LDS then holds vectors only (41 KB instead of 135 KB at
 // 1000 nodes): three chains per CU can be resident.  The level-0 tile is kept as floats too (converted where used).
 template <int BS, int MODE, typename FT = double, bool REGDEEP = false>
