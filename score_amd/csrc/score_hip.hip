@@ -438,6 +438,7 @@ struct HipBackend {
     DevBuf<ChainDesc> chains, chainsH;         // chainsH / levelsH: the same chains with factors of their own (Newton matrix)
     DevBuf<ChainLevelDesc> levels, levelsH;
     DevBuf<PrecRecord> prec_rec, prec_recH;    // one record per work item: work + chain + level table (k_prec_pre)
+    DevBuf<int64_t> fac_rangeK, fac_rangeH;    // per chain: its factor range (k_fac_round_items)
     static constexpr int64_t kHelpEntries = (int64_t)kPrecThreads * kPrecChunk;  // vector entries per update helper
     int n_help = 0;                            // update-helper records appended to prec_rec / prec_recH
     DevBuf<int32_t> vb_first, vb_end, vb_prob; // blocks of <= 256 vector entries per problem (k_xupdate)
@@ -635,6 +636,7 @@ struct HipBackend {
         node_col.upload(h.node_col); diag_cols.upload(h.diag_cols);
         kblk_part_ptr.upload(h.rbK.part_ptr);
         prec_work.upload(h.prec_work); chains.upload(h.chains); levels.upload(h.levels);
+        fac_rangeK.upload(h.fac_range); fac_rangeH.upload(h.fac_range_H);
         factor_work.upload(h.factor_work);
         if (h.rep > 1) { chainsH.upload(h.chainsH); levelsH.upload(h.levelsH); }
         else { chainsH.view(chains.d, chains.n); levelsH.view(levels.d, levels.n); }
@@ -885,7 +887,10 @@ struct HipBackend {
         const int64_t nf = (int64_t)(newton_set ? H->fac_doubles_H : H->fac_doubles);
         if ((newton_set ? newton_fac32 : use_fac32) && nf > 0) {
             float* shadow = newton_set ? q_fac32.d : fac32.d;
-            hipLaunchKernelGGL(k_fac_round, dim3((unsigned)((nf + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, fa.fac, shadow, nf);
+            // (chain by chain, honouring the launch's skip flags: the Newton polish re-factors only the problems whose
+            //  active set has moved, and rounding the whole array again cost as much as re-factoring them)
+            hipLaunchKernelGGL(k_fac_round_items, dim3(16, (unsigned)np), dim3(kThreads), 0, stream, fa.work,
+                               (const int64_t*)(newton_set ? fac_rangeH.d : fac_rangeK.d), fa.skip, fa.fac, shadow);
             if (prec_reg)  // ... and the lane-major copy of the coarse levels the register-resident chain kernel loads
                 hipLaunchKernelGGL(k_deep_pack, dim3((unsigned)(deep_padded_slots(bs) / 4), (unsigned)np), dim3(kThreads), 0, stream, fa.work, fa.chains,
                                    fa.levels, (const int32_t*)deep_map.d, (const float*)shadow, newton_set ? deepH.d : deepK.d, fa.skip, bs * bs);

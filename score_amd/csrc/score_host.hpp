@@ -780,6 +780,7 @@ struct HostSystem {
     std::vector<double> kkt_bytes; // per problem: algorithmic bytes of one K-apply
 
     std::vector<int64_t> fac_off;  // per chain: offset of its records in `fac` (doubles)
+    std::vector<int64_t> fac_range, fac_range_H;  // per chain: [begin, end) of its factors in `fac` / in the Newton set
 
     // ---- row replication (score_problem::rep_d / rep_n, checked by check_replication) ----
     // rep > 1: every problem of the batch is  K = I_rep (x) K_row (+ tail).  Then K and G1 = A' hold the rows of
@@ -1586,6 +1587,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     pt.mark("chain positions");
     // level layout (structure only) + storage
     H.fac_off.clear();
+    H.fac_range.clear(); H.fac_range_H.clear();
     struct Layout { int N; std::vector<ChainLevelDesc> lv; size_t fac_size; int scr; int32_t map_off; };
     constexpr int kDeepLanes = 256;
     H.deep_ok = bs >= 1 && bs <= 3 && !H.chains.empty();
@@ -1633,6 +1635,8 @@ inline void build_system(const score_problem* probs, int count, const score_sett
                 L.offR += (int64_t)fac_total_H; L.offS += (int64_t)fac_total_H; L.offB += (int64_t)fac_total_H;
                 H.levelsH.push_back(L);
             }
+            H.fac_range_H.push_back((int64_t)fac_total_H);
+            H.fac_range_H.push_back((int64_t)(fac_total_H + fac_size));
             fac_total_H += fac_size;
             cH.scratch_off = (int32_t)scratch_H;
             cH.scratch_nodes = scr;
@@ -1648,12 +1652,16 @@ inline void build_system(const score_problem* probs, int count, const score_sett
                 H.levels.push_back(L);
             }
             H.fac_off.push_back(dbl_base);
+            H.fac_range.push_back(dbl_base);
+            H.fac_range.push_back(dbl_base + (int64_t)fac_size);
             fac_total += fac_size;
             ch.deep_off = (int32_t)H.deep_floats;
             H.deep_floats += deep_sz;
         } else {  // (owners precede their replicas)
             ch.level_begin = H.chains[(size_t)H.chain_owner[ci]].level_begin;
             H.fac_off.push_back(H.fac_off[(size_t)H.chain_owner[ci]]);
+            H.fac_range.push_back(H.fac_range[2 * (size_t)H.chain_owner[ci]]);
+            H.fac_range.push_back(H.fac_range[2 * (size_t)H.chain_owner[ci] + 1]);
             ch.deep_off = H.chains[(size_t)H.chain_owner[ci]].deep_off;
         }
         ch.scratch_off = (int32_t)H.scratch_nodes;

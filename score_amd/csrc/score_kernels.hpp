@@ -1999,6 +1999,20 @@ __global__ __launch_bounds__(kThreads) void k_fac_round(double* __restrict__ fac
     fac[i] = (double)f;
 }
 
+// k_fac_round for the chains of a work list only: block (x, w) rounds a slice of work item w's factor range.  What a
+// factorisation launch skipped (frozen problems, problems whose active set has not moved) is not touched.
+__global__ __launch_bounds__(kThreads) void k_fac_round_items(const PrecWork* __restrict__ work, const int64_t* __restrict__ range,
+                                                              const int32_t* skip, double* __restrict__ fac, float* __restrict__ fac32) {
+    const PrecWork wk = work[blockIdx.y];
+    if (wk.kind != 0 || (skip && skip[wk.prob])) return;
+    const int64_t b = range[2 * (size_t)wk.index], e = range[2 * (size_t)wk.index + 1];
+    for (int64_t i = b + (int64_t)blockIdx.x * kThreads + threadIdx.x; i < e; i += (int64_t)gridDim.x * kThreads) {
+        const float f = (float)fac[i];
+        fac32[i] = f;
+        fac[i] = (double)f;
+    }
+}
+
 // Lane-major copy of the coarse-level factors of every chain of the work list (HostSystem::deep_map): block (q, w) fills
 // 16-byte packet q of work item w's chain for the 256 staging lanes -- what k_prec_pre<.., float, true> loads straight into
 // registers.  Slot groups are padded to multiples of 4 (deep_padded_slot, score_host.hpp); b2 = block size squared.
