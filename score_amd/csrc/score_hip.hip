@@ -439,6 +439,8 @@ struct HipBackend {
     DevBuf<ChainLevelDesc> levels, levelsH;
     DevBuf<PrecRecord> prec_rec, prec_recH;    // one record per work item: work + chain + level table (k_prec_pre)
     DevBuf<int64_t> fac_rangeK, fac_rangeH;    // per chain: its factor range (k_fac_round_items)
+    DevBuf<int64_t> q_entpart;                 // per problem: its entry range in the Newton matrix
+    int64_t q_ent_max = 0;
     static constexpr int64_t kHelpEntries = (int64_t)kPrecThreads * kPrecChunk;  // vector entries per update helper
     int n_help = 0;                            // update-helper records appended to prec_rec / prec_recH
     DevBuf<int32_t> vb_first, vb_end, vb_prob; // blocks of <= 256 vector entries per problem (k_xupdate)
@@ -1575,6 +1577,13 @@ struct HipBackend {
         q_theta.upload(Q.theta); q_xstar.upload(Q.xstar);
         q_posd.upload(Q.pos_diag); q_poss.upload(Q.pos_sub); q_diagpos.upload(Q.diag_pos);
         q_hblk_part.upload(Q.rbH.part_ptr);
+        {   // entry range of every problem in H (k_hassemble runs problem by problem)
+            std::vector<int64_t> ep((size_t)h.count + 1);
+            q_ent_max = 0;
+            for (int p = 0; p <= h.count; ++p) ep[(size_t)p] = Q.Hm.ptr[(size_t)h.xoff[p]];
+            for (int p = 0; p < h.count; ++p) q_ent_max = std::max(q_ent_max, ep[(size_t)p + 1] - ep[(size_t)p]);
+            q_entpart.upload(ep);
+        }
         {
             std::vector<int32_t> longs;
             for (size_t e = 0; e + 1 < Q.cptr.size(); ++e)
@@ -1642,8 +1651,9 @@ struct HipBackend {
         ha.nnz = (int64_t)Q.Hm.col.size(); ha.Pon = q_Pon.d; ha.cptr = q_cptr.d; ha.ccone = q_ccone.d; ha.cab = q_cab.d;
         ha.ccoef = q_ccoef.d; ha.Bbuf = q_Bbuf.d; ha.T2 = Q.T * Q.T; ha.Hval = Hm.val.d;
         ha.ndiag = (int)h.diag_cols.size(); ha.diag_pos = q_diagpos.d; ha.dinv = q_dinv.d;
-        const int base_blocks = (int)((ha.nnz + kThreads - 1) / kThreads);
-        hipLaunchKernelGGL(k_hassemble, dim3((unsigned)(base_blocks + n_long)), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d, base_blocks);
+        ha.ent_part = q_entpart.d; ha.skip = q_skip.d;  // (the live mask: a frozen problem's matrix is not read any more)
+        const int base_blocks = (int)((q_ent_max + kThreads - 1) / kThreads);
+        hipLaunchKernelGGL(k_hassemble, dim3((unsigned)(base_blocks + n_long), (unsigned)h.count), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d, base_blocks);
         if (n_prec_items() && refactor) {  // chain factors and the reciprocal Jacobi diagonal, one launch
             FactorArgs fa{};
             fa.work = prec_work.d; fa.chains = chainsH.d; fa.levels = levelsH.d; fa.Hval = Hm.val.d;

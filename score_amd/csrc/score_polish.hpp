@@ -55,13 +55,19 @@ struct HAsmArgs {
     int ndiag;
     const int32_t* diag_pos;
     double* dinv;
+    // lock-step batches: entries [ent_part[q], ent_part[q + 1]) belong to problem q = blockIdx.y; a problem with
+    // skip[q] != 0 (frozen: converged or stalled) keeps its matrix -- nothing reads it any more
+    const int64_t* ent_part;
+    const int32_t* skip;
 };
 
 constexpr int kLongContrib = 64;  // entries with more contributions get a workgroup of their own
 
-// grid = ceil(nnz / 256) entry blocks followed by one block per long entry (k_hassemble_long's work)
+// grid.x = ceil(largest problem's entries / 256) entry blocks followed by one block per long entry (k_hassemble_long's
+// work), grid.y = problems
 __global__ __launch_bounds__(kThreads) void k_hassemble(HAsmArgs a, const int32_t* long_entries, int first_long_block) {
     if ((int)blockIdx.x >= first_long_block) {
+        if (blockIdx.y != 0) return;  // (the long entries: one workgroup each, whatever their problem)
         __shared__ double red[8];
         const int64_t pl = long_entries[blockIdx.x - first_long_block];
         const int c0 = a.cptr[pl], c1 = a.cptr[pl + 1];
@@ -71,8 +77,10 @@ __global__ __launch_bounds__(kThreads) void k_hassemble(HAsmArgs a, const int32_
         if (threadIdx.x == 0) a.Hval[pl] = a.Pon[pl] + v;
         return;
     }
-    const int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x;
-    if (p >= a.nnz) return;
+    const int q = blockIdx.y;
+    if (a.skip && a.skip[q]) return;
+    const int64_t p = a.ent_part[q] + (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (p >= a.ent_part[q + 1]) return;
     const int c0 = a.cptr[p], c1 = a.cptr[p + 1];
     if (c1 - c0 > kLongContrib) return;  // k_hassemble_long
     double v = a.Pon[p];
