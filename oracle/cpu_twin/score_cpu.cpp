@@ -25,6 +25,7 @@
 #include "../../score_amd/csrc/score_assemble.hpp"
 #include "../../score_amd/csrc/score_gn.hpp"
 #include "../../score_amd/csrc/score_round.hpp"
+#include "../../score_amd/csrc/score_polish_host.hpp"  // (layout checks only: band_check_h; the twin has no polish)
 
 namespace {
 
@@ -342,6 +343,75 @@ struct CpuBackend {
             const double v[3] = {(double)h.rep, (double)h.K.col.size(), (double)h.G1.col.size()};
             if (out && len > 0) std::memcpy(out, v, sizeof(double) * (size_t)std::min<int64_t>(len, 3));
             return 3;
+        }
+        else if (nm == "band_check" || nm == "band_check_h") {
+            // Layout check of the product's band view (score_band.hpp) on the host: build the view of K (as the
+            // backend would: owner chains, stored row segments) or of the Newton matrix pattern, fill V through dst,
+            // apply it with band_apply_host and compare with the CSR rows.
+            // -> [max |difference|, on, band tiles, csr tiles, diag tiles, slots, bytes of problem 0, source nnz, V size]
+            double res[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            const bool newton = nm == "band_check_h";
+            PolishData Q;
+            std::vector<double> hval;
+            const Csr* M = &h.K;
+            const double* mval = h.K.val.data();
+            BandLayout L;
+            int nr_rhs = h.rep;
+            if (newton) {
+                build_polish(h, Q, false, true);
+                if (!Q.available) return -1;
+                M = &Q.Hm;
+                hval.resize(Q.Hm.col.size());
+                for (size_t k = 0; k < hval.size(); ++k) hval[k] = Q.Pon[k] + 1e-3 * std::sin((double)k);  // (any values on the pattern)
+                mval = hval.data();
+                L = std::move(Q.band);
+                nr_rhs = 1;
+            } else {
+                std::vector<char> use(h.chains.size());
+                for (size_t ci = 0; ci < h.chains.size(); ++ci) use[ci] = h.chain_owner[ci] == (int32_t)ci;
+                std::vector<RowSegment> sg;
+                if (h.rep > 1) {
+                    for (int p = 0; p < h.count; ++p) {
+                        const int64_t nr = h.rep_n[(size_t)p];
+                        sg.push_back(RowSegment{h.xoff[p], h.xoff[p] + nr, p, (int32_t)nr});
+                        sg.push_back(RowSegment{h.xoff[p] + (int64_t)h.rep * nr, h.xoff[p + 1], p, 0});
+                    }
+                } else {
+                    sg = plain_segments(h.xoff);
+                }
+                L = build_band_layout(h.K, sg, band_runs(h.chains, use, h.bs, h.rep, h.rep_n, true), h.bs, h.count);
+            }
+            res[1] = L.on ? 1.0 : 0.0;
+            if (L.on) {
+                std::vector<double> V((size_t)L.v_size, 0.0), xv((size_t)h.n_tot), y0((size_t)h.n_tot, 0.0), y1((size_t)h.n_tot, 0.0);
+                for (size_t k = 0; k < L.dst.size(); ++k)
+                    if (L.dst[k] >= 0) V[(size_t)L.dst[k]] = mval[k];
+                for (int64_t i = 0; i < h.n_tot; ++i) xv[(size_t)i] = std::cos(0.37 * (double)i) + 1e-3 * (double)(i % 11);
+                band_apply_host(L, *M, V.data(), mval, nr_rhs, xv.data(), y1.data());
+                // reference: every stored row applied to its right-hand sides (a split long row counts with its first segment)
+                std::vector<char> covered((size_t)h.n_tot, 0);
+                double worst = 0.0;
+                for (int b = 0; b < L.nb(); ++b) {
+                    const int rs = L.rs[(size_t)b], nrep = rs > 0 ? nr_rhs : 1;
+                    const int32_t* m = &L.meta[4 * (size_t)b];
+                    const int kind = (int)((uint32_t)L.meta2[4 * (size_t)b + 3] >> 28);
+                    if (kind == BAND_KIND_CSR && m[1] - m[0] == 1 && m[2] != M->ptr[m[0]]) continue;  // a later segment
+                    for (int row = m[0]; row < m[1]; ++row)
+                        for (int q = 0; q < nrep; ++q) {
+                            double acc = 0.0;
+                            for (int k = M->ptr[row]; k < M->ptr[row + 1]; ++k) acc += mval[k] * xv[(size_t)M->col[k] + (size_t)q * rs];
+                            worst = std::max(worst, std::fabs(acc - y1[(size_t)row + (size_t)q * rs]) / (1.0 + std::fabs(acc)));
+                            covered[(size_t)row + (size_t)q * rs] += 1;
+                        }
+                }
+                for (int64_t i = 0; i < h.n_tot; ++i)
+                    if (covered[(size_t)i] != 1) worst = std::max(worst, 1e30);  // every unknown's row exactly once
+                res[0] = worst;
+                res[2] = L.n_band; res[3] = L.n_csr; res[4] = L.n_diag; res[5] = L.S; res[6] = L.bytes.empty() ? 0.0 : L.bytes[0];
+                res[7] = (double)M->col.size(); res[8] = (double)L.v_size;
+            }
+            if (out && len > 0) std::memcpy(out, res, sizeof(double) * (size_t)std::min<int64_t>(len, 9));
+            return 9;
         }
         else return -1;
         if (out) std::memcpy(out, src, sizeof(double) * (size_t)std::min(len, sz));

@@ -309,7 +309,14 @@ struct DevBuf {
 
 struct CsrBufs {
     DevBuf<int32_t> ptr, col, first_row, blk_prob, blk_rs, split;
-    DevBuf<int4> blk_meta;
+    DevBuf<int4> blk_meta, blk_long;
+    DevBuf<double> long_part;               // split long rows: kLongVals sums per segment
+    DevBuf<unsigned long long> long_cnt;    // ... and one arrival counter per row (never reset: a launch adds `segments`)
+    void alloc_long(int n_long, int n_slots) {
+        long_part.alloc((size_t)std::max(1, n_slots) * kLongVals);
+        long_cnt.alloc((size_t)std::max(1, n_long));
+        HIP_CHECK(hipMemsetAsync(long_cnt.d, 0, long_cnt.n * sizeof(unsigned long long), tl_copy_stream));
+    }
     DevBuf<double> val;
     int nblocks = 0;
     int rep = 1;     // right-hand sides per row of the replicated blocks (HostSystem::rep), 1 = plain rows only
@@ -331,14 +338,60 @@ struct CsrBufs {
         first_row.upload(rb.first_row);
         blk_prob.upload(rb.prob);
         blk_rs.upload(rb.rs);
-        std::vector<int4> meta(rb.nb());
-        for (int b = 0; b < rb.nb(); ++b)
-            meta[b] = make_int4(rb.first_row[b], rb.end_row[b], M.ptr[rb.first_row[b]], M.ptr[rb.end_row[b]]);
+        std::vector<int4> meta(rb.nb()), lg(rb.nb());
+        for (int b = 0; b < rb.nb(); ++b) {
+            const bool seg = rb.kbeg[b] >= 0;  // a segment of a split long row (kLongSeg)
+            meta[b] = make_int4(rb.first_row[b], rb.end_row[b], seg ? rb.kbeg[b] : M.ptr[rb.first_row[b]], seg ? rb.kend[b] : M.ptr[rb.end_row[b]]);
+            lg[b] = make_int4(rb.lfirst[b], rb.lseg[b], rb.lbase[b], rb.lid[b]);
+        }
         blk_meta.upload(meta);
+        blk_long.upload(lg);
+        alloc_long(rb.n_long, rb.n_long_slots);
         if (sp) split.upload(*sp);
         nblocks = rb.nb();
     }
-    CsrDev dev() const { return CsrDev{ptr.d, col.d, val.d, first_row.d, blk_prob.d, blk_meta.d, blk_rs.d, split.d, nblocks}; }
+    CsrDev dev() const { return CsrDev{ptr.d, col.d, val.d, first_row.d, blk_prob.d, blk_meta.d, blk_rs.d, split.d, nblocks, blk_long.d, long_part.d, long_cnt.d}; }
+};
+
+// Device side of a band view (score_band.hpp): the unified tile tables, V and the remainder arrays.  The source CsrBufs
+// keeps its pattern and values (the factor kernels, k_kval and the CSR tiles of the view read them).
+struct BandBufs {
+    bool on = false;
+    BandLayout L;  // host copy (part_ptr, dst, bytes)
+    DevBuf<double> V;
+    DevBuf<int32_t> rem_col, rowseg, dst, prob, rs, part_ptr;
+    DevBuf<int4> meta, meta2, lng;
+    DevBuf<double> long_part;
+    DevBuf<unsigned long long> long_cnt;
+    int nblocks = 0;
+    void upload(BandLayout&& l) {
+        L = std::move(l);
+        on = L.on;
+        if (!on) return;
+        nblocks = L.nb();
+        V.alloc((size_t)L.v_size + 64);
+        HIP_CHECK(hipMemsetAsync(V.d, 0, V.n * sizeof(double), tl_copy_stream));  // padding slots stay zero for ever
+        rem_col.upload_padded(L.rem_col, 64);
+        rowseg.upload(L.rowseg); dst.upload(L.dst); prob.upload(L.prob); rs.upload(L.rs); part_ptr.upload(L.part_ptr);
+        std::vector<int4> m((size_t)nblocks), m2((size_t)nblocks);
+        for (int b = 0; b < nblocks; ++b) {
+            m[(size_t)b] = make_int4(L.meta[4 * (size_t)b], L.meta[4 * (size_t)b + 1], L.meta[4 * (size_t)b + 2], L.meta[4 * (size_t)b + 3]);
+            m2[(size_t)b] = make_int4(L.meta2[4 * (size_t)b], L.meta2[4 * (size_t)b + 1], L.meta2[4 * (size_t)b + 2], L.meta2[4 * (size_t)b + 3]);
+        }
+        meta.upload(m); meta2.upload(m2);
+        std::vector<int4> lg((size_t)nblocks);
+        for (int b = 0; b < nblocks; ++b) lg[(size_t)b] = make_int4(L.lng[4 * (size_t)b], L.lng[4 * (size_t)b + 1], L.lng[4 * (size_t)b + 2], L.lng[4 * (size_t)b + 3]);
+        lng.upload(lg);
+        long_part.alloc((size_t)std::max(1, L.n_long_slots) * kLongVals);
+        long_cnt.alloc((size_t)std::max(1, L.n_long));
+        HIP_CHECK(hipMemsetAsync(long_cnt.d, 0, long_cnt.n * sizeof(unsigned long long), tl_copy_stream));
+    }
+    BandDev dev() const {
+        BandDev d{};
+        d.val = V.d; d.rem_col = rem_col.d; d.rowseg = rowseg.d; d.meta2 = meta2.d; d.rem0 = (int32_t)L.rem0; d.bs = L.bs;
+        for (int j = 0; j < kBandMaxS / 2; ++j) d.offw[j] = L.offw[j];
+        return d;
+    }
 };
 
 // The passes of the Ruiz equilibration on the device (RuizOffload, score_host.hpp): the raw P and A of ONE problem go
@@ -423,161 +476,44 @@ struct HipBackend {
     DevArena arena;  // declared before every buffer: destroyed after them
 
     CsrBufs K, G1, G2;
-    DevBuf<int32_t> A_ptr, A_col;
-    DevBuf<double> A_val;
-    DevBuf<double> q, b, invD, invE, rho, fac, dinv, K0d, K1d;
-    DevBuf<int32_t> kposd, kposs, kdiagpos;  // K.val positions of the chain blocks / Jacobi diagonals
-    DevBuf<int32_t> done, cone_row, cone_dim, cone_type, cone_block_first, cone_block_prob;
-    DevBuf<int4> cone_meta;
-    DevBuf<int2> cone_large;    // {cone, problem} of the cones with more than kWaveCone rows (k_cone_wave)
-    int n_large_cones = 0;
-    DevBuf<int32_t> cone_cols;  // 8 per cone (two int4)
-    DevBuf<double> cone_vals;   // 8 per cone (four double2)
-    DevBuf<int32_t> node_col, diag_cols, prec_part_ptr, kblk_part_ptr;
-    DevBuf<PrecWork> prec_work, factor_work;   // factor_work: what a factorisation of K visits (HostSystem::factor_work)
-    DevBuf<ChainDesc> chains, chainsH;         // chainsH / levelsH: the same chains with factors of their own (Newton matrix)
-    DevBuf<ChainLevelDesc> levels, levelsH;
-    DevBuf<PrecRecord> prec_rec, prec_recH;    // one record per work item: work + chain + level table (k_prec_pre)
-    DevBuf<int64_t> fac_rangeK, fac_rangeH;    // per chain: its factor range (k_fac_round_items)
-    DevBuf<int64_t> q_entpart;                 // per problem: its entry range in the Newton matrix
-    int64_t q_ent_max = 0;
-    static constexpr int64_t kHelpEntries = (int64_t)kPrecThreads * kPrecChunk;  // vector entries per update helper
-    int n_help = 0;                            // update-helper records appended to prec_rec / prec_recH
-    DevBuf<int32_t> vb_first, vb_end, vb_prob; // blocks of <= 256 vector entries per problem (k_xupdate)
-    int n_vblocks = 0;
-    DevBuf<double> xtu, xy, s, r, z, p, p2, w, kx, step;
-    DevBuf<double> pw_part, rz_part0, rz_part1, rz_meas0, rz_meas1, pres_part, dres_part;
-    // ---- semismooth-Newton polish (score_polish*.hpp) ----
-    DevBuf<float> fac32, q_fac32;  // float copies of the chain factors (ADMM / Newton), see k_fac_round
-    DevBuf<float> deepK, deepH;    // lane-major copies of their coarse levels (k_deep_pack -> k_prec_pre<.., float, true>)
-    DevBuf<int32_t> deep_map;
-    bool prec_reg = false;         // every chain has a lane plan: the register-resident variant serves the 4-byte streams
-    size_t prec_reg_lds = 0;
-    bool use_fac32 = false;     // ADMM-loop factors (K)
-    bool newton_fac32 = false;  // Newton-polish factors (H): fac_fp32 = 2 only, see DESIGN.md section 4
-    PolishData Q;
-    std::future<void> polish_build;  // build_polish runs beside the uploads of init()
-    CsrBufs Hm;
-    DevBuf<double> q_Pon, q_ccoef, q_Bbuf, q_fpart, q_X0, q_X1, q_g, q_delta, q_fac, q_dinv, q_work, q_dummy, q_gd, q_pw;
-    DevBuf<double> q_aabs, q_ck, q_theta, q_xstar;
-    DevBuf<int32_t> q_cptr, q_ccone, q_cab, q_head, q_ishead, q_posd, q_poss, q_diagpos, q_hblk_part, q_long;
-    int n_long = 0;
-    // lock-step polish of a batch (count > 1)
-    DevBuf<int32_t> q_skip, q_reref, q_fskip, q_act;  // (q_skip, q_reref, q_fskip: views into ctl)
-    DevBuf<double> q_step;
-    DevBuf<int64_t> q_seg_begin, q_seg_end;
-    static constexpr int kFlagSlots = 32;
-    char* h_ring = nullptr;      // pinned (host-mapped) ring of upload slots
-    size_t ring_slot_bytes = 0;
-    int flag_slot = 0, ring_used = 0;
-    DevBuf<double> q_negg;                   // -gradient of the last evaluation (right-hand side of the next PCG)
-    DevBuf<double> q_gate_tol2, q_gate_ref;  // device-side PCG termination (pcg_gate)
-    DevBuf<int32_t> q_gate_used;
-    int32_t* h_gate = nullptr;   // [gate flags | iterations used]          } windows into h_rep
-    double* h_gd = nullptr;      // partials of g'delta                      }
-    // Everything the host reads back between launches lives in ONE device allocation, mirrored by
-    // one pinned host buffer, so that a convergence check (ADMM) or a Newton iteration costs a
-    // single device-to-host copy:  [pres | dres | fpart | gd | gate flags, gate counts]
-    DevBuf<double> rep;          // window: the device address of h_rep (host-mapped pinned memory)
-    double* h_rep = nullptr;
-    size_t h_rep_bytes = 0, h_ring_bytes = 0;
-    size_t rep_dres_off = 0;     // doubles
-    // Kernels write their per-workgroup partials straight into that host-mapped memory; small device
-    // arrays the device itself reads (r'z measurements, PCG gate words) are pushed there by k_push,
-    // which then publishes a sequence number the host spins on: no copy command, no stream
-    // synchronisation on the path of a convergence check or a Newton iteration.
-    unsigned long long* h_seq = nullptr;   // [0]: last published sequence number (host-mapped)
-    unsigned long long* d_seq = nullptr;
-    unsigned long long seq_next = 0;
-    double* h_meas = nullptr;    // [rz_meas0 | rz_meas1] as pushed
-    double* d_meas = nullptr;
-    int32_t* d_gate_host = nullptr;  // device address of h_gate
-    char* d_ring = nullptr;      // device address of h_ring
-    size_t n_fpart = 0, n_gd = 0;
-    // ... and everything the host tells the kernels per problem in one upload: [step | tol2 | skip]
-    DevBuf<double> ctl;
-    DevBuf<int32_t> q_pcgdone;   // window into rep: raised by pcg_gate
-    int pcg_used_total = 0;
-    double newton_eta_max = 1e-1;  // inexact Newton: linear residual <= min(eta_max, coef * |g|^pow)
-    double newton_eta_coef = 1.0, newton_eta_pow = 0.5;
-    double* h_newton = nullptr;  // window into h_rep: partials of the cone part of F
-
-    int cg_iters = 2;
-    const double* last_rz = nullptr;  // r'z partials / direction of the pending end-of-PCG update
-    const double* last_p = nullptr;
-    double* h_pres = nullptr;  // pinned
-    double* h_dres = nullptr;
-    int n_cone_blocks = 0, n_prec = 0;  // n_prec: work items of the ACTIVE preconditioner launch (split or not)
-    // split chain kernel (score_split.hpp / score_prec_wave.hpp)
-    SplitSystem split;
-    std::vector<int32_t> active_part_ptr;   // host copy of the active per-problem work ranges
-    DevBuf<PrecWork> split_work;
-    DevBuf<SplitItem> split_items;
-    DevBuf<SplitPlan> split_plans;
-    DevBuf<int32_t> split_stage;
-    DevBuf<double> split_xbuf;
-    DevBuf<unsigned int> split_xflag, split_epoch;
-    size_t split_lds = 0;
-    unsigned long long split_poll_limit = 0;
-    size_t prec_lds = 0;
-    bool prec_lds0 = true;
-    bool prec_pre = false;  // every chain fits the lane budget of k_prec_pre (4 x 4 blocks: with the 4-byte factor stream only)
-    size_t prec_pre_lds = 0;
-    static bool n_prec_chains(const HostSystem& h) { return !h.chains.empty(); }
-
-    ~HipBackend() {
-        PhaseTimer pt(st.verbose != 0);
-        if (stream) (void)hipStreamSynchronize(stream);
-        pt.mark("destroy: sync");
-        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-        pt.mark("destroy: graph");
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-        block_cache().give(h_rep, h_rep_bytes, st.device, true);
-        block_cache().give(h_ring, h_ring_bytes, st.device, true);
-        pt.mark("destroy: events, pinned blocks");
-        stream_pool().give(st.device, stream);  // (drained above)
-        pt.mark("destroy: stream");
+    BandBufs Kb, Hb;  // band views of K and of the Newton matrix (score_band.hpp); off: the CSR-stream kernels serve them
+    // SCORE_BAND_K / SCORE_BAND_H = 0 / 1 force a view off / on (experiments); default: see band_k() / band_h()
+    static int band_env(const char* name) { const char* e = std::getenv(name); return e ? std::atoi(e) : -1; }
+    bool band_k(const HostSystem&) const {
+        // K through its band view whatever the batch size (what a problem computes must not depend on its batch mates: the two
+        // layouts add a row's terms in different orders).  A lock-step batch streams K from HBM and the view moves 19 % fewer
+        // bytes: batch of 16 headline problems kp 46 -> 34 us, kpb 50 -> 40 us; a single problem's product is a chain of
+        // dependent trips bound by its slowest workgroup (the landmark rows' segments): 6.4 / 7.1 us either way.
+        const int e = band_env("SCORE_BAND_K");
+        return std::getenv("SCORE_NO_BAND") == nullptr && (e >= 0 ? e != 0 : true);
     }
-
-    void init(const HostSystem& h, const score_settings& s_) {
-        H = &h;
-        st = s_;
-        PhaseTimer pt(st.verbose != 0);
-        int ndev = 0;
-        hipError_t e = hipGetDeviceCount(&ndev);
-        if (e != hipSuccess || ndev <= 0)
-            throw std::runtime_error("no HIP device available (the SCORE solver has no CPU fallback)");
-        if (st.device < 0 || st.device >= ndev) throw std::runtime_error("score_settings.device out of range");
-        HIP_CHECK(hipSetDevice(st.device));
-        arena.dev = st.device;
-        stream = stream_pool().take(st.device);
-        tl_copy_stream = stream;
-        struct ArenaScope {  // buffers allocated during init come from this handle's arena
-            explicit ArenaScope(DevArena* a) { tl_arena = a; }
-            ~ArenaScope() { tl_arena = nullptr; }
-        } arena_scope(&arena);
-        HIP_CHECK(hipEventCreate(&ev0));
-        HIP_CHECK(hipEventCreate(&ev1));
-        pt.mark("device + stream");
-        if (h.bs != 0 && h.bs != 3 && h.bs != 4 && h.bs != 1 && h.bs != 2)
-            throw std::runtime_error("unsupported block size");
-        struct JoinPolish {  // an exception below must not leave the builder running against a dying handle
-            std::future<void>& f;
-            ~JoinPolish() { if (f.valid()) f.wait(); }
-        } join_polish{polish_build};
-        // the Newton matrix pattern and its contribution lists only read the finished host system:
-        // built on another thread while this one uploads (4.3 ms beside 2.4 ms of uploads / allocations)
-        if (st.polish) polish_build = std::async(std::launch::async, [this, &h] { build_polish(h, Q, st.verbose != 0); });
-        K.upload(h.K, h.rbK);
-        G1.upload(h.G1, h.rbG1);
-        G2.upload(h.G2, h.rbG2, &h.g2_split);
-        // replicated problems (HostSystem::rep): K and G1 = A' hold replica 0's rows; K's operands repeat with the
-        // block's replica stride, G1's are the consecutive tail rows of a cone
-        K.rep = h.rep; K.rs_in = 0;
-        G1.rep = h.rep; G1.rs_in = 1;
-        K.unroll = (h.rep > 1) ? h.tile_nnz / kThreads : kUnroll;
-        G1.unroll = (h.rep > 1) ? kUnroll / 2 : kUnroll;  // (tiles of at most kTileNnz / 2 nonzeros, see build_system)
+    bool band_h(const HostSystem&) const {
+        // the Newton matrix: measured without effect (64 config-5 trials in lock-step handles of 16: 7.0 ms per solve with and
+        // without; headline default solve 4.5 ms either way) -- the view costs setup time, so it stays off (SCORE_BAND_H=1)
+        const int e = band_env("SCORE_BAND_H");
+        return std::getenv("SCORE_NO_BAND") == nullptr && e > 0;
+    }
+        if (band_k(h) && !h.chains.empty()) {  // band view of K: the chain rows without column indices (score_band.hpp)
+            std::vector<char> use(h.chains.size());
+            for (size_t ci = 0; ci < h.chains.size(); ++ci) use[ci] = h.chain_owner[ci] == (int32_t)ci;
+            std::vector<RowSegment> sg;
+            if (h.rep > 1) {
+                for (int p = 0; p < h.count; ++p) {
+                    const int64_t nr = h.rep_n[(size_t)p];
+                    sg.push_back(RowSegment{h.xoff[p], h.xoff[p] + nr, p, (int32_t)nr});
+                    sg.push_back(RowSegment{h.xoff[p] + (int64_t)h.rep * nr, h.xoff[p + 1], p, 0});
+                }
+            } else {
+                sg = plain_segments(h.xoff);
+            }
+            Kb.upload(build_band_layout(h.K, sg, band_runs(h.chains, use, h.bs, h.rep, h.rep_n, true), h.bs, h.count));
+            if (Kb.on)
+                for (int p = 0; p < h.count; ++p) h.kkt_bytes[(size_t)p] = Kb.L.bytes[(size_t)p] + 16.0 * (double)(h.xoff[p + 1] - h.xoff[p]);
+            if (st.verbose)
+                std::fprintf(stderr, "[score setup] band view of K: %s (%d band + %d csr + %d diag tiles, %d slots per row)\n", Kb.on ? "on" : "off",
+                             Kb.L.n_band, Kb.L.n_csr, Kb.L.n_diag, Kb.L.S);
+            pt.mark("band view of K");
+        }
         {
             std::vector<int32_t> vf, ve, vp;
             for (int p = 0; p < h.count; ++p)
@@ -636,7 +572,7 @@ struct HipBackend {
             if (n_large_cones) cone_large.upload(lg);
         }
         node_col.upload(h.node_col); diag_cols.upload(h.diag_cols);
-        kblk_part_ptr.upload(h.rbK.part_ptr);
+        kblk_part_ptr.upload(Kb.on ? Kb.L.part_ptr : h.rbK.part_ptr);
         prec_work.upload(h.prec_work); chains.upload(h.chains); levels.upload(h.levels);
         fac_rangeK.upload(h.fac_range); fac_rangeH.upload(h.fac_range_H);
         factor_work.upload(h.factor_work);
@@ -770,7 +706,7 @@ struct HipBackend {
         }
         xtu.alloc(h.n_tot + h.m_tot); xy.alloc(h.n_tot + h.m_tot); s.alloc(h.m_tot);
         r.alloc(h.n_tot); z.alloc(h.n_tot); p.alloc(h.n_tot); p2.alloc(h.n_tot); w.alloc(h.n_tot); kx.alloc(h.n_tot); step.alloc(h.count);
-        pw_part.alloc(K.nblocks); rz_part0.alloc(n_prec); rz_part1.alloc(n_prec);
+        pw_part.alloc(kblocks()); rz_part0.alloc(n_prec); rz_part1.alloc(n_prec);
         rz_meas0.alloc(n_prec); rz_meas1.alloc(n_prec);
         cg_iters = st.cg_iters;
         std::vector<int32_t> dz(h.count, 0);
@@ -845,6 +781,11 @@ struct HipBackend {
         }
         hipLaunchKernelGGL(k_kval, dim3(K.nblocks), dim3(kThreads), 0, stream, K.dev(), (const double*)K0d.d, (const double*)K1d.d,
                            (const double*)rho.d, K.val.d, (const int32_t*)nullptr);
+        if (Kb.on) {
+            const int64_t nnz = (int64_t)h.K.col.size();
+            hipLaunchKernelGGL(k_band_pack, dim3((unsigned)((nnz + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, (const int32_t*)Kb.dst.d,
+                               (const double*)K.val.d, Kb.V.d, nnz);
+        }
         if (!h.factor_work.empty()) {
             FactorArgs fa{};
             fa.work = factor_work.d; fa.chains = chains.d; fa.levels = levels.d; fa.Hval = K.val.d;
@@ -911,7 +852,7 @@ struct HipBackend {
         a.alpha_relax = st.alpha; a.invE = invE.d; a.pres_part = pres_part.d;
         a.apply_alpha = 0; a.pfin = p.d; a.pw_in = pw_part.d; a.rz_in = rz_part0.d;
         a.prec_part_ptr = prec_part_ptr.d; a.kblk_part_ptr = kblk_part_ptr.d; a.step_out = step.d;
-        a.uni = uni_for(K.nblocks);
+        a.uni = uni_for(kblocks());
         a.skip_large = n_large_cones > 0 ? 1 : 0;
         return a;
     }
@@ -1092,9 +1033,9 @@ struct HipBackend {
     // 48.0 -> 45.6 us (3.06 -> 3.23 TB/s), single problem 8.2 -> 7.8 us; kpb and rhs gain 2-3 %.
     bool xcd_spmv = std::getenv("SCORE_NO_XCD_SPMV") == nullptr;
     unsigned xcd_grid(SpmvArgs& a, int nblocks) const {
-        if (!xcd_spmv || nblocks < 16) { a.xcd_chunk = 0; a.n_tiles = nblocks; return (unsigned)nblocks; }
-        a.xcd_chunk = (nblocks + 7) / 8;
         a.n_tiles = nblocks;
+        if (!xcd_spmv || nblocks < 16) { a.xcd_chunk = 0; return (unsigned)nblocks; }
+        a.xcd_chunk = (nblocks + 7) / 8;
         return (unsigned)(8 * a.xcd_chunk);
     }
     // partial-sum ranges by value for single-problem handles (UniRanges, score_kernels.hpp); kblocks = row blocks of the
@@ -1107,9 +1048,38 @@ struct HipBackend {
         u.k0 = 0; u.k1 = kblocks;
         return u;
     }
+    // K / H product over a band view: the view's tile tables replace the source matrix's
+    template <int MODE, int NR>
+    void launch_band_s(const BandBufs& Bv, const SpmvArgs& a, unsigned grid, int slot) {
+        if (Bv.L.S == 8) launch_on_stream(k_spmv_band<MODE, NR, 4>, dim3(grid), dim3(kThreads), 0, slot, a);
+        else if (Bv.L.S == 10) launch_on_stream(k_spmv_band<MODE, NR, 5>, dim3(grid), dim3(kThreads), 0, slot, a);
+        else launch_on_stream(k_spmv_band<MODE, NR, 6>, dim3(grid), dim3(kThreads), 0, slot, a);
+    }
+    template <int MODE>
+    void launch_band(const CsrBufs& M, const BandBufs& Bv, const SpmvArgs& a_in, int slot = -1) {
+        SpmvArgs a = a_in;
+        a.M.blk_meta = Bv.meta.d; a.M.blk_prob = Bv.prob.d; a.M.blk_rs = Bv.rs.d; a.M.nblocks = Bv.nblocks;
+        a.M.blk_long = Bv.lng.d; a.M.long_part = Bv.long_part.d; a.M.long_cnt = Bv.long_cnt.d;
+        a.B = Bv.dev();
+        const unsigned grid = xcd_grid(a, Bv.nblocks);
+        if (M.rep == 2) launch_band_s<MODE, 2>(Bv, a, grid, slot);
+        else if (M.rep == 3) launch_band_s<MODE, 3>(Bv, a, grid, slot);
+        else launch_band_s<MODE, 1>(Bv, a, grid, slot);
+    }
+    // the products with the Newton matrix (plain rows)
+    template <int MODE>
+    void launch_h(const SpmvArgs& a_in) {
+        if (Hb.on) { launch_band<MODE>(Hm, Hb, a_in); return; }
+        SpmvArgs a = a_in;
+        const unsigned grid = xcd_grid(a, Hm.nblocks);
+        hipLaunchKernelGGL(k_spmv<MODE>, dim3(grid), dim3(kThreads), 0, stream, a);
+    }
     template <int MODE>
     void launch_spmv(const CsrBufs& M, const SpmvArgs& a_in, int slot = -1) {
         static_assert(MODE == MODE_RHS || MODE == MODE_KP || MODE == MODE_KPB, "the residual / gradient modes run on plain rows (G2, H)");
+        if constexpr (MODE != MODE_RHS) {
+            if (&M == &K && Kb.on) { launch_band<MODE>(K, Kb, a_in, slot); return; }
+        }
         SpmvArgs a = a_in;
         const unsigned grid = xcd_grid(a, M.nblocks);
         const bool half = (M.unroll == kUnroll / 2);
@@ -1123,10 +1093,11 @@ struct HipBackend {
     SpmvArgs spmv_args(const CsrBufs& M, const double* xin) {
         SpmvArgs a{};
         a.M = M.dev(); a.xin = xin; a.done = done.d; a.rs_in = M.rs_in;
+        a.n_tiles = M.nblocks;  // (a launch through xcd_grid restates it)
         a.x = xy.d; a.q = q.d; a.kx = kx.d; a.r = r.d; a.sigma = H->sigma;
         a.p = p.d; a.w = w.d; a.pw_part = pw_part.d;
         a.prec_part_ptr = prec_part_ptr.d; a.kblk_part_ptr = kblk_part_ptr.d;
-        a.uni = uni_for(K.nblocks);
+        a.uni = uni_for(kblocks());
         a.apply_update = 0; a.pfin = p.d; a.wfin = w.d; a.xt_rw = xtu.d; a.kx_rw = kx.d; a.x_rw = xy.d;
         a.alpha_relax = st.alpha; a.step_in = step.d;
         a.invD = invD.d; a.dres_part = dres_part.d;
@@ -1188,7 +1159,7 @@ struct HipBackend {
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.rec = prec_rec.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = done.d;
-        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d; pa.uni = uni_for(K.nblocks);
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d; pa.uni = uni_for(kblocks());
         pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d;
         pa.pw_part = pw_part.d;
         double* rz_cur = measure ? rz_meas0.d : rz_part0.d;
@@ -1251,7 +1222,7 @@ struct HipBackend {
         HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, st.device));
         if (khz <= 0) throw std::runtime_error("score_time_iteration: no wall clock rate");
         for (int k = 0; k < 12; ++k) us[k] = 0.0;
-        const int maxb = std::max(std::max(G1.nblocks, K.nblocks) + 8, std::max(n_prec + n_help, n_cone_blocks + 8));  // (grids: XCD rounding, update helpers)
+        const int maxb = std::max(std::max(G1.nblocks, kblocks()) + 8, std::max(n_prec + n_help, n_cone_blocks + 8));  // (grids: XCD rounding, update helpers)
         ts_stride = (size_t)2 * maxb;
         const size_t per_iter = 6 * ts_stride, nslot = per_iter * iters;
         {
@@ -1273,6 +1244,19 @@ struct HipBackend {
                     for (int b = 0; b < maxb; ++b) { t0 = std::min(t0, p[2 * b]); t1 = std::max(t1, p[2 * b + 1]); }
                     if (t1 > t0) us[k] += (double)(t1 - t0) * 1e3 / (double)khz / iters;
                 }
+            if (std::getenv("SCORE_DUMP_STAMPS")) {
+                // per-workgroup timeline of the last timed iteration: kernel, workgroup, entry and exit in us after the
+                // iteration's first entry (stdout; profiles/scripts/r04_timeline.py draws it)
+                const unsigned long long* base = &hts[per_iter * (size_t)(iters - 1)];
+                unsigned long long t00 = ~0ull;
+                for (size_t j = 0; j < per_iter; j += 2) t00 = std::min(t00, base[j]);
+                for (int k = 0; k < 6; ++k)
+                    for (int b = 0; b < maxb; ++b) {
+                        const unsigned long long a0 = base[ts_stride * k + 2 * (size_t)b], a1 = base[ts_stride * k + 2 * (size_t)b + 1];
+                        if (a0 == ~0ull || a1 == 0ull) continue;
+                        std::printf("STAMP %d %d %.3f %.3f\n", k, b, (double)(a0 - t00) * 1e3 / (double)khz, (double)(a1 - t00) * 1e3 / (double)khz);
+                    }
+            }
         }
         if (!with_events) return;
         std::vector<hipEvent_t> evs((size_t)12 * iters, nullptr);
@@ -1423,7 +1407,7 @@ struct HipBackend {
                 PrecArgs pa{};
                 pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.rec = prec_recH.d; pa.fac = q_fac.d;
                 pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = q_skip.d;
-                pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d; pa.uni = uni_for(Hm.nblocks);
+                pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d; pa.uni = uni_for(hblocks());
                 pa.r = r.d; pa.r_in = q_negg.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d;
                 pa.pw_part = q_pw.d; pa.rz_in = nullptr; pa.rz_out = rz_part0.d;
                 launch_prec<PREC_INIT>(pa);
@@ -1512,7 +1496,7 @@ struct HipBackend {
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.rec = prec_rec.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = lin_flag.d;
-        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d; pa.uni = uni_for(K.nblocks);
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d; pa.uni = uni_for(kblocks());
         pa.r = r.d; pa.r_in = rhs_dev; pa.z = z.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d; pa.pw_part = pw_part.d;
         pa.gate_used = lin_flag.d + 1;
         pa.early_done = 1;
@@ -1576,7 +1560,11 @@ struct HipBackend {
         q_head.upload(Q.head_col); q_ishead.upload(Q.is_head); q_aabs.upload(Q.a_abs); q_ck.upload(Q.ck);
         q_theta.upload(Q.theta); q_xstar.upload(Q.xstar);
         q_posd.upload(Q.pos_diag); q_poss.upload(Q.pos_sub); q_diagpos.upload(Q.diag_pos);
-        q_hblk_part.upload(Q.rbH.part_ptr);
+        Hb.upload(std::move(Q.band));
+        if (st.verbose)
+            std::fprintf(stderr, "[score setup] band view of H: %s (%d band + %d csr + %d diag tiles, %d slots per row)\n", Hb.on ? "on" : "off",
+                         Hb.L.n_band, Hb.L.n_csr, Hb.L.n_diag, Hb.L.S);
+        q_hblk_part.upload(Hb.on ? Hb.L.part_ptr : Q.rbH.part_ptr);
         {   // entry range of every problem in H (k_hassemble runs problem by problem)
             std::vector<int64_t> ep((size_t)h.count + 1);
             q_ent_max = 0;
@@ -1602,7 +1590,7 @@ struct HipBackend {
         if (newton_fac32) { q_fac32.alloc(h.fac_doubles_H); q_fac32.zero(stream); }
         if (newton_fac32 && prec_reg) deepH.alloc((size_t)std::max<int64_t>(1, h.deep_floats_H));
         n_gd = std::max<size_t>((h.n_tot + kThreads - 1) / kThreads, (size_t)Hm.nblocks);
-        q_pw.alloc(Hm.nblocks);
+        q_pw.alloc(hblocks());
         {
             q_gate_ref.alloc(h.count);
             std::vector<int64_t> sb(2 * h.count), se(2 * h.count);
@@ -1650,6 +1638,7 @@ struct HipBackend {
         HAsmArgs ha{};
         ha.nnz = (int64_t)Q.Hm.col.size(); ha.Pon = q_Pon.d; ha.cptr = q_cptr.d; ha.ccone = q_ccone.d; ha.cab = q_cab.d;
         ha.ccoef = q_ccoef.d; ha.Bbuf = q_Bbuf.d; ha.T2 = Q.T * Q.T; ha.Hval = Hm.val.d;
+        ha.dst = Hb.on ? Hb.dst.d : nullptr; ha.V = Hb.on ? Hb.V.d : nullptr;
         ha.ndiag = (int)h.diag_cols.size(); ha.diag_pos = q_diagpos.d; ha.dinv = q_dinv.d;
         ha.ent_part = q_entpart.d; ha.skip = q_skip.d;  // (the live mask: a frozen problem's matrix is not read any more)
         const int base_blocks = (int)((q_ent_max + kThreads - 1) / kThreads);
@@ -1761,7 +1750,7 @@ struct HipBackend {
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.rec = prec_recH.d; pa.fac = q_fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = q_skip.d;
-        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d; pa.uni = uni_for(Hm.nblocks);
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d; pa.uni = uni_for(hblocks());
         pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d; pa.pw_part = q_pw.d;
         pa.gate_used = q_gate_used.d;
         pa.early_done = 1;  // launches queued beyond the gate are no-ops: keep them cheap
@@ -1777,8 +1766,7 @@ struct HipBackend {
             pa.gate_init = nullptr;
             SpmvArgs a = spmv_args(Hm, pcg_p_cur);
             a.p = pcg_p_cur; a.pw_part = q_pw.d; a.done = q_skip.d;
-            const unsigned grid = xcd_grid(a, Hm.nblocks);  // (sets a.xcd_chunk: before the launch copies `a`)
-            hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(grid), dim3(kThreads), 0, stream, a);
+            launch_h<MODE_KP>(a);
         } else {
             // flags of the problems that go on: lowered again (their gates had not fired; the host's skip
             // flags now hold exactly the resumed set)
@@ -1797,14 +1785,12 @@ struct HipBackend {
             SpmvArgs a = spmv_args(Hm, pcg_p_cur);
             a.p = pcg_p_cur; a.z = z.d; a.p_out = pcg_p_oth; a.rz_new = rz_nxt; a.rz_old = pcg_rz_cur; a.pw_part = q_pw.d; a.done = q_pcgdone.d;
             a.early_done = 1;
-            const unsigned grid = xcd_grid(a, Hm.nblocks);
-            hipLaunchKernelGGL(k_spmv<MODE_KPB>, dim3(grid), dim3(kThreads), 0, stream, a);
+            launch_h<MODE_KPB>(a);
             std::swap(pcg_p_cur, pcg_p_oth);
             if (++pcg_steps_queued % kDirectEvery == 0) {  // (see linear_solve_core)
                 SpmvArgs d = spmv_args(Hm, pcg_p_cur);
                 d.p = pcg_p_cur; d.pw_part = q_pw.d; d.done = q_pcgdone.d; d.early_done = 1;
-                const unsigned dgrid = xcd_grid(d, Hm.nblocks);
-                hipLaunchKernelGGL(k_spmv<MODE_KP>, dim3(dgrid), dim3(kThreads), 0, stream, d);
+                launch_h<MODE_KP>(d);
             }
             pcg_rz_cur = rz_nxt;
         }
@@ -2011,7 +1997,7 @@ struct HipBackend {
         PrecArgs pa{};
         pa.work = prec_work.d; pa.chains = chains.d; pa.levels = levels.d; pa.rec = prec_rec.d; pa.fac = fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = dinv.d; pa.done = done.d;
-        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d; pa.uni = uni_for(K.nblocks);
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = kblk_part_ptr.d; pa.uni = uni_for(kblocks());
         pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.p = p.d; pa.w = w.d; pa.xt = xtu.d; pa.kx = kx.d;
         pa.pw_part = pw_part.d; pa.rz_in = rz_part0.d; pa.rz_out = rz_part1.d;
         VecArgs va{};

@@ -43,6 +43,11 @@ namespace score {
 constexpr int kRowsPerBlock = 256;  // rows (= threads) per SpMV workgroup
 constexpr int kTileNnz = 2048;      // products staged in LDS per workgroup (16 KiB); 2048 measured best of 1536..4608
 constexpr int kLongRow = 48;        // rows longer than this get a workgroup of their own
+constexpr int kLongSeg = 512;       // ... and beyond this many nonzeros several: segments of <= kLongSeg (2 per lane), whose sums the
+                                    // last segment to finish adds in segment order (spmv_tile).  A landmark seen by 2000 ranges was the
+                                    // last workgroup of every K product to leave (7.5 us against 3.8 us for the median tile)
+constexpr int kLongSegMax = 256;    // segments per row at most (longer rows: longer segments)
+constexpr int kLongVals = 4;        // sums a segment publishes (up to 3 right-hand sides, or P and A' parts)
 constexpr int kConesPerBlock = 256;
 constexpr int kMaxBs = 4;
 
@@ -307,6 +312,10 @@ struct RowBlocks {
     std::vector<int32_t> prob;       // nb
     std::vector<int32_t> rs;         // nb: replica stride of a block of replicated rows (see HostSystem::rep), 0 = plain rows
     std::vector<int32_t> part_ptr;   // count + 1 : block range of each problem
+    // segments of split long rows (kLongSeg): per block its nonzero range [kbeg, kend) (-1: the block's whole rows) and
+    // {first block of the row, segments | segment << 16, first partial-sum slot, long-row ordinal} (segments == 0: none)
+    std::vector<int32_t> kbeg, kend, lfirst, lseg, lbase, lid;
+    int n_long = 0, n_long_slots = 0;
     int nb() const { return (int)prob.size(); }
 };
 // A contiguous range of matrix rows to be tiled: plain rows (rs == 0) or rows of replica 0 whose results
@@ -777,7 +786,7 @@ struct HostSystem {
     std::vector<int32_t> prec_part_ptr;  // count + 1
 
     std::vector<double> rho;       // per problem
-    std::vector<double> kkt_bytes; // per problem: algorithmic bytes of one K-apply
+    mutable std::vector<double> kkt_bytes; // per problem: algorithmic bytes of one K-apply (a backend that streams another layout of K restates it)
 
     std::vector<int64_t> fac_off;  // per chain: offset of its records in `fac` (doubles)
     std::vector<int64_t> fac_range, fac_range_H;  // per chain: [begin, end) of its factors in `fac` / in the Newton set
@@ -834,9 +843,22 @@ inline RowBlocks make_rowblocks(const Csr& M, const std::vector<RowSegment>& seg
             rb.prob.push_back(sg.prob);
             rb.rs.push_back(sg.rs);
             int64_t len0 = M.ptr[r + 1] - M.ptr[r];
-            if (len0 > kLongRow) {  // a long row is a block of its own
+            if (len0 > kLongRow) {  // a long row is a block of its own -- or several (kLongSeg)
+                static const bool no_split = std::getenv("SCORE_NO_LONG_SPLIT") != nullptr;
+                const int nseg = (len0 > kLongSeg && !no_split) ? (int)std::min<int64_t>(kLongSegMax, (len0 + kLongSeg - 1) / kLongSeg) : 1;
+                const int32_t bfirst = (int32_t)rb.prob.size() - 1;
+                for (int sgi = 0; sgi < nseg; ++sgi) {
+                    if (sgi) { rb.first_row.push_back((int32_t)r); rb.prob.push_back(sg.prob); rb.rs.push_back(sg.rs); }
+                    rb.end_row.push_back((int32_t)(r + 1));
+                    rb.kbeg.push_back(nseg > 1 ? (int32_t)(M.ptr[r] + len0 * sgi / nseg) : -1);
+                    rb.kend.push_back(nseg > 1 ? (int32_t)(M.ptr[r] + len0 * (sgi + 1) / nseg) : -1);
+                    rb.lfirst.push_back(bfirst);
+                    rb.lseg.push_back(nseg > 1 ? (nseg | (sgi << 16)) : 0);
+                    rb.lbase.push_back(rb.n_long_slots);
+                    rb.lid.push_back(rb.n_long);
+                }
+                if (nseg > 1) { rb.n_long_slots += nseg; ++rb.n_long; }
                 ++r;
-                rb.end_row.push_back((int32_t)r);
                 continue;
             }
             int64_t nn = 0, r1 = r;
@@ -848,6 +870,7 @@ inline RowBlocks make_rowblocks(const Csr& M, const std::vector<RowSegment>& seg
             }
             r = r1;
             rb.end_row.push_back((int32_t)r);
+            rb.kbeg.push_back(-1); rb.kend.push_back(-1); rb.lfirst.push_back(0); rb.lseg.push_back(0); rb.lbase.push_back(0); rb.lid.push_back(0);
         }
         rb.part_ptr[sg.prob + 1] = (int32_t)rb.prob.size();  // (segments come problem by problem)
     }

@@ -29,12 +29,13 @@
 #include <hip/hip_runtime.h>
 
 #include "score_host.hpp"
+#include "score_band.hpp"
 
 namespace score {
 
 constexpr int kThreads = 256;
 constexpr int kUnroll = kTileNnz / kThreads;  // 8 nonzeros per lane
-constexpr int kLongUnroll = 8;
+constexpr int kLongUnroll = 2;  // nonzeros per lane and trip of a long row (segments hold <= kLongSeg = 512)
 constexpr int kPartStride = 12;  // doubles per workgroup in the residual partial arrays
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -119,6 +120,11 @@ struct CsrDev {
     const int32_t* blk_rs;     // per block: replica stride (rows of replica 0 applied to NR right-hand sides), 0 = plain rows
     const int32_t* split;      // G2 only
     int nblocks;
+    // split long rows (kLongSeg, score_host.hpp): per block {first block of the row, segments | segment << 16, first
+    // partial slot, row ordinal} (segments == 0: an ordinary block), the published segment sums, the arrival counters
+    const int4* blk_long;
+    double* long_part;
+    unsigned long long* long_cnt;
 };
 
 // Optional device-side timing of one launch (score_time_iteration): the first lane of every
@@ -148,9 +154,21 @@ struct UniRanges {
     int k0, k1;  // kblk_part_ptr[0], kblk_part_ptr[1]
 };
 
+// Band view of a matrix (score_band.hpp): what k_spmv_band reads next to the source arrays
+struct BandDev {
+    const double* val;        // V: band tiles (S x 256 doubles, slot-major), diag tiles, remainder entries
+    const int32_t* rem_col;   // column of every remainder entry
+    const int32_t* rowseg;    // per band tile x 256 lanes: (first << 16) | count of the row's remainder entries
+    const int4* meta2;        // per tile {remainder entries, run begin, run end, ordinal | kind << 28}
+    int32_t rem0;             // first remainder entry in V
+    int32_t bs;
+    int32_t offw[kBandMaxS / 2];  // slot pair j: window offset of its first slot, class c in byte c
+};
+
 struct SpmvArgs {
     UniRanges uni;
     CsrDev M;
+    BandDev B;              // (k_spmv_band only)
     const double* xin;      // gathered vector
     const int32_t* done;
     int xcd_chunk;          // > 0: tiles are dealt to the XCDs in contiguous runs of this many (workgroup i runs on XCD i % 8 and
@@ -211,8 +229,8 @@ constexpr int kMaxRep = 3;
 // once, the gathers and the LDS products are per replica; sums are per replica in CSR order, so every replica gets
 // exactly what a plain SpMV on its own copy of the rows would give.
 template <int MODE, int NR, int UNR = kUnroll>
-__device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b, const int4 meta, const int prob, const int my_ptr, const int end_ptr,
-                                          const int rs_out, double* __restrict__ prod, double* red, int32_t* srow) {
+__device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, const int4 meta, const int prob, const int my_ptr, const int end_ptr,
+                                          const int rs_out, double* __restrict__ prod, double* red, int32_t* srow, const int4 lg = make_int4(0, 0, 0, 0)) {
     static_assert(NR == 1 || (MODE != MODE_DRES && MODE != MODE_GRAD), "residual / gradient modes run on plain rows");
     auto kpad = [](int k) -> int { return k + (k >> 3); };
     constexpr int kPlane = UNR * kThreads + UNR * kThreads / 8;  // one padded plane of products per right-hand side
@@ -250,7 +268,9 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b, const 
     // first wait -- tile record -> {matrix, row pointers, own entries, flag} -> gathers -- instead of five dependent trips.
     const int dn = a.done[prob];
     if (a.early_done && dn) return;
-    const bool one_long = (r1 - r0 == 1 && nn > kLongRow);
+    const int nseg = lg.y & 0xffff;  // > 1: this block is one segment of a split long row
+    const bool one_long = (r1 - r0 == 1 && (nn > kLongRow || nseg > 1));
+    int b = b_in;                    // (the last segment to arrive writes the row's partial sums into the FIRST segment's slot)
     const int ro = one_long ? r0 : min(row, max(r1 - 1, r0));
     double e0[NR], e1[NR], e2[NR], e3[NR], e4[NR], e5[NR];
 #pragma unroll
@@ -302,6 +322,40 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b, const 
 #pragma unroll
         for (int q = 0; q < NR; ++q) sum[q] = block_sum(acc[q], red);
         if (MODE == MODE_DRES || MODE == MODE_GRAD) sum2 = block_sum(acc2, red);
+        if (nseg > 1) {
+            // A segment publishes its sums (agent-scope stores, drained) and takes a ticket; every launch adds `nseg` to the
+            // row's counter, so the segment that draws the last ticket of the launch knows that all sums are out: it adds them
+            // in SEGMENT order -- the result does not depend on who arrives when -- and finishes the row; the others leave.
+            double* slot = a.M.long_part + (size_t)(lg.z + (lg.y >> 16)) * kLongVals;
+            if (t == 0) {
+#pragma unroll
+                for (int q = 0; q < NR; ++q) __hip_atomic_store(slot + q, sum[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (MODE == MODE_DRES || MODE == MODE_GRAD) __hip_atomic_store(slot + NR, sum2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long ticket = __hip_atomic_fetch_add(a.M.long_cnt + lg.w, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                srow[0] = ((int)(ticket % (unsigned long long)nseg) == nseg - 1) ? 1 : 0;
+            }
+            __syncthreads();
+            if (!srow[0]) return;  // (uniform)
+            const double* all = a.M.long_part + (size_t)lg.z * kLongVals;
+            if (t == 0) {
+                double tot[kLongVals] = {0.0, 0.0, 0.0, 0.0};
+                for (int sg = 0; sg < nseg; ++sg) {
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) tot[q] += __hip_atomic_load(all + (size_t)sg * kLongVals + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (MODE == MODE_DRES || MODE == MODE_GRAD) tot[NR] += __hip_atomic_load(all + (size_t)sg * kLongVals + NR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int q = 0; q < NR; ++q) sum[q] = tot[q];
+                if (MODE == MODE_DRES || MODE == MODE_GRAD) sum2 = tot[NR];
+            }
+            // the partial-sum slots of the other segments' blocks (p'w, residual norms): zero, the row's own go to the first
+            if (MODE == MODE_KP || MODE == MODE_KPB)
+                for (int i = 1 + t; i < nseg; i += kThreads) a.pw_part[lg.x + i] = 0.0;
+            if (MODE == MODE_DRES || MODE == MODE_GRAD)
+                for (int i = kPartStride + t; i < nseg * kPartStride; i += kThreads) a.dres_part[(size_t)lg.x * kPartStride + i] = 0.0;
+            b = lg.x;
+        }
         has_row = (t == 0);
         row = r0;
     } else {
@@ -467,7 +521,7 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     __shared__ double red[8];
     __shared__ int32_t srow[kRowsPerBlock + 1];  // row pointers of the tile, relative to k0
     const int b = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    if (a.xcd_chunk > 0 && b >= a.n_tiles) return;
+    if (b >= a.n_tiles) return;
     const int t = threadIdx.x;
     // one 16-byte load gives the whole tile geometry; the frozen-problem flag and the
     // tile's row pointers are requested together with it
@@ -476,8 +530,258 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     const int rs = (NR > 1) ? a.M.blk_rs[b] : 0;
     const int my_ptr = a.M.ptr[min(meta.x + t, meta.y)];
     const int end_ptr = (t == 0) ? meta.w : 0;
-    if (NR > 1 && rs > 0) spmv_tile<MODE, NR, UNR>(a, b, meta, prob, my_ptr, end_ptr, rs, prod, red, srow);
-    else spmv_tile<MODE, 1, UNR>(a, b, meta, prob, my_ptr, end_ptr, 0, prod, red, srow);
+    const int4 lg = a.M.blk_long[b];
+    if (NR > 1 && rs > 0) spmv_tile<MODE, NR, UNR>(a, b, meta, prob, my_ptr, end_ptr, rs, prod, red, srow, lg);
+    else spmv_tile<MODE, 1, UNR>(a, b, meta, prob, my_ptr, end_ptr, 0, prod, red, srow, lg);
+}
+
+// ---------------------------------------------------------------------------
+// band view (score_band.hpp): K p for matrices whose rows follow the pose chains
+// ---------------------------------------------------------------------------
+// KP / KPB epilogue of one row with NR right-hand sides: stores w (and, KPB, the new direction), returns p'w of the row
+template <int MODE, int NR>
+__device__ __forceinline__ double kp_row_finish(const SpmvArgs& a, const int row, const int rs_out, const double beta, const double (&sum)[NR],
+                                                const double (&e0)[NR], const double (&e1)[NR], const double (&e2)[NR]) {
+    double local = 0.0;
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int o = row + q * rs_out;
+        double pi, sq = sum[q];
+        if (MODE == MODE_KPB) {  // K (z + beta p) = K z + beta w_old, see spmv_tile
+            sq += beta * e0[q];
+            pi = e1[q] + beta * e2[q];
+            a.p_out[o] = pi;
+        } else {
+            pi = e0[q];
+        }
+        a.w[o] = sq;
+        local += pi * sq;
+    }
+    return local;
+}
+
+// One band tile: every lane owns a row of the tile.  Nothing it requests depends on anything but the tile record:
+// NP value pairs (pair-major: lane t reads the 16 bytes at V[base + j * 512 + 2 t], 1 KiB contiguous per wavefront and
+// pair), the NP operand pairs of its window per right-hand side (16-byte loads; neighbouring lanes read neighbouring or
+// equal addresses), the row's (first, count) remainder word, the tile's remainder entries (coalesced) -- then ONE
+// dependent trip for the remainder's gathers (a tenth of the nonzeros), whose products go to LDS and are added row by
+// row in CSR order.  A pair whose base falls outside the run [lo, hi) is loaded from the clamped base and put right by a
+// select (the slots of positions outside the run hold zeros and must meet finite operands from the run itself: a
+// neighbouring problem's entries may be NaN).
+template <int MODE, int NR, int NP>
+__device__ __forceinline__ void band_tile(const SpmvArgs& a, const int b, const int4 meta, const int4 m2, const int prob, const int rs_out,
+                                          double* __restrict__ prod, double* red) {
+    static_assert(MODE == MODE_KP || MODE == MODE_KPB, "band tiles serve the K / H products");
+    constexpr int kPlane = kBandRemMax + kBandRemMax / 8;
+    auto kpad = [](int k) -> int { return k + (k >> 3); };
+    const int t = threadIdx.x;
+    const int r0 = meta.x, r1 = meta.y;
+    const int rem_cnt = m2.x, lo = m2.y, hi = m2.z, ord = m2.w & 0x0fffffff;
+    const int rs_in = (NR > 1) ? (a.rs_in ? a.rs_in : rs_out) : 0;
+    const double* __restrict__ xin = (MODE == MODE_KPB) ? a.z : a.xin;
+    double beta = 0.0, acc_n = 0.0, acc_o = 0.0;
+    if (MODE == MODE_KPB) {
+        const int l0 = a.uni.on ? a.uni.l0 : a.prec_part_ptr[prob], l1 = a.uni.on ? a.uni.l1 : a.prec_part_ptr[prob + 1];
+        for (int i = l0 + t; i < l1; i += kThreads) { acc_n += a.rz_new[i]; acc_o += a.rz_old[i]; }
+    }
+    const int dn = a.done[prob];
+    if (a.early_done && dn) return;
+    const int row = r0 + t;
+    const bool has_row = row < r1;
+    const int ro = min(row, r1 - 1);
+    double e0[NR], e1[NR], e2[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int o = ro + q * rs_out;
+        e0[q] = e1[q] = e2[q] = 0.0;
+        if (MODE == MODE_KP) e0[q] = a.p[o];
+        else { e0[q] = a.w[o]; e1[q] = a.z[o]; e2[q] = a.p[o]; }
+    }
+    const int bs = a.B.bs;
+    const int cls = (bs == 3) ? t % 3 : (t & (bs - 1));
+    const int nb = row - cls;
+    const double2* __restrict__ bv = reinterpret_cast<const double2*>(a.B.val + meta.z) + t;
+    double2 v[NP], g[NP][NR];
+    int dsh[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) v[j] = bv[j * kBandLanes];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+        const int base = nb + __builtin_amdgcn_sbfe(a.B.offw[j], 8 * cls, 8);
+        const int cb = min(max(base, lo), hi - 2);
+        dsh[j] = base - cb;
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {  // (8-byte aligned 16-byte load)
+            const double* src = xin + cb + q * rs_in;
+            double2 ld;
+            __builtin_memcpy(&ld, src, sizeof(double2));
+            g[j][q] = ld;
+        }
+    }
+    // the remainder: entries [0, rem_cnt) of the tile, 64 per wavefront and trip (whole wavefronts beyond the count skip)
+    constexpr int RU = kBandRemMax / kThreads;
+    const int seg = a.B.rowseg[ord * kBandLanes + t];
+    int32_t c[RU];
+    double rv[RU], gx[RU][NR];
+    const int wave0 = __builtin_amdgcn_readfirstlane(t & ~63);
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+        c[u] = lo; rv[u] = 0.0;
+        if (u * kThreads + wave0 < rem_cnt) {
+            const int k = meta.w + u * kThreads + t;
+            c[u] = a.B.rem_col[k];
+            rv[u] = a.B.val[a.B.rem0 + k];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+        if (u * kThreads + wave0 < rem_cnt) {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) gx[u][q] = xin[c[u] + q * rs_in];
+        } else {
+#pragma unroll
+            for (int q = 0; q < NR; ++q) gx[u][q] = 0.0;
+        }
+    }
+    if (dn) return;  // (uniform over the workgroup; nothing has been written)
+    if (MODE == MODE_KPB) {
+        block_sum2(acc_n, acc_o, red);
+        beta = acc_o > 0.0 ? acc_n / acc_o : 0.0;
+    }
+    double sum[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) sum[q] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            const double x0 = dsh[j] > 0 ? g[j][q].y : g[j][q].x;
+            const double x1 = dsh[j] < 0 ? g[j][q].x : g[j][q].y;
+            sum[q] += v[j].x * x0;
+            sum[q] += v[j].y * x1;
+        }
+    }
+    if (rem_cnt > 0) {  // (uniform)
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            if (u * kThreads + wave0 < rem_cnt) {
+                const int k = t + u * kThreads;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) prod[q * kPlane + kpad(k)] = rv[u] * gx[u][q];
+            }
+        }
+        __syncthreads();
+        if (has_row) {
+            // four slots per trip (clamped reads, exact zeros for the surplus: the additions keep the CSR order)
+            const int k0 = seg >> 16, k1 = k0 + (seg & 0xffff);
+            for (int k = k0; k < k1; k += 4) {
+                const int ka = min(k + 1, k1 - 1), kb = min(k + 2, k1 - 1), kc = min(k + 3, k1 - 1);
+                double p0[NR], p1[NR], p2[NR], p3[NR];
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    p0[q] = prod[q * kPlane + kpad(k)];
+                    p1[q] = prod[q * kPlane + kpad(ka)];
+                    p2[q] = prod[q * kPlane + kpad(kb)];
+                    p3[q] = prod[q * kPlane + kpad(kc)];
+                }
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    sum[q] += p0[q];
+                    sum[q] += (k + 1 < k1) ? p1[q] : 0.0;
+                    sum[q] += (k + 2 < k1) ? p2[q] : 0.0;
+                    sum[q] += (k + 3 < k1) ? p3[q] : 0.0;
+                }
+            }
+        }
+    }
+    double local = 0.0;
+    if (has_row) local = kp_row_finish<MODE, NR>(a, row, rs_out, beta, sum, e0, e1, e2);
+    const double tot = block_sum(local, red);
+    if (t == 0) a.pw_part[b] = tot;
+}
+
+// One diag tile: plain rows whose only entry is their diagonal, kBandDiagRows / 256 per lane, everything requested at once.
+template <int MODE>
+__device__ __forceinline__ void diag_tile(const SpmvArgs& a, const int b, const int4 meta, const int prob, double* red) {
+    constexpr int DU = kBandDiagRows / kThreads;
+    const int t = threadIdx.x;
+    const int r0 = meta.x, r1 = meta.y;
+    double beta = 0.0, acc_n = 0.0, acc_o = 0.0;
+    if (MODE == MODE_KPB) {
+        const int l0 = a.uni.on ? a.uni.l0 : a.prec_part_ptr[prob], l1 = a.uni.on ? a.uni.l1 : a.prec_part_ptr[prob + 1];
+        for (int i = l0 + t; i < l1; i += kThreads) { acc_n += a.rz_new[i]; acc_o += a.rz_old[i]; }
+    }
+    const int dn = a.done[prob];
+    if (a.early_done && dn) return;
+    double v[DU], x[DU][1], e0[DU][1], e1[DU][1], e2[DU][1];
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+        const int ro = min(r0 + u * kThreads + t, r1 - 1);
+        v[u] = a.B.val[meta.z + (ro - r0)];
+        e0[u][0] = e1[u][0] = e2[u][0] = 0.0;
+        // (the operand of a diagonal row is the row's own entry of the vector the epilogue reads anyway)
+        if (MODE == MODE_KP) { e0[u][0] = a.p[ro]; x[u][0] = (a.p == a.xin) ? e0[u][0] : a.xin[ro]; }
+        else { e0[u][0] = a.w[ro]; e1[u][0] = a.z[ro]; e2[u][0] = a.p[ro]; x[u][0] = e1[u][0]; }
+    }
+    if (dn) return;  // (uniform; nothing has been written)
+    if (MODE == MODE_KPB) {
+        block_sum2(acc_n, acc_o, red);
+        beta = acc_o > 0.0 ? acc_n / acc_o : 0.0;
+    }
+    double local = 0.0;
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+        const int row = r0 + u * kThreads + t;
+        if (row < r1) {
+            const double sum[1] = {v[u] * x[u][0]};
+            local += kp_row_finish<MODE, 1>(a, row, 0, beta, sum, e0[u], e1[u], e2[u]);
+        }
+    }
+    const double tot = block_sum(local, red);
+    if (t == 0) a.pw_part[b] = tot;
+}
+
+// The SpMV over a band view: CSR tiles (the landmark rows; 2 nonzero slots per lane), band tiles and diag tiles in one
+// launch, a uniform branch per workgroup.  NR as in k_spmv (the band tiles of a replicated matrix are all replicated:
+// chains live in the replicas, never in the tail); NP = value-slot pairs per band row (4, 5 or 6).
+template <int MODE, int NR, int NP>
+__device__ __forceinline__ void spmv_band_body(const SpmvArgs& a) {
+    KernelStamp stamp(a.tstamp);
+    constexpr int UNR = kBandCsrNnz / kThreads;
+    constexpr int kCsrPlane = UNR * kThreads + UNR * kThreads / 8;
+    constexpr int kRemPlane = kBandRemMax + kBandRemMax / 8;
+    __shared__ double prod[NR * (kCsrPlane > kRemPlane ? kCsrPlane : kRemPlane)];
+    __shared__ double red[8];
+    __shared__ int32_t srow[kRowsPerBlock + 1];
+    const int b = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (b >= a.n_tiles) return;
+    const int t = threadIdx.x;
+    const int4 meta = a.M.blk_meta[b];
+    const int4 m2 = a.B.meta2[b];
+    const int prob = a.uni.on ? 0 : a.M.blk_prob[b];
+    const int rs = (NR > 1) ? a.M.blk_rs[b] : 0;
+    const int kind = (int)((unsigned)m2.w >> 28);
+    if (kind == BAND_KIND_BAND) {
+        band_tile<MODE, NR, NP>(a, b, meta, m2, prob, rs, prod, red);
+    } else if (kind == BAND_KIND_DIAG) {
+        diag_tile<MODE>(a, b, meta, prob, red);
+    } else {
+        const int my_ptr = a.M.ptr[min(meta.x + t, meta.y)];
+        const int end_ptr = (t == 0) ? meta.w : 0;
+        const int4 lg = a.M.blk_long[b];
+        if (NR > 1 && rs > 0) spmv_tile<MODE, NR, UNR>(a, b, meta, prob, my_ptr, end_ptr, rs, prod, red, srow, lg);
+        else spmv_tile<MODE, 1, UNR>(a, b, meta, prob, my_ptr, end_ptr, 0, prod, red, srow, lg);
+    }
+}
+template <int MODE, int NR, int NP>
+__global__ __launch_bounds__(kThreads) void k_spmv_band(SpmvArgs a) { spmv_band_body<MODE, NR, NP>(a); }
+
+// V[dst[k]] = val[k] for the entries a band view serves (after k_kval: once per penalty update)
+__global__ __launch_bounds__(kThreads) void k_band_pack(const int32_t* __restrict__ dst, const double* __restrict__ val, double* __restrict__ V, int64_t nnz) {
+    const int64_t k = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (k >= nnz) return;
+    const int d = dst[k];
+    if (d >= 0) V[d] = val[k];
 }
 
 // ---------------------------------------------------------------------------

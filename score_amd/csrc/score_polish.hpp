@@ -51,6 +51,8 @@ struct HAsmArgs {
     const double* Bbuf;
     int T2;
     double* Hval;
+    const int32_t* dst;  // band view of H (score_band.hpp): entry p is stored at V[dst[p]] as well (null: no view)
+    double* V;
     // Jacobi part
     int ndiag;
     const int32_t* diag_pos;
@@ -74,7 +76,10 @@ __global__ __launch_bounds__(kThreads) void k_hassemble(HAsmArgs a, const int32_
         double v = 0.0;
         for (int c = c0 + (int)threadIdx.x; c < c1; c += kThreads) v += a.ccoef[c] * a.Bbuf[(size_t)a.ccone[c] * a.T2 + a.cab[c]];
         v = block_sum(v, red);
-        if (threadIdx.x == 0) a.Hval[pl] = a.Pon[pl] + v;
+        if (threadIdx.x == 0) {
+            a.Hval[pl] = a.Pon[pl] + v;
+            if (a.dst && a.dst[pl] >= 0) a.V[a.dst[pl]] = a.Pon[pl] + v;
+        }
         return;
     }
     const int q = blockIdx.y;
@@ -84,8 +89,10 @@ __global__ __launch_bounds__(kThreads) void k_hassemble(HAsmArgs a, const int32_
     const int c0 = a.cptr[p], c1 = a.cptr[p + 1];
     if (c1 - c0 > kLongContrib) return;  // k_hassemble_long
     double v = a.Pon[p];
+    const int d = a.dst ? a.dst[p] : -1;
     for (int c = c0; c < c1; ++c) v += a.ccoef[c] * a.Bbuf[(size_t)a.ccone[c] * a.T2 + a.cab[c]];
     a.Hval[p] = v;
+    if (d >= 0) a.V[d] = v;
 }
 // (landmark entries collect a contribution from every cone that touches the landmark -- thousands:
 //  strided partial sums + a fixed-order tree instead of one serial lane: the long-entry blocks above)

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "score_host.hpp"
+#include "score_band.hpp"
 
 namespace score {
 
@@ -44,9 +45,10 @@ struct PolishData {
     RowBlocks rbH;
     // chain / Jacobi positions in Hm.val
     std::vector<int32_t> pos_diag, pos_sub, diag_pos;
+    BandLayout band;  // band view of Hm (score_band.hpp): every chain of every replica is a run of plain rows
 };
 
-inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = false) {
+inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = false, bool band_view = false) {
     Q = PolishData();
     BuildScope scope;  // (built on a thread of its own next to the handle's uploads: shares the thread budget)
     PhaseTimer pt(verbose);
@@ -209,6 +211,11 @@ inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = fals
     Q.diag_pos.clear();
     for (int32_t c : H.diag_cols) Q.diag_pos.push_back(find_in_row(Q.Hm, c, c));
     pt.mark("    polish: positions");
+    if (!H.chainsH.empty() && band_view) {
+        const std::vector<char> all(H.chainsH.size(), 1);
+        Q.band = build_band_layout(Q.Hm, plain_segments(H.xoff), band_runs(H.chainsH, all, bs, 1, H.rep_n, false), bs, H.count);
+        pt.mark("    polish: band view");
+    }
     Q.available = true;
 }
 
