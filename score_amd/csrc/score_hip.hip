@@ -493,6 +493,163 @@ struct HipBackend {
         const int e = band_env("SCORE_BAND_H");
         return std::getenv("SCORE_NO_BAND") == nullptr && e > 0;
     }
+    int kblocks() const { return Kb.on ? Kb.nblocks : K.nblocks; }   // tiles of the K product (= p'w partials per launch)
+    int hblocks() const { return Hb.on ? Hb.nblocks : Hm.nblocks; }
+    DevBuf<int32_t> A_ptr, A_col;
+    DevBuf<double> A_val;
+    DevBuf<double> q, b, invD, invE, rho, fac, dinv, K0d, K1d;
+    DevBuf<int32_t> kposd, kposs, kdiagpos;  // K.val positions of the chain blocks / Jacobi diagonals
+    DevBuf<int32_t> done, cone_row, cone_dim, cone_type, cone_block_first, cone_block_prob;
+    DevBuf<int4> cone_meta;
+    DevBuf<int2> cone_large;    // {cone, problem} of the cones with more than kWaveCone rows (k_cone_wave)
+    int n_large_cones = 0;
+    DevBuf<int32_t> cone_cols;  // 8 per cone (two int4)
+    DevBuf<double> cone_vals;   // 8 per cone (four double2)
+    DevBuf<int32_t> node_col, diag_cols, prec_part_ptr, kblk_part_ptr;
+    DevBuf<PrecWork> prec_work, factor_work;   // factor_work: what a factorisation of K visits (HostSystem::factor_work)
+    DevBuf<ChainDesc> chains, chainsH;         // chainsH / levelsH: the same chains with factors of their own (Newton matrix)
+    DevBuf<ChainLevelDesc> levels, levelsH;
+    DevBuf<PrecRecord> prec_rec, prec_recH;    // one record per work item: work + chain + level table (k_prec_pre)
+    DevBuf<int64_t> fac_rangeK, fac_rangeH;    // per chain: its factor range (k_fac_round_items)
+    DevBuf<int64_t> q_entpart;                 // per problem: its entry range in the Newton matrix
+    int64_t q_ent_max = 0;
+    static constexpr int64_t kHelpEntries = (int64_t)kPrecThreads * kPrecChunk;  // vector entries per update helper
+    int n_help = 0;                            // update-helper records appended to prec_rec / prec_recH
+    DevBuf<int32_t> vb_first, vb_end, vb_prob; // blocks of <= 256 vector entries per problem (k_xupdate)
+    int n_vblocks = 0;
+    DevBuf<double> xtu, xy, s, r, z, p, p2, w, kx, step;
+    DevBuf<double> pw_part, rz_part0, rz_part1, rz_meas0, rz_meas1, pres_part, dres_part;
+    // ---- semismooth-Newton polish (score_polish*.hpp) ----
+    DevBuf<float> fac32, q_fac32;  // float copies of the chain factors (ADMM / Newton), see k_fac_round
+    DevBuf<float> deepK, deepH;    // lane-major copies of their coarse levels (k_deep_pack -> k_prec_pre<.., float, true>)
+    DevBuf<int32_t> deep_map;
+    bool prec_reg = false;         // every chain has a lane plan: the register-resident variant serves the 4-byte streams
+    size_t prec_reg_lds = 0;
+    bool use_fac32 = false;     // ADMM-loop factors (K)
+    bool newton_fac32 = false;  // Newton-polish factors (H): fac_fp32 = 2 only, see DESIGN.md section 4
+    PolishData Q;
+    std::future<void> polish_build;  // build_polish runs beside the uploads of init()
+    CsrBufs Hm;
+    DevBuf<double> q_Pon, q_ccoef, q_Bbuf, q_fpart, q_X0, q_X1, q_g, q_delta, q_fac, q_dinv, q_work, q_dummy, q_gd, q_pw;
+    DevBuf<double> q_aabs, q_ck, q_theta, q_xstar;
+    DevBuf<int32_t> q_cptr, q_ccone, q_cab, q_head, q_ishead, q_posd, q_poss, q_diagpos, q_hblk_part, q_long;
+    int n_long = 0;
+    // lock-step polish of a batch (count > 1)
+    DevBuf<int32_t> q_skip, q_reref, q_fskip, q_act;  // (q_skip, q_reref, q_fskip: views into ctl)
+    DevBuf<double> q_step;
+    DevBuf<int64_t> q_seg_begin, q_seg_end;
+    static constexpr int kFlagSlots = 32;
+    char* h_ring = nullptr;      // pinned (host-mapped) ring of upload slots
+    size_t ring_slot_bytes = 0;
+    int flag_slot = 0, ring_used = 0;
+    DevBuf<double> q_negg;                   // -gradient of the last evaluation (right-hand side of the next PCG)
+    DevBuf<double> q_gate_tol2, q_gate_ref;  // device-side PCG termination (pcg_gate)
+    DevBuf<int32_t> q_gate_used;
+    int32_t* h_gate = nullptr;   // [gate flags | iterations used]          } windows into h_rep
+    double* h_gd = nullptr;      // partials of g'delta                      }
+    // Everything the host reads back between launches lives in ONE device allocation, mirrored by
+    // one pinned host buffer, so that a convergence check (ADMM) or a Newton iteration costs a
+    // single device-to-host copy:  [pres | dres | fpart | gd | gate flags, gate counts]
+    DevBuf<double> rep;          // window: the device address of h_rep (host-mapped pinned memory)
+    double* h_rep = nullptr;
+    size_t h_rep_bytes = 0, h_ring_bytes = 0;
+    size_t rep_dres_off = 0;     // doubles
+    // Kernels write their per-workgroup partials straight into that host-mapped memory; small device
+    // arrays the device itself reads (r'z measurements, PCG gate words) are pushed there by k_push,
+    // which then publishes a sequence number the host spins on: no copy command, no stream
+    // synchronisation on the path of a convergence check or a Newton iteration.
+    unsigned long long* h_seq = nullptr;   // [0]: last published sequence number (host-mapped)
+    unsigned long long* d_seq = nullptr;
+    unsigned long long seq_next = 0;
+    double* h_meas = nullptr;    // [rz_meas0 | rz_meas1] as pushed
+    double* d_meas = nullptr;
+    int32_t* d_gate_host = nullptr;  // device address of h_gate
+    char* d_ring = nullptr;      // device address of h_ring
+    size_t n_fpart = 0, n_gd = 0;
+    // ... and everything the host tells the kernels per problem in one upload: [step | tol2 | skip]
+    DevBuf<double> ctl;
+    DevBuf<int32_t> q_pcgdone;   // window into rep: raised by pcg_gate
+    int pcg_used_total = 0;
+    double newton_eta_max = 1e-1;  // inexact Newton: linear residual <= min(eta_max, coef * |g|^pow)
+    double newton_eta_coef = 1.0, newton_eta_pow = 0.5;
+    double* h_newton = nullptr;  // window into h_rep: partials of the cone part of F
+
+    int cg_iters = 2;
+    const double* last_rz = nullptr;  // r'z partials / direction of the pending end-of-PCG update
+    const double* last_p = nullptr;
+    double* h_pres = nullptr;  // pinned
+    double* h_dres = nullptr;
+    int n_cone_blocks = 0, n_prec = 0;  // n_prec: work items of the ACTIVE preconditioner launch (split or not)
+    // split chain kernel (score_split.hpp / score_prec_wave.hpp)
+    SplitSystem split;
+    std::vector<int32_t> active_part_ptr;   // host copy of the active per-problem work ranges
+    DevBuf<PrecWork> split_work;
+    DevBuf<SplitItem> split_items;
+    DevBuf<SplitPlan> split_plans;
+    DevBuf<int32_t> split_stage;
+    DevBuf<double> split_xbuf;
+    DevBuf<unsigned int> split_xflag, split_epoch;
+    size_t split_lds = 0;
+    unsigned long long split_poll_limit = 0;
+    size_t prec_lds = 0;
+    bool prec_lds0 = true;
+    bool prec_pre = false;  // every chain fits the lane budget of k_prec_pre (4 x 4 blocks: with the 4-byte factor stream only)
+    size_t prec_pre_lds = 0;
+    static bool n_prec_chains(const HostSystem& h) { return !h.chains.empty(); }
+
+    ~HipBackend() {
+        PhaseTimer pt(st.verbose != 0);
+        if (stream) (void)hipStreamSynchronize(stream);
+        pt.mark("destroy: sync");
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        pt.mark("destroy: graph");
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        block_cache().give(h_rep, h_rep_bytes, st.device, true);
+        block_cache().give(h_ring, h_ring_bytes, st.device, true);
+        pt.mark("destroy: events, pinned blocks");
+        stream_pool().give(st.device, stream);  // (drained above)
+        pt.mark("destroy: stream");
+    }
+
+    void init(const HostSystem& h, const score_settings& s_) {
+        H = &h;
+        st = s_;
+        PhaseTimer pt(st.verbose != 0);
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0)
+            throw std::runtime_error("no HIP device available (the SCORE solver has no CPU fallback)");
+        if (st.device < 0 || st.device >= ndev) throw std::runtime_error("score_settings.device out of range");
+        HIP_CHECK(hipSetDevice(st.device));
+        arena.dev = st.device;
+        stream = stream_pool().take(st.device);
+        tl_copy_stream = stream;
+        struct ArenaScope {  // buffers allocated during init come from this handle's arena
+            explicit ArenaScope(DevArena* a) { tl_arena = a; }
+            ~ArenaScope() { tl_arena = nullptr; }
+        } arena_scope(&arena);
+        HIP_CHECK(hipEventCreate(&ev0));
+        HIP_CHECK(hipEventCreate(&ev1));
+        pt.mark("device + stream");
+        if (h.bs != 0 && h.bs != 3 && h.bs != 4 && h.bs != 1 && h.bs != 2)
+            throw std::runtime_error("unsupported block size");
+        struct JoinPolish {  // an exception below must not leave the builder running against a dying handle
+            std::future<void>& f;
+            ~JoinPolish() { if (f.valid()) f.wait(); }
+        } join_polish{polish_build};
+        // the Newton matrix pattern and its contribution lists only read the finished host system:
+        // built on another thread while this one uploads (4.3 ms beside 2.4 ms of uploads / allocations)
+        if (st.polish) polish_build = std::async(std::launch::async, [this, &h] { build_polish(h, Q, st.verbose != 0, band_h(h)); });
+        K.upload(h.K, h.rbK);
+        G1.upload(h.G1, h.rbG1);
+        G2.upload(h.G2, h.rbG2, &h.g2_split);
+        // replicated problems (HostSystem::rep): K and G1 = A' hold replica 0's rows; K's operands repeat with the
+        // block's replica stride, G1's are the consecutive tail rows of a cone
+        K.rep = h.rep; K.rs_in = 0;
+        G1.rep = h.rep; G1.rs_in = 1;
+        K.unroll = (h.rep > 1) ? h.tile_nnz / kThreads : kUnroll;
+        G1.unroll = (h.rep > 1) ? kUnroll / 2 : kUnroll;  // (tiles of at most kTileNnz / 2 nonzeros, see build_system)
         if (band_k(h) && !h.chains.empty()) {  // band view of K: the chain rows without column indices (score_band.hpp)
             std::vector<char> use(h.chains.size());
             for (size_t ci = 0; ci < h.chains.size(); ++ci) use[ci] = h.chain_owner[ci] == (int32_t)ci;
