@@ -16,6 +16,8 @@
 //
 // Kernels and their design notes: score_kernels.hpp.
 #include <hip/hip_runtime.h>
+#include <sched.h>
+#include <time.h>
 #include <hip/hip_ext.h>
 
 #include <cstdio>
@@ -1073,12 +1075,34 @@ struct HipBackend {
         hipLaunchKernelGGL(k_push, dim3(1), dim3(kThreads), 0, stream, a);
         return a.seq;
     }
+    // The host's side of a publish: a short spin with the CPU's pause hint (a result that is about to land is picked up within
+    // a fraction of a microsecond), then yields (the waiting thread gives its core to whoever can run: with several ranks per
+    // node and several driver threads per rank the host has fewer cores than waiters -- a bare spin there burns exactly the
+    // CPU quota the other ranks' setup needs), then short sleeps; a stream synchronisation, which also surfaces device errors,
+    // when nothing arrives within 2 s.  SCORE_WAIT_SPIN_US: length of the first phase (default 30).
     void wait_published(unsigned long long seq) {
         HIP_CHECK(hipGetLastError());
+        static const double spin_us = std::getenv("SCORE_WAIT_SPIN_US") ? std::atof(std::getenv("SCORE_WAIT_SPIN_US")) : 30.0;
         const auto t0 = std::chrono::steady_clock::now();
-        int spins = 0;
+        unsigned spins = 0;
+        int phase = 0;  // 0 spin, 1 yield, 2 sleep
         while (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) < seq) {
-            if ((++spins & 1023) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            if (phase == 0) {
+#if defined(__x86_64__) || defined(__i386__)
+                __builtin_ia32_pause();
+#endif
+                if ((++spins & 63) != 0) continue;
+            } else if (phase == 1) {
+                sched_yield();
+                if ((++spins & 15) != 0) continue;
+            } else {
+                struct timespec ts = {0, 50000};  // 50 us
+                nanosleep(&ts, nullptr);
+            }
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            if (phase == 0 && us > spin_us) phase = 1;
+            else if (phase == 1 && us > 2000.0) phase = 2;
+            else if (us > 2e6) {
                 HIP_CHECK(hipStreamSynchronize(stream));
                 if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) < seq) throw std::runtime_error("device did not publish its results");
                 break;

@@ -77,6 +77,12 @@ inline int host_threads() {
             }
             if (ok && quota > 0 && period > 0) h = std::min<unsigned>(h, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
         }
+        // several ranks on one node (torch.distributed.run / bench.py --gpus N export LOCAL_WORLD_SIZE) share the host:
+        // each takes its share of what the node grants
+        if (const char* e = std::getenv("LOCAL_WORLD_SIZE")) {
+            const int ranks = std::atoi(e);
+            if (ranks > 1) h = std::max(1u, h / (unsigned)ranks);
+        }
         if (const char* e = std::getenv("SCORE_HOST_THREADS")) h = (unsigned)std::max(1, std::atoi(e));
         return (int)std::min(16u, std::max(1u, h));
     }();

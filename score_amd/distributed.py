@@ -6,7 +6,10 @@ set of factor graphs shards embarrassingly: one process per GPU
 CPU), problem i goes to one rank (longest-processing-time assignment by
 problem size), every rank solves its share as ONE lock-step batch on its own
 device, and a single all_gather of fixed-stride float64 records returns the
-estimates.  There is no collective on the data path.
+estimates.  There is no collective on the data path.  When only one rank holds
+the data set (a pickle loaded on rank 0), ``root=`` broadcasts the graphs first:
+one object broadcast of names and sizes, one tensor broadcast of every numeric
+array, concatenated.
 """
 from __future__ import annotations
 
@@ -16,6 +19,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import compat
+from .native import ArrayGraph, graph_arrays
 from .solve_score import solve_score_batch
 
 _HDR = 8  # status, iters, cg_iters, pobj, res_pri, res_dual, solve_ms, n_values
@@ -33,14 +37,24 @@ def shard_assignment(costs: Sequence[float], world_size: int) -> List[List[int]]
     return [sorted(s) for s in shards]
 
 
+def _meta(data):
+    """(dimension, pose names, landmark names, number of ranges) of a FactorGraphData or an ArrayGraph."""
+    if isinstance(data, ArrayGraph):
+        a = data.arrays
+        return int(a["dim"]), list(a["pose_names"]), list(a["landmark_names"]), len(a["range_keys"])
+    return (data.dimension, [p.name for chain in data.pose_variables for p in chain],
+            [l.name for l in data.landmark_variables], len(data.range_measurements))
+
+
 def problem_cost(data) -> float:
-    return float(sum(len(c) for c in data.pose_variables) * 6 + 3 * len(data.range_measurements))
+    _, poses, _, n_ranges = _meta(data)
+    return float(len(poses) * 6 + 3 * n_ranges)
 
 
 def _pack(res: compat.SolverResults, data) -> np.ndarray:
-    names = [p.name for chain in data.pose_variables for p in chain]
+    _, names, lm_names, _ = _meta(data)
     vals = [res.poses[n].ravel() for n in names]
-    vals += [np.asarray(res.landmarks[l.name]).ravel() for l in data.landmark_variables]
+    vals += [np.asarray(res.landmarks[l]).ravel() for l in lm_names]
     v = np.concatenate(vals) if vals else np.zeros(0)
     info = res.info or {}
     hdr = np.array([
@@ -52,14 +66,13 @@ def _pack(res: compat.SolverResults, data) -> np.ndarray:
 
 
 def _unpack(rec: np.ndarray, data) -> compat.SolverResults:
-    d = data.dimension
+    d, names, lm_names, _ = _meta(data)
     nv = int(rec[7])
     v = rec[_HDR : _HDR + nv]
-    names = [p.name for chain in data.pose_variables for p in chain]
     k = (d + 1) * (d + 1)
     poses = {n: v[i * k : (i + 1) * k].reshape(d + 1, d + 1).copy() for i, n in enumerate(names)}
     off = len(names) * k
-    lms = {l.name: v[off + i * d : off + (i + 1) * d].copy() for i, l in enumerate(data.landmark_variables)}
+    lms = {l: v[off + i * d : off + (i + 1) * d].copy() for i, l in enumerate(lm_names)}
     info = dict(status=int(rec[0]), iters=int(rec[1]), cg_iters=int(rec[2]), pobj=float(rec[3]),
                 res_pri=float(rec[4]), res_dual=float(rec[5]), solve_ms=float(rec[6]))
     return compat.SolverResults(
@@ -71,9 +84,64 @@ def _unpack(rec: np.ndarray, data) -> compat.SolverResults:
 def record_stride(datas: Sequence) -> int:
     worst = 0
     for data in datas:
-        d = data.dimension
-        worst = max(worst, sum(len(c) for c in data.pose_variables) * (d + 1) ** 2 + len(data.landmark_variables) * d)
+        d, names, lm_names, _ = _meta(data)
+        worst = max(worst, len(names) * (d + 1) ** 2 + len(lm_names) * d)
     return _HDR + worst
+
+
+# numeric fields of ``native.graph_arrays`` (everything else in that dict is names / small integers)
+_NUMERIC = ("chain_len", "rel_base", "rel_to", "rel_t", "rel_R", "rel_kappa", "rel_tau", "rng_a", "rng_b", "rng_dist",
+            "rng_prec", "lprior_lm", "lprior_t", "lprior_prec")
+
+
+def broadcast_graphs(datas: Optional[Sequence], root: int = 0, device: Optional[int] = None) -> List[ArrayGraph]:
+    """Rank ``root`` holds the factor graphs (FactorGraphData or ArrayGraph), the other ranks pass ``None``; every rank
+    returns the list as ``ArrayGraph``s.  Two collectives: ONE object broadcast (names, range keys, shapes and dtypes
+    of the numeric arrays) and ONE broadcast of all numeric arrays concatenated into a float64 buffer (the int32 index
+    arrays travel as exact float64 values; backend "nccl" = RCCL: through this rank's GPU).  Without a process
+    group: the arrays of ``datas``."""
+    import torch
+    import torch.distributed as dist
+
+    def arrays_of(g):
+        return g.arrays if isinstance(g, ArrayGraph) else graph_arrays(g)
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return [ArrayGraph(arrays_of(g)) for g in (datas or [])]
+    rank = dist.get_rank()
+    header, flat = None, None
+    if rank == root:
+        if datas is None:
+            raise ValueError("broadcast_graphs: the root rank must hold the graphs")
+        header, chunks = [], []
+        for g in datas:
+            a = arrays_of(g)
+            meta = {k: v for k, v in a.items() if k not in _NUMERIC}
+            meta["_shapes"] = {k: (tuple(np.shape(a[k])), np.asarray(a[k]).dtype.str) for k in _NUMERIC}
+            header.append(meta)
+            chunks += [np.asarray(a[k], dtype=np.float64).ravel() for k in _NUMERIC]
+        flat = np.concatenate(chunks) if chunks else np.zeros(0)
+    box = [header, int(flat.size) if flat is not None else 0]
+    dist.broadcast_object_list(box, src=root)
+    header, total = box
+    t = torch.from_numpy(flat) if rank == root else torch.empty(total, dtype=torch.float64)
+    if dist.get_backend() == "nccl":
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        t = t.to(f"cuda:{device}")
+    if total:
+        dist.broadcast(t, src=root)
+    flat = t.cpu().numpy()
+    out, o = [], 0
+    for meta in header:
+        a = {k: v for k, v in meta.items() if k != "_shapes"}
+        for k in _NUMERIC:
+            shape, dt = meta["_shapes"][k]
+            n = int(np.prod(shape)) if len(shape) else 1
+            a[k] = flat[o : o + n].astype(np.dtype(dt)).reshape(shape)
+            o += n
+        out.append(ArrayGraph(a))
+    return out
 
 
 def all_gather_records(buf: np.ndarray, device: Optional[int] = None) -> List[np.ndarray]:
@@ -97,10 +165,12 @@ def all_gather_records(buf: np.ndarray, device: Optional[int] = None) -> List[np
 
 
 def solve_score_sharded(
-    datas: Sequence, relaxation_type: str = "QCQP", solver_settings: Optional[dict] = None,
-    lib_path: Optional[str] = None, device: Optional[int] = None,
+    datas: Optional[Sequence], relaxation_type: str = "QCQP", solver_settings: Optional[dict] = None,
+    lib_path: Optional[str] = None, device: Optional[int] = None, root: Optional[int] = None,
 ) -> List[compat.SolverResults]:
-    """Every rank passes the SAME list of factor graphs and gets ALL results.
+    """Every rank passes the SAME list of factor graphs and gets ALL results -- or, with ``root=r``, only rank r holds
+    the graphs (a data set loaded from disk, e.g. the reference's examples/goats_14_data pickle), the others pass
+    ``None``, and the graphs are broadcast first (``broadcast_graphs``: two collectives).
 
     (Monte-Carlo graphs are generated from seeds, so holding the whole list on every rank costs
     nothing and spares a broadcast of problem data; a rank only ASSEMBLES and solves its own
@@ -112,6 +182,8 @@ def solve_score_sharded(
     if not (dist.is_available() and dist.is_initialized()):
         return solve_score_batch(datas, relaxation_type, solver_settings=solver_settings, lib_path=lib_path)
     world, rank = dist.get_world_size(), dist.get_rank()
+    if root is not None:
+        datas = broadcast_graphs(datas if rank == root else None, root, device)
     shards = shard_assignment([problem_cost(d) for d in datas], world)
     mine = shards[rank]
     settings = dict(solver_settings or {})

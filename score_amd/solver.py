@@ -222,10 +222,11 @@ class ConicSolver:
 
     def _split(self, x, y, s, infos) -> List[ConicSolution]:
         out, xo, ro = [], 0, 0
+        backend = self.backend  # which library produced the numbers ("hip-gfx950"; "cpu-twin" only in tests)
         for i in range(self.count):
             out.append(ConicSolution(
                 x[xo : xo + self.ns[i]].copy(), y[ro : ro + self.ms[i]].copy(), s[ro : ro + self.ms[i]].copy(),
-                infos[i].as_dict(),
+                dict(infos[i].as_dict(), backend=backend),
             ))
             xo += self.ns[i]
             ro += self.ms[i]

@@ -39,7 +39,7 @@ def test_bench_gpus_flag_launches_that_many_ranks(twin_lib):
     primary metric as one rank (SOCP iterations/s, every rank its own headline problem: weak scaling), plus BASELINE
     configs[4] sharded t mod N with ONE all_gather of the result records per sweep.  Run here on gloo + the oracle's
     CPU twin (--test-cpu-twin); on the GPU box the same launcher starts RCCL ranks."""
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2", SCORE_BENCH_TEST_MODE="1")
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
     out = subprocess.run(
         [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--test-cpu-twin", "--robots", "2", "--poses", "30",
@@ -65,7 +65,7 @@ def test_bench_gpus_flag_launches_that_many_ranks(twin_lib):
 def test_bench_is_one_of_the_ranks_under_a_launcher(twin_lib):
     """With RANK / WORLD_SIZE already in the environment (torch.distributed.run) bench.py must not
     spawn anything: world size 1 here, process group forced on (the gather then runs as a 1-rank collective)."""
-    env = dict(os.environ, OMP_NUM_THREADS="2", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+    env = dict(os.environ, OMP_NUM_THREADS="2", SCORE_BENCH_TEST_MODE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT="29533")
     out = subprocess.run(
         [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--test-cpu-twin", "--force-dist", "--robots", "1",
@@ -84,7 +84,7 @@ def test_a_failing_rank_takes_the_launch_down_promptly(twin_lib):
     launch with a non-zero code at once -- no rank is left waiting in a collective for the backend's timeout."""
     import time
 
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2", SCORE_BENCH_TEST_MODE="1")
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
     t0 = time.time()
     out = subprocess.run(
@@ -106,3 +106,44 @@ def test_montecarlo_group_sizes():
     for n in (1, 2, 3, 8, 9, 32, 33, 100):
         g = bench.mc_groups(n, 16, 4)
         assert sum(g) == n and max(g) <= 16 and min(g) >= 1 and max(g) - min(g) <= 1
+
+
+def test_cpu_twin_flag_needs_the_test_mode_switch():
+    """`--test-cpu-twin` routes the timed region through the oracle's twin: bench.py refuses it unless
+    SCORE_BENCH_TEST_MODE=1 is set as well, so that no measurement can be taken through oracle/ by accident."""
+    env = dict(os.environ)
+    env.pop("SCORE_BENCH_TEST_MODE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--test-cpu-twin", "--steps", "1"],
+                         capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "SCORE_BENCH_TEST_MODE" in out.stderr
+
+
+def test_four_ranks_on_four_cpus_do_not_starve_each_other(twin_lib):
+    """Host-side safety of the N-rank run: `bench.py --gpus 4` (gloo + the CPU twin, no GPU involved) with the launcher's
+    affinity narrowed to four CPUs -- one per rank -- must not take much longer than with all CPUs: every rank sizes its
+    host teams to its share of the CPUs it may use (host_threads(): affinity / cgroup quota / LOCAL_WORLD_SIZE), waits
+    yield instead of spinning, and the launcher's children inherit the mask."""
+    import time
+
+    cpus = sorted(os.sched_getaffinity(0))
+    if len(cpus) < 8:
+        import pytest
+        pytest.skip("needs 8 CPUs for the unpinned run")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--test-cpu-twin", "--robots", "2", "--poses", "40",
+           "--montecarlo", "8", "--mc-robots", "2", "--mc-poses", "30", "--mc-batch", "2", "--steps", "1", "--warmup", "0"]
+    env = dict(os.environ, OMP_NUM_THREADS="1", SCORE_BENCH_TEST_MODE="1")
+    env.pop("RANK", None); env.pop("WORLD_SIZE", None)
+
+    def run(mask):
+        t0 = time.perf_counter()
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env,
+                             preexec_fn=(lambda: os.sched_setaffinity(0, mask)) if mask else None)
+        dt = time.perf_counter() - t0
+        assert out.returncode == 0, out.stderr[-3000:]
+        rec = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][0])
+        assert rec["n_gpus"] == 4 and rec["config5_montecarlo"]["results_gathered"] == 8
+        return dt
+
+    free = run(None)
+    pinned = run(set(cpus[:4]))
+    assert pinned <= 1.5 * free + 5.0, (free, pinned)

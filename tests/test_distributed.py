@@ -35,6 +35,33 @@ def _worker(rank, world, port, lib, outdir):
     dist.destroy_process_group()
 
 
+def _worker_root(rank, world, port, lib, outdir):
+    """Only rank 0 holds the graphs (one of them the reference's GOATS pickle); rank 1 passes None."""
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from score_amd.distributed import solve_score_sharded
+
+    graphs = _root_graphs() if rank == 0 else None
+    res = solve_score_sharded(graphs, "SOCP", lib_path=lib, device=0, root=0)
+    flat = np.concatenate([np.concatenate([r.poses[n].ravel() for n in sorted(r.poses)] + [np.asarray(r.landmarks[n]).ravel() for n in sorted(r.landmarks)]) for r in res])
+    np.save(os.path.join(outdir, f"root_rank{rank}.npy"), flat)
+    np.save(os.path.join(outdir, f"root_solved{rank}.npy"), np.array([r.solved for r in res]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _root_graphs():
+    from score_amd.io import load_pyfg_pickle
+    from score_amd.manhattan import make_manhattan
+
+    graphs = [make_manhattan(n_robots=2, n_poses=30 + 7 * i, n_beacons=2, seed=51 + i) for i in range(3)]
+    graphs.append(load_pyfg_pickle(os.path.join(ROOT, "tests", "golden", "goats_14_6_2002_15_20.pkl")))
+    return graphs
+
+
 def test_shard_assignment_is_balanced_and_deterministic():
     costs = [10, 1, 7, 3, 8, 2, 9]
     a = shard_assignment(costs, 3)
@@ -56,6 +83,21 @@ def test_two_rank_gloo_matches_single_process(twin_lib, tmp_path):
     graphs = [make_manhattan(n_robots=2, n_poses=30 + 7 * i, n_beacons=2, seed=51 + i) for i in range(5)]
     single = [solve_score(g, "SOCP", lib_path=twin_lib) for g in graphs]
     flat = np.concatenate([np.concatenate([r.poses[n].ravel() for n in sorted(r.poses)]) for r in single])
+    np.testing.assert_allclose(r0, flat, atol=1e-6)
+
+
+def test_root_rank_broadcasts_the_graphs(twin_lib, tmp_path):
+    """north_star's "broadcast/gather of problem data and results": rank 0 alone holds the data set (three synthetic graphs
+    and the reference's goats_14 pickle), rank 1 is given None; both return every result, equal to a single-process solve."""
+    port = _free_port()
+    mp.spawn(_worker_root, args=(2, port, twin_lib, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "root_rank0.npy"), np.load(tmp_path / "root_rank1.npy")
+    np.testing.assert_array_equal(r0, r1)
+    assert np.load(tmp_path / "root_solved0.npy").all() and np.load(tmp_path / "root_solved1.npy").all()
+    from score_amd.solve_score import solve_score
+
+    single = [solve_score(g, "SOCP", lib_path=twin_lib) for g in _root_graphs()]
+    flat = np.concatenate([np.concatenate([r.poses[n].ravel() for n in sorted(r.poses)] + [np.asarray(r.landmarks[n]).ravel() for n in sorted(r.landmarks)]) for r in single])
     np.testing.assert_allclose(r0, flat, atol=1e-6)
 
 
@@ -82,6 +124,11 @@ for a, b in zip(res, ref):
         worst = max(worst, float(np.abs(a.poses[n] - b.poses[n]).max()))
     for n in b.landmarks:
         worst = max(worst, float(np.abs(a.landmarks[n] - b.landmarks[n]).max()))
+assert worst <= 1e-9, worst
+res2 = solve_score_sharded(graphs, "SOCP", device=0, root=0)  # the graphs broadcast from rank 0 first (RCCL broadcast through the GPU)
+for a, b in zip(res2, ref):
+    for n in b.poses:
+        worst = max(worst, float(np.abs(a.poses[n] - b.poses[n]).max()))
 assert worst <= 1e-9, worst
 dist.barrier()
 dist.destroy_process_group()
