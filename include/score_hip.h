@@ -314,6 +314,14 @@ void score_refine_destroy(score_refine* r);
 const char* score_last_error(void);
 const char* score_backend(void);   /* "hip-gfx950" or "cpu-twin"             */
 
+/* Layout version of the structs above.  A binding built against another header (an out-of-tree ctypes
+ * struct, say) would be misread silently -- score_create_batch walks an ARRAY of score_problem, so a
+ * stale stride goes wrong from the second problem on.  Bump SCORE_ABI_VERSION whenever a struct changes;
+ * loaders compare (score_amd.solver.load_library does).  History: 1 = rounds 1-2, 2 = score_problem
+ * gained rep_d / rep_n, 3 = this function.                                                        */
+#define SCORE_ABI_VERSION 3
+int32_t score_abi_version(void);   /* SCORE_ABI_VERSION of the library's build, times 1000, plus sizeof(score_problem) */
+
 #ifdef __cplusplus
 }
 #endif

@@ -675,6 +675,7 @@ int score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rota
 }
 int64_t score_trim_caches(void) { return 0; }  // the twin parks nothing
 const char* score_last_error(void) { return g_err.c_str(); }
+int32_t score_abi_version(void) { return SCORE_ABI_VERSION * 1000 + (int32_t)sizeof(score_problem); }
 const char* score_backend(void) { return "cpu-twin"; }
 }
 

@@ -534,7 +534,7 @@ struct HipBackend {
     CsrBufs Hm;
     DevBuf<double> q_Pon, q_ccoef, q_Bbuf, q_fpart, q_X0, q_X1, q_g, q_delta, q_fac, q_dinv, q_work, q_dummy, q_gd, q_pw;
     DevBuf<double> q_aabs, q_ck, q_theta, q_xstar;
-    DevBuf<int32_t> q_cptr, q_ccone, q_cab, q_head, q_ishead, q_posd, q_poss, q_diagpos, q_hblk_part, q_long;
+    DevBuf<int32_t> q_cptr, q_ccone, q_cab, q_head, q_ishead, q_posd, q_poss, q_diagpos, q_hblk_part, q_long, q_long_prob;
     int n_long = 0;
     // lock-step polish of a batch (count > 1)
     DevBuf<int32_t> q_skip, q_reref, q_fskip, q_act;  // (q_skip, q_reref, q_fskip: views into ctl)
@@ -986,6 +986,7 @@ struct HipBackend {
         else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
         else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
         else hipLaunchKernelGGL(k_factor<4>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
+        if (np > 65535) throw std::runtime_error("too many preconditioner work items for one handle (65535): split the batch");
         const int64_t nf = (int64_t)(newton_set ? H->fac_doubles_H : H->fac_doubles);
         if ((newton_set ? newton_fac32 : use_fac32) && nf > 0) {
             float* shadow = newton_set ? q_fac32.d : fac32.d;
@@ -1249,11 +1250,57 @@ struct HipBackend {
     }
     // the products with the Newton matrix (plain rows)
     template <int MODE>
-    void launch_h(const SpmvArgs& a_in) {
-        if (Hb.on) { launch_band<MODE>(Hm, Hb, a_in); return; }
+    void launch_h(const SpmvArgs& a_in, int slot = -1) {
+        if (Hb.on) { launch_band<MODE>(Hm, Hb, a_in, slot); return; }
         SpmvArgs a = a_in;
         const unsigned grid = xcd_grid(a, Hm.nblocks);
-        hipLaunchKernelGGL(k_spmv<MODE>, dim3(grid), dim3(kThreads), 0, stream, a);
+        launch_on_stream(k_spmv<MODE>, dim3(grid), dim3(kThreads), 0, slot, a);
+    }
+    // ---- probe of the Newton PCG's launches (score_debug_get "newton_probe_arm" / "newton_probe"): the next polish
+    //      binds start / stop events to its chain-kernel STEPs and H products (as score_time_iteration does for the ADMM
+    //      loop) and reports the mean dispatch duration of those that did work (launches queued beyond a solve's
+    //      convergence are no-ops and are left out) ----
+    static constexpr int kProbeCap = 1024;
+    bool np_armed = false;
+    std::vector<hipEvent_t> np_ev;
+    struct ProbeSlot { int kind, newton_it, step; bool real; };
+    std::vector<ProbeSlot> np_slots;
+    int np_newton_it = 0;
+    double np_out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int probe_slot(int kind, int step) {
+        if (!np_armed || (int)np_slots.size() >= kProbeCap) return -1;
+        np_slots.push_back(ProbeSlot{kind, np_newton_it, step, false});
+        tev = np_ev.data();
+        return (int)np_slots.size() - 1;
+    }
+    void probe_mark(int used) {  // the PCG steps of the current Newton iteration that did work
+        for (auto& sl : np_slots)
+            if (sl.newton_it == np_newton_it && sl.step < used) sl.real = true;
+    }
+    void probe_collect() {
+        if (!np_armed) return;
+        double sum[2] = {0, 0};
+        int cnt[2] = {0, 0};
+        for (size_t i = 0; i < np_slots.size(); ++i) {
+            if (!np_slots[i].real) continue;
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, np_ev[2 * i], np_ev[2 * i + 1]) != hipSuccess) continue;
+            sum[np_slots[i].kind] += 1e3 * (double)ms;
+            cnt[np_slots[i].kind] += 1;
+        }
+        const HostSystem& h = *H;
+        // algorithmic bytes: H product (KPB: + p, z, w_old in, p out), chain STEP of the Newton set (every chain its own factors)
+        double hbytes = 0.0;
+        if (Hb.on) { for (double b : Hb.L.bytes) hbytes += b; }
+        else hbytes = 12.0 * (double)Q.Hm.col.size() + 4.0 * (double)(h.n_tot + 1);
+        hbytes += 40.0 * (double)h.n_tot;
+        const double fbytes = (newton_fac32 ? 4.0 : 8.0) * (double)h.fac_doubles_H;
+        np_out[0] = cnt[0]; np_out[1] = cnt[0] ? sum[0] / cnt[0] : 0.0; np_out[2] = hbytes;
+        np_out[3] = cnt[1]; np_out[4] = cnt[1] ? sum[1] / cnt[1] : 0.0; np_out[5] = fbytes;
+        np_out[6] = (double)hblocks(); np_out[7] = (double)n_prec;
+        for (hipEvent_t e : np_ev) (void)hipEventDestroy(e);
+        np_ev.clear(); np_slots.clear();
+        np_armed = false;
     }
     template <int MODE>
     void launch_spmv(const CsrBufs& M, const SpmvArgs& a_in, int slot = -1) {
@@ -1556,6 +1603,24 @@ struct HipBackend {
             return 3;
         }
         else if (nm == "fac") { src = fac.d; sz = (int64_t)h.fac_doubles; }
+        else if (nm == "newton_probe_arm") {  // the next polish times its PCG launches (see probe_slot)
+            if (!Q.available) return -1;
+            if (out && len > 0) {
+                for (hipEvent_t e : np_ev) (void)hipEventDestroy(e);
+                np_ev.assign((size_t)2 * kProbeCap, nullptr);
+                for (auto& e : np_ev)
+                    if (hipEventCreate(&e) != hipSuccess) return -2;
+                np_slots.clear();
+                np_armed = true;
+                out[0] = 1.0;
+            }
+            return 1;
+        }
+        else if (nm == "newton_probe") {
+            // [H products timed, mean us, bytes per launch, chain STEPs timed, mean us, factor bytes per launch, H tiles, prec work items]
+            if (out && len > 0) std::memcpy(out, np_out, sizeof(double) * (size_t)std::min<int64_t>(len, 8));
+            return 8;
+        }
         // ---- kernel-level checks of the Newton polish (tests/test_gpu_parity.py) ----
         else if (nm == "polish_assemble_at_x") {
             // evaluate F, gradient, generalised Hessian and its chain factors at the current ADMM
@@ -1754,11 +1819,16 @@ struct HipBackend {
             q_entpart.upload(ep);
         }
         {
-            std::vector<int32_t> longs;
+            std::vector<int32_t> longs, lprob;
+            int pr = 0;
             for (size_t e = 0; e + 1 < Q.cptr.size(); ++e)
-                if (Q.cptr[e + 1] - Q.cptr[e] > kLongContrib) longs.push_back((int32_t)e);
+                if (Q.cptr[e + 1] - Q.cptr[e] > kLongContrib) {
+                    while (pr + 1 < h.count && (int64_t)e >= (int64_t)Q.Hm.ptr[(size_t)h.xoff[pr + 1]]) ++pr;
+                    longs.push_back((int32_t)e);
+                    lprob.push_back(pr);
+                }
             n_long = (int)longs.size();
-            q_long.upload(longs);
+            q_long.upload(longs); q_long_prob.upload(lprob);
         }
         const size_t nc = h.cone_row.size();
         q_Bbuf.alloc(nc * Q.T * Q.T);
@@ -1823,7 +1893,9 @@ struct HipBackend {
         ha.ndiag = (int)h.diag_cols.size(); ha.diag_pos = q_diagpos.d; ha.dinv = q_dinv.d;
         ha.ent_part = q_entpart.d; ha.skip = q_skip.d;  // (the live mask: a frozen problem's matrix is not read any more)
         const int base_blocks = (int)((q_ent_max + kThreads - 1) / kThreads);
-        hipLaunchKernelGGL(k_hassemble, dim3((unsigned)(base_blocks + n_long), (unsigned)h.count), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d, base_blocks);
+        hipLaunchKernelGGL(k_hassemble, dim3((unsigned)((int64_t)base_blocks * h.count + n_long)), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d,
+                           (const int32_t*)q_long_prob.d, base_blocks, h.count);
+        HIP_CHECK(hipGetLastError());
         if (n_prec_items() && refactor) {  // chain factors and the reciprocal Jacobi diagonal, one launch
             FactorArgs fa{};
             fa.work = prec_work.d; fa.chains = chainsH.d; fa.levels = levelsH.d; fa.Hval = Hm.val.d;
@@ -1962,11 +2034,13 @@ struct HipBackend {
             pa.gate_first = first ? 1 : 0;
             pa.r_in = first ? q_negg.d : r.d;
             pa.xt_zero = first ? 1 : 0;
-            launch_prec<PREC_STEP>(pa);   // delta += a p ; r -= a w ; z = M^-1 r   (or: gate fires, nothing happens)
+            launch_prec<PREC_STEP>(pa, probe_slot(1, pcg_steps_queued));   // delta += a p ; r -= a w ; z = M^-1 r   (or: gate fires, nothing happens)
+            tev = nullptr;
             SpmvArgs a = spmv_args(Hm, pcg_p_cur);
             a.p = pcg_p_cur; a.z = z.d; a.p_out = pcg_p_oth; a.rz_new = rz_nxt; a.rz_old = pcg_rz_cur; a.pw_part = q_pw.d; a.done = q_pcgdone.d;
             a.early_done = 1;
-            launch_h<MODE_KPB>(a);
+            launch_h<MODE_KPB>(a, probe_slot(0, pcg_steps_queued));
+            tev = nullptr;
             std::swap(pcg_p_cur, pcg_p_oth);
             if (++pcg_steps_queued % kDirectEvery == 0) {  // (see linear_solve_core)
                 SpmvArgs d = spmv_args(Hm, pcg_p_cur);
@@ -2055,7 +2129,8 @@ struct HipBackend {
                 std::fprintf(stderr, "[score] newton it %d: active-set flips since the last factorisation (max over live problems) %.0f -> %d problems refactor\n", it + 1, mx, nre);
             }
             upload_skip(live);
-            newton_hessian(q_fskip.d, refactor);  // (the matrix entries of a frozen problem are simply re-derived)
+            np_newton_it = it;
+            newton_hessian(q_fskip.d, refactor);  // (a frozen problem's short entries keep their values, see k_hassemble)
             newton_pcg_enqueue(live, eta, n_pcg, false);
             eta_prev = eta;
             bool control_stale = false;
@@ -2100,6 +2175,7 @@ struct HipBackend {
                     }
                     pcg_used_total += used_now;
                     used_prev = used_now;
+                    probe_mark(used_now);
                 }
                 std::vector<int32_t> acc_now(count, 0);
                 bool any_acc = false, any_ls = false;
@@ -2171,6 +2247,7 @@ struct HipBackend {
         }
         HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipGetLastError());
+        probe_collect();
         return true;
     }
 
@@ -2681,5 +2758,6 @@ int64_t score_trim_caches(void) {
     return (int64_t)freed;
 }
 const char* score_last_error(void) { return g_err.c_str(); }
+int32_t score_abi_version(void) { return SCORE_ABI_VERSION * 1000 + (int32_t)sizeof(score_problem); }
 const char* score_backend(void) { return "hip-gfx950"; }
 }

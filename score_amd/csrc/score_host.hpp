@@ -172,15 +172,28 @@ inline std::atomic<TeamPool*>& team_pool_slot() {
     static std::atomic<TeamPool*> slot{nullptr};
     return slot;
 }
-inline TeamPool* team_pool() {
+inline std::mutex& team_pool_make_mutex() {
     static std::mutex make;
+    return make;
+}
+inline TeamPool* team_pool() {
+    std::mutex& make = team_pool_make_mutex();
     static std::once_flag fork_hook;
     TeamPool* t = team_pool_slot().load(std::memory_order_acquire);
     if (t) return t;
     std::lock_guard<std::mutex> lk(make);
     t = team_pool_slot().load(std::memory_order_acquire);
     if (!t) {
-        std::call_once(fork_hook, [] { pthread_atfork(nullptr, nullptr, [] { team_pool_slot().store(nullptr); }); });
+        // a forked child has none of the parent's threads: no team, nobody inside a build or a parallel region
+        std::call_once(fork_hook, [] {
+            // (the creation mutex is taken across the fork, so the child never inherits it locked by a thread it does not have)
+            pthread_atfork([] { team_pool_make_mutex().lock(); }, [] { team_pool_make_mutex().unlock(); }, [] {
+                team_pool_slot().store(nullptr);
+                active_builders().store(0);
+                extra_threads_busy().store(0);
+                team_pool_make_mutex().unlock();
+            });
+        });
         t = new TeamPool();
         team_pool_slot().store(t, std::memory_order_release);
     }
@@ -289,20 +302,26 @@ inline int parallel_parts(int64_t n, int64_t min_per_thread) {
 // "its" rows in its own cache across the passes of an iterative setup step.
 struct TeamBarrier {
     explicit TeamBarrier(int n) : T(n) {}
+    // a member that fails calls abort() instead of arriving: the others leave their wait with an exception
+    void abort() { failed.store(true, std::memory_order_release); }
     void wait() {
         if (T <= 1) return;
+        if (failed.load(std::memory_order_acquire)) throw std::runtime_error("parallel setup aborted: another part failed");
         const int g = gen.load(std::memory_order_acquire);
         if (count.fetch_add(1, std::memory_order_acq_rel) == T - 1) {
             count.store(0, std::memory_order_relaxed);
             gen.store(g + 1, std::memory_order_release);
         } else {
             int spins = 0;
-            while (gen.load(std::memory_order_acquire) == g)
+            while (gen.load(std::memory_order_acquire) == g) {
+                if (failed.load(std::memory_order_acquire)) throw std::runtime_error("parallel setup aborted: another part failed");
                 if (++spins > 4096) std::this_thread::yield();
+            }
         }
     }
     int T;
     std::atomic<int> count{0}, gen{0};
+    std::atomic<bool> failed{false};
 };
 
 struct Csr {
@@ -975,6 +994,10 @@ inline void ruiz_scale(const score_problem& p, int iters, ProblemScaled& out, in
     if (iters > 0 && !offloaded)
         parallel_ranges_balanced(n_act, 4096, col_weight, [&, T](int t, int64_t a0, int64_t a1) {
             const int64_t g0 = ngroups * t / T, g1 = ngroups * (t + 1) / T;
+            struct Guard {  // (an exception in this part must not leave the others waiting at the barrier)
+                TeamBarrier& b; bool ok = false;
+                ~Guard() { if (!ok) b.abort(); }
+            } guard{bar};
             for (int it = 0; it < iters; ++it) {
                 for (int64_t a = a0; a < a1; ++a) {
                     const int64_t j = act_col(a);
@@ -1008,6 +1031,7 @@ inline void ruiz_scale(const score_problem& p, int iters, ProblemScaled& out, in
                     for (int r = gstart[(size_t)g]; r < gstart[(size_t)g + 1]; ++r) E[r] *= e[(size_t)g];
                 bar.wait();  // D, E updated: the next pass reads them
             }
+            guard.ok = true;
         }, T);
     phase_mark(pt, "  ruiz: passes");
     // the equilibrated values, once

@@ -65,13 +65,17 @@ struct HAsmArgs {
 
 constexpr int kLongContrib = 64;  // entries with more contributions get a workgroup of their own
 
-// grid.x = ceil(largest problem's entries / 256) entry blocks followed by one block per long entry (k_hassemble_long's
-// work), grid.y = problems
-__global__ __launch_bounds__(kThreads) void k_hassemble(HAsmArgs a, const int32_t* long_entries, int first_long_block) {
+// 1-D grid: `count` x `blocks_per_problem` entry blocks (problem q = block / blocks_per_problem: entries
+// [ent_part[q], ent_part[q + 1]), 256 per block), then one block per long entry.  A frozen problem (skip[q] != 0) keeps
+// its matrix, the long entries included (long_prob: their problems) -- nothing reads it any more.
+__global__ __launch_bounds__(kThreads) void k_hassemble(HAsmArgs a, const int32_t* long_entries, const int32_t* long_prob, int blocks_per_problem,
+                                                        int count) {
+    const int first_long_block = blocks_per_problem * count;
     if ((int)blockIdx.x >= first_long_block) {
-        if (blockIdx.y != 0) return;  // (the long entries: one workgroup each, whatever their problem)
         __shared__ double red[8];
-        const int64_t pl = long_entries[blockIdx.x - first_long_block];
+        const int li = (int)blockIdx.x - first_long_block;
+        if (a.skip && a.skip[long_prob[li]]) return;
+        const int64_t pl = long_entries[li];
         const int c0 = a.cptr[pl], c1 = a.cptr[pl + 1];
         double v = 0.0;
         for (int c = c0 + (int)threadIdx.x; c < c1; c += kThreads) v += a.ccoef[c] * a.Bbuf[(size_t)a.ccone[c] * a.T2 + a.cab[c]];
@@ -82,12 +86,12 @@ __global__ __launch_bounds__(kThreads) void k_hassemble(HAsmArgs a, const int32_
         }
         return;
     }
-    const int q = blockIdx.y;
+    const int q = (int)blockIdx.x / blocks_per_problem;
     if (a.skip && a.skip[q]) return;
-    const int64_t p = a.ent_part[q] + (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    const int64_t p = a.ent_part[q] + (int64_t)((int)blockIdx.x - q * blocks_per_problem) * kThreads + threadIdx.x;
     if (p >= a.ent_part[q + 1]) return;
     const int c0 = a.cptr[p], c1 = a.cptr[p + 1];
-    if (c1 - c0 > kLongContrib) return;  // k_hassemble_long
+    if (c1 - c0 > kLongContrib) return;  // (a long entry: its own block)
     double v = a.Pon[p];
     const int d = a.dst ? a.dst[p] : -1;
     for (int c = c0; c < c1; ++c) v += a.ccoef[c] * a.Bbuf[(size_t)a.ccone[c] * a.T2 + a.cab[c]];

@@ -81,8 +81,10 @@ ABI_SYMBOLS = [
     "score_assemble", "score_assembled_view", "score_assembled_free", "score_round_to_so",
     "score_default_settings", "score_create", "score_create_batch", "score_dims", "score_solve",
     "score_reset", "score_solve_steps", "score_newton_steps", "score_linear_create", "score_linear_solve", "score_refine_create", "score_refine_run", "score_refine_destroy", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
-    "score_trim_caches", "score_last_error", "score_backend",
+    "score_trim_caches", "score_last_error", "score_backend", "score_abi_version",
 ]
+
+ABI_VERSION = 3  # SCORE_ABI_VERSION of include/score_hip.h this binding's structs follow
 
 
 def load_library(path: Optional[str] = None) -> C.CDLL:
@@ -122,6 +124,11 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.score_trim_caches.restype = C.c_int64
     lib.score_last_error.restype = C.c_char_p
     lib.score_backend.restype = C.c_char_p
+    lib.score_abi_version.restype = C.c_int32
+    want = ABI_VERSION * 1000 + C.sizeof(ScoreProblem)
+    if lib.score_abi_version() != want:
+        raise RuntimeError(f"{path}: ABI {lib.score_abi_version()} (version * 1000 + sizeof(score_problem)), this binding expects {want}: "
+                           "rebuild the library or update the binding")
     return lib
 
 
