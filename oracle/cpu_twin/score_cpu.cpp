@@ -348,8 +348,8 @@ struct CpuBackend {
             // Layout check of the product's band view (score_band.hpp) on the host: build the view of K (as the
             // backend would: owner chains, stored row segments) or of the Newton matrix pattern, fill V through dst,
             // apply it with band_apply_host and compare with the CSR rows.
-            // -> [max |difference|, on, band tiles, csr tiles, diag tiles, slots, bytes of problem 0, source nnz, V size]
-            double res[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            // -> [max |difference|, on, band tiles, csr tiles, diag tiles, slots, bytes of problem 0, source nnz, V size, layout build ms]
+            double res[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
             const bool newton = nm == "band_check_h";
             PolishData Q;
             std::vector<double> hval;
@@ -379,7 +379,9 @@ struct CpuBackend {
                 } else {
                     sg = plain_segments(h.xoff);
                 }
+                const double tb0 = now_ms();
                 L = build_band_layout(h.K, sg, band_runs(h.chains, use, h.bs, h.rep, h.rep_n, true), h.bs, h.count);
+                res[9] = now_ms() - tb0;
             }
             res[1] = L.on ? 1.0 : 0.0;
             if (L.on) {
@@ -410,8 +412,8 @@ struct CpuBackend {
                 res[2] = L.n_band; res[3] = L.n_csr; res[4] = L.n_diag; res[5] = L.S; res[6] = L.bytes.empty() ? 0.0 : L.bytes[0];
                 res[7] = (double)M->col.size(); res[8] = (double)L.v_size;
             }
-            if (out && len > 0) std::memcpy(out, res, sizeof(double) * (size_t)std::min<int64_t>(len, 9));
-            return 9;
+            if (out && len > 0) std::memcpy(out, res, sizeof(double) * (size_t)std::min<int64_t>(len, 10));
+            return 10;
         }
         else return -1;
         if (out) std::memcpy(out, src, sizeof(double) * (size_t)std::min(len, sz));

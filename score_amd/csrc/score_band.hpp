@@ -96,39 +96,40 @@ inline BandLayout build_band_layout(const Csr& M, const std::vector<RowSegment>&
     BandLayout L;
     L.bs = bs;
     if (runs.empty() || bs < 1 || bs > kMaxBs) return L;
+    PhaseTimer bt_(std::getenv("SCORE_BAND_TIMING") != nullptr);
     const int32_t* ptr = M.ptr.data();
     const int32_t* col = M.col.data();
     // ---- pass 1: window offsets in use, per class ----
     const int W = 3 * bs;  // window positions: offsets -bs .. 2 bs - 1
-    std::vector<uint32_t> masks((size_t)runs.size() * kMaxBs, 0u);
+    std::vector<uint32_t> masks(kMaxBs, 0u);
     std::vector<int64_t> node0((size_t)runs.size() + 1, 0);  // node numbering over all runs
     for (size_t r = 0; r < runs.size(); ++r) node0[r + 1] = node0[r] + (runs[r].r1 - runs[r].r0) / bs;
     const int64_t n_nodes = node0.back();
     std::vector<int32_t> node_rem((size_t)n_nodes, 0);  // remainder entries per node
-    for (size_t r = 0; r < runs.size(); ++r) {
-        const BandRun& R = runs[r];
-        const int64_t nn = (R.r1 - R.r0) / bs;
-        parallel_ranges(nn, 4096, [&](int, int64_t j0, int64_t j1) {
-            uint32_t mk[kMaxBs] = {0, 0, 0, 0};
-            for (int64_t j = j0; j < j1; ++j) {
-                const int64_t nb = R.r0 + j * bs;
-                int32_t rem = 0;
-                for (int c = 0; c < bs; ++c)
-                    for (int k = ptr[nb + c]; k < ptr[nb + c + 1]; ++k) {
-                        const int64_t w = (int64_t)col[k] - nb;
-                        if (w >= -bs && w < 2 * bs && col[k] >= R.r0 && col[k] < R.r1) mk[c] |= 1u << (int)(w + bs);
-                        else ++rem;
-                    }
-                node_rem[(size_t)(node0[r] + j)] = rem;
-            }
-            for (int c = 0; c < bs; ++c) __atomic_fetch_or(&masks[r * kMaxBs + c], mk[c], __ATOMIC_RELAXED);
-        });
-    }
+    // (one parallel sweep over the nodes of all runs: a batch is many short runs)
+    parallel_ranges(n_nodes, 1024, [&](int, int64_t g0, int64_t g1) {
+        uint32_t mk[kMaxBs] = {0, 0, 0, 0};
+        size_t r = (size_t)(std::upper_bound(node0.begin(), node0.end(), g0) - node0.begin()) - 1;
+        for (int64_t g = g0; g < g1; ++g) {
+            while (g >= node0[r + 1]) ++r;
+            const BandRun& R = runs[r];
+            const int64_t nb = R.r0 + (g - node0[r]) * bs;
+            int32_t rem = 0;
+            for (int c = 0; c < bs; ++c)
+                for (int k = ptr[nb + c]; k < ptr[nb + c + 1]; ++k) {
+                    const int64_t w = (int64_t)col[k] - nb;
+                    if (w >= -bs && w < 2 * bs && col[k] >= R.r0 && col[k] < R.r1) mk[c] |= 1u << (int)(w + bs);
+                    else ++rem;
+                }
+            node_rem[(size_t)g] = rem;
+        }
+        for (int c = 0; c < bs; ++c) __atomic_fetch_or(&masks[c], mk[c], __ATOMIC_RELAXED);
+    });
+    bt_.mark("band: pass 1");
     uint32_t cls_mask[kMaxBs] = {0, 0, 0, 0};
-    for (size_t r = 0; r < runs.size(); ++r) {
+    for (size_t r = 0; r < runs.size(); ++r)
         if (runs[r].r1 - runs[r].r0 < 2) return L;  // (the pair loads clamp to [run begin, run end - 2])
-        for (int c = 0; c < bs; ++c) cls_mask[c] |= masks[r * kMaxBs + c];
-    }
+    for (int c = 0; c < bs; ++c) cls_mask[c] = masks[c];
     // cover the used offsets of every class by pairs (w, w + 1), greedily from the left; classes with fewer pairs are
     // padded with their own diagonal (slots that stay zero)
     int8_t pair_off[kMaxBs][kBandMaxS / 2];
@@ -180,6 +181,7 @@ inline BandLayout build_band_layout(const Csr& M, const std::vector<RowSegment>&
             j = j1;
         }
     }
+    bt_.mark("band: tiles");
     // ---- rows outside the runs: diag tiles (rows holding only their diagonal) and CSR tiles ----
     struct Piece { int64_t r0, r1; int32_t prob, rs; bool diag; };
     std::vector<Piece> pieces;
@@ -214,7 +216,9 @@ inline BandLayout build_band_layout(const Csr& M, const std::vector<RowSegment>&
             if (!csr_segs.empty() && csr_segs.back().end == pc.r0 && csr_segs.back().prob == pc.prob && csr_segs.back().rs == pc.rs) csr_segs.back().end = pc.r1;
             else csr_segs.push_back(RowSegment{pc.r0, pc.r1, pc.prob, pc.rs});
         }
+    bt_.mark("band: pieces");
     const RowBlocks rbc = make_rowblocks(M, csr_segs, count, csr_tile_nnz);
+    bt_.mark("band: csr row blocks");
     L.n_long = rbc.n_long; L.n_long_slots = rbc.n_long_slots;
     // ---- V layout ----
     L.n_band = (int)bts.size();
@@ -230,6 +234,7 @@ inline BandLayout build_band_layout(const Csr& M, const std::vector<RowSegment>&
     L.rem_col.assign((size_t)rem_off.back(), 0);
     L.rowseg.assign((size_t)L.n_band * kBandLanes, 0);
     L.dst.assign(M.col.size(), -1);
+    bt_.mark("band: assign");
     // ---- fill the band tiles ----
     parallel_ranges(L.n_band, 8, [&](int, int64_t b0, int64_t b1) {
         for (int64_t b = b0; b < b1; ++b) {
@@ -257,6 +262,7 @@ inline BandLayout build_band_layout(const Csr& M, const std::vector<RowSegment>&
             for (int64_t k = rem_off[(size_t)b] + k_rem; k < rem_off[(size_t)b + 1]; ++k) L.rem_col[(size_t)k] = (int32_t)T.r0;  // (value 0)
         }
     });
+    bt_.mark("band: fill");
     // ---- the unified tile list, problem by problem ----
     L.part_ptr.assign((size_t)count + 1, 0);
     L.bytes.assign((size_t)count, 0.0);
@@ -306,6 +312,7 @@ inline BandLayout build_band_layout(const Csr& M, const std::vector<RowSegment>&
         L.part_ptr[(size_t)p + 1] = (int32_t)L.prob.size();
         L.bytes[(size_t)p] = by;
     }
+    bt_.mark("band: tile list");
     L.on = true;
     return L;
 }

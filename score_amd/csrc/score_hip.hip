@@ -643,6 +643,28 @@ struct HipBackend {
         // the Newton matrix pattern and its contribution lists only read the finished host system:
         // built on another thread while this one uploads (4.3 ms beside 2.4 ms of uploads / allocations)
         if (st.polish) polish_build = std::async(std::launch::async, [this, &h] { build_polish(h, Q, st.verbose != 0, band_h(h)); });
+        std::future<BandLayout> band_layout_job;
+        if (band_k(h) && !h.chains.empty())  // the band view of K only reads the finished host system: laid out on a thread of its own
+            band_layout_job = std::async(std::launch::async, [&h] {
+                BuildScope scope;
+                std::vector<char> use(h.chains.size());
+                for (size_t ci = 0; ci < h.chains.size(); ++ci) use[ci] = h.chain_owner[ci] == (int32_t)ci;
+                std::vector<RowSegment> sg;
+                if (h.rep > 1) {
+                    for (int p = 0; p < h.count; ++p) {
+                        const int64_t nr = h.rep_n[(size_t)p];
+                        sg.push_back(RowSegment{h.xoff[p], h.xoff[p] + nr, p, (int32_t)nr});
+                        sg.push_back(RowSegment{h.xoff[p] + (int64_t)h.rep * nr, h.xoff[p + 1], p, 0});
+                    }
+                } else {
+                    sg = plain_segments(h.xoff);
+                }
+                return build_band_layout(h.K, sg, band_runs(h.chains, use, h.bs, h.rep, h.rep_n, true), h.bs, h.count);
+            });
+        struct JoinBand {  // (an exception below must not leave the job running against a dying handle)
+            std::future<BandLayout>& f;
+            ~JoinBand() { if (f.valid()) f.wait(); }
+        } join_band{band_layout_job};
         K.upload(h.K, h.rbK);
         G1.upload(h.G1, h.rbG1);
         G2.upload(h.G2, h.rbG2, &h.g2_split);
@@ -652,27 +674,6 @@ struct HipBackend {
         G1.rep = h.rep; G1.rs_in = 1;
         K.unroll = (h.rep > 1) ? h.tile_nnz / kThreads : kUnroll;
         G1.unroll = (h.rep > 1) ? kUnroll / 2 : kUnroll;  // (tiles of at most kTileNnz / 2 nonzeros, see build_system)
-        if (band_k(h) && !h.chains.empty()) {  // band view of K: the chain rows without column indices (score_band.hpp)
-            std::vector<char> use(h.chains.size());
-            for (size_t ci = 0; ci < h.chains.size(); ++ci) use[ci] = h.chain_owner[ci] == (int32_t)ci;
-            std::vector<RowSegment> sg;
-            if (h.rep > 1) {
-                for (int p = 0; p < h.count; ++p) {
-                    const int64_t nr = h.rep_n[(size_t)p];
-                    sg.push_back(RowSegment{h.xoff[p], h.xoff[p] + nr, p, (int32_t)nr});
-                    sg.push_back(RowSegment{h.xoff[p] + (int64_t)h.rep * nr, h.xoff[p + 1], p, 0});
-                }
-            } else {
-                sg = plain_segments(h.xoff);
-            }
-            Kb.upload(build_band_layout(h.K, sg, band_runs(h.chains, use, h.bs, h.rep, h.rep_n, true), h.bs, h.count));
-            if (Kb.on)
-                for (int p = 0; p < h.count; ++p) h.kkt_bytes[(size_t)p] = Kb.L.bytes[(size_t)p] + 16.0 * (double)(h.xoff[p + 1] - h.xoff[p]);
-            if (st.verbose)
-                std::fprintf(stderr, "[score setup] band view of K: %s (%d band + %d csr + %d diag tiles, %d slots per row)\n", Kb.on ? "on" : "off",
-                             Kb.L.n_band, Kb.L.n_csr, Kb.L.n_diag, Kb.L.S);
-            pt.mark("band view of K");
-        }
         {
             std::vector<int32_t> vf, ve, vp;
             for (int p = 0; p < h.count; ++p)
@@ -731,7 +732,6 @@ struct HipBackend {
             if (n_large_cones) cone_large.upload(lg);
         }
         node_col.upload(h.node_col); diag_cols.upload(h.diag_cols);
-        kblk_part_ptr.upload(Kb.on ? Kb.L.part_ptr : h.rbK.part_ptr);
         prec_work.upload(h.prec_work); chains.upload(h.chains); levels.upload(h.levels);
         fac_rangeK.upload(h.fac_range); fac_rangeH.upload(h.fac_range_H);
         factor_work.upload(h.factor_work);
@@ -863,6 +863,16 @@ struct HipBackend {
             if (h.bs <= 1) allow_big_lds<1>(); else if (h.bs == 2) allow_big_lds<2>();
             else if (h.bs == 3) allow_big_lds<3>(); else allow_big_lds<4>();
         }
+        if (band_layout_job.valid()) {  // band view of K (score_band.hpp), laid out beside everything above
+            Kb.upload(band_layout_job.get());
+            if (Kb.on)
+                for (int p = 0; p < h.count; ++p) h.kkt_bytes[(size_t)p] = Kb.L.bytes[(size_t)p] + 16.0 * (double)(h.xoff[p + 1] - h.xoff[p]);
+            if (st.verbose)
+                std::fprintf(stderr, "[score setup] band view of K: %s (%d band + %d csr + %d diag tiles, %d slots per row)\n", Kb.on ? "on" : "off",
+                             Kb.L.n_band, Kb.L.n_csr, Kb.L.n_diag, Kb.L.S);
+            pt.mark("band view of K (wait + upload)");
+        }
+        kblk_part_ptr.upload(Kb.on ? Kb.L.part_ptr : h.rbK.part_ptr);
         xtu.alloc(h.n_tot + h.m_tot); xy.alloc(h.n_tot + h.m_tot); s.alloc(h.m_tot);
         r.alloc(h.n_tot); z.alloc(h.n_tot); p.alloc(h.n_tot); p2.alloc(h.n_tot); w.alloc(h.n_tot); kx.alloc(h.n_tot); step.alloc(h.count);
         pw_part.alloc(kblocks()); rz_part0.alloc(n_prec); rz_part1.alloc(n_prec);

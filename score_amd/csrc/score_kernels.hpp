@@ -33,6 +33,15 @@
 
 namespace score {
 
+// Bulk vector stores of the loop's kernels.  SCORE_NT_STORES (build switch, experiments): non-temporal stores -- the
+// data leaves the L2 as it is written instead of at the kernel's end (every kernel boundary first writes the
+// predecessor's dirty lines back).
+#ifdef SCORE_NT_STORES
+#define NTS(lhs, val) __builtin_nontemporal_store((val), &(lhs))
+#else
+#define NTS(lhs, val) ((lhs) = (val))
+#endif
+
 constexpr int kThreads = 256;
 constexpr int kUnroll = kTileNnz / kThreads;  // 8 nonzeros per lane
 constexpr int kLongUnroll = 2;  // nonzeros per lane and trip of a long row (segments hold <= kLongSeg = 512)
@@ -432,11 +441,11 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
                     const double xt = e3[q] + beta * e4[q];
                     kxv += beta * e5[q];
                     xv = a.alpha_relax * xt + (1.0 - a.alpha_relax) * xv;
-                    a.xt_rw[o] = xt;
-                    a.kx_rw[o] = kxv;
-                    a.x_rw[o] = xv;
+                    NTS(a.xt_rw[o], xt);
+                    NTS(a.kx_rw[o], kxv);
+                    NTS(a.x_rw[o], xv);
                 }
-                a.r[o] = a.sigma * xv - e2[q] + sum[q] - kxv;
+                NTS(a.r[o], a.sigma * xv - e2[q] + sum[q] - kxv);
             }
         }
     } else if (MODE == MODE_KP || MODE == MODE_KPB) {
@@ -451,11 +460,11 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
                     // row's own entry.  (The first product of a solve is always the direct one, MODE_KP.)
                     sq += beta * e0[q];
                     pi = e1[q] + beta * e2[q];
-                    a.p_out[o] = pi;
+                    NTS(a.p_out[o], pi);
                 } else {
                     pi = e0[q];
                 }
-                a.w[o] = sq;
+                NTS(a.w[o], sq);
                 local += pi * sq;
             }
         }
@@ -469,7 +478,7 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
             const double g = head ? 0.0 : sum[0] + qi + sum2;
             if (g != g) bad = 1.0;
             a.gout[row] = g;
-            a.r[row] = -g;
+            NTS(a.r[row], -g);
             m0 = fabs(g) * a.invD[row];
             m1 = fabs(g);
             const double xi = xin[row];
@@ -550,11 +559,11 @@ __device__ __forceinline__ double kp_row_finish(const SpmvArgs& a, const int row
         if (MODE == MODE_KPB) {  // K (z + beta p) = K z + beta w_old, see spmv_tile
             sq += beta * e0[q];
             pi = e1[q] + beta * e2[q];
-            a.p_out[o] = pi;
+            NTS(a.p_out[o], pi);
         } else {
             pi = e0[q];
         }
-        a.w[o] = sq;
+        NTS(a.w[o], sq);
         local += pi * sq;
     }
     return local;
@@ -936,15 +945,15 @@ __device__ __forceinline__ double prec_jacobi_item(const PrecArgs& a, const Prec
                 double r_ = rv[u];
                 if (MODE == PREC_STEP) {
                     if (!a.split_update) {
-                        a.xt[cols[u]] = xv[u] + alpha * pv[u];
-                        a.kx[cols[u]] = kv[u] + alpha * wv[u];
+                        NTS(a.xt[cols[u]], xv[u] + alpha * pv[u]);
+                        NTS(a.kx[cols[u]], kv[u] + alpha * wv[u]);
                     }
                     r_ -= alpha * wv[u];
-                    a.r[cols[u]] = r_;
+                    NTS(a.r[cols[u]], r_);
                 }
                 const double zv = r_ * dv[u];
-                a.z[cols[u]] = zv;
-                if (MODE == PREC_INIT) a.p[cols[u]] = zv;
+                NTS(a.z[cols[u]], zv);
+                if (MODE == PREC_INIT) NTS(a.p[cols[u]], zv);
                 local += r_ * zv;
             }
         }
@@ -1034,10 +1043,10 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
                     if (idx < NB) {
                         double r_ = rv[u];
                         if (MODE == PREC_STEP) {
-                            a.xt[cols[u]] = xv[u] + alpha * pv[u];
-                            a.kx[cols[u]] = kv[u] + alpha * wv[u];
+                            NTS(a.xt[cols[u]], xv[u] + alpha * pv[u]);
+                            NTS(a.kx[cols[u]], kv[u] + alpha * wv[u]);
                             r_ -= alpha * wv[u];
-                            a.r[cols[u]] = r_;
+                            NTS(a.r[cols[u]], r_);
                         }
                         if (LDS0) v0[idx] = r_;
                     }
@@ -1261,8 +1270,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
             for (int u = 0; u < kPrecChunk; ++u) {
                 const int idx = base + u * kPrecThreads;
                 if (idx < NB) {
-                    if (LDS0) a.z[cols[u]] = zz[u];
-                    if (MODE == PREC_INIT) a.p[cols[u]] = zz[u];
+                    if (LDS0) NTS(a.z[cols[u]], zz[u]);
+                    if (MODE == PREC_INIT) NTS(a.p[cols[u]], zz[u]);
                     local += rv[u] * zz[u];
                 }
             }
@@ -1394,8 +1403,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
 #pragma unroll
         for (int u = 0; u < kPrecChunk; ++u) {
             if (wk.index + t + u * kPrecThreads < e_end) {
-                a.xt[idx[u]] = xv[u] + alpha * pv[u];
-                a.kx[idx[u]] = kv[u] + alpha * wv[u];
+                NTS(a.xt[idx[u]], xv[u] + alpha * pv[u]);
+                NTS(a.kx[idx[u]], kv[u] + alpha * wv[u]);
             }
         }
         return;
@@ -1543,7 +1552,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                 double r_ = rv[u];
                 if (MODE == PREC_STEP) {
                     r_ -= alpha * wv[u];
-                    a.r[cols[u]] = r_;
+                    NTS(a.r[cols[u]], r_);
                 }
                 v0[idx + pad(L0, idx / BS)] = r_;
                 rv[u] = r_;
@@ -1671,8 +1680,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
 #pragma unroll
             for (int u = 0; u < kHalf; ++u) {
                 if (t + (u0 + u) * kPrecThreads < NB) {
-                    a.xt[cols[u0 + u]] = xv[u] + alpha * pv[u];
-                    a.kx[cols[u0 + u]] = kv[u] + alpha * wq[u];
+                    NTS(a.xt[cols[u0 + u]], xv[u] + alpha * pv[u]);
+                    NTS(a.kx[cols[u0 + u]], kv[u] + alpha * wq[u]);
                 }
             }
         };
@@ -1856,8 +1865,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             const int idx = t + u * kPrecThreads;
             if (idx < NB) {
                 const double zz = v0[idx + pad(L0, idx / BS)];
-                a.z[cols[u]] = zz;
-                if (MODE == PREC_INIT) a.p[cols[u]] = zz;
+                NTS(a.z[cols[u]], zz);
+                if (MODE == PREC_INIT) NTS(a.p[cols[u]], zz);
                 local += rv[u] * zz;
             }
         }
@@ -1901,7 +1910,7 @@ __global__ __launch_bounds__(kThreads) void k_xupdate(VecArgs a) {
     const int row = a.first_row[b] + threadIdx.x;
     if (row < a.end_row[b]) {
         const double xt = a.xt[row] + alpha * a.p[row];
-        a.xt[row] = xt;
+        NTS(a.xt[row], xt);
         if (a.apply_alpha) a.kx[row] += alpha * a.w[row];
         a.x[row] = a.alpha_relax * xt + (1.0 - a.alpha_relax) * a.x[row];
     }
@@ -2062,9 +2071,9 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
                 const int i = row + k;
                 const double sn = (k == 0) ? head : tail * wv[k];
                 const double yn = yv[k] + rho * (sn - v[k]);
-                a.s[i] = sn;
-                a.y[i] = yn;
-                a.u[i] = rho * (bv[k] - sn) - yn;
+                NTS(a.s[i], sn);
+                NTS(a.y[i], yn);
+                NTS(a.u[i], rho * (bv[k] - sn) - yn);
             }
         return;
     }
@@ -2085,9 +2094,9 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
         const double sn = (k == 0) ? head : tail * a.s[i];
         const double v_ = a.u[i];
         const double yn = a.y[i] + rho * (sn - v_);
-        a.s[i] = sn;
-        a.y[i] = yn;
-        a.u[i] = rho * (a.b[i] - sn) - yn;
+        NTS(a.s[i], sn);
+        NTS(a.y[i], yn);
+        NTS(a.u[i], rho * (a.b[i] - sn) - yn);
     }
 }
 
@@ -2134,9 +2143,9 @@ __global__ __launch_bounds__(kThreads) void k_cone_wave(ConeArgs a, const int2* 
         const double sn = (k == 0) ? head : tail * a.s[i];
         const double v_ = a.u[i];
         const double yn = a.y[i] + rho * (sn - v_);
-        a.s[i] = sn;
-        a.y[i] = yn;
-        a.u[i] = rho * (a.b[i] - sn) - yn;
+        NTS(a.s[i], sn);
+        NTS(a.y[i], yn);
+        NTS(a.u[i], rho * (a.b[i] - sn) - yn);
     }
 }
 
@@ -2150,7 +2159,7 @@ __global__ __launch_bounds__(kThreads) void k_refresh_u(ConeArgs a) {
     const double rho = a.rho[prob];
     for (int k = 0; k < dim; ++k) {
         const int i = row + k;
-        a.u[i] = rho * (a.b[i] - a.s[i]) - a.y[i];
+        NTS(a.u[i], rho * (a.b[i] - a.s[i]) - a.y[i]);
     }
 }
 
