@@ -576,6 +576,14 @@ struct HipBackend {
     double newton_eta_coef = 1.0, newton_eta_pow = 0.5;
     double* h_newton = nullptr;  // window into h_rep: partials of the cone part of F
 
+    // Fused cones (FuseArgs, score_kernels.hpp): the right-hand-side kernel of iteration k + 1 evaluates the cones of iteration k
+    // -- five launches per ADMM iteration instead of six.  s and y alternate between their own buffers and s_alt / y_alt
+    // (evaluation j of a sequence reads copy (j - 1) & 1 and writes copy j & 1); the measuring iteration that closes every
+    // sequence runs the stand-alone cone kernel, which reads the current copy and writes the canonical one.
+    bool fuse_cone = false;
+    DevBuf<double> s_alt, y_alt;
+    int seq_idx = 0;  // iteration index within the current sequence (begin_sequence)
+    void begin_sequence() { seq_idx = 0; }
     int cg_iters = 2;
     const double* last_rz = nullptr;  // r'z partials / direction of the pending end-of-PCG update
     const double* last_p = nullptr;
@@ -873,6 +881,28 @@ struct HipBackend {
             pt.mark("band view of K (wait + upload)");
         }
         kblk_part_ptr.upload(Kb.on ? Kb.L.part_ptr : h.rbK.part_ptr);
+        {   // fused cones (FuseArgs): a single problem whose cones are all small second-order cones, d + 1 rows each from row 0
+            // on, every cone with a private head column (its head row is the ONE entry of that column of A -- the entry that
+            // owns the cone's new state); the pending xt update then belongs to the INIT launch's helper items
+            bool ok = h.count == 1 && uni_ranges && n_help > 0 && !split.active && prec_pre && st.fac_fp32 != 0 && n_large_cones == 0 &&
+                      !h.cone_row.empty() && std::getenv("SCORE_NO_FUSED_CONE") == nullptr;
+            const int dim = ok ? h.cone_dim[0] : 0;
+            ok = ok && dim >= 2 && dim <= kSmallCone && dim <= kMaxRep + 1;
+            for (size_t c = 0; c < h.cone_row.size() && ok; ++c) {
+                const int r0 = (int)c * dim;
+                ok = h.cone_type[c] == 1 && h.cone_dim[c] == dim && h.cone_row[c] == r0;
+                for (int k = 0; k < dim && ok; ++k) ok = (h.A.ptr[r0 + k + 1] - h.A.ptr[r0 + k]) <= kConeRowNnz;
+                if (!ok) break;
+                ok = h.A.ptr[r0 + 1] - h.A.ptr[r0] == 1;
+                if (!ok) break;
+                const int32_t hc = h.A.col[h.A.ptr[r0]];
+                ok = h.G1.ptr[hc + 1] - h.G1.ptr[hc] == 1 && h.G1.col[h.G1.ptr[hc]] == (int32_t)(h.n_tot + r0);
+            }
+            // (every other entry of A' must be a TAIL row: a head row referenced from a second place would write the state twice)
+            fuse_cone = ok;
+            if (fuse_cone) { s_alt.alloc(h.m_tot); y_alt.alloc(h.m_tot); s_alt.zero(stream); y_alt.zero(stream); }
+            if (st.verbose) std::fprintf(stderr, "[score setup] cone projections: %s\n", fuse_cone ? "fused into the right-hand-side kernel" : "their own launch");
+        }
         xtu.alloc(h.n_tot + h.m_tot); xy.alloc(h.n_tot + h.m_tot); s.alloc(h.m_tot);
         r.alloc(h.n_tot); z.alloc(h.n_tot); p.alloc(h.n_tot); p2.alloc(h.n_tot); w.alloc(h.n_tot); kx.alloc(h.n_tot); step.alloc(h.count);
         pw_part.alloc(kblocks()); rz_part0.alloc(n_prec); rz_part1.alloc(n_prec);
@@ -1019,6 +1049,7 @@ struct HipBackend {
         a.block_first = cone_block_first.d; a.block_prob = cone_block_prob.d;
         a.done = done.d; a.rho = rho.d; a.b = b.d; a.xt = gathered;
         a.s = s.d; a.y = xy.d + H->n_tot; a.u = xtu.d + H->n_tot;
+        a.s_in = a.s; a.y_in = a.y;
         a.alpha_relax = st.alpha; a.invE = invE.d; a.pres_part = pres_part.d;
         a.apply_alpha = 0; a.pfin = p.d; a.pw_in = pw_part.d; a.rz_in = rz_part0.d;
         a.prec_part_ptr = prec_part_ptr.d; a.kblk_part_ptr = kblk_part_ptr.d; a.step_out = step.d;
@@ -1174,9 +1205,9 @@ struct HipBackend {
     void launch_prec_bs(const PrecArgs& pa_in, int slot, bool use_fac32) {
         // (the k_prec_pre launches of a STEP carry the update helpers of a single-problem handle, see the records)
         PrecArgs pa = pa_in;
-        const bool help = MODE == PREC_STEP && n_help > 0 && pa.rec != nullptr && !pa.debug_skip;
+        const bool help = (MODE == PREC_STEP || pa.pend_p != nullptr) && n_help > 0 && pa.rec != nullptr && !pa.debug_skip;
         const int n_prec = this->n_prec + (help ? n_help : 0);
-        pa.split_update = help ? 1 : 0;
+        pa.split_update = (help && MODE == PREC_STEP) ? 1 : 0;
         // k_prec_pre (level 0 in registers, coarse levels in LDS) when every chain fits; 4 x 4 blocks (3-D problems) only
         // with the 4-byte factor stream (score_settings.fac_fp32), otherwise the streaming kernel
         if constexpr (BS <= 3) {
@@ -1387,11 +1418,26 @@ struct HipBackend {
     size_t ts_stride = 0;
     void enqueue_iteration(bool measure, bool first, unsigned long long* ts = nullptr) {
         auto slot = [&](int k) -> unsigned long long* { return ts ? ts + ts_stride * k : nullptr; };
+        const int idx = first ? (seq_idx = 0) : seq_idx;
+        ++seq_idx;
+        const bool fused = fuse_cone && !first;  // this iteration's right-hand side evaluates the previous iteration's cones
+        double* const s_buf[2] = {s.d, s_alt.d};
+        double* const y_buf[2] = {xy.d + H->n_tot, y_alt.d};
         {
             SpmvArgs ra = spmv_args(G1, xtu.d);
             ra.tstamp = slot(0);
             ra.apply_update = first ? 0 : 1;
             ra.pfin = last_p;
+            if (fused) {
+                FuseArgs& f = ra.F;
+                f.on = 1; f.dim = H->cone_dim[0]; f.u_col0 = (int)H->n_tot;
+                f.cone_cols = (const int4*)cone_cols.d; f.cone_vals = (const double2*)cone_vals.d;
+                f.b = b.d; f.rho = rho.d; f.alpha_relax = st.alpha;
+                f.s_old = s_buf[(idx - 1) & 1]; f.y_old = y_buf[(idx - 1) & 1];
+                f.s_new = s_buf[idx & 1]; f.y_new = y_buf[idx & 1];
+                f.u_out = xtu.d + H->n_tot; f.xt = xtu.d; f.pfin = last_p;
+                f.rz_in = last_rz; f.pw_in = pw_part.d; f.step_out = step.d;
+            }
             launch_spmv<MODE_RHS>(G1, ra, 0);
         }
         PrecArgs pa{};
@@ -1405,7 +1451,9 @@ struct HipBackend {
         double* p_oth = p2.d;
         pa.p = p_cur; pa.rz_in = nullptr; pa.rz_out = rz_cur;
         pa.tstamp = slot(1);
+        if (fused) { pa.pend_p = last_p; pa.pend_step = step.d; }  // (the helpers of this launch apply the pending xt += step * p)
         launch_prec<PREC_INIT>(pa, 1);
+        pa.pend_p = nullptr; pa.pend_step = nullptr;
         launch_kp(p_cur, slot(2), 2);
         for (int j = 2; j <= cg_iters; ++j) {
             double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
@@ -1417,6 +1465,7 @@ struct HipBackend {
             rz_cur = rz_nxt;
         }
         ConeArgs ca = cone_args(xtu.d);
+        const int cur = fuse_cone ? (idx & 1) : 0;  // the copy of s, y the last (fused) evaluation wrote
         if (measure) {
             pa.tstamp = nullptr;
             pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_meas1.d;
@@ -1427,13 +1476,14 @@ struct HipBackend {
             va.pw_part = pw_part.d; va.p = p_cur; va.w = w.d; va.kx = kx.d; va.xt = xtu.d; va.x = xy.d;
             va.alpha_relax = st.alpha; va.rz_old = rz_cur; va.apply_alpha = 0;
             hipLaunchKernelGGL(k_xupdate, dim3(n_vblocks), dim3(kThreads), 0, stream, va);
+            ca.s_in = s_buf[cur]; ca.y_in = y_buf[cur];  // (reads the current copy, writes the canonical one)
         } else {
             ca.apply_alpha = 1; ca.pfin = p_cur; ca.rz_in = rz_cur;
             last_rz = rz_cur;  // what the next iteration's right-hand-side kernel has to apply
             last_p = p_cur;
         }
         ca.tstamp = slot(5);
-        if (n_cone_blocks) {
+        if (n_cone_blocks && (measure || !fuse_cone)) {
             unsigned cgrid = (unsigned)n_cone_blocks;
             if (xcd_spmv && n_cone_blocks >= 16) { ca.xcd_chunk = (n_cone_blocks + 7) / 8; ca.n_blocks = n_cone_blocks; cgrid = 8u * (unsigned)ca.xcd_chunk; }
             launch_on_stream(k_cone, dim3(cgrid), dim3(kThreads), 0, 5, ca);
@@ -1472,6 +1522,7 @@ struct HipBackend {
             HIP_CHECK(hipStreamSynchronize(stream));
             for (int i = 0; i < warmup; ++i) enqueue_iteration(false, i == 0);
             for (int i = 0; i < iters; ++i) enqueue_iteration(false, warmup == 0 && i == 0, dts.d + per_iter * i);
+            if (fuse_cone) enqueue_iteration(true, false);  // (closes the sequence: the pending cones, s and y back in their own buffers)
             HIP_CHECK(hipMemcpyAsync(hts.data(), dts.d, nslot * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
             HIP_CHECK(hipGetLastError());
@@ -1503,17 +1554,18 @@ struct HipBackend {
             ~EvFree() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
         } ev_free{evs};
         for (auto& e : evs) HIP_CHECK(hipEventCreate(&e));
-        for (int i = 0; i < warmup; ++i) enqueue_iteration(false, false);
+        for (int i = 0; i < warmup; ++i) enqueue_iteration(false, fuse_cone && i == 0);
         for (int i = 0; i < iters; ++i) {
             tev = evs.data() + (size_t)12 * i;
-            enqueue_iteration(false, false);
+            enqueue_iteration(false, fuse_cone && warmup == 0 && i == 0);
         }
         tev = nullptr;
+        if (fuse_cone) enqueue_iteration(true, false);
         HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipGetLastError());
         for (int i = 0; i < iters; ++i)
             for (int k = 0; k < 6; ++k) {
-                if (k == 5 && !n_cone_blocks) continue;
+                if (k == 5 && (!n_cone_blocks || fuse_cone)) continue;  // (fused cones: no cone launch in these iterations)
                 float ms = 0.f;
                 HIP_CHECK(hipEventElapsedTime(&ms, evs[(size_t)12 * i + 2 * k], evs[(size_t)12 * i + 2 * k + 1]));
                 us[6 + k] += 1e3 * (double)ms / iters;

@@ -94,6 +94,39 @@ def test_update_helpers_change_no_bit(name, fixtures, hip_lib, monkeypatch):
     assert a.info["newton_cg_iters"] == b.info["newton_cg_iters"] and np.array_equal(a.x, b.x)
     with_h.close(); without.close()
 
+@pytest.mark.parametrize("name", ["manhattan", "graph3d", "prior2d"])
+def test_fused_cones_follow_the_six_launch_iteration(name, fixtures, hip_lib, monkeypatch):
+    """Single-problem handles of SCORE "SOCP" models let the right-hand-side kernel of iteration k + 1 evaluate the cone
+    projections of iteration k (FuseArgs: five launches per ADMM iteration; s and y alternate between two copies; the
+    pending xt update moves to the INIT launch's helper items).  Same formulas at the same points: the iterates, the
+    internal vectors and the polished solution equal those of the six-launch iteration (SCORE_NO_FUSED_CONE) to rounding,
+    at sequence lengths of both parities."""
+    _hip_only(hip_lib)
+    qp = assemble(graph_by_name(name, fixtures), "SOCP").qp
+    st = dict(adaptive_cg=0, check_interval=5)
+    monkeypatch.delenv("SCORE_NO_FUSED_CONE", raising=False)
+    fused = ConicSolver(qp, st, lib_path=hip_lib)
+    monkeypatch.setenv("SCORE_NO_FUSED_CONE", "1")
+    plain = ConicSolver(qp, st, lib_path=hip_lib)
+    monkeypatch.delenv("SCORE_NO_FUSED_CONE", raising=False)
+    fused.reset(); plain.reset()
+    for k in (1, 2, 4, 11, 25):
+        a, b = fused.steps(k)[0], plain.steps(k)[0]
+        for v in VECS + ("s", "y", "u"):
+            va, vb = fused.debug_get(v), plain.debug_get(v)
+            assert np.allclose(va, vb, rtol=1e-11, atol=1e-11 * max(1.0, float(np.abs(vb).max()))), (v, k, float(np.abs(va - vb).max()))
+        assert np.allclose(a.x, b.x, rtol=1e-11, atol=1e-12)
+    a, b = fused.solve()[0], plain.solve()[0]
+    assert a.solved and b.solved and a.info["iters"] == b.info["iters"] and a.info["newton_iters"] == b.info["newton_iters"]
+    assert np.allclose(a.x, b.x, rtol=1e-9, atol=1e-10)
+    fused.close(); plain.close()
+    # the ADMM loop alone runs to convergence on the fused path
+    lone = ConicSolver(qp, dict(polish=0), lib_path=hip_lib)
+    o = lone.solve()[0]
+    assert o.solved
+    lone.close()
+
+
 def test_xcd_aware_tile_order_changes_no_bit(fixtures, hip_lib, monkeypatch):
     """k_spmv / k_cone deal their tiles to the XCDs in contiguous runs (workgroup i takes tile (i % 8) * chunk + i / 8;
     the grid is rounded up and the surplus workgroups leave).  Which workgroup computes a tile changes nothing in
