@@ -885,7 +885,11 @@ struct HipBackend {
             // on, every cone with a private head column (its head row is the ONE entry of that column of A -- the entry that
             // owns the cone's new state); the pending xt update then belongs to the INIT launch's helper items
             bool ok = h.count == 1 && uni_ranges && n_help > 0 && !split.active && prec_pre && st.fac_fp32 != 0 && n_large_cones == 0 &&
-                      !h.cone_row.empty() && std::getenv("SCORE_NO_FUSED_CONE") == nullptr;
+                      !h.cone_row.empty() && std::getenv("SCORE_FUSED_CONE") != nullptr;
+            // (OPT-IN, SCORE_FUSED_CONE=1.  Measured on the headline problem: the fused right-hand side takes 13.9 us -- four
+            //  dependent trips: entries of A' -> cone records, s, y, b -> gathers of xt and p -> projection -- against 6.6 us
+            //  + 7.0 us for the two launches it replaces plus 1.4 us of boundary: 16.9 k it/s either way.  The launch saved
+            //  is paid back in the longer dependent chain of the row-parallel kernel.)
             const int dim = ok ? h.cone_dim[0] : 0;
             ok = ok && dim >= 2 && dim <= kSmallCone && dim <= kMaxRep + 1;
             for (size_t c = 0; c < h.cone_row.size() && ok; ++c) {
