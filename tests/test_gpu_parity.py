@@ -131,6 +131,37 @@ def test_fused_cones_follow_the_six_launch_iteration(name, fixtures, hip_lib, mo
     lone.close()
 
 
+def test_band_view_and_split_long_rows_against_the_csr_stream(fixtures, hip_lib, monkeypatch):
+    """K through its band view (score_band.hpp: chain rows as value-slot pairs without column indices, remainder
+    entries, diagonal tiles) and long rows in segments (the last segment to arrive adds the segment sums in segment
+    order) against the plain CSR-stream kernels (SCORE_NO_BAND, SCORE_NO_LONG_SPLIT): the same products up to the order
+    of a row's additions -- iterates of a lock-step batch of 2-D graphs (a landmark seen by > 512 ranges: split rows) and
+    of a 3-D graph (three replicas, 4 x 4 blocks: six slot pairs) to 1e-10; repeated runs of one handle are bit-identical
+    (the combine order of the segments does not depend on who arrives last)."""
+    _hip_only(hip_lib)
+    qps2 = [assemble(make_manhattan(n_robots=4, n_poses=1500 + 200 * k, n_beacons=2, seed=60 + k, p_range=0.3), "SOCP").qp for k in range(2)]
+    qp3 = assemble(graph_by_name("graph3d", fixtures), "SOCP").qp
+    st = dict(adaptive_cg=0, check_interval=5, polish=0)
+    for qps in (qps2, [qp3]):
+        monkeypatch.delenv("SCORE_NO_BAND", raising=False); monkeypatch.delenv("SCORE_NO_LONG_SPLIT", raising=False)
+        new = ConicSolver(qps, st, lib_path=hip_lib)
+        again = ConicSolver(qps, st, lib_path=hip_lib)
+        monkeypatch.setenv("SCORE_NO_BAND", "1"); monkeypatch.setenv("SCORE_NO_LONG_SPLIT", "1")
+        old = ConicSolver(qps, st, lib_path=hip_lib)
+        monkeypatch.delenv("SCORE_NO_BAND", raising=False); monkeypatch.delenv("SCORE_NO_LONG_SPLIT", raising=False)
+        for sv in (new, again, old):
+            sv.reset()
+        for k in (1, 6):
+            a, r, b = new.steps(k), again.steps(k), old.steps(k)
+            for v in VECS:
+                va, vr, vb = new.debug_get(v), again.debug_get(v), old.debug_get(v)
+                assert np.array_equal(va, vr), (v, k)
+                tol = 1e-10 if v in ("x", "xt", "s", "y", "u") else 1e-7
+                assert np.allclose(va, vb, rtol=0.0, atol=tol * max(1.0, float(np.abs(vb).max()))), (v, k, float(np.abs(va - vb).max()))
+        for sv in (new, again, old):
+            sv.close()
+
+
 def test_xcd_aware_tile_order_changes_no_bit(fixtures, hip_lib, monkeypatch):
     """k_spmv / k_cone deal their tiles to the XCDs in contiguous runs (workgroup i takes tile (i % 8) * chunk + i / 8;
     the grid is rounded up and the surplus workgroups leave).  Which workgroup computes a tile changes nothing in
