@@ -1021,19 +1021,30 @@ struct HipBackend {
             HIP_CHECK(hipFuncSetAttribute((const void*)k_factor<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));
         }
     }
-    // newton_set: the factors of the Newton matrix (every chain its own: chainsH / levelsH / q_fac)
-    void launch_factor(FactorArgs fa, int np, bool newton_set) {
-        if (np == 0) return;
-        fa.lds_wmat = factor_lds_wmat;
+    void launch_factor_kernels(const FactorArgs& fa, int np) {
         const int bs = H->bs;
         if (bs <= 1) hipLaunchKernelGGL(k_factor<1>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
         else if (bs == 2) hipLaunchKernelGGL(k_factor<2>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
         else if (bs == 3) hipLaunchKernelGGL(k_factor<3>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
         else hipLaunchKernelGGL(k_factor<4>, dim3(np), dim3(kThreads), factor_lds_bytes, stream, fa);
+    }
+    // newton_set: the factors of the Newton matrix (every chain its own: chainsH / levelsH / q_fac)
+    void launch_factor(FactorArgs fa, int np, bool newton_set) {
+        if (np == 0) return;
+        fa.lds_wmat = factor_lds_wmat;
+        const int bs = H->bs;
         if (np > 65535) throw std::runtime_error("too many preconditioner work items for one handle (65535): split the batch");
         const int64_t nf = (int64_t)(newton_set ? H->fac_doubles_H : H->fac_doubles);
-        if ((newton_set ? newton_fac32 : use_fac32) && nf > 0) {
+        // When every application of this factor set goes through k_prec_pre<.., float> (the 4-byte stream), k_factor writes the
+        // float copy itself and nobody reads the doubles: no rounding launch (33 us a time on the headline problem, seven times
+        // per default solve).  The streaming kernel reads `fac`: then the factors are rounded in place as before.
+        const bool want32 = (newton_set ? newton_fac32 : use_fac32) && nf > 0;
+        const bool direct32 = want32 && prec_pre && !split.active && std::getenv("SCORE_FAC_ROUND_LAUNCH") == nullptr;
+        fa.fac32 = direct32 ? (newton_set ? q_fac32.d : fac32.d) : nullptr;
+        launch_factor_kernels(fa, np);
+        if (want32) {
             float* shadow = newton_set ? q_fac32.d : fac32.d;
+            if (!direct32)
             // (chain by chain, honouring the launch's skip flags: the Newton polish re-factors only the problems whose
             //  active set has moved, and rounding the whole array again cost as much as re-factoring them)
             hipLaunchKernelGGL(k_fac_round_items, dim3(16, (unsigned)np), dim3(kThreads), 0, stream, fa.work,

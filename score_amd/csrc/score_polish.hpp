@@ -176,6 +176,8 @@ struct FactorArgs {
     const int32_t* pos_diag;   // per level-0 node, bs*bs positions in Hval
     const int32_t* pos_sub;
     double* fac;               // output, same layout as the ADMM factor
+    float* fac32;              // optional: the same values as floats, written with them (what k_prec_pre<.., float> streams) -- the
+                               // separate rounding launch is then only needed when something reads `fac` itself (the streaming kernel)
     double* work_mat;          // level >= 1 matrices: 2*bs*bs doubles per scratch node
     const int32_t* skip;       // optional, per problem: chains of a frozen problem keep their factors
     // Jacobi work items (columns outside every chain): dinv[e] = 1 / H[diag_pos[e]]
@@ -249,11 +251,22 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
         double* R = a.fac + L.offR;
         double* S = a.fac + L.offS;
         double* Bk = a.fac + L.offB;
+        float* R32 = a.fac32 ? a.fac32 + L.offR : nullptr;
+        float* S32 = a.fac32 ? a.fac32 + L.offS : nullptr;
+        float* B32 = a.fac32 ? a.fac32 + L.offB : nullptr;
         auto Rst = [&](int slot, int q, int j, const double* M) {
-            for (int e = 0; e < B2; ++e) R[((size_t)(slot * B2 + e) * L.P + q) * L.nruns + j] = M[e];
+            for (int e = 0; e < B2; ++e) {
+                const size_t o = ((size_t)(slot * B2 + e) * L.P + q) * L.nruns + j;
+                R[o] = M[e];
+                if (R32) R32[o] = (float)M[e];
+            }
         };
         auto Bst = [&](int slot, int i, const double* M) {
-            for (int e = 0; e < B2; ++e) Bk[(size_t)(slot * B2 + e) * L.N + i] = M[e];
+            for (int e = 0; e < B2; ++e) {
+                const size_t o = (size_t)(slot * B2 + e) * L.N + i;
+                Bk[o] = M[e];
+                if (B32) B32[o] = (float)M[e];
+            }
         };
         auto Bld = [&](int slot, int i, double* M) {
             for (int e = 0; e < B2; ++e) M[e] = Bk[(size_t)(slot * B2 + e) * L.N + i];
@@ -413,6 +426,7 @@ __global__ __launch_bounds__(kThreads) void k_factor(FactorArgs a) {
             for (int e = 0; e < B2; ++e) {
                 S[(size_t)(0 * B2 + e) * nsep + j] = Cl[e];
                 S[(size_t)(1 * B2 + e) * nsep + j] = Cr[e];
+                if (S32) { S32[(size_t)(0 * B2 + e) * nsep + j] = (float)Cl[e]; S32[(size_t)(1 * B2 + e) * nsep + j] = (float)Cr[e]; }
             }
             double* dstA = in_lds ? fl + ((size_t)(Ln.vec_off + j) * 2 + 0) * B2
                                   : a.work_mat + ((size_t)(ch.scratch_off + Ln.vec_off + j) * 2 + 0) * B2;
