@@ -608,6 +608,9 @@ struct HipBackend {
     static bool n_prec_chains(const HostSystem& h) { return !h.chains.empty(); }
 
     ~HipBackend() {
+        if (std::getenv("SCORE_HOST_TIMING"))
+            std::fprintf(stderr, "[score host] Newton PCG queueing: %.2f ms for %ld launches (%.2f us each); waits: %ld, %.2f ms\n", enq_ms, enq_launches,
+                         enq_launches ? 1e3 * enq_ms / (double)enq_launches : 0.0, waits, wait_ms);
         PhaseTimer pt(st.verbose != 0);
         if (stream) (void)hipStreamSynchronize(stream);
         pt.mark("destroy: sync");
@@ -1139,6 +1142,10 @@ struct HipBackend {
     // when nothing arrives within 2 s.  SCORE_WAIT_SPIN_US: length of the first phase (default 30).
     void wait_published(unsigned long long seq) {
         HIP_CHECK(hipGetLastError());
+        struct WaitTimer {
+            HipBackend* b; double t0;
+            ~WaitTimer() { b->wait_ms += now_ms() - t0; b->waits += 1; }
+        } wait_timer{this, now_ms()};
         static const double spin_us = std::getenv("SCORE_WAIT_SPIN_US") ? std::atof(std::getenv("SCORE_WAIT_SPIN_US")) : 30.0;
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
@@ -2068,12 +2075,19 @@ struct HipBackend {
     // raised by the device).  No host synchronisation.  `resume`: continue the solve the previous
     // call left unfinished (its state -- delta, r, z, p, w, the r'z partials -- is intact because a
     // gate that has not fired has not frozen anything).
+    // host-side cost of queueing the Newton PCG (SCORE_HOST_TIMING: printed when the handle goes)
+    double enq_ms = 0.0, wait_ms = 0.0;
+    long enq_launches = 0, waits = 0;
     int pcg_steps_queued = 0;
     double* pcg_rz_cur = nullptr;
     double* pcg_p_cur = nullptr;
     double* pcg_p_oth = nullptr;
     void newton_pcg_enqueue(const std::vector<char>& live, const std::vector<double>& eta, int n_iters, bool resume) {
         const HostSystem& h = *H;
+        struct EnqTimer {
+            HipBackend* b; double t0; int n;
+            ~EnqTimer() { b->enq_ms += now_ms() - t0; b->enq_launches += 2 * n + 2; }
+        } enq_timer{this, now_ms(), n_iters};
         // (a fresh solve finds its control words -- skip flags, tolerances -- uploaded by the caller)
         if (resume) upload_skip(live);
         (void)eta;
