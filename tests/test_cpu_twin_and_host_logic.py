@@ -292,3 +292,50 @@ def test_row_replicated_setup_equals_the_general_one(name, relax, fixtures, twin
     assert res.solved
     if name in GOLDEN_NAMES:
         compare_with_golden(res, load_golden(name), pose_tol=1e-4)
+
+
+@pytest.mark.parametrize("name,relax,replicated", [
+    ("goats", "SOCP", True), ("manhattan", "SOCP", True), ("manhattan", "SOCP", False), ("synth_b", "SOCP", True),
+    ("graph3d", "SOCP", True), ("graph3d", "SOCP", False), ("synth_d", "QCQP", True), ("prior2d", "SOCP", True),
+])
+def test_band_view_layout_reproduces_the_csr_rows(name, relax, replicated, fixtures, twin_lib, monkeypatch):
+    """The product streams K (and, on request, the Newton matrix) through a band view (csrc/score_band.hpp): chain rows as
+    value-slot pairs without column indices, a per-tile remainder, diagonal tiles, CSR tiles with long rows in segments.
+    The layout builder is host code shared with the twin, which applies it with band_apply_host (the specification of
+    k_spmv_band) and compares with the CSR rows: same products to rounding, every unknown's row served exactly once --
+    with and without the row-replicated host structures, 2-D and 3-D, loop closures, priors, the direct QCQP form (no
+    distance rows), the reference's GOATS data (one robot, 4 beacons seen hundreds of times: split long rows)."""
+    fg = graph_by_name(name, fixtures)
+    qp = assemble(fg, relax).qp if relax != "QCQP" else _model_for_direct(fg).qp
+    if replicated:
+        monkeypatch.setenv("SCORE_TWIN_REPLICATION", "1")
+    else:
+        monkeypatch.delenv("SCORE_TWIN_REPLICATION", raising=False)
+    sol = ConicSolver(qp, dict(polish=0), lib_path=twin_lib)
+    k = sol.debug_get("band_check")
+    assert k[1] == 1.0 and k[0] < 1e-12, k           # view on, products equal
+    assert k[2] >= 1 and k[5] in (8.0, 10.0, 12.0)    # band tiles exist; 4, 5 or 6 slot pairs per row
+    d = fg.dimension
+    assert k[5] == (8.0 if d == 2 else 12.0)
+    if relax == "SOCP":
+        h = sol.debug_get("band_check_h")
+        assert h[1] == 1.0 and h[0] < 1e-12, h
+    sol.close()
+
+
+def _model_for_direct(fg):
+    from score_amd.solve_score import _model_for
+
+    return _model_for(fg, "QCQP", "direct", assembler="python")
+
+
+def test_broadcast_graphs_without_a_process_group():
+    """broadcast_graphs / solve_score_sharded(root=) outside torch.distributed: the single-process code path returns the
+    graphs as ArrayGraphs and solves them like solve_score_batch."""
+    from score_amd.distributed import broadcast_graphs
+    from score_amd.native import ArrayGraph
+
+    graphs = [make_manhattan(n_robots=2, n_poses=12 + i, n_beacons=2, seed=70 + i) for i in range(2)]
+    out = broadcast_graphs(graphs, root=0)
+    assert len(out) == 2 and all(isinstance(g, ArrayGraph) for g in out)
+    assert out[0].num_poses == 24 and out[1].num_poses == 26
