@@ -41,6 +41,12 @@ namespace score {
 #else
 #define NTS(lhs, val) ((lhs) = (val))
 #endif
+// ... and the chain kernels' own (SCORE_NT_PREC: only those)
+#if defined(SCORE_NT_STORES) || defined(SCORE_NT_PREC)
+#define NTSP(lhs, val) __builtin_nontemporal_store((val), &(lhs))
+#else
+#define NTSP(lhs, val) ((lhs) = (val))
+#endif
 
 constexpr int kThreads = 256;
 constexpr int kUnroll = kTileNnz / kThreads;  // 8 nonzeros per lane
@@ -439,9 +445,17 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
                 }
             }
         }
-#pragma unroll
-        for (int q = 0; q < NR; ++q) sum[q] = block_sum(acc[q], red);
-        if (MODE == MODE_DRES || MODE == MODE_GRAD) sum2 = block_sum(acc2, red);
+        // (two sums per pair of barriers)
+        if (MODE == MODE_DRES || MODE == MODE_GRAD) {
+            block_sum2(acc[0], acc2, red);
+            sum[0] = acc[0]; sum2 = acc2;
+        } else if (NR == 1) {
+            sum[0] = block_sum(acc[0], red);
+        } else {
+            block_sum2(acc[0], acc[1], red);
+            sum[0] = acc[0]; sum[1] = acc[1];
+            if (NR > 2) sum[NR - 1] = block_sum(acc[NR - 1], red);
+        }
         if (nseg > 1) {
             // A segment publishes its sums (agent-scope stores, drained) and takes a ticket; every launch adds `nseg` to the
             // row's counter, so the segment that draws the last ticket of the launch knows that all sums are out: it adds them
@@ -457,13 +471,22 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
             }
             __syncthreads();
             if (!srow[0]) return;  // (uniform)
+            // (every published sum is requested at once -- one trip for the lanes together instead of a dependent load per
+            //  segment on lane 0 -- staged in LDS and added there in segment order)
             const double* all = a.M.long_part + (size_t)lg.z * kLongVals;
+            const bool staged = nseg * kLongVals <= NR * kPlane;  // (always, short of rows with > 70 000 nonzeros)
+            if (staged)
+                for (int i = t; i < nseg * kLongVals; i += kThreads)
+                    prod[i] = __hip_atomic_load(all + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
             if (t == 0) {
                 double tot[kLongVals] = {0.0, 0.0, 0.0, 0.0};
                 for (int sg = 0; sg < nseg; ++sg) {
 #pragma unroll
-                    for (int q = 0; q < NR; ++q) tot[q] += __hip_atomic_load(all + (size_t)sg * kLongVals + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (MODE == MODE_DRES || MODE == MODE_GRAD) tot[NR] += __hip_atomic_load(all + (size_t)sg * kLongVals + NR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int q = 0; q < NR; ++q)
+                        tot[q] += staged ? prod[sg * kLongVals + q] : __hip_atomic_load(all + (size_t)sg * kLongVals + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (MODE == MODE_DRES || MODE == MODE_GRAD)
+                        tot[NR] += staged ? prod[sg * kLongVals + NR] : __hip_atomic_load(all + (size_t)sg * kLongVals + NR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
 #pragma unroll
                 for (int q = 0; q < NR; ++q) sum[q] = tot[q];
@@ -1070,15 +1093,15 @@ __device__ __forceinline__ double prec_jacobi_item(const PrecArgs& a, const Prec
                 double r_ = rv[u];
                 if (MODE == PREC_STEP) {
                     if (!a.split_update) {
-                        NTS(a.xt[cols[u]], xv[u] + alpha * pv[u]);
-                        NTS(a.kx[cols[u]], kv[u] + alpha * wv[u]);
+                        NTSP(a.xt[cols[u]], xv[u] + alpha * pv[u]);
+                        NTSP(a.kx[cols[u]], kv[u] + alpha * wv[u]);
                     }
                     r_ -= alpha * wv[u];
-                    NTS(a.r[cols[u]], r_);
+                    NTSP(a.r[cols[u]], r_);
                 }
                 const double zv = r_ * dv[u];
-                NTS(a.z[cols[u]], zv);
-                if (MODE == PREC_INIT) NTS(a.p[cols[u]], zv);
+                NTSP(a.z[cols[u]], zv);
+                if (MODE == PREC_INIT) NTSP(a.p[cols[u]], zv);
                 local += r_ * zv;
             }
         }
@@ -1168,10 +1191,10 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
                     if (idx < NB) {
                         double r_ = rv[u];
                         if (MODE == PREC_STEP) {
-                            NTS(a.xt[cols[u]], xv[u] + alpha * pv[u]);
-                            NTS(a.kx[cols[u]], kv[u] + alpha * wv[u]);
+                            NTSP(a.xt[cols[u]], xv[u] + alpha * pv[u]);
+                            NTSP(a.kx[cols[u]], kv[u] + alpha * wv[u]);
                             r_ -= alpha * wv[u];
-                            NTS(a.r[cols[u]], r_);
+                            NTSP(a.r[cols[u]], r_);
                         }
                         if (LDS0) v0[idx] = r_;
                     }
@@ -1395,8 +1418,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
             for (int u = 0; u < kPrecChunk; ++u) {
                 const int idx = base + u * kPrecThreads;
                 if (idx < NB) {
-                    if (LDS0) NTS(a.z[cols[u]], zz[u]);
-                    if (MODE == PREC_INIT) NTS(a.p[cols[u]], zz[u]);
+                    if (LDS0) NTSP(a.z[cols[u]], zz[u]);
+                    if (MODE == PREC_INIT) NTSP(a.p[cols[u]], zz[u]);
                     local += rv[u] * zz[u];
                 }
             }
@@ -1539,8 +1562,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
 #pragma unroll
         for (int u = 0; u < kPrecChunk; ++u) {
             if (wk.index + t + u * kPrecThreads < e_end) {
-                NTS(a.xt[idx[u]], xv[u] + alpha * pv[u]);
-                NTS(a.kx[idx[u]], kv[u] + alpha * wv[u]);
+                NTSP(a.xt[idx[u]], xv[u] + alpha * pv[u]);
+                NTSP(a.kx[idx[u]], kv[u] + alpha * wv[u]);
             }
         }
         return;
@@ -1688,7 +1711,7 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
                 double r_ = rv[u];
                 if (MODE == PREC_STEP) {
                     r_ -= alpha * wv[u];
-                    NTS(a.r[cols[u]], r_);
+                    NTSP(a.r[cols[u]], r_);
                 }
                 v0[idx + pad(L0, idx / BS)] = r_;
                 rv[u] = r_;
@@ -1816,8 +1839,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
 #pragma unroll
             for (int u = 0; u < kHalf; ++u) {
                 if (t + (u0 + u) * kPrecThreads < NB) {
-                    NTS(a.xt[cols[u0 + u]], xv[u] + alpha * pv[u]);
-                    NTS(a.kx[cols[u0 + u]], kv[u] + alpha * wq[u]);
+                    NTSP(a.xt[cols[u0 + u]], xv[u] + alpha * pv[u]);
+                    NTSP(a.kx[cols[u0 + u]], kv[u] + alpha * wq[u]);
                 }
             }
         };
@@ -2001,8 +2024,8 @@ __global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
             const int idx = t + u * kPrecThreads;
             if (idx < NB) {
                 const double zz = v0[idx + pad(L0, idx / BS)];
-                NTS(a.z[cols[u]], zz);
-                if (MODE == PREC_INIT) NTS(a.p[cols[u]], zz);
+                NTSP(a.z[cols[u]], zz);
+                if (MODE == PREC_INIT) NTSP(a.p[cols[u]], zz);
                 local += rv[u] * zz;
             }
         }
