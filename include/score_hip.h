@@ -260,6 +260,11 @@ typedef struct score_assembled score_assembled;
 
 /* Build the program (host memory owned by *out).  Inputs are borrowed for the call. */
 int  score_assemble(const score_graph* g, score_assembled** out);
+/* The same for `count` graphs in one call, one graph per host thread of the library's team (the Monte-Carlo path:
+ * score_amd.solve_score.solve_score_batch builds the models of a lock-step group this way -- one foreign call
+ * per group instead of one per graph keeps the callers' interpreter lock out of the picture).  out[0..count-1];
+ * on failure nothing is left allocated and the message names the first graph that failed.   */
+int  score_assemble_batch(const score_graph* graphs, int32_t count, score_assembled** out);
 /* Fill `view` with pointers into the assembled program (valid until score_assembled_free);
  * pass it to score_create / score_create_batch like any other score_problem.   */
 int  score_assembled_view(const score_assembled* a, score_problem* view);
@@ -319,7 +324,7 @@ const char* score_backend(void);   /* "hip-gfx950" or "cpu-twin"             */
  * stale stride goes wrong from the second problem on.  Bump SCORE_ABI_VERSION whenever a struct changes;
  * loaders compare (score_amd.solver.load_library does).  History: 1 = rounds 1-2, 2 = score_problem
  * gained rep_d / rep_n, 3 = this function.                                                        */
-#define SCORE_ABI_VERSION 3
+#define SCORE_ABI_VERSION 4
 int32_t score_abi_version(void);   /* SCORE_ABI_VERSION of the library's build, times 1000, plus sizeof(score_problem) */
 
 #ifdef __cplusplus

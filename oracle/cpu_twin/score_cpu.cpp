@@ -660,6 +660,22 @@ int score_assemble(const score_graph* g, score_assembled** out) {
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
+int score_assemble_batch(const score_graph* graphs, int32_t count, score_assembled** out) {
+    try {
+        if (!graphs || !out || count <= 0) throw std::runtime_error("null argument");
+        std::vector<score_assembled*> made((size_t)count, nullptr);
+        std::vector<score::AssembledQP*> qps((size_t)count, nullptr);
+        try {
+            for (int i = 0; i < count; ++i) { made[(size_t)i] = new score_assembled(); qps[(size_t)i] = &made[(size_t)i]->qp; }
+            score::assemble_graphs(graphs, count, qps.data());
+        } catch (...) {
+            for (auto* a : made) delete a;
+            throw;
+        }
+        for (int i = 0; i < count; ++i) out[i] = made[(size_t)i];
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
 int score_assembled_view(const score_assembled* a, score_problem* view) {
     if (!a || !view) { g_err = "null argument"; return -1; }
     a->qp.view(view);

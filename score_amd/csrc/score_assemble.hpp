@@ -29,7 +29,9 @@
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
+#include <atomic>
 #include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "score_host.hpp"
@@ -341,6 +343,30 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
         }
     }
     pt.mark("assemble: cones");
+}
+
+// `count` graphs, one graph per part of one parallel region (score_assemble_batch).  out[i] is filled for every i or an
+// exception names the first graph that failed (the others' results are dropped by the caller).
+inline void assemble_graphs(const score_graph* graphs, int count, AssembledQP* const* out) {
+    BuildScope scope;
+    std::vector<std::string> err((size_t)count);
+    // (a graph takes 1-2 ms: parts of one graph each, dealt round-robin by an atomic counter so that a large graph
+    //  does not hold up the part it shares with others)
+    std::atomic<int> next{0};
+    const int T = (int)std::min<int64_t>(region_width(), count);
+    parallel_ranges(T, 1, [&](int, int64_t, int64_t) {
+        for (;;) {
+            const int i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= count) break;
+            try {
+                assemble_graph(graphs[i], *out[i]);
+            } catch (const std::exception& e) {
+                err[(size_t)i] = e.what()[0] ? e.what() : "error";
+            }
+        }
+    }, T);
+    for (int i = 0; i < count; ++i)
+        if (!err[(size_t)i].empty()) throw std::runtime_error("graph " + std::to_string(i) + ": " + err[(size_t)i]);
 }
 
 }  // namespace score

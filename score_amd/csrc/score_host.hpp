@@ -104,9 +104,13 @@ inline std::atomic<int>& extra_threads_busy() {
     static std::atomic<int> n{0};
     return n;
 }
+inline bool& tl_in_parallel_region();
 struct BuildScope {
-    BuildScope() { active_builders().fetch_add(1, std::memory_order_acq_rel); }
-    ~BuildScope() { active_builders().fetch_sub(1, std::memory_order_acq_rel); }
+    // (a builder running as a part of somebody's parallel region -- score_assemble_batch: one graph per part -- is
+    //  already counted among that region's threads)
+    bool counted;
+    BuildScope() : counted(!tl_in_parallel_region()) { if (counted) active_builders().fetch_add(1, std::memory_order_acq_rel); }
+    ~BuildScope() { if (counted) active_builders().fetch_sub(1, std::memory_order_acq_rel); }
     BuildScope(const BuildScope&) = delete;
     BuildScope& operator=(const BuildScope&) = delete;
 };

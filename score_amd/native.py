@@ -47,6 +47,7 @@ def _bind(lib: C.CDLL) -> None:
     if getattr(lib, "_score_assemble_bound", False):
         return
     lib.score_assemble.argtypes = [C.POINTER(ScoreGraph), C.POINTER(C.c_void_p)]
+    lib.score_assemble_batch.argtypes = [C.POINTER(ScoreGraph), C.c_int32, C.POINTER(C.c_void_p)]
     lib.score_assembled_view.argtypes = [C.c_void_p, C.POINTER(ScoreProblem)]
     lib.score_assembled_free.argtypes = [C.c_void_p]
     lib.score_assembled_free.restype = None
@@ -267,38 +268,28 @@ def score_graph_struct(a: Dict[str, np.ndarray], relaxation: int = 0) -> ScoreGr
     return g
 
 
-def assemble_native(data, relaxation: str = QCQP_RELAXATION, lib_path: Optional[str] = None, arrays: Optional[dict] = None) -> ScoreModel:
-    check_valid_relaxation(relaxation)
-    lib = load_library(lib_path)
-    _bind(lib)
-    a = arrays if arrays is not None else graph_arrays(data)
+def _read_back_maps(a: Dict[str, np.ndarray], relaxation: str, qp: "NativeQP") -> ScoreModel:
+    """The ScoreModel around an assembled program: the same read-back maps as assemble.py (model space keeps the
+    Gurobi layout; solver space: replica by replica, see score_assemble.hpp)."""
     d = int(a["dim"])
-    g = score_graph_struct(a, 0 if relaxation == SOCP_RELAXATION else 1)
-    h = C.c_void_p()
-    if lib.score_assemble(C.byref(g), C.byref(h)) != 0:
-        raise ValueError(lib.score_last_error().decode())
-    qp = NativeQP(lib, h)
-    # read-back maps: the same formulas as assemble.py (model space keeps the Gurobi layout)
     D1, PB = d + 1, d * (d + 1)
     Np, Nl, Nr = len(a["pose_names"]), len(a["landmark_names"]), len(a["range_keys"])
     rw = 1 if relaxation == SOCP_RELAXATION else d
     lm_base = Np * PB
     rng_base = lm_base + Nl * d
     n_model = rng_base + Nr * rw
+    # replica 0: every pose but the pinned one (pose 0 of chain 0), chain by chain = poses 1..Np-1 in order; then
+    # the landmarks; then (QCQP) the range vectors' component 0.  Replica k: the same columns shifted.
+    pose0 = (np.arange(1, Np, dtype=np.int64)[:, None] * PB + np.arange(D1, dtype=np.int64)[None, :]).ravel()
+    lm0 = lm_base + np.arange(Nl, dtype=np.int64) * d
+    rq0 = rng_base + np.arange(Nr, dtype=np.int64) * d if relaxation != SOCP_RELAXATION else np.zeros(0, np.int64)
     pieces = []
-    j_ar = np.arange(D1)
-    for k in range(d):  # replica by replica (score_assemble.hpp / assemble.py: the same order)
-        base = 0
-        for L in a["chain_len"]:
-            idx = base + np.arange(int(L))
-            idx = idx[idx != 0]
-            pieces.append((idx[:, None] * PB + k * D1 + j_ar[None, :]).ravel())
-            base += int(L)
-        pieces.append(lm_base + np.arange(Nl) * d + k)
+    for k in range(d):
+        pieces += [pose0 + k * D1, lm0 + k]
         if relaxation != SOCP_RELAXATION:
-            pieces.append(rng_base + np.arange(Nr) * d + k)
+            pieces.append(rq0 + k)
     if relaxation == SOCP_RELAXATION:
-        pieces.append(rng_base + np.arange(Nr))
+        pieces.append(rng_base + np.arange(Nr, dtype=np.int64))
     free_cols = np.concatenate(pieces)
     assert free_cols.size == qp.n, (free_cols.size, qp.n)
     ends = dist = None
@@ -319,3 +310,40 @@ def assemble_native(data, relaxation: str = QCQP_RELAXATION, lib_path: Optional[
         pose_names=a["pose_names"], landmark_names=a["landmark_names"], range_keys=a["range_keys"],
         lm_base=lm_base, rng_base=rng_base, rng_width=rw, range_ends=ends, range_dist=dist,
     )
+
+
+def assemble_native(data, relaxation: str = QCQP_RELAXATION, lib_path: Optional[str] = None, arrays: Optional[dict] = None) -> ScoreModel:
+    check_valid_relaxation(relaxation)
+    lib = load_library(lib_path)
+    _bind(lib)
+    a = arrays if arrays is not None else graph_arrays(data)
+    g = score_graph_struct(a, 0 if relaxation == SOCP_RELAXATION else 1)
+    h = C.c_void_p()
+    if lib.score_assemble(C.byref(g), C.byref(h)) != 0:
+        raise ValueError(lib.score_last_error().decode())
+    return _read_back_maps(a, relaxation, NativeQP(lib, h))
+
+
+def assemble_native_batch(arrays: list, relaxation: str = QCQP_RELAXATION, lib_path: Optional[str] = None) -> list:
+    """``assemble_native`` for a list of flat-array graphs in ONE foreign call (``score_assemble_batch``: one graph per
+    host thread of the library's team).  A thread that builds the models of its lock-step group this way leaves the
+    interpreter lock once per group: with one call per graph from a pool of Python threads the lock's hand-overs, not
+    the model construction, set the pace (64 four-robot graphs: 1.6 ms each in the library, 7-15 ms each as seen from
+    the pool; profiles/scripts/r04_e2e_timeline.py)."""
+    check_valid_relaxation(relaxation)
+    if not arrays:
+        return []
+    lib = load_library(lib_path)
+    _bind(lib)
+    n = len(arrays)
+    gs = (ScoreGraph * n)()
+    keep = []
+    for i, a in enumerate(arrays):
+        g = score_graph_struct(a, 0 if relaxation == SOCP_RELAXATION else 1)
+        keep.append(g)
+        C.memmove(C.byref(gs[i]), C.byref(g), C.sizeof(ScoreGraph))
+    hs = (C.c_void_p * n)()
+    if lib.score_assemble_batch(gs, n, hs) != 0:
+        raise ValueError(lib.score_last_error().decode())
+    qps = [NativeQP(lib, C.c_void_p(hs[i])) for i in range(n)]
+    return [_read_back_maps(a, relaxation, qp) for a, qp in zip(arrays, qps)]

@@ -121,6 +121,25 @@ def _model_for(data, relaxation_type: str, qcqp_mode: str, lib_path: Optional[st
     return assemble(data, relax)
 
 
+def _models_for(datas: Sequence, relaxation_type: str, qcqp_mode: str, lib_path: Optional[str] = None, assembler: str = "native") -> List[ScoreModel]:
+    """``_model_for`` for a list of graphs; the native assembler takes them in one foreign call
+    (``native.assemble_native_batch`` -> ``score_assemble_batch``: one graph per host thread of the library)."""
+    if assembler != "native":
+        out = []
+        for data in datas:
+            _check_factor_graph(data)
+            out.append(_model_for(data, relaxation_type, qcqp_mode, lib_path, assembler))
+        return out
+    from .native import ArrayGraph, assemble_native_batch, graph_arrays, unconnected_variable_names
+
+    relax = SOCP_RELAXATION if (relaxation_type == QCQP_RELAXATION and qcqp_mode == "via_socp") else relaxation_type
+    arrays = [data.arrays if isinstance(data, ArrayGraph) else graph_arrays(data) for data in datas]
+    for a in arrays:  # score/solve_score.py:28-32, on the flat arrays
+        unconnected_variables = unconnected_variable_names(a)
+        assert len(unconnected_variables) == 0, f"Found {unconnected_variables} unconnected variables. "
+    return assemble_native_batch(arrays, relax, lib_path=lib_path)
+
+
 def solve_score(
     data, *args, relaxation_type: str = QCQP_RELAXATION, qcqp_mode: str = "via_socp",
     solver_settings: Optional[dict] = None, lib_path: Optional[str] = None, assembler: str = "native",
@@ -186,16 +205,11 @@ def solve_score_batch(
         first_error = []
         if qcqp_mode not in ("via_socp", "direct"):
             raise ValueError(f"qcqp_mode {qcqp_mode} is not supported")
-        futs: dict = {}
-
-        def build(i):  # model construction, graph by graph (the native assembler releases the GIL)
-            if assembler != "native":
-                _check_factor_graph(datas[i])
-            return _model_for(datas[i], relaxation_type, qcqp_mode, lib_path, assembler)
-
         def one(idx):
             try:
-                models = [futs[i].result() if i in futs else build(i) for i in idx]
+                # every group builds its own models, in one foreign call for the whole group (_models_for): the group's
+                # thread leaves the interpreter lock once for all of them
+                models = _models_for([datas[i] for i in idx], relaxation_type, qcqp_mode, lib_path, assembler)
                 return solve_score_batch([datas[i] for i in idx], relaxation_type, qcqp_mode, solver_settings, lib_path,
                                          lockstep=True, assembler=assembler, _models=models)
             except ValueError as exc:  # keep what the other graphs of this group produced
@@ -212,12 +226,8 @@ def solve_score_batch(
         else:
             from concurrent.futures import ThreadPoolExecutor
 
-            # every group's models are built by the whole pool (in group order: the first group's handle
-            # is being set up while the later groups' models are still under construction)
-            with ThreadPoolExecutor(max_workers=workers) as pool:
-                futs.update((i, pool.submit(build, i)) for c in chunks for i in c)
-                with ThreadPoolExecutor(max_workers=min(workers, len(chunks))) as gpool:
-                    parts = list(gpool.map(one, chunks))
+            with ThreadPoolExecutor(max_workers=min(workers, len(chunks))) as gpool:
+                parts = list(gpool.map(one, chunks))
         out = [None] * len(datas)
         for idx, rs in zip(chunks, parts):
             for i, r in zip(idx, rs):
@@ -230,11 +240,7 @@ def solve_score_batch(
         return out
     if qcqp_mode not in ("via_socp", "direct"):
         raise ValueError(f"qcqp_mode {qcqp_mode} is not supported")
-    models = list(_models) if _models is not None else []
-    for data in datas if _models is None else ():
-        if assembler != "native":
-            _check_factor_graph(data)  # (the native path checks on its flat arrays)
-        models.append(_model_for(data, relaxation_type, qcqp_mode, lib_path, assembler))
+    models = list(_models) if _models is not None else _models_for(datas, relaxation_type, qcqp_mode, lib_path, assembler)
     settings = dict(DEFAULT_SOLVER_SETTINGS)
     if any((d.n_loop_closures if hasattr(d, "arrays") else len(d.loop_closure_measurements)) for d in datas):
         # loop closures are stiff couplings outside the per-robot chains the

@@ -246,6 +246,35 @@ def test_native_assembler_errors(twin_lib):
         assemble_native(fg, "SOCP", lib_path=twin_lib)
 
 
+def test_batch_assembler_equals_graph_by_graph_calls(fixtures, twin_lib):
+    """score_assemble_batch (one foreign call, one graph per host thread of the library) returns, graph for graph, what
+    score_assemble returns: mixed sizes and dimensions, SOCP and QCQP; a bad graph fails the call, names its index and
+    leaves nothing behind."""
+    from score_amd.manhattan import make_manhattan
+    from score_amd.native import assemble_native, assemble_native_batch, graph_arrays
+
+    fgs = [graph_by_name(nm, fixtures) for nm in ("synth_a", "synth_b", "graph3d", "prior2d")]
+    fgs += [make_manhattan(n_robots=1 + t % 3, n_poses=40 + 17 * t, n_beacons=2, seed=70 + t) for t in range(9)]
+    for relax in ("SOCP", "QCQP"):
+        arrs = [graph_arrays(fg) for fg in fgs]
+        got = assemble_native_batch(arrs, relax, lib_path=twin_lib)
+        assert len(got) == len(fgs)
+        for fg, a, m in zip(fgs, arrs, got):
+            ref = assemble_native(fg, relax, lib_path=twin_lib, arrays=a)
+            qa, qb = ref.qp, m.qp
+            assert (qa.n, qa.m, qa.block_size, qa.rep_d, qa.rep_n, qa.c0) == (qb.n, qb.m, qb.block_size, qb.rep_d, qb.rep_n, qb.c0)
+            for x, y in ((qa.P, qb.P), (qa.A, qb.A)):
+                assert np.array_equal(x.indptr, y.indptr) and np.array_equal(x.indices, y.indices) and np.array_equal(x.data, y.data)
+            assert np.array_equal(qa.q, qb.q) and np.array_equal(qa.b, qb.b)
+            assert np.array_equal(qa.chain_ptr, qb.chain_ptr) and np.array_equal(qa.node_cols, qb.node_cols)
+            assert np.array_equal(ref.free_cols, m.free_cols) and ref.n_model == m.n_model
+    assert assemble_native_batch([], "SOCP", lib_path=twin_lib) == []
+    bad = [graph_arrays(fg) for fg in fgs[:3]]
+    bad[1] = dict(bad[1], rng_a=bad[1]["rng_a"] + 10**6)
+    with pytest.raises(ValueError, match="graph 1: .*out of range"):
+        assemble_native_batch(bad, "SOCP", lib_path=twin_lib)
+
+
 def test_headline_config_golden_is_an_optimum_of_the_literal_model():
     """tests/golden/config3_golden.npz (BASELINE configs[3], 20 robots x 1000 poses; produced offline by the oracle's
     Newton method): the stored estimate belongs to the graph make_config(3) regenerates, satisfies the pin, evaluates
