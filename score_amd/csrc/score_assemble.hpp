@@ -132,7 +132,11 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
     std::vector<double> tvals;
     std::vector<int32_t> fill;
     bool filling = false;
+    // P = I_d (x) P_row (+ the tail's diagonal): the d replicas of a row hold the same values at shifted columns, so only
+    // replica 0's rows (r < n_rep) and the tail's are gathered, sorted and merged; the others are copies (below).  q and
+    // c0 are not replicated (the pinned pose is [I | 0]: its row k is e_k) and come from every replica's terms.
     auto addP = [&](int64_t r, int64_t c, double v) {
+        if (r >= n_rep && r < rng_base) return;
         if (!filling) { ++cnt[(size_t)r + 1]; return; }
         const int32_t pos = fill[(size_t)r]++;
         tcols[(size_t)pos] = (int32_t)c;
@@ -253,23 +257,29 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
     measurements();  // filling pass
     pt.mark("assemble: filling pass");
     out.c0 = c0;
-    // sort + merge every row (stable: equal columns are summed in the order they were met)
+    // sort + merge every stored row (stable: equal columns are summed in the order they were met)
     out.n = (int32_t)n;
     out.P_ptr.assign((size_t)n + 1, 0);
     {
-        const int T = parallel_parts(n, 8192);
+        const int64_t n_tail = n - rng_base, n_act = n_rep + n_tail;  // active rows: replica 0, then the tail
+        auto act_row = [&](int64_t a) { return a < n_rep ? a : a - n_rep + rng_base; };
+        const int T = parallel_parts(n_act, 8192);
         std::vector<std::vector<int32_t>> pc(T);
         std::vector<std::vector<double>> pv(T);
-        parallel_ranges(n, 8192, [&](int t, int64_t i0, int64_t i1) {
+        std::vector<int32_t> len((size_t)n_act, 0);
+        parallel_ranges(n_act, 8192, [&](int t, int64_t a0, int64_t a1) {
             // thread-local buffers, handed over at the end: the headers of pc[t] / pv[t] share cache lines
             // with their neighbours', and every push_back writes the header (measured: the 16-thread phase
             // was slower than one thread)
             std::vector<int32_t> lc;
             std::vector<double> lv;
-            lc.reserve((size_t)(cnt[(size_t)i1] - cnt[(size_t)i0]));
-            lv.reserve((size_t)(cnt[(size_t)i1] - cnt[(size_t)i0]));
+            size_t ub = 0;
+            for (int64_t a = a0; a < a1; ++a) ub += (size_t)(cnt[(size_t)act_row(a) + 1] - cnt[(size_t)act_row(a)]);
+            lc.reserve(ub);
+            lv.reserve(ub);
             std::vector<detail::Trip> L;
-            for (int64_t i = i0; i < i1; ++i) {
+            for (int64_t a = a0; a < a1; ++a) {
+                const int64_t i = act_row(a);
                 L.clear();
                 for (int32_t k = cnt[(size_t)i]; k < cnt[(size_t)i + 1]; ++k) L.push_back(detail::Trip{tcols[(size_t)k], tvals[(size_t)k]});
                 // stable order by column: insertion sort for the usual short rows
@@ -292,24 +302,48 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
                     lc.push_back(c); lv.push_back(s_);
                     ++c_;
                 }
-                out.P_ptr[(size_t)i + 1] = c_;
+                len[(size_t)a] = c_;
             }
             pc[t] = std::move(lc);
             pv[t] = std::move(lv);
         }, T);
         pt.mark("assemble:   rows (parallel)");
+        // row pointers: replica k's rows repeat replica 0's lengths
+        for (int k = 0; k < d; ++k)
+            for (int64_t a = 0; a < n_rep; ++a) out.P_ptr[(size_t)(k * n_rep + a) + 1] = len[(size_t)a];
+        for (int64_t a = n_rep; a < n_act; ++a) out.P_ptr[(size_t)act_row(a) + 1] = len[(size_t)a];
         for (int64_t i = 0; i < n; ++i) out.P_ptr[(size_t)i + 1] += out.P_ptr[(size_t)i];
         out.P_col.resize((size_t)out.P_ptr[(size_t)n]);
         out.P_val.resize((size_t)out.P_ptr[(size_t)n]);
+        // the parts, in order, are replica 0's entries followed by the tail's: every part is copied into place once per
+        // replica (columns shifted by the replica's offset); a part may straddle the end of replica 0
+        std::vector<int64_t> part_a0((size_t)T + 1);
+        for (int t = 0; t <= T; ++t) part_a0[(size_t)t] = n_act * t / T;  // the ranges of parallel_ranges are contiguous and ordered
+        const int64_t e_rep = out.P_ptr[(size_t)n_rep];                    // entries of one replica
         parallel_ranges(T, 1, [&](int, int64_t t0, int64_t t1) {
             for (int64_t t = t0; t < t1; ++t) {
-                if (pc[(size_t)t].empty()) continue;
-                const int64_t i0 = n * t / T;  // the ranges of parallel_ranges are contiguous and ordered
-                std::memcpy(&out.P_col[(size_t)out.P_ptr[(size_t)i0]], pc[(size_t)t].data(), pc[(size_t)t].size() * sizeof(int32_t));
-                std::memcpy(&out.P_val[(size_t)out.P_ptr[(size_t)i0]], pv[(size_t)t].data(), pv[(size_t)t].size() * sizeof(double));
+                const std::vector<int32_t>& lc = pc[(size_t)t];
+                const std::vector<double>& lv = pv[(size_t)t];
+                if (lc.empty()) continue;
+                const int64_t a0 = part_a0[(size_t)t];
+                const int64_t o0 = a0 < n_rep ? out.P_ptr[(size_t)a0] : e_rep + (out.P_ptr[(size_t)act_row(a0)] - out.P_ptr[(size_t)rng_base]);  // offset within [replica 0 | tail]
+                const int64_t in_rep = std::max<int64_t>(0, std::min<int64_t>((int64_t)lc.size(), e_rep - o0));  // entries of this part that belong to replica 0
+                for (int k = 0; k < d; ++k) {
+                    const int32_t shift = (int32_t)(k * n_rep);
+                    int32_t* dc = &out.P_col[(size_t)(k * e_rep + o0)];
+                    if (in_rep > 0) {
+                        for (int64_t e = 0; e < in_rep; ++e) dc[e] = lc[(size_t)e] + shift;
+                        std::memcpy(&out.P_val[(size_t)(k * e_rep + o0)], lv.data(), (size_t)in_rep * sizeof(double));
+                    }
+                }
+                if ((int64_t)lc.size() > in_rep) {  // tail entries: behind all replicas
+                    const int64_t ot = (int64_t)d * e_rep + (o0 + in_rep - e_rep);
+                    std::memcpy(&out.P_col[(size_t)ot], lc.data() + in_rep, (size_t)((int64_t)lc.size() - in_rep) * sizeof(int32_t));
+                    std::memcpy(&out.P_val[(size_t)ot], lv.data() + in_rep, (size_t)((int64_t)lv.size() - in_rep) * sizeof(double));
+                }
             }
         });
-        pt.mark("assemble:   concatenate");
+        pt.mark("assemble:   replicate + concatenate");
     }
     pt.mark("assemble: sort + merge rows");
     // ---- cones (:336-352): s = b - A x ----

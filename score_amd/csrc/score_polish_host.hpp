@@ -137,7 +137,17 @@ inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = fals
                         rowc.push_back(Contrib{H.A.col[kk], cone, a * T + b, vi * H.A.val[kk]});
                 }
             }
-            std::stable_sort(rowc.begin(), rowc.end(), [](const Contrib& x, const Contrib& y) { return x.j < y.j; });
+            // stable order by column: insertion sort for the usual short rows (std::stable_sort allocates its buffer per call)
+            if (rowc.size() > 64) {
+                std::stable_sort(rowc.begin(), rowc.end(), [](const Contrib& x, const Contrib& y) { return x.j < y.j; });
+            } else {
+                for (size_t x = 1; x < rowc.size(); ++x) {
+                    const Contrib c = rowc[x];
+                    size_t y = x;
+                    while (y > 0 && rowc[y - 1].j > c.j) { rowc[y] = rowc[y - 1]; --y; }
+                    rowc[y] = c;
+                }
+            }
             size_t e = 0;
             int32_t nent = 0;
             while (e < rowc.size()) {
