@@ -54,17 +54,49 @@ def _bind(lib: C.CDLL) -> None:
     lib._score_assemble_bound = True
 
 
+try:  # CPython helper (score_amd/csrc/_objread.c, built by __graft_entry__.build()): host glue, optional
+    from . import _objread
+except ImportError:  # pragma: no cover - the fromiter passes below are the same reads, one attribute at a time
+    _objread = None
+
+
+def _pose_meas_fast(meas: list, pose_idx: Dict[str, int], d: int):
+    """``assemble._pose_meas_arrays`` in one pass over the measurement objects (``_objread.gather``)."""
+    ne = len(meas)
+    m0 = meas[0]
+    planar = d == 2 and all(hasattr(m0, a) for a in ("x", "y", "theta"))
+    if _objread is None or not planar:
+        return _pose_meas_arrays(meas, pose_idx, d)
+    bi, tj = np.empty(ne, np.int32), np.empty(ne, np.int32)
+    kap, tau, x, y, th = (np.empty(ne) for _ in range(5))
+    try:
+        _objread.gather(meas, ("base_pose", "to_pose", "translation_precision", "rotation_precision", "x", "y", "theta"), "iiddddd",
+                        (bi, tj, kap, tau, x, y, th), (pose_idx, pose_idx, None, None, None, None, None))
+    except KeyError as exc:
+        raise KeyError(exc.args[0]) from None
+    tm = np.empty((ne, 2))
+    Rm = np.empty((ne, 2, 2))
+    tm[:, 0] = x; tm[:, 1] = y
+    cs, sn = np.cos(th), np.sin(th)
+    Rm[:, 0, 0] = cs; Rm[:, 0, 1] = -sn
+    Rm[:, 1, 0] = sn; Rm[:, 1, 1] = cs
+    return bi, tj, kap, tau, tm, Rm
+
+
 def graph_arrays(data) -> Dict[str, np.ndarray]:
     """FactorGraphData -> the flat arrays of ``score_graph`` (the only per-measurement Python work
-    left on the path: attribute reads).  Raises the reference's errors for duplicate / unknown
+    left on the path: attribute reads -- one pass over every measurement list with ``_objread.gather``, or one
+    ``numpy.fromiter`` pass per attribute without it).  Raises the reference's errors for duplicate / unknown
     variable names (gurobi_utils.py:62-80, :103-109)."""
     d = data.dimension
     check_dimension(d)
     pose_names = [p.name for chain in data.pose_variables for p in chain]
     landmark_names = [l.name for l in data.landmark_variables]
-    _check_unique(pose_names, "pose_vars")
-    _check_unique(landmark_names, "landmark_vars")
     pose_idx = {nm: i for i, nm in enumerate(pose_names)}
+    if len(pose_idx) != len(pose_names):
+        _check_unique(pose_names, "pose_vars")  # (names the duplicate)
+    if len(set(landmark_names)) != len(landmark_names):
+        _check_unique(landmark_names, "landmark_vars")
     for nm in landmark_names:
         if nm in pose_idx:
             raise ValueError(f"Variable name {nm} already exists in pose_vars")
@@ -73,10 +105,26 @@ def graph_arrays(data) -> Dict[str, np.ndarray]:
         raise ValueError("factor graph has no pose variables")
     var_idx = dict(pose_idx)
     var_idx.update((nm, Np + i) for i, nm in enumerate(landmark_names))
-    if data.range_measurements and hasattr(data.range_measurements[0], "association"):
-        range_keys = [tuple(a) for a in map(attrgetter("association"), data.range_measurements)]
+    rm = data.range_measurements
+    nr = len(rm)
+    has_assoc = bool(nr) and hasattr(rm[0], "association")
+    has_std = bool(nr) and hasattr(rm[0], "stddev")  # PyFactorGraph stores stddev; precision = 1 / stddev^2 is a derived property
+    ra = rb = dist = prec = None
+    if _objread is not None and has_assoc:
+        range_keys = [None] * nr
+        ab = np.empty((nr, 2), np.int32)
+        dist, w = np.empty(nr), np.empty(nr)
+        try:
+            _objread.gather(rm, ("association", "association", "dist", "stddev" if has_std else "precision"), "Opdd",
+                            (range_keys, ab, dist, w), (None, var_idx, None, None))
+        except KeyError as exc:
+            raise ValueError(f"Variable name {exc.args[0]} not found") from None
+        ra, rb = np.ascontiguousarray(ab[:, 0]), np.ascontiguousarray(ab[:, 1])
+        prec = 1.0 / (w * w) if has_std else w
+    elif has_assoc:
+        range_keys = [tuple(a) for a in map(attrgetter("association"), rm)]
     else:
-        range_keys = [(m.first_key, m.second_key) for m in data.range_measurements]
+        range_keys = [(m.first_key, m.second_key) for m in rm]
     if len(set(range_keys)) != len(range_keys):
         seen = set()
         for k in range_keys:
@@ -87,23 +135,21 @@ def graph_arrays(data) -> Dict[str, np.ndarray]:
     meas += list(data.loop_closure_measurements)
     ne = len(meas)
     if ne:
-        bi, tj, kap, tau, tm, Rm = _pose_meas_arrays(meas, pose_idx, d)
+        bi, tj, kap, tau, tm, Rm = _pose_meas_fast(meas, pose_idx, d)
     else:
         bi = tj = np.zeros(0, np.int64); kap = tau = np.zeros(0); tm = np.zeros((0, d)); Rm = np.zeros((0, d, d))
-    nr = len(range_keys)
-
-    try:  # (dict lookups in C: itemgetter over all keys at once)
-        ra = np.fromiter(map(var_idx.__getitem__, (k[0] for k in range_keys)), dtype=np.int32, count=nr)
-        rb = np.fromiter(map(var_idx.__getitem__, (k[1] for k in range_keys)), dtype=np.int32, count=nr)
-    except KeyError as exc:
-        raise ValueError(f"Variable name {exc.args[0]} not found") from None
-    rm = data.range_measurements
-    dist = np.fromiter(map(attrgetter("dist"), rm), dtype=np.float64, count=nr)
-    if nr and hasattr(rm[0], "stddev"):  # PyFactorGraph stores stddev; precision = 1 / stddev^2 is a derived property
-        std = np.fromiter(map(attrgetter("stddev"), rm), dtype=np.float64, count=nr)
-        prec = 1.0 / (std * std)
-    else:
-        prec = np.fromiter(map(attrgetter("precision"), rm), dtype=np.float64, count=nr)
+    if ra is None:
+        try:  # (dict lookups in C: itemgetter over all keys at once)
+            ra = np.fromiter(map(var_idx.__getitem__, (k[0] for k in range_keys)), dtype=np.int32, count=nr)
+            rb = np.fromiter(map(var_idx.__getitem__, (k[1] for k in range_keys)), dtype=np.int32, count=nr)
+        except KeyError as exc:
+            raise ValueError(f"Variable name {exc.args[0]} not found") from None
+        dist = np.fromiter(map(attrgetter("dist"), rm), dtype=np.float64, count=nr)
+        if has_std:
+            std = np.fromiter(map(attrgetter("stddev"), rm), dtype=np.float64, count=nr)
+            prec = 1.0 / (std * std)
+        else:
+            prec = np.fromiter(map(attrgetter("precision"), rm), dtype=np.float64, count=nr)
     lm_idx = {nm: i for i, nm in enumerate(landmark_names)}
     pri = list(data.landmark_priors)
     for p in pri:
@@ -115,7 +161,7 @@ def graph_arrays(data) -> Dict[str, np.ndarray]:
         dim=d, pose_names=pose_names, landmark_names=landmark_names, range_keys=range_keys,
         n_loop_closures=len(data.loop_closure_measurements), pose_chain_names=data.get_pose_chain_names(),
         chain_len=np.array([len(c) for c in data.pose_variables], dtype=np.int32),
-        rel_base=bi.astype(np.int32), rel_to=tj.astype(np.int32), rel_t=np.ascontiguousarray(tm, dtype=np.float64),
+        rel_base=bi.astype(np.int32, copy=False), rel_to=tj.astype(np.int32, copy=False), rel_t=np.ascontiguousarray(tm, dtype=np.float64),
         rel_R=np.ascontiguousarray(Rm, dtype=np.float64), rel_kappa=np.ascontiguousarray(kap, dtype=np.float64),
         rel_tau=np.ascontiguousarray(tau, dtype=np.float64),
         rng_a=ra, rng_b=rb, rng_dist=dist, rng_prec=prec,

@@ -246,6 +246,53 @@ def test_native_assembler_errors(twin_lib):
         assemble_native(fg, "SOCP", lib_path=twin_lib)
 
 
+def test_one_pass_object_reader_equals_the_attribute_passes(fixtures, monkeypatch):
+    """score_amd/csrc/_objread.c (one pass over every measurement list, plain attributes straight from the instance dict)
+    yields the same flat arrays as one numpy.fromiter pass per attribute -- on the reference's data sets, a 3-D graph, a
+    graph whose measurement classes answer through properties only, and with the same errors for unknown names."""
+    import score_amd.native as nat
+    from score_amd import compat
+    from score_amd.manhattan import make_manhattan
+
+    assert nat._objread is not None, "score_amd/_objread*.so is not built (python -c 'import __graft_entry__ as g; g.build()')"
+
+    class PropRange:  # first_key / second_key / precision only, association as a list, values behind properties
+        def __init__(self, m):
+            self._m = m
+        association = property(lambda self: list(self._m.association))
+        dist = property(lambda self: self._m.dist)
+        stddev = property(lambda self: self._m.stddev)
+
+    fgs = [graph_by_name(nm, fixtures) for nm in ("goats", "synth_b", "graph3d", "prior2d")] + [make_manhattan(n_robots=3, n_poses=60, n_beacons=2, seed=5)]
+    wrapped = make_manhattan(n_robots=2, n_poses=30, n_beacons=2, seed=6)
+    wrapped.range_measurements = [PropRange(m) for m in wrapped.range_measurements]
+    fgs.append(wrapped)
+    for fg in fgs:
+        fast = nat.graph_arrays(fg)
+        with monkeypatch.context() as mp:
+            mp.setattr(nat, "_objread", None)
+            slow = nat.graph_arrays(fg)
+        assert fast.keys() == slow.keys()
+        for k in fast:
+            if isinstance(fast[k], np.ndarray):
+                assert fast[k].dtype == slow[k].dtype and np.array_equal(fast[k], slow[k]), k
+            else:
+                assert fast[k] == slow[k], k
+        assert all(isinstance(k, tuple) for k in fast["range_keys"])
+    fg = make_manhattan(n_robots=1, n_poses=5, n_beacons=1, seed=1, p_range=1.0)
+    fg.range_measurements.append(compat.FGRangeMeasurement(("A1", "nope"), 1.0, 1.0))
+    with pytest.raises(ValueError, match="Variable name nope not found"):
+        nat.graph_arrays(fg)
+    fg.range_measurements.pop()
+    fg.odom_measurements[0][0].to_pose = "nowhere"
+    with pytest.raises(KeyError, match="nowhere"):
+        nat.graph_arrays(fg)
+    fg.odom_measurements[0][0].to_pose = "A1"
+    fg.odom_measurements[0][0].x = "not a number"
+    with pytest.raises(TypeError):
+        nat.graph_arrays(fg)
+
+
 def test_batch_assembler_equals_graph_by_graph_calls(fixtures, twin_lib):
     """score_assemble_batch (one foreign call, one graph per host thread of the library) returns, graph for graph, what
     score_assemble returns: mixed sizes and dimensions, SOCP and QCQP; a bad graph fails the call, names its index and
