@@ -127,7 +127,11 @@ struct BlockCache {
             }
         }
         void* p = nullptr;
+        const auto t_raw = std::chrono::steady_clock::now();
         hipError_t e = raw_alloc(&p, bytes, host);
+        if (std::getenv("SCORE_CACHE_VERBOSE"))
+            std::fprintf(stderr, "[score cache] %s of %zu bytes: %.2f ms\n", host ? "hipHostMalloc" : "hipMalloc", bytes,
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_raw).count());
         if (e != hipSuccess) {
             // out of device or locked memory: what this cache holds back (other size classes, devices, kinds) is the
             // first thing to give up -- release every parked block and try once more
@@ -245,6 +249,55 @@ struct DevArena {
 };
 thread_local DevArena* tl_arena = nullptr;  // set while a handle is being initialised on this thread
 
+// OPT-IN (SCORE_STAGED_UPLOADS=1): uploads of a handle under construction through pinned staging.  hipMemcpyAsync from
+// pageable memory blocks the caller for the whole transfer (the runtime stages it itself, a stream synchronisation per
+// array on top); from pinned memory it returns at once.  Here the source is copied into a pinned chunk (large arrays by
+// a team of host threads), the transfer is queued on the handle's stream and the caller moves on; the chunks go back to
+// the block cache after ONE synchronisation at the end of the setup.  Measured on the headline create (round 4, A/B on
+// three boxes): the upload phases shrink by 0.3-0.5 ms, the copy teams take threads from the Newton-matrix builder that
+// runs beside them, and score_create comes out the same or 0.5-1 ms slower (typical calls 12.0-13.5 against 11.3-12.4 ms)
+// -- the transfers were never the bound, the host work around them is.  Off by default.
+struct StageArena {
+    int dev = 0;
+    std::vector<size_t> chunk_bytes;
+    std::vector<void*> chunks;
+    char* cur = nullptr;
+    size_t left = 0;
+    void* take(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes > left) {
+            size_t got = std::max(bytes, (size_t)32 << 20);
+            void* p = block_cache().take(got, dev, true);
+            chunks.push_back(p);
+            chunk_bytes.push_back(got);
+            cur = (char*)p;
+            left = got;
+        }
+        void* r = cur;
+        cur += bytes;
+        left -= bytes;
+        return r;
+    }
+    // copy `bytes` from src into a pinned slot and queue its transfer to `dst` on `st`
+    void upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
+        if (!bytes) return;
+        char* pin = (char*)take(bytes);
+        if (bytes >= ((size_t)1 << 20))
+            score::parallel_ranges((int64_t)bytes, (int64_t)1 << 19, [&](int, int64_t b0, int64_t b1) { std::memcpy(pin + b0, (const char*)src + b0, (size_t)(b1 - b0)); });
+        else
+            std::memcpy(pin, src, bytes);
+        HIP_CHECK(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, st));
+    }
+    // (the caller has synchronised the stream the transfers were queued on)
+    void release() {
+        for (size_t i = 0; i < chunks.size(); ++i) block_cache().give(chunks[i], chunk_bytes[i], dev, true);
+        chunks.clear(); chunk_bytes.clear();
+        cur = nullptr; left = 0;
+    }
+    ~StageArena() { release(); }
+};
+thread_local StageArena* tl_stage = nullptr;  // set while a handle's setup uploads on this thread
+
 template <class T>
 struct DevBuf {
     T* d = nullptr;
@@ -265,6 +318,7 @@ struct DevBuf {
     void upload(const std::vector<T>& h) {
         if (h.size() != n || !d) alloc(h.size());
         if (!h.empty()) {
+            if (tl_stage) { tl_stage->upload(d, h.data(), h.size() * sizeof(T), tl_copy_stream); return; }
             HIP_CHECK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
             HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
         }
@@ -272,12 +326,14 @@ struct DevBuf {
     // (no synchronisation: the caller waits for the stream before the source goes away)
     void upload_from(const T* src, size_t count) {
         if (count != n || !d) alloc(count);
+        if (count && tl_stage) { tl_stage->upload(d, src, count * sizeof(T), tl_copy_stream); return; }
         if (count) HIP_CHECK(hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
     }
     // upload into an allocation with `pad` extra zeroed elements at the end
     void upload_padded(const std::vector<T>& h, size_t pad) {
         if (h.size() + pad != n || !d) alloc(h.size() + pad);
         HIP_CHECK(hipMemsetAsync(d + h.size(), 0, pad * sizeof(T), tl_copy_stream));
+        if (tl_stage) { tl_stage->upload(d, h.data(), h.size() * sizeof(T), tl_copy_stream); return; }
         if (!h.empty())
             HIP_CHECK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
         HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
@@ -418,11 +474,16 @@ struct RuizDevice : RuizOffload {
         {
             DevArena arena;
             arena.dev = device;
+            StageArena stage;  // (the raw matrices go up through pinned staging; released after the synchronisation below)
+            stage.dev = device;
             struct Scope {
-                DevArena* a_; hipStream_t s_;
-                Scope(DevArena* a, hipStream_t s) : a_(tl_arena), s_(tl_copy_stream) { tl_arena = a; tl_copy_stream = s; }
-                ~Scope() { tl_arena = a_; tl_copy_stream = s_; }
-            } scope(&arena, st);
+                DevArena* a_; hipStream_t s_; StageArena* g_;
+                Scope(DevArena* a, hipStream_t s, StageArena* g) : a_(tl_arena), s_(tl_copy_stream), g_(tl_stage) {
+                    tl_arena = a; tl_copy_stream = s;
+                    if (std::getenv("SCORE_STAGED_UPLOADS") != nullptr) tl_stage = g;
+                }
+                ~Scope() { tl_arena = a_; tl_copy_stream = s_; tl_stage = g_; }
+            } scope(&arena, st, &stage);
             try {
                 DevBuf<int32_t> Pp, Pc, Ap, Ac, dat, dpos, drow, dg;
                 DevBuf<double> Pv, Av, dD, dE, dd, de;
@@ -642,6 +703,18 @@ struct HipBackend {
             explicit ArenaScope(DevArena* a) { tl_arena = a; }
             ~ArenaScope() { tl_arena = nullptr; }
         } arena_scope(&arena);
+        struct StageScope {  // setup uploads through pinned staging (StageArena); one synchronisation when the setup is over
+            StageArena a;
+            hipStream_t st;
+            StageScope(int dev, hipStream_t s) : st(s) {
+                a.dev = dev;
+                if (std::getenv("SCORE_STAGED_UPLOADS") != nullptr) tl_stage = &a;
+            }
+            ~StageScope() {
+                tl_stage = nullptr;
+                (void)hipStreamSynchronize(st);  // (every queued transfer has left its pinned slot)
+            }
+        } stage_scope(st.device, stream);
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
         pt.mark("device + stream");
@@ -676,9 +749,10 @@ struct HipBackend {
             std::future<BandLayout>& f;
             ~JoinBand() { if (f.valid()) f.wait(); }
         } join_band{band_layout_job};
-        K.upload(h.K, h.rbK);
+        K.upload(h.K, h.rbK, nullptr, false);  // (values: K0 + rho K1, on the device -- derive_rho_data)
         G1.upload(h.G1, h.rbG1);
         G2.upload(h.G2, h.rbG2, &h.g2_split);
+        pt.mark("  uploads: K, G1, G2");
         // replicated problems (HostSystem::rep): K and G1 = A' hold replica 0's rows; K's operands repeat with the
         // block's replica stride, G1's are the consecutive tail rows of a cone
         K.rep = h.rep; K.rs_in = 0;
@@ -699,41 +773,42 @@ struct HipBackend {
         A_col.upload_padded(h.A.col, 64); A_val.upload_padded(h.A.val, 64);
         q.upload(h.q); b.upload(h.b);
         std::vector<double> iD(h.D.size()), iE(h.E.size());
-        for (size_t i = 0; i < iD.size(); ++i) iD[i] = 1.0 / h.D[i];
-        for (size_t i = 0; i < iE.size(); ++i) iE[i] = 1.0 / h.E[i];
+        parallel_ranges((int64_t)iD.size(), 32768, [&](int, int64_t i0, int64_t i1) { for (int64_t i = i0; i < i1; ++i) iD[(size_t)i] = 1.0 / h.D[(size_t)i]; });
+        parallel_ranges((int64_t)iE.size(), 32768, [&](int, int64_t i0, int64_t i1) { for (int64_t i = i0; i < i1; ++i) iE[(size_t)i] = 1.0 / h.E[(size_t)i]; });
         invD.upload(iD); invE.upload(iE);
+        pt.mark("  uploads: A, q, b, 1/D, 1/E");
         cone_row.upload(h.cone_row); cone_dim.upload(h.cone_dim); cone_type.upload(h.cone_type);
         cone_block_first.upload(h.cone_block_first); cone_block_prob.upload(h.cone_block_prob);
         {
             std::vector<int4> meta(2 * h.cone_row.size());
-            for (size_t c = 0; c < h.cone_row.size(); ++c) {
-                const int row = h.cone_row[c], dim = h.cone_dim[c];
-                auto ptr = [&](int k) { return h.A.ptr[row + std::min(k, dim)]; };
-                meta[2 * c] = make_int4(row, dim, h.cone_type[c], ptr(0));
-                meta[2 * c + 1] = make_int4(ptr(1), ptr(2), ptr(3), ptr(4));
-            }
-            cone_meta.upload(meta);
             // the entries of the small cones again, by cone index (see ConeArgs::cone_cols)
             std::vector<int32_t> pc(8 * h.cone_row.size(), 0);
             std::vector<double> pv(8 * h.cone_row.size(), 0.0);
-            for (size_t c = 0; c < h.cone_row.size(); ++c) {
-                const int row = h.cone_row[c], dim = h.cone_dim[c];
-                bool small = dim <= kSmallCone;
-                for (int k = 0; k < std::min(dim, (int)kSmallCone) && small; ++k) small = (h.A.ptr[row + k + 1] - h.A.ptr[row + k]) <= kConeRowNnz;
-                int32_t safe = h.A.ptr[row] < h.A.ptr[row + dim] ? h.A.col[h.A.ptr[row]] : 0;  // any valid column
-                for (int k = 0; k < kSmallCone; ++k)
-                    for (int e = 0; e < kConeRowNnz; ++e) {
-                        const size_t o = 8 * c + (size_t)k * kConeRowNnz + e;
-                        pc[o] = safe;
-                        if (small && k < dim && h.A.ptr[row + k] + e < h.A.ptr[row + k + 1]) {
-                            pc[o] = h.A.col[h.A.ptr[row + k] + e];
-                            pv[o] = h.A.val[h.A.ptr[row + k] + e];
+            parallel_ranges((int64_t)h.cone_row.size(), 8192, [&](int, int64_t c0, int64_t c1) {
+                for (size_t c = (size_t)c0; c < (size_t)c1; ++c) {
+                    const int row = h.cone_row[c], dim = h.cone_dim[c];
+                    auto ptr = [&](int k) { return h.A.ptr[row + std::min(k, dim)]; };
+                    meta[2 * c] = make_int4(row, dim, h.cone_type[c], ptr(0));
+                    meta[2 * c + 1] = make_int4(ptr(1), ptr(2), ptr(3), ptr(4));
+                    bool small = dim <= kSmallCone;
+                    for (int k = 0; k < std::min(dim, (int)kSmallCone) && small; ++k) small = (h.A.ptr[row + k + 1] - h.A.ptr[row + k]) <= kConeRowNnz;
+                    int32_t safe = h.A.ptr[row] < h.A.ptr[row + dim] ? h.A.col[h.A.ptr[row]] : 0;  // any valid column
+                    for (int k = 0; k < kSmallCone; ++k)
+                        for (int e = 0; e < kConeRowNnz; ++e) {
+                            const size_t o = 8 * c + (size_t)k * kConeRowNnz + e;
+                            pc[o] = safe;
+                            if (small && k < dim && h.A.ptr[row + k] + e < h.A.ptr[row + k + 1]) {
+                                pc[o] = h.A.col[h.A.ptr[row + k] + e];
+                                pv[o] = h.A.val[h.A.ptr[row + k] + e];
+                            }
                         }
-                    }
-            }
+                }
+            });
+            cone_meta.upload(meta);
             cone_cols.upload(pc); cone_vals.upload(pv);
         }
         n_cone_blocks = (int)h.cone_block_prob.size();
+        pt.mark("  uploads: cone records");
         {
             std::vector<int2> lg;
             for (int bl = 0; bl < n_cone_blocks; ++bl)
@@ -973,6 +1048,8 @@ struct HipBackend {
         }
         reset();
         pt.mark("reset");
+        HIP_CHECK(hipStreamSynchronize(stream));
+        pt.mark("staged uploads: drain");
     }
 
     // Everything that depends on the penalties, on the device and in stream order: K = K0 + rho K1 on
@@ -1680,7 +1757,7 @@ struct HipBackend {
         else if (nm == "kx") { src = kx.d; sz = h.n_tot; }
         else if (nm == "D") { src = h.D.data(); sz = h.n_tot; host = true; }
         else if (nm == "E") { src = h.E.data(); sz = h.m_tot; host = true; }
-        else if (nm == "Kval") { src = K.val.d; sz = (int64_t)h.K.val.size(); }
+        else if (nm == "Kval") { src = K.val.d; sz = (int64_t)h.K.col.size(); }
         else if (nm == "rep") {  // [replicas the kernels run with (1 = general problem), nnz of the stored K, of the stored A']
             const double v[3] = {(double)h.rep, (double)h.K.col.size(), (double)h.G1.col.size()};
             if (out && len > 0) std::memcpy(out, v, sizeof(double) * (size_t)std::min<int64_t>(len, 3));
@@ -1890,6 +1967,7 @@ struct HipBackend {
         q_head.upload(Q.head_col); q_ishead.upload(Q.is_head); q_aabs.upload(Q.a_abs); q_ck.upload(Q.ck);
         q_theta.upload(Q.theta); q_xstar.upload(Q.xstar);
         q_posd.upload(Q.pos_diag); q_poss.upload(Q.pos_sub); q_diagpos.upload(Q.diag_pos);
+        pt.mark("  polish: uploads");
         Hb.upload(std::move(Q.band));
         if (st.verbose)
             std::fprintf(stderr, "[score setup] band view of H: %s (%d band + %d csr + %d diag tiles, %d slots per row)\n", Hb.on ? "on" : "off",
@@ -1902,18 +1980,8 @@ struct HipBackend {
             for (int p = 0; p < h.count; ++p) q_ent_max = std::max(q_ent_max, ep[(size_t)p + 1] - ep[(size_t)p]);
             q_entpart.upload(ep);
         }
-        {
-            std::vector<int32_t> longs, lprob;
-            int pr = 0;
-            for (size_t e = 0; e + 1 < Q.cptr.size(); ++e)
-                if (Q.cptr[e + 1] - Q.cptr[e] > kLongContrib) {
-                    while (pr + 1 < h.count && (int64_t)e >= (int64_t)Q.Hm.ptr[(size_t)h.xoff[pr + 1]]) ++pr;
-                    longs.push_back((int32_t)e);
-                    lprob.push_back(pr);
-                }
-            n_long = (int)longs.size();
-            q_long.upload(longs); q_long_prob.upload(lprob);
-        }
+        n_long = (int)Q.long_ent.size();  // (found by build_polish while it lays the contribution lists out)
+        q_long.upload(Q.long_ent); q_long_prob.upload(Q.long_prob);
         const size_t nc = h.cone_row.size();
         q_Bbuf.alloc(nc * Q.T * Q.T);
         q_act.alloc(nc); q_act.zero(stream);

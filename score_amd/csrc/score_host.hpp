@@ -1090,23 +1090,26 @@ inline bool check_replication(const score_problem& p) {
     for (int64_t i = t0; i < n; ++i)
         for (int k = p.P_rowptr[i]; k < p.P_rowptr[i + 1]; ++k)
             if (p.P_col[k] < t0) return false;
-    // cones: head row on tail columns, then d rows that repeat replica by replica
-    int64_t row = 0;
-    for (int c = 0; c < p.n_soc; ++c) {
+    // cones: head row on tail columns, then d rows that repeat replica by replica (all cones have d + 1 rows: cone c starts at row c (d + 1))
+    for (int c = 0; c < p.n_soc; ++c)
         if (p.soc_dims[c] != d + 1) return false;
-        for (int k = p.A_rowptr[row]; k < p.A_rowptr[row + 1]; ++k)
-            if (p.A_col[k] < t0) return false;
-        const int a0 = p.A_rowptr[row + 1], a1 = p.A_rowptr[row + 2];
-        for (int k = a0; k < a1; ++k)
-            if (p.A_col[k] >= nr) return false;
-        for (int rpl = 1; rpl < d; ++rpl) {
-            const int b0 = p.A_rowptr[row + 1 + rpl];
-            if (p.A_rowptr[row + 2 + rpl] - b0 != a1 - a0) return false;
-            for (int k = 0; k < a1 - a0; ++k)
-                if (p.A_col[b0 + k] != p.A_col[a0 + k] + rpl * nr || !close(p.A_val[b0 + k], p.A_val[a0 + k])) return false;
+    parallel_ranges(p.n_soc, 8192, [&](int, int64_t c0, int64_t c1) {
+        for (int64_t c = c0; c < c1 && ok.load(std::memory_order_relaxed); ++c) {
+            const int64_t row = c * (d + 1);
+            for (int k = p.A_rowptr[row]; k < p.A_rowptr[row + 1]; ++k)
+                if (p.A_col[k] < t0) { ok = false; return; }
+            const int a0 = p.A_rowptr[row + 1], a1 = p.A_rowptr[row + 2];
+            for (int k = a0; k < a1; ++k)
+                if (p.A_col[k] >= nr) { ok = false; return; }
+            for (int rpl = 1; rpl < d; ++rpl) {
+                const int b0 = p.A_rowptr[row + 1 + rpl];
+                if (p.A_rowptr[row + 2 + rpl] - b0 != a1 - a0) { ok = false; return; }
+                for (int k = 0; k < a1 - a0; ++k)
+                    if (p.A_col[b0 + k] != p.A_col[a0 + k] + rpl * nr || !close(p.A_val[b0 + k], p.A_val[a0 + k])) { ok = false; return; }
+            }
         }
-        row += d + 1;
-    }
+    });
+    if (!ok) return false;
     // chains: replica by replica, each a shifted copy of replica 0's
     if (p.n_chains > 0) {
         if (p.n_chains % d != 0) return false;
@@ -1137,22 +1140,28 @@ inline void validate_problem(const score_problem& p) {
     }
     if (tot != p.m) throw std::runtime_error("score_problem: z + sum(soc_dims) != m");
     if (p.P_rowptr[0] != 0 || p.A_rowptr[0] != 0) throw std::runtime_error("score_problem: rowptr[0] != 0");
-    for (int i = 0; i < p.n; ++i) {
+    // (row pointers first, serially: the column checks below index with them.  Then the rows in parallel parts; a part that
+    //  finds a fault throws, run_parts hands the first part's exception on)
+    for (int i = 0; i < p.n; ++i)
         if (p.P_rowptr[i + 1] < p.P_rowptr[i]) throw std::runtime_error("score_problem: P_rowptr not monotone");
-        for (int k = p.P_rowptr[i]; k < p.P_rowptr[i + 1]; ++k) {
-            if (p.P_col[k] < 0 || p.P_col[k] >= p.n) throw std::runtime_error("score_problem: P column out of range");
-            if (k > p.P_rowptr[i] && p.P_col[k] <= p.P_col[k - 1])
-                throw std::runtime_error("score_problem: P columns must be sorted and unique per row");
-        }
-    }
-    for (int r = 0; r < p.m; ++r) {
+    for (int r = 0; r < p.m; ++r)
         if (p.A_rowptr[r + 1] < p.A_rowptr[r]) throw std::runtime_error("score_problem: A_rowptr not monotone");
-        for (int k = p.A_rowptr[r]; k < p.A_rowptr[r + 1]; ++k) {
-            if (p.A_col[k] < 0 || p.A_col[k] >= p.n) throw std::runtime_error("score_problem: A column out of range");
-            if (k > p.A_rowptr[r] && p.A_col[k] <= p.A_col[k - 1])
-                throw std::runtime_error("score_problem: A columns must be sorted and unique per row");
-        }
-    }
+    parallel_ranges(p.n, 16384, [&](int, int64_t i0, int64_t i1) {
+        for (int64_t i = i0; i < i1; ++i)
+            for (int k = p.P_rowptr[i]; k < p.P_rowptr[i + 1]; ++k) {
+                if (p.P_col[k] < 0 || p.P_col[k] >= p.n) throw std::runtime_error("score_problem: P column out of range");
+                if (k > p.P_rowptr[i] && p.P_col[k] <= p.P_col[k - 1])
+                    throw std::runtime_error("score_problem: P columns must be sorted and unique per row");
+            }
+    });
+    parallel_ranges(p.m, 16384, [&](int, int64_t r0, int64_t r1) {
+        for (int64_t r = r0; r < r1; ++r)
+            for (int k = p.A_rowptr[r]; k < p.A_rowptr[r + 1]; ++k) {
+                if (p.A_col[k] < 0 || p.A_col[k] >= p.n) throw std::runtime_error("score_problem: A column out of range");
+                if (k > p.A_rowptr[r] && p.A_col[k] <= p.A_col[k - 1])
+                    throw std::runtime_error("score_problem: A columns must be sorted and unique per row");
+            }
+    });
     if (p.n_chains > 0) {
         if (p.block_size < 1 || p.block_size > kMaxBs) throw std::runtime_error("score_problem: block_size must be 1..4");
         if (!p.chain_ptr || !p.node_first_col) throw std::runtime_error("score_problem: null chain hint");
@@ -1547,7 +1556,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         H.cone_part_ptr[p + 1] = (int32_t)H.cone_block_prob.size();
     }
     H.cone_block_first.push_back((int32_t)H.cone_row.size());
-    H.K.val.assign(H.K.col.size(), 0.0);
+    if (factor_on_host) H.K.val.assign(H.K.col.size(), 0.0);  // (a backend that derives K = K0 + rho K1 itself never reads it)
     // Tile size of K and G1 (SCORE_TILE_NNZ: 1024 / 2048 for replicated problems).  Measured on the headline problem,
     // whose replicated K is 250 tiles of 2048 nonzeros -- one per CU: half-size tiles are SLOWER (kp 7.3 -> 7.8 us,
     // kpb 7.8 -> 8.6 us): the SpMV of a single problem is a chain of dependent trips to memory, not a throughput loop.

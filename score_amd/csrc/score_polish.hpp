@@ -63,7 +63,6 @@ struct HAsmArgs {
     const int32_t* skip;
 };
 
-constexpr int kLongContrib = 64;  // entries with more contributions get a workgroup of their own
 
 // 1-D grid: `count` x `blocks_per_problem` entry blocks (problem q = block / blocks_per_problem: entries
 // [ent_part[q], ent_part[q + 1]), 256 per block), then one block per long entry.  A frozen problem (skip[q] != 0) keeps

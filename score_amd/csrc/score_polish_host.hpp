@@ -29,6 +29,7 @@ constexpr int kPolishMaxTail = 3;  // tail dimension d of SOC(d + 1), d in {2, 3
 // added to the diagonal of the non-head rows: keeps H positive definite along flat directions
 // (landmarks all of whose cones are slack, gauge modes of robots no active cone ties down)
 constexpr double kPolishDiagReg = 1e-9;
+constexpr int kLongContrib = 64;  // entries of H with more contributions get a workgroup of their own (k_hassemble)
 
 struct PolishData {
     bool available = false;
@@ -46,6 +47,7 @@ struct PolishData {
     // chain / Jacobi positions in Hm.val
     std::vector<int32_t> pos_diag, pos_sub, diag_pos;
     BandLayout band;  // band view of Hm (score_band.hpp): every chain of every replica is a run of plain rows
+    std::vector<int32_t> long_ent, long_prob;  // entries with more than kLongContrib contributions, and their problems
 };
 
 inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = false, bool band_view = false) {
@@ -171,6 +173,7 @@ inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = fals
     Q.Hm.nrows = Q.Hm.ncols = n;
     Q.Hm.ptr.assign(1, 0);
     Q.cptr.assign(1, 0);
+    std::vector<std::vector<int32_t>> longs(parts.size());  // entries with more than kLongContrib contributions, part by part
     {   // sizes, then every part is copied into place by its own thread
         std::vector<size_t> eoff(parts.size() + 1, 0), coff(parts.size() + 1, 0), roff(parts.size() + 1, 0);
         for (size_t k = 0; k < parts.size(); ++k) {
@@ -184,6 +187,8 @@ inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = fals
         parallel_ranges((int64_t)parts.size(), 1, [&](int, int64_t k0, int64_t k1) {
             for (int64_t k = k0; k < k1; ++k) {
                 const Part& W = parts[k];
+                for (size_t e = 0; e < W.ent_len.size(); ++e)
+                    if (W.ent_len[e] > kLongContrib) longs[(size_t)k].push_back((int32_t)(eoff[k] + e));
                 std::copy(W.col.begin(), W.col.end(), Q.Hm.col.begin() + eoff[k]);
                 std::copy(W.pon.begin(), W.pon.end(), Q.Pon.begin() + eoff[k]);
                 std::copy(W.ccone.begin(), W.ccone.end(), Q.ccone.begin() + coff[k]);
@@ -195,6 +200,15 @@ inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = fals
                 for (size_t e = 0; e < W.ent_len.size(); ++e) { cacc += W.ent_len[e]; Q.cptr[eoff[k] + e + 1] = cacc; }
             }
         });
+    }
+    {   // the long entries in order, with the problem each belongs to
+        int pr = 0;
+        for (const auto& lp : longs)
+            for (int32_t e : lp) {
+                while (pr + 1 < H.count && (int64_t)e >= (int64_t)Q.Hm.ptr[(size_t)H.xoff[pr + 1]]) ++pr;
+                Q.long_ent.push_back(e);
+                Q.long_prob.push_back(pr);
+            }
     }
     pt.mark("    polish: concatenate");
     Q.rbH = make_rowblocks(Q.Hm, plain_segments(H.xoff), H.count);
