@@ -487,7 +487,23 @@ struct RuizDevice : RuizOffload {
             try {
                 DevBuf<int32_t> Pp, Pc, Ap, Ac, dat, dpos, drow, dg;
                 DevBuf<double> Pv, Av, dD, dE, dd, de;
-                Pp.upload_from(p.P_rowptr, (size_t)n + 1); Pc.upload_from(p.P_col, (size_t)nnzP); Pv.upload_from(p.P_val, (size_t)nnzP);
+                Pp.upload_from(p.P_rowptr, (size_t)n + 1);
+                if (rep > 1) {
+                    // only the columns of replica 0 and of the tail are swept (P is symmetric: their rows): two contiguous
+                    // ranges of P's entries go up, the rest of the buffers is never read
+                    Pc.alloc((size_t)nnzP); Pv.alloc((size_t)nnzP);
+                    const int64_t e0 = p.P_rowptr[rep_n], t0 = p.P_rowptr[(int64_t)rep * rep_n];
+                    if (e0 > 0) {
+                        HIP_CHECK(hipMemcpyAsync(Pc.d, p.P_col, (size_t)e0 * sizeof(int32_t), hipMemcpyHostToDevice, st));
+                        HIP_CHECK(hipMemcpyAsync(Pv.d, p.P_val, (size_t)e0 * sizeof(double), hipMemcpyHostToDevice, st));
+                    }
+                    if (nnzP > t0) {
+                        HIP_CHECK(hipMemcpyAsync(Pc.d + t0, p.P_col + t0, (size_t)(nnzP - t0) * sizeof(int32_t), hipMemcpyHostToDevice, st));
+                        HIP_CHECK(hipMemcpyAsync(Pv.d + t0, p.P_val + t0, (size_t)(nnzP - t0) * sizeof(double), hipMemcpyHostToDevice, st));
+                    }
+                } else {
+                    Pc.upload_from(p.P_col, (size_t)nnzP); Pv.upload_from(p.P_val, (size_t)nnzP);
+                }
                 Ap.upload_from(p.A_rowptr, (size_t)m + 1); Ac.upload_from(p.A_col, (size_t)nnzA); Av.upload_from(p.A_val, (size_t)nnzA);
                 dat.upload_from(atp.data(), atp.size()); dpos.upload_from(atpos.data(), atpos.size());
                 drow.upload_from(arow.data(), arow.size()); dg.upload_from(gstart.data(), gstart.size());
