@@ -113,6 +113,7 @@ class ScoreModel:
     # and the measured distance
     range_ends: Optional[np.ndarray] = None  # (Nr, 4) int64: ta, sa, tb, sb
     range_dist: Optional[np.ndarray] = None
+    pose_chain_names: Optional[list] = None  # FactorGraphData.get_pose_chain_names(), when the builder had it at hand
 
     def expand(self, x_solver: np.ndarray) -> np.ndarray:
         """solver space -> model space (re-inserts the pinned pose)."""

@@ -1435,8 +1435,16 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     H.m_tot = H.roff[count];
     {   // row replication: every problem of the batch must carry the same, verified, hint
         int rep = (allow_rep && std::getenv("SCORE_NO_REPLICATION") == nullptr) ? probs[0].rep_d : 0;
-        for (int p = 0; p < count && rep > 1; ++p)
-            if (probs[p].rep_d != rep || !check_replication(probs[p])) rep = 0;
+        if (rep > 1 && count > 1) {  // (a batch: one problem per part, the sweeps inside run serially)
+            std::atomic<bool> all{true};
+            parallel_ranges(count, 1, [&](int, int64_t p0, int64_t p1) {
+                for (int64_t p = p0; p < p1 && all.load(std::memory_order_relaxed); ++p)
+                    if (probs[p].rep_d != rep || !check_replication(probs[p])) all = false;
+            });
+            if (!all) rep = 0;
+        } else if (rep > 1 && (probs[0].rep_d != rep || !check_replication(probs[0]))) {
+            rep = 0;
+        }
         H.rep = rep > 1 ? rep : 1;
         H.rep_n.assign((size_t)count, 0);
         if (H.rep > 1)

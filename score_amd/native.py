@@ -14,6 +14,7 @@ for ``.P`` / ``.A`` (tests, the oracle's certificate).
 from __future__ import annotations
 
 import ctypes as C
+from itertools import chain
 from operator import attrgetter
 from typing import Dict, Optional
 
@@ -90,9 +91,15 @@ def graph_arrays(data) -> Dict[str, np.ndarray]:
     variable names (gurobi_utils.py:62-80, :103-109)."""
     d = data.dimension
     check_dimension(d)
-    pose_names = [p.name for chain in data.pose_variables for p in chain]
+    chain_len = [len(c) for c in data.pose_variables]
+    if _objread is not None:
+        pvars = list(chain.from_iterable(data.pose_variables))
+        pose_names = [None] * len(pvars)
+        _objread.gather(pvars, ("name",), "o", (pose_names,), (None,))
+    else:
+        pose_names = [p.name for chain_ in data.pose_variables for p in chain_]
     landmark_names = [l.name for l in data.landmark_variables]
-    pose_idx = {nm: i for i, nm in enumerate(pose_names)}
+    pose_idx = dict(zip(pose_names, range(len(pose_names))))
     if len(pose_idx) != len(pose_names):
         _check_unique(pose_names, "pose_vars")  # (names the duplicate)
     if len(set(landmark_names)) != len(landmark_names):
@@ -131,7 +138,7 @@ def graph_arrays(data) -> Dict[str, np.ndarray]:
             if k in seen:
                 raise ValueError(f"Variable name {k} already exists in distance_vars")
             seen.add(k)
-    meas = [m for chain in data.odom_measurements for m in chain]
+    meas = list(chain.from_iterable(data.odom_measurements))
     meas += list(data.loop_closure_measurements)
     ne = len(meas)
     if ne:
@@ -159,8 +166,10 @@ def graph_arrays(data) -> Dict[str, np.ndarray]:
             raise ValueError(f"landmark prior on {p.name}: not a landmark")
     return dict(
         dim=d, pose_names=pose_names, landmark_names=landmark_names, range_keys=range_keys,
-        n_loop_closures=len(data.loop_closure_measurements), pose_chain_names=data.get_pose_chain_names(),
-        chain_len=np.array([len(c) for c in data.pose_variables], dtype=np.int32),
+        n_loop_closures=len(data.loop_closure_measurements),
+        # (= data.get_pose_chain_names(): the names just read, cut chain by chain)
+        pose_chain_names=[pose_names[o - n_:o] for o, n_ in zip(np.cumsum(chain_len).tolist(), chain_len)],
+        chain_len=np.array(chain_len, dtype=np.int32),
         rel_base=bi.astype(np.int32, copy=False), rel_to=tj.astype(np.int32, copy=False), rel_t=np.ascontiguousarray(tm, dtype=np.float64),
         rel_R=np.ascontiguousarray(Rm, dtype=np.float64), rel_kappa=np.ascontiguousarray(kap, dtype=np.float64),
         rel_tau=np.ascontiguousarray(tau, dtype=np.float64),
@@ -355,6 +364,7 @@ def _read_back_maps(a: Dict[str, np.ndarray], relaxation: str, qp: "NativeQP") -
         fixed_cols=np.arange(PB), fixed_vals=np.hstack([np.eye(d), np.zeros((d, 1))]).ravel(),
         pose_names=a["pose_names"], landmark_names=a["landmark_names"], range_keys=a["range_keys"],
         lm_base=lm_base, rng_base=rng_base, rng_width=rw, range_ends=ends, range_dist=dist,
+        pose_chain_names=a.get("pose_chain_names"),
     )
 
 

@@ -85,7 +85,8 @@ def extract_solver_results(
     values = compat.VariableValues(d, poses, landmarks, dists)
     return compat.SolverResults(
         variables=values, total_time=total_time, solved=solved,
-        pose_chain_names=data.get_pose_chain_names(), solver_cost=(info or {}).get("pobj"), info=info,
+        pose_chain_names=model.pose_chain_names if model.pose_chain_names is not None else data.get_pose_chain_names(),
+        solver_cost=(info or {}).get("pobj"), info=info,
         relaxed_poses=compat.ArrayDict(model.pose_names, blocks.copy()),
     )
 
