@@ -122,48 +122,82 @@ struct BuildScope {
 // region starts its own threads.  Part 0 runs on the calling thread; every part of a region runs
 // concurrently (TeamBarrier relies on that).  Teams are leaked at exit on purpose and rebuilt lazily in
 // a forked child (their threads do not exist there).
+// Hand-over of a job: its fields go into the slot of its generation's parity before the generation counter is published
+// (release); a worker that sees a new generation g (acquire) reads slot g & 1 and checks that the counter still says g --
+// a worker that takes no part in a job may lag behind, but the slot of g is only rewritten for g + 2, after g + 1 has
+// been published.  Workers SPIN for the next job for team_spin_us() before they sleep on the condition
+// variable, and the caller spins for the last part before it sleeps: the parallel phases of one setup follow each other
+// within tens of microseconds, and waking 15 sleepers through one mutex cost 0.1-0.2 ms per phase -- more than many of
+// the phases themselves (a headline score_create is ~29 ms of single-thread work and took 10 ms on 16 threads).
+inline int team_spin_us() {  // SCORE_TEAM_SPIN_US (0: sleep at once)
+    static const int v = [] {
+        const char* e = std::getenv("SCORE_TEAM_SPIN_US");
+        return e ? std::max(0, std::atoi(e)) : 120;
+    }();
+    return v;
+}
 struct HostTeam {
     std::mutex m;
     std::condition_variable cv_work, cv_done;
     std::vector<std::thread> workers;
-    const std::function<void(int)>* job = nullptr;
-    int job_parts = 0;
-    uint64_t gen = 0;
-    int remaining = 0;
+    struct Slot {
+        std::atomic<const std::function<void(int)>*> job{nullptr};
+        std::atomic<int> parts{0};
+    } slot[2];
+    std::atomic<uint64_t> gen{0};
+    std::atomic<int> remaining{0};
     explicit HostTeam(int n_workers) {
         for (int w = 0; w < n_workers; ++w) workers.emplace_back([this, w] { loop(w + 1); });
+    }
+    static bool spin_until(const std::function<bool()>& ready) {
+        const int limit = team_spin_us();
+        if (limit <= 0) return ready();
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0;; ++i) {
+            if (ready()) return true;
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+            if ((i & 127) == 127 &&
+                std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count() > limit)
+                return ready();
+        }
     }
     void loop(int part) {
         uint64_t seen = 0;
         for (;;) {
-            const std::function<void(int)>* j;
-            {
+            if (!spin_until([&] { return gen.load(std::memory_order_acquire) != seen; })) {
                 std::unique_lock<std::mutex> lk(m);
-                cv_work.wait(lk, [&] { return gen != seen; });
-                seen = gen;
-                if (part >= job_parts) continue;
-                j = job;
+                cv_work.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen; });
             }
+            const uint64_t g = gen.load(std::memory_order_acquire);
+            const std::function<void(int)>* j = slot[g & 1].job.load(std::memory_order_relaxed);
+            const int parts = slot[g & 1].parts.load(std::memory_order_relaxed);
+            if (gen.load(std::memory_order_acquire) != g) continue;  // (published again meanwhile: read it afresh)
+            seen = g;
+            if (part >= parts) continue;
             (*j)(part);
-            {
+            if (remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 std::lock_guard<std::mutex> lk(m);
-                if (--remaining == 0) cv_done.notify_one();
+                cv_done.notify_one();
             }
         }
     }
     void run(int parts, const std::function<void(int)>& f) {  // caller holds the lease; parts - 1 <= workers.size()
+        const uint64_t g = gen.load(std::memory_order_relaxed) + 1;  // (one caller at a time: the lease)
+        slot[g & 1].job.store(&f, std::memory_order_relaxed);
+        slot[g & 1].parts.store(parts, std::memory_order_relaxed);
+        remaining.store(parts - 1, std::memory_order_relaxed);
         {
-            std::lock_guard<std::mutex> lk(m);
-            job = &f;
-            job_parts = parts;
-            remaining = parts - 1;
-            ++gen;
+            std::lock_guard<std::mutex> lk(m);  // (sleepers check the generation under this mutex)
+            gen.store(g, std::memory_order_release);
         }
         cv_work.notify_all();
         f(0);
-        std::unique_lock<std::mutex> lk(m);
-        cv_done.wait(lk, [&] { return remaining == 0; });
-        job = nullptr;
+        if (!spin_until([&] { return remaining.load(std::memory_order_acquire) == 0; })) {
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return remaining.load(std::memory_order_acquire) == 0; });
+        }
     }
 };
 constexpr int kMaxTeams = 8;
