@@ -34,6 +34,7 @@
 #include "score_round.hpp"
 #include "score_kernels.hpp"
 #include "score_polish.hpp"
+#include "score_polish_device.hpp"
 #include "score_prec_wave.hpp"
 
 namespace {
@@ -380,6 +381,23 @@ struct CsrBufs {
     int rep = 1;     // right-hand sides per row of the replicated blocks (HostSystem::rep), 1 = plain rows only
     int unroll = kUnroll;  // nonzeros per lane of a tile (HostSystem::tile_nnz / 256)
     int rs_in = 0;   // replicated blocks: operand stride between replicas (0 = the block's own replica stride)
+    // the tile tables of a matrix whose pattern is already on the device (ptr, col filled by kernels: the Newton matrix built
+    // by score_polish_device.hpp); M.ptr is its host copy
+    void adopt_tiles(const Csr& M, const RowBlocks& rb) {
+        first_row.upload(rb.first_row);
+        blk_prob.upload(rb.prob);
+        blk_rs.upload(rb.rs);
+        std::vector<int4> meta(rb.nb()), lg(rb.nb());
+        for (int b = 0; b < rb.nb(); ++b) {
+            const bool seg = rb.kbeg[b] >= 0;
+            meta[b] = make_int4(rb.first_row[b], rb.end_row[b], seg ? rb.kbeg[b] : M.ptr[rb.first_row[b]], seg ? rb.kend[b] : M.ptr[rb.end_row[b]]);
+            lg[b] = make_int4(rb.lfirst[b], rb.lseg[b], rb.lbase[b], rb.lid[b]);
+        }
+        blk_meta.upload(meta);
+        blk_long.upload(lg);
+        alloc_long(rb.n_long, rb.n_long_slots);
+        nblocks = rb.nb();
+    }
     // values = false: the value array is only allocated (zeroed); a kernel fills it
     void upload(const Csr& M, const RowBlocks& rb, const std::vector<int32_t>* sp = nullptr, bool values = true) {
         ptr.upload(M.ptr);
@@ -607,7 +625,9 @@ struct HipBackend {
     bool use_fac32 = false;     // ADMM-loop factors (K)
     bool newton_fac32 = false;  // Newton-polish factors (H): fac_fp32 = 2 only, see DESIGN.md section 4
     PolishData Q;
-    std::future<void> polish_build;  // build_polish runs beside the uploads of init()
+    std::future<void> polish_build;  // build_polish (or only its structure check) runs beside the uploads of init()
+    bool polish_on_device = false;   // the Newton matrix's pattern and lists come from score_polish_device.hpp
+    int64_t hm_nnz = 0;              // entries of the Newton matrix
     CsrBufs Hm;
     DevBuf<double> q_Pon, q_ccoef, q_Bbuf, q_fpart, q_X0, q_X1, q_g, q_delta, q_fac, q_dinv, q_work, q_dummy, q_gd, q_pw;
     DevBuf<double> q_aabs, q_ck, q_theta, q_xstar;
@@ -742,7 +762,15 @@ struct HipBackend {
         } join_polish{polish_build};
         // the Newton matrix pattern and its contribution lists only read the finished host system:
         // built on another thread while this one uploads (4.3 ms beside 2.4 ms of uploads / allocations)
-        if (st.polish) polish_build = std::async(std::launch::async, [this, &h] { build_polish(h, Q, st.verbose != 0, band_h(h)); });
+        // The Newton matrix: its pattern and contribution lists are built on the device (score_polish_device.hpp) from the
+        // matrices uploaded below -- unless its band view is asked for or SCORE_HOST_POLISH_BUILD is set: then on another
+        // host thread while this one uploads.  Either way the structure check (per-cone data) runs on that thread.
+        polish_on_device = st.polish && !band_h(h) && std::getenv("SCORE_HOST_POLISH_BUILD") == nullptr;
+        if (st.polish)
+            polish_build = std::async(std::launch::async, [this, &h] {
+                if (polish_on_device) { Q = PolishData(); polish_structure(h, Q); }
+                else build_polish(h, Q, st.verbose != 0, band_h(h));
+            });
         std::future<BandLayout> band_layout_job;
         if (band_k(h) && !h.chains.empty())  // the band view of K only reads the finished host system: laid out on a thread of its own
             band_layout_job = std::async(std::launch::async, [&h] {
@@ -1448,7 +1476,7 @@ struct HipBackend {
         // algorithmic bytes: H product (KPB: + p, z, w_old in, p out), chain STEP of the Newton set (every chain its own factors)
         double hbytes = 0.0;
         if (Hb.on) { for (double b : Hb.L.bytes) hbytes += b; }
-        else hbytes = 12.0 * (double)Q.Hm.col.size() + 4.0 * (double)(h.n_tot + 1);
+        else hbytes = 12.0 * (double)hm_nnz + 4.0 * (double)(h.n_tot + 1);
         hbytes += 40.0 * (double)h.n_tot;
         const double fbytes = (newton_fac32 ? 4.0 : 8.0) * (double)h.fac_doubles_H;
         np_out[0] = cnt[0]; np_out[1] = cnt[0] ? sum[0] / cnt[0] : 0.0; np_out[2] = hbytes;
@@ -1793,6 +1821,54 @@ struct HipBackend {
             }
             return 1;
         }
+        else if (nm == "polish_build_check") {
+            // the Newton matrix built on the device against the host loop's (score_polish_host.hpp): [built on the device (0/1),
+            // entries device, entries host, mismatching row pointers, columns, max |P-on-pattern difference|, mismatching
+            // list pointers, cones, block indices, max |coefficient difference|, mismatching chain positions (diagonal,
+            // sub-diagonal), Jacobi positions, long entries]
+            if (!Q.available) return -1;
+            if (out && len >= 14) {
+                PolishData R;
+                build_polish(h, R, false, false);
+                auto down_i = [&](const int32_t* d, size_t cnt) {
+                    std::vector<int32_t> v(cnt);
+                    if (cnt) HIP_CHECK(hipMemcpyAsync(v.data(), d, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    return v;
+                };
+                auto down_d = [&](const double* d, size_t cnt) {
+                    std::vector<double> v(cnt);
+                    if (cnt) HIP_CHECK(hipMemcpyAsync(v.data(), d, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    return v;
+                };
+                auto mism = [](const std::vector<int32_t>& x, const std::vector<int32_t>& y) {
+                    double c = (double)(x.size() > y.size() ? x.size() - y.size() : y.size() - x.size());
+                    for (size_t i = 0; i < std::min(x.size(), y.size()); ++i) c += x[i] != y[i];
+                    return c;
+                };
+                auto maxd = [](const std::vector<double>& x, const std::vector<double>& y) {
+                    double c = x.size() == y.size() ? 0.0 : 1e300;
+                    for (size_t i = 0; i < std::min(x.size(), y.size()); ++i) c = std::max(c, std::fabs(x[i] - y[i]));
+                    return c;
+                };
+                const size_t nz = (size_t)hm_nnz, nc = R.ccone.size();
+                out[0] = polish_on_device ? 1.0 : 0.0;
+                out[1] = (double)hm_nnz; out[2] = (double)R.Hm.col.size();
+                out[3] = mism(down_i(Hm.ptr.d, (size_t)h.n_tot + 1), R.Hm.ptr);
+                out[4] = mism(down_i(Hm.col.d, nz), R.Hm.col);
+                out[5] = maxd(down_d(q_Pon.d, nz), R.Pon);
+                out[6] = mism(down_i(q_cptr.d, nz + 1), R.cptr);
+                out[7] = mism(down_i(q_ccone.d, nc), R.ccone);
+                out[8] = mism(down_i(q_cab.d, nc), R.cab);
+                out[9] = maxd(down_d(q_ccoef.d, nc), R.ccoef);
+                out[10] = mism(down_i(q_posd.d, R.pos_diag.size()), R.pos_diag);
+                out[11] = mism(down_i(q_poss.d, R.pos_sub.size()), R.pos_sub);
+                out[12] = mism(down_i(q_diagpos.d, R.diag_pos.size()), R.diag_pos);
+                out[13] = mism(Q.long_ent, R.long_ent) + mism(Q.long_prob, R.long_prob);
+            }
+            return 14;
+        }
         else if (nm == "newton_probe") {
             // [H products timed, mean us, bytes per launch, chain STEPs timed, mean us, factor bytes per launch, H tiles, prec work items]
             if (out && len > 0) std::memcpy(out, np_out, sizeof(double) * (size_t)std::min<int64_t>(len, 8));
@@ -1838,11 +1914,17 @@ struct HipBackend {
             src = z.d; sz = h.n_tot;
         }
         else if (nm == "polish_g") { src = q_g.d; sz = Q.available ? h.n_tot : 0; }
-        else if (nm == "Hval") { src = Hm.val.d; sz = Q.available ? (int64_t)Q.Hm.col.size() : 0; }
+        else if (nm == "Hval") { src = Hm.val.d; sz = Q.available ? hm_nnz : 0; }
         else if (nm == "Hcol" || nm == "Hptr" || nm == "is_head" || nm == "chain_of_col") {
             if (!Q.available) return -1;
             std::vector<double> tmp;
-            if (nm == "Hcol") tmp.assign(Q.Hm.col.begin(), Q.Hm.col.end());
+            if (nm == "Hcol" && polish_on_device) {  // (built on the device: the host never held it)
+                std::vector<int32_t> hc((size_t)hm_nnz);
+                HIP_CHECK(hipMemcpyAsync(hc.data(), Hm.col.d, sizeof(int32_t) * hc.size(), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                tmp.assign(hc.begin(), hc.end());
+            }
+            else if (nm == "Hcol") tmp.assign(Q.Hm.col.begin(), Q.Hm.col.end());
             else if (nm == "Hptr") tmp.assign(Q.Hm.ptr.begin(), Q.Hm.ptr.end());
             else if (nm == "is_head") tmp.assign(Q.is_head.begin(), Q.is_head.end());
             else {  // per column: chain node index (global numbering over all chains) or -1
@@ -1970,6 +2052,127 @@ struct HipBackend {
         return state[0] != 0;
     }
 
+    // The Newton matrix's pattern, P on it and the contribution lists, on the device (score_polish_device.hpp); the host keeps
+    // the row pointers (tiles, per-problem entry ranges).  false: the program's cones are not laid out the way the kernels
+    // assume -- the caller builds on the host.
+    bool build_polish_on_device(const HostSystem& h) {
+        const int T = Q.T, D1 = T + 1, bs = h.bs, b2 = bs * bs;
+        const int64_t n = h.n_tot;
+        PhaseTimer pt(st.verbose != 0);
+        for (size_t k = 0; k < h.cone_row.size(); ++k)
+            if ((int64_t)h.cone_row[k] != (int64_t)k * D1) return false;
+        int64_t con_max = 0;
+        const int64_t rec_max = polish_record_bound(h, T, &con_max);
+        if (rec_max + 64 >= ((int64_t)1 << 31)) return false;
+        const int long_max = 1 << 16;
+        // what stays: pattern, P on it, lists, positions (the handle's arena)
+        Hm.ptr.alloc((size_t)n + 1);
+        Hm.col.alloc((size_t)rec_max + 64); Hm.val.alloc((size_t)rec_max + 64);
+        HIP_CHECK(hipMemsetAsync(Hm.col.d, 0, Hm.col.n * sizeof(int32_t), stream));
+        HIP_CHECK(hipMemsetAsync(Hm.val.d, 0, Hm.val.n * sizeof(double), stream));
+        q_Pon.alloc((size_t)rec_max); q_cptr.alloc((size_t)rec_max + 1);
+        q_ccone.alloc((size_t)std::max<int64_t>(1, con_max)); q_cab.alloc((size_t)std::max<int64_t>(1, con_max)); q_ccoef.alloc((size_t)std::max<int64_t>(1, con_max));
+        q_posd.alloc(h.node_col.size() * (size_t)b2); q_poss.alloc(h.node_col.size() * (size_t)b2); q_diagpos.alloc(h.diag_cols.size());
+        std::vector<long long> res(3, 0);
+        std::vector<int32_t> longs((size_t)long_max);
+        Q.Hm.nrows = Q.Hm.ncols = n;
+        Q.Hm.ptr.assign((size_t)n + 1, 0);
+        {
+            // scratch of the build: its own arena, back to the block cache when the build is over
+            DevArena tmp;
+            tmp.dev = st.device;
+            struct Swap {
+                DevArena* keep;
+                explicit Swap(DevArena* a) : keep(tl_arena) { tl_arena = a; }
+                ~Swap() { tl_arena = keep; }
+            } swap(&tmp);
+            try {
+            DevBuf<long long> cnt, off, result;
+            DevBuf<unsigned long long> key0, key1, flag, flag_s;
+            DevBuf<uint32_t> idx0, idx1;
+            DevBuf<int32_t> rcone, rab, hrow, long_ent, prev_col;
+            DevBuf<double> rcoef;
+            cnt.alloc((size_t)n + 1); off.alloc((size_t)n + 1); result.alloc(3);
+            key0.alloc((size_t)rec_max); key1.alloc((size_t)rec_max); idx0.alloc((size_t)rec_max); idx1.alloc((size_t)rec_max);
+            flag.alloc((size_t)rec_max); flag_s.alloc((size_t)rec_max);
+            rcone.alloc((size_t)rec_max); rab.alloc((size_t)rec_max); rcoef.alloc((size_t)rec_max); hrow.alloc((size_t)rec_max);
+            long_ent.alloc((size_t)long_max);
+            HIP_CHECK(hipMemsetAsync(result.d, 0, 3 * sizeof(long long), stream));
+            {
+                std::vector<int32_t> pc(h.node_col.size(), -1);  // column of the chain predecessor
+                for (const auto& ch : h.chains)
+                    for (int i = 1; i < ch.N; ++i) pc[(size_t)ch.node_begin + i] = h.node_col[(size_t)ch.node_begin + i - 1];
+                prev_col.upload(pc);
+            }
+            HBuildArgs a{};
+            a.n = n; a.T = T;
+            a.g2_ptr = G2.ptr.d; a.g2_split = G2.split.d; a.g2_col = G2.col.d; a.g2_val = G2.val.d;
+            a.A_ptr = A_ptr.d; a.A_col = A_col.d; a.A_val = A_val.d; a.is_head = q_ishead.d;
+            a.rec_max = rec_max; a.key = key0.d; a.idx = idx0.d; a.rcone = rcone.d; a.rab = rab.d; a.rcoef = rcoef.d;
+            const unsigned grows = (unsigned)((n + 1 + 3) / 4), grec = (unsigned)((rec_max + 255) / 256);  // (a wavefront per row)
+            a.rec_cnt = cnt.d;
+            hipLaunchKernelGGL(k_hb_count, dim3(grows), dim3(256), 0, stream, a);
+            size_t tb = 0, tb2 = 0, tb3 = 0;
+            int bits = 1;
+            while (((int64_t)1 << bits) <= n) ++bits;  // (the sentinel row n sorts last)
+            HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, cnt.d, off.d, (long long)0, (size_t)n + 1, rocprim::plus<long long>(), stream));
+            HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb2, key0.d, key1.d, idx0.d, idx1.d, (size_t)rec_max, 0, 32 + bits, stream));
+            HIP_CHECK(rocprim::inclusive_scan(nullptr, tb3, flag.d, flag_s.d, (size_t)rec_max, rocprim::plus<unsigned long long>(), stream));
+            DevBuf<unsigned char> scratch;
+            scratch.alloc(std::max(tb, std::max(tb2, tb3)) + 256);
+            HIP_CHECK(rocprim::exclusive_scan((void*)scratch.d, tb, cnt.d, off.d, (long long)0, (size_t)n + 1, rocprim::plus<long long>(), stream));
+            a.rec_cnt = off.d;
+            hipLaunchKernelGGL(k_hb_expand, dim3(grows), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(k_hb_pad, dim3(grec), dim3(256), 0, stream, a);
+            HIP_CHECK(rocprim::radix_sort_pairs((void*)scratch.d, tb2, key0.d, key1.d, idx0.d, idx1.d, (size_t)rec_max, 0, 32 + bits, stream));
+            HScatterArgs sa{};
+            sa.n = n; sa.rec_max = rec_max; sa.key = key1.d; sa.idx = idx1.d; sa.rcone = rcone.d; sa.rab = rab.d; sa.rcoef = rcoef.d;
+            sa.flag = flag.d; sa.Hcol = Hm.col.d; sa.Hrow = hrow.d; sa.Pon = q_Pon.d; sa.cptr = q_cptr.d;
+            sa.ccone = q_ccone.d; sa.cab = q_cab.d; sa.ccoef = q_ccoef.d; sa.Hptr = Hm.ptr.d; sa.result = result.d;
+            sa.long_ent = long_ent.d; sa.long_max = long_max; sa.diag_reg = kPolishDiagReg;
+            hipLaunchKernelGGL(k_hb_flags, dim3(grec), dim3(256), 0, stream, sa);
+            HIP_CHECK(rocprim::inclusive_scan((void*)scratch.d, tb3, flag.d, flag_s.d, (size_t)rec_max, rocprim::plus<unsigned long long>(), stream));
+            sa.flag = flag_s.d;
+            hipLaunchKernelGGL(k_hb_scatter, dim3(grec), dim3(256), 0, stream, sa);
+            hipLaunchKernelGGL(k_hb_rows, dim3(grec), dim3(256), 0, stream, sa);
+            HPosArgs pa{};
+            pa.Hptr = Hm.ptr.d; pa.Hcol = Hm.col.d; pa.node_col = node_col.d; pa.prev_col = prev_col.d;
+            pa.n_nodes = (int64_t)h.node_col.size(); pa.bs = bs; pa.pos_diag = q_posd.d; pa.pos_sub = q_poss.d;
+            pa.diag_cols = diag_cols.d; pa.n_diag = (int64_t)h.diag_cols.size(); pa.diag_pos = q_diagpos.d;
+            const int64_t npos = std::max<int64_t>(pa.n_nodes * b2, pa.n_diag);
+            if (npos > 0) hipLaunchKernelGGL(k_hb_positions, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, stream, pa);
+            HIP_CHECK(hipGetLastError());
+            pt.mark("    polish (device): buffers + launches");
+            HIP_CHECK(hipMemcpyAsync(res.data(), result.d, 3 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(Q.Hm.ptr.data(), Hm.ptr.d, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipMemcpyAsync(longs.data(), long_ent.d, (size_t)long_max * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            HIP_CHECK(hipStreamSynchronize(stream));
+            pt.mark("    polish (device): kernels + row pointers back");
+            } catch (...) {
+                (void)hipStreamSynchronize(stream);  // (nothing in flight may touch the scratch once it goes back to the cache)
+                throw;
+            }
+        }
+        if (res[2] > long_max) throw std::runtime_error("Newton matrix: too many long entries");
+        hm_nnz = res[0];
+        longs.resize((size_t)res[2]);
+        std::sort(longs.begin(), longs.end());
+        Q.long_ent = longs;
+        Q.long_prob.assign(longs.size(), 0);
+        {
+            int pr = 0;
+            for (size_t x = 0; x < longs.size(); ++x) {
+                while (pr + 1 < h.count && (int64_t)longs[x] >= (int64_t)Q.Hm.ptr[(size_t)h.xoff[pr + 1]]) ++pr;
+                Q.long_prob[x] = pr;
+            }
+        }
+        Q.rbH = make_rowblocks(Q.Hm, plain_segments(h.xoff), h.count);
+        Hm.adopt_tiles(Q.Hm, Q.rbH);
+        pt.mark("    polish (device): tiles");
+        Q.available = true;
+        return true;
+    }
+
     void init_polish(const HostSystem& h) {
         PhaseTimer pt(st.verbose != 0);
         if (const char* e = std::getenv("SCORE_NEWTON_ETA_MAX")) newton_eta_max = std::atof(e);
@@ -1977,12 +2180,26 @@ struct HipBackend {
         if (const char* e = std::getenv("SCORE_NEWTON_ETA_POW")) newton_eta_pow = std::atof(e);
         polish_build.get();  // (rethrows what build_polish threw)
         pt.mark("  polish: host structures (wait)");
+        bool on_device = false;
+        if (polish_on_device && Q.T > 0) {
+            q_head.upload(Q.head_col); q_ishead.upload(Q.is_head); q_aabs.upload(Q.a_abs); q_ck.upload(Q.ck);
+            q_theta.upload(Q.theta); q_xstar.upload(Q.xstar);
+            on_device = build_polish_on_device(h);
+            pt.mark("  polish: pattern + lists on the device");
+            if (!on_device) {  // (cones not laid out row after row, more than 2^32 records: the host loop takes over)
+                polish_on_device = false;
+                build_polish(h, Q, st.verbose != 0, false);
+            }
+        }
         if (!Q.available) return;
-        Hm.upload(Q.Hm, Q.rbH, nullptr, false);
-        q_Pon.upload(Q.Pon); q_ccoef.upload(Q.ccoef); q_cptr.upload(Q.cptr); q_ccone.upload(Q.ccone); q_cab.upload(Q.cab);
-        q_head.upload(Q.head_col); q_ishead.upload(Q.is_head); q_aabs.upload(Q.a_abs); q_ck.upload(Q.ck);
-        q_theta.upload(Q.theta); q_xstar.upload(Q.xstar);
-        q_posd.upload(Q.pos_diag); q_poss.upload(Q.pos_sub); q_diagpos.upload(Q.diag_pos);
+        if (!on_device) {
+            hm_nnz = (int64_t)Q.Hm.col.size();
+            Hm.upload(Q.Hm, Q.rbH, nullptr, false);
+            q_Pon.upload(Q.Pon); q_ccoef.upload(Q.ccoef); q_cptr.upload(Q.cptr); q_ccone.upload(Q.ccone); q_cab.upload(Q.cab);
+            q_head.upload(Q.head_col); q_ishead.upload(Q.is_head); q_aabs.upload(Q.a_abs); q_ck.upload(Q.ck);
+            q_theta.upload(Q.theta); q_xstar.upload(Q.xstar);
+            q_posd.upload(Q.pos_diag); q_poss.upload(Q.pos_sub); q_diagpos.upload(Q.diag_pos);
+        }
         pt.mark("  polish: uploads");
         Hb.upload(std::move(Q.band));
         if (st.verbose)
@@ -2055,7 +2272,7 @@ struct HipBackend {
     void newton_hessian(const int32_t* skip = nullptr, bool refactor = true) {
         const HostSystem& h = *H;
         HAsmArgs ha{};
-        ha.nnz = (int64_t)Q.Hm.col.size(); ha.Pon = q_Pon.d; ha.cptr = q_cptr.d; ha.ccone = q_ccone.d; ha.cab = q_cab.d;
+        ha.nnz = hm_nnz; ha.Pon = q_Pon.d; ha.cptr = q_cptr.d; ha.ccone = q_ccone.d; ha.cab = q_cab.d;
         ha.ccoef = q_ccoef.d; ha.Bbuf = q_Bbuf.d; ha.T2 = Q.T * Q.T; ha.Hval = Hm.val.d;
         ha.dst = Hb.on ? Hb.dst.d : nullptr; ha.V = Hb.on ? Hb.V.d : nullptr;
         ha.ndiag = (int)h.diag_cols.size(); ha.diag_pos = q_diagpos.d; ha.dinv = q_dinv.d;

@@ -1,0 +1,266 @@
+// score_polish_device.hpp -- the Newton matrix's pattern and contribution lists, built on the device.
+//
+// What score_polish_host.hpp::build_polish computes row by row on the host -- the pattern of H = P + A_tail' B A_tail on the
+// union of P's entries and the cone couplings, P on that pattern, and for every entry the list of (cone, block index,
+// coefficient) contributions in the order the host meets them -- from the matrices the handle has just uploaded (G2 = [P | A'],
+// A, the head flags): every row EXPANDS into records (key = row << 32 | column; P entries first, then the contributions in
+// the host loop's order: entries of A' of the row, tail index b, entries of A's row), a stable radix sort by key groups them,
+// one scan numbers the entries (runs of equal keys) and the contributions, one scatter writes Hcol, P-on-pattern, cptr and the
+// lists.  Equal to the host build entry by entry and contribution by contribution (the sort is stable, the records are laid
+// out in the host loop's order), so k_hassemble sums the same terms in the same order:
+// score_debug_get("polish_build_check"), tests/test_gpu_parity.py::test_device_built_newton_matrix_equals_the_host_build.
+// Replaces, for this part of score_create, the host loops that were the largest share of its CPU time (13.5 ms of 29 on the
+// headline problem, single thread; 18 of 64 ms per 8-trial Monte-Carlo handle) -- SURVEY 8 f2, the reference builds the same
+// couplings term by term in /root/reference/score/utils/gurobi_utils.py:336-352 (cones) and :449-501 (range cost).
+#pragma once
+
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "score_polish_host.hpp"
+
+namespace score {
+
+struct HBuildArgs {
+    int64_t n;        // rows of H
+    int32_t T;        // tail dimension: every cone has T + 1 rows of A, cone c owns rows c (T + 1) ..
+    const int32_t* g2_ptr;    // G2 = [P | A'] by rows: P entries [g2_ptr[i], g2_split[i]), A' entries [g2_split[i], g2_ptr[i + 1])
+    const int32_t* g2_split;
+    const int32_t* g2_col;    // (A' entries: n + row of A)
+    const double* g2_val;
+    const int32_t* A_ptr;
+    const int32_t* A_col;
+    const double* A_val;
+    const int32_t* is_head;
+    long long* rec_cnt;       // n + 1: records per row, then (exclusive scan) first record of every row
+    int64_t rec_max;          // room in the record arrays
+    unsigned long long* key;
+    uint32_t* idx;
+    int32_t* rcone;           // >= 0: cone of a contribution; -1: a P entry; -2: the unit diagonal of a head row
+    int32_t* rab;
+    double* rcoef;
+};
+
+// One WAVEFRONT per row (a landmark's row holds thousands of entries of A' and expands into tens of thousands of records;
+// a pose row a dozen): the lanes stride over the row's entries, a wave scan places every entry's records.
+__device__ inline long long hb_wave_sum(long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// records of row i (host loop: score_polish_host.hpp, build_polish)
+__global__ __launch_bounds__(256) void k_hb_count(HBuildArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i > a.n) return;
+    if (i == a.n) { if (lane == 0) a.rec_cnt[i] = 0; return; }
+    if (a.is_head[i]) { if (lane == 0) a.rec_cnt[i] = 1; return; }
+    const int p0 = a.g2_ptr[i], sp = a.g2_split[i], p1 = a.g2_ptr[i + 1];
+    long long c = 0;
+    int diag = 0;
+    for (int k = p0 + lane; k < sp; k += 64) diag |= (a.g2_col[k] == (int32_t)i);
+    const int D1 = a.T + 1;
+    for (int t = sp + lane; t < p1; t += 64) {
+        const int r = a.g2_col[t] - (int32_t)a.n;
+        const int r0 = r / D1 * D1;
+        if (r - r0 - 1 >= 0) c += a.A_ptr[r0 + 1 + a.T] - a.A_ptr[r0 + 1];  // (head rows only hold the head column)
+    }
+    c = hb_wave_sum(c);
+    const bool has_diag = __any(diag);
+    if (lane == 0) a.rec_cnt[i] = (long long)(sp - p0) + (has_diag ? 0 : 1) + c;
+}
+
+__global__ __launch_bounds__(256) void k_hb_expand(HBuildArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.n) return;
+    long long base = a.rec_cnt[i];
+    const unsigned long long hi = (unsigned long long)i << 32;
+    auto put = [&](long long o, int32_t j, int32_t cone, int32_t ab, double coef) {
+        a.key[o] = hi | (unsigned long long)(uint32_t)j;
+        a.idx[o] = (uint32_t)o;
+        a.rcone[o] = cone; a.rab[o] = ab; a.rcoef[o] = coef;
+    };
+    if (a.is_head[i]) { if (lane == 0) put(base, (int32_t)i, -2, 0, 1.0); return; }
+    const int p0 = a.g2_ptr[i], sp = a.g2_split[i], p1 = a.g2_ptr[i + 1];
+    int diag = 0;
+    for (int k = p0 + lane; k < sp; k += 64) {
+        put(base + (k - p0), a.g2_col[k], -1, 0, a.g2_val[k]);
+        diag |= (a.g2_col[k] == (int32_t)i);
+    }
+    base += sp - p0;
+    if (!__any(diag)) {
+        if (lane == 0) put(base, (int32_t)i, -1, 0, 0.0);
+        ++base;
+    }
+    const int D1 = a.T + 1;
+    for (int t0 = sp; t0 < p1; t0 += 64) {
+        const int t = t0 + lane;
+        int cone = 0, ta = -1, r0 = 0;
+        double vi = 0.0;
+        long long mine = 0;
+        if (t < p1) {
+            const int r = a.g2_col[t] - (int32_t)a.n;
+            vi = a.g2_val[t];
+            cone = r / D1; r0 = cone * D1; ta = r - r0 - 1;
+            if (ta >= 0) mine = a.A_ptr[r0 + 1 + a.T] - a.A_ptr[r0 + 1];
+        }
+        // exclusive prefix of `mine` over the lanes (entries of A' in order)
+        long long incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        long long o = base + incl - mine;
+        if (ta >= 0)
+            for (int b = 0; b < a.T; ++b) {
+                const int rb = r0 + 1 + b;
+                for (int kk = a.A_ptr[rb]; kk < a.A_ptr[rb + 1]; ++kk, ++o) put(o, a.A_col[kk], cone, ta * a.T + b, vi * a.A_val[kk]);
+            }
+        base += __shfl(incl, 63, 64);
+    }
+}
+
+// the unused tail of the record arrays sorts behind every row: key = n << 32
+__global__ __launch_bounds__(256) void k_hb_pad(HBuildArgs a) {
+    const int64_t s = a.rec_cnt[a.n] + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.rec_max) return;
+    a.key[s] = (unsigned long long)a.n << 32;
+    a.idx[s] = 0;
+}
+
+struct HScatterArgs {
+    int64_t n, rec_max;
+    const unsigned long long* key;   // sorted
+    const uint32_t* idx;             // sorted: position of the record before the sort
+    const int32_t* rcone;
+    const int32_t* rab;
+    const double* rcoef;
+    unsigned long long* flag;        // per sorted record: (starts an entry) << 32 | (is a contribution); then its inclusive scan
+    int32_t* Hcol;
+    int32_t* Hrow;
+    double* Pon;
+    int32_t* cptr;
+    int32_t* ccone;
+    int32_t* cab;
+    double* ccoef;
+    int32_t* Hptr;                   // n + 1
+    long long* result;               // [0] entries, [1] contributions, [2] long entries
+    int32_t* long_ent;               // entries with more than kLongContrib contributions (unordered; the host sorts them)
+    int32_t long_max;
+    double diag_reg;
+};
+
+__global__ __launch_bounds__(256) void k_hb_flags(HScatterArgs a) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.rec_max) return;
+    const unsigned long long k = a.key[s];
+    unsigned long long f = 0;
+    if ((int64_t)(k >> 32) < a.n) {
+        if (s == 0 || a.key[s - 1] != k) f |= 1ull << 32;
+        if (a.rcone[a.idx[s]] >= 0) f |= 1ull;
+    }
+    a.flag[s] = f;
+}
+
+__global__ __launch_bounds__(256) void k_hb_scatter(HScatterArgs a) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.rec_max) return;
+    const unsigned long long k = a.key[s];
+    const int64_t i = (int64_t)(k >> 32);
+    if (i >= a.n) return;
+    const unsigned long long S = a.flag[s];  // inclusive
+    const int64_t e = (int64_t)(S >> 32) - 1;
+    const uint32_t r = a.idx[s];
+    const int32_t cone = a.rcone[r];
+    const int64_t con_incl = (int64_t)(S & 0xffffffffull), con = con_incl - (cone >= 0 ? 1 : 0);
+    const int32_t j = (int32_t)(uint32_t)(k & 0xffffffffull);
+    const bool head = s == 0 || a.key[s - 1] != k;
+    if (head) {
+        a.Hcol[e] = j;
+        a.Hrow[e] = (int32_t)i;
+        a.cptr[e] = (int32_t)con;
+        // (a P entry, when the key has one, is the first record of its run: P entries precede the contributions of a row)
+        a.Pon[e] = cone == -2 ? 1.0 : (cone == -1 ? a.rcoef[r] + (j == (int32_t)i ? a.diag_reg : 0.0) : 0.0);
+    }
+    if (cone >= 0) {
+        a.ccone[con] = cone;
+        a.cab[con] = a.rab[r];
+        a.ccoef[con] = a.rcoef[r];
+    }
+    const bool last = s + 1 == a.rec_max || (int64_t)(a.key[s + 1] >> 32) >= a.n;
+    if (last) {
+        a.result[0] = e + 1;
+        a.result[1] = con_incl;
+        a.cptr[e + 1] = (int32_t)con_incl;
+    }
+}
+
+// row pointers of H, long entries (launched over the record bound; the entry count is read on the device)
+__global__ __launch_bounds__(256) void k_hb_rows(HScatterArgs a) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t nnz = a.result[0];
+    if (e >= nnz) return;
+    const int32_t row = a.Hrow[e];
+    if (e == 0 || a.Hrow[e - 1] != row) a.Hptr[row] = (int32_t)e;
+    if (e == nnz - 1) a.Hptr[a.n] = (int32_t)nnz;
+    if (a.cptr[e + 1] - a.cptr[e] > kLongContrib) {
+        const unsigned long long slot = atomicAdd((unsigned long long*)&a.result[2], 1ull);
+        if ((int64_t)slot < a.long_max) a.long_ent[slot] = (int32_t)e;
+    }
+}
+
+// positions of the chain blocks and of the Jacobi diagonals in H (find_in_row on the device)
+struct HPosArgs {
+    const int32_t* Hptr;
+    const int32_t* Hcol;
+    const int32_t* node_col;
+    const int32_t* prev_col;   // column of a node's chain predecessor, -1 for the first node of a chain
+    int64_t n_nodes;
+    int32_t bs;
+    int32_t* pos_diag;
+    int32_t* pos_sub;
+    const int32_t* diag_cols;
+    int64_t n_diag;
+    int32_t* diag_pos;
+};
+__device__ inline int32_t hb_find(const int32_t* ptr, const int32_t* col, int32_t row, int32_t c) {
+    int lo = ptr[row], hi = ptr[row + 1];
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (col[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    return (lo < ptr[row + 1] && col[lo] == c) ? lo : -1;
+}
+__global__ __launch_bounds__(256) void k_hb_positions(HPosArgs a) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b2 = a.bs * a.bs;
+    if (t < a.n_nodes * b2) {
+        const int64_t g = t / b2;
+        const int ab = (int)(t - g * b2), ra = ab / a.bs, cb = ab - ra * a.bs;
+        const int32_t col = a.node_col[g];
+        a.pos_diag[t] = hb_find(a.Hptr, a.Hcol, col + ra, col + cb);
+        const int32_t pc = a.prev_col[g];
+        a.pos_sub[t] = pc >= 0 ? hb_find(a.Hptr, a.Hcol, col + ra, pc + cb) : -1;
+    }
+    if (t < a.n_diag) a.diag_pos[t] = hb_find(a.Hptr, a.Hcol, a.diag_cols[t], a.diag_cols[t]);
+}
+
+// upper bound of the records (exact but for the rows of P without a diagonal entry): P entries, one record per head
+// row, one per row for a missing diagonal, (entries of a cone's tail rows)^2 contributions per cone
+inline int64_t polish_record_bound(const HostSystem& H, int T, int64_t* contributions = nullptr) {
+    int64_t con = 0;
+    for (size_t k = 0; k < H.cone_row.size(); ++k) {
+        const int r0 = H.cone_row[k];
+        const int64_t L = H.A.ptr[r0 + 1 + T] - H.A.ptr[r0 + 1];
+        con += L * L;
+    }
+    if (contributions) *contributions = con;
+    int64_t nnzP = 0;
+    for (int64_t i = 0; i < H.n_tot; ++i) nnzP += H.g2_split[(size_t)i] - H.G2.ptr[(size_t)i];
+    return nnzP + H.n_tot + con;
+}
+
+}  // namespace score

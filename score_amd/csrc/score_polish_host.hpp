@@ -50,33 +50,31 @@ struct PolishData {
     std::vector<int32_t> long_ent, long_prob;  // entries with more than kLongContrib contributions, and their problems
 };
 
-inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = false, bool band_view = false) {
-    Q = PolishData();
-    BuildScope scope;  // (built on a thread of its own next to the handle's uploads: shares the thread budget)
-    PhaseTimer pt(verbose);
+// Structure detection (see the head of this file): fills the per-cone data and Q.T; false when the program is not of that
+// form.  cone_of_row (optional): the cone of every row of A.
+inline bool polish_structure(const HostSystem& H, PolishData& Q, std::vector<int32_t>* cone_of_row_out = nullptr) {
     const int64_t n = H.n_tot, m = H.m_tot;
     const size_t ncones = H.cone_row.size();
-    if (ncones == 0 || m == 0) return;
-    // ---- structure detection ----
+    if (ncones == 0 || m == 0) return false;
     int T = H.cone_dim[0] - 1;
-    if (T < 1 || T > kPolishMaxTail) return;
+    if (T < 1 || T > kPolishMaxTail) return false;
     Q.head_col.assign(ncones, -1);
     Q.a_abs.assign(ncones, 0.0); Q.ck.assign(ncones, 0.0); Q.theta.assign(ncones, 0.0); Q.xstar.assign(ncones, 0.0);
     Q.is_head.assign(n, 0);
     std::vector<int32_t> cone_of_row(m, -1);
     for (size_t k = 0; k < ncones; ++k) {
-        if (H.cone_type[k] != 1 || H.cone_dim[k] - 1 != T) return;
+        if (H.cone_type[k] != 1 || H.cone_dim[k] - 1 != T) return false;
         const int r0 = H.cone_row[k];
         for (int a = 0; a <= T; ++a) cone_of_row[r0 + a] = (int32_t)k;
-        if (H.A.ptr[r0 + 1] - H.A.ptr[r0] != 1) return;
+        if (H.A.ptr[r0 + 1] - H.A.ptr[r0] != 1) return false;
         const int32_t h = H.A.col[H.A.ptr[r0]];
         const double a = H.A.val[H.A.ptr[r0]];
-        if (!(a < 0.0) || H.b[r0] != 0.0) return;
+        if (!(a < 0.0) || H.b[r0] != 0.0) return false;
         // column h: a single entry in A (this one) and a positive diagonal-only row in P
-        if (H.G2.ptr[h + 1] - H.g2_split[h] != 1) return;
-        if (H.g2_split[h] - H.G2.ptr[h] != 1 || H.G2.col[H.G2.ptr[h]] != h) return;
+        if (H.G2.ptr[h + 1] - H.g2_split[h] != 1) return false;
+        if (H.g2_split[h] - H.G2.ptr[h] != 1 || H.G2.col[H.G2.ptr[h]] != h) return false;
         const double phh = H.G2.val[H.G2.ptr[h]];
-        if (!(phh > 0.0)) return;
+        if (!(phh > 0.0)) return false;
         Q.head_col[k] = h;
         Q.is_head[h] = 1;
         Q.a_abs[k] = -a;
@@ -85,6 +83,18 @@ inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = fals
         Q.theta[k] = -a * Q.xstar[k];
     }
     Q.T = T;
+    if (cone_of_row_out) *cone_of_row_out = std::move(cone_of_row);
+    return true;
+}
+
+inline void build_polish(const HostSystem& H, PolishData& Q, bool verbose = false, bool band_view = false) {
+    Q = PolishData();
+    BuildScope scope;  // (built on a thread of its own next to the handle's uploads: shares the thread budget)
+    PhaseTimer pt(verbose);
+    const int64_t n = H.n_tot;
+    std::vector<int32_t> cone_of_row;
+    if (!polish_structure(H, Q, &cone_of_row)) return;
+    const int T = Q.T;
     pt.mark("    polish: structure check");
     // ---- Newton matrix pattern + contribution lists ----
     struct Contrib { int32_t j, cone, ab; double coef; };

@@ -162,6 +162,37 @@ def test_band_view_and_split_long_rows_against_the_csr_stream(fixtures, hip_lib,
             sv.close()
 
 
+def test_device_built_newton_matrix_equals_the_host_build(fixtures, hip_lib, monkeypatch):
+    """score_create builds the Newton matrix's pattern, P on it, the contribution lists, the chain / Jacobi positions and the
+    long entries ON THE DEVICE (score_polish_device.hpp: records, stable radix sort, scan, scatter).  Entry by entry and
+    contribution by contribution it is what the host loop (score_polish_host.hpp, kept for the twin and as the fallback)
+    builds -- no mismatch, coefficients bit-equal -- on 2-D and 3-D goldens, a graph with loop closures and landmark priors, a
+    lock-step batch of different sizes and a graph whose landmark is seen by thousands of ranges (long entries); and the
+    default solves through either build agree to the last bit."""
+    _hip_only(hip_lib)
+    cases = [[assemble(graph_by_name(nm, fixtures), "SOCP").qp] for nm in ("synth_a", "synth_b", "graph3d", "prior2d")]
+    cases.append([assemble(make_manhattan(n_robots=2 + k, n_poses=300 + 170 * k, n_beacons=2, seed=90 + k), "SOCP").qp for k in range(3)])
+    cases.append([assemble(make_manhattan(n_robots=4, n_poses=1500, n_beacons=1, seed=61, p_range=0.4), "SOCP").qp])
+    for qps in cases:
+        monkeypatch.delenv("SCORE_HOST_POLISH_BUILD", raising=False)
+        dev = ConicSolver(qps, {}, lib_path=hip_lib)
+        c = dev.debug_get("polish_build_check")
+        assert c[0] == 1.0, "the Newton matrix was not built on the device"
+        assert c[1] == c[2] and c[1] > 0, c
+        assert not c[3:].any(), c
+        sd = dev.solve()
+        dev.close()
+        monkeypatch.setenv("SCORE_HOST_POLISH_BUILD", "1")
+        host = ConicSolver(qps, {}, lib_path=hip_lib)
+        assert host.debug_get("polish_build_check")[0] == 0.0
+        sh = host.solve()
+        host.close()
+        monkeypatch.delenv("SCORE_HOST_POLISH_BUILD", raising=False)
+        for a, b in zip(sd, sh):
+            assert a.solved and b.solved
+            assert np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y) and a.info["newton_iters"] == b.info["newton_iters"]
+
+
 def test_xcd_aware_tile_order_changes_no_bit(fixtures, hip_lib, monkeypatch):
     """k_spmv / k_cone deal their tiles to the XCDs in contiguous runs (workgroup i takes tile (i % 8) * chunk + i / 8;
     the grid is rounded up and the surplus workgroups leave).  Which workgroup computes a tile changes nothing in
