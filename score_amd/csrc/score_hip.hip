@@ -1037,7 +1037,20 @@ struct HipBackend {
         std::vector<int32_t> dz(h.count, 0);
         done.upload(dz);
         K0d.upload_padded(h.K0, 64); K1d.upload_padded(h.K1, 64);
-        kposd.upload(h.pos_diag); kposs.upload(h.pos_sub); kdiagpos.upload(h.diag_kpos);
+        {   // positions of the chain blocks and the Jacobi diagonals in K's value array: looked up on the device (binary
+            // search per block entry; on the host this was 0.5 ms of a headline create and 2.4 of an 8-trial handle's)
+            const int b2 = h.bs * h.bs;
+            kposd.alloc(h.node_col.size() * (size_t)b2); kposs.alloc(h.node_col.size() * (size_t)b2); kdiagpos.alloc(h.diag_cols.size());
+            DevBuf<int32_t> prevc, drow;
+            prevc.upload(h.node_prev_owned); drow.upload(h.diag_row0);
+            HPosArgs pa{};
+            pa.Hptr = K.ptr.d; pa.Hcol = K.col.d; pa.node_col = node_col.d; pa.prev_col = prevc.d;
+            pa.n_nodes = (int64_t)h.node_col.size(); pa.bs = h.bs; pa.pos_diag = kposd.d; pa.pos_sub = kposs.d;
+            pa.diag_cols = drow.d; pa.n_diag = (int64_t)h.diag_cols.size(); pa.diag_pos = kdiagpos.d;
+            const int64_t npos = std::max<int64_t>(pa.n_nodes * b2, pa.n_diag);
+            if (npos > 0) hipLaunchKernelGGL(k_hb_positions, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, stream, pa);
+            HIP_CHECK(hipGetLastError());
+        }
         fac.alloc(h.fac_doubles); fac.zero(stream);  // separator slots of the spike region are never written (nor used)
         use_fac32 = st.fac_fp32 != 0;
         // 4 x 4 blocks (3-D problems): the LDS-resident chain kernel only exists for the 4-byte stream, and the streaming

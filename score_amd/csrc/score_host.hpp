@@ -837,6 +837,10 @@ struct HostSystem {
     // preconditioner
     std::vector<int32_t> node_col;            // level-0 node -> first (global) column
     std::vector<int32_t> pos_diag, pos_sub;   // K.val positions of the block entries (-1 = 0)
+    // what a backend that looks the positions up itself needs instead (factor_on_host == false: pos_diag, pos_sub and
+    // diag_kpos stay empty): per chain node the column of its chain predecessor (-1: first node, -2: a node whose blocks
+    // are its owner's -- replicated chains), per Jacobi column the row of K that holds its diagonal
+    std::vector<int32_t> node_prev_owned, diag_row0;
     std::vector<ChainDesc> chains;
     std::vector<ChainLevelDesc> levels;
     std::vector<double> fac;
@@ -1677,7 +1681,11 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     for (size_t ci = 0; ci < H.chains.size(); ++ci)
         if (H.chain_owner[ci] != (int32_t)ci)
             for (int i = 0; i < H.chains[ci].N; ++i) node_owned[(size_t)H.chains[ci].node_begin + i] = 0;
-    // K.val positions of the diagonal / sub-diagonal block entries of every chain node
+    H.node_prev_owned.resize(H.node_col.size());
+    for (size_t g = 0; g < H.node_col.size(); ++g) H.node_prev_owned[g] = node_owned[g] ? node_prev[g] : -2;
+    // K.val positions of the diagonal / sub-diagonal block entries of every chain node (host factorisation only: a device
+    // backend finds them with a kernel once K's pattern is up)
+    if (factor_on_host) {
     H.pos_diag.assign(H.node_col.size() * b2, -1);
     H.pos_sub.assign(H.node_col.size() * b2, -1);
     parallel_ranges((int64_t)H.node_col.size(), 2048, [&](int, int64_t g0, int64_t g1) {
@@ -1692,6 +1700,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
                 }
         }
     });
+    }
     pt.mark("chain positions");
     // level layout (structure only) + storage
     H.fac_off.clear();
@@ -1806,7 +1815,8 @@ inline void build_system(const score_problem* probs, int count, const score_sett
                     const int64_t local = c - H.xoff[p], nr = H.rep_n[(size_t)p];
                     if (local < (int64_t)H.rep * nr) c0_ = H.xoff[p] + local % nr;
                 }
-                H.diag_kpos.push_back(find_in_row(H.K, c0_, (int32_t)c0_));
+                H.diag_row0.push_back((int32_t)c0_);
+                if (factor_on_host) H.diag_kpos.push_back(find_in_row(H.K, c0_, (int32_t)c0_));
             }
         // (one Jacobi item = what a 512-thread workgroup requests in one batch of loads: 6 entries per lane)
         constexpr size_t kJacobiItem = 3072;

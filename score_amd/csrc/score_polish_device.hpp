@@ -217,7 +217,7 @@ struct HPosArgs {
     const int32_t* Hptr;
     const int32_t* Hcol;
     const int32_t* node_col;
-    const int32_t* prev_col;   // column of a node's chain predecessor, -1 for the first node of a chain
+    const int32_t* prev_col;   // column of a node's chain predecessor, -1 for the first node of a chain, -2: not this node's blocks (no look-up)
     int64_t n_nodes;
     int32_t bs;
     int32_t* pos_diag;
@@ -241,11 +241,11 @@ __global__ __launch_bounds__(256) void k_hb_positions(HPosArgs a) {
         const int64_t g = t / b2;
         const int ab = (int)(t - g * b2), ra = ab / a.bs, cb = ab - ra * a.bs;
         const int32_t col = a.node_col[g];
-        a.pos_diag[t] = hb_find(a.Hptr, a.Hcol, col + ra, col + cb);
         const int32_t pc = a.prev_col[g];
+        a.pos_diag[t] = pc > -2 ? hb_find(a.Hptr, a.Hcol, col + ra, col + cb) : -1;
         a.pos_sub[t] = pc >= 0 ? hb_find(a.Hptr, a.Hcol, col + ra, pc + cb) : -1;
     }
-    if (t < a.n_diag) a.diag_pos[t] = hb_find(a.Hptr, a.Hcol, a.diag_cols[t], a.diag_cols[t]);
+    if (t < a.n_diag) a.diag_pos[t] = hb_find(a.Hptr, a.Hcol, a.diag_cols[t], a.diag_cols[t]);  // (diag_cols: the ROW that holds the diagonal)
 }
 
 // upper bound of the records (exact but for the rows of P without a diagonal entry): P entries, one record per head
