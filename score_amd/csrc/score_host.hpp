@@ -265,7 +265,12 @@ inline int region_width() {
     if (tl_in_parallel_region()) return 1;
     const int callers = std::max(1, active_builders().load(std::memory_order_acquire));
     const int free_extra = host_threads() - callers - extra_threads_busy().load(std::memory_order_acquire);
-    return 1 + std::max(0, free_extra);
+    int width = 1 + std::max(0, free_extra);
+    // many builders at once (the lock-step groups of a Monte-Carlo sweep start together): nobody takes more than its share --
+    // the first to open a region used to take every free thread and left the others serial (8 groups' model construction:
+    // 17-22 ms per group, the last one done 24-28 ms into the sweep)
+    if (callers >= 4 && std::getenv("SCORE_NO_FAIR_SHARE") == nullptr) width = std::min(width, std::max(1, (host_threads() + callers - 1) / callers));
+    return width;
 }
 
 // fn(part, begin, end) for part = 0..T-1 over the boundaries `bound` (T + 1 entries), all parts concurrently
