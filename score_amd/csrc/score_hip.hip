@@ -250,14 +250,25 @@ struct DevArena {
 };
 thread_local DevArena* tl_arena = nullptr;  // set while a handle is being initialised on this thread
 
-// OPT-IN (SCORE_STAGED_UPLOADS=1): uploads of a handle under construction through pinned staging.  hipMemcpyAsync from
-// pageable memory blocks the caller for the whole transfer (the runtime stages it itself, a stream synchronisation per
-// array on top); from pinned memory it returns at once.  Here the source is copied into a pinned chunk (large arrays by
-// a team of host threads), the transfer is queued on the handle's stream and the caller moves on; the chunks go back to
-// the block cache after ONE synchronisation at the end of the setup.  Measured on the headline create (round 4, A/B on
-// three boxes): the upload phases shrink by 0.3-0.5 ms, the copy teams take threads from the Newton-matrix builder that
-// runs beside them, and score_create comes out the same or 0.5-1 ms slower (typical calls 12.0-13.5 against 11.3-12.4 ms)
-// -- the transfers were never the bound, the host work around them is.  Off by default.
+// Uploads of a handle under construction go through pinned staging when they are SMALL.  hipMemcpyAsync from pageable
+// memory blocks the caller for the whole transfer and every array is followed by a stream synchronisation: a create issues
+// ~80 uploads of which ~65 are small tables (tile records, cone tables, per-problem ranges), 15 us each in calls and waits
+// whatever their size -- 1 ms of a 2 ms create of a 100-pose graph, 0.9 ms of a headline create.  A small source is copied
+// into a pinned chunk, its transfer queued on the handle's stream, and the caller moves on (the source may die at once); the
+// chunks go back to the block cache after ONE synchronisation at the end of the setup.  Large arrays keep the pageable
+// path: their cost is bandwidth, and staging them (copy teams of host threads into 32 MB pinned chunks) measured no gain on
+// the headline create.  Measured (round 4): create of 1 x 100 poses 2.11 -> 1.17 ms, 1 x 500: 2.40 -> 1.48, 4 x 1000: 4.06 ->
+// 2.82, 20 x 1000: 9.2 -> 8.6-9.0 ms.  SCORE_NO_STAGED_UPLOADS: everything pageable; SCORE_STAGED_UPLOADS=1: everything staged;
+// SCORE_STAGE_MAX_KB: the size limit (default 512).
+inline size_t stage_limit_bytes() {
+    static const size_t v = [] {
+        if (std::getenv("SCORE_NO_STAGED_UPLOADS")) return (size_t)0;
+        if (std::getenv("SCORE_STAGED_UPLOADS")) return ~(size_t)0;
+        const char* e = std::getenv("SCORE_STAGE_MAX_KB");
+        return (size_t)(e ? std::max(0L, std::atol(e)) : 512L) << 10;
+    }();
+    return v;
+}
 struct StageArena {
     int dev = 0;
     std::vector<size_t> chunk_bytes;
@@ -267,7 +278,7 @@ struct StageArena {
     void* take(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
         if (bytes > left) {
-            size_t got = std::max(bytes, (size_t)32 << 20);
+            size_t got = std::max(bytes, stage_limit_bytes() == ~(size_t)0 ? (size_t)32 << 20 : (size_t)4 << 20);
             void* p = block_cache().take(got, dev, true);
             chunks.push_back(p);
             chunk_bytes.push_back(got);
@@ -279,15 +290,18 @@ struct StageArena {
         left -= bytes;
         return r;
     }
-    // copy `bytes` from src into a pinned slot and queue its transfer to `dst` on `st`
-    void upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
-        if (!bytes) return;
+    // copy `bytes` from src into a pinned slot and queue its transfer to `dst` on `st`; false: too large, the caller
+    // takes the pageable path
+    bool upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
+        if (!bytes) return true;
+        if (bytes > stage_limit_bytes()) return false;
         char* pin = (char*)take(bytes);
         if (bytes >= ((size_t)1 << 20))
             score::parallel_ranges((int64_t)bytes, (int64_t)1 << 19, [&](int, int64_t b0, int64_t b1) { std::memcpy(pin + b0, (const char*)src + b0, (size_t)(b1 - b0)); });
         else
             std::memcpy(pin, src, bytes);
         HIP_CHECK(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, st));
+        return true;
     }
     // (the caller has synchronised the stream the transfers were queued on)
     void release() {
@@ -319,7 +333,7 @@ struct DevBuf {
     void upload(const std::vector<T>& h) {
         if (h.size() != n || !d) alloc(h.size());
         if (!h.empty()) {
-            if (tl_stage) { tl_stage->upload(d, h.data(), h.size() * sizeof(T), tl_copy_stream); return; }
+            if (tl_stage && tl_stage->upload(d, h.data(), h.size() * sizeof(T), tl_copy_stream)) return;
             HIP_CHECK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
             HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
         }
@@ -327,14 +341,14 @@ struct DevBuf {
     // (no synchronisation: the caller waits for the stream before the source goes away)
     void upload_from(const T* src, size_t count) {
         if (count != n || !d) alloc(count);
-        if (count && tl_stage) { tl_stage->upload(d, src, count * sizeof(T), tl_copy_stream); return; }
+        if (count && tl_stage && tl_stage->upload(d, src, count * sizeof(T), tl_copy_stream)) return;
         if (count) HIP_CHECK(hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
     }
     // upload into an allocation with `pad` extra zeroed elements at the end
     void upload_padded(const std::vector<T>& h, size_t pad) {
         if (h.size() + pad != n || !d) alloc(h.size() + pad);
         HIP_CHECK(hipMemsetAsync(d + h.size(), 0, pad * sizeof(T), tl_copy_stream));
-        if (tl_stage) { tl_stage->upload(d, h.data(), h.size() * sizeof(T), tl_copy_stream); return; }
+        if (tl_stage && tl_stage->upload(d, h.data(), h.size() * sizeof(T), tl_copy_stream)) return;
         if (!h.empty())
             HIP_CHECK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
         HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
@@ -498,7 +512,7 @@ struct RuizDevice : RuizOffload {
                 DevArena* a_; hipStream_t s_; StageArena* g_;
                 Scope(DevArena* a, hipStream_t s, StageArena* g) : a_(tl_arena), s_(tl_copy_stream), g_(tl_stage) {
                     tl_arena = a; tl_copy_stream = s;
-                    if (std::getenv("SCORE_STAGED_UPLOADS") != nullptr) tl_stage = g;
+                    if (stage_limit_bytes() > 0) tl_stage = g;
                 }
                 ~Scope() { tl_arena = a_; tl_copy_stream = s_; tl_stage = g_; }
             } scope(&arena, st, &stage);
@@ -744,7 +758,7 @@ struct HipBackend {
             hipStream_t st;
             StageScope(int dev, hipStream_t s) : st(s) {
                 a.dev = dev;
-                if (std::getenv("SCORE_STAGED_UPLOADS") != nullptr) tl_stage = &a;
+                if (stage_limit_bytes() > 0) tl_stage = &a;
             }
             ~StageScope() {
                 tl_stage = nullptr;
