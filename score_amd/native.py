@@ -132,7 +132,12 @@ def graph_arrays(data) -> Dict[str, np.ndarray]:
         range_keys = [tuple(a) for a in map(attrgetter("association"), rm)]
     else:
         range_keys = [(m.first_key, m.second_key) for m in rm]
-    if len(set(range_keys)) != len(range_keys):
+    if ra is not None:  # (the keys as index pairs: a sort of 64-bit codes instead of a set of tuples of strings)
+        codes = np.sort(ra.astype(np.int64) * np.int64(len(var_idx)) + rb.astype(np.int64))
+        duplicate_keys = bool(nr > 1 and (codes[1:] == codes[:-1]).any())
+    else:
+        duplicate_keys = len(set(range_keys)) != len(range_keys)
+    if duplicate_keys:
         seen = set()
         for k in range_keys:
             if k in seen:
