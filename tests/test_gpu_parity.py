@@ -173,6 +173,10 @@ def test_device_built_newton_matrix_equals_the_host_build(fixtures, hip_lib, mon
     cases = [[assemble(graph_by_name(nm, fixtures), "SOCP").qp] for nm in ("synth_a", "synth_b", "graph3d", "prior2d")]
     cases.append([assemble(make_manhattan(n_robots=2 + k, n_poses=300 + 170 * k, n_beacons=2, seed=90 + k), "SOCP").qp for k in range(3)])
     cases.append([assemble(make_manhattan(n_robots=4, n_poses=1500, n_beacons=1, seed=61, p_range=0.4), "SOCP").qp])
+    from score_amd.manhattan import make_config
+    from score_amd.native import assemble_native
+
+    cases.append([assemble_native(make_config(3), "SOCP", lib_path=hip_lib).qp])  # BASELINE configs[3]: 20 x 1000 poses, landmark rows of thousands of entries
     for qps in cases:
         monkeypatch.delenv("SCORE_HOST_POLISH_BUILD", raising=False)
         dev = ConicSolver(qps, {}, lib_path=hip_lib)
