@@ -837,33 +837,17 @@ struct HipBackend {
         pt.mark("  uploads: A, q, b, 1/D, 1/E");
         cone_row.upload(h.cone_row); cone_dim.upload(h.cone_dim); cone_type.upload(h.cone_type);
         cone_block_first.upload(h.cone_block_first); cone_block_prob.upload(h.cone_block_prob);
-        {
-            std::vector<int4> meta(2 * h.cone_row.size());
-            // the entries of the small cones again, by cone index (see ConeArgs::cone_cols)
-            std::vector<int32_t> pc(8 * h.cone_row.size(), 0);
-            std::vector<double> pv(8 * h.cone_row.size(), 0.0);
-            parallel_ranges((int64_t)h.cone_row.size(), 8192, [&](int, int64_t c0, int64_t c1) {
-                for (size_t c = (size_t)c0; c < (size_t)c1; ++c) {
-                    const int row = h.cone_row[c], dim = h.cone_dim[c];
-                    auto ptr = [&](int k) { return h.A.ptr[row + std::min(k, dim)]; };
-                    meta[2 * c] = make_int4(row, dim, h.cone_type[c], ptr(0));
-                    meta[2 * c + 1] = make_int4(ptr(1), ptr(2), ptr(3), ptr(4));
-                    bool small = dim <= kSmallCone;
-                    for (int k = 0; k < std::min(dim, (int)kSmallCone) && small; ++k) small = (h.A.ptr[row + k + 1] - h.A.ptr[row + k]) <= kConeRowNnz;
-                    int32_t safe = h.A.ptr[row] < h.A.ptr[row + dim] ? h.A.col[h.A.ptr[row]] : 0;  // any valid column
-                    for (int k = 0; k < kSmallCone; ++k)
-                        for (int e = 0; e < kConeRowNnz; ++e) {
-                            const size_t o = 8 * c + (size_t)k * kConeRowNnz + e;
-                            pc[o] = safe;
-                            if (small && k < dim && h.A.ptr[row + k] + e < h.A.ptr[row + k + 1]) {
-                                pc[o] = h.A.col[h.A.ptr[row + k] + e];
-                                pv[o] = h.A.val[h.A.ptr[row + k] + e];
-                            }
-                        }
-                }
-            });
-            cone_meta.upload(meta);
-            cone_cols.upload(pc); cone_vals.upload(pv);
+        {   // the cone tables (row pointers, the entries of the small cones again by cone index): from A on the device
+            const size_t nc = h.cone_row.size();
+            cone_meta.alloc(2 * nc); cone_cols.alloc(8 * nc); cone_vals.alloc(8 * nc);
+            if (nc) {
+                ConeTabArgs ca{};
+                ca.ncones = (int64_t)nc; ca.cone_row = cone_row.d; ca.cone_dim = cone_dim.d; ca.cone_type = cone_type.d;
+                ca.A_ptr = A_ptr.d; ca.A_col = A_col.d; ca.A_val = A_val.d;
+                ca.meta = cone_meta.d; ca.cols = cone_cols.d; ca.vals = cone_vals.d;
+                hipLaunchKernelGGL(k_cone_tables, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream, ca);
+                HIP_CHECK(hipGetLastError());
+            }
         }
         n_cone_blocks = (int)h.cone_block_prob.size();
         pt.mark("  uploads: cone records");

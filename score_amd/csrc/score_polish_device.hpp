@@ -248,6 +248,51 @@ __global__ __launch_bounds__(256) void k_hb_positions(HPosArgs a) {
     if (t < a.n_diag) a.diag_pos[t] = hb_find(a.Hptr, a.Hcol, a.diag_cols[t], a.diag_cols[t]);  // (diag_cols: the ROW that holds the diagonal)
 }
 
+// The cone tables k_cone reads by cone index (ConeArgs::cone_meta, cone_cols, cone_vals): row, dimension, kind and the row
+// pointers of the cone's first four rows; for small cones (<= kSmallCone rows of <= kConeRowNnz entries) the entries of A
+// again, 8 slots per cone, unused slots pointing at a valid column with value 0.  From A on the device (was: a host loop
+// over the cones and 6 MB of uploads).
+struct ConeTabArgs {
+    int64_t ncones;
+    const int32_t* cone_row;
+    const int32_t* cone_dim;
+    const int32_t* cone_type;
+    const int32_t* A_ptr;
+    const int32_t* A_col;
+    const double* A_val;
+    int4* meta;       // 2 per cone
+    int32_t* cols;    // 8 per cone
+    double* vals;     // 8 per cone
+};
+__global__ __launch_bounds__(256) void k_cone_tables(ConeTabArgs a) {
+    const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (c >= a.ncones) return;
+    const int row = a.cone_row[c], dim = a.cone_dim[c];
+    int ptr[kSmallCone + 1];
+#pragma unroll
+    for (int k = 0; k <= kSmallCone; ++k) ptr[k] = a.A_ptr[row + (k < dim ? k : dim)];
+    a.meta[2 * c] = make_int4(row, dim, a.cone_type[c], ptr[0]);
+    a.meta[2 * c + 1] = make_int4(ptr[1], ptr[2], ptr[3], ptr[4]);
+    bool small = dim <= kSmallCone;
+    for (int k = 0; k < kSmallCone && k < dim && small; ++k) small = (ptr[k + 1] - ptr[k]) <= kConeRowNnz;
+    const int p_end = a.A_ptr[row + dim];
+    const int32_t safe = ptr[0] < p_end ? a.A_col[ptr[0]] : 0;  // any valid column
+#pragma unroll
+    for (int k = 0; k < kSmallCone; ++k)
+#pragma unroll
+        for (int e = 0; e < kConeRowNnz; ++e) {
+            const int64_t o = 8 * c + k * kConeRowNnz + e;
+            int32_t cc = safe;
+            double vv = 0.0;
+            if (small && k < dim && ptr[k] + e < ptr[k + 1]) {
+                cc = a.A_col[ptr[k] + e];
+                vv = a.A_val[ptr[k] + e];
+            }
+            a.cols[o] = cc;
+            a.vals[o] = vv;
+        }
+}
+
 // upper bound of the records (exact but for the rows of P without a diagonal entry): P entries, one record per head
 // row, one per row for a missing diagonal, (entries of a cone's tail rows)^2 contributions per cone
 inline int64_t polish_record_bound(const HostSystem& H, int T, int64_t* contributions = nullptr) {
