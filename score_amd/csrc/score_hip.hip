@@ -538,8 +538,15 @@ struct RuizDevice : RuizOffload {
                 }
                 Ap.upload_from(p.A_rowptr, (size_t)m + 1); Ac.upload_from(p.A_col, (size_t)nnzA); Av.upload_from(p.A_val, (size_t)nnzA);
                 dat.upload_from(atp.data(), atp.size()); dpos.upload_from(atpos.data(), atpos.size());
-                drow.upload_from(arow.data(), arow.size()); dg.upload_from(gstart.data(), gstart.size());
-                dD.upload_from(D, (size_t)n); dE.upload_from(E, (size_t)m);  // (all ones)
+                dg.upload_from(gstart.data(), gstart.size());
+                // (D = E = 1 and the row of every entry of A are made on the device: 4 MB less to send)
+                drow.alloc(std::max<size_t>(1, arow.size())); dD.alloc((size_t)std::max(1, n)); dE.alloc((size_t)std::max(1, m));
+                {
+                    RuizInitArgs ia{};
+                    ia.D = dD.d; ia.E = dE.d; ia.n = n; ia.m = m; ia.A_ptr = Ap.d; ia.arow = drow.d;
+                    const unsigned gi = (unsigned)((std::max(n, m) + kThreads - 1) / kThreads);
+                    hipLaunchKernelGGL(k_ruiz_init, dim3(std::max(1u, gi)), dim3(kThreads), 0, st, ia);
+                }
                 dd.alloc((size_t)std::max<int64_t>(1, n_act)); de.alloc((size_t)std::max<int64_t>(1, ngroups));
                 RuizArgs a{};
                 a.P_ptr = Pp.d; a.P_col = Pc.d; a.P_val = Pv.d; a.A_ptr = Ap.d; a.A_col = Ac.d; a.A_val = Av.d;

@@ -2406,6 +2406,19 @@ struct RuizArgs {
     int64_t n_act, nr, ngroups;
     int rep;  // 1: plain problem (every column swept)
 };
+// what the passes start from, made on the device instead of uploaded: D = E = 1, the row of every entry of A
+struct RuizInitArgs {
+    double* D; double* E; int64_t n, m;
+    const int32_t* A_ptr; int32_t* arow;
+};
+__global__ __launch_bounds__(kThreads) void k_ruiz_init(RuizInitArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x;
+    if (i < a.n) a.D[i] = 1.0;
+    if (i < a.m) {
+        a.E[i] = 1.0;
+        for (int k = a.A_ptr[i]; k < a.A_ptr[i + 1]; ++k) a.arow[k] = (int32_t)i;
+    }
+}
 __device__ __forceinline__ int64_t ruiz_col(const RuizArgs& a, int64_t act) {
     return (a.rep <= 1 || act < a.nr) ? act : act + (int64_t)(a.rep - 1) * a.nr;
 }
