@@ -1374,8 +1374,15 @@ inline void append_problem(HostSystem& H, int pi, const score_problem& p, const 
         H.g2_split[sp_row0 + i] = (int32_t)(g2_base + S.P.ptr[i + 1] + atp[i]);
         H.G2.ptr[g2_row0 + i] = (int32_t)(g2_base + S.P.ptr[i + 1] + atp[i + 1]);
     }
-    H.G1.col.resize(g1_base + (size_t)g1p[(size_t)n]); H.G1.val.resize(g1_base + (size_t)g1p[(size_t)n]);
-    H.G2.col.resize(g2_base + (size_t)S.P.nnz + atr.size()); H.G2.val.resize(g2_base + (size_t)S.P.nnz + atr.size());
+    // (four value-initialising resizes of 2-9 MB each: one thread per array)
+    parallel_ranges(4, 1, [&](int, int64_t v0, int64_t v1) {
+        for (int64_t v = v0; v < v1; ++v) {
+            if (v == 0) H.G1.col.resize(g1_base + (size_t)g1p[(size_t)n]);
+            else if (v == 1) H.G1.val.resize(g1_base + (size_t)g1p[(size_t)n]);
+            else if (v == 2) H.G2.col.resize(g2_base + (size_t)S.P.nnz + atr.size());
+            else H.G2.val.resize(g2_base + (size_t)S.P.nnz + atr.size());
+        }
+    });
     pt.mark("  append: G resize");
     const int32_t ucol0 = (int32_t)(H.n_tot + ro);
     parallel_ranges(n, 16384, [&](int, int64_t i0, int64_t i1) {
