@@ -243,10 +243,13 @@ struct DevArena {
         left -= bytes;
         return r;
     }
-    ~DevArena() {
-        // (the owner has synchronised its stream: nothing in flight touches these blocks)
+    // (the owner has synchronised its stream: nothing in flight touches these blocks)
+    void release_all() {
         for (size_t i = 0; i < chunks.size(); ++i) block_cache().give(chunks[i], chunk_bytes[i], dev, false);
+        chunks.clear(); chunk_bytes.clear();
+        cur = nullptr; left = 0; next_chunk = (size_t)8 << 20;
     }
+    ~DevArena() { release_all(); }
 };
 thread_local DevArena* tl_arena = nullptr;  // set while a handle is being initialised on this thread
 
@@ -413,12 +416,18 @@ struct CsrBufs {
         nblocks = rb.nb();
     }
     // values = false: the value array is only allocated (zeroed); a kernel fills it
-    void upload(const Csr& M, const RowBlocks& rb, const std::vector<int32_t>* sp = nullptr, bool values = true) {
+    // columns = false: the column array is only allocated as well (pad zeroed); a kernel fills it
+    void upload(const Csr& M, const RowBlocks& rb, const std::vector<int32_t>* sp = nullptr, bool values = true, bool columns = true) {
         ptr.upload(M.ptr);
         // The SpMV issues its loads unconditionally on clamped indices; for an empty tile at the
         // very end of the matrix the clamp lands one past the last nonzero.  Pad with harmless
         // entries (column 0, value 0) so that such a read stays in bounds and gathers x[0].
-        col.upload_padded(M.col, 64);
+        if (columns) {
+            col.upload_padded(M.col, 64);
+        } else {
+            col.alloc(M.col.size() + 64);
+            HIP_CHECK(hipMemsetAsync(col.d + M.col.size(), 0, 64 * sizeof(int32_t), tl_copy_stream));
+        }
         if (values) {
             val.upload_padded(M.val, 64);
         } else {
@@ -490,10 +499,27 @@ struct BandBufs {
 // ~1 ms either way.  Buffers and stream come from the process-wide caches and go back before it returns.
 struct RuizDevice : RuizOffload {
     int device = 0;
+    // What the passes held on the device stays there for the handle's setup (HipBackend::init derives the equilibrated A,
+    // G1 and G2 from it -- k_derive_a / k_derive_g -- instead of uploading them) and goes back to the block cache when the
+    // setup is over (drop()).
+    DevArena keep;
+    bool kept = false;
+    DevBuf<int32_t> Pp, Pc, Ap, Ac, dat, dpos, drow, dg;
+    DevBuf<double> Pv, Av, dD, dE, dd, de;
+    int64_t k_n = 0, k_m = 0, k_nnzA = 0, k_nr = 0;
+    int k_rep = 1;
+    std::mutex mu;
+    void drop() {
+        kept = false;
+        for (DevBuf<int32_t>* b : {&Pp, &Pc, &Ap, &Ac, &dat, &dpos, &drow, &dg}) b->release();
+        for (DevBuf<double>* b : {&Pv, &Av, &dD, &dE, &dd, &de}) b->release();
+        keep.release_all();
+    }
     bool passes(const score_problem& p, int iters, int rep, int64_t rep_n, const std::vector<int32_t>& atp,
                 const std::vector<int32_t>& atpos, const std::vector<int32_t>& arow, const std::vector<int32_t>& gstart,
                 double* D, double* E) override {
         if (std::getenv("SCORE_NO_DEVICE_RUIZ")) return false;
+        std::lock_guard<std::mutex> one_at_a_time(mu);  // (the kept buffers are members)
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return false;  // (score_create reports it)
         DeviceGuard guard(device);
@@ -503,8 +529,9 @@ struct RuizDevice : RuizOffload {
         const int64_t n_act = rep > 1 ? n - (int64_t)(rep - 1) * rep_n : n;
         hipStream_t st = stream_pool().take(device);
         bool ok = true;
+        drop();
         {
-            DevArena arena;
+            DevArena& arena = keep;
             arena.dev = device;
             StageArena stage;  // (the raw matrices go up through pinned staging; released after the synchronisation below)
             stage.dev = device;
@@ -517,8 +544,6 @@ struct RuizDevice : RuizOffload {
                 ~Scope() { tl_arena = a_; tl_copy_stream = s_; tl_stage = g_; }
             } scope(&arena, st, &stage);
             try {
-                DevBuf<int32_t> Pp, Pc, Ap, Ac, dat, dpos, drow, dg;
-                DevBuf<double> Pv, Av, dD, dE, dd, de;
                 Pp.upload_from(p.P_rowptr, (size_t)n + 1);
                 if (rep > 1) {
                     // only the columns of replica 0 and of the tail are swept (P is symmetric: their rows): two contiguous
@@ -574,6 +599,8 @@ struct RuizDevice : RuizOffload {
             }
         }
         stream_pool().give(device, st);
+        if (ok) { kept = true; k_n = n; k_m = m; k_nnzA = nnzA; k_rep = rep; k_nr = rep > 1 ? rep_n : 0; }
+        else drop();
         return ok;
     }
 };
@@ -648,6 +675,7 @@ struct HipBackend {
     PolishData Q;
     std::future<void> polish_build;  // build_polish (or only its structure check) runs beside the uploads of init()
     bool polish_on_device = false;   // the Newton matrix's pattern and lists come from score_polish_device.hpp
+    bool derive_ag = false;          // the equilibrated A, G1, G2 were derived on the device (k_derive_a / k_derive_g)
     int64_t hm_nnz = 0;              // entries of the Newton matrix
     CsrBufs Hm;
     DevBuf<double> q_Pon, q_ccoef, q_Bbuf, q_fpart, q_X0, q_X1, q_g, q_delta, q_fac, q_dinv, q_work, q_dummy, q_gd, q_pw;
@@ -815,8 +843,22 @@ struct HipBackend {
             ~JoinBand() { if (f.valid()) f.wait(); }
         } join_band{band_layout_job};
         K.upload(h.K, h.rbK, nullptr, false);  // (values: K0 + rho K1, on the device -- derive_rho_data)
-        G1.upload(h.G1, h.rbG1);
-        G2.upload(h.G2, h.rbG2, &h.g2_split);
+        // A single problem whose equilibration ran on the device: the equilibrated A, G1 = A' and G2 = [P | A'] are derived
+        // there from the raw matrices and scales those passes left behind (k_derive_a / k_derive_g; 26 MB of uploads less
+        // for the headline problem) -- a replicated problem only when its replicas' P values are bit-equal to replica 0's.
+        derive_ag = h.count == 1 && h.m_tot > 0 && ruiz_dev.kept && ruiz_dev.k_n == h.n_tot && ruiz_dev.k_m == h.m_tot &&
+                    ruiz_dev.k_nnzA == (int64_t)h.A.col.size() && ruiz_dev.k_rep == h.rep && (h.rep == 1 || h.rep_exact) &&
+                    std::getenv("SCORE_NO_DEVICE_AG") == nullptr;
+        struct DropKept {  // (the kept buffers go back when the setup is over, whatever happens -- once nothing reads them any more)
+            RuizDevice& r;
+            hipStream_t st;
+            ~DropKept() {
+                if (r.kept) (void)hipStreamSynchronize(st);
+                r.drop();
+            }
+        } drop_kept{ruiz_dev, stream};
+        G1.upload(h.G1, h.rbG1, nullptr, !derive_ag, !derive_ag);
+        G2.upload(h.G2, h.rbG2, &h.g2_split, !derive_ag, !derive_ag);
         pt.mark("  uploads: K, G1, G2");
         // replicated problems (HostSystem::rep): K and G1 = A' hold replica 0's rows; K's operands repeat with the
         // block's replica stride, G1's are the consecutive tail rows of a cone
@@ -835,7 +877,25 @@ struct HipBackend {
         }
         A_ptr.upload(h.A.ptr);
         // padded like the SpMV matrices: the cone kernel clamps its unconditional loads
-        A_col.upload_padded(h.A.col, 64); A_val.upload_padded(h.A.val, 64);
+        if (derive_ag) {
+            const size_t nz = h.A.col.size();
+            A_col.alloc(nz + 64); A_val.alloc(nz + 64);
+            HIP_CHECK(hipMemsetAsync(A_col.d + nz, 0, 64 * sizeof(int32_t), stream));
+            HIP_CHECK(hipMemsetAsync(A_val.d + nz, 0, 64 * sizeof(double), stream));
+            DeriveArgs da{};
+            da.n = h.n_tot; da.m = h.m_tot; da.nnzA = (int64_t)nz; da.rep = h.rep; da.nr = h.rep > 1 ? h.rep_n[0] : 0;
+            da.P_ptr = ruiz_dev.Pp.d; da.P_col = ruiz_dev.Pc.d; da.P_val = ruiz_dev.Pv.d;
+            da.A_ptr = ruiz_dev.Ap.d; da.A_col = ruiz_dev.Ac.d; da.A_val = ruiz_dev.Av.d;
+            da.atp = ruiz_dev.dat.d; da.atpos = ruiz_dev.dpos.d; da.arow = ruiz_dev.drow.d; da.D = ruiz_dev.dD.d; da.E = ruiz_dev.dE.d;
+            da.oA_col = A_col.d; da.oA_val = A_val.d;
+            da.g1_ptr = G1.ptr.d; da.g1_col = G1.col.d; da.g1_val = G1.val.d;
+            da.g2_ptr = G2.ptr.d; da.g2_split = G2.split.d; da.g2_col = G2.col.d; da.g2_val = G2.val.d;
+            if (nz) hipLaunchKernelGGL(k_derive_a, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, stream, da);
+            hipLaunchKernelGGL(k_derive_g, dim3((unsigned)((h.n_tot + 3) / 4)), dim3(256), 0, stream, da);
+            HIP_CHECK(hipGetLastError());
+        } else {
+            A_col.upload_padded(h.A.col, 64); A_val.upload_padded(h.A.val, 64);
+        }
         q.upload(h.q); b.upload(h.b);
         std::vector<double> iD(h.D.size()), iE(h.E.size());
         parallel_ranges((int64_t)iD.size(), 32768, [&](int, int64_t i0, int64_t i1) { for (int64_t i = i0; i < i1; ++i) iD[(size_t)i] = 1.0 / h.D[(size_t)i]; });
@@ -1838,6 +1898,39 @@ struct HipBackend {
                 out[0] = 1.0;
             }
             return 1;
+        }
+        else if (nm == "ag_device_check") {
+            // the equilibrated A, G1, G2 on the device against the host arrays: [derived on the device (0/1), mismatching
+            // columns of A, max |A value difference|, the same for G1, for G2]
+            if (out && len >= 7) {
+                auto down_i = [&](const int32_t* d, size_t cnt) {
+                    std::vector<int32_t> v(cnt);
+                    if (cnt) HIP_CHECK(hipMemcpyAsync(v.data(), d, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    return v;
+                };
+                auto down_d = [&](const double* d, size_t cnt) {
+                    std::vector<double> v(cnt);
+                    if (cnt) HIP_CHECK(hipMemcpyAsync(v.data(), d, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    return v;
+                };
+                auto mism = [](const std::vector<int32_t>& x, const std::vector<int32_t>& y) {
+                    double c = 0;
+                    for (size_t i = 0; i < y.size(); ++i) c += x[i] != y[i];
+                    return c;
+                };
+                auto maxd = [](const std::vector<double>& x, const std::vector<double>& y) {
+                    double c = 0;
+                    for (size_t i = 0; i < y.size(); ++i) c = std::max(c, std::fabs(x[i] - y[i]));
+                    return c;
+                };
+                out[0] = derive_ag ? 1.0 : 0.0;
+                out[1] = mism(down_i(A_col.d, h.A.col.size()), h.A.col); out[2] = maxd(down_d(A_val.d, h.A.val.size()), h.A.val);
+                out[3] = mism(down_i(G1.col.d, h.G1.col.size()), h.G1.col); out[4] = maxd(down_d(G1.val.d, h.G1.val.size()), h.G1.val);
+                out[5] = mism(down_i(G2.col.d, h.G2.col.size()), h.G2.col); out[6] = maxd(down_d(G2.val.d, h.G2.val.size()), h.G2.val);
+            }
+            return 7;
         }
         else if (nm == "polish_build_check") {
             // the Newton matrix built on the device against the host loop's (score_polish_host.hpp): [built on the device (0/1),

@@ -846,6 +846,7 @@ struct HostSystem {
     // diag_kpos stay empty): per chain node the column of its chain predecessor (-1: first node, -2: a node whose blocks
     // are its owner's -- replicated chains), per Jacobi column the row of K that holds its diagonal
     std::vector<int32_t> node_prev_owned, diag_row0;
+    bool rep_exact = false;  // single replicated problem whose replicas' P values are bit-equal to replica 0's (check_replication)
     std::vector<ChainDesc> chains;
     std::vector<ChainLevelDesc> levels;
     std::vector<double> fac;
@@ -1107,15 +1108,18 @@ inline void ruiz_scale(const score_problem& p, int iters, ProblemScaled& out, in
 // Pattern and values, to a relative 1e-12 (assemblers that sum a row's terms in a different order per replica
 // differ in the last bits; the solver then uses replica 0's values for all of them -- a perturbation far below
 // the inexactness of its PCG solves, and the residual tests keep using the problem as given).
-inline bool check_replication(const score_problem& p) {
+// exact (optional): the replicas' values of P are BIT-equal to replica 0's (a backend may then derive the replicas' copies of
+// the scaled matrices from replica 0's and get what the host computes from the rows as given).
+inline bool check_replication(const score_problem& p, bool* exact = nullptr) {
     const int d = p.rep_d;
     const int64_t nr = p.rep_n, n = p.n;
     if (d < 2 || d > 3 || nr < 1 || (int64_t)d * nr > n) return false;
     if (p.z != 0) return false;
     const int64_t t0 = (int64_t)d * nr;
     auto close = [](double a, double b) { return std::fabs(a - b) <= 1e-12 * std::max(std::fabs(a), std::fabs(b)); };
-    std::atomic<bool> ok{true};
+    std::atomic<bool> ok{true}, same{true};
     parallel_ranges(nr, 8192, [&](int, int64_t i0, int64_t i1) {
+        bool all_same = true;
         for (int64_t i = i0; i < i1 && ok.load(std::memory_order_relaxed); ++i) {
             const int a0 = p.P_rowptr[i], a1 = p.P_rowptr[i + 1];
             for (int k = a0; k < a1; ++k)
@@ -1124,12 +1128,16 @@ inline bool check_replication(const score_problem& p) {
                 const int64_t ir = i + rpl * nr;
                 const int b0 = p.P_rowptr[ir];
                 if (p.P_rowptr[ir + 1] - b0 != a1 - a0) { ok = false; return; }
-                for (int k = 0; k < a1 - a0; ++k)
+                for (int k = 0; k < a1 - a0; ++k) {
                     if (p.P_col[b0 + k] != p.P_col[a0 + k] + rpl * nr || !close(p.P_val[b0 + k], p.P_val[a0 + k])) { ok = false; return; }
+                    all_same = all_same && p.P_val[b0 + k] == p.P_val[a0 + k];
+                }
             }
         }
+        if (!all_same) same = false;
     });
     if (!ok) return false;
+    if (exact) *exact = same.load();
     for (int64_t i = t0; i < n; ++i)
         for (int k = p.P_rowptr[i]; k < p.P_rowptr[i + 1]; ++k)
             if (p.P_col[k] < t0) return false;
@@ -1485,15 +1493,18 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     H.m_tot = H.roff[count];
     {   // row replication: every problem of the batch must carry the same, verified, hint
         int rep = (allow_rep && std::getenv("SCORE_NO_REPLICATION") == nullptr) ? probs[0].rep_d : 0;
-        if (rep > 1 && count > 1) {  // (a batch: one problem per part, the sweeps inside run serially)
+        H.rep_exact = false;
+        if (rep > 1 && count == 1) {
+            bool ex = false;
+            if (probs[0].rep_d != rep || !check_replication(probs[0], &ex)) rep = 0;
+            H.rep_exact = rep > 1 && ex;
+        } else if (rep > 1 && count > 1) {  // (a batch: one problem per part, the sweeps inside run serially)
             std::atomic<bool> all{true};
             parallel_ranges(count, 1, [&](int, int64_t p0, int64_t p1) {
                 for (int64_t p = p0; p < p1 && all.load(std::memory_order_relaxed); ++p)
                     if (probs[p].rep_d != rep || !check_replication(probs[p])) all = false;
             });
             if (!all) rep = 0;
-        } else if (rep > 1 && (probs[0].rep_d != rep || !check_replication(probs[0]))) {
-            rep = 0;
         }
         H.rep = rep > 1 ? rep : 1;
         H.rep_n.assign((size_t)count, 0);

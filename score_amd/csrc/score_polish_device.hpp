@@ -293,6 +293,58 @@ __global__ __launch_bounds__(256) void k_cone_tables(ConeTabArgs a) {
         }
 }
 
+// The equilibrated A, G1 = A' (stored rows) and G2 = [P | A'] (all rows) DERIVED on the device from what the device
+// equilibration holds there anyway -- the raw P (replica 0's rows and the tail's when the problem is replicated), the raw A,
+// the A' position map, the final scales D and E -- instead of filled on the host and uploaded (26 MB for the headline
+// problem).  Same expressions in the same order as the host ((v * d_i) * d_j, (v * e_r) * d_j): bit-equal to the host arrays
+// (score_debug_get "ag_device_check").  A replicated problem's replica rows take replica 0's raw values: only when
+// check_replication found them bit-equal (HostSystem::rep_exact).
+struct DeriveArgs {
+    int64_t n, m, nnzA;
+    int32_t rep;              // 1: plain
+    int64_t nr;               // unknowns per replica (rep > 1)
+    const int32_t* P_ptr; const int32_t* P_col; const double* P_val;   // raw (rows of replica 0 and of the tail valid)
+    const int32_t* A_ptr; const int32_t* A_col; const double* A_val;   // raw
+    const int32_t* atp; const int32_t* atpos; const int32_t* arow;
+    const double* D; const double* E;
+    int32_t* oA_col; double* oA_val;                                    // equilibrated A (pattern copied)
+    const int32_t* g1_ptr; int32_t* g1_col; double* g1_val;
+    const int32_t* g2_ptr; const int32_t* g2_split; int32_t* g2_col; double* g2_val;
+};
+__global__ __launch_bounds__(256) void k_derive_a(DeriveArgs a) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= a.nnzA) return;
+    const int32_t c = a.A_col[k];
+    a.oA_col[k] = c;
+    a.oA_val[k] = (a.A_val[k] * a.E[a.arow[k]]) * a.D[c];
+}
+// a wavefront per row i of G2 (= column i of A): P part, then the entries of A' (also into G1 when the row is stored)
+__global__ __launch_bounds__(256) void k_derive_g(DeriveArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.n) return;
+    const bool in_rep = a.rep > 1 && i < (int64_t)a.rep * a.nr;
+    const int64_t i0 = in_rep ? i % a.nr : i;
+    const int32_t shift = (int32_t)(i - i0);
+    const bool stored = a.rep <= 1 || i < a.nr || i >= (int64_t)a.rep * a.nr;
+    const double di = a.D[i];
+    const int k0 = a.P_ptr[i0], np = a.P_ptr[i0 + 1] - k0, o2 = a.g2_ptr[i];
+    for (int l = lane; l < np; l += 64) {
+        const int32_t c = a.P_col[k0 + l] + shift;
+        a.g2_col[o2 + l] = c;
+        a.g2_val[o2 + l] = (a.P_val[k0 + l] * di) * a.D[c];
+    }
+    const int t0 = a.atp[i], nt = a.atp[i + 1] - t0, s2 = a.g2_split[i], s1 = stored ? a.g1_ptr[i] : 0;
+    for (int l = lane; l < nt; l += 64) {
+        const int32_t q = a.atpos[t0 + l];
+        const int32_t c = (int32_t)a.n + a.arow[q];
+        const double v = a.oA_val[q];
+        a.g2_col[s2 + l] = c;
+        a.g2_val[s2 + l] = v;
+        if (stored) { a.g1_col[s1 + l] = c; a.g1_val[s1 + l] = v; }
+    }
+}
+
 // upper bound of the records (exact but for the rows of P without a diagonal entry): P entries, one record per head
 // row, one per row for a missing diagonal, (entries of a cone's tail rows)^2 contributions per cone
 inline int64_t polish_record_bound(const HostSystem& H, int T, int64_t* contributions = nullptr) {

@@ -162,6 +162,46 @@ def test_band_view_and_split_long_rows_against_the_csr_stream(fixtures, hip_lib,
             sv.close()
 
 
+def test_device_derived_a_g1_g2_equal_the_host_arrays(fixtures, hip_lib, monkeypatch):
+    """A single problem whose equilibration ran on the device gets its equilibrated A, G1 = A' and G2 = [P | A'] DERIVED there
+    (k_derive_a / k_derive_g: from the raw matrices, the A' map and the scales the passes left on the device) instead of filled
+    on the host and uploaded: bit-equal to the host arrays -- 2-D and 3-D, replicated (native assembler: replicas bit-equal) and
+    not (SCORE_NO_REPLICATION), BASELINE configs[3]; a batch keeps the uploads; the default solve is the same to the last bit
+    with the derivation switched off."""
+    _hip_only(hip_lib)
+    from score_amd.manhattan import make_config
+    from score_amd.native import assemble_native
+
+    cases = [assemble_native(graph_by_name(nm, fixtures), "SOCP", lib_path=hip_lib).qp for nm in ("synth_a", "synth_b", "graph3d", "prior2d")]
+    cases.append(assemble_native(make_config(3), "SOCP", lib_path=hip_lib).qp)
+    for k, qp in enumerate(cases):
+        for norep in (False, True):
+            monkeypatch.delenv("SCORE_NO_DEVICE_AG", raising=False)
+            if norep:
+                monkeypatch.setenv("SCORE_NO_REPLICATION", "1")
+            dev = ConicSolver([qp], {}, lib_path=hip_lib)
+            c = dev.debug_get("ag_device_check")
+            assert c[0] == 1.0, "A, G1, G2 were not derived on the device"
+            assert not c[1:].any(), c
+            sd = dev.solve()[0]
+            dev.close()
+            monkeypatch.setenv("SCORE_NO_DEVICE_AG", "1")
+            up = ConicSolver([qp], {}, lib_path=hip_lib)
+            cu = up.debug_get("ag_device_check")
+            assert cu[0] == 0.0 and not cu[1:].any()
+            su = up.solve()[0]
+            up.close()
+            monkeypatch.delenv("SCORE_NO_DEVICE_AG", raising=False)
+            monkeypatch.delenv("SCORE_NO_REPLICATION", raising=False)
+            assert sd.solved and np.array_equal(sd.x, su.x) and np.array_equal(sd.y, su.y)
+            if k < 4 and norep:
+                break
+    batch = ConicSolver(cases[:2], {}, lib_path=hip_lib)
+    cb = batch.debug_get("ag_device_check")
+    assert cb[0] == 0.0 and not cb[1:].any()
+    batch.close()
+
+
 def test_device_built_newton_matrix_equals_the_host_build(fixtures, hip_lib, monkeypatch):
     """score_create builds the Newton matrix's pattern, P on it, the contribution lists, the chain / Jacobi positions and the
     long entries ON THE DEVICE (score_polish_device.hpp: records, stable radix sort, scan, scatter).  Entry by entry and
