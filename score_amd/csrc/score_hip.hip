@@ -897,10 +897,18 @@ struct HipBackend {
             A_col.upload_padded(h.A.col, 64); A_val.upload_padded(h.A.val, 64);
         }
         q.upload(h.q); b.upload(h.b);
-        std::vector<double> iD(h.D.size()), iE(h.E.size());
-        parallel_ranges((int64_t)iD.size(), 32768, [&](int, int64_t i0, int64_t i1) { for (int64_t i = i0; i < i1; ++i) iD[(size_t)i] = 1.0 / h.D[(size_t)i]; });
-        parallel_ranges((int64_t)iE.size(), 32768, [&](int, int64_t i0, int64_t i1) { for (int64_t i = i0; i < i1; ++i) iE[(size_t)i] = 1.0 / h.E[(size_t)i]; });
-        invD.upload(iD); invE.upload(iE);
+        if (derive_ag) {  // (D and E are on the device: their reciprocals too)
+            invD.alloc(h.D.size()); invE.alloc(h.E.size());
+            const int64_t nm = std::max<int64_t>((int64_t)h.D.size(), (int64_t)h.E.size());
+            hipLaunchKernelGGL(k_derive_inv, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, stream, (const double*)ruiz_dev.dD.d, (const double*)ruiz_dev.dE.d,
+                               invD.d, invE.d, (int64_t)h.D.size(), (int64_t)h.E.size());
+            HIP_CHECK(hipGetLastError());
+        } else {
+            std::vector<double> iD(h.D.size()), iE(h.E.size());
+            parallel_ranges((int64_t)iD.size(), 32768, [&](int, int64_t i0, int64_t i1) { for (int64_t i = i0; i < i1; ++i) iD[(size_t)i] = 1.0 / h.D[(size_t)i]; });
+            parallel_ranges((int64_t)iE.size(), 32768, [&](int, int64_t i0, int64_t i1) { for (int64_t i = i0; i < i1; ++i) iE[(size_t)i] = 1.0 / h.E[(size_t)i]; });
+            invD.upload(iD); invE.upload(iE);
+        }
         pt.mark("  uploads: A, q, b, 1/D, 1/E");
         cone_row.upload(h.cone_row); cone_dim.upload(h.cone_dim); cone_type.upload(h.cone_type);
         cone_block_first.upload(h.cone_block_first); cone_block_prob.upload(h.cone_block_prob);

@@ -318,6 +318,12 @@ __global__ __launch_bounds__(256) void k_derive_a(DeriveArgs a) {
     a.oA_col[k] = c;
     a.oA_val[k] = (a.A_val[k] * a.E[a.arow[k]]) * a.D[c];
 }
+// 1 / D and 1 / E (the solver's unscaling vectors) from the scales on the device
+__global__ __launch_bounds__(256) void k_derive_inv(const double* D, const double* E, double* iD, double* iE, int64_t n, int64_t m) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) iD[i] = 1.0 / D[i];
+    if (i < m) iE[i] = 1.0 / E[i];
+}
 // a wavefront per row i of G2 (= column i of A): P part, then the entries of A' (also into G1 when the row is stored)
 __global__ __launch_bounds__(256) void k_derive_g(DeriveArgs a) {
     const int lane = threadIdx.x & 63;
