@@ -33,7 +33,9 @@ static PyObject* fetch(PyObject* obj, PyObject* name, PyTypeObject** seen, int* 
     PyTypeObject* tp = Py_TYPE(obj);
     if (*seen != tp) {
         PyObject* descr = _PyType_Lookup(tp, name); /* borrowed */
-        *plain = !(descr && Py_TYPE(descr)->tp_descr_set);
+        /* a class with its own __getattribute__ / __getattr__ slot decides for itself: only the generic protocol may be
+           short-cut through the instance dict */
+        *plain = tp->tp_getattro == PyObject_GenericGetAttr && !(descr && Py_TYPE(descr)->tp_descr_set);
         *seen = tp;
     }
     if (*plain) {
@@ -90,10 +92,17 @@ static PyObject* gather(PyObject* self, PyObject* args) {
         }
         if (k != 'd' && k != 'i' && k != 'p') { PyErr_SetString(PyExc_ValueError, "gather: unknown kind"); ok = 0; break; }
         if ((k == 'i' || k == 'p') && !PyDict_Check(mp)) { PyErr_SetString(PyExc_TypeError, "gather: 'i' / 'p' need a dict"); ok = 0; break; }
-        if (PyObject_GetBuffer(o, &buf[j], PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS) != 0) { ok = 0; break; }
+        if (PyObject_GetBuffer(o, &buf[j], PyBUF_WRITABLE | PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) != 0) { ok = 0; break; }
         have[j] = 1;
         const Py_ssize_t want = (k == 'd') ? n * 8 : (k == 'i' ? n * 4 : n * 8);
         if (buf[j].len != want) { PyErr_SetString(PyExc_ValueError, "gather: output buffer has the wrong size"); ok = 0; }
+        /* the element type as well as the byte length: a float32 or int64 array of the right byte size would be filled
+           with misread data (format: native float64 for 'd', native int32 for 'i' / 'p') */
+        const char* f = buf[j].format ? buf[j].format : "B";
+        if (*f == '@' || *f == '=' || *f == '<') ++f;
+        const int fmt_ok = (k == 'd') ? (buf[j].itemsize == 8 && f[0] == 'd' && !f[1])
+                                      : (buf[j].itemsize == 4 && (f[0] == 'i' || f[0] == 'l') && !f[1]);
+        if (ok && !fmt_ok) { PyErr_SetString(PyExc_TypeError, "gather: output buffer must be float64 ('d') or int32 ('i', 'p')"); ok = 0; }
     }
     for (Py_ssize_t i = 0; i < n && ok; ++i) {
         PyObject* obj = items[i];

@@ -2272,7 +2272,7 @@ struct HipBackend {
                 throw;
             }
         }
-        if (res[2] > long_max) throw std::runtime_error("Newton matrix: too many long entries");
+        if (res[2] > long_max) return false;  // (more long entries than the device list holds: the host loop has no such limit)
         hm_nnz = res[0];
         longs.resize((size_t)res[2]);
         std::sort(longs.begin(), longs.end());
@@ -2303,7 +2303,15 @@ struct HipBackend {
         if (polish_on_device && Q.T > 0) {
             q_head.upload(Q.head_col); q_ishead.upload(Q.is_head); q_aabs.upload(Q.a_abs); q_ck.upload(Q.ck);
             q_theta.upload(Q.theta); q_xstar.upload(Q.xstar);
-            on_device = build_polish_on_device(h);
+            try {
+                on_device = build_polish_on_device(h);
+            } catch (const std::exception& e) {
+                // the scratch of the device build (~60 bytes per record, sized by an upper bound) did not fit: the host loop
+                // needs none of it.  Anything else is a real failure.
+                if (std::strstr(e.what(), "hipMalloc") == nullptr) throw;
+                (void)hipGetLastError();
+                on_device = false;
+            }
             pt.mark("  polish: pattern + lists on the device");
             if (!on_device) {  // (cones not laid out row after row, more than 2^32 records: the host loop takes over)
                 polish_on_device = false;

@@ -173,7 +173,10 @@ struct HostTeam {
             const uint64_t g = gen.load(std::memory_order_acquire);
             const std::function<void(int)>* j = slot[g & 1].job.load(std::memory_order_relaxed);
             const int parts = slot[g & 1].parts.load(std::memory_order_relaxed);
-            if (gen.load(std::memory_order_acquire) != g) continue;  // (published again meanwhile: read it afresh)
+            // (a seqlock read: the slot loads above must not sink below the re-check -- an acquire LOAD alone does not order
+            //  the earlier relaxed loads before it; the fence does)
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (gen.load(std::memory_order_relaxed) != g) continue;  // (published again meanwhile: read it afresh)
             seen = g;
             if (part >= parts) continue;
             (*j)(part);
@@ -273,6 +276,11 @@ inline int region_width() {
     return width;
 }
 
+// what the surviving members of a TeamBarrier region throw when another member failed (never the root cause)
+struct TeamAborted : std::runtime_error {
+    TeamAborted() : std::runtime_error("parallel setup aborted: another part failed") {}
+};
+
 // fn(part, begin, end) for part = 0..T-1 over the boundaries `bound` (T + 1 entries), all parts concurrently
 template <class F>
 inline void run_parts(const std::vector<int64_t>& bound, F&& fn) {
@@ -307,7 +315,16 @@ inline void run_parts(const std::vector<int64_t>& bound, F&& fn) {
         body(0);
         for (auto& x : th) x.join();
     }
-    for (auto& e : err) if (e) std::rethrow_exception(e);
+    // the first part that failed for a reason of its own; the "aborted: another part failed" exceptions the surviving parts
+    // of a TeamBarrier region throw (TeamAborted) are secondary and only reported when nothing else is
+    std::exception_ptr secondary;
+    for (auto& e : err) {
+        if (!e) continue;
+        try { std::rethrow_exception(e); }
+        catch (const TeamAborted&) { if (!secondary) secondary = e; }
+        catch (...) { std::rethrow_exception(e); }
+    }
+    if (secondary) std::rethrow_exception(secondary);
 }
 
 template <class F>
@@ -349,7 +366,7 @@ struct TeamBarrier {
     void abort() { failed.store(true, std::memory_order_release); }
     void wait() {
         if (T <= 1) return;
-        if (failed.load(std::memory_order_acquire)) throw std::runtime_error("parallel setup aborted: another part failed");
+        if (failed.load(std::memory_order_acquire)) throw TeamAborted();
         const int g = gen.load(std::memory_order_acquire);
         if (count.fetch_add(1, std::memory_order_acq_rel) == T - 1) {
             count.store(0, std::memory_order_relaxed);
@@ -357,7 +374,7 @@ struct TeamBarrier {
         } else {
             int spins = 0;
             while (gen.load(std::memory_order_acquire) == g) {
-                if (failed.load(std::memory_order_acquire)) throw std::runtime_error("parallel setup aborted: another part failed");
+                if (failed.load(std::memory_order_acquire)) throw TeamAborted();
                 if (++spins > 4096) std::this_thread::yield();
             }
         }

@@ -22,7 +22,7 @@ from . import compat
 from .native import ArrayGraph, graph_arrays
 from .solve_score import solve_score_batch
 
-_HDR = 8  # status, iters, cg_iters, pobj, res_pri, res_dual, solve_ms, n_values
+_HDR = 10  # status, iters, cg_iters, pobj, res_pri, res_dual, solve_ms, n_values, n_distances, distance width
 
 
 def shard_assignment(costs: Sequence[float], world_size: int) -> List[List[int]]:
@@ -46,6 +46,16 @@ def _meta(data):
             [l.name for l in data.landmark_variables], len(data.range_measurements))
 
 
+def _range_keys(data) -> list:
+    """The keys of the distance variables, in measurement order (gurobi_utils.py:288: (first_key, second_key))."""
+    if isinstance(data, ArrayGraph):
+        return [tuple(k) for k in data.arrays["range_keys"]]
+    rm = data.range_measurements
+    if rm and hasattr(rm[0], "association"):
+        return [tuple(m.association) for m in rm]
+    return [(m.first_key, m.second_key) for m in rm]
+
+
 def problem_cost(data) -> float:
     _, poses, _, n_ranges = _meta(data)
     return float(len(poses) * 6 + 3 * n_ranges)
@@ -55,12 +65,21 @@ def _pack(res: compat.SolverResults, data) -> np.ndarray:
     _, names, lm_names, _ = _meta(data)
     vals = [res.poses[n].ravel() for n in names]
     vals += [np.asarray(res.landmarks[l]).ravel() for l in lm_names]
+    # the range variables, every one of them as the reference returns them (gurobi_utils.py:127-136: a 1-array per SOCP
+    # distance, a d-vector per QCQP direction), in measurement order
+    dists = res.variables.distances
+    nd, wd = 0, 0
+    if dists is not None and len(dists):
+        stack = dists.array if hasattr(dists, "array") else np.array([np.asarray(dists[k]).ravel() for k in _range_keys(data)])
+        stack = np.asarray(stack, dtype=np.float64).reshape(len(dists), -1)
+        nd, wd = stack.shape
+        vals.append(stack.ravel())
     v = np.concatenate(vals) if vals else np.zeros(0)
     info = res.info or {}
     hdr = np.array([
         float(info.get("status", 1 if res.solved else 0)), float(info.get("iters", 0)), float(info.get("cg_iters", 0)),
         float(info.get("pobj", np.nan)), float(info.get("res_pri", np.nan)), float(info.get("res_dual", np.nan)),
-        float(info.get("solve_ms", res.total_time * 1e3)), float(v.size),
+        float(info.get("solve_ms", res.total_time * 1e3)), float(v.size), float(nd), float(wd),
     ])
     return np.concatenate([hdr, v])
 
@@ -73,10 +92,13 @@ def _unpack(rec: np.ndarray, data) -> compat.SolverResults:
     poses = {n: v[i * k : (i + 1) * k].reshape(d + 1, d + 1).copy() for i, n in enumerate(names)}
     off = len(names) * k
     lms = {l: v[off + i * d : off + (i + 1) * d].copy() for i, l in enumerate(lm_names)}
+    off += len(lm_names) * d
+    nd, wd = int(rec[8]), int(rec[9])
+    dists = compat.ArrayDict(_range_keys(data), v[off : off + nd * wd].reshape(nd, wd).copy()) if nd else {}
     info = dict(status=int(rec[0]), iters=int(rec[1]), cg_iters=int(rec[2]), pobj=float(rec[3]),
                 res_pri=float(rec[4]), res_dual=float(rec[5]), solve_ms=float(rec[6]))
     return compat.SolverResults(
-        variables=compat.VariableValues(d, poses, lms, None), total_time=info["solve_ms"] * 1e-3,
+        variables=compat.VariableValues(d, poses, lms, dists), total_time=info["solve_ms"] * 1e-3,
         solved=info["status"] == 1, pose_chain_names=data.get_pose_chain_names(), solver_cost=info["pobj"], info=info,
     )
 
@@ -84,8 +106,9 @@ def _unpack(rec: np.ndarray, data) -> compat.SolverResults:
 def record_stride(datas: Sequence) -> int:
     worst = 0
     for data in datas:
-        d, names, lm_names, _ = _meta(data)
-        worst = max(worst, len(names) * (d + 1) ** 2 + len(lm_names) * d)
+        d, names, lm_names, n_ranges = _meta(data)
+        # (room for d values per range: the QCQP directions; the SOCP distances use one)
+        worst = max(worst, len(names) * (d + 1) ** 2 + len(lm_names) * d + n_ranges * d)
     return _HDR + worst
 
 
@@ -109,25 +132,36 @@ def broadcast_graphs(datas: Optional[Sequence], root: int = 0, device: Optional[
     if not (dist.is_available() and dist.is_initialized()):
         return [ArrayGraph(arrays_of(g)) for g in (datas or [])]
     rank = dist.get_rank()
-    header, flat = None, None
+    nccl = dist.get_backend() == "nccl"
+    if nccl and device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    header, flat, error = None, None, None
     if rank == root:
-        if datas is None:
-            raise ValueError("broadcast_graphs: the root rank must hold the graphs")
-        header, chunks = [], []
-        for g in datas:
-            a = arrays_of(g)
-            meta = {k: v for k, v in a.items() if k not in _NUMERIC}
-            meta["_shapes"] = {k: (tuple(np.shape(a[k])), np.asarray(a[k]).dtype.str) for k in _NUMERIC}
-            header.append(meta)
-            chunks += [np.asarray(a[k], dtype=np.float64).ravel() for k in _NUMERIC]
-        flat = np.concatenate(chunks) if chunks else np.zeros(0)
-    box = [header, int(flat.size) if flat is not None else 0]
-    dist.broadcast_object_list(box, src=root)
-    header, total = box
+        # Whatever goes wrong while the root reads its graphs (no graphs at all, duplicate or unknown variable names, a
+        # graph without poses: graph_arrays raises the reference's errors), the root must still reach the collective --
+        # the other ranks are waiting in it.  The error travels as a string and is raised on EVERY rank afterwards.
+        try:
+            if datas is None:
+                raise ValueError("broadcast_graphs: the root rank must hold the graphs")
+            header, chunks = [], []
+            for g in datas:
+                a = arrays_of(g)
+                meta = {k: v for k, v in a.items() if k not in _NUMERIC}
+                meta["_shapes"] = {k: (tuple(np.shape(a[k])), np.asarray(a[k]).dtype.str) for k in _NUMERIC}
+                header.append(meta)
+                chunks += [np.asarray(a[k], dtype=np.float64).ravel() for k in _NUMERIC]
+            flat = np.concatenate(chunks) if chunks else np.zeros(0)
+        except Exception as exc:  # noqa: BLE001 - re-raised on every rank after the collective
+            error = f"{type(exc).__name__}: {exc}"
+            header, flat = None, np.zeros(0)
+    box = [header, int(flat.size) if flat is not None else 0, error]
+    # (backend "nccl" moves the pickled payload through a GPU: this rank's, not whatever torch.cuda.current_device() is)
+    dist.broadcast_object_list(box, src=root, device=torch.device(f"cuda:{device}") if nccl else None)
+    header, total, error = box
+    if error is not None:
+        raise ValueError(f"broadcast_graphs: rank {root} could not read its graphs ({error})")
     t = torch.from_numpy(flat) if rank == root else torch.empty(total, dtype=torch.float64)
-    if dist.get_backend() == "nccl":
-        if device is None:
-            device = int(os.environ.get("LOCAL_RANK", "0"))
+    if nccl:
         t = t.to(f"cuda:{device}")
     if total:
         dist.broadcast(t, src=root)

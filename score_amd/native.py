@@ -125,6 +125,14 @@ def graph_arrays(data) -> Dict[str, np.ndarray]:
             _objread.gather(rm, ("association", "association", "dist", "stddev" if has_std else "precision"), "Opdd",
                             (range_keys, ab, dist, w), (None, var_idx, None, None))
         except KeyError as exc:
+            # the reference adds every distance variable (duplicate keys raise there, gurobi_utils.py:62-67, :288) before it
+            # resolves an endpoint name (:103-109): a duplicate key anywhere in the list is reported first, as on the
+            # fromiter path below
+            seen = set()
+            for k in (tuple(a) for a in map(attrgetter("association"), rm)):
+                if k in seen:
+                    raise ValueError(f"Variable name {k} already exists in distance_vars") from None
+                seen.add(k)
             raise ValueError(f"Variable name {exc.args[0]} not found") from None
         ra, rb = np.ascontiguousarray(ab[:, 0]), np.ascontiguousarray(ab[:, 1])
         prec = 1.0 / (w * w) if has_std else w

@@ -30,6 +30,12 @@ def _worker(rank, world, port, lib, outdir):
     res = solve_score_sharded(graphs, "SOCP", lib_path=lib, device=0)
     flat = np.concatenate([np.concatenate([r.poses[n].ravel() for n in sorted(r.poses)]) for r in res])
     np.save(os.path.join(outdir, f"rank{rank}.npy"), flat)
+    # every distance variable, keyed as the reference keys them (gurobi_utils.py:127-136)
+    dflat = np.concatenate([np.concatenate([np.asarray(r.variables.distances[k]).ravel() for k in sorted(r.variables.distances)]) for r in res])
+    np.save(os.path.join(outdir, f"dist{rank}.npy"), dflat)
+    resq = solve_score_sharded(graphs[:2], "QCQP", lib_path=lib, device=0)  # the QCQP directions: d values per range
+    np.save(os.path.join(outdir, f"distq{rank}.npy"),
+            np.concatenate([np.concatenate([np.asarray(r.variables.distances[k]).ravel() for k in sorted(r.variables.distances)]) for r in resq]))
     np.save(os.path.join(outdir, f"solved{rank}.npy"), np.array([r.solved for r in res]))
     dist.barrier()
     dist.destroy_process_group()
@@ -84,6 +90,53 @@ def test_two_rank_gloo_matches_single_process(twin_lib, tmp_path):
     single = [solve_score(g, "SOCP", lib_path=twin_lib) for g in graphs]
     flat = np.concatenate([np.concatenate([r.poses[n].ravel() for n in sorted(r.poses)]) for r in single])
     np.testing.assert_allclose(r0, flat, atol=1e-6)
+    # the sharded results carry every field solve_score returns: the distance variables too, under the same keys
+    d0, d1 = np.load(tmp_path / "dist0.npy"), np.load(tmp_path / "dist1.npy")
+    np.testing.assert_array_equal(d0, d1)
+    for r, g in zip(single, graphs):
+        assert sorted(r.variables.distances) == sorted((m.first_key, m.second_key) for m in g.range_measurements)
+    dflat = np.concatenate([np.concatenate([np.asarray(r.variables.distances[k]).ravel() for k in sorted(r.variables.distances)]) for r in single])
+    assert dflat.size == sum(len(g.range_measurements) for g in graphs)
+    np.testing.assert_allclose(d0, dflat, atol=1e-6)
+    singleq = [solve_score(g, "QCQP", lib_path=twin_lib) for g in graphs[:2]]
+    qflat = np.concatenate([np.concatenate([np.asarray(r.variables.distances[k]).ravel() for k in sorted(r.variables.distances)]) for r in singleq])
+    assert qflat.size == 2 * sum(len(g.range_measurements) for g in graphs[:2])
+    np.testing.assert_allclose(np.load(tmp_path / "distq0.npy"), qflat, atol=1e-6)
+    np.testing.assert_array_equal(np.load(tmp_path / "distq0.npy"), np.load(tmp_path / "distq1.npy"))
+
+
+def _worker_bad_root(rank, world, port, lib, outdir):
+    """The root's graphs cannot be read (a duplicate pose name): every rank must raise, none may hang in the collective."""
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from score_amd.distributed import solve_score_sharded
+    from score_amd.manhattan import make_manhattan
+
+    graphs = None
+    if rank == 0:
+        graphs = [make_manhattan(n_robots=2, n_poses=20, n_beacons=2, seed=5)]
+        graphs[0].pose_variables[1][3].name = graphs[0].pose_variables[1][2].name
+    try:
+        solve_score_sharded(graphs, "SOCP", lib_path=lib, device=0, root=0)
+        msg = "no error"
+    except ValueError as exc:
+        msg = f"ValueError: {exc}"
+    with open(os.path.join(outdir, f"bad{rank}.txt"), "w") as f:
+        f.write(msg)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_root_that_cannot_read_its_graphs_fails_on_every_rank(twin_lib, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker_bad_root, args=(2, port, twin_lib, str(tmp_path)), nprocs=2, join=True)
+    for rank in (0, 1):
+        msg = (tmp_path / f"bad{rank}.txt").read_text()
+        assert msg.startswith("ValueError: broadcast_graphs: rank 0 could not read its graphs"), msg
+        assert "already exists" in msg, msg
 
 
 def test_root_rank_broadcasts_the_graphs(twin_lib, tmp_path):
@@ -129,6 +182,9 @@ res2 = solve_score_sharded(graphs, "SOCP", device=0, root=0)  # the graphs broad
 for a, b in zip(res2, ref):
     for n in b.poses:
         worst = max(worst, float(np.abs(a.poses[n] - b.poses[n]).max()))
+    assert list(a.variables.distances) == list(b.variables.distances)
+    for k in b.variables.distances:
+        worst = max(worst, float(np.abs(np.asarray(a.variables.distances[k]) - np.asarray(b.variables.distances[k])).max()))
 assert worst <= 1e-9, worst
 dist.barrier()
 dist.destroy_process_group()

@@ -283,6 +283,16 @@ def test_one_pass_object_reader_equals_the_attribute_passes(fixtures, monkeypatc
     fg.range_measurements.append(compat.FGRangeMeasurement(("A1", "nope"), 1.0, 1.0))
     with pytest.raises(ValueError, match="Variable name nope not found"):
         nat.graph_arrays(fg)
+    # a duplicate key anywhere in the list is reported before an unknown endpoint, with the helper and without it
+    # (gurobi_utils.py:62-67 raises while the distance variables are added, :103-109 only when the costs are built)
+    fg.range_measurements.append(fg.range_measurements[0])
+    with pytest.raises(ValueError, match="already exists in distance_vars"):
+        nat.graph_arrays(fg)
+    with monkeypatch.context() as mp:
+        mp.setattr(nat, "_objread", None)
+        with pytest.raises(ValueError, match="already exists in distance_vars"):
+            nat.graph_arrays(fg)
+    fg.range_measurements.pop()
     fg.range_measurements.pop()
     fg.odom_measurements[0][0].to_pose = "nowhere"
     with pytest.raises(KeyError, match="nowhere"):
