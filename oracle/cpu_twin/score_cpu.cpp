@@ -72,7 +72,8 @@ struct CpuBackend {
     void set_newton_limit(int) {}
     void cg_reduction(std::vector<double>& out) { out = cg_red; }
 
-    void init(const HostSystem& h, const score_settings& s_) {
+    bool device_setup_ok(const HostSystem&, const score_problem*, const score_settings&) const { return false; }  // (the twin IS the host setup)
+    void init(const HostSystem& h, const score_settings& s_, const score_problem* = nullptr) {
         H = &h;
         st = s_;
         xtu.assign(h.n_tot + h.m_tot, 0.0);

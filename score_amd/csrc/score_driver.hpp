@@ -55,8 +55,9 @@ struct Solver {
         if (st.max_cg_iters < st.cg_iters) st.max_cg_iters = st.cg_iters;
         if (!(st.cg_target > 0.0 && st.cg_target < 1.0)) st.cg_target = 0.5;
         cg_now = st.cg_iters;
-        build_system(probs, count, st, H, Backend::kFactorOnHost, Backend::allow_rep(), be.ruiz_offload(st));
-        be.init(H, st);
+        build_system(probs, count, st, H, Backend::kFactorOnHost, Backend::allow_rep(), be.ruiz_offload(st),
+                     [&](const HostSystem& hs) { return be.device_setup_ok(hs, probs, st); });
+        be.init(H, st, probs);
         infos.assign(count, score_info{});
         done.assign(count, 0);
         dual_scale.assign(count, 0.0);

@@ -35,6 +35,7 @@
 #include "score_kernels.hpp"
 #include "score_polish.hpp"
 #include "score_polish_device.hpp"
+#include "score_setup_device.hpp"
 #include "score_prec_wave.hpp"
 
 namespace {
@@ -771,7 +772,341 @@ struct HipBackend {
         pt.mark("destroy: stream");
     }
 
-    void init(const HostSystem& h, const score_settings& s_) {
+    // ---- the handle's matrices built on the device (score_setup_device.hpp; HostSystem::device_setup) ----
+    DevBuf<double> Dd, Ed;                      // the equilibration's scales (the host keeps none)
+    DevBuf<int32_t> tab_xoff, tab_roff, tab_nr;  // ProbTab
+    DevArena setup_tmp;                          // scratch of the setup: back to the block cache when init() is over
+    int64_t g1_nnz = 0, nnzP_full = 0;
+    ProbTab prob_tab() const {
+        ProbTab t{};
+        t.xoff = tab_xoff.d; t.roff = tab_roff.d; t.nr = tab_nr.d; t.count = H->count; t.rep = H->rep;
+        return t;
+    }
+    // asked by build_system once sizes and the replication structure are known
+    bool device_setup_ok(const HostSystem& h, const score_problem* probs, const score_settings& s_) const {
+        if (std::getenv("SCORE_HOST_SETUP") || std::getenv("SCORE_HOST_POLISH_BUILD") || std::getenv("SCORE_FUSED_CONE") ||
+            std::getenv("SCORE_NO_DEVICE_RUIZ") || std::getenv("SCORE_NO_DEVICE_AG")) return false;  // (switches that ask for a host-side piece)
+        if (h.m_tot <= 0 || s_.chain_split > 0 || band_h(h)) return false;   // (linear mode keeps K0 on the host)
+        if (h.rep > 1)
+            for (char ex : h.rep_exact_all)
+                if (!ex) return false;  // (replicas that differ in their last bits: the host uses every replica's own values)
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || s_.device < 0 || s_.device >= ndev) return false;  // (init reports it)
+        // record bounds of the K and Newton-matrix builds: 32-bit positions
+        int64_t rec = h.n_tot, sq = 0;
+        for (int p = 0; p < h.count; ++p) {
+            const score_problem& pr = probs[p];
+            rec += pr.P_rowptr[pr.n];
+            for (int r = 0; r < pr.m; ++r) { const int64_t L = pr.A_rowptr[r + 1] - pr.A_rowptr[r]; sq += L * L; }
+        }
+        // (the Newton matrix's contributions: (entries of a cone's tail rows)^2 per cone, at most (sum of the rows' lengths)^2)
+        int64_t con = 0;
+        for (int p = 0; p < h.count; ++p) {
+            const score_problem& pr = probs[p];
+            int row = pr.z;
+            for (int c = 0; c < pr.n_soc; ++c) {
+                const int64_t L = pr.A_rowptr[row + pr.soc_dims[c]] - pr.A_rowptr[row];
+                con += L * L;
+                row += pr.soc_dims[c];
+            }
+        }
+        return rec + sq + 64 < ((int64_t)1 << 31) && rec + con + 64 < ((int64_t)1 << 31);
+    }
+    template <class T>
+    void copy_up(T* dst, const T* src, size_t count) {  // staged when small, pageable otherwise (returns once the source is consumed)
+        if (!count) return;
+        if (tl_stage && tl_stage->upload(dst, src, count * sizeof(T), stream)) return;
+        HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, stream));
+    }
+    // records (key, idx, v0, v1; rec_max of them, the unused tail padded with row n_rows) -> CSR pattern + summed values:
+    // stable sort, flags, scan, merge (an entry adds its records in order), row counts -> row pointers.  Everything lands in
+    // arrays of the CURRENT arena (the caller's scratch); result[0] = entries.
+    struct MergeOut {
+        DevBuf<int32_t> ptr, col;
+        DevBuf<double> o0, o1;
+        DevBuf<long long> result;
+    };
+    void merge_records(int64_t n_rows, int64_t rec_max, DevBuf<unsigned long long>& key0, DevBuf<uint32_t>& idx0, const double* v0,
+                       const double* v1, int32_t qcol, double* qout, MergeOut& out) {
+        DevBuf<unsigned long long> key1, flag, flag_s;
+        DevBuf<uint32_t> idx1;
+        DevBuf<int32_t> row_cnt;
+        DevBuf<int4> long_run;
+        key1.alloc((size_t)rec_max); idx1.alloc((size_t)rec_max); flag.alloc((size_t)rec_max); flag_s.alloc((size_t)rec_max);
+        row_cnt.alloc((size_t)n_rows + 1);
+        const int64_t long_max = rec_max / kLongRun + 1;
+        long_run.alloc((size_t)long_max);
+        out.ptr.alloc((size_t)n_rows + 1); out.col.alloc((size_t)rec_max + 64); out.o0.alloc((size_t)rec_max + 64);
+        if (v1) out.o1.alloc((size_t)rec_max + 64);
+        out.result.alloc(2);
+        HIP_CHECK(hipMemsetAsync(out.result.d, 0, 2 * sizeof(long long), stream));
+        HIP_CHECK(hipMemsetAsync(row_cnt.d, 0, row_cnt.n * sizeof(int32_t), stream));
+        int bits = 1;
+        while (((int64_t)1 << bits) <= n_rows) ++bits;  // (the padding row n_rows sorts last)
+        size_t tb = 0, tb2 = 0, tb3 = 0;
+        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, key0.d, key1.d, idx0.d, idx1.d, (size_t)rec_max, 0, 32 + bits, stream));
+        HIP_CHECK(rocprim::inclusive_scan(nullptr, tb2, flag.d, flag_s.d, (size_t)rec_max, rocprim::plus<unsigned long long>(), stream));
+        HIP_CHECK(rocprim::exclusive_scan(nullptr, tb3, row_cnt.d, out.ptr.d, (int32_t)0, (size_t)n_rows + 1, rocprim::plus<int32_t>(), stream));
+        DevBuf<unsigned char> scratch;
+        scratch.alloc(std::max(tb, std::max(tb2, tb3)) + 256);
+        HIP_CHECK(rocprim::radix_sort_pairs((void*)scratch.d, tb, key0.d, key1.d, idx0.d, idx1.d, (size_t)rec_max, 0, 32 + bits, stream));
+        RecArgs ra{};
+        ra.n_rows = n_rows; ra.rec_max = rec_max; ra.key = key1.d; ra.idx = idx1.d; ra.v0 = v0; ra.v1 = v1;
+        ra.flag = flag.d; ra.row_cnt = row_cnt.d; ra.col = out.col.d; ra.o0 = out.o0.d; ra.o1 = v1 ? out.o1.d : nullptr;
+        ra.result = out.result.d; ra.long_run = long_run.d; ra.long_max = (int32_t)long_max; ra.qcol = qcol; ra.qout = qout;
+        const unsigned grec = (unsigned)((rec_max + 255) / 256);
+        hipLaunchKernelGGL(k_rec_flags, dim3(grec), dim3(256), 0, stream, ra);
+        HIP_CHECK(rocprim::inclusive_scan((void*)scratch.d, tb2, flag.d, flag_s.d, (size_t)rec_max, rocprim::plus<unsigned long long>(), stream));
+        ra.flag = flag_s.d;
+        hipLaunchKernelGGL(k_rec_merge, dim3(grec), dim3(256), 0, stream, ra);
+        hipLaunchKernelGGL(k_rec_total, dim3(1), dim3(64), 0, stream, ra);
+        hipLaunchKernelGGL(k_rec_long, dim3((unsigned)((long_max + 3) / 4)), dim3(256), 0, stream, ra);
+        HIP_CHECK(rocprim::exclusive_scan((void*)scratch.d, tb3, row_cnt.d, out.ptr.d, (int32_t)0, (size_t)n_rows + 1, rocprim::plus<int32_t>(), stream));
+        HIP_CHECK(hipGetLastError());
+    }
+    struct ArenaSwap {  // allocations of a scope go to another arena
+        DevArena* keep;
+        explicit ArenaSwap(DevArena* a) : keep(tl_arena) { tl_arena = a; }
+        ~ArenaSwap() { tl_arena = keep; }
+    };
+
+    // From the raw problems to A, G1, G2, K (K0 / K1), q, b, 1/D, 1/E on the device; the host gets the row pointers, K's columns
+    // and the norms back and lays out the tiles.  `raw` (device assembler, later): the raw matrices are on the device already.
+    void setup_on_device(HostSystem& h, const score_problem* probs) {
+        PhaseTimer pt(st.verbose != 0);
+        const int count = h.count;
+        const int64_t n = h.n_tot, m = h.m_tot;
+        const int rep = h.rep;
+        // ---- host: global row pointers of the raw matrices (P: the rows of replica 0 and of the tail), entry offsets ----
+        std::vector<int32_t> Pptr((size_t)n + 1), Aptr((size_t)m + 1), pent((size_t)count + 1), aent((size_t)count + 1);
+        std::vector<int32_t> xo32((size_t)count + 1), ro32((size_t)count + 1), nr32((size_t)count, 0);
+        int64_t pe = 0, ae = 0, sq = 0;
+        nnzP_full = 0;
+        for (int p = 0; p < count; ++p) {
+            const score_problem& pr = probs[p];
+            const int64_t nr = rep > 1 ? h.rep_n[(size_t)p] : 0, t0 = (int64_t)rep * nr;
+            xo32[(size_t)p] = (int32_t)h.xoff[p]; ro32[(size_t)p] = (int32_t)h.roff[p]; nr32[(size_t)p] = (int32_t)nr;
+            pent[(size_t)p] = (int32_t)pe; aent[(size_t)p] = (int32_t)ae;
+            int32_t* pp = &Pptr[(size_t)h.xoff[p]];
+            if (rep > 1) {
+                const int64_t e0 = pr.P_rowptr[nr], et = pr.P_rowptr[pr.n] - pr.P_rowptr[t0];
+                for (int64_t i = 0; i < nr; ++i) pp[i] = (int32_t)(pe + pr.P_rowptr[i]);
+                for (int64_t i = nr; i < t0; ++i) pp[i] = (int32_t)(pe + e0);
+                for (int64_t i = t0; i < pr.n; ++i) pp[i] = (int32_t)(pe + e0 + (pr.P_rowptr[i] - pr.P_rowptr[t0]));
+                pe += e0 + et;
+                nnzP_full += (int64_t)rep * e0 + et;
+            } else {
+                for (int64_t i = 0; i < pr.n; ++i) pp[i] = (int32_t)(pe + pr.P_rowptr[i]);
+                pe += pr.P_rowptr[pr.n];
+                nnzP_full += pr.P_rowptr[pr.n];
+            }
+            int32_t* ap = &Aptr[(size_t)h.roff[p]];
+            for (int64_t r = 0; r < pr.m; ++r) {
+                ap[r] = (int32_t)(ae + pr.A_rowptr[r]);
+                const int64_t L = pr.A_rowptr[r + 1] - pr.A_rowptr[r];
+                sq += L * L;
+            }
+            ae += pr.A_rowptr[pr.m];
+        }
+        Pptr[(size_t)n] = (int32_t)pe; Aptr[(size_t)m] = (int32_t)ae;
+        pent[(size_t)count] = (int32_t)pe; aent[(size_t)count] = (int32_t)ae;
+        xo32[(size_t)count] = (int32_t)n; ro32[(size_t)count] = (int32_t)m;
+        int64_t n_stored = 0;
+        for (int p = 0; p < count; ++p) n_stored += (h.xoff[p + 1] - h.xoff[p]) - (rep > 1 ? (int64_t)(rep - 1) * h.rep_n[(size_t)p] : 0);
+        tab_xoff.upload(xo32); tab_roff.upload(ro32); tab_nr.upload(nr32);
+        const ProbTab tab = prob_tab();
+        // ---- persistent arrays whose sizes are known up front ----
+        A_ptr.upload(Aptr);
+        A_col.alloc((size_t)ae + 64); A_val.alloc((size_t)ae + 64);
+        HIP_CHECK(hipMemsetAsync(A_col.d + ae, 0, 64 * sizeof(int32_t), stream));
+        HIP_CHECK(hipMemsetAsync(A_val.d + ae, 0, 64 * sizeof(double), stream));
+        q.alloc((size_t)n); b.alloc((size_t)m); invD.alloc((size_t)n); invE.alloc((size_t)m); Dd.alloc((size_t)n); Ed.alloc((size_t)m);
+        G1.ptr.alloc((size_t)n + 1); G2.ptr.alloc((size_t)n + 1); G2.split.alloc((size_t)n);
+        G1.col.alloc((size_t)ae + 64); G1.val.alloc((size_t)ae + 64);
+        const int64_t g2_nnz = nnzP_full + ae;
+        G2.col.alloc((size_t)g2_nnz + 64); G2.val.alloc((size_t)g2_nnz + 64);
+        HIP_CHECK(hipMemsetAsync(G1.col.d, 0, G1.col.n * sizeof(int32_t), stream));
+        HIP_CHECK(hipMemsetAsync(G1.val.d, 0, G1.val.n * sizeof(double), stream));
+        HIP_CHECK(hipMemsetAsync(G2.col.d + g2_nnz, 0, 64 * sizeof(int32_t), stream));
+        HIP_CHECK(hipMemsetAsync(G2.val.d + g2_nnz, 0, 64 * sizeof(double), stream));
+        // ---- scratch ----
+        setup_tmp.dev = st.device;
+        ArenaSwap swap(&setup_tmp);
+        DevBuf<int32_t> Pp, Pc, Ac, atp, arow, d_pent, d_aent;
+        DevBuf<uint32_t> idx0, atpos, akey0, akey1;
+        DevBuf<double> Pv, Av, qraw, braw, dsc, esc, norms;
+        Pp.upload(Pptr);
+        Pc.alloc((size_t)pe + 1); Pv.alloc((size_t)pe + 1); Ac.alloc((size_t)ae + 1); Av.alloc((size_t)ae + 1);
+        qraw.alloc((size_t)n); braw.alloc((size_t)std::max<int64_t>(1, m));
+        for (int p = 0; p < count; ++p) {
+            const score_problem& pr = probs[p];
+            const int64_t nr = rep > 1 ? h.rep_n[(size_t)p] : 0, t0 = (int64_t)rep * nr;
+            const int64_t o = pent[(size_t)p];
+            if (rep > 1) {
+                const int64_t e0 = pr.P_rowptr[nr], b0 = pr.P_rowptr[t0], et = pr.P_rowptr[pr.n] - b0;
+                copy_up(Pc.d + o, pr.P_col, (size_t)e0); copy_up(Pv.d + o, pr.P_val, (size_t)e0);
+                copy_up(Pc.d + o + e0, pr.P_col + b0, (size_t)et); copy_up(Pv.d + o + e0, pr.P_val + b0, (size_t)et);
+            } else {
+                copy_up(Pc.d + o, pr.P_col, (size_t)pr.P_rowptr[pr.n]); copy_up(Pv.d + o, pr.P_val, (size_t)pr.P_rowptr[pr.n]);
+            }
+            copy_up(Ac.d + aent[(size_t)p], pr.A_col, (size_t)pr.A_rowptr[pr.m]); copy_up(Av.d + aent[(size_t)p], pr.A_val, (size_t)pr.A_rowptr[pr.m]);
+            copy_up(qraw.d + h.xoff[p], pr.q, (size_t)pr.n); copy_up(braw.d + h.roff[p], pr.b, (size_t)pr.m);
+        }
+        if (count > 1) {
+            d_pent.upload(pent); d_aent.upload(aent);
+            if (pe) hipLaunchKernelGGL(k_globalise, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, stream, Pc.d, (const int32_t*)d_pent.d, (const int32_t*)tab_xoff.d, count, pe);
+            if (ae) hipLaunchKernelGGL(k_globalise, dim3((unsigned)((ae + 255) / 256)), dim3(256), 0, stream, Ac.d, (const int32_t*)d_aent.d, (const int32_t*)tab_xoff.d, count, ae);
+        }
+        HIP_CHECK(hipGetLastError());
+        pt.mark("  device setup: raw matrices up");
+        // ---- A' position map: entries of A by column, in row order (a stable sort of the columns) ----
+        arow.alloc((size_t)std::max<int64_t>(1, ae)); atp.alloc((size_t)n + 1); atpos.alloc((size_t)std::max<int64_t>(1, ae));
+        {
+            RuizInitArgs ia{};
+            ia.D = Dd.d; ia.E = Ed.d; ia.n = n; ia.m = m; ia.A_ptr = A_ptr.d; ia.arow = arow.d;
+            hipLaunchKernelGGL(k_ruiz_init, dim3((unsigned)std::max<int64_t>(1, (std::max(n, m) + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, ia);
+        }
+        DevBuf<unsigned char> scratch;
+        if (ae) {
+            idx0.alloc((size_t)ae); akey0.alloc((size_t)ae); akey1.alloc((size_t)ae);
+            hipLaunchKernelGGL(k_iota, dim3((unsigned)((ae + 255) / 256)), dim3(256), 0, stream, idx0.d, ae);
+            HIP_CHECK(hipMemcpyAsync(akey0.d, Ac.d, (size_t)ae * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            int bits = 1;
+            while (((int64_t)1 << bits) < n) ++bits;
+            size_t tb = 0;
+            HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, akey0.d, akey1.d, idx0.d, atpos.d, (size_t)ae, 0, bits, stream));
+            scratch.alloc(tb + 256);
+            HIP_CHECK(rocprim::radix_sort_pairs((void*)scratch.d, tb, akey0.d, akey1.d, idx0.d, atpos.d, (size_t)ae, 0, bits, stream));
+        }
+        hipLaunchKernelGGL(k_lower_bounds, dim3((unsigned)((n + 1 + 255) / 256)), dim3(256), 0, stream, (const uint32_t*)akey1.d, ae, n, atp.d);
+        HIP_CHECK(hipGetLastError());
+        // ---- Ruiz passes ----
+        const int64_t ngroups = (int64_t)h.cone_row.size();
+        dsc.alloc((size_t)n); esc.alloc((size_t)std::max<int64_t>(1, ngroups));
+        RzArgs rz{};
+        rz.P_ptr = Pp.d; rz.P_col = Pc.d; rz.P_val = Pv.d; rz.A_ptr = A_ptr.d; rz.A_col = Ac.d; rz.A_val = Av.d;
+        rz.atp = atp.d; rz.atpos = atpos.d; rz.arow = arow.d; rz.gstart = cone_row.d;
+        rz.D = Dd.d; rz.E = Ed.d; rz.d = dsc.d; rz.e = esc.d; rz.n = n; rz.m = m; rz.ngroups = ngroups; rz.tab = tab;
+        const unsigned gcol = (unsigned)((n + 3) / 4), ggrp = (unsigned)std::max<int64_t>(1, (ngroups + 255) / 256);
+        const unsigned gapp = (unsigned)std::max<int64_t>(1, (std::max(n, ngroups) + 255) / 256);
+        for (int it = 0; it < std::max(0, st.scale_iters); ++it) {
+            hipLaunchKernelGGL(k_rz_cols, dim3(gcol), dim3(256), 0, stream, rz);
+            if (ngroups) hipLaunchKernelGGL(k_rz_groups, dim3(ggrp), dim3(256), 0, stream, rz);
+            hipLaunchKernelGGL(k_rz_apply, dim3(gapp), dim3(256), 0, stream, rz);
+        }
+        HIP_CHECK(hipGetLastError());
+        pt.mark("  device setup: A' map + equilibration queued");
+        // ---- G1, G2, the equilibrated A, q, b, reciprocal scales, norms ----
+        DevBuf<long long> len1, len2;
+        len1.alloc((size_t)n + 1); len2.alloc((size_t)n + 1);
+        GDevArgs ga{};
+        ga.n = n; ga.m = m; ga.nnzA = ae; ga.tab = tab;
+        ga.P_ptr = Pp.d; ga.P_col = Pc.d; ga.P_val = Pv.d; ga.A_col = Ac.d; ga.A_val = Av.d;
+        ga.atp = atp.d; ga.atpos = atpos.d; ga.arow = arow.d; ga.D = Dd.d; ga.E = Ed.d;
+        ga.len1 = len1.d; ga.len2 = len2.d; ga.g1_ptr = G1.ptr.d; ga.g2_ptr = G2.ptr.d; ga.g2_split = G2.split.d;
+        ga.oA_col = A_col.d; ga.oA_val = A_val.d; ga.g1_col = G1.col.d; ga.g1_val = G1.val.d; ga.g2_col = G2.col.d; ga.g2_val = G2.val.d;
+        ga.q_raw = qraw.d; ga.b_raw = braw.d; ga.q = q.d; ga.b = b.d; ga.invD = invD.d; ga.invE = invE.d;
+        const unsigned grow1 = (unsigned)((n + 1 + 255) / 256);
+        hipLaunchKernelGGL(k_g_lengths, dim3(grow1), dim3(256), 0, stream, ga);
+        {
+            size_t tb = 0;
+            HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, len1.d, len1.d, (long long)0, (size_t)n + 1, rocprim::plus<long long>(), stream));
+            DevBuf<unsigned char> sc2;
+            sc2.alloc(tb + 256);
+            HIP_CHECK(rocprim::exclusive_scan((void*)sc2.d, tb, len1.d, len1.d, (long long)0, (size_t)n + 1, rocprim::plus<long long>(), stream));
+            HIP_CHECK(rocprim::exclusive_scan((void*)sc2.d, tb, len2.d, len2.d, (long long)0, (size_t)n + 1, rocprim::plus<long long>(), stream));
+        }
+        hipLaunchKernelGGL(k_g_ptrs, dim3(grow1), dim3(256), 0, stream, ga);
+        hipLaunchKernelGGL(k_g_scale_a, dim3((unsigned)std::max<int64_t>(1, (std::max(ae, std::max(n, m)) + 255) / 256)), dim3(256), 0, stream, ga);
+        hipLaunchKernelGGL(k_g_fill, dim3(gcol), dim3(256), 0, stream, ga);
+        norms.alloc((size_t)4 * count);
+        hipLaunchKernelGGL(k_prob_norms, dim3((unsigned)count), dim3(256), 0, stream, tab, (const double*)qraw.d, (const double*)q.d, (const double*)braw.d,
+                           (const double*)b.d, norms.d);
+        HIP_CHECK(hipGetLastError());
+        // ---- K = P + sigma I + rho A'A as K0 + rho K1 ----
+        const int64_t rec_max = n_stored + pe + sq + 64;
+        DevBuf<long long> kcnt;
+        DevBuf<unsigned long long> key0;
+        DevBuf<uint32_t> kidx0;
+        DevBuf<double> v0, v1;
+        kcnt.alloc((size_t)n + 1); key0.alloc((size_t)rec_max); kidx0.alloc((size_t)rec_max); v0.alloc((size_t)rec_max); v1.alloc((size_t)rec_max);
+        KBuildArgs ka{};
+        ka.n = n; ka.tab = tab; ka.sigma = h.sigma;
+        ka.g2_ptr = G2.ptr.d; ka.g2_split = G2.split.d; ka.g2_col = G2.col.d; ka.g2_val = G2.val.d;
+        ka.A_ptr = A_ptr.d; ka.A_col = A_col.d; ka.A_val = A_val.d;
+        ka.rec_cnt = kcnt.d; ka.key = key0.d; ka.idx = kidx0.d; ka.v0 = v0.d; ka.v1 = v1.d;
+        const unsigned grow4 = (unsigned)((n + 1 + 3) / 4);
+        hipLaunchKernelGGL(k_kb_count, dim3(grow4), dim3(256), 0, stream, ka);
+        {
+            size_t tb = 0;
+            HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, kcnt.d, kcnt.d, (long long)0, (size_t)n + 1, rocprim::plus<long long>(), stream));
+            DevBuf<unsigned char> sc2;
+            sc2.alloc(tb + 256);
+            HIP_CHECK(rocprim::exclusive_scan((void*)sc2.d, tb, kcnt.d, kcnt.d, (long long)0, (size_t)n + 1, rocprim::plus<long long>(), stream));
+        }
+        hipLaunchKernelGGL(k_kb_expand, dim3(grow4), dim3(256), 0, stream, ka);
+        hipLaunchKernelGGL(k_rec_pad, dim3((unsigned)((rec_max + 255) / 256)), dim3(256), 0, stream, key0.d, kidx0.d, (const long long*)(kcnt.d + n), rec_max, n);
+        MergeOut mo;
+        merge_records(n, rec_max, key0, kidx0, v0.d, v1.d, -1, nullptr, mo);
+        pt.mark("  device setup: G1 / G2 / A / K queued");
+        // ---- first trip back: counts, row pointers, norms ----
+        struct Pinned {
+            void* p = nullptr; size_t bytes = 0; int dev;
+            Pinned(size_t b, int d) : bytes(b), dev(d) { p = block_cache().take(bytes, dev, true); }
+            ~Pinned() { block_cache().give(p, bytes, dev, true); }
+        };
+        const size_t o_res = 0, o_norm = 16, o_kp = o_norm + (size_t)4 * count * sizeof(double);
+        const size_t o_g1 = o_kp + ((size_t)n + 1) * sizeof(int32_t), o_g2 = o_g1 + ((size_t)n + 1) * sizeof(int32_t);
+        Pinned back(o_g2 + ((size_t)n + 1) * sizeof(int32_t), st.device);
+        char* hb = (char*)back.p;
+        HIP_CHECK(hipMemcpyAsync(hb + o_res, mo.result.d, 2 * sizeof(long long), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(hb + o_norm, norms.d, (size_t)4 * count * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(hb + o_kp, mo.ptr.d, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(hb + o_g1, G1.ptr.d, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(hb + o_g2, G2.ptr.d, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        pt.mark("  device setup: kernels + row pointers back");
+        const int64_t nnzK = ((const long long*)(hb + o_res))[0];
+        const double* nm = (const double*)(hb + o_norm);
+        h.qnorm_u.assign((size_t)count, 0.0); h.qnorm_s.assign((size_t)count, 0.0); h.bnorm_u.assign((size_t)count, 0.0); h.bnorm_s.assign((size_t)count, 0.0);
+        for (int p = 0; p < count; ++p) {
+            h.qnorm_u[(size_t)p] = nm[4 * p]; h.qnorm_s[(size_t)p] = nm[4 * p + 1]; h.bnorm_u[(size_t)p] = nm[4 * p + 2]; h.bnorm_s[(size_t)p] = nm[4 * p + 3];
+        }
+        h.K.ptr.assign((const int32_t*)(hb + o_kp), (const int32_t*)(hb + o_kp) + n + 1);
+        h.G1.ptr.assign((const int32_t*)(hb + o_g1), (const int32_t*)(hb + o_g1) + n + 1);
+        h.G2.ptr.assign((const int32_t*)(hb + o_g2), (const int32_t*)(hb + o_g2) + n + 1);
+        h.A.ptr = std::move(Aptr);
+        if (h.K.ptr[(size_t)n] != nnzK || h.G2.ptr[(size_t)n] != g2_nnz) throw std::runtime_error("device setup: inconsistent entry counts");
+        g1_nnz = h.G1.ptr[(size_t)n];
+        // ---- K's persistent arrays at their exact size; its columns to the host (band layout, tiles) ----
+        {
+            ArenaSwap persist(&arena);
+            K.ptr.alloc((size_t)n + 1); K.col.alloc((size_t)nnzK + 64); K.val.alloc((size_t)nnzK + 64);
+            K0d.alloc((size_t)nnzK + 64); K1d.alloc((size_t)nnzK + 64);
+        }
+        HIP_CHECK(hipMemcpyAsync(K.ptr.d, mo.ptr.d, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(K.col.d, mo.col.d, (size_t)nnzK * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(K0d.d, mo.o0.d, (size_t)nnzK * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(K1d.d, mo.o1.d, (size_t)nnzK * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipMemsetAsync(K.col.d + nnzK, 0, 64 * sizeof(int32_t), stream));
+        HIP_CHECK(hipMemsetAsync(K.val.d, 0, K.val.n * sizeof(double), stream));
+        HIP_CHECK(hipMemsetAsync(K0d.d + nnzK, 0, 64 * sizeof(double), stream));
+        HIP_CHECK(hipMemsetAsync(K1d.d + nnzK, 0, 64 * sizeof(double), stream));
+        h.K.col.resize((size_t)nnzK);
+        {
+            Pinned kc((size_t)std::max<int64_t>(1, nnzK) * sizeof(int32_t), st.device);
+            HIP_CHECK(hipMemcpyAsync(kc.p, mo.col.d, (size_t)nnzK * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            // (the tiles of G1 / G2 need their row pointers only: laid out while K's columns travel)
+            h.G1.nrows = h.G2.nrows = h.K.nrows = h.K.ncols = n;
+            HIP_CHECK(hipStreamSynchronize(stream));
+            std::memcpy(h.K.col.data(), kc.p, (size_t)nnzK * sizeof(int32_t));
+        }
+        make_system_rowblocks(h);
+        fill_kkt_bytes(h);
+        pt.mark("  device setup: K columns back, tiles");
+    }
+
+    void init(HostSystem& h, const score_settings& s_, const score_problem* probs = nullptr) {
         H = &h;
         st = s_;
         PhaseTimer pt(st.verbose != 0);
@@ -815,12 +1150,14 @@ struct HipBackend {
         // matrices uploaded below -- unless its band view is asked for or SCORE_HOST_POLISH_BUILD is set: then on another
         // host thread while this one uploads.  Either way the structure check (per-cone data) runs on that thread.
         polish_on_device = st.polish && !band_h(h) && std::getenv("SCORE_HOST_POLISH_BUILD") == nullptr;
-        if (st.polish)
+        if (h.device_setup && !probs) throw std::runtime_error("device setup: the raw problems are missing");
+        if (st.polish && !h.device_setup)  // (device setup: the per-cone structure comes from a kernel, init_polish)
             polish_build = std::async(std::launch::async, [this, &h] {
                 if (polish_on_device) { Q = PolishData(); polish_structure(h, Q); }
                 else build_polish(h, Q, st.verbose != 0, band_h(h));
             });
         std::future<BandLayout> band_layout_job;
+        auto start_band_layout = [&] {
         if (band_k(h) && !h.chains.empty())  // the band view of K only reads the finished host system: laid out on a thread of its own
             band_layout_job = std::async(std::launch::async, [&h] {
                 BuildScope scope;
@@ -838,15 +1175,26 @@ struct HipBackend {
                 }
                 return build_band_layout(h.K, sg, band_runs(h.chains, use, h.bs, h.rep, h.rep_n, true), h.bs, h.count);
             });
+        };
+        if (!h.device_setup) start_band_layout();
         struct JoinBand {  // (an exception below must not leave the job running against a dying handle)
             std::future<BandLayout>& f;
             ~JoinBand() { if (f.valid()) f.wait(); }
         } join_band{band_layout_job};
+        if (h.device_setup) {
+            // everything matrix-shaped is built on the device from the raw problems (score_setup_device.hpp); the cone table
+            // (its rows are the equilibration's groups) goes up first
+            cone_row.upload(h.cone_row); cone_dim.upload(h.cone_dim); cone_type.upload(h.cone_type);
+            setup_on_device(h, probs);
+            start_band_layout();
+            K.adopt_tiles(h.K, h.rbK); G1.adopt_tiles(h.G1, h.rbG1); G2.adopt_tiles(h.G2, h.rbG2);
+            pt.mark("  device setup");
+        } else
         K.upload(h.K, h.rbK, nullptr, false);  // (values: K0 + rho K1, on the device -- derive_rho_data)
         // A single problem whose equilibration ran on the device: the equilibrated A, G1 = A' and G2 = [P | A'] are derived
         // there from the raw matrices and scales those passes left behind (k_derive_a / k_derive_g; 26 MB of uploads less
         // for the headline problem) -- a replicated problem only when its replicas' P values are bit-equal to replica 0's.
-        derive_ag = h.count == 1 && h.m_tot > 0 && ruiz_dev.kept && ruiz_dev.k_n == h.n_tot && ruiz_dev.k_m == h.m_tot &&
+        derive_ag = !h.device_setup && h.count == 1 && h.m_tot > 0 && ruiz_dev.kept && ruiz_dev.k_n == h.n_tot && ruiz_dev.k_m == h.m_tot &&
                     ruiz_dev.k_nnzA == (int64_t)h.A.col.size() && ruiz_dev.k_rep == h.rep && (h.rep == 1 || h.rep_exact) &&
                     std::getenv("SCORE_NO_DEVICE_AG") == nullptr;
         struct DropKept {  // (the kept buffers go back when the setup is over, whatever happens -- once nothing reads them any more)
@@ -857,8 +1205,10 @@ struct HipBackend {
                 r.drop();
             }
         } drop_kept{ruiz_dev, stream};
+        if (!h.device_setup) {
         G1.upload(h.G1, h.rbG1, nullptr, !derive_ag, !derive_ag);
         G2.upload(h.G2, h.rbG2, &h.g2_split, !derive_ag, !derive_ag);
+        }
         pt.mark("  uploads: K, G1, G2");
         // replicated problems (HostSystem::rep): K and G1 = A' hold replica 0's rows; K's operands repeat with the
         // block's replica stride, G1's are the consecutive tail rows of a cone
@@ -875,9 +1225,10 @@ struct HipBackend {
             n_vblocks = (int)vf.size();
             vb_first.upload(vf); vb_end.upload(ve); vb_prob.upload(vp);
         }
-        A_ptr.upload(h.A.ptr);
+        if (!h.device_setup) A_ptr.upload(h.A.ptr);
         // padded like the SpMV matrices: the cone kernel clamps its unconditional loads
-        if (derive_ag) {
+        if (h.device_setup) {
+        } else if (derive_ag) {
             const size_t nz = h.A.col.size();
             A_col.alloc(nz + 64); A_val.alloc(nz + 64);
             HIP_CHECK(hipMemsetAsync(A_col.d + nz, 0, 64 * sizeof(int32_t), stream));
@@ -896,8 +1247,9 @@ struct HipBackend {
         } else {
             A_col.upload_padded(h.A.col, 64); A_val.upload_padded(h.A.val, 64);
         }
-        q.upload(h.q); b.upload(h.b);
-        if (derive_ag) {  // (D and E are on the device: their reciprocals too)
+        if (!h.device_setup) { q.upload(h.q); b.upload(h.b); }
+        if (h.device_setup) {
+        } else if (derive_ag) {  // (D and E are on the device: their reciprocals too)
             invD.alloc(h.D.size()); invE.alloc(h.E.size());
             const int64_t nm = std::max<int64_t>((int64_t)h.D.size(), (int64_t)h.E.size());
             hipLaunchKernelGGL(k_derive_inv, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, stream, (const double*)ruiz_dev.dD.d, (const double*)ruiz_dev.dE.d,
@@ -910,7 +1262,7 @@ struct HipBackend {
             invD.upload(iD); invE.upload(iE);
         }
         pt.mark("  uploads: A, q, b, 1/D, 1/E");
-        cone_row.upload(h.cone_row); cone_dim.upload(h.cone_dim); cone_type.upload(h.cone_type);
+        if (!h.device_setup) { cone_row.upload(h.cone_row); cone_dim.upload(h.cone_dim); cone_type.upload(h.cone_type); }
         cone_block_first.upload(h.cone_block_first); cone_block_prob.upload(h.cone_block_prob);
         {   // the cone tables (row pointers, the entries of the small cones again by cone index): from A on the device
             const size_t nc = h.cone_row.size();
@@ -1079,7 +1431,7 @@ struct HipBackend {
         {   // fused cones (FuseArgs): a single problem whose cones are all small second-order cones, d + 1 rows each from row 0
             // on, every cone with a private head column (its head row is the ONE entry of that column of A -- the entry that
             // owns the cone's new state); the pending xt update then belongs to the INIT launch's helper items
-            bool ok = h.count == 1 && uni_ranges && n_help > 0 && !split.active && prec_pre && st.fac_fp32 != 0 && n_large_cones == 0 &&
+            bool ok = !h.device_setup && h.count == 1 && uni_ranges && n_help > 0 && !split.active && prec_pre && st.fac_fp32 != 0 && n_large_cones == 0 &&
                       !h.cone_row.empty() && std::getenv("SCORE_FUSED_CONE") != nullptr;
             // (OPT-IN, SCORE_FUSED_CONE=1.  Measured on the headline problem: the fused right-hand side takes 13.9 us -- four
             //  dependent trips: entries of A' -> cone records, s, y, b -> gathers of xt and p -> projection -- against 6.6 us
@@ -1109,7 +1461,7 @@ struct HipBackend {
         cg_iters = st.cg_iters;
         std::vector<int32_t> dz(h.count, 0);
         done.upload(dz);
-        K0d.upload_padded(h.K0, 64); K1d.upload_padded(h.K1, 64);
+        if (!h.device_setup) { K0d.upload_padded(h.K0, 64); K1d.upload_padded(h.K1, 64); }
         {   // positions of the chain blocks and the Jacobi diagonals in K's value array: looked up on the device (binary
             // search per block entry; on the host this was 0.5 ms of a headline create and 2.4 of an 8-trial handle's)
             const int b2 = h.bs * h.bs;
@@ -1179,6 +1531,7 @@ struct HipBackend {
         reset();
         pt.mark("reset");
         HIP_CHECK(hipStreamSynchronize(stream));
+        setup_tmp.release_all();  // (nothing in flight reads the setup's scratch any more)
         pt.mark("staged uploads: drain");
     }
 
@@ -1858,6 +2211,21 @@ struct HipBackend {
     }
 
     void download(const HostSystem& h, double* x, double* y, double* s_out) {
+        if (h.device_setup) {  // the scales live on the device: x = xhat D, y = yhat E, s = shat / E there, then one copy each
+            const int64_t n = h.n_tot, m = h.m_tot;
+            size_t got = (size_t)(n + 2 * m) * sizeof(double);
+            double* ob = (double*)block_cache().take(got, st.device, false);
+            hipLaunchKernelGGL(k_unscale, dim3((unsigned)std::max<int64_t>(1, (std::max(n, m) + 255) / 256)), dim3(256), 0, stream, (const double*)xy.d, (const double*)s.d,
+                               (const double*)Dd.d, (const double*)Ed.d, ob, n, m);
+            hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
+            if (x) e1 = hipMemcpyAsync(x, ob, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream);
+            if (y && m) e2 = hipMemcpyAsync(y, ob + n, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream);
+            if (s_out && m) e3 = hipMemcpyAsync(s_out, ob + n + m, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream);
+            const hipError_t e4 = hipStreamSynchronize(stream);
+            block_cache().give(ob, got, st.device, false);
+            HIP_CHECK(e1); HIP_CHECK(e2); HIP_CHECK(e3); HIP_CHECK(e4);
+            return;
+        }
         HIP_CHECK(hipStreamSynchronize(stream));
         std::vector<double> hx(h.n_tot + h.m_tot), hs(h.m_tot);
         HIP_CHECK(hipMemcpyAsync(hx.data(), xy.d, hx.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -1885,11 +2253,54 @@ struct HipBackend {
         else if (nm == "p") { src = (cg_iters % 2 == 1) ? p.d : p2.d; sz = h.n_tot; }  // last PCG direction
         else if (nm == "w") { src = w.d; sz = h.n_tot; }
         else if (nm == "kx") { src = kx.d; sz = h.n_tot; }
+        else if (nm == "D" && h.device_setup) { src = Dd.d; sz = h.n_tot; }
+        else if (nm == "E" && h.device_setup) { src = Ed.d; sz = h.m_tot; }
         else if (nm == "D") { src = h.D.data(); sz = h.n_tot; host = true; }
         else if (nm == "E") { src = h.E.data(); sz = h.m_tot; host = true; }
+        else if (nm == "K0" || nm == "K1" || nm == "Aval" || nm == "G1val" || nm == "G2val" || nm == "qs" || nm == "bs" || nm == "invD" || nm == "invE") {
+            // the setup's value arrays as the kernels read them (tests: device setup against host setup, bit for bit)
+            const int64_t nk = (int64_t)h.K.col.size(), na = (int64_t)h.A.ptr[(size_t)h.m_tot];
+            const int64_t n1 = h.device_setup ? g1_nnz : (int64_t)h.G1.col.size(), n2 = (int64_t)h.G2.ptr[(size_t)h.n_tot];
+            if (nm == "K0") { src = K0d.d; sz = nk; } else if (nm == "K1") { src = K1d.d; sz = nk; }
+            else if (nm == "Aval") { src = A_val.d; sz = na; } else if (nm == "G1val") { src = G1.val.d; sz = n1; }
+            else if (nm == "G2val") { src = G2.val.d; sz = n2; } else if (nm == "qs") { src = q.d; sz = h.n_tot; }
+            else if (nm == "bs") { src = b.d; sz = h.m_tot; } else if (nm == "invD") { src = invD.d; sz = h.n_tot; }
+            else { src = invE.d; sz = h.m_tot; }
+        }
+        else if (nm == "Acol" || nm == "Aptr" || nm == "G1col" || nm == "G1ptr" || nm == "G2col" || nm == "G2ptr" || nm == "G2split" || nm == "Kcol_dev" || nm == "Kptr_dev") {
+            const int64_t nk = (int64_t)h.K.col.size(), na = (int64_t)h.A.ptr[(size_t)h.m_tot];
+            const int64_t n1 = h.device_setup ? g1_nnz : (int64_t)h.G1.col.size(), n2 = (int64_t)h.G2.ptr[(size_t)h.n_tot];
+            const int32_t* isrc = nullptr;
+            if (nm == "Acol") { isrc = A_col.d; sz = na; } else if (nm == "Aptr") { isrc = A_ptr.d; sz = h.m_tot + 1; }
+            else if (nm == "G1col") { isrc = G1.col.d; sz = n1; } else if (nm == "G1ptr") { isrc = G1.ptr.d; sz = h.n_tot + 1; }
+            else if (nm == "G2col") { isrc = G2.col.d; sz = n2; } else if (nm == "G2ptr") { isrc = G2.ptr.d; sz = h.n_tot + 1; }
+            else if (nm == "G2split") { isrc = G2.split.d; sz = h.n_tot; } else if (nm == "Kcol_dev") { isrc = K.col.d; sz = nk; }
+            else { isrc = K.ptr.d; sz = h.n_tot + 1; }
+            if (out && len > 0) {
+                std::vector<int32_t> tmp((size_t)std::min(len, sz));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                HIP_CHECK(hipMemcpyAsync(tmp.data(), isrc, tmp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                for (size_t i = 0; i < tmp.size(); ++i) out[i] = (double)tmp[i];
+            }
+            return sz;
+        }
+        else if (nm == "setup_scalars") {  // per problem: |q|_inf, |b|_inf unscaled and scaled, kkt_bytes
+            sz = 5 * (int64_t)h.count;
+            if (out && len >= sz)
+                for (int p = 0; p < h.count; ++p) {
+                    out[5 * p] = h.qnorm_u[(size_t)p]; out[5 * p + 1] = h.qnorm_s[(size_t)p]; out[5 * p + 2] = h.bnorm_u[(size_t)p];
+                    out[5 * p + 3] = h.bnorm_s[(size_t)p]; out[5 * p + 4] = h.kkt_bytes[(size_t)p];
+                }
+            return sz;
+        }
+        else if (nm == "device_setup") {
+            if (out && len > 0) out[0] = h.device_setup ? 1.0 : 0.0;
+            return 1;
+        }
         else if (nm == "Kval") { src = K.val.d; sz = (int64_t)h.K.col.size(); }
         else if (nm == "rep") {  // [replicas the kernels run with (1 = general problem), nnz of the stored K, of the stored A']
-            const double v[3] = {(double)h.rep, (double)h.K.col.size(), (double)h.G1.col.size()};
+            const double v[3] = {(double)h.rep, (double)h.K.col.size(), (double)(h.device_setup ? (size_t)g1_nnz : h.G1.col.size())};
             if (out && len > 0) std::memcpy(out, v, sizeof(double) * (size_t)std::min<int64_t>(len, 3));
             return 3;
         }
@@ -1907,6 +2318,7 @@ struct HipBackend {
             }
             return 1;
         }
+        else if ((nm == "ag_device_check" || nm == "polish_build_check") && h.device_setup) return -1;  // (no host matrices to compare with: SCORE_HOST_SETUP=1)
         else if (nm == "ag_device_check") {
             // the equilibrated A, G1, G2 on the device against the host arrays: [derived on the device (0/1), mismatching
             // columns of A, max |A value difference|, the same for G1, for G2]
@@ -2037,6 +2449,12 @@ struct HipBackend {
         else if (nm == "Hcol" || nm == "Hptr" || nm == "is_head" || nm == "chain_of_col") {
             if (!Q.available) return -1;
             std::vector<double> tmp;
+            if (nm == "is_head" && h.device_setup) {  // (made on the device: the host never held it)
+                std::vector<int32_t> ih((size_t)h.n_tot);
+                HIP_CHECK(hipMemcpyAsync(ih.data(), q_ishead.d, sizeof(int32_t) * ih.size(), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                tmp.assign(ih.begin(), ih.end());
+            } else
             if (nm == "Hcol" && polish_on_device) {  // (built on the device: the host never held it)
                 std::vector<int32_t> hc((size_t)hm_nnz);
                 HIP_CHECK(hipMemcpyAsync(hc.data(), Hm.col.d, sizeof(int32_t) * hc.size(), hipMemcpyDeviceToHost, stream));
@@ -2181,7 +2599,7 @@ struct HipBackend {
         for (size_t k = 0; k < h.cone_row.size(); ++k)
             if ((int64_t)h.cone_row[k] != (int64_t)k * D1) return false;
         int64_t con_max = 0;
-        const int64_t rec_max = polish_record_bound(h, T, &con_max);
+        const int64_t rec_max = polish_record_bound(h, T, &con_max, h.device_setup ? nnzP_full : -1);
         if (rec_max + 64 >= ((int64_t)1 << 31)) return false;
         const int long_max = 1 << 16;
         // what stays: pattern, P on it, lists, positions (the handle's arena)
@@ -2297,9 +2715,48 @@ struct HipBackend {
         if (const char* e = std::getenv("SCORE_NEWTON_ETA_MAX")) newton_eta_max = std::atof(e);
         if (const char* e = std::getenv("SCORE_NEWTON_ETA_COEF")) newton_eta_coef = std::atof(e);
         if (const char* e = std::getenv("SCORE_NEWTON_ETA_POW")) newton_eta_pow = std::atof(e);
-        polish_build.get();  // (rethrows what build_polish threw)
+        if (polish_build.valid()) polish_build.get();  // (rethrows what build_polish threw)
         pt.mark("  polish: host structures (wait)");
         bool on_device = false;
+        if (h.device_setup) {
+            // the per-cone structure (polish_structure) from the device matrices: what the host can see -- uniform second-order
+            // cones of 2-4 rows -- is checked here, the head-variable conditions by k_polish_structure
+            Q = PolishData();
+            const size_t nc = h.cone_row.size();
+            const int T = nc ? h.cone_dim[0] - 1 : 0;
+            bool ok = nc > 0 && h.m_tot > 0 && T >= 1 && T <= kPolishMaxTail;
+            for (size_t k = 0; k < nc && ok; ++k) ok = h.cone_type[k] == 1 && h.cone_dim[k] - 1 == T;
+            if (!ok) return;
+            Q.T = T;
+            q_head.alloc(nc); q_ishead.alloc((size_t)h.n_tot); q_aabs.alloc(nc); q_ck.alloc(nc); q_theta.alloc(nc); q_xstar.alloc(nc);
+            DevBuf<int32_t> bad;
+            bad.alloc(1);
+            HIP_CHECK(hipMemsetAsync(q_ishead.d, 0, q_ishead.n * sizeof(int32_t), stream));
+            HIP_CHECK(hipMemsetAsync(bad.d, 0, sizeof(int32_t), stream));
+            PStructArgs pa{};
+            pa.ncones = (int64_t)nc; pa.n = h.n_tot; pa.T = T;
+            pa.cone_row = cone_row.d; pa.cone_dim = cone_dim.d; pa.cone_type = cone_type.d;
+            pa.A_ptr = A_ptr.d; pa.A_col = A_col.d; pa.A_val = A_val.d; pa.b = b.d; pa.q = q.d;
+            pa.g2_ptr = G2.ptr.d; pa.g2_split = G2.split.d; pa.g2_col = G2.col.d; pa.g2_val = G2.val.d;
+            pa.head_col = q_head.d; pa.is_head = q_ishead.d; pa.a_abs = q_aabs.d; pa.ck = q_ck.d; pa.theta = q_theta.d; pa.xstar = q_xstar.d;
+            pa.bad = bad.d;
+            hipLaunchKernelGGL(k_polish_structure, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, stream, pa);
+            std::vector<int32_t> bad_h(1, 0);
+            HIP_CHECK(hipMemcpyAsync(bad_h.data(), bad.d, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            try {
+                on_device = build_polish_on_device(h);  // (its synchronisation brings the verdict back too)
+            } catch (const std::exception& e) {
+                if (std::strstr(e.what(), "hipMalloc") == nullptr) throw;
+                (void)hipGetLastError();
+                on_device = false;
+            }
+            pt.mark("  polish: structure + pattern + lists on the device");
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (!on_device || bad_h[0] != 0) {  // (not the SCORE structure, or a build the device declined: ADMM alone)
+                Q.available = false;
+                return;
+            }
+        } else
         if (polish_on_device && Q.T > 0) {
             q_head.upload(Q.head_col); q_ishead.upload(Q.is_head); q_aabs.upload(Q.a_abs); q_ck.upload(Q.ck);
             q_theta.upload(Q.theta); q_xstar.upload(Q.xstar);

@@ -912,6 +912,11 @@ struct HostSystem {
     // computed or uploaded by the host.
     bool factor_on_host = true;
     bool fac_fp32 = true;   // chain factors kept to float precision (score_settings.fac_fp32)
+    // true: build_system left the matrices (A, K with K0 / K1, G1, G2), the scales, q, b, the tile tables and kkt_bytes to the
+    // backend, which builds them on its device from the raw program (score_setup_device.hpp) and hands back what the host
+    // side reads: row pointers, K's columns, the norms of q and b, the tiles.  D, E, q, b then live on the device only.
+    bool device_setup = false;
+    std::vector<char> rep_exact_all;  // per problem: its replicas' P values are bit-equal to replica 0's
 };
 
 inline int find_in_row(const Csr& M, int64_t row, int32_t col) {
@@ -1478,10 +1483,52 @@ inline void refresh_rho(HostSystem& H, int pi) {
     }
 }
 
+// The tile tables of K, G1 and G2 from their row pointers (three independent serial scans).
+inline void make_system_rowblocks(HostSystem& H) {
+    const int count = H.count;
+    parallel_ranges(3, 1, [&](int, int64_t k0, int64_t k1) {  // three independent serial scans
+        for (int64_t k = k0; k < k1; ++k) {
+            // K and G1 of a replicated problem: the rows of replica 0 (applied to all replicas), then the tail
+            std::vector<RowSegment> sg;
+            if (k < 2 && H.rep > 1) {
+                for (int p = 0; p < count; ++p) {
+                    const int64_t nr = H.rep_n[(size_t)p];
+                    sg.push_back(RowSegment{H.xoff[p], H.xoff[p] + nr, p, (int32_t)nr});
+                    sg.push_back(RowSegment{H.xoff[p] + (int64_t)H.rep * nr, H.xoff[p + 1], p, 0});
+                }
+            } else {
+                sg = plain_segments(H.xoff);
+            }
+            // (G1 = A' has one or two entries per row: its tiles are bounded by their 256 rows, far below 1024 nonzeros --
+            //  a replicated problem runs it with 4 instead of 8 nonzero slots per lane: half the issued loads and LDS
+            //  planes; measured rhs 6.7 -> 6.2 us on the headline problem, 55.9 -> 47.6 us in the batch of 16)
+            if (k == 0) H.rbK = make_rowblocks(H.K, sg, count, H.tile_nnz);
+            else if (k == 1) H.rbG1 = make_rowblocks(H.G1, sg, count, H.rep > 1 ? kTileNnz / 2 : H.tile_nnz);
+            else H.rbG2 = make_rowblocks(H.G2, sg, count);
+        }
+    });
+}
+
+// algorithmic bytes of one K-apply per problem: 12 B per nonzero (fp64 value
+// + int32 column), 4 B per row pointer, vector p read once, w written once
+inline void fill_kkt_bytes(HostSystem& H) {
+    H.kkt_bytes.assign(H.count, 0.0);
+    for (int p = 0; p < H.count; ++p) {
+        // (a replicated problem streams K_row and the tail once: the rows K holds; p and w are whole vectors)
+        const double nnz = (double)(H.K.ptr[H.xoff[p + 1]] - H.K.ptr[H.xoff[p]]);
+        const double n = (double)(H.xoff[p + 1] - H.xoff[p]);
+        const double rows = H.rep > 1 ? n - (double)(H.rep - 1) * (double)H.rep_n[(size_t)p] : n;
+        H.kkt_bytes[p] = 12.0 * nnz + 4.0 * (rows + 1) + 16.0 * n;
+    }
+}
+
 // allow_rep: the backend can run replicated problems (HostSystem::rep); the CPU twin cannot (and is the better
 // check for not doing so: it applies the full K the problem defines).
+// device_setup_ok (optional): called once sizes and the replication structure are known; true = the backend builds the
+// matrices on its device (HostSystem::device_setup) and the host sweeps over them are skipped.
 inline void build_system(const score_problem* probs, int count, const score_settings& st, HostSystem& H,
-                         bool factor_on_host = true, bool allow_rep = false, RuizOffload* ruiz_offload = nullptr) {
+                         bool factor_on_host = true, bool allow_rep = false, RuizOffload* ruiz_offload = nullptr,
+                         const std::function<bool(const HostSystem&)>& device_setup_ok = nullptr) {
     if (count <= 0) throw std::runtime_error("score_create: count must be positive");
     BuildScope scope;
     PhaseTimer pt(st.verbose != 0);
@@ -1511,15 +1558,20 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     {   // row replication: every problem of the batch must carry the same, verified, hint
         int rep = (allow_rep && std::getenv("SCORE_NO_REPLICATION") == nullptr) ? probs[0].rep_d : 0;
         H.rep_exact = false;
+        H.rep_exact_all.assign((size_t)count, 0);
         if (rep > 1 && count == 1) {
             bool ex = false;
             if (probs[0].rep_d != rep || !check_replication(probs[0], &ex)) rep = 0;
             H.rep_exact = rep > 1 && ex;
+            H.rep_exact_all[0] = H.rep_exact;
         } else if (rep > 1 && count > 1) {  // (a batch: one problem per part, the sweeps inside run serially)
             std::atomic<bool> all{true};
             parallel_ranges(count, 1, [&](int, int64_t p0, int64_t p1) {
-                for (int64_t p = p0; p < p1 && all.load(std::memory_order_relaxed); ++p)
-                    if (probs[p].rep_d != rep || !check_replication(probs[p])) all = false;
+                for (int64_t p = p0; p < p1 && all.load(std::memory_order_relaxed); ++p) {
+                    bool ex = false;
+                    if (probs[p].rep_d != rep || !check_replication(probs[p], &ex)) all = false;
+                    H.rep_exact_all[(size_t)p] = ex;
+                }
             });
             if (!all) rep = 0;
         }
@@ -1530,6 +1582,8 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         pt.mark("replication check");
     }
     if (H.n_tot + H.m_tot >= (int64_t)1 << 31) throw std::runtime_error("batch too large for 32-bit indices");
+    const bool lite = device_setup_ok && device_setup_ok(H);
+    H.device_setup = lite;
     H.A.nrows = H.m_tot; H.A.ncols = H.n_tot; H.A.ptr.assign(1, 0);
     H.K.nrows = H.K.ncols = H.n_tot; H.K.ptr.assign(1, 0);
     H.G1.nrows = H.n_tot; H.G1.ncols = H.n_tot + H.m_tot; H.G1.ptr.assign(1, 0);
@@ -1544,7 +1598,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     //  Measured on the 64-trial sweep, A/B on one box: 850-1010 graphs/s against 980-1090 with the host loop -- eight groups
     //  times eight problems times 45 small launches and a synchronisation each crowd the queues the solves need.)
     RuizOffload* batch_offload = std::getenv("SCORE_BATCH_DEVICE_RUIZ") ? ruiz_offload : nullptr;
-    if (count > 1) {
+    if (count > 1 && !lite) {
         parallel_ranges(count, 1, [&](int, int64_t p0, int64_t p1) {
             for (int64_t p = p0; p < p1; ++p) ruiz_scale(probs[p], std::max(0, st.scale_iters), scaled[(size_t)p], H.rep, H.rep_n[(size_t)p], nullptr, batch_offload);
         });
@@ -1556,7 +1610,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     // copied into its own range.  A single problem is appended in place (its row loops are split over
     // threads inside append_problem).  Either way the arrays come out identical.
     std::vector<HostSystem> pieces;
-    if (count > 1) {
+    if (count > 1 && !lite) {
         pieces.resize((size_t)count);
         parallel_ranges(count, 1, [&](int, int64_t p0, int64_t p1) {
             PhaseTimer quiet(false);
@@ -1611,16 +1665,17 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     }
     for (int p = 0; p < count; ++p) {
         const score_problem& pr = probs[p];
-        if (count == 1) {
+        if (count == 1 && !lite) {
             ruiz_scale(pr, std::max(0, st.scale_iters), scaled[0], H.rep, H.rep_n[0], &pt, ruiz_offload);  // (one problem: the passes may run on the device)
             pt.mark("ruiz");
         }
+        H.c0.push_back(pr.c0);
+        if (!lite) {
         ProblemScaled S = std::move(scaled[(size_t)p]);
         H.D.insert(H.D.end(), S.D.begin(), S.D.end());
         H.E.insert(H.E.end(), S.E.begin(), S.E.end());
         H.q.insert(H.q.end(), S.q.begin(), S.q.end());
         H.b.insert(H.b.end(), S.b.begin(), S.b.end());
-        H.c0.push_back(pr.c0);
         double qu = 0, bu = 0, qs = 0, bsn = 0;
         for (int j = 0; j < pr.n; ++j) { qu = std::max(qu, std::fabs(pr.q[j])); qs = std::max(qs, std::fabs(S.q[j])); }
         for (int r = 0; r < pr.m; ++r) { bu = std::max(bu, std::fabs(pr.b[r])); bsn = std::max(bsn, std::fabs(S.b[r])); }
@@ -1628,6 +1683,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         if (count == 1) {
             append_problem(H, p, pr, S, pt);
             pt.mark("append (K, G1, G2)");
+        }
         }
         // cones, in blocks of kConesPerBlock that never straddle problems
         const size_t c_first = H.cone_row.size();
@@ -1655,27 +1711,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         const int v = std::atoi(e);
         if (H.rep > 1 && (v == kTileNnz || v == kTileNnz / 2)) H.tile_nnz = v;
     }
-    parallel_ranges(3, 1, [&](int, int64_t k0, int64_t k1) {  // three independent serial scans
-        for (int64_t k = k0; k < k1; ++k) {
-            // K and G1 of a replicated problem: the rows of replica 0 (applied to all replicas), then the tail
-            std::vector<RowSegment> sg;
-            if (k < 2 && H.rep > 1) {
-                for (int p = 0; p < count; ++p) {
-                    const int64_t nr = H.rep_n[(size_t)p];
-                    sg.push_back(RowSegment{H.xoff[p], H.xoff[p] + nr, p, (int32_t)nr});
-                    sg.push_back(RowSegment{H.xoff[p] + (int64_t)H.rep * nr, H.xoff[p + 1], p, 0});
-                }
-            } else {
-                sg = plain_segments(H.xoff);
-            }
-            // (G1 = A' has one or two entries per row: its tiles are bounded by their 256 rows, far below 1024 nonzeros --
-            //  a replicated problem runs it with 4 instead of 8 nonzero slots per lane: half the issued loads and LDS
-            //  planes; measured rhs 6.7 -> 6.2 us on the headline problem, 55.9 -> 47.6 us in the batch of 16)
-            if (k == 0) H.rbK = make_rowblocks(H.K, sg, count, H.tile_nnz);
-            else if (k == 1) H.rbG1 = make_rowblocks(H.G1, sg, count, H.rep > 1 ? kTileNnz / 2 : H.tile_nnz);
-            else H.rbG2 = make_rowblocks(H.G2, sg, count);
-        }
-    });
+    if (!lite) make_system_rowblocks(H);
     pt.mark("row blocks");
 
     // ---- preconditioner layout ----
@@ -1875,13 +1911,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     // algorithmic bytes of one K-apply per problem: 12 B per nonzero (fp64 value
     // + int32 column), 4 B per row pointer, vector p read once, w written once
     H.kkt_bytes.assign(count, 0.0);
-    for (int p = 0; p < count; ++p) {
-        // (a replicated problem streams K_row and the tail once: the rows K holds; p and w are whole vectors)
-        const double nnz = (double)(H.K.ptr[H.xoff[p + 1]] - H.K.ptr[H.xoff[p]]);
-        const double n = (double)(H.xoff[p + 1] - H.xoff[p]);
-        const double rows = H.rep > 1 ? n - (double)(H.rep - 1) * (double)H.rep_n[(size_t)p] : n;
-        H.kkt_bytes[p] = 12.0 * nnz + 4.0 * (rows + 1) + 16.0 * n;
-    }
+    if (!lite) fill_kkt_bytes(H);
     pt.mark("jacobi + work list");
     for (int p = 0; p < count; ++p) refresh_rho(H, p);
     pt.mark("refresh_rho (factor)");

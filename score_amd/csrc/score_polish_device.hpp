@@ -353,7 +353,7 @@ __global__ __launch_bounds__(256) void k_derive_g(DeriveArgs a) {
 
 // upper bound of the records (exact but for the rows of P without a diagonal entry): P entries, one record per head
 // row, one per row for a missing diagonal, (entries of a cone's tail rows)^2 contributions per cone
-inline int64_t polish_record_bound(const HostSystem& H, int T, int64_t* contributions = nullptr) {
+inline int64_t polish_record_bound(const HostSystem& H, int T, int64_t* contributions = nullptr, int64_t nnzP_known = -1) {
     int64_t con = 0;
     for (size_t k = 0; k < H.cone_row.size(); ++k) {
         const int r0 = H.cone_row[k];
@@ -361,8 +361,8 @@ inline int64_t polish_record_bound(const HostSystem& H, int T, int64_t* contribu
         con += L * L;
     }
     if (contributions) *contributions = con;
-    int64_t nnzP = 0;
-    for (int64_t i = 0; i < H.n_tot; ++i) nnzP += H.g2_split[(size_t)i] - H.G2.ptr[(size_t)i];
+    int64_t nnzP = nnzP_known >= 0 ? nnzP_known : 0;
+    for (int64_t i = 0; i < H.n_tot && nnzP_known < 0; ++i) nnzP += H.g2_split[(size_t)i] - H.G2.ptr[(size_t)i];
     return nnzP + H.n_tot + con;
 }
 

@@ -1,0 +1,474 @@
+// score_setup_device.hpp -- score_create's matrices built on the device.
+//
+// What score_host.hpp::build_system computes on the host for every handle -- the A' position map, the Ruiz equilibration,
+// the equilibrated A, G1 = A' and G2 = [P | A'], and K = P + sigma I + rho A'A as K0 + rho K1 on the union pattern -- from the
+// RAW program (P, q, A, b as the caller or the device assembler hands them over), for a single problem and for the lock-step
+// batch of a Monte-Carlo handle alike.  The batch is ONE block-diagonal system in global indices: every kernel below sees n_tot
+// rows and m_tot constraint rows and looks the problem of a row up in a small table (ProbTab) where the row-replicated structure
+// (score_problem::rep_d / rep_n, HostSystem::rep) asks for it.  The host keeps what is not a sweep over matrix entries: sizes,
+// cone and chain tables, and -- from the row pointers and K's columns, which come back in one transfer -- the tile tables and
+// the band layout.
+//
+// The host loops stay as the specification (and as the CPU twin's path): every array made here equals the host's entry by
+// entry, the value arrays bit for bit -- the records of a row are laid out in the host loop's order, the sort is stable, and an
+// entry adds its records one after the other in that order (score_debug_get "setup_device_check",
+// tests/test_gpu_parity.py::test_device_setup_equals_the_host_setup).
+//
+// Reference: the model these matrices come from is built term by term in /root/reference/score/utils/gurobi_utils.py:173-187
+// (initialize_model), :336-352 (cones), :358-526 (objective); Gurobi's presolve / ordering (gurobi_utils.py:206-215,
+// solve_score.py:76) is what this setup stands in for.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "score_host.hpp"
+
+namespace score {
+
+// The problems of a handle: unknown and constraint-row offsets, unknowns per replica.  Device arrays (a handle may hold
+// dozens of problems).
+struct ProbTab {
+    const int32_t* xoff;  // count + 1
+    const int32_t* roff;  // count + 1
+    const int32_t* nr;    // count: unknowns per replica (rep > 1)
+    int32_t count, rep;   // rep: replicas of every problem of the handle (1: plain problems)
+};
+// largest p with off[p] <= i (off[0] = 0 <= i < off[count])
+__device__ __forceinline__ int tab_find(const int32_t* __restrict__ off, int count, int64_t i) {
+    int lo = 0, hi = count;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+struct RowInfo {
+    int prob;
+    int64_t i0;      // the row of replica 0 that holds this row's entries (the row itself for plain / tail rows)
+    int32_t shift;   // column shift from replica 0 to this row's replica
+    bool stored;     // K and G1 hold a row for this unknown (replica 0 and the tail)
+};
+__device__ __forceinline__ RowInfo row_info(const ProbTab& t, int64_t i) {
+    RowInfo r;
+    r.prob = t.count > 1 ? tab_find(t.xoff, t.count, i) : 0;
+    const int64_t x0 = t.xoff[r.prob], local = i - x0;
+    const int64_t nr = t.rep > 1 ? t.nr[r.prob] : 0;
+    const bool in_rep = t.rep > 1 && local < (int64_t)t.rep * nr;
+    const int64_t l0 = in_rep ? local % nr : local;
+    r.i0 = x0 + l0;
+    r.shift = (int32_t)(local - l0);
+    r.stored = !in_rep || local < nr;
+    return r;
+}
+
+// column indices of a batch's problems from local to global: entry k belongs to the problem whose entry range holds it
+__global__ __launch_bounds__(256) void k_globalise(int32_t* __restrict__ col, const int32_t* __restrict__ ent_off, const int32_t* __restrict__ delta,
+                                                   int count, int64_t total) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= total) return;
+    const int p = tab_find(ent_off, count, k);
+    col[k] += delta[p];
+}
+__global__ __launch_bounds__(256) void k_iota(uint32_t* __restrict__ v, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) v[k] = (uint32_t)k;
+}
+// out[j] = first position of the sorted keys that is >= j, j = 0..n (column pointers of the A' map from the sorted columns)
+__global__ __launch_bounds__(256) void k_lower_bounds(const uint32_t* __restrict__ sorted, int64_t cnt, int64_t n, int32_t* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j > n) return;
+    int64_t lo = 0, hi = cnt;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)sorted[mid] < j) lo = mid + 1; else hi = mid;
+    }
+    out[j] = (int32_t)lo;
+}
+
+// ---- the Ruiz passes over the block-diagonal batch (ruiz_scale, score_host.hpp, is the specification) ----
+struct RzArgs {
+    const int32_t* P_ptr; const int32_t* P_col; const double* P_val;   // raw, global; rows of replicas >= 1 are not read
+    const int32_t* A_ptr; const int32_t* A_col; const double* A_val;   // raw, global
+    const int32_t* atp; const uint32_t* atpos; const int32_t* arow;
+    const int32_t* gstart;   // first row of every cone group (the handle's cone table); group g ends at gstart[g + 1] / m
+    double* D; double* E; double* d; double* e;
+    int64_t n, m, ngroups;
+    ProbTab tab;
+};
+// one wavefront per column (a landmark's column holds thousands of entries); columns of replicas >= 1 copy replica 0's scale
+__global__ __launch_bounds__(256) void k_rz_cols(RzArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= a.n) return;
+    const RowInfo ri = row_info(a.tab, j);
+    if (!ri.stored) return;
+    double mx = 0.0;
+    for (int k = a.P_ptr[j] + lane; k < a.P_ptr[j + 1]; k += 64) mx = fmax(mx, fabs(a.P_val[k]) * a.D[a.P_col[k]]);
+    for (int k = a.atp[j] + lane; k < a.atp[j + 1]; k += 64) {
+        const uint32_t q = a.atpos[k];
+        mx = fmax(mx, fabs(a.A_val[q]) * a.E[a.arow[q]]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) {
+        mx *= a.D[j];
+        a.d[j] = mx > 1e-12 ? 1.0 / sqrt(mx) : 1.0;
+    }
+}
+__global__ __launch_bounds__(256) void k_rz_groups(RzArgs a) {
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.ngroups) return;
+    const int r0 = a.gstart[g];
+    const int rend = g + 1 < a.ngroups ? a.gstart[g + 1] : (int)a.m;
+    // (replicated: the head row and the first tail row stand for the whole cone)
+    const int r1 = a.tab.rep > 1 ? min(r0 + 2, rend) : rend;
+    double mx = 0.0;
+    for (int k = a.A_ptr[r0]; k < a.A_ptr[r1]; ++k) mx = fmax(mx, fabs(a.A_val[k]) * a.D[a.A_col[k]]);
+    mx *= a.E[r0];
+    a.e[g] = mx > 1e-12 ? 1.0 / sqrt(mx) : 1.0;
+}
+__global__ __launch_bounds__(256) void k_rz_apply(RzArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < a.n) {
+        const RowInfo ri = row_info(a.tab, i);
+        if (ri.stored) {
+            const double v = a.D[i] * a.d[i];
+            a.D[i] = v;
+            if (a.tab.rep > 1 && ri.i0 == i && i - a.tab.xoff[ri.prob] < a.tab.nr[ri.prob]) {
+                const int64_t nr = a.tab.nr[ri.prob];
+                for (int q = 1; q < a.tab.rep; ++q) a.D[i + q * nr] = v;
+            }
+        }
+    }
+    if (i < a.ngroups) {
+        const double eg = a.e[i];
+        const int rend = i + 1 < a.ngroups ? a.gstart[i + 1] : (int)a.m;
+        for (int r = a.gstart[i]; r < rend; ++r) a.E[r] *= eg;
+    }
+}
+
+// ---- G1 = A' (stored rows), G2 = [P | A'] (all rows), the equilibrated A, q, b, 1/D, 1/E ----
+struct GDevArgs {
+    int64_t n, m, nnzA;
+    ProbTab tab;
+    const int32_t* P_ptr; const int32_t* P_col; const double* P_val;   // raw
+    const int32_t* A_col; const double* A_val;                          // raw
+    const int32_t* atp; const uint32_t* atpos; const int32_t* arow;
+    const double* D; const double* E;
+    long long* len1; long long* len2;                                    // n + 1 each: row lengths, then (exclusive scan) row starts
+    int32_t* g1_ptr; int32_t* g2_ptr; int32_t* g2_split;
+    int32_t* oA_col; double* oA_val;
+    int32_t* g1_col; double* g1_val; int32_t* g2_col; double* g2_val;
+    const double* q_raw; const double* b_raw; double* q; double* b; double* invD; double* invE;
+};
+__global__ __launch_bounds__(256) void k_g_lengths(GDevArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i > a.n) return;
+    if (i == a.n) { a.len1[i] = 0; a.len2[i] = 0; return; }
+    const RowInfo ri = row_info(a.tab, i);
+    const int np = a.P_ptr[ri.i0 + 1] - a.P_ptr[ri.i0], nt = a.atp[i + 1] - a.atp[i];
+    a.len1[i] = ri.stored ? nt : 0;
+    a.len2[i] = np + nt;
+}
+__global__ __launch_bounds__(256) void k_g_ptrs(GDevArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i > a.n) return;
+    a.g1_ptr[i] = (int32_t)a.len1[i];
+    a.g2_ptr[i] = (int32_t)a.len2[i];
+}
+__global__ __launch_bounds__(256) void k_g_scale_a(GDevArgs a) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k < a.nnzA) {
+        const int32_t c = a.A_col[k];
+        a.oA_col[k] = c;
+        a.oA_val[k] = (a.A_val[k] * a.E[a.arow[k]]) * a.D[c];
+    }
+    if (k < a.n) { const double d = a.D[k]; a.q[k] = a.q_raw[k] * d; a.invD[k] = 1.0 / d; }
+    if (k < a.m) { const double e = a.E[k]; a.b[k] = a.b_raw[k] * e; a.invE[k] = 1.0 / e; }
+}
+// a wavefront per row i of G2 (= column i of A): P part, then the entries of A' (also into G1 when the row is stored)
+__global__ __launch_bounds__(256) void k_g_fill(GDevArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.n) return;
+    const RowInfo ri = row_info(a.tab, i);
+    const double di = a.D[i];
+    const int k0 = a.P_ptr[ri.i0], np = a.P_ptr[ri.i0 + 1] - k0, o2 = a.g2_ptr[i];
+    for (int l = lane; l < np; l += 64) {
+        const int32_t c = a.P_col[k0 + l] + ri.shift;
+        a.g2_col[o2 + l] = c;
+        a.g2_val[o2 + l] = (a.P_val[k0 + l] * di) * a.D[c];
+    }
+    const int t0 = a.atp[i], nt = a.atp[i + 1] - t0, s2 = o2 + np, s1 = ri.stored ? a.g1_ptr[i] : 0;
+    if (lane == 0) a.g2_split[i] = s2;
+    for (int l = lane; l < nt; l += 64) {
+        const uint32_t q = a.atpos[t0 + l];
+        const int32_t c = (int32_t)a.n + a.arow[q];
+        const double v = a.oA_val[q];
+        a.g2_col[s2 + l] = c;
+        a.g2_val[s2 + l] = v;
+        if (ri.stored) { a.g1_col[s1 + l] = c; a.g1_val[s1 + l] = v; }
+    }
+}
+// per problem: |q|_inf and |b|_inf, unscaled and scaled (the scales of the residual tests); one workgroup per problem
+__global__ __launch_bounds__(256) void k_prob_norms(ProbTab tab, const double* __restrict__ q_raw, const double* __restrict__ q,
+                                                    const double* __restrict__ b_raw, const double* __restrict__ b, double* __restrict__ out) {
+    const int p = blockIdx.x;
+    double v[4] = {0, 0, 0, 0};
+    for (int64_t i = tab.xoff[p] + threadIdx.x; i < tab.xoff[p + 1]; i += 256) { v[0] = fmax(v[0], fabs(q_raw[i])); v[1] = fmax(v[1], fabs(q[i])); }
+    for (int64_t r = tab.roff[p] + threadIdx.x; r < tab.roff[p + 1]; r += 256) { v[2] = fmax(v[2], fabs(b_raw[r])); v[3] = fmax(v[3], fabs(b[r])); }
+    __shared__ double sh[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[c] = fmax(v[c], __shfl_xor(v[c], o, 64));
+        if ((threadIdx.x & 63) == 0) sh[c][threadIdx.x >> 6] = v[c];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) out[4 * p + threadIdx.x] = fmax(fmax(sh[threadIdx.x][0], sh[threadIdx.x][1]), fmax(sh[threadIdx.x][2], sh[threadIdx.x][3]));
+}
+// x = xhat * D, y = yhat * E, s = shat / E into a staging buffer [x | y | s] (score_solve's copy-out)
+__global__ __launch_bounds__(256) void k_unscale(const double* __restrict__ xy, const double* __restrict__ s, const double* __restrict__ D,
+                                                 const double* __restrict__ E, double* __restrict__ out, int64_t n, int64_t m) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = xy[i] * D[i];
+    if (i < m) { out[n + i] = xy[n + i] * E[i]; out[n + m + i] = s[i] / E[i]; }
+}
+
+// ---- records -> CSR with summed values: the merge step shared by the builders of K (and of P, device assembler) ----
+// A builder lays records out in the host loop's order: key = row << 32 | column (row = n: padding, sorts last), two values
+// per record.  After the stable sort by key an entry is a run of equal keys; it adds its records ONE AFTER THE OTHER in that
+// order (what the host's merge does) -- a run of more than kLongRun records is handed to a wavefront (k_rec_long).
+constexpr int kLongRun = 48;
+struct RecArgs {
+    int64_t n_rows, rec_max;
+    const unsigned long long* key;   // sorted
+    const uint32_t* idx;             // sorted: position of the record before the sort
+    const double* v0; const double* v1;   // by position before the sort (v1 may be null)
+    unsigned long long* flag;        // per sorted record: starts an entry; then its inclusive scan
+    int32_t* row_cnt;                // n_rows + 1, zeroed: entries per row
+    int32_t* col; double* o0; double* o1;   // per entry (o1 may be null)
+    long long* result;               // [0] entries, [1] long runs
+    int4* long_run;                  // {first sorted record, length, entry, 0}
+    int32_t long_max;
+    int32_t qcol;                    // >= 0: a record of this column is the row's entry of a dense vector (qout), not of the matrix
+    double* qout;
+};
+__global__ __launch_bounds__(256) void k_rec_flags(RecArgs a) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.rec_max) return;
+    const unsigned long long k = a.key[s];
+    unsigned long long f = 0;
+    if ((int64_t)(k >> 32) < a.n_rows && (int32_t)(uint32_t)(k & 0xffffffffull) != a.qcol && (s == 0 || a.key[s - 1] != k)) f = 1;
+    a.flag[s] = f;
+}
+__global__ __launch_bounds__(256) void k_rec_merge(RecArgs a) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.rec_max) return;
+    const unsigned long long k = a.key[s];
+    const int64_t row = (int64_t)(k >> 32);
+    if (row >= a.n_rows) return;
+    if (s > 0 && a.key[s - 1] == k) return;  // (not the first record of its run)
+    const int32_t j = (int32_t)(uint32_t)(k & 0xffffffffull);
+    int64_t len = 1;
+    while (s + len < a.rec_max && a.key[s + len] == k && len <= kLongRun) ++len;
+    const bool is_q = a.qcol >= 0 && j == a.qcol;
+    const int64_t e = is_q ? -1 : (int64_t)a.flag[s] - 1;
+    if (!is_q) {
+        a.col[e] = j;
+        atomicAdd(&a.row_cnt[row], 1);
+    }
+    if (len > kLongRun) {
+        const unsigned long long slot = atomicAdd((unsigned long long*)&a.result[1], 1ull);
+        if ((int64_t)slot < a.long_max) a.long_run[slot] = make_int4((int)s, is_q ? -1 : 0, (int)(is_q ? row : e), 0);
+        return;
+    }
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t t = 0; t < len; ++t) {
+        const uint32_t r = a.idx[s + t];
+        s0 += a.v0[r];
+        if (a.v1) s1 += a.v1[r];
+    }
+    if (is_q) a.qout[row] = s0;
+    else {
+        a.o0[e] = s0;
+        if (a.o1) a.o1[e] = s1;
+    }
+}
+// total number of entries: the scan's last value
+__global__ void k_rec_total(RecArgs a) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) a.result[0] = a.rec_max > 0 ? (long long)a.flag[a.rec_max - 1] : 0;
+}
+// one wavefront per long run: 64 records are fetched together, lane 0's order of addition is the records' order
+__global__ __launch_bounds__(256) void k_rec_long(RecArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long n_long = a.result[1] < (long long)a.long_max ? a.result[1] : (long long)a.long_max;
+    if (w >= n_long) return;
+    const int4 lr = a.long_run[w];
+    const int64_t s = lr.x;
+    const unsigned long long k = a.key[s];
+    double s0 = 0.0, s1 = 0.0;
+    for (int64_t base = s;; base += 64) {
+        const int64_t t = base + lane;
+        const bool mine = t < a.rec_max && a.key[t] == k;
+        double x0 = 0.0, x1 = 0.0;
+        if (mine) {
+            const uint32_t r = a.idx[t];
+            x0 = a.v0[r];
+            if (a.v1) x1 = a.v1[r];
+        }
+        const unsigned long long live = __ballot(mine);
+        const int cnt = __popcll(live);  // (a run is contiguous: the live lanes are 0 .. cnt - 1)
+        for (int l = 0; l < cnt; ++l) {
+            s0 += __shfl(x0, l, 64);
+            s1 += __shfl(x1, l, 64);
+        }
+        if (cnt < 64) break;
+    }
+    if (lane == 0) {
+        if (lr.y < 0) a.qout[lr.z] = s0;
+        else {
+            a.o0[lr.z] = s0;
+            if (a.o1) a.o1[lr.z] = s1;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_cnt_to_ll(const int32_t* __restrict__ cnt, long long* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = cnt[i];
+}
+__global__ __launch_bounds__(256) void k_ll_to_i32(const long long* __restrict__ in, int32_t* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = (int32_t)in[i];
+}
+__global__ __launch_bounds__(256) void k_rec_pad(unsigned long long* __restrict__ key, uint32_t* __restrict__ idx, const long long* __restrict__ used,
+                                                 int64_t rec_max, int64_t n_rows) {
+    const int64_t s = used[0] + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= rec_max) return;
+    key[s] = (unsigned long long)n_rows << 32;
+    idx[s] = 0;
+}
+
+// ---- K = P + sigma I + rho A'A as K0 + rho K1: the records of every stored row (append_problem, score_host.hpp) ----
+struct KBuildArgs {
+    int64_t n;
+    ProbTab tab;
+    double sigma;
+    const int32_t* g2_ptr; const int32_t* g2_split; const int32_t* g2_col; const double* g2_val;  // equilibrated [P | A']
+    const int32_t* A_ptr; const int32_t* A_col; const double* A_val;                                // equilibrated A, global
+    long long* rec_cnt;      // n + 1: records per row, then (exclusive scan) first record of every row
+    unsigned long long* key; uint32_t* idx; double* v0; double* v1;
+};
+__global__ __launch_bounds__(256) void k_kb_count(KBuildArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i > a.n) return;
+    if (i == a.n) { if (lane == 0) a.rec_cnt[i] = 0; return; }
+    const RowInfo ri = row_info(a.tab, i);
+    if (!ri.stored) { if (lane == 0) a.rec_cnt[i] = 0; return; }
+    const int p0 = a.g2_ptr[i], sp = a.g2_split[i], p1 = a.g2_ptr[i + 1];
+    long long c = 0;
+    for (int t = sp + lane; t < p1; t += 64) {
+        const int r = a.g2_col[t] - (int32_t)a.n;
+        c += a.A_ptr[r + 1] - a.A_ptr[r];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if (lane == 0) a.rec_cnt[i] = 1 + (long long)(sp - p0) + c;
+}
+__global__ __launch_bounds__(256) void k_kb_expand(KBuildArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= a.n) return;
+    const RowInfo ri = row_info(a.tab, i);
+    if (!ri.stored) return;
+    long long base = a.rec_cnt[i];
+    const unsigned long long hi = (unsigned long long)i << 32;
+    auto put = [&](long long o, int32_t j, double x0, double x1) {
+        a.key[o] = hi | (unsigned long long)(uint32_t)j;
+        a.idx[o] = (uint32_t)o;
+        a.v0[o] = x0; a.v1[o] = x1;
+    };
+    if (lane == 0) put(base, (int32_t)i, a.sigma, 0.0);
+    ++base;
+    const int p0 = a.g2_ptr[i], sp = a.g2_split[i], p1 = a.g2_ptr[i + 1];
+    for (int k = p0 + lane; k < sp; k += 64) put(base + (k - p0), a.g2_col[k], a.g2_val[k], 0.0);
+    base += sp - p0;
+    for (int t0 = sp; t0 < p1; t0 += 64) {
+        const int t = t0 + lane;
+        int r = 0;
+        double av = 0.0;
+        long long mine = 0;
+        if (t < p1) {
+            r = a.g2_col[t] - (int32_t)a.n;
+            av = a.g2_val[t];
+            mine = a.A_ptr[r + 1] - a.A_ptr[r];
+        }
+        long long incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const long long up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        long long o = base + incl - mine;
+        if (t < p1)
+            for (int kk = a.A_ptr[r]; kk < a.A_ptr[r + 1]; ++kk, ++o) put(o, a.A_col[kk], 0.0, av * a.A_val[kk]);
+        base += __shfl(incl, 63, 64);
+    }
+}
+
+// ---- the structure the Newton polish needs per cone (polish_structure, score_polish_host.hpp), from the device matrices ----
+struct PStructArgs {
+    int64_t ncones, n;
+    int32_t T;
+    const int32_t* cone_row; const int32_t* cone_dim; const int32_t* cone_type;
+    const int32_t* A_ptr; const int32_t* A_col; const double* A_val; const double* b; const double* q;
+    const int32_t* g2_ptr; const int32_t* g2_split; const int32_t* g2_col; const double* g2_val;
+    int32_t* head_col; int32_t* is_head; double* a_abs; double* ck; double* theta; double* xstar;
+    int32_t* bad;      // [0]: cones that do not have the structure
+};
+__global__ __launch_bounds__(256) void k_polish_structure(PStructArgs a) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (k >= a.ncones) return;
+    bool ok = a.cone_type[k] == 1 && a.cone_dim[k] - 1 == a.T;
+    const int r0 = a.cone_row[k];
+    ok = ok && (a.A_ptr[r0 + 1] - a.A_ptr[r0] == 1);
+    int32_t h = 0;
+    double av = -1.0, phh = 1.0;
+    if (ok) {
+        h = a.A_col[a.A_ptr[r0]];
+        av = a.A_val[a.A_ptr[r0]];
+        ok = (av < 0.0) && a.b[r0] == 0.0;
+        ok = ok && (a.g2_ptr[h + 1] - a.g2_split[h] == 1) && (a.g2_split[h] - a.g2_ptr[h] == 1) && a.g2_col[a.g2_ptr[h]] == h;
+        if (ok) {
+            phh = a.g2_val[a.g2_ptr[h]];
+            ok = phh > 0.0;
+        }
+    }
+    if (!ok) { atomicAdd(a.bad, 1); return; }
+    a.head_col[k] = h;
+    a.is_head[h] = 1;
+    a.a_abs[k] = -av;
+    a.ck[k] = phh / (av * av);
+    const double xs = -a.q[h] / phh;
+    a.xstar[k] = xs;
+    a.theta[k] = -av * xs;
+}
+// sum over the cones of (entries of the cone's tail rows)^2: the contribution bound of the Newton matrix's records
+__global__ __launch_bounds__(256) void k_cone_sq(const int32_t* __restrict__ cone_row, const int32_t* __restrict__ A_ptr, int64_t ncones, int T,
+                                                 unsigned long long* __restrict__ out) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned long long v = 0;
+    if (k < ncones) {
+        const int r0 = cone_row[k];
+        const unsigned long long L = (unsigned long long)(A_ptr[r0 + 1 + T] - A_ptr[r0 + 1]);
+        v = L * L;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+}  // namespace score

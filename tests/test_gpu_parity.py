@@ -172,6 +172,7 @@ def test_device_derived_a_g1_g2_equal_the_host_arrays(fixtures, hip_lib, monkeyp
     from score_amd.manhattan import make_config
     from score_amd.native import assemble_native
 
+    monkeypatch.setenv("SCORE_HOST_SETUP", "1")  # (the host-side setup and its device-derived pieces: the default builds everything on the device)
     cases = [assemble_native(graph_by_name(nm, fixtures), "SOCP", lib_path=hip_lib).qp for nm in ("synth_a", "synth_b", "graph3d", "prior2d")]
     cases.append(assemble_native(make_config(3), "SOCP", lib_path=hip_lib).qp)
     for k, qp in enumerate(cases):
@@ -217,6 +218,7 @@ def test_device_built_newton_matrix_equals_the_host_build(fixtures, hip_lib, mon
     from score_amd.native import assemble_native
 
     cases.append([assemble_native(make_config(3), "SOCP", lib_path=hip_lib).qp])  # BASELINE configs[3]: 20 x 1000 poses, landmark rows of thousands of entries
+    monkeypatch.setenv("SCORE_HOST_SETUP", "1")  # (polish_build_check compares with the host loop, which reads the host-side matrices)
     for qps in cases:
         monkeypatch.delenv("SCORE_HOST_POLISH_BUILD", raising=False)
         dev = ConicSolver(qps, {}, lib_path=hip_lib)
@@ -235,6 +237,58 @@ def test_device_built_newton_matrix_equals_the_host_build(fixtures, hip_lib, mon
         for a, b in zip(sd, sh):
             assert a.solved and b.solved
             assert np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y) and a.info["newton_iters"] == b.info["newton_iters"]
+
+
+_SETUP_INT = ("Aptr", "Acol", "G1ptr", "G1col", "G2ptr", "G2split", "G2col", "Kptr", "Kcol", "Kptr_dev", "Kcol_dev", "Hptr", "Hcol")
+_SETUP_VAL = ("D", "E", "invD", "invE", "qs", "bs", "Aval", "G1val", "G2val", "K0", "K1", "Kval", "setup_scalars")
+
+
+def test_device_setup_equals_the_host_setup(fixtures, hip_lib, monkeypatch):
+    """f2: score_create builds every matrix of a handle ON THE DEVICE from the raw program (score_setup_device.hpp): the A' map
+    (a stable sort of the columns), the equilibration over the block-diagonal batch, the equilibrated A, G1 = A', G2 = [P | A'],
+    q, b, and K = P + sigma I + rho A'A as K0 + rho K1 (records in the host loop's order, stable radix sort, an entry adds its
+    records in order).  Against the host setup (build_system, SCORE_HOST_SETUP=1; its equilibration on the device too, so that
+    both sides start from the same scales): every pattern equal entry by entry, every value array equal BIT FOR BIT -- 2-D, 3-D,
+    loop closures, priors, the direct QCQP form, general (non-replicated) problems, a lock-step batch of different sizes, a
+    landmark seen by thousands of ranges, BASELINE configs[3] -- and the default solves agree to the last bit."""
+    _hip_only(hip_lib)
+    from score_amd.manhattan import make_config
+    from score_amd.native import assemble_native
+
+    cases = [([assemble_native(graph_by_name(nm, fixtures), "SOCP", lib_path=hip_lib).qp], {}) for nm in ("synth_a", "synth_b", "graph3d", "prior2d", "goats")]
+    cases.append(([assemble_native(graph_by_name("synth_d", fixtures), "QCQP", lib_path=hip_lib).qp], dict(cg_iters=8, adaptive_rho=0)))
+    cases.append(([assemble(graph_by_name("synth_c", fixtures), "SOCP").qp], {}))
+    cases.append(([assemble_native(make_manhattan(n_robots=2 + k, n_poses=300 + 170 * k, n_beacons=2, seed=90 + k), "SOCP", lib_path=hip_lib).qp for k in range(3)], {}))
+    cases.append(([assemble_native(make_manhattan(n_robots=4, n_poses=1500, n_beacons=1, seed=61, p_range=0.4), "SOCP", lib_path=hip_lib).qp], {}))
+    cases.append(([assemble_native(make_config(3), "SOCP", lib_path=hip_lib).qp], {}))
+    monkeypatch.setenv("SCORE_BATCH_DEVICE_RUIZ", "1")
+    for k, (qps, st) in enumerate(cases):
+        for norep in (False, True):
+            if norep:
+                monkeypatch.setenv("SCORE_NO_REPLICATION", "1")
+            monkeypatch.delenv("SCORE_HOST_SETUP", raising=False)
+            dev = ConicSolver(qps, st, lib_path=hip_lib)
+            assert dev.debug_get("device_setup")[0] == 1.0, "the matrices were not built on the device"
+            monkeypatch.setenv("SCORE_HOST_SETUP", "1")
+            host = ConicSolver(qps, st, lib_path=hip_lib)
+            assert host.debug_get("device_setup")[0] == 0.0
+            monkeypatch.delenv("SCORE_HOST_SETUP", raising=False)
+            for nm in _SETUP_INT + _SETUP_VAL:
+                if nm in ("Hptr", "Hcol") and st:  # (the direct QCQP form has no Newton matrix)
+                    continue
+                a, b = dev.debug_get(nm), host.debug_get(nm)
+                assert a.shape == b.shape and a.size > 0, (k, norep, nm, a.shape, b.shape)
+                bad = np.nonzero(a != b)[0]
+                assert bad.size == 0, (k, norep, nm, bad[:5], a[bad[:5]], b[bad[:5]])
+            sd, sh = dev.solve(), host.solve()
+            dev.close(); host.close()
+            for x, y in zip(sd, sh):
+                assert x.solved and y.solved
+                assert np.array_equal(x.x, y.x) and np.array_equal(x.y, y.y) and np.array_equal(x.s, y.s)
+                assert x.info["newton_iters"] == y.info["newton_iters"] and x.info["pobj"] == y.info["pobj"]
+            monkeypatch.delenv("SCORE_NO_REPLICATION", raising=False)
+            if k not in (0, 2, 7):
+                break  # (the general kernels on the full K: a 2-D graph, the 3-D one, the batch)
 
 
 def test_xcd_aware_tile_order_changes_no_bit(fixtures, hip_lib, monkeypatch):
