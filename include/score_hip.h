@@ -163,6 +163,31 @@ int  score_create(const score_problem* p, const score_settings* s, score_handle*
 int  score_create_batch(const score_problem* p, int32_t count, const score_settings* s,
                         score_handle** out);
 
+/* A handle for `count` factor graphs (struct score_graph, below), model construction included: the whole of the reference's
+ * `initialize_model` (gurobi_utils.py:173-187: variables :221-310, pin :316-333, cones :336-352, objective :358-526) plus the
+ * model's creation (:206-215) in one call.  The graphs' flat arrays are all that crosses to the device: every measurement
+ * writes its terms there, the conic program (P, q, A, b) is merged from them and equilibrated, K, A' and the Newton matrix are
+ * built from it -- the program score_assemble would build, entry by entry (bit-equal P, q, A, b; the host assembler stays as
+ * the specification and takes over when the device path is switched off: SCORE_HOST_ASSEMBLE / SCORE_HOST_SETUP).  Unknowns
+ * are ordered as score_assemble orders them; solutions come back through score_solve as for any other handle.            */
+struct score_graph;
+int  score_create_from_graphs(const struct score_graph* graphs, int32_t count, const score_settings* s,
+                              score_handle** out);
+
+/* After a solve of a handle made by score_create_from_graphs: the estimate in the reference's own shapes, straight from the
+ * solution on the device -- replaces VariableCollection.get_variable_values (gurobi_utils.py:114-136; extract_solver_results
+ * :190-203 wraps it).  Problem after problem:
+ *   poses      n_poses x (d+1) x (d+1)  homogeneous [[R, t], [0, 1]], R = the relaxed block rounded onto SO(d) as
+ *                                       score_round_to_so rounds it (gurobi_utils.py:115-125); pose 0 is the pinned [I | 0]
+ *   relaxed    n_poses x d x (d+1)      the relaxation's own blocks [R | t]
+ *   landmarks  n_landmarks x d
+ *   ranges     n_ranges x 1 (SOCP distances) or x d (QCQP directions; qcqp_directions != 0 on an SOCP program: the optimal
+ *                                       directions r = D / max(|D|, dist) of the equivalent QCQP, gurobi_utils.py:488-496)
+ *   degenerate n_poses                  1 where the rounding is not unique (the block is the identity then)
+ * Any output may be NULL.  Handles made from score_problem arrays do not know the graph: error.                            */
+int  score_read_estimates(score_handle* h, int32_t qcqp_directions, double* poses, double* relaxed, double* landmarks,
+                          double* ranges, int32_t* degenerate);
+
 /* Concatenated sizes of the handle's problems (sum of n, sum of m, count).  */
 int  score_dims(const score_handle* h, int64_t* n_total, int64_t* m_total, int32_t* count);
 
@@ -323,8 +348,8 @@ const char* score_backend(void);   /* "hip-gfx950" or "cpu-twin"             */
  * struct, say) would be misread silently -- score_create_batch walks an ARRAY of score_problem, so a
  * stale stride goes wrong from the second problem on.  Bump SCORE_ABI_VERSION whenever a struct changes;
  * loaders compare (score_amd.solver.load_library does).  History: 1 = rounds 1-2, 2 = score_problem
- * gained rep_d / rep_n, 3 = this function.                                                        */
-#define SCORE_ABI_VERSION 4
+ * gained rep_d / rep_n, 3 = this function, 4 = score_assemble_batch, 5 = score_create_from_graphs.                                                        */
+#define SCORE_ABI_VERSION 5
 int32_t score_abi_version(void);   /* SCORE_ABI_VERSION of the library's build, times 1000, plus sizeof(score_problem) */
 
 #ifdef __cplusplus

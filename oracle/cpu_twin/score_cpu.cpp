@@ -73,7 +73,8 @@ struct CpuBackend {
     void cg_reduction(std::vector<double>& out) { out = cg_red; }
 
     bool device_setup_ok(const HostSystem&, const score_problem*, const score_settings&) const { return false; }  // (the twin IS the host setup)
-    void init(const HostSystem& h, const score_settings& s_, const score_problem* = nullptr) {
+    bool device_setup_ok_graphs(const HostSystem&, const score_graph*, const score_settings&) const { return false; }
+    void init(const HostSystem& h, const score_settings& s_, const score_problem* = nullptr, const score_graph* = nullptr) {
         H = &h;
         st = s_;
         xtu.assign(h.n_tot + h.m_tot, 0.0);
@@ -577,6 +578,35 @@ int score_create_batch(const score_problem* p, int32_t count, const score_settin
 }
 int score_create(const score_problem* p, const score_settings* s, score_handle** out) {
     return score_create_batch(p, 1, s, out);
+}
+// (the twin builds the model with the host assembler -- the specification the product's device assembler is tested against)
+int score_create_from_graphs(const score_graph* graphs, int32_t count, const score_settings* s, score_handle** out) {
+    try {
+        if (!graphs || !out || count <= 0) throw std::runtime_error("null argument");
+        std::vector<score::AssembledQP> qps((size_t)count);
+        std::vector<score::AssembledQP*> ptrs((size_t)count);
+        for (int i = 0; i < count; ++i) ptrs[(size_t)i] = &qps[(size_t)i];
+        score::assemble_graphs(graphs, count, ptrs.data());
+        std::vector<score_problem> probs((size_t)count);
+        for (int i = 0; i < count; ++i) qps[(size_t)i].view(&probs[(size_t)i]);
+        const int rc = score_create_batch(probs.data(), count, s, out);
+        if (rc == 0) score::est_layout_from_graphs(graphs, count, (*out)->solver.H.xoff, (*out)->solver.est);
+        return rc;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+int score_read_estimates(score_handle* h, int32_t qcqp_directions, double* poses, double* relaxed, double* landmarks, double* ranges,
+                         int32_t* degenerate) {
+    try {
+        if (!h) throw std::runtime_error("null handle");
+        if (!h->solver.est.valid()) throw std::runtime_error("score_read_estimates: the handle was not made by score_create_from_graphs");
+        std::vector<double> x((size_t)h->solver.H.n_tot);
+        h->solver.be.download(h->solver.H, x.data(), nullptr, nullptr);
+        score::read_estimates_host(h->solver.est, qcqp_directions, x.data(), poses, relaxed, landmarks, ranges, degenerate);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 int score_dims(const score_handle* h, int64_t* n_total, int64_t* m_total, int32_t* count) {
     if (!h) { g_err = "null handle"; return -1; }

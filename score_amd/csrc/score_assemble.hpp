@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "score_host.hpp"
+#include "score_round.hpp"
 
 namespace score {
 
@@ -377,6 +378,200 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
         }
     }
     pt.mark("assemble: cones");
+}
+
+// The SKELETON of the program assemble_graph builds: sizes, cone dimensions, the chain and replication hints and the
+// objective constant c0 -- everything a handle's host side needs when the matrices themselves are built on the device from the
+// graph's arrays (score_create_from_graphs; score_setup_device.hpp, k_ga_*).  Same checks, same messages as assemble_graph;
+// c0 is accumulated in assemble_graph's order (measurement by measurement), so it is the same double.
+inline void graph_skeleton(const score_graph& g, AssembledQP& out) {
+    const int d = g.dim;
+    if (d != 2 && d != 3) throw std::runtime_error("score_graph: dim must be 2 or 3");
+    if (g.relaxation != 0 && g.relaxation != 1) throw std::runtime_error("score_graph: relaxation must be 0 (SOCP) or 1 (QCQP)");
+    if (g.n_chains <= 0 || !g.chain_len) throw std::runtime_error("score_graph: no pose chains");
+    const int D1 = d + 1;
+    int64_t Np = 0;
+    for (int c = 0; c < g.n_chains; ++c) {
+        if (g.chain_len[c] < 0) throw std::runtime_error("score_graph: negative chain length");
+        Np += g.chain_len[c];
+    }
+    if (Np == 0 || g.chain_len[0] == 0) throw std::runtime_error("factor graph has no pose variables");
+    const int64_t Nl = g.n_landmarks, Nr = g.n_rng;
+    const int64_t n_rep = (Np - 1) * D1 + Nl + (g.relaxation == 0 ? 0 : Nr);
+    const int64_t rng_base = (int64_t)d * n_rep;
+    const int64_t n = rng_base + (g.relaxation == 0 ? Nr : 0);
+    if (n >= ((int64_t)1 << 31)) throw std::runtime_error("score_graph: too many unknowns");
+    out = AssembledQP();
+    out.dim = d; out.relaxation = g.relaxation;
+    out.n = (int32_t)n; out.m = (int32_t)(Nr * D1);
+    out.rep_n = (int32_t)n_rep;
+    out.block_size = D1;
+    out.soc_dims.assign((size_t)Nr, D1);
+    out.chain_ptr.assign(1, 0);
+    {
+        std::vector<int64_t> chain_col, chain_free;
+        int64_t col = 0;
+        for (int c = 0; c < g.n_chains; ++c) {
+            const int64_t Lfree = (int64_t)g.chain_len[c] - (c == 0 ? 1 : 0);
+            chain_col.push_back(col);
+            chain_free.push_back(Lfree);
+            col += Lfree * D1;
+        }
+        for (int k = 0; k < d; ++k)
+            for (int c = 0; c < g.n_chains; ++c) {
+                if (chain_free[(size_t)c] <= 0) continue;
+                for (int64_t node = 0; node < chain_free[(size_t)c]; ++node)
+                    out.node_first_col.push_back((int32_t)(k * n_rep + chain_col[(size_t)c] + node * D1));
+                out.chain_ptr.push_back(out.chain_ptr.back() + (int32_t)chain_free[(size_t)c]);
+            }
+    }
+    double c0 = 0.0;
+    for (int64_t e = 0; e < g.n_rel; ++e) {
+        const int64_t i = g.rel_base[e], j = g.rel_to[e];
+        if (i < 0 || i >= Np || j < 0 || j >= Np) throw std::runtime_error("score_graph: relative-pose endpoint out of range");
+        if (i != 0 && j != 0) continue;  // (only measurements at the pinned pose leave a constant)
+        const double* tm = g.rel_t + e * d;
+        const double* Rm = g.rel_R + e * d * d;
+        const double kap = g.rel_kappa[e], tau = g.rel_tau[e];
+        double G[4][4] = {{0}}, W[4];
+        for (int c = 0; c < d; ++c) {
+            for (int l = 0; l < d; ++l) G[c][l] = Rm[l * d + c];
+            W[c] = tau;
+        }
+        for (int l = 0; l < d; ++l) G[d][l] = tm[l];
+        G[d][d] = 1.0;
+        W[d] = kap;
+        for (int k = 0; k < d; ++k) {
+            double ui[4] = {0, 0, 0, 0}, uj[4] = {0, 0, 0, 0};
+            ui[k] = 1.0; uj[k] = 1.0;
+            if (j != 0 && i == 0) {
+                for (int a = 0; a < D1; ++a) {
+                    double gu = 0;
+                    for (int l = 0; l < D1; ++l) gu += G[a][l] * ui[l];
+                    c0 += W[a] * gu * gu;
+                }
+            }
+            if (i != 0 && j == 0)
+                for (int c = 0; c < D1; ++c) c0 += W[c] * uj[c] * uj[c];
+            if (i == 0 && j == 0)
+                for (int a = 0; a < D1; ++a) {
+                    double gu = 0;
+                    for (int l = 0; l < D1; ++l) gu += G[a][l] * ui[l];
+                    c0 += W[a] * (uj[a] - gu) * (uj[a] - gu);
+                }
+        }
+    }
+    for (int64_t r = 0; r < Nr; ++r) {
+        const int64_t va = g.rng_a[r], vb = g.rng_b[r];
+        if (va < 0 || va >= Np + Nl || vb < 0 || vb >= Np + Nl) throw std::runtime_error("score_graph: range endpoint out of range");
+        if (g.relaxation == 0) {
+            if (va == vb && va != 0) throw std::runtime_error("score_graph: range between a variable and itself");
+            const double w = g.rng_prec[r], dist = g.rng_dist[r];
+            c0 += w * dist * dist;
+        }
+    }
+    for (int64_t e = 0; e < g.n_lprior; ++e) {
+        const int64_t l = g.lprior_lm[e];
+        if (l < 0 || l >= Nl) throw std::runtime_error("score_graph: landmark prior out of range");
+        const double w = g.lprior_prec[e];
+        for (int k = 0; k < d; ++k) {
+            const double tv = g.lprior_t[e * d + k];
+            c0 += w * tv * tv;
+        }
+    }
+    out.c0 = c0;
+}
+
+// What a handle made from factor graphs remembers of them for score_read_estimates: per problem its offsets and counts, and the
+// range endpoints / measured distances (the QCQP directions of a program solved through the SOCP are r = D / max(|D|, dist)).
+struct EstProb {
+    int32_t xoff, Np, Nl, Nr, n_rep;
+    int32_t pose_off, lm_off, rng_off;   // first pose / landmark / range of the problem in the concatenated outputs
+};
+struct EstLayout {
+    int32_t d = 0, relaxation = 0;
+    std::vector<EstProb> probs;
+    std::vector<int32_t> rng_a, rng_b;   // concatenated, problem-local variable ids
+    std::vector<double> rng_dist;
+    int64_t n_pose = 0, n_lm = 0, n_rng = 0;
+    bool valid() const { return !probs.empty(); }
+};
+inline void est_layout_from_graphs(const score_graph* graphs, int count, const std::vector<int64_t>& xoff, EstLayout& L) {
+    L = EstLayout();
+    L.d = graphs[0].dim; L.relaxation = graphs[0].relaxation;
+    const int D1 = L.d + 1;
+    for (int p = 0; p < count; ++p) {
+        const score_graph& g = graphs[p];
+        int64_t Np = 0;
+        for (int c = 0; c < g.n_chains; ++c) Np += g.chain_len[c];
+        EstProb e{};
+        e.xoff = (int32_t)xoff[(size_t)p]; e.Np = (int32_t)Np; e.Nl = g.n_landmarks; e.Nr = (int32_t)g.n_rng;
+        e.n_rep = (int32_t)((Np - 1) * D1 + g.n_landmarks + (g.relaxation == 0 ? 0 : g.n_rng));
+        e.pose_off = (int32_t)L.n_pose; e.lm_off = (int32_t)L.n_lm; e.rng_off = (int32_t)L.n_rng;
+        L.n_pose += Np; L.n_lm += g.n_landmarks; L.n_rng += g.n_rng;
+        L.probs.push_back(e);
+        L.rng_a.insert(L.rng_a.end(), g.rng_a, g.rng_a + g.n_rng);
+        L.rng_b.insert(L.rng_b.end(), g.rng_b, g.rng_b + g.n_rng);
+        L.rng_dist.insert(L.rng_dist.end(), g.rng_dist, g.rng_dist + g.n_rng);
+    }
+}
+// The estimate of every problem of the handle in the reference's own shapes, from the solver-space solution x (unscaled):
+// replaces VariableCollection.get_variable_values (/root/reference/score/utils/gurobi_utils.py:114-136) -- poses as homogeneous
+// (d+1) x (d+1) matrices with the rotation block rounded onto SO(d) (score_round.hpp: the maximiser of tr(R'M), what
+// round_to_special_orthogonal computes; degenerate[i] = 1 where it is not unique: identity then, the caller decides), the
+// relaxation's own blocks [R | t], landmarks, range variables (qcqp_dirs on an SOCP program: the optimal QCQP directions).
+// The host specification of k_read_estimates (and the CPU twin's path).
+inline void read_estimates_host(const EstLayout& L, int qcqp_dirs, const double* x, double* poses, double* relaxed, double* lms,
+                                double* rng, int32_t* degenerate) {
+    const int d = L.d, D1 = d + 1;
+    for (const EstProb& P : L.probs) {
+        auto xv = [&](int64_t local) { return x[(size_t)(P.xoff + local)]; };
+        for (int64_t lp = 0; lp < P.Np; ++lp) {
+            const int64_t i = P.pose_off + lp;
+            double blk[3][4], m[9], r[9];
+            for (int k = 0; k < d; ++k)
+                for (int j = 0; j < D1; ++j) blk[k][j] = lp == 0 ? (j == k ? 1.0 : 0.0) : xv((int64_t)k * P.n_rep + (lp - 1) * D1 + j);
+            for (int k = 0; k < d; ++k)
+                for (int j = 0; j < d; ++j) m[k * d + j] = blk[k][j];
+            int32_t bad = 0;
+            if (d == 2) round_so2(m, r, &bad); else round_so3(m, r, &bad);
+            if (degenerate) degenerate[i] = bad;
+            if (relaxed)
+                for (int k = 0; k < d; ++k)
+                    for (int j = 0; j < D1; ++j) relaxed[(size_t)i * d * D1 + k * D1 + j] = blk[k][j];
+            if (poses) {
+                double* T = poses + (size_t)i * D1 * D1;
+                for (int k = 0; k < d; ++k) {
+                    for (int j = 0; j < d; ++j) T[k * D1 + j] = r[k * d + j];
+                    T[k * D1 + d] = blk[k][d];
+                }
+                for (int j = 0; j < d; ++j) T[d * D1 + j] = 0.0;
+                T[d * D1 + d] = 1.0;
+            }
+        }
+        const int64_t lm0 = (int64_t)(P.Np - 1) * D1;
+        if (lms)
+            for (int64_t l = 0; l < P.Nl; ++l)
+                for (int k = 0; k < d; ++k) lms[(size_t)(P.lm_off + l) * d + k] = xv((int64_t)k * P.n_rep + lm0 + l);
+        if (!rng) continue;
+        auto tvar = [&](int64_t v, int k) {
+            if (v < P.Np) return v == 0 ? 0.0 : xv((int64_t)k * P.n_rep + (v - 1) * D1 + d);
+            return xv((int64_t)k * P.n_rep + lm0 + (v - P.Np));
+        };
+        for (int64_t r_ = 0; r_ < P.Nr; ++r_) {
+            const int64_t i = P.rng_off + r_;
+            if (L.relaxation != 0) {
+                for (int k = 0; k < d; ++k) rng[(size_t)i * d + k] = xv((int64_t)k * P.n_rep + lm0 + P.Nl + r_);
+            } else if (!qcqp_dirs) {
+                rng[(size_t)i] = xv((int64_t)d * P.n_rep + r_);
+            } else {
+                double dl[3], nn = 0.0;
+                for (int k = 0; k < d; ++k) { dl[k] = tvar(L.rng_a[(size_t)i], k) - tvar(L.rng_b[(size_t)i], k); nn += dl[k] * dl[k]; }
+                const double den = std::max(std::sqrt(nn), L.rng_dist[(size_t)i]);
+                for (int k = 0; k < d; ++k) rng[(size_t)i * d + k] = den > 0.0 ? dl[k] / den : 0.0;
+            }
+        }
+    }
 }
 
 // `count` graphs, one graph per part of one parallel region (score_assemble_batch).  out[i] is filled for every i or an

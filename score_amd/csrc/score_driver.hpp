@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "score_host.hpp"
+#include "score_assemble.hpp"
 
 namespace score {
 
@@ -58,6 +59,46 @@ struct Solver {
         build_system(probs, count, st, H, Backend::kFactorOnHost, Backend::allow_rep(), be.ruiz_offload(st),
                      [&](const HostSystem& hs) { return be.device_setup_ok(hs, probs, st); });
         be.init(H, st, probs);
+        infos.assign(count, score_info{});
+        done.assign(count, 0);
+        dual_scale.assign(count, 0.0);
+        setup_ms = now_ms() - t0;
+    }
+
+    // A handle straight from factor graphs (score_create_from_graphs): when the backend can build the model on its device
+    // (Backend::device_setup_ok_graphs) the host only lays out sizes, cones and chains (graph_skeleton) and the graphs'
+    // arrays are all that crosses the link; otherwise the host assembler builds the programs and create() takes over.
+    EstLayout est;  // handles made from factor graphs: what score_read_estimates needs of them
+    template <class AssembleFn>
+    void create_from_graphs(const score_graph* graphs, int count, const score_settings& s, AssembleFn&& assemble_on_host) {
+        const double t0 = now_ms();
+        if (count <= 0) throw std::runtime_error("score_create_from_graphs: count must be positive");
+        struct KeepLayout {  // (filled once the handle exists, whichever path built it)
+            Solver& S; const score_graph* g; int c;
+            ~KeepLayout() { if (!std::uncaught_exceptions() && S.H.count == c) est_layout_from_graphs(g, c, S.H.xoff, S.est); }
+        } keep_layout{*this, graphs, count};
+        std::vector<AssembledQP> skel((size_t)count);
+        std::vector<score_problem> probs((size_t)count);
+        for (int i = 0; i < count; ++i) {
+            try { graph_skeleton(graphs[i], skel[(size_t)i]); }
+            catch (const std::exception& e) { throw std::runtime_error(count > 1 ? "graph " + std::to_string(i) + ": " + e.what() : std::string(e.what())); }
+            skel[(size_t)i].view(&probs[(size_t)i]);
+        }
+        st = s;
+        if (st.check_interval < 1) st.check_interval = 25;
+        if (st.cg_iters < 1) st.cg_iters = 1;
+        if (st.adaptive_rho_interval < st.check_interval) st.adaptive_rho_interval = st.check_interval;
+        if (st.max_cg_iters < st.cg_iters) st.max_cg_iters = st.cg_iters;
+        if (!(st.cg_target > 0.0 && st.cg_target < 1.0)) st.cg_target = 0.5;
+        cg_now = st.cg_iters;
+        try {
+            build_system(probs.data(), count, st, H, Backend::kFactorOnHost, Backend::allow_rep(), nullptr,
+                         [&](const HostSystem& hs) { return be.device_setup_ok_graphs(hs, graphs, st); }, /*trusted=*/true);
+        } catch (const DeviceSetupDeclined&) {  // (the backend declined: model construction on the host, then the ordinary create)
+            assemble_on_host();
+            return;
+        }
+        be.init(H, st, nullptr, graphs);
         infos.assign(count, score_info{});
         done.assign(count, 0);
         dual_scale.assign(count, 0.0);

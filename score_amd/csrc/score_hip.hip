@@ -767,6 +767,7 @@ struct HipBackend {
         if (ev1) (void)hipEventDestroy(ev1);
         block_cache().give(h_rep, h_rep_bytes, st.device, true);
         block_cache().give(h_ring, h_ring_bytes, st.device, true);
+        for (auto& pb : setup_pinned) block_cache().give(pb.first, pb.second, st.device, true);  // (an init that threw: drained above)
         pt.mark("destroy: events, pinned blocks");
         stream_pool().give(st.device, stream);  // (drained above)
         pt.mark("destroy: stream");
@@ -776,6 +777,7 @@ struct HipBackend {
     DevBuf<double> Dd, Ed;                      // the equilibration's scales (the host keeps none)
     DevBuf<int32_t> tab_xoff, tab_roff, tab_nr;  // ProbTab
     DevArena setup_tmp;                          // scratch of the setup: back to the block cache when init() is over
+    std::vector<std::pair<void*, size_t>> setup_pinned;  // ... and its pinned staging blocks
     int64_t g1_nnz = 0, nnzP_full = 0;
     ProbTab prob_tab() const {
         ProbTab t{};
@@ -783,7 +785,7 @@ struct HipBackend {
         return t;
     }
     // asked by build_system once sizes and the replication structure are known
-    bool device_setup_ok(const HostSystem& h, const score_problem* probs, const score_settings& s_) const {
+    bool device_setup_allowed(const HostSystem& h, const score_settings& s_) const {
         if (std::getenv("SCORE_HOST_SETUP") || std::getenv("SCORE_HOST_POLISH_BUILD") || std::getenv("SCORE_FUSED_CONE") ||
             std::getenv("SCORE_NO_DEVICE_RUIZ") || std::getenv("SCORE_NO_DEVICE_AG")) return false;  // (switches that ask for a host-side piece)
         if (h.m_tot <= 0 || s_.chain_split > 0 || band_h(h)) return false;   // (linear mode keeps K0 on the host)
@@ -792,6 +794,23 @@ struct HipBackend {
                 if (!ex) return false;  // (replicas that differ in their last bits: the host uses every replica's own values)
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || s_.device < 0 || s_.device >= ndev) return false;  // (init reports it)
+        return true;
+    }
+    // the same question for handles made from factor graphs (score_create_from_graphs): record bounds by formula
+    bool device_setup_ok_graphs(const HostSystem& h, const score_graph* graphs, const score_settings& s_) const {
+        if (std::getenv("SCORE_HOST_ASSEMBLE") || !device_setup_allowed(h, s_)) return false;
+        const int d = graphs[0].dim, D1 = d + 1;
+        int64_t rec = h.n_tot, con = 0;
+        for (int p = 0; p < h.count; ++p) {
+            const score_graph& g = graphs[p];
+            if (g.dim != d || g.relaxation != graphs[0].relaxation) return false;
+            rec += g.n_rel * (D1 + 3 * D1 * D1) * d + g.n_rng * 9 * d + g.n_lprior * d;
+            con += g.n_rng * (int64_t)(4 * d * d + 1);
+        }
+        return rec + con + 64 < ((int64_t)1 << 31);
+    }
+    bool device_setup_ok(const HostSystem& h, const score_problem* probs, const score_settings& s_) const {
+        if (!device_setup_allowed(h, s_)) return false;
         // record bounds of the K and Newton-matrix builds: 32-bit positions
         int64_t rec = h.n_tot, sq = 0;
         for (int p = 0; p < h.count; ++p) {
@@ -870,22 +889,38 @@ struct HipBackend {
         ~ArenaSwap() { tl_arena = keep; }
     };
 
-    // From the raw problems to A, G1, G2, K (K0 / K1), q, b, 1/D, 1/E on the device; the host gets the row pointers, K's columns
-    // and the norms back and lays out the tiles.  `raw` (device assembler, later): the raw matrices are on the device already.
-    void setup_on_device(HostSystem& h, const score_problem* probs) {
-        PhaseTimer pt(st.verbose != 0);
+    // The raw program of the handle on the device, in global numbering: P (the rows of replica 0 and of the tail), q, A, b.
+    // From the caller's problems (uploads) or from the factor graphs themselves (the device assembler, k_ga_*).
+    struct RawDev {
+        DevBuf<int32_t> Pp, Pc, Ac;
+        DevBuf<double> Pv, Av, qraw, braw;
+        MergeOut pm;                 // (graph path: P as the merge left it)
+        const int32_t* P_ptr = nullptr; const int32_t* P_col = nullptr; const double* P_val = nullptr;
+        std::vector<int32_t> Aptr;   // global row pointers of A (host copy)
+        int64_t pe = 0;              // stored entries of P (graph path: an upper bound)
+        int64_t ae = 0, sq = 0, n_stored = 0, nnzP_full = 0;
+        bool exact = true;           // pe / nnzP_full are exact counts
+    };
+    void fill_tab(const HostSystem& h) {
+        const int count = h.count;
+        std::vector<int32_t> xo32((size_t)count + 1), ro32((size_t)count + 1), nr32((size_t)count, 0);
+        for (int p = 0; p <= count; ++p) { xo32[(size_t)p] = (int32_t)h.xoff[p]; ro32[(size_t)p] = (int32_t)h.roff[p]; }
+        for (int p = 0; p < count; ++p) nr32[(size_t)p] = h.rep > 1 ? (int32_t)h.rep_n[(size_t)p] : 0;
+        ArenaSwap persist(&arena);
+        tab_xoff.upload(xo32); tab_roff.upload(ro32); tab_nr.upload(nr32);
+    }
+    void raw_from_problems(const HostSystem& h, const score_problem* probs, RawDev& R) {
         const int count = h.count;
         const int64_t n = h.n_tot, m = h.m_tot;
         const int rep = h.rep;
         // ---- host: global row pointers of the raw matrices (P: the rows of replica 0 and of the tail), entry offsets ----
-        std::vector<int32_t> Pptr((size_t)n + 1), Aptr((size_t)m + 1), pent((size_t)count + 1), aent((size_t)count + 1);
-        std::vector<int32_t> xo32((size_t)count + 1), ro32((size_t)count + 1), nr32((size_t)count, 0);
+        std::vector<int32_t> Pptr((size_t)n + 1), pent((size_t)count + 1), aent((size_t)count + 1);
+        R.Aptr.assign((size_t)m + 1, 0);
         int64_t pe = 0, ae = 0, sq = 0;
-        nnzP_full = 0;
+        R.nnzP_full = 0;
         for (int p = 0; p < count; ++p) {
             const score_problem& pr = probs[p];
             const int64_t nr = rep > 1 ? h.rep_n[(size_t)p] : 0, t0 = (int64_t)rep * nr;
-            xo32[(size_t)p] = (int32_t)h.xoff[p]; ro32[(size_t)p] = (int32_t)h.roff[p]; nr32[(size_t)p] = (int32_t)nr;
             pent[(size_t)p] = (int32_t)pe; aent[(size_t)p] = (int32_t)ae;
             int32_t* pp = &Pptr[(size_t)h.xoff[p]];
             if (rep > 1) {
@@ -894,13 +929,13 @@ struct HipBackend {
                 for (int64_t i = nr; i < t0; ++i) pp[i] = (int32_t)(pe + e0);
                 for (int64_t i = t0; i < pr.n; ++i) pp[i] = (int32_t)(pe + e0 + (pr.P_rowptr[i] - pr.P_rowptr[t0]));
                 pe += e0 + et;
-                nnzP_full += (int64_t)rep * e0 + et;
+                R.nnzP_full += (int64_t)rep * e0 + et;
             } else {
                 for (int64_t i = 0; i < pr.n; ++i) pp[i] = (int32_t)(pe + pr.P_rowptr[i]);
                 pe += pr.P_rowptr[pr.n];
-                nnzP_full += pr.P_rowptr[pr.n];
+                R.nnzP_full += pr.P_rowptr[pr.n];
             }
-            int32_t* ap = &Aptr[(size_t)h.roff[p]];
+            int32_t* ap = &R.Aptr[(size_t)h.roff[p]];
             for (int64_t r = 0; r < pr.m; ++r) {
                 ap[r] = (int32_t)(ae + pr.A_rowptr[r]);
                 const int64_t L = pr.A_rowptr[r + 1] - pr.A_rowptr[r];
@@ -908,57 +943,229 @@ struct HipBackend {
             }
             ae += pr.A_rowptr[pr.m];
         }
-        Pptr[(size_t)n] = (int32_t)pe; Aptr[(size_t)m] = (int32_t)ae;
+        Pptr[(size_t)n] = (int32_t)pe; R.Aptr[(size_t)m] = (int32_t)ae;
         pent[(size_t)count] = (int32_t)pe; aent[(size_t)count] = (int32_t)ae;
-        xo32[(size_t)count] = (int32_t)n; ro32[(size_t)count] = (int32_t)m;
-        int64_t n_stored = 0;
-        for (int p = 0; p < count; ++p) n_stored += (h.xoff[p + 1] - h.xoff[p]) - (rep > 1 ? (int64_t)(rep - 1) * h.rep_n[(size_t)p] : 0);
-        tab_xoff.upload(xo32); tab_roff.upload(ro32); tab_nr.upload(nr32);
-        const ProbTab tab = prob_tab();
-        // ---- persistent arrays whose sizes are known up front ----
-        A_ptr.upload(Aptr);
-        A_col.alloc((size_t)ae + 64); A_val.alloc((size_t)ae + 64);
-        HIP_CHECK(hipMemsetAsync(A_col.d + ae, 0, 64 * sizeof(int32_t), stream));
-        HIP_CHECK(hipMemsetAsync(A_val.d + ae, 0, 64 * sizeof(double), stream));
-        q.alloc((size_t)n); b.alloc((size_t)m); invD.alloc((size_t)n); invE.alloc((size_t)m); Dd.alloc((size_t)n); Ed.alloc((size_t)m);
-        G1.ptr.alloc((size_t)n + 1); G2.ptr.alloc((size_t)n + 1); G2.split.alloc((size_t)n);
-        G1.col.alloc((size_t)ae + 64); G1.val.alloc((size_t)ae + 64);
-        const int64_t g2_nnz = nnzP_full + ae;
-        G2.col.alloc((size_t)g2_nnz + 64); G2.val.alloc((size_t)g2_nnz + 64);
-        HIP_CHECK(hipMemsetAsync(G1.col.d, 0, G1.col.n * sizeof(int32_t), stream));
-        HIP_CHECK(hipMemsetAsync(G1.val.d, 0, G1.val.n * sizeof(double), stream));
-        HIP_CHECK(hipMemsetAsync(G2.col.d + g2_nnz, 0, 64 * sizeof(int32_t), stream));
-        HIP_CHECK(hipMemsetAsync(G2.val.d + g2_nnz, 0, 64 * sizeof(double), stream));
-        // ---- scratch ----
-        setup_tmp.dev = st.device;
-        ArenaSwap swap(&setup_tmp);
-        DevBuf<int32_t> Pp, Pc, Ac, atp, arow, d_pent, d_aent;
-        DevBuf<uint32_t> idx0, atpos, akey0, akey1;
-        DevBuf<double> Pv, Av, qraw, braw, dsc, esc, norms;
-        Pp.upload(Pptr);
-        Pc.alloc((size_t)pe + 1); Pv.alloc((size_t)pe + 1); Ac.alloc((size_t)ae + 1); Av.alloc((size_t)ae + 1);
-        qraw.alloc((size_t)n); braw.alloc((size_t)std::max<int64_t>(1, m));
+        R.pe = pe; R.ae = ae; R.sq = sq; R.exact = true;
+        R.n_stored = 0;
+        for (int p = 0; p < count; ++p) R.n_stored += (h.xoff[p + 1] - h.xoff[p]) - (rep > 1 ? (int64_t)(rep - 1) * h.rep_n[(size_t)p] : 0);
+        DevBuf<int32_t> d_pent, d_aent;
+        R.Pp.upload(Pptr);
+        R.Pc.alloc((size_t)pe + 1); R.Pv.alloc((size_t)pe + 1); R.Ac.alloc((size_t)ae + 1); R.Av.alloc((size_t)ae + 1);
+        R.qraw.alloc((size_t)n); R.braw.alloc((size_t)std::max<int64_t>(1, m));
         for (int p = 0; p < count; ++p) {
             const score_problem& pr = probs[p];
             const int64_t nr = rep > 1 ? h.rep_n[(size_t)p] : 0, t0 = (int64_t)rep * nr;
             const int64_t o = pent[(size_t)p];
             if (rep > 1) {
                 const int64_t e0 = pr.P_rowptr[nr], b0 = pr.P_rowptr[t0], et = pr.P_rowptr[pr.n] - b0;
-                copy_up(Pc.d + o, pr.P_col, (size_t)e0); copy_up(Pv.d + o, pr.P_val, (size_t)e0);
-                copy_up(Pc.d + o + e0, pr.P_col + b0, (size_t)et); copy_up(Pv.d + o + e0, pr.P_val + b0, (size_t)et);
+                copy_up(R.Pc.d + o, pr.P_col, (size_t)e0); copy_up(R.Pv.d + o, pr.P_val, (size_t)e0);
+                copy_up(R.Pc.d + o + e0, pr.P_col + b0, (size_t)et); copy_up(R.Pv.d + o + e0, pr.P_val + b0, (size_t)et);
             } else {
-                copy_up(Pc.d + o, pr.P_col, (size_t)pr.P_rowptr[pr.n]); copy_up(Pv.d + o, pr.P_val, (size_t)pr.P_rowptr[pr.n]);
+                copy_up(R.Pc.d + o, pr.P_col, (size_t)pr.P_rowptr[pr.n]); copy_up(R.Pv.d + o, pr.P_val, (size_t)pr.P_rowptr[pr.n]);
             }
-            copy_up(Ac.d + aent[(size_t)p], pr.A_col, (size_t)pr.A_rowptr[pr.m]); copy_up(Av.d + aent[(size_t)p], pr.A_val, (size_t)pr.A_rowptr[pr.m]);
-            copy_up(qraw.d + h.xoff[p], pr.q, (size_t)pr.n); copy_up(braw.d + h.roff[p], pr.b, (size_t)pr.m);
+            copy_up(R.Ac.d + aent[(size_t)p], pr.A_col, (size_t)pr.A_rowptr[pr.m]); copy_up(R.Av.d + aent[(size_t)p], pr.A_val, (size_t)pr.A_rowptr[pr.m]);
+            copy_up(R.qraw.d + h.xoff[p], pr.q, (size_t)pr.n); copy_up(R.braw.d + h.roff[p], pr.b, (size_t)pr.m);
         }
         if (count > 1) {
             d_pent.upload(pent); d_aent.upload(aent);
-            if (pe) hipLaunchKernelGGL(k_globalise, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, stream, Pc.d, (const int32_t*)d_pent.d, (const int32_t*)tab_xoff.d, count, pe);
-            if (ae) hipLaunchKernelGGL(k_globalise, dim3((unsigned)((ae + 255) / 256)), dim3(256), 0, stream, Ac.d, (const int32_t*)d_aent.d, (const int32_t*)tab_xoff.d, count, ae);
+            if (pe) hipLaunchKernelGGL(k_globalise, dim3((unsigned)((pe + 255) / 256)), dim3(256), 0, stream, R.Pc.d, (const int32_t*)d_pent.d, (const int32_t*)tab_xoff.d, count, pe);
+            if (ae) hipLaunchKernelGGL(k_globalise, dim3((unsigned)((ae + 255) / 256)), dim3(256), 0, stream, R.Ac.d, (const int32_t*)d_aent.d, (const int32_t*)tab_xoff.d, count, ae);
         }
         HIP_CHECK(hipGetLastError());
-        pt.mark("  device setup: raw matrices up");
+        R.P_ptr = R.Pp.d; R.P_col = R.Pc.d; R.P_val = R.Pv.d;
+    }
+
+    // The device assembler: the factor graphs' flat arrays go up as they are, every measurement writes its records (k_ga_*),
+    // the merge turns them into P (replica 0 + tail rows) and q; A and b are written in place.  c0 comes from the host (a sum
+    // over the ranges, the priors and the few measurements at the pinned pose, in assemble_graph's order).
+    void raw_from_graphs(HostSystem& h, const score_graph* graphs, RawDev& R) {
+        const int count = h.count;
+        const int64_t n = h.n_tot, m = h.m_tot;
+        const int d = graphs[0].dim, D1 = d + 1, relax = graphs[0].relaxation;
+        const int per_rel = D1 + 3 * D1 * D1, per_rng = relax == 0 ? 1 : 9;
+        std::vector<GaProb> gp((size_t)count);
+        std::vector<int32_t> rel_off((size_t)count + 1, 0), rng_off((size_t)count + 1, 0), pri_off((size_t)count + 1, 0), pin_off((size_t)count + 1, 0);
+        std::vector<int32_t> pin_edge;
+        R.Aptr.assign((size_t)m + 1, 0);
+        int64_t ae = 0, sq = 0;
+        for (int p = 0; p < count; ++p) {
+            const score_graph& g = graphs[p];
+            int64_t Np = 0;
+            for (int c = 0; c < g.n_chains; ++c) Np += g.chain_len[c];
+            GaProb& P = gp[(size_t)p];
+            P.xoff = (int32_t)h.xoff[p]; P.roff = (int32_t)h.roff[p];
+            P.Np = (int32_t)Np; P.Nl = g.n_landmarks; P.Nr = (int32_t)g.n_rng;
+            P.n_rep = (int32_t)h.rep_n[(size_t)p];
+            P.rel_off = rel_off[(size_t)p]; P.rng_off = rng_off[(size_t)p]; P.pri_off = pri_off[(size_t)p]; P.pin_off = pin_off[(size_t)p];
+            rel_off[(size_t)p + 1] = rel_off[(size_t)p] + (int32_t)g.n_rel;
+            rng_off[(size_t)p + 1] = rng_off[(size_t)p] + (int32_t)g.n_rng;
+            pri_off[(size_t)p + 1] = pri_off[(size_t)p] + (int32_t)g.n_lprior;
+            for (int64_t e = 0; e < g.n_rel; ++e)
+                if (g.rel_base[e] == 0 || g.rel_to[e] == 0) pin_edge.push_back((int32_t)(rel_off[(size_t)p] + e));
+            pin_off[(size_t)p + 1] = (int32_t)pin_edge.size();
+            // rows of A: a head row (SOCP: the distance variable; QCQP: none) and d rows per range
+            P.a_off = (int32_t)ae;
+            int32_t* ap = &R.Aptr[(size_t)h.roff[p]];
+            for (int64_t r = 0; r < g.n_rng; ++r) {
+                const int cnt = relax == 0 ? (g.rng_a[r] != 0) + (g.rng_b[r] != 0) : 1;
+                const int head = relax == 0 ? 1 : 0;
+                ap[r * D1] = (int32_t)ae;
+                ae += head;
+                for (int k = 0; k < d; ++k) { ap[r * D1 + 1 + k] = (int32_t)ae; ae += cnt; }
+                sq += head + (int64_t)d * cnt * cnt;
+            }
+        }
+        R.Aptr[(size_t)m] = (int32_t)ae;
+        {   // (the assembler writes A through its row pointers: they go up first, into the handle's own arena)
+            ArenaSwap persist(&arena);
+            A_ptr.upload(R.Aptr);
+        }
+        // record slots: P records [relative poses | ranges | priors] problem by problem, then the q records likewise
+        int64_t o = 0;
+        for (int p = 0; p < count; ++p) {
+            GaProb& P = gp[(size_t)p];
+            const score_graph& g = graphs[p];
+            P.rec_rel = (int32_t)o; o += g.n_rel * per_rel;
+            P.rec_rng = (int32_t)o; o += g.n_rng * per_rng;
+            P.rec_pri = (int32_t)o; o += g.n_lprior;
+        }
+        const int64_t p_slots = o;
+        for (int p = 0; p < count; ++p) {
+            GaProb& P = gp[(size_t)p];
+            const score_graph& g = graphs[p];
+            P.recq_pin = (int32_t)o; o += (int64_t)(pin_off[(size_t)p + 1] - pin_off[(size_t)p]) * d * D1;
+            P.recq_rng = (int32_t)o; o += relax == 0 ? g.n_rng : 0;
+            P.recq_pri = (int32_t)o; o += g.n_lprior * d;
+        }
+        const int64_t rec_max = o + 64;
+        if (rec_max >= ((int64_t)1 << 31)) throw std::runtime_error("score_graph: too many measurement records for one handle");
+        R.pe = p_slots; R.ae = ae; R.sq = sq; R.exact = false;
+        R.nnzP_full = (int64_t)std::max(1, h.rep) * p_slots;
+        R.n_stored = 0;
+        for (int p = 0; p < count; ++p) R.n_stored += (h.xoff[p + 1] - h.xoff[p]) - (h.rep > 1 ? (int64_t)(h.rep - 1) * h.rep_n[(size_t)p] : 0);
+        // ---- the graphs' arrays, concatenated: everything into ONE pinned block and up in ONE transfer (a transfer per array
+        //      and graph was ~200 copy dispatches for a 16-trial handle) ----
+        const int64_t n_rel = rel_off[(size_t)count], n_rng = rng_off[(size_t)count], n_pri = pri_off[(size_t)count], n_pin = (int64_t)pin_edge.size();
+        auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+        const size_t i4 = sizeof(int32_t), f8 = sizeof(double);
+        size_t off = 0;
+        auto region = [&](size_t bytes) { const size_t o_ = off; off += al(std::max<size_t>(bytes, 8)); return o_; };
+        const size_t o_rel_base = region(n_rel * i4), o_rel_to = region(n_rel * i4), o_rel_t = region(n_rel * d * f8), o_rel_R = region(n_rel * d * d * f8);
+        const size_t o_rel_kappa = region(n_rel * f8), o_rel_tau = region(n_rel * f8);
+        const size_t o_rng_a = region(n_rng * i4), o_rng_b = region(n_rng * i4), o_rng_dist = region(n_rng * f8), o_rng_prec = region(n_rng * f8);
+        const size_t o_pri_lm = region(n_pri * i4), o_pri_t = region(n_pri * d * f8), o_pri_prec = region(n_pri * f8);
+        const size_t o_relp = region(n_rel * i4), o_rngp = region(n_rng * i4), o_prip = region(n_pri * i4), o_pinp = region(n_pin * i4), o_pin = region(n_pin * i4);
+        const size_t o_gp = region((size_t)count * sizeof(GaProb));
+        const size_t pack_bytes = off;
+        size_t got_h = pack_bytes;
+        char* hb = (char*)block_cache().take(got_h, st.device, true);
+        setup_pinned.push_back({hb, got_h});
+        DevBuf<unsigned char> pack;
+        pack.alloc(pack_bytes);
+        auto cp = [&](size_t o_, const void* src, size_t bytes) { if (bytes) std::memcpy(hb + o_, src, bytes); };
+        for (int p = 0; p < count; ++p) {
+            const score_graph& g = graphs[p];
+            const size_t eo = (size_t)rel_off[(size_t)p], ro = (size_t)rng_off[(size_t)p], po = (size_t)pri_off[(size_t)p];
+            cp(o_rel_base + eo * i4, g.rel_base, (size_t)g.n_rel * i4); cp(o_rel_to + eo * i4, g.rel_to, (size_t)g.n_rel * i4);
+            cp(o_rel_t + eo * d * f8, g.rel_t, (size_t)g.n_rel * d * f8); cp(o_rel_R + eo * d * d * f8, g.rel_R, (size_t)g.n_rel * d * d * f8);
+            cp(o_rel_kappa + eo * f8, g.rel_kappa, (size_t)g.n_rel * f8); cp(o_rel_tau + eo * f8, g.rel_tau, (size_t)g.n_rel * f8);
+            cp(o_rng_a + ro * i4, g.rng_a, (size_t)g.n_rng * i4); cp(o_rng_b + ro * i4, g.rng_b, (size_t)g.n_rng * i4);
+            cp(o_rng_dist + ro * f8, g.rng_dist, (size_t)g.n_rng * f8); cp(o_rng_prec + ro * f8, g.rng_prec, (size_t)g.n_rng * f8);
+            cp(o_pri_lm + po * i4, g.lprior_lm, (size_t)g.n_lprior * i4); cp(o_pri_t + po * d * f8, g.lprior_t, (size_t)g.n_lprior * d * f8);
+            cp(o_pri_prec + po * f8, g.lprior_prec, (size_t)g.n_lprior * f8);
+            std::fill((int32_t*)(hb + o_relp) + eo, (int32_t*)(hb + o_relp) + eo + g.n_rel, p);
+            std::fill((int32_t*)(hb + o_rngp) + ro, (int32_t*)(hb + o_rngp) + ro + g.n_rng, p);
+            std::fill((int32_t*)(hb + o_prip) + po, (int32_t*)(hb + o_prip) + po + g.n_lprior, p);
+            std::fill((int32_t*)(hb + o_pinp) + pin_off[(size_t)p], (int32_t*)(hb + o_pinp) + pin_off[(size_t)p + 1], p);
+        }
+        cp(o_pin, pin_edge.data(), (size_t)n_pin * i4);
+        cp(o_gp, gp.data(), (size_t)count * sizeof(GaProb));
+        HIP_CHECK(hipMemcpyAsync(pack.d, hb, pack_bytes, hipMemcpyHostToDevice, stream));
+        struct Slice { const void* d; };
+        auto dI = [&](size_t o_) { return (const int32_t*)(pack.d + o_); };
+        auto dF = [&](size_t o_) { return (const double*)(pack.d + o_); };
+        struct { const int32_t* d; } rel_base{dI(o_rel_base)}, rel_to{dI(o_rel_to)}, rng_a{dI(o_rng_a)}, rng_b{dI(o_rng_b)}, pri_lm{dI(o_pri_lm)}, d_pin{dI(o_pin)},
+            rel_prob{dI(o_relp)}, rng_prob{dI(o_rngp)}, pri_prob{dI(o_prip)}, pin_prob{dI(o_pinp)};
+        struct { const double* d; } rel_t{dF(o_rel_t)}, rel_R{dF(o_rel_R)}, rel_kappa{dF(o_rel_kappa)}, rel_tau{dF(o_rel_tau)}, rng_dist{dF(o_rng_dist)},
+            rng_prec{dF(o_rng_prec)}, pri_t{dF(o_pri_t)}, pri_prec{dF(o_pri_prec)};
+        struct { const GaProb* d; } d_gp{(const GaProb*)(pack.d + o_gp)};
+        // ---- records ----
+        DevBuf<unsigned long long> key0;
+        DevBuf<uint32_t> idx0;
+        DevBuf<double> val;
+        key0.alloc((size_t)rec_max); idx0.alloc((size_t)rec_max); val.alloc((size_t)rec_max);
+        R.Ac.alloc((size_t)ae + 1); R.Av.alloc((size_t)ae + 1);
+        R.qraw.alloc((size_t)n); R.braw.alloc((size_t)std::max<int64_t>(1, m));
+        HIP_CHECK(hipMemsetAsync(R.qraw.d, 0, (size_t)n * sizeof(double), stream));
+        GaArgs a{};
+        a.d = d; a.relaxation = relax; a.count = count; a.probs = d_gp.d;
+        a.rel_prob = rel_prob.d; a.rng_prob = rng_prob.d; a.pri_prob = pri_prob.d; a.pin_prob = pin_prob.d;
+        a.n_rel = n_rel; a.n_rng = n_rng; a.n_pri = n_pri; a.n_pin = n_pin;
+        a.rel_base = rel_base.d; a.rel_to = rel_to.d; a.rel_t = rel_t.d; a.rel_R = rel_R.d; a.rel_kappa = rel_kappa.d; a.rel_tau = rel_tau.d;
+        a.rng_a = rng_a.d; a.rng_b = rng_b.d; a.rng_dist = rng_dist.d; a.rng_prec = rng_prec.d;
+        a.pri_lm = pri_lm.d; a.pri_t = pri_t.d; a.pri_prec = pri_prec.d; a.pin_edge = d_pin.d;
+        a.key = key0.d; a.idx = idx0.d; a.val = val.d; a.pad_key = (unsigned long long)n << 32;
+        a.A_ptr = A_ptr.d; a.A_col = R.Ac.d; a.A_val = R.Av.d; a.b = R.braw.d;
+        if (n_rel) hipLaunchKernelGGL(k_ga_rel, dim3((unsigned)((n_rel + 255) / 256)), dim3(256), 0, stream, a);
+        if (n_pin) hipLaunchKernelGGL(k_ga_pin, dim3((unsigned)((n_pin + 255) / 256)), dim3(256), 0, stream, a);
+        if (n_rng) hipLaunchKernelGGL(k_ga_rng, dim3((unsigned)((n_rng + 255) / 256)), dim3(256), 0, stream, a);
+        if (n_pri) hipLaunchKernelGGL(k_ga_pri, dim3((unsigned)((n_pri + 255) / 256)), dim3(256), 0, stream, a);
+        {   // the 64 slots behind the records: padding
+            DevBuf<long long> used;
+            used.alloc(1);
+            const long long u = o;
+            std::vector<long long> uv(1, u);
+            used.upload(uv);
+            hipLaunchKernelGGL(k_rec_pad, dim3(1), dim3(256), 0, stream, key0.d, idx0.d, (const long long*)used.d, rec_max, n);
+        }
+        HIP_CHECK(hipGetLastError());
+        merge_records(n, rec_max, key0, idx0, val.d, nullptr, kQCol, R.qraw.d, R.pm);
+        R.P_ptr = R.pm.ptr.d; R.P_col = R.pm.col.d; R.P_val = R.pm.o0.d;
+    }
+
+    // From the raw program to A, G1, G2, K (K0 / K1), q, b, 1/D, 1/E on the device; the host gets the row pointers, K's columns
+    // and the norms back and lays out the tiles.
+    void setup_on_device(HostSystem& h, const score_problem* probs, const score_graph* graphs) {
+        PhaseTimer pt(st.verbose != 0);
+        const int count = h.count;
+        const int64_t n = h.n_tot, m = h.m_tot;
+        fill_tab(h);
+        const ProbTab tab = prob_tab();
+        setup_tmp.dev = st.device;
+        RawDev R;
+        ArenaSwap swap(&setup_tmp);
+        if (!graphs) raw_from_problems(h, probs, R);
+        else raw_from_graphs(h, graphs, R);
+        const int64_t pe = R.pe, ae = R.ae, sq = R.sq, n_stored = R.n_stored;
+        nnzP_full = R.nnzP_full;
+        // ---- persistent arrays whose sizes are known up front ----
+        {
+            ArenaSwap persist(&arena);
+            if (!graphs) A_ptr.upload(R.Aptr);
+            A_col.alloc((size_t)ae + 64); A_val.alloc((size_t)ae + 64);
+            q.alloc((size_t)n); b.alloc((size_t)m); invD.alloc((size_t)n); invE.alloc((size_t)m); Dd.alloc((size_t)n); Ed.alloc((size_t)m);
+            G1.ptr.alloc((size_t)n + 1); G2.ptr.alloc((size_t)n + 1); G2.split.alloc((size_t)n);
+            G1.col.alloc((size_t)ae + 64); G1.val.alloc((size_t)ae + 64);
+            G2.col.alloc((size_t)(nnzP_full + ae) + 64); G2.val.alloc((size_t)(nnzP_full + ae) + 64);
+        }
+        const int64_t g2_nnz = nnzP_full + ae;  // (graph path: an upper bound)
+        HIP_CHECK(hipMemsetAsync(A_col.d + ae, 0, 64 * sizeof(int32_t), stream));
+        HIP_CHECK(hipMemsetAsync(A_val.d + ae, 0, 64 * sizeof(double), stream));
+        HIP_CHECK(hipMemsetAsync(G1.col.d, 0, G1.col.n * sizeof(int32_t), stream));
+        HIP_CHECK(hipMemsetAsync(G1.val.d, 0, G1.val.n * sizeof(double), stream));
+        if (R.exact) {
+            HIP_CHECK(hipMemsetAsync(G2.col.d + g2_nnz, 0, 64 * sizeof(int32_t), stream));
+            HIP_CHECK(hipMemsetAsync(G2.val.d + g2_nnz, 0, 64 * sizeof(double), stream));
+        } else {  // (the end of the entries is not known yet: everything behind them reads as (column 0, value 0))
+            HIP_CHECK(hipMemsetAsync(G2.col.d, 0, G2.col.n * sizeof(int32_t), stream));
+            HIP_CHECK(hipMemsetAsync(G2.val.d, 0, G2.val.n * sizeof(double), stream));
+        }
+        DevBuf<int32_t> atp, arow;
+        DevBuf<uint32_t> idx0, atpos, akey0, akey1;
+        DevBuf<double> dsc, esc, norms;
+        const int32_t* const Pp_d = R.P_ptr; const int32_t* const Pc_d = R.P_col; const double* const Pv_d = R.P_val;
+        const int32_t* const Ac_d = R.Ac.d; const double* const Av_d = R.Av.d;
+        pt.mark(graphs ? "  device setup: graphs up, assembler queued" : "  device setup: raw matrices up");
         // ---- A' position map: entries of A by column, in row order (a stable sort of the columns) ----
         arow.alloc((size_t)std::max<int64_t>(1, ae)); atp.alloc((size_t)n + 1); atpos.alloc((size_t)std::max<int64_t>(1, ae));
         {
@@ -970,7 +1177,7 @@ struct HipBackend {
         if (ae) {
             idx0.alloc((size_t)ae); akey0.alloc((size_t)ae); akey1.alloc((size_t)ae);
             hipLaunchKernelGGL(k_iota, dim3((unsigned)((ae + 255) / 256)), dim3(256), 0, stream, idx0.d, ae);
-            HIP_CHECK(hipMemcpyAsync(akey0.d, Ac.d, (size_t)ae * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(akey0.d, Ac_d, (size_t)ae * sizeof(uint32_t), hipMemcpyDeviceToDevice, stream));
             int bits = 1;
             while (((int64_t)1 << bits) < n) ++bits;
             size_t tb = 0;
@@ -983,14 +1190,19 @@ struct HipBackend {
         // ---- Ruiz passes ----
         const int64_t ngroups = (int64_t)h.cone_row.size();
         dsc.alloc((size_t)n); esc.alloc((size_t)std::max<int64_t>(1, ngroups));
+        DevBuf<double> cmax;
+        cmax.alloc((size_t)n);
+        HIP_CHECK(hipMemsetAsync(cmax.d, 0, (size_t)n * sizeof(double), stream));
         RzArgs rz{};
-        rz.P_ptr = Pp.d; rz.P_col = Pc.d; rz.P_val = Pv.d; rz.A_ptr = A_ptr.d; rz.A_col = Ac.d; rz.A_val = Av.d;
+        rz.cmax = cmax.d; rz.acol_sorted = akey1.d; rz.nnzA = ae;
+        rz.P_ptr = Pp_d; rz.P_col = Pc_d; rz.P_val = Pv_d; rz.A_ptr = A_ptr.d; rz.A_col = Ac_d; rz.A_val = Av_d;
         rz.atp = atp.d; rz.atpos = atpos.d; rz.arow = arow.d; rz.gstart = cone_row.d;
         rz.D = Dd.d; rz.E = Ed.d; rz.d = dsc.d; rz.e = esc.d; rz.n = n; rz.m = m; rz.ngroups = ngroups; rz.tab = tab;
         const unsigned gcol = (unsigned)((n + 3) / 4), ggrp = (unsigned)std::max<int64_t>(1, (ngroups + 255) / 256);
         const unsigned gapp = (unsigned)std::max<int64_t>(1, (std::max(n, ngroups) + 255) / 256);
         for (int it = 0; it < std::max(0, st.scale_iters); ++it) {
-            hipLaunchKernelGGL(k_rz_cols, dim3(gcol), dim3(256), 0, stream, rz);
+            if (ae) hipLaunchKernelGGL(k_rz_colsA, dim3((unsigned)((ae + 255) / 256)), dim3(256), 0, stream, rz);
+            hipLaunchKernelGGL(k_rz_cols, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, rz);
             if (ngroups) hipLaunchKernelGGL(k_rz_groups, dim3(ggrp), dim3(256), 0, stream, rz);
             hipLaunchKernelGGL(k_rz_apply, dim3(gapp), dim3(256), 0, stream, rz);
         }
@@ -1001,11 +1213,11 @@ struct HipBackend {
         len1.alloc((size_t)n + 1); len2.alloc((size_t)n + 1);
         GDevArgs ga{};
         ga.n = n; ga.m = m; ga.nnzA = ae; ga.tab = tab;
-        ga.P_ptr = Pp.d; ga.P_col = Pc.d; ga.P_val = Pv.d; ga.A_col = Ac.d; ga.A_val = Av.d;
+        ga.P_ptr = Pp_d; ga.P_col = Pc_d; ga.P_val = Pv_d; ga.A_col = Ac_d; ga.A_val = Av_d;
         ga.atp = atp.d; ga.atpos = atpos.d; ga.arow = arow.d; ga.D = Dd.d; ga.E = Ed.d;
         ga.len1 = len1.d; ga.len2 = len2.d; ga.g1_ptr = G1.ptr.d; ga.g2_ptr = G2.ptr.d; ga.g2_split = G2.split.d;
         ga.oA_col = A_col.d; ga.oA_val = A_val.d; ga.g1_col = G1.col.d; ga.g1_val = G1.val.d; ga.g2_col = G2.col.d; ga.g2_val = G2.val.d;
-        ga.q_raw = qraw.d; ga.b_raw = braw.d; ga.q = q.d; ga.b = b.d; ga.invD = invD.d; ga.invE = invE.d;
+        ga.q_raw = R.qraw.d; ga.b_raw = R.braw.d; ga.q = q.d; ga.b = b.d; ga.invD = invD.d; ga.invE = invE.d;
         const unsigned grow1 = (unsigned)((n + 1 + 255) / 256);
         hipLaunchKernelGGL(k_g_lengths, dim3(grow1), dim3(256), 0, stream, ga);
         {
@@ -1020,7 +1232,8 @@ struct HipBackend {
         hipLaunchKernelGGL(k_g_scale_a, dim3((unsigned)std::max<int64_t>(1, (std::max(ae, std::max(n, m)) + 255) / 256)), dim3(256), 0, stream, ga);
         hipLaunchKernelGGL(k_g_fill, dim3(gcol), dim3(256), 0, stream, ga);
         norms.alloc((size_t)4 * count);
-        hipLaunchKernelGGL(k_prob_norms, dim3((unsigned)count), dim3(256), 0, stream, tab, (const double*)qraw.d, (const double*)q.d, (const double*)braw.d,
+        HIP_CHECK(hipMemsetAsync(norms.d, 0, (size_t)4 * count * sizeof(double), stream));
+        hipLaunchKernelGGL(k_prob_norms, dim3(count > 8 ? 8u : 32u, (unsigned)count), dim3(256), 0, stream, tab, (const double*)R.qraw.d, (const double*)q.d, (const double*)R.braw.d,
                            (const double*)b.d, norms.d);
         HIP_CHECK(hipGetLastError());
         // ---- K = P + sigma I + rho A'A as K0 + rho K1 ----
@@ -1075,8 +1288,9 @@ struct HipBackend {
         h.K.ptr.assign((const int32_t*)(hb + o_kp), (const int32_t*)(hb + o_kp) + n + 1);
         h.G1.ptr.assign((const int32_t*)(hb + o_g1), (const int32_t*)(hb + o_g1) + n + 1);
         h.G2.ptr.assign((const int32_t*)(hb + o_g2), (const int32_t*)(hb + o_g2) + n + 1);
-        h.A.ptr = std::move(Aptr);
-        if (h.K.ptr[(size_t)n] != nnzK || h.G2.ptr[(size_t)n] != g2_nnz) throw std::runtime_error("device setup: inconsistent entry counts");
+        h.A.ptr = std::move(R.Aptr);
+        if (h.K.ptr[(size_t)n] != nnzK || (R.exact && h.G2.ptr[(size_t)n] != g2_nnz)) throw std::runtime_error("device setup: inconsistent entry counts");
+        nnzP_full = h.G2.ptr[(size_t)n] - ae;
         g1_nnz = h.G1.ptr[(size_t)n];
         // ---- K's persistent arrays at their exact size; its columns to the host (band layout, tiles) ----
         {
@@ -1106,7 +1320,7 @@ struct HipBackend {
         pt.mark("  device setup: K columns back, tiles");
     }
 
-    void init(HostSystem& h, const score_settings& s_, const score_problem* probs = nullptr) {
+    void init(HostSystem& h, const score_settings& s_, const score_problem* probs = nullptr, const score_graph* graphs = nullptr) {
         H = &h;
         st = s_;
         PhaseTimer pt(st.verbose != 0);
@@ -1150,7 +1364,7 @@ struct HipBackend {
         // matrices uploaded below -- unless its band view is asked for or SCORE_HOST_POLISH_BUILD is set: then on another
         // host thread while this one uploads.  Either way the structure check (per-cone data) runs on that thread.
         polish_on_device = st.polish && !band_h(h) && std::getenv("SCORE_HOST_POLISH_BUILD") == nullptr;
-        if (h.device_setup && !probs) throw std::runtime_error("device setup: the raw problems are missing");
+        if (h.device_setup && !probs && !graphs) throw std::runtime_error("device setup: the raw problems are missing");
         if (st.polish && !h.device_setup)  // (device setup: the per-cone structure comes from a kernel, init_polish)
             polish_build = std::async(std::launch::async, [this, &h] {
                 if (polish_on_device) { Q = PolishData(); polish_structure(h, Q); }
@@ -1185,7 +1399,7 @@ struct HipBackend {
             // everything matrix-shaped is built on the device from the raw problems (score_setup_device.hpp); the cone table
             // (its rows are the equilibration's groups) goes up first
             cone_row.upload(h.cone_row); cone_dim.upload(h.cone_dim); cone_type.upload(h.cone_type);
-            setup_on_device(h, probs);
+            setup_on_device(h, probs, graphs);
             start_band_layout();
             K.adopt_tiles(h.K, h.rbK); G1.adopt_tiles(h.G1, h.rbG1); G2.adopt_tiles(h.G2, h.rbG2);
             pt.mark("  device setup");
@@ -1454,10 +1668,20 @@ struct HipBackend {
             if (fuse_cone) { s_alt.alloc(h.m_tot); y_alt.alloc(h.m_tot); s_alt.zero(stream); y_alt.zero(stream); }
             if (st.verbose) std::fprintf(stderr, "[score setup] cone projections: %s\n", fuse_cone ? "fused into the right-hand-side kernel" : "their own launch");
         }
-        xtu.alloc(h.n_tot + h.m_tot); xy.alloc(h.n_tot + h.m_tot); s.alloc(h.m_tot);
-        r.alloc(h.n_tot); z.alloc(h.n_tot); p.alloc(h.n_tot); p2.alloc(h.n_tot); w.alloc(h.n_tot); kx.alloc(h.n_tot); step.alloc(h.count);
-        pw_part.alloc(kblocks()); rz_part0.alloc(n_prec); rz_part1.alloc(n_prec);
-        rz_meas0.alloc(n_prec); rz_meas1.alloc(n_prec);
+        {   // the iterates and partial sums a reset zeroes: ONE block (a reset is one fill instead of fifteen -- each a 4 us
+            // dispatch, on every solve)
+            auto pad = [](size_t c) { return (std::max<size_t>(1, c) + 31) & ~(size_t)31; };  // (256-byte aligned pieces)
+            const size_t nm = pad((size_t)(h.n_tot + h.m_tot)), nn = pad((size_t)h.n_tot), mm = pad((size_t)h.m_tot), cc = pad((size_t)h.count);
+            const size_t kb = pad((size_t)kblocks()), np_ = pad((size_t)n_prec);
+            iter_block.alloc(2 * nm + mm + 6 * nn + cc + kb + 4 * np_);
+            double* o = iter_block.d;
+            auto take = [&](DevBuf<double>& b, size_t count, size_t padded) { b.view(o, count); o += padded; };
+            take(xtu, (size_t)(h.n_tot + h.m_tot), nm); take(xy, (size_t)(h.n_tot + h.m_tot), nm); take(s, (size_t)h.m_tot, mm);
+            take(r, (size_t)h.n_tot, nn); take(z, (size_t)h.n_tot, nn); take(p, (size_t)h.n_tot, nn); take(p2, (size_t)h.n_tot, nn);
+            take(w, (size_t)h.n_tot, nn); take(kx, (size_t)h.n_tot, nn); take(step, (size_t)h.count, cc);
+            take(pw_part, (size_t)kblocks(), kb); take(rz_part0, (size_t)n_prec, np_); take(rz_part1, (size_t)n_prec, np_);
+            take(rz_meas0, (size_t)n_prec, np_); take(rz_meas1, (size_t)n_prec, np_);
+        }
         cg_iters = st.cg_iters;
         std::vector<int32_t> dz(h.count, 0);
         done.upload(dz);
@@ -1532,6 +1756,8 @@ struct HipBackend {
         pt.mark("reset");
         HIP_CHECK(hipStreamSynchronize(stream));
         setup_tmp.release_all();  // (nothing in flight reads the setup's scratch any more)
+        for (auto& pb : setup_pinned) block_cache().give(pb.first, pb.second, st.device, true);
+        setup_pinned.clear();
         pt.mark("staged uploads: drain");
     }
 
@@ -1735,11 +1961,9 @@ struct HipBackend {
         ring_used = 0;  // everything queued before the publish has run: all ring slots are free again
     }
 
+    DevBuf<double> iter_block;  // xtu | xy | s | r | z | p | p2 | w | kx | step | pw_part | rz_part0/1 | rz_meas0/1
     void reset() {
-        xtu.zero(stream); xy.zero(stream); s.zero(stream);
-        r.zero(stream); z.zero(stream); p.zero(stream); p2.zero(stream); w.zero(stream); kx.zero(stream); step.zero(stream);
-        pw_part.zero(stream); rz_part0.zero(stream); rz_part1.zero(stream);
-        rz_meas0.zero(stream); rz_meas1.zero(stream);
+        iter_block.zero(stream);
         if (n_cone_blocks) {
             hipLaunchKernelGGL(k_refresh_u, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xtu.d));
             HIP_CHECK(hipGetLastError());
@@ -1854,8 +2078,16 @@ struct HipBackend {
         return u;
     }
     // K / H product over a band view: the view's tile tables replace the source matrix's
+    // SCORE_BAND_LDS = 0 / 1: the band tiles' operand window through global loads / staged in LDS (band_tile, LDSW)
+    bool band_lds = [] { const char* e = std::getenv("SCORE_BAND_LDS"); return e ? std::atoi(e) != 0 : true; }();
     template <int MODE, int NR>
     void launch_band_s(const BandBufs& Bv, const SpmvArgs& a, unsigned grid, int slot) {
+        if (band_lds) {
+            if (Bv.L.S == 8) launch_on_stream((k_spmv_band<MODE, NR, 4, true>), dim3(grid), dim3(kThreads), 0, slot, a);
+            else if (Bv.L.S == 10) launch_on_stream((k_spmv_band<MODE, NR, 5, true>), dim3(grid), dim3(kThreads), 0, slot, a);
+            else launch_on_stream((k_spmv_band<MODE, NR, 6, true>), dim3(grid), dim3(kThreads), 0, slot, a);
+            return;
+        }
         if (Bv.L.S == 8) launch_on_stream(k_spmv_band<MODE, NR, 4>, dim3(grid), dim3(kThreads), 0, slot, a);
         else if (Bv.L.S == 10) launch_on_stream(k_spmv_band<MODE, NR, 5>, dim3(grid), dim3(kThreads), 0, slot, a);
         else launch_on_stream(k_spmv_band<MODE, NR, 6>, dim3(grid), dim3(kThreads), 0, slot, a);
@@ -2208,6 +2440,62 @@ struct HipBackend {
             }
             R[pi] = a;
         }
+    }
+
+    // score_read_estimates: poses (rounded, homogeneous), the relaxation's blocks, landmarks, range variables from the solution
+    // on the device (k_read_estimates); one staging block, one wait
+    DevBuf<EstProb> est_probs;
+    DevBuf<int32_t> est_pose_off, est_lm_off, est_rng_off, est_rng_a, est_rng_b;
+    DevBuf<double> est_rng_dist;
+    bool est_up = false;
+    void read_estimates(const HostSystem& h, const EstLayout& L, int qcqp_dirs, double* poses, double* relaxed, double* lms, double* rng, int32_t* degenerate) {
+        const int d = L.d, D1 = d + 1, count = (int)L.probs.size();
+        if (!est_up) {  // (the handle's arena: lives as long as the handle)
+            tl_copy_stream = stream;
+            ArenaSwap persist(&arena);
+            std::vector<int32_t> po((size_t)count + 1), lo((size_t)count + 1), ro((size_t)count + 1);
+            for (int p = 0; p < count; ++p) { po[(size_t)p] = L.probs[(size_t)p].pose_off; lo[(size_t)p] = L.probs[(size_t)p].lm_off; ro[(size_t)p] = L.probs[(size_t)p].rng_off; }
+            po[(size_t)count] = (int32_t)L.n_pose; lo[(size_t)count] = (int32_t)L.n_lm; ro[(size_t)count] = (int32_t)L.n_rng;
+            std::vector<EstProb> pr = L.probs;
+            est_probs.upload(pr); est_pose_off.upload(po); est_lm_off.upload(lo); est_rng_off.upload(ro);
+            est_rng_a.upload(L.rng_a); est_rng_b.upload(L.rng_b); est_rng_dist.upload(L.rng_dist);
+            est_up = true;
+        }
+        const int rw = (L.relaxation != 0 || qcqp_dirs) ? d : 1;
+        const size_t n_T = (size_t)L.n_pose * D1 * D1, n_B = (size_t)L.n_pose * d * D1, n_L = (size_t)L.n_lm * d, n_R = (size_t)L.n_rng * rw;
+        const size_t n_dbl = n_T + n_B + n_L + n_R, bytes_d = n_dbl * sizeof(double), bytes = bytes_d + (size_t)L.n_pose * sizeof(int32_t);
+        size_t got_d = std::max<size_t>(bytes, 64), got_h = got_d;
+        char* dv = (char*)block_cache().take(got_d, st.device, false);
+        char* hv = (char*)block_cache().take(got_h, st.device, true);
+        EstArgs a{};
+        a.d = d; a.relaxation = L.relaxation; a.count = count; a.qcqp_dirs = qcqp_dirs ? 1 : 0;
+        a.probs = est_probs.d; a.pose_off = est_pose_off.d; a.lm_off = est_lm_off.d; a.rng_off = est_rng_off.d;
+        a.n_pose = L.n_pose; a.n_lm = L.n_lm; a.n_rng = L.n_rng;
+        a.x = xy.d; a.D = h.device_setup ? Dd.d : nullptr;
+        a.rng_a = est_rng_a.d; a.rng_b = est_rng_b.d; a.rng_dist = est_rng_dist.d;
+        a.poses = (double*)dv; a.relaxed = a.poses + n_T; a.lms = a.relaxed + n_B; a.rng = a.lms + n_L; a.degenerate = (int32_t*)(dv + bytes_d);
+        hipError_t e = hipSuccess;
+        DevBuf<double> Dtmp;
+        if (!h.device_setup) {  // (host setup: the scales live on the host)
+            Dtmp.alloc((size_t)h.n_tot);
+            e = hipMemcpyAsync(Dtmp.d, h.D.data(), (size_t)h.n_tot * sizeof(double), hipMemcpyHostToDevice, stream);
+            a.D = Dtmp.d;
+        }
+        const int64_t nmax = std::max(L.n_pose, std::max(L.n_lm, L.n_rng));
+        if (e == hipSuccess && nmax > 0) hipLaunchKernelGGL(k_read_estimates, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, stream, a);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(hv, dv, bytes, hipMemcpyDeviceToHost, stream);
+        const hipError_t e2 = hipStreamSynchronize(stream);
+        if (e == hipSuccess && e2 == hipSuccess) {
+            if (poses) std::memcpy(poses, hv, n_T * sizeof(double));
+            if (relaxed) std::memcpy(relaxed, hv + n_T * sizeof(double), n_B * sizeof(double));
+            if (lms) std::memcpy(lms, hv + (n_T + n_B) * sizeof(double), n_L * sizeof(double));
+            if (rng) std::memcpy(rng, hv + (n_T + n_B + n_L) * sizeof(double), n_R * sizeof(double));
+            if (degenerate) std::memcpy(degenerate, hv + bytes_d, (size_t)L.n_pose * sizeof(int32_t));
+        }
+        block_cache().give(dv, got_d, st.device, false);
+        block_cache().give(hv, got_h, st.device, true);
+        HIP_CHECK(e); HIP_CHECK(e2);
     }
 
     void download(const HostSystem& h, double* x, double* y, double* s_out) {
@@ -3512,6 +3800,49 @@ int score_create_batch(const score_problem* p, int32_t count, const score_settin
 }
 int score_create(const score_problem* p, const score_settings* s, score_handle** out) {
     return score_create_batch(p, 1, s, out);
+}
+int score_create_from_graphs(const score_graph* graphs, int32_t count, const score_settings* s, score_handle** out) {
+    try {
+        tune_host_allocator_once();
+        if (!graphs || !out) throw std::runtime_error("null argument");
+        score_settings st;
+        if (s) st = *s; else score::default_settings(&st);
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+            throw std::runtime_error("no HIP device available (the SCORE solver has no CPU fallback)");
+        if (st.device < 0 || st.device >= ndev) throw std::runtime_error("score_settings.device out of range");
+        DeviceGuard guard(st.device);
+        auto* h = new score_handle();
+        try {
+            h->solver.create_from_graphs(graphs, count, st, [&] {
+                std::vector<score::AssembledQP> qps((size_t)count);
+                std::vector<score::AssembledQP*> ptrs((size_t)count);
+                for (int i = 0; i < count; ++i) ptrs[(size_t)i] = &qps[(size_t)i];
+                score::assemble_graphs(graphs, count, ptrs.data());
+                std::vector<score_problem> probs((size_t)count);
+                for (int i = 0; i < count; ++i) qps[(size_t)i].view(&probs[(size_t)i]);
+                h->solver.create(probs.data(), count, st);
+            });
+        } catch (...) {
+            delete h;
+            throw;
+        }
+        *out = h;
+        return 0;
+    } catch (const std::exception& e) {
+        g_err = e.what();
+        return -1;
+    }
+}
+int score_read_estimates(score_handle* h, int32_t qcqp_directions, double* poses, double* relaxed, double* landmarks, double* ranges,
+                         int32_t* degenerate) {
+    try {
+        if (!h) throw std::runtime_error("null handle");
+        if (!h->solver.est.valid()) throw std::runtime_error("score_read_estimates: the handle was not made by score_create_from_graphs");
+        DeviceGuard guard(h->solver.st.device);
+        h->solver.be.read_estimates(h->solver.H, h->solver.est, qcqp_directions, poses, relaxed, landmarks, ranges, degenerate);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 int score_dims(const score_handle* h, int64_t* n_total, int64_t* m_total, int32_t* count) {
     if (!h) { g_err = "null handle"; return -1; }

@@ -1524,11 +1524,14 @@ inline void fill_kkt_bytes(HostSystem& H) {
 
 // allow_rep: the backend can run replicated problems (HostSystem::rep); the CPU twin cannot (and is the better
 // check for not doing so: it applies the full K the problem defines).
+struct DeviceSetupDeclined : std::runtime_error {
+    DeviceSetupDeclined() : std::runtime_error("device setup declined") {}
+};
 // device_setup_ok (optional): called once sizes and the replication structure are known; true = the backend builds the
 // matrices on its device (HostSystem::device_setup) and the host sweeps over them are skipped.
 inline void build_system(const score_problem* probs, int count, const score_settings& st, HostSystem& H,
                          bool factor_on_host = true, bool allow_rep = false, RuizOffload* ruiz_offload = nullptr,
-                         const std::function<bool(const HostSystem&)>& device_setup_ok = nullptr) {
+                         const std::function<bool(const HostSystem&)>& device_setup_ok = nullptr, bool trusted = false) {
     if (count <= 0) throw std::runtime_error("score_create: count must be positive");
     BuildScope scope;
     PhaseTimer pt(st.verbose != 0);
@@ -1541,8 +1544,10 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     H.xoff.assign(count + 1, 0);
     H.roff.assign(count + 1, 0);
     int bs = 0;
+    // trusted: skeleton problems of the library's own device assembler (sizes, cones, chain and replication hints; no
+    // matrices) -- nothing to validate, the replicated structure holds by construction
     for (int p = 0; p < count; ++p) {
-        validate_problem(probs[p]);
+        if (!trusted) validate_problem(probs[p]);
         pt.mark("validate");
         H.xoff[p + 1] = H.xoff[p] + probs[p].n;
         H.roff[p + 1] = H.roff[p] + probs[p].m;
@@ -1559,6 +1564,12 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         int rep = (allow_rep && std::getenv("SCORE_NO_REPLICATION") == nullptr) ? probs[0].rep_d : 0;
         H.rep_exact = false;
         H.rep_exact_all.assign((size_t)count, 0);
+        if (trusted) {
+            for (int p = 0; p < count; ++p)
+                if (probs[p].rep_d != rep) rep = 0;
+            H.rep_exact = rep > 1 && count == 1;
+            H.rep_exact_all.assign((size_t)count, rep > 1 ? 1 : 0);
+        } else
         if (rep > 1 && count == 1) {
             bool ex = false;
             if (probs[0].rep_d != rep || !check_replication(probs[0], &ex)) rep = 0;
@@ -1584,6 +1595,7 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     if (H.n_tot + H.m_tot >= (int64_t)1 << 31) throw std::runtime_error("batch too large for 32-bit indices");
     const bool lite = device_setup_ok && device_setup_ok(H);
     H.device_setup = lite;
+    if (trusted && !lite) throw DeviceSetupDeclined();  // (skeleton problems hold no matrices: the caller assembles on the host)
     H.A.nrows = H.m_tot; H.A.ncols = H.n_tot; H.A.ptr.assign(1, 0);
     H.K.nrows = H.K.ncols = H.n_tot; H.K.ptr.assign(1, 0);
     H.G1.nrows = H.n_tot; H.G1.ncols = H.n_tot + H.m_tot; H.G1.ptr.assign(1, 0);

@@ -723,9 +723,14 @@ __device__ __forceinline__ double kp_row_finish(const SpmvArgs& a, const int row
 // row in CSR order.  A pair whose base falls outside the run [lo, hi) is loaded from the clamped base and put right by a
 // select (the slots of positions outside the run hold zeros and must meet finite operands from the run itself: a
 // neighbouring problem's entries may be NaN).
-template <int MODE, int NR, int NP>
+// LDSW (round 5): the operand window of the tile -- the positions [r0 - 8, r0 + 264) of the operand, clamped to the run, per
+// right-hand side: ~2 KiB -- is loaded ONCE per tile, coalesced, into LDS, and a lane takes its NP pairs from there
+// (ds_read) instead of issuing NP * NR sixteen-byte global loads whose addresses its neighbours request as well: two thirds
+// of the tile's vector-memory instructions gone; same values, same order of additions.  kBandWin = positions per window.
+constexpr int kBandWin = kBandLanes + 16;
+template <int MODE, int NR, int NP, bool LDSW = false>
 __device__ __forceinline__ void band_tile(const SpmvArgs& a, const int b, const int4 meta, const int4 m2, const int prob, const int rs_out,
-                                          double* __restrict__ prod, double* red) {
+                                          double* __restrict__ prod, double* red, double* __restrict__ win = nullptr) {
     static_assert(MODE == MODE_KP || MODE == MODE_KPB, "band tiles serve the K / H products");
     constexpr int kPlane = kBandRemMax + kBandRemMax / 8;
     auto kpad = [](int k) -> int { return k + (k >> 3); };
@@ -757,20 +762,32 @@ __device__ __forceinline__ void band_tile(const SpmvArgs& a, const int b, const 
     const int nb = row - cls;
     const double2* __restrict__ bv = reinterpret_cast<const double2*>(a.B.val + meta.z) + t;
     double2 v[NP], g[NP][NR];
-    int dsh[NP];
+    int dsh[NP], cbs[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) v[j] = bv[j * kBandLanes];
+    const int w0 = max(lo, r0 - 8);  // first position of the staged window
+    double wl[NR], wx[NR];
+    if (LDSW) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {  // (positions beyond the run are never multiplied by a nonzero: any finite entry of the run will do)
+            wl[q] = xin[min(w0 + t, hi - 1) + q * rs_in];
+            wx[q] = (t < kBandWin - kBandLanes) ? xin[min(w0 + kBandLanes + t, hi - 1) + q * rs_in] : 0.0;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
         const int base = nb + __builtin_amdgcn_sbfe(a.B.offw[j], 8 * cls, 8);
         const int cb = min(max(base, lo), hi - 2);
         dsh[j] = base - cb;
+        cbs[j] = cb;
+        if (!LDSW) {
 #pragma unroll
-        for (int q = 0; q < NR; ++q) {  // (8-byte aligned 16-byte load)
-            const double* src = xin + cb + q * rs_in;
-            double2 ld;
-            __builtin_memcpy(&ld, src, sizeof(double2));
-            g[j][q] = ld;
+            for (int q = 0; q < NR; ++q) {  // (8-byte aligned 16-byte load)
+                const double* src = xin + cb + q * rs_in;
+                double2 ld;
+                __builtin_memcpy(&ld, src, sizeof(double2));
+                g[j][q] = ld;
+            }
         }
     }
     // the remainder: entries [0, rem_cnt) of the tile, 64 per wavefront and trip (whole wavefronts beyond the count skip)
@@ -799,9 +816,27 @@ __device__ __forceinline__ void band_tile(const SpmvArgs& a, const int b, const 
         }
     }
     if (dn) return;  // (uniform over the workgroup; nothing has been written)
+    if (LDSW) {
+#pragma unroll
+        for (int q = 0; q < NR; ++q) {
+            win[q * kBandWin + t] = wl[q];
+            if (t < kBandWin - kBandLanes) win[q * kBandWin + kBandLanes + t] = wx[q];
+        }
+    }
     if (MODE == MODE_KPB) {
-        block_sum2(acc_n, acc_o, red);
+        block_sum2(acc_n, acc_o, red);  // (its barriers also publish the window)
         beta = acc_o > 0.0 ? acc_n / acc_o : 0.0;
+    } else if (LDSW) {
+        __syncthreads();
+    }
+    if (LDSW) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            // (a row whose pair lies outside the staged window -- a surplus lane behind the tile's last row -- reads a clamped slot)
+            const int o = min(max(cbs[j] - w0, 0), kBandWin - 2);
+#pragma unroll
+            for (int q = 0; q < NR; ++q) g[j][q] = make_double2(win[q * kBandWin + o], win[q * kBandWin + o + 1]);
+        }
     }
     double sum[NR];
 #pragma unroll
@@ -899,13 +934,14 @@ __device__ __forceinline__ void diag_tile(const SpmvArgs& a, const int b, const 
 // The SpMV over a band view: CSR tiles (the landmark rows; 2 nonzero slots per lane), band tiles and diag tiles in one
 // launch, a uniform branch per workgroup.  NR as in k_spmv (the band tiles of a replicated matrix are all replicated:
 // chains live in the replicas, never in the tail); NP = value-slot pairs per band row (4, 5 or 6).
-template <int MODE, int NR, int NP>
+template <int MODE, int NR, int NP, bool LDSW = false>
 __device__ __forceinline__ void spmv_band_body(const SpmvArgs& a) {
     KernelStamp stamp(a.tstamp);
     constexpr int UNR = kBandCsrNnz / kThreads;
     constexpr int kCsrPlane = UNR * kThreads + UNR * kThreads / 8;
     constexpr int kRemPlane = kBandRemMax + kBandRemMax / 8;
     __shared__ double prod[NR * (kCsrPlane > kRemPlane ? kCsrPlane : kRemPlane)];
+    __shared__ double win[LDSW ? NR * kBandWin : 1];
     __shared__ double red[8];
     __shared__ int32_t srow[kRowsPerBlock + 1];
     const int b = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
@@ -917,7 +953,7 @@ __device__ __forceinline__ void spmv_band_body(const SpmvArgs& a) {
     const int rs = (NR > 1) ? a.M.blk_rs[b] : 0;
     const int kind = (int)((unsigned)m2.w >> 28);
     if (kind == BAND_KIND_BAND) {
-        band_tile<MODE, NR, NP>(a, b, meta, m2, prob, rs, prod, red);
+        band_tile<MODE, NR, NP, LDSW>(a, b, meta, m2, prob, rs, prod, red, win);
     } else if (kind == BAND_KIND_DIAG) {
         diag_tile<MODE>(a, b, meta, prob, red);
     } else {
@@ -928,8 +964,8 @@ __device__ __forceinline__ void spmv_band_body(const SpmvArgs& a) {
         else spmv_tile<MODE, 1, UNR>(a, b, meta, prob, my_ptr, end_ptr, 0, prod, red, srow, lg);
     }
 }
-template <int MODE, int NR, int NP>
-__global__ __launch_bounds__(kThreads) void k_spmv_band(SpmvArgs a) { spmv_band_body<MODE, NR, NP>(a); }
+template <int MODE, int NR, int NP, bool LDSW = false>
+__global__ __launch_bounds__(kThreads) void k_spmv_band(SpmvArgs a) { spmv_band_body<MODE, NR, NP, LDSW>(a); }
 
 // V[dst[k]] = val[k] for the entries a band view serves (after k_kval: once per penalty update)
 __global__ __launch_bounds__(kThreads) void k_band_pack(const int32_t* __restrict__ dst, const double* __restrict__ val, double* __restrict__ V, int64_t nnz) {

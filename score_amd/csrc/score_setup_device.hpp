@@ -93,25 +93,48 @@ struct RzArgs {
     const int32_t* atp; const uint32_t* atpos; const int32_t* arow;
     const int32_t* gstart;   // first row of every cone group (the handle's cone table); group g ends at gstart[g + 1] / m
     double* D; double* E; double* d; double* e;
-    int64_t n, m, ngroups;
+    double* cmax;                    // n: per column the maximum of its A part (k_rz_colsA), zero between passes
+    const uint32_t* acol_sorted;     // the columns of A's entries in A'-map order
+    int64_t n, m, ngroups, nnzA;
     ProbTab tab;
 };
-// one wavefront per column (a landmark's column holds thousands of entries); columns of replicas >= 1 copy replica 0's scale
-__global__ __launch_bounds__(256) void k_rz_cols(RzArgs a) {
+// Column norms in two kernels.  The A part runs over the entries of A in COLUMN order (the A' map: a landmark's column holds
+// thousands of entries, a pose column two or three): a lane per entry, |v| E[row], a segmented maximum over the lanes of a
+// wavefront by column, and the last lane of every run folds its maximum into the column's cell with an integer atomic max on the
+// bit pattern (non-negative doubles order like their bits; a maximum does not depend on the order: deterministic).  The P part
+// and the scale itself: eight lanes per column (a row of P holds a dozen entries).  cmax is zeroed by k_rz_apply.
+__global__ __launch_bounds__(256) void k_rz_colsA(RzArgs a) {
     const int lane = threadIdx.x & 63;
-    const int64_t j = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool on = k < a.nnzA;
+    const uint32_t col = on ? a.acol_sorted[k] : 0xffffffffu;
+    double v = 0.0;
+    if (on) {
+        const uint32_t q = a.atpos[k];
+        v = fabs(a.A_val[q]) * a.E[a.arow[q]];
+    }
+    // segmented inclusive max-scan over the wavefront (runs of equal columns are contiguous)
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(v, o, 64);
+        const uint32_t cu = __shfl_up(col, o, 64);
+        if (lane >= o && cu == col) v = fmax(v, up);
+    }
+    const uint32_t cn = __shfl_down(col, 1, 64);
+    if (on && (lane == 63 || cn != col)) atomicMax((unsigned long long*)&a.cmax[col], (unsigned long long)__double_as_longlong(v));
+}
+__global__ __launch_bounds__(256) void k_rz_cols(RzArgs a) {
+    const int sub = threadIdx.x & 7;
+    const int64_t j = (int64_t)blockIdx.x * 32 + (threadIdx.x >> 3);
     if (j >= a.n) return;
     const RowInfo ri = row_info(a.tab, j);
     if (!ri.stored) return;
     double mx = 0.0;
-    for (int k = a.P_ptr[j] + lane; k < a.P_ptr[j + 1]; k += 64) mx = fmax(mx, fabs(a.P_val[k]) * a.D[a.P_col[k]]);
-    for (int k = a.atp[j] + lane; k < a.atp[j + 1]; k += 64) {
-        const uint32_t q = a.atpos[k];
-        mx = fmax(mx, fabs(a.A_val[q]) * a.E[a.arow[q]]);
-    }
+    for (int k = a.P_ptr[j] + sub; k < a.P_ptr[j + 1]; k += 8) mx = fmax(mx, fabs(a.P_val[k]) * a.D[a.P_col[k]]);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
-    if (lane == 0) {
+    for (int o = 4; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o, 8));
+    if (sub == 0) {
+        mx = fmax(mx, a.cmax[j]);
         mx *= a.D[j];
         a.d[j] = mx > 1e-12 ? 1.0 / sqrt(mx) : 1.0;
     }
@@ -131,6 +154,7 @@ __global__ __launch_bounds__(256) void k_rz_groups(RzArgs a) {
 __global__ __launch_bounds__(256) void k_rz_apply(RzArgs a) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < a.n) {
+        a.cmax[i] = 0.0;
         const RowInfo ri = row_info(a.tab, i);
         if (ri.stored) {
             const double v = a.D[i] * a.d[i];
@@ -211,22 +235,21 @@ __global__ __launch_bounds__(256) void k_g_fill(GDevArgs a) {
         if (ri.stored) { a.g1_col[s1 + l] = c; a.g1_val[s1 + l] = v; }
     }
 }
-// per problem: |q|_inf and |b|_inf, unscaled and scaled (the scales of the residual tests); one workgroup per problem
+// per problem: |q|_inf and |b|_inf, unscaled and scaled (the scales of the residual tests).  gridDim.y = problem, gridDim.x
+// workgroups share its entries and fold their maxima in with integer atomic maxima on the bit patterns (`out` zeroed first).
 __global__ __launch_bounds__(256) void k_prob_norms(ProbTab tab, const double* __restrict__ q_raw, const double* __restrict__ q,
                                                     const double* __restrict__ b_raw, const double* __restrict__ b, double* __restrict__ out) {
-    const int p = blockIdx.x;
+    const int p = blockIdx.y;
+    const int64_t stride = (int64_t)gridDim.x * 256, t0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     double v[4] = {0, 0, 0, 0};
-    for (int64_t i = tab.xoff[p] + threadIdx.x; i < tab.xoff[p + 1]; i += 256) { v[0] = fmax(v[0], fabs(q_raw[i])); v[1] = fmax(v[1], fabs(q[i])); }
-    for (int64_t r = tab.roff[p] + threadIdx.x; r < tab.roff[p + 1]; r += 256) { v[2] = fmax(v[2], fabs(b_raw[r])); v[3] = fmax(v[3], fabs(b[r])); }
-    __shared__ double sh[4][4];
+    for (int64_t i = tab.xoff[p] + t0; i < tab.xoff[p + 1]; i += stride) { v[0] = fmax(v[0], fabs(q_raw[i])); v[1] = fmax(v[1], fabs(q[i])); }
+    for (int64_t r = tab.roff[p] + t0; r < tab.roff[p + 1]; r += stride) { v[2] = fmax(v[2], fabs(b_raw[r])); v[3] = fmax(v[3], fabs(b[r])); }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v[c] = fmax(v[c], __shfl_xor(v[c], o, 64));
-        if ((threadIdx.x & 63) == 0) sh[c][threadIdx.x >> 6] = v[c];
+        if ((threadIdx.x & 63) == 0 && v[c] > 0.0) atomicMax((unsigned long long*)&out[4 * p + c], (unsigned long long)__double_as_longlong(v[c]));
     }
-    __syncthreads();
-    if (threadIdx.x < 4) out[4 * p + threadIdx.x] = fmax(fmax(sh[threadIdx.x][0], sh[threadIdx.x][1]), fmax(sh[threadIdx.x][2], sh[threadIdx.x][3]));
 }
 // x = xhat * D, y = yhat * E, s = shat / E into a staging buffer [x | y | s] (score_solve's copy-out)
 __global__ __launch_bounds__(256) void k_unscale(const double* __restrict__ xy, const double* __restrict__ s, const double* __restrict__ D,
@@ -469,6 +492,278 @@ __global__ __launch_bounds__(256) void k_cone_sq(const int32_t* __restrict__ con
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Model construction on the device: the factor graphs as flat arrays (score_graph) -> the raw program (P, q, A, b) in the
+// handle's global numbering, as records for the merge above.  score_assemble.hpp::assemble_graph is the specification:
+// every measurement writes the records assemble_graph's filling pass adds, in that order (slots the host skips -- a pinned
+// pose, an exactly-zero entry of the measurement's matrix -- hold the padding key), so P and q come out bit-equal to the host
+// assembler's.  Only replica 0's rows of P and the tail's are built (P = I_d (x) P_row + tail); q gets every replica's terms.
+// Reference: /root/reference/score/utils/gurobi_utils.py:504-526 (relative-pose cost), :449-501 (range cost), :433-446
+// (landmark priors), :336-352 (cones), :316-333 (pinned first pose: eliminated, its terms move to q and c0).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int32_t kQCol = 0x7fffffff;  // "column" of a record that belongs to q
+struct GaProb {          // one problem of the handle
+    int32_t xoff, roff;  // first unknown / first constraint row (global)
+    int32_t Np, Nl, Nr;  // poses (pose 0 is the pinned one), landmarks, ranges
+    int32_t n_rep;       // unknowns per replica
+    int32_t rel_off, rng_off, pri_off, pin_off;   // first relative-pose measurement / range / prior / pinned-edge entry of the problem
+    int32_t rec_rel, rec_rng, rec_pri;             // first P-record slot of its relative-pose measurements / ranges / priors
+    int32_t recq_pin, recq_rng, recq_pri;          // first q-record slot of its pinned edges / ranges / priors
+    int32_t a_off;                                  // first entry of its rows of A
+};
+struct GaArgs {
+    int32_t d, relaxation, count;
+    const GaProb* probs;
+    const int32_t* rel_prob; const int32_t* rng_prob; const int32_t* pri_prob; const int32_t* pin_prob;  // measurement -> problem (sorted: tab_find over offsets)
+    int64_t n_rel, n_rng, n_pri, n_pin;
+    const int32_t* rel_base; const int32_t* rel_to; const double* rel_t; const double* rel_R; const double* rel_kappa; const double* rel_tau;
+    const int32_t* rng_a; const int32_t* rng_b; const double* rng_dist; const double* rng_prec;
+    const int32_t* pri_lm; const double* pri_t; const double* pri_prec;
+    const int32_t* pin_edge;     // relative-pose measurements (global index) that touch a pinned pose
+    unsigned long long* key; uint32_t* idx; double* val;     // records
+    unsigned long long pad_key;                              // (n_tot << 32)
+    const int32_t* A_ptr; int32_t* A_col; double* A_val; double* b;   // raw A (global), b
+};
+// solver column (local) of entry j of row k of pose p; -1 for the pinned pose
+__device__ __forceinline__ int64_t ga_pcol(const GaProb& P, int d, int64_t p, int k, int j) {
+    return p == 0 ? -1 : (int64_t)k * P.n_rep + (p - 1) * (d + 1) + j;
+}
+__device__ __forceinline__ int64_t ga_tcol(const GaProb& P, int d, int64_t v, int k) {
+    if (v < P.Np) return ga_pcol(P, d, v, k, d);
+    return (int64_t)k * P.n_rep + (int64_t)(P.Np - 1) * (d + 1) + (v - P.Np);
+}
+struct GaEdge {  // G, W, G'W, G'WG of one relative-pose measurement (assemble_graph's locals)
+    double G[4][4], W[4], GtW[4][4], GtWG[4][4];
+};
+__device__ __forceinline__ void ga_edge_blocks(const GaArgs& a, int64_t e, GaEdge& E) {
+#pragma clang fp contract(off)  // (the host assembler's arithmetic, operation by operation: no fused multiply-adds)
+    const int d = a.d, D1 = d + 1;
+    const double* tm = a.rel_t + e * d;
+    const double* Rm = a.rel_R + e * d * d;
+    const double kap = a.rel_kappa[e], tau = a.rel_tau[e];
+    for (int c = 0; c < 4; ++c)
+        for (int l = 0; l < 4; ++l) E.G[c][l] = 0.0;
+    for (int c = 0; c < d; ++c) {
+        for (int l = 0; l < d; ++l) E.G[c][l] = Rm[l * d + c];
+        E.W[c] = tau;
+    }
+    for (int l = 0; l < d; ++l) E.G[d][l] = tm[l];
+    E.G[d][d] = 1.0;
+    E.W[d] = kap;
+    for (int x = 0; x < D1; ++x)
+        for (int y = 0; y < D1; ++y) {
+            E.GtW[x][y] = E.G[y][x] * E.W[y];
+            double s_ = 0;
+            for (int c = 0; c < D1; ++c) s_ += E.G[c][x] * E.W[c] * E.G[c][y];
+            E.GtWG[x][y] = s_;
+        }
+}
+// P records of the relative-pose measurements: D1 + 3 D1^2 slots each, in assemble_graph's order (k = 0)
+__global__ __launch_bounds__(256) void k_ga_rel(GaArgs a) {
+#pragma clang fp contract(off)
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.n_rel) return;
+    const GaProb P = a.probs[a.rel_prob[e]];
+    const int d = a.d, D1 = d + 1, per = D1 + 3 * D1 * D1;
+    const int64_t i = a.rel_base[e], j = a.rel_to[e];
+    GaEdge E;
+    ga_edge_blocks(a, e, E);
+    int64_t o = (int64_t)P.rec_rel + (e - P.rel_off) * per;
+    const int64_t ci = ga_pcol(P, d, i, 0, 0), cj = ga_pcol(P, d, j, 0, 0);
+    auto put = [&](bool on, int64_t r, int64_t c, double v) {
+        a.key[o] = on ? (((unsigned long long)(P.xoff + r)) << 32 | (unsigned long long)(uint32_t)(P.xoff + c)) : a.pad_key;
+        a.idx[o] = (uint32_t)o;
+        a.val[o] = v;
+        ++o;
+    };
+    for (int x = 0; x < D1; ++x) put(cj >= 0, cj + x, cj + x, 2.0 * E.W[x]);
+    for (int x = 0; x < D1; ++x)
+        for (int y = 0; y < D1; ++y) {
+            const double v = -2.0 * E.GtW[x][y];
+            const bool on = cj >= 0 && ci >= 0 && E.G[y][x] != 0.0;
+            put(on, ci + x, cj + y, v);
+            put(on, cj + y, ci + x, v);
+        }
+    for (int x = 0; x < D1; ++x)
+        for (int y = 0; y < D1; ++y) put(ci >= 0, ci + x, ci + y, 2.0 * E.GtWG[x][y]);
+}
+// q records of the measurements that touch the pinned pose: d * D1 slots each (replica k: D1 entries)
+__global__ __launch_bounds__(256) void k_ga_pin(GaArgs a) {
+#pragma clang fp contract(off)
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= a.n_pin) return;
+    const GaProb P = a.probs[a.pin_prob[t]];
+    const int d = a.d, D1 = d + 1;
+    const int64_t e = a.pin_edge[t];
+    const int64_t i = a.rel_base[e], j = a.rel_to[e];
+    GaEdge E;
+    ga_edge_blocks(a, e, E);
+    int64_t o = (int64_t)P.recq_pin + (t - P.pin_off) * d * D1;
+    auto putq = [&](bool on, int64_t r, double v) {
+        a.key[o] = on ? (((unsigned long long)(P.xoff + r)) << 32 | (unsigned long long)(uint32_t)kQCol) : a.pad_key;
+        a.idx[o] = (uint32_t)o;
+        a.val[o] = v;
+        ++o;
+    };
+    for (int k = 0; k < d; ++k) {
+        const int64_t ci = ga_pcol(P, d, i, k, 0), cj = ga_pcol(P, d, j, k, 0);
+        double ui[4] = {0, 0, 0, 0}, uj[4] = {0, 0, 0, 0};  // the pinned pose is [I | 0]: its row k is e_k
+        ui[k] = 1.0; uj[k] = 1.0;
+        for (int x = 0; x < D1; ++x) {
+            if (cj >= 0 && ci < 0) {  // u_i fixed
+                double gu = 0;
+                for (int l = 0; l < D1; ++l) gu += E.G[x][l] * ui[l];
+                putq(true, cj + x, -2.0 * E.W[x] * gu);
+            } else if (ci >= 0 && cj < 0) {  // u_j fixed
+                double s_ = 0;
+                for (int c = 0; c < D1; ++c) s_ += E.GtW[x][c] * uj[c];
+                putq(true, ci + x, -2.0 * s_);
+            } else {
+                putq(false, 0, 0.0);
+            }
+        }
+    }
+}
+// ranges: P records (SOCP: the distance variable's diagonal; QCQP: 9 couplings of replica 0), q record (SOCP), the cone's
+// rows of A and b
+__global__ __launch_bounds__(256) void k_ga_rng(GaArgs a) {
+#pragma clang fp contract(off)
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.n_rng) return;
+    const GaProb P = a.probs[a.rng_prob[r]];
+    const int d = a.d, D1 = d + 1;
+    const int64_t lr = r - P.rng_off;
+    const double w = a.rng_prec[r], dist = a.rng_dist[r];
+    const int64_t va = a.rng_a[r], vb = a.rng_b[r];
+    const int64_t rng_base = (int64_t)d * P.n_rep, rq_base = (int64_t)(P.Np - 1) * D1 + P.Nl;
+    const int64_t row0 = (int64_t)P.roff + lr * D1;
+    if (a.relaxation == 0) {
+        const int64_t c = rng_base + lr;
+        const int64_t o = (int64_t)P.rec_rng + lr, oq = (int64_t)P.recq_rng + lr;
+        a.key[o] = ((unsigned long long)(P.xoff + c)) << 32 | (unsigned long long)(uint32_t)(P.xoff + c);
+        a.idx[o] = (uint32_t)o; a.val[o] = 2.0 * w;
+        a.key[oq] = ((unsigned long long)(P.xoff + c)) << 32 | (unsigned long long)(uint32_t)kQCol;
+        a.idx[oq] = (uint32_t)oq; a.val[oq] = -2.0 * w * dist;
+        // (d_ij, t_a - t_b) in SOC: A = -[e_d ; e_ta - e_tb], b = 0
+        int k0 = a.A_ptr[row0];
+        a.A_col[k0] = (int32_t)(P.xoff + c); a.A_val[k0] = -1.0;
+        a.b[row0] = 0.0;
+        for (int k = 0; k < d; ++k) {
+            int64_t ca = ga_tcol(P, d, va, k), cb = ga_tcol(P, d, vb, k);
+            double xa = -1.0, xb = 1.0;
+            if (ca >= 0 && cb >= 0 && cb < ca) { const int64_t t = ca; ca = cb; cb = t; const double u = xa; xa = xb; xb = u; }
+            int kk = a.A_ptr[row0 + 1 + k];
+            if (ca >= 0) { a.A_col[kk] = (int32_t)(P.xoff + ca); a.A_val[kk] = xa; ++kk; }
+            if (cb >= 0) { a.A_col[kk] = (int32_t)(P.xoff + cb); a.A_val[kk] = xb; }
+            a.b[row0 + 1 + k] = 0.0;
+        }
+    } else {
+        // w || t_a - t_b - dist r ||^2: replica 0's couplings; (1, r_ij) in SOC: A = -[0 ; I], b = (1, 0 .. 0)
+        int64_t o = (int64_t)P.rec_rng + lr * 9;
+        const int64_t cs[3] = {ga_tcol(P, d, va, 0), ga_tcol(P, d, vb, 0), rq_base + lr};
+        const double cf[3] = {1.0, -1.0, -dist};
+        for (int x = 0; x < 3; ++x)
+            for (int y = 0; y < 3; ++y) {
+                const bool on = cs[x] >= 0 && cs[y] >= 0;
+                a.key[o] = on ? (((unsigned long long)(P.xoff + cs[x])) << 32 | (unsigned long long)(uint32_t)(P.xoff + cs[y])) : a.pad_key;
+                a.idx[o] = (uint32_t)o; a.val[o] = 2.0 * w * cf[x] * cf[y];
+                ++o;
+            }
+        a.b[row0] = 1.0;
+        for (int k = 0; k < d; ++k) {
+            const int kk = a.A_ptr[row0 + 1 + k];
+            a.A_col[kk] = (int32_t)(P.xoff + (int64_t)k * P.n_rep + rq_base + lr); a.A_val[kk] = -1.0;
+            a.b[row0 + 1 + k] = 0.0;
+        }
+    }
+}
+// landmark priors: one P record (replica 0), d q records
+__global__ __launch_bounds__(256) void k_ga_pri(GaArgs a) {
+#pragma clang fp contract(off)
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= a.n_pri) return;
+    const GaProb P = a.probs[a.pri_prob[e]];
+    const int d = a.d, D1 = d + 1;
+    const int64_t le = e - P.pri_off, l = a.pri_lm[e];
+    const double w = a.pri_prec[e];
+    const int64_t lm_base = (int64_t)(P.Np - 1) * D1;
+    const int64_t o = (int64_t)P.rec_pri + le;
+    const int64_t c0 = lm_base + l;
+    a.key[o] = ((unsigned long long)(P.xoff + c0)) << 32 | (unsigned long long)(uint32_t)(P.xoff + c0);
+    a.idx[o] = (uint32_t)o; a.val[o] = 2.0 * w;
+    for (int k = 0; k < d; ++k) {
+        const int64_t oq = (int64_t)P.recq_pri + le * d + k;
+        const int64_t c = (int64_t)k * P.n_rep + lm_base + l;
+        a.key[oq] = ((unsigned long long)(P.xoff + c)) << 32 | (unsigned long long)(uint32_t)kQCol;
+        a.idx[oq] = (uint32_t)oq; a.val[oq] = -2.0 * w * a.pri_t[e * d + k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The estimate in the reference's own shapes, straight from the device-resident solution (read_estimates_host,
+// score_assemble.hpp, is the specification): one thread per pose / landmark / range.  Replaces
+// VariableCollection.get_variable_values, /root/reference/score/utils/gurobi_utils.py:114-136.
+// ---------------------------------------------------------------------------------------------------------------------
+struct EstArgs {
+    int32_t d, relaxation, count, qcqp_dirs;
+    const EstProb* probs;
+    const int32_t* pose_off; const int32_t* lm_off; const int32_t* rng_off;   // count + 1 each
+    int64_t n_pose, n_lm, n_rng;
+    const double* x; const double* D;     // the equilibrated solution and the column scales: x = xhat * D
+    const int32_t* rng_a; const int32_t* rng_b; const double* rng_dist;
+    double* poses; double* relaxed; double* lms; double* rng; int32_t* degenerate;
+};
+__global__ __launch_bounds__(256) void k_read_estimates(EstArgs a) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int d = a.d, D1 = d + 1;
+    auto xv = [&](const EstProb& P, int64_t local) { const int64_t c = P.xoff + local; return a.x[c] * a.D[c]; };
+    if (i < a.n_pose) {
+        const EstProb P = a.probs[a.count > 1 ? tab_find(a.pose_off, a.count, i) : 0];
+        const int64_t lp = i - P.pose_off;
+        double blk[3][4], m[9], r[9];
+        for (int k = 0; k < d; ++k)
+            for (int j = 0; j < D1; ++j) blk[k][j] = lp == 0 ? (j == k ? 1.0 : 0.0) : xv(P, (int64_t)k * P.n_rep + (lp - 1) * D1 + j);
+        for (int k = 0; k < d; ++k)
+            for (int j = 0; j < d; ++j) m[k * d + j] = blk[k][j];
+        int32_t bad = 0;
+        if (d == 2) round_so2(m, r, &bad); else round_so3(m, r, &bad);
+        a.degenerate[i] = bad;
+        for (int k = 0; k < d; ++k)
+            for (int j = 0; j < D1; ++j) a.relaxed[i * d * D1 + k * D1 + j] = blk[k][j];
+        double* T = a.poses + i * D1 * D1;
+        for (int k = 0; k < d; ++k) {
+            for (int j = 0; j < d; ++j) T[k * D1 + j] = r[k * d + j];
+            T[k * D1 + d] = blk[k][d];
+        }
+        for (int j = 0; j < d; ++j) T[d * D1 + j] = 0.0;
+        T[d * D1 + d] = 1.0;
+    }
+    if (i < a.n_lm) {
+        const EstProb P = a.probs[a.count > 1 ? tab_find(a.lm_off, a.count, i) : 0];
+        const int64_t l = i - P.lm_off, lm0 = (int64_t)(P.Np - 1) * D1;
+        for (int k = 0; k < d; ++k) a.lms[i * d + k] = xv(P, (int64_t)k * P.n_rep + lm0 + l);
+    }
+    if (i < a.n_rng) {
+        const EstProb P = a.probs[a.count > 1 ? tab_find(a.rng_off, a.count, i) : 0];
+        const int64_t r_ = i - P.rng_off, lm0 = (int64_t)(P.Np - 1) * D1;
+        if (a.relaxation != 0) {
+            for (int k = 0; k < d; ++k) a.rng[i * d + k] = xv(P, (int64_t)k * P.n_rep + lm0 + P.Nl + r_);
+        } else if (!a.qcqp_dirs) {
+            a.rng[i] = xv(P, (int64_t)d * P.n_rep + r_);
+        } else {
+            auto tvar = [&](int64_t v, int k) {
+                if (v < P.Np) return v == 0 ? 0.0 : xv(P, (int64_t)k * P.n_rep + (v - 1) * D1 + d);
+                return xv(P, (int64_t)k * P.n_rep + lm0 + (v - P.Np));
+            };
+            double dl[3], nn = 0.0;
+            for (int k = 0; k < d; ++k) { dl[k] = tvar(a.rng_a[i], k) - tvar(a.rng_b[i], k); nn += dl[k] * dl[k]; }
+            const double den = fmax(sqrt(nn), a.rng_dist[i]);
+            for (int k = 0; k < d; ++k) a.rng[i * d + k] = den > 0.0 ? dl[k] / den : 0.0;
+        }
+    }
 }
 
 }  // namespace score

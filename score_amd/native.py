@@ -381,6 +381,92 @@ def _read_back_maps(a: Dict[str, np.ndarray], relaxation: str, qp: "NativeQP") -
     )
 
 
+class GraphQP:
+    """Sizes of the conic program of a graph whose model is built inside ``score_create_from_graphs`` (on the device): what
+    ``ScoreModel`` needs of a ``ConicQP`` when nobody asks for the matrices."""
+
+    def __init__(self, a: Dict[str, np.ndarray], relaxation: str):
+        d = int(a["dim"])
+        Np, Nl, Nr = len(a["pose_names"]), len(a["landmark_names"]), len(a["range_keys"])
+        socp = relaxation == SOCP_RELAXATION
+        self.rep_d, self.rep_n = d, (Np - 1) * (d + 1) + Nl + (0 if socp else Nr)
+        self.n = d * self.rep_n + (Nr if socp else 0)
+        self.m, self.z = Nr * (d + 1), 0
+        self.block_size = d + 1
+
+
+class GraphModel:
+    """``ScoreModel``'s interface for a graph whose program is built inside ``score_create_from_graphs``.  The native column
+    layout is regular (replica by replica: the pose entries, the landmark coordinates, the QCQP range components; then the SOCP
+    distances), so a solution is read back with reshapes (``views``) instead of index maps; the maps themselves
+    (``free_cols``, ``range_ends``: model space, the Gurobi layout) are made on first use -- per graph they cost more than
+    the read-back itself, and a Monte-Carlo sweep never asks for them."""
+
+    def __init__(self, a: Dict[str, np.ndarray], relaxation: str):
+        check_valid_relaxation(relaxation)
+        self.graph_arrays = a
+        self.relaxation = relaxation
+        self.dim = d = int(a["dim"])
+        self.qp = GraphQP(a, relaxation)
+        self.pose_names, self.landmark_names, self.range_keys = a["pose_names"], a["landmark_names"], a["range_keys"]
+        self.pose_chain_names = a.get("pose_chain_names")
+        Np, Nl, Nr = len(self.pose_names), len(self.landmark_names), len(self.range_keys)
+        self.rng_width = 1 if relaxation == SOCP_RELAXATION else d
+        self.lm_base = Np * d * (d + 1)
+        self.rng_base = self.lm_base + Nl * d
+        self.n_model = self.rng_base + Nr * self.rng_width
+        self.range_dist = a["rng_dist"] if Nr else None
+        self._full = None
+
+    def _maps(self) -> ScoreModel:
+        if self._full is None:
+            self._full = _read_back_maps(self.graph_arrays, self.relaxation, self.qp)
+        return self._full
+
+    free_cols = property(lambda self: self._maps().free_cols)
+    fixed_cols = property(lambda self: self._maps().fixed_cols)
+    fixed_vals = property(lambda self: self._maps().fixed_vals)
+    range_ends = property(lambda self: self._maps().range_ends)
+
+    def expand(self, x_solver: np.ndarray) -> np.ndarray:
+        return self._maps().expand(x_solver)
+
+    def reduce(self, x_model: np.ndarray) -> np.ndarray:
+        return self._maps().reduce(x_model)
+
+    def pose_blocks(self, x_model: np.ndarray) -> np.ndarray:
+        return self._maps().pose_blocks(x_model)
+
+    def landmark_block(self, x_model: np.ndarray) -> np.ndarray:
+        return self._maps().landmark_block(x_model)
+
+    def range_block(self, x_model: np.ndarray) -> np.ndarray:
+        return self._maps().range_block(x_model)
+
+    def views(self, x_solver: np.ndarray):
+        """(pose blocks (Np, d, d + 1) with the pinned pose, landmarks (Nl, d), range variables (Nr, 1 or d)) of a solver-space
+        vector -- what ``pose_blocks / landmark_block / range_block`` give for ``expand(x_solver)``, by reshapes."""
+        d, D1 = self.dim, self.dim + 1
+        Np, Nl, Nr = len(self.pose_names), len(self.landmark_names), len(self.range_keys)
+        n_rep = self.qp.rep_n
+        X = x_solver[: d * n_rep].reshape(d, n_rep)
+        blocks = np.empty((Np, d, D1))
+        blocks[0] = np.hstack([np.eye(d), np.zeros((d, 1))])
+        blocks[1:] = X[:, : (Np - 1) * D1].reshape(d, Np - 1, D1).transpose(1, 0, 2)
+        lm0 = (Np - 1) * D1
+        lms = np.ascontiguousarray(X[:, lm0 : lm0 + Nl].T)
+        if self.relaxation == SOCP_RELAXATION:
+            rng = x_solver[d * n_rep :].reshape(Nr, 1).copy()
+        else:
+            rng = np.ascontiguousarray(X[:, lm0 + Nl : lm0 + Nl + Nr].T)
+        return blocks, lms, rng
+
+
+def graph_model(a: Dict[str, np.ndarray], relaxation: str) -> GraphModel:
+    """The read-back side of ``assemble_native`` without the program itself (``solver.ConicSolver.from_graphs`` builds it)."""
+    return GraphModel(a, relaxation)
+
+
 def assemble_native(data, relaxation: str = QCQP_RELAXATION, lib_path: Optional[str] = None, arrays: Optional[dict] = None) -> ScoreModel:
     check_valid_relaxation(relaxation)
     lib = load_library(lib_path)

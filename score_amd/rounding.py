@@ -109,3 +109,21 @@ def round_to_special_orthogonal(mat: np.ndarray, lib=None, device: int = 0) -> n
     except (ValueError, np.linalg.LinAlgError):
         raise ValueError(f"Could not round matrix to special orthogonal form: {mat}")
     return R[0] if single else R
+
+
+def finish_device_poses(T: np.ndarray, relaxed: np.ndarray, flags: np.ndarray) -> np.ndarray:
+    """The host's share of ``score_read_estimates``: pose blocks the device flagged as degenerate (their SO(d) projection is
+    not unique: rank-deficient / reflection-like) take the reference's SVD formula (matrix_utils.py:59-79) and its validity
+    check; a non-finite estimate raises the reference's ``ValueError``."""
+    d = T.shape[-1] - 1
+    try:
+        if not np.isfinite(T).all() or not np.isfinite(relaxed).all():
+            raise ValueError("non-finite entries")
+        degenerate = flags != 0
+        if degenerate.any():
+            R = _svd_round(np.ascontiguousarray(relaxed[degenerate][:, :, :d]))
+            check_rotation_matrix(R, assert_test=True)
+            T[degenerate, :d, :d] = R
+    except (ValueError, np.linalg.LinAlgError):
+        raise ValueError(f"Could not round matrix to special orthogonal form: {relaxed[:, :, :d]}")
+    return T

@@ -69,17 +69,31 @@ def extract_solver_results(
 ) -> compat.SolverResults:
     """gurobi_utils.py:190-203 + VariableCollection.get_variable_values (:114-136)."""
     d = model.dim
-    xm = model.expand(x_solver)
-    blocks = model.pose_blocks(xm)  # (Np, d, d+1)
+    fast = getattr(model, "views", None)  # (native.GraphModel: the regular native layout, read back by reshapes)
+    if fast is not None:
+        blocks, lm_vals, rng_vals = fast(x_solver)
+    else:
+        xm = model.expand(x_solver)
+        blocks = model.pose_blocks(xm)  # (Np, d, d+1)
+        lm_vals = model.landmark_block(xm).copy()
     R = round_to_special_orthogonal(blocks[:, :, :d], lib=lib, device=device)  # lib: on the device
-    T = np.tile(np.eye(d + 1), (blocks.shape[0], 1, 1))
+    T = np.zeros((blocks.shape[0], d + 1, d + 1))
+    T[:, d, d] = 1.0
     T[:, :d, :d] = R
     T[:, :d, d] = blocks[:, :, d]
     # dict-like views over the stacked arrays (compat.ArrayDict): no per-pose Python objects
     poses = compat.ArrayDict(model.pose_names, T)
-    landmarks = compat.ArrayDict(model.landmark_names, model.landmark_block(xm).copy())
+    landmarks = compat.ArrayDict(model.landmark_names, lm_vals)
     if requested_relaxation == model.relaxation:
-        dists = compat.ArrayDict(model.range_keys, model.range_block(xm).copy())
+        dists = compat.ArrayDict(model.range_keys, rng_vals if fast is not None else model.range_block(xm).copy())
+    elif fast is not None:  # QCQP answered through the SOCP: r = D / max(|D|, dist) from the stacked translations
+        a = model.graph_arrays
+        tr = np.concatenate([blocks[:, :, d], lm_vals]) if len(lm_vals) else blocks[:, :, d]
+        delta = tr[a["rng_a"]] - tr[a["rng_b"]]
+        den = np.maximum(np.sqrt(np.einsum("ij,ij->i", delta, delta)), a["rng_dist"]) if len(delta) else np.zeros(0)
+        dv = np.zeros((len(delta), d))
+        np.divide(delta, den[:, None], out=dv, where=den[:, None] > 0)
+        dists = compat.ArrayDict(model.range_keys, dv)
     else:  # QCQP answered through the SOCP
         dists = compat.ArrayDict(model.range_keys, _qcqp_dists_from_socp(model, xm, data))
     values = compat.VariableValues(d, poses, landmarks, dists)
@@ -87,7 +101,7 @@ def extract_solver_results(
         variables=values, total_time=total_time, solved=solved,
         pose_chain_names=model.pose_chain_names if model.pose_chain_names is not None else data.get_pose_chain_names(),
         solver_cost=(info or {}).get("pobj"), info=info,
-        relaxed_poses=compat.ArrayDict(model.pose_names, blocks.copy()),
+        relaxed_poses=compat.ArrayDict(model.pose_names, blocks if fast is not None else blocks.copy()),
     )
 
 
@@ -124,7 +138,17 @@ def _model_for(data, relaxation_type: str, qcqp_mode: str, lib_path: Optional[st
 
 def _models_for(datas: Sequence, relaxation_type: str, qcqp_mode: str, lib_path: Optional[str] = None, assembler: str = "native") -> List[ScoreModel]:
     """``_model_for`` for a list of graphs; the native assembler takes them in one foreign call
-    (``native.assemble_native_batch`` -> ``score_assemble_batch``: one graph per host thread of the library)."""
+    (``native.assemble_native_batch`` -> ``score_assemble_batch``: one graph per host thread of the library);
+    ``assembler="device"``: the read-back maps only -- the model itself is built inside ``score_create_from_graphs``."""
+    if assembler == "device":
+        from .native import ArrayGraph, graph_arrays, graph_model, unconnected_variable_names
+
+        relax = SOCP_RELAXATION if (relaxation_type == QCQP_RELAXATION and qcqp_mode == "via_socp") else relaxation_type
+        arrays = [data.arrays if isinstance(data, ArrayGraph) else graph_arrays(data) for data in datas]
+        for a in arrays:  # score/solve_score.py:28-32, on the flat arrays
+            unconnected_variables = unconnected_variable_names(a)
+            assert len(unconnected_variables) == 0, f"Found {unconnected_variables} unconnected variables. "
+        return [graph_model(a, relax) for a in arrays]  # (model.graph_arrays: what ConicSolver.from_graphs hands to the library)
     if assembler != "native":
         out = []
         for data in datas:
@@ -143,7 +167,7 @@ def _models_for(datas: Sequence, relaxation_type: str, qcqp_mode: str, lib_path:
 
 def solve_score(
     data, *args, relaxation_type: str = QCQP_RELAXATION, qcqp_mode: str = "via_socp",
-    solver_settings: Optional[dict] = None, lib_path: Optional[str] = None, assembler: str = "native",
+    solver_settings: Optional[dict] = None, lib_path: Optional[str] = None, assembler: str = "device",
 ) -> compat.SolverResults:
     """MLE estimate of poses and landmarks from the SCORE relaxation.
 
@@ -163,9 +187,14 @@ def solve_score(
 def solve_score_batch(
     datas: Sequence, relaxation_type: str = QCQP_RELAXATION, qcqp_mode: str = "via_socp",
     solver_settings: Optional[dict] = None, lib_path: Optional[str] = None, lockstep: Optional[bool] = None,
-    workers: int = 4, assembler: str = "native", _models: Optional[list] = None, group_size: Optional[int] = None,
+    workers: int = 4, assembler: str = "device", _models: Optional[list] = None, group_size: Optional[int] = None,
 ) -> List[compat.SolverResults]:
     """Independent factor graphs on one GPU.
+
+    ``assembler``: where the model (gurobi_utils.py:173-187 ``initialize_model``) is built -- ``"device"`` (default): inside
+    ``score_create_from_graphs``, on the GPU, from the graphs' flat arrays; ``"native"``: the C++ assembler on the host
+    (``score_assemble``), the program handed to ``score_create``; ``"python"``: the NumPy / SciPy twin of it.  Same program,
+    same column layout, bit-equal P, q, A, b between the first two.
 
     ``lockstep=True``: all graphs in ONE handle, advancing through the same kernel launches --
     ADMM warm-up and semismooth-Newton polish alike, with per-problem penalties, step lengths,
@@ -250,6 +279,43 @@ def solve_score_batch(
     if relaxation_type == QCQP_RELAXATION and qcqp_mode == "direct":
         settings.update(cg_iters=8, adaptive_rho=0)
     settings.update(solver_settings or {})
+    if assembler == "device":
+        # model construction inside score_create_from_graphs, the estimate straight from the device (score_read_estimates):
+        # rounded poses, landmarks, range variables -- no x / y / s copies, no index maps on the host
+        from .rounding import finish_device_poses
+
+        solver = ConicSolver.from_graphs([m.graph_arrays for m in models], 0 if models[0].relaxation == SOCP_RELAXATION else 1,
+                                         settings, lib_path=lib_path)
+        try:
+            infos, ests = solver.solve_estimates(qcqp_directions=(relaxation_type != models[0].relaxation))
+        finally:
+            solver.close()
+        out, errors = [], []
+        for k, (data, model, info, (T, B, Lm, Rg, flags)) in enumerate(zip(datas, models, infos, ests)):
+            solved = info["status"] == 1
+            if not solved:
+                logger.warning("SCORE solve did not converge: %s", info)
+            try:
+                T = finish_device_poses(T, B, flags)
+            except ValueError as exc:
+                if len(datas) == 1:
+                    raise
+                errors.append((k, exc))
+                out.append(None)
+                continue
+            values = compat.VariableValues(model.dim, compat.ArrayDict(model.pose_names, T), compat.ArrayDict(model.landmark_names, Lm),
+                                           compat.ArrayDict(model.range_keys, Rg))
+            out.append(compat.SolverResults(
+                variables=values, total_time=info["solve_ms"] * 1e-3, solved=solved,
+                pose_chain_names=model.pose_chain_names if model.pose_chain_names is not None else data.get_pose_chain_names(),
+                solver_cost=info.get("pobj"), info=info, relaxed_poses=compat.ArrayDict(model.pose_names, B),
+            ))
+        if errors:
+            k, exc = errors[0]
+            err = ValueError(f"{len(errors)} of {len(datas)} graphs could not be extracted (first: #{k}: {exc})")
+            err.partial_results = out  # type: ignore[attr-defined]
+            raise err
+        return out
     solver = ConicSolver([m.qp for m in models], settings, lib_path=lib_path)
     lib, device = solver.lib, int(solver.settings.device)
     try:

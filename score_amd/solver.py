@@ -79,12 +79,12 @@ STATUS_NAMES = {0: "unsolved", 1: "solved", 2: "max_iters", 3: "numerical"}
 # every symbol include/score_hip.h declares
 ABI_SYMBOLS = [
     "score_assemble", "score_assemble_batch", "score_assembled_view", "score_assembled_free", "score_round_to_so",
-    "score_default_settings", "score_create", "score_create_batch", "score_dims", "score_solve",
+    "score_default_settings", "score_create", "score_create_batch", "score_create_from_graphs", "score_read_estimates", "score_dims", "score_solve",
     "score_reset", "score_solve_steps", "score_newton_steps", "score_linear_create", "score_linear_solve", "score_refine_create", "score_refine_run", "score_refine_destroy", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
     "score_trim_caches", "score_last_error", "score_backend", "score_abi_version",
 ]
 
-ABI_VERSION = 4  # SCORE_ABI_VERSION of include/score_hip.h this binding's structs follow
+ABI_VERSION = 5  # SCORE_ABI_VERSION of include/score_hip.h this binding's structs follow
 
 
 def load_library(path: Optional[str] = None) -> C.CDLL:
@@ -164,6 +164,54 @@ def trim_caches(lib_path: Optional[str] = None) -> int:
 
 class ConicSolver:
     """A batch of conic QPs (``score_amd.assemble.ConicQP``) resident on one GPU."""
+
+    @classmethod
+    def from_graphs(cls, arrays: Sequence[dict], relaxation: int, settings: Optional[dict] = None, lib_path: Optional[str] = None) -> "ConicSolver":
+        """A handle straight from factor graphs (``score_create_from_graphs``): ``arrays`` are the flat arrays of
+        ``native.graph_arrays``, ``relaxation`` 0 = "SOCP" / 1 = "QCQP".  Model construction (the reference's
+        ``initialize_model``, gurobi_utils.py:173-187) happens inside the call, on the device; the unknowns are ordered as
+        ``score_assemble`` orders them, so ``native.graph_model`` supplies the read-back maps."""
+        from .native import ScoreGraph, score_graph_struct  # (native imports this module)
+
+        self = cls.__new__(cls)
+        self.lib = load_library(lib_path)
+        self.lib.score_create_from_graphs.argtypes = [C.POINTER(ScoreGraph), C.c_int32, C.POINTER(ScoreSettings), C.POINTER(C.c_void_p)]
+        self.count = len(arrays)
+        st = ScoreSettings()
+        self.lib.score_default_settings(C.byref(st))
+        for k, v in (settings or {}).items():
+            if not hasattr(st, k):
+                raise ValueError(f"unknown solver setting {k}")
+            setattr(st, k, v)
+        self.settings = st
+        gs = (ScoreGraph * self.count)()
+        keep = []
+        self.ns, self.ms = [], []
+        for i, a in enumerate(arrays):
+            g = score_graph_struct(a, int(relaxation))
+            keep.append(g)
+            C.memmove(C.byref(gs[i]), C.byref(g), C.sizeof(ScoreGraph))
+            d = int(a["dim"])
+            Np, Nl, Nr = len(a["pose_names"]), len(a["landmark_names"]), len(a["rng_a"])
+            n_rep = (Np - 1) * (d + 1) + Nl + (Nr if relaxation else 0)
+            self.ns.append(d * n_rep + (0 if relaxation else Nr))
+            self.ms.append(Nr * (d + 1))
+            est_per = getattr(self, "_est_per", None)
+            if est_per is None:
+                est_per = self._est_per = []
+            est_per.append((Np, Nl, Nr))
+            self._est_dims = (d, int(relaxation), est_per)
+        self._keep = []
+        self._h = C.c_void_p()
+        rc = self.lib.score_create_from_graphs(gs, self.count, C.byref(st), C.byref(self._h))
+        if rc != 0:
+            self._h = None
+            raise ValueError(f"score_create_from_graphs failed: {self.lib.score_last_error().decode()}")
+        self.n_total, self.m_total = sum(self.ns), sum(self.ms)
+        nt, mt, cnt = C.c_int64(), C.c_int64(), C.c_int32()
+        self.lib.score_dims(self._h, C.byref(nt), C.byref(mt), C.byref(cnt))
+        assert (nt.value, mt.value, cnt.value) == (self.n_total, self.m_total, self.count), "score_create_from_graphs: sizes differ from the column layout"
+        return self
 
     def __init__(self, qps: Sequence, settings: Optional[dict] = None, lib_path: Optional[str] = None):
         if not isinstance(qps, (list, tuple)):
@@ -246,6 +294,35 @@ class ConicSolver:
         if rc != 0:
             raise RuntimeError(f"score_solve failed: {self.lib.score_last_error().decode()}")
         return self._split(x, y, s, infos)
+
+    def solve_estimates(self, qcqp_directions: bool = False):
+        """Cold-start solve of a handle made by ``from_graphs``, the estimate read back in the reference's own shapes straight
+        from the device (``score_read_estimates``; replaces ``get_variable_values``, gurobi_utils.py:114-136) -- no x / y / s
+        copies, no index maps.  Returns ``(infos, estimates)``: per problem a dict of ``info`` and a tuple
+        ``(poses (Np, d+1, d+1), relaxed (Np, d, d+1), landmarks (Nl, d), ranges (Nr, 1 | d), degenerate (Np,))`` of views into
+        the handle-wide arrays."""
+        dims = getattr(self, "_est_dims", None)
+        if dims is None:
+            raise RuntimeError("solve_estimates: the handle was not made by ConicSolver.from_graphs")
+        d, relax, per = dims
+        infos = (ScoreInfo * self.count)()
+        if self.lib.score_solve(self._h, None, None, None, infos) != 0:
+            raise RuntimeError(f"score_solve failed: {self.lib.score_last_error().decode()}")
+        rw = d if (relax or qcqp_directions) else 1
+        nP, nL, nR = sum(p[0] for p in per), sum(p[1] for p in per), sum(p[2] for p in per)
+        T = np.empty((nP, d + 1, d + 1)); B = np.empty((nP, d, d + 1)); Lm = np.empty((nL, d)); Rg = np.empty((nR, rw))
+        flags = np.empty(nP, dtype=np.int32)
+        self.lib.score_read_estimates.argtypes = [C.c_void_p, C.c_int32, _f64p, _f64p, _f64p, _f64p, C.POINTER(C.c_int32)]
+        if self.lib.score_read_estimates(self._h, 1 if qcqp_directions else 0, _ptr(T, _f64p), _ptr(B, _f64p), _ptr(Lm, _f64p), _ptr(Rg, _f64p),
+                                         flags.ctypes.data_as(C.POINTER(C.c_int32))) != 0:
+            raise RuntimeError(f"score_read_estimates failed: {self.lib.score_last_error().decode()}")
+        backend = self.backend
+        out_i, out_e, po, lo, ro = [], [], 0, 0, 0
+        for i, (np_, nl_, nr_) in enumerate(per):
+            out_i.append(dict(infos[i].as_dict(), backend=backend))
+            out_e.append((T[po : po + np_], B[po : po + np_], Lm[lo : lo + nl_], Rg[ro : ro + nr_], flags[po : po + np_]))
+            po += np_; lo += nl_; ro += nr_
+        return out_i, out_e
 
     def reset(self) -> None:
         if self.lib.score_reset(self._h) != 0:

@@ -291,6 +291,62 @@ def test_device_setup_equals_the_host_setup(fixtures, hip_lib, monkeypatch):
                 break  # (the general kernels on the full K: a 2-D graph, the 3-D one, the batch)
 
 
+def test_device_assembler_equals_the_host_assembler(fixtures, hip_lib, monkeypatch):
+    """f2: score_create_from_graphs builds the MODEL on the device (k_ga_*: every relative-pose measurement, range and prior
+    writes the records score_assemble's filling pass adds, in that order; a stable sort and an in-order merge turn them into P
+    and q; A and b are written in place) -- replaces initialize_model, /root/reference/score/utils/gurobi_utils.py:173-187,
+    :233-352, :358-526.  Against a handle made from the host assembler's program (score_assemble -> score_create, both with the
+    device setup): every setup array -- A, G1, G2, K0, K1, q, b, the scales -- bit-equal, i.e. P, q, A, b are the host
+    assembler's to the last bit; the default solves identical including the objective (c0).  2-D, 3-D, loop closures, priors,
+    the pinned pose in ranges and loop closures, the direct QCQP form, a batch, BASELINE configs[3]."""
+    _hip_only(hip_lib)
+    from score_amd.manhattan import make_config
+    from score_amd.native import assemble_native, graph_arrays
+
+    def graphs_of(names):
+        return [graph_by_name(nm, fixtures) for nm in names]
+
+    cases = [([g], "SOCP", {}) for g in graphs_of(("synth_a", "synth_b", "synth_c", "graph3d", "prior2d", "goats", "manhattan"))]
+    cases.append((graphs_of(("synth_d",)), "QCQP", dict(cg_iters=8, adaptive_rho=0)))
+    cases.append((graphs_of(("graph3d",)), "QCQP", dict(cg_iters=8, adaptive_rho=0)))
+    cases.append(([make_manhattan(n_robots=2 + k, n_poses=300 + 170 * k, n_beacons=2, seed=90 + k) for k in range(3)], "SOCP", {}))
+    cases.append(([make_config(3)], "SOCP", {}))
+    for k, (graphs, relax, st) in enumerate(cases):
+        arrays = [graph_arrays(g) for g in graphs]
+        dev = ConicSolver.from_graphs(arrays, 0 if relax == "SOCP" else 1, st, lib_path=hip_lib)
+        assert dev.debug_get("device_setup")[0] == 1.0
+        host = ConicSolver([assemble_native(g, relax, lib_path=hip_lib, arrays=a).qp for g, a in zip(graphs, arrays)], st, lib_path=hip_lib)
+        assert host.debug_get("device_setup")[0] == 1.0
+        for nm in _SETUP_INT + _SETUP_VAL:
+            if nm in ("Hptr", "Hcol") and st:
+                continue
+            a, b = dev.debug_get(nm), host.debug_get(nm)
+            assert a.shape == b.shape and a.size > 0, (k, nm, a.shape, b.shape)
+            bad = np.nonzero(a != b)[0]
+            assert bad.size == 0, (k, nm, bad[:5], a[bad[:5]], b[bad[:5]])
+        sd, sh = dev.solve(), host.solve()
+        dev.close(); host.close()
+        for x, y in zip(sd, sh):
+            assert x.solved and y.solved
+            assert np.array_equal(x.x, y.x) and np.array_equal(x.y, y.y) and np.array_equal(x.s, y.s)
+            assert x.info["newton_iters"] == y.info["newton_iters"] and x.info["pobj"] == y.info["pobj"]
+    # the switch back to the host assembler, and what solve_score makes of either
+    fg = graph_by_name("manhattan", fixtures)
+    r_dev = solve_score(fg, "SOCP", lib_path=hip_lib)
+    monkeypatch.setenv("SCORE_HOST_ASSEMBLE", "1")
+    r_host = solve_score(fg, "SOCP", lib_path=hip_lib)
+    monkeypatch.delenv("SCORE_HOST_ASSEMBLE", raising=False)
+    r_nat = solve_score(fg, "SOCP", lib_path=hip_lib, assembler="native")
+    for r in (r_host, r_nat):
+        assert r.solved and r_dev.solved
+        assert np.array_equal(r.poses.array, r_dev.poses.array) and np.array_equal(r.landmarks.array, r_dev.landmarks.array)
+    # errors of the graph checks travel as ValueError
+    arr = dict(graph_arrays(graph_by_name("synth_a", fixtures)))
+    arr["rng_a"] = arr["rng_a"].copy(); arr["rng_a"][0] = 10 ** 6
+    with pytest.raises(ValueError, match="range endpoint out of range"):
+        ConicSolver.from_graphs([arr], 0, {}, lib_path=hip_lib)
+
+
 def test_xcd_aware_tile_order_changes_no_bit(fixtures, hip_lib, monkeypatch):
     """k_spmv / k_cone deal their tiles to the XCDs in contiguous runs (workgroup i takes tile (i % 8) * chunk + i / 8;
     the grid is rounded up and the surplus workgroups leave).  Which workgroup computes a tile changes nothing in
