@@ -174,6 +174,11 @@ struct score_graph;
 int  score_create_from_graphs(const struct score_graph* graphs, int32_t count, const score_settings* s,
                               score_handle** out);
 
+/* The reference's graph check (score/solve_score.py:28-32: assert data.unconnected_variable_names == []) on the flat arrays:
+ * 0 = every variable of every graph is touched by a measurement or a prior, i > 0 = graph i - 1 is the first that has
+ * unconnected variables, < 0 = error.  (score_create_from_graphs itself builds whatever it is given, like initialize_model.) */
+int  score_graphs_connected(const struct score_graph* graphs, int32_t count);
+
 /* After a solve of a handle made by score_create_from_graphs: the estimate in the reference's own shapes, straight from the
  * solution on the device -- replaces VariableCollection.get_variable_values (gurobi_utils.py:114-136; extract_solver_results
  * :190-203 wraps it).  Problem after problem:

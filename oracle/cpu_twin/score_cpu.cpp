@@ -586,6 +586,11 @@ int score_create_from_graphs(const score_graph* graphs, int32_t count, const sco
         std::vector<score::AssembledQP> qps((size_t)count);
         std::vector<score::AssembledQP*> ptrs((size_t)count);
         for (int i = 0; i < count; ++i) ptrs[(size_t)i] = &qps[(size_t)i];
+        for (int i = 0; i < count; ++i) {  // (the graph checks of score_create_from_graphs)
+            score::AssembledQP sk;
+            try { score::graph_skeleton(graphs[i], sk); }
+            catch (const std::exception& e) { throw std::runtime_error(count > 1 ? "graph " + std::to_string(i) + ": " + e.what() : std::string(e.what())); }
+        }
         score::assemble_graphs(graphs, count, ptrs.data());
         std::vector<score_problem> probs((size_t)count);
         for (int i = 0; i < count; ++i) qps[(size_t)i].view(&probs[(size_t)i]);
@@ -607,6 +612,12 @@ int score_read_estimates(score_handle* h, int32_t qcqp_directions, double* poses
         score::read_estimates_host(h->solver.est, qcqp_directions, x.data(), poses, relaxed, landmarks, ranges, degenerate);
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_graphs_connected(const score_graph* graphs, int32_t count) {
+    if (!graphs || count < 0) { g_err = "null argument"; return -1; }
+    for (int32_t i = 0; i < count; ++i)
+        if (!score::graph_connected(graphs[i])) return i + 1;
+    return 0;
 }
 int score_dims(const score_handle* h, int64_t* n_total, int64_t* m_total, int32_t* count) {
     if (!h) { g_err = "null handle"; return -1; }

@@ -1,0 +1,26 @@
+"""GPU busy fraction and per-kernel time of one window of a rocprofv3 kernel trace (rocpd sqlite output).
+python r05_trace_busy.py results.db [t0_ns t1_ns]"""
+import sqlite3, sys
+con = sqlite3.connect(sys.argv[1]); cur = con.cursor()
+rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+if len(sys.argv) > 3:
+    t0, t1 = int(sys.argv[2]), int(sys.argv[3])
+else:
+    t0, t1 = rows[0][1], rows[-1][2]
+sel = [(n, max(s, t0), min(e, t1)) for n, s, e in rows if e > t0 and s < t1]
+# union of intervals
+busy, cur_e = 0, None
+cs = None
+for n, s, e in sorted(sel, key=lambda r: r[1]):
+    if cs is None: cs, cur_e = s, e
+    elif s <= cur_e: cur_e = max(cur_e, e)
+    else: busy += cur_e - cs; cs, cur_e = s, e
+if cs is not None: busy += cur_e - cs
+tot = sum(e - s for _, s, e in sel)
+print(f"window {1e-6*(t1-t0):.2f} ms: {len(sel)} kernels, busy {1e-6*busy:.2f} ms = {100*busy/(t1-t0):.1f} %, kernel time {1e-6*tot:.2f} ms (overlap {tot/max(1,busy):.2f})")
+agg = {}
+for n, s, e in sel:
+    k = n.split("(")[0][:70]
+    a = agg.setdefault(k, [0, 0]); a[0] += 1; a[1] += e - s
+for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:30]:
+    print(f"  {1e-3*t:9.1f} us {100*t/tot:5.1f} % {c:5d} x {1e-3*t/c:7.2f}  {k}")

@@ -482,6 +482,22 @@ inline void graph_skeleton(const score_graph& g, AssembledQP& out) {
     out.c0 = c0;
 }
 
+// score/solve_score.py:28-32 (_check_factor_graph): is every variable touched by a measurement or a prior?  (Indices out of
+// range count as "not connected": the model construction reports them.)
+inline bool graph_connected(const score_graph& g) {
+    int64_t Np = 0;
+    for (int c = 0; c < g.n_chains; ++c) Np += std::max(0, g.chain_len[c]);
+    const int64_t Nv = Np + std::max(0, g.n_landmarks);
+    std::vector<char> touched((size_t)Nv, 0);
+    auto touch = [&](int64_t v) { if (v >= 0 && v < Nv) touched[(size_t)v] = 1; };
+    for (int64_t e = 0; e < g.n_rel; ++e) { touch(g.rel_base[e]); touch(g.rel_to[e]); }
+    for (int64_t r = 0; r < g.n_rng; ++r) { touch(g.rng_a[r]); touch(g.rng_b[r]); }
+    for (int64_t e = 0; e < g.n_lprior; ++e) touch(Np + g.lprior_lm[e]);
+    for (char tch : touched)
+        if (!tch) return false;
+    return true;
+}
+
 // What a handle made from factor graphs remembers of them for score_read_estimates: per problem its offsets and counts, and the
 // range endpoints / measured distances (the QCQP directions of a program solved through the SOCP are r = D / max(|D|, dist)).
 struct EstProb {

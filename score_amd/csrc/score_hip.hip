@@ -713,6 +713,9 @@ struct HipBackend {
     double* h_meas = nullptr;    // [rz_meas0 | rz_meas1] as pushed
     double* d_meas = nullptr;
     int32_t* d_gate_host = nullptr;  // device address of h_gate
+    int32_t* h_gate_live = nullptr;  // [fired: epoch | used: epoch << 12 | STEPs] per problem, written by pcg_gate itself
+    int32_t* d_gate_live = nullptr;
+    int32_t gate_epoch = 0;
     char* d_ring = nullptr;      // device address of h_ring
     size_t n_fpart = 0, n_gd = 0;
     // ... and everything the host tells the kernels per problem in one upload: [step | tol2 | skip]
@@ -1725,7 +1728,7 @@ struct HipBackend {
             const size_t n_pres = (size_t)std::max(1, n_cone_blocks) * kPartStride, n_dres = (size_t)G2.nblocks * kPartStride;
             const size_t n_int = (2 * (size_t)h.count + 1) / 2;  // 2 * count int32
             const size_t n_meas = 2 * (size_t)std::max(1, n_prec);
-            const size_t total = n_pres + n_dres + n_fpart + n_gd + n_meas + n_int + 1;
+            const size_t total = n_pres + n_dres + n_fpart + n_gd + n_meas + 2 * n_int + 1;
             h_rep_bytes = total * sizeof(double);
             h_rep = (double*)block_cache().take(h_rep_bytes, st.device, true);
             std::memset(h_rep, 0, total * sizeof(double));
@@ -1740,6 +1743,7 @@ struct HipBackend {
             q_gd.view(d_rep + o, n_gd); h_gd = h_rep + o; o += n_gd;
             h_meas = h_rep + o; d_meas = d_rep + o; o += n_meas;
             h_gate = (int32_t*)(h_rep + o); d_gate_host = (int32_t*)(d_rep + o); o += n_int;
+            h_gate_live = (int32_t*)(h_rep + o); d_gate_live = (int32_t*)(d_rep + o); o += n_int;  // (written by pcg_gate as the PCG runs)
             h_seq = (unsigned long long*)(h_rep + o); d_seq = (unsigned long long*)(d_rep + o);
             // device-resident words the kernels read: gate flags and counts, control block
             q_pcgdone.alloc(2 * (size_t)h.count);
@@ -3255,16 +3259,14 @@ struct HipBackend {
     double* pcg_rz_cur = nullptr;
     double* pcg_p_cur = nullptr;
     double* pcg_p_oth = nullptr;
-    void newton_pcg_enqueue(const std::vector<char>& live, const std::vector<double>& eta, int n_iters, bool resume) {
+    PrecArgs pcg_pa{};
+    // start a PCG solve (INIT + first product) or take up the one the previous call left unfinished
+    void newton_pcg_begin(const std::vector<char>& live, bool resume) {
         const HostSystem& h = *H;
-        struct EnqTimer {
-            HipBackend* b; double t0; int n;
-            ~EnqTimer() { b->enq_ms += now_ms() - t0; b->enq_launches += 2 * n + 2; }
-        } enq_timer{this, now_ms(), n_iters};
         // (a fresh solve finds its control words -- skip flags, tolerances -- uploaded by the caller)
         if (resume) upload_skip(live);
-        (void)eta;
-        PrecArgs pa{};
+        PrecArgs& pa = pcg_pa;
+        pa = PrecArgs{};
         pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.rec = prec_recH.d; pa.fac = q_fac.d;
         pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = q_skip.d;
         pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d; pa.uni = uni_for(hblocks());
@@ -3276,6 +3278,8 @@ struct HipBackend {
             // starts from zero without a memset: the first STEP writes r and delta
             pcg_rz_cur = rz_part0.d; pcg_p_cur = p.d; pcg_p_oth = p2.d;
             pcg_steps_queued = 0;
+            gate_epoch = (gate_epoch + 1) & 0x7ffff;
+            if (gate_epoch == 0) gate_epoch = 1;
             pa.p = pcg_p_cur; pa.rz_in = nullptr; pa.rz_out = pcg_rz_cur;
             pa.r_in = q_negg.d;
             pa.gate_init = q_pcgdone.d;  // gate flags start as the host's skip flags
@@ -3291,28 +3295,87 @@ struct HipBackend {
         }
         pa.done = q_pcgdone.d;
         pa.gate_flag = q_pcgdone.d; pa.gate_tol2 = q_gate_tol2.d; pa.gate_ref = q_gate_ref.d;
-        for (int j = 0; j < n_iters; ++j) {
-            double* rz_nxt = (pcg_rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
-            const bool first = !resume && j == 0;
-            pa.p = pcg_p_cur; pa.rz_in = pcg_rz_cur; pa.rz_out = rz_nxt;
-            pa.gate_first = first ? 1 : 0;
-            pa.r_in = first ? q_negg.d : r.d;
-            pa.xt_zero = first ? 1 : 0;
-            launch_prec<PREC_STEP>(pa, probe_slot(1, pcg_steps_queued));   // delta += a p ; r -= a w ; z = M^-1 r   (or: gate fires, nothing happens)
-            tev = nullptr;
-            SpmvArgs a = spmv_args(Hm, pcg_p_cur);
-            a.p = pcg_p_cur; a.z = z.d; a.p_out = pcg_p_oth; a.rz_new = rz_nxt; a.rz_old = pcg_rz_cur; a.pw_part = q_pw.d; a.done = q_pcgdone.d;
-            a.early_done = 1;
-            launch_h<MODE_KPB>(a, probe_slot(0, pcg_steps_queued));
-            tev = nullptr;
-            std::swap(pcg_p_cur, pcg_p_oth);
-            if (++pcg_steps_queued % kDirectEvery == 0) {  // (see linear_solve_core)
-                SpmvArgs d = spmv_args(Hm, pcg_p_cur);
-                d.p = pcg_p_cur; d.pw_part = q_pw.d; d.done = q_pcgdone.d; d.early_done = 1;
-                launch_h<MODE_KP>(d);
-            }
-            pcg_rz_cur = rz_nxt;
+        pa.gate_host = d_gate_live; pa.gate_epoch = gate_epoch; pa.gate_count = h.count;
+        pcg_first = !resume;
+    }
+    bool pcg_first = false;
+    // one PCG iteration: STEP (delta += a p ; r -= a w ; z = M^-1 r -- or: the gate fires, nothing happens), then the product
+    void newton_pcg_pair() {
+        PrecArgs& pa = pcg_pa;
+        double* rz_nxt = (pcg_rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
+        const bool first = pcg_first;
+        pcg_first = false;
+        pa.p = pcg_p_cur; pa.rz_in = pcg_rz_cur; pa.rz_out = rz_nxt;
+        pa.gate_first = first ? 1 : 0;
+        pa.r_in = first ? q_negg.d : r.d;
+        pa.xt_zero = first ? 1 : 0;
+        launch_prec<PREC_STEP>(pa, probe_slot(1, pcg_steps_queued));
+        tev = nullptr;
+        SpmvArgs a = spmv_args(Hm, pcg_p_cur);
+        a.p = pcg_p_cur; a.z = z.d; a.p_out = pcg_p_oth; a.rz_new = rz_nxt; a.rz_old = pcg_rz_cur; a.pw_part = q_pw.d; a.done = q_pcgdone.d;
+        a.early_done = 1;
+        launch_h<MODE_KPB>(a, probe_slot(0, pcg_steps_queued));
+        tev = nullptr;
+        std::swap(pcg_p_cur, pcg_p_oth);
+        if (++pcg_steps_queued % kDirectEvery == 0) {  // (see linear_solve_core)
+            SpmvArgs d = spmv_args(Hm, pcg_p_cur);
+            d.p = pcg_p_cur; d.pw_part = q_pw.d; d.done = q_pcgdone.d; d.early_done = 1;
+            launch_h<MODE_KP>(d);
         }
+        pcg_rz_cur = rz_nxt;
+    }
+    void newton_pcg_enqueue(const std::vector<char>& live, const std::vector<double>& eta, int n_iters, bool resume) {
+        struct EnqTimer {
+            HipBackend* b; double t0; int n;
+            ~EnqTimer() { b->enq_ms += now_ms() - t0; b->enq_launches += 2 * n + 2; }
+        } enq_timer{this, now_ms(), n_iters};
+        (void)eta;
+        newton_pcg_begin(live, resume);
+        for (int j = 0; j < n_iters; ++j) newton_pcg_pair();
+    }
+    // The PCG queued a few iterations AHEAD of the device instead of to a guessed length: pcg_gate's lead workgroups publish
+    // "fired" and "STEPs executed" in host-mapped memory as they go (PrecArgs::gate_host); the host keeps `depth` iterations
+    // in the queue beyond what has executed and stops at the first look that shows every live problem's gate fired.  At most
+    // `depth` launches pairs run as no-ops (the guessed queue: a third of the launches on the headline solve), none is ever
+    // missing (no resume).  Returns the iterations queued.
+    int newton_pcg_follow(const std::vector<char>& live, int cap) {
+        const HostSystem& h = *H;
+        static const int depth = std::getenv("SCORE_PCG_DEPTH") ? std::max(1, std::atoi(std::getenv("SCORE_PCG_DEPTH"))) : 3;
+        newton_pcg_begin(live, false);
+        int queued = 0;
+        const auto t0 = std::chrono::steady_clock::now();
+        unsigned spins = 0;
+        for (;;) {
+            bool all = true;
+            int used = 1 << 30;
+            for (int p = 0; p < h.count; ++p) {
+                if (!live[p]) continue;
+                const int32_t f = __atomic_load_n(&h_gate_live[p], __ATOMIC_ACQUIRE), u = __atomic_load_n(&h_gate_live[h.count + p], __ATOMIC_ACQUIRE);
+                if (f != gate_epoch) {
+                    all = false;
+                    used = std::min(used, (u >> 12) == gate_epoch ? (int)(u & 0xfff) : 0);  // (the slowest live problem that still runs)
+                }
+            }
+            if (all || queued >= cap) break;
+            if (queued - used < depth) {
+                newton_pcg_pair();
+                ++queued;
+                spins = 0;
+                continue;
+            }
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+            if ((++spins & 1023) == 0) {
+                HIP_CHECK(hipGetLastError());
+                if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {  // (a device that stopped answering: let the caller's wait report it)
+                    break;
+                }
+                if (spins > (1u << 14)) sched_yield();
+            }
+        }
+        enq_launches += 2 * queued + 2;
+        return queued;
     }
 
     // dual_scale (optional): per problem |A'y|_inf -- Newton then stops at half the tolerance the
@@ -3395,7 +3458,9 @@ struct HipBackend {
             upload_skip(live);
             np_newton_it = it;
             newton_hessian(q_fskip.d, refactor);  // (a frozen problem's short entries keep their values, see k_hassemble)
-            newton_pcg_enqueue(live, eta, n_pcg, false);
+            static const bool guess_queue = std::getenv("SCORE_PCG_GUESS") != nullptr;  // (the round-2 queue: a length guessed from the previous iteration)
+            if (guess_queue) newton_pcg_enqueue(live, eta, n_pcg, false);
+            else newton_pcg_follow(live, 400);
             eta_prev = eta;
             bool control_stale = false;
             int used_now = 0;
@@ -3843,6 +3908,12 @@ int score_read_estimates(score_handle* h, int32_t qcqp_directions, double* poses
         h->solver.be.read_estimates(h->solver.H, h->solver.est, qcqp_directions, poses, relaxed, landmarks, ranges, degenerate);
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_graphs_connected(const score_graph* graphs, int32_t count) {
+    if (!graphs || count < 0) { g_err = "null argument"; return -1; }
+    for (int32_t i = 0; i < count; ++i)
+        if (!score::graph_connected(graphs[i])) return i + 1;
+    return 0;
 }
 int score_dims(const score_handle* h, int64_t* n_total, int64_t* m_total, int32_t* count) {
     if (!h) { g_err = "null handle"; return -1; }

@@ -1038,6 +1038,11 @@ struct PrecArgs {
     double* gate_ref;          // per problem: threshold
     int32_t* gate_used;        // per problem: STEPs executed
     int gate_first;
+    // The same two words per problem in HOST-mapped memory, stamped with the solve's epoch (stale values of an earlier solve
+    // never match): [fired: epoch | used: epoch << 12 | STEPs] -- written by the problem's lead workgroup as it goes, so that the
+    // host can queue the PCG a few iterations ahead of the device instead of guessing its length (polish_lockstep).
+    int32_t* gate_host;        // 2 * gate_count words, or null
+    int32_t gate_epoch, gate_count;
 };
 
 enum { PREC_INIT = 0, PREC_STEP = 1 };
@@ -1050,17 +1055,24 @@ __device__ __forceinline__ bool pcg_gate(const PrecArgs& a, int prob, double rz,
     const bool lead = (threadIdx.x == 0) && ((int)blockIdx.x == a.prec_part_ptr[prob]);
     if (a.gate_first) {
         if (!(rz > 0.0)) {
-            if (lead) a.gate_flag[prob] = 1;
+            if (lead) { a.gate_flag[prob] = 1; if (a.gate_host) a.gate_host[prob] = a.gate_epoch; }
             return true;
         }
-        if (lead) { a.gate_ref[prob] = rz * a.gate_tol2[prob]; a.gate_used[prob] = 1; }
+        if (lead) {
+            a.gate_ref[prob] = rz * a.gate_tol2[prob]; a.gate_used[prob] = 1;
+            if (a.gate_host) a.gate_host[a.gate_count + prob] = (a.gate_epoch << 12) | 1;
+        }
         return false;
     }
     if (!(rz > ref_loaded)) {  // converged (or NaN: stop, the host sees it in F)
-        if (lead) a.gate_flag[prob] = 1;
+        if (lead) { a.gate_flag[prob] = 1; if (a.gate_host) a.gate_host[prob] = a.gate_epoch; }
         return true;
     }
-    if (lead) a.gate_used[prob] += 1;
+    if (lead) {
+        const int32_t u = a.gate_used[prob] + 1;
+        a.gate_used[prob] = u;
+        if (a.gate_host) a.gate_host[a.gate_count + prob] = (a.gate_epoch << 12) | (u & 0xfff);
+    }
     return false;
 }
 
@@ -1515,8 +1527,16 @@ struct PreTile {
 // so a lane loads its slots straight into registers (16-byte packets, packet-major: coalesced) and every coarse phase starts its arithmetic
 // at once instead of pulling 18..72 values from LDS first.  LDS then holds vectors only (41 KB instead of 135 KB at
 // 1000 nodes): three chains per CU can be resident.  The level-0 tile is kept as floats too (converted where used).
+template <int BS, int MODE, typename FT, bool REGDEEP>
+__device__ __forceinline__ void prec_pre_body(const PrecArgs& a);
 template <int BS, int MODE, typename FT = double, bool REGDEEP = false>
-__global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
+__global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) { prec_pre_body<BS, MODE, FT, REGDEEP>(a); }
+// (Round 5, measured and removed: the same body compiled for TWO workgroups per CU -- __launch_bounds__(512, 4): 128 registers
+//  per lane, 432 of them spilled, 672 bytes of scratch per lane -- for lock-step batches whose chain work items otherwise run in
+//  two rounds.  64 config-5 trials in 4 handles of 16: 4170-4230 -> 2180-2210 problems/s.  A two-per-CU chain kernel needs a
+//  different division of labour, not a register cap; profiles/TRIED.md.)
+template <int BS, int MODE, typename FT, bool REGDEEP>
+__device__ __forceinline__ void prec_pre_body(const PrecArgs& a) {
     static_assert(!REGDEEP || (sizeof(FT) == 4 && BS <= 3), "register-resident coarse levels: 4-byte stream, blocks up to 3 x 3");
     KernelStamp stamp(a.tstamp);
     constexpr int RMAX = 3;

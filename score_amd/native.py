@@ -381,6 +381,26 @@ def _read_back_maps(a: Dict[str, np.ndarray], relaxation: str, qp: "NativeQP") -
     )
 
 
+def graphs_connected(arrays: list, lib_path: Optional[str] = None) -> Optional[int]:
+    """``score_graphs_connected``: None when every variable of every graph is touched by a measurement or a prior
+    (score/solve_score.py:28-32), else the index of the first graph that has unconnected variables."""
+    if not arrays:
+        return None
+    lib = load_library(lib_path)
+    lib.score_graphs_connected.argtypes = [C.POINTER(ScoreGraph), C.c_int32]
+    n = len(arrays)
+    gs = (ScoreGraph * n)()
+    keep = []
+    for i, a in enumerate(arrays):
+        g = score_graph_struct(a, 0)
+        keep.append(g)
+        C.memmove(C.byref(gs[i]), C.byref(g), C.sizeof(ScoreGraph))
+    rc = lib.score_graphs_connected(gs, n)
+    if rc < 0:
+        raise RuntimeError(lib.score_last_error().decode())
+    return None if rc == 0 else rc - 1
+
+
 class GraphQP:
     """Sizes of the conic program of a graph whose model is built inside ``score_create_from_graphs`` (on the device): what
     ``ScoreModel`` needs of a ``ConicQP`` when nobody asks for the matrices."""

@@ -145,8 +145,13 @@ def _models_for(datas: Sequence, relaxation_type: str, qcqp_mode: str, lib_path:
 
         relax = SOCP_RELAXATION if (relaxation_type == QCQP_RELAXATION and qcqp_mode == "via_socp") else relaxation_type
         arrays = [data.arrays if isinstance(data, ArrayGraph) else graph_arrays(data) for data in datas]
-        for a in arrays:  # score/solve_score.py:28-32, on the flat arrays
-            unconnected_variables = unconnected_variable_names(a)
+        # score/solve_score.py:28-32 on the flat arrays: one foreign call for the whole group (score_graphs_connected); the names
+        # for the reference's message only when a graph fails
+        from .native import graphs_connected
+
+        bad = graphs_connected(arrays, lib_path=lib_path)
+        if bad is not None:
+            unconnected_variables = unconnected_variable_names(arrays[bad])
             assert len(unconnected_variables) == 0, f"Found {unconnected_variables} unconnected variables. "
         return [graph_model(a, relax) for a in arrays]  # (model.graph_arrays: what ConicSolver.from_graphs hands to the library)
     if assembler != "native":

@@ -79,7 +79,7 @@ STATUS_NAMES = {0: "unsolved", 1: "solved", 2: "max_iters", 3: "numerical"}
 # every symbol include/score_hip.h declares
 ABI_SYMBOLS = [
     "score_assemble", "score_assemble_batch", "score_assembled_view", "score_assembled_free", "score_round_to_so",
-    "score_default_settings", "score_create", "score_create_batch", "score_create_from_graphs", "score_read_estimates", "score_dims", "score_solve",
+    "score_default_settings", "score_create", "score_create_batch", "score_create_from_graphs", "score_read_estimates", "score_graphs_connected", "score_dims", "score_solve",
     "score_reset", "score_solve_steps", "score_newton_steps", "score_linear_create", "score_linear_solve", "score_refine_create", "score_refine_run", "score_refine_destroy", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
     "score_trim_caches", "score_last_error", "score_backend", "score_abi_version",
 ]
