@@ -1233,7 +1233,16 @@ struct HipBackend {
         }
         hipLaunchKernelGGL(k_g_ptrs, dim3(grow1), dim3(256), 0, stream, ga);
         hipLaunchKernelGGL(k_g_scale_a, dim3((unsigned)std::max<int64_t>(1, (std::max(ae, std::max(n, m)) + 255) / 256)), dim3(256), 0, stream, ga);
-        hipLaunchKernelGGL(k_g_fill, dim3(gcol), dim3(256), 0, stream, ga);
+        // rows of G2 by length: eight lanes for the usual ones, a wavefront for the listed long ones (k_row_classify)
+        const int64_t long_cap = (nnzP_full + ae) / kLongRowEntries + 1;
+        DevBuf<int32_t> long_rows, n_long_rows;
+        long_rows.alloc((size_t)long_cap); n_long_rows.alloc(1);
+        HIP_CHECK(hipMemsetAsync(n_long_rows.d, 0, sizeof(int32_t), stream));
+        hipLaunchKernelGGL(k_row_classify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const int32_t*)G2.ptr.d, n, long_rows.d, n_long_rows.d);
+        const unsigned g8 = (unsigned)((n + 31) / 32), g64 = (unsigned)((long_cap + 3) / 4);
+        ga.long_rows = long_rows.d; ga.n_long_rows = n_long_rows.d;
+        hipLaunchKernelGGL(k_g_fill<8>, dim3(g8), dim3(256), 0, stream, ga);
+        hipLaunchKernelGGL(k_g_fill<64>, dim3(g64), dim3(256), 0, stream, ga);
         norms.alloc((size_t)4 * count);
         HIP_CHECK(hipMemsetAsync(norms.d, 0, (size_t)4 * count * sizeof(double), stream));
         hipLaunchKernelGGL(k_prob_norms, dim3(count > 8 ? 8u : 32u, (unsigned)count), dim3(256), 0, stream, tab, (const double*)R.qraw.d, (const double*)q.d, (const double*)R.braw.d,
@@ -1252,7 +1261,9 @@ struct HipBackend {
         ka.A_ptr = A_ptr.d; ka.A_col = A_col.d; ka.A_val = A_val.d;
         ka.rec_cnt = kcnt.d; ka.key = key0.d; ka.idx = kidx0.d; ka.v0 = v0.d; ka.v1 = v1.d;
         const unsigned grow4 = (unsigned)((n + 1 + 3) / 4);
-        hipLaunchKernelGGL(k_kb_count, dim3(grow4), dim3(256), 0, stream, ka);
+        ka.long_rows = long_rows.d; ka.n_long_rows = n_long_rows.d;
+        hipLaunchKernelGGL(k_kb_count<8>, dim3(g8), dim3(256), 0, stream, ka);
+        hipLaunchKernelGGL(k_kb_count<64>, dim3(g64), dim3(256), 0, stream, ka);
         {
             size_t tb = 0;
             HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, kcnt.d, kcnt.d, (long long)0, (size_t)n + 1, rocprim::plus<long long>(), stream));
@@ -1260,7 +1271,8 @@ struct HipBackend {
             sc2.alloc(tb + 256);
             HIP_CHECK(rocprim::exclusive_scan((void*)sc2.d, tb, kcnt.d, kcnt.d, (long long)0, (size_t)n + 1, rocprim::plus<long long>(), stream));
         }
-        hipLaunchKernelGGL(k_kb_expand, dim3(grow4), dim3(256), 0, stream, ka);
+        hipLaunchKernelGGL(k_kb_expand<8>, dim3(g8), dim3(256), 0, stream, ka);
+        hipLaunchKernelGGL(k_kb_expand<64>, dim3(g64), dim3(256), 0, stream, ka);
         hipLaunchKernelGGL(k_rec_pad, dim3((unsigned)((rec_max + 255) / 256)), dim3(256), 0, stream, key0.d, kidx0.d, (const long long*)(kcnt.d + n), rec_max, n);
         MergeOut mo;
         merge_records(n, rec_max, key0, kidx0, v0.d, v1.d, -1, nullptr, mo);
@@ -2938,9 +2950,18 @@ struct HipBackend {
             a.g2_ptr = G2.ptr.d; a.g2_split = G2.split.d; a.g2_col = G2.col.d; a.g2_val = G2.val.d;
             a.A_ptr = A_ptr.d; a.A_col = A_col.d; a.A_val = A_val.d; a.is_head = q_ishead.d;
             a.rec_max = rec_max; a.key = key0.d; a.idx = idx0.d; a.rcone = rcone.d; a.rab = rab.d; a.rcoef = rcoef.d;
-            const unsigned grows = (unsigned)((n + 1 + 3) / 4), grec = (unsigned)((rec_max + 255) / 256);  // (a wavefront per row)
+            const unsigned grec = (unsigned)((rec_max + 255) / 256);
+            // (eight lanes per row; the listed long rows -- landmark rows -- a wavefront each)
+            const int64_t long_cap = rec_max / kLongRowEntries + 1;
+            DevBuf<int32_t> long_rows, n_long_rows;
+            long_rows.alloc((size_t)long_cap); n_long_rows.alloc(1);
+            HIP_CHECK(hipMemsetAsync(n_long_rows.d, 0, sizeof(int32_t), stream));
+            hipLaunchKernelGGL(k_row_classify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const int32_t*)G2.ptr.d, n, long_rows.d, n_long_rows.d);
+            const unsigned g8 = (unsigned)((n + 31) / 32), g64 = (unsigned)((long_cap + 3) / 4);
+            a.long_rows = long_rows.d; a.n_long_rows = n_long_rows.d;
             a.rec_cnt = cnt.d;
-            hipLaunchKernelGGL(k_hb_count, dim3(grows), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(k_hb_count<8>, dim3(g8), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(k_hb_count<64>, dim3(g64), dim3(256), 0, stream, a);
             size_t tb = 0, tb2 = 0, tb3 = 0;
             int bits = 1;
             while (((int64_t)1 << bits) <= n) ++bits;  // (the sentinel row n sorts last)
@@ -2951,7 +2972,8 @@ struct HipBackend {
             scratch.alloc(std::max(tb, std::max(tb2, tb3)) + 256);
             HIP_CHECK(rocprim::exclusive_scan((void*)scratch.d, tb, cnt.d, off.d, (long long)0, (size_t)n + 1, rocprim::plus<long long>(), stream));
             a.rec_cnt = off.d;
-            hipLaunchKernelGGL(k_hb_expand, dim3(grows), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(k_hb_expand<8>, dim3(g8), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(k_hb_expand<64>, dim3(g64), dim3(256), 0, stream, a);
             hipLaunchKernelGGL(k_hb_pad, dim3(grec), dim3(256), 0, stream, a);
             HIP_CHECK(rocprim::radix_sort_pairs((void*)scratch.d, tb2, key0.d, key1.d, idx0.d, idx1.d, (size_t)rec_max, 0, 32 + bits, stream));
             HScatterArgs sa{};

@@ -40,7 +40,44 @@ struct HBuildArgs {
     int32_t* rcone;           // >= 0: cone of a contribution; -1: a P entry; -2: the unit diagonal of a head row
     int32_t* rab;
     double* rcoef;
+    // rows by length (round 5): a row of a dozen entries is served by EIGHT lanes (a wavefront per row left 56 lanes idle on
+    // all but the few landmark rows); rows of more than kLongRowEntries entries of G2 are listed (k_row_classify) and served
+    // by a wavefront each in a second launch of the same kernel
+    const int32_t* long_rows; const int32_t* n_long_rows;
 };
+constexpr int kLongRowEntries = 128;
+// rows of [ptr[i], ptr[i + 1]) longer than kLongRowEntries -> list (unordered), *cnt
+__global__ __launch_bounds__(256) void k_row_classify(const int32_t* __restrict__ ptr, int64_t n, int32_t* __restrict__ list, int32_t* __restrict__ cnt) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (ptr[i + 1] - ptr[i] > kLongRowEntries) list[atomicAdd(cnt, 1)] = (int32_t)i;
+}
+// the row a group of G lanes serves: G < 64 -- row = group index, long rows are left to the second launch; G == 64 -- the
+// w-th long row.  Returns -1 when there is nothing to do.
+template <int G>
+__device__ __forceinline__ int64_t group_row(const int32_t* __restrict__ ptr, int64_t n, const int32_t* __restrict__ long_rows,
+                                             const int32_t* __restrict__ n_long_rows) {
+    const int64_t g = ((int64_t)blockIdx.x * 256 + threadIdx.x) / G;
+    if (G == 64) {
+        if (!long_rows) return g < n ? g : -1;   // (no list: a wavefront per row, every row)
+        return g < *n_long_rows ? (int64_t)long_rows[g] : -1;
+    }
+    if (g >= n) return -1;
+    return (ptr[g + 1] - ptr[g] > kLongRowEntries) ? -1 : g;
+}
+template <int G>
+__device__ __forceinline__ long long group_sum(long long v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+    return v;
+}
+template <int G>
+__device__ __forceinline__ bool group_any(bool pred) {
+    const unsigned long long b = __ballot(pred);
+    if (G == 64) return b != 0;
+    const int lane = threadIdx.x & 63;
+    return ((b >> (lane & ~(G - 1))) & ((1ull << G) - 1ull)) != 0;
+}
 
 // One WAVEFRONT per row (a landmark's row holds thousands of entries of A' and expands into tens of thousands of records;
 // a pose row a dozen): the lanes stride over the row's entries, a wave scan places every entry's records.
@@ -50,31 +87,33 @@ __device__ inline long long hb_wave_sum(long long v) {
     return v;
 }
 // records of row i (host loop: score_polish_host.hpp, build_polish)
+template <int G>
 __global__ __launch_bounds__(256) void k_hb_count(HBuildArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i > a.n) return;
-    if (i == a.n) { if (lane == 0) a.rec_cnt[i] = 0; return; }
+    const int lane = threadIdx.x & (G - 1);
+    if (G == 64 && blockIdx.x == 0 && threadIdx.x == 0) a.rec_cnt[a.n] = 0;
+    const int64_t i = group_row<G>(a.g2_ptr, a.n, a.long_rows, a.n_long_rows);
+    if (i < 0) return;
     if (a.is_head[i]) { if (lane == 0) a.rec_cnt[i] = 1; return; }
     const int p0 = a.g2_ptr[i], sp = a.g2_split[i], p1 = a.g2_ptr[i + 1];
     long long c = 0;
     int diag = 0;
-    for (int k = p0 + lane; k < sp; k += 64) diag |= (a.g2_col[k] == (int32_t)i);
+    for (int k = p0 + lane; k < sp; k += G) diag |= (a.g2_col[k] == (int32_t)i);
     const int D1 = a.T + 1;
-    for (int t = sp + lane; t < p1; t += 64) {
+    for (int t = sp + lane; t < p1; t += G) {
         const int r = a.g2_col[t] - (int32_t)a.n;
         const int r0 = r / D1 * D1;
         if (r - r0 - 1 >= 0) c += a.A_ptr[r0 + 1 + a.T] - a.A_ptr[r0 + 1];  // (head rows only hold the head column)
     }
-    c = hb_wave_sum(c);
-    const bool has_diag = __any(diag);
+    c = group_sum<G>(c);
+    const bool has_diag = group_any<G>(diag != 0);
     if (lane == 0) a.rec_cnt[i] = (long long)(sp - p0) + (has_diag ? 0 : 1) + c;
 }
 
+template <int G>
 __global__ __launch_bounds__(256) void k_hb_expand(HBuildArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= a.n) return;
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t i = group_row<G>(a.g2_ptr, a.n, a.long_rows, a.n_long_rows);
+    if (i < 0) return;
     long long base = a.rec_cnt[i];
     const unsigned long long hi = (unsigned long long)i << 32;
     auto put = [&](long long o, int32_t j, int32_t cone, int32_t ab, double coef) {
@@ -85,17 +124,17 @@ __global__ __launch_bounds__(256) void k_hb_expand(HBuildArgs a) {
     if (a.is_head[i]) { if (lane == 0) put(base, (int32_t)i, -2, 0, 1.0); return; }
     const int p0 = a.g2_ptr[i], sp = a.g2_split[i], p1 = a.g2_ptr[i + 1];
     int diag = 0;
-    for (int k = p0 + lane; k < sp; k += 64) {
+    for (int k = p0 + lane; k < sp; k += G) {
         put(base + (k - p0), a.g2_col[k], -1, 0, a.g2_val[k]);
         diag |= (a.g2_col[k] == (int32_t)i);
     }
     base += sp - p0;
-    if (!__any(diag)) {
+    if (!group_any<G>(diag != 0)) {
         if (lane == 0) put(base, (int32_t)i, -1, 0, 0.0);
         ++base;
     }
     const int D1 = a.T + 1;
-    for (int t0 = sp; t0 < p1; t0 += 64) {
+    for (int t0 = sp; t0 < p1; t0 += G) {
         const int t = t0 + lane;
         int cone = 0, ta = -1, r0 = 0;
         double vi = 0.0;
@@ -106,11 +145,11 @@ __global__ __launch_bounds__(256) void k_hb_expand(HBuildArgs a) {
             cone = r / D1; r0 = cone * D1; ta = r - r0 - 1;
             if (ta >= 0) mine = a.A_ptr[r0 + 1 + a.T] - a.A_ptr[r0 + 1];
         }
-        // exclusive prefix of `mine` over the lanes (entries of A' in order)
+        // exclusive prefix of `mine` over the lanes of the group (entries of A' in order)
         long long incl = mine;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const long long up = __shfl_up(incl, o, 64);
+        for (int o = 1; o < G; o <<= 1) {
+            const long long up = __shfl_up(incl, o, G);
             if (lane >= o) incl += up;
         }
         long long o = base + incl - mine;
@@ -119,7 +158,7 @@ __global__ __launch_bounds__(256) void k_hb_expand(HBuildArgs a) {
                 const int rb = r0 + 1 + b;
                 for (int kk = a.A_ptr[rb]; kk < a.A_ptr[rb + 1]; ++kk, ++o) put(o, a.A_col[kk], cone, ta * a.T + b, vi * a.A_val[kk]);
             }
-        base += __shfl(incl, 63, 64);
+        base += __shfl(incl, G - 1, G);
     }
 }
 

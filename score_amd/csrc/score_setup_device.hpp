@@ -23,6 +23,7 @@
 #include <rocprim/rocprim.hpp>
 
 #include "score_host.hpp"
+#include "score_polish_device.hpp"
 
 namespace score {
 
@@ -185,6 +186,7 @@ struct GDevArgs {
     int32_t* oA_col; double* oA_val;
     int32_t* g1_col; double* g1_val; int32_t* g2_col; double* g2_val;
     const double* q_raw; const double* b_raw; double* q; double* b; double* invD; double* invE;
+    const int32_t* long_rows; const int32_t* n_long_rows;   // rows of G2 beyond kLongRowEntries (k_row_classify): a wavefront each
 };
 __global__ __launch_bounds__(256) void k_g_lengths(GDevArgs a) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -211,22 +213,24 @@ __global__ __launch_bounds__(256) void k_g_scale_a(GDevArgs a) {
     if (k < a.n) { const double d = a.D[k]; a.q[k] = a.q_raw[k] * d; a.invD[k] = 1.0 / d; }
     if (k < a.m) { const double e = a.E[k]; a.b[k] = a.b_raw[k] * e; a.invE[k] = 1.0 / e; }
 }
-// a wavefront per row i of G2 (= column i of A): P part, then the entries of A' (also into G1 when the row is stored)
+// G lanes per row i of G2 (= column i of A): P part, then the entries of A' (also into G1 when the row is stored); eight
+// lanes for the usual rows of a dozen entries, a wavefront for the listed long ones (landmark rows)
+template <int G>
 __global__ __launch_bounds__(256) void k_g_fill(GDevArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= a.n) return;
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t i = group_row<G>(a.g2_ptr, a.n, a.long_rows, a.n_long_rows);
+    if (i < 0) return;
     const RowInfo ri = row_info(a.tab, i);
     const double di = a.D[i];
     const int k0 = a.P_ptr[ri.i0], np = a.P_ptr[ri.i0 + 1] - k0, o2 = a.g2_ptr[i];
-    for (int l = lane; l < np; l += 64) {
+    for (int l = lane; l < np; l += G) {
         const int32_t c = a.P_col[k0 + l] + ri.shift;
         a.g2_col[o2 + l] = c;
         a.g2_val[o2 + l] = (a.P_val[k0 + l] * di) * a.D[c];
     }
     const int t0 = a.atp[i], nt = a.atp[i + 1] - t0, s2 = o2 + np, s1 = ri.stored ? a.g1_ptr[i] : 0;
     if (lane == 0) a.g2_split[i] = s2;
-    for (int l = lane; l < nt; l += 64) {
+    for (int l = lane; l < nt; l += G) {
         const uint32_t q = a.atpos[t0 + l];
         const int32_t c = (int32_t)a.n + a.arow[q];
         const double v = a.oA_val[q];
@@ -383,28 +387,30 @@ struct KBuildArgs {
     const int32_t* A_ptr; const int32_t* A_col; const double* A_val;                                // equilibrated A, global
     long long* rec_cnt;      // n + 1: records per row, then (exclusive scan) first record of every row
     unsigned long long* key; uint32_t* idx; double* v0; double* v1;
+    const int32_t* long_rows; const int32_t* n_long_rows;   // as GDevArgs
 };
+template <int G>
 __global__ __launch_bounds__(256) void k_kb_count(KBuildArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i > a.n) return;
-    if (i == a.n) { if (lane == 0) a.rec_cnt[i] = 0; return; }
+    const int lane = threadIdx.x & (G - 1);
+    if (G == 64 && blockIdx.x == 0 && threadIdx.x == 0) a.rec_cnt[a.n] = 0;
+    const int64_t i = group_row<G>(a.g2_ptr, a.n, a.long_rows, a.n_long_rows);
+    if (i < 0) return;
     const RowInfo ri = row_info(a.tab, i);
     if (!ri.stored) { if (lane == 0) a.rec_cnt[i] = 0; return; }
     const int p0 = a.g2_ptr[i], sp = a.g2_split[i], p1 = a.g2_ptr[i + 1];
     long long c = 0;
-    for (int t = sp + lane; t < p1; t += 64) {
+    for (int t = sp + lane; t < p1; t += G) {
         const int r = a.g2_col[t] - (int32_t)a.n;
         c += a.A_ptr[r + 1] - a.A_ptr[r];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    c = group_sum<G>(c);
     if (lane == 0) a.rec_cnt[i] = 1 + (long long)(sp - p0) + c;
 }
+template <int G>
 __global__ __launch_bounds__(256) void k_kb_expand(KBuildArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= a.n) return;
+    const int lane = threadIdx.x & (G - 1);
+    const int64_t i = group_row<G>(a.g2_ptr, a.n, a.long_rows, a.n_long_rows);
+    if (i < 0) return;
     const RowInfo ri = row_info(a.tab, i);
     if (!ri.stored) return;
     long long base = a.rec_cnt[i];
@@ -417,9 +423,9 @@ __global__ __launch_bounds__(256) void k_kb_expand(KBuildArgs a) {
     if (lane == 0) put(base, (int32_t)i, a.sigma, 0.0);
     ++base;
     const int p0 = a.g2_ptr[i], sp = a.g2_split[i], p1 = a.g2_ptr[i + 1];
-    for (int k = p0 + lane; k < sp; k += 64) put(base + (k - p0), a.g2_col[k], a.g2_val[k], 0.0);
+    for (int k = p0 + lane; k < sp; k += G) put(base + (k - p0), a.g2_col[k], a.g2_val[k], 0.0);
     base += sp - p0;
-    for (int t0 = sp; t0 < p1; t0 += 64) {
+    for (int t0 = sp; t0 < p1; t0 += G) {
         const int t = t0 + lane;
         int r = 0;
         double av = 0.0;
@@ -431,14 +437,14 @@ __global__ __launch_bounds__(256) void k_kb_expand(KBuildArgs a) {
         }
         long long incl = mine;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const long long up = __shfl_up(incl, o, 64);
+        for (int o = 1; o < G; o <<= 1) {
+            const long long up = __shfl_up(incl, o, G);
             if (lane >= o) incl += up;
         }
         long long o = base + incl - mine;
         if (t < p1)
             for (int kk = a.A_ptr[r]; kk < a.A_ptr[r + 1]; ++kk, ++o) put(o, a.A_col[kk], 0.0, av * a.A_val[kk]);
-        base += __shfl(incl, 63, 64);
+        base += __shfl(incl, G - 1, G);
     }
 }
 
