@@ -84,7 +84,8 @@ thread_local hipStream_t tl_copy_stream = nullptr;
 // device): freed blocks are parked in a small process-wide cache, per device and size class (powers
 // of two), and handed to the next handle that asks.  Bounded: at most kMaxCachedBytes stay parked.
 struct BlockCache {
-    struct Block { void* p; size_t bytes; int dev; bool host; };
+    struct Block { void* p; size_t bytes; int dev; bool host; unsigned long long stamp; };
+    unsigned long long clock = 0;
     std::mutex mu;
     std::vector<Block> free_blocks;
     size_t cached = 0;
@@ -145,17 +146,34 @@ struct BlockCache {
             throw std::runtime_error(std::string(host ? "hipHostMalloc" : "hipMalloc") + " of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
         return p;
     }
+    // A block that does not fit under the cap makes room for itself: the blocks parked LONGEST ago go (round 5: a cache filled
+    // to its cap by one large handle -- 16 headline problems in one -- used to refuse every later block, and every later create
+    // and destroy paid for raw hipMalloc / hipFree, the latter a device synchronisation: 64 fresh graphs 30 -> 38 ms per sweep,
+    // solve_score() on the headline graph 15 -> 24 ms in a process that had held such a handle).
     void give(void* p, size_t bytes, int dev, bool host) {
         if (!p) return;
+        std::vector<Block> evict;
+        bool parked = false;
         {
             std::lock_guard<std::mutex> lk(mu);
-            if (cached + bytes <= max_cached_bytes()) {
-                free_blocks.push_back(Block{p, bytes, dev, host});
+            const size_t cap = max_cached_bytes();
+            if (bytes <= cap) {
+                while (cached + bytes > cap && !free_blocks.empty()) {
+                    size_t oldest = 0;
+                    for (size_t i = 1; i < free_blocks.size(); ++i)
+                        if (free_blocks[i].stamp < free_blocks[oldest].stamp) oldest = i;
+                    evict.push_back(free_blocks[oldest]);
+                    cached -= free_blocks[oldest].bytes;
+                    free_blocks[oldest] = free_blocks.back();
+                    free_blocks.pop_back();
+                }
+                free_blocks.push_back(Block{p, bytes, dev, host, ++clock});
                 cached += bytes;
-                return;
+                parked = true;
             }
         }
-        if (host) (void)hipHostFree(p); else (void)hipFree(p);
+        for (const Block& b : evict) { if (b.host) (void)hipHostFree(b.p); else (void)hipFree(b.p); }
+        if (!parked) { if (host) (void)hipHostFree(p); else (void)hipFree(p); }
     }
     // release every parked block (score_trim_caches; also the retry path of take()); returns the bytes freed
     size_t trim() {
@@ -382,6 +400,31 @@ struct DevBuf {
         owned = false;
     }
     ~DevBuf() { release(); }
+};
+
+// Several zero-initialised buffers as ONE allocation and ONE fill (a fill is a 4-5 us dispatch -- two or three when its range
+// is not aligned --, and a create had a hundred of them): add() the buffers, commit() allocates from the current arena
+// (tl_arena) and queues the fill on the stream.
+struct ZeroGroup {
+    struct Item { void** d; size_t* n; size_t count, bytes, off; };
+    std::vector<Item> items;
+    size_t total = 0;
+    template <class T>
+    void add(DevBuf<T>& b, size_t count) {
+        b.release();
+        const size_t bytes = (std::max<size_t>(1, count) * sizeof(T) + 255) & ~(size_t)255;
+        items.push_back(Item{(void**)&b.d, &b.n, count, bytes, total});
+        total += bytes;
+    }
+    void commit(hipStream_t st) {
+        if (!total) return;
+        if (!tl_arena) throw std::runtime_error("ZeroGroup: no arena");
+        char* base = (char*)tl_arena->take(total);
+        for (const Item& it : items) { *it.d = base + it.off; *it.n = it.count; }
+        HIP_CHECK(hipMemsetAsync(base, 0, total, st));
+        items.clear();
+        total = 0;
+    }
 };
 
 struct CsrBufs {
@@ -855,14 +898,15 @@ struct HipBackend {
         DevBuf<int32_t> row_cnt;
         DevBuf<int4> long_run;
         key1.alloc((size_t)rec_max); idx1.alloc((size_t)rec_max); flag.alloc((size_t)rec_max); flag_s.alloc((size_t)rec_max);
-        row_cnt.alloc((size_t)n_rows + 1);
         const int64_t long_max = rec_max / kLongRun + 1;
         long_run.alloc((size_t)long_max);
         out.ptr.alloc((size_t)n_rows + 1); out.col.alloc((size_t)rec_max + 64); out.o0.alloc((size_t)rec_max + 64);
         if (v1) out.o1.alloc((size_t)rec_max + 64);
-        out.result.alloc(2);
-        HIP_CHECK(hipMemsetAsync(out.result.d, 0, 2 * sizeof(long long), stream));
-        HIP_CHECK(hipMemsetAsync(row_cnt.d, 0, row_cnt.n * sizeof(int32_t), stream));
+        {
+            ZeroGroup zg;
+            zg.add(row_cnt, (size_t)n_rows + 1); zg.add(out.result, 2);
+            zg.commit(stream);
+        }
         int bits = 1;
         while (((int64_t)1 << bits) <= n_rows) ++bits;  // (the padding row n_rows sorts last)
         size_t tb = 0, tb2 = 0, tb3 = 0;
@@ -1148,20 +1192,19 @@ struct HipBackend {
             A_col.alloc((size_t)ae + 64); A_val.alloc((size_t)ae + 64);
             q.alloc((size_t)n); b.alloc((size_t)m); invD.alloc((size_t)n); invE.alloc((size_t)m); Dd.alloc((size_t)n); Ed.alloc((size_t)m);
             G1.ptr.alloc((size_t)n + 1); G2.ptr.alloc((size_t)n + 1); G2.split.alloc((size_t)n);
-            G1.col.alloc((size_t)ae + 64); G1.val.alloc((size_t)ae + 64);
-            G2.col.alloc((size_t)(nnzP_full + ae) + 64); G2.val.alloc((size_t)(nnzP_full + ae) + 64);
+            // (G1's and, on the graph path, G2's entries end where the kernels say: everything behind them must read as
+            //  (column 0, value 0) -- one block, one fill)
+            ZeroGroup zg;
+            zg.add(G1.col, (size_t)ae + 64); zg.add(G1.val, (size_t)ae + 64);
+            if (!R.exact) { zg.add(G2.col, (size_t)(nnzP_full + ae) + 64); zg.add(G2.val, (size_t)(nnzP_full + ae) + 64); }
+            zg.commit(stream);
+            if (R.exact) { G2.col.alloc((size_t)(nnzP_full + ae) + 64); G2.val.alloc((size_t)(nnzP_full + ae) + 64); }
         }
         const int64_t g2_nnz = nnzP_full + ae;  // (graph path: an upper bound)
-        HIP_CHECK(hipMemsetAsync(A_col.d + ae, 0, 64 * sizeof(int32_t), stream));
-        HIP_CHECK(hipMemsetAsync(A_val.d + ae, 0, 64 * sizeof(double), stream));
-        HIP_CHECK(hipMemsetAsync(G1.col.d, 0, G1.col.n * sizeof(int32_t), stream));
-        HIP_CHECK(hipMemsetAsync(G1.val.d, 0, G1.val.n * sizeof(double), stream));
+        // (A's padding: k_g_scale_a writes it)
         if (R.exact) {
             HIP_CHECK(hipMemsetAsync(G2.col.d + g2_nnz, 0, 64 * sizeof(int32_t), stream));
             HIP_CHECK(hipMemsetAsync(G2.val.d + g2_nnz, 0, 64 * sizeof(double), stream));
-        } else {  // (the end of the entries is not known yet: everything behind them reads as (column 0, value 0))
-            HIP_CHECK(hipMemsetAsync(G2.col.d, 0, G2.col.n * sizeof(int32_t), stream));
-            HIP_CHECK(hipMemsetAsync(G2.val.d, 0, G2.val.n * sizeof(double), stream));
         }
         DevBuf<int32_t> atp, arow;
         DevBuf<uint32_t> idx0, atpos, akey0, akey1;
@@ -1194,8 +1237,12 @@ struct HipBackend {
         const int64_t ngroups = (int64_t)h.cone_row.size();
         dsc.alloc((size_t)n); esc.alloc((size_t)std::max<int64_t>(1, ngroups));
         DevBuf<double> cmax;
-        cmax.alloc((size_t)n);
-        HIP_CHECK(hipMemsetAsync(cmax.d, 0, (size_t)n * sizeof(double), stream));
+        DevBuf<int32_t> long_rows, n_long_rows;
+        {
+            ZeroGroup zg;
+            zg.add(cmax, (size_t)n); zg.add(norms, (size_t)4 * count); zg.add(n_long_rows, 1);
+            zg.commit(stream);
+        }
         RzArgs rz{};
         rz.cmax = cmax.d; rz.acol_sorted = akey1.d; rz.nnzA = ae;
         rz.P_ptr = Pp_d; rz.P_col = Pc_d; rz.P_val = Pv_d; rz.A_ptr = A_ptr.d; rz.A_col = Ac_d; rz.A_val = Av_d;
@@ -1235,16 +1282,12 @@ struct HipBackend {
         hipLaunchKernelGGL(k_g_scale_a, dim3((unsigned)std::max<int64_t>(1, (std::max(ae, std::max(n, m)) + 255) / 256)), dim3(256), 0, stream, ga);
         // rows of G2 by length: eight lanes for the usual ones, a wavefront for the listed long ones (k_row_classify)
         const int64_t long_cap = (nnzP_full + ae) / kLongRowEntries + 1;
-        DevBuf<int32_t> long_rows, n_long_rows;
-        long_rows.alloc((size_t)long_cap); n_long_rows.alloc(1);
-        HIP_CHECK(hipMemsetAsync(n_long_rows.d, 0, sizeof(int32_t), stream));
+        long_rows.alloc((size_t)long_cap);
         hipLaunchKernelGGL(k_row_classify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const int32_t*)G2.ptr.d, n, long_rows.d, n_long_rows.d);
         const unsigned g8 = (unsigned)((n + 31) / 32), g64 = (unsigned)((long_cap + 3) / 4);
         ga.long_rows = long_rows.d; ga.n_long_rows = n_long_rows.d;
         hipLaunchKernelGGL(k_g_fill<8>, dim3(g8), dim3(256), 0, stream, ga);
         hipLaunchKernelGGL(k_g_fill<64>, dim3(g64), dim3(256), 0, stream, ga);
-        norms.alloc((size_t)4 * count);
-        HIP_CHECK(hipMemsetAsync(norms.d, 0, (size_t)4 * count * sizeof(double), stream));
         hipLaunchKernelGGL(k_prob_norms, dim3(count > 8 ? 8u : 32u, (unsigned)count), dim3(256), 0, stream, tab, (const double*)R.qraw.d, (const double*)q.d, (const double*)R.braw.d,
                            (const double*)b.d, norms.d);
         HIP_CHECK(hipGetLastError());
@@ -1314,13 +1357,11 @@ struct HipBackend {
             K0d.alloc((size_t)nnzK + 64); K1d.alloc((size_t)nnzK + 64);
         }
         HIP_CHECK(hipMemcpyAsync(K.ptr.d, mo.ptr.d, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
-        HIP_CHECK(hipMemcpyAsync(K.col.d, mo.col.d, (size_t)nnzK * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
-        HIP_CHECK(hipMemcpyAsync(K0d.d, mo.o0.d, (size_t)nnzK * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        HIP_CHECK(hipMemcpyAsync(K1d.d, mo.o1.d, (size_t)nnzK * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        HIP_CHECK(hipMemsetAsync(K.col.d + nnzK, 0, 64 * sizeof(int32_t), stream));
+        // (the 64 padding entries behind the last one come along: k_rec_total has zeroed them in the merge's arrays)
+        HIP_CHECK(hipMemcpyAsync(K.col.d, mo.col.d, ((size_t)nnzK + 64) * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(K0d.d, mo.o0.d, ((size_t)nnzK + 64) * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        HIP_CHECK(hipMemcpyAsync(K1d.d, mo.o1.d, ((size_t)nnzK + 64) * sizeof(double), hipMemcpyDeviceToDevice, stream));
         HIP_CHECK(hipMemsetAsync(K.val.d, 0, K.val.n * sizeof(double), stream));
-        HIP_CHECK(hipMemsetAsync(K0d.d + nnzK, 0, 64 * sizeof(double), stream));
-        HIP_CHECK(hipMemsetAsync(K1d.d + nnzK, 0, 64 * sizeof(double), stream));
         h.K.col.resize((size_t)nnzK);
         {
             Pinned kc((size_t)std::max<int64_t>(1, nnzK) * sizeof(int32_t), st.device);
@@ -1715,7 +1756,9 @@ struct HipBackend {
             if (npos > 0) hipLaunchKernelGGL(k_hb_positions, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, stream, pa);
             HIP_CHECK(hipGetLastError());
         }
-        fac.alloc(h.fac_doubles); fac.zero(stream);  // separator slots of the spike region are never written (nor used)
+        // (separator slots of the spike region are never written, nor used: zeroed once, with the float copy, in one fill)
+        ZeroGroup zfac;
+        zfac.add(fac, h.fac_doubles);
         use_fac32 = st.fac_fp32 != 0;
         // 4 x 4 blocks (3-D problems): the LDS-resident chain kernel only exists for the 4-byte stream, and the streaming
         // kernel is three times slower (22 / 30 us against 66 / 74 us per application on 1000-pose chains) -- the Newton
@@ -1727,7 +1770,8 @@ struct HipBackend {
         int min_chain = 1 << 30;
         for (const auto& ch : h.chains) min_chain = std::min(min_chain, (int)ch.N);
         newton_fac32 = st.fac_fp32 >= 2 || (st.fac_fp32 == 1 && prec_pre && (h.bs >= 4 || min_chain >= 256));
-        if (use_fac32) { fac32.alloc(h.fac_doubles); fac32.zero(stream); }
+        if (use_fac32) zfac.add(fac32, h.fac_doubles);
+        zfac.commit(stream);
         if (use_fac32 && prec_reg) deepK.alloc((size_t)std::max<int64_t>(1, h.deep_floats));
         dinv.alloc(h.dinv.size()); rho.upload(h.rho);
         q_work.alloc((size_t)std::max<int64_t>(1, h.scratch_nodes) * 2 * std::max(1, h.bs * h.bs));
@@ -2415,8 +2459,18 @@ struct HipBackend {
         pt.mark("graph capture + instantiate");
     }
 
+    // Launch graphs pay for long blocks (the ADMM loop alone: 25 iterations = 150 launches replayed per convergence test);
+    // the product default runs ONE short block (polish_warmup = 6 iterations) before the Newton polish: capturing and
+    // instantiating a graph for it costs more than its 36 direct launches (0.2-0.3 ms per handle), and -- measured, round 5,
+    // profiles/r05_graph_after_effect.txt -- a process that has destroyed a graph executable runs every LATER lock-step batch
+    // 15 % slower (64 config-5 trials: 4130-4220 -> 3520-3580 problems/s after one default solve of any handle with a graph,
+    // 4130 after the same solve without; the runtime's doing, not ours).  Blocks below kGraphMinIters are launched directly.
+    static int graph_min_iters() {
+        static const int v = std::getenv("SCORE_GRAPH_MIN_ITERS") ? std::max(2, std::atoi(std::getenv("SCORE_GRAPH_MIN_ITERS"))) : 16;
+        return v;
+    }
     void run(int iters) {
-        if (st.use_graph && iters > 1) {
+        if (st.use_graph && iters >= graph_min_iters()) {
             if (!graph_exec || graph_iters != iters) build_graph(iters);
             HIP_CHECK(hipGraphLaunch(graph_exec, stream));
         } else {
@@ -2908,9 +2962,11 @@ struct HipBackend {
         const int long_max = 1 << 16;
         // what stays: pattern, P on it, lists, positions (the handle's arena)
         Hm.ptr.alloc((size_t)n + 1);
-        Hm.col.alloc((size_t)rec_max + 64); Hm.val.alloc((size_t)rec_max + 64);
-        HIP_CHECK(hipMemsetAsync(Hm.col.d, 0, Hm.col.n * sizeof(int32_t), stream));
-        HIP_CHECK(hipMemsetAsync(Hm.val.d, 0, Hm.val.n * sizeof(double), stream));
+        {
+            ZeroGroup zg;
+            zg.add(Hm.col, (size_t)rec_max + 64); zg.add(Hm.val, (size_t)rec_max + 64);
+            zg.commit(stream);
+        }
         q_Pon.alloc((size_t)rec_max); q_cptr.alloc((size_t)rec_max + 1);
         q_ccone.alloc((size_t)std::max<int64_t>(1, con_max)); q_cab.alloc((size_t)std::max<int64_t>(1, con_max)); q_ccoef.alloc((size_t)std::max<int64_t>(1, con_max));
         q_posd.alloc(h.node_col.size() * (size_t)b2); q_poss.alloc(h.node_col.size() * (size_t)b2); q_diagpos.alloc(h.diag_cols.size());
@@ -3042,11 +3098,13 @@ struct HipBackend {
             for (size_t k = 0; k < nc && ok; ++k) ok = h.cone_type[k] == 1 && h.cone_dim[k] - 1 == T;
             if (!ok) return;
             Q.T = T;
-            q_head.alloc(nc); q_ishead.alloc((size_t)h.n_tot); q_aabs.alloc(nc); q_ck.alloc(nc); q_theta.alloc(nc); q_xstar.alloc(nc);
+            q_head.alloc(nc); q_aabs.alloc(nc); q_ck.alloc(nc); q_theta.alloc(nc); q_xstar.alloc(nc);
             DevBuf<int32_t> bad;
-            bad.alloc(1);
-            HIP_CHECK(hipMemsetAsync(q_ishead.d, 0, q_ishead.n * sizeof(int32_t), stream));
-            HIP_CHECK(hipMemsetAsync(bad.d, 0, sizeof(int32_t), stream));
+            {
+                ZeroGroup zg;
+                zg.add(q_ishead, (size_t)h.n_tot); zg.add(bad, 1);
+                zg.commit(stream);
+            }
             PStructArgs pa{};
             pa.ncones = (int64_t)nc; pa.n = h.n_tot; pa.T = T;
             pa.cone_row = cone_row.d; pa.cone_dim = cone_dim.d; pa.cone_type = cone_type.d;
@@ -3115,13 +3173,15 @@ struct HipBackend {
         q_long.upload(Q.long_ent); q_long_prob.upload(Q.long_prob);
         const size_t nc = h.cone_row.size();
         q_Bbuf.alloc(nc * Q.T * Q.T);
-        q_act.alloc(nc); q_act.zero(stream);
+        ZeroGroup zq;
+        zq.add(q_act, nc);
         n_fpart = 2 * std::max<size_t>((nc + kThreads - 1) / kThreads, (size_t)n_cone_blocks);  // F partials, then active-set flips
         q_X0.alloc(h.n_tot + h.m_tot); q_X1.alloc(h.n_tot + h.m_tot);
         q_g.alloc(h.n_tot); q_delta.alloc(h.n_tot); q_dummy.alloc(h.n_tot); q_negg.alloc(h.n_tot);
-        q_fac.alloc(h.fac_doubles_H); q_dinv.alloc(h.dinv.size());
-        q_fac.zero(stream);  // separator slots of the spike region are never written (nor used)
-        if (newton_fac32) { q_fac32.alloc(h.fac_doubles_H); q_fac32.zero(stream); }
+        q_dinv.alloc(h.dinv.size());
+        zq.add(q_fac, h.fac_doubles_H);  // separator slots of the spike region are never written (nor used)
+        if (newton_fac32) zq.add(q_fac32, h.fac_doubles_H);
+        zq.commit(stream);
         if (newton_fac32 && prec_reg) deepH.alloc((size_t)std::max<int64_t>(1, h.deep_floats_H));
         n_gd = std::max<size_t>((h.n_tot + kThreads - 1) / kThreads, (size_t)Hm.nblocks);
         q_pw.alloc(hblocks());

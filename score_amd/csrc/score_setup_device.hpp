@@ -210,6 +210,7 @@ __global__ __launch_bounds__(256) void k_g_scale_a(GDevArgs a) {
         a.oA_col[k] = c;
         a.oA_val[k] = (a.A_val[k] * a.E[a.arow[k]]) * a.D[c];
     }
+    if (k < 64) { a.oA_col[a.nnzA + k] = 0; a.oA_val[a.nnzA + k] = 0.0; }  // (the cone kernel's clamped loads land here)
     if (k < a.n) { const double d = a.D[k]; a.q[k] = a.q_raw[k] * d; a.invD[k] = 1.0 / d; }
     if (k < a.m) { const double e = a.E[k]; a.b[k] = a.b_raw[k] * e; a.invE[k] = 1.0 / e; }
 }
@@ -323,9 +324,16 @@ __global__ __launch_bounds__(256) void k_rec_merge(RecArgs a) {
         if (a.o1) a.o1[e] = s1;
     }
 }
-// total number of entries: the scan's last value
+// total number of entries: the scan's last value; the 64 entries behind the last one read as (column 0, value 0) (launched
+// with 64 threads)
 __global__ void k_rec_total(RecArgs a) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) a.result[0] = a.rec_max > 0 ? (long long)a.flag[a.rec_max - 1] : 0;
+    const long long tot = a.rec_max > 0 ? (long long)a.flag[a.rec_max - 1] : 0;
+    if (threadIdx.x == 0 && blockIdx.x == 0) a.result[0] = tot;
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        a.col[tot + threadIdx.x] = 0;
+        a.o0[tot + threadIdx.x] = 0.0;
+        if (a.o1) a.o1[tot + threadIdx.x] = 0.0;
+    }
 }
 // one wavefront per long run: 64 records are fetched together, lane 0's order of addition is the records' order
 __global__ __launch_bounds__(256) void k_rec_long(RecArgs a) {

@@ -295,7 +295,7 @@ class ConicSolver:
             raise RuntimeError(f"score_solve failed: {self.lib.score_last_error().decode()}")
         return self._split(x, y, s, infos)
 
-    def solve_estimates(self, qcqp_directions: bool = False):
+    def solve_estimates(self, qcqp_directions: bool = False, return_x: bool = False):
         """Cold-start solve of a handle made by ``from_graphs``, the estimate read back in the reference's own shapes straight
         from the device (``score_read_estimates``; replaces ``get_variable_values``, gurobi_utils.py:114-136) -- no x / y / s
         copies, no index maps.  Returns ``(infos, estimates)``: per problem a dict of ``info`` and a tuple
@@ -306,7 +306,8 @@ class ConicSolver:
             raise RuntimeError("solve_estimates: the handle was not made by ConicSolver.from_graphs")
         d, relax, per = dims
         infos = (ScoreInfo * self.count)()
-        if self.lib.score_solve(self._h, None, None, None, infos) != 0:
+        x = np.empty(self.n_total) if return_x else None  # (tests: the same solve's solver-space solution beside the estimate)
+        if self.lib.score_solve(self._h, _ptr(x, _f64p) if return_x else None, None, None, infos) != 0:
             raise RuntimeError(f"score_solve failed: {self.lib.score_last_error().decode()}")
         rw = d if (relax or qcqp_directions) else 1
         nP, nL, nR = sum(p[0] for p in per), sum(p[1] for p in per), sum(p[2] for p in per)
@@ -322,6 +323,8 @@ class ConicSolver:
             out_i.append(dict(infos[i].as_dict(), backend=backend))
             out_e.append((T[po : po + np_], B[po : po + np_], Lm[lo : lo + nl_], Rg[ro : ro + nr_], flags[po : po + np_]))
             po += np_; lo += nl_; ro += nr_
+        if return_x:
+            return out_i, out_e, x
         return out_i, out_e
 
     def reset(self) -> None:

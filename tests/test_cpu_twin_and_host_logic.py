@@ -339,3 +339,54 @@ def test_broadcast_graphs_without_a_process_group():
     out = broadcast_graphs(graphs, root=0)
     assert len(out) == 2 and all(isinstance(g, ArrayGraph) for g in out)
     assert out[0].num_poses == 24 and out[1].num_poses == 26
+
+
+def test_graph_handles_and_the_estimate_read_back(twin_lib):
+    """score_create_from_graphs / score_read_estimates / score_graphs_connected through the ABI (here: the twin, which builds
+    the model with the host assembler and reads the estimate back with read_estimates_host -- the host specification of the
+    device kernel): the estimate equals what the index maps and the reference's rounding make of the SAME solve's x --
+    homogeneous poses with the pinned [I | 0], the relaxed blocks, landmarks, SOCP distances, QCQP directions (native and
+    reconstructed from the SOCP), 2-D and 3-D; GraphModel's reshapes equal ScoreModel's maps."""
+    from score_amd.native import assemble_native, graph_arrays, graph_model, graphs_connected
+    from score_amd.rounding import round_to_special_orthogonal
+    from score_amd.solver import ConicSolver
+
+    g2 = make_manhattan(n_robots=3, n_poses=40, n_beacons=3, seed=11, p_range=0.5)
+    from score_amd.manhattan import make_manhattan_3d
+
+    g3 = make_manhattan_3d(n_robots=2, n_poses=25, n_beacons=3, seed=12, p_range=0.6)
+    for fg in (g2, g3):
+        a = graph_arrays(fg)
+        d = int(a["dim"])
+        assert graphs_connected([a, a], lib_path=twin_lib) is None
+        for relax, qdirs in (("SOCP", False), ("SOCP", True), ("QCQP", False)):
+            sv = ConicSolver.from_graphs([a], 0 if relax == "SOCP" else 1, dict(cg_iters=8) if relax == "QCQP" else {}, lib_path=twin_lib)
+            infos, ests, x = sv.solve_estimates(qcqp_directions=qdirs, return_x=True)
+            sv.close()
+            T, B, Lm, Rg, flags = ests[0]
+            gm, full = graph_model(a, relax), assemble_native(fg, relax, lib_path=twin_lib, arrays=a)
+            assert np.array_equal(gm.free_cols, full.free_cols) and gm.n_model == full.n_model
+            xm = full.expand(x)
+            blocks, lms, rng = gm.views(x)
+            assert np.array_equal(blocks, full.pose_blocks(xm)) and np.array_equal(lms, full.landmark_block(xm)) and np.array_equal(rng, full.range_block(xm))
+            assert np.array_equal(B, blocks) and np.array_equal(Lm, lms) and not flags.any()
+            assert np.array_equal(B[0], np.hstack([np.eye(d), np.zeros((d, 1))]))
+            R = round_to_special_orthogonal(blocks[:, :, :d])
+            np.testing.assert_allclose(T[:, :d, :d], R, atol=1e-12)
+            assert np.array_equal(T[:, :d, d], blocks[:, :, d]) and np.array_equal(T[:, d, :d], np.zeros((len(T), d))) and np.all(T[:, d, d] == 1.0)
+            if not qdirs:
+                assert np.array_equal(Rg, rng)
+            else:
+                tr = np.concatenate([blocks[:, :, d], lms])
+                delta = tr[a["rng_a"]] - tr[a["rng_b"]]
+                den = np.maximum(np.sqrt((delta * delta).sum(axis=1)), a["rng_dist"])
+                np.testing.assert_allclose(Rg, delta / den[:, None], atol=1e-14)
+    # a graph with an unconnected landmark: the check names it through the index of the failing graph
+    a_bad = dict(graph_arrays(g2))
+    a_bad["landmark_names"] = list(a_bad["landmark_names"]) + ["L_free"]
+    assert graphs_connected([graph_arrays(g2), a_bad], lib_path=twin_lib) == 1
+    # handles made from score_problem arrays do not know the graph
+    plain = ConicSolver([assemble_native(g2, "SOCP", lib_path=twin_lib).qp], {}, lib_path=twin_lib)
+    with pytest.raises(RuntimeError, match="not made by ConicSolver.from_graphs"):
+        plain.solve_estimates()
+    plain.close()
