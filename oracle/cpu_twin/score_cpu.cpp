@@ -595,7 +595,7 @@ int score_create_from_graphs(const score_graph* graphs, int32_t count, const sco
         std::vector<score_problem> probs((size_t)count);
         for (int i = 0; i < count; ++i) qps[(size_t)i].view(&probs[(size_t)i]);
         const int rc = score_create_batch(probs.data(), count, s, out);
-        if (rc == 0) score::est_layout_from_graphs(graphs, count, (*out)->solver.H.xoff, (*out)->solver.est);
+        if (rc == 0) score::est_layout_from_graphs(graphs, count, (*out)->solver.H.xoff, (*out)->solver.est, (*out)->solver.hf.empty() ? -1 : 0);
         return rc;
     } catch (const std::exception& e) {
         g_err = e.what();
@@ -609,7 +609,7 @@ int score_read_estimates(score_handle* h, int32_t qcqp_directions, double* poses
         if (!h->solver.est.valid()) throw std::runtime_error("score_read_estimates: the handle was not made by score_create_from_graphs");
         std::vector<double> x((size_t)h->solver.H.n_tot);
         h->solver.be.download(h->solver.H, x.data(), nullptr, nullptr);
-        score::read_estimates_host(h->solver.est, qcqp_directions, x.data(), poses, relaxed, landmarks, ranges, degenerate);
+        score::read_estimates_host(h->solver.est, (qcqp_directions || h->solver.est.dirs_always) ? 1 : 0, x.data(), poses, relaxed, landmarks, ranges, degenerate);
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
@@ -621,8 +621,8 @@ int score_graphs_connected(const score_graph* graphs, int32_t count) {
 }
 int score_dims(const score_handle* h, int64_t* n_total, int64_t* m_total, int32_t* count) {
     if (!h) { g_err = "null handle"; return -1; }
-    if (n_total) *n_total = h->solver.H.n_tot;
-    if (m_total) *m_total = h->solver.H.m_tot;
+    if (n_total) *n_total = h->solver.user_n();  // (the programs as given: score_headform.hpp)
+    if (m_total) *m_total = h->solver.user_m();
     if (count) *count = h->solver.H.count;
     return 0;
 }

@@ -510,11 +510,16 @@ struct EstLayout {
     std::vector<int32_t> rng_a, rng_b;   // concatenated, problem-local variable ids
     std::vector<double> rng_dist;
     int64_t n_pose = 0, n_lm = 0, n_rng = 0;
+    bool dirs_always = false;            // a QCQP graph solved in head form: ranges are always the directions
     bool valid() const { return !probs.empty(); }
 };
-inline void est_layout_from_graphs(const score_graph* graphs, int count, const std::vector<int64_t>& xoff, EstLayout& L) {
+// relaxation_as >= 0: the columns are those of that relaxation's program whatever the graphs say (score_headform.hpp: a QCQP
+// graph's head form has the SOCP program's columns)
+inline void est_layout_from_graphs(const score_graph* graphs, int count, const std::vector<int64_t>& xoff, EstLayout& L, int relaxation_as = -1) {
     L = EstLayout();
-    L.d = graphs[0].dim; L.relaxation = graphs[0].relaxation;
+    const int relax = relaxation_as >= 0 ? relaxation_as : graphs[0].relaxation;
+    L.d = graphs[0].dim; L.relaxation = relax;
+    L.dirs_always = relaxation_as == 0 && graphs[0].relaxation == 1;
     const int D1 = L.d + 1;
     for (int p = 0; p < count; ++p) {
         const score_graph& g = graphs[p];
@@ -522,7 +527,7 @@ inline void est_layout_from_graphs(const score_graph* graphs, int count, const s
         for (int c = 0; c < g.n_chains; ++c) Np += g.chain_len[c];
         EstProb e{};
         e.xoff = (int32_t)xoff[(size_t)p]; e.Np = (int32_t)Np; e.Nl = g.n_landmarks; e.Nr = (int32_t)g.n_rng;
-        e.n_rep = (int32_t)((Np - 1) * D1 + g.n_landmarks + (g.relaxation == 0 ? 0 : g.n_rng));
+        e.n_rep = (int32_t)((Np - 1) * D1 + g.n_landmarks + (relax == 0 ? 0 : g.n_rng));
         e.pose_off = (int32_t)L.n_pose; e.lm_off = (int32_t)L.n_lm; e.rng_off = (int32_t)L.n_rng;
         L.n_pose += Np; L.n_lm += g.n_landmarks; L.n_rng += g.n_rng;
         L.probs.push_back(e);

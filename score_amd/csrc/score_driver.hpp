@@ -15,6 +15,7 @@
 
 #include "score_host.hpp"
 #include "score_assemble.hpp"
+#include "score_headform.hpp"
 
 namespace score {
 
@@ -47,9 +48,54 @@ struct Solver {
     double setup_ms = 0;
     std::vector<double> dual_scale;  // per problem: |A'y|_inf of the last residual test (scale of the dual test)
 
-    void create(const score_problem* probs, int count, const score_settings& s) {
+    // Programs of the constant-head unit-ball kind (the reference's default "QCQP" relaxation) are solved in their head form
+    // (score_headform.hpp): H, the backend and every iterate live there; sizes, x, y and s at the boundary are the caller's.
+    std::vector<HeadForm> hf;          // per problem; empty: the programs are solved as given
+    std::vector<int64_t> uxoff, uroff; // offsets of the programs as given (hf non-empty)
+    int64_t user_n() const { return hf.empty() ? H.n_tot : uxoff.back(); }
+    int64_t user_m() const { return hf.empty() ? H.m_tot : uroff.back(); }
+    void download(double* x, double* y, double* s) {
+        if (hf.empty()) { be.download(H, x, y, s); return; }
+        if (!x && !y && !s) return;
+        std::vector<double> xr((size_t)H.n_tot), yr(y ? (size_t)H.m_tot : 0), sr(s ? (size_t)H.m_tot : 0);
+        be.download(H, xr.data(), y ? yr.data() : nullptr, s ? sr.data() : nullptr);
+        parallel_ranges(H.count, 1, [&](int, int64_t p0, int64_t p1) {
+            for (int64_t p = p0; p < p1; ++p)
+                headform_expand(hf[(size_t)p], xr.data() + H.xoff[(size_t)p], y ? yr.data() + H.roff[(size_t)p] : nullptr,
+                                s ? sr.data() + H.roff[(size_t)p] : nullptr, x ? x + uxoff[(size_t)p] : nullptr,
+                                y ? y + uroff[(size_t)p] : nullptr, s ? s + uroff[(size_t)p] : nullptr);
+        });
+    }
+
+    void create(const score_problem* probs, int count, const score_settings& s, bool keep_hf = false) {
         const double t0 = now_ms();
         st = s;
+        std::vector<score_problem> head_probs;
+        if (!keep_hf) hf.clear();
+        if (!keep_hf && headform_enabled() && count > 0 && probs && probs[0].n_soc > 0 && probs[0].A_rowptr && probs[0].z < probs[0].m &&
+            probs[0].A_rowptr[probs[0].z + 1] == probs[0].A_rowptr[probs[0].z]) {  // (first cone's head row is empty: worth a look)
+            for (int p = 0; p < count; ++p) validate_problem(probs[p]);
+            std::vector<HeadForm> F((size_t)count);
+            std::atomic<bool> all{true};
+            parallel_ranges(count, 1, [&](int, int64_t p0, int64_t p1) {
+                for (int64_t p = p0; p < p1 && all.load(std::memory_order_relaxed); ++p)
+                    if (!headform_reduce(probs[p], F[(size_t)p])) all = false;
+            });
+            if (all) {
+                hf = std::move(F);
+                uxoff.assign((size_t)count + 1, 0); uroff.assign((size_t)count + 1, 0);
+                head_probs.resize((size_t)count);
+                for (int p = 0; p < count; ++p) {
+                    headform_rebind(hf[(size_t)p]);
+                    head_probs[(size_t)p] = hf[(size_t)p].view;
+                    uxoff[(size_t)p + 1] = uxoff[(size_t)p] + probs[p].n;
+                    uroff[(size_t)p + 1] = uroff[(size_t)p] + probs[p].m;
+                }
+                probs = head_probs.data();
+                if (st.verbose) std::fprintf(stderr, "[score setup] constant-head unit-ball cones: solved in head form (n %lld -> %lld)\n",
+                                             (long long)uxoff.back(), (long long)(hf[0].n1));
+            }
+        }
         if (st.check_interval < 1) st.check_interval = 25;
         if (st.cg_iters < 1) st.cg_iters = 1;
         if (st.adaptive_rho_interval < st.check_interval) st.adaptive_rho_interval = st.check_interval;
@@ -75,7 +121,8 @@ struct Solver {
         if (count <= 0) throw std::runtime_error("score_create_from_graphs: count must be positive");
         struct KeepLayout {  // (filled once the handle exists, whichever path built it)
             Solver& S; const score_graph* g; int c;
-            ~KeepLayout() { if (!std::uncaught_exceptions() && S.H.count == c) est_layout_from_graphs(g, c, S.H.xoff, S.est); }
+            // (a QCQP graph solved in head form: the head form's columns are the SOCP program's, directions from the translations)
+            ~KeepLayout() { if (!std::uncaught_exceptions() && S.H.count == c) est_layout_from_graphs(g, c, S.H.xoff, S.est, S.hf.empty() ? -1 : 0); }
         } keep_layout{*this, graphs, count};
         std::vector<AssembledQP> skel((size_t)count);
         std::vector<score_problem> probs((size_t)count);
@@ -85,6 +132,26 @@ struct Solver {
             skel[(size_t)i].view(&probs[(size_t)i]);
         }
         st = s;
+        hf.clear();
+        std::vector<score_graph> as_socp;
+        bool all_qcqp = true;
+        for (int i = 0; i < count; ++i) all_qcqp = all_qcqp && graphs[i].relaxation == 1;
+        if (all_qcqp && headform_enabled()) {
+            // the direct QCQP form, solved in its head form -- which for a factor graph is the graph's SOCP program
+            // (score_headform.hpp): that one is built, on the device; sizes, x, y, s at the boundary stay the QCQP program's
+            as_socp.assign(graphs, graphs + count);
+            hf.resize((size_t)count);
+            uxoff.assign((size_t)count + 1, 0); uroff.assign((size_t)count + 1, 0);
+            for (int i = 0; i < count; ++i) {
+                as_socp[(size_t)i].relaxation = 0;
+                headform_from_graph(graphs[i], hf[(size_t)i]);
+                uxoff[(size_t)i + 1] = uxoff[(size_t)i] + hf[(size_t)i].n0;
+                uroff[(size_t)i + 1] = uroff[(size_t)i] + hf[(size_t)i].m0;
+                graph_skeleton(as_socp[(size_t)i], skel[(size_t)i]);
+                skel[(size_t)i].view(&probs[(size_t)i]);
+            }
+            graphs = as_socp.data();
+        }
         if (st.check_interval < 1) st.check_interval = 25;
         if (st.cg_iters < 1) st.cg_iters = 1;
         if (st.adaptive_rho_interval < st.check_interval) st.adaptive_rho_interval = st.check_interval;
@@ -95,7 +162,7 @@ struct Solver {
             build_system(probs.data(), count, st, H, Backend::kFactorOnHost, Backend::allow_rep(), nullptr,
                          [&](const HostSystem& hs) { return be.device_setup_ok_graphs(hs, graphs, st); }, /*trusted=*/true);
         } catch (const DeviceSetupDeclined&) {  // (the backend declined: model construction on the host, then the ordinary create)
-            assemble_on_host();
+            assemble_on_host(graphs, !hf.empty());
             return;
         }
         be.init(H, st, nullptr, graphs);
@@ -214,7 +281,7 @@ struct Solver {
             infos[p].setup_ms = setup_ms;
             infos[p].solve_ms = ms;
         }
-        be.download(H, x, y, s);
+        download(x, y, s);
         if (out)
             for (int p = 0; p < H.count; ++p) out[p] = infos[p];
     }
@@ -350,7 +417,7 @@ struct Solver {
         for (int p = 0; p < H.count; ++p)
             if (snap[p].status == SCORE_STATUS_UNSOLVED) snap[p].status = SCORE_STATUS_MAX_ITERS;
         const double ms = now_ms() - t0;
-        be.download(H, x, y, s);
+        download(x, y, s);
         if (out)
             for (int p = 0; p < H.count; ++p) {
                 out[p] = snap[p];

@@ -3961,14 +3961,14 @@ int score_create_from_graphs(const score_graph* graphs, int32_t count, const sco
         DeviceGuard guard(st.device);
         auto* h = new score_handle();
         try {
-            h->solver.create_from_graphs(graphs, count, st, [&] {
+            h->solver.create_from_graphs(graphs, count, st, [&](const score_graph* gs, bool keep_hf) {
                 std::vector<score::AssembledQP> qps((size_t)count);
                 std::vector<score::AssembledQP*> ptrs((size_t)count);
                 for (int i = 0; i < count; ++i) ptrs[(size_t)i] = &qps[(size_t)i];
-                score::assemble_graphs(graphs, count, ptrs.data());
+                score::assemble_graphs(gs, count, ptrs.data());
                 std::vector<score_problem> probs((size_t)count);
                 for (int i = 0; i < count; ++i) qps[(size_t)i].view(&probs[(size_t)i]);
-                h->solver.create(probs.data(), count, st);
+                h->solver.create(probs.data(), count, st, keep_hf);
             });
         } catch (...) {
             delete h;
@@ -3987,7 +3987,7 @@ int score_read_estimates(score_handle* h, int32_t qcqp_directions, double* poses
         if (!h) throw std::runtime_error("null handle");
         if (!h->solver.est.valid()) throw std::runtime_error("score_read_estimates: the handle was not made by score_create_from_graphs");
         DeviceGuard guard(h->solver.st.device);
-        h->solver.be.read_estimates(h->solver.H, h->solver.est, qcqp_directions, poses, relaxed, landmarks, ranges, degenerate);
+        h->solver.be.read_estimates(h->solver.H, h->solver.est, (qcqp_directions || h->solver.est.dirs_always) ? 1 : 0, poses, relaxed, landmarks, ranges, degenerate);
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
@@ -3999,8 +3999,8 @@ int score_graphs_connected(const score_graph* graphs, int32_t count) {
 }
 int score_dims(const score_handle* h, int64_t* n_total, int64_t* m_total, int32_t* count) {
     if (!h) { g_err = "null handle"; return -1; }
-    if (n_total) *n_total = h->solver.H.n_tot;
-    if (m_total) *m_total = h->solver.H.m_tot;
+    if (n_total) *n_total = h->solver.user_n();  // (the programs as given: score_headform.hpp)
+    if (m_total) *m_total = h->solver.user_m();
     if (count) *count = h->solver.H.count;
     return 0;
 }

@@ -20,6 +20,7 @@ cone program itself to the solver.
 from __future__ import annotations
 
 import logging
+import os
 import time
 from typing import List, Optional, Sequence
 
@@ -281,7 +282,9 @@ def solve_score_batch(
         # loop closures are stiff couplings outside the per-robot chains the
         # preconditioner captures: start with more PCG iterations per KKT solve
         settings.update(cg_iters=16, cg_target=0.1)
-    if relaxation_type == QCQP_RELAXATION and qcqp_mode == "direct":
+    if relaxation_type == QCQP_RELAXATION and qcqp_mode == "direct" and os.environ.get("SCORE_QCQP_PLAIN"):
+        # (the plain splitting loop on the program as given; by default the library solves the direct form in its head form,
+        #  csrc/score_headform.hpp, with the default settings)
         settings.update(cg_iters=8, adaptive_rho=0)
     settings.update(solver_settings or {})
     if assembler == "device":
@@ -360,8 +363,7 @@ def solve_problem_with_intermediate_iterates(
     Gurobi's barrier solver with BarIterLimit = 0, 1, 2, ... until it reports OPTIMAL; here ONE run of
     the product's default solver is paused along its own trajectory: every ``every`` ADMM iterations
     during the warm-up (``polish_warmup`` iterations, 6 by default), then after every semismooth-Newton
-    iteration of the polish.  Where the polish does not apply (the direct QCQP form, polish=0) the run
-    continues with ADMM snapshots.  ``solved`` is the solver's own verdict (its three termination tests,
+    iteration of the polish.  Where the polish does not apply (polish=0) the run continues with ADMM snapshots.  ``solved`` is the solver's own verdict (its three termination tests,
     the counterpart of ``model.status == GRB.OPTIMAL``, gurobi_utils.py:195); the list ends with the
     first solved iterate."""
     check_valid_relaxation(relaxation_type)
@@ -370,7 +372,7 @@ def solve_problem_with_intermediate_iterates(
     n_lc = int(data.n_loop_closures) if hasattr(data, "arrays") else len(data.loop_closure_measurements)  # (ArrayGraph or objects)
     if n_lc:
         settings.update(cg_iters=16, cg_target=0.1)
-    if relaxation_type == QCQP_RELAXATION and qcqp_mode == "direct":
+    if relaxation_type == QCQP_RELAXATION and qcqp_mode == "direct" and os.environ.get("SCORE_QCQP_PLAIN"):
         settings.update(cg_iters=8, adaptive_rho=0)
     settings.update(solver_settings or {})
     every = max(1, int(every))

@@ -65,6 +65,52 @@ def test_qcqp_direct_equals_via_socp(fixtures, twin_lib):
             np.testing.assert_allclose(a.distances[k], b.distances[k], atol=5e-4)
 
 
+@pytest.mark.parametrize("dim", [2, 3])
+def test_direct_qcqp_is_solved_in_head_form_and_mapped_back(twin_lib, monkeypatch, dim):
+    """csrc/score_headform.hpp (the reference's default relaxation, gurobi_utils.py:341-344, :488-496, handed over as it is):
+    the library rewrites the constant-head unit-ball cones into private-head cones, solves THAT program and maps the
+    solution back.  What comes back must be a KKT point of the program AS GIVEN -- checked here with the given P, q, A, b
+    alone -- with the SOCP relaxation's optimal value, zero-distance measurements (idle cones) included."""
+    from score_amd.assemble import assemble
+    from score_amd.manhattan import make_manhattan_3d
+    from score_amd.solver import ConicSolver
+
+    if dim == 2:
+        fg = make_manhattan(n_robots=2, n_poses=50, n_beacons=3, seed=14, p_range=0.5)  # (synth_d: two ranges of distance 0)
+        assert min(m.dist for m in fg.range_measurements) == 0.0
+    else:
+        fg = make_manhattan_3d(n_robots=2, n_poses=25, n_beacons=3, seed=12, p_range=0.6)
+    qp = assemble(fg, "QCQP").qp
+    ref = assemble(fg, "SOCP").qp
+    sv = ConicSolver([qp], dict(eps_abs=1e-9, eps_rel=1e-9, max_iters=60000), lib_path=twin_lib)
+    sol = sv.solve()[0]
+    assert (sv.n_total, sv.m_total) == (qp.n, qp.m)  # sizes at the boundary are the caller's
+    sv.close()
+    sv = ConicSolver([ref], dict(eps_abs=1e-9, eps_rel=1e-9, max_iters=60000), lib_path=twin_lib)
+    sref = sv.solve()[0]
+    sv.close()
+    assert sol.solved and sref.solved
+    x, y, s = sol.x, sol.y, sol.s
+    scale = max(1.0, np.abs(y).max())
+    assert np.abs(qp.A @ x + s - qp.b).max() <= 1e-12
+    assert np.abs(qp.P @ x + qp.q + qp.A.T @ y).max() <= 2e-6 * scale
+    T = dim
+    S, Y = s.reshape(-1, T + 1), y.reshape(-1, T + 1)
+    assert np.all(S[:, 0] == 1.0) and np.all(np.linalg.norm(S[:, 1:], axis=1) <= 1.0 + 1e-12)
+    assert np.all(Y[:, 0] >= np.linalg.norm(Y[:, 1:], axis=1) - 1e-12 * scale)
+    assert np.abs((S * Y).sum(axis=1)).max() <= 1e-9 * scale
+    assert qp.objective(x) == pytest.approx(ref.objective(sref.x), rel=1e-7, abs=1e-7)  # (sums of terms of magnitude 1e5..1e6)
+    assert sol.info["pobj"] == pytest.approx(qp.objective(x), rel=1e-9, abs=1e-7)
+    # the plain splitting loop on the program as given (rounds 1-4) ends at the same value
+    monkeypatch.setenv("SCORE_QCQP_PLAIN", "1")
+    sv = ConicSolver([qp], dict(eps_abs=1e-6, eps_rel=1e-6, max_iters=40000, cg_iters=8, adaptive_rho=0), lib_path=twin_lib)
+    plain = sv.solve()[0]
+    sv.close()
+    assert plain.solved
+    assert plain.info["pobj"] == pytest.approx(sol.info["pobj"], rel=1e-5, abs=1e-5)
+    # (x itself is not unique here: idle directions, a landmark no active cone determines)
+
+
 def test_batch_equals_individual(twin_lib):
     graphs = [make_manhattan(n_robots=3, n_poses=40 + 10 * (s % 4), n_beacons=4, seed=s, p_range=0.4) for s in (300, 303, 305)]
     batch = solve_score_batch(graphs, "SOCP", lib_path=twin_lib, lockstep=True)
@@ -362,6 +408,7 @@ def test_graph_handles_and_the_estimate_read_back(twin_lib):
         for relax, qdirs in (("SOCP", False), ("SOCP", True), ("QCQP", False)):
             sv = ConicSolver.from_graphs([a], 0 if relax == "SOCP" else 1, dict(cg_iters=8) if relax == "QCQP" else {}, lib_path=twin_lib)
             infos, ests, x = sv.solve_estimates(qcqp_directions=qdirs, return_x=True)
+            sv_n = sv.n_total
             sv.close()
             T, B, Lm, Rg, flags = ests[0]
             gm, full = graph_model(a, relax), assemble_native(fg, relax, lib_path=twin_lib, arrays=a)
@@ -369,12 +416,16 @@ def test_graph_handles_and_the_estimate_read_back(twin_lib):
             xm = full.expand(x)
             blocks, lms, rng = gm.views(x)
             assert np.array_equal(blocks, full.pose_blocks(xm)) and np.array_equal(lms, full.landmark_block(xm)) and np.array_equal(rng, full.range_block(xm))
+            if relax == "QCQP":  # (solved in its head form, csrc/score_headform.hpp: x's directions are r*(u) of the rewrite)
+                assert sv_n == full.qp.n
             assert np.array_equal(B, blocks) and np.array_equal(Lm, lms) and not flags.any()
             assert np.array_equal(B[0], np.hstack([np.eye(d), np.zeros((d, 1))]))
             R = round_to_special_orthogonal(blocks[:, :, :d])
             np.testing.assert_allclose(T[:, :d, :d], R, atol=1e-12)
             assert np.array_equal(T[:, :d, d], blocks[:, :, d]) and np.array_equal(T[:, d, :d], np.zeros((len(T), d))) and np.all(T[:, d, d] == 1.0)
-            if not qdirs:
+            if relax == "QCQP":
+                np.testing.assert_allclose(Rg, rng, atol=1e-12)
+            elif not qdirs:
                 assert np.array_equal(Rg, rng)
             else:
                 tr = np.concatenate([blocks[:, :, d], lms])
