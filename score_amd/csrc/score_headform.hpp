@@ -38,6 +38,7 @@
 #include <vector>
 
 #include "../../include/score_hip.h"
+#include "score_host.hpp"
 
 namespace score {
 
@@ -136,53 +137,86 @@ inline bool headform_reduce(const score_problem& p, HeadForm& F) {
     F.n1 = nu + (int32_t)nc;
     // ---- P~ = P_uu - P_ur G^-1 P_ru, q~ = q_u - P_ur G^-1 q_r; head rows: c = 1/g on the diagonal, q_h = -R ----
     struct Ent { int32_t col; double val, mag; bool schur; };
-    std::vector<Ent> L;
     F.P_ptr.assign((size_t)F.n1 + 1, 0);
-    F.P_col.reserve((size_t)p.P_rowptr[n]); F.P_val.reserve((size_t)p.P_rowptr[n]);
     F.q.assign((size_t)F.n1, 0.0);
     double c0 = p.c0;
-    for (int32_t iu = 0; iu < nu; ++iu) {
-        const int32_t i = F.u_cols[(size_t)iu];
-        L.clear();
-        double qi = p.q[i];
-        for (int32_t e = p.P_rowptr[i]; e < p.P_rowptr[i + 1]; ++e) {
-            const int32_t j = p.P_col[e];
-            const double v = p.P_val[e];
-            const int32_t k = cone_of[(size_t)j];
-            if (k < 0) { L.push_back(Ent{cmap[(size_t)j], v, std::fabs(v), false}); continue; }
-            if (F.g[(size_t)k] == 0.0) continue;  // (idle cone: the entry is zero)
-            const double f = v / F.g[(size_t)k];  // P[i, rho] / g
-            qi -= f * p.q[j];
-            for (int32_t e2 = p.P_rowptr[j]; e2 < p.P_rowptr[j + 1]; ++e2) {
-                const int32_t j2 = p.P_col[e2];
-                if (cone_of[(size_t)j2] >= 0) continue;  // (the diagonal of rho)
-                const double t = f * p.P_val[e2];
-                L.push_back(Ent{cmap[(size_t)j2], -t, std::fabs(t), true});
+    {   // rows of P~ in parts (one per host thread), written in place after a count
+        const int parts = parallel_parts(nu, 8192);
+        std::vector<std::vector<int32_t>> pc((size_t)parts);
+        std::vector<std::vector<double>> pv((size_t)parts);
+        std::vector<int64_t> part_row0((size_t)parts + 1, 0);
+        parallel_ranges(nu, 8192, [&](int t, int64_t i0, int64_t i1) {
+            if (i1 <= i0) return;
+            std::vector<Ent> L;
+            std::vector<int32_t> lc;
+            std::vector<double> lv;
+            lc.reserve((size_t)(p.P_rowptr[F.u_cols[(size_t)(i1 - 1)] + 1] - p.P_rowptr[F.u_cols[(size_t)i0]]));
+            lv.reserve(lc.capacity());
+            for (int64_t iu = i0; iu < i1; ++iu) {
+                const int32_t i = F.u_cols[(size_t)iu];
+                L.clear();
+                double qi = p.q[i];
+                for (int32_t e = p.P_rowptr[i]; e < p.P_rowptr[i + 1]; ++e) {
+                    const int32_t j = p.P_col[e];
+                    const double v = p.P_val[e];
+                    const int32_t k = cone_of[(size_t)j];
+                    if (k < 0) { L.push_back(Ent{cmap[(size_t)j], v, std::fabs(v), false}); continue; }
+                    if (F.g[(size_t)k] == 0.0) continue;  // (idle cone: the entry is zero)
+                    const double f = v / F.g[(size_t)k];  // P[i, rho] / g
+                    qi -= f * p.q[j];
+                    for (int32_t e2 = p.P_rowptr[j]; e2 < p.P_rowptr[j + 1]; ++e2) {
+                        const int32_t j2 = p.P_col[e2];
+                        if (cone_of[(size_t)j2] >= 0) continue;  // (the diagonal of rho)
+                        const double tt = f * p.P_val[e2];
+                        L.push_back(Ent{cmap[(size_t)j2], -tt, std::fabs(tt), true});
+                    }
+                }
+                F.q[(size_t)iu] = qi;
+                // stable order by column, then merge; a sum the Schur terms have cancelled to rounding is not an entry
+                if (L.size() > 64) {
+                    std::stable_sort(L.begin(), L.end(), [](const Ent& x, const Ent& y) { return x.col < y.col; });
+                } else {
+                    for (size_t x = 1; x < L.size(); ++x) {
+                        const Ent e = L[x];
+                        size_t y = x;
+                        while (y > 0 && L[y - 1].col > e.col) { L[y] = L[y - 1]; --y; }
+                        L[y] = e;
+                    }
+                }
+                size_t x = 0;
+                int32_t len = 0;
+                while (x < L.size()) {
+                    const int32_t c = L[x].col;
+                    double sum = 0.0, mag = 0.0;
+                    bool schur = false;
+                    for (; x < L.size() && L[x].col == c; ++x) { sum += L[x].val; mag = std::max(mag, L[x].mag); schur |= L[x].schur; }
+                    if (schur && std::fabs(sum) <= 1e-12 * mag) continue;
+                    lc.push_back(c); lv.push_back(sum);
+                    ++len;
+                }
+                F.P_ptr[(size_t)iu + 1] = len;
             }
-        }
-        F.q[(size_t)iu] = qi;
-        // stable order by column, then merge; a sum the Schur terms have cancelled to rounding is not an entry
-        for (size_t x = 1; x < L.size(); ++x) {
-            const Ent e = L[x];
-            size_t y = x;
-            while (y > 0 && L[y - 1].col > e.col) { L[y] = L[y - 1]; --y; }
-            L[y] = e;
-        }
-        size_t x = 0;
-        while (x < L.size()) {
-            const int32_t c = L[x].col;
-            double s = 0.0, mag = 0.0;
-            bool schur = false;
-            for (; x < L.size() && L[x].col == c; ++x) { s += L[x].val; mag = std::max(mag, L[x].mag); schur |= L[x].schur; }
-            if (schur && std::fabs(s) <= 1e-12 * mag) continue;
-            F.P_col.push_back(c); F.P_val.push_back(s);
-        }
-        F.P_ptr[(size_t)iu + 1] = (int32_t)F.P_col.size();
+            part_row0[(size_t)t] = i0;
+            pc[(size_t)t] = std::move(lc);
+            pv[(size_t)t] = std::move(lv);
+        }, parts);
+        for (int32_t iu = 0; iu < nu; ++iu) F.P_ptr[(size_t)iu + 1] += F.P_ptr[(size_t)iu];
+        F.P_col.resize((size_t)F.P_ptr[(size_t)nu] + nc);
+        F.P_val.resize((size_t)F.P_ptr[(size_t)nu] + nc);
+        parallel_ranges(parts, 1, [&](int, int64_t t0, int64_t t1) {
+            for (int64_t t = t0; t < t1; ++t) {
+                if (pc[(size_t)t].empty()) continue;
+                const size_t o = (size_t)F.P_ptr[(size_t)part_row0[(size_t)t]];
+                std::copy(pc[(size_t)t].begin(), pc[(size_t)t].end(), F.P_col.begin() + (std::ptrdiff_t)o);
+                std::copy(pv[(size_t)t].begin(), pv[(size_t)t].end(), F.P_val.begin() + (std::ptrdiff_t)o);
+            }
+        });
     }
     for (size_t k = 0; k < nc; ++k) {
         const int32_t h = nu + (int32_t)k;
-        F.P_col.push_back(h); F.P_val.push_back(F.g[k] > 0.0 ? 1.0 / (F.g[k] * F.lambda[k] * F.lambda[k]) : 1.0);
-        F.P_ptr[(size_t)h + 1] = (int32_t)F.P_col.size();
+        const size_t at = (size_t)F.P_ptr[(size_t)h];
+        F.P_col[at] = h; F.P_val[at] = F.g[k] > 0.0 ? 1.0 / (F.g[k] * F.lambda[k] * F.lambda[k]) : 1.0;
+        F.P_ptr[(size_t)h + 1] = (int32_t)at + 1;
         if (F.g[k] == 0.0) continue;
         F.q[(size_t)h] = -F.R[k] / F.lambda[k];
         c0 += 0.5 * F.g[k] * F.R[k] * F.R[k];

@@ -37,6 +37,7 @@
 #include "score_polish_device.hpp"
 #include "score_setup_device.hpp"
 #include "score_prec_wave.hpp"
+#include "score_join.hpp"
 
 namespace {
 
@@ -708,6 +709,13 @@ struct HipBackend {
     int n_vblocks = 0;
     DevBuf<double> xtu, xy, s, r, z, p, p2, w, kx, step;
     DevBuf<double> pw_part, rz_part0, rz_part1, rz_meas0, rz_meas1, pres_part, dres_part;
+    // ---- segmented long chains (score_join.hpp): K's set, the Newton matrix's set ----
+    int n_join_items = 0, n_join_chains = 0, n_join_seps = 0;
+    bool join_suspend = false;  // the spike solves of a refresh: the chain kernel alone
+    DevBuf<JoinChain> join_jc;
+    DevBuf<JoinItem> join_items;
+    DevBuf<int32_t> join_sep_col, join_sep_diag, join_pcol, join_pprev, join_posd_K, join_poss_K, join_posd_H, join_poss_H, join_zero;
+    DevBuf<double> join_W_K, join_W_H, join_data_K, join_data_H, join_rhs, join_tmp_p, join_tmp_rz, join_zb;
     // ---- semismooth-Newton polish (score_polish*.hpp) ----
     DevBuf<float> fac32, q_fac32;  // float copies of the chain factors (ADMM / Newton), see k_fac_round
     DevBuf<float> deepK, deepH;    // lane-major copies of their coarse levels (k_deep_pack -> k_prec_pre<.., float, true>)
@@ -1756,6 +1764,7 @@ struct HipBackend {
             if (npos > 0) hipLaunchKernelGGL(k_hb_positions, dim3((unsigned)((npos + 255) / 256)), dim3(256), 0, stream, pa);
             HIP_CHECK(hipGetLastError());
         }
+        join_init(h);
         // (separator slots of the spike region are never written, nor used: zeroed once, with the float copy, in one fill)
         ZeroGroup zfac;
         zfac.add(fac, h.fac_doubles);
@@ -1847,6 +1856,120 @@ struct HipBackend {
         }
         HIP_CHECK(hipGetLastError());
     }
+    // ---- segmented long chains (score_join.hpp) ----
+    // tables of the long chains + the positions of the separators' blocks in K; the Newton matrix's come with init_polish
+    void join_init(const HostSystem& h) {
+        n_join_items = (int)h.join_items.size(); n_join_chains = (int)h.join_chains.size(); n_join_seps = (int)h.join_sep_col.size();
+        if (!n_join_items) return;
+        for (const JoinChain& jc : h.join_chains)
+            if (jc.n_seg - 1 > kJoinMaxSeps) throw std::runtime_error("chain too long: more than 65 segments of 1023 nodes");
+        join_jc.upload(h.join_chains); join_items.upload(h.join_items);
+        join_sep_col.upload(h.join_sep_col); join_sep_diag.upload(h.join_sep_diag);
+        // pseudo-nodes for the position look-up (k_hb_positions): [separator | prev = last node of the segment before it] and
+        // [first node of the segment after it | prev = separator]
+        std::vector<int32_t> pc(2 * (size_t)n_join_seps), pp(2 * (size_t)n_join_seps);
+        for (const JoinChain& jc : h.join_chains)
+            for (int sg = 0; sg + 1 < jc.n_seg; ++sg) {
+                const ChainDesc& cl = h.chains[(size_t)jc.first_chain + sg];
+                const ChainDesc& cr = h.chains[(size_t)jc.first_chain + sg + 1];
+                const size_t sp = (size_t)jc.sep_begin + sg;
+                const int32_t b = h.join_sep_col[sp];
+                pc[2 * sp] = b; pp[2 * sp] = h.node_col[(size_t)cl.node_begin + cl.N - 1];
+                pc[2 * sp + 1] = h.node_col[(size_t)cr.node_begin]; pp[2 * sp + 1] = b;
+            }
+        join_pcol.upload(pc); join_pprev.upload(pp);
+        const size_t b2 = (size_t)h.bs * h.bs, nb = 2 * (size_t)h.bs;
+        ZeroGroup zj;
+        zj.add(join_W_K, nb * (size_t)h.n_tot); zj.add(join_rhs, (size_t)h.n_tot); zj.add(join_data_K, 5 * b2 * (size_t)n_join_seps);
+        zj.add(join_zero, (size_t)h.count); zj.add(join_zb, (size_t)h.bs * n_join_seps);
+        zj.commit(stream);
+        join_tmp_p.alloc((size_t)h.n_tot); join_tmp_rz.alloc(h.prec_work.size() + 4096);  // (every workgroup of a chain-kernel launch has a slot: work items + update helpers)
+        join_positions(K.ptr.d, K.col.d, join_posd_K, join_poss_K);
+        if (st.verbose) std::fprintf(stderr, "[score setup] long chains: %d in %d segments of <= %d nodes (second level: score_join.hpp)\n",
+                                     n_join_chains, n_join_items, kSegMaxNodes);
+    }
+    void join_positions(const int32_t* ptr, const int32_t* col, DevBuf<int32_t>& posd, DevBuf<int32_t>& poss) {
+        const size_t b2 = (size_t)H->bs * H->bs;
+        posd.alloc(2 * (size_t)n_join_seps * b2); poss.alloc(2 * (size_t)n_join_seps * b2);
+        HPosArgs pa{};
+        pa.Hptr = ptr; pa.Hcol = col; pa.node_col = join_pcol.d; pa.prev_col = join_pprev.d;
+        pa.n_nodes = 2 * (int64_t)n_join_seps; pa.bs = H->bs; pa.pos_diag = posd.d; pa.pos_sub = poss.d;
+        pa.diag_cols = nullptr; pa.n_diag = 0; pa.diag_pos = nullptr;
+        hipLaunchKernelGGL(k_hb_positions, dim3((unsigned)((pa.n_nodes * (int64_t)b2 + 255) / 256)), dim3(256), 0, stream, pa);
+        HIP_CHECK(hipGetLastError());
+    }
+    void join_init_newton(const HostSystem& h) {
+        if (!n_join_items) return;
+        const size_t b2 = (size_t)h.bs * h.bs, nb = 2 * (size_t)h.bs;
+        ZeroGroup zj;
+        zj.add(join_W_H, nb * (size_t)h.n_tot); zj.add(join_data_H, 5 * b2 * (size_t)n_join_seps);
+        zj.commit(stream);
+        join_positions(Hm.ptr.d, Hm.col.d, join_posd_H, join_poss_H);
+    }
+    JoinArgs join_args(bool newton_set) {
+        JoinArgs ja{};
+        ja.jc = join_jc.d; ja.items = join_items.d; ja.chains = newton_set ? chainsH.d : chains.d; ja.node_col = node_col.d;
+        ja.sep_col = join_sep_col.d; ja.done = join_zero.d;
+        ja.use_owner = (!newton_set && H->rep > 1) ? 1 : 0;
+        ja.W = newton_set ? join_W_H.d : join_W_K.d; ja.n_tot = H->n_tot;
+        ja.data = newton_set ? join_data_H.d : join_data_K.d;
+        ja.val = newton_set ? Hm.val.d : K.val.d;
+        ja.pos_diag = newton_set ? join_posd_H.d : join_posd_K.d; ja.pos_sub = newton_set ? join_poss_H.d : join_poss_K.d;
+        ja.rhs = join_rhs.d; ja.zb = join_zb.d;
+        ja.sep_diag = join_sep_diag.d; ja.dinv = newton_set ? q_dinv.d : dinv.d; ja.n_sep_entries = (int)H->join_sep_diag.size();
+        return ja;
+    }
+    template <int BS>
+    void join_refresh_bs(bool newton_set) {
+        JoinArgs ja = join_args(newton_set);
+        hipLaunchKernelGGL(k_join_dinv, dim3((unsigned)((ja.n_sep_entries + kJoinThreads - 1) / kJoinThreads)), dim3(kJoinThreads), 0, stream, ja);
+        // the spikes: 2 BS applications of the chain kernel alone to the coupling columns
+        PrecArgs pa{};
+        pa.work = prec_work.d; pa.chains = newton_set ? chainsH.d : chains.d; pa.levels = newton_set ? levelsH.d : levels.d;
+        pa.rec = newton_set ? prec_recH.d : prec_rec.d; pa.fac = newton_set ? q_fac.d : fac.d;
+        pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = newton_set ? q_dinv.d : dinv.d; pa.done = join_zero.d;
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = newton_set ? q_hblk_part.d : kblk_part_ptr.d;
+        pa.uni = uni_for(newton_set ? hblocks() : kblocks());
+        pa.r = join_rhs.d; pa.r_in = join_rhs.d; pa.p = join_tmp_p.d; pa.w = w.d; pa.xt = join_tmp_p.d; pa.kx = join_tmp_p.d;
+        pa.pw_part = nullptr; pa.rz_in = nullptr; pa.rz_out = join_tmp_rz.d;
+        join_suspend = true;
+        for (int c = 0; c < 2 * BS; ++c) {
+            ja.column = c;
+            hipLaunchKernelGGL(k_join_rhs<BS>, dim3((unsigned)((n_join_items * BS + kJoinThreads - 1) / kJoinThreads)), dim3(kJoinThreads), 0, stream, ja, n_join_items);
+            pa.z = ja.W + (size_t)c * (size_t)H->n_tot;
+            launch_prec<PREC_INIT>(pa);
+        }
+        join_suspend = false;
+        hipLaunchKernelGGL(k_join_schur<BS>, dim3((unsigned)((n_join_chains + 63) / 64)), dim3(64), 0, stream, ja, n_join_chains);
+    }
+    void join_refresh(bool newton_set) {
+        if (!n_join_items) return;
+        switch (H->bs) {
+            case 1: join_refresh_bs<1>(newton_set); break;
+            case 2: join_refresh_bs<2>(newton_set); break;
+            case 3: join_refresh_bs<3>(newton_set); break;
+            default: join_refresh_bs<4>(newton_set); break;
+        }
+    }
+    template <int BS, int MODE>
+    void join_apply_bs(const PrecArgs& pa, bool newton_set) {
+        JoinArgs ja = join_args(newton_set);
+        ja.done = pa.done;
+        ja.r = (MODE == PREC_INIT) ? pa.r_in : pa.r;
+        ja.z = pa.z; ja.p = pa.p; ja.rz_out = pa.rz_out;
+        hipLaunchKernelGGL(k_join_solve<BS>, dim3((unsigned)n_join_chains), dim3(64), 0, stream, ja);
+        hipLaunchKernelGGL((k_join_apply<BS, MODE>), dim3((unsigned)n_join_items), dim3(kJoinThreads), 0, stream, ja);
+    }
+    template <int MODE>
+    void join_apply(const PrecArgs& pa, bool newton_set) {
+        switch (H->bs) {
+            case 1: join_apply_bs<1, MODE>(pa, newton_set); break;
+            case 2: join_apply_bs<2, MODE>(pa, newton_set); break;
+            case 3: join_apply_bs<3, MODE>(pa, newton_set); break;
+            default: join_apply_bs<4, MODE>(pa, newton_set); break;
+        }
+    }
+
     int n_prec_items() const { return (int)H->prec_work.size(); }
     // k_factor keeps the level-to-level matrices in LDS when the longest chain fits
     int factor_lds_wmat = 0;
@@ -1902,6 +2025,7 @@ struct HipBackend {
                 hipLaunchKernelGGL(k_deep_pack, dim3((unsigned)(deep_padded_slots(bs) / 4), (unsigned)np), dim3(kThreads), 0, stream, fa.work, fa.chains,
                                    fa.levels, (const int32_t*)deep_map.d, (const float*)shadow, newton_set ? deepH.d : deepK.d, fa.skip, bs * bs);
         }
+        join_refresh(newton_set);  // (segmented long chains: separators' inverse diagonals, spikes, Schur factors)
     }
 
     ConeArgs cone_args(const double* gathered) {
@@ -2059,13 +2183,15 @@ struct HipBackend {
             wa.items = split_items.d; wa.plans = split_plans.d; wa.stage_rel = split_stage.d;
             wa.xbuf = split_xbuf.d; wa.xflag = split_xflag.d; wa.epoch = split_epoch.d; wa.poll_limit = split_poll_limit;
             launch_on_stream(k_prec_wave<MODE>, dim3(n_prec), dim3(kWaveThreads), split_lds, slot, wa);
-            return;
+        } else {
+            const int bs = H->bs;
+            if (bs <= 1) launch_prec_bs<1, MODE>(pa, slot, use_fac32);
+            else if (bs == 2) launch_prec_bs<2, MODE>(pa, slot, use_fac32);
+            else if (bs == 3) launch_prec_bs<3, MODE>(pa, slot, use_fac32);
+            else launch_prec_bs<4, MODE>(pa, slot, use_fac32);
         }
-        const int bs = H->bs;
-        if (bs <= 1) launch_prec_bs<1, MODE>(pa, slot, use_fac32);
-        else if (bs == 2) launch_prec_bs<2, MODE>(pa, slot, use_fac32);
-        else if (bs == 3) launch_prec_bs<3, MODE>(pa, slot, use_fac32);
-        else launch_prec_bs<4, MODE>(pa, slot, use_fac32);
+        // segmented long chains: the second level (score_join.hpp) after every application of the chain kernel
+        if (n_join_items && !join_suspend && !pa.debug_skip) join_apply<MODE>(pa, newton_set);
     }
     template <int BS, int MODE>
     void launch_prec_bs(const PrecArgs& pa_in, int slot, bool use_fac32) {
@@ -3194,6 +3320,7 @@ struct HipBackend {
             }
             q_seg_begin.upload(sb); q_seg_end.upload(se);
         }
+        join_init_newton(h);
     }
 
     PolishArgs polish_args(double* X) {

@@ -828,6 +828,26 @@ inline void chain_solve_host(const ChainDesc& ch, const ChainLevelDesc* levels, 
     }
 }
 
+// Chains of more than kSegMaxNodes nodes (device backends): cut into segments of at most that many nodes -- ordinary chains
+// for the chain kernel -- with ONE separator node between neighbours.  The separators are Jacobi columns whose inverse
+// diagonal is held at zero; after every application of the chain kernel a second kernel (score_join.hpp) solves the
+// separators' Schur system (block tridiagonal, n_seg - 1 nodes) and corrects the segments with their spikes: together the
+// exact solve with the whole chain's block-tridiagonal matrix, as the streaming kernel computes it.
+constexpr int kSegMaxNodes = 1023;
+struct JoinChain {
+    int32_t prob, n_seg;
+    int32_t first_chain;  // H.chains index of segment 0 (the segments follow)
+    int32_t sep_begin;    // first separator in join_sep_col (n_seg - 1 of them)
+    int32_t owner;        // join chain whose matrix blocks this one's are (replicated problems; itself otherwise)
+    int32_t pad_[3];
+};
+struct JoinItem {
+    int32_t chain;  // segment (H.chains index)
+    int32_t jc;     // its join chain
+    int32_t seg;    // position in the join chain
+    int32_t work;   // the segment's work item in prec_work (its slot of the r'z partial sums)
+};
+
 // ---------------------------------------------------------------------------
 // The assembled batch
 // ---------------------------------------------------------------------------
@@ -874,6 +894,10 @@ struct HostSystem {
     std::vector<double> dinv;  // per entry of diag_cols
     std::vector<PrecWork> prec_work;
     std::vector<int32_t> prec_part_ptr;  // count + 1
+    // segmented long chains (kSegMaxNodes; empty when there are none)
+    std::vector<JoinChain> join_chains;
+    std::vector<JoinItem> join_items;
+    std::vector<int32_t> join_sep_col, join_sep_diag;  // per separator: its first column, its entry in diag_cols / dinv
 
     std::vector<double> rho;       // per problem
     mutable std::vector<double> kkt_bytes; // per problem: algorithmic bytes of one K-apply (a backend that streams another layout of K restates it)
@@ -1731,38 +1755,63 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     std::vector<char> in_chain(H.n_tot, 0);
     std::vector<int32_t> node_prev;  // column of each chain node's predecessor (-1: first of its chain)
     const int max_nodes = 1 << 20;
+    // (the twin factors on the host and keeps whole chains: its streaming solve is the specification)
+    const bool segments_ok = !factor_on_host && H.radix == 4 && bs >= 1 && bs <= 4 && std::getenv("SCORE_NO_SEGMENTS") == nullptr;
     for (int p = 0; p < count; ++p) {
         const score_problem& pr = probs[p];
+        const size_t jc_first = H.join_chains.size();
         for (int c = 0; c < pr.n_chains; ++c) {
             const int nb = pr.chain_ptr[c], ne = pr.chain_ptr[c + 1];
             if (ne <= nb) continue;
             if (ne - nb > max_nodes) throw std::runtime_error("chain too long");
-            ChainDesc ch{};
-            ch.prob = p;
-            ch.node_begin = (int32_t)H.node_col.size();
-            ch.N = ne - nb;
-            for (int j = nb; j < ne; ++j) {
-                const int32_t col = (int32_t)(H.xoff[p] + pr.node_first_col[j]);
-                H.node_col.push_back(col);
-                node_prev.push_back(j > nb ? (int32_t)(H.xoff[p] + pr.node_first_col[j - 1]) : -1);
-                for (int a = 0; a < bs; ++a) in_chain[col + a] = 1;
+            // a chain of more than kSegMaxNodes nodes: segments with one separator node between neighbours (JoinChain)
+            const int Nall = ne - nb;
+            const int n_seg = (segments_ok && Nall > kSegMaxNodes) ? (Nall + 1 + kSegMaxNodes) / (kSegMaxNodes + 1) : 1;
+            if (n_seg > 1) {
+                JoinChain jc{};
+                jc.prob = p; jc.n_seg = n_seg; jc.first_chain = (int32_t)H.chains.size();
+                jc.sep_begin = (int32_t)H.join_sep_col.size(); jc.owner = (int32_t)H.join_chains.size();
+                H.join_chains.push_back(jc);
             }
-            ch.col0 = H.node_col[ch.node_begin];
-            ch.col_stride = 0;
-            if (ch.N >= 2) {
-                const int32_t st0 = H.node_col[ch.node_begin + 1] - H.node_col[ch.node_begin];
-                bool even = st0 > 0;
-                for (int i = 2; i < ch.N && even; ++i)
-                    even = (H.node_col[ch.node_begin + i] - H.node_col[ch.node_begin + i - 1]) == st0;
-                if (even) ch.col_stride = st0;
+            const int seg_nodes = Nall - (n_seg - 1);
+            int at = nb;
+            for (int sg = 0; sg < n_seg; ++sg) {
+                const int len = seg_nodes / n_seg + (sg < seg_nodes % n_seg ? 1 : 0);
+                ChainDesc ch{};
+                ch.prob = p;
+                ch.node_begin = (int32_t)H.node_col.size();
+                ch.N = len;
+                for (int j = at; j < at + len; ++j) {
+                    const int32_t col = (int32_t)(H.xoff[p] + pr.node_first_col[j]);
+                    H.node_col.push_back(col);
+                    node_prev.push_back(j > at ? (int32_t)(H.xoff[p] + pr.node_first_col[j - 1]) : -1);
+                    for (int a = 0; a < bs; ++a) in_chain[col + a] = 1;
+                }
+                ch.col0 = H.node_col[ch.node_begin];
+                ch.col_stride = 0;
+                if (ch.N >= 2) {
+                    const int32_t st0 = H.node_col[ch.node_begin + 1] - H.node_col[ch.node_begin];
+                    bool even = st0 > 0;
+                    for (int i = 2; i < ch.N && even; ++i)
+                        even = (H.node_col[ch.node_begin + i] - H.node_col[ch.node_begin + i - 1]) == st0;
+                    if (even) ch.col_stride = st0;
+                }
+                if (n_seg > 1) H.join_items.push_back(JoinItem{(int32_t)H.chains.size(), (int32_t)H.join_chains.size() - 1, sg, -1});
+                H.chains.push_back(ch);
+                at += len;
+                if (sg + 1 < n_seg) {  // the separator after this segment: a Jacobi column (below)
+                    H.join_sep_col.push_back((int32_t)(H.xoff[p] + pr.node_first_col[at]));
+                    ++at;
+                }
             }
-            H.chains.push_back(ch);
         }
         // replicated problem: the chains come replica by replica (check_replication); replica k's chain c is
         // replica 0's chain c shifted by k * rep_n and uses its factors
         const size_t first = H.chain_owner.size(), mine = H.chains.size() - first;
         const size_t per_rep = H.rep > 1 ? mine / (size_t)H.rep : mine;
         for (size_t c = 0; c < mine; ++c) H.chain_owner.push_back((int32_t)(first + (per_rep ? c % per_rep : c)));
+        const size_t jmine = H.join_chains.size() - jc_first, jper = H.rep > 1 ? jmine / (size_t)H.rep : jmine;
+        for (size_t c = 0; c < jmine; ++c) H.join_chains[jc_first + c].owner = (int32_t)(jc_first + (jper ? c % jper : c));
     }
     for (size_t ci = 0; ci < H.chains.size(); ++ci) {
         const ChainDesc& a = H.chains[ci];
@@ -1885,6 +1934,17 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     H.fac_doubles = fac_total;
     pt.mark("level layout");
     // Jacobi columns + work list (problem-major: chains, then Jacobi blocks)
+    std::vector<int32_t> chain_item, sep_of_col;  // (segmented chains: join item of a chain, separator of a column)
+    std::vector<char> sep_comp;
+    if (!H.join_chains.empty()) {
+        chain_item.assign(H.chains.size(), -1);
+        for (size_t i = 0; i < H.join_items.size(); ++i) chain_item[(size_t)H.join_items[i].chain] = (int32_t)i;
+        sep_of_col.assign((size_t)H.n_tot, -1);
+        sep_comp.assign((size_t)H.n_tot, 0);
+        for (size_t sp = 0; sp < H.join_sep_col.size(); ++sp)
+            for (int a = 0; a < bs; ++a) { sep_of_col[(size_t)H.join_sep_col[sp] + a] = (int32_t)sp; sep_comp[(size_t)H.join_sep_col[sp] + a] = (char)a; }
+        H.join_sep_diag.assign(H.join_sep_col.size() * (size_t)bs, -1);
+    }
     size_t ci = 0;
     for (int p = 0; p < count; ++p) {
         const size_t c_first = ci;
@@ -1896,10 +1956,14 @@ inline void build_system(const score_problem* probs, int count, const score_sett
         //  so that the chains sharing one factor set sit 8 items apart -- on one XCD's L2 under round-robin placement:
         //  no change, 61.6 vs 62.5 us at 16 problems.  The chain kernel is bound by its dependent phases at one
         //  workgroup per CU, not by where its factors come from.)
-        for (size_t c = c_first; c < ci; ++c) H.prec_work.push_back(PrecWork{0, (int32_t)c, 0, p});
+        for (size_t c = c_first; c < ci; ++c) {
+            if (!chain_item.empty() && chain_item[c] >= 0) H.join_items[(size_t)chain_item[c]].work = (int32_t)H.prec_work.size();
+            H.prec_work.push_back(PrecWork{0, (int32_t)c, 0, p});
+        }
         const size_t d_first = H.diag_cols.size();
         for (int64_t c = H.xoff[p]; c < H.xoff[p + 1]; ++c)
             if (!in_chain[c]) {
+                if (!sep_of_col.empty() && sep_of_col[(size_t)c] >= 0) H.join_sep_diag[(size_t)sep_of_col[(size_t)c] * bs + (size_t)sep_comp[(size_t)c]] = (int32_t)H.diag_cols.size();
                 H.diag_cols.push_back((int32_t)c);
                 // (a column of replica k finds its diagonal in replica 0's row)
                 int64_t c0_ = c;

@@ -560,14 +560,17 @@ def test_long_chain_and_3d_blocks(hip_lib, twin_lib):
 
 @pytest.mark.parametrize("n_poses", [255, 1023, 1024])
 def test_both_chain_kernels_match_the_twin(n_poses, hip_lib, twin_lib):
-    """Chains of up to 1023 poses run the register/LDS-resident chain kernel (k_prec_pre), longer
-    ones (and radix != 4) the streaming one (k_prec): same preconditioner, same iterates.  A fixed
-    number of ADMM iterations is compared with the CPU twin on both sides of the boundary, and the
-    two kernels with each other on the same chain (radix 2 forces the streaming kernel)."""
+    """Chains of up to 1023 poses run the register/LDS-resident chain kernel (k_prec_pre); longer ones are cut into
+    segments for it and joined by a second level (score_join.hpp; 1024 poses: robot B's 1024 free nodes), radix != 4 takes
+    the streaming kernel (k_prec): same preconditioner, same iterates.  A fixed number of ADMM iterations is compared with
+    the CPU twin on both sides of the boundary, and the kernels with each other on the same chain (radix 2 forces the
+    streaming kernel).  With float factors (the default) a segmented chain's operator is the exact inverse of a matrix
+    rounded differently from the twin's whole-chain factors: compared with double factors there."""
     fg = make_manhattan(n_robots=2, n_poses=n_poses, n_beacons=3, seed=21)
     qp = assemble(fg, "SOCP").qp
     outs = {}
-    for name, lib, extra in (("hip", None, {}), ("twin", twin_lib, {}), ("hip_r2", None, dict(chain_radix=2)),
+    f32 = dict(fac_fp32=0) if n_poses > 1023 else {}
+    for name, lib, extra in (("hip", None, f32), ("twin", twin_lib, f32), ("hip_r2", None, dict(chain_radix=2)),
                              ("twin_r2", twin_lib, dict(chain_radix=2))):
         sol = ConicSolver(qp, dict(polish=0, adaptive_rho=0, adaptive_cg=0, **extra), lib_path=lib)
         outs[name] = sol.steps(50)[0]
@@ -576,6 +579,58 @@ def test_both_chain_kernels_match_the_twin(n_poses, hip_lib, twin_lib):
         scale = np.abs(outs[b].x).max()
         np.testing.assert_allclose(outs[a].x, outs[b].x, atol=1e-7 * scale)
         assert outs[a].info["pobj"] == pytest.approx(outs[b].info["pobj"], rel=1e-8)
+
+
+@pytest.mark.parametrize("case", ["2d", "3d", "batch"])
+def test_segmented_long_chains_equal_the_streaming_solve(case, hip_lib, twin_lib, monkeypatch):
+    """Chains of more than 1023 poses (score_host.hpp: JoinChain; score_join.hpp): segments for the LDS-resident chain
+    kernel + separators' Schur system + spike correction = the exact solve with the whole chain's block-tridiagonal matrix.
+    With double factors the ADMM iterates equal the twin's (whole chains, streaming solve) and the streaming kernel's
+    (SCORE_NO_SEGMENTS=1) to rounding; the default solver (float factors, Newton polish with its own segmented factors)
+    takes the same Newton iterations and ends at the same point; 2-D, 3-D (4 x 4 blocks) and a lock-step batch."""
+    from score_amd.manhattan import make_manhattan_3d
+
+    if case == "2d":
+        graphs = [make_manhattan(n_robots=2, n_poses=2500, n_beacons=3, seed=31)]  # 3 segments per chain
+    elif case == "3d":
+        graphs = [make_manhattan_3d(n_robots=2, n_poses=1300, n_beacons=3, seed=32, p_range=0.3)]
+    else:
+        graphs = [make_manhattan(n_robots=1, n_poses=1100, n_beacons=2, seed=33), make_manhattan(n_robots=2, n_poses=700, n_beacons=3, seed=34),
+                  make_manhattan(n_robots=2, n_poses=2100, n_beacons=3, seed=35)]
+    qps = [assemble(g, "SOCP").qp for g in graphs]
+    fixed = dict(polish=0, adaptive_rho=0, adaptive_cg=0, fac_fp32=0)
+    outs = {}
+    for name, lib, env in (("seg", None, None), ("stream", None, "1"), ("twin", twin_lib, None)):
+        if env:
+            monkeypatch.setenv("SCORE_NO_SEGMENTS", env)
+        else:
+            monkeypatch.delenv("SCORE_NO_SEGMENTS", raising=False)
+        sol = ConicSolver(qps, fixed, lib_path=lib)
+        outs[name] = sol.steps(40)
+        sol.close()
+    for k in range(len(qps)):
+        scale = max(1.0, np.abs(outs["twin"][k].x).max())
+        np.testing.assert_allclose(outs["seg"][k].x, outs["twin"][k].x, atol=1e-9 * scale)
+        np.testing.assert_allclose(outs["seg"][k].x, outs["stream"][k].x, atol=1e-9 * scale)
+    full = {}
+    for name, env in (("seg", None), ("stream", "1")):
+        if env:
+            monkeypatch.setenv("SCORE_NO_SEGMENTS", env)
+        else:
+            monkeypatch.delenv("SCORE_NO_SEGMENTS", raising=False)
+        sol = ConicSolver(qps, {})
+        full[name] = sol.solve()
+        sol.close()
+    monkeypatch.delenv("SCORE_NO_SEGMENTS", raising=False)
+    for k, qp in enumerate(qps):
+        a, b = full["seg"][k], full["stream"][k]
+        assert a.solved and b.solved and a.info["newton_iters"] > 0
+        assert a.info["newton_iters"] == b.info["newton_iters"] and a.info["iters"] == b.info["iters"]
+        scale = max(1.0, np.abs(b.x).max())
+        np.testing.assert_allclose(a.x, b.x, atol=1e-7 * scale)
+        assert a.info["pobj"] == pytest.approx(b.info["pobj"], rel=1e-8, abs=1e-8)
+        cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, a.x, a.y, a.s)
+        assert cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4, cert
 
 
 @pytest.mark.parametrize("index", [1, 2, 3])
