@@ -107,8 +107,9 @@ typedef struct score_settings {
     int32_t chain_radix;       /* partition radix of the chain solver (2..4) */
     int32_t device;            /* HIP device ordinal                         */
     int32_t use_graph;         /* replay iterations from a hipGraph          */
-    int32_t polish;            /* 0/1: semismooth-Newton polish once ADMM is close (single problems whose
-                                  cones have private head variables, i.e. the SCORE SOCP form)          */
+    int32_t polish;            /* 0/1: semismooth-Newton polish once ADMM is close (programs whose cones have
+                                  private head variables: the SCORE SOCP form, and the QCQP form after the
+                                  library's rewrite, score_headform.hpp)                                 */
     double  polish_start;      /* start it when both relative residuals are below this                  */
     int32_t polish_warmup;     /* ADMM iterations before the first polish attempt (0: one check_interval) */
     int32_t verbose;
@@ -158,7 +159,11 @@ typedef struct score_handle score_handle;
 
 void score_default_settings(score_settings* s);
 
-/* Build a solver for ONE problem / for a batch of `count` independent problems. */
+/* Build a solver for ONE problem / for a batch of `count` independent problems.
+ * Programs whose cones all have a CONSTANT head and private tail columns (the reference's default "QCQP" relaxation:
+ * ||r_ij|| <= 1, gurobi_utils.py:341-344, cost :488-496) are rewritten into private-head cones and solved in that form
+ * (score_amd/csrc/score_headform.hpp) -- the same optimum, with the Newton polish; sizes, x, y, s at this boundary stay those
+ * of the program as given.  SCORE_QCQP_PLAIN=1 in the environment: the plain ADMM loop on the program as given.            */
 int  score_create(const score_problem* p, const score_settings* s, score_handle** out);
 int  score_create_batch(const score_problem* p, int32_t count, const score_settings* s,
                         score_handle** out);
