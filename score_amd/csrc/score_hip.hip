@@ -287,8 +287,10 @@ inline size_t stage_limit_bytes() {
     static const size_t v = [] {
         if (std::getenv("SCORE_NO_STAGED_UPLOADS")) return (size_t)0;
         if (std::getenv("SCORE_STAGED_UPLOADS")) return ~(size_t)0;
+        // (round 5: EVERYTHING goes through pinned memory of the library's own by default -- see staged_d2h below for why no
+        //  pageable pointer is ever handed to the runtime; SCORE_STAGE_MAX_KB restores a size limit)
         const char* e = std::getenv("SCORE_STAGE_MAX_KB");
-        return (size_t)(e ? std::max(0L, std::atol(e)) : 512L) << 10;
+        return e ? (size_t)std::max(0L, std::atol(e)) << 10 : ~(size_t)0;
     }();
     return v;
 }
@@ -296,17 +298,27 @@ struct StageArena {
     int dev = 0;
     std::vector<size_t> chunk_bytes;
     std::vector<void*> chunks;
+    size_t at = 0;        // chunk in use
     char* cur = nullptr;
     size_t left = 0;
+    size_t inflight = 0;  // bytes staged since the last synchronisation
+    static constexpr size_t kMaxInflight = (size_t)192 << 20;
     void* take(size_t bytes) {
         bytes = (bytes + 255) & ~(size_t)255;
         if (bytes > left) {
-            size_t got = std::max(bytes, stage_limit_bytes() == ~(size_t)0 ? (size_t)32 << 20 : (size_t)4 << 20);
-            void* p = block_cache().take(got, dev, true);
-            chunks.push_back(p);
-            chunk_bytes.push_back(got);
-            cur = (char*)p;
-            left = got;
+            // the next parked chunk if it is large enough, a new one otherwise
+            size_t k = chunks.empty() ? 0 : at + 1;
+            while (k < chunks.size() && chunk_bytes[k] < bytes) ++k;
+            if (k >= chunks.size()) {
+                size_t got = std::max(bytes, (size_t)32 << 20);
+                void* p = block_cache().take(got, dev, true);
+                chunks.push_back(p);
+                chunk_bytes.push_back(got);
+                k = chunks.size() - 1;
+            }
+            at = k;
+            cur = (char*)chunks[k];
+            left = chunk_bytes[k];
         }
         void* r = cur;
         cur += bytes;
@@ -314,27 +326,86 @@ struct StageArena {
         return r;
     }
     // copy `bytes` from src into a pinned slot and queue its transfer to `dst` on `st`; false: too large, the caller
-    // takes the pageable path
+    // takes its own path
     bool upload(void* dst, const void* src, size_t bytes, hipStream_t st) {
         if (!bytes) return true;
         if (bytes > stage_limit_bytes()) return false;
+        if (inflight + bytes > kMaxInflight && inflight > 0) {  // everything queued so far has to leave its slots: start over
+            HIP_CHECK(hipStreamSynchronize(st));
+            inflight = 0; at = 0;
+            cur = chunks.empty() ? nullptr : (char*)chunks[0];
+            left = chunks.empty() ? 0 : chunk_bytes[0];
+        }
         char* pin = (char*)take(bytes);
         if (bytes >= ((size_t)1 << 20))
             score::parallel_ranges((int64_t)bytes, (int64_t)1 << 19, [&](int, int64_t b0, int64_t b1) { std::memcpy(pin + b0, (const char*)src + b0, (size_t)(b1 - b0)); });
         else
             std::memcpy(pin, src, bytes);
         HIP_CHECK(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, st));
+        inflight += bytes;
         return true;
     }
     // (the caller has synchronised the stream the transfers were queued on)
     void release() {
         for (size_t i = 0; i < chunks.size(); ++i) block_cache().give(chunks[i], chunk_bytes[i], dev, true);
         chunks.clear(); chunk_bytes.clear();
-        cur = nullptr; left = 0;
+        cur = nullptr; left = 0; at = 0; inflight = 0;
     }
     ~StageArena() { release(); }
 };
 thread_local StageArena* tl_stage = nullptr;  // set while a handle's setup uploads on this thread
+
+// Host <-> device copies never hand PAGEABLE memory to the runtime.  For a transfer of a megabyte or more the runtime registers
+// the caller's pages with the driver; when the caller later frees that memory (NumPy arrays of the previous solve, the vectors
+// of a model construction) the change of the address space evicts EVERY queue of the process until the driver has restored
+// them -- measured (round 5, 20 x 5000 poses: 12 MB of x, y, s per solve): the first kernel after such a free started 14-37 ms
+// late, whichever handle or thread it belonged to; solves 47 / 46 / 21 / 21 ms became 32 / 21 / 21 / 21 with the download
+// staged, 21 / 21 / 21 / 21 with the uploads of score_create staged as well.  Both directions therefore go through pinned
+// blocks of the library's own (block cache), in pieces of at most 16 MB; synchronous.
+inline void staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (!bytes) return;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    size_t got = std::min<size_t>(bytes, (size_t)16 << 20);
+    char* pin = (char*)block_cache().take(got, dev, true);
+    hipError_t e = hipSuccess;
+    for (size_t off = 0; off < bytes && e == hipSuccess; off += got) {
+        const size_t nb = std::min(got, bytes - off);
+        if (nb >= ((size_t)1 << 20))
+            score::parallel_ranges((int64_t)nb, (int64_t)1 << 19, [&](int, int64_t b0, int64_t b1) { std::memcpy(pin + b0, (const char*)src + off + b0, (size_t)(b1 - b0)); });
+        else
+            std::memcpy(pin, (const char*)src + off, nb);
+        e = hipMemcpyAsync((char*)dst + off, pin, nb, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    block_cache().give(pin, got, dev, true);
+    HIP_CHECK(e);
+}
+inline void staged_d2h(void* dst, const void* src, size_t bytes, hipStream_t st) {
+    if (!bytes) return;
+    int dev = 0;
+    HIP_CHECK(hipGetDevice(&dev));
+    size_t got = std::min<size_t>(bytes, (size_t)16 << 20);
+    char* pin = (char*)block_cache().take(got, dev, true);
+    hipError_t e = hipSuccess;
+    for (size_t off = 0; off < bytes && e == hipSuccess; off += got) {
+        const size_t nb = std::min(got, bytes - off);
+        e = hipMemcpyAsync(pin, (const char*)src + off, nb, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) break;
+        if (nb >= ((size_t)1 << 20))
+            score::parallel_ranges((int64_t)nb, (int64_t)1 << 19, [&](int, int64_t b0, int64_t b1) { std::memcpy((char*)dst + off + b0, pin + b0, (size_t)(b1 - b0)); });
+        else
+            std::memcpy((char*)dst + off, pin, nb);
+    }
+    block_cache().give(pin, got, dev, true);
+    HIP_CHECK(e);
+}
+
+__global__ __launch_bounds__(256) void k_zero16(uint4* __restrict__ p, size_t n16) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = z;
+}
 
 template <class T>
 struct DevBuf {
@@ -357,35 +428,37 @@ struct DevBuf {
         if (h.size() != n || !d) alloc(h.size());
         if (!h.empty()) {
             if (tl_stage && tl_stage->upload(d, h.data(), h.size() * sizeof(T), tl_copy_stream)) return;
-            HIP_CHECK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
-            HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
+            staged_h2d(d, h.data(), h.size() * sizeof(T), tl_copy_stream);
         }
     }
-    // (no synchronisation: the caller waits for the stream before the source goes away)
+    // (staged: the source may go away when the call returns)
     void upload_from(const T* src, size_t count) {
         if (count != n || !d) alloc(count);
         if (count && tl_stage && tl_stage->upload(d, src, count * sizeof(T), tl_copy_stream)) return;
-        if (count) HIP_CHECK(hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
+        if (count) staged_h2d(d, src, count * sizeof(T), tl_copy_stream);
     }
     // upload into an allocation with `pad` extra zeroed elements at the end
     void upload_padded(const std::vector<T>& h, size_t pad) {
         if (h.size() + pad != n || !d) alloc(h.size() + pad);
         HIP_CHECK(hipMemsetAsync(d + h.size(), 0, pad * sizeof(T), tl_copy_stream));
         if (tl_stage && tl_stage->upload(d, h.data(), h.size() * sizeof(T), tl_copy_stream)) return;
-        if (!h.empty())
-            HIP_CHECK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
+        if (!h.empty()) staged_h2d(d, h.data(), h.size() * sizeof(T), tl_copy_stream);
         HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
     }
     // copy into the existing allocation (which may be larger: padded), never re-allocating
     void upload_into(const std::vector<T>& h) {
         if (!d || h.size() > n) throw std::runtime_error("upload_into: buffer too small");
-        if (!h.empty()) {
-            HIP_CHECK(hipMemcpyAsync(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, tl_copy_stream));
-            HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
-        }
+        if (!h.empty()) staged_h2d(d, h.data(), h.size() * sizeof(T), tl_copy_stream);
     }
+    // (a kernel of the library's own for large blocks: hipMemsetAsync took 22-25 ms for the 57 MB iterate block of a
+    //  20 x 5000-pose problem in the first two solves of a handle and 0.03 ms afterwards -- measured, round 5)
     void zero(hipStream_t st) {
-        if (n) HIP_CHECK(hipMemsetAsync(d, 0, n * sizeof(T), st));
+        const size_t bytes = n * sizeof(T);
+        if (bytes >= ((size_t)1 << 20) && bytes % 16 == 0 && ((uintptr_t)d % 16) == 0) {
+            const size_t n16 = bytes / 16;
+            const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, 4096);
+            hipLaunchKernelGGL(k_zero16, dim3(grid), dim3(256), 0, st, (uint4*)d, n16);
+        } else if (n) HIP_CHECK(hipMemsetAsync(d, 0, bytes, st));
     }
     // a window into somebody else's allocation
     void view(T* ptr, size_t count) {
@@ -595,13 +668,16 @@ struct RuizDevice : RuizOffload {
                     // ranges of P's entries go up, the rest of the buffers is never read
                     Pc.alloc((size_t)nnzP); Pv.alloc((size_t)nnzP);
                     const int64_t e0 = p.P_rowptr[rep_n], t0 = p.P_rowptr[(int64_t)rep * rep_n];
+                    auto up = [&](void* dst, const void* src, size_t bytes) {
+                        if (!(tl_stage && tl_stage->upload(dst, src, bytes, st))) staged_h2d(dst, src, bytes, st);
+                    };
                     if (e0 > 0) {
-                        HIP_CHECK(hipMemcpyAsync(Pc.d, p.P_col, (size_t)e0 * sizeof(int32_t), hipMemcpyHostToDevice, st));
-                        HIP_CHECK(hipMemcpyAsync(Pv.d, p.P_val, (size_t)e0 * sizeof(double), hipMemcpyHostToDevice, st));
+                        up(Pc.d, p.P_col, (size_t)e0 * sizeof(int32_t));
+                        up(Pv.d, p.P_val, (size_t)e0 * sizeof(double));
                     }
                     if (nnzP > t0) {
-                        HIP_CHECK(hipMemcpyAsync(Pc.d + t0, p.P_col + t0, (size_t)(nnzP - t0) * sizeof(int32_t), hipMemcpyHostToDevice, st));
-                        HIP_CHECK(hipMemcpyAsync(Pv.d + t0, p.P_val + t0, (size_t)(nnzP - t0) * sizeof(double), hipMemcpyHostToDevice, st));
+                        up(Pc.d + t0, p.P_col + t0, (size_t)(nnzP - t0) * sizeof(int32_t));
+                        up(Pv.d + t0, p.P_val + t0, (size_t)(nnzP - t0) * sizeof(double));
                     }
                 } else {
                     Pc.upload_from(p.P_col, (size_t)nnzP); Pv.upload_from(p.P_val, (size_t)nnzP);
@@ -632,8 +708,8 @@ struct RuizDevice : RuizOffload {
                     hipLaunchKernelGGL(k_ruiz_apply, dim3(ga), dim3(kThreads), 0, st, a);
                 }
                 HIP_CHECK(hipGetLastError());
-                HIP_CHECK(hipMemcpyAsync(D, dD.d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, st));
-                if (m) HIP_CHECK(hipMemcpyAsync(E, dE.d, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, st));
+                staged_d2h(D, dD.d, (size_t)n * sizeof(double), st);
+                if (m) staged_d2h(E, dE.d, (size_t)m * sizeof(double), st);
                 HIP_CHECK(hipStreamSynchronize(st));
             } catch (const std::exception&) {
                 (void)hipStreamSynchronize(st);
@@ -889,7 +965,7 @@ struct HipBackend {
     void copy_up(T* dst, const T* src, size_t count) {  // staged when small, pageable otherwise (returns once the source is consumed)
         if (!count) return;
         if (tl_stage && tl_stage->upload(dst, src, count * sizeof(T), stream)) return;
-        HIP_CHECK(hipMemcpyAsync(dst, src, count * sizeof(T), hipMemcpyHostToDevice, stream));
+        staged_h2d(dst, src, count * sizeof(T), stream);
     }
     // records (key, idx, v0, v1; rec_max of them, the unused tail padded with row n_rows) -> CSR pattern + summed values:
     // stable sort, flags, scan, merge (an entry adds its records in order), row counts -> row pointers.  Everything lands in
@@ -2147,12 +2223,20 @@ struct HipBackend {
 
     DevBuf<double> iter_block;  // xtu | xy | s | r | z | p | p2 | w | kx | step | pw_part | rz_part0/1 | rz_meas0/1
     void reset() {
+        const double t0 = st.verbose ? now_ms() : 0.0;
+        if (st.verbose) HIP_CHECK(hipStreamSynchronize(stream));
+        const double t1 = st.verbose ? now_ms() : 0.0;
         iter_block.zero(stream);
+        const double t2 = st.verbose ? now_ms() : 0.0;
+        if (st.verbose) HIP_CHECK(hipStreamSynchronize(stream));
+        const double t3 = st.verbose ? now_ms() : 0.0;
         if (n_cone_blocks) {
             hipLaunchKernelGGL(k_refresh_u, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xtu.d));
             HIP_CHECK(hipGetLastError());
         }
         HIP_CHECK(hipStreamSynchronize(stream));
+        if (st.verbose) std::fprintf(stderr, "[score] reset: %.3f ms waiting for work queued earlier, fill of %.1f MB: %.3f ms call + %.3f ms wait, refresh %.3f ms\n", t1 - t0,
+                                     (double)iter_block.n * 8e-6, t2 - t1, t3 - t2, now_ms() - t3);
     }
 
     // Launch on the handle's stream.  Inside score_time_iteration (tev != nullptr, slot >= 0) the
@@ -2674,7 +2758,7 @@ struct HipBackend {
         DevBuf<double> Dtmp;
         if (!h.device_setup) {  // (host setup: the scales live on the host)
             Dtmp.alloc((size_t)h.n_tot);
-            e = hipMemcpyAsync(Dtmp.d, h.D.data(), (size_t)h.n_tot * sizeof(double), hipMemcpyHostToDevice, stream);
+            staged_h2d(Dtmp.d, h.D.data(), (size_t)h.n_tot * sizeof(double), stream);
             a.D = Dtmp.d;
         }
         const int64_t nmax = std::max(L.n_pose, std::max(L.n_lm, L.n_rng));
@@ -2694,31 +2778,62 @@ struct HipBackend {
         HIP_CHECK(e); HIP_CHECK(e2);
     }
 
+    // Device -> caller's arrays THROUGH PINNED MEMORY of the library's own.  A hipMemcpy into pageable memory registers the
+    // caller's pages with the driver for the transfer; when the caller later frees them (NumPy arrays of the previous solve,
+    // temporaries of a model construction) the address-space change evicts every queue of the process until the driver has
+    // restored them -- measured, round 5: the first kernel after such a free started 14-37 ms late (20 x 5000 poses: 12 MB of
+    // x, y, s per solve; solves 47 / 46 / 21 / 21 ms), whichever handle or thread it belonged to.
+    void copy_out(const std::vector<std::pair<double*, std::pair<const double*, size_t>>>& parts) {  // {host dst, {device src, count}}
+        size_t total = 0;
+        for (const auto& pt : parts) if (pt.first) total += pt.second.second;
+        if (!total) return;
+        size_t got = total * sizeof(double);
+        double* pin = (double*)block_cache().take(got, st.device, true);
+        size_t off = 0;
+        hipError_t err = hipSuccess;
+        for (const auto& pt : parts)
+            if (pt.first && pt.second.second) {
+                const hipError_t e = hipMemcpyAsync(pin + off, pt.second.first, pt.second.second * sizeof(double), hipMemcpyDeviceToHost, stream);
+                if (e != hipSuccess) err = e;
+                off += pt.second.second;
+            }
+        const hipError_t es = hipStreamSynchronize(stream);
+        if (err == hipSuccess && es == hipSuccess) {
+            std::vector<std::pair<double*, std::pair<const double*, size_t>>> hp;
+            off = 0;
+            for (const auto& pt : parts)
+                if (pt.first && pt.second.second) { hp.push_back({pt.first, {pin + off, pt.second.second}}); off += pt.second.second; }
+            for (const auto& c : hp) {
+                const size_t cnt = c.second.second;
+                parallel_ranges((int64_t)cnt, (int64_t)1 << 17, [&](int, int64_t a, int64_t b) {
+                    std::memcpy(c.first + a, c.second.first + a, (size_t)(b - a) * sizeof(double));
+                });
+            }
+        }
+        block_cache().give(pin, got, st.device, true);
+        HIP_CHECK(err); HIP_CHECK(es);
+    }
     void download(const HostSystem& h, double* x, double* y, double* s_out) {
+        const int64_t n = h.n_tot, m = h.m_tot;
         if (h.device_setup) {  // the scales live on the device: x = xhat D, y = yhat E, s = shat / E there, then one copy each
-            const int64_t n = h.n_tot, m = h.m_tot;
             size_t got = (size_t)(n + 2 * m) * sizeof(double);
             double* ob = (double*)block_cache().take(got, st.device, false);
             hipLaunchKernelGGL(k_unscale, dim3((unsigned)std::max<int64_t>(1, (std::max(n, m) + 255) / 256)), dim3(256), 0, stream, (const double*)xy.d, (const double*)s.d,
                                (const double*)Dd.d, (const double*)Ed.d, ob, n, m);
-            hipError_t e1 = hipSuccess, e2 = hipSuccess, e3 = hipSuccess;
-            if (x) e1 = hipMemcpyAsync(x, ob, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream);
-            if (y && m) e2 = hipMemcpyAsync(y, ob + n, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream);
-            if (s_out && m) e3 = hipMemcpyAsync(s_out, ob + n + m, (size_t)m * sizeof(double), hipMemcpyDeviceToHost, stream);
-            const hipError_t e4 = hipStreamSynchronize(stream);
+            try {
+                copy_out({{x, {ob, (size_t)n}}, {y, {ob + n, (size_t)m}}, {s_out, {ob + n + m, (size_t)m}}});
+            } catch (...) {
+                block_cache().give(ob, got, st.device, false);
+                throw;
+            }
             block_cache().give(ob, got, st.device, false);
-            HIP_CHECK(e1); HIP_CHECK(e2); HIP_CHECK(e3); HIP_CHECK(e4);
             return;
         }
-        HIP_CHECK(hipStreamSynchronize(stream));
-        std::vector<double> hx(h.n_tot + h.m_tot), hs(h.m_tot);
-        HIP_CHECK(hipMemcpyAsync(hx.data(), xy.d, hx.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        if (h.m_tot) HIP_CHECK(hipMemcpyAsync(hs.data(), s.d, hs.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        if (x) for (int64_t i = 0; i < h.n_tot; ++i) x[i] = hx[i] * h.D[i];
-        if (y) for (int64_t i = 0; i < h.m_tot; ++i) y[i] = hx[h.n_tot + i] * h.E[i];
-        if (s_out) for (int64_t i = 0; i < h.m_tot; ++i) s_out[i] = hs[i] / h.E[i];
+        std::vector<double> hx((size_t)(n + m)), hs((size_t)m);
+        copy_out({{hx.data(), {xy.d, hx.size()}}, {m ? hs.data() : nullptr, {s.d, hs.size()}}});
+        if (x) for (int64_t i = 0; i < n; ++i) x[i] = hx[i] * h.D[i];
+        if (y) for (int64_t i = 0; i < m; ++i) y[i] = hx[n + i] * h.E[i];
+        if (s_out) for (int64_t i = 0; i < m; ++i) s_out[i] = hs[i] / h.E[i];
     }
 
     int64_t get_vec(const char* name, double* out, int64_t len) {
@@ -2763,7 +2878,7 @@ struct HipBackend {
             if (out && len > 0) {
                 std::vector<int32_t> tmp((size_t)std::min(len, sz));
                 HIP_CHECK(hipStreamSynchronize(stream));
-                HIP_CHECK(hipMemcpyAsync(tmp.data(), isrc, tmp.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                staged_d2h(tmp.data(), isrc, tmp.size() * sizeof(int32_t), stream);
                 HIP_CHECK(hipStreamSynchronize(stream));
                 for (size_t i = 0; i < tmp.size(); ++i) out[i] = (double)tmp[i];
             }
@@ -2809,13 +2924,13 @@ struct HipBackend {
             if (out && len >= 7) {
                 auto down_i = [&](const int32_t* d, size_t cnt) {
                     std::vector<int32_t> v(cnt);
-                    if (cnt) HIP_CHECK(hipMemcpyAsync(v.data(), d, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                    if (cnt) staged_d2h(v.data(), d, cnt * sizeof(int32_t), stream);
                     HIP_CHECK(hipStreamSynchronize(stream));
                     return v;
                 };
                 auto down_d = [&](const double* d, size_t cnt) {
                     std::vector<double> v(cnt);
-                    if (cnt) HIP_CHECK(hipMemcpyAsync(v.data(), d, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
+                    if (cnt) staged_d2h(v.data(), d, cnt * sizeof(double), stream);
                     HIP_CHECK(hipStreamSynchronize(stream));
                     return v;
                 };
@@ -2847,13 +2962,13 @@ struct HipBackend {
                 build_polish(h, R, false, false);
                 auto down_i = [&](const int32_t* d, size_t cnt) {
                     std::vector<int32_t> v(cnt);
-                    if (cnt) HIP_CHECK(hipMemcpyAsync(v.data(), d, cnt * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+                    if (cnt) staged_d2h(v.data(), d, cnt * sizeof(int32_t), stream);
                     HIP_CHECK(hipStreamSynchronize(stream));
                     return v;
                 };
                 auto down_d = [&](const double* d, size_t cnt) {
                     std::vector<double> v(cnt);
-                    if (cnt) HIP_CHECK(hipMemcpyAsync(v.data(), d, cnt * sizeof(double), hipMemcpyDeviceToHost, stream));
+                    if (cnt) staged_d2h(v.data(), d, cnt * sizeof(double), stream);
                     HIP_CHECK(hipStreamSynchronize(stream));
                     return v;
                 };
@@ -2935,13 +3050,13 @@ struct HipBackend {
             std::vector<double> tmp;
             if (nm == "is_head" && h.device_setup) {  // (made on the device: the host never held it)
                 std::vector<int32_t> ih((size_t)h.n_tot);
-                HIP_CHECK(hipMemcpyAsync(ih.data(), q_ishead.d, sizeof(int32_t) * ih.size(), hipMemcpyDeviceToHost, stream));
+                staged_d2h(ih.data(), q_ishead.d, sizeof(int32_t) * ih.size(), stream);
                 HIP_CHECK(hipStreamSynchronize(stream));
                 tmp.assign(ih.begin(), ih.end());
             } else
             if (nm == "Hcol" && polish_on_device) {  // (built on the device: the host never held it)
                 std::vector<int32_t> hc((size_t)hm_nnz);
-                HIP_CHECK(hipMemcpyAsync(hc.data(), Hm.col.d, sizeof(int32_t) * hc.size(), hipMemcpyDeviceToHost, stream));
+                staged_d2h(hc.data(), Hm.col.d, sizeof(int32_t) * hc.size(), stream);
                 HIP_CHECK(hipStreamSynchronize(stream));
                 tmp.assign(hc.begin(), hc.end());
             }
@@ -2982,8 +3097,7 @@ struct HipBackend {
             if (host) std::memcpy(out, src, bytes);
             else {
                 if (hipStreamSynchronize(stream) != hipSuccess) return -2;
-                if (hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return -2;
-                if (hipStreamSynchronize(stream) != hipSuccess) return -2;
+                try { staged_d2h(out, src, bytes, stream); } catch (const std::exception&) { return -2; }
             }
         }
         return sz;
@@ -3005,11 +3119,10 @@ struct HipBackend {
         linear_buffers(h);
         const size_t n = (size_t)h.n_tot;
         // values -> K0 (K1 = 0)
-        HIP_CHECK(hipMemcpyAsync(K0d.d, h.K0.data(), h.K0.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipMemcpyAsync(lin_rhs.d, rhs, n * sizeof(double), hipMemcpyHostToDevice, stream));
+        staged_h2d(K0d.d, h.K0.data(), h.K0.size() * sizeof(double), stream);
+        staged_h2d(lin_rhs.d, rhs, n * sizeof(double), stream);
         const bool ok = linear_solve_core(h, lin_rhs.d, rel_tol, max_iters, used_out);
-        HIP_CHECK(hipMemcpyAsync(x, xtu.d, n * sizeof(double), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+        staged_d2h(x, xtu.d, n * sizeof(double), stream);
         return ok;
     }
     // K0d holds the values and rhs_dev the right-hand side, both on the device; the solution is left in xtu
@@ -3177,8 +3290,8 @@ struct HipBackend {
             HIP_CHECK(hipGetLastError());
             pt.mark("    polish (device): buffers + launches");
             HIP_CHECK(hipMemcpyAsync(res.data(), result.d, 3 * sizeof(long long), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipMemcpyAsync(Q.Hm.ptr.data(), Hm.ptr.d, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipMemcpyAsync(longs.data(), long_ent.d, (size_t)long_max * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
+            staged_d2h(Q.Hm.ptr.data(), Hm.ptr.d, ((size_t)n + 1) * sizeof(int32_t), stream);
+            staged_d2h(longs.data(), long_ent.d, (size_t)long_max * sizeof(int32_t), stream);
             HIP_CHECK(hipStreamSynchronize(stream));
             pt.mark("    polish (device): kernels + row pointers back");
             } catch (...) {
@@ -3844,7 +3957,7 @@ struct HipBackend {
         std::vector<double> hp(h.n_tot);
         for (int64_t i = 0; i < h.n_tot; ++i) hp[i] = 1.0 + 1e-3 * (double)(i % 7);
         HIP_CHECK(hipStreamSynchronize(stream));
-        HIP_CHECK(hipMemcpyAsync(p.d, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+        staged_h2d(p.d, hp.data(), hp.size() * sizeof(double), stream);
         HIP_CHECK(hipStreamSynchronize(stream));
         std::vector<int32_t> zero(h.count, 0), keep(h.count);
         HIP_CHECK(hipMemcpyAsync(keep.data(), done.d, keep.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
@@ -4011,10 +4124,10 @@ struct score_refine {
             std::copy(poses_in, poses_in + 12 * P.Np, u0.begin());
             if (P.Nl) std::copy(lms_in, lms_in + 3 * P.Nl, u0.begin() + (std::ptrdiff_t)(12 * P.Np));
         }
-        HIP_CHECK(hipMemcpyAsync(u.d, u0.data(), u0.size() * sizeof(double), hipMemcpyHostToDevice, stream()));
+        staged_h2d(u.d, u0.data(), u0.size() * sizeof(double), stream());
         HIP_CHECK(hipStreamSynchronize(stream()));
         score::gn_levenberg_marquardt(*this, max_iters, tol, 1e-9, info);
-        HIP_CHECK(hipMemcpyAsync(u0.data(), u.d, u0.size() * sizeof(double), hipMemcpyDeviceToHost, stream()));
+        staged_d2h(u0.data(), u.d, u0.size() * sizeof(double), stream());
         HIP_CHECK(hipStreamSynchronize(stream()));
         if (P.dim == 2) {
             for (int k = 0; k < 3; ++k) poses_out[k] = poses_in[k];

@@ -313,6 +313,12 @@ def test_device_assembler_equals_the_host_assembler(fixtures, hip_lib, monkeypat
     cases.append(([make_config(3)], "SOCP", {}))
     for k, (graphs, relax, st) in enumerate(cases):
         arrays = [graph_arrays(g) for g in graphs]
+        if relax == "QCQP":
+            # the device assembler's own QCQP program (SCORE_QCQP_PLAIN: without the library's rewrite into private-head cones,
+            # csrc/score_headform.hpp -- with it a QCQP graph handle builds the SOCP program; compared below)
+            monkeypatch.setenv("SCORE_QCQP_PLAIN", "1")
+        else:
+            monkeypatch.delenv("SCORE_QCQP_PLAIN", raising=False)
         dev = ConicSolver.from_graphs(arrays, 0 if relax == "SOCP" else 1, st, lib_path=hip_lib)
         assert dev.debug_get("device_setup")[0] == 1.0
         host = ConicSolver([assemble_native(g, relax, lib_path=hip_lib, arrays=a).qp for g, a in zip(graphs, arrays)], st, lib_path=hip_lib)
@@ -330,6 +336,24 @@ def test_device_assembler_equals_the_host_assembler(fixtures, hip_lib, monkeypat
             assert x.solved and y.solved
             assert np.array_equal(x.x, y.x) and np.array_equal(x.y, y.y) and np.array_equal(x.s, y.s)
             assert x.info["newton_iters"] == y.info["newton_iters"] and x.info["pobj"] == y.info["pobj"]
+        if relax == "QCQP":
+            # by default: the graph handle solves the graph's SOCP program and maps back (headform_from_graph), the array handle
+            # rewrites the QCQP program it is given (headform_reduce) -- the same optimum, x / y / s of the QCQP program from both
+            monkeypatch.delenv("SCORE_QCQP_PLAIN", raising=False)
+            dev = ConicSolver.from_graphs(arrays, 1, {}, lib_path=hip_lib)
+            host = ConicSolver([assemble_native(g, relax, lib_path=hip_lib, arrays=a).qp for g, a in zip(graphs, arrays)], {}, lib_path=hip_lib)
+            assert (dev.n_total, dev.m_total) == (host.n_total, host.m_total)
+            sd, sh = dev.solve(), host.solve()
+            dev.close(); host.close()
+            for x, y, g in zip(sd, sh, graphs):
+                assert x.solved and y.solved and x.info["newton_iters"] > 0 and y.info["newton_iters"] > 0
+                assert x.info["pobj"] == pytest.approx(y.info["pobj"], rel=1e-7, abs=1e-8)
+                T = g.dimension
+                # the cones' duals (zero where a cone is slack; the slacks (1, r) of slack cones follow undetermined landmarks)
+                U, V = x.y.reshape(-1, T + 1), y.y.reshape(-1, T + 1)
+                np.testing.assert_allclose(U, V, atol=1e-5 * max(1.0, np.abs(V).max()))
+                assert np.all(x.s.reshape(-1, T + 1)[:, 0] == 1.0) and np.all(y.s.reshape(-1, T + 1)[:, 0] == 1.0)
+    monkeypatch.delenv("SCORE_QCQP_PLAIN", raising=False)
     # the switch back to the host assembler, and what solve_score makes of either
     fg = graph_by_name("manhattan", fixtures)
     r_dev = solve_score(fg, "SOCP", lib_path=hip_lib)
