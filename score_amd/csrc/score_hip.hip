@@ -1985,7 +1985,7 @@ struct HipBackend {
     JoinArgs join_args(bool newton_set) {
         JoinArgs ja{};
         ja.jc = join_jc.d; ja.items = join_items.d; ja.chains = newton_set ? chainsH.d : chains.d; ja.node_col = node_col.d;
-        ja.sep_col = join_sep_col.d; ja.done = join_zero.d;
+        ja.sep_col = join_sep_col.d; ja.sep_nodes = join_pcol.d; ja.sep_prev = join_pprev.d; ja.done = join_zero.d;
         ja.use_owner = (!newton_set && H->rep > 1) ? 1 : 0;
         ja.W = newton_set ? join_W_H.d : join_W_K.d; ja.n_tot = H->n_tot;
         ja.data = newton_set ? join_data_H.d : join_data_K.d;

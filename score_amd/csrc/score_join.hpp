@@ -32,6 +32,8 @@ struct JoinArgs {
     const ChainDesc* chains;
     const int32_t* node_col;
     const int32_t* sep_col;
+    const int32_t* sep_nodes;  // pseudo-node tables (2 per separator): [b, first of the segment after]; sep_prev: [last of the segment before, b]
+    const int32_t* sep_prev;
     const int32_t* done;
     int use_owner;            // the matrix blocks of a join chain are its owner's (K of a replicated problem)
     // spikes and Schur data
@@ -216,16 +218,21 @@ template <int BS>
 __global__ __launch_bounds__(64) void k_join_solve(JoinArgs a) {
     constexpr int B2 = BS * BS;
     __shared__ double g[kJoinMaxSeps * BS];
+    __shared__ double F[kJoinMaxSeps * 3 * B2];  // Pinv, Lo, Up of every separator: the sequential solve reads LDS only
     const JoinChain jc = a.jc[blockIdx.x];
     if (a.done[jc.prob]) return;  // frozen problem (or a PCG whose gate has fired): the chain kernel wrote nothing either
     const int sep0 = a.use_owner ? a.jc[jc.owner].sep_begin : jc.sep_begin;  // the matrix blocks
     const int t = threadIdx.x;
     const int n_sep = jc.n_seg - 1;
+    for (int e = t; e < n_sep * 3 * B2; e += 64) {
+        const int s = e / (3 * B2);
+        F[e] = a.data[(size_t)(sep0 + s) * 5 * B2 + 2 * B2 + (e - s * 3 * B2)];
+    }
     for (int s = t; s < n_sep; s += 64) {
         const double* __restrict__ D = a.data + (size_t)(sep0 + s) * 5 * B2;
-        const ChainDesc cl = a.chains[jc.first_chain + s], cr = a.chains[jc.first_chain + s + 1];
-        const int last = join_col<BS>(cl, a.node_col, cl.N - 1), first = join_col<BS>(cr, a.node_col, 0);
-        const int b = a.sep_col[jc.sep_begin + s];
+        // (the pseudo-node tables of the position look-up hold the columns: [b | last of the left segment], [first of the right | b])
+        const int sp = jc.sep_begin + s;
+        const int b = a.sep_nodes[2 * sp], last = a.sep_prev[2 * sp], first = a.sep_nodes[2 * sp + 1];
         double yl[BS], yr[BS];
 #pragma unroll
         for (int c = 0; c < BS; ++c) { yl[c] = a.z[last + c]; yr[c] = a.z[first + c]; }
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(64) void k_join_solve(JoinArgs a) {
     __syncthreads();
     if (t == 0) {
         for (int s = 1; s < n_sep; ++s) {
-            const double* __restrict__ Lo = a.data + (size_t)(sep0 + s) * 5 * B2 + 3 * B2;
+            const double* Lo = F + s * 3 * B2 + B2;
             double v[BS];
 #pragma unroll
             for (int r = 0; r < BS; ++r) {
@@ -253,14 +260,15 @@ __global__ __launch_bounds__(64) void k_join_solve(JoinArgs a) {
             for (int r = 0; r < BS; ++r) g[s * BS + r] = v[r];
         }
         for (int s = n_sep - 1; s >= 0; --s) {
-            const double* __restrict__ D = a.data + (size_t)(sep0 + s) * 5 * B2;
+            const double* Pinv = F + s * 3 * B2;
+            const double* Up = Pinv + 2 * B2;
             double v[BS], x[BS];
 #pragma unroll
             for (int r = 0; r < BS; ++r) {
                 double acc = g[s * BS + r];
                 if (s + 1 < n_sep) {
 #pragma unroll
-                    for (int c = 0; c < BS; ++c) acc -= D[4 * B2 + r * BS + c] * g[(s + 1) * BS + c];
+                    for (int c = 0; c < BS; ++c) acc -= Up[r * BS + c] * g[(s + 1) * BS + c];
                 }
                 v[r] = acc;
             }
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(64) void k_join_solve(JoinArgs a) {
             for (int r = 0; r < BS; ++r) {
                 double acc = 0.0;
 #pragma unroll
-                for (int c = 0; c < BS; ++c) acc += D[2 * B2 + r * BS + c] * v[c];
+                for (int c = 0; c < BS; ++c) acc += Pinv[r * BS + c] * v[c];
                 x[r] = acc;
             }
 #pragma unroll

@@ -398,7 +398,7 @@ def test_xcd_aware_tile_order_changes_no_bit(fixtures, hip_lib, monkeypatch):
 
 
 @pytest.mark.parametrize("name,relax", [("manhattan", "SOCP"), ("graph3d", "SOCP"), ("synth_d", "QCQP"), ("synth_b", "SOCP"), ("prior2d", "SOCP")])
-def test_device_setup_against_scipy(name, relax, fixtures, hip_lib):
+def test_device_setup_against_scipy(name, relax, fixtures, hip_lib, monkeypatch):
     """The setup the kernels run on, checked without any of the product's (or the twin's) host code: the scales D, E
     and the stored KKT operator come back from the handle; SciPy rebuilds K = D P D + sigma I + rho (E A D)'(E A D)
     from the problem data alone.  The stored rows (replica 0 of every pose row / landmark coordinate + the tail)
@@ -406,6 +406,7 @@ def test_device_setup_against_scipy(name, relax, fixtures, hip_lib):
     kernels rely on (gurobi_utils.py:504-526: the cost couples one row of [R | t] at a time; :345-352: only the
     cones couple rows, and K sees them through A'A, which is per coordinate)."""
     _hip_only(hip_lib)
+    monkeypatch.setenv("SCORE_QCQP_PLAIN", "1")  # (the QCQP program as given, not its head form: csrc/score_headform.hpp)
     qp = assemble(graph_by_name(name, fixtures), relax).qp
     rho, sigma = 0.37, 1e-6
     sol = ConicSolver(qp, dict(rho=rho, sigma=sigma, adaptive_rho=0), lib_path=hip_lib)
@@ -446,6 +447,7 @@ def test_replicated_kernels_match_the_general_ones(name, relax, rep, fixtures, h
     the full K) and against the CPU twin: every internal vector after k ADMM iterations, in 2-D, 3-D (three
     replicas), for the direct QCQP form (no tail unknowns) and with loop closures."""
     _hip_only(hip_lib)
+    monkeypatch.setenv("SCORE_QCQP_PLAIN", "1")  # (the QCQP program as given -- replicas without a tail --, not its head form)
     qp = assemble(graph_by_name(name, fixtures), relax).qp
     st = dict(adaptive_cg=0, adaptive_rho=0, check_interval=5, fac_fp32=0, polish=0)
     monkeypatch.delenv("SCORE_NO_REPLICATION", raising=False)
