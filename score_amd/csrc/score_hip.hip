@@ -89,13 +89,21 @@ struct BlockCache {
     unsigned long long clock = 0;
     std::mutex mu;
     std::vector<Block> free_blocks;
-    size_t cached = 0;
-    static size_t max_cached_bytes() {  // SCORE_CACHE_MB: cap of the parked bytes (0 = park nothing)
-        static const size_t v = [] {
-            const char* e = std::getenv("SCORE_CACHE_MB");
-            return e ? (size_t)std::max(0L, std::atol(e)) << 20 : (size_t)4 << 30;
+    size_t cached[2] = {0, 0};  // parked bytes: device blocks, pinned host blocks
+    // Caps of the parked bytes, per kind.  Device blocks: an eighth of the device's memory, at most 32 GiB (round 5: the 4 GiB
+    // both kinds shared until then were filled by the handles of one Monte-Carlo sweep -- 8 live handles of 0.3-0.5 GB each in
+    // a dozen size classes -- and every other sweep paid for evictions: hipFree, a device synchronisation, 5-15 ms inside
+    // score_destroy; sweeps of 30 ms became 40-47).  Pinned host blocks: 4 GiB.  SCORE_CACHE_MB: both caps (0 = park nothing).
+    static size_t max_cached_bytes(bool host) {
+        static const long env_mb = [] { const char* e = std::getenv("SCORE_CACHE_MB"); return e ? std::max(0L, std::atol(e)) : -1L; }();
+        if (env_mb >= 0) return (size_t)env_mb << 20;
+        if (host) return (size_t)4 << 30;
+        static const size_t dev_cap = [] {
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return (size_t)4 << 30; }
+            return std::min<size_t>(tot / 8, (size_t)32 << 30);
         }();
-        return v;
+        return dev_cap;
     }
     // size classes: powers of two up to 1 MiB, multiples of 2 MiB above (a 65 MiB request parks 66 MiB, not 128)
     static size_t round_up(size_t b) {
@@ -124,7 +132,7 @@ struct BlockCache {
             if (best != free_blocks.size()) {
                 void* p = free_blocks[best].p;
                 bytes = free_blocks[best].bytes;
-                cached -= bytes;
+                cached[host ? 1 : 0] -= bytes;
                 free_blocks[best] = free_blocks.back();
                 free_blocks.pop_back();
                 return p;
@@ -157,19 +165,21 @@ struct BlockCache {
         bool parked = false;
         {
             std::lock_guard<std::mutex> lk(mu);
-            const size_t cap = max_cached_bytes();
+            const size_t cap = max_cached_bytes(host);
+            size_t& held = cached[host ? 1 : 0];
             if (bytes <= cap) {
-                while (cached + bytes > cap && !free_blocks.empty()) {
-                    size_t oldest = 0;
-                    for (size_t i = 1; i < free_blocks.size(); ++i)
-                        if (free_blocks[i].stamp < free_blocks[oldest].stamp) oldest = i;
+                while (held + bytes > cap) {  // the blocks of this kind parked longest ago make room
+                    size_t oldest = free_blocks.size();
+                    for (size_t i = 0; i < free_blocks.size(); ++i)
+                        if (free_blocks[i].host == host && (oldest == free_blocks.size() || free_blocks[i].stamp < free_blocks[oldest].stamp)) oldest = i;
+                    if (oldest == free_blocks.size()) break;
                     evict.push_back(free_blocks[oldest]);
-                    cached -= free_blocks[oldest].bytes;
+                    held -= free_blocks[oldest].bytes;
                     free_blocks[oldest] = free_blocks.back();
                     free_blocks.pop_back();
                 }
                 free_blocks.push_back(Block{p, bytes, dev, host, ++clock});
-                cached += bytes;
+                held += bytes;
                 parked = true;
             }
         }
@@ -183,8 +193,8 @@ struct BlockCache {
         {
             std::lock_guard<std::mutex> lk(mu);
             all.swap(free_blocks);
-            freed = cached;
-            cached = 0;
+            freed = cached[0] + cached[1];
+            cached[0] = cached[1] = 0;
         }
         for (const Block& b : all) {
             if (b.host) (void)hipHostFree(b.p); else (void)hipFree(b.p);
@@ -310,7 +320,7 @@ struct StageArena {
             size_t k = chunks.empty() ? 0 : at + 1;
             while (k < chunks.size() && chunk_bytes[k] < bytes) ++k;
             if (k >= chunks.size()) {
-                size_t got = std::max(bytes, (size_t)32 << 20);
+                size_t got = std::max(bytes, (size_t)8 << 20);  // (a pinned allocation costs ~0.2 ms per MB when the cache misses)
                 void* p = block_cache().take(got, dev, true);
                 chunks.push_back(p);
                 chunk_bytes.push_back(got);
