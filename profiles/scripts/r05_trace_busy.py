@@ -1,9 +1,11 @@
 """GPU busy fraction and per-kernel time of one window of a rocprofv3 kernel trace (rocpd sqlite output).
-python r05_trace_busy.py results.db [t0_ns t1_ns]"""
+python r05_trace_busy.py results.db [t0_ns t1_ns | last <ms>]"""
 import sqlite3, sys
 con = sqlite3.connect(sys.argv[1]); cur = con.cursor()
 rows = cur.execute("select name, start, end from kernels order by start").fetchall()
-if len(sys.argv) > 3:
+if len(sys.argv) > 3 and sys.argv[2] == "last":  # the last <ms> of the trace (the trace's clock is not the wall clock)
+    t1 = max(r[2] for r in rows); t0 = t1 - int(float(sys.argv[3]) * 1e6)
+elif len(sys.argv) > 3:
     t0, t1 = int(sys.argv[2]), int(sys.argv[3])
 else:
     t0, t1 = rows[0][1], rows[-1][2]
