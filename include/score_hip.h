@@ -252,7 +252,8 @@ int64_t score_debug_get(score_handle* h, const char* name, double* out, int64_t 
 void score_destroy(score_handle* h);
 
 /* Handles come and go at a high rate in Monte-Carlo use, so device blocks, pinned host blocks and streams of
- * destroyed handles are parked in a process-wide cache (at most 4 GiB, SCORE_CACHE_MB overrides) and reused by the
+ * destroyed handles are parked in a process-wide cache (device blocks: at most an eighth of the device memory, 32 GiB at most;
+ * pinned host blocks: at most 4 GiB; SCORE_CACHE_MB overrides both) and reused by the
  * next score_create.  score_trim_caches releases everything parked (live handles are not touched) and returns the
  * bytes freed; the cache also releases itself and retries once when an allocation fails.                        */
 int64_t score_trim_caches(void);
