@@ -306,6 +306,34 @@ int  score_assemble_batch(const score_graph* graphs, int32_t count, score_assemb
 int  score_assembled_view(const score_assembled* a, score_problem* view);
 void score_assembled_free(score_assembled* a);
 
+/* ---------------------------------------------------------------------------
+ * Synthetic Manhattan-world RA-SLAM graphs, generated where they are solved (the batched generator).
+ * The reference's simulation study draws such worlds one at a time in Python (its shipped fixture
+ * examples/manhattan/factor_graph.pickle is one of them; statistics measured in SURVEY 8(d) and restated in
+ * score_amd/csrc/score_generate.hpp: lattice walks with 81 / 9 / 9 / 1 % straight / left / right / back, odometry and range
+ * noise, every robot-beacon and same-timestep robot-robot pair measured with probability p_range).  score_generate_manhattan
+ * makes `count` worlds on the device -- trial t is the world of seed + t whatever the batch (counter-based Philox4x32-10) -- and
+ * hands back their flat arrays: score_generated_graph fills a score_graph view (valid until score_generated_free) that
+ * score_create_from_graphs / score_assemble / score_refine_create take like any other; score_generated_truth the ground
+ * truth (poses: n_robots * n_poses x (x, y, theta); beacons: n_beacons x (x, y); either may be NULL).
+ * ------------------------------------------------------------------------- */
+typedef struct score_manhattan_spec {
+    int32_t  n_robots;      /* 1..64; robot 0's first pose is the pinned one (origin, identity heading) */
+    int32_t  n_poses;       /* poses per robot (>= 2)                       */
+    int32_t  n_beacons;
+    int32_t  side;          /* grid [0, side]^2                             */
+    double   p_range;       /* probability of a range measurement per pair and timestep */
+    double   sigma_t;       /* odometry translation noise (precision 1 / sigma^2) */
+    double   sigma_theta;   /* odometry rotation noise                      */
+    double   sigma_range;   /* range noise; measurements clamped at >= 0    */
+    uint64_t seed;          /* world t of the call: seed + t                */
+} score_manhattan_spec;
+typedef struct score_generated score_generated;
+int  score_generate_manhattan(const score_manhattan_spec* spec, int32_t count, int32_t device, score_generated** out);
+int  score_generated_graph(const score_generated* g, int32_t index, struct score_graph* view);
+int  score_generated_truth(const score_generated* g, int32_t index, double* poses, double* beacons);
+void score_generated_free(score_generated* g);
+
 /* SO(d) rounding of the relaxed rotation blocks: replaces the per-pose
  * round_to_special_orthogonal(...) calls of VariableCollection.get_variable_values
  * (score/utils/gurobi_utils.py:115-125; score/utils/matrix_utils.py:59-79).
@@ -360,7 +388,7 @@ const char* score_backend(void);   /* "hip-gfx950" or "cpu-twin"             */
  * stale stride goes wrong from the second problem on.  Bump SCORE_ABI_VERSION whenever a struct changes;
  * loaders compare (score_amd.solver.load_library does).  History: 1 = rounds 1-2, 2 = score_problem
  * gained rep_d / rep_n, 3 = this function, 4 = score_assemble_batch, 5 = score_create_from_graphs.                                                        */
-#define SCORE_ABI_VERSION 5
+#define SCORE_ABI_VERSION 6
 int32_t score_abi_version(void);   /* SCORE_ABI_VERSION of the library's build, times 1000, plus sizeof(score_problem) */
 
 #ifdef __cplusplus

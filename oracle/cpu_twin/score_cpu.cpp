@@ -25,6 +25,7 @@
 #include "../../score_amd/csrc/score_assemble.hpp"
 #include "../../score_amd/csrc/score_gn.hpp"
 #include "../../score_amd/csrc/score_round.hpp"
+#include "../../score_amd/csrc/score_generate.hpp"
 #include "../../score_amd/csrc/score_polish_host.hpp"  // (layout checks only: band_check_h; the twin has no polish)
 
 namespace {
@@ -544,6 +545,8 @@ struct score_refine {
     }
 };
 
+struct score_generated { score::GeneratedBatch B; };
+
 extern "C" {
 
 void score_default_settings(score_settings* s) { score::default_settings(s); }
@@ -724,6 +727,32 @@ int score_assembled_view(const score_assembled* a, score_problem* view) {
     return 0;
 }
 void score_assembled_free(score_assembled* a) { delete a; }
+// (the generator as host loops: the specification the product's kernels are tested against)
+int score_generate_manhattan(const score_manhattan_spec* spec, int32_t count, int32_t /*device*/, score_generated** out) {
+    try {
+        if (!spec || !out) throw std::runtime_error("null argument");
+        score::GenSpec S{spec->n_robots, spec->n_poses, spec->n_beacons, spec->side, spec->p_range, spec->sigma_t, spec->sigma_theta, spec->sigma_range, spec->seed};
+        auto* g = new score_generated();
+        try { score::generate_manhattan_host(S, count, g->B); } catch (...) { delete g; throw; }
+        *out = g;
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_generated_graph(const score_generated* g, int32_t index, score_graph* view) {
+    try {
+        if (!g || !view) throw std::runtime_error("null argument");
+        g->B.view(index, view);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_generated_truth(const score_generated* g, int32_t index, double* poses, double* beacons) {
+    try {
+        if (!g) throw std::runtime_error("null argument");
+        g->B.truth(index, poses, beacons);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+void score_generated_free(score_generated* g) { delete g; }
 int score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rotations, int32_t* degenerate, int32_t /*device*/) {
     if (dim != 2 && dim != 3) { g_err = "score_round_to_so: dim must be 2 or 3"; return -1; }
     if (n < 0 || (n > 0 && (!blocks || !rotations || !degenerate))) { g_err = "score_round_to_so: null argument"; return -1; }

@@ -38,6 +38,7 @@
 #include "score_setup_device.hpp"
 #include "score_prec_wave.hpp"
 #include "score_join.hpp"
+#include "score_generate.hpp"
 
 namespace {
 
@@ -4437,6 +4438,108 @@ void score_refine_destroy(score_refine* r) {
     delete r;
     if (prev >= 0) (void)hipSetDevice(prev);
 }
+}  // extern "C"
+
+struct score_generated { score::GeneratedBatch B; };
+namespace {
+// The generator on the device: walks + beacons (one thread per robot / beacon), the ranges counted per (trial, group, time),
+// scanned, filled; the arrays come back through pinned staging (the host lays out the handles from them:
+// score_create_from_graphs takes the views like any other score_graph).
+void generate_manhattan_device(const score::GenSpec& S, int count, int device, score::GeneratedBatch& B) {
+    using namespace score;
+    gen_check_spec(S, count);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available (the SCORE solver has no CPU fallback)");
+    if (device < 0 || device >= ndev) throw std::runtime_error("score_generate_manhattan: device out of range");
+    DeviceGuard guard(device);
+    B = GeneratedBatch();
+    B.S = S; B.count = count;
+    B.size_fixed();
+    const size_t R = (size_t)S.n_robots, T = (size_t)S.n_poses, E = (size_t)B.edges(), c = (size_t)count, G = (size_t)gen_groups(S), nb = (size_t)S.n_beacons;
+    hipStream_t st = stream_pool().take(device);
+    DevArena arena;
+    arena.dev = device;
+    struct Scope {
+        DevArena* keep_a; hipStream_t keep_s;
+        Scope(DevArena* a, hipStream_t s) : keep_a(tl_arena), keep_s(tl_copy_stream) { tl_arena = a; tl_copy_stream = s; }
+        ~Scope() { tl_arena = keep_a; tl_copy_stream = keep_s; }
+    } scope(&arena, st);
+    try {
+        DevBuf<int32_t> px, py, ph, bx, by, rel_base, rel_to, cnt, off, ra, rb;
+        DevBuf<double> rel_t, rel_R, rel_kappa, rel_tau, dist, prec;
+        px.alloc(c * R * T); py.alloc(c * R * T); ph.alloc(c * R * T); bx.alloc(c * nb); by.alloc(c * nb);
+        rel_base.alloc(c * E); rel_to.alloc(c * E); rel_t.alloc(2 * c * E); rel_R.alloc(4 * c * E); rel_kappa.alloc(c * E); rel_tau.alloc(c * E);
+        const size_t n_cnt = c * G * T;
+        cnt.alloc(n_cnt + 1); off.alloc(n_cnt + 1);
+        GenArgs a{};
+        a.S = S; a.count = count;
+        a.px = px.d; a.py = py.d; a.ph = ph.d; a.bx = bx.d; a.by = by.d;
+        a.rel_base = rel_base.d; a.rel_to = rel_to.d; a.rel_t = rel_t.d; a.rel_R = rel_R.d; a.rel_kappa = rel_kappa.d; a.rel_tau = rel_tau.d;
+        a.cnt = cnt.d; a.off = off.d;
+        const size_t n_walk = std::max(c * R, c * nb);
+        hipLaunchKernelGGL(k_gen_walk, dim3((unsigned)((n_walk + 63) / 64)), dim3(64), 0, st, a);
+        HIP_CHECK(hipMemsetAsync(cnt.d + n_cnt, 0, sizeof(int32_t), st));
+        hipLaunchKernelGGL(k_gen_ranges<false>, dim3((unsigned)((n_cnt + 255) / 256)), dim3(256), 0, st, a);
+        size_t tb = 0;
+        HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, cnt.d, off.d, (int32_t)0, n_cnt + 1, rocprim::plus<int32_t>(), st));
+        DevBuf<unsigned char> scratch;
+        scratch.alloc(tb + 256);
+        HIP_CHECK(rocprim::exclusive_scan((void*)scratch.d, tb, cnt.d, off.d, (int32_t)0, n_cnt + 1, rocprim::plus<int32_t>(), st));
+        HIP_CHECK(hipGetLastError());
+        // the trials' first ranges + the total: every (G T)-th entry of the scan
+        std::vector<int32_t> offs(n_cnt + 1);
+        staged_d2h(offs.data(), off.d, (n_cnt + 1) * sizeof(int32_t), st);
+        for (size_t t = 0; t <= c; ++t) B.rng_first[t] = offs[t * G * T];
+        const size_t total = (size_t)B.rng_first[c];
+        B.size_ranges((int64_t)total);
+        ra.alloc(total); rb.alloc(total); dist.alloc(total); prec.alloc(total);
+        a.ra = ra.d; a.rb = rb.d; a.dist = dist.d; a.prec = prec.d;
+        hipLaunchKernelGGL(k_gen_ranges<true>, dim3((unsigned)((n_cnt + 255) / 256)), dim3(256), 0, st, a);
+        HIP_CHECK(hipGetLastError());
+        auto back = [&](auto& dst, const auto& src) { if (!dst.empty()) staged_d2h(dst.data(), src.d, dst.size() * sizeof(dst[0]), st); };
+        back(B.px, px); back(B.py, py); back(B.ph, ph); back(B.bx, bx); back(B.by, by);
+        back(B.rel_base, rel_base); back(B.rel_to, rel_to); back(B.rel_t, rel_t); back(B.rel_R, rel_R); back(B.rel_kappa, rel_kappa); back(B.rel_tau, rel_tau);
+        back(B.ra, ra); back(B.rb, rb); back(B.dist, dist); back(B.prec, prec);
+        // (a trial's range endpoints are trial-local already: pose r * T + t, landmark Np + b)
+        HIP_CHECK(hipStreamSynchronize(st));
+    } catch (...) {
+        (void)hipStreamSynchronize(st);
+        stream_pool().give(device, st);
+        throw;
+    }
+    stream_pool().give(device, st);
+}
+}  // namespace
+
+extern "C" {
+int score_generate_manhattan(const score_manhattan_spec* spec, int32_t count, int32_t device, score_generated** out) {
+    try {
+        if (!spec || !out) throw std::runtime_error("null argument");
+        score::GenSpec S{spec->n_robots, spec->n_poses, spec->n_beacons, spec->side, spec->p_range, spec->sigma_t, spec->sigma_theta, spec->sigma_range, spec->seed};
+        auto* g = new score_generated();
+        try { generate_manhattan_device(S, count, device, g->B); } catch (...) { delete g; throw; }
+        *out = g;
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_generated_graph(const score_generated* g, int32_t index, score_graph* view) {
+    try {
+        if (!g || !view) throw std::runtime_error("null argument");
+        g->B.view(index, view);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+int score_generated_truth(const score_generated* g, int32_t index, double* poses, double* beacons) {
+    try {
+        if (!g) throw std::runtime_error("null argument");
+        g->B.truth(index, poses, beacons);
+        return 0;
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
+void score_generated_free(score_generated* g) { delete g; }
+}  // extern "C"
+
+extern "C" {
 int score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rotations, int32_t* degenerate, int32_t device) {
     try {
         if (dim != 2 && dim != 3) throw std::runtime_error("score_round_to_so: dim must be 2 or 3");

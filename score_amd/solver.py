@@ -82,9 +82,10 @@ ABI_SYMBOLS = [
     "score_default_settings", "score_create", "score_create_batch", "score_create_from_graphs", "score_read_estimates", "score_graphs_connected", "score_dims", "score_solve",
     "score_reset", "score_solve_steps", "score_newton_steps", "score_linear_create", "score_linear_solve", "score_refine_create", "score_refine_run", "score_refine_destroy", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
     "score_trim_caches", "score_last_error", "score_backend", "score_abi_version",
+    "score_generate_manhattan", "score_generated_graph", "score_generated_truth", "score_generated_free",
 ]
 
-ABI_VERSION = 5  # SCORE_ABI_VERSION of include/score_hip.h this binding's structs follow
+ABI_VERSION = 6  # SCORE_ABI_VERSION of include/score_hip.h this binding's structs follow
 
 
 def load_library(path: Optional[str] = None) -> C.CDLL:

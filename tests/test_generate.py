@@ -1,0 +1,111 @@
+"""The batched generator of synthetic Manhattan-world graphs (csrc/score_generate.hpp).
+
+CPU: the host loops of the CPU twin -- the generator's specification -- against the statistics SURVEY 8(d) measured from
+the reference's shipped fixture (examples/manhattan/factor_graph.pickle: 4 x 400 poses, 6 beacons, 1 160 ranges), the
+structural rules of the walk, and the solver.  GPU: the device kernels against those host loops (integers bit for bit,
+reals to the rounding of the math library) and through the product path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from score_amd.generate import GeneratedBatch, ManhattanSpec, generate_manhattan
+from score_amd.solve_score import solve_score, solve_score_batch
+
+
+def test_generated_worlds_have_the_fixtures_statistics(twin_lib):
+    R, T, Nb, side, p = 4, 400, 6, 20, 0.10
+    count = 24
+    B = GeneratedBatch(count, seed=7000, n_robots=R, n_poses=T, n_beacons=Nb, side=side, p_range=p, lib_path=twin_lib)
+    dturn, n_rb, n_rr, odo_t, odo_th, rng_err = [], 0, 0, [], [], []
+    for i in range(count):
+        a = B.arrays(i)
+        poses, beacons = B.truth(i)
+        xy = poses[:, :2].reshape(R, T, 2)
+        hd = (np.round(poses[:, 2] / (np.pi / 2)).astype(int) % 4).reshape(R, T)
+        assert np.array_equal(xy[0, 0], [0.0, 0.0]) and hd[0, 0] == 0  # the pinned pose
+        assert xy.min() >= 0 and xy.max() <= side and beacons.min() >= 0 and beacons.max() <= side
+        step = xy[:, 1:] - xy[:, :-1]
+        dirs = np.array([[1, 0], [0, 1], [-1, 0], [0, -1]], dtype=float)
+        assert np.array_equal(step, dirs[hd[:, :-1]])  # unit steps along the heading of the pose they leave
+        dturn.append(((hd[:, 1:] - hd[:, :-1]) % 4).ravel())
+        # measurements: odometry chain by chain, indices as score_graph wants them
+        assert np.array_equal(a["rel_base"], np.concatenate([r * T + np.arange(T - 1) for r in range(R)]))
+        assert np.array_equal(a["rel_to"], a["rel_base"] + 1)
+        assert np.all(a["rel_kappa"] == 1e4) and np.allclose(a["rel_tau"], 2.5e5)
+        th = np.arctan2(a["rel_R"][:, 1, 0], a["rel_R"][:, 0, 0])
+        true_dth = (((hd[:, 1:] - hd[:, :-1] + 1) % 4 - 1) * (np.pi / 2)).ravel()
+        odo_th.append(np.arctan2(np.sin(th - true_dth), np.cos(th - true_dth)))
+        odo_t.append(a["rel_t"] - np.array([1.0, 0.0]))
+        np.testing.assert_allclose(a["rel_R"][:, 0, 0], a["rel_R"][:, 1, 1]); np.testing.assert_allclose(a["rel_R"][:, 0, 1], -a["rel_R"][:, 1, 0])
+        # ranges: robot by robot against the beacons (time-major), then the robot pairs at equal timesteps
+        ra, rb = a["rng_a"], a["rng_b"]
+        is_rb = rb >= R * T
+        n_rb += int(is_rb.sum()); n_rr += int((~is_rb).sum())
+        assert np.all(np.diff(is_rb.astype(int)) <= 0)  # all robot-beacon measurements first
+        assert np.all(ra[~is_rb] % T == rb[~is_rb] % T) and np.all(ra[~is_rb] // T < rb[~is_rb] // T)
+        pts = np.concatenate([xy.reshape(-1, 2), beacons])
+        true = np.linalg.norm(pts[ra] - pts[rb], axis=1)
+        assert np.all(a["rng_dist"] >= 0.0) and np.all(a["rng_prec"] == 1.0)
+        keep = a["rng_dist"] > 0.0
+        rng_err.append((a["rng_dist"] - true)[keep & (true > 4.0)])  # (away from the clamp)
+        assert len({tuple(k) for k in a["range_keys"]}) == len(ra)  # no duplicate keys
+    d = np.concatenate(dturn)
+    left_right, back = ((d == 1) | (d == 3)).mean(), (d == 2).mean()
+    assert 0.17 <= left_right <= 0.22 and 0.005 <= back <= 0.03, (left_right, back)  # ~18 % turns, ~1 % U-turns (+ the walls)
+    exp_rb, exp_rr = count * R * T * Nb * p, count * (R * (R - 1) // 2) * T * p
+    assert abs(n_rb - exp_rb) < 4 * np.sqrt(exp_rb) and abs(n_rr - exp_rr) < 4 * np.sqrt(exp_rr), (n_rb, exp_rb, n_rr, exp_rr)
+    ot, oth, re_ = np.concatenate(odo_t), np.concatenate(odo_th), np.concatenate(rng_err)
+    assert abs(ot.std() - 0.01) < 3e-4 and abs(ot.mean()) < 2e-4 and abs(oth.std() - 0.002) < 6e-5
+    assert abs(re_.std() - 1.0) < 0.02 and abs(re_.mean()) < 0.02
+    # world t of a batch is the world of seed + t, whatever the batch
+    one = GeneratedBatch(1, seed=7005, n_robots=R, n_poses=T, n_beacons=Nb, side=side, p_range=p, lib_path=twin_lib)
+    a5, b0 = B.arrays(5), one.arrays(0)
+    for k in ("rel_t", "rel_R", "rng_a", "rng_b", "rng_dist"):
+        assert np.array_equal(a5[k], b0[k])
+    assert not np.array_equal(B.arrays(4)["rng_dist"][:50], a5["rng_dist"][:50])
+
+
+def test_generated_worlds_solve_and_errors(twin_lib):
+    graphs = generate_manhattan(3, seed=11, n_robots=2, n_poses=60, n_beacons=3, p_range=0.4, lib_path=twin_lib)
+    B = graphs[0].arrays["_owner"]
+    res = solve_score_batch(graphs, "SOCP", lib_path=twin_lib)
+    assert all(r.solved for r in res)
+    poses, _ = B.truth(1)
+    est = np.array([res[1].poses[f"A{i}"][:2, 2] for i in range(60)])
+    assert np.abs(est - poses[:60, :2]).max() < 1.0  # the pinned robot's trajectory: odometry noise of 1 cm per step
+    assert res[1].pose_chain_names[1][3] == "B3" and set(res[1].landmarks) == {"L0", "L1", "L2"}
+    rq = solve_score(graphs[2], lib_path=twin_lib)  # the reference's default relaxation
+    assert rq.solved and len(rq.distances) == graphs[2].num_ranges
+    with pytest.raises(ValueError, match="robots"):
+        GeneratedBatch(1, n_robots=0, lib_path=twin_lib)
+    with pytest.raises(ValueError, match="p_range"):
+        GeneratedBatch(1, p_range=1.5, lib_path=twin_lib)
+    with pytest.raises(IndexError):
+        B.arrays(3)
+    assert C.sizeof(ManhattanSpec) == 56
+
+
+@pytest.mark.gpu
+def test_device_generator_equals_the_host_loops(hip_lib, twin_lib):
+    """The kernels (one thread per robot walk / per (trial, group, timestep) of the ranges, a scan in between) against the host
+    loops of the twin: every integer (positions, headings, beacons, endpoints, counts) bit for bit, every real to a few ulps of
+    the math libraries (sin, cos, log, sqrt, atan2 of device and host); BASELINE configs[4]'s shape and an odd one."""
+    for spec in (dict(n_robots=4, n_poses=1000, n_beacons=4), dict(n_robots=7, n_poses=129, n_beacons=9, side=11, p_range=0.33, sigma_range=0.5)):
+        dev = GeneratedBatch(5, seed=4000, lib_path=hip_lib, **spec)
+        ref = GeneratedBatch(5, seed=4000, lib_path=twin_lib, **spec)
+        for i in range(5):
+            a, b = dev.arrays(i), ref.arrays(i)
+            for k in ("rel_base", "rel_to", "rng_a", "rng_b", "chain_len"):
+                assert np.array_equal(a[k], b[k]), (spec, i, k)
+            for k in ("rel_t", "rel_R", "rel_kappa", "rel_tau", "rng_dist", "rng_prec"):
+                np.testing.assert_allclose(a[k], b[k], rtol=0, atol=1e-12, err_msg=f"{spec} {i} {k}")
+            (pa, ba), (pb, bb) = dev.truth(i), ref.truth(i)
+            assert np.array_equal(pa[:, :2], pb[:, :2]) and np.array_equal(ba, bb)
+            np.testing.assert_allclose(pa[:, 2], pb[:, 2], atol=1e-15)
+    # through the product: generated on the device, model + setup + solve + estimates on the device
+    graphs = generate_manhattan(8, seed=4000, n_robots=4, n_poses=1000, n_beacons=4, lib_path=hip_lib)
+    res = solve_score_batch(graphs, "SOCP")
+    assert all(r.solved and r.info["newton_iters"] > 0 for r in res)
+    again = solve_score(graphs[3], "SOCP")
+    assert again.info["pobj"] == pytest.approx(res[3].info["pobj"], rel=1e-9)
