@@ -114,34 +114,34 @@ SCORE_GEN_HD inline int gen_next_heading(const GenSpec& S, uint64_t key, int r, 
 }
 SCORE_GEN_HD inline double gen_wrap(double th) { return std::atan2(std::sin(th), std::cos(th)); }
 
-// The walk of robot r of the world `key`: true poses (x, y, heading index) and its n_poses - 1 odometry measurements.
-// rel_* point at the robot's first edge; pose0 = index of the robot's first pose.
-SCORE_GEN_HD inline void gen_robot(const GenSpec& S, uint64_t key, int r, int32_t pose0, int32_t* px, int32_t* py, int32_t* ph,
-                               int32_t* rel_base, int32_t* rel_to, double* rel_t, double* rel_R, double* rel_kappa, double* rel_tau) {
+// The walk of robot r of the world `key`: true poses (x, y, heading index).  Sequential in the steps (the next heading depends on
+// where the robot stands); everything else about a world is independent per item.
+SCORE_GEN_HD inline void gen_walk(const GenSpec& S, uint64_t key, int r, int32_t* px, int32_t* py, int32_t* ph) {
     int x, y, h;
     gen_start(S, key, r, x, y, h);
     px[0] = x; py[0] = y; ph[0] = h;
-    const double kappa = 1.0 / (S.sigma_t * S.sigma_t), tau = 1.0 / (S.sigma_theta * S.sigma_theta);
     for (int i = 1; i < S.n_poses; ++i) {
         int dx, dy;
         gen_dir(h, dx, dy);
         x += dx; y += dy;
-        const int hn = gen_next_heading(S, key, r, i, x, y, h);
-        px[i] = x; py[i] = y; ph[i] = hn;
-        // odometry edge i - 1 -> i: a unit step forward in the base frame, then the turn
-        const int e = i - 1;
-        const double dth = (double)(((hn - h + 1) & 3) - 1) * 1.5707963267948966192313216916398;
-        double n0, n1, n2, n3;
-        gen_normal2(philox4x32_10(key, GEN_ODOM_A, (uint32_t)r, (uint32_t)e, 0), n0, n1);
-        gen_normal2(philox4x32_10(key, GEN_ODOM_B, (uint32_t)r, (uint32_t)e, 0), n2, n3);
-        const double th = gen_wrap(dth + S.sigma_theta * n2);
-        const double c = std::cos(th), s = std::sin(th);
-        rel_base[e] = pose0 + e; rel_to[e] = pose0 + e + 1;
-        rel_t[2 * e] = 1.0 + S.sigma_t * n0; rel_t[2 * e + 1] = S.sigma_t * n1;
-        rel_R[4 * e] = c; rel_R[4 * e + 1] = -s; rel_R[4 * e + 2] = s; rel_R[4 * e + 3] = c;
-        rel_kappa[e] = kappa; rel_tau[e] = tau;
-        h = hn;
+        h = gen_next_heading(S, key, r, i, x, y, h);
+        px[i] = x; py[i] = y; ph[i] = h;
     }
+}
+// Odometry edge e of robot r (pose e -> e + 1): a unit step forward in the base frame, then the turn, with noise.
+// rel_* point at the edge's slots; pose0 = index of the robot's first pose; h, hn: headings at the two poses.
+SCORE_GEN_HD inline void gen_odom(const GenSpec& S, uint64_t key, int r, int e, int32_t pose0, int h, int hn, int32_t* rel_base, int32_t* rel_to,
+                                  double* rel_t, double* rel_R, double* rel_kappa, double* rel_tau) {
+    const double dth = (double)(((hn - h + 1) & 3) - 1) * 1.5707963267948966192313216916398;
+    double n0, n1, n2, n3;
+    gen_normal2(philox4x32_10(key, GEN_ODOM_A, (uint32_t)r, (uint32_t)e, 0), n0, n1);
+    gen_normal2(philox4x32_10(key, GEN_ODOM_B, (uint32_t)r, (uint32_t)e, 0), n2, n3);
+    const double th = gen_wrap(dth + S.sigma_theta * n2);
+    const double c = std::cos(th), s = std::sin(th);
+    rel_base[0] = pose0 + e; rel_to[0] = pose0 + e + 1;
+    rel_t[0] = 1.0 + S.sigma_t * n0; rel_t[1] = S.sigma_t * n1;
+    rel_R[0] = c; rel_R[1] = -s; rel_R[2] = s; rel_R[3] = c;
+    rel_kappa[0] = 1.0 / (S.sigma_t * S.sigma_t); rel_tau[0] = 1.0 / (S.sigma_theta * S.sigma_theta);
 }
 SCORE_GEN_HD inline void gen_beacon(const GenSpec& S, uint64_t key, int b, int32_t& x, int32_t& y) {
     const Philox4 p = philox4x32_10(key, GEN_BEACON, (uint32_t)b, 0, 0);
@@ -211,14 +211,35 @@ inline void gen_check_spec(const GenSpec& S, int count) {
         throw std::runtime_error("score_generate_manhattan: batch too large");
 }
 
+// (storage that is NOT zero-filled when sized: every element is written by the generator; a std::vector's resize touches
+//  22 MB for 64 worlds of 4 x 1000 poses before the first useful byte arrives)
+template <class T>
+struct RawVec {
+    T* p = nullptr;
+    size_t n = 0;
+    RawVec() = default;
+    RawVec(const RawVec&) = delete;
+    RawVec& operator=(const RawVec&) = delete;
+    RawVec(RawVec&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    RawVec& operator=(RawVec&& o) noexcept { if (this != &o) { delete[] p; p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~RawVec() { delete[] p; }
+    void resize(size_t count) { delete[] p; p = count ? new T[count] : nullptr; n = count; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+};
+
 // A generated batch on the host: the flat arrays of `count` score_graph structs (trial after trial) + the ground truth.
 struct GeneratedBatch {
     GenSpec S{};
     int32_t count = 0;
     std::vector<int32_t> chain_len;                       // n_robots entries (shared by every trial)
-    std::vector<int32_t> px, py, ph, bx, by;              // truth: lattice positions, heading indices, beacons
-    std::vector<int32_t> rel_base, rel_to, ra, rb;
-    std::vector<double> rel_t, rel_R, rel_kappa, rel_tau, dist, prec;
+    RawVec<int32_t> px, py, ph, bx, by;                   // truth: lattice positions, heading indices, beacons
+    RawVec<int32_t> rel_base, rel_to, ra, rb;
+    RawVec<double> rel_t, rel_R, rel_kappa, rel_tau, dist, prec;
     std::vector<int64_t> rng_first;                       // count + 1: a trial's ranges in ra / rb / dist / prec
     int64_t edges() const { return (int64_t)S.n_robots * (S.n_poses - 1); }
     void size_fixed() {
@@ -267,8 +288,10 @@ inline void generate_manhattan_host(const GenSpec& S, int count, GeneratedBatch&
         const uint64_t key = S.seed + (uint64_t)trial;
         for (int r = 0; r < R; ++r) {
             const size_t po = ((size_t)trial * R + r) * T, eo = (size_t)trial * E + (size_t)r * (T - 1);
-            gen_robot(S, key, r, r * T, &B.px[po], &B.py[po], &B.ph[po], &B.rel_base[eo], &B.rel_to[eo], &B.rel_t[2 * eo], &B.rel_R[4 * eo],
-                      &B.rel_kappa[eo], &B.rel_tau[eo]);
+            gen_walk(S, key, r, &B.px[po], &B.py[po], &B.ph[po]);
+            for (int e = 0; e + 1 < T; ++e)
+                gen_odom(S, key, r, e, r * T, B.ph[po + e], B.ph[po + e + 1], &B.rel_base[eo + e], &B.rel_to[eo + e], &B.rel_t[2 * (eo + e)],
+                         &B.rel_R[4 * (eo + e)], &B.rel_kappa[eo + e], &B.rel_tau[eo + e]);
         }
         for (int b = 0; b < S.n_beacons; ++b) gen_beacon(S, key, b, B.bx[(size_t)trial * S.n_beacons + b], B.by[(size_t)trial * S.n_beacons + b]);
     }
@@ -320,16 +343,27 @@ __global__ __launch_bounds__(64) void k_gen_walk(GenArgs a) {
     const int R = a.S.n_robots, T = a.S.n_poses;
     if (i < a.count * R) {
         const int trial = i / R, r = i - trial * R;
-        const uint64_t key = a.S.seed + (uint64_t)trial;
-        const size_t po = ((size_t)trial * R + r) * T, eo = (size_t)trial * R * (T - 1) + (size_t)r * (T - 1);
-        gen_robot(a.S, key, r, r * T, a.px + po, a.py + po, a.ph + po, a.rel_base + eo, a.rel_to + eo, a.rel_t + 2 * eo, a.rel_R + 4 * eo,
-                  a.rel_kappa + eo, a.rel_tau + eo);
+        const size_t po = ((size_t)trial * R + r) * T;
+        gen_walk(a.S, a.S.seed + (uint64_t)trial, r, a.px + po, a.py + po, a.ph + po);
     }
     const int nb = a.count * a.S.n_beacons;
     if (i < nb) {
         const int trial = i / a.S.n_beacons, b = i - trial * a.S.n_beacons;
         gen_beacon(a.S, a.S.seed + (uint64_t)trial, b, a.bx[i], a.by[i]);
     }
+}
+// one thread per odometry edge (after the walks)
+__global__ __launch_bounds__(256) void k_gen_odom(GenArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int R = a.S.n_robots, T = a.S.n_poses;
+    const int64_t E = (int64_t)R * (T - 1);
+    if (i >= a.count * E) return;
+    const int trial = (int)(i / E);
+    const int rem = (int)(i - trial * E);
+    const int r = rem / (T - 1), e = rem - r * (T - 1);
+    const size_t po = ((size_t)trial * R + r) * T;
+    gen_odom(a.S, a.S.seed + (uint64_t)trial, r, e, r * T, a.ph[po + e], a.ph[po + e + 1], a.rel_base + i, a.rel_to + i, a.rel_t + 2 * i, a.rel_R + 4 * i,
+             a.rel_kappa + i, a.rel_tau + i);
 }
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_gen_ranges(GenArgs a) {

@@ -4478,6 +4478,7 @@ void generate_manhattan_device(const score::GenSpec& S, int count, int device, s
         a.cnt = cnt.d; a.off = off.d;
         const size_t n_walk = std::max(c * R, c * nb);
         hipLaunchKernelGGL(k_gen_walk, dim3((unsigned)((n_walk + 63) / 64)), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(k_gen_odom, dim3((unsigned)((c * E + 255) / 256)), dim3(256), 0, st, a);
         HIP_CHECK(hipMemsetAsync(cnt.d + n_cnt, 0, sizeof(int32_t), st));
         hipLaunchKernelGGL(k_gen_ranges<false>, dim3((unsigned)((n_cnt + 255) / 256)), dim3(256), 0, st, a);
         size_t tb = 0;
@@ -4496,12 +4497,34 @@ void generate_manhattan_device(const score::GenSpec& S, int count, int device, s
         a.ra = ra.d; a.rb = rb.d; a.dist = dist.d; a.prec = prec.d;
         hipLaunchKernelGGL(k_gen_ranges<true>, dim3((unsigned)((n_cnt + 255) / 256)), dim3(256), 0, st, a);
         HIP_CHECK(hipGetLastError());
-        auto back = [&](auto& dst, const auto& src) { if (!dst.empty()) staged_d2h(dst.data(), src.d, dst.size() * sizeof(dst[0]), st); };
+        // every array into ONE pinned block (all transfers queued, one wait), then out to the batch's vectors by the thread team
+        struct Part { void* dst; const void* src; size_t bytes, off; };
+        std::vector<Part> parts;
+        size_t tot_bytes = 0;
+        auto back = [&](auto& dst, const auto& src) {
+            if (dst.empty()) return;
+            const size_t nbytes = dst.size() * sizeof(dst[0]);
+            parts.push_back(Part{dst.data(), src.d, nbytes, tot_bytes});
+            tot_bytes += (nbytes + 255) & ~(size_t)255;
+        };
         back(B.px, px); back(B.py, py); back(B.ph, ph); back(B.bx, bx); back(B.by, by);
         back(B.rel_base, rel_base); back(B.rel_to, rel_to); back(B.rel_t, rel_t); back(B.rel_R, rel_R); back(B.rel_kappa, rel_kappa); back(B.rel_tau, rel_tau);
         back(B.ra, ra); back(B.rb, rb); back(B.dist, dist); back(B.prec, prec);
         // (a trial's range endpoints are trial-local already: pose r * T + t, landmark Np + b)
-        HIP_CHECK(hipStreamSynchronize(st));
+        size_t got = std::max<size_t>(tot_bytes, 256);
+        char* pin = (char*)block_cache().take(got, device, true);
+        hipError_t err = hipSuccess;
+        for (const Part& pt : parts) {
+            const hipError_t e1 = hipMemcpyAsync(pin + pt.off, pt.src, pt.bytes, hipMemcpyDeviceToHost, st);
+            if (e1 != hipSuccess) err = e1;
+        }
+        const hipError_t es = hipStreamSynchronize(st);
+        if (err == hipSuccess && es == hipSuccess)
+            parallel_ranges((int64_t)parts.size(), 1, [&](int, int64_t p0, int64_t p1) {
+                for (int64_t k = p0; k < p1; ++k) std::memcpy(parts[(size_t)k].dst, pin + parts[(size_t)k].off, parts[(size_t)k].bytes);
+            });
+        block_cache().give(pin, got, device, true);
+        HIP_CHECK(err); HIP_CHECK(es);
     } catch (...) {
         (void)hipStreamSynchronize(st);
         stream_pool().give(device, st);
