@@ -657,6 +657,22 @@ def test_segmented_long_chains_equal_the_streaming_solve(case, hip_lib, twin_lib
         assert a.info["pobj"] == pytest.approx(b.info["pobj"], rel=1e-8, abs=1e-8)
         cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, a.x, a.y, a.s)
         assert cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4, cert
+    if case == "2d":
+        # the linear mode (Gauss-Newton / LM refinement after SCORE: score_linear_solve on the pose chains) takes the same path
+        from score_amd.refine import refine_estimate
+
+        res = solve_score(graphs[0], "SOCP")
+        ref = {}
+        for name, env in (("seg", None), ("stream", "1")):
+            if env:
+                monkeypatch.setenv("SCORE_NO_SEGMENTS", env)
+            else:
+                monkeypatch.delenv("SCORE_NO_SEGMENTS", raising=False)
+            ref[name] = refine_estimate(graphs[0], res)
+        monkeypatch.delenv("SCORE_NO_SEGMENTS", raising=False)
+        (ra, ia), (rb, ib) = ref["seg"], ref["stream"]
+        assert ia["iterations"] == ib["iterations"] and ia["cost_final"] == pytest.approx(ib["cost_final"], rel=1e-10)
+        assert max(np.abs(ra.poses[k] - rb.poses[k]).max() for k in ra.poses) < 1e-9
 
 
 @pytest.mark.parametrize("index", [1, 2, 3])
