@@ -58,6 +58,25 @@ def test_generated_worlds_have_the_fixtures_statistics(twin_lib):
     ot, oth, re_ = np.concatenate(odo_t), np.concatenate(odo_th), np.concatenate(rng_err)
     assert abs(ot.std() - 0.01) < 3e-4 and abs(ot.mean()) < 2e-4 and abs(oth.std() - 0.002) < 6e-5
     assert abs(re_.std() - 1.0) < 0.02 and abs(re_.mean()) < 0.02
+    # ... and against the reference's own simulation file (tests/golden/manhattan_fg.npz = examples/manhattan/factor_graph.pickle:
+    # 4 x 400 poses, 6 beacons, the shape generated above)
+    import os
+
+    from score_amd.io import load_fg_npz
+
+    fx = load_fg_npz(os.path.join(os.path.dirname(__file__), "golden", "manhattan_fg.npz"))
+    od = [m_ for ch in fx.odom_measurements for m_ in ch]
+    fth = np.array([m_.theta for m_ in od])
+    fk = np.round(fth / (np.pi / 2)).astype(int) % 4
+    f_lr, f_back = ((fk == 1) | (fk == 3)).mean(), (fk == 2).mean()
+    assert abs(left_right - f_lr) < 0.03 and abs(back - f_back) < 0.02, (left_right, f_lr, back, f_back)
+    assert abs(oth.std() - (fth - np.round(fth / (np.pi / 2)) * (np.pi / 2)).std()) < 1.5e-4
+    assert od[0].translation_precision == 1e4 and od[0].rotation_precision == pytest.approx(2.5e5)
+    lm = {v.name for v in fx.landmark_variables}
+    f_rb = sum(1 for m_ in fx.range_measurements if m_.first_key in lm or m_.second_key in lm)
+    f_rr = len(fx.range_measurements) - f_rb
+    assert abs(n_rb / count - f_rb) < 0.08 * f_rb and abs(n_rr / count - f_rr) < 0.15 * f_rr, (n_rb / count, f_rb, n_rr / count, f_rr)
+    assert fx.range_measurements[0].precision == 1.0
     # world t of a batch is the world of seed + t, whatever the batch
     one = GeneratedBatch(1, seed=7005, n_robots=R, n_poses=T, n_beacons=Nb, side=side, p_range=p, lib_path=twin_lib)
     a5, b0 = B.arrays(5), one.arrays(0)
