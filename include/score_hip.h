@@ -333,6 +333,11 @@ int  score_generate_manhattan(const score_manhattan_spec* spec, int32_t count, i
 int  score_generated_graph(const score_generated* g, int32_t index, struct score_graph* view);
 int  score_generated_truth(const score_generated* g, int32_t index, double* poses, double* beacons);
 void score_generated_free(score_generated* g);
+/* A handle for worlds first .. first + count - 1 of a generated batch, as score_create_from_graphs builds it for their views --
+ * but when the batch lives on the handle's device the measurement arrays are read where the generator left them: nothing of a
+ * world crosses the link again (the host lays out sizes, cones and chains from its copy).  relaxation: 0 = "SOCP", 1 = "QCQP". */
+int  score_create_from_generated(const score_generated* g, int32_t first, int32_t count, int32_t relaxation,
+                                 const score_settings* s, score_handle** out);
 
 /* SO(d) rounding of the relaxed rotation blocks: replaces the per-pose
  * round_to_special_orthogonal(...) calls of VariableCollection.get_variable_values

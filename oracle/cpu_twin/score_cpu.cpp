@@ -753,6 +753,16 @@ int score_generated_truth(const score_generated* g, int32_t index, double* poses
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 void score_generated_free(score_generated* g) { delete g; }
+int score_create_from_generated(const score_generated* g, int32_t first, int32_t count, int32_t relaxation, const score_settings* s, score_handle** out) {
+    try {
+        if (!g || !out) throw std::runtime_error("null argument");
+        if (first < 0 || count <= 0 || first + count > g->B.count) throw std::runtime_error("score_create_from_generated: worlds out of range");
+        if (relaxation != 0 && relaxation != 1) throw std::runtime_error("score_create_from_generated: relaxation must be 0 (SOCP) or 1 (QCQP)");
+        std::vector<score_graph> views((size_t)count);
+        for (int i = 0; i < count; ++i) { g->B.view(first + i, &views[(size_t)i]); views[(size_t)i].relaxation = relaxation; }
+        return score_create_from_graphs(views.data(), count, s, out);
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
 int score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rotations, int32_t* degenerate, int32_t /*device*/) {
     if (dim != 2 && dim != 3) { g_err = "score_round_to_so: dim must be 2 or 3"; return -1; }
     if (n < 0 || (n > 0 && (!blocks || !rotations || !degenerate))) { g_err = "score_round_to_so: null argument"; return -1; }

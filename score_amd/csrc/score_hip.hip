@@ -796,6 +796,13 @@ struct HipBackend {
     int n_vblocks = 0;
     DevBuf<double> xtu, xy, s, r, z, p, p2, w, kx, step;
     DevBuf<double> pw_part, rz_part0, rz_part1, rz_meas0, rz_meas1, pres_part, dres_part;
+    // graphs drawn by the library's generator on this device (score_generate_manhattan): the measurement arrays of the handle's
+    // graphs as they lie in the generator's device memory -- the assembler kernels read them there, nothing is uploaded again
+    struct GenSource {
+        const int32_t* rel_base; const int32_t* rel_to; const double* rel_t; const double* rel_R; const double* rel_kappa; const double* rel_tau;
+        const int32_t* rng_a; const int32_t* rng_b; const double* rng_dist; const double* rng_prec;
+    };
+    const GenSource* gen_src = nullptr;  // (set by score_create_from_generated for the duration of the create)
     // ---- segmented long chains (score_join.hpp): K's set, the Newton matrix's set ----
     int n_join_items = 0, n_join_chains = 0, n_join_seps = 0;
     bool join_suspend = false;  // the spike solves of a refresh: the chain kernel alone
@@ -1192,9 +1199,11 @@ struct HipBackend {
         const size_t i4 = sizeof(int32_t), f8 = sizeof(double);
         size_t off = 0;
         auto region = [&](size_t bytes) { const size_t o_ = off; off += al(std::max<size_t>(bytes, 8)); return o_; };
-        const size_t o_rel_base = region(n_rel * i4), o_rel_to = region(n_rel * i4), o_rel_t = region(n_rel * d * f8), o_rel_R = region(n_rel * d * d * f8);
-        const size_t o_rel_kappa = region(n_rel * f8), o_rel_tau = region(n_rel * f8);
-        const size_t o_rng_a = region(n_rng * i4), o_rng_b = region(n_rng * i4), o_rng_dist = region(n_rng * f8), o_rng_prec = region(n_rng * f8);
+        // (graphs from the library's generator: those ten arrays are read where the generator left them -- no room for them here)
+        const size_t gs = gen_src ? 0 : 1;
+        const size_t o_rel_base = region(gs * n_rel * i4), o_rel_to = region(gs * n_rel * i4), o_rel_t = region(gs * n_rel * d * f8), o_rel_R = region(gs * n_rel * d * d * f8);
+        const size_t o_rel_kappa = region(gs * n_rel * f8), o_rel_tau = region(gs * n_rel * f8);
+        const size_t o_rng_a = region(gs * n_rng * i4), o_rng_b = region(gs * n_rng * i4), o_rng_dist = region(gs * n_rng * f8), o_rng_prec = region(gs * n_rng * f8);
         const size_t o_pri_lm = region(n_pri * i4), o_pri_t = region(n_pri * d * f8), o_pri_prec = region(n_pri * f8);
         const size_t o_relp = region(n_rel * i4), o_rngp = region(n_rng * i4), o_prip = region(n_pri * i4), o_pinp = region(n_pin * i4), o_pin = region(n_pin * i4);
         const size_t o_gp = region((size_t)count * sizeof(GaProb));
@@ -1208,11 +1217,13 @@ struct HipBackend {
         for (int p = 0; p < count; ++p) {
             const score_graph& g = graphs[p];
             const size_t eo = (size_t)rel_off[(size_t)p], ro = (size_t)rng_off[(size_t)p], po = (size_t)pri_off[(size_t)p];
+            if (!gen_src) {
             cp(o_rel_base + eo * i4, g.rel_base, (size_t)g.n_rel * i4); cp(o_rel_to + eo * i4, g.rel_to, (size_t)g.n_rel * i4);
             cp(o_rel_t + eo * d * f8, g.rel_t, (size_t)g.n_rel * d * f8); cp(o_rel_R + eo * d * d * f8, g.rel_R, (size_t)g.n_rel * d * d * f8);
             cp(o_rel_kappa + eo * f8, g.rel_kappa, (size_t)g.n_rel * f8); cp(o_rel_tau + eo * f8, g.rel_tau, (size_t)g.n_rel * f8);
             cp(o_rng_a + ro * i4, g.rng_a, (size_t)g.n_rng * i4); cp(o_rng_b + ro * i4, g.rng_b, (size_t)g.n_rng * i4);
             cp(o_rng_dist + ro * f8, g.rng_dist, (size_t)g.n_rng * f8); cp(o_rng_prec + ro * f8, g.rng_prec, (size_t)g.n_rng * f8);
+            }
             cp(o_pri_lm + po * i4, g.lprior_lm, (size_t)g.n_lprior * i4); cp(o_pri_t + po * d * f8, g.lprior_t, (size_t)g.n_lprior * d * f8);
             cp(o_pri_prec + po * f8, g.lprior_prec, (size_t)g.n_lprior * f8);
             std::fill((int32_t*)(hb + o_relp) + eo, (int32_t*)(hb + o_relp) + eo + g.n_rel, p);
@@ -1245,6 +1256,11 @@ struct HipBackend {
         a.n_rel = n_rel; a.n_rng = n_rng; a.n_pri = n_pri; a.n_pin = n_pin;
         a.rel_base = rel_base.d; a.rel_to = rel_to.d; a.rel_t = rel_t.d; a.rel_R = rel_R.d; a.rel_kappa = rel_kappa.d; a.rel_tau = rel_tau.d;
         a.rng_a = rng_a.d; a.rng_b = rng_b.d; a.rng_dist = rng_dist.d; a.rng_prec = rng_prec.d;
+        if (gen_src) {
+            a.rel_base = gen_src->rel_base; a.rel_to = gen_src->rel_to; a.rel_t = gen_src->rel_t; a.rel_R = gen_src->rel_R;
+            a.rel_kappa = gen_src->rel_kappa; a.rel_tau = gen_src->rel_tau;
+            a.rng_a = gen_src->rng_a; a.rng_b = gen_src->rng_b; a.rng_dist = gen_src->rng_dist; a.rng_prec = gen_src->rng_prec;
+        }
         a.pri_lm = pri_lm.d; a.pri_t = pri_t.d; a.pri_prec = pri_prec.d; a.pin_edge = d_pin.d;
         a.key = key0.d; a.idx = idx0.d; a.val = val.d; a.pad_key = (unsigned long long)n << 32;
         a.A_ptr = A_ptr.d; a.A_col = R.Ac.d; a.A_val = R.Av.d; a.b = R.braw.d;
@@ -4199,7 +4215,7 @@ int score_create_batch(const score_problem* p, int32_t count, const score_settin
 int score_create(const score_problem* p, const score_settings* s, score_handle** out) {
     return score_create_batch(p, 1, s, out);
 }
-int score_create_from_graphs(const score_graph* graphs, int32_t count, const score_settings* s, score_handle** out) {
+static int score_create_from_graphs_impl(const score_graph* graphs, int32_t count, const score_settings* s, score_handle** out, const HipBackend::GenSource* gen_src) {
     try {
         tune_host_allocator_once();
         if (!graphs || !out) throw std::runtime_error("null argument");
@@ -4211,7 +4227,10 @@ int score_create_from_graphs(const score_graph* graphs, int32_t count, const sco
         if (st.device < 0 || st.device >= ndev) throw std::runtime_error("score_settings.device out of range");
         DeviceGuard guard(st.device);
         auto* h = new score_handle();
+        h->solver.be.gen_src = gen_src;
+        struct ClearSrc { score_handle* h; ~ClearSrc() { h->solver.be.gen_src = nullptr; } };
         try {
+            ClearSrc clear{h};
             h->solver.create_from_graphs(graphs, count, st, [&](const score_graph* gs, bool keep_hf) {
                 std::vector<score::AssembledQP> qps((size_t)count);
                 std::vector<score::AssembledQP*> ptrs((size_t)count);
@@ -4231,6 +4250,9 @@ int score_create_from_graphs(const score_graph* graphs, int32_t count, const sco
         g_err = e.what();
         return -1;
     }
+}
+int score_create_from_graphs(const score_graph* graphs, int32_t count, const score_settings* s, score_handle** out) {
+    return score_create_from_graphs_impl(graphs, count, s, out, nullptr);
 }
 int score_read_estimates(score_handle* h, int32_t qcqp_directions, double* poses, double* relaxed, double* landmarks, double* ranges,
                          int32_t* degenerate) {
@@ -4440,13 +4462,28 @@ void score_refine_destroy(score_refine* r) {
 }
 }  // extern "C"
 
-struct score_generated { score::GeneratedBatch B; };
+// (the generated arrays stay in device memory for as long as the batch lives: score_create_from_generated builds handles
+//  from them without another transfer)
+struct score_generated {
+    score::GeneratedBatch B;
+    DevArena arena;
+    int device = -1;
+    const int32_t* d_rel_base = nullptr; const int32_t* d_rel_to = nullptr; const int32_t* d_ra = nullptr; const int32_t* d_rb = nullptr;
+    const double* d_rel_t = nullptr; const double* d_rel_R = nullptr; const double* d_rel_kappa = nullptr; const double* d_rel_tau = nullptr;
+    const double* d_dist = nullptr; const double* d_prec = nullptr;
+    ~score_generated() {
+        if (device >= 0) {
+            try { DeviceGuard guard(device); (void)hipDeviceSynchronize(); } catch (...) {}
+        }
+    }
+};
 namespace {
 // The generator on the device: walks + beacons (one thread per robot / beacon), the ranges counted per (trial, group, time),
 // scanned, filled; the arrays come back through pinned staging (the host lays out the handles from them:
 // score_create_from_graphs takes the views like any other score_graph).
-void generate_manhattan_device(const score::GenSpec& S, int count, int device, score::GeneratedBatch& B) {
+void generate_manhattan_device(const score::GenSpec& S, int count, int device, score_generated& Gd) {
     using namespace score;
+    GeneratedBatch& B = Gd.B;
     gen_check_spec(S, count);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device available (the SCORE solver has no CPU fallback)");
@@ -4457,8 +4494,9 @@ void generate_manhattan_device(const score::GenSpec& S, int count, int device, s
     B.size_fixed();
     const size_t R = (size_t)S.n_robots, T = (size_t)S.n_poses, E = (size_t)B.edges(), c = (size_t)count, G = (size_t)gen_groups(S), nb = (size_t)S.n_beacons;
     hipStream_t st = stream_pool().take(device);
-    DevArena arena;
+    DevArena& arena = Gd.arena;
     arena.dev = device;
+    Gd.device = device;
     struct Scope {
         DevArena* keep_a; hipStream_t keep_s;
         Scope(DevArena* a, hipStream_t s) : keep_a(tl_arena), keep_s(tl_copy_stream) { tl_arena = a; tl_copy_stream = s; }
@@ -4525,6 +4563,8 @@ void generate_manhattan_device(const score::GenSpec& S, int count, int device, s
             });
         block_cache().give(pin, got, device, true);
         HIP_CHECK(err); HIP_CHECK(es);
+        Gd.d_rel_base = rel_base.d; Gd.d_rel_to = rel_to.d; Gd.d_rel_t = rel_t.d; Gd.d_rel_R = rel_R.d; Gd.d_rel_kappa = rel_kappa.d; Gd.d_rel_tau = rel_tau.d;
+        Gd.d_ra = ra.d; Gd.d_rb = rb.d; Gd.d_dist = dist.d; Gd.d_prec = prec.d;
     } catch (...) {
         (void)hipStreamSynchronize(st);
         stream_pool().give(device, st);
@@ -4540,7 +4580,7 @@ int score_generate_manhattan(const score_manhattan_spec* spec, int32_t count, in
         if (!spec || !out) throw std::runtime_error("null argument");
         score::GenSpec S{spec->n_robots, spec->n_poses, spec->n_beacons, spec->side, spec->p_range, spec->sigma_t, spec->sigma_theta, spec->sigma_range, spec->seed};
         auto* g = new score_generated();
-        try { generate_manhattan_device(S, count, device, g->B); } catch (...) { delete g; throw; }
+        try { generate_manhattan_device(S, count, device, *g); } catch (...) { delete g; throw; }
         *out = g;
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
@@ -4560,6 +4600,26 @@ int score_generated_truth(const score_generated* g, int32_t index, double* poses
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
 void score_generated_free(score_generated* g) { delete g; }
+int score_create_from_generated(const score_generated* g, int32_t first, int32_t count, int32_t relaxation, const score_settings* s, score_handle** out) {
+    try {
+        if (!g || !out) throw std::runtime_error("null argument");
+        if (first < 0 || count <= 0 || first + count > g->B.count) throw std::runtime_error("score_create_from_generated: worlds out of range");
+        if (relaxation != 0 && relaxation != 1) throw std::runtime_error("score_create_from_generated: relaxation must be 0 (SOCP) or 1 (QCQP)");
+        std::vector<score_graph> views((size_t)count);
+        for (int i = 0; i < count; ++i) { g->B.view(first + i, &views[(size_t)i]); views[(size_t)i].relaxation = relaxation; }
+        score_settings st;
+        if (s) st = *s; else score::default_settings(&st);
+        HipBackend::GenSource src{};
+        const bool resident = g->device >= 0 && st.device == g->device;
+        if (resident) {  // the measurement arrays where the generator left them (world `first` onwards: the worlds follow each other)
+            const size_t E = (size_t)g->B.edges(), eo = (size_t)first * E, ro = (size_t)g->B.rng_first[(size_t)first];
+            src.rel_base = g->d_rel_base + eo; src.rel_to = g->d_rel_to + eo; src.rel_t = g->d_rel_t + 2 * eo; src.rel_R = g->d_rel_R + 4 * eo;
+            src.rel_kappa = g->d_rel_kappa + eo; src.rel_tau = g->d_rel_tau + eo;
+            src.rng_a = g->d_ra + ro; src.rng_b = g->d_rb + ro; src.rng_dist = g->d_dist + ro; src.rng_prec = g->d_prec + ro;
+        }
+        return score_create_from_graphs_impl(views.data(), count, &st, out, resident ? &src : nullptr);
+    } catch (const std::exception& e) { g_err = e.what(); return -1; }
+}
 }  // extern "C"
 
 extern "C" {

@@ -227,8 +227,14 @@ def solve_score_batch(
         # dimension, graphs of similar size share a group: it runs as long as its slowest member
         chunks = []
         group = max(1, min(16, -(-len(datas) // max(1, workers)))) if group_size is None else max(1, int(group_size))
+        # (worlds of one generated batch -- score_amd.generate -- stay in their order: they are of one shape, and a run of
+        #  consecutive worlds is built from the arrays the generator left on the device)
+        own = [getattr(d_, "arrays", {}).get("_owner") if hasattr(d_, "arrays") else None for d_ in datas]
+        keep_order = own[0] is not None and all(o is own[0] for o in own)
         for dim in sorted({int(datas[i].dimension) for i in order}):
-            sub = sorted((i for i in order if int(datas[i].dimension) == dim), key=size_of)
+            sub = [i for i in order if int(datas[i].dimension) == dim]
+            if not keep_order:
+                sub = sorted(sub, key=size_of)
             chunks += [sub[i : i + group] for i in range(0, len(sub), group)]
     elif not lockstep and len(datas) > 1:
         chunks = [[i] for i in order]

@@ -82,7 +82,7 @@ ABI_SYMBOLS = [
     "score_default_settings", "score_create", "score_create_batch", "score_create_from_graphs", "score_read_estimates", "score_graphs_connected", "score_dims", "score_solve",
     "score_reset", "score_solve_steps", "score_newton_steps", "score_linear_create", "score_linear_solve", "score_refine_create", "score_refine_run", "score_refine_destroy", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
     "score_trim_caches", "score_last_error", "score_backend", "score_abi_version",
-    "score_generate_manhattan", "score_generated_graph", "score_generated_truth", "score_generated_free",
+    "score_generate_manhattan", "score_generated_graph", "score_generated_truth", "score_generated_free", "score_create_from_generated",
 ]
 
 ABI_VERSION = 6  # SCORE_ABI_VERSION of include/score_hip.h this binding's structs follow
@@ -204,7 +204,18 @@ class ConicSolver:
             self._est_dims = (d, int(relaxation), est_per)
         self._keep = []
         self._h = C.c_void_p()
-        rc = self.lib.score_create_from_graphs(gs, self.count, C.byref(st), C.byref(self._h))
+        # worlds of ONE generated batch (score_amd.generate), in a row: the library builds the handle from the arrays the
+        # generator left on the device (score_create_from_generated) -- the same program, nothing of a world uploaded again
+        owner = arrays[0].get("_owner") if self.count else None
+        first = arrays[0].get("_index") if owner is not None else None
+        resident = (owner is not None and getattr(owner, "_h", None) and getattr(getattr(owner, "lib", None), "_handle", None) == self.lib._handle
+                    and all(a.get("_owner") is owner and a.get("_index") == first + i for i, a in enumerate(arrays)))
+        if resident:
+            self.lib.score_create_from_generated.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ScoreSettings), C.POINTER(C.c_void_p)]
+            rc = self.lib.score_create_from_generated(owner._h, int(first), self.count, int(relaxation), C.byref(st), C.byref(self._h))
+            self._keep.append(owner)
+        else:
+            rc = self.lib.score_create_from_graphs(gs, self.count, C.byref(st), C.byref(self._h))
         if rc != 0:
             self._h = None
             raise ValueError(f"score_create_from_graphs failed: {self.lib.score_last_error().decode()}")

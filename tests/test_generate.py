@@ -122,6 +122,24 @@ def test_device_generator_equals_the_host_loops(hip_lib, twin_lib):
             (pa, ba), (pb, bb) = dev.truth(i), ref.truth(i)
             assert np.array_equal(pa[:, :2], pb[:, :2]) and np.array_equal(ba, bb)
             np.testing.assert_allclose(pa[:, 2], pb[:, 2], atol=1e-15)
+    # worlds in a row of one batch: the handle is built from the arrays the generator left ON THE DEVICE (score_create_from_generated);
+    # the same worlds handed over as host arrays (score_create_from_graphs) give the same program and the same solutions, bit for bit
+    from score_amd.solver import ConicSolver
+
+    B = GeneratedBatch(6, seed=4100, n_robots=4, n_poses=500, n_beacons=4, lib_path=hip_lib)
+    arrs = [B.arrays(i) for i in range(6)]
+    for relax in (0, 1):
+        res_dev = ConicSolver.from_graphs(arrs[1:5], relax, {}, lib_path=hip_lib)
+        assert res_dev._keep and res_dev._keep[0] is B  # (took the resident path)
+        plain = [{k: v for k, v in a.items() if k not in ("_owner", "_index")} for a in arrs[1:5]]
+        res_host = ConicSolver.from_graphs(plain, relax, {}, lib_path=hip_lib)
+        assert not res_host._keep
+        if relax == 0:
+            for nm in ("qs", "bs", "Aval", "K0", "K1"):
+                assert np.array_equal(res_dev.debug_get(nm), res_host.debug_get(nm)), nm
+        for x, y in zip(res_dev.solve(), res_host.solve()):
+            assert x.solved and y.solved and np.array_equal(x.x, y.x) and np.array_equal(x.y, y.y) and x.info["pobj"] == y.info["pobj"]
+        res_dev.close(); res_host.close()
     # through the product: generated on the device, model + setup + solve + estimates on the device
     graphs = generate_manhattan(8, seed=4000, n_robots=4, n_poses=1000, n_beacons=4, lib_path=hip_lib)
     res = solve_score_batch(graphs, "SOCP")
