@@ -263,3 +263,101 @@ def solve_score_sharded(
     if failed or failure:
         raise RuntimeError(f"solve_score_sharded: problems {failed} failed" + (f" ({failure})" if failure else ""))
     return out  # type: ignore[return-value]
+
+
+def solve_generated_sharded(
+    total: int, seed: int = 0, relaxation_type: str = "QCQP", solver_settings: Optional[dict] = None,
+    lib_path: Optional[str] = None, device: Optional[int] = None, **spec,
+) -> List[compat.SolverResults]:
+    """A Monte-Carlo study from seeds over the ranks: ``total`` synthetic Manhattan worlds (``score_amd.generate``: world t is
+    the world of ``seed + t``), a block of consecutive worlds per rank -- DRAWN THERE, on that rank's device, so that no problem
+    data is distributed at all --, solved as lock-step batches, and one all_gather of fixed-stride records returns every estimate
+    to every rank (two small collectives in front of it agree on the record stride).  A record carries what ``_pack`` carries
+    plus the endpoints of the world's range measurements: a foreign world's distance keys are rebuilt from them.  Without an
+    initialised process group: the single-process run of the same code."""
+    import torch
+    import torch.distributed as dist
+
+    from .generate import GeneratedBatch, _PoseNames, _RangeKeys
+    from .manhattan import robot_letters
+
+    on = dist.is_available() and dist.is_initialized()
+    world, rank = (dist.get_world_size(), dist.get_rank()) if on else (1, 0)
+    per = -(-int(total) // world)
+    lo, hi = min(total, rank * per), min(total, (rank + 1) * per)
+    settings = dict(solver_settings or {})
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    settings.setdefault("device", device)
+    failure = None
+    graphs, results = [], []
+    try:
+        if hi > lo:
+            batch = GeneratedBatch(hi - lo, seed=int(seed) + lo, device=int(settings["device"]), lib_path=lib_path, **spec)
+            graphs = batch.graphs()
+            results = solve_score_batch(graphs, relaxation_type, solver_settings=settings, lib_path=lib_path)
+    except Exception as exc:  # noqa: BLE001 - re-raised after the collectives
+        failure = f"rank {rank}: {type(exc).__name__}: {exc}"
+        results = [None] * len(graphs)
+    # the record stride: the largest world anywhere (ranges differ from world to world)
+    recs = []
+    for g, res in zip(graphs, results):
+        try:
+            if res is None:
+                raise RuntimeError("no result")
+            a = g.arrays
+            recs.append(np.concatenate([_pack(res, g), a["rng_a"].astype(np.float64), a["rng_b"].astype(np.float64)]))
+        except Exception as exc:  # noqa: BLE001
+            if failure is None:
+                failure = f"rank {rank}: {type(exc).__name__}: {exc}"
+            recs.append(None)
+    stride = max([r.size for r in recs if r is not None] + [_HDR])
+    if on:
+        t = torch.tensor([float(stride)], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.to(f"cuda:{int(settings['device'])}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        stride = int(t.item())
+    buf = np.zeros((per, stride))
+    buf[:, 7] = -2.0  # empty slot
+    for slot, r in enumerate(recs):
+        if r is None:
+            buf[slot, :] = np.nan
+            buf[slot, 0], buf[slot, 7] = 3.0, -1.0
+        else:
+            buf[slot, : r.size] = r
+    gathered = all_gather_records(buf, int(settings["device"]))
+    R, T, Nb = int(spec.get("n_robots", 4)), int(spec.get("n_poses", 400)), int(spec.get("n_beacons", 6))
+    poses = _PoseNames(robot_letters(R), T)
+    lms = [f"L{k}" for k in range(Nb)]
+    chains = [_PoseNames([ch], T) for ch in robot_letters(R)]
+    out: List[Optional[compat.SolverResults]] = [None] * int(total)
+    failed = []
+    for r in range(world):
+        for slot in range(per):
+            i = r * per + slot
+            if i >= total:
+                break
+            rec = gathered[r][slot]
+            if rec[7] < 0:
+                failed.append(i)
+                continue
+            nv, nd, wd = int(rec[7]), int(rec[8]), int(rec[9])
+            v = rec[_HDR : _HDR + nv]
+            k = 9
+            P = v[: len(poses) * k].reshape(len(poses), 3, 3).copy()
+            off = len(poses) * k
+            L = v[off : off + Nb * 2].reshape(Nb, 2).copy()
+            off += Nb * 2
+            D = v[off : off + nd * wd].reshape(nd, wd).copy()
+            ends = rec[_HDR + nv : _HDR + nv + 2 * nd]
+            keys = _RangeKeys(ends[:nd].astype(np.int32), ends[nd:].astype(np.int32), poses)
+            info = dict(status=int(rec[0]), iters=int(rec[1]), cg_iters=int(rec[2]), pobj=float(rec[3]), res_pri=float(rec[4]),
+                        res_dual=float(rec[5]), solve_ms=float(rec[6]), seed=int(seed) + i, rank=r)
+            out[i] = compat.SolverResults(
+                variables=compat.VariableValues(2, compat.ArrayDict(poses, P), compat.ArrayDict(lms, L), compat.ArrayDict(keys, D) if nd else {}),
+                total_time=info["solve_ms"] * 1e-3, solved=info["status"] == 1, pose_chain_names=chains, solver_cost=info["pobj"], info=info,
+            )
+    if failed or failure:
+        raise RuntimeError(f"solve_generated_sharded: worlds {failed} failed" + (f" ({failure})" if failure else ""))
+    return out  # type: ignore[return-value]

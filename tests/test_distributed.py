@@ -186,6 +186,15 @@ for a, b in zip(res2, ref):
     for k in b.variables.distances:
         worst = max(worst, float(np.abs(np.asarray(a.variables.distances[k]) - np.asarray(b.variables.distances[k])).max()))
 assert worst <= 1e-9, worst
+# a Monte-Carlo study from seeds: the worlds drawn on this rank's GPU, built from there, records through RCCL
+from score_amd.distributed import solve_generated_sharded
+from score_amd.generate import generate_manhattan
+gen = solve_generated_sharded(6, seed=77, relaxation_type="SOCP", device=0, n_robots=3, n_poses=200, n_beacons=3)
+ref3 = solve_score_batch(generate_manhattan(6, seed=77, n_robots=3, n_poses=200, n_beacons=3), "SOCP", solver_settings=dict(device=0))
+for a, b in zip(gen, ref3):
+    assert a.solved and b.solved and list(a.variables.distances) == list(b.variables.distances)
+    worst = max(worst, float(np.abs(a.poses.array - b.poses.array).max()), float(np.abs(a.variables.distances.array - b.variables.distances.array).max()))
+assert worst <= 1e-9, worst
 dist.barrier()
 dist.destroy_process_group()
 print("NCCL_SHARDED_OK", worst)
@@ -205,3 +214,42 @@ def test_sharded_solve_under_rccl_equals_the_batch_solve(hip_lib):
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-3000:])
     assert "NCCL_SHARDED_OK" in out.stdout
+
+
+def _worker_generated(rank, world, port, lib, outdir):
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from score_amd.distributed import solve_generated_sharded
+
+    res = solve_generated_sharded(5, seed=900, relaxation_type="SOCP", lib_path=lib, device=0, n_robots=2, n_poses=40, n_beacons=3, p_range=0.3)
+    np.save(os.path.join(outdir, f"gen{rank}.npy"), np.concatenate([r.poses.array.ravel() for r in res]))
+    np.save(os.path.join(outdir, f"gend{rank}.npy"), np.concatenate([r.variables.distances.array.ravel() for r in res]))
+    with open(os.path.join(outdir, f"genk{rank}.txt"), "w") as f:
+        f.write(repr([list(r.variables.distances)[:3] for r in res]) + repr([r.info["rank"] for r in res]))
+    dist.destroy_process_group()
+
+
+def test_generated_worlds_sharded_over_two_ranks(twin_lib, tmp_path):
+    """A Monte-Carlo study from seeds over two ranks (gloo, CPU twin): every rank draws and solves ITS block of worlds (no problem
+    data is distributed), every rank ends with every estimate -- equal to the single-process run, distance keys included."""
+    port = _free_port()
+    mp.spawn(_worker_generated, args=(2, port, twin_lib, str(tmp_path)), nprocs=2, join=True)
+    g0, g1 = np.load(tmp_path / "gen0.npy"), np.load(tmp_path / "gen1.npy")
+    np.testing.assert_array_equal(g0, g1)
+    np.testing.assert_array_equal(np.load(tmp_path / "gend0.npy"), np.load(tmp_path / "gend1.npy"))
+    assert open(tmp_path / "genk0.txt").read() == open(tmp_path / "genk1.txt").read()
+    assert open(tmp_path / "genk0.txt").read().endswith("[0, 0, 0, 1, 1]")  # worlds 0-2 on rank 0, 3-4 on rank 1
+    from score_amd.distributed import solve_generated_sharded
+    from score_amd.generate import generate_manhattan
+    from score_amd.solve_score import solve_score_batch
+
+    single = solve_generated_sharded(5, seed=900, relaxation_type="SOCP", lib_path=twin_lib, n_robots=2, n_poses=40, n_beacons=3, p_range=0.3)
+    np.testing.assert_allclose(g0, np.concatenate([r.poses.array.ravel() for r in single]), atol=1e-6)
+    direct = solve_score_batch(generate_manhattan(5, seed=900, n_robots=2, n_poses=40, n_beacons=3, p_range=0.3, lib_path=twin_lib), "SOCP", lib_path=twin_lib)
+    for a, b in zip(single, direct):
+        assert a.solved and list(a.variables.distances) == list(b.variables.distances) and a.pose_chain_names[1][5] == "B5"
+        np.testing.assert_allclose(a.poses.array, b.poses.array, atol=1e-6)
+        np.testing.assert_allclose(a.variables.distances.array, b.variables.distances.array, atol=1e-6)
