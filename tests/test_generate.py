@@ -85,6 +85,39 @@ def test_generated_worlds_have_the_fixtures_statistics(twin_lib):
     assert not np.array_equal(B.arrays(4)["rng_dist"][:50], a5["rng_dist"][:50])
 
 
+def test_generator_against_the_independent_restatement(twin_lib):
+    """oracle/generate_oracle.py restates the generator in plain Python (its own Philox4x32-10, pinned here by the known-answer
+    vectors of Random123; walk, measurements and their order written from the description, not from the C++): the library's
+    host loops -- which the device kernels are tested against -- must draw the same worlds: every integer equal, reals to 1e-12."""
+    from oracle.generate_oracle import philox4x32_10, world
+
+    kat = [((0, 0, 0, 0), (0, 0), "6627e8d5 e169c58d bc57ac4c 9b00dbd8"),
+           ((0xFFFFFFFF,) * 4, (0xFFFFFFFF, 0xFFFFFFFF), "408f276d 41c83b0e a20bc7c6 6d5451fd"),
+           ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0), "d16cfe09 94fdcceb 5001e420 24126ea1")]
+    for ctr, key, want in kat:  # Random123 kat_vectors, philox4x32 10 rounds
+        assert " ".join("%08x" % v for v in philox4x32_10(key[0] | (key[1] << 32), *ctr)) == want
+    spec = dict(n_robots=3, n_poses=60, n_beacons=5, side=7, p_range=0.3, sigma_t=0.02, sigma_theta=0.01, sigma_range=0.7)
+    B = GeneratedBatch(3, seed=123456789012, lib_path=twin_lib, **spec)
+    for t in range(3):
+        w = world(123456789012, t, **spec)
+        a = B.arrays(t)
+        poses, beacons = B.truth(t)
+        R, T = spec["n_robots"], spec["n_poses"]
+        assert np.array_equal(poses[:, :2], np.array([p for r in range(R) for p in w["pos"][r]], dtype=float))
+        hd = np.array([h for r in range(R) for h in w["hd"][r]])
+        np.testing.assert_allclose(poses[:, 2], np.arctan2(np.sin(hd * np.pi / 2), np.cos(hd * np.pi / 2)), atol=1e-15)
+        assert np.array_equal(beacons, np.array(w["beacons"], dtype=float))
+        od = np.array(w["odom"])
+        assert np.array_equal(a["rel_base"], od[:, 0].astype(np.int32)) and np.array_equal(a["rel_to"], od[:, 1].astype(np.int32))
+        np.testing.assert_allclose(a["rel_t"], od[:, 2:4], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(np.arctan2(a["rel_R"][:, 1, 0], a["rel_R"][:, 0, 0]), od[:, 4], rtol=0, atol=1e-12)
+        rg = np.array(w["ranges"])
+        assert len(rg) == len(a["rng_a"]) > 50
+        assert np.array_equal(a["rng_a"], rg[:, 0].astype(np.int32)) and np.array_equal(a["rng_b"], rg[:, 1].astype(np.int32))
+        np.testing.assert_allclose(a["rng_dist"], rg[:, 2], rtol=0, atol=1e-12)
+        assert np.all(a["rng_prec"] == pytest.approx(1.0 / 0.49)) and np.all(a["rel_kappa"] == pytest.approx(2500.0))
+
+
 def test_generated_worlds_solve_and_errors(twin_lib):
     graphs = generate_manhattan(3, seed=11, n_robots=2, n_poses=60, n_beacons=3, p_range=0.4, lib_path=twin_lib)
     B = graphs[0].arrays["_owner"]
