@@ -4471,11 +4471,8 @@ struct score_generated {
     const int32_t* d_rel_base = nullptr; const int32_t* d_rel_to = nullptr; const int32_t* d_ra = nullptr; const int32_t* d_rb = nullptr;
     const double* d_rel_t = nullptr; const double* d_rel_R = nullptr; const double* d_rel_kappa = nullptr; const double* d_rel_tau = nullptr;
     const double* d_dist = nullptr; const double* d_prec = nullptr;
-    ~score_generated() {
-        if (device >= 0) {
-            try { DeviceGuard guard(device); (void)hipDeviceSynchronize(); } catch (...) {}
-        }
-    }
+    // (nothing to wait for when the batch goes: score_create_from_generated returns with its handle's setup -- the only reader of
+    //  these arrays -- complete; the arena's blocks go back to the cache)
 };
 namespace {
 // The generator on the device: walks + beacons (one thread per robot / beacon), the ranges counted per (trial, group, time),
