@@ -88,27 +88,32 @@ SCORE_GEN_HD inline void gen_start(const GenSpec& S, uint64_t key, int r, int& x
     x = 0; y = 0; h = 0;  // (a grid of side >= 1 always has a feasible draw long before)
 }
 // heading after arriving at (x, y) with heading h_prev at step i: weighted random order of {straight, left, right, back}
+// (scalars and selects only: arrays indexed by the draw would live in scratch memory on the device -- the walk is the one
+//  sequential loop of the generator)
 SCORE_GEN_HD inline int gen_next_heading(const GenSpec& S, uint64_t key, int r, int i, int x, int y, int h_prev) {
     const Philox4 p = philox4x32_10(key, GEN_TURN, (uint32_t)r, (uint32_t)i, 0);
-    double w[4] = {0.81, 0.09, 0.09, 0.01};
-    const int turn[4] = {0, 1, 3, 2};  // straight, left (+1), right (-1), back
+    double w0 = 0.81, w1 = 0.09, w2 = 0.09, w3 = 0.01;  // straight, left (+1), right (-1 = +3), back (+2)
     double tot = 1.0;
+#pragma unroll
     for (int draw = 0; draw < 4; ++draw) {
-        const double u = gen_u32(p.v[draw]) * tot;
+        const uint32_t bits = draw == 0 ? p.v[0] : draw == 1 ? p.v[1] : draw == 2 ? p.v[2] : p.v[3];
+        const double u = gen_u32(bits) * tot;
+        // the first live weight whose running sum exceeds u; the last live one otherwise
         int pick = -1;
         double acc = 0.0;
-        for (int k = 0; k < 4; ++k) {
-            if (w[k] <= 0.0) continue;
-            pick = k;
-            acc += w[k];
-            if (u < acc) break;
-        }
-        const int h = (h_prev + turn[pick]) & 3;
+        bool found = false;
+        if (w0 > 0.0) { pick = 0; acc += w0; found = u < acc; }
+        if (!found && w1 > 0.0) { pick = 1; acc += w1; found = u < acc; }
+        if (!found && w2 > 0.0) { pick = 2; acc += w2; found = u < acc; }
+        if (!found && w3 > 0.0) { pick = 3; acc += w3; found = u < acc; }
+        const int turn = pick == 0 ? 0 : pick == 1 ? 1 : pick == 2 ? 3 : 2;
+        const int h = (h_prev + turn) & 3;
         int dx, dy;
         gen_dir(h, dx, dy);
         if (gen_inside(x + dx, y + dy, S.side)) return h;
-        tot -= w[pick];
-        w[pick] = 0.0;
+        const double wp = pick == 0 ? w0 : pick == 1 ? w1 : pick == 2 ? w2 : w3;
+        tot -= wp;
+        if (pick == 0) w0 = 0.0; else if (pick == 1) w1 = 0.0; else if (pick == 2) w2 = 0.0; else w3 = 0.0;
     }
     return (h_prev + 2) & 3;
 }
