@@ -3947,6 +3947,11 @@ struct HipBackend {
             else if (which == "prec_init") launch_prec<PREC_INIT>(pa);
             else if (which.rfind("prec_step:", 0) == 0) { pa.debug_skip = std::atoi(which.c_str() + 10); launch_prec<PREC_STEP>(pa); }
             else if (which == "prec_step") launch_prec<PREC_STEP>(pa);
+            // (segmented long chains: the chain kernel alone / the second level alone -- k_join_solve + k_join_apply)
+            else if (which == "prec_init_chain") { join_suspend = true; launch_prec<PREC_INIT>(pa); join_suspend = false; }
+            else if (which == "prec_step_chain") { join_suspend = true; launch_prec<PREC_STEP>(pa); join_suspend = false; }
+            else if (which == "join_init") { if (n_join_items) join_apply<PREC_INIT>(pa, false); }
+            else if (which == "join_step") { if (n_join_items) join_apply<PREC_STEP>(pa, false); }
             else if (which == "kp") launch_kp(p.d);
             else if (which == "kpb") launch_kpb(p.d, p2.d, rz_part1.d, rz_part0.d);
             else if (which == "xupdate") hipLaunchKernelGGL(k_xupdate, dim3(n_vblocks), dim3(kThreads), 0, stream, va);
