@@ -179,3 +179,35 @@ def test_device_generator_equals_the_host_loops(hip_lib, twin_lib):
     assert all(r.solved and r.info["newton_iters"] > 0 for r in res)
     again = solve_score(graphs[3], "SOCP")
     assert again.info["pobj"] == pytest.approx(res[3].info["pobj"], rel=1e-9)
+
+
+@pytest.mark.gpu
+def test_config5_from_seeds_is_certified(hip_lib):
+    """BASELINE configs[4]'s shape from nothing but seeds: 64 worlds of 4 robots x 1000 poses drawn on the device, built there
+    (score_create_from_generated) and solved in lock-step groups; every world solved, the solver-independent KKT certificate of
+    the conic program (built by the host assembler from the same arrays) for a sample of them, the pinned robot's trajectory
+    within the odometry's drift of the ground truth, both relaxations' direct forms agreeing."""
+    from oracle import score_oracle as so
+    from score_amd.native import assemble_native
+    from score_amd.solver import ConicSolver
+
+    B = GeneratedBatch(64, seed=64000, n_robots=4, n_poses=1000, n_beacons=4, lib_path=hip_lib)
+    graphs = B.graphs()
+    res = solve_score_batch(graphs, "SOCP")
+    assert len(res) == 64 and all(r.solved and r.info["newton_iters"] > 0 for r in res)
+    for i in (0, 17, 63):
+        truth, beacons = B.truth(i)
+        est = res[i].poses.array[:1000, :2, 2]  # robot A (pinned at the origin)
+        assert np.abs(est - truth[:1000, :2]).max() < 10.0, i  # (1000 steps of 0.002 rad heading noise on a 20 m grid: metres)
+        a = B.arrays(i)
+        qp = assemble_native(graphs[i], "SOCP", arrays=a).qp
+        sv = ConicSolver.from_graphs([a], 0, {})
+        out = sv.solve()[0]
+        sv.close()
+        cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, out.x, out.y, out.s)
+        assert cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4 and cert["s_cone_dist"] < 1e-9 and cert["y_cone_dist"] < 1e-9, (i, cert)
+        assert out.info["pobj"] == pytest.approx(res[i].info["pobj"], rel=1e-8)
+    rq = solve_score_batch(graphs[:8], "QCQP", qcqp_mode="direct")
+    for a_, b_ in zip(rq, res[:8]):
+        assert a_.solved and a_.info["pobj"] == pytest.approx(b_.info["pobj"], rel=1e-7)
+        np.testing.assert_allclose(a_.poses.array, b_.poses.array, atol=1e-6 * max(1.0, np.abs(b_.poses.array).max()))
