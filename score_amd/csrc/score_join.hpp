@@ -305,15 +305,36 @@ __global__ __launch_bounds__(kJoinThreads) void k_join_apply(JoinArgs a) {
     const ChainDesc ch = a.chains[it.chain];
     const int NB = ch.N * BS;
     double local = 0.0;
-    for (int e = t; e < NB; e += kJoinThreads) {
-        const int node = e / BS;
-        const int col = join_col<BS>(ch, a.node_col, node) + (e - node * BS);
-        double zz = a.z[col];
+    // four entries per lane and trip, every load of the trip requested before the first use (clamped addresses, predicated
+    // stores): a segment is one workgroup's work, and 200 workgroups on 256 CUs hide no latency by themselves
+    constexpr int U = 4;
+    for (int base = t; base < NB; base += kJoinThreads * U) {
+        int col[U];
+        double zv[U], rv[U], wl_[U][BS], wr_[U][BS];
 #pragma unroll
-        for (int c = 0; c < BS; ++c) zz -= a.W[(size_t)c * a.n_tot + col] * zl[c] + a.W[(size_t)(BS + c) * a.n_tot + col] * zr[c];
-        a.z[col] = zz;
-        if (MODE == PREC_INIT) a.p[col] = zz;
-        local += a.r[col] * zz;
+        for (int u = 0; u < U; ++u) {
+            const int e = min(base + u * kJoinThreads, NB - 1);
+            const int node = e / BS;
+            col[u] = join_col<BS>(ch, a.node_col, node) + (e - node * BS);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            zv[u] = a.z[col[u]];
+            rv[u] = a.r[col[u]];
+#pragma unroll
+            for (int c = 0; c < BS; ++c) { wl_[u][c] = a.W[(size_t)c * a.n_tot + col[u]]; wr_[u][c] = a.W[(size_t)(BS + c) * a.n_tot + col[u]]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (base + u * kJoinThreads < NB) {
+                double zz = zv[u];
+#pragma unroll
+                for (int c = 0; c < BS; ++c) zz -= wl_[u][c] * zl[c] + wr_[u][c] * zr[c];
+                a.z[col[u]] = zz;
+                if (MODE == PREC_INIT) a.p[col[u]] = zz;
+                local += rv[u] * zz;
+            }
+        }
     }
     if (it.seg < n_sep && t < BS) {  // the separator to the right of this segment
         const int b = a.sep_col[jc.sep_begin + it.seg];
