@@ -127,6 +127,20 @@ def test_generated_worlds_solve_and_errors(twin_lib):
     est = np.array([res[1].poses[f"A{i}"][:2, 2] for i in range(60)])
     assert np.abs(est - poses[:60, :2]).max() < 1.0  # the pinned robot's trajectory: odometry noise of 1 cm per step
     assert res[1].pose_chain_names[1][3] == "B3" and set(res[1].landmarks) == {"L0", "L1", "L2"}
+    # ground truth as results (TUM export of the reference trajectory) and trajectory errors against it
+    from score_amd.io import load_tum, save_to_tum
+
+    gt = B.truth_results(1)
+    assert np.array_equal(gt.poses["A0"], np.eye(3)) and list(gt.landmarks) == ["L0", "L1", "L2"]
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        files = save_to_tum(gt, tmp + "/gt")
+        assert len(files) == 2 and load_tum(files[0]).shape == (60, 8)
+        np.testing.assert_allclose(load_tum(files[1])[:, 1:3], poses[60:, :2])
+    err = B.trajectory_errors(1, res[1])
+    assert set(err) == {"A", "B"} and err["A"]["translation_rmse"] < 0.5 and err["A"]["heading_max"] < 0.2
+    assert B.trajectory_errors(1, gt)["B"]["translation_max"] == 0.0
     rq = solve_score(graphs[2], lib_path=twin_lib)  # the reference's default relaxation
     assert rq.solved and len(rq.distances) == graphs[2].num_ranges
     with pytest.raises(ValueError, match="robots"):
