@@ -111,6 +111,32 @@ def test_direct_qcqp_is_solved_in_head_form_and_mapped_back(twin_lib, monkeypatc
     # (x itself is not unique here: idle directions, a landmark no active cone determines)
 
 
+def test_head_form_keeps_equality_rows(twin_lib):
+    """The rewrite of constant-head unit-ball cones (csrc/score_headform.hpp) on a program that also has zero-cone rows in
+    front (the general ABI form: z > 0; here one landmark coordinate fixed by an equality): the rows keep their places, their
+    duals and slacks come back unchanged, and the returned point is a KKT point of the program as given."""
+    import scipy.sparse as sp
+
+    from oracle import score_oracle as so
+
+    from score_amd.assemble import ConicQP, assemble
+    from score_amd.solver import ConicSolver
+
+    fg = make_manhattan(n_robots=2, n_poses=40, n_beacons=3, seed=21, p_range=0.4)
+    qp = assemble(fg, "QCQP").qp
+    col = (sum(len(c) for c in fg.pose_variables) - 1) * 3  # landmark 0's x coordinate (replica 0)
+    A2 = sp.vstack([sp.csr_matrix(([1.0], ([0], [col])), shape=(1, qp.n)), qp.A]).tocsr()
+    qp2 = ConicQP(P=qp.P, q=qp.q, c0=qp.c0, A=A2, b=np.concatenate([[3.25], qp.b]), z=1, soc_dims=qp.soc_dims, chain_ptr=qp.chain_ptr,
+                  node_cols=qp.node_cols, block_size=qp.block_size, rep_d=qp.rep_d, rep_n=qp.rep_n)
+    sv = ConicSolver([qp2], dict(eps_abs=1e-8, eps_rel=1e-8, max_iters=100000), lib_path=twin_lib)
+    out = sv.solve()[0]
+    assert (sv.n_total, sv.m_total) == (qp2.n, qp2.m)
+    sv.close()
+    assert out.solved and out.x[col] == pytest.approx(3.25, abs=1e-7) and out.s[0] == pytest.approx(0.0, abs=1e-7)
+    cert = so.kkt_certificate(qp2.P, qp2.q, qp2.A, qp2.b, 1, qp2.soc_dims, out.x, out.y, out.s)
+    assert cert["primal_res_inf"] < 1e-7 and cert["dual_res_inf"] < 1e-5 and cert["s_cone_dist"] < 1e-12 and cert["y_cone_dist"] < 1e-12, cert
+
+
 def test_batch_equals_individual(twin_lib):
     graphs = [make_manhattan(n_robots=3, n_poses=40 + 10 * (s % 4), n_beacons=4, seed=s, p_range=0.4) for s in (300, 303, 305)]
     batch = solve_score_batch(graphs, "SOCP", lib_path=twin_lib, lockstep=True)
