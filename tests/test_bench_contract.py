@@ -63,6 +63,7 @@ def test_bench_gpus_flag_launches_that_many_ranks(twin_lib):
     # (score_create_from_graphs), beside the re-solve figure and labelled as such; every rank builds ITS shard's models only
     fr = c5["fresh_graphs"]
     assert c5["fresh_graphs_problems_per_sec"] == fr["problems_per_sec"] > 0 and "RE-SOLVES" in c5["problems_per_sec_is"]
+    assert "generated_graphs_problems_per_sec" in c5 and c5["generated_graphs"] is None  # (the twin run skips the generated-worlds leg)
     assert fr["solved_last_sweep"] == 5 and fr["host_cpu_ms_per_problem_mean_over_ranks"] > 0
     assert sum(fr["trials_per_handle_rank0"]) == 3  # (rank 0 holds trials 0, 2, 4 of 5)
     assert "test_mode" in rec
