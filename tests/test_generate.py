@@ -150,6 +150,23 @@ def test_generated_worlds_solve_and_errors(twin_lib):
     with pytest.raises(IndexError):
         B.arrays(3)
     assert C.sizeof(ManhattanSpec) == 56
+    # score_create_from_generated: argument errors come back as errors, not crashes
+    from score_amd.solver import ScoreSettings
+
+    lib = B.lib
+    lib.score_create_from_generated.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ScoreSettings), C.POINTER(C.c_void_p)]
+    h = C.c_void_p()
+    for first, count, relax, what in ((-1, 1, 0, b"range"), (2, 2, 0, b"range"), (0, 0, 0, b"range"), (0, 1, 2, b"relaxation")):
+        assert lib.score_create_from_generated(B._h, first, count, relax, None, C.byref(h)) != 0
+        assert what in lib.score_last_error()
+    assert lib.score_create_from_generated(None, 0, 1, 0, None, C.byref(h)) != 0
+    assert lib.score_create_from_generated(B._h, 1, 2, 1, None, C.byref(h)) == 0  # worlds 1-2, the QCQP form
+    n, m, cnt = C.c_int64(), C.c_int64(), C.c_int32()
+    lib.score_dims(h, C.byref(n), C.byref(m), C.byref(cnt))
+    a1, a2 = B.arrays(1), B.arrays(2)
+    assert cnt.value == 2 and m.value == 3 * (len(a1["rng_a"]) + len(a2["rng_a"]))
+    assert n.value == sum(2 * ((2 * 60 - 1) * 3 + 3 + len(a["rng_a"])) for a in (a1, a2))  # the QCQP program's columns
+    lib.score_destroy(h)
 
 
 @pytest.mark.gpu
