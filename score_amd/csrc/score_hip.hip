@@ -948,6 +948,7 @@ struct HipBackend {
     bool device_setup_ok_graphs(const HostSystem& h, const score_graph* graphs, const score_settings& s_) const {
         if (std::getenv("SCORE_HOST_ASSEMBLE") || !device_setup_allowed(h, s_)) return false;
         const int d = graphs[0].dim, D1 = d + 1;
+        if (h.rep != d) return false;  // (the assembler kernels write one replica's rows: SCORE_NO_REPLICATION takes the host assembler)
         int64_t rec = h.n_tot, con = 0;
         for (int p = 0; p < h.count; ++p) {
             const score_graph& g = graphs[p];

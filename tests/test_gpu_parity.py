@@ -498,6 +498,22 @@ def test_solve_score_matches_golden(name, relax, fixtures, hip_lib):
     compare_residuals_with_golden(res, fg, gold, tol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["manhattan", "graph3d"])
+def test_solve_score_without_replication(name, fixtures, hip_lib, monkeypatch):
+    """The experiment switch SCORE_NO_REPLICATION through the product entry point: the graph assembler on the device writes one
+    replica's rows, so a handle that is not to be replicated must take the host assembler (device_setup_ok_graphs) -- same golden
+    optimum, polish included."""
+    _hip_only(hip_lib)
+    fg = graph_by_name(name, fixtures)
+    monkeypatch.setenv("SCORE_NO_REPLICATION", "1")
+    res = solve_score(fg, "SOCP")
+    monkeypatch.delenv("SCORE_NO_REPLICATION", raising=False)
+    assert res.solved and res.info["newton_iters"] > 0, res.info
+    gold = load_golden(name)
+    assert res.info["pobj"] == pytest.approx(float(gold["objective"]), rel=1e-5, abs=1e-6)
+    compare_with_golden(res, gold, pose_tol=1e-4)
+
+
 def test_qcqp_direct_on_gpu(fixtures, hip_lib, monkeypatch):
     """The reference's default relaxation handed over as it is (gurobi_utils.py:341-344, :488-496): the library rewrites the
     constant-head unit-ball cones into private-head cones (csrc/score_headform.hpp), so the direct form takes the same
