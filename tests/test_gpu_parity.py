@@ -521,6 +521,7 @@ def test_qcqp_direct_on_gpu(fixtures, hip_lib, monkeypatch):
     in comparable time; the directions r_ij come back in closed form.  SCORE_QCQP_PLAIN=1: the plain loop of rounds 1-4."""
     fg = fixtures["manhattan"]
     gold = load_golden("manhattan")
+    monkeypatch.delenv("SCORE_QCQP_PLAIN", raising=False)
     solve_score(fg, "QCQP"); solve_score(fg, "QCQP", qcqp_mode="direct")  # (warm: first handles of a process pay for the runtime)
     a = solve_score(fg, "QCQP")
     b = solve_score(fg, "QCQP", qcqp_mode="direct")
