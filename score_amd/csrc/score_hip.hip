@@ -1990,7 +1990,7 @@ struct HipBackend {
         join_tmp_p.alloc((size_t)h.n_tot); join_tmp_rz.alloc(h.prec_work.size() + 4096);  // (every workgroup of a chain-kernel launch has a slot: work items + update helpers)
         join_positions(K.ptr.d, K.col.d, join_posd_K, join_poss_K);
         if (st.verbose) std::fprintf(stderr, "[score setup] long chains: %d in %d segments of <= %d nodes (second level: score_join.hpp)\n",
-                                     n_join_chains, n_join_items, kSegMaxNodes);
+                                     n_join_chains, n_join_items, seg_max_nodes());
     }
     void join_positions(const int32_t* ptr, const int32_t* col, DevBuf<int32_t>& posd, DevBuf<int32_t>& poss) {
         const size_t b2 = (size_t)H->bs * H->bs;

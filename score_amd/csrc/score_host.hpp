@@ -834,6 +834,14 @@ inline void chain_solve_host(const ChainDesc& ch, const ChainLevelDesc* levels, 
 // separators' Schur system (block tridiagonal, n_seg - 1 nodes) and corrects the segments with their spikes: together the
 // exact solve with the whole chain's block-tridiagonal matrix, as the streaming kernel computes it.
 constexpr int kSegMaxNodes = 1023;
+inline int seg_max_nodes() {  // (SCORE_SEG_NODES: shorter segments, for experiments -- profiles/TRIED.md)
+    static const int v = [] {
+        const char* e = std::getenv("SCORE_SEG_NODES");
+        const int x = e ? std::atoi(e) : kSegMaxNodes;
+        return x < 15 ? 15 : (x > kSegMaxNodes ? kSegMaxNodes : x);
+    }();
+    return v;
+}
 struct JoinChain {
     int32_t prob, n_seg;
     int32_t first_chain;  // H.chains index of segment 0 (the segments follow)
@@ -1766,7 +1774,8 @@ inline void build_system(const score_problem* probs, int count, const score_sett
             if (ne - nb > max_nodes) throw std::runtime_error("chain too long");
             // a chain of more than kSegMaxNodes nodes: segments with one separator node between neighbours (JoinChain)
             const int Nall = ne - nb;
-            const int n_seg = (segments_ok && Nall > kSegMaxNodes) ? (Nall + 1 + kSegMaxNodes) / (kSegMaxNodes + 1) : 1;
+            const int seg_max = seg_max_nodes();
+            const int n_seg = (segments_ok && Nall > seg_max) ? (Nall + 1 + seg_max) / (seg_max + 1) : 1;
             if (n_seg > 1) {
                 JoinChain jc{};
                 jc.prob = p; jc.n_seg = n_seg; jc.first_chain = (int32_t)H.chains.size();
