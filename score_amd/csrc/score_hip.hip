@@ -2241,12 +2241,13 @@ struct HipBackend {
             if (phase == 0 && us > spin_us) phase = 1;
             else if (phase == 1 && us > 2000.0) phase = 2;
             else if (us > 2e6) {
+                release_prequeued();  // (a fetch waiting for the host's words would keep the stream from draining)
                 HIP_CHECK(hipStreamSynchronize(stream));
                 if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) < seq) throw std::runtime_error("device did not publish its results");
                 break;
             }
         }
-        ring_used = 0;  // everything queued before the publish has run: all ring slots are free again
+        ring_used = pre_slot ? 1 : 0;  // everything queued before the publish has run: those ring slots are free again
     }
 
     DevBuf<double> iter_block;  // xtu | xy | s | r | z | p | p2 | w | kx | step | pw_part | rz_part0/1 | rz_meas0/1
@@ -3487,6 +3488,7 @@ struct HipBackend {
             return polish_lockstep(h, s_, done_host, newton_iters, cg_used, dual_scale);
         } catch (const std::exception& e) {
             if (st.verbose) std::fprintf(stderr, "[score] polish abandoned: %s\n", e.what());
+            release_prequeued();  // (a fetch waiting for the host's words would keep the stream from draining)
             (void)hipStreamSynchronize(stream);
             (void)hipGetLastError();
             return false;
@@ -3495,7 +3497,7 @@ struct HipBackend {
 
     // Generalised Hessian from the cone blocks of the last evaluation (q_Bbuf), the Jacobi diagonal
     // and the chain factors of the Newton preconditioner (device-side factorisation)
-    void newton_hessian(const int32_t* skip = nullptr, bool refactor = true) {
+    void launch_hassemble() {
         const HostSystem& h = *H;
         HAsmArgs ha{};
         ha.nnz = hm_nnz; ha.Pon = q_Pon.d; ha.cptr = q_cptr.d; ha.ccone = q_ccone.d; ha.cab = q_cab.d;
@@ -3507,6 +3509,10 @@ struct HipBackend {
         hipLaunchKernelGGL(k_hassemble, dim3((unsigned)((int64_t)base_blocks * h.count + n_long)), dim3(kThreads), 0, stream, ha, (const int32_t*)q_long.d,
                            (const int32_t*)q_long_prob.d, base_blocks, h.count);
         HIP_CHECK(hipGetLastError());
+    }
+    void newton_hessian(const int32_t* skip = nullptr, bool refactor = true) {
+        if (!hassemble_queued) launch_hassemble();  // (queued ahead by prequeue_control() otherwise)
+        hassemble_queued = false;
         if (n_prec_items() && refactor) {  // chain factors and the reciprocal Jacobi diagonal, one launch
             FactorArgs fa{};
             fa.work = prec_work.d; fa.chains = chainsH.d; fa.levels = levelsH.d; fa.Hval = Hm.val.d;
@@ -3535,21 +3541,74 @@ struct HipBackend {
     //   fskip: ... are not (the skip flags of the factor kernels).  Both return to "no" after one upload.
     std::vector<double> c_step, c_tol2;
     std::vector<int32_t> c_skip, c_reref;
-    void upload_control() {
+    void fill_control(char* v) {
         const size_t c = c_skip.size();
-        if (c_reref.size() != c) c_reref.assign(c, 0);
-        char* v = next_ring_slot(ctl.n * sizeof(double));
         std::memcpy(v, c_step.data(), c * sizeof(double));
         std::memcpy(v + c * sizeof(double), c_tol2.data(), c * sizeof(double));
         int32_t* w = (int32_t*)(v + 2 * c * sizeof(double));
         std::memcpy(w, c_skip.data(), c * sizeof(int32_t));
         for (size_t i = 0; i < c; ++i) { w[c + i] = c_reref[i]; w[2 * c + i] = c_reref[i] ? 0 : 1; }
+    }
+    // `consume`: the upload that opens a Newton iteration -- if prequeue_control() queued its fetch (and the Hessian assembly
+    // behind it) before the host's wait, the words go into that slot and its flag is raised: no launch.  Any other upload
+    // finds a pending slot released with "skip everything" first (the assembly behind it then does nothing).
+    void upload_control(bool consume = false) {
+        const size_t c = c_skip.size();
+        if (c_reref.size() != c) c_reref.assign(c, 0);
+        if (pre_slot) {
+            if (consume) {
+                fill_control(pre_slot);
+                raise_prequeued();
+                hassemble_queued = true;
+                std::fill(c_reref.begin(), c_reref.end(), 0);
+                return;
+            }
+            release_prequeued();
+        }
+        char* v = next_ring_slot(ctl.n * sizeof(double));
+        fill_control(v);
         fetch_words((int32_t*)ctl.d, v, (int)(4 * c + 3 * c));
         std::fill(c_reref.begin(), c_reref.end(), 0);
     }
-    void upload_skip(const std::vector<char>& live) {  // skip = !live
+    // ---- the next Newton iteration's control fetch + Hessian assembly, queued before the host waits for this one's results:
+    //      the device goes on a PCIe round trip after the host has decided instead of a launch latency after it (the assembly
+    //      covers the launches that follow).  Between prequeue_control() and the raise / release the host calls nothing that
+    //      waits for the stream: wait_published() polls memory (its fall-back releases first), next_ring_slot() is not called.
+    char* pre_slot = nullptr;
+    unsigned long long pre_expect = 0;
+    bool hassemble_queued = false;
+    size_t pre_flag_offset() const { return (ctl.n * sizeof(double) + 7) & ~(size_t)7; }
+    void prequeue_control() {
+        static const bool off = std::getenv("SCORE_NO_PREQUEUE") != nullptr;
+        if (off || pre_slot) return;
+        const size_t c = c_skip.size();
+        char* v = next_ring_slot(pre_flag_offset() + 8);
+        __atomic_store_n((unsigned long long*)(v + pre_flag_offset()), 0ull, __ATOMIC_RELEASE);
+        pre_slot = v;
+        pre_expect = ++pre_seq_next;
+        const char* d = d_ring + (v - h_ring);
+        hipLaunchKernelGGL(k_fetch_wait, dim3(1), dim3(kThreads), 0, stream, (const int32_t*)d, (int32_t*)ctl.d, (int)(7 * c),
+                           (const unsigned long long*)(d + pre_flag_offset()), pre_expect);
+        launch_hassemble();
+    }
+    unsigned long long pre_seq_next = 0;
+    void raise_prequeued() {
+        __atomic_store_n((unsigned long long*)(pre_slot + pre_flag_offset()), pre_expect, __ATOMIC_RELEASE);
+        pre_slot = nullptr;
+    }
+    void release_prequeued() {  // "skip everything": the queued assembly finds no problem to work on
+        if (!pre_slot) return;
+        const size_t c = c_skip.size();
+        double* v = (double*)pre_slot;
+        for (size_t i = 0; i < c; ++i) { v[i] = 1.0; v[c + i] = 0.0; }
+        int32_t* w = (int32_t*)(pre_slot + 2 * c * sizeof(double));
+        for (size_t i = 0; i < c; ++i) { w[i] = 1; w[c + i] = 0; w[2 * c + i] = 1; }
+        raise_prequeued();
+        hassemble_queued = false;
+    }
+    void upload_skip(const std::vector<char>& live, bool consume = false) {  // skip = !live
         for (size_t i = 0; i < live.size(); ++i) c_skip[i] = live[i] ? 0 : 1;
-        upload_control();
+        upload_control(consume);
     }
     void upload_flags(const std::vector<int32_t>& f) {  // nonzero = selected
         c_skip = f;
@@ -3805,7 +3864,7 @@ struct HipBackend {
                 for (int p = 0; p < count; ++p) if (live[p]) { mx = std::max(mx, act_flips[p]); nre += c_reref[p]; }
                 std::fprintf(stderr, "[score] newton it %d: active-set flips since the last factorisation (max over live problems) %.0f -> %d problems refactor\n", it + 1, mx, nre);
             }
-            upload_skip(live);
+            upload_skip(live, /*consume=*/true);
             np_newton_it = it;
             newton_hessian(q_fskip.d, refactor);  // (a frozen problem's short entries keep their values, see k_hassemble)
             static const bool guess_queue = std::getenv("SCORE_PCG_GUESS") != nullptr;  // (the round-2 queue: a length guessed from the previous iteration)
@@ -3826,6 +3885,9 @@ struct HipBackend {
                 va.u = X; va.delta = q_delta.d; va.step = 0.0; va.out = Xt;
                 hipLaunchKernelGGL(k_newton_trial_b, dim3(nbh), dim3(kThreads), 0, stream, va, batch_tables());
                 newton_eval_enqueue(Xt);  // overwrites nu / B / g of the problems searched; copies gd and the gate words too
+                // (the usual course -- full step accepted, next iteration -- starts with a control upload and the assembly of H
+                //  from the blocks this evaluation leaves: both queued now, behind the evaluation, waiting for the host's words)
+                if (k == 0 && !control_stale && it + 1 < it_max) prequeue_control();
                 wait_published(eval_seq);  // the one wait of a Newton iteration (step 1 accepted)
                 if (k == 0) {
                     // a problem whose queue ran dry before its gate fired resumes its PCG (state intact);

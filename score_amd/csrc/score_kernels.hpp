@@ -2433,6 +2433,17 @@ __global__ __launch_bounds__(kThreads) void k_push(PushArgs a) {
 __global__ __launch_bounds__(kThreads) void k_fetch(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int n_words) {
     for (int i = threadIdx.x; i < n_words; i += kThreads) dst[i] = src[i];
 }
+// The same, queued BEFORE the host has written the words: the lead lane waits for the slot's flag (host-mapped memory, raised by
+// the host after the payload), then the words are copied.  Whoever queues this must raise the flag without calling the runtime
+// in between (HipBackend::prequeue_control).
+__global__ __launch_bounds__(kThreads) void k_fetch_wait(const int32_t* src, int32_t* __restrict__ dst, int n_words,
+                                                         const unsigned long long* flag, unsigned long long expect) {
+    if (threadIdx.x == 0) {
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != expect) __builtin_amdgcn_s_sleep(4);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_words; i += kThreads) dst[i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // K = K0 + rho[prob] * K1 on the fixed pattern (grid = K row blocks; one tile of <= kTileNnz entries each,
 // or one long row)
