@@ -3579,8 +3579,7 @@ struct HipBackend {
     bool hassemble_queued = false;
     size_t pre_flag_offset() const { return (ctl.n * sizeof(double) + 7) & ~(size_t)7; }
     void prequeue_control() {
-        static const bool off = std::getenv("SCORE_NO_PREQUEUE") != nullptr;
-        if (off || pre_slot) return;
+        if (pre_slot || std::getenv("SCORE_NO_PREQUEUE") != nullptr) return;  // (read at every call: the GPU test switches it in-process)
         const size_t c = c_skip.size();
         char* v = next_ring_slot(pre_flag_offset() + 8);
         __atomic_store_n((unsigned long long*)(v + pre_flag_offset()), 0ull, __ATOMIC_RELEASE);
@@ -3812,7 +3811,10 @@ struct HipBackend {
         std::vector<double> F(count, 0.0), gn(count, 0.0), Ft(count, 0.0), gt(count, 0.0), eta(count, 0.0);
         std::vector<double> step(count, 1.0), gd(count, 0.0);
         upload_skip(part);
-        newton_eval_batch(X, part, F, gn);
+        newton_eval_enqueue(X);
+        prequeue_control();  // (the first iteration's control words and assembly: see the loop)
+        wait_published(eval_seq);
+        newton_eval_collect(part, F, gn);
         const double tol = std::max(1e-12, 0.3 * s_.eps_abs);
         std::vector<double> tolp(count, tol);
         if (dual_scale)

@@ -498,6 +498,36 @@ def test_solve_score_matches_golden(name, relax, fixtures, hip_lib):
     compare_residuals_with_golden(res, fg, gold, tol=1e-4)
 
 
+def test_newton_control_queued_ahead_is_bit_equal(fixtures, hip_lib, monkeypatch):
+    """The polish queues the next Newton iteration's control fetch and Hessian assembly before the host waits for the
+    evaluation (k_fetch_wait: released by the host's words; HipBackend::prequeue_control).  Against the launch after the
+    decision (SCORE_NO_PREQUEUE=1): same Newton iterations, x, y, s to the last bit -- single problems (2-D fixture, GOATS with
+    its step-length searches, 3-D), a lock-step batch whose members finish at different iterations, and a handle solved twice."""
+    _hip_only(hip_lib)
+    from score_amd.native import assemble_native
+
+    cases = [[assemble_native(graph_by_name(nm, fixtures), "SOCP", lib_path=hip_lib).qp] for nm in ("manhattan", "goats", "graph3d", "synth_b")]
+    cases.append([assemble_native(make_manhattan(n_robots=2 + k, n_poses=120 + 90 * k, n_beacons=3, seed=70 + k, p_range=0.2 + 0.1 * k), "SOCP", lib_path=hip_lib).qp
+                  for k in range(4)])
+    for qps in cases:
+        runs = {}
+        for off in (False, True):
+            if off:
+                monkeypatch.setenv("SCORE_NO_PREQUEUE", "1")
+            else:
+                monkeypatch.delenv("SCORE_NO_PREQUEUE", raising=False)
+            sv = ConicSolver(qps, {}, lib_path=hip_lib)
+            first = sv.solve()
+            runs[off] = (first, sv.solve())
+            sv.close()
+        monkeypatch.delenv("SCORE_NO_PREQUEUE", raising=False)
+        for a_run, b_run in zip(runs[False], runs[True]):
+            for a, b in zip(a_run, b_run):
+                assert a.solved and b.solved and a.info["newton_iters"] == b.info["newton_iters"] > 0
+                assert a.info["newton_cg_iters"] == b.info["newton_cg_iters"]
+                assert np.array_equal(a.x, b.x) and np.array_equal(a.y, b.y) and np.array_equal(a.s, b.s)
+
+
 @pytest.mark.parametrize("name", ["manhattan", "graph3d"])
 def test_solve_score_without_replication(name, fixtures, hip_lib, monkeypatch):
     """The experiment switch SCORE_NO_REPLICATION through the product entry point: the graph assembler on the device writes one
