@@ -17,6 +17,9 @@ sel = rows[i0:i1]
 t0, t1 = sel[0][1], sel[-1][2]
 busy = sum(e - s for _, s, e in sel)
 print(f"one default solve: {len(sel)} kernels over {1e-3*(t1-t0):.1f} us; kernel time {1e-3*busy:.1f} us ({100*busy/(t1-t0):.1f} % busy)")
+wait = sum(e - s for n, s, e in sel if "k_fetch_wait" in n)
+if wait:
+    print(f"   of which k_fetch_wait (one workgroup polling a host-mapped flag: the host's decision) {1e-3*wait:.1f} us; without it {100*(busy-wait)/(t1-t0):.1f} % busy")
 gaps = []
 for (n0, s0, e0), (n1, s1, e1) in zip(sel[:-1], sel[1:]):
     gaps.append((s1 - e0, n0.split("(")[0][-40:], n1.split("(")[0][-40:]))
