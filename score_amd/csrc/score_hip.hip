@@ -907,6 +907,7 @@ struct HipBackend {
             std::fprintf(stderr, "[score host] Newton PCG queueing: %.2f ms for %ld launches (%.2f us each); waits: %ld, %.2f ms\n", enq_ms, enq_launches,
                          enq_launches ? 1e3 * enq_ms / (double)enq_launches : 0.0, waits, wait_ms);
         PhaseTimer pt(st.verbose != 0);
+        if (pre_slot && h_ring) release_prequeued();  // (never pending here; a kernel waiting for the host must not outlive its ring)
         if (stream) (void)hipStreamSynchronize(stream);
         pt.mark("destroy: sync");
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
@@ -3793,6 +3794,8 @@ struct HipBackend {
         *newton_iters = 0; *cg_used = 0;
         pcg_used_total = 0;
         const double t_start = now_ms();
+        release_prequeued();  // (nothing is pending between solves: every exit below releases; this is the belt to those braces)
+        hassemble_queued = false;
         c_step.assign(h.count, 1.0); c_tol2.assign(h.count, 0.0); c_skip.assign(h.count, 0);
         if (!Q.available) return false;
         const int count = h.count, nbh = Hm.nblocks;
