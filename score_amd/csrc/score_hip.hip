@@ -512,6 +512,12 @@ struct ZeroGroup {
     }
 };
 
+// SCORE_NO_LONG_SPIN=1: the split long rows of every matrix go through the ticket path (CsrDev::long_spin)
+inline bool long_spin_enabled() {
+    static const bool on = std::getenv("SCORE_NO_LONG_SPIN") == nullptr;
+    return on;
+}
+
 struct CsrBufs {
     DevBuf<int32_t> ptr, col, first_row, blk_prob, blk_rs, split;
     DevBuf<int4> blk_meta, blk_long;
@@ -521,7 +527,10 @@ struct CsrBufs {
         long_part.alloc((size_t)std::max(1, n_slots) * kLongVals);
         long_cnt.alloc((size_t)std::max(1, n_long));
         HIP_CHECK(hipMemsetAsync(long_cnt.d, 0, long_cnt.n * sizeof(unsigned long long), tl_copy_stream));
+        // (every slot starts as "not published": the polling mode of the split rows -- CsrDev::long_spin -- reads it that way)
+        HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)long_part.d, (int)kLongSentinel32, long_part.n * 2, tl_copy_stream));
     }
+    int spin_max_tiles = 0;  // long_spin when the matrix has at most this many tiles (0: never); set where the matrix is made
     DevBuf<double> val;
     int nblocks = 0;
     int rep = 1;     // right-hand sides per row of the replicated blocks (HostSystem::rep), 1 = plain rows only
@@ -578,7 +587,10 @@ struct CsrBufs {
         if (sp) split.upload(*sp);
         nblocks = rb.nb();
     }
-    CsrDev dev() const { return CsrDev{ptr.d, col.d, val.d, first_row.d, blk_prob.d, blk_meta.d, blk_rs.d, split.d, nblocks, blk_long.d, long_part.d, long_cnt.d}; }
+    CsrDev dev() const {
+        return CsrDev{ptr.d, col.d, val.d, first_row.d, blk_prob.d, blk_meta.d, blk_rs.d, split.d, nblocks, blk_long.d, long_part.d, long_cnt.d,
+                      (nblocks <= spin_max_tiles && long_spin_enabled()) ? 1 : 0};
+    }
 };
 
 // Device side of a band view (score_band.hpp): the unified tile tables, V and the remainder arrays.  The source CsrBufs
@@ -613,6 +625,7 @@ struct BandBufs {
         long_part.alloc((size_t)std::max(1, L.n_long_slots) * kLongVals);
         long_cnt.alloc((size_t)std::max(1, L.n_long));
         HIP_CHECK(hipMemsetAsync(long_cnt.d, 0, long_cnt.n * sizeof(unsigned long long), tl_copy_stream));
+        HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)long_part.d, (int)kLongSentinel32, long_part.n * 2, tl_copy_stream));
     }
     BandDev dev() const {
         BandDev d{};
@@ -1520,6 +1533,13 @@ struct HipBackend {
         } stage_scope(st.device, stream);
         HIP_CHECK(hipEventCreate(&ev0));
         HIP_CHECK(hipEventCreate(&ev1));
+        {   // split long rows finished by polling (CsrDev::long_spin) only where the whole launch is resident at once: every
+            // SpMV kernel fits two workgroups per CU (<= 216 registers), the products with the Newton matrix six (<= 82)
+            int cus = 0;
+            HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st.device));
+            K.spin_max_tiles = G1.spin_max_tiles = G2.spin_max_tiles = cus * 3 / 2;
+            Hm.spin_max_tiles = cus * 4;
+        }
         pt.mark("device + stream");
         if (h.bs != 0 && h.bs != 3 && h.bs != 4 && h.bs != 1 && h.bs != 2)
             throw std::runtime_error("unsupported block size");
@@ -2397,6 +2417,7 @@ struct HipBackend {
         SpmvArgs a = a_in;
         a.M.blk_meta = Bv.meta.d; a.M.blk_prob = Bv.prob.d; a.M.blk_rs = Bv.rs.d; a.M.nblocks = Bv.nblocks;
         a.M.blk_long = Bv.lng.d; a.M.long_part = Bv.long_part.d; a.M.long_cnt = Bv.long_cnt.d;
+        a.M.long_spin = (Bv.nblocks <= M.spin_max_tiles && long_spin_enabled()) ? 1 : 0;
         a.B = Bv.dev();
         const unsigned grid = xcd_grid(a, Bv.nblocks);
         if (M.rep == 2) launch_band_s<MODE, 2>(Bv, a, grid, slot);

@@ -140,7 +140,14 @@ struct CsrDev {
     const int4* blk_long;
     double* long_part;
     unsigned long long* long_cnt;
+    // 1: the segments of a split row publish their sums and LEAVE; segment 0 polls the slots until every sum has arrived (a
+    //    slot holds kLongSentinel until then), adds them in segment order and resets the slots.  Only for matrices whose whole
+    //    launch is resident at once (the host decides by the number of tiles: a polling workgroup must never wait for one that
+    //    has not been given a CU yet).  0: the ticket path (the segment that draws the last ticket finishes the row).
+    int long_spin;
 };
+constexpr unsigned long long kLongSentinel = 0x7ff8dead7ff8deadull;  // a NaN no sum can be (payload), both halves equal: filled by a 32-bit memset
+constexpr unsigned kLongSentinel32 = 0x7ff8deadu;
 
 // Optional device-side timing of one launch (score_time_iteration): the first lane of every
 // workgroup stores the wall clock at entry / exit into its own slot ts[2 b], ts[2 b + 1]; the host
@@ -334,13 +341,42 @@ __device__ __forceinline__ void fused_cone_u(const FuseArgs& f, const int i0, co
     }
 }
 
+// The FIRST trip of a tile kernel: everything that depends on the tile index alone -- the tile record(s), the problem, the
+// replica stride, the split-row record -- and, for single-problem handles, the frozen flag of problem 0, requested back to back
+// and waited for ONCE.  Written as one pinned group because the compiler otherwise sinks each of these uniform loads to its
+// first use behind a branch of its own and a tile starts with four dependent trips (record -> problem -> stride -> flag)
+// instead of one; the values are made scalar again by readfirstlane (they are uniform: the address is).
+struct TileHead {
+    int4 meta, m2, lg;
+    int prob, rs, dn0;
+};
+#define SCORE_RFL(x) (x) = __builtin_amdgcn_readfirstlane(x)
+template <int NR, bool BAND>
+__device__ __forceinline__ TileHead tile_head(const SpmvArgs& a, const int b) {
+    TileHead h;
+    h.meta = a.M.blk_meta[b];
+    h.m2 = BAND ? a.B.meta2[b] : make_int4(0, 0, 0, 0);
+    h.lg = a.M.blk_long[b];
+    h.prob = a.M.blk_prob[b];
+    h.rs = (NR > 1) ? a.M.blk_rs[b] : 0;
+    h.dn0 = a.done[0];
+    asm volatile("" : "+v"(h.meta.x), "+v"(h.meta.y), "+v"(h.meta.z), "+v"(h.meta.w), "+v"(h.m2.x), "+v"(h.m2.y), "+v"(h.m2.z), "+v"(h.m2.w),
+                      "+v"(h.lg.x), "+v"(h.lg.y), "+v"(h.lg.z), "+v"(h.lg.w), "+v"(h.prob), "+v"(h.rs), "+v"(h.dn0));
+    SCORE_RFL(h.meta.x); SCORE_RFL(h.meta.y); SCORE_RFL(h.meta.z); SCORE_RFL(h.meta.w);
+    SCORE_RFL(h.m2.x); SCORE_RFL(h.m2.y); SCORE_RFL(h.m2.z); SCORE_RFL(h.m2.w);
+    SCORE_RFL(h.lg.x); SCORE_RFL(h.lg.y); SCORE_RFL(h.lg.z); SCORE_RFL(h.lg.w);
+    SCORE_RFL(h.prob); SCORE_RFL(h.rs); SCORE_RFL(h.dn0);
+    if (a.uni.on) h.prob = 0;
+    return h;
+}
+
 // One tile (row block) of the SpMV with NR right-hand sides per matrix row.  NR == 1: plain CSR rows.  NR > 1: the
 // rows of replica 0 of a problem whose operator is I_NR (x) K_row -- the matrix stream (12 B per nonzero) is read
 // once, the gathers and the LDS products are per replica; sums are per replica in CSR order, so every replica gets
 // exactly what a plain SpMV on its own copy of the rows would give.
 template <int MODE, int NR, int UNR = kUnroll>
-__device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, const int4 meta, const int prob, const int my_ptr, const int end_ptr,
-                                          const int rs_out, double* __restrict__ prod, double* red, int32_t* srow, const int4 lg = make_int4(0, 0, 0, 0)) {
+__device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, const int4 meta, const int prob, const int end_ptr,
+                                          const int rs_out, double* __restrict__ prod, double* red, int32_t* srow, const int4 lg, const int dn0) {
     static_assert(NR == 1 || (MODE != MODE_DRES && MODE != MODE_GRAD), "residual / gradient modes run on plain rows");
     auto kpad = [](int k) -> int { return k + (k >> 3); };
     constexpr int kPlane = UNR * kThreads + UNR * kThreads / 8;  // one padded plane of products per right-hand side
@@ -352,13 +388,26 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
     const int32_t* __restrict__ col = a.M.col;
     const double* __restrict__ xin = (MODE == MODE_KPB) ? a.z : a.xin;
 
-    // KPB: beta = r'z_new / r'z_old.  The partial sums are requested here, but reduced
-    // (two barriers) only after the matrix and vector loads of the tile are in flight.
-    double beta = 0.0, acc_n = 0.0, acc_o = 0.0;
-    if (MODE == MODE_KPB) {
-        const int l0 = a.uni.on ? a.uni.l0 : a.prec_part_ptr[prob], l1 = a.uni.on ? a.uni.l1 : a.prec_part_ptr[prob + 1];
-        for (int i = l0 + t; i < l1; i += kThreads) { acc_n += a.rz_new[i]; acc_o += a.rz_old[i]; }
+    // (gated PCG solves queue launches that are MEANT to be no-ops: they test the flag before anything else is requested)
+    if (a.early_done) {
+        const int d = a.uni.on ? dn0 : a.done[prob];
+        if (d) return;
     }
+    // KPB: beta = r'z_new / r'z_old.  The ranges of the partial sums are requested with the second trip (a batch member's:
+    // single problems carry them in the arguments), the partials with the third -- load_partials(), called once the tile's
+    // matrix entries and gathers are in flight -- and reduced (two barriers) after that.
+    double beta = 0.0, acc_n = 0.0, acc_o = 0.0;
+    int pi0 = 0, pl1 = 0;
+    if (MODE == MODE_KPB) {
+        pi0 = (a.uni.on ? a.uni.l0 : a.prec_part_ptr[prob]) + t;
+        pl1 = a.uni.on ? a.uni.l1 : a.prec_part_ptr[prob + 1];
+    }
+    auto load_partials = [&]() {
+        if (MODE == MODE_KPB) {  // (the first 256 by their own lanes -- every handle so far --, the rest in a loop; the order of the sums is the loop's)
+            if (pi0 < pl1) { acc_n = a.rz_new[pi0]; acc_o = a.rz_old[pi0]; }
+            for (int i = pi0 + kThreads; i < pl1; i += kThreads) { acc_n += a.rz_new[i]; acc_o += a.rz_old[i]; }
+        }
+    };
     // RHS: the step length of the last PCG step was published by the cone kernel -- or (fused cones, FuseArgs) is formed
     // here from the partial sums of r'z and p'w, in k_cone's order
     const bool fuse = (MODE == MODE_RHS) && a.F.on;
@@ -387,8 +436,8 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
     // The frozen-problem flag and the operands of the epilogue (this lane's own vector entries) are requested together
     // with the matrix entries, on a clamped row: every trip to memory the tile needs is then in flight before the
     // first wait -- tile record -> {matrix, row pointers, own entries, flag} -> gathers -- instead of five dependent trips.
-    const int dn = a.done[prob];
-    if (a.early_done && dn) return;
+    const int dn = a.uni.on ? dn0 : a.done[prob];
+    const int my_ptr = a.M.ptr[min(r0 + t, r1)];
     const int nseg = lg.y & 0xffff;  // > 1: this block is one segment of a split long row
     const bool one_long = (r1 - r0 == 1 && (nn > kLongRow || nseg > 1));
     int b = b_in;                    // (the last segment to arrive writes the row's partial sums into the FIRST segment's slot)
@@ -414,6 +463,7 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
 #pragma unroll
         for (int q = 0; q < NR; ++q) acc[q] = 0.0;
         const int split = (MODE == MODE_DRES || MODE == MODE_GRAD) ? a.M.split[r0] : k1;
+        load_partials();
         if (dn) return;  // (uniform over the workgroup)
         finish_beta();  // uniform: lanes beyond the row's end never enter the sweep
         for (int kb = k0 + t; kb < k1; kb += kThreads * kLongUnroll) {
@@ -456,7 +506,62 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
             sum[0] = acc[0]; sum[1] = acc[1];
             if (NR > 2) sum[NR - 1] = block_sum(acc[NR - 1], red);
         }
-        if (nseg > 1) {
+        const bool spin = nseg > 1 && a.M.long_spin && nseg * kLongVals <= NR * kPlane;
+        if (spin) {
+            // Polling mode (CsrDev::long_spin: the whole launch is resident): segments 1 .. nseg-1 publish their sums and leave;
+            // segment 0 keeps requesting all slots at once until none holds the sentinel any more, adds the sums in SEGMENT
+            // order -- as the ticket path does: the result does not depend on who arrives when -- and puts the sentinels back
+            // for the next launch.  Against the ticket path a row saves the drain of its stores, the ticket's round trip and
+            // a dependent read-back: the split rows are the last workgroups out of every product.
+            constexpr int NV = NR + ((MODE == MODE_DRES || MODE == MODE_GRAD) ? 1 : 0);
+            const int sgi = lg.y >> 16;
+            unsigned long long* allb = reinterpret_cast<unsigned long long*>(a.M.long_part + (size_t)lg.z * kLongVals);
+            if (sgi != 0) {
+                if (t == 0) {
+                    unsigned long long* slot = allb + (size_t)sgi * kLongVals;
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) __hip_atomic_store(slot + q, (unsigned long long)__double_as_longlong(sum[q]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (MODE == MODE_DRES || MODE == MODE_GRAD)
+                        __hip_atomic_store(slot + NR, (unsigned long long)__double_as_longlong(sum2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                return;  // (uniform)
+            }
+            const int total = nseg * kLongVals;
+            int ok = 0;
+            for (int tries = 0; !ok && tries < (1 << 22); ++tries) {  // (bounded: a launch that could not be resident ends in NaNs, not in a hang)
+                ok = 1;
+                for (int i = kLongVals + t; i < total; i += kThreads) {
+                    if ((i % kLongVals) < NV) {
+                        const unsigned long long bits = __hip_atomic_load(allb + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (bits == kLongSentinel) ok = 0;
+                        else prod[i] = __longlong_as_double((long long)bits);
+                    }
+                }
+                ok = __syncthreads_and(ok);
+            }
+            for (int i = kLongVals + t; i < total; i += kThreads)
+                if ((i % kLongVals) < NV) __hip_atomic_store(allb + i, kLongSentinel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t == 0) {
+                double tot[kLongVals] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < NR; ++q) tot[q] += sum[q];  // (0.0 + own sum: what the ticket path's loop starts with)
+                if (MODE == MODE_DRES || MODE == MODE_GRAD) tot[NR] += sum2;
+                for (int sg = 1; sg < nseg; ++sg) {
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) tot[q] += prod[sg * kLongVals + q];
+                    if (MODE == MODE_DRES || MODE == MODE_GRAD) tot[NR] += prod[sg * kLongVals + NR];
+                }
+                const double fail = ok ? 0.0 : __builtin_nan("");
+#pragma unroll
+                for (int q = 0; q < NR; ++q) sum[q] = tot[q] + fail;
+                if (MODE == MODE_DRES || MODE == MODE_GRAD) sum2 = tot[NR] + fail;
+            }
+            if (MODE == MODE_KP || MODE == MODE_KPB)
+                for (int i = 1 + t; i < nseg; i += kThreads) a.pw_part[lg.x + i] = 0.0;
+            if (MODE == MODE_DRES || MODE == MODE_GRAD)
+                for (int i = kPartStride + t; i < nseg * kPartStride; i += kThreads) a.dres_part[(size_t)lg.x * kPartStride + i] = 0.0;
+            b = lg.x;
+        } else if (nseg > 1) {
             // A segment publishes its sums (agent-scope stores, drained) and takes a ticket; every launch adds `nseg` to the
             // row's counter, so the segment that draws the last ticket of the launch knows that all sums are out: it adds them
             // in SEGMENT order -- the result does not depend on who arrives when -- and finishes the row; the others leave.
@@ -520,6 +625,7 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
                 for (int q = 0; q < NR; ++q) g[u][q] = xin[c[u] + q * rs_in];
             }
         }
+        load_partials();
         if (dn) return;  // (uniform over the workgroup; nothing has been written)
         finish_beta();
         if (fuse) {
@@ -678,16 +784,11 @@ __global__ __launch_bounds__(kThreads) void k_spmv(SpmvArgs a) {
     const int b = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (b >= a.n_tiles) return;
     const int t = threadIdx.x;
-    // one 16-byte load gives the whole tile geometry; the frozen-problem flag and the
-    // tile's row pointers are requested together with it
-    const int4 meta = a.M.blk_meta[b];
-    const int prob = a.uni.on ? 0 : a.M.blk_prob[b];
-    const int rs = (NR > 1) ? a.M.blk_rs[b] : 0;
-    const int my_ptr = a.M.ptr[min(meta.x + t, meta.y)];
-    const int end_ptr = (t == 0) ? meta.w : 0;
-    const int4 lg = a.M.blk_long[b];
-    if (NR > 1 && rs > 0) spmv_tile<MODE, NR, UNR>(a, b, meta, prob, my_ptr, end_ptr, rs, prod, red, srow, lg);
-    else spmv_tile<MODE, 1, UNR>(a, b, meta, prob, my_ptr, end_ptr, 0, prod, red, srow, lg);
+    // first trip: the tile record, its problem, stride, split-row record and (single problem) the frozen flag -- tile_head
+    const TileHead h = tile_head<NR, false>(a, b);
+    const int end_ptr = (t == 0) ? h.meta.w : 0;
+    if (NR > 1 && h.rs > 0) spmv_tile<MODE, NR, UNR>(a, b, h.meta, h.prob, end_ptr, h.rs, prod, red, srow, h.lg, h.dn0);
+    else spmv_tile<MODE, 1, UNR>(a, b, h.meta, h.prob, end_ptr, 0, prod, red, srow, h.lg, h.dn0);
 }
 
 // ---------------------------------------------------------------------------
@@ -730,7 +831,7 @@ __device__ __forceinline__ double kp_row_finish(const SpmvArgs& a, const int row
 constexpr int kBandWin = kBandLanes + 16;
 template <int MODE, int NR, int NP, bool LDSW = false>
 __device__ __forceinline__ void band_tile(const SpmvArgs& a, const int b, const int4 meta, const int4 m2, const int prob, const int rs_out,
-                                          double* __restrict__ prod, double* red, double* __restrict__ win = nullptr) {
+                                          const int dn0, double* __restrict__ prod, double* red, double* __restrict__ win = nullptr) {
     static_assert(MODE == MODE_KP || MODE == MODE_KPB, "band tiles serve the K / H products");
     constexpr int kPlane = kBandRemMax + kBandRemMax / 8;
     auto kpad = [](int k) -> int { return k + (k >> 3); };
@@ -740,12 +841,32 @@ __device__ __forceinline__ void band_tile(const SpmvArgs& a, const int b, const 
     const int rs_in = (NR > 1) ? (a.rs_in ? a.rs_in : rs_out) : 0;
     const double* __restrict__ xin = (MODE == MODE_KPB) ? a.z : a.xin;
     double beta = 0.0, acc_n = 0.0, acc_o = 0.0;
-    if (MODE == MODE_KPB) {
-        const int l0 = a.uni.on ? a.uni.l0 : a.prec_part_ptr[prob], l1 = a.uni.on ? a.uni.l1 : a.prec_part_ptr[prob + 1];
-        for (int i = l0 + t; i < l1; i += kThreads) { acc_n += a.rz_new[i]; acc_o += a.rz_old[i]; }
+    // (gated PCG solves queue launches that are MEANT to be no-ops: they test the flag before anything else is requested)
+    if (a.early_done) {
+        const int d = a.uni.on ? dn0 : a.done[prob];
+        if (d) return;
     }
-    const int dn = a.done[prob];
-    if (a.early_done && dn) return;
+    // Second trip, requested in this order: the remainder's columns FIRST (the third trip -- their gathers -- waits for them
+    // alone: loads return in order), the ranges of the r'z partials and the frozen flag of a batch member, then the bulk.
+    constexpr int RU = kBandRemMax / kThreads;
+    int32_t c[RU];
+    double rv[RU], gx[RU][NR];
+    const int wave0 = __builtin_amdgcn_readfirstlane(t & ~63);
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+        c[u] = lo; rv[u] = 0.0;
+        if (u * kThreads + wave0 < rem_cnt) {
+            const int k = meta.w + u * kThreads + t;
+            c[u] = a.B.rem_col[k];
+            rv[u] = a.B.val[a.B.rem0 + k];
+        }
+    }
+    int pi0 = 0, pl1 = 0;
+    if (MODE == MODE_KPB) {
+        pi0 = (a.uni.on ? a.uni.l0 : a.prec_part_ptr[prob]) + t;
+        pl1 = a.uni.on ? a.uni.l1 : a.prec_part_ptr[prob + 1];
+    }
+    const int dn = a.uni.on ? dn0 : a.done[prob];
     const int row = r0 + t;
     const bool has_row = row < r1;
     const int ro = min(row, r1 - 1);
@@ -791,20 +912,7 @@ __device__ __forceinline__ void band_tile(const SpmvArgs& a, const int b, const 
         }
     }
     // the remainder: entries [0, rem_cnt) of the tile, 64 per wavefront and trip (whole wavefronts beyond the count skip)
-    constexpr int RU = kBandRemMax / kThreads;
     const int seg = a.B.rowseg[ord * kBandLanes + t];
-    int32_t c[RU];
-    double rv[RU], gx[RU][NR];
-    const int wave0 = __builtin_amdgcn_readfirstlane(t & ~63);
-#pragma unroll
-    for (int u = 0; u < RU; ++u) {
-        c[u] = lo; rv[u] = 0.0;
-        if (u * kThreads + wave0 < rem_cnt) {
-            const int k = meta.w + u * kThreads + t;
-            c[u] = a.B.rem_col[k];
-            rv[u] = a.B.val[a.B.rem0 + k];
-        }
-    }
 #pragma unroll
     for (int u = 0; u < RU; ++u) {
         if (u * kThreads + wave0 < rem_cnt) {
@@ -814,6 +922,10 @@ __device__ __forceinline__ void band_tile(const SpmvArgs& a, const int b, const 
 #pragma unroll
             for (int q = 0; q < NR; ++q) gx[u][q] = 0.0;
         }
+    }
+    if (MODE == MODE_KPB) {  // the partials of r'z: the first 256 by their own lanes (every handle so far), the rest in a loop
+        if (pi0 < pl1) { acc_n = a.rz_new[pi0]; acc_o = a.rz_old[pi0]; }
+        for (int i = pi0 + kThreads; i < pl1; i += kThreads) { acc_n += a.rz_new[i]; acc_o += a.rz_old[i]; }
     }
     if (dn) return;  // (uniform over the workgroup; nothing has been written)
     if (LDSW) {
@@ -892,17 +1004,21 @@ __device__ __forceinline__ void band_tile(const SpmvArgs& a, const int b, const 
 
 // One diag tile: plain rows whose only entry is their diagonal, kBandDiagRows / 256 per lane, everything requested at once.
 template <int MODE>
-__device__ __forceinline__ void diag_tile(const SpmvArgs& a, const int b, const int4 meta, const int prob, double* red) {
+__device__ __forceinline__ void diag_tile(const SpmvArgs& a, const int b, const int4 meta, const int prob, const int dn0, double* red) {
     constexpr int DU = kBandDiagRows / kThreads;
     const int t = threadIdx.x;
     const int r0 = meta.x, r1 = meta.y;
     double beta = 0.0, acc_n = 0.0, acc_o = 0.0;
-    if (MODE == MODE_KPB) {
-        const int l0 = a.uni.on ? a.uni.l0 : a.prec_part_ptr[prob], l1 = a.uni.on ? a.uni.l1 : a.prec_part_ptr[prob + 1];
-        for (int i = l0 + t; i < l1; i += kThreads) { acc_n += a.rz_new[i]; acc_o += a.rz_old[i]; }
+    if (a.early_done) {
+        const int d = a.uni.on ? dn0 : a.done[prob];
+        if (d) return;
     }
-    const int dn = a.done[prob];
-    if (a.early_done && dn) return;
+    int pi0 = 0, pl1 = 0;
+    if (MODE == MODE_KPB) {
+        pi0 = (a.uni.on ? a.uni.l0 : a.prec_part_ptr[prob]) + t;
+        pl1 = a.uni.on ? a.uni.l1 : a.prec_part_ptr[prob + 1];
+    }
+    const int dn = a.uni.on ? dn0 : a.done[prob];
     double v[DU], x[DU][1], e0[DU][1], e1[DU][1], e2[DU][1];
 #pragma unroll
     for (int u = 0; u < DU; ++u) {
@@ -912,6 +1028,10 @@ __device__ __forceinline__ void diag_tile(const SpmvArgs& a, const int b, const 
         // (the operand of a diagonal row is the row's own entry of the vector the epilogue reads anyway)
         if (MODE == MODE_KP) { e0[u][0] = a.p[ro]; x[u][0] = (a.p == a.xin) ? e0[u][0] : a.xin[ro]; }
         else { e0[u][0] = a.w[ro]; e1[u][0] = a.z[ro]; e2[u][0] = a.p[ro]; x[u][0] = e1[u][0]; }
+    }
+    if (MODE == MODE_KPB) {
+        if (pi0 < pl1) { acc_n = a.rz_new[pi0]; acc_o = a.rz_old[pi0]; }
+        for (int i = pi0 + kThreads; i < pl1; i += kThreads) { acc_n += a.rz_new[i]; acc_o += a.rz_old[i]; }
     }
     if (dn) return;  // (uniform; nothing has been written)
     if (MODE == MODE_KPB) {
@@ -947,21 +1067,18 @@ __device__ __forceinline__ void spmv_band_body(const SpmvArgs& a) {
     const int b = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (b >= a.n_tiles) return;
     const int t = threadIdx.x;
-    const int4 meta = a.M.blk_meta[b];
-    const int4 m2 = a.B.meta2[b];
-    const int prob = a.uni.on ? 0 : a.M.blk_prob[b];
-    const int rs = (NR > 1) ? a.M.blk_rs[b] : 0;
+    const TileHead h = tile_head<NR, true>(a, b);
+    const int4 meta = h.meta, m2 = h.m2;
+    const int prob = h.prob, rs = h.rs;
     const int kind = (int)((unsigned)m2.w >> 28);
     if (kind == BAND_KIND_BAND) {
-        band_tile<MODE, NR, NP, LDSW>(a, b, meta, m2, prob, rs, prod, red, win);
+        band_tile<MODE, NR, NP, LDSW>(a, b, meta, m2, prob, rs, h.dn0, prod, red, win);
     } else if (kind == BAND_KIND_DIAG) {
-        diag_tile<MODE>(a, b, meta, prob, red);
+        diag_tile<MODE>(a, b, meta, prob, h.dn0, red);
     } else {
-        const int my_ptr = a.M.ptr[min(meta.x + t, meta.y)];
         const int end_ptr = (t == 0) ? meta.w : 0;
-        const int4 lg = a.M.blk_long[b];
-        if (NR > 1 && rs > 0) spmv_tile<MODE, NR, UNR>(a, b, meta, prob, my_ptr, end_ptr, rs, prod, red, srow, lg);
-        else spmv_tile<MODE, 1, UNR>(a, b, meta, prob, my_ptr, end_ptr, 0, prod, red, srow, lg);
+        if (NR > 1 && rs > 0) spmv_tile<MODE, NR, UNR>(a, b, meta, prob, end_ptr, rs, prod, red, srow, h.lg, h.dn0);
+        else spmv_tile<MODE, 1, UNR>(a, b, meta, prob, end_ptr, 0, prod, red, srow, h.lg, h.dn0);
     }
 }
 template <int MODE, int NR, int NP, bool LDSW = false>
@@ -1557,12 +1674,21 @@ __device__ __forceinline__ void prec_pre_body(const PrecArgs& a) {
     const int t = threadIdx.x;
     // trip 1: the work item's record (and, for a single-problem handle, the partial sums of alpha: their ranges are launch
     // constants).  Trip 2: everything else -- frozen flag, partial sums of a batch, vectors, factors.
+    // (the loads of trip 1 back to back, the record first -- the barrier below waits for it alone --, the partials by their own
+    //  lanes: a loop of loads in front of the record put two more round trips before everything else; the frozen flag of a
+    //  single problem is that of problem 0)
     double acc_rz = 0.0, acc_pw = 0.0;
+    int4 rec4 = make_int4(0, 0, 0, 0);
+    if (t < 32) rec4 = reinterpret_cast<const int4*>(a.rec + blockIdx.x)[t];
+    const int dn0 = a.uni.on ? a.done[0] : 0;
     if (MODE == PREC_STEP && a.uni.on) {
-        for (int i = a.uni.l0 + t; i < a.uni.l1; i += kPrecThreads) acc_rz += a.rz_in[i];
-        for (int i = a.uni.k0 + t; i < a.uni.k1; i += kPrecThreads) acc_pw += a.pw_part[i];
+        const int i0 = a.uni.l0 + t, j0 = a.uni.k0 + t;
+        if (i0 < a.uni.l1) acc_rz = a.rz_in[i0];
+        if (j0 < a.uni.k1) acc_pw = a.pw_part[j0];
+        for (int i = i0 + kPrecThreads; i < a.uni.l1; i += kPrecThreads) acc_rz += a.rz_in[i];
+        for (int i = j0 + kPrecThreads; i < a.uni.k1; i += kPrecThreads) acc_pw += a.pw_part[i];
     }
-    if (t < 32) reinterpret_cast<int4*>(&srec)[t] = reinterpret_cast<const int4*>(a.rec + blockIdx.x)[t];
+    if (t < 32) reinterpret_cast<int4*>(&srec)[t] = rec4;
     __syncthreads();
     const PrecWork wk = srec.wk;
     const ChainLevelDesc* sLv = srec.lv;
@@ -1572,10 +1698,10 @@ __device__ __forceinline__ void prec_pre_body(const PrecArgs& a) {
     // waiting for it now would put one more round trip to memory in front of every load below.
     int dn = 0;
     if (a.early_done) {
-        dn = a.done[prob];
+        dn = a.uni.on ? dn0 : a.done[prob];
         if (dn) return;
     }
-    const int dn_late = a.early_done ? 0 : a.done[prob];
+    const int dn_late = a.early_done ? 0 : (a.uni.on ? dn0 : a.done[prob]);
     if (MODE == PREC_INIT && a.gate_init && threadIdx.x == 0 && (int)blockIdx.x == a.prec_part_ptr[prob]) {
         a.gate_init[prob] = a.early_done ? dn : dn_late;
         a.gate_used[prob] = 0;
@@ -1583,8 +1709,10 @@ __device__ __forceinline__ void prec_pre_body(const PrecArgs& a) {
     if (MODE == PREC_STEP && !a.uni.on) {
         const int l0 = a.prec_part_ptr[prob], l1 = a.prec_part_ptr[prob + 1];
         const int k0 = a.kblk_part_ptr[prob], k1 = a.kblk_part_ptr[prob + 1];
-        for (int i = l0 + t; i < l1; i += kPrecThreads) acc_rz += a.rz_in[i];
-        for (int i = k0 + t; i < k1; i += kPrecThreads) acc_pw += a.pw_part[i];
+        if (l0 + t < l1) acc_rz = a.rz_in[l0 + t];
+        if (k0 + t < k1) acc_pw = a.pw_part[k0 + t];
+        for (int i = l0 + t + kPrecThreads; i < l1; i += kPrecThreads) acc_rz += a.rz_in[i];
+        for (int i = k0 + t + kPrecThreads; i < k1; i += kPrecThreads) acc_pw += a.pw_part[i];
     }
     double local = 0.0;
     if (wk.kind == 2) {
