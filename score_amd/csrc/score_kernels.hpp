@@ -2321,15 +2321,20 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
     const int b = a.xcd_chunk > 0 ? (int)(blockIdx.x & 7) * a.xcd_chunk + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     if (a.xcd_chunk > 0 && b >= a.n_blocks) return;
     const int prob = a.uni.on ? 0 : a.block_prob[b];
-    if (a.done[prob]) return;
-    // Partial sums of the last PCG step's r'z and p'w: requested now, reduced (two barriers) only
-    // after the cone's own loads are in flight.
+    // First trip (single problem; a batch member's starts once its problem is known): the frozen flag, the partial sums of the
+    // last PCG step's r'z and p'w -- the first 256 of each by their own lanes, not as a loop of loads with a wait of its own in
+    // front of everything --, the cone records, rho.  The flag is tested before the first dependent load; the partials are
+    // reduced (two barriers) only after the cone's own loads are in flight.
+    const int dnv = a.done[prob];
     double rz = 0.0, pw = 0.0;
     if (a.apply_alpha) {
         const int l0 = a.uni.on ? a.uni.l0 : a.prec_part_ptr[prob], l1 = a.uni.on ? a.uni.l1 : a.prec_part_ptr[prob + 1];
         const int k0 = a.uni.on ? a.uni.k0 : a.kblk_part_ptr[prob], k1 = a.uni.on ? a.uni.k1 : a.kblk_part_ptr[prob + 1];
-        for (int i = l0 + (int)threadIdx.x; i < l1; i += kThreads) rz += a.rz_in[i];
-        for (int i = k0 + (int)threadIdx.x; i < k1; i += kThreads) pw += a.pw_in[i];
+        const int i0 = l0 + (int)threadIdx.x, j0 = k0 + (int)threadIdx.x;
+        if (i0 < l1) rz = a.rz_in[i0];
+        if (j0 < k1) pw = a.pw_in[j0];
+        for (int i = i0 + kThreads; i < l1; i += kThreads) rz += a.rz_in[i];
+        for (int i = j0 + kThreads; i < k1; i += kThreads) pw += a.pw_in[i];
     }
     double step = 0.0;  // step length of the last PCG step (its xt update is applied on the fly)
     auto finish_step = [&]() {
@@ -2352,6 +2357,7 @@ __global__ __launch_bounds__(kThreads) void k_cone(ConeArgs a) {
     const int row = m0.x, dim = m0.y, type = m0.z;
     const int ptrs[kSmallCone + 1] = {m0.w, m1.x, m1.y, m1.z, m1.w};
     const double rho = a.rho[prob], irho = 1.0 / rho, al = a.alpha_relax;
+    if (dnv) return;  // (uniform over the block; nothing has been written)
     double t0 = 0.0, nz2 = 0.0, head, tail;
     // SCORE's cones have d + 1 = 3 or 4 rows with at most 2 entries each: every column/value,
     // then every gathered x are requested as batches of unconditional loads (clamped indices)
