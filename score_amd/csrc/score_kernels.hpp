@@ -463,10 +463,45 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
 #pragma unroll
         for (int q = 0; q < NR; ++q) acc[q] = 0.0;
         const int split = (MODE == MODE_DRES || MODE == MODE_GRAD) ? a.M.split[r0] : k1;
-        load_partials();
-        if (dn) return;  // (uniform over the workgroup)
-        finish_beta();  // uniform: lanes beyond the row's end never enter the sweep
-        for (int kb = k0 + t; kb < k1; kb += kThreads * kLongUnroll) {
+        // The first trip of the sweep -- for a segment (<= kLongSeg entries) the only one -- is requested BEFORE the partial sums
+        // of beta are reduced: entries and gathers on clamped indices by every lane (the lanes beyond the row's end add exact
+        // zeros); behind the reduction's two barriers the segments of a KPB product were one dependent trip behind every
+        // other tile of the launch.
+        const int kb0 = k0 + t;
+        {
+            int32_t c[kLongUnroll];
+            double v[kLongUnroll], g[kLongUnroll][NR];
+#pragma unroll
+            for (int u = 0; u < kLongUnroll; ++u) {
+                const int k = min(kb0 + u * kThreads, k1 - 1);
+                c[u] = col[k];
+                v[u] = val[k];
+            }
+            if (!fuse) {
+#pragma unroll
+                for (int u = 0; u < kLongUnroll; ++u) {
+#pragma unroll
+                    for (int q = 0; q < NR; ++q) g[u][q] = xin[c[u] + q * rs_in];
+                }
+            }
+            load_partials();
+            if (dn) return;  // (uniform over the workgroup)
+            finish_beta();
+            if (fuse) {
+#pragma unroll
+                for (int u = 0; u < kLongUnroll; ++u) fused_cone_u<NR>(a.F, c[u] - a.F.u_col0, beta, kb0 + u * kThreads < k1, g[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kLongUnroll; ++u) {
+                const int k = kb0 + u * kThreads;
+#pragma unroll
+                for (int q = 0; q < NR; ++q) {
+                    const double pr = (k < k1) ? v[u] * g[u][q] : 0.0;
+                    if ((MODE == MODE_DRES || MODE == MODE_GRAD) && k >= split) acc2 += pr; else acc[q] += pr;
+                }
+            }
+        }
+        for (int kb = kb0 + kThreads * kLongUnroll; kb < k1; kb += kThreads * kLongUnroll) {
             int32_t c[kLongUnroll];
             double v[kLongUnroll], g[kLongUnroll][NR];
 #pragma unroll
