@@ -895,6 +895,7 @@ struct HipBackend {
     int cg_iters = 2;
     const double* last_rz = nullptr;  // r'z partials / direction of the pending end-of-PCG update
     const double* last_p = nullptr;
+    const double* dbg_p = nullptr;   // the buffer the last queued iteration left its last direction in (score_debug_get "p")
     double* h_pres = nullptr;  // pinned
     double* h_dres = nullptr;
     int n_cone_blocks = 0, n_prec = 0;  // n_prec: work items of the ACTIVE preconditioner launch (split or not)
@@ -2584,6 +2585,9 @@ struct HipBackend {
         double* rz_cur = measure ? rz_meas0.d : rz_part0.d;
         double* p_cur = p.d;
         double* p_oth = p2.d;
+        // (fused cones: the helpers of the INIT launch read the PENDING direction while its chains write the new one -- never
+        //  into the same buffer: after an odd number of PCG iterations the pending direction sits in p, and INIT takes p2)
+        if (fused && last_p == p_cur) std::swap(p_cur, p_oth);
         pa.p = p_cur; pa.rz_in = nullptr; pa.rz_out = rz_cur;
         pa.tstamp = slot(1);
         if (fused) { pa.pend_p = last_p; pa.pend_step = step.d; }  // (the helpers of this launch apply the pending xt += step * p)
@@ -2599,6 +2603,7 @@ struct HipBackend {
             std::swap(p_cur, p_oth);
             rz_cur = rz_nxt;
         }
+        dbg_p = p_cur;
         ConeArgs ca = cone_args(xtu.d);
         const int cur = fuse_cone ? (idx & 1) : 0;  // the copy of s, y the last (fused) evaluation wrote
         if (measure) {
@@ -2900,7 +2905,7 @@ struct HipBackend {
         else if (nm == "s") { src = s.d; sz = h.m_tot; }
         else if (nm == "r") { src = r.d; sz = h.n_tot; }
         else if (nm == "z") { src = z.d; sz = h.n_tot; }
-        else if (nm == "p") { src = (cg_iters % 2 == 1) ? p.d : p2.d; sz = h.n_tot; }  // last PCG direction
+        else if (nm == "p") { src = dbg_p ? dbg_p : ((cg_iters % 2 == 1) ? p.d : p2.d); sz = h.n_tot; }  // last PCG direction (fused cones: INIT may have started in p2)
         else if (nm == "w") { src = w.d; sz = h.n_tot; }
         else if (nm == "kx") { src = kx.d; sz = h.n_tot; }
         else if (nm == "D" && h.device_setup) { src = Dd.d; sz = h.n_tot; }

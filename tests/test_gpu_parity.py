@@ -129,6 +129,21 @@ def test_fused_cones_follow_the_six_launch_iteration(name, fixtures, hip_lib, mo
     o = lone.solve()[0]
     assert o.solved
     lone.close()
+    # an ODD number of PCG iterations leaves the pending direction in the buffer the next INIT launch would write its new
+    # direction into while its helper items still read the pending one (a race until round 5: INIT now takes the other
+    # buffer): the fused path is repeatable to the last bit and follows the six-launch iteration
+    st3 = dict(adaptive_cg=0, cg_iters=3, check_interval=5, polish=0)
+    monkeypatch.setenv("SCORE_FUSED_CONE", "1")
+    f1, f2 = ConicSolver(qp, st3, lib_path=hip_lib), ConicSolver(qp, st3, lib_path=hip_lib)
+    monkeypatch.delenv("SCORE_FUSED_CONE", raising=False)
+    pl = ConicSolver(qp, st3, lib_path=hip_lib)
+    f1.reset(); f2.reset(); pl.reset()
+    for k in (3, 8, 20):
+        a, b, c = f1.steps(k)[0], f2.steps(k)[0], pl.steps(k)[0]
+        assert np.array_equal(a.x, b.x) and np.array_equal(f1.debug_get("p"), f2.debug_get("p"))
+        assert np.allclose(a.x, c.x, rtol=0.0, atol=1e-9 * max(1.0, float(np.abs(c.x).max())))
+        assert np.allclose(f1.debug_get("p"), pl.debug_get("p"), rtol=0.0, atol=1e-6 * max(1.0, float(np.abs(pl.debug_get("p")).max())))
+    f1.close(); f2.close(); pl.close()
 
 
 def test_band_view_and_split_long_rows_against_the_csr_stream(fixtures, hip_lib, monkeypatch):
