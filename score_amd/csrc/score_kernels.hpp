@@ -1731,19 +1731,25 @@ __device__ __forceinline__ void prec_pre_body(const PrecArgs& a) {
     // The frozen-problem flag.  Gated PCG solves (early_done) test it before anything else: their queue holds launches
     // that are meant to be no-ops.  The ADMM loop requests it here and tests it where the first write would happen --
     // waiting for it now would put one more round trip to memory in front of every load below.
+    // (a batch member's flag and the ranges of its partial sums depend on the problem alone: requested together, the flag first)
+    const int dn_ld = a.uni.on ? dn0 : a.done[prob];
+    int bl0 = 0, bl1 = 0, bk0 = 0, bk1 = 0;
+    if (MODE == PREC_STEP && !a.uni.on) {
+        bl0 = a.prec_part_ptr[prob]; bl1 = a.prec_part_ptr[prob + 1];
+        bk0 = a.kblk_part_ptr[prob]; bk1 = a.kblk_part_ptr[prob + 1];
+    }
     int dn = 0;
     if (a.early_done) {
-        dn = a.uni.on ? dn0 : a.done[prob];
+        dn = dn_ld;
         if (dn) return;
     }
-    const int dn_late = a.early_done ? 0 : (a.uni.on ? dn0 : a.done[prob]);
+    const int dn_late = a.early_done ? 0 : dn_ld;
     if (MODE == PREC_INIT && a.gate_init && threadIdx.x == 0 && (int)blockIdx.x == a.prec_part_ptr[prob]) {
         a.gate_init[prob] = a.early_done ? dn : dn_late;
         a.gate_used[prob] = 0;
     }
     if (MODE == PREC_STEP && !a.uni.on) {
-        const int l0 = a.prec_part_ptr[prob], l1 = a.prec_part_ptr[prob + 1];
-        const int k0 = a.kblk_part_ptr[prob], k1 = a.kblk_part_ptr[prob + 1];
+        const int l0 = bl0, l1 = bl1, k0 = bk0, k1 = bk1;
         if (l0 + t < l1) acc_rz = a.rz_in[l0 + t];
         if (k0 + t < k1) acc_pw = a.pw_part[k0 + t];
         for (int i = l0 + t + kPrecThreads; i < l1; i += kPrecThreads) acc_rz += a.rz_in[i];
