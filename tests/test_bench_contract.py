@@ -8,15 +8,33 @@ import sys
 from conftest import ROOT
 
 
-def test_bench_cpu_baseline_leg_runs_and_reports(twin_lib):
+def run_bench(argv, tmp_path, env=None, timeout=900, **kw):
+    """bench.py as the driver runs it; returns (process, compact record = LAST stdout line, full record = --full-out file).
+    The contract (round 6, after BENCH_r05.json came back unparsed): stdout carries ONE json line, <= 4 KB."""
+    full = os.path.join(str(tmp_path), "bench_full.json")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv, "--full-out", full],
+                         capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env, **kw)
+    if out.returncode != 0:
+        return out, None, None
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout  # ONE json line, from rank 0
+    last = out.stdout.strip().splitlines()[-1]
+    assert last == lines[0] and len(last.encode()) <= 4096, len(last)
+    tail = out.stdout.encode()[-8192:].decode()
+    compact = json.loads(tail.strip().splitlines()[-1])  # what a reader of the last 8 KB of stdout gets
+    for v in compact.values():
+        assert not (isinstance(v, str) and len(v) > 200)  # no prose in the contract line
+    with open(full) as fh:
+        return out, compact, json.load(fh)
+
+
+def test_bench_cpu_baseline_leg_runs_and_reports(twin_lib, tmp_path):
     """The cpu_baseline leg of bench.py (oracle's CPU twin on a bounded sample)."""
-    out = subprocess.run(
-        [sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-baseline-only", "--robots", "2", "--poses", "60",
-         "--mc-robots", "3", "--mc-poses", "80", "--cpu-seconds", "5"],
-        capture_output=True, text=True, timeout=600, cwd=ROOT,
-    )
+    out, compact, rec = run_bench(["--cpu-baseline-only", "--robots", "2", "--poses", "60",
+                                   "--mc-robots", "3", "--mc-poses", "80", "--cpu-seconds", "5"], tmp_path, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
-    rec = json.loads(out.stdout.strip().splitlines()[-1])
+    cc = compact["cpu_baseline"]
+    assert set(cc) == {"value", "unit", "cores", "kind", "seconds", "sample"} and cc["kind"] == "port" and cc["value"] > 0
     cb = rec["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0
     assert cb["cores"] >= 1 and "sample" in cb
@@ -34,25 +52,23 @@ CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
                  "vs_baseline", "dtype", "data", "config")
 
 
-def test_bench_gpus_flag_launches_that_many_ranks(twin_lib):
+def test_bench_gpus_flag_launches_that_many_ranks(twin_lib, tmp_path):
     """`python bench.py --gpus 2` must start two ranks by itself (no torchrun) and report n_gpus = 2 with the SAME
     primary metric as one rank (SOCP iterations/s, every rank its own headline problem: weak scaling), plus BASELINE
     configs[4] sharded t mod N with ONE all_gather of the result records per sweep.  Run here on gloo + the oracle's
     CPU twin (--test-cpu-twin); on the GPU box the same launcher starts RCCL ranks."""
     env = dict(os.environ, OMP_NUM_THREADS="2", SCORE_BENCH_TEST_MODE="1")
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
-    out = subprocess.run(
-        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--test-cpu-twin", "--robots", "2", "--poses", "30",
+    out, compact, rec = run_bench(
+        ["--gpus", "2", "--test-cpu-twin", "--robots", "2", "--poses", "30",
          "--montecarlo", "5", "--mc-robots", "2", "--mc-poses", "30", "--mc-batch", "2", "--mc-threads", "1", "--steps", "1",
-         "--warmup", "0"],
-        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env,
-    )
+         "--warmup", "0"], tmp_path, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout  # ONE json line, from rank 0
-    rec = json.loads(lines[0])
-    for key in CONTRACT_KEYS:
-        assert key in rec
+    for key in CONTRACT_KEYS + ("roofline", "cpu_baseline"):
+        assert key in rec and key in compact
+    assert compact["n_gpus"] == 2 and compact["metric"] == "socp_iters_per_sec" and compact["value"] > 0 and compact["scaling"] == "weak"
+    assert compact["legs"]["config5_trials"] == 5 and compact["legs"]["config5_solved_last_sweep"] == 5
+    assert compact["legs"]["config5_resolve_problems_per_sec"] > 0 and compact["legs"]["config5_fresh_graphs_problems_per_sec"] > 0
     assert rec["n_gpus"] == 2 and rec["metric"] == "socp_iters_per_sec" and rec["scaling"] == "weak" and rec["value"] > 0
     assert rec["timed_region"]["problems_total"] == 2 and rec["timed_region"]["problems_solved"] == 2  # one per rank
     c5 = rec["config5_montecarlo"]
@@ -69,19 +85,17 @@ def test_bench_gpus_flag_launches_that_many_ranks(twin_lib):
     assert "test_mode" in rec
 
 
-def test_bench_is_one_of_the_ranks_under_a_launcher(twin_lib):
+def test_bench_is_one_of_the_ranks_under_a_launcher(twin_lib, tmp_path):
     """With RANK / WORLD_SIZE already in the environment (torch.distributed.run) bench.py must not
     spawn anything: world size 1 here, process group forced on (the gather then runs as a 1-rank collective)."""
     env = dict(os.environ, OMP_NUM_THREADS="2", SCORE_BENCH_TEST_MODE="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
                MASTER_PORT="29533")
-    out = subprocess.run(
-        [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--test-cpu-twin", "--force-dist", "--robots", "1",
+    out, compact, rec = run_bench(
+        ["--gpus", "1", "--test-cpu-twin", "--force-dist", "--robots", "1",
          "--poses", "30", "--beacons", "2", "--montecarlo", "2", "--mc-robots", "1", "--mc-poses", "30", "--mc-beacons", "2",
-         "--steps", "1", "--warmup", "0"],
-        capture_output=True, text=True, timeout=900, cwd=ROOT, env=env,
-    )
+         "--steps", "1", "--warmup", "0"], tmp_path, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
-    rec = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert compact["n_gpus"] == 1 and compact["metric"] == "socp_iters_per_sec"
     assert rec["n_gpus"] == 1 and rec["metric"] == "socp_iters_per_sec"
     assert rec["config5_montecarlo"]["solved_last_sweep"] == 2 and rec["config5_montecarlo"]["results_gathered"] == 2
 
@@ -125,7 +139,7 @@ def test_cpu_twin_flag_needs_the_test_mode_switch():
     assert out.returncode != 0 and "SCORE_BENCH_TEST_MODE" in out.stderr
 
 
-def test_four_ranks_on_four_cpus_do_not_starve_each_other(twin_lib):
+def test_four_ranks_on_four_cpus_do_not_starve_each_other(twin_lib, tmp_path):
     """Host-side safety of the N-rank run: `bench.py --gpus 4` (gloo + the CPU twin, no GPU involved) with the launcher's
     affinity narrowed to four CPUs -- one per rank -- must not take much longer than with all CPUs: every rank sizes its
     host teams to its share of the CPUs it may use (host_threads(): affinity / cgroup quota / LOCAL_WORLD_SIZE), waits
@@ -136,21 +150,43 @@ def test_four_ranks_on_four_cpus_do_not_starve_each_other(twin_lib):
     if len(cpus) < 8:
         import pytest
         pytest.skip("needs 8 CPUs for the unpinned run")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--test-cpu-twin", "--robots", "2", "--poses", "40",
+    cmd = ["--gpus", "4", "--test-cpu-twin", "--robots", "2", "--poses", "40",
            "--montecarlo", "8", "--mc-robots", "2", "--mc-poses", "30", "--mc-batch", "2", "--steps", "1", "--warmup", "0"]
     env = dict(os.environ, OMP_NUM_THREADS="1", SCORE_BENCH_TEST_MODE="1")
     env.pop("RANK", None); env.pop("WORLD_SIZE", None)
 
     def run(mask):
         t0 = time.perf_counter()
-        out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env,
-                             preexec_fn=(lambda: os.sched_setaffinity(0, mask)) if mask else None)
+        out, compact, rec = run_bench(cmd, tmp_path, env=env, preexec_fn=(lambda: os.sched_setaffinity(0, mask)) if mask else None)
         dt = time.perf_counter() - t0
         assert out.returncode == 0, out.stderr[-3000:]
-        rec = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][0])
         assert rec["n_gpus"] == 4 and rec["config5_montecarlo"]["results_gathered"] == 8
         return dt
 
     free = run(None)
     pinned = run(set(cpus[:4]))
     assert pinned <= 1.5 * free + 5.0, (free, pinned)
+
+
+def test_the_contract_line_of_a_full_single_gpu_record_fits_4k():
+    """BENCH_r05.json.parsed was null: the one stdout line had grown to 20.6 KB.  The compact record of the LARGEST full record
+    this bench has produced (round 5's committed single-GPU run, every leg present) must fit 4 KB, carry the contract keys, a
+    numeric roofline and cpu_baseline, and no prose."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    with open(os.path.join(ROOT, "profiles", "r05_bench.json")) as fh:
+        full = json.load(fh)
+    assert len(json.dumps(full)) > 16000
+    c = bench.compact_record(full)
+    line = json.dumps(c, separators=(",", ":"))
+    assert len(line.encode()) <= bench.CONTRACT_MAX_BYTES, len(line)
+    for key in CONTRACT_KEYS:
+        assert key in c
+    r = c["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0
+    assert abs(r["achieved"] - r["bytes_per_launch"] / r["us_per_launch"] * 1e-3) < 1e-2 * r["achieved"]
+    assert c["roofline_dominant"]["frac"] > 0 and c["roofline_batch16"]["frac"] > 0
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["cores"] >= 1 and c["cpu_baseline"]["value"] > 0
+    assert c["legs"]["config5_fresh_graphs_problems_per_sec"] > 0 and c["legs"]["solve_score_ms"] > 0
+    assert abs(c["value"] - full["value"]) < 1e-4 * full["value"]
