@@ -589,7 +589,10 @@ inline void read_estimates_host(const EstLayout& L, int qcqp_dirs, const double*
                 double dl[3], nn = 0.0;
                 for (int k = 0; k < d; ++k) { dl[k] = tvar(L.rng_a[(size_t)i], k) - tvar(L.rng_b[(size_t)i], k); nn += dl[k] * dl[k]; }
                 const double den = std::max(std::sqrt(nn), L.rng_dist[(size_t)i]);
-                for (int k = 0; k < d; ++k) rng[(size_t)i * d + k] = den > 0.0 ? dl[k] / den : 0.0;
+                // (a range measured as exactly 0: the cost w |t_i - t_j - 0 r|^2 does not depend on r -- every path returns r = 0 there,
+                //  as headform_expand does for its idle cone)
+                const bool idle = !(L.rng_dist[(size_t)i] > 0.0);
+                for (int k = 0; k < d; ++k) rng[(size_t)i * d + k] = (den > 0.0 && !idle) ? dl[k] / den : 0.0;
             }
         }
     }

@@ -214,6 +214,11 @@ inline void gen_check_spec(const GenSpec& S, int count) {
     const int64_t Np = (int64_t)S.n_robots * S.n_poses;
     if (Np * count >= ((int64_t)1 << 30) || (int64_t)gen_groups(S) * S.n_poses * count >= ((int64_t)1 << 30))
         throw std::runtime_error("score_generate_manhattan: batch too large");
+    // the ranges: a robot-beacon slot emits up to n_beacons measurements, a timestep's robot pairs R (R - 1) / 2; offsets and
+    // the device scan are 32-bit
+    const int64_t worst = (int64_t)count * S.n_poses * ((int64_t)S.n_robots * S.n_beacons + (int64_t)S.n_robots * (S.n_robots - 1) / 2);
+    if (worst >= ((int64_t)1 << 30))
+        throw std::runtime_error("score_generate_manhattan: batch too large (more than 2^30 possible range measurements): draw fewer worlds per call");
 }
 
 // (storage that is NOT zero-filled when sized: every element is written by the generator; a std::vector's resize touches

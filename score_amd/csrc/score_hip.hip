@@ -1988,7 +1988,7 @@ struct HipBackend {
         n_join_items = (int)h.join_items.size(); n_join_chains = (int)h.join_chains.size(); n_join_seps = (int)h.join_sep_col.size();
         if (!n_join_items) return;
         for (const JoinChain& jc : h.join_chains)
-            if (jc.n_seg - 1 > kJoinMaxSeps) throw std::runtime_error("chain too long: more than 65 segments of 1023 nodes");
+            if (jc.n_seg - 1 > kJoinMaxSeps) throw std::runtime_error("internal: a segmented chain with more separators than the join kernel holds (build_system keeps such chains whole)");
         join_jc.upload(h.join_chains); join_items.upload(h.join_items);
         join_sep_col.upload(h.join_sep_col); join_sep_diag.upload(h.join_sep_diag);
         // pseudo-nodes for the position look-up (k_hb_positions): [separator | prev = last node of the segment before it] and

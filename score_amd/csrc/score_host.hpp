@@ -834,6 +834,7 @@ inline void chain_solve_host(const ChainDesc& ch, const ChainLevelDesc* levels, 
 // separators' Schur system (block tridiagonal, n_seg - 1 nodes) and corrects the segments with their spikes: together the
 // exact solve with the whole chain's block-tridiagonal matrix, as the streaming kernel computes it.
 constexpr int kSegMaxNodes = 1023;
+constexpr int kJoinMaxSepsHost = 64;  // == score_join.hpp kJoinMaxSeps (static_assert there): separators of one long chain
 inline int seg_max_nodes() {  // (SCORE_SEG_NODES: shorter segments, for experiments -- profiles/TRIED.md)
     static const int v = [] {
         const char* e = std::getenv("SCORE_SEG_NODES");
@@ -1764,7 +1765,18 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     std::vector<int32_t> node_prev;  // column of each chain node's predecessor (-1: first of its chain)
     const int max_nodes = 1 << 20;
     // (the twin factors on the host and keeps whole chains: its streaming solve is the specification)
-    const bool segments_ok = !factor_on_host && H.radix == 4 && bs >= 1 && bs <= 4 && std::getenv("SCORE_NO_SEGMENTS") == nullptr;
+    bool segments_ok = !factor_on_host && H.radix == 4 && bs >= 1 && bs <= 4 && std::getenv("SCORE_NO_SEGMENTS") == nullptr;
+    // The second level keeps one long chain's separators in LDS (score_join.hpp: kJoinMaxSeps).  A handle with a chain that
+    // would need more keeps ALL its chains whole -- the streaming kernel k_prec, as before round 5 (chains of up to 2^20 nodes) --
+    // instead of failing at score_create.
+    if (segments_ok) {
+        const int seg_max = seg_max_nodes();
+        for (int p = 0; p < count && segments_ok; ++p)
+            for (int c = 0; c < probs[p].n_chains; ++c) {
+                const int Nall = probs[p].chain_ptr[c + 1] - probs[p].chain_ptr[c];
+                if (Nall > seg_max && (Nall + 1 + seg_max) / (seg_max + 1) - 1 > kJoinMaxSepsHost) { segments_ok = false; break; }
+            }
+    }
     for (int p = 0; p < count; ++p) {
         const score_problem& pr = probs[p];
         const size_t jc_first = H.join_chains.size();

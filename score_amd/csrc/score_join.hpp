@@ -25,6 +25,7 @@ namespace score {
 
 constexpr int kJoinThreads = 256;
 constexpr int kJoinMaxSeps = 64;  // separators of one long chain the join kernel keeps in LDS (chains of up to 65 segments)
+static_assert(kJoinMaxSeps == kJoinMaxSepsHost, "build_system keeps longer chains whole (score_host.hpp)");
 
 struct JoinArgs {
     const JoinChain* jc;

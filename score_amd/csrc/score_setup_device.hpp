@@ -775,7 +775,8 @@ __global__ __launch_bounds__(256) void k_read_estimates(EstArgs a) {
             double dl[3], nn = 0.0;
             for (int k = 0; k < d; ++k) { dl[k] = tvar(a.rng_a[i], k) - tvar(a.rng_b[i], k); nn += dl[k] * dl[k]; }
             const double den = fmax(sqrt(nn), a.rng_dist[i]);
-            for (int k = 0; k < d; ++k) a.rng[i * d + k] = den > 0.0 ? dl[k] / den : 0.0;
+            const bool idle = !(a.rng_dist[i] > 0.0);  // (measured distance 0: r = 0 on every path, see read_estimates_host)
+            for (int k = 0; k < d; ++k) a.rng[i * d + k] = (den > 0.0 && !idle) ? dl[k] / den : 0.0;
         }
     }
 }

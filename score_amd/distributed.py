@@ -13,6 +13,7 @@ array, concatenated.
 """
 from __future__ import annotations
 
+import inspect
 import os
 from typing import List, Optional, Sequence
 
@@ -146,7 +147,13 @@ def broadcast_graphs(datas: Optional[Sequence], root: int = 0, device: Optional[
             header, chunks = [], []
             for g in datas:
                 a = arrays_of(g)
-                meta = {k: v for k, v in a.items() if k not in _NUMERIC}
+                # (private keys -- a generated world's '_owner' holds a CDLL and the generator's handle -- stay here; the lazy
+                #  name tables of generated worlds travel as plain lists: the receivers get ordinary array graphs)
+                meta = {k: v for k, v in a.items() if k not in _NUMERIC and not k.startswith("_")}
+                meta["pose_names"] = list(meta["pose_names"])
+                meta["range_keys"] = [tuple(k) for k in meta["range_keys"]]
+                meta["landmark_names"] = list(meta["landmark_names"])
+                meta["pose_chain_names"] = [list(c) for c in meta["pose_chain_names"]]
                 meta["_shapes"] = {k: (tuple(np.shape(a[k])), np.asarray(a[k]).dtype.str) for k in _NUMERIC}
                 header.append(meta)
                 chunks += [np.asarray(a[k], dtype=np.float64).ravel() for k in _NUMERIC]
@@ -327,7 +334,9 @@ def solve_generated_sharded(
         else:
             buf[slot, : r.size] = r
     gathered = all_gather_records(buf, int(settings["device"]))
-    R, T, Nb = int(spec.get("n_robots", 4)), int(spec.get("n_poses", 400)), int(spec.get("n_beacons", 6))
+    # (the shape of a world: the generator's own defaults, from its signature -- nothing restated here)
+    gen_defaults = {k: v.default for k, v in inspect.signature(GeneratedBatch.__init__).parameters.items() if v.default is not inspect.Parameter.empty}
+    R, T, Nb = (int(spec.get(k, gen_defaults[k])) for k in ("n_robots", "n_poses", "n_beacons"))
     poses = _PoseNames(robot_letters(R), T)
     lms = [f"L{k}" for k in range(Nb)]
     chains = [_PoseNames([ch], T) for ch in robot_letters(R)]
@@ -343,8 +352,10 @@ def solve_generated_sharded(
                 failed.append(i)
                 continue
             nv, nd, wd = int(rec[7]), int(rec[8]), int(rec[9])
-            v = rec[_HDR : _HDR + nv]
             k = 9
+            if nv != len(poses) * k + Nb * 2 + nd * wd:
+                raise RuntimeError(f"solve_generated_sharded: world {i}: record of {nv} values does not match {R} robots x {T} poses, {Nb} beacons, {nd} ranges")
+            v = rec[_HDR : _HDR + nv]
             P = v[: len(poses) * k].reshape(len(poses), 3, 3).copy()
             off = len(poses) * k
             L = v[off : off + Nb * 2].reshape(Nb, 2).copy()

@@ -60,7 +60,8 @@ def _qcqp_dists_from_socp(model: ScoreModel, x_model: np.ndarray, data) -> np.nd
     delta = x_model[e[:, 0:1] + e[:, 1:2] * k] - x_model[e[:, 2:3] + e[:, 3:4] * k]
     den = np.maximum(np.sqrt(np.einsum("ij,ij->i", delta, delta)), model.range_dist)
     out = np.zeros((nr, d))
-    np.divide(delta, den[:, None], out=out, where=den[:, None] > 0)
+    # (a range measured as exactly 0 leaves r free -- w |D - 0 r|^2: every path returns r = 0 there)
+    np.divide(delta, den[:, None], out=out, where=(den[:, None] > 0) & (np.asarray(model.range_dist)[:, None] > 0))
     return out
 
 
@@ -93,7 +94,7 @@ def extract_solver_results(
         delta = tr[a["rng_a"]] - tr[a["rng_b"]]
         den = np.maximum(np.sqrt(np.einsum("ij,ij->i", delta, delta)), a["rng_dist"]) if len(delta) else np.zeros(0)
         dv = np.zeros((len(delta), d))
-        np.divide(delta, den[:, None], out=dv, where=den[:, None] > 0)
+        np.divide(delta, den[:, None], out=dv, where=(den[:, None] > 0) & (np.asarray(a["rng_dist"])[:, None] > 0))
         dists = compat.ArrayDict(model.range_keys, dv)
     else:  # QCQP answered through the SOCP
         dists = compat.ArrayDict(model.range_keys, _qcqp_dists_from_socp(model, xm, data))

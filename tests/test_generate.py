@@ -147,6 +147,8 @@ def test_generated_worlds_solve_and_errors(twin_lib):
         GeneratedBatch(1, n_robots=0, lib_path=twin_lib)
     with pytest.raises(ValueError, match="p_range"):
         GeneratedBatch(1, p_range=1.5, lib_path=twin_lib)
+    with pytest.raises(ValueError, match="2\\^30 possible range measurements"):  # (32-bit range offsets: refused, not wrapped)
+        GeneratedBatch(16, n_robots=64, n_poses=1000, n_beacons=4096, lib_path=twin_lib)
     with pytest.raises(IndexError):
         B.arrays(3)
     assert C.sizeof(ManhattanSpec) == 56
@@ -242,3 +244,20 @@ def test_config5_from_seeds_is_certified(hip_lib):
     for a_, b_ in zip(rq, res[:8]):
         assert a_.solved and a_.info["pobj"] == pytest.approx(b_.info["pobj"], rel=1e-7)
         np.testing.assert_allclose(a_.poses.array, b_.poses.array, atol=1e-6 * max(1.0, np.abs(b_.poses.array).max()))
+
+
+def test_zero_distance_ranges_get_one_direction_convention(twin_lib):
+    """A range measured as exactly 0 (the generator clamps at 0; the shipped fixture holds five) leaves its QCQP direction free:
+    w |t_i - t_j - 0 r|^2 does not depend on r.  Every path returns r = 0 there -- the device read-back (k_read_estimates /
+    read_estimates_host), the Python closed form and the direct QCQP's headform_expand -- so the answer does not depend on the
+    assembler (advisor finding, round 5: 0.708 between 'device' and 'native' on this world)."""
+    G = generate_manhattan(3, seed=5, lib_path=twin_lib)[2]
+    zero = np.nonzero(G.arrays["rng_dist"] == 0)[0]
+    assert len(zero) >= 1
+    a = solve_score(G, "QCQP", lib_path=twin_lib, assembler="device")
+    b = solve_score(G, "QCQP", lib_path=twin_lib, assembler="native")
+    c = solve_score(G, "QCQP", lib_path=twin_lib, assembler="native", qcqp_mode="direct")
+    A, B, Cc = (r.variables.distances.array for r in (a, b, c))
+    assert np.all(A[zero] == 0.0) and np.all(B[zero] == 0.0) and np.all(Cc[zero] == 0.0)
+    np.testing.assert_allclose(A, B, atol=1e-8)
+    np.testing.assert_allclose(A, Cc, atol=1e-4)

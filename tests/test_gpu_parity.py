@@ -737,6 +737,21 @@ def test_segmented_long_chains_equal_the_streaming_solve(case, hip_lib, twin_lib
         assert max(np.abs(ra.poses[k] - rb.poses[k]).max() for k in ra.poses) < 1e-9
 
 
+def test_a_chain_beyond_the_second_level_keeps_the_streaming_kernel(hip_lib):
+    """Round-5 regression (advisor): a chain of more than 65 segments of 1023 nodes (> 66.6 k poses) failed at score_create
+    ("chain too long: more than 65 segments") where round 4 solved it with the streaming kernel k_prec (host limit 2^20
+    nodes).  build_system now keeps every chain of such a handle whole.  One robot x 67 000 poses: created, solved, KKT
+    certificate of the program as given."""
+    fg = make_manhattan(n_robots=1, n_poses=67000, n_beacons=2, seed=5, p_range=0.02)
+    qp = assemble(fg, "SOCP").qp
+    sol = ConicSolver([qp], {})
+    out = sol.solve()[0]
+    sol.close()
+    assert out.solved, out.info
+    cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, out.x, out.y, out.s)
+    assert cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4, cert
+
+
 @pytest.mark.parametrize("index", [1, 2, 3])
 def test_full_size_configs_are_certified(index, hip_lib):
     """BASELINE.json's full sizes (1x500, 4x1000, 20x1000 poses): the solver-
