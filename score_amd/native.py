@@ -193,6 +193,48 @@ def graph_arrays(data) -> Dict[str, np.ndarray]:
     )
 
 
+_CACHE_ATTR = "_score_amd_graph_arrays"
+
+
+def graph_fingerprint(data) -> tuple:
+    """What ``cached_graph_arrays`` keys the flat arrays of a graph object on: the dimension and, for every variable / measurement
+    list of the graph, its identity, its length and the identities of its first and last element.  Appending, removing or
+    replacing elements, or swapping a list, changes it; editing a field of a measurement object IN PLACE does not -- call
+    ``invalidate_graph_cache(data)`` after such an edit (PyFactorGraph's measurement classes are immutable attrs classes)."""
+    def one(lst):
+        n = len(lst)
+        return (id(lst), n, id(lst[0]) if n else 0, id(lst[-1]) if n else 0)
+
+    return (int(data.dimension), one(data.pose_variables), tuple(one(c) for c in data.pose_variables), one(data.landmark_variables),
+            one(data.odom_measurements), tuple(one(c) for c in data.odom_measurements), one(data.loop_closure_measurements),
+            one(data.range_measurements), one(data.landmark_priors))
+
+
+def cached_graph_arrays(data) -> Dict[str, np.ndarray]:
+    """``graph_arrays(data)``, kept on the graph object: the reference's callers solve the same FactorGraphData again and again
+    (both relaxations of one graph, score/solve_score.py:54-57; the intermediate iterates, :89-116), and the pass over 47 k
+    measurement objects of the headline graph is 7.5 ms of attribute reads in front of a 3.8 ms solve.  The arrays are reused
+    while ``graph_fingerprint(data)`` stands; they are never written to by the solve."""
+    fp = graph_fingerprint(data)
+    hit = getattr(data, _CACHE_ATTR, None)
+    if hit is not None and hit[0] == fp:
+        return hit[1]
+    arrays = graph_arrays(data)
+    try:
+        object.__setattr__(data, _CACHE_ATTR, (fp, arrays))  # (also for frozen attrs classes; objects with __slots__: no cache)
+    except (AttributeError, TypeError):
+        pass
+    return arrays
+
+
+def invalidate_graph_cache(data) -> None:
+    """Drop the flat arrays kept on ``data`` (after editing a measurement object in place)."""
+    try:
+        object.__delattr__(data, _CACHE_ATTR)
+    except (AttributeError, TypeError):
+        pass
+
+
 class ArrayGraph:
     """A factor graph that already IS flat arrays (``graph_arrays(data)``, or a producer that never builds
     per-measurement Python objects): accepted wherever ``solve_score`` / ``solve_score_batch`` accept a

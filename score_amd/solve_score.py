@@ -107,6 +107,14 @@ def extract_solver_results(
     )
 
 
+def _runtime_s(info: dict) -> float:
+    """``SolverResults.total_time``: the reference reports ``model.Runtime`` (gurobi_utils.py:194) -- Gurobi's optimize() wall
+    time, presolve, ordering and factorisation included.  The counterpart here is score_create (model construction, equilibration,
+    K, factors: ``setup_ms``) + the solve (``solve_ms``), both of the handle the graph was solved in (a lock-step group reports its
+    handle's times for every member); both stay in ``SolverResults.info``."""
+    return (float(info.get("setup_ms", 0.0)) + float(info.get("solve_ms", 0.0))) * 1e-3
+
+
 def _resolve_args(args, relaxation_type):
     """Accept both the reference signature ``solve_score(data, relaxation)`` and
     the stale example's ``solve_score(data, solver_params, relaxation)``
@@ -126,9 +134,9 @@ def _model_for(data, relaxation_type: str, qcqp_mode: str, lib_path: Optional[st
     one (score_amd/assemble.py) -- same program, same column layout."""
     relax = SOCP_RELAXATION if (relaxation_type == QCQP_RELAXATION and qcqp_mode == "via_socp") else relaxation_type
     if assembler == "native":
-        from .native import ArrayGraph, assemble_native, graph_arrays, unconnected_variable_names
+        from .native import ArrayGraph, assemble_native, cached_graph_arrays, unconnected_variable_names
 
-        arrays = data.arrays if isinstance(data, ArrayGraph) else graph_arrays(data)
+        arrays = data.arrays if isinstance(data, ArrayGraph) else cached_graph_arrays(data)
         # score/solve_score.py:28-32, evaluated on the arrays just extracted (one pass over the graph objects)
         unconnected_variables = unconnected_variable_names(arrays)
         assert len(unconnected_variables) == 0, f"Found {unconnected_variables} unconnected variables. "
@@ -143,10 +151,11 @@ def _models_for(datas: Sequence, relaxation_type: str, qcqp_mode: str, lib_path:
     (``native.assemble_native_batch`` -> ``score_assemble_batch``: one graph per host thread of the library);
     ``assembler="device"``: the read-back maps only -- the model itself is built inside ``score_create_from_graphs``."""
     if assembler == "device":
-        from .native import ArrayGraph, graph_arrays, graph_model, unconnected_variable_names
+        from .native import ArrayGraph, cached_graph_arrays, graph_model, unconnected_variable_names
 
         relax = SOCP_RELAXATION if (relaxation_type == QCQP_RELAXATION and qcqp_mode == "via_socp") else relaxation_type
-        arrays = [data.arrays if isinstance(data, ArrayGraph) else graph_arrays(data) for data in datas]
+        # (objects -> flat arrays once per graph object: kept on it while its lists stand, native.cached_graph_arrays)
+        arrays = [data.arrays if isinstance(data, ArrayGraph) else cached_graph_arrays(data) for data in datas]
         # score/solve_score.py:28-32 on the flat arrays: one foreign call for the whole group (score_graphs_connected); the names
         # for the reference's message only when a graph fails
         from .native import graphs_connected
@@ -162,10 +171,10 @@ def _models_for(datas: Sequence, relaxation_type: str, qcqp_mode: str, lib_path:
             _check_factor_graph(data)
             out.append(_model_for(data, relaxation_type, qcqp_mode, lib_path, assembler))
         return out
-    from .native import ArrayGraph, assemble_native_batch, graph_arrays, unconnected_variable_names
+    from .native import ArrayGraph, assemble_native_batch, cached_graph_arrays, unconnected_variable_names
 
     relax = SOCP_RELAXATION if (relaxation_type == QCQP_RELAXATION and qcqp_mode == "via_socp") else relaxation_type
-    arrays = [data.arrays if isinstance(data, ArrayGraph) else graph_arrays(data) for data in datas]
+    arrays = [data.arrays if isinstance(data, ArrayGraph) else cached_graph_arrays(data) for data in datas]
     for a in arrays:  # score/solve_score.py:28-32, on the flat arrays
         unconnected_variables = unconnected_variable_names(a)
         assert len(unconnected_variables) == 0, f"Found {unconnected_variables} unconnected variables. "
@@ -321,7 +330,7 @@ def solve_score_batch(
             values = compat.VariableValues(model.dim, compat.ArrayDict(model.pose_names, T), compat.ArrayDict(model.landmark_names, Lm),
                                            compat.ArrayDict(model.range_keys, Rg))
             out.append(compat.SolverResults(
-                variables=values, total_time=info["solve_ms"] * 1e-3, solved=solved,
+                variables=values, total_time=_runtime_s(info), solved=solved,
                 pose_chain_names=model.pose_chain_names if model.pose_chain_names is not None else data.get_pose_chain_names(),
                 solver_cost=info.get("pobj"), info=info, relaxed_poses=compat.ArrayDict(model.pose_names, B),
             ))
@@ -344,7 +353,7 @@ def solve_score_batch(
             logger.warning("SCORE solve did not converge: %s", sol.info)
         try:
             out.append(extract_solver_results(
-                model, sol.x, data, total_time=sol.info["solve_ms"] * 1e-3, solved=sol.solved,
+                model, sol.x, data, total_time=_runtime_s(sol.info), solved=sol.solved,
                 requested_relaxation=relaxation_type, info=sol.info, lib=lib, device=device,
             ))
         except ValueError as exc:

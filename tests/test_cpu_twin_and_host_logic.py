@@ -55,7 +55,7 @@ def test_qcqp_direct_equals_via_socp(fixtures, twin_lib):
     a = solve_score(fg, "QCQP", lib_path=twin_lib)
     b = solve_score(fg, "QCQP", qcqp_mode="direct", lib_path=twin_lib)
     assert a.solved and b.solved
-    assert a.info["pobj"] == pytest.approx(b.info["pobj"], rel=1e-6)
+    assert a.info["pobj"] == pytest.approx(b.info["pobj"], rel=1e-6, abs=1e-6)
     for nm in a.poses:
         np.testing.assert_allclose(a.poses[nm], b.poses[nm], atol=2e-4)
     # r_ij agree wherever the measured distance is not (numerically) zero
@@ -189,6 +189,40 @@ def test_api_errors(twin_lib):
     # non-convergence is reported through solved=False, not an exception
     res = solve_score(fg, "SOCP", solver_settings=dict(max_iters=25, eps_abs=1e-14, eps_rel=1e-14), lib_path=twin_lib)
     assert res.solved is False and res.info["status"] == 2
+
+
+def test_flat_arrays_are_kept_on_the_graph_and_follow_its_lists(twin_lib):
+    """The drop-in call on a graph solved before (score/solve_score.py:54-57: the same FactorGraphData for both relaxations, for
+    the intermediate iterates): the pass over the measurement objects happens once, the arrays stay on the object while its
+    lists stand (native.cached_graph_arrays), and every change of a list -- append, pop, replace -- is seen.  total_time is
+    setup + solve, the counterpart of model.Runtime (gurobi_utils.py:194)."""
+    from score_amd import native
+
+    fg = make_manhattan(n_robots=2, n_poses=25, n_beacons=2, seed=3, p_range=0.5)
+    a = solve_score(fg, "SOCP", lib_path=twin_lib)
+    kept = getattr(fg, native._CACHE_ATTR)
+    assert kept[0] == native.graph_fingerprint(fg)
+    b = solve_score(fg, "QCQP", lib_path=twin_lib)
+    assert getattr(fg, native._CACHE_ATTR)[1] is kept[1]  # the second call read no measurement object
+    assert a.solved and b.solved and a.info["pobj"] == pytest.approx(b.info["pobj"], rel=1e-6, abs=1e-6)
+    assert a.total_time == pytest.approx((a.info["setup_ms"] + a.info["solve_ms"]) * 1e-3) and a.total_time > a.info["solve_ms"] * 1e-3
+    # a dropped measurement changes the answer: the cached arrays must not be used
+    nr = len(fg.range_measurements)
+    last = fg.range_measurements.pop()
+    c = solve_score(fg, "SOCP", lib_path=twin_lib)
+    assert len(c.distances) == nr - 1 and getattr(fg, native._CACHE_ATTR)[1] is not kept[1]
+    fg.range_measurements.append(last)
+    d = solve_score(fg, "SOCP", lib_path=twin_lib)
+    assert len(d.distances) == nr and d.info["pobj"] == pytest.approx(a.info["pobj"], rel=1e-9, abs=1e-9)
+    # same list, same length, another element: seen through the first / last identities; an in-place edit needs the explicit call
+    fg.range_measurements[-1] = compat.FGRangeMeasurement(last.association, dist=last.dist + 1.0, stddev=last.stddev)
+    assert native.graph_fingerprint(fg) != getattr(fg, native._CACHE_ATTR)[0]
+    native.invalidate_graph_cache(fg)
+    assert not hasattr(fg, native._CACHE_ATTR)
+    # the unconnected-variable check still fires on a cached graph (it is evaluated on the arrays of the CURRENT lists)
+    fg.landmark_variables.append(compat.LandmarkVariable2D("L9"))
+    with pytest.raises(AssertionError, match="unconnected"):
+        solve_score(fg, lib_path=twin_lib)
 
 
 def test_no_ranges_and_single_pose_chain(twin_lib):
