@@ -124,7 +124,7 @@ inline void assemble_graph(const score_graph& g, AssembledQP& out) {
     // ---- P, q, c0.  The measurement loops run twice over the same code: a counting pass sizes every
     //      row, a filling pass writes (column, value) pairs into one flat array; rows are then sorted
     //      and merged in parallel (rows are short: a few (d+1)-blocks each). ----
-    PhaseTimer pt(std::getenv("SCORE_ASSEMBLE_VERBOSE") != nullptr);  // phase marks on stderr
+    PhaseTimer pt(trace_on("assemble"));  // phase marks on stderr
     pt.mark("assemble: layout");
     out.q.assign((size_t)n, 0.0);
     double c0 = 0.0;

@@ -96,7 +96,7 @@ inline BandLayout build_band_layout(const Csr& M, const std::vector<RowSegment>&
     BandLayout L;
     L.bs = bs;
     if (runs.empty() || bs < 1 || bs > kMaxBs) return L;
-    PhaseTimer bt_(std::getenv("SCORE_BAND_TIMING") != nullptr);
+    PhaseTimer bt_(trace_on("band"));
     const int32_t* ptr = M.ptr.data();
     const int32_t* col = M.col.data();
     // ---- pass 1: window offsets in use, per class ----

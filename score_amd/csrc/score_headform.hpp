@@ -63,7 +63,7 @@ inline bool headform_enabled() { return std::getenv("SCORE_QCQP_PLAIN") == nullp
 
 // false: the program is not of the constant-head kind (out is left in an unspecified state)
 inline bool headform_no(int where) {
-    if (std::getenv("SCORE_HEADFORM_DEBUG")) std::fprintf(stderr, "[score setup] head form declined at check %d\n", where);
+    if (trace_on("headform")) std::fprintf(stderr, "[score setup] head form declined at check %d\n", where);
     return false;
 }
 inline bool headform_reduce(const score_problem& p, HeadForm& F) {

@@ -38,6 +38,7 @@
 #include "score_setup_device.hpp"
 #include "score_prec_wave.hpp"
 #include "score_join.hpp"
+#include "score_link.hpp"
 #include "score_generate.hpp"
 
 namespace {
@@ -142,7 +143,7 @@ struct BlockCache {
         void* p = nullptr;
         const auto t_raw = std::chrono::steady_clock::now();
         hipError_t e = raw_alloc(&p, bytes, host);
-        if (std::getenv("SCORE_CACHE_VERBOSE"))
+        if (trace_on("cache"))
             std::fprintf(stderr, "[score cache] %s of %zu bytes: %.2f ms\n", host ? "hipHostMalloc" : "hipMalloc", bytes,
                          std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_raw).count());
         if (e != hipSuccess) {
@@ -292,19 +293,9 @@ thread_local DevArena* tl_arena = nullptr;  // set while a handle is being initi
 // chunks go back to the block cache after ONE synchronisation at the end of the setup.  Large arrays keep the pageable
 // path: their cost is bandwidth, and staging them (copy teams of host threads into 32 MB pinned chunks) measured no gain on
 // the headline create.  Measured (round 4): create of 1 x 100 poses 2.11 -> 1.17 ms, 1 x 500: 2.40 -> 1.48, 4 x 1000: 4.06 ->
-// 2.82, 20 x 1000: 9.2 -> 8.6-9.0 ms.  SCORE_NO_STAGED_UPLOADS: everything pageable; SCORE_STAGED_UPLOADS=1: everything staged;
-// SCORE_STAGE_MAX_KB: the size limit (default 512).
-inline size_t stage_limit_bytes() {
-    static const size_t v = [] {
-        if (std::getenv("SCORE_NO_STAGED_UPLOADS")) return (size_t)0;
-        if (std::getenv("SCORE_STAGED_UPLOADS")) return ~(size_t)0;
-        // (round 5: EVERYTHING goes through pinned memory of the library's own by default -- see staged_d2h below for why no
-        //  pageable pointer is ever handed to the runtime; SCORE_STAGE_MAX_KB restores a size limit)
-        const char* e = std::getenv("SCORE_STAGE_MAX_KB");
-        return e ? (size_t)std::max(0L, std::atol(e)) << 10 : ~(size_t)0;
-    }();
-    return v;
-}
+// 2.82, 20 x 1000: 9.2 -> 8.6-9.0 ms.  Round 5: EVERYTHING goes through pinned memory of the library's own -- see staged_d2h
+// below for why no pageable pointer is ever handed to the runtime (the size-limit switches of rounds 4-5 are gone: TRIED.md).
+inline size_t stage_limit_bytes() { return ~(size_t)0; }
 struct StageArena {
     int dev = 0;
     std::vector<size_t> chunk_bytes;
@@ -767,22 +758,17 @@ struct HipBackend {
 
     CsrBufs K, G1, G2;
     BandBufs Kb, Hb;  // band views of K and of the Newton matrix (score_band.hpp); off: the CSR-stream kernels serve them
-    // SCORE_BAND_K / SCORE_BAND_H = 0 / 1 force a view off / on (experiments); default: see band_k() / band_h()
-    static int band_env(const char* name) { const char* e = std::getenv(name); return e ? std::atoi(e) : -1; }
+    // SCORE_NO_BAND=1: the CSR-stream kernels serve K (tests: both layouts against the twin)
     bool band_k(const HostSystem&) const {
         // K through its band view whatever the batch size (what a problem computes must not depend on its batch mates: the two
         // layouts add a row's terms in different orders).  A lock-step batch streams K from HBM and the view moves 19 % fewer
         // bytes: batch of 16 headline problems kp 46 -> 34 us, kpb 50 -> 40 us; a single problem's product is a chain of
         // dependent trips bound by its slowest workgroup (the landmark rows' segments): 6.4 / 7.1 us either way.
-        const int e = band_env("SCORE_BAND_K");
-        return std::getenv("SCORE_NO_BAND") == nullptr && (e >= 0 ? e != 0 : true);
+        return std::getenv("SCORE_NO_BAND") == nullptr;
     }
-    bool band_h(const HostSystem&) const {
-        // the Newton matrix: measured without effect (64 config-5 trials in lock-step handles of 16: 7.0 ms per solve with and
-        // without; headline default solve 4.5 ms either way) -- the view costs setup time, so it stays off (SCORE_BAND_H=1)
-        const int e = band_env("SCORE_BAND_H");
-        return std::getenv("SCORE_NO_BAND") == nullptr && e > 0;
-    }
+    // (a band view of the Newton matrix was measured without effect -- 64 config-5 trials 7.0 ms per solve with and without,
+    //  headline default solve 4.5 ms either way -- and cost setup time: removed in round 6, profiles/TRIED.md)
+    static constexpr bool band_h(const HostSystem&) { return false; }
     int kblocks() const { return Kb.on ? Kb.nblocks : K.nblocks; }   // tiles of the K product (= p'w partials per launch)
     int hblocks() const { return Hb.on ? Hb.nblocks : Hm.nblocks; }
     DevBuf<int32_t> A_ptr, A_col;
@@ -884,14 +870,9 @@ struct HipBackend {
     double newton_eta_coef = 1.0, newton_eta_pow = 0.5;
     double* h_newton = nullptr;  // window into h_rep: partials of the cone part of F
 
-    // Fused cones (FuseArgs, score_kernels.hpp): the right-hand-side kernel of iteration k + 1 evaluates the cones of iteration k
-    // -- five launches per ADMM iteration instead of six.  s and y alternate between their own buffers and s_alt / y_alt
-    // (evaluation j of a sequence reads copy (j - 1) & 1 and writes copy j & 1); the measuring iteration that closes every
-    // sequence runs the stand-alone cone kernel, which reads the current copy and writes the canonical one.
-    bool fuse_cone = false;
-    DevBuf<double> s_alt, y_alt;
-    int seq_idx = 0;  // iteration index within the current sequence (begin_sequence)
-    void begin_sequence() { seq_idx = 0; }
+    // (Rounds 4-5 could evaluate the previous iteration's cones inside the right-hand-side kernel -- five launches per ADMM
+    //  iteration instead of six, opt-in, measured no faster: 13.9 us against 6.6 + 7.0 + 1.4 -- removed in round 6, TRIED.md.)
+    void begin_sequence() {}
     int cg_iters = 2;
     const double* last_rz = nullptr;  // r'z partials / direction of the pending end-of-PCG update
     const double* last_p = nullptr;
@@ -917,7 +898,7 @@ struct HipBackend {
     static bool n_prec_chains(const HostSystem& h) { return !h.chains.empty(); }
 
     ~HipBackend() {
-        if (std::getenv("SCORE_HOST_TIMING"))
+        if (trace_on("host"))
             std::fprintf(stderr, "[score host] Newton PCG queueing: %.2f ms for %ld launches (%.2f us each); waits: %ld, %.2f ms\n", enq_ms, enq_launches,
                          enq_launches ? 1e3 * enq_ms / (double)enq_launches : 0.0, waits, wait_ms);
         PhaseTimer pt(st.verbose != 0);
@@ -949,8 +930,7 @@ struct HipBackend {
     }
     // asked by build_system once sizes and the replication structure are known
     bool device_setup_allowed(const HostSystem& h, const score_settings& s_) const {
-        if (std::getenv("SCORE_HOST_SETUP") || std::getenv("SCORE_HOST_POLISH_BUILD") || std::getenv("SCORE_FUSED_CONE") ||
-            std::getenv("SCORE_NO_DEVICE_RUIZ") || std::getenv("SCORE_NO_DEVICE_AG")) return false;  // (switches that ask for a host-side piece)
+        if (std::getenv("SCORE_HOST_SETUP") || std::getenv("SCORE_HOST_POLISH_BUILD") || std::getenv("SCORE_NO_DEVICE_RUIZ")) return false;  // (switches that ask for a host-side piece)
         if (h.m_tot <= 0 || s_.chain_split > 0 || band_h(h)) return false;   // (linear mode keeps K0 on the host)
         if (h.rep > 1)
             for (char ex : h.rep_exact_all)
@@ -1599,8 +1579,7 @@ struct HipBackend {
         // there from the raw matrices and scales those passes left behind (k_derive_a / k_derive_g; 26 MB of uploads less
         // for the headline problem) -- a replicated problem only when its replicas' P values are bit-equal to replica 0's.
         derive_ag = !h.device_setup && h.count == 1 && h.m_tot > 0 && ruiz_dev.kept && ruiz_dev.k_n == h.n_tot && ruiz_dev.k_m == h.m_tot &&
-                    ruiz_dev.k_nnzA == (int64_t)h.A.col.size() && ruiz_dev.k_rep == h.rep && (h.rep == 1 || h.rep_exact) &&
-                    std::getenv("SCORE_NO_DEVICE_AG") == nullptr;
+                    ruiz_dev.k_nnzA == (int64_t)h.A.col.size() && ruiz_dev.k_rep == h.rep && (h.rep == 1 || h.rep_exact);
         struct DropKept {  // (the kept buffers go back when the setup is over, whatever happens -- once nothing reads them any more)
             RuizDevice& r;
             hipStream_t st;
@@ -1723,8 +1702,7 @@ struct HipBackend {
                 int cus = 0;
                 HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st.device));
                 const int want = (int)((h.n_tot + kHelpEntries - 1) / kHelpEntries);
-                const bool on = h.count == 1 && std::getenv("SCORE_NO_UPDATE_HELPERS") == nullptr &&
-                                (int)h.prec_work.size() + want <= cus;  // the whole launch resident at once
+                const bool on = h.count == 1 && (int)h.prec_work.size() + want <= cus;  // the whole launch resident at once
                 n_help = on ? want : 0;
             }
             prec_rec.upload(build(h.chains, h.levels));
@@ -1736,7 +1714,7 @@ struct HipBackend {
         {   // split chain kernel: only when the whole launch is resident at once (one workgroup per CU)
             int cus = 0;
             HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, st.device));
-            const bool off = st.chain_split <= 0 || h.rep > 1 || std::getenv("SCORE_NO_CHAIN_SPLIT") != nullptr;
+            const bool off = st.chain_split <= 0 || h.rep > 1;
             if (!off && cus > 0) build_split_system(h, cus, split);
             if (split.active && split.stage_rel.size() > 0) {
                 for (const auto& pl : split.plans)
@@ -1803,7 +1781,7 @@ struct HipBackend {
         if (lds_pre > 158 * 1024) prec_pre = false;  // 160 KiB per CU, minus the static record and slack
         prec_pre_lds = prec_pre ? lds_pre : 0;
         // register-resident coarse levels (k_prec_pre<.., float, true>): LDS holds the vectors only
-        prec_reg = prec_pre && h.deep_ok && h.bs <= 3 && st.fac_fp32 != 0 && std::getenv("SCORE_NO_REGDEEP") == nullptr;
+        prec_reg = prec_pre && h.deep_ok && h.bs <= 3 && st.fac_fp32 != 0;
         if (prec_reg) {
             size_t lds_reg = 0;
             for (const auto& ch : h.chains) {
@@ -1832,32 +1810,6 @@ struct HipBackend {
             pt.mark("band view of K (wait + upload)");
         }
         kblk_part_ptr.upload(Kb.on ? Kb.L.part_ptr : h.rbK.part_ptr);
-        {   // fused cones (FuseArgs): a single problem whose cones are all small second-order cones, d + 1 rows each from row 0
-            // on, every cone with a private head column (its head row is the ONE entry of that column of A -- the entry that
-            // owns the cone's new state); the pending xt update then belongs to the INIT launch's helper items
-            bool ok = !h.device_setup && h.count == 1 && uni_ranges && n_help > 0 && !split.active && prec_pre && st.fac_fp32 != 0 && n_large_cones == 0 &&
-                      !h.cone_row.empty() && std::getenv("SCORE_FUSED_CONE") != nullptr;
-            // (OPT-IN, SCORE_FUSED_CONE=1.  Measured on the headline problem: the fused right-hand side takes 13.9 us -- four
-            //  dependent trips: entries of A' -> cone records, s, y, b -> gathers of xt and p -> projection -- against 6.6 us
-            //  + 7.0 us for the two launches it replaces plus 1.4 us of boundary: 16.9 k it/s either way.  The launch saved
-            //  is paid back in the longer dependent chain of the row-parallel kernel.)
-            const int dim = ok ? h.cone_dim[0] : 0;
-            ok = ok && dim >= 2 && dim <= kSmallCone && dim <= kMaxRep + 1;
-            for (size_t c = 0; c < h.cone_row.size() && ok; ++c) {
-                const int r0 = (int)c * dim;
-                ok = h.cone_type[c] == 1 && h.cone_dim[c] == dim && h.cone_row[c] == r0;
-                for (int k = 0; k < dim && ok; ++k) ok = (h.A.ptr[r0 + k + 1] - h.A.ptr[r0 + k]) <= kConeRowNnz;
-                if (!ok) break;
-                ok = h.A.ptr[r0 + 1] - h.A.ptr[r0] == 1;
-                if (!ok) break;
-                const int32_t hc = h.A.col[h.A.ptr[r0]];
-                ok = h.G1.ptr[hc + 1] - h.G1.ptr[hc] == 1 && h.G1.col[h.G1.ptr[hc]] == (int32_t)(h.n_tot + r0);
-            }
-            // (every other entry of A' must be a TAIL row: a head row referenced from a second place would write the state twice)
-            fuse_cone = ok;
-            if (fuse_cone) { s_alt.alloc(h.m_tot); y_alt.alloc(h.m_tot); s_alt.zero(stream); y_alt.zero(stream); }
-            if (st.verbose) std::fprintf(stderr, "[score setup] cone projections: %s\n", fuse_cone ? "fused into the right-hand-side kernel" : "their own launch");
-        }
         {   // the iterates and partial sums a reset zeroes: ONE block (a reset is one fill instead of fifteen -- each a 4 us
             // dispatch, on every solve)
             auto pad = [](size_t c) { return (std::max<size_t>(1, c) + 31) & ~(size_t)31; };  // (256-byte aligned pieces)
@@ -1914,6 +1866,7 @@ struct HipBackend {
         derive_rho_data(false);
         pt.mark("allocations + rho data (device)");
         if (st.polish) init_polish(h);
+        link_init(h, probs, graphs);
         pt.mark("polish setup");
         {   // the report arena (see `rep`) and the control block (see `ctl`)
             const size_t n_pres = (size_t)std::max(1, n_cone_blocks) * kPartStride, n_dres = (size_t)G2.nblocks * kPartStride;
@@ -2096,6 +2049,94 @@ struct HipBackend {
         }
     }
 
+    // ---- loop closures inside the Newton preconditioner (score_link.hpp): Woodbury correction of the chain solve ----
+    LinkPlan link_plan;
+    int n_link_items = 0, n_link_probs = 0, n_link_u = 0, link_rounds = 0, link_max_u = 0;
+    bool link_suspend = false;
+    DevBuf<LinkProb> link_probs;
+    DevBuf<LinkItem> link_items;
+    DevBuf<int32_t> link_ucol, link_uround, link_usuper, link_pos, link_zero, link_status;
+    DevBuf<uint8_t> link_mask;
+    DevBuf<double> link_Qt, link_t, link_Zr, link_rhs, link_tmp_p, link_tmp_rz;
+    void link_init(const HostSystem& h, const score_problem* probs, const score_graph* graphs) {
+        n_link_items = n_link_probs = n_link_u = link_rounds = 0;
+        if (!st.polish || !Q.available || h.chainsH.empty() || std::getenv("SCORE_NO_LINKS") != nullptr) return;
+        std::vector<int32_t> pairs;
+        if (graphs) find_link_pairs_graphs(h, graphs, pairs);
+        else if (probs) find_link_pairs_P(h, probs, pairs);
+        if (pairs.empty()) return;
+        make_link_plan(h, pairs, link_plan);
+        const LinkPlan& L = link_plan;
+        if (st.verbose) std::fprintf(stderr, "[score setup] loop closures: %d node pairs outside the chains, %d inside the Newton preconditioner (%d unknowns, %d chains, %d rounds)\n",
+                                     L.pairs_total, L.pairs_used, (int)L.ucol.size(), (int)L.items.size(), L.rounds);
+        if (L.empty()) return;
+        n_link_items = (int)L.items.size(); n_link_probs = (int)L.probs.size(); n_link_u = (int)L.ucol.size(); link_rounds = L.rounds;
+        link_max_u = 0;
+        for (const LinkProb& P : L.probs) link_max_u = std::max(link_max_u, (int)P.n_u);
+        link_probs.upload(L.probs); link_items.upload(L.items);
+        link_ucol.upload(L.ucol); link_uround.upload(L.uround); link_usuper.upload(L.usuper); link_mask.upload(L.mask);
+        link_pos.alloc(L.mask.size()); link_status.alloc(n_link_probs);
+        ZeroGroup zl;
+        zl.add(link_Qt, L.mask.size()); zl.add(link_t, (size_t)n_link_u); zl.add(link_Zr, (size_t)link_rounds * (size_t)h.n_tot);
+        zl.add(link_rhs, (size_t)h.n_tot); zl.add(link_zero, (size_t)h.count);
+        zl.commit(stream);
+        link_tmp_p.alloc((size_t)h.n_tot); link_tmp_rz.alloc(h.prec_work.size() + 4096);
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_link_cap, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLinkMaxU * kLinkMaxU * (int)sizeof(double)));
+        LinkArgs la = link_args();
+        hipLaunchKernelGGL(k_link_positions, dim3(16), dim3(kLinkThreads), 0, stream, la, n_link_probs);
+        HIP_CHECK(hipGetLastError());
+    }
+    LinkArgs link_args() {
+        LinkArgs la{};
+        la.probs = link_probs.d; la.items = link_items.d; la.ucol = link_ucol.d; la.uround = link_uround.d; la.usuper = link_usuper.d;
+        la.mask = link_mask.d; la.pos = link_pos.d; la.Qt = link_Qt.d; la.t = link_t.d; la.Zr = link_Zr.d; la.rhs = link_rhs.d;
+        la.n_tot = H->n_tot; la.rounds = link_rounds; la.n_u_total = n_link_u; la.round = 0;
+        la.Hptr = Hm.ptr.d; la.Hcol = Hm.col.d; la.Hval = Hm.val.d;
+        la.chains = chainsH.d; la.node_col = node_col.d; la.done = link_zero.d; la.status = link_status.d;
+        return la;
+    }
+    // after every factorisation of the Newton matrix's chains: the columns Z = T^-1 U (one application of the chain kernel --
+    // second level included -- per round) and Q = (I + G Z[U,:])^-1 G
+    void link_refresh() {
+        if (!n_link_items) return;
+        LinkArgs la = link_args();
+        PrecArgs pa{};
+        pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.rec = prec_recH.d; pa.fac = q_fac.d;
+        pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = link_zero.d;
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d; pa.uni = uni_for(hblocks());
+        pa.r = link_rhs.d; pa.r_in = link_rhs.d; pa.p = link_tmp_p.d; pa.w = w.d; pa.xt = link_tmp_p.d; pa.kx = link_tmp_p.d;
+        pa.pw_part = nullptr; pa.rz_in = nullptr; pa.rz_out = link_tmp_rz.d;
+        link_suspend = true;
+        for (int r = 0; r < link_rounds; ++r) {
+            la.round = r;
+            hipLaunchKernelGGL(k_link_rhs, dim3((unsigned)((n_link_u + kLinkThreads - 1) / kLinkThreads)), dim3(kLinkThreads), 0, stream, la);
+            pa.z = link_Zr.d + (size_t)r * (size_t)H->n_tot;
+            launch_prec<PREC_INIT>(pa);
+        }
+        link_suspend = false;
+        la.round = -1;  // (leaves the right-hand side zero again)
+        hipLaunchKernelGGL(k_link_rhs, dim3((unsigned)((n_link_u + kLinkThreads - 1) / kLinkThreads)), dim3(kLinkThreads), 0, stream, la);
+        hipLaunchKernelGGL(k_link_cap, dim3((unsigned)n_link_probs), dim3(kLinkThreads), (size_t)2 * link_max_u * link_max_u * sizeof(double), stream, la);
+    }
+    template <int BS, int MODE>
+    void link_apply_bs(const PrecArgs& pa) {
+        LinkArgs la = link_args();
+        la.done = pa.done;
+        la.r = (MODE == PREC_INIT) ? pa.r_in : pa.r;
+        la.z = pa.z; la.p = pa.p; la.rz_out = pa.rz_out;
+        hipLaunchKernelGGL(k_link_solve, dim3((unsigned)n_link_probs), dim3(128), 0, stream, la);
+        hipLaunchKernelGGL((k_link_apply<BS, MODE>), dim3((unsigned)n_link_items), dim3(kLinkThreads), 0, stream, la);
+    }
+    template <int MODE>
+    void link_apply(const PrecArgs& pa) {
+        switch (H->bs) {
+            case 1: link_apply_bs<1, MODE>(pa); break;
+            case 2: link_apply_bs<2, MODE>(pa); break;
+            case 3: link_apply_bs<3, MODE>(pa); break;
+            default: link_apply_bs<4, MODE>(pa); break;
+        }
+    }
+
     int n_prec_items() const { return (int)H->prec_work.size(); }
     // k_factor keeps the level-to-level matrices in LDS when the longest chain fits
     int factor_lds_wmat = 0;
@@ -2137,7 +2178,7 @@ struct HipBackend {
         // float copy itself and nobody reads the doubles: no rounding launch (33 us a time on the headline problem, seven times
         // per default solve).  The streaming kernel reads `fac`: then the factors are rounded in place as before.
         const bool want32 = (newton_set ? newton_fac32 : use_fac32) && nf > 0;
-        const bool direct32 = want32 && prec_pre && !split.active && std::getenv("SCORE_FAC_ROUND_LAUNCH") == nullptr;
+        const bool direct32 = want32 && prec_pre && !split.active;
         fa.fac32 = direct32 ? (newton_set ? q_fac32.d : fac32.d) : nullptr;
         launch_factor_kernels(fa, np);
         if (want32) {
@@ -2152,6 +2193,7 @@ struct HipBackend {
                                    fa.levels, (const int32_t*)deep_map.d, (const float*)shadow, newton_set ? deepH.d : deepK.d, fa.skip, bs * bs);
         }
         join_refresh(newton_set);  // (segmented long chains: separators' inverse diagonals, spikes, Schur factors)
+        if (newton_set) link_refresh();  // (loop closures: the Woodbury columns and the capacitance matrix, score_link.hpp)
     }
 
     ConeArgs cone_args(const double* gathered) {
@@ -2235,14 +2277,14 @@ struct HipBackend {
     // a fraction of a microsecond), then yields (the waiting thread gives its core to whoever can run: with several ranks per
     // node and several driver threads per rank the host has fewer cores than waiters -- a bare spin there burns exactly the
     // CPU quota the other ranks' setup needs), then short sleeps; a stream synchronisation, which also surfaces device errors,
-    // when nothing arrives within 2 s.  SCORE_WAIT_SPIN_US: length of the first phase (default 30).
+    // when nothing arrives within 2 s.
     void wait_published(unsigned long long seq) {
         HIP_CHECK(hipGetLastError());
         struct WaitTimer {
             HipBackend* b; double t0;
             ~WaitTimer() { b->wait_ms += now_ms() - t0; b->waits += 1; }
         } wait_timer{this, now_ms()};
-        static const double spin_us = std::getenv("SCORE_WAIT_SPIN_US") ? std::atof(std::getenv("SCORE_WAIT_SPIN_US")) : 30.0;
+        constexpr double spin_us = 30.0;
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
         int phase = 0;  // 0 spin, 1 yield, 2 sleep
@@ -2327,12 +2369,14 @@ struct HipBackend {
         }
         // segmented long chains: the second level (score_join.hpp) after every application of the chain kernel
         if (n_join_items && !join_suspend && !pa.debug_skip) join_apply<MODE>(pa, newton_set);
+        // loop closures (score_link.hpp): the Woodbury correction of the Newton set's chain solve
+        if (n_link_items && newton_set && !link_suspend && !join_suspend && !pa.debug_skip) link_apply<MODE>(pa);
     }
     template <int BS, int MODE>
     void launch_prec_bs(const PrecArgs& pa_in, int slot, bool use_fac32) {
         // (the k_prec_pre launches of a STEP carry the update helpers of a single-problem handle, see the records)
         PrecArgs pa = pa_in;
-        const bool help = (MODE == PREC_STEP || pa.pend_p != nullptr) && n_help > 0 && pa.rec != nullptr && !pa.debug_skip;
+        const bool help = MODE == PREC_STEP && n_help > 0 && pa.rec != nullptr && !pa.debug_skip;
         const int n_prec = this->n_prec + (help ? n_help : 0);
         pa.split_update = (help && MODE == PREC_STEP) ? 1 : 0;
         // k_prec_pre (level 0 in registers, coarse levels in LDS) when every chain fits; 4 x 4 blocks (3-D problems) only
@@ -2381,16 +2425,15 @@ struct HipBackend {
     // SpMV launch: matrices of a replicated problem (K, G1) run with rep right-hand sides per stored row
     // XCD-aware tile order (SpmvArgs::xcd_chunk): returns the grid size.  Measured: KKT SpMV of a 16-problem batch
     // 48.0 -> 45.6 us (3.06 -> 3.23 TB/s), single problem 8.2 -> 7.8 us; kpb and rhs gain 2-3 %.
-    bool xcd_spmv = std::getenv("SCORE_NO_XCD_SPMV") == nullptr;
     unsigned xcd_grid(SpmvArgs& a, int nblocks) const {
         a.n_tiles = nblocks;
-        if (!xcd_spmv || nblocks < 16) { a.xcd_chunk = 0; return (unsigned)nblocks; }
+        if (nblocks < 16) { a.xcd_chunk = 0; return (unsigned)nblocks; }
         a.xcd_chunk = (nblocks + 7) / 8;
         return (unsigned)(8 * a.xcd_chunk);
     }
     // partial-sum ranges by value for single-problem handles (UniRanges, score_kernels.hpp); kblocks = row blocks of the
     // matrix whose p'w partials the launch reads (K in the ADMM loop, H in the Newton PCG)
-    bool uni_ranges = std::getenv("SCORE_NO_UNI_RANGES") == nullptr;
+    static constexpr bool uni_ranges = true;
     UniRanges uni_for(int kblocks) const {
         UniRanges u{};
         u.on = (uni_ranges && H->count == 1 && active_part_ptr.size() == 2) ? 1 : 0;
@@ -2399,19 +2442,13 @@ struct HipBackend {
         return u;
     }
     // K / H product over a band view: the view's tile tables replace the source matrix's
-    // SCORE_BAND_LDS = 0 / 1: the band tiles' operand window through global loads / staged in LDS (band_tile, LDSW)
-    bool band_lds = [] { const char* e = std::getenv("SCORE_BAND_LDS"); return e ? std::atoi(e) != 0 : true; }();
+    // (the band tiles stage their operand window in LDS: band_tile<.., LDSW = true>; the per-lane global loads of round 4 lost
+    //  their A/B -- profiles/r05_band_lds_ab.txt -- and are no longer instantiated)
     template <int MODE, int NR>
     void launch_band_s(const BandBufs& Bv, const SpmvArgs& a, unsigned grid, int slot) {
-        if (band_lds) {
-            if (Bv.L.S == 8) launch_on_stream((k_spmv_band<MODE, NR, 4, true>), dim3(grid), dim3(kThreads), 0, slot, a);
-            else if (Bv.L.S == 10) launch_on_stream((k_spmv_band<MODE, NR, 5, true>), dim3(grid), dim3(kThreads), 0, slot, a);
-            else launch_on_stream((k_spmv_band<MODE, NR, 6, true>), dim3(grid), dim3(kThreads), 0, slot, a);
-            return;
-        }
-        if (Bv.L.S == 8) launch_on_stream(k_spmv_band<MODE, NR, 4>, dim3(grid), dim3(kThreads), 0, slot, a);
-        else if (Bv.L.S == 10) launch_on_stream(k_spmv_band<MODE, NR, 5>, dim3(grid), dim3(kThreads), 0, slot, a);
-        else launch_on_stream(k_spmv_band<MODE, NR, 6>, dim3(grid), dim3(kThreads), 0, slot, a);
+        if (Bv.L.S == 8) launch_on_stream((k_spmv_band<MODE, NR, 4, true>), dim3(grid), dim3(kThreads), 0, slot, a);
+        else if (Bv.L.S == 10) launch_on_stream((k_spmv_band<MODE, NR, 5, true>), dim3(grid), dim3(kThreads), 0, slot, a);
+        else launch_on_stream((k_spmv_band<MODE, NR, 6, true>), dim3(grid), dim3(kThreads), 0, slot, a);
     }
     template <int MODE>
     void launch_band(const CsrBufs& M, const BandBufs& Bv, const SpmvArgs& a_in, int slot = -1) {
@@ -2554,26 +2591,11 @@ struct HipBackend {
     size_t ts_stride = 0;
     void enqueue_iteration(bool measure, bool first, unsigned long long* ts = nullptr) {
         auto slot = [&](int k) -> unsigned long long* { return ts ? ts + ts_stride * k : nullptr; };
-        const int idx = first ? (seq_idx = 0) : seq_idx;
-        ++seq_idx;
-        const bool fused = fuse_cone && !first;  // this iteration's right-hand side evaluates the previous iteration's cones
-        double* const s_buf[2] = {s.d, s_alt.d};
-        double* const y_buf[2] = {xy.d + H->n_tot, y_alt.d};
         {
             SpmvArgs ra = spmv_args(G1, xtu.d);
             ra.tstamp = slot(0);
             ra.apply_update = first ? 0 : 1;
             ra.pfin = last_p;
-            if (fused) {
-                FuseArgs& f = ra.F;
-                f.on = 1; f.dim = H->cone_dim[0]; f.u_col0 = (int)H->n_tot;
-                f.cone_cols = (const int4*)cone_cols.d; f.cone_vals = (const double2*)cone_vals.d;
-                f.b = b.d; f.rho = rho.d; f.alpha_relax = st.alpha;
-                f.s_old = s_buf[(idx - 1) & 1]; f.y_old = y_buf[(idx - 1) & 1];
-                f.s_new = s_buf[idx & 1]; f.y_new = y_buf[idx & 1];
-                f.u_out = xtu.d + H->n_tot; f.xt = xtu.d; f.pfin = last_p;
-                f.rz_in = last_rz; f.pw_in = pw_part.d; f.step_out = step.d;
-            }
             launch_spmv<MODE_RHS>(G1, ra, 0);
         }
         PrecArgs pa{};
@@ -2585,14 +2607,9 @@ struct HipBackend {
         double* rz_cur = measure ? rz_meas0.d : rz_part0.d;
         double* p_cur = p.d;
         double* p_oth = p2.d;
-        // (fused cones: the helpers of the INIT launch read the PENDING direction while its chains write the new one -- never
-        //  into the same buffer: after an odd number of PCG iterations the pending direction sits in p, and INIT takes p2)
-        if (fused && last_p == p_cur) std::swap(p_cur, p_oth);
         pa.p = p_cur; pa.rz_in = nullptr; pa.rz_out = rz_cur;
         pa.tstamp = slot(1);
-        if (fused) { pa.pend_p = last_p; pa.pend_step = step.d; }  // (the helpers of this launch apply the pending xt += step * p)
         launch_prec<PREC_INIT>(pa, 1);
-        pa.pend_p = nullptr; pa.pend_step = nullptr;
         launch_kp(p_cur, slot(2), 2);
         for (int j = 2; j <= cg_iters; ++j) {
             double* rz_nxt = (rz_cur == rz_part0.d) ? rz_part1.d : rz_part0.d;
@@ -2605,7 +2622,6 @@ struct HipBackend {
         }
         dbg_p = p_cur;
         ConeArgs ca = cone_args(xtu.d);
-        const int cur = fuse_cone ? (idx & 1) : 0;  // the copy of s, y the last (fused) evaluation wrote
         if (measure) {
             pa.tstamp = nullptr;
             pa.p = p_cur; pa.rz_in = rz_cur; pa.rz_out = rz_meas1.d;
@@ -2616,16 +2632,15 @@ struct HipBackend {
             va.pw_part = pw_part.d; va.p = p_cur; va.w = w.d; va.kx = kx.d; va.xt = xtu.d; va.x = xy.d;
             va.alpha_relax = st.alpha; va.rz_old = rz_cur; va.apply_alpha = 0;
             hipLaunchKernelGGL(k_xupdate, dim3(n_vblocks), dim3(kThreads), 0, stream, va);
-            ca.s_in = s_buf[cur]; ca.y_in = y_buf[cur];  // (reads the current copy, writes the canonical one)
         } else {
             ca.apply_alpha = 1; ca.pfin = p_cur; ca.rz_in = rz_cur;
             last_rz = rz_cur;  // what the next iteration's right-hand-side kernel has to apply
             last_p = p_cur;
         }
         ca.tstamp = slot(5);
-        if (n_cone_blocks && (measure || !fuse_cone)) {
+        if (n_cone_blocks) {
             unsigned cgrid = (unsigned)n_cone_blocks;
-            if (xcd_spmv && n_cone_blocks >= 16) { ca.xcd_chunk = (n_cone_blocks + 7) / 8; ca.n_blocks = n_cone_blocks; cgrid = 8u * (unsigned)ca.xcd_chunk; }
+            if (n_cone_blocks >= 16) { ca.xcd_chunk = (n_cone_blocks + 7) / 8; ca.n_blocks = n_cone_blocks; cgrid = 8u * (unsigned)ca.xcd_chunk; }
             launch_on_stream(k_cone, dim3(cgrid), dim3(kThreads), 0, 5, ca);
             ca.xcd_chunk = 0;
         }
@@ -2662,7 +2677,6 @@ struct HipBackend {
             HIP_CHECK(hipStreamSynchronize(stream));
             for (int i = 0; i < warmup; ++i) enqueue_iteration(false, i == 0);
             for (int i = 0; i < iters; ++i) enqueue_iteration(false, warmup == 0 && i == 0, dts.d + per_iter * i);
-            if (fuse_cone) enqueue_iteration(true, false);  // (closes the sequence: the pending cones, s and y back in their own buffers)
             HIP_CHECK(hipMemcpyAsync(hts.data(), dts.d, nslot * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
             HIP_CHECK(hipGetLastError());
@@ -2673,7 +2687,7 @@ struct HipBackend {
                     for (int b = 0; b < maxb; ++b) { t0 = std::min(t0, p[2 * b]); t1 = std::max(t1, p[2 * b + 1]); }
                     if (t1 > t0) us[k] += (double)(t1 - t0) * 1e3 / (double)khz / iters;
                 }
-            if (std::getenv("SCORE_DUMP_STAMPS")) {
+            if (trace_on("stamps")) {
                 // per-workgroup timeline of the last timed iteration: kernel, workgroup, entry and exit in us after the
                 // iteration's first entry (stdout; profiles/scripts/r04_timeline.py draws it)
                 const unsigned long long* base = &hts[per_iter * (size_t)(iters - 1)];
@@ -2694,18 +2708,17 @@ struct HipBackend {
             ~EvFree() { for (hipEvent_t e : v) if (e) (void)hipEventDestroy(e); }
         } ev_free{evs};
         for (auto& e : evs) HIP_CHECK(hipEventCreate(&e));
-        for (int i = 0; i < warmup; ++i) enqueue_iteration(false, fuse_cone && i == 0);
+        for (int i = 0; i < warmup; ++i) enqueue_iteration(false, false);
         for (int i = 0; i < iters; ++i) {
             tev = evs.data() + (size_t)12 * i;
-            enqueue_iteration(false, fuse_cone && warmup == 0 && i == 0);
+            enqueue_iteration(false, false);
         }
         tev = nullptr;
-        if (fuse_cone) enqueue_iteration(true, false);
         HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipGetLastError());
         for (int i = 0; i < iters; ++i)
             for (int k = 0; k < 6; ++k) {
-                if (k == 5 && (!n_cone_blocks || fuse_cone)) continue;  // (fused cones: no cone launch in these iterations)
+                if (k == 5 && !n_cone_blocks) continue;
                 float ms = 0.f;
                 HIP_CHECK(hipEventElapsedTime(&ms, evs[(size_t)12 * i + 2 * k], evs[(size_t)12 * i + 2 * k + 1]));
                 us[6 + k] += 1e3 * (double)ms / iters;
@@ -2731,10 +2744,7 @@ struct HipBackend {
     // profiles/r05_graph_after_effect.txt -- a process that has destroyed a graph executable runs every LATER lock-step batch
     // 15 % slower (64 config-5 trials: 4130-4220 -> 3520-3580 problems/s after one default solve of any handle with a graph,
     // 4130 after the same solve without; the runtime's doing, not ours).  Blocks below kGraphMinIters are launched directly.
-    static int graph_min_iters() {
-        static const int v = std::getenv("SCORE_GRAPH_MIN_ITERS") ? std::max(2, std::atoi(std::getenv("SCORE_GRAPH_MIN_ITERS"))) : 16;
-        return v;
-    }
+    static constexpr int graph_min_iters() { return 16; }
     void run(int iters) {
         if (st.use_graph && iters >= graph_min_iters()) {
             if (!graph_exec || graph_iters != iters) build_graph(iters);
@@ -2905,7 +2915,7 @@ struct HipBackend {
         else if (nm == "s") { src = s.d; sz = h.m_tot; }
         else if (nm == "r") { src = r.d; sz = h.n_tot; }
         else if (nm == "z") { src = z.d; sz = h.n_tot; }
-        else if (nm == "p") { src = dbg_p ? dbg_p : ((cg_iters % 2 == 1) ? p.d : p2.d); sz = h.n_tot; }  // last PCG direction (fused cones: INIT may have started in p2)
+        else if (nm == "p") { src = dbg_p ? dbg_p : ((cg_iters % 2 == 1) ? p.d : p2.d); sz = h.n_tot; }  // last PCG direction
         else if (nm == "w") { src = w.d; sz = h.n_tot; }
         else if (nm == "kx") { src = kx.d; sz = h.n_tot; }
         else if (nm == "D" && h.device_setup) { src = Dd.d; sz = h.n_tot; }
@@ -2958,6 +2968,17 @@ struct HipBackend {
             const double v[3] = {(double)h.rep, (double)h.K.col.size(), (double)(h.device_setup ? (size_t)g1_nnz : h.G1.col.size())};
             if (out && len > 0) std::memcpy(out, v, sizeof(double) * (size_t)std::min<int64_t>(len, 3));
             return 3;
+        }
+        else if (nm == "links") {  // [node pairs outside the chains, pairs inside the preconditioner, unknowns, affected chains, rounds, problems whose capacitance matrix was singular]
+            double v[6] = {(double)link_plan.pairs_total, (double)link_plan.pairs_used, (double)n_link_u, (double)n_link_items, (double)link_rounds, 0.0};
+            if (n_link_probs && out) {
+                std::vector<int32_t> stt((size_t)n_link_probs);
+                HIP_CHECK(hipStreamSynchronize(stream));
+                HIP_CHECK(hipMemcpy(stt.data(), link_status.d, sizeof(int32_t) * (size_t)n_link_probs, hipMemcpyDeviceToHost));
+                for (int32_t x : stt) v[5] += x;
+            }
+            if (out && len > 0) std::memcpy(out, v, sizeof(double) * (size_t)std::min<int64_t>(len, 6));
+            return 6;
         }
         else if (nm == "fac") { src = fac.d; sz = (int64_t)h.fac_doubles; }
         else if (nm == "newton_probe_arm") {  // the next polish times its PCG launches (see probe_slot)
@@ -3377,9 +3398,6 @@ struct HipBackend {
 
     void init_polish(const HostSystem& h) {
         PhaseTimer pt(st.verbose != 0);
-        if (const char* e = std::getenv("SCORE_NEWTON_ETA_MAX")) newton_eta_max = std::atof(e);
-        if (const char* e = std::getenv("SCORE_NEWTON_ETA_COEF")) newton_eta_coef = std::atof(e);
-        if (const char* e = std::getenv("SCORE_NEWTON_ETA_POW")) newton_eta_pow = std::atof(e);
         if (polish_build.valid()) polish_build.get();  // (rethrows what build_polish threw)
         pt.mark("  polish: host structures (wait)");
         bool on_device = false;
@@ -3646,8 +3664,7 @@ struct HipBackend {
         PolishArgs pa = polish_args(Xbuf);
         hipLaunchKernelGGL(k_newton_cone_b, dim3(n_cone_blocks), dim3(kThreads), 0, stream, pa, batch_tables());
         SpmvArgs ga = spmv_args(G2, Xbuf);
-        // -g goes to its own buffer, not to the PCG residual r: an unfinished PCG solve can then be
-        // resumed after the evaluation of a trial point
+        // (-g goes to its own buffer, not to the PCG residual r)
         ga.is_head = q_ishead.d; ga.gout = q_g.d; ga.r = q_negg.d; ga.done = q_skip.d;
         const unsigned ggrid = xcd_grid(ga, G2.nblocks);
         hipLaunchKernelGGL(k_spmv<MODE_GRAD>, dim3(ggrid), dim3(kThreads), 0, stream, ga);
@@ -3684,10 +3701,8 @@ struct HipBackend {
 
     // Queue PCG iterations on H delta = -g for the problems in `live`, each to its own relative
     // tolerance eta[p]; a problem's launches turn into no-ops once its gate has fired (q_skip[p] is
-    // raised by the device).  No host synchronisation.  `resume`: continue the solve the previous
-    // call left unfinished (its state -- delta, r, z, p, w, the r'z partials -- is intact because a
-    // gate that has not fired has not frozen anything).
-    // host-side cost of queueing the Newton PCG (SCORE_HOST_TIMING: printed when the handle goes)
+    // raised by the device).  No host synchronisation.
+    // host-side cost of queueing the Newton PCG (SCORE_TRACE=host: printed when the handle goes)
     double enq_ms = 0.0, wait_ms = 0.0;
     long enq_launches = 0, waits = 0;
     int pcg_steps_queued = 0;
@@ -3695,11 +3710,9 @@ struct HipBackend {
     double* pcg_p_cur = nullptr;
     double* pcg_p_oth = nullptr;
     PrecArgs pcg_pa{};
-    // start a PCG solve (INIT + first product) or take up the one the previous call left unfinished
-    void newton_pcg_begin(const std::vector<char>& live, bool resume) {
+    // start a PCG solve (INIT + first product); the control words -- skip flags, tolerances -- were uploaded by the caller
+    void newton_pcg_begin() {
         const HostSystem& h = *H;
-        // (a fresh solve finds its control words -- skip flags, tolerances -- uploaded by the caller)
-        if (resume) upload_skip(live);
         PrecArgs& pa = pcg_pa;
         pa = PrecArgs{};
         pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.rec = prec_recH.d; pa.fac = q_fac.d;
@@ -3708,7 +3721,7 @@ struct HipBackend {
         pa.r = r.d; pa.r_in = r.d; pa.z = z.d; pa.w = w.d; pa.xt = q_delta.d; pa.kx = q_dummy.d; pa.pw_part = q_pw.d;
         pa.gate_used = q_gate_used.d;
         pa.early_done = 1;  // launches queued beyond the gate are no-ops: keep them cheap
-        if (!resume) {
+        {
             // the right-hand side is read where the evaluation left it (-g in q_negg) and the solution
             // starts from zero without a memset: the first STEP writes r and delta
             pcg_rz_cur = rz_part0.d; pcg_p_cur = p.d; pcg_p_oth = p2.d;
@@ -3723,15 +3736,11 @@ struct HipBackend {
             SpmvArgs a = spmv_args(Hm, pcg_p_cur);
             a.p = pcg_p_cur; a.pw_part = q_pw.d; a.done = q_skip.d;
             launch_h<MODE_KP>(a);
-        } else {
-            // flags of the problems that go on: lowered again (their gates had not fired; the host's skip
-            // flags now hold exactly the resumed set)
-            hipLaunchKernelGGL(k_fetch, dim3(1), dim3(kThreads), 0, stream, (const int32_t*)q_skip.d, q_pcgdone.d, h.count);
         }
         pa.done = q_pcgdone.d;
         pa.gate_flag = q_pcgdone.d; pa.gate_tol2 = q_gate_tol2.d; pa.gate_ref = q_gate_ref.d;
         pa.gate_host = d_gate_live; pa.gate_epoch = gate_epoch; pa.gate_count = h.count;
-        pcg_first = !resume;
+        pcg_first = true;
     }
     bool pcg_first = false;
     // one PCG iteration: STEP (delta += a p ; r -= a w ; z = M^-1 r -- or: the gate fires, nothing happens), then the product
@@ -3759,15 +3768,6 @@ struct HipBackend {
         }
         pcg_rz_cur = rz_nxt;
     }
-    void newton_pcg_enqueue(const std::vector<char>& live, const std::vector<double>& eta, int n_iters, bool resume) {
-        struct EnqTimer {
-            HipBackend* b; double t0; int n;
-            ~EnqTimer() { b->enq_ms += now_ms() - t0; b->enq_launches += 2 * n + 2; }
-        } enq_timer{this, now_ms(), n_iters};
-        (void)eta;
-        newton_pcg_begin(live, resume);
-        for (int j = 0; j < n_iters; ++j) newton_pcg_pair();
-    }
     // The PCG queued a few iterations AHEAD of the device instead of to a guessed length: pcg_gate's lead workgroups publish
     // "fired" and "STEPs executed" in host-mapped memory as they go (PrecArgs::gate_host); the host keeps `depth` iterations
     // in the queue beyond what has executed and stops at the first look that shows every live problem's gate fired.  At most
@@ -3775,8 +3775,8 @@ struct HipBackend {
     // missing (no resume).  Returns the iterations queued.
     int newton_pcg_follow(const std::vector<char>& live, int cap) {
         const HostSystem& h = *H;
-        static const int depth = std::getenv("SCORE_PCG_DEPTH") ? std::max(1, std::atoi(std::getenv("SCORE_PCG_DEPTH"))) : 3;
-        newton_pcg_begin(live, false);
+        constexpr int depth = 3;  // (iterations kept in the queue beyond what the device has executed; 2-5 measured alike, TRIED.md)
+        newton_pcg_begin();
         int queued = 0;
         const auto t0 = std::chrono::steady_clock::now();
         unsigned spins = 0;
@@ -3850,9 +3850,6 @@ struct HipBackend {
             for (int p = 0; p < count; ++p) tolp[p] = std::max(tol, 0.5 * (s_.eps_abs + s_.eps_rel * (*dual_scale)[p]));
         std::vector<char> live(count), stalled(count, 0);
         int it = 0;
-        int n_pcg = 12;  // PCG iterations queued for the first Newton step
-        int used_prev = 0;
-        std::vector<double> eta_prev(count, 0.0);
         const int it_max = newton_limit > 0 ? std::min(50, newton_limit) : 50;
         for (; it < it_max; ++it) {
             any = false;
@@ -3865,15 +3862,6 @@ struct HipBackend {
                 const double enough = gn[p] > 0.0 ? 0.1 * tolp[p] / gn[p] : 1.0;
                 eta[p] = std::min(newton_eta_max, std::max(superlinear, enough));
             }
-            // PCG iterations to queue: what the previous Newton step needed, scaled by the digits this
-            // one asks for (PCG converges linearly), plus a margin; skipped launches cost ~2 us each
-            if (it > 0 && used_prev > 0) {
-                double scale = 1.0;
-                for (int p = 0; p < count; ++p)
-                    if (live[p] && eta_prev[p] > 0.0 && eta_prev[p] < 1.0 && eta[p] < 1.0)
-                        scale = std::max(scale, std::log(eta[p]) / std::log(eta_prev[p]));
-                n_pcg = std::min(400, (int)std::ceil(used_prev * std::min(scale, 4.0)) + 3);
-            }
             // ONE upload of the control words serves the whole iteration: skip = !live for the Hessian,
             // the PCG solve and the first trial point; the PCG tolerances; unit step lengths
             for (int p = 0; p < count; ++p) { c_tol2[p] = eta[p] * eta[p]; c_step[p] = 1.0; }
@@ -3881,12 +3869,12 @@ struct HipBackend {
             // moved since they were last computed (act_flips, counted by the evaluation kernel): in the last Newton
             // iterations the blocks of B change by the step alone and the factors of the previous iteration
             // precondition as well (same PCG counts; k_factor + k_fac_round + k_deep_pack are 60-150 us a time).
-            static const double flip_tol = std::getenv("SCORE_REFACTOR_FLIPS") ? std::atof(std::getenv("SCORE_REFACTOR_FLIPS")) : 0.0;
+            constexpr double flip_tol = 0.0;
             // (decided problem by problem: what a problem computes never depends on its batch mates)
             bool refactor = false;
             c_reref.assign((size_t)count, 0);
             for (int p = 0; p < count; ++p) {
-                c_reref[p] = live[p] && (it == 0 || flip_tol < 0.0 || act_flips[p] > flip_tol);
+                c_reref[p] = live[p] && (it == 0 || act_flips[p] > flip_tol);
                 refactor = refactor || c_reref[p];
             }
             if (st.verbose) {
@@ -3898,45 +3886,27 @@ struct HipBackend {
             upload_skip(live, /*consume=*/true);
             np_newton_it = it;
             newton_hessian(q_fskip.d, refactor);  // (a frozen problem's short entries keep their values, see k_hassemble)
-            static const bool guess_queue = std::getenv("SCORE_PCG_GUESS") != nullptr;  // (the round-2 queue: a length guessed from the previous iteration)
-            if (guess_queue) newton_pcg_enqueue(live, eta, n_pcg, false);
-            else newton_pcg_follow(live, 400);
-            eta_prev = eta;
-            bool control_stale = false;
+            newton_pcg_follow(live, 400);  // (queued a few iterations ahead of the device until every live problem's gate has fired)
             int used_now = 0;
             // backtracking per problem; a problem leaves the search when its step is accepted
             std::vector<char> ls = live, accepted(count, 0);
             for (int p = 0; p < count; ++p) step[p] = 1.0;
             for (int k = 0; k < 40; ++k) {
-                if (k > 0 || control_stale) {
+                if (k > 0) {
                     c_step = step;
                     upload_skip(ls);  // (uploads the step lengths too)
-                    control_stale = false;
                 }
                 va.u = X; va.delta = q_delta.d; va.step = 0.0; va.out = Xt;
                 hipLaunchKernelGGL(k_newton_trial_b, dim3(nbh), dim3(kThreads), 0, stream, va, batch_tables());
                 newton_eval_enqueue(Xt);  // overwrites nu / B / g of the problems searched; copies gd and the gate words too
                 // (the usual course -- full step accepted, next iteration -- starts with a control upload and the assembly of H
                 //  from the blocks this evaluation leaves: both queued now, behind the evaluation, waiting for the host's words)
-                if (k == 0 && !control_stale && it + 1 < it_max) prequeue_control();
+                if (k == 0 && it + 1 < it_max) prequeue_control();
                 wait_published(eval_seq);  // the one wait of a Newton iteration (step 1 accepted)
                 if (k == 0) {
-                    // a problem whose queue ran dry before its gate fired resumes its PCG (state intact);
-                    // the trial point and its evaluation are then redone
-                    std::vector<char> more(count, 0);
-                    bool any_more = false;
                     used_now = 0;
-                    for (int p = 0; p < count; ++p) {
-                        if (!live[p]) continue;
-                        used_now = std::max(used_now, (int)h_gate[count + p]);
-                        if (!h_gate[p] && h_gate[count + p] < 400) { more[p] = 1; any_more = true; }
-                    }
-                    if (any_more) {
-                        newton_pcg_enqueue(more, eta, std::max(4, used_now / 2), true);
-                        control_stale = true;  // the skip flags now describe the resumed set
-                        --k;  // same step length again
-                        continue;
-                    }
+                    for (int p = 0; p < count; ++p)
+                        if (live[p]) used_now = std::max(used_now, (int)h_gate[count + p]);
                 }
                 newton_eval_collect(ls, Ft, gt);
                 if (k == 0) {
@@ -3946,7 +3916,6 @@ struct HipBackend {
                         for (int b = Q.rbH.part_ptr[p]; b < Q.rbH.part_ptr[p + 1]; ++b) gd[p] += h_gd[b];
                     }
                     pcg_used_total += used_now;
-                    used_prev = used_now;
                     probe_mark(used_now);
                 }
                 std::vector<int32_t> acc_now(count, 0);
@@ -3990,7 +3959,7 @@ struct HipBackend {
                 if (live[p] && !accepted[p]) { stalled[p] = 1; any_stalled = true; }
             if (st.verbose) {
                 for (int p = 0; p < count; ++p)
-                    if (live[p]) std::fprintf(stderr, "[score] newton it %d prob %d F %.12g |g| %.3e step %.3g pcg %d (conv %d, queued next %d) t %.3f ms%s\n", it + 1, p, F[p], gn[p], step[p], h_gate[count + p], h_gate[p], n_pcg, now_ms() - t_start, stalled[p] ? " (stalled)" : "");
+                    if (live[p]) std::fprintf(stderr, "[score] newton it %d prob %d F %.12g |g| %.3e step %.3g pcg %d (conv %d) t %.3f ms%s\n", it + 1, p, F[p], gn[p], step[p], h_gate[count + p], h_gate[p], now_ms() - t_start, stalled[p] ? " (stalled)" : "");
             }
             if (any_stalled) {  // re-establish nu / B / g of the current point of the stalled problems
                 std::vector<char> sv(stalled.begin(), stalled.end());
@@ -4277,7 +4246,6 @@ void score_default_settings(score_settings* s) { score::default_settings(s); }
 static void tune_host_allocator_once() {
     static std::once_flag once;
     std::call_once(once, [] {
-        if (std::getenv("SCORE_KEEP_MALLOC_DEFAULTS")) return;
         // (glibc refuses an mmap threshold above HEAP_MAX_SIZE / 2 = 32 MiB and then keeps its default -- a
         //  larger request here used to be a silent no-op)
         mallopt(M_MMAP_THRESHOLD, 32 << 20);

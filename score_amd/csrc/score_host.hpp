@@ -51,6 +51,23 @@ constexpr int kLongVals = 4;        // sums a segment publishes (up to 3 right-h
 constexpr int kConesPerBlock = 256;
 constexpr int kMaxBs = 4;
 
+// Diagnostics on stderr / stdout, ONE switch: SCORE_TRACE=<comma-separated list> of
+//   cache (every raw hipMalloc / hipHostMalloc of the block cache), host (queueing and wait times of a handle, printed when it
+//   goes), stamps (per-workgroup timeline of score_time_iteration), band (phases of the band-layout builder), assemble (phases
+//   of the host assembler), headform (which check of the QCQP rewrite declined a program).  Nothing here changes a result.
+inline bool trace_on(const char* what) {
+    static const std::string list = [] { const char* e = std::getenv("SCORE_TRACE"); return std::string(e ? e : ""); }();
+    if (list.empty()) return false;
+    const std::string w(what);
+    size_t at = 0;
+    while (at <= list.size()) {
+        const size_t end = std::min(list.find(',', at), list.size());
+        if (list.compare(at, end - at, w) == 0 || list.compare(at, end - at, "all") == 0) return true;
+        at = end + 1;
+    }
+    return false;
+}
+
 // Setup work (equilibration, K = P + sigma I + rho A'A, chain factorisations) is split into
 // contiguous index ranges over a few host threads.  Every range computes exactly what the serial
 // loop would, so results do not depend on the thread count.
@@ -129,13 +146,7 @@ struct BuildScope {
 // variable, and the caller spins for the last part before it sleeps: the parallel phases of one setup follow each other
 // within tens of microseconds, and waking 15 sleepers through one mutex cost 0.1-0.2 ms per phase -- more than many of
 // the phases themselves (a headline score_create is ~29 ms of single-thread work and took 10 ms on 16 threads).
-inline int team_spin_us() {  // SCORE_TEAM_SPIN_US (0: sleep at once)
-    static const int v = [] {
-        const char* e = std::getenv("SCORE_TEAM_SPIN_US");
-        return e ? std::max(0, std::atoi(e)) : 120;
-    }();
-    return v;
-}
+constexpr int team_spin_us() { return 120; }
 struct HostTeam {
     std::mutex m;
     std::condition_variable cv_work, cv_done;
@@ -272,7 +283,7 @@ inline int region_width() {
     // many builders at once (the lock-step groups of a Monte-Carlo sweep start together): nobody takes more than its share --
     // the first to open a region used to take every free thread and left the others serial (8 groups' model construction:
     // 17-22 ms per group, the last one done 24-28 ms into the sweep)
-    if (callers >= 4 && std::getenv("SCORE_NO_FAIR_SHARE") == nullptr) width = std::min(width, std::max(1, (host_threads() + callers - 1) / callers));
+    if (callers >= 4) width = std::min(width, std::max(1, (host_threads() + callers - 1) / callers));
     return width;
 }
 
@@ -835,14 +846,7 @@ inline void chain_solve_host(const ChainDesc& ch, const ChainLevelDesc* levels, 
 // exact solve with the whole chain's block-tridiagonal matrix, as the streaming kernel computes it.
 constexpr int kSegMaxNodes = 1023;
 constexpr int kJoinMaxSepsHost = 64;  // == score_join.hpp kJoinMaxSeps (static_assert there): separators of one long chain
-inline int seg_max_nodes() {  // (SCORE_SEG_NODES: shorter segments, for experiments -- profiles/TRIED.md)
-    static const int v = [] {
-        const char* e = std::getenv("SCORE_SEG_NODES");
-        const int x = e ? std::atoi(e) : kSegMaxNodes;
-        return x < 15 ? 15 : (x > kSegMaxNodes ? kSegMaxNodes : x);
-    }();
-    return v;
-}
+constexpr int seg_max_nodes() { return kSegMaxNodes; }  // (shorter segments: slower everywhere, profiles/r05_seg_nodes_ab.txt)
 struct JoinChain {
     int32_t prob, n_seg;
     int32_t first_chain;  // H.chains index of segment 0 (the segments follow)
@@ -972,8 +976,7 @@ inline RowBlocks make_rowblocks(const Csr& M, const std::vector<RowSegment>& seg
             rb.rs.push_back(sg.rs);
             int64_t len0 = M.ptr[r + 1] - M.ptr[r];
             if (len0 > kLongRow) {  // a long row is a block of its own -- or several (kLongSeg)
-                static const bool no_split = std::getenv("SCORE_NO_LONG_SPLIT") != nullptr;
-                const int nseg = (len0 > kLongSeg && !no_split) ? (int)std::min<int64_t>(kLongSegMax, (len0 + kLongSeg - 1) / kLongSeg) : 1;
+                const int nseg = (len0 > kLongSeg) ? (int)std::min<int64_t>(kLongSegMax, (len0 + kLongSeg - 1) / kLongSeg) : 1;
                 const int32_t bfirst = (int32_t)rb.prob.size() - 1;
                 for (int sgi = 0; sgi < nseg; ++sgi) {
                     if (sgi) { rb.first_row.push_back((int32_t)r); rb.prob.push_back(sg.prob); rb.rs.push_back(sg.rs); }
@@ -1639,10 +1642,11 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     // Equilibration is independent per problem: a batch of small problems (each below the row count
     // at which ruiz_scale splits its own passes over threads) is scaled one problem per thread.
     std::vector<ProblemScaled> scaled((size_t)count);
-    // (OPT-IN, SCORE_BATCH_DEVICE_RUIZ=1: the passes of a batch's problems on the device as well, each from its part's thread.
-    //  Measured on the 64-trial sweep, A/B on one box: 850-1010 graphs/s against 980-1090 with the host loop -- eight groups
-    //  times eight problems times 45 small launches and a synchronisation each crowd the queues the solves need.)
-    RuizOffload* batch_offload = std::getenv("SCORE_BATCH_DEVICE_RUIZ") ? ruiz_offload : nullptr;
+    // (host setup of a BATCH: the passes stay on the host -- offloading each problem's passes from its part's thread measured
+    //  slower, 850-1010 graphs/s against 980-1090: profiles/TRIED.md; the device setup path does not come here at all)
+    // SCORE_HOST_SETUP=1 (the host setup asked for explicitly -- tests compare it with the device setup bit for bit): the passes
+    // run where the device setup's do, so that both sides start from the same scales.
+    RuizOffload* batch_offload = std::getenv("SCORE_HOST_SETUP") ? ruiz_offload : nullptr;
     if (count > 1 && !lite) {
         parallel_ranges(count, 1, [&](int, int64_t p0, int64_t p1) {
             for (int64_t p = p0; p < p1; ++p) ruiz_scale(probs[p], std::max(0, st.scale_iters), scaled[(size_t)p], H.rep, H.rep_n[(size_t)p], nullptr, batch_offload);
@@ -1748,14 +1752,10 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     }
     H.cone_block_first.push_back((int32_t)H.cone_row.size());
     if (factor_on_host) H.K.val.assign(H.K.col.size(), 0.0);  // (a backend that derives K = K0 + rho K1 itself never reads it)
-    // Tile size of K and G1 (SCORE_TILE_NNZ: 1024 / 2048 for replicated problems).  Measured on the headline problem,
+    // Tile size of K and G1.  Measured on the headline problem,
     // whose replicated K is 250 tiles of 2048 nonzeros -- one per CU: half-size tiles are SLOWER (kp 7.3 -> 7.8 us,
     // kpb 7.8 -> 8.6 us): the SpMV of a single problem is a chain of dependent trips to memory, not a throughput loop.
     H.tile_nnz = kTileNnz;
-    if (const char* e = std::getenv("SCORE_TILE_NNZ")) {
-        const int v = std::atoi(e);
-        if (H.rep > 1 && (v == kTileNnz || v == kTileNnz / 2)) H.tile_nnz = v;
-    }
     if (!lite) make_system_rowblocks(H);
     pt.mark("row blocks");
 

@@ -187,39 +187,10 @@ struct BandDev {
     int32_t offw[kBandMaxS / 2];  // slot pair j: window offset of its first slot, class c in byte c
 };
 
-// The cone projections of the PREVIOUS iteration recomputed by the rows of the right-hand-side kernel that need A'u
-// (single-problem handles whose cones are all small second-order cones with a private head column: every SCORE "SOCP"
-// model): one launch per ADMM iteration less.  An entry (row i of u, value) of A' stands for a whole cone -- its d + 1
-// rows are evaluated at x~ = xt + step * pfin from the packed cone record, exactly as k_cone does -- and yields u for
-// the entry's rows.  The entry of the cone's HEAD row (it sits in the row of the cone's private head variable, once)
-// also writes the cone's new s, y and u -- into the OTHER copy of s and y: the other rows' evaluations of this launch
-// still read the old ones.
-struct FuseArgs {
-    int on;                   // 0: a plain right-hand side (u is gathered)
-    int dim;                  // rows per cone (d + 1)
-    int u_col0;               // column of u[0] in the gathered buffer [xt ; u] (= n_tot)
-    const int4* cone_cols;    // as ConeArgs
-    const double2* cone_vals;
-    const double* b;
-    const double* rho;
-    const double* s_old;
-    const double* y_old;
-    double* s_new;
-    double* y_new;
-    double* u_out;
-    const double* xt;
-    const double* pfin;       // last PCG direction (the pending step's)
-    const double* rz_in;      // partial sums of that step's r'z and p'w: step = r'z / p'w (as k_cone forms it)
-    const double* pw_in;
-    double* step_out;         // published by tile 0: the next kernel (INIT) applies xt += step * pfin
-    double alpha_relax;
-};
-
 struct SpmvArgs {
     UniRanges uni;
     CsrDev M;
     BandDev B;              // (k_spmv_band only)
-    FuseArgs F;             // (MODE_RHS of a single-problem handle)
     const double* xin;      // gathered vector
     const int32_t* done;
     int xcd_chunk;          // > 0: tiles are dealt to the XCDs in contiguous runs of this many (workgroup i runs on XCD i % 8 and
@@ -284,61 +255,6 @@ __device__ __forceinline__ void soc_scales(int type, double t0, double nz2, doub
     if (nz <= t0) { head = t0; tail = 1.0; }
     else if (nz <= -t0) { head = 0.0; tail = 0.0; }
     else { const double m = 0.5 * (t0 + nz); head = m; tail = m / nz; }
-}
-
-// u of the rows i0 .. i0 + NU - 1 of one small cone (FuseArgs): the cone of row i0, evaluated as in k_cone's register path.
-// `write`: this entry is the cone's head-row entry -- store the cone's new s, y, u.
-template <int NU>
-__device__ __forceinline__ void fused_cone_u(const FuseArgs& f, const int i0, const double step, const bool valid, double (&uo)[NU]) {
-    static_assert(kMaxRep + 1 <= 4, "small cones: at most 4 rows");
-    const int dim = f.dim;
-    const int cl = max(i0, 0) / dim;          // cone index (rows of the cones are consecutive, dim each, from row 0)
-    const int k0 = max(i0, 0) - cl * dim;     // row of the entry within its cone
-    const int row = cl * dim;
-    const int4 pc0 = f.cone_cols[2 * cl], pc1 = f.cone_cols[2 * cl + 1];
-    const double2 pv0 = f.cone_vals[4 * cl], pv1 = f.cone_vals[4 * cl + 1], pv2 = f.cone_vals[4 * cl + 2], pv3 = f.cone_vals[4 * cl + 3];
-    const int cc[4][2] = {{pc0.x, pc0.y}, {pc0.z, pc0.w}, {pc1.x, pc1.y}, {pc1.z, pc1.w}};
-    const double av[4][2] = {{pv0.x, pv0.y}, {pv1.x, pv1.y}, {pv2.x, pv2.y}, {pv3.x, pv3.y}};
-    double bv[4], yv[4], sv[4], xv[4][2], pq[4][2];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = row + min(k, dim - 1);
-        bv[k] = f.b[i]; yv[k] = f.y_old[i]; sv[k] = f.s_old[i];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) { xv[k][e] = f.xt[cc[k][e]]; pq[k][e] = f.pfin[cc[k][e]]; }
-    const double rho = f.rho[0], irho = 1.0 / rho, al = f.alpha_relax;
-    double v[4], wv[4], t0 = 0.0, nz2 = 0.0, head, tail;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        // (missing entries of the packed record hold value 0: they add an exact zero, as the predicate in k_cone does)
-        double tt = 0.0;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) tt += av[k][e] * (xv[k][e] + step * pq[k][e]);
-        v[k] = al * (bv[k] - tt) + (1.0 - al) * sv[k];
-        wv[k] = v[k] - yv[k] * irho;
-        if (k == 0) t0 = wv[k]; else if (k < dim) nz2 += wv[k] * wv[k];
-    }
-    soc_scales(1, t0, nz2, head, tail);
-    double sn[4], yn[4], un[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        sn[k] = (k == 0) ? head : tail * wv[k];
-        yn[k] = yv[k] + rho * (sn[k] - v[k]);
-        un[k] = rho * (bv[k] - sn[k]) - yn[k];
-    }
-    if (valid && k0 == 0) {  // the head-row entry: the cone's new state
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (k < dim) { f.s_new[row + k] = sn[k]; f.y_new[row + k] = yn[k]; f.u_out[row + k] = un[k]; }
-    }
-#pragma unroll
-    for (int q = 0; q < NU; ++q) {
-        const int k = k0 + q;
-        uo[q] = k == 0 ? un[0] : (k == 1 ? un[1] : (k == 2 ? un[2] : un[3]));
-    }
 }
 
 // The FIRST trip of a tile kernel: everything that depends on the tile index alone -- the tile record(s), the problem, the
@@ -408,23 +324,12 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
             for (int i = pi0 + kThreads; i < pl1; i += kThreads) { acc_n += a.rz_new[i]; acc_o += a.rz_old[i]; }
         }
     };
-    // RHS: the step length of the last PCG step was published by the cone kernel -- or (fused cones, FuseArgs) is formed
-    // here from the partial sums of r'z and p'w, in k_cone's order
-    const bool fuse = (MODE == MODE_RHS) && a.F.on;
-    if (MODE == MODE_RHS && a.apply_update && !fuse) beta = a.step_in[prob];
-    if (fuse) {
-        for (int i = a.uni.l0 + t; i < a.uni.l1; i += kThreads) acc_n += a.F.rz_in[i];
-        for (int i = a.uni.k0 + t; i < a.uni.k1; i += kThreads) acc_o += a.F.pw_in[i];
-    }
+    // RHS: the step length of the last PCG step was published by the cone kernel
+    if (MODE == MODE_RHS && a.apply_update) beta = a.step_in[prob];
     auto finish_beta = [&]() {
         if (MODE == MODE_KPB) {
             block_sum2(acc_n, acc_o, red);
             beta = acc_o > 0.0 ? acc_n / acc_o : 0.0;
-        }
-        if (fuse) {
-            block_sum2(acc_n, acc_o, red);
-            beta = acc_o > 0.0 ? acc_n / acc_o : 0.0;
-            if (b_in == 0 && t == 0) a.F.step_out[0] = beta;  // (the INIT launch that follows applies xt += step * pfin)
         }
     };
 
@@ -477,20 +382,14 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
                 c[u] = col[k];
                 v[u] = val[k];
             }
-            if (!fuse) {
 #pragma unroll
-                for (int u = 0; u < kLongUnroll; ++u) {
+            for (int u = 0; u < kLongUnroll; ++u) {
 #pragma unroll
-                    for (int q = 0; q < NR; ++q) g[u][q] = xin[c[u] + q * rs_in];
-                }
+                for (int q = 0; q < NR; ++q) g[u][q] = xin[c[u] + q * rs_in];
             }
             load_partials();
             if (dn) return;  // (uniform over the workgroup)
             finish_beta();
-            if (fuse) {
-#pragma unroll
-                for (int u = 0; u < kLongUnroll; ++u) fused_cone_u<NR>(a.F, c[u] - a.F.u_col0, beta, kb0 + u * kThreads < k1, g[u]);
-            }
 #pragma unroll
             for (int u = 0; u < kLongUnroll; ++u) {
                 const int k = kb0 + u * kThreads;
@@ -510,15 +409,10 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
                 c[u] = col[k];
                 v[u] = val[k];
             }
-            if (fuse) {
 #pragma unroll
-                for (int u = 0; u < kLongUnroll; ++u) fused_cone_u<NR>(a.F, c[u] - a.F.u_col0, beta, kb + u * kThreads < k1, g[u]);
-            } else {
+            for (int u = 0; u < kLongUnroll; ++u) {
 #pragma unroll
-                for (int u = 0; u < kLongUnroll; ++u) {
-#pragma unroll
-                    for (int q = 0; q < NR; ++q) g[u][q] = xin[c[u] + q * rs_in];
-                }
+                for (int q = 0; q < NR; ++q) g[u][q] = xin[c[u] + q * rs_in];
             }
 #pragma unroll
             for (int u = 0; u < kLongUnroll; ++u) {
@@ -653,26 +547,14 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
             c[u] = col[k0 + k];
             v[u] = val[k0 + k];
         }
-        if (!fuse) {
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
+        for (int u = 0; u < UNR; ++u) {
 #pragma unroll
-                for (int q = 0; q < NR; ++q) g[u][q] = xin[c[u] + q * rs_in];
-            }
+            for (int q = 0; q < NR; ++q) g[u][q] = xin[c[u] + q * rs_in];
         }
         load_partials();
         if (dn) return;  // (uniform over the workgroup; nothing has been written)
         finish_beta();
-        if (fuse) {
-            // one cone evaluation per entry, slot by slot (a tile of A' holds one or two entries per lane; the slots beyond the
-            // tile's nonzeros are skipped by the whole workgroup)
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-#pragma unroll
-                for (int q = 0; q < NR; ++q) g[u][q] = 0.0;
-                if (u * kThreads < nn) fused_cone_u<NR>(a.F, c[u] - a.F.u_col0, beta, t + u * kThreads < nn, g[u]);
-            }
-        }
         // (every lane stores all its products: slots beyond the tile's last nonzero hold copies of the last product and
         //  are never read -- a row adds the slots of its own nonzeros only -- and a predicated store is an exec-mask
         //  branch per product)
@@ -728,7 +610,7 @@ __device__ __forceinline__ void spmv_tile(const SpmvArgs& a, const int b_in, con
                     const double xt = e3[q] + beta * e4[q];
                     kxv += beta * e5[q];
                     xv = a.alpha_relax * xt + (1.0 - a.alpha_relax) * xv;
-                    if (!fuse) NTS(a.xt_rw[o], xt);  // (fused cones: other rows of this launch gather the OLD xt; INIT applies the step)
+                    NTS(a.xt_rw[o], xt);
                     NTS(a.kx_rw[o], kxv);
                     NTS(a.x_rw[o], xv);
                 }
@@ -1168,8 +1050,6 @@ struct PrecArgs {
     double* rz_out;        // one partial per work item
     unsigned long long* tstamp;  // see KernelStamp
     int debug_skip;        // timing experiments only: 1 run, 2 separator, 4 back-subst, 8 head, 16 tail
-    const double* pend_p;     // INIT with fused cones (FuseArgs): the helper items (kind 2) apply the PREVIOUS iteration's last
-    const double* pend_step;  // PCG step, xt += pend_step[0] * pend_p (the right-hand-side kernel no longer does: it gathers the old xt)
     int split_update;      // STEP of k_prec_pre: xt += alpha p, kx += alpha w are done by the helper items (kind 2) of this
                            // launch, on CUs the chains leave idle, instead of by the chain / Jacobi workgroups themselves
     // Device-side termination of a PCG solve (the Newton polish; null in the ADMM loop, whose PCG
@@ -1761,17 +1641,7 @@ __device__ __forceinline__ void prec_pre_body(const PrecArgs& a) {
         // outside the r'z partials): entries [index, index + count) of xt and kx.  alpha and the gate's verdict are
         // derived from the same partial sums in the same order as in the chain workgroups -- the same bits.
         if (dn || dn_late) return;
-        if (MODE == PREC_INIT) {  // the pending step of the previous iteration (fused cones)
-            if (!a.pend_p) return;
-            const double st = a.pend_step[0];
-            const int e_end_ = wk.index + wk.count;
-#pragma unroll
-            for (int u = 0; u < kPrecChunk; ++u) {
-                const int i = wk.index + t + u * kPrecThreads;
-                if (i < e_end_) a.xt[i] += st * a.pend_p[i];
-            }
-            return;
-        }
+        if (MODE == PREC_INIT) return;  // (helpers ride on STEP launches only)
         const double gref = (a.gate_flag && !a.gate_first) ? a.gate_ref[prob] : 0.0;
         const int e_end = wk.index + wk.count;
         int idx[kPrecChunk];
@@ -2325,7 +2195,7 @@ struct ConeArgs {
     const double* rho;
     const double* b;
     const double* xt;   // gathered (xt for the iteration, x for residuals)
-    const double* s_in; // k_cone's register path reads the old s, y here (fused cones: the copy the last fused evaluation wrote);
+    const double* s_in; // k_cone's register path reads the old s, y here;
     const double* y_in; // the new ones go to s, y
     double* s;
     double* y;

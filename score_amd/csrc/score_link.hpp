@@ -1,0 +1,371 @@
+// score_link.hpp -- loop closures inside the Newton preconditioner (round 6).
+//
+// The chain preconditioner T (score_kernels.hpp: k_prec_pre; score_join.hpp for chains beyond 1023 nodes) is the exact inverse
+// of the per-robot block-tridiagonal part of the Newton matrix H: what ODOMETRY couples (gurobi_utils.py:380-404).  A loop
+// closure (:407-430) is the same relative-pose term (:504-526) between two poses that are NOT neighbours in a chain -- as stiff
+// as an odometry edge and outside T.  Measured on the oracle's Newton systems (scratch prototype): a 2 x 397-pose
+// graph with two loop closures takes 377 PCG iterations with T alone and 97 with the loop-closure blocks inside the preconditioner,
+// 2 x 2570 poses with three 495 -> 106.
+//
+// With U the columns of the unknowns of the linked nodes (a selection: n_u <= kLinkMaxU per problem) and G = the entries of H
+// between linked nodes (the blocks T does not hold), the preconditioner becomes the exact inverse of T + U G U':
+//
+//     (T + U G U')^-1 r = y - Z t,    y = T^-1 r,   Z = T^-1 U,   t = Q y[U],   Q = (I + G Z[U,:])^-1 G          (Woodbury)
+//
+// Z e_u is nonzero on u's own chain only, so one application of the chain kernel to a sum of unit vectors -- one per chain --
+// yields one column for every chain at once: `rounds` = the most unknowns any chain carries (3 per linked pose and matrix row in
+// 2-D).  After every factorisation of H's chains (HipBackend::launch_factor -> link_refresh): the rounds (k_link_rhs + the chain
+// kernel, second level included), then k_link_cap: G from H's values, S = I + G Z[U,:], Q = S^-1 G by Gauss-Jordan with partial
+// pivoting in LDS (one workgroup per problem).  After every application of the chain kernel to the Newton set (launch_prec ->
+// link_apply): k_link_solve (t = Q y[U], one workgroup per problem) and k_link_apply (one workgroup per affected chain:
+// z -= Z t, and the chain's r'z partial sum restated with the corrected z) -- two launches because the first reads what the
+// second overwrites, as in score_join.hpp.  Graphs without loop closures never come here (n_items == 0: no launch, no buffer).
+//
+// The ADMM loop's K keeps T alone (the default solver runs six ADMM iterations); SCORE_NO_LINKS=1 switches the correction off.
+#pragma once
+
+#include <algorithm>
+#include <cstdint>
+#include <unordered_map>
+#include <vector>
+
+#include "score_join.hpp"
+
+namespace score {
+
+constexpr int kLinkMaxU = 96;       // unknowns of one problem the correction covers (8 loop closures in 2-D, 4 in 3-D)
+constexpr int kLinkMaxRounds = 24;  // unknowns of one (whole) chain: applications of the chain kernel per refresh
+constexpr int kLinkThreads = 256;
+
+struct LinkItem {   // one affected chain (a segment of a long chain: every segment of it) of a problem
+    int32_t prob, chain, work, sep_col;  // work: its slot of the r'z partial sums; sep_col: separator to its right (-1: none)
+    int32_t u[kLinkMaxRounds];           // per round: the unknown (index into the handle's unknown list) whose column this chain carries, -1 none
+};
+struct LinkProb {
+    int32_t prob, u_begin, n_u, q_off;   // q_off: first entry of the problem's n_u x n_u tables (mask / positions / Q')
+};
+
+// ---- host: which chain nodes do relative-pose terms couple outside the chains? (pairs of global first columns) ----
+inline void find_link_pairs_graphs(const HostSystem& h, const score_graph* graphs, std::vector<int32_t>& out) {
+    for (int p = 0; p < h.count; ++p) {
+        const score_graph& g = graphs[p];
+        const int d = g.dim, D1 = d + 1;
+        std::vector<int64_t> first((size_t)g.n_chains + 1, 0);
+        for (int c = 0; c < g.n_chains; ++c) first[(size_t)c + 1] = first[(size_t)c] + g.chain_len[c];
+        const int64_t Np = first[(size_t)g.n_chains];
+        const int64_t n_rep = (Np - 1) * D1 + g.n_landmarks + (g.relaxation == 0 ? 0 : g.n_rng);  // (graph_skeleton's layout)
+        auto chain_of = [&](int64_t v) { return (int)(std::upper_bound(first.begin(), first.end(), v) - first.begin()) - 1; };
+        for (int64_t e = 0; e < g.n_rel; ++e) {
+            const int64_t i = g.rel_base[e], j = g.rel_to[e];
+            if (i <= 0 || j <= 0 || i >= Np || j >= Np || i == j) continue;  // (the pinned pose is no unknown)
+            if ((i - j == 1 || j - i == 1) && chain_of(i) == chain_of(j)) continue;  // odometry: inside the chain
+            for (int k = 0; k < d; ++k) {
+                out.push_back((int32_t)(h.xoff[p] + k * n_rep + (std::min(i, j) - 1) * D1));
+                out.push_back((int32_t)(h.xoff[p] + k * n_rep + (std::max(i, j) - 1) * D1));
+            }
+        }
+    }
+}
+// The same from P's pattern (handles made from arrays): the row of a node's FIRST unknown -- a rotation entry, which only
+// relative-pose terms touch (range terms couple translations, also after the head-form rewrite) -- holds a column of a chain
+// node that is neither the node itself nor its neighbour in the chain.
+inline void find_link_pairs_P(const HostSystem& h, const score_problem* probs, std::vector<int32_t>& out) {
+    for (int p = 0; p < h.count; ++p) {
+        const score_problem& pr = probs[p];
+        if (!pr.P_rowptr || !pr.P_col || pr.n_chains <= 0 || !pr.node_first_col) continue;
+        const int bs = pr.block_size, nn = pr.chain_ptr[pr.n_chains];
+        std::vector<int32_t> node_of((size_t)pr.n, -1), chain_of((size_t)nn, 0);
+        for (int c = 0; c < pr.n_chains; ++c)
+            for (int j = pr.chain_ptr[c]; j < pr.chain_ptr[c + 1]; ++j) {
+                chain_of[(size_t)j] = c;
+                for (int a = 0; a < bs; ++a) node_of[(size_t)pr.node_first_col[j] + a] = j;
+            }
+        int32_t last_a = -1, last_b = -1;
+        for (int j = 0; j < nn; ++j) {
+            const int32_t r = pr.node_first_col[j];
+            for (int32_t k = pr.P_rowptr[r]; k < pr.P_rowptr[r + 1]; ++k) {
+                const int32_t j2 = node_of[(size_t)pr.P_col[k]];
+                if (j2 <= j) continue;
+                if (j2 == j + 1 && chain_of[(size_t)j2] == chain_of[(size_t)j]) continue;
+                const int32_t a = (int32_t)(h.xoff[p] + r), b = (int32_t)(h.xoff[p] + pr.node_first_col[j2]);
+                if (a == last_a && b == last_b) continue;  // (the other entries of the same block)
+                out.push_back(a); out.push_back(b);
+                last_a = a; last_b = b;
+            }
+        }
+    }
+}
+
+// What the backend uploads: unknowns, rounds, items, masks -- built from the pairs and the Newton set's chains.
+struct LinkPlan {
+    std::vector<LinkProb> probs;
+    std::vector<LinkItem> items;
+    std::vector<int32_t> ucol, uround, usuper;  // per unknown: global column, its round, its (whole) chain
+    std::vector<uint8_t> mask;                  // per problem n_u x n_u: 1 = (a, b) lie in linked nodes (an entry of G)
+    int rounds = 0;
+    int pairs_total = 0, pairs_used = 0;
+    bool empty() const { return items.empty(); }
+};
+inline void make_link_plan(const HostSystem& h, const std::vector<int32_t>& pairs, LinkPlan& L) {
+    L = LinkPlan();
+    L.pairs_total = (int)(pairs.size() / 2);
+    if (pairs.empty()) return;
+    const int bs = h.bs;
+    const std::vector<ChainDesc>& chains = h.chainsH;
+    // column -> (chain, node); whole-chain id of every chain (a long chain's segments share their join chain's)
+    std::unordered_map<int32_t, std::pair<int32_t, int32_t>> where;
+    where.reserve(pairs.size());
+    {
+        std::unordered_map<int32_t, int> wanted;
+        for (int32_t c : pairs) wanted[c] = 1;
+        for (size_t ci = 0; ci < chains.size(); ++ci)
+            for (int i = 0; i < chains[ci].N; ++i) {
+                const int32_t col = h.node_col[(size_t)chains[ci].node_begin + i];
+                if (wanted.count(col)) where[col] = {(int32_t)ci, i};
+            }
+    }
+    std::vector<int32_t> super(chains.size());
+    for (size_t ci = 0; ci < chains.size(); ++ci) super[ci] = (int32_t)ci;
+    for (const JoinItem& it : h.join_items) super[(size_t)it.chain] = h.join_chains[(size_t)it.jc].first_chain;
+    std::vector<int32_t> work_of(chains.size(), -1);
+    for (size_t w = 0; w < h.prec_work.size(); ++w)
+        if (h.prec_work[w].kind == 0) work_of[(size_t)h.prec_work[w].index] = (int32_t)w;
+    // per problem: nodes in order of appearance, under the caps
+    struct Node { int32_t col, chain, sup, u0; };
+    std::vector<std::vector<Node>> nodes((size_t)h.count);
+    std::vector<std::vector<std::pair<int, int>>> used((size_t)h.count);  // node-index pairs per problem
+    std::unordered_map<int32_t, int> rounds_of;                            // whole chain -> unknowns so far
+    for (size_t k = 0; k + 1 < pairs.size(); k += 2) {
+        const auto fa = where.find(pairs[k]), fb = where.find(pairs[k + 1]);
+        if (fa == where.end() || fb == where.end()) continue;  // (an endpoint that is a separator of a long chain: left out)
+        const int p = chains[(size_t)fa->second.first].prob;
+        if (p != chains[(size_t)fb->second.first].prob) continue;
+        auto& N = nodes[(size_t)p];
+        auto find = [&](int32_t col) { for (size_t i = 0; i < N.size(); ++i) if (N[i].col == col) return (int)i; return -1; };
+        int ia = find(pairs[k]), ib = find(pairs[k + 1]);
+        const int32_t sa = super[(size_t)fa->second.first], sb = super[(size_t)fb->second.first];
+        const int add_a = ia < 0 ? bs : 0, add_b = ib < 0 ? bs : 0;
+        if ((int)N.size() * bs + add_a + add_b > kLinkMaxU) continue;
+        if (rounds_of[sa] + add_a + (sa == sb ? add_b : 0) > kLinkMaxRounds || rounds_of[sb] + add_b + (sa == sb ? add_a : 0) > kLinkMaxRounds) continue;
+        if (ia < 0) { ia = (int)N.size(); N.push_back(Node{pairs[k], fa->second.first, sa, 0}); rounds_of[sa] += bs; }
+        if (ib < 0) { ib = (int)N.size(); N.push_back(Node{pairs[k + 1], fb->second.first, sb, 0}); rounds_of[sb] += bs; }
+        used[(size_t)p].push_back({ia, ib});
+        ++L.pairs_used;
+    }
+    std::unordered_map<int32_t, int> next_round;  // whole chain -> next free round
+    for (int p = 0; p < h.count; ++p) {
+        auto& N = nodes[(size_t)p];
+        if (N.empty()) continue;
+        LinkProb P{};
+        P.prob = p; P.u_begin = (int32_t)L.ucol.size(); P.n_u = (int32_t)N.size() * bs; P.q_off = (int32_t)L.mask.size();
+        for (Node& nd : N) {
+            nd.u0 = (int32_t)L.ucol.size();
+            for (int a = 0; a < bs; ++a) {
+                L.ucol.push_back(nd.col + a);
+                L.uround.push_back(next_round[nd.sup]++);
+                L.usuper.push_back(nd.sup);
+            }
+        }
+        L.mask.resize(L.mask.size() + (size_t)P.n_u * P.n_u, 0);
+        for (const auto& pr : used[(size_t)p])
+            for (int a = 0; a < bs; ++a)
+                for (int b = 0; b < bs; ++b) {
+                    const int ua = N[(size_t)pr.first].u0 - P.u_begin + a, ub = N[(size_t)pr.second].u0 - P.u_begin + b;
+                    L.mask[(size_t)P.q_off + (size_t)ua * P.n_u + ub] = 1;
+                    L.mask[(size_t)P.q_off + (size_t)ub * P.n_u + ua] = 1;
+                }
+        L.probs.push_back(P);
+        // the affected chains: every segment of every whole chain that carries an unknown
+        std::vector<int32_t> sups;
+        for (const Node& nd : N) if (std::find(sups.begin(), sups.end(), nd.sup) == sups.end()) sups.push_back(nd.sup);
+        for (int32_t s : sups) {
+            std::vector<std::pair<int32_t, int32_t>> segs;  // (chain, separator to the right or -1)
+            bool joined = false;
+            for (const JoinItem& it : h.join_items)
+                if (h.join_chains[(size_t)it.jc].first_chain == s) {
+                    const JoinChain& jc = h.join_chains[(size_t)it.jc];
+                    segs.push_back({it.chain, it.seg + 1 < jc.n_seg ? h.join_sep_col[(size_t)jc.sep_begin + it.seg] : -1});
+                    joined = true;
+                }
+            if (!joined) segs.push_back({s, -1});
+            for (const auto& sg : segs) {
+                LinkItem it{};
+                it.prob = p; it.chain = sg.first; it.work = work_of[(size_t)sg.first]; it.sep_col = sg.second;
+                for (int r = 0; r < kLinkMaxRounds; ++r) it.u[r] = -1;
+                for (size_t u = (size_t)P.u_begin; u < (size_t)P.u_begin + P.n_u; ++u)
+                    if (L.usuper[u] == s) it.u[L.uround[u]] = (int32_t)u;
+                L.items.push_back(it);
+            }
+        }
+    }
+    for (int32_t r : L.uround) L.rounds = std::max(L.rounds, r + 1);
+}
+
+#if defined(__HIPCC__)
+struct LinkArgs {
+    const LinkProb* probs;
+    const LinkItem* items;
+    const int32_t* ucol;
+    const int32_t* uround;
+    const int32_t* usuper;
+    const uint8_t* mask;
+    int32_t* pos;            // per problem n_u x n_u: position of H[u_a, u_b] in the Newton matrix's values (-1: no entry of G)
+    double* Qt;              // per problem n_u x n_u: Q transposed (thread a of k_link_solve reads Qt[b n_u + a])
+    double* t;               // per unknown: t = Q y[U]
+    double* Zr;              // rounds x n_tot: round r's applications of the chain kernel
+    double* rhs;             // n_tot, zero except at the unknowns of the round being solved
+    int64_t n_tot;
+    int rounds, n_u_total, round;
+    const int32_t* Hptr;
+    const int32_t* Hcol;
+    const double* Hval;
+    const ChainDesc* chains;
+    const int32_t* node_col;
+    const int32_t* done;
+    const double* r;
+    double* z;
+    double* p;
+    double* rz_out;
+    int32_t* status;         // per problem with links: 0 fine, 1 = singular capacitance matrix (Q := 0: the chain preconditioner alone)
+};
+
+__global__ __launch_bounds__(kLinkThreads) void k_link_positions(LinkArgs a, int n_probs) {
+    for (int q = 0; q < n_probs; ++q) {
+        const LinkProb P = a.probs[q];
+        for (int e = blockIdx.x * kLinkThreads + threadIdx.x; e < P.n_u * P.n_u; e += gridDim.x * kLinkThreads) {
+            const int ua = e / P.n_u, ub = e - ua * P.n_u;
+            a.pos[P.q_off + e] = a.mask[P.q_off + e] ? hb_find(a.Hptr, a.Hcol, a.ucol[P.u_begin + ua], a.ucol[P.u_begin + ub]) : -1;
+        }
+    }
+}
+
+// right-hand side of round a.round: 1 at the unknowns of that round, 0 at the others (the rest of rhs stays zero)
+__global__ __launch_bounds__(kLinkThreads) void k_link_rhs(LinkArgs a) {
+    const int i = blockIdx.x * kLinkThreads + threadIdx.x;
+    if (i < a.n_u_total) a.rhs[a.ucol[i]] = a.uround[i] == a.round ? 1.0 : 0.0;
+}
+
+// Q = (I + G Z[U,:])^-1 G, one workgroup per problem; dynamic LDS: G and S, n_u x n_u doubles each
+__global__ __launch_bounds__(kLinkThreads) void k_link_cap(LinkArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double link_lds[];
+    __shared__ int piv_row;
+    __shared__ double piv_val;
+    __shared__ double fcol[kLinkMaxU];
+    const LinkProb P = a.probs[blockIdx.x];
+    const int n = P.n_u, t = threadIdx.x;
+    double* G = link_lds;
+    double* S = link_lds + n * n;
+    for (int e = t; e < n * n; e += kLinkThreads) {
+        const int pos = a.pos[P.q_off + e];
+        G[e] = pos >= 0 ? a.Hval[pos] : 0.0;
+    }
+    __syncthreads();
+    for (int e = t; e < n * n; e += kLinkThreads) {
+        const int ra = e / n, cb = e - ra * n;
+        // S[ra][cb] = delta + sum_c G[ra][c] Z_cb[u_c],  Z_cb = column of unknown cb: round(cb)'s vector on cb's chain only
+        const int sup_b = a.usuper[P.u_begin + cb];
+        const double* __restrict__ Zb = a.Zr + (size_t)a.uround[P.u_begin + cb] * a.n_tot;
+        double acc = ra == cb ? 1.0 : 0.0;
+        for (int c = 0; c < n; ++c) {
+            const double g = G[ra * n + c];
+            if (g != 0.0 && a.usuper[P.u_begin + c] == sup_b) acc += g * Zb[a.ucol[P.u_begin + c]];
+        }
+        S[e] = acc;
+    }
+    __syncthreads();
+    bool singular = false;
+    for (int k = 0; k < n; ++k) {
+        if (t == 0) {
+            int best = k;
+            double bv = fabs(S[k * n + k]);
+            for (int i = k + 1; i < n; ++i) { const double v = fabs(S[i * n + k]); if (v > bv) { bv = v; best = i; } }
+            piv_row = best; piv_val = bv;
+        }
+        __syncthreads();
+        if (!(piv_val > 1e-300)) { singular = true; break; }  // (uniform)
+        const int pr = piv_row;
+        if (pr != k) {
+            for (int c = t; c < 2 * n; c += kLinkThreads) {
+                double* M = c < n ? S : G;
+                const int cc = c < n ? c : c - n;
+                const double x = M[k * n + cc]; M[k * n + cc] = M[pr * n + cc]; M[pr * n + cc] = x;
+            }
+            __syncthreads();
+        }
+        const double inv = 1.0 / S[k * n + k];
+        __syncthreads();
+        for (int c = t; c < 2 * n; c += kLinkThreads) {
+            double* M = c < n ? S : G;
+            const int cc = c < n ? c : c - n;
+            M[k * n + cc] *= inv;
+        }
+        __syncthreads();
+        // every other row: row_i -= S[i][k] * row_k, all rows at once (column k's factors are set aside first: the update
+        // overwrites them; row k itself stays)
+        for (int i = t; i < n; i += kLinkThreads) fcol[i] = (i == k) ? 0.0 : S[i * n + k];
+        __syncthreads();
+        for (int e = t; e < 2 * n * n; e += kLinkThreads) {
+            const int i = e / (2 * n), c = e - i * 2 * n;
+            double* M = c < n ? S : G;
+            const int cc = c < n ? c : c - n;
+            const double f = fcol[i];
+            if (f != 0.0) M[i * n + cc] -= f * M[k * n + cc];
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int e = t; e < n * n; e += kLinkThreads) {
+        const int ra = e / n, cb = e - ra * n;
+        a.Qt[P.q_off + cb * n + ra] = singular ? 0.0 : G[e];
+    }
+    if (t == 0) a.status[blockIdx.x] = singular ? 1 : 0;
+}
+
+// t = Q y[U] (y = what the chain kernel left in z), one workgroup per problem with links
+__global__ __launch_bounds__(128) void k_link_solve(LinkArgs a) {
+    __shared__ double v[kLinkMaxU];
+    const LinkProb P = a.probs[blockIdx.x];
+    if (a.done[P.prob]) return;  // frozen problem / a PCG whose gate has fired: the chain kernel wrote nothing either
+    const int t = threadIdx.x;
+    if (t < P.n_u) v[t] = a.z[a.ucol[P.u_begin + t]];
+    __syncthreads();
+    if (t < P.n_u) {
+        const double* __restrict__ Q = a.Qt + P.q_off;
+        double acc = 0.0;
+        for (int b = 0; b < P.n_u; ++b) acc += Q[b * P.n_u + t] * v[b];
+        a.t[P.u_begin + t] = acc;
+    }
+}
+
+// z -= Z t on one affected chain (and the separator to its right); its r'z partial sum restated with the corrected z
+template <int BS, int MODE>
+__global__ __launch_bounds__(kLinkThreads) void k_link_apply(LinkArgs a) {
+    __shared__ double red[16];
+    __shared__ double ts[kLinkMaxRounds];
+    const LinkItem it = a.items[blockIdx.x];
+    if (a.done[it.prob]) return;
+    const int t = threadIdx.x;
+    if (t < kLinkMaxRounds) ts[t] = (t < a.rounds && it.u[t] >= 0) ? a.t[it.u[t]] : 0.0;
+    __syncthreads();
+    const ChainDesc ch = a.chains[it.chain];
+    const int NB = ch.N * BS, NE = NB + (it.sep_col >= 0 ? BS : 0);
+    double local = 0.0;
+    for (int e = t; e < NE; e += kLinkThreads) {
+        int col;
+        if (e < NB) {
+            const int node = e / BS;
+            col = join_col<BS>(ch, a.node_col, node) + (e - node * BS);
+        } else col = it.sep_col + (e - NB);
+        double zz = a.z[col];
+        for (int r = 0; r < a.rounds; ++r)
+            if (it.u[r] >= 0) zz -= a.Zr[(size_t)r * a.n_tot + col] * ts[r];  // (uniform over the workgroup)
+        a.z[col] = zz;
+        if (MODE == PREC_INIT) a.p[col] = zz;
+        local += a.r[col] * zz;
+    }
+    const double tot = block_sum_n<kLinkThreads / 64>(local, red);
+    if (t == 0) a.rz_out[it.work] = tot;
+}
+#endif  // __HIPCC__
+
+}  // namespace score

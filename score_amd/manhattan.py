@@ -176,6 +176,7 @@ def make_manhattan_3d(
     sigma_theta: float = 0.002,
     sigma_range: float = 1.0,
     p_turn: float = 0.25,
+    n_loop_closures: int = 0,
 ) -> compat.FactorGraphData:
     """The 3-D counterpart of `make_manhattan` (the reference's model is dimension-generic,
     gurobi_utils.py:37-50, :53-60; it ships no 3-D data): every robot walks the integer lattice of a cube of
@@ -241,6 +242,15 @@ def make_manhattan_3d(
             meas = np.maximum(0.0, true + sigma_range * rng.standard_normal(true.size))
             for t, dd in zip(ti, meas):
                 fg.range_measurements.append(compat.FGRangeMeasurement((f"{letters[a]}{t}", f"{letters[b]}{t}"), float(dd), float(sigma_range)))
+    # optional loop closures within a robot's trajectory (drawn last: graphs without them are unchanged)
+    for _ in range(n_loop_closures):
+        r = int(rng.integers(0, n_robots))
+        i, j = sorted(int(x) for x in rng.choice(n_poses, size=2, replace=False))
+        Ri, Rj = fg.pose_variables[r][i].rotation_matrix, fg.pose_variables[r][j].rotation_matrix
+        Pi, Pj = all_pos[r][i], all_pos[r][j]
+        fg.loop_closure_measurements.append(compat.PoseMeasurement3D(
+            f"{letters[r]}{i}", f"{letters[r]}{j}", Ri.T @ (Pj - Pi) + sigma_t * rng.standard_normal(3),
+            Ri.T @ Rj @ _rotvec(sigma_theta * rng.standard_normal(3)), 1.0 / sigma_t ** 2, 1.0 / sigma_theta ** 2))
     return fg
 
 

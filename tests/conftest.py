@@ -71,14 +71,28 @@ def hip_lib():
     return g.build_hip()
 
 
-@pytest.fixture(scope="session")
-def fixtures():
+def load_fixtures():
     from score_amd.io import load_fg_npz
 
     return {
         "manhattan": load_fg_npz(os.path.join(GOLDEN, "manhattan_fg.npz")),
         "goats": load_fg_npz(os.path.join(GOLDEN, "goats_fg.npz")),
     }
+
+
+@pytest.fixture(scope="session")
+def fixtures():
+    return load_fixtures()
+
+
+# Every environment switch the library still reads (INTEGRATION.md lists them; round 6 pruned 48 to these): the GPU suite solves
+# the goldens under each (test_gpu_parity.py), the CPU suite checks that the sources read exactly this list (test_abi.py).
+SURVIVING_SWITCHES = [
+    ("SCORE_NO_REPLICATION", "1"), ("SCORE_NO_SEGMENTS", "1"), ("SCORE_HOST_SETUP", "1"), ("SCORE_HOST_ASSEMBLE", "1"),
+    ("SCORE_HOST_POLISH_BUILD", "1"), ("SCORE_NO_PREQUEUE", "1"), ("SCORE_QCQP_PLAIN", "1"), ("SCORE_NO_BAND", "1"),
+    ("SCORE_NO_DEVICE_RUIZ", "1"), ("SCORE_NO_LONG_SPIN", "1"), ("SCORE_NO_LINKS", "1"), ("SCORE_HOST_THREADS", "2"),
+    ("SCORE_CACHE_MB", "0"), ("SCORE_TRACE", "all"),
+]
 
 
 def load_golden(name):

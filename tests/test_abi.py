@@ -77,3 +77,22 @@ def test_score_import_shim_matches_reference_paths():
 
     sig = inspect.signature(solve_score)
     assert list(sig.parameters)[0] == "data" and sig.parameters["relaxation_type"].default == "QCQP"
+
+
+def test_the_switch_list_is_the_one_the_sources_read():
+    """No switch enters the library without entering SURVIVING_SWITCHES (and INTEGRATION.md): the getenv calls of the product's
+    sources are exactly that list (+ LOCAL_WORLD_SIZE, which the launchers export)."""
+    import glob
+    import re
+
+    from conftest import ROOT, SURVIVING_SWITCHES
+
+    found = set()
+    for path in glob.glob(os.path.join(ROOT, "score_amd", "csrc", "*")):
+        if path.endswith((".hpp", ".hip", ".c")):
+            found |= set(re.findall(r'getenv\("(SCORE_[A-Z0-9_]+)"\)', open(path).read()))
+    assert found == {s for s, _ in SURVIVING_SWITCHES}, found ^ {s for s, _ in SURVIVING_SWITCHES}
+    assert len(found) <= 15
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for s in found:
+        assert s in doc, s
