@@ -257,6 +257,13 @@ void score_destroy(score_handle* h);
  * next score_create.  score_trim_caches releases everything parked (live handles are not touched) and returns the
  * bytes freed; the cache also releases itself and retries once when an allocation fails.                        */
 int64_t score_trim_caches(void);
+/* What the library's threads spent waiting for the device since the process started (process-wide, all handles):
+ * out[0] = milliseconds SPINNING on host-mapped result words (a thread alone in its solve: lowest latency; burns a CPU),
+ * out[1] = milliseconds ASLEEP between looks (several solves at once, or several ranks on the node: "economy" waits,
+ * csrc/score_hip.hip), out[2] = waits, out[3] = sleeps.  Returns the number of counters (4); fills min(len, 4).
+ * The reference blocks inside model.optimize() (score/solve_score.py:76) and reports nothing of the kind; bench.py uses the
+ * counters to split the host CPU per problem into work and wait.                                                  */
+int32_t score_host_counters(double* out, int32_t len);
 
 /* ---------------------------------------------------------------------------
  * Native model construction: the factor graph as flat arrays -> the conic program above.

@@ -773,6 +773,10 @@ int score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rota
     return 0;
 }
 int64_t score_trim_caches(void) { return 0; }  // the twin parks nothing
+int32_t score_host_counters(double* out, int32_t len) {  // (the twin waits for no device)
+    if (out) for (int i = 0; i < len && i < 4; ++i) out[i] = 0.0;
+    return 4;
+}
 const char* score_last_error(void) { return g_err.c_str(); }
 int32_t score_abi_version(void) { return SCORE_ABI_VERSION * 1000 + (int32_t)sizeof(score_problem); }
 const char* score_backend(void) { return "cpu-twin"; }

@@ -17,6 +17,7 @@
 // Kernels and their design notes: score_kernels.hpp.
 #include <hip/hip_runtime.h>
 #include <sched.h>
+#include <sys/prctl.h>
 #include <time.h>
 #include <hip/hip_ext.h>
 
@@ -501,6 +502,41 @@ struct ZeroGroup {
         items.clear();
         total = 0;
     }
+};
+
+// ---- how a host thread waits for the device (round 6) ----
+// A driver thread alternates queueing launches and waiting for small results in host-mapped memory.  Alone in the process it
+// spins (a result is picked up within a fraction of a microsecond: the latency of ONE default solve).  As soon as several
+// threads are inside solves at once (the lock-step groups of a Monte-Carlo sweep: 4 per rank) or several ranks share the node,
+// the waits go ECONOMY: a short spin, then sleeps of kEconomySleepNs with the thread's timer slack lowered to 1 us -- a waiting
+// thread costs no CPU, the Newton PCG is queued deeper ahead of the device (kEconomyDepth instead of 3) so that the device does
+// not run dry while its driver sleeps.  Rounds 4-5 spun, then yielded: with idle CPUs around a yield returns at once, and every
+// driver thread burnt a full CPU for the length of its solves -- 2.6-2.8 ms of host CPU per problem (BENCH_r05), which caps eight
+// ranks on the 16 CPUs the boxes grant at a third of the GPUs' capacity.
+struct HostWaitStats {
+    std::atomic<long long> spin_ns{0}, sleep_ns{0}, waits{0}, sleeps{0};
+    std::atomic<int> active_solves{0};
+};
+inline HostWaitStats& wait_stats() { static HostWaitStats s; return s; }
+constexpr long kEconomySleepNs = 25000;
+constexpr int kEconomyDepth = 6;
+inline bool several_ranks_here() {
+    static const bool v = [] { const char* e = std::getenv("LOCAL_WORLD_SIZE"); return e && std::atoi(e) > 1; }();
+    return v;
+}
+inline bool economy_waits() { return wait_stats().active_solves.load(std::memory_order_relaxed) >= 2 || several_ranks_here(); }
+inline void economy_sleep() {
+    static thread_local bool slack_set = false;
+    if (!slack_set) { prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }  // (default 50 us: a 25 us sleep would take 75)
+    struct timespec ts = {0, kEconomySleepNs};
+    const auto t0 = std::chrono::steady_clock::now();
+    nanosleep(&ts, nullptr);
+    wait_stats().sleep_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+    wait_stats().sleeps.fetch_add(1, std::memory_order_relaxed);
+}
+struct ActiveSolve {  // (every entry point that runs a solve: score_solve, score_solve_steps, score_newton_steps, score_linear_solve)
+    ActiveSolve() { wait_stats().active_solves.fetch_add(1, std::memory_order_relaxed); }
+    ~ActiveSolve() { wait_stats().active_solves.fetch_sub(1, std::memory_order_relaxed); }
 };
 
 // SCORE_NO_LONG_SPIN=1: the split long rows of every matrix go through the ticket path (CsrDev::long_spin)
@@ -2125,7 +2161,7 @@ struct HipBackend {
         la.r = (MODE == PREC_INIT) ? pa.r_in : pa.r;
         la.z = pa.z; la.p = pa.p; la.rz_out = pa.rz_out;
         hipLaunchKernelGGL(k_link_solve, dim3((unsigned)n_link_probs), dim3(128), 0, stream, la);
-        hipLaunchKernelGGL((k_link_apply<BS, MODE>), dim3((unsigned)n_link_items), dim3(kLinkThreads), 0, stream, la);
+        hipLaunchKernelGGL((k_link_apply<BS, MODE>), dim3((unsigned)n_link_items), dim3(kLinkApplyThreads), 0, stream, la);
     }
     template <int MODE>
     void link_apply(const PrecArgs& pa) {
@@ -2284,10 +2320,11 @@ struct HipBackend {
             HipBackend* b; double t0;
             ~WaitTimer() { b->wait_ms += now_ms() - t0; b->waits += 1; }
         } wait_timer{this, now_ms()};
-        constexpr double spin_us = 30.0;
         const auto t0 = std::chrono::steady_clock::now();
+        auto t_spin0 = t0;
         unsigned spins = 0;
-        int phase = 0;  // 0 spin, 1 yield, 2 sleep
+        int phase = 0;  // 0 spin, 1 yield (alone) / economy sleeps, 2 sleep
+        long long slept_ns = 0;
         while (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) < seq) {
             if (phase == 0) {
 #if defined(__x86_64__) || defined(__i386__)
@@ -2295,21 +2332,35 @@ struct HipBackend {
 #endif
                 if ((++spins & 63) != 0) continue;
             } else if (phase == 1) {
-                sched_yield();
-                if ((++spins & 15) != 0) continue;
+                if (economy_waits()) {
+                    const auto s0 = std::chrono::steady_clock::now();
+                    economy_sleep();
+                    slept_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - s0).count();
+                } else {
+                    sched_yield();
+                    if ((++spins & 15) != 0) continue;
+                }
             } else {
+                const auto s0 = std::chrono::steady_clock::now();
                 struct timespec ts = {0, 50000};  // 50 us
                 nanosleep(&ts, nullptr);
+                slept_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - s0).count();
             }
             const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            const double spin_us = economy_waits() ? 10.0 : 30.0;
             if (phase == 0 && us > spin_us) phase = 1;
-            else if (phase == 1 && us > 2000.0) phase = 2;
+            else if (phase == 1 && us > 2000.0 && !economy_waits()) phase = 2;
             else if (us > 2e6) {
                 release_prequeued();  // (a fetch waiting for the host's words would keep the stream from draining)
                 HIP_CHECK(hipStreamSynchronize(stream));
                 if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) < seq) throw std::runtime_error("device did not publish its results");
                 break;
             }
+        }
+        {
+            const long long total_ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_spin0).count();
+            wait_stats().spin_ns.fetch_add(std::max(0LL, total_ns - slept_ns), std::memory_order_relaxed);  // (sleeps account for themselves)
+            wait_stats().waits.fetch_add(1, std::memory_order_relaxed);
         }
         ring_used = pre_slot ? 1 : 0;  // everything queued before the publish has run: those ring slots are free again
     }
@@ -3775,10 +3826,21 @@ struct HipBackend {
     // missing (no resume).  Returns the iterations queued.
     int newton_pcg_follow(const std::vector<char>& live, int cap) {
         const HostSystem& h = *H;
-        constexpr int depth = 3;  // (iterations kept in the queue beyond what the device has executed; 2-5 measured alike, TRIED.md)
+        // (iterations kept in the queue beyond what the device has executed: 3 when this thread spins -- 2-5 measured alike,
+        //  TRIED.md --, kEconomyDepth when it sleeps between looks: 25 us are most of a PCG iteration)
+        const bool economy = economy_waits();
+        const int depth = economy ? kEconomyDepth : 3;
         newton_pcg_begin();
         int queued = 0;
         const auto t0 = std::chrono::steady_clock::now();
+        long long slept_ns = 0;
+        struct SpinAccount {
+            std::chrono::steady_clock::time_point t0; long long& slept;
+            ~SpinAccount() {
+                const long long ns = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                wait_stats().spin_ns.fetch_add(std::max(0LL, ns - slept), std::memory_order_relaxed);
+            }
+        } spin_account{t0, slept_ns};
         unsigned spins = 0;
         for (;;) {
             bool all = true;
@@ -3798,9 +3860,16 @@ struct HipBackend {
                 spins = 0;
                 continue;
             }
+            if (economy) {  // the queue is full: nothing to do for most of a PCG iteration
+                const auto s0 = std::chrono::steady_clock::now();
+                economy_sleep();
+                slept_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - s0).count();
+                spins += 1023;
+            } else {
 #if defined(__x86_64__) || defined(__i386__)
-            __builtin_ia32_pause();
+                __builtin_ia32_pause();
 #endif
+            }
             if ((++spins & 1023) == 0) {
                 HIP_CHECK(hipGetLastError());
                 if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 2.0) {  // (a device that stopped answering: let the caller's wait report it)
@@ -4348,6 +4417,7 @@ int score_solve(score_handle* h, double* x, double* y, double* s, score_info* in
     try {
         if (!h) throw std::runtime_error("null handle");
         DeviceGuard guard(h->solver.st.device);
+        ActiveSolve active;
         return h->solver.solve(x, y, s, infos);
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
@@ -4363,6 +4433,7 @@ int score_solve_steps(score_handle* h, int32_t iters, double* x, double* y, doub
     try {
         if (!h) throw std::runtime_error("null handle");
         DeviceGuard guard(h->solver.st.device);
+        ActiveSolve active;
         return h->solver.steps(iters, x, y, s, infos);
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
@@ -4370,6 +4441,7 @@ int score_newton_steps(score_handle* h, int32_t iters, double* x, double* y, dou
     try {
         if (!h) throw std::runtime_error("null handle");
         DeviceGuard guard(h->solver.st.device);
+        ActiveSolve active;
         return h->solver.newton_steps(iters, x, y, s, infos);
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
 }
@@ -4732,6 +4804,12 @@ int64_t score_trim_caches(void) {
     stream_pool().trim();
     malloc_trim(0);  // the host heap kept by tune_host_allocator_once goes back to the system as well
     return (int64_t)freed;
+}
+int32_t score_host_counters(double* out, int32_t len) {
+    const HostWaitStats& w = wait_stats();
+    const double v[4] = {1e-6 * (double)w.spin_ns.load(), 1e-6 * (double)w.sleep_ns.load(), (double)w.waits.load(), (double)w.sleeps.load()};
+    if (out) for (int i = 0; i < len && i < 4; ++i) out[i] = v[i];
+    return 4;
 }
 const char* score_last_error(void) { return g_err.c_str(); }
 int32_t score_abi_version(void) { return SCORE_ABI_VERSION * 1000 + (int32_t)sizeof(score_problem); }

@@ -106,10 +106,20 @@ struct LinkPlan {
     int pairs_total = 0, pairs_used = 0;
     bool empty() const { return items.empty(); }
 };
-inline void make_link_plan(const HostSystem& h, const std::vector<int32_t>& pairs, LinkPlan& L) {
+inline void make_link_plan(const HostSystem& h, const std::vector<int32_t>& pairs_in, LinkPlan& L) {
     L = LinkPlan();
+    if (pairs_in.empty()) return;
+    // one order whatever found the pairs (the measurement list or P's pattern): sorted by columns, duplicates dropped -- the
+    // unknowns' order decides the order of every sum below, and both paths must give the same bits
+    std::vector<int32_t> pairs;
+    {
+        std::vector<std::pair<int32_t, int32_t>> pp;
+        for (size_t k = 0; k + 1 < pairs_in.size(); k += 2) pp.push_back({std::min(pairs_in[k], pairs_in[k + 1]), std::max(pairs_in[k], pairs_in[k + 1])});
+        std::sort(pp.begin(), pp.end());
+        pp.erase(std::unique(pp.begin(), pp.end()), pp.end());
+        for (const auto& q : pp) { pairs.push_back(q.first); pairs.push_back(q.second); }
+    }
     L.pairs_total = (int)(pairs.size() / 2);
-    if (pairs.empty()) return;
     const int bs = h.bs;
     const std::vector<ChainDesc>& chains = h.chainsH;
     // column -> (chain, node); whole-chain id of every chain (a long chain's segments share their join chain's)
@@ -337,33 +347,53 @@ __global__ __launch_bounds__(128) void k_link_solve(LinkArgs a) {
     }
 }
 
-// z -= Z t on one affected chain (and the separator to its right); its r'z partial sum restated with the corrected z
+// z -= Z t on one affected chain (and the separator to its right); its r'z partial sum restated with the corrected z.
+// The rounds a chain carries are compacted first; an entry then requests kLinkBatch columns of Z at a time before it uses any
+// (a chain is ONE workgroup's work: a loop of dependent loads over 24 rounds took 100 us -- measured on the first build).
+constexpr int kLinkApplyThreads = 512;
+constexpr int kLinkBatch = 8;
 template <int BS, int MODE>
-__global__ __launch_bounds__(kLinkThreads) void k_link_apply(LinkArgs a) {
+__global__ __launch_bounds__(kLinkApplyThreads) void k_link_apply(LinkArgs a) {
     __shared__ double red[16];
-    __shared__ double ts[kLinkMaxRounds];
+    __shared__ double ts[kLinkMaxRounds + kLinkBatch];
+    __shared__ int rr[kLinkMaxRounds + kLinkBatch];
+    __shared__ int n_act;
     const LinkItem it = a.items[blockIdx.x];
     if (a.done[it.prob]) return;
     const int t = threadIdx.x;
-    if (t < kLinkMaxRounds) ts[t] = (t < a.rounds && it.u[t] >= 0) ? a.t[it.u[t]] : 0.0;
+    if (t == 0) {
+        int k = 0;
+        for (int r = 0; r < a.rounds; ++r)
+            if (it.u[r] >= 0) { rr[k] = r; ts[k] = a.t[it.u[r]]; ++k; }
+        n_act = k;
+        for (int q = 0; q < kLinkBatch; ++q) { rr[k + q] = k ? rr[k - 1] : 0; ts[k + q] = 0.0; }  // (padding: a valid column of Z, weight 0)
+    }
     __syncthreads();
+    const int na = n_act;
     const ChainDesc ch = a.chains[it.chain];
     const int NB = ch.N * BS, NE = NB + (it.sep_col >= 0 ? BS : 0);
+    const double* __restrict__ Zr = a.Zr;
     double local = 0.0;
-    for (int e = t; e < NE; e += kLinkThreads) {
+    for (int e = t; e < NE; e += kLinkApplyThreads) {
         int col;
         if (e < NB) {
             const int node = e / BS;
             col = join_col<BS>(ch, a.node_col, node) + (e - node * BS);
         } else col = it.sep_col + (e - NB);
         double zz = a.z[col];
-        for (int r = 0; r < a.rounds; ++r)
-            if (it.u[r] >= 0) zz -= a.Zr[(size_t)r * a.n_tot + col] * ts[r];  // (uniform over the workgroup)
+        const double rv = a.r[col];
+        for (int k0 = 0; k0 < na; k0 += kLinkBatch) {
+            double zv[kLinkBatch];
+#pragma unroll
+            for (int q = 0; q < kLinkBatch; ++q) zv[q] = Zr[(size_t)rr[k0 + q] * a.n_tot + col];
+#pragma unroll
+            for (int q = 0; q < kLinkBatch; ++q) zz -= zv[q] * ts[k0 + q];
+        }
         a.z[col] = zz;
         if (MODE == PREC_INIT) a.p[col] = zz;
-        local += a.r[col] * zz;
+        local += rv * zz;
     }
-    const double tot = block_sum_n<kLinkThreads / 64>(local, red);
+    const double tot = block_sum_n<kLinkApplyThreads / 64>(local, red);
     if (t == 0) a.rz_out[it.work] = tot;
 }
 #endif  // __HIPCC__

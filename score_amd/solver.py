@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "score_assemble", "score_assemble_batch", "score_assembled_view", "score_assembled_free", "score_round_to_so",
     "score_default_settings", "score_create", "score_create_batch", "score_create_from_graphs", "score_read_estimates", "score_graphs_connected", "score_dims", "score_solve",
     "score_reset", "score_solve_steps", "score_newton_steps", "score_linear_create", "score_linear_solve", "score_refine_create", "score_refine_run", "score_refine_destroy", "score_time_kkt_apply", "score_time_iteration", "score_debug_time", "score_debug_get", "score_destroy",
-    "score_trim_caches", "score_last_error", "score_backend", "score_abi_version",
+    "score_trim_caches", "score_host_counters", "score_last_error", "score_backend", "score_abi_version",
     "score_generate_manhattan", "score_generated_graph", "score_generated_truth", "score_generated_free", "score_create_from_generated",
 ]
 
@@ -123,6 +123,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.score_round_to_so.restype = C.c_int
     lib.score_trim_caches.argtypes = []
     lib.score_trim_caches.restype = C.c_int64
+    lib.score_host_counters.argtypes = [C.POINTER(C.c_double), C.c_int32]
+    lib.score_host_counters.restype = C.c_int32
     lib.score_last_error.restype = C.c_char_p
     lib.score_backend.restype = C.c_char_p
     lib.score_abi_version.restype = C.c_int32
@@ -155,6 +157,14 @@ class ConicSolution:
     @property
     def solved(self) -> bool:
         return self.info["status"] == 1
+
+
+def host_counters(lib_path: Optional[str] = None) -> dict:
+    """What the library's threads spent waiting for the device since the process started (``score_host_counters``):
+    milliseconds spinning (CPU busy), milliseconds asleep (economy waits), number of waits and of sleeps."""
+    v = (C.c_double * 4)()
+    load_library(lib_path).score_host_counters(v, 4)
+    return dict(spin_ms=float(v[0]), sleep_ms=float(v[1]), waits=int(v[2]), sleeps=int(v[3]))
 
 
 def trim_caches(lib_path: Optional[str] = None) -> int:
