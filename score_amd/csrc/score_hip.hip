@@ -1830,7 +1830,7 @@ struct HipBackend {
         }
         {   // does any launch fall back to the streaming kernel (k_prec)?  4 x 4 blocks: every factor set kept in double
             const bool fallback = !prec_pre || (h.bs >= 4 && st.fac_fp32 == 0);
-            if (fallback && prec_lds > 144 * 1024) throw std::runtime_error("chain too long for the LDS-resident chain solver");
+            if (fallback && prec_lds > 144 * 1024) throw std::runtime_error("chain too long: more than 129 segments of 1023 nodes (132 k) for the segmented chain solver, and beyond what the streaming kernel keeps in LDS");
         }
         if (n_prec_chains(h)) {
             if (h.bs <= 1) allow_big_lds<1>(); else if (h.bs == 2) allow_big_lds<2>();
@@ -2111,8 +2111,9 @@ struct HipBackend {
         for (const LinkProb& P : L.probs) link_max_u = std::max(link_max_u, (int)P.n_u);
         link_probs.upload(L.probs); link_items.upload(L.items);
         link_ucol.upload(L.ucol); link_uround.upload(L.uround); link_usuper.upload(L.usuper); link_mask.upload(L.mask);
-        link_pos.alloc(L.mask.size()); link_status.alloc(n_link_probs);
+        link_pos.alloc(L.mask.size());
         ZeroGroup zl;
+        zl.add(link_status, (size_t)n_link_probs);
         zl.add(link_Qt, L.mask.size()); zl.add(link_t, (size_t)n_link_u); zl.add(link_Zr, (size_t)link_rounds * (size_t)h.n_tot);
         zl.add(link_rhs, (size_t)h.n_tot); zl.add(link_zero, (size_t)h.count);
         zl.commit(stream);
@@ -3030,6 +3031,12 @@ struct HipBackend {
             }
             if (out && len > 0) std::memcpy(out, v, sizeof(double) * (size_t)std::min<int64_t>(len, 6));
             return 6;
+        }
+        else if (nm == "link_pairs") {  // first columns of the node pairs inside the Newton preconditioner (two per pair)
+            const std::vector<int32_t>& pc = link_plan.pair_cols;
+            const int64_t np_ = n_link_items ? (int64_t)pc.size() : 0;
+            if (out) for (int64_t i = 0; i < np_ && i < len; ++i) out[i] = (double)pc[(size_t)i];
+            return np_;
         }
         else if (nm == "fac") { src = fac.d; sz = (int64_t)h.fac_doubles; }
         else if (nm == "newton_probe_arm") {  // the next polish times its PCG launches (see probe_slot)

@@ -845,7 +845,7 @@ inline void chain_solve_host(const ChainDesc& ch, const ChainLevelDesc* levels, 
 // separators' Schur system (block tridiagonal, n_seg - 1 nodes) and corrects the segments with their spikes: together the
 // exact solve with the whole chain's block-tridiagonal matrix, as the streaming kernel computes it.
 constexpr int kSegMaxNodes = 1023;
-constexpr int kJoinMaxSepsHost = 64;  // == score_join.hpp kJoinMaxSeps (static_assert there): separators of one long chain
+constexpr int kJoinMaxSepsHost = 128;  // == score_join.hpp kJoinMaxSeps (static_assert there): separators of one long chain
 constexpr int seg_max_nodes() { return kSegMaxNodes; }  // (shorter segments: slower everywhere, profiles/r05_seg_nodes_ab.txt)
 struct JoinChain {
     int32_t prob, n_seg;
@@ -1766,9 +1766,10 @@ inline void build_system(const score_problem* probs, int count, const score_sett
     const int max_nodes = 1 << 20;
     // (the twin factors on the host and keeps whole chains: its streaming solve is the specification)
     bool segments_ok = !factor_on_host && H.radix == 4 && bs >= 1 && bs <= 4 && std::getenv("SCORE_NO_SEGMENTS") == nullptr;
-    // The second level keeps one long chain's separators in LDS (score_join.hpp: kJoinMaxSeps).  A handle with a chain that
-    // would need more keeps ALL its chains whole -- the streaming kernel k_prec, as before round 5 (chains of up to 2^20 nodes) --
-    // instead of failing at score_create.
+    // The second level keeps one long chain's separators in LDS (score_join.hpp: kJoinMaxSeps = 128: chains of up to 129
+    // segments, 132 k nodes; round 5 stopped at 65 segments).  A handle with a longer chain keeps ALL its chains whole for the
+    // streaming kernel k_prec -- which holds the coarse levels' vectors in LDS and therefore ends at ~18 k nodes of 3 x 3 blocks:
+    // score_create then fails with "chain too long for the LDS-resident chain solver", as it did for such chains in every round.
     if (segments_ok) {
         const int seg_max = seg_max_nodes();
         for (int p = 0; p < count && segments_ok; ++p)

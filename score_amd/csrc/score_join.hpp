@@ -24,7 +24,7 @@
 namespace score {
 
 constexpr int kJoinThreads = 256;
-constexpr int kJoinMaxSeps = 64;  // separators of one long chain the join kernel keeps in LDS (chains of up to 65 segments)
+constexpr int kJoinMaxSeps = 128;  // separators of one long chain the join kernel keeps in LDS (chains of up to 129 segments: 132 k nodes)
 static_assert(kJoinMaxSeps == kJoinMaxSepsHost, "build_system keeps longer chains whole (score_host.hpp)");
 
 struct JoinArgs {

@@ -624,11 +624,11 @@ def test_segmented_long_chains_equal_the_streaming_solve(case, hip_lib, twin_lib
         assert max(np.abs(ra.poses[k] - rb.poses[k]).max() for k in ra.poses) < 1e-9
 
 
-def test_a_chain_beyond_the_second_level_keeps_the_streaming_kernel(hip_lib):
-    """Round-5 regression (advisor): a chain of more than 65 segments of 1023 nodes (> 66.6 k poses) failed at score_create
-    ("chain too long: more than 65 segments") where round 4 solved it with the streaming kernel k_prec (host limit 2^20
-    nodes).  build_system now keeps every chain of such a handle whole.  One robot x 67 000 poses: created, solved, KKT
-    certificate of the program as given."""
+def test_a_chain_of_more_than_65_segments(hip_lib):
+    """Advisor finding (round 5): a chain of more than 65 segments of 1023 nodes (> 66.6 k poses) failed at score_create
+    ("chain too long: more than 65 segments").  The second level now holds 128 separators per chain (132 k poses; the
+    streaming kernel, which a longer chain falls back to, keeps its coarse levels in LDS and ends at ~18 k: it never reached
+    this size).  One robot x 67 000 poses (66 segments): created, solved, KKT certificate of the program as given."""
     fg = make_manhattan(n_robots=1, n_poses=67000, n_beacons=2, seed=5, p_range=0.02)
     qp = assemble(fg, "SOCP").qp
     sol = ConicSolver([qp], {})
@@ -944,6 +944,13 @@ def test_newton_kernels_against_the_oracle(name, fixtures, hip_lib):
     np.minimum.at(first, chain[chain >= 0], np.nonzero(chain >= 0)[0])
     node = np.where(chain >= 0, (np.arange(n) - first[np.maximum(chain, 0)]) // bs, -1)
     keep = (chain[coo.row] >= 0) & (chain[coo.row] == chain[coo.col]) & (np.abs(node[coo.row] - node[coo.col]) <= 1)
+    # ... plus the loop-closure blocks (round 6, csrc/score_link.hpp: the Woodbury correction makes the preconditioner the exact
+    # inverse of chains + the blocks between linked nodes; graph3d has one loop closure)
+    pairs = sol.debug_get("link_pairs").astype(np.int64).reshape(-1, 2)
+    assert len(pairs) == (3 if name == "graph3d" else 0)
+    for ca, cb in pairs:
+        ra, rb = (coo.row >= ca) & (coo.row < ca + bs), (coo.row >= cb) & (coo.row < cb + bs)
+        keep |= (ra & (coo.col >= cb) & (coo.col < cb + bs)) | (rb & (coo.col >= ca) & (coo.col < ca + bs))
     T = sp.csr_matrix((coo.data[keep], (coo.row[keep], coo.col[keep])), shape=(n, n))
     inchain = chain >= 0
     resid = (T @ z + g)[inchain]
@@ -1096,7 +1103,8 @@ def test_bench_montecarlo_mode_reports_a_contract_line(hip_lib):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config"):
         assert key in rec
-    assert rec["metric"] == "problems_per_sec" and rec["value"] > 0 and rec["problems_solved_last_sweep"] == 4
+    assert rec["metric"] == "problems_per_sec" and rec["value"] > 0 and rec["legs"]["problems_solved_last_sweep"] == 4
+    assert len(out.stdout.strip().splitlines()[-1]) <= 4096
 
 
 @pytest.mark.parametrize("d", [2, 3])
