@@ -19,7 +19,8 @@ def find(sub, suffix):
     return hits[0] if hits else None
 
 
-for sub, name in (("loop", f"{tag}_loop_only_kernel_stats.csv"), ("full", f"{tag}_full_kernel_stats.csv")):
+for sub, name in (("loop", f"{tag}_loop_only_kernel_stats.csv"), ("full", f"{tag}_full_kernel_stats.csv"),
+                  ("batch16", f"{tag}_batch16_loop_kernel_stats.csv"), ("links", f"{tag}_links_kernel_stats.csv")):
     src = find(sub, "kernel_stats.csv")
     if src:
         shutil.copy(src, os.path.join(prof, name)); print("wrote", name)
@@ -52,7 +53,7 @@ if rec["sections"]:
     with open(os.path.join(prof, f"{tag}_pmc_fetch_write_per_kernel.json"), "w") as fh:
         json.dump(rec, fh, indent=1, sort_keys=True)
     print("wrote", f"{tag}_pmc_fetch_write_per_kernel.json", list(rec["sections"]))
-for sub in ("loop", "full"):
+for sub in ("loop", "full", "batch16"):
     src = os.path.join(out, f"{sub}_bench.json")
     if os.path.exists(src) and os.path.getsize(src):
         shutil.copy(src, os.path.join(prof, f"{tag}_{sub}_bench.json"))

@@ -55,6 +55,52 @@ thread_local std::string g_err;
             throw std::runtime_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));  \
     } while (0)
 
+// ---- how a host thread waits for the device (round 6) ----
+// A driver thread alternates queueing launches and waiting for small results in host-mapped memory.  Alone in the process it
+// spins (a result is picked up within a fraction of a microsecond: the latency of ONE default solve).  As soon as several
+// threads are inside solves at once (the lock-step groups of a Monte-Carlo sweep: 4 per rank) or several ranks share the node,
+// the waits go ECONOMY: a short spin, then sleeps of kEconomySleepNs with the thread's timer slack lowered to 1 us -- a waiting
+// thread costs no CPU, the Newton PCG is queued deeper ahead of the device (kEconomyDepth instead of 3) so that the device does
+// not run dry while its driver sleeps.  Rounds 4-5 spun, then yielded: with idle CPUs around a yield returns at once, and every
+// driver thread burnt a full CPU for the length of its solves -- 2.6-2.8 ms of host CPU per problem (BENCH_r05), which caps eight
+// ranks on the 16 CPUs the boxes grant at a third of the GPUs' capacity.
+struct HostWaitStats {
+    std::atomic<long long> spin_ns{0}, sleep_ns{0}, waits{0}, sleeps{0};
+    std::atomic<int> active_solves{0};
+};
+inline HostWaitStats& wait_stats() { static HostWaitStats s; return s; }
+constexpr long kEconomySleepNs = 25000;
+constexpr int kEconomyDepth = 6;
+inline bool several_ranks_here() {
+    static const bool v = [] { const char* e = std::getenv("LOCAL_WORLD_SIZE"); return e && std::atoi(e) > 1; }();
+    return v;
+}
+inline bool economy_waits() { return wait_stats().active_solves.load(std::memory_order_relaxed) >= 2 || several_ranks_here(); }
+inline void economy_sleep() {
+    static thread_local bool slack_set = false;
+    if (!slack_set) { prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }  // (default 50 us: a 25 us sleep would take 75)
+    struct timespec ts = {0, kEconomySleepNs};
+    const auto t0 = std::chrono::steady_clock::now();
+    nanosleep(&ts, nullptr);
+    wait_stats().sleep_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
+    wait_stats().sleeps.fetch_add(1, std::memory_order_relaxed);
+}
+struct ActiveSolve {  // (every entry point that creates, solves, reads or destroys a handle: two of them at once = economy waits)
+    ActiveSolve() { wait_stats().active_solves.fetch_add(1, std::memory_order_relaxed); }
+    ~ActiveSolve() { wait_stats().active_solves.fetch_sub(1, std::memory_order_relaxed); }
+};
+// hipStreamSynchronize spins inside the runtime (the default scheduling policy): with economy waits the stream is polled with
+// sleeps in between instead -- setup, read-back and teardown wait for the device as cheaply as the solves do
+inline hipError_t sync_stream(hipStream_t s) {
+    if (!economy_waits()) return hipStreamSynchronize(s);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 10.0) economy_sleep();
+    }
+}
+
 // Every entry point that takes a handle runs with the handle's device current and restores the
 // caller's device on exit: a host thread that never called hipSetDevice (a pool worker on a rank
 // with LOCAL_RANK > 0) would otherwise capture / launch / allocate on device 0 while the handle's
@@ -334,7 +380,7 @@ struct StageArena {
         if (!bytes) return true;
         if (bytes > stage_limit_bytes()) return false;
         if (inflight + bytes > kMaxInflight && inflight > 0) {  // everything queued so far has to leave its slots: start over
-            HIP_CHECK(hipStreamSynchronize(st));
+            HIP_CHECK(sync_stream(st));
             inflight = 0; at = 0;
             cur = chunks.empty() ? nullptr : (char*)chunks[0];
             left = chunks.empty() ? 0 : chunk_bytes[0];
@@ -379,7 +425,7 @@ inline void staged_h2d(void* dst, const void* src, size_t bytes, hipStream_t st)
         else
             std::memcpy(pin, (const char*)src + off, nb);
         e = hipMemcpyAsync((char*)dst + off, pin, nb, hipMemcpyHostToDevice, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = sync_stream(st);
     }
     block_cache().give(pin, got, dev, true);
     HIP_CHECK(e);
@@ -394,7 +440,7 @@ inline void staged_d2h(void* dst, const void* src, size_t bytes, hipStream_t st)
     for (size_t off = 0; off < bytes && e == hipSuccess; off += got) {
         const size_t nb = std::min(got, bytes - off);
         e = hipMemcpyAsync(pin, (const char*)src + off, nb, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = sync_stream(st);
         if (e != hipSuccess) break;
         if (nb >= ((size_t)1 << 20))
             score::parallel_ranges((int64_t)nb, (int64_t)1 << 19, [&](int, int64_t b0, int64_t b1) { std::memcpy((char*)dst + off + b0, pin + b0, (size_t)(b1 - b0)); });
@@ -446,7 +492,7 @@ struct DevBuf {
         HIP_CHECK(hipMemsetAsync(d + h.size(), 0, pad * sizeof(T), tl_copy_stream));
         if (tl_stage && tl_stage->upload(d, h.data(), h.size() * sizeof(T), tl_copy_stream)) return;
         if (!h.empty()) staged_h2d(d, h.data(), h.size() * sizeof(T), tl_copy_stream);
-        HIP_CHECK(hipStreamSynchronize(tl_copy_stream));
+        HIP_CHECK(sync_stream(tl_copy_stream));
     }
     // copy into the existing allocation (which may be larger: padded), never re-allocating
     void upload_into(const std::vector<T>& h) {
@@ -502,41 +548,6 @@ struct ZeroGroup {
         items.clear();
         total = 0;
     }
-};
-
-// ---- how a host thread waits for the device (round 6) ----
-// A driver thread alternates queueing launches and waiting for small results in host-mapped memory.  Alone in the process it
-// spins (a result is picked up within a fraction of a microsecond: the latency of ONE default solve).  As soon as several
-// threads are inside solves at once (the lock-step groups of a Monte-Carlo sweep: 4 per rank) or several ranks share the node,
-// the waits go ECONOMY: a short spin, then sleeps of kEconomySleepNs with the thread's timer slack lowered to 1 us -- a waiting
-// thread costs no CPU, the Newton PCG is queued deeper ahead of the device (kEconomyDepth instead of 3) so that the device does
-// not run dry while its driver sleeps.  Rounds 4-5 spun, then yielded: with idle CPUs around a yield returns at once, and every
-// driver thread burnt a full CPU for the length of its solves -- 2.6-2.8 ms of host CPU per problem (BENCH_r05), which caps eight
-// ranks on the 16 CPUs the boxes grant at a third of the GPUs' capacity.
-struct HostWaitStats {
-    std::atomic<long long> spin_ns{0}, sleep_ns{0}, waits{0}, sleeps{0};
-    std::atomic<int> active_solves{0};
-};
-inline HostWaitStats& wait_stats() { static HostWaitStats s; return s; }
-constexpr long kEconomySleepNs = 25000;
-constexpr int kEconomyDepth = 6;
-inline bool several_ranks_here() {
-    static const bool v = [] { const char* e = std::getenv("LOCAL_WORLD_SIZE"); return e && std::atoi(e) > 1; }();
-    return v;
-}
-inline bool economy_waits() { return wait_stats().active_solves.load(std::memory_order_relaxed) >= 2 || several_ranks_here(); }
-inline void economy_sleep() {
-    static thread_local bool slack_set = false;
-    if (!slack_set) { prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }  // (default 50 us: a 25 us sleep would take 75)
-    struct timespec ts = {0, kEconomySleepNs};
-    const auto t0 = std::chrono::steady_clock::now();
-    nanosleep(&ts, nullptr);
-    wait_stats().sleep_ns.fetch_add(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(), std::memory_order_relaxed);
-    wait_stats().sleeps.fetch_add(1, std::memory_order_relaxed);
-}
-struct ActiveSolve {  // (every entry point that runs a solve: score_solve, score_solve_steps, score_newton_steps, score_linear_solve)
-    ActiveSolve() { wait_stats().active_solves.fetch_add(1, std::memory_order_relaxed); }
-    ~ActiveSolve() { wait_stats().active_solves.fetch_sub(1, std::memory_order_relaxed); }
 };
 
 // SCORE_NO_LONG_SPIN=1: the split long rows of every matrix go through the ticket path (CsrDev::long_spin)
@@ -761,9 +772,9 @@ struct RuizDevice : RuizOffload {
                 HIP_CHECK(hipGetLastError());
                 staged_d2h(D, dD.d, (size_t)n * sizeof(double), st);
                 if (m) staged_d2h(E, dE.d, (size_t)m * sizeof(double), st);
-                HIP_CHECK(hipStreamSynchronize(st));
+                HIP_CHECK(sync_stream(st));
             } catch (const std::exception&) {
-                (void)hipStreamSynchronize(st);
+                (void)sync_stream(st);
                 (void)hipGetLastError();
                 ok = false;  // the host loop takes over (D, E may be partly written: reset them)
                 std::fill(D, D + n, 1.0);
@@ -939,7 +950,7 @@ struct HipBackend {
                          enq_launches ? 1e3 * enq_ms / (double)enq_launches : 0.0, waits, wait_ms);
         PhaseTimer pt(st.verbose != 0);
         if (pre_slot && h_ring) release_prequeued();  // (never pending here; a kernel waiting for the host must not outlive its ring)
-        if (stream) (void)hipStreamSynchronize(stream);
+        if (stream) (void)sync_stream(stream);
         pt.mark("destroy: sync");
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         pt.mark("destroy: graph");
@@ -1478,7 +1489,7 @@ struct HipBackend {
         HIP_CHECK(hipMemcpyAsync(hb + o_kp, mo.ptr.d, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipMemcpyAsync(hb + o_g1, G1.ptr.d, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipMemcpyAsync(hb + o_g2, G2.ptr.d, ((size_t)n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         pt.mark("  device setup: kernels + row pointers back");
         const int64_t nnzK = ((const long long*)(hb + o_res))[0];
         const double* nm = (const double*)(hb + o_norm);
@@ -1511,7 +1522,7 @@ struct HipBackend {
             HIP_CHECK(hipMemcpyAsync(kc.p, mo.col.d, (size_t)nnzK * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             // (the tiles of G1 / G2 need their row pointers only: laid out while K's columns travel)
             h.G1.nrows = h.G2.nrows = h.K.nrows = h.K.ncols = n;
-            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(sync_stream(stream));
             std::memcpy(h.K.col.data(), kc.p, (size_t)nnzK * sizeof(int32_t));
         }
         make_system_rowblocks(h);
@@ -1545,7 +1556,7 @@ struct HipBackend {
             }
             ~StageScope() {
                 tl_stage = nullptr;
-                (void)hipStreamSynchronize(st);  // (every queued transfer has left its pinned slot)
+                (void)sync_stream(st);  // (every queued transfer has left its pinned slot)
             }
         } stage_scope(st.device, stream);
         HIP_CHECK(hipEventCreate(&ev0));
@@ -1620,7 +1631,7 @@ struct HipBackend {
             RuizDevice& r;
             hipStream_t st;
             ~DropKept() {
-                if (r.kept) (void)hipStreamSynchronize(st);
+                if (r.kept) (void)sync_stream(st);
                 r.drop();
             }
         } drop_kept{ruiz_dev, stream};
@@ -1938,7 +1949,7 @@ struct HipBackend {
         }
         reset();
         pt.mark("reset");
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         setup_tmp.release_all();  // (nothing in flight reads the setup's scratch any more)
         for (auto& pb : setup_pinned) block_cache().give(pb.first, pb.second, st.device, true);
         setup_pinned.clear();
@@ -2072,8 +2083,14 @@ struct HipBackend {
         ja.done = pa.done;
         ja.r = (MODE == PREC_INIT) ? pa.r_in : pa.r;
         ja.z = pa.z; ja.p = pa.p; ja.rz_out = pa.rz_out;
-        hipLaunchKernelGGL(k_join_solve<BS>, dim3((unsigned)n_join_chains), dim3(64), 0, stream, ja);
-        hipLaunchKernelGGL((k_join_apply<BS, MODE>), dim3((unsigned)n_join_items), dim3(kJoinThreads), 0, stream, ja);
+        unsigned nv = 1;
+        if (MODE == PREC_INIT && pa.n_vec > 1) {  // (score_link.hpp's refresh: every round's vector in one launch)
+            nv = (unsigned)pa.n_vec;
+            ja.n_vec = pa.n_vec; ja.vec_stride = pa.vec_stride; ja.zb_stride = (long long)H->bs * n_join_seps; ja.rz_stride = (long long)n_prec;
+            ja.zb = link_zb.d;
+        }
+        hipLaunchKernelGGL(k_join_solve<BS>, dim3((unsigned)n_join_chains, nv), dim3(64), 0, stream, ja);
+        hipLaunchKernelGGL((k_join_apply<BS, MODE>), dim3((unsigned)n_join_items, nv), dim3(kJoinThreads), 0, stream, ja);
     }
     template <int MODE>
     void join_apply(const PrecArgs& pa, bool newton_set) {
@@ -2093,7 +2110,7 @@ struct HipBackend {
     DevBuf<LinkItem> link_items;
     DevBuf<int32_t> link_ucol, link_uround, link_usuper, link_pos, link_zero, link_status;
     DevBuf<uint8_t> link_mask;
-    DevBuf<double> link_Qt, link_t, link_Zr, link_rhs, link_tmp_p, link_tmp_rz;
+    DevBuf<double> link_Qt, link_t, link_Zr, link_rhs, link_tmp_p, link_tmp_rz, link_zb;
     void link_init(const HostSystem& h, const score_problem* probs, const score_graph* graphs) {
         n_link_items = n_link_probs = n_link_u = link_rounds = 0;
         if (!st.polish || !Q.available || h.chainsH.empty() || std::getenv("SCORE_NO_LINKS") != nullptr) return;
@@ -2115,12 +2132,15 @@ struct HipBackend {
         ZeroGroup zl;
         zl.add(link_status, (size_t)n_link_probs);
         zl.add(link_Qt, L.mask.size()); zl.add(link_t, (size_t)n_link_u); zl.add(link_Zr, (size_t)link_rounds * (size_t)h.n_tot);
-        zl.add(link_rhs, (size_t)h.n_tot); zl.add(link_zero, (size_t)h.count);
+        zl.add(link_rhs, (size_t)link_rounds * (size_t)h.n_tot); zl.add(link_zero, (size_t)h.count);
         zl.commit(stream);
-        link_tmp_p.alloc((size_t)h.n_tot); link_tmp_rz.alloc(h.prec_work.size() + 4096);
+        // (one launch applies the chain kernel to every round's right-hand side: a vector of n_tot per round)
+        link_tmp_p.alloc((size_t)link_rounds * (size_t)h.n_tot); link_tmp_rz.alloc((size_t)link_rounds * (h.prec_work.size() + 4096));
+        if (n_join_seps) link_zb.alloc((size_t)link_rounds * (size_t)h.bs * (size_t)n_join_seps);
         HIP_CHECK(hipFuncSetAttribute((const void*)k_link_cap, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLinkMaxU * kLinkMaxU * (int)sizeof(double)));
         LinkArgs la = link_args();
         hipLaunchKernelGGL(k_link_positions, dim3(16), dim3(kLinkThreads), 0, stream, la, n_link_probs);
+        hipLaunchKernelGGL(k_link_rhs, dim3((unsigned)((n_link_u + kLinkThreads - 1) / kLinkThreads)), dim3(kLinkThreads), 0, stream, la);
         HIP_CHECK(hipGetLastError());
     }
     LinkArgs link_args() {
@@ -2143,16 +2163,20 @@ struct HipBackend {
         pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d; pa.uni = uni_for(hblocks());
         pa.r = link_rhs.d; pa.r_in = link_rhs.d; pa.p = link_tmp_p.d; pa.w = w.d; pa.xt = link_tmp_p.d; pa.kx = link_tmp_p.d;
         pa.pw_part = nullptr; pa.rz_in = nullptr; pa.rz_out = link_tmp_rz.d;
+        // (the right-hand sides -- unit vectors, round r's in vector r -- were written once, at link_init: the chain kernel does
+        //  not touch r_in)
+        pa.z = link_Zr.d;
         link_suspend = true;
-        for (int r = 0; r < link_rounds; ++r) {
-            la.round = r;
-            hipLaunchKernelGGL(k_link_rhs, dim3((unsigned)((n_link_u + kLinkThreads - 1) / kLinkThreads)), dim3(kLinkThreads), 0, stream, la);
-            pa.z = link_Zr.d + (size_t)r * (size_t)H->n_tot;
+        if (split.active || link_rounds == 1) {  // (the split chain kernel takes one vector per launch)
+            for (int r = 0; r < link_rounds; ++r) {
+                pa.r = link_rhs.d + (size_t)r * (size_t)H->n_tot; pa.r_in = pa.r; pa.z = link_Zr.d + (size_t)r * (size_t)H->n_tot;
+                launch_prec<PREC_INIT>(pa);
+            }
+        } else {
+            pa.n_vec = link_rounds; pa.vec_stride = (long long)H->n_tot;
             launch_prec<PREC_INIT>(pa);
         }
         link_suspend = false;
-        la.round = -1;  // (leaves the right-hand side zero again)
-        hipLaunchKernelGGL(k_link_rhs, dim3((unsigned)((n_link_u + kLinkThreads - 1) / kLinkThreads)), dim3(kLinkThreads), 0, stream, la);
         hipLaunchKernelGGL(k_link_cap, dim3((unsigned)n_link_probs), dim3(kLinkThreads), (size_t)2 * link_max_u * link_max_u * sizeof(double), stream, la);
     }
     template <int BS, int MODE>
@@ -2272,7 +2296,7 @@ struct HipBackend {
     char* next_ring_slot(size_t bytes) {
         const size_t need = (bytes + 63) & ~(size_t)63;
         if (need > ring_slot_bytes) {
-            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(sync_stream(stream));
             block_cache().give(h_ring, h_ring_bytes, st.device, true);
             h_ring = nullptr;
             ring_slot_bytes = std::max<size_t>(need, 256);
@@ -2282,7 +2306,7 @@ struct HipBackend {
             ring_used = 0;
         }
         if (++ring_used >= kFlagSlots) {  // about to reuse a slot a queued fetch may not have read yet
-            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(sync_stream(stream));
             ring_used = 1;
         }
         flag_slot = (flag_slot + 1) % kFlagSlots;
@@ -2353,7 +2377,7 @@ struct HipBackend {
             else if (phase == 1 && us > 2000.0 && !economy_waits()) phase = 2;
             else if (us > 2e6) {
                 release_prequeued();  // (a fetch waiting for the host's words would keep the stream from draining)
-                HIP_CHECK(hipStreamSynchronize(stream));
+                HIP_CHECK(sync_stream(stream));
                 if (__atomic_load_n(h_seq, __ATOMIC_ACQUIRE) < seq) throw std::runtime_error("device did not publish its results");
                 break;
             }
@@ -2369,17 +2393,17 @@ struct HipBackend {
     DevBuf<double> iter_block;  // xtu | xy | s | r | z | p | p2 | w | kx | step | pw_part | rz_part0/1 | rz_meas0/1
     void reset() {
         const double t0 = st.verbose ? now_ms() : 0.0;
-        if (st.verbose) HIP_CHECK(hipStreamSynchronize(stream));
+        if (st.verbose) HIP_CHECK(sync_stream(stream));
         const double t1 = st.verbose ? now_ms() : 0.0;
         iter_block.zero(stream);
         const double t2 = st.verbose ? now_ms() : 0.0;
-        if (st.verbose) HIP_CHECK(hipStreamSynchronize(stream));
+        if (st.verbose) HIP_CHECK(sync_stream(stream));
         const double t3 = st.verbose ? now_ms() : 0.0;
         if (n_cone_blocks) {
             hipLaunchKernelGGL(k_refresh_u, dim3(n_cone_blocks), dim3(kThreads), 0, stream, cone_args(xtu.d));
             HIP_CHECK(hipGetLastError());
         }
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         if (st.verbose) std::fprintf(stderr, "[score] reset: %.3f ms waiting for work queued earlier, fill of %.1f MB: %.3f ms call + %.3f ms wait, refresh %.3f ms\n", t1 - t0,
                                      (double)iter_block.n * 8e-6, t2 - t1, t3 - t2, now_ms() - t3);
     }
@@ -2406,6 +2430,7 @@ struct HipBackend {
         pa.deep = newton_set ? deepH.d : deepK.d;
         const bool use_fac32 = newton_set ? newton_fac32 : this->use_fac32;
         if (split.active) {
+            if (pa.n_vec > 1) throw std::runtime_error("internal: several right-hand sides through the split chain kernel");
             WaveArgs wa{};
             wa.p = pa;
             wa.p.work = split_work.d;
@@ -2431,27 +2456,29 @@ struct HipBackend {
         const bool help = MODE == PREC_STEP && n_help > 0 && pa.rec != nullptr && !pa.debug_skip;
         const int n_prec = this->n_prec + (help ? n_help : 0);
         pa.split_update = (help && MODE == PREC_STEP) ? 1 : 0;
+        const unsigned nv = (MODE == PREC_INIT && pa.n_vec > 1) ? (unsigned)pa.n_vec : 1u;  // (several right-hand sides: PrecArgs::n_vec)
+        if (nv == 1) pa.n_vec = 0;
         // k_prec_pre (level 0 in registers, coarse levels in LDS) when every chain fits; 4 x 4 blocks (3-D problems) only
         // with the 4-byte factor stream (score_settings.fac_fp32), otherwise the streaming kernel
         if constexpr (BS <= 3) {
             if (prec_reg && use_fac32) {  // coarse-level factors in registers, vectors only in LDS
-                launch_on_stream((k_prec_pre<BS, MODE, float, true>), dim3(n_prec), dim3(kPrecThreads), prec_reg_lds, slot, pa);
+                launch_on_stream((k_prec_pre<BS, MODE, float, true>), dim3(n_prec, nv), dim3(kPrecThreads), prec_reg_lds, slot, pa);
                 return;
             }
         }
         if (prec_pre && use_fac32) {
-            launch_on_stream((k_prec_pre<BS, MODE, float>), dim3(n_prec), dim3(kPrecThreads), prec_pre_lds, slot, pa);
+            launch_on_stream((k_prec_pre<BS, MODE, float>), dim3(n_prec, nv), dim3(kPrecThreads), prec_pre_lds, slot, pa);
             return;
         }
         if constexpr (BS <= 3) {
             if (prec_pre) {
-                launch_on_stream((k_prec_pre<BS, MODE, double>), dim3(n_prec), dim3(kPrecThreads), prec_pre_lds, slot, pa);
+                launch_on_stream((k_prec_pre<BS, MODE, double>), dim3(n_prec, nv), dim3(kPrecThreads), prec_pre_lds, slot, pa);
                 return;
             }
         }
         pa.split_update = 0;  // (the streaming kernel reads the plain work list: no helpers)
-        if (prec_lds0) launch_on_stream((k_prec<BS, 3, MODE, true>), dim3(this->n_prec), dim3(kPrecThreads), prec_lds, slot, pa);
-        else launch_on_stream((k_prec<BS, 3, MODE, false>), dim3(this->n_prec), dim3(kPrecThreads), prec_lds, slot, pa);
+        if (prec_lds0) launch_on_stream((k_prec<BS, 3, MODE, true>), dim3(this->n_prec, nv), dim3(kPrecThreads), prec_lds, slot, pa);
+        else launch_on_stream((k_prec<BS, 3, MODE, false>), dim3(this->n_prec, nv), dim3(kPrecThreads), prec_lds, slot, pa);
     }
 
     // The attribute is per kernel function, i.e. shared by every handle of the process: always
@@ -2726,11 +2753,11 @@ struct HipBackend {
             DevBuf<unsigned long long> dts;  // (tl_arena is null outside init: a plain hipMalloc on the handle's device)
             dts.alloc(nslot);
             HIP_CHECK(hipMemcpyAsync(dts.d, hts.data(), nslot * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(sync_stream(stream));
             for (int i = 0; i < warmup; ++i) enqueue_iteration(false, i == 0);
             for (int i = 0; i < iters; ++i) enqueue_iteration(false, warmup == 0 && i == 0, dts.d + per_iter * i);
             HIP_CHECK(hipMemcpyAsync(hts.data(), dts.d, nslot * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(sync_stream(stream));
             HIP_CHECK(hipGetLastError());
             for (int i = 0; i < iters; ++i)
                 for (int k = 0; k < 6; ++k) {
@@ -2766,7 +2793,7 @@ struct HipBackend {
             enqueue_iteration(false, false);
         }
         tev = nullptr;
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         HIP_CHECK(hipGetLastError());
         for (int i = 0; i < iters; ++i)
             for (int k = 0; k < 6; ++k) {
@@ -2883,7 +2910,7 @@ struct HipBackend {
         if (e == hipSuccess && nmax > 0) hipLaunchKernelGGL(k_read_estimates, dim3((unsigned)((nmax + 255) / 256)), dim3(256), 0, stream, a);
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(hv, dv, bytes, hipMemcpyDeviceToHost, stream);
-        const hipError_t e2 = hipStreamSynchronize(stream);
+        const hipError_t e2 = sync_stream(stream);
         if (e == hipSuccess && e2 == hipSuccess) {
             if (poses) std::memcpy(poses, hv, n_T * sizeof(double));
             if (relaxed) std::memcpy(relaxed, hv + n_T * sizeof(double), n_B * sizeof(double));
@@ -2915,7 +2942,7 @@ struct HipBackend {
                 if (e != hipSuccess) err = e;
                 off += pt.second.second;
             }
-        const hipError_t es = hipStreamSynchronize(stream);
+        const hipError_t es = sync_stream(stream);
         if (err == hipSuccess && es == hipSuccess) {
             std::vector<std::pair<double*, std::pair<const double*, size_t>>> hp;
             off = 0;
@@ -2995,9 +3022,9 @@ struct HipBackend {
             else { isrc = K.ptr.d; sz = h.n_tot + 1; }
             if (out && len > 0) {
                 std::vector<int32_t> tmp((size_t)std::min(len, sz));
-                HIP_CHECK(hipStreamSynchronize(stream));
+                HIP_CHECK(sync_stream(stream));
                 staged_d2h(tmp.data(), isrc, tmp.size() * sizeof(int32_t), stream);
-                HIP_CHECK(hipStreamSynchronize(stream));
+                HIP_CHECK(sync_stream(stream));
                 for (size_t i = 0; i < tmp.size(); ++i) out[i] = (double)tmp[i];
             }
             return sz;
@@ -3025,7 +3052,7 @@ struct HipBackend {
             double v[6] = {(double)link_plan.pairs_total, (double)link_plan.pairs_used, (double)n_link_u, (double)n_link_items, (double)link_rounds, 0.0};
             if (n_link_probs && out) {
                 std::vector<int32_t> stt((size_t)n_link_probs);
-                HIP_CHECK(hipStreamSynchronize(stream));
+                HIP_CHECK(sync_stream(stream));
                 HIP_CHECK(hipMemcpy(stt.data(), link_status.d, sizeof(int32_t) * (size_t)n_link_probs, hipMemcpyDeviceToHost));
                 for (int32_t x : stt) v[5] += x;
             }
@@ -3060,13 +3087,13 @@ struct HipBackend {
                 auto down_i = [&](const int32_t* d, size_t cnt) {
                     std::vector<int32_t> v(cnt);
                     if (cnt) staged_d2h(v.data(), d, cnt * sizeof(int32_t), stream);
-                    HIP_CHECK(hipStreamSynchronize(stream));
+                    HIP_CHECK(sync_stream(stream));
                     return v;
                 };
                 auto down_d = [&](const double* d, size_t cnt) {
                     std::vector<double> v(cnt);
                     if (cnt) staged_d2h(v.data(), d, cnt * sizeof(double), stream);
-                    HIP_CHECK(hipStreamSynchronize(stream));
+                    HIP_CHECK(sync_stream(stream));
                     return v;
                 };
                 auto mism = [](const std::vector<int32_t>& x, const std::vector<int32_t>& y) {
@@ -3098,13 +3125,13 @@ struct HipBackend {
                 auto down_i = [&](const int32_t* d, size_t cnt) {
                     std::vector<int32_t> v(cnt);
                     if (cnt) staged_d2h(v.data(), d, cnt * sizeof(int32_t), stream);
-                    HIP_CHECK(hipStreamSynchronize(stream));
+                    HIP_CHECK(sync_stream(stream));
                     return v;
                 };
                 auto down_d = [&](const double* d, size_t cnt) {
                     std::vector<double> v(cnt);
                     if (cnt) staged_d2h(v.data(), d, cnt * sizeof(double), stream);
-                    HIP_CHECK(hipStreamSynchronize(stream));
+                    HIP_CHECK(sync_stream(stream));
                     return v;
                 };
                 auto mism = [](const std::vector<int32_t>& x, const std::vector<int32_t>& y) {
@@ -3157,7 +3184,7 @@ struct HipBackend {
                     std::vector<double> F(h.count), gn(h.count);
                     newton_eval_batch(q_X0.d, all, F, gn);
                     newton_hessian(q_skip.d);
-                    HIP_CHECK(hipStreamSynchronize(stream));
+                    HIP_CHECK(sync_stream(stream));
                     out[0] = F[0];
                 } catch (const std::exception&) { return -2; }
             }
@@ -3186,13 +3213,13 @@ struct HipBackend {
             if (nm == "is_head" && h.device_setup) {  // (made on the device: the host never held it)
                 std::vector<int32_t> ih((size_t)h.n_tot);
                 staged_d2h(ih.data(), q_ishead.d, sizeof(int32_t) * ih.size(), stream);
-                HIP_CHECK(hipStreamSynchronize(stream));
+                HIP_CHECK(sync_stream(stream));
                 tmp.assign(ih.begin(), ih.end());
             } else
             if (nm == "Hcol" && polish_on_device) {  // (built on the device: the host never held it)
                 std::vector<int32_t> hc((size_t)hm_nnz);
                 staged_d2h(hc.data(), Hm.col.d, sizeof(int32_t) * hc.size(), stream);
-                HIP_CHECK(hipStreamSynchronize(stream));
+                HIP_CHECK(sync_stream(stream));
                 tmp.assign(hc.begin(), hc.end());
             }
             else if (nm == "Hcol") tmp.assign(Q.Hm.col.begin(), Q.Hm.col.end());
@@ -3231,7 +3258,7 @@ struct HipBackend {
             const size_t bytes = sizeof(double) * (size_t)std::min(len, sz);
             if (host) std::memcpy(out, src, bytes);
             else {
-                if (hipStreamSynchronize(stream) != hipSuccess) return -2;
+                if (sync_stream(stream) != hipSuccess) return -2;
                 try { staged_d2h(out, src, bytes, stream); } catch (const std::exception&) { return -2; }
             }
         }
@@ -3315,7 +3342,7 @@ struct HipBackend {
             queued += chunk;
             HIP_CHECK(hipGetLastError());
             HIP_CHECK(hipMemcpyAsync(state, lin_flag.d, sizeof(state), hipMemcpyDeviceToHost, stream));
-            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(sync_stream(stream));
         }
         if (used_out) *used_out = state[1];
         return state[0] != 0;
@@ -3427,10 +3454,10 @@ struct HipBackend {
             HIP_CHECK(hipMemcpyAsync(res.data(), result.d, 3 * sizeof(long long), hipMemcpyDeviceToHost, stream));
             staged_d2h(Q.Hm.ptr.data(), Hm.ptr.d, ((size_t)n + 1) * sizeof(int32_t), stream);
             staged_d2h(longs.data(), long_ent.d, (size_t)long_max * sizeof(int32_t), stream);
-            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(sync_stream(stream));
             pt.mark("    polish (device): kernels + row pointers back");
             } catch (...) {
-                (void)hipStreamSynchronize(stream);  // (nothing in flight may touch the scratch once it goes back to the cache)
+                (void)sync_stream(stream);  // (nothing in flight may touch the scratch once it goes back to the cache)
                 throw;
             }
         }
@@ -3494,7 +3521,7 @@ struct HipBackend {
                 on_device = false;
             }
             pt.mark("  polish: structure + pattern + lists on the device");
-            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(sync_stream(stream));
             if (!on_device || bad_h[0] != 0) {  // (not the SCORE structure, or a build the device declined: ADMM alone)
                 Q.available = false;
                 return;
@@ -3592,7 +3619,7 @@ struct HipBackend {
         } catch (const std::exception& e) {
             if (st.verbose) std::fprintf(stderr, "[score] polish abandoned: %s\n", e.what());
             release_prequeued();  // (a fetch waiting for the host's words would keep the stream from draining)
-            (void)hipStreamSynchronize(stream);
+            (void)sync_stream(stream);
             (void)hipGetLastError();
             return false;
         }
@@ -4062,7 +4089,7 @@ struct HipBackend {
             a.p = xtu.d; a.w = kx.d; a.done = q_skip.d;
             launch_spmv<MODE_KP>(K, a);
         }
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         HIP_CHECK(hipGetLastError());
         probe_collect();
         return true;
@@ -4103,13 +4130,13 @@ struct HipBackend {
         // problems that have converged are skipped by every kernel: time them as active
         const HostSystem& h = *H;
         std::vector<int32_t> zero(h.count, 0), keep(h.count);
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         HIP_CHECK(hipMemcpyAsync(keep.data(), done.d, keep.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         HIP_CHECK(hipMemcpyAsync(done.d, zero.data(), zero.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         for (int i = 0; i < 5; ++i) once();
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         HIP_CHECK(hipEventRecord(ev0, stream));
         for (int i = 0; i < reps; ++i) once();
         HIP_CHECK(hipEventRecord(ev1, stream));
@@ -4118,7 +4145,7 @@ struct HipBackend {
         HIP_CHECK(hipEventElapsedTime(&t, ev0, ev1));
         *ms = (double)t / std::max(1, reps);
         HIP_CHECK(hipMemcpyAsync(done.d, keep.data(), keep.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
     }
 
     // roofline probe: average launch duration of the KKT SpMV (w = K p), HIP
@@ -4127,16 +4154,16 @@ struct HipBackend {
         const HostSystem& h = *H;
         std::vector<double> hp(h.n_tot);
         for (int64_t i = 0; i < h.n_tot; ++i) hp[i] = 1.0 + 1e-3 * (double)(i % 7);
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         staged_h2d(p.d, hp.data(), hp.size() * sizeof(double), stream);
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         std::vector<int32_t> zero(h.count, 0), keep(h.count);
         HIP_CHECK(hipMemcpyAsync(keep.data(), done.d, keep.size() * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         HIP_CHECK(hipMemcpyAsync(done.d, zero.data(), zero.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         for (int i = 0; i < 10; ++i) launch_kp(p.d);
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
         HIP_CHECK(hipEventRecord(ev0, stream));
         for (int i = 0; i < reps; ++i) launch_kp(p.d);
         HIP_CHECK(hipEventRecord(ev1, stream));
@@ -4148,7 +4175,7 @@ struct HipBackend {
         for (double v : h.kkt_bytes) bsum += v;
         *bytes = bsum;
         HIP_CHECK(hipMemcpyAsync(done.d, keep.data(), keep.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(sync_stream(stream));
     }
 };
 
@@ -4251,7 +4278,7 @@ struct score_refine {
                                cost_part.d, with_blocks ? 1 : 0);
         part_host.resize((size_t)n_mblocks);
         HIP_CHECK(hipMemcpyAsync(part_host.data(), cost_part.d, (size_t)n_mblocks * sizeof(double), hipMemcpyDeviceToHost, stream()));
-        HIP_CHECK(hipStreamSynchronize(stream()));
+        HIP_CHECK(sync_stream(stream()));
         double f = 0.0;
         for (double v : part_host) f += v;
         return f;
@@ -4272,7 +4299,7 @@ struct score_refine {
                            (const int32_t*)gc_slot.d, (const double*)gblk.d, rhs.d, gmax_part.d, (int64_t)P.n);
         part_host.resize((size_t)n_ublocks);
         HIP_CHECK(hipMemcpyAsync(part_host.data(), gmax_part.d, (size_t)n_ublocks * sizeof(double), hipMemcpyDeviceToHost, stream()));
-        HIP_CHECK(hipStreamSynchronize(stream()));
+        HIP_CHECK(sync_stream(stream()));
         double m = 0.0;
         for (double v : part_host) m = std::max(m, v);
         return m;
@@ -4296,10 +4323,10 @@ struct score_refine {
             if (P.Nl) std::copy(lms_in, lms_in + 3 * P.Nl, u0.begin() + (std::ptrdiff_t)(12 * P.Np));
         }
         staged_h2d(u.d, u0.data(), u0.size() * sizeof(double), stream());
-        HIP_CHECK(hipStreamSynchronize(stream()));
+        HIP_CHECK(sync_stream(stream()));
         score::gn_levenberg_marquardt(*this, max_iters, tol, 1e-9, info);
         staged_d2h(u0.data(), u.d, u0.size() * sizeof(double), stream());
-        HIP_CHECK(hipStreamSynchronize(stream()));
+        HIP_CHECK(sync_stream(stream()));
         if (P.dim == 2) {
             for (int k = 0; k < 3; ++k) poses_out[k] = poses_in[k];
             for (int64_t p = 1; p < P.Np; ++p)
@@ -4332,6 +4359,7 @@ static void tune_host_allocator_once() {
 
 int score_create_batch(const score_problem* p, int32_t count, const score_settings* s, score_handle** out) {
     try {
+        ActiveSolve active;
         tune_host_allocator_once();
         if (!p || !out) throw std::runtime_error("null argument");
         score_settings st;
@@ -4360,6 +4388,7 @@ int score_create(const score_problem* p, const score_settings* s, score_handle**
 }
 static int score_create_from_graphs_impl(const score_graph* graphs, int32_t count, const score_settings* s, score_handle** out, const HipBackend::GenSource* gen_src) {
     try {
+        ActiveSolve active;
         tune_host_allocator_once();
         if (!graphs || !out) throw std::runtime_error("null argument");
         score_settings st;
@@ -4403,6 +4432,7 @@ int score_read_estimates(score_handle* h, int32_t qcqp_directions, double* poses
         if (!h) throw std::runtime_error("null handle");
         if (!h->solver.est.valid()) throw std::runtime_error("score_read_estimates: the handle was not made by score_create_from_graphs");
         DeviceGuard guard(h->solver.st.device);
+        ActiveSolve active;
         h->solver.be.read_estimates(h->solver.H, h->solver.est, (qcqp_directions || h->solver.est.dirs_always) ? 1 : 0, poses, relaxed, landmarks, ranges, degenerate);
         return 0;
     } catch (const std::exception& e) { g_err = e.what(); return -1; }
@@ -4517,6 +4547,7 @@ int64_t score_debug_get(score_handle* h, const char* name, double* out, int64_t 
 void score_destroy(score_handle* h) {
     if (!h) return;
     try {
+        ActiveSolve active;
         DeviceGuard guard(h->solver.st.device);
         score::PhaseTimer pt(h->solver.st.verbose != 0);
         delete h;
@@ -4699,7 +4730,7 @@ void generate_manhattan_device(const score::GenSpec& S, int count, int device, s
             const hipError_t e1 = hipMemcpyAsync(pin + pt.off, pt.src, pt.bytes, hipMemcpyDeviceToHost, st);
             if (e1 != hipSuccess) err = e1;
         }
-        const hipError_t es = hipStreamSynchronize(st);
+        const hipError_t es = sync_stream(st);
         if (err == hipSuccess && es == hipSuccess)
             parallel_ranges((int64_t)parts.size(), 1, [&](int, int64_t p0, int64_t p1) {
                 for (int64_t k = p0; k < p1; ++k) std::memcpy(parts[(size_t)k].dst, pin + parts[(size_t)k].off, parts[(size_t)k].bytes);
@@ -4709,7 +4740,7 @@ void generate_manhattan_device(const score::GenSpec& S, int count, int device, s
         Gd.d_rel_base = rel_base.d; Gd.d_rel_to = rel_to.d; Gd.d_rel_t = rel_t.d; Gd.d_rel_R = rel_R.d; Gd.d_rel_kappa = rel_kappa.d; Gd.d_rel_tau = rel_tau.d;
         Gd.d_ra = ra.d; Gd.d_rb = rb.d; Gd.d_dist = dist.d; Gd.d_prec = prec.d;
     } catch (...) {
-        (void)hipStreamSynchronize(st);
+        (void)sync_stream(st);
         stream_pool().give(device, st);
         throw;
     }
@@ -4790,14 +4821,14 @@ int score_round_to_so(int32_t dim, int64_t n, const double* blocks, double* rota
             if (dim == 2) hipLaunchKernelGGL(k_round_so<2>, dim3(grid), dim3(256), 0, st, dM, dR, dF, (int64_t)n);
             else hipLaunchKernelGGL(k_round_so<3>, dim3(grid), dim3(256), 0, st, dM, dR, dF, (int64_t)n);
             HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipStreamSynchronize(st));
+            HIP_CHECK(sync_stream(st));
             std::memcpy(rotations, stage + in_bytes, in_bytes);
             std::memcpy(degenerate, stage + 2 * in_bytes, flag_bytes);
         } catch (const std::exception& e) { g_err = e.what(); rc = -1; }
         // After an error the kernel may still be running on the staging block: hand block and stream back only once
         // the stream has drained; if even that fails, drop them (a leak of one block beats a kernel writing into a
         // block another handle has been given).
-        if (rc == 0 || hipStreamSynchronize(st) == hipSuccess) {
+        if (rc == 0 || sync_stream(st) == hipSuccess) {
             stream_pool().give(device, st);
             block_cache().give(stage, cap, device, true);
         } else {

@@ -55,6 +55,10 @@ struct JoinArgs {
     double* p;                // INIT: receives z
     double* rz_out;
     double* zb;               // the separators' solution (k_join_solve -> k_join_apply): BS per separator
+    // several vectors in one launch (grid.y; score_link.hpp's refresh): r, z, p advance by y * vec_stride, zb by y * zb_stride,
+    // rz_out by y * rz_stride (the chain kernel's grid)
+    int n_vec;
+    long long vec_stride, zb_stride, rz_stride;
     // k_join_dinv
     const int32_t* sep_diag;
     double* dinv;
@@ -215,8 +219,17 @@ __global__ __launch_bounds__(64) void k_join_schur(JoinArgs a, int n_jc) {
 // sides r_b - A y[last of the left segment] - B y[first of the right segment], the block-Thomas solve, z_b into `zb`;
 // k_join_apply -- one workgroup per segment: z -= W_left z_b[seg - 1] + W_right z_b[seg], the separator to its right, and the
 // r'z partial sum of the segment's work item restated with the corrected z.
+__device__ __forceinline__ void join_select_vector(JoinArgs& a) {
+    if (a.n_vec > 1) {
+        const long long off = (long long)blockIdx.y * a.vec_stride;
+        a.r += off; a.z += off; a.zb += (long long)blockIdx.y * a.zb_stride;
+        if (a.p) a.p += off;
+        if (a.rz_out) a.rz_out += (long long)blockIdx.y * a.rz_stride;
+    }
+}
 template <int BS>
 __global__ __launch_bounds__(64) void k_join_solve(JoinArgs a) {
+    join_select_vector(a);
     constexpr int B2 = BS * BS;
     __shared__ double g[kJoinMaxSeps * BS];
     __shared__ double F[kJoinMaxSeps * 3 * B2];  // Pinv, Lo, Up of every separator: the sequential solve reads LDS only
@@ -290,6 +303,7 @@ __global__ __launch_bounds__(64) void k_join_solve(JoinArgs a) {
 
 template <int BS, int MODE>
 __global__ __launch_bounds__(kJoinThreads) void k_join_apply(JoinArgs a) {
+    join_select_vector(a);
     __shared__ double red[16];
     const JoinItem it = a.items[blockIdx.x];
     const JoinChain jc = a.jc[it.jc];

@@ -1050,6 +1050,10 @@ struct PrecArgs {
     double* rz_out;        // one partial per work item
     unsigned long long* tstamp;  // see KernelStamp
     int debug_skip;        // timing experiments only: 1 run, 2 separator, 4 back-subst, 8 head, 16 tail
+    // INIT over several right-hand sides in ONE launch (score_link.hpp: the columns Z = T^-1 U of a refresh): grid.y = n_vec,
+    // workgroup (x, y) applies item x to vector y -- r_in, z, p advance by y * vec_stride, rz_out by y * gridDim.x
+    int n_vec;
+    long long vec_stride;
     int split_update;      // STEP of k_prec_pre: xt += alpha p, kx += alpha w are done by the helper items (kind 2) of this
                            // launch, on CUs the chains leave idle, instead of by the chain / Jacobi workgroups themselves
     // Device-side termination of a PCG solve (the Newton polish; null in the ADMM loop, whose PCG
@@ -1195,8 +1199,17 @@ __device__ __forceinline__ double prec_jacobi_item(const PrecArgs& a, const Prec
 // afterwards (back) the levels are back-substituted coarse to fine.  The factor
 // blocks of a phase never depend on vector data, so they are requested BEFORE the
 // barrier that ends the previous phase and arrive while it drains.
+// (INIT launches over several vectors: see PrecArgs::n_vec)
+__device__ __forceinline__ void prec_select_vector(PrecArgs& a) {
+    if (a.n_vec > 1) {
+        const long long off = (long long)blockIdx.y * a.vec_stride;
+        a.r_in += off; a.z += off; a.p += off;
+        a.rz_out += (size_t)blockIdx.y * gridDim.x;
+    }
+}
 template <int BS, int RMAX, int MODE, bool LDS0>
 __global__ __launch_bounds__(kPrecThreads) void k_prec(PrecArgs a) {
+    if (MODE == PREC_INIT) prec_select_vector(a);
     KernelStamp stamp(a.tstamp);
     extern __shared__ __attribute__((aligned(16))) double lds[];  // [0,16) reductions, [16,16+6*kMaxLevels) level table, vectors
     __shared__ ChainLevelDesc sLv[kMaxLevels];
@@ -1562,7 +1575,10 @@ struct PreTile {
 template <int BS, int MODE, typename FT, bool REGDEEP>
 __device__ __forceinline__ void prec_pre_body(const PrecArgs& a);
 template <int BS, int MODE, typename FT = double, bool REGDEEP = false>
-__global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) { prec_pre_body<BS, MODE, FT, REGDEEP>(a); }
+__global__ __launch_bounds__(kPrecThreads) void k_prec_pre(PrecArgs a) {
+    if (MODE == PREC_INIT) prec_select_vector(a);
+    prec_pre_body<BS, MODE, FT, REGDEEP>(a);
+}
 // (Round 5, measured and removed: the same body compiled for TWO workgroups per CU -- __launch_bounds__(512, 4): 128 registers
 //  per lane, 432 of them spilled, 672 bytes of scratch per lane -- for lock-step batches whose chain work items otherwise run in
 //  two rounds.  64 config-5 trials in 4 handles of 16: 4170-4230 -> 2180-2210 problems/s.  A two-per-CU chain kernel needs a

@@ -234,7 +234,7 @@ struct LinkArgs {
     double* Qt;              // per problem n_u x n_u: Q transposed (thread a of k_link_solve reads Qt[b n_u + a])
     double* t;               // per unknown: t = Q y[U]
     double* Zr;              // rounds x n_tot: round r's applications of the chain kernel
-    double* rhs;             // n_tot, zero except at the unknowns of the round being solved
+    double* rhs;             // rounds x n_tot, zero except for a 1 at every unknown, in its round's vector
     int64_t n_tot;
     int rounds, n_u_total, round;
     const int32_t* Hptr;
@@ -260,10 +260,10 @@ __global__ __launch_bounds__(kLinkThreads) void k_link_positions(LinkArgs a, int
     }
 }
 
-// right-hand side of round a.round: 1 at the unknowns of that round, 0 at the others (the rest of rhs stays zero)
+// the right-hand sides, once: vector r (n_tot entries each, zero-filled) holds a 1 at every unknown of round r
 __global__ __launch_bounds__(kLinkThreads) void k_link_rhs(LinkArgs a) {
     const int i = blockIdx.x * kLinkThreads + threadIdx.x;
-    if (i < a.n_u_total) a.rhs[a.ucol[i]] = a.uround[i] == a.round ? 1.0 : 0.0;
+    if (i < a.n_u_total) a.rhs[(size_t)a.uround[i] * a.n_tot + a.ucol[i]] = 1.0;
 }
 
 // Q = (I + G Z[U,:])^-1 G, one workgroup per problem; dynamic LDS: G and S, n_u x n_u doubles each
@@ -272,6 +272,9 @@ __global__ __launch_bounds__(kLinkThreads) void k_link_cap(LinkArgs a) {
     __shared__ int piv_row;
     __shared__ double piv_val;
     __shared__ double fcol[kLinkMaxU];
+    __shared__ double wv[2];
+    __shared__ int wi[2];
+    static_assert(kLinkMaxU <= 128, "the pivot search uses two wavefronts");
     const LinkProb P = a.probs[blockIdx.x];
     const int n = P.n_u, t = threadIdx.x;
     double* G = link_lds;
@@ -296,11 +299,22 @@ __global__ __launch_bounds__(kLinkThreads) void k_link_cap(LinkArgs a) {
     __syncthreads();
     bool singular = false;
     for (int k = 0; k < n; ++k) {
+        // pivot: the largest |S[i][k]|, i >= k -- by the first two wavefronts (n <= 128), ties to the smallest row
+        if (t < 128) {
+            double v = (t >= k && t < n) ? fabs(S[t * n + k]) : -1.0;
+            int idx = t;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ov = __shfl_down(v, off);
+                const int oi = __shfl_down(idx, off);
+                if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+            }
+            if ((t & 63) == 0) { wv[t >> 6] = v; wi[t >> 6] = idx; }
+        }
+        __syncthreads();
         if (t == 0) {
-            int best = k;
-            double bv = fabs(S[k * n + k]);
-            for (int i = k + 1; i < n; ++i) { const double v = fabs(S[i * n + k]); if (v > bv) { bv = v; best = i; } }
-            piv_row = best; piv_val = bv;
+            const bool second = wv[1] > wv[0];
+            piv_row = second ? wi[1] : wi[0]; piv_val = second ? wv[1] : wv[0];
         }
         __syncthreads();
         if (!(piv_val > 1e-300)) { singular = true; break; }  // (uniform)
@@ -388,24 +402,41 @@ __global__ __launch_bounds__(kLinkApplyThreads) void k_link_apply(LinkArgs a) {
     const int NB = ch.N * BS, NE = NB + (it.sep_col >= 0 ? BS : 0);
     const double* __restrict__ Zr = a.Zr;
     double local = 0.0;
-    for (int e = t; e < NE; e += kLinkApplyThreads) {
-        int col;
-        if (e < NB) {
-            const int node = e / BS;
-            col = join_col<BS>(ch, a.node_col, node) + (e - node * BS);
-        } else col = it.sep_col + (e - NB);
-        double zz = a.z[col];
-        const double rv = a.r[col];
-        for (int k0 = 0; k0 < na; k0 += kLinkBatch) {
-            double zv[kLinkBatch];
+    // kLinkEnt entries per lane and trip (a chain of 1023 nodes of 3 unknowns: one trip), every load of a batch of rounds
+    // requested before the first use
+    constexpr int kLinkEnt = 6;
+    for (int e0 = t; e0 < NE; e0 += kLinkApplyThreads * kLinkEnt) {
+        int col[kLinkEnt];
+        double zz[kLinkEnt], rv[kLinkEnt];
 #pragma unroll
-            for (int q = 0; q < kLinkBatch; ++q) zv[q] = Zr[(size_t)rr[k0 + q] * a.n_tot + col];
-#pragma unroll
-            for (int q = 0; q < kLinkBatch; ++q) zz -= zv[q] * ts[k0 + q];
+        for (int j = 0; j < kLinkEnt; ++j) {
+            const int e = min(e0 + j * kLinkApplyThreads, NE - 1);
+            if (e < NB) {
+                const int node = e / BS;
+                col[j] = join_col<BS>(ch, a.node_col, node) + (e - node * BS);
+            } else col[j] = it.sep_col + (e - NB);
         }
-        a.z[col] = zz;
-        if (MODE == PREC_INIT) a.p[col] = zz;
-        local += rv * zz;
+#pragma unroll
+        for (int j = 0; j < kLinkEnt; ++j) { zz[j] = a.z[col[j]]; rv[j] = a.r[col[j]]; }
+        for (int k0 = 0; k0 < na; k0 += kLinkBatch) {
+            double zv[kLinkEnt][kLinkBatch];
+#pragma unroll
+            for (int j = 0; j < kLinkEnt; ++j)
+#pragma unroll
+                for (int q = 0; q < kLinkBatch; ++q) zv[j][q] = Zr[(size_t)rr[k0 + q] * a.n_tot + col[j]];
+#pragma unroll
+            for (int j = 0; j < kLinkEnt; ++j)
+#pragma unroll
+                for (int q = 0; q < kLinkBatch; ++q) zz[j] -= zv[j][q] * ts[k0 + q];
+        }
+#pragma unroll
+        for (int j = 0; j < kLinkEnt; ++j) {
+            if (e0 + j * kLinkApplyThreads < NE) {
+                a.z[col[j]] = zz[j];
+                if (MODE == PREC_INIT) a.p[col[j]] = zz[j];
+                local += rv[j] * zz[j];
+            }
+        }
     }
     const double tot = block_sum_n<kLinkApplyThreads / 64>(local, red);
     if (t == 0) a.rz_out[it.work] = tot;
