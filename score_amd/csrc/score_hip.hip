@@ -75,7 +75,10 @@ inline bool several_ranks_here() {
     static const bool v = [] { const char* e = std::getenv("LOCAL_WORLD_SIZE"); return e && std::atoi(e) > 1; }();
     return v;
 }
-inline bool economy_waits() { return wait_stats().active_solves.load(std::memory_order_relaxed) >= 2 || several_ranks_here(); }
+inline bool economy_waits() {
+    static const bool always_spin = trace_on("spin");  // (SCORE_TRACE=spin: the spinning waits everywhere -- the A/B of this policy)
+    return !always_spin && (wait_stats().active_solves.load(std::memory_order_relaxed) >= 2 || several_ranks_here());
+}
 inline void economy_sleep() {
     static thread_local bool slack_set = false;
     if (!slack_set) { prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }  // (default 50 us: a 25 us sleep would take 75)
@@ -2137,7 +2140,8 @@ struct HipBackend {
         // (one launch applies the chain kernel to every round's right-hand side: a vector of n_tot per round)
         link_tmp_p.alloc((size_t)link_rounds * (size_t)h.n_tot); link_tmp_rz.alloc((size_t)link_rounds * (h.prec_work.size() + 4096));
         if (n_join_seps) link_zb.alloc((size_t)link_rounds * (size_t)h.bs * (size_t)n_join_seps);
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_link_cap, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLinkMaxU * kLinkMaxU * (int)sizeof(double)));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_link_cap<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLinkMaxU * kLinkMaxU * (int)sizeof(double)));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_link_cap<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLinkMaxU * kLinkMaxU * (int)sizeof(double)));
         LinkArgs la = link_args();
         hipLaunchKernelGGL(k_link_positions, dim3(16), dim3(kLinkThreads), 0, stream, la, n_link_probs);
         hipLaunchKernelGGL(k_link_rhs, dim3((unsigned)((n_link_u + kLinkThreads - 1) / kLinkThreads)), dim3(kLinkThreads), 0, stream, la);
@@ -2177,7 +2181,9 @@ struct HipBackend {
             launch_prec<PREC_INIT>(pa);
         }
         link_suspend = false;
-        hipLaunchKernelGGL(k_link_cap, dim3((unsigned)n_link_probs), dim3(kLinkThreads), (size_t)2 * link_max_u * link_max_u * sizeof(double), stream, la);
+        // (up to 48 unknowns: one wavefront per problem, no block barriers; beyond: four wavefronts)
+        if (link_max_u <= 48) hipLaunchKernelGGL(k_link_cap<64>, dim3((unsigned)n_link_probs), dim3(64), (size_t)2 * link_max_u * link_max_u * sizeof(double), stream, la);
+        else hipLaunchKernelGGL(k_link_cap<256>, dim3((unsigned)n_link_probs), dim3(256), (size_t)2 * link_max_u * link_max_u * sizeof(double), stream, la);
     }
     template <int BS, int MODE>
     void link_apply_bs(const PrecArgs& pa) {

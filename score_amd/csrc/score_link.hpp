@@ -266,25 +266,36 @@ __global__ __launch_bounds__(kLinkThreads) void k_link_rhs(LinkArgs a) {
     if (i < a.n_u_total) a.rhs[(size_t)a.uround[i] * a.n_tot + a.ucol[i]] = 1.0;
 }
 
-// Q = (I + G Z[U,:])^-1 G, one workgroup per problem; dynamic LDS: G and S, n_u x n_u doubles each
-__global__ __launch_bounds__(kLinkThreads) void k_link_cap(LinkArgs a) {
+// Q = (I + G Z[U,:])^-1 G, one workgroup per problem; dynamic LDS: G and S, n_u x n_u doubles each.  Gauss-Jordan with partial
+// pivoting, rows never moved or scaled on the way (the pivot of step k is the largest entry of column k among the rows not
+// used yet; a used row is left with its pivot as the only entry of its column): four barriers per step -- the first build had
+// eight, and its 123 us for n_u = 36 were barriers, not arithmetic.  NT = 64 (n_u <= 48): one wavefront, no block barrier at all.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_link_cap(LinkArgs a) {
     extern __shared__ __attribute__((aligned(16))) double link_lds[];
-    __shared__ int piv_row;
-    __shared__ double piv_val;
+    __shared__ int piv_of[kLinkMaxU];      // step k -> its pivot row
+    __shared__ char used[kLinkMaxU];
     __shared__ double fcol[kLinkMaxU];
-    __shared__ double wv[2];
-    __shared__ int wi[2];
-    static_assert(kLinkMaxU <= 128, "the pivot search uses two wavefronts");
+    __shared__ double wv[4];
+    __shared__ int wi[4];
+    __shared__ int bad;
+    static_assert(kLinkMaxU <= 128, "the pivot search looks at 128 rows");
+    auto sync = [] {
+        if (NT == 64) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+        else __syncthreads();
+    };
     const LinkProb P = a.probs[blockIdx.x];
     const int n = P.n_u, t = threadIdx.x;
     double* G = link_lds;
     double* S = link_lds + n * n;
-    for (int e = t; e < n * n; e += kLinkThreads) {
+    for (int e = t; e < n * n; e += NT) {
         const int pos = a.pos[P.q_off + e];
         G[e] = pos >= 0 ? a.Hval[pos] : 0.0;
     }
-    __syncthreads();
-    for (int e = t; e < n * n; e += kLinkThreads) {
+    for (int i = t; i < n; i += NT) used[i] = 0;
+    if (t == 0) bad = 0;
+    sync();
+    for (int e = t; e < n * n; e += NT) {
         const int ra = e / n, cb = e - ra * n;
         // S[ra][cb] = delta + sum_c G[ra][c] Z_cb[u_c],  Z_cb = column of unknown cb: round(cb)'s vector on cb's chain only
         const int sup_b = a.usuper[P.u_begin + cb];
@@ -296,13 +307,16 @@ __global__ __launch_bounds__(kLinkThreads) void k_link_cap(LinkArgs a) {
         }
         S[e] = acc;
     }
-    __syncthreads();
-    bool singular = false;
+    sync();
     for (int k = 0; k < n; ++k) {
-        // pivot: the largest |S[i][k]|, i >= k -- by the first two wavefronts (n <= 128), ties to the smallest row
-        if (t < 128) {
-            double v = (t >= k && t < n) ? fabs(S[t * n + k]) : -1.0;
-            int idx = t;
+        // pivot: the largest |S[i][k]| among the rows not used yet (ties: the smallest row)
+        {
+            double v = -1.0;
+            int idx = 0x7fffffff;
+            for (int i = t; i < n; i += NT) {
+                const double x = used[i] ? -1.0 : fabs(S[i * n + k]);
+                if (x > v || (x == v && i < idx)) { v = x; idx = i; }
+            }
 #pragma unroll
             for (int off = 32; off >= 1; off >>= 1) {
                 const double ov = __shfl_down(v, off);
@@ -311,47 +325,39 @@ __global__ __launch_bounds__(kLinkThreads) void k_link_cap(LinkArgs a) {
             }
             if ((t & 63) == 0) { wv[t >> 6] = v; wi[t >> 6] = idx; }
         }
-        __syncthreads();
+        sync();
         if (t == 0) {
-            const bool second = wv[1] > wv[0];
-            piv_row = second ? wi[1] : wi[0]; piv_val = second ? wv[1] : wv[0];
+            double v = wv[0];
+            int idx = wi[0];
+            for (int w = 1; w < NT / 64; ++w)
+                if (wv[w] > v || (wv[w] == v && wi[w] < idx)) { v = wv[w]; idx = wi[w]; }
+            if (!(v > 1e-300)) bad = 1;
+            piv_of[k] = idx; used[idx] = 1;
         }
-        __syncthreads();
-        if (!(piv_val > 1e-300)) { singular = true; break; }  // (uniform)
-        const int pr = piv_row;
-        if (pr != k) {
-            for (int c = t; c < 2 * n; c += kLinkThreads) {
-                double* M = c < n ? S : G;
-                const int cc = c < n ? c : c - n;
-                const double x = M[k * n + cc]; M[k * n + cc] = M[pr * n + cc]; M[pr * n + cc] = x;
-            }
-            __syncthreads();
-        }
-        const double inv = 1.0 / S[k * n + k];
-        __syncthreads();
-        for (int c = t; c < 2 * n; c += kLinkThreads) {
-            double* M = c < n ? S : G;
-            const int cc = c < n ? c : c - n;
-            M[k * n + cc] *= inv;
-        }
-        __syncthreads();
-        // every other row: row_i -= S[i][k] * row_k, all rows at once (column k's factors are set aside first: the update
-        // overwrites them; row k itself stays)
-        for (int i = t; i < n; i += kLinkThreads) fcol[i] = (i == k) ? 0.0 : S[i * n + k];
-        __syncthreads();
-        for (int e = t; e < 2 * n * n; e += kLinkThreads) {
+        sync();
+        if (bad) break;  // (uniform)
+        const int pr = piv_of[k];
+        const double inv = 1.0 / S[pr * n + k];
+        for (int i = t; i < n; i += NT) fcol[i] = (i == pr) ? 0.0 : S[i * n + k] * inv;
+        sync();
+        // every other row: row_i -= (S[i][k] / pivot) * row_pr, all rows at once (the factors were set aside: the update
+        // overwrites column k; the pivot row stays as it is)
+        for (int e = t; e < 2 * n * n; e += NT) {
             const int i = e / (2 * n), c = e - i * 2 * n;
             double* M = c < n ? S : G;
             const int cc = c < n ? c : c - n;
             const double f = fcol[i];
-            if (f != 0.0) M[i * n + cc] -= f * M[k * n + cc];
+            if (f != 0.0) M[i * n + cc] -= f * M[pr * n + cc];
         }
-        __syncthreads();
+        sync();
     }
-    __syncthreads();
-    for (int e = t; e < n * n; e += kLinkThreads) {
-        const int ra = e / n, cb = e - ra * n;
-        a.Qt[P.q_off + cb * n + ra] = singular ? 0.0 : G[e];
+    const bool singular = bad != 0;
+    // row piv_of[k] now holds d_k e_k' in S: unknown k's row of Q is that row of G over d_k
+    for (int e = t; e < n * n; e += NT) {
+        const int k = e / n, cb = e - k * n;
+        double q = 0.0;
+        if (!singular) { const int pr = piv_of[k]; q = G[pr * n + cb] / S[pr * n + k]; }
+        a.Qt[P.q_off + cb * n + k] = q;
     }
     if (t == 0) a.status[blockIdx.x] = singular ? 1 : 0;
 }
