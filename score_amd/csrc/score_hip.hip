@@ -71,13 +71,24 @@ struct HostWaitStats {
 inline HostWaitStats& wait_stats() { static HostWaitStats s; return s; }
 constexpr long kEconomySleepNs = 25000;
 constexpr int kEconomyDepth = 6;
-inline bool several_ranks_here() {
-    static const bool v = [] { const char* e = std::getenv("LOCAL_WORLD_SIZE"); return e && std::atoi(e) > 1; }();
+// Policy (SCORE_WAIT_POLICY = auto | spin | economy; default auto): economy when the waiting drivers would take more than half
+// of the CPUs this rank may use (host_threads(): affinity, cgroup quota, LOCAL_WORLD_SIZE) -- measured on one MI355X box with 16
+// CPUs granted, 64 fresh graphs per sweep on 4 driver threads: spinning 2 232-2 267 problems/s at 2.3-2.5 ms of CPU per problem,
+// economy 2 073-2 098 at 1.36-1.53 (profiles/r06_economy_ab.txt): a lone rank with idle CPUs keeps the 7 %, eight ranks on those 16
+// CPUs (two each) cannot afford 4 spinning drivers per rank and sleep.
+inline int wait_policy() {  // 0 auto, 1 spin, 2 economy
+    static const int v = [] {
+        const char* e = std::getenv("SCORE_WAIT_POLICY");
+        if (!e) return 0;
+        const std::string s(e);
+        return s == "spin" ? 1 : s == "economy" ? 2 : 0;
+    }();
     return v;
 }
 inline bool economy_waits() {
-    static const bool always_spin = trace_on("spin");  // (SCORE_TRACE=spin: the spinning waits everywhere -- the A/B of this policy)
-    return !always_spin && (wait_stats().active_solves.load(std::memory_order_relaxed) >= 2 || several_ranks_here());
+    const int pol = wait_policy();
+    if (pol) return pol == 2;
+    return 2 * wait_stats().active_solves.load(std::memory_order_relaxed) > host_threads();
 }
 inline void economy_sleep() {
     static thread_local bool slack_set = false;

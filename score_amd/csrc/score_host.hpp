@@ -54,8 +54,7 @@ constexpr int kMaxBs = 4;
 // Diagnostics on stderr / stdout, ONE switch: SCORE_TRACE=<comma-separated list> of
 //   cache (every raw hipMalloc / hipHostMalloc of the block cache), host (queueing and wait times of a handle, printed when it
 //   goes), stamps (per-workgroup timeline of score_time_iteration), band (phases of the band-layout builder), assemble (phases
-//   of the host assembler), headform (which check of the QCQP rewrite declined a program), spin (host threads keep spinning on
-//   the device's result words even when several solves run at once: the A/B of the economy waits).  Nothing here changes a result.
+//   of the host assembler), headform (which check of the QCQP rewrite declined a program).  Nothing here changes a result.
 inline bool trace_on(const char* what) {
     static const std::string list = [] { const char* e = std::getenv("SCORE_TRACE"); return std::string(e ? e : ""); }();
     if (list.empty()) return false;
@@ -63,7 +62,7 @@ inline bool trace_on(const char* what) {
     size_t at = 0;
     while (at <= list.size()) {
         const size_t end = std::min(list.find(',', at), list.size());
-        if (list.compare(at, end - at, w) == 0 || (list.compare(at, end - at, "all") == 0 && w != "spin")) return true;
+        if (list.compare(at, end - at, w) == 0 || list.compare(at, end - at, "all") == 0) return true;
         at = end + 1;
     }
     return false;

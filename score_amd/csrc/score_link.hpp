@@ -342,12 +342,17 @@ __global__ __launch_bounds__(NT) void k_link_cap(LinkArgs a) {
         sync();
         // every other row: row_i -= (S[i][k] / pivot) * row_pr, all rows at once (the factors were set aside: the update
         // overwrites column k; the pivot row stays as it is)
-        for (int e = t; e < 2 * n * n; e += NT) {
-            const int i = e / (2 * n), c = e - i * 2 * n;
+        // (a lane owns columns of [S | G] and walks down the rows: consecutive lanes touch consecutive words, the factor is a
+        //  broadcast, and there is no index division in the loop -- the first single-wavefront build spent 280 us on those)
+        for (int c = t; c < 2 * n; c += NT) {
             double* M = c < n ? S : G;
             const int cc = c < n ? c : c - n;
-            const double f = fcol[i];
-            if (f != 0.0) M[i * n + cc] -= f * M[pr * n + cc];
+            const double pv = M[pr * n + cc];
+            if (pv != 0.0)
+                for (int i = 0; i < n; ++i) {
+                    const double f = fcol[i];
+                    if (f != 0.0) M[i * n + cc] -= f * pv;
+                }
         }
         sync();
     }

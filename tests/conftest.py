@@ -91,7 +91,7 @@ SURVIVING_SWITCHES = [
     ("SCORE_NO_REPLICATION", "1"), ("SCORE_NO_SEGMENTS", "1"), ("SCORE_HOST_SETUP", "1"), ("SCORE_HOST_ASSEMBLE", "1"),
     ("SCORE_HOST_POLISH_BUILD", "1"), ("SCORE_NO_PREQUEUE", "1"), ("SCORE_QCQP_PLAIN", "1"), ("SCORE_NO_BAND", "1"),
     ("SCORE_NO_DEVICE_RUIZ", "1"), ("SCORE_NO_LONG_SPIN", "1"), ("SCORE_NO_LINKS", "1"), ("SCORE_HOST_THREADS", "2"),
-    ("SCORE_CACHE_MB", "0"), ("SCORE_TRACE", "all"),
+    ("SCORE_CACHE_MB", "0"), ("SCORE_TRACE", "all"), ("SCORE_WAIT_POLICY", "economy"),
 ]
 
 
