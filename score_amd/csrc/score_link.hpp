@@ -348,11 +348,22 @@ __global__ __launch_bounds__(NT) void k_link_cap(LinkArgs a) {
             double* M = c < n ? S : G;
             const int cc = c < n ? c : c - n;
             const double pv = M[pr * n + cc];
-            if (pv != 0.0)
-                for (int i = 0; i < n; ++i) {
-                    const double f = fcol[i];
-                    if (f != 0.0) M[i * n + cc] -= f * pv;
+            if (pv != 0.0) {
+                // (eight rows per trip, every read requested before the first write: a row at a time, the loop was a chain of
+                //  LDS round trips -- 3 us per step)
+                constexpr int kRows = 8;
+                for (int i0 = 0; i0 < n; i0 += kRows) {
+                    double mv[kRows], fv[kRows];
+#pragma unroll
+                    for (int q = 0; q < kRows; ++q) {
+                        const int i = min(i0 + q, n - 1);
+                        mv[q] = M[i * n + cc]; fv[q] = fcol[i];
+                    }
+#pragma unroll
+                    for (int q = 0; q < kRows; ++q)
+                        if (i0 + q < n) M[(i0 + q) * n + cc] = mv[q] - fv[q] * pv;  // (fcol[pr] = 0: the pivot row stays)
                 }
+            }
         }
         sync();
     }
