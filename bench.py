@@ -41,42 +41,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-MC_SEED0 = 4000        # Monte-Carlo trial t is make_manhattan(seed = 4000 + t)
-# committed profiler artefacts the roofline blocks refer to (regenerated by profiles/scripts/r06_profile.sh + r04_summarise.py)
-LOOP_TRACE = "profiles/r06_loop_only_kernel_stats.csv"
-PMC_FILE = "profiles/r06_pmc_fetch_write_per_kernel.json"
-# kernel names in those files (the headline problem runs row-replicated: two right-hand sides per stored row; K through
-# its band view); the Newton products run on the plain rows of H
-PMC_KERNELS = {"kp": "void score::k_spmv_band<1, 2, 4, true>(score::SpmvArgs)", "prec_step": "void score::k_prec_pre<3, 1, float, true>(score::PrecArgs)",
-               "h_kpb": "void score::k_spmv<3, 1, 8>(score::SpmvArgs)"}
-
-
-def pmc_traffic(kernel_key: str, section: str = "headline_loop"):
-    """HBM bytes per launch of a kernel from the committed PMC passes (profiles/scripts/r05_profile.sh: separate --pmc
-    FETCH_SIZE / WRITE_SIZE runs; sections: headline_loop = `bench.py --steps 1 --no-probes`, batch16_loop = the same with
-    --batch 16, newton_headline / newton_mc16 = default solves; FETCH_SIZE doubled: the gfx950 correction of
-    /opt/skills/guides/MI355X_MICROARCH.md -- exact for 16-byte lane loads, an upper bound for the 8- and 4-byte ones).
-    None when the file or the section is absent."""
-    if not section:
-        return None
-    try:
-        with open(os.path.join(ROOT, PMC_FILE)) as fh:
-            rec = json.load(fh)
-        return float(rec["sections"][section]["hbm_bytes_per_launch"][PMC_KERNELS[kernel_key]]["traffic_upper_bound"])
-    except (OSError, KeyError, ValueError):
-        return None
-
-
-def newton_probe(solver):
-    """In-solve dispatch durations of the Newton PCG's launches (score_debug_get "newton_probe": start / stop events bound
-    to the chain-kernel STEPs and H products of ONE default solve; launches queued beyond convergence are left out)."""
-    solver.debug_get("newton_probe_arm")
-    out = solver.solve()
-    p = solver.debug_get("newton_probe")
-    return out, {"h_launches": int(p[0]), "h_us": float(p[1]), "h_bytes": float(p[2]), "step_launches": int(p[3]), "step_us": float(p[4]),
-                 "step_factor_bytes": float(p[5]), "h_tiles": int(p[6]), "prec_items": int(p[7])}
-
+from bench_legs import (  # noqa: E402  (the legs: workloads, Monte-Carlo, CPU baselines, roofline helpers -- bench_legs.py)
+    HBM_PEAK_GBS, Dist, algorithmic_bytes, config5_leg, cpu_baseline, economy_leg, end_to_end, long_chain_leg, make_headline, mc_groups,
+    mc_models, newton_probe, pmc_traffic, roofline_block, roofline_newton, run_montecarlo_leg, solver_lib, survey_prec_bytes, three_d_leg,
+)
 
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
@@ -282,606 +250,6 @@ def launch_ranks(n: int) -> int:
     return rc
 
 
-class Dist:
-    """Process group (RCCL on the GPU box; gloo in the CPU test mode) or a single process."""
-
-    def __init__(self, args):
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.world = int(os.environ.get("WORLD_SIZE", "1"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        self.cpu = bool(args.test_cpu_twin)
-        self.on = self.world > 1 or args.force_dist
-        self.torch = None
-        if not self.cpu or self.on:
-            import torch
-
-            self.torch = torch
-        if self.on:
-            import torch.distributed as dist
-
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
-            if not self.cpu:
-                self.torch.cuda.set_device(self.local_rank)
-            if self.cpu:
-                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
-            else:  # bind the communicator to this rank's GPU (no guessing from the global rank)
-                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
-                                        device_id=self.torch.device(f"cuda:{self.local_rank}"))
-            self.dist = dist
-
-    @property
-    def device(self) -> int:
-        return 0 if self.cpu else self.local_rank
-
-    def barrier(self):
-        if self.on:
-            self.dist.barrier()
-        if not self.cpu:
-            self.torch.cuda.synchronize()
-
-    def reduce(self, dt: float, sums):
-        """max over ranks of dt, sum over ranks of `sums`."""
-        if not self.on:
-            return dt, list(sums)
-        t = self.torch.tensor([dt], dtype=self.torch.float64)
-        v = self.torch.tensor(list(sums), dtype=self.torch.float64)
-        if not self.cpu:
-            t, v = t.cuda(), v.cuda()
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        self.dist.all_reduce(v, op=self.dist.ReduceOp.SUM)
-        return float(t.item()), v.cpu().tolist()
-
-    def close(self):
-        if self.on:
-            self.dist.barrier()
-            self.dist.destroy_process_group()
-
-
-def solver_lib(args):
-    """None = the product's HIP library (ConicSolver fails loudly without it)."""
-    if not args.test_cpu_twin:
-        return None
-    import __graft_entry__ as g
-
-    return g.build_oracle()
-
-
-# ---------------------------------------------------------------------------------------------
-# workloads
-# ---------------------------------------------------------------------------------------------
-def make_headline(args, rank: int, batch: int):
-    from score_amd.manhattan import make_manhattan
-    from score_amd.native import assemble_native
-
-    lib = solver_lib(args)
-
-    def assemble(fg, relax):
-        return assemble_native(fg, relax, lib_path=lib)
-
-    return [assemble(make_manhattan(n_robots=args.robots, n_poses=args.poses, n_beacons=args.beacons,
-                                    seed=3000 + rank * batch + j), args.relaxation) for j in range(batch)]
-
-
-def mc_models(args, trials):
-    from score_amd.manhattan import make_manhattan
-    from score_amd.native import assemble_native
-
-    lib = solver_lib(args)
-
-    def assemble(fg, relax):
-        return assemble_native(fg, relax, lib_path=lib)
-
-    return [assemble(make_manhattan(n_robots=args.mc_robots, n_poses=args.mc_poses, n_beacons=args.mc_beacons,
-                                    seed=MC_SEED0 + t), "SOCP") for t in trials]
-
-
-def mc_groups(n_local: int, per_handle: int, threads: int):
-    """Lock-step group sizes of one rank: at most `per_handle` trials per handle, and up to `threads`
-    handles of at least four trials each when there are enough trials (independent handles overlap on
-    the GPU; measured, profiles/scripts/r02_mc_small.py: 8 trials as [4, 4], 16 as [4] * 4, 32 as [8] * 4)."""
-    if n_local == 0:
-        return []
-    n_handles = max(-(-n_local // max(1, per_handle)), min(max(1, threads), max(1, n_local // 4)))
-    base, extra = divmod(n_local, n_handles)
-    return [base + (1 if i < extra else 0) for i in range(n_handles)]
-
-
-class MonteCarlo:
-    """BASELINE configs[4] on this rank: its trials in lock-step handles (one HIP stream each),
-    solved from a pool of host threads with the product's default solver."""
-
-    def __init__(self, args, trials, device, lib_path):
-        from score_amd.solver import ConicSolver
-
-        self.trials = list(trials)
-        self.models = mc_models(args, self.trials)
-        # driver threads of this rank: its share of what the host grants (N ranks x --mc-threads waiting threads on a host
-        # that grants 16 CPUs would compete with the ranks' own setup threads for the quota)
-        local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-        granted = cpu_quota() or float(len(os.sched_getaffinity(0)))
-        args.mc_threads = max(1, min(args.mc_threads, int(granted // local_world)))
-        sizes = mc_groups(len(self.trials), args.mc_batch, args.mc_threads)
-        self.solvers, self.slices, o = [], [], 0
-        for sz in sizes:
-            self.solvers.append(ConicSolver([m.qp for m in self.models[o : o + sz]],
-                                            dict(eps_abs=args.eps, eps_rel=args.eps, device=device), lib_path=lib_path))
-            self.slices.append((o, o + sz))
-            o += sz
-        self.threads = max(1, args.mc_threads)
-        self.group_sizes = sizes
-
-    def sweep(self, pool, record=None):
-        """One solve of every handle, one host thread each.  `record(first_slot, results)`, if given, is called by a
-        handle's own thread as soon as its solve returns (the result records are packed while the other handles are
-        still solving)."""
-        out = [None] * len(self.trials)
-
-        def one(k):
-            rs = self.solvers[k].solve()
-            if record is not None:
-                record(self.slices[k][0], rs)
-            return rs
-
-        for (a, b), rs in zip(self.slices, pool.map(one, range(len(self.solvers)))):
-            out[a:b] = rs
-        return out
-
-    def close(self):
-        for s in self.solvers:
-            s.close()
-
-
-def config5_leg(args, D: Dist, trials_total: int = 64, sweeps: int = 12):
-    """BASELINE configs[4] at THIS rank count, carried by every bench line: `trials_total` Monte-Carlo trials, trial t
-    on rank t mod N (strong scaling), product default solver in lock-step handles; after every sweep the ranks
-    exchange their result records [status, iters, newton_iters, pobj, n, x...] with ONE all_gather (RCCL over xGMI
-    on the GPU box, score_amd.distributed.all_gather_records; a single process takes the same code path without a
-    collective).  problems/s = trials * sweeps / slowest rank's time, gather included."""
-    from concurrent.futures import ThreadPoolExecutor
-
-    from score_amd.distributed import all_gather_records
-
-    mine = [t for t in range(trials_total) if t % D.world == D.rank]
-    mc = MonteCarlo(args, mine, D.device, solver_lib(args))
-    per_rank = -(-trials_total // D.world)
-    n_max = max([int(m.qp.n) for m in mc.models] + [1])
-    # (the generated-worlds leg draws new worlds every sweep: room for half as many ranges again as the measurement probability
-    #  gives on average -- more than twenty standard deviations)
-    n_max += int(0.5 * 0.10 * args.mc_poses * (args.mc_robots * args.mc_beacons + args.mc_robots * (args.mc_robots - 1) // 2)) + 64
-    if D.on:  # the record stride is the same on every rank
-        t = D.torch.tensor([float(n_max)], dtype=D.torch.float64)
-        if not D.cpu:
-            t = t.cuda()
-        D.dist.all_reduce(t, op=D.dist.ReduceOp.MAX)
-        n_max = int(t.item())
-    hdr = 5
-    buf = np.zeros((per_rank, hdr + n_max))
-
-    def pack(first_slot, results):
-        # (called by the handle's own host thread right after its solve: rows of different handles do not overlap.  The
-        #  buffer is zeroed once: a slot always carries the same trial, so its padding stays zero)
-        for k, r in enumerate(results):
-            slot = first_slot + k
-            buf[slot, :hdr] = (float(r.info["status"]), float(r.info["iters"]), float(r.info["newton_iters"]), float(r.info["pobj"]), float(r.x.size))
-            buf[slot, hdr : hdr + r.x.size] = r.x
-            buf[slot, hdr + r.x.size :] = 0.0  # (generated worlds: a slot's trial changes from sweep to sweep)
-
-    def exchange(results):
-        buf[len(results):, 0] = -1.0  # empty slot
-        return all_gather_records(buf, D.device)
-
-    with ThreadPoolExecutor(max_workers=mc.threads) as pool:
-        for _ in range(2):  # (untimed: the first sweeps of four fresh handles pay for graph capture and block-cache misses)
-            exchange(mc.sweep(pool, pack))
-        D.barrier()
-        t0 = time.perf_counter()
-        blocks = None
-        for _ in range(sweeps):
-            blocks = exchange(mc.sweep(pool, pack))
-        D.barrier()
-        dt = time.perf_counter() - t0
-    mc.close()
-    dt_max, _ = D.reduce(dt, [0.0])
-    status = np.concatenate([blk[:, 0] for blk in blocks])
-    fresh = fresh_graphs_leg(args, D, mine, trials_total, pack, exchange)
-    gen = None if args.test_cpu_twin else fresh_graphs_leg(args, D, mine, trials_total, pack, exchange, generated=True)
-    return {"fresh_graphs_problems_per_sec": fresh["problems_per_sec"], "fresh_graphs": fresh,
-            "generated_graphs_problems_per_sec": gen["problems_per_sec"] if gen else None, "generated_graphs": gen,
-            "problems_per_sec_is": "RE-SOLVES of handles created outside the timer (the solver alone); fresh_graphs_problems_per_sec is what a "
-                                   "Monte-Carlo study gets: every graph solved once, handle creation and model construction inside the timer",
-            "problems_per_sec": trials_total * sweeps / dt_max, "trials": trials_total, "n_gpus": D.world, "scaling": "strong",
-            "sweeps": sweeps, "ms_per_sweep": 1e3 * dt_max / sweeps, "trials_per_handle_rank0": mc.group_sizes,
-            "host_threads_per_gpu": mc.threads, "solved_last_sweep": int((status == 1.0).sum()),
-            "results_gathered": int((status >= 0.0).sum()),
-            "gather": ("one all_gather of %d x %d float64 per rank and sweep (%s)" % (per_rank, hdr + n_max, "RCCL over xGMI" if (D.on and not D.cpu) else ("gloo" if D.on else "single process: no collective"))),
-            "workload": f"BASELINE configs[4]: {args.mc_robots} robots x {args.mc_poses} poses, {args.mc_beacons} beacons, SOCP, "
-                        f"product default solver (ADMM warm-up + Newton polish in lock-step), trial t on rank t mod {D.world}"}
-
-
-def fresh_graphs_leg(args, D: Dist, mine, trials_total, pack, exchange, sweeps: int = 8, generated: bool = False):
-    """BASELINE configs[4] as a Monte-Carlo study runs it: every graph is solved ONCE.  The rank's trials are flat graph arrays
-    (score_graph: what a generator or a data loader hands over); per sweep every lock-step group is created by
-    score_create_from_graphs -- model construction (the reference's initialize_model, gurobi_utils.py:173-187), equilibration,
-    K, the Newton matrix: on the device -- solved once, its records packed, its handle destroyed, all inside the timer, one host
-    thread per group; the ranks exchange their records with one all_gather per sweep as in the re-solve leg.  Host CPU time per
-    problem is the process's user + system time over the timed sweeps divided by the rank's problems.
-    ``generated``: the worlds themselves are drawn inside the timer as well, by the library's generator on the device
-    (score_generate_manhattan, csrc/score_generate.hpp; every group draws its own worlds, new seeds every sweep) -- a study
-    from nothing but seeds."""
-    import resource
-    from concurrent.futures import ThreadPoolExecutor
-
-    from score_amd.manhattan import make_manhattan
-    from score_amd.native import graph_arrays
-    from score_amd.solver import ConicSolver
-
-    lib = solver_lib(args)
-    arrs = [] if generated else [graph_arrays(make_manhattan(n_robots=args.mc_robots, n_poses=args.mc_poses, n_beacons=args.mc_beacons, seed=MC_SEED0 + t)) for t in mine]
-    sweep_no = [0]
-
-    def draw(a, b):  # worlds a .. b-1 of this rank in the current sweep: seeds 10^6 * sweep + trial (a world depends on its seed alone)
-        from score_amd.generate import GeneratedBatch
-
-        gb = GeneratedBatch(b - a, seed=1000000 * sweep_no[0] + mine[a], n_robots=args.mc_robots, n_poses=args.mc_poses,
-                            n_beacons=args.mc_beacons, device=D.device, lib_path=lib)
-        return [gb.arrays(i) for i in range(b - a)]
-    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
-    granted = cpu_quota() or float(len(os.sched_getaffinity(0)))
-    args.fresh_threads = max(1, min(args.fresh_threads, int(granted // local_world)))
-    sizes = mc_groups(len(mine), args.fresh_batch, args.fresh_threads)
-    slices, o = [], 0
-    for sz in sizes:
-        slices.append((o, o + sz))
-        o += sz
-    st = dict(eps_abs=args.eps, eps_rel=args.eps, device=D.device)
-    solved = [0]
-
-    def one(k):
-        a, b = slices[k]
-        sv = ConicSolver.from_graphs(draw(a, b) if generated else arrs[a:b], 0, st, lib_path=lib)  # (generated: every group draws its own worlds)
-        try:
-            rs = sv.solve()
-        finally:
-            sv.close()
-        pack(a, rs)
-        return sum(1 for r in rs if r.solved)
-
-    def cpu_ms():
-        ru = resource.getrusage(resource.RUSAGE_SELF)
-        return 1e3 * (ru.ru_utime + ru.ru_stime)
-
-    threads = max(1, min(args.fresh_threads, len(slices)))
-    per_sweep = []
-    # (the interpreter's cyclic collector: this process holds ~0.5 M long-lived Python objects -- the headline graph's and the
-    #  trials' measurement objects -- and a full collection walks all of them: 100-200 ms in the middle of a 35 ms sweep, once
-    #  every few sweeps.  They are moved to the permanent generation for the timed region; the solver allocates no cycles.)
-    import gc
-    gc.collect(); gc.freeze()
-    with ThreadPoolExecutor(max_workers=threads) as pool:
-        for _ in range(2):  # untimed (block-cache misses, pool threads)
-            sweep_no[0] += 1
-            exchange([None] * sum(pool.map(one, range(len(slices)))))
-        D.barrier()
-        from score_amd.solver import host_counters
-
-        w0 = host_counters(lib)
-        c0, t0 = cpu_ms(), time.perf_counter()
-        for _ in range(sweeps):
-            ts = time.perf_counter()
-            sweep_no[0] += 1
-            solved[0] = sum(pool.map(one, range(len(slices))))
-            exchange([None] * len(mine))
-            per_sweep.append(1e3 * (time.perf_counter() - ts))
-        D.barrier()
-        dt, cpu = time.perf_counter() - t0, cpu_ms() - c0
-        w1 = host_counters(lib)
-    gc.unfreeze()
-    per = max(1, sweeps * max(1, len(mine)))
-    spin = (w1["spin_ms"] - w0["spin_ms"]) / per    # CPU the library's threads burnt spinning on the device's result words
-    asleep = (w1["sleep_ms"] - w0["sleep_ms"]) / per  # ... and what they slept instead (no CPU)
-    dt_max, tot = D.reduce(dt, [float(solved[0]), cpu / per, spin, asleep])
-    return {"problems_per_sec": trials_total * sweeps / dt_max, "sweeps": sweeps, "ms_per_sweep": 1e3 * dt_max / sweeps,
-            "ms_per_sweep_rank0": per_sweep,
-            "solved_last_sweep": int(tot[0]), "host_cpu_ms_per_problem_mean_over_ranks": tot[1] / D.world,
-            # [work, spinning wait] of the CPU figure above, and the milliseconds per problem the driver threads slept (no CPU)
-            "host_cpu_ms_work_wait": [max(0.0, tot[1] - tot[2]) / D.world, tot[2] / D.world], "host_wait_asleep_ms_per_problem": tot[3] / D.world,
-            "trials_per_handle_rank0": sizes, "host_threads_per_gpu": threads,
-            "includes": ("score_generate_manhattan (the worlds drawn on the device, new seeds every sweep), " if generated else "") +
-                        "score_create_from_graphs (model construction, equilibration, K, Newton matrix: on the device), one default solve, "
-                        "result records packed, handle destroyed, one all_gather per sweep"}
-
-
-def economy_leg(args):
-    """The fresh-graph sweep once more in a child process with SCORE_WAIT_POLICY=economy (the policy several ranks on one node
-    get by themselves: sleeping driver threads): problems/s and host CPU per problem, for the N = 8 budget --
-    16 CPUs / this figure is what the node's host can feed.  (The policy is read once per process: hence the child.)"""
-    import re
-
-    try:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "profiles", "scripts", "r06_host_cpu.py"), "10"], capture_output=True, text=True, timeout=300,
-                             env=dict(os.environ, SCORE_WAIT_POLICY="economy"), cwd=ROOT)
-        m1 = re.search(r"([0-9.]+) ms per sweep, ([0-9.]+) problems/s", out.stdout)
-        m2 = re.search(r"host CPU ([0-9.]+) ms per problem", out.stdout)
-        return {"problems_per_sec": float(m1.group(2)), "ms_per_sweep": float(m1.group(1)), "host_cpu_ms_per_problem": float(m2.group(1)),
-                "what": "profiles/scripts/r06_host_cpu.py 10 under SCORE_WAIT_POLICY=economy: 64 fresh graphs per sweep, 4 handles of 16 on 4 host threads"}
-    except Exception as exc:  # noqa: BLE001 - an optional leg must not cost the contract line
-        return {"error": repr(exc)[:200]}
-
-
-def run_montecarlo(args, D: Dist):
-    from concurrent.futures import ThreadPoolExecutor
-
-    trials_total = args.montecarlo or 64
-    mine = [t for t in range(trials_total) if t % D.world == D.rank]
-    mc = MonteCarlo(args, mine, D.device, solver_lib(args))
-    with ThreadPoolExecutor(max_workers=mc.threads) as pool:
-        for _ in range(args.warmup):
-            mc.sweep(pool)
-        D.barrier()
-        t0 = time.perf_counter()
-        last = []
-        for _ in range(args.steps):
-            last = mc.sweep(pool)
-        D.barrier()
-        dt = time.perf_counter() - t0
-    sums = [float(len(mine) * args.steps), float(sum(1 for r in last if r.solved)),
-            float(sum(r.info["iters"] for r in last)), float(sum(r.info["newton_iters"] for r in last)),
-            float(sum(r.info["newton_cg_iters"] for r in last))]
-    dt_max, tot = D.reduce(dt, sums)
-    mc.close()
-    weak = None
-    if not args.test_cpu_twin and not args.no_probes:
-        weak = weak_scaling_iters(args, D)  # every rank its own headline problem, ADMM loop alone
-    if D.rank == 0:
-        rec = {
-            "metric": "problems_per_sec", "value": tot[0] / dt_max, "unit": "problems/s", "n_gpus": D.world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt_max / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[4]: {trials_total} Monte-Carlo trials, manhattan RA-SLAM "
-                                   f"{args.mc_robots} robots x {args.mc_poses} poses, {args.mc_beacons} beacons, SOCP; "
-                                   f"product default solver (ADMM warm-up + semismooth-Newton polish, eps {args.eps:g}); "
-                                   f"trial i on rank i mod {D.world}; lock-step handles of {mc.group_sizes} trials on rank 0, "
-                                   f"{mc.threads} host threads per GPU",
-                       "eps": args.eps, "parallelism": f"trials sharded x{D.world}, no data-path collective"},
-            "problems_total_per_step": trials_total, "problems_solved_last_sweep": int(tot[1]),
-            "admm_iters_last_sweep": int(tot[2]), "newton_iters_last_sweep": int(tot[3]),
-            "newton_pcg_iters_last_sweep": int(tot[4]),
-            "roofline": None, "cpu_baseline": None,
-            "note": "roofline and cpu_baseline are measured by the single-GPU headline line (python bench.py)",
-        }
-        if weak is not None:
-            rec["weak_scaling_socp_iters_per_sec"] = weak
-        if args.test_cpu_twin:
-            rec["test_mode"] = "gloo + oracle CPU twin: launcher test, NOT a measurement"
-        emit(args, rec)
-    D.close()
-
-
-def weak_scaling_iters(args, D: Dist):
-    """SOCP iterations/s with every rank solving its own headline problem (ADMM loop alone)."""
-    from score_amd.solver import ConicSolver
-
-    models = make_headline(args, D.rank, 1)
-    solver = ConicSolver([m.qp for m in models], dict(eps_abs=args.eps, eps_rel=args.eps, device=D.device, polish=0))
-    solver.solve()
-    D.barrier()
-    t0 = time.perf_counter()
-    iters = 0
-    for _ in range(3):
-        iters += sum(s.info["iters"] for s in solver.solve())
-    D.barrier()
-    dt = time.perf_counter() - t0
-    solver.close()
-    dt_max, tot = D.reduce(dt, [float(iters)])
-    return {"value": tot[0] / dt_max, "unit": "iters/s", "scaling": "weak",
-            "workload": f"{args.robots} robots x {args.poses} poses per rank, 3 cold-start solves, polish off"}
-
-
-# ---------------------------------------------------------------------------------------------
-# CPU baselines (rank 0, N = 1 only).  The oracle is the thing timed HERE and only here.
-# ---------------------------------------------------------------------------------------------
-def _twin_time_to_solution(lib, qp, eps, threads, omp, budget):
-    """Seconds of one cold-start ADMM solve by the CPU twin with `threads` OpenMP threads; if the
-    budget runs out first: the measured iterations/s extrapolated to the iteration count."""
-    from score_amd.solver import ConicSolver
-
-    if omp is not None:
-        omp.omp_set_num_threads(int(threads))
-    sol = ConicSolver([qp], dict(eps_abs=eps, eps_rel=eps, polish=0), lib_path=lib)
-    sol.reset()
-    t0 = time.perf_counter()
-    it, out = 0, None
-    while True:
-        out = sol.steps(25)[0]
-        it += 25
-        dt = time.perf_counter() - t0
-        if out.info["status"] == 1 or dt > budget or it >= 20000:
-            break
-    sol.close()
-    return {"seconds": dt, "iters": it, "iters_per_sec": it / dt, "solved": out.info["status"] == 1,
-            "pobj": out.info["pobj"], "threads": int(threads)}
-
-
-def cpu_quota():
-    """CPUs' worth of time the container may use per period (cgroup cpu.max), or None when unlimited: the MI355X
-    boxes show 256 CPUs and grant 16, so a 32-thread team is not 32 cores."""
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
-        return None if quota == "max" else float(quota) / float(period)
-    except (OSError, ValueError):
-        return None
-
-
-def cpu_baseline(args, models, gpu_iters_per_solve=None, small_qp=None):
-    """(C1) SciPy direct-KKT ADMM, 1 thread -- the stand-in for north_star's
-    "CVXPY -> SCS" path; (C2) the oracle's C++ twin of the GPU algorithm at 1 thread and at its
-    best OpenMP team.  Each entry: seconds to eps on the SAME problem instance, or -- when its time
-    budget runs out -- the bounded sample and the extrapolation, stated as such."""
-    import ctypes
-
-    import __graft_entry__ as g
-    from oracle import scipy_admm
-    from score_amd.solver import ConicSolver
-
-    lib = g.build_oracle()
-    qp = models[0].qp
-    if small_qp is None:
-        small_qp = mc_models(args, [0])[0].qp
-    cores = os.cpu_count() or 1
-    # the CPUs this process may actually use: affinity and the cgroup quota (the MI355X boxes show 256 and grant 16) -- a team
-    # beyond that is throttled for the rest of every scheduling period, which is where round 3's 2x scatter came from
-    granted = len(os.sched_getaffinity(0))
-    if cpu_quota():
-        granted = max(1, min(granted, int(cpu_quota())))
-    try:
-        omp = ctypes.CDLL("libgomp.so.1")
-    except OSError:
-        omp = None
-    # --- C2: calibrate the OpenMP team on 25-iteration blocks (this sparse, memory-bound iteration
-    #     stops scaling long before a big host runs out of cores)
-    sol = ConicSolver([qp], dict(eps_abs=args.eps, eps_rel=args.eps, polish=0), lib_path=lib)
-    timed = []
-    for nt in sorted({1, 2, 4, 8, 12, 16, granted}):
-        if nt > granted or (omp is None and nt != granted):
-            continue
-        if omp is not None:
-            omp.omp_set_num_threads(nt)
-        sol.reset()
-        sol.steps(25)
-        dts = []
-        for _ in range(3):  # (a busy host makes single blocks noisy: best of three)
-            t0 = time.perf_counter()
-            sol.steps(25)
-            dts.append(time.perf_counter() - t0)
-        timed.append((min(dts), nt))
-    sol.close()
-    timed.sort()
-    best = (timed[0][1], timed[0][0])
-    # three bounded runs at the best team: the MEDIAN rate is the stated baseline, minimum and maximum travel with it
-    runs = [_twin_time_to_solution(lib, qp, args.eps, best[0], omp, args.cpu_seconds / 2) for _ in range(3)]
-    runs.sort(key=lambda r_: r_["iters_per_sec"])
-    c2_best = dict(runs[1], rate_min=runs[0]["iters_per_sec"], rate_max=runs[2]["iters_per_sec"])
-    c2_one = _twin_time_to_solution(lib, qp, args.eps, 1, omp, args.cpu_seconds) if best[0] != 1 else dict(c2_best)
-    # --- C1: SciPy / SuperLU direct-KKT ADMM, 1 thread (SuperLU is serial).  On BASELINE configs[2]
-    #     (4 robots x 1000 poses, trial 0 of the Monte-Carlo set): on the 20-robot problem the sparse LU
-    #     of K alone takes longer than this leg's whole budget (measured: > 50 s), which is the point
-    #     of an indirect solver -- and not a useful number.
-    r = scipy_admm.solve(small_qp, eps=args.eps, time_limit=args.cpu_seconds)
-    c1 = {"seconds": r["seconds"], "iters": r["iters"], "iters_per_sec": r["iters"] / r["seconds"], "solved": bool(r["solved"]),
-          "pobj": r.get("pobj"), "factorizations": r["factorizations"], "threads": 1}
-    c2_small = _twin_time_to_solution(lib, small_qp, args.eps, 1, omp, args.cpu_seconds)
-    if omp is not None:
-        omp.omp_set_num_threads(best[0])
-
-    def to_solution(e):
-        """seconds to eps: measured when the run finished, else extrapolated with the GPU's ADMM iteration count"""
-        if e["solved"]:
-            return e["seconds"], "measured"
-        if gpu_iters_per_solve:
-            return gpu_iters_per_solve / e["iters_per_sec"], f"extrapolated: {gpu_iters_per_solve:.0f} ADMM iterations at the sampled rate"
-        return None, "not finished within the budget"
-
-    entries = {}
-    big = f"{args.robots} robots x {args.poses} poses (the headline problem)"
-    small = f"BASELINE configs[2]: {args.mc_robots} robots x {args.mc_poses} poses, Monte-Carlo trial 0"
-    for name, e, kind, what, prob in (
-        ("C1_scipy_direct_kkt_admm_config2", c1, "port", "oracle/scipy_admm.py: equilibrated direct-KKT (SuperLU) ADMM, the OSQP / SCS-direct scheme", small),
-        ("C2_twin_1_thread_config2", c2_small, "port", "oracle/cpu_twin: the GPU algorithm (chain-preconditioned CG ADMM) as C++ loops", small),
-        ("C2_twin_1_thread", c2_one, "port", "oracle/cpu_twin: the GPU algorithm (chain-preconditioned CG ADMM) as C++ loops", big),
-        ("C2_twin_best_team", c2_best, "port", "oracle/cpu_twin, OpenMP team calibrated on this host", big),
-    ):
-        secs, how = to_solution(e)
-        entries[name] = {"kind": kind, "cores": e["threads"], "what": what, "problem": prob, "seconds_to_eps": secs, "seconds_to_eps_is": how,
-                         "sample": f"{e['iters']} cold-start ADMM iterations in {e['seconds']:.2f} s" + (", converged" if e["solved"] else ", budget reached"),
-                         "iters_per_sec": e["iters_per_sec"], "pobj": e["pobj"]}
-    return {
-        # contract fields: the apples-to-apples port at its best thread count, in the bench metric's unit
-        "value": c2_best["iters_per_sec"], "unit": "iters/s", "cores": int(best[0]), "host_cores": int(cores), "host_cpu_quota": cpu_quota(),
-        "cpus_granted": int(granted), "value_min_max_of_3_runs": [c2_best["rate_min"], c2_best["rate_max"]], "kind": "port",
-        "sample": "median of 3 runs: " + entries["C2_twin_best_team"]["sample"] + " of trial 0 of the same workload (oracle/cpu_twin, OpenMP team <= the CPUs granted)",
-        "seconds": c2_best["seconds"],
-        "entries": entries,
-        "note": "the reference's own CPU path (Gurobi barrier at score/solve_score.py:76; north_star's CVXPY->SCS) "
-                "cannot run here: kind is 'port' for every entry.  C1 (SciPy direct-KKT) runs on configs[2] only: on the headline "
-                "problem the sparse LU of K alone exceeds this leg's whole budget (> 50 s measured), so its seconds_to_eps there "
-                "could not even be extrapolated from a sample",
-    }
-
-
-# ---------------------------------------------------------------------------------------------
-# roofline helpers
-# ---------------------------------------------------------------------------------------------
-def chain_factor_doubles(N: int, bs: int, radix: int = 4):
-    """Doubles of chain-factor data one preconditioner application reads for a chain of N nodes:
-    level 0 run + separator blocks (its spikes are not read by k_prec_pre), every block of the
-    coarser levels (layout of score_host.hpp factor_chain_levels)."""
-    b2 = bs * bs
-    total, level = 0, 0
-    while True:
-        last = N <= radix - 1
-        nsep = 0 if last else N // radix
-        nruns = nsep + 1
-        P = N if last else radix - 1
-        total += 2 * b2 * P * nruns + 2 * b2 * nsep
-        if level > 0 and not last:
-            total += 2 * b2 * N
-        if last:
-            return total
-        N, level = nsep, level + 1
-
-
-def algorithmic_bytes(qp, kkt_bytes: float, rep: int = 1, nnz_at: int = 0):
-    """Algorithmic HBM bytes per launch of the six kernels of one ADMM iteration.  `rep` > 1: the
-    solver runs the problem row-replicated (K = I_rep (x) K_row + tail): A' and the chain factors exist once for
-    the rep replicas (nnz_at = entries of the stored A'), the vectors are whole."""
-    n, m, nnzA = int(qp.n), int(qp.m), int(qp.A.nnz)
-    bs = int(qp.block_size)
-    lens = np.diff(np.asarray(qp.chain_ptr))
-    if rep > 1:
-        lens = lens[: len(lens) // rep]  # the chains come replica by replica; one factor set per robot
-    # chain factors: streamed as 4-byte values by the LDS-resident chain kernel (score_settings.fac_fp32 = 1, the default)
-    fac = 4.0 * sum(chain_factor_doubles(int(L), bs) for L in lens if L > 0)
-    n_chain = int(lens.sum()) * bs * max(1, rep)
-    n_jac = n - n_chain
-    return {
-        "rhs": 12.0 * (nnz_at if rep > 1 else nnzA) + 8.0 * (9 * n + m),
-        "prec_init": fac + 24.0 * n_chain + 32.0 * n_jac,   # r in, z and p out (+ 1/diag for Jacobi columns)
-        "kp": float(kkt_bytes),
-        "prec_step": fac + 72.0 * n_chain + 80.0 * n_jac,   # + w, p, xt, kx in; r, xt, kx out
-        "kpb": float(kkt_bytes) + 24.0 * n,
-        "cone": 12.0 * nnzA + 56.0 * m,
-    }
-
-
-def survey_prec_bytes(qp):
-    """B_prec = 8 * 2 (d+1)^2 * N_p + 16 n -- one diagonal + one off-diagonal block per
-    pose, shared by the d decoupled rows, plus vector read/write (a plain block-tridiagonal factor)."""
-    bs = int(qp.block_size)
-    n_pose_rows = int(np.diff(np.asarray(qp.chain_ptr)).sum())  # chain nodes = poses x d rows
-    d = bs - 1
-    return 8.0 * 2 * bs * bs * (n_pose_rows / max(1, d)) + 16.0 * int(qp.n)
-
-
-def roofline_block(kernel, bytes_per_launch, us_dispatch, us_device, extra=None):
-    ach = bytes_per_launch / (us_dispatch * 1e-6) / 1e9
-    rec = {"bound": "hbm", "kernel": kernel, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-           "traffic": None, "traffic_profile": PMC_FILE,
-           "traffic_note": "bytes per launch from the committed PMC passes (2 x FETCH_SIZE + WRITE_SIZE: upper bound); null = workload differs from the profiled one", "bytes_per_launch": bytes_per_launch, "us_per_launch": us_dispatch,
-           "timing": "in the ADMM loop: begin-to-end of each dispatch from start/stop HIP events bound to the launch "
-                     "(hipExtLaunchKernel) on the solver's stream, averaged over the probe's iterations -- the interval "
-                     "rocprofv3 --kernel-trace reports; compare " + LOOP_TRACE,
-           "us_first_workgroup_in_to_last_out": us_device}
-    if us_device:
-        rec["frac_on_device_clock"] = bytes_per_launch / (us_device * 1e-6) / 1e9 / HBM_PEAK_GBS
-    if extra:
-        rec.update(extra)
-    return rec
-
-
-# ---------------------------------------------------------------------------------------------
-# headline
-# ---------------------------------------------------------------------------------------------
 def run_headline(args, D: Dist):
     from score_amd.solver import ConicSolver
 
@@ -1101,224 +469,6 @@ def run_headline(args, D: Dist):
     D.close()
 
 
-def roofline_newton(args, device, qp, probe, headline_shape):
-    """The rooflines of what the PRODUCT DEFAULT runs (Newton PCG: the product with the generalised Hessian H, plain rows,
-    and the chain STEP on the Newton factor set -- every chain its own factors), (a) in the headline default solve,
-    (b) in one lock-step handle of 16 BASELINE configs[4] trials.  Durations: start / stop events bound to the launches
-    inside one solve (newton_probe); traffic: the committed PMC passes of the same workloads."""
-    from score_amd.solver import ConicSolver
-
-    def blocks(pr, q, batch, sec):
-        lens = np.diff(np.asarray(q.chain_ptr))
-        n_chain = int(lens.sum()) * int(q.block_size)
-        n_jac = int(q.n) - n_chain
-        step_bytes = pr["step_factor_bytes"] + batch * (72.0 * n_chain + 80.0 * n_jac)
-        out = {}
-        if pr["h_launches"]:
-            out["h_product"] = roofline_block("k_spmv<KPB> on H (Newton PCG)", pr["h_bytes"], pr["h_us"], None,
-                                              {"launches_timed": pr["h_launches"], "traffic": pmc_traffic("h_kpb", sec),
-                                               "timing": "inside one default solve: start / stop HIP events bound to each launch of the Newton PCG that did work"})
-        if pr["step_launches"]:
-            out["chain_step"] = roofline_block("k_prec_pre<STEP> on the Newton factor set", step_bytes, pr["step_us"], None,
-                                               {"launches_timed": pr["step_launches"], "traffic": pmc_traffic("prec_step", sec),
-                                                "timing": "inside one default solve: start / stop HIP events bound to each launch of the Newton PCG that did work"})
-        return out
-
-    res = {"headline_default_solve": blocks(probe, qp, 1, "newton_headline" if headline_shape else None)}
-    mc = mc_models(args, range(16))
-    hs = ConicSolver([m.qp for m in mc], dict(eps_abs=args.eps, eps_rel=args.eps, device=device))
-    hs.solve()
-    outs, pr = newton_probe(hs)
-    hs.close()
-    res["config5_handle_of_16"] = dict(blocks(pr, mc[0].qp, 16, "newton_mc16"),
-                                       solved=int(sum(1 for o in outs if o.solved)), newton_iters_max=max(o.info["newton_iters"] for o in outs))
-    return res
-
-
-def three_d_leg(args, device, robots: int = 4, poses: int = 1000):
-    """The reference's model is dimension-generic (gurobi_utils.py:37-50, :53-60); BASELINE names no 3-D size, so this
-    leg takes configs[2]'s shape in 3-D: 4 robots x 1000 poses, 4 beacons (score_amd.manhattan.make_manhattan_3d) --
-    3 x 4 pose matrices, chains of 4 x 4 blocks, three replicas.  ADMM loop alone (iterations/s), the product default
-    solve, and the in-loop rooflines of the KKT SpMV and of the chain kernel (k_prec_pre<4, STEP, float>)."""
-    from score_amd.manhattan import make_manhattan_3d
-    from score_amd.native import assemble_native
-    from score_amd.solver import ConicSolver
-
-    m = assemble_native(make_manhattan_3d(n_robots=robots, n_poses=poses, n_beacons=args.beacons, seed=7000), "SOCP")
-    base = dict(eps_abs=args.eps, eps_rel=args.eps, device=device)
-    s = ConicSolver([m.qp], dict(base, polish=0))
-    s.solve()
-    t0 = time.perf_counter()
-    its = 0
-    for _ in range(3):
-        o = s.solve()[0]
-        its += o.info["iters"]
-    dt = time.perf_counter() - t0
-    admm_solved = bool(o.solved)
-    _, kb = s.time_kkt_apply(50)
-    rep = s.debug_get("rep")
-    alg = algorithmic_bytes(m.qp, kb, int(rep[0]), int(rep[2]))
-    dev_us, disp_us = s.time_iteration(warmup=30, iters=100, dispatch=True)
-    s.close()
-    p = ConicSolver([m.qp], dict(base))
-    p.solve()
-    t0 = time.perf_counter()
-    for _ in range(5):
-        po = p.solve()[0]
-    pdt = (time.perf_counter() - t0) / 5
-    p.close()
-    return {"workload": f"3-D manhattan RA-SLAM, {robots} robots x {poses} poses, {args.beacons} beacons, SOCP (n {int(m.qp.n)}, m {int(m.qp.m)})",
-            "socp_iters_per_sec": its / dt, "admm_iters_per_solve": its / 3, "admm_solved": admm_solved,
-            "product_default_ms": 1e3 * pdt, "product_default_solved": bool(po.solved), "newton_iters": po.info["newton_iters"],
-            "newton_pcg_iters": po.info["newton_cg_iters"], "row_replication": int(rep[0]),
-            "roofline_kkt_spmv": roofline_block("k_spmv<KP, 3 replicas>", kb, disp_us["kp"], dev_us["kp"]),
-            "roofline_chain_kernel": roofline_block("k_prec_pre<4, STEP, float> (4 x 4 blocks)", alg["prec_step"], disp_us["prec_step"], dev_us["prec_step"]),
-            "kernel_us_dispatch": disp_us}
-
-
-def long_chain_leg(args, device, robots: int = 20, poses: int = 5000):
-    """Chains beyond the LDS-resident chain kernel's 1023 nodes (trajectories of 5000 poses per robot; BASELINE names no such
-    size): the chains are cut into segments for that kernel and joined by a second level (csrc/score_join.hpp -- separators'
-    Schur system, spikes): the exact whole-chain preconditioner.  ADMM loop alone (iterations/s) and the product default solve."""
-    from score_amd.manhattan import make_manhattan
-    from score_amd.native import assemble_native
-    from score_amd.solver import ConicSolver
-
-    m = assemble_native(make_manhattan(n_robots=robots, n_poses=poses, n_beacons=args.beacons, seed=0), "SOCP")
-    base = dict(eps_abs=args.eps, eps_rel=args.eps, device=device)
-    s = ConicSolver([m.qp], dict(base, polish=0))
-    s.solve()
-    t0 = time.perf_counter()
-    o = s.solve()[0]
-    dt = time.perf_counter() - t0
-    dev_us, disp_us = s.time_iteration(warmup=10, iters=40, dispatch=True)
-    # the second level of the chain preconditioner (k_join_solve + k_join_apply, back to back): per chain entry the 2 * bs spike
-    # values, z read and written, r, and p (INIT) -- 8 bytes each
-    join_us = 1e3 * s.debug_time("join_init", 200)
-    chain_us = 1e3 * s.debug_time("prec_init_chain", 200)
-    chain_entries = robots * (poses - 1) * 3 * 2  # (20 chains x 2 replicas x 3 entries per node, separators included)
-    join_bytes = chain_entries * 8.0 * (2 * 3 + 4)
-    s.close()
-    p = ConicSolver([m.qp], dict(base))
-    p.solve()
-    each = []
-    import gc
-
-    gc.collect(); gc.freeze()  # (the other legs' long-lived objects: a full collection over them is 25 ms inside a 22 ms solve)
-    for _ in range(5):
-        t0 = time.perf_counter()
-        po = p.solve()[0]
-        each.append(1e3 * (time.perf_counter() - t0))
-    gc.unfreeze()
-    pdt = 1e-3 * sorted(each)[len(each) // 2]
-    p.close()
-    return {"workload": f"manhattan RA-SLAM, {robots} robots x {poses} poses, {args.beacons} beacons, SOCP (n {int(m.qp.n)}, m {int(m.qp.m)})",
-            "product_default_ms_each": each, "product_default_ms_is": "median of 5 calls",
-            "socp_iters_per_sec": o.info["iters"] / dt, "admm_iters_per_solve": o.info["iters"], "admm_solved": bool(o.solved),
-            "product_default_ms": 1e3 * pdt, "product_default_solved": bool(po.solved), "newton_iters": po.info["newton_iters"],
-            "newton_pcg_iters": po.info["newton_cg_iters"], "segments_per_chain": (poses - 1 + 1 + 1023) // 1024,
-            "second_level": {"kernels": "k_join_solve + k_join_apply after every application of the chain kernel", "us_back_to_back": join_us,
-                             "chain_kernel_init_us_back_to_back": chain_us, "bytes": join_bytes, "GB/s": join_bytes / join_us * 1e-3,
-                             "frac_of_hbm_peak": join_bytes / join_us * 1e-3 / 8000.0},
-            "kernel_us_dispatch": disp_us}
-
-
-def end_to_end(args, device, fg=None):
-    """The callers either side of the path: FactorGraphData objects in, SolverResults out --
-    native model construction (score_assemble), score_create (host setup + uploads), the product default
-    solve, SO(d) rounding and result views, handle teardown.  (a) one headline graph through
-    solve_score(); (b) BASELINE configs[4], 64 trials through solve_score_batch() (lock-step groups of 8
-    on 8 host threads: construction and setup of one group overlap the solves of the others)."""
-    from score_amd.manhattan import make_manhattan
-    from score_amd.solve_score import solve_score, solve_score_batch
-
-    if fg is None:
-        fg = make_manhattan(n_robots=args.robots, n_poses=args.poses, n_beacons=args.beacons, seed=3000)
-    st = dict(device=device, eps_abs=args.eps, eps_rel=args.eps)
-    solve_score(fg, "SOCP", solver_settings=st)
-    parts = []
-    import gc
-
-    # (as in the Monte-Carlo legs: the bench process holds ~0.5 M long-lived Python objects of the other legs; a call reads 47 k
-    #  measurement objects and allocates as many names, which triggers collections that walk all of that ballast)
-    from score_amd.native import invalidate_graph_cache
-
-    gc.collect(); gc.freeze()
-    repeat = []
-    for first_call in (True, False):
-        for _ in range(5):
-            if first_call:  # a graph object the library has not seen: the pass over its measurement objects is part of the call
-                invalidate_graph_cache(fg)
-            t1 = time.perf_counter()
-            r = solve_score(fg, "SOCP", solver_settings=st)
-            (parts if first_call else repeat).append({"total_ms": 1e3 * (time.perf_counter() - t1), "score_create_ms": r.info["setup_ms"],
-                                                      "solve_ms": r.info["solve_ms"], "total_time_reported_ms": 1e3 * r.total_time})
-    gc.unfreeze()
-    # (median of five calls; every call is listed in headline_calls / headline_repeat_calls)
-    one = 1e-3 * sorted(p_["total_ms"] for p_ in parts)[len(parts) // 2]
-    again = 1e-3 * sorted(p_["total_ms"] for p_ in repeat)[len(repeat) // 2]
-    if os.environ.get("SCORE_BENCH_PROFILE"):  # where the Python side of one call goes (stderr)
-        import cProfile
-        import pstats
-
-        pr = cProfile.Profile()
-        pr.enable()
-        solve_score(fg, "SOCP", solver_settings=st)
-        pr.disable()
-        pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(25)
-    trials = [make_manhattan(n_robots=args.mc_robots, n_poses=args.mc_poses, n_beacons=args.mc_beacons, seed=MC_SEED0 + t)
-              for t in range(64)]
-    # (steady state, like every other leg: one untimed pass first -- the first pass of a process pays for the device
-    #  and pinned blocks of the concurrent handles, the thread teams and the heap growth)
-    # (the library's default grouping: lock-step groups of 16 on 4 host threads -- round 5, with model construction and setup on
-    #  the device: 2.7 ms of host CPU per graph against 4.0 with 8 groups of 8 on 8 threads, and the faster sweep)
-    e2e_workers = 4
-
-    def sweeps(graphs, first_pass=False):  # median of five timed passes after an untimed one
-        import gc
-
-        solve_score_batch(graphs, "SOCP", solver_settings=st, workers=e2e_workers)
-        gc.collect(); gc.freeze()  # (see fresh_graphs_leg: no full collection over the ~0.5 M graph objects inside a sweep)
-        ts = []
-        for _ in range(5):
-            if first_pass:
-                for g_ in graphs:
-                    invalidate_graph_cache(g_)
-            t0 = time.perf_counter()
-            out = solve_score_batch(graphs, "SOCP", solver_settings=st, workers=e2e_workers)
-            ts.append(time.perf_counter() - t0)
-        gc.unfreeze()
-        return sorted(ts)[len(ts) // 2], out, ts
-
-    # from flat arrays (native.ArrayGraph: what a generator or a data loader that never builds per-measurement Python objects
-    # hands over) -- the Monte-Carlo path; then the same from graph objects, whose per-measurement attribute reads hold the
-    # interpreter lock
-    from score_amd.native import ArrayGraph, graph_arrays
-
-    flat = [ArrayGraph(graph_arrays(fg_)) for fg_ in trials]
-    dta, ra, dtas = sweeps(flat)
-    dt1, rs, dts1 = sweeps(trials, first_pass=True)
-    dt, rs, dts = sweeps(trials)
-    return {"headline_solve_score_ms": 1e3 * one, "headline_solve_score_ms_best": min(p_["total_ms"] for p_ in parts),
-            "headline_solve_score_repeat_ms": 1e3 * again,
-            "solve_score_ms_is": "headline_solve_score_ms: a graph object the library has not seen (its measurement objects are read inside "
-                                 "the call); headline_solve_score_repeat_ms: the same object again (flat arrays kept on it, native.cached_graph_arrays)",
-            "score_create_ms_best": min(p_["score_create_ms"] for p_ in parts),
-            "headline_solved": bool(r.solved), "headline_calls": parts, "headline_repeat_calls": repeat,
-            "config4_end_to_end_problems_per_sec": len(trials) / dt, "config4_solved": int(sum(1 for x in rs if x.solved)),
-            "config4_end_to_end_first_pass_problems_per_sec": len(trials) / dt1,
-            "config4_problems_per_sec_is": "graph OBJECTS solved before (arrays kept on them); first_pass: objects the library has not seen",
-            "config4_end_to_end_from_arrays_problems_per_sec": len(flat) / dta, "config4_from_arrays_solved": int(sum(1 for x in ra if x.solved)),
-            "includes": "graph objects -> flat arrays (skipped in the from_arrays figure), score_create_from_graphs (model construction, "
-                        "equilibration, K, Newton matrix: on the device), default solve, score_read_estimates (rounded poses, landmarks, "
-                        "distances from the device), result views, teardown",
-            "score_create_ms_is": "score_info.setup_ms of score_create_from_graphs: model construction INCLUDED (round 4: score_create alone, "
-                                  "after a 4.3-5.2 ms host assembler)",
-            "config4_sweeps_ms": {"from_objects": [1e3 * t for t in dts], "from_objects_first_pass": [1e3 * t for t in dts1], "from_arrays": [1e3 * t for t in dtas]},
-            "statistic": "median of 5 calls (headline) / of 5 sweeps (config 4), after one untimed pass each",
-            "host_threads": e2e_workers}
-
-
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
@@ -1328,10 +478,14 @@ def main():
     if workload == "auto":  # the same primary metric at every N (a 1 -> 8 curve compares like with like)
         workload = "headline"
     if workload == "montecarlo":
-        run_montecarlo(args, D)
+        rec = run_montecarlo_leg(args, D)
+        if rec is not None:
+            emit(args, rec)
+        D.close()
     else:
         run_headline(args, D)
 
 
 if __name__ == "__main__":
     main()
+
