@@ -322,7 +322,8 @@ void score_assembled_free(score_assembled* a);
  * makes `count` worlds on the device -- trial t is the world of seed + t whatever the batch (counter-based Philox4x32-10) -- and
  * hands back their flat arrays: score_generated_graph fills a score_graph view (valid until score_generated_free) that
  * score_create_from_graphs / score_assemble / score_refine_create take like any other; score_generated_truth the ground
- * truth (poses: n_robots * n_poses x (x, y, theta); beacons: n_beacons x (x, y); either may be NULL).
+ * truth (2-D: poses n_robots * n_poses x (x, y, theta), beacons n_beacons x (x, y); 3-D: poses x (x, y, z, R row-major --
+ * 12 values), beacons x (x, y, z); either may be NULL).
  * ------------------------------------------------------------------------- */
 typedef struct score_manhattan_spec {
     int32_t  n_robots;      /* 1..64; robot 0's first pose is the pinned one (origin, identity heading) */
@@ -334,6 +335,10 @@ typedef struct score_manhattan_spec {
     double   sigma_theta;   /* odometry rotation noise                      */
     double   sigma_range;   /* range noise; measurements clamped at >= 0    */
     uint64_t seed;          /* world t of the call: seed + t                */
+    int32_t  dim;           /* 2 (0 = 2): the shipped fixture's worlds; 3: walks on the lattice of the cube [0, side]^3 with
+                               axis-aligned orientations (the model is dimension-generic, gurobi_utils.py:37-50; the reference
+                               ships no 3-D data: statistics carried over, csrc/score_generate.hpp)                         */
+    int32_t  reserved;
 } score_manhattan_spec;
 typedef struct score_generated score_generated;
 int  score_generate_manhattan(const score_manhattan_spec* spec, int32_t count, int32_t device, score_generated** out);
@@ -400,7 +405,7 @@ const char* score_backend(void);   /* "hip-gfx950" or "cpu-twin"             */
  * stale stride goes wrong from the second problem on.  Bump SCORE_ABI_VERSION whenever a struct changes;
  * loaders compare (score_amd.solver.load_library does).  History: 1 = rounds 1-2, 2 = score_problem
  * gained rep_d / rep_n, 3 = this function, 4 = score_assemble_batch, 5 = score_create_from_graphs.                                                        */
-#define SCORE_ABI_VERSION 6
+#define SCORE_ABI_VERSION 7
 int32_t score_abi_version(void);   /* SCORE_ABI_VERSION of the library's build, times 1000, plus sizeof(score_problem) */
 
 #ifdef __cplusplus

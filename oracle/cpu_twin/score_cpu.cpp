@@ -731,7 +731,8 @@ void score_assembled_free(score_assembled* a) { delete a; }
 int score_generate_manhattan(const score_manhattan_spec* spec, int32_t count, int32_t /*device*/, score_generated** out) {
     try {
         if (!spec || !out) throw std::runtime_error("null argument");
-        score::GenSpec S{spec->n_robots, spec->n_poses, spec->n_beacons, spec->side, spec->p_range, spec->sigma_t, spec->sigma_theta, spec->sigma_range, spec->seed};
+        score::GenSpec S{spec->n_robots, spec->n_poses, spec->n_beacons, spec->side, spec->p_range, spec->sigma_t, spec->sigma_theta, spec->sigma_range, spec->seed,
+                         spec->dim == 0 ? 2 : spec->dim};
         auto* g = new score_generated();
         try { score::generate_manhattan_host(S, count, g->B); } catch (...) { delete g; throw; }
         *out = g;

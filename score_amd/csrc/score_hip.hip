@@ -4694,15 +4694,17 @@ void generate_manhattan_device(const score::GenSpec& S, int count, int device, s
         ~Scope() { tl_arena = keep_a; tl_copy_stream = keep_s; }
     } scope(&arena, st);
     try {
-        DevBuf<int32_t> px, py, ph, bx, by, rel_base, rel_to, cnt, off, ra, rb;
+        DevBuf<int32_t> px, py, ph, pz, bx, by, bz, rel_base, rel_to, cnt, off, ra, rb;
         DevBuf<double> rel_t, rel_R, rel_kappa, rel_tau, dist, prec;
+        const size_t dd = (size_t)S.dim;
         px.alloc(c * R * T); py.alloc(c * R * T); ph.alloc(c * R * T); bx.alloc(c * nb); by.alloc(c * nb);
-        rel_base.alloc(c * E); rel_to.alloc(c * E); rel_t.alloc(2 * c * E); rel_R.alloc(4 * c * E); rel_kappa.alloc(c * E); rel_tau.alloc(c * E);
+        if (dd == 3) { pz.alloc(c * R * T); bz.alloc(c * nb); }
+        rel_base.alloc(c * E); rel_to.alloc(c * E); rel_t.alloc(dd * c * E); rel_R.alloc(dd * dd * c * E); rel_kappa.alloc(c * E); rel_tau.alloc(c * E);
         const size_t n_cnt = c * G * T;
         cnt.alloc(n_cnt + 1); off.alloc(n_cnt + 1);
         GenArgs a{};
         a.S = S; a.count = count;
-        a.px = px.d; a.py = py.d; a.ph = ph.d; a.bx = bx.d; a.by = by.d;
+        a.px = px.d; a.py = py.d; a.ph = ph.d; a.bx = bx.d; a.by = by.d; a.pz = pz.d; a.bz = bz.d;
         a.rel_base = rel_base.d; a.rel_to = rel_to.d; a.rel_t = rel_t.d; a.rel_R = rel_R.d; a.rel_kappa = rel_kappa.d; a.rel_tau = rel_tau.d;
         a.cnt = cnt.d; a.off = off.d;
         const size_t n_walk = std::max(c * R, c * nb);
@@ -4736,7 +4738,7 @@ void generate_manhattan_device(const score::GenSpec& S, int count, int device, s
             parts.push_back(Part{dst.data(), src.d, nbytes, tot_bytes});
             tot_bytes += (nbytes + 255) & ~(size_t)255;
         };
-        back(B.px, px); back(B.py, py); back(B.ph, ph); back(B.bx, bx); back(B.by, by);
+        back(B.px, px); back(B.py, py); back(B.ph, ph); back(B.bx, bx); back(B.by, by); back(B.pz, pz); back(B.bz, bz);
         back(B.rel_base, rel_base); back(B.rel_to, rel_to); back(B.rel_t, rel_t); back(B.rel_R, rel_R); back(B.rel_kappa, rel_kappa); back(B.rel_tau, rel_tau);
         back(B.ra, ra); back(B.rb, rb); back(B.dist, dist); back(B.prec, prec);
         // (a trial's range endpoints are trial-local already: pose r * T + t, landmark Np + b)
@@ -4769,7 +4771,8 @@ extern "C" {
 int score_generate_manhattan(const score_manhattan_spec* spec, int32_t count, int32_t device, score_generated** out) {
     try {
         if (!spec || !out) throw std::runtime_error("null argument");
-        score::GenSpec S{spec->n_robots, spec->n_poses, spec->n_beacons, spec->side, spec->p_range, spec->sigma_t, spec->sigma_theta, spec->sigma_range, spec->seed};
+        score::GenSpec S{spec->n_robots, spec->n_poses, spec->n_beacons, spec->side, spec->p_range, spec->sigma_t, spec->sigma_theta, spec->sigma_range, spec->seed,
+                         spec->dim == 0 ? 2 : spec->dim};
         auto* g = new score_generated();
         try { generate_manhattan_device(S, count, device, *g); } catch (...) { delete g; throw; }
         *out = g;
@@ -4804,7 +4807,8 @@ int score_create_from_generated(const score_generated* g, int32_t first, int32_t
         const bool resident = g->device >= 0 && st.device == g->device;
         if (resident) {  // the measurement arrays where the generator left them (world `first` onwards: the worlds follow each other)
             const size_t E = (size_t)g->B.edges(), eo = (size_t)first * E, ro = (size_t)g->B.rng_first[(size_t)first];
-            src.rel_base = g->d_rel_base + eo; src.rel_to = g->d_rel_to + eo; src.rel_t = g->d_rel_t + 2 * eo; src.rel_R = g->d_rel_R + 4 * eo;
+            const size_t dd = (size_t)g->B.S.dim;
+            src.rel_base = g->d_rel_base + eo; src.rel_to = g->d_rel_to + eo; src.rel_t = g->d_rel_t + dd * eo; src.rel_R = g->d_rel_R + dd * dd * eo;
             src.rel_kappa = g->d_rel_kappa + eo; src.rel_tau = g->d_rel_tau + eo;
             src.rng_a = g->d_ra + ro; src.rng_b = g->d_rb + ro; src.rng_dist = g->d_dist + ro; src.rng_prec = g->d_prec + ro;
         }

@@ -336,7 +336,7 @@ def solve_generated_sharded(
     gathered = all_gather_records(buf, int(settings["device"]))
     # (the shape of a world: the generator's own defaults, from its signature -- nothing restated here)
     gen_defaults = {k: v.default for k, v in inspect.signature(GeneratedBatch.__init__).parameters.items() if v.default is not inspect.Parameter.empty}
-    R, T, Nb = (int(spec.get(k, gen_defaults[k])) for k in ("n_robots", "n_poses", "n_beacons"))
+    R, T, Nb, d = (int(spec.get(k, gen_defaults[k])) for k in ("n_robots", "n_poses", "n_beacons", "dim"))
     poses = _PoseNames(robot_letters(R), T)
     lms = [f"L{k}" for k in range(Nb)]
     chains = [_PoseNames([ch], T) for ch in robot_letters(R)]
@@ -352,21 +352,21 @@ def solve_generated_sharded(
                 failed.append(i)
                 continue
             nv, nd, wd = int(rec[7]), int(rec[8]), int(rec[9])
-            k = 9
-            if nv != len(poses) * k + Nb * 2 + nd * wd:
+            k = (d + 1) * (d + 1)
+            if nv != len(poses) * k + Nb * d + nd * wd:
                 raise RuntimeError(f"solve_generated_sharded: world {i}: record of {nv} values does not match {R} robots x {T} poses, {Nb} beacons, {nd} ranges")
             v = rec[_HDR : _HDR + nv]
-            P = v[: len(poses) * k].reshape(len(poses), 3, 3).copy()
+            P = v[: len(poses) * k].reshape(len(poses), d + 1, d + 1).copy()
             off = len(poses) * k
-            L = v[off : off + Nb * 2].reshape(Nb, 2).copy()
-            off += Nb * 2
+            L = v[off : off + Nb * d].reshape(Nb, d).copy()
+            off += Nb * d
             D = v[off : off + nd * wd].reshape(nd, wd).copy()
             ends = rec[_HDR + nv : _HDR + nv + 2 * nd]
             keys = _RangeKeys(ends[:nd].astype(np.int32), ends[nd:].astype(np.int32), poses)
             info = dict(status=int(rec[0]), iters=int(rec[1]), cg_iters=int(rec[2]), pobj=float(rec[3]), res_pri=float(rec[4]),
                         res_dual=float(rec[5]), solve_ms=float(rec[6]), seed=int(seed) + i, rank=r)
             out[i] = compat.SolverResults(
-                variables=compat.VariableValues(2, compat.ArrayDict(poses, P), compat.ArrayDict(lms, L), compat.ArrayDict(keys, D) if nd else {}),
+                variables=compat.VariableValues(d, compat.ArrayDict(poses, P), compat.ArrayDict(lms, L), compat.ArrayDict(keys, D) if nd else {}),
                 total_time=info["solve_ms"] * 1e-3, solved=info["status"] == 1, pose_chain_names=chains, solver_cost=info["pobj"], info=info,
             )
     if failed or failure:

@@ -85,7 +85,7 @@ ABI_SYMBOLS = [
     "score_generate_manhattan", "score_generated_graph", "score_generated_truth", "score_generated_free", "score_create_from_generated",
 ]
 
-ABI_VERSION = 6  # SCORE_ABI_VERSION of include/score_hip.h this binding's structs follow
+ABI_VERSION = 7  # SCORE_ABI_VERSION of include/score_hip.h this binding's structs follow
 
 
 def load_library(path: Optional[str] = None) -> C.CDLL:

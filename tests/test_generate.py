@@ -151,7 +151,9 @@ def test_generated_worlds_solve_and_errors(twin_lib):
         GeneratedBatch(16, n_robots=64, n_poses=1000, n_beacons=4096, lib_path=twin_lib)
     with pytest.raises(IndexError):
         B.arrays(3)
-    assert C.sizeof(ManhattanSpec) == 56
+    assert C.sizeof(ManhattanSpec) == 64  # (ABI v7: + dim, reserved)
+    with pytest.raises(ValueError, match="dimension must be 2 or 3"):
+        GeneratedBatch(1, dim=4, lib_path=twin_lib)
     # score_create_from_generated: argument errors come back as errors, not crashes
     from score_amd.solver import ScoreSettings
 
@@ -171,12 +173,57 @@ def test_generated_worlds_solve_and_errors(twin_lib):
     lib.score_destroy(h)
 
 
+def test_3d_generator_against_the_independent_restatement(twin_lib):
+    """The generator draws 3-D worlds too (round 6; the reference's model is dimension-generic, gurobi_utils.py:37-50): walks on the
+    lattice of a cube with axis-aligned orientations, odometry with rotation-vector noise, ranges in space.  Against
+    oracle/generate_oracle.py::world3 (written from the description): every integer equal -- positions, orientations as
+    rotation matrices, beacons, endpoints, counts --, reals to 1e-12; every odometry rotation is a rotation; the worlds solve
+    (3 x 4 pose matrices, 4 x 4 chain blocks) and the estimate follows the truth; trial t is the same world in any batch."""
+    from oracle.generate_oracle import rot3, world3
+
+    spec = dict(n_robots=3, n_poses=50, n_beacons=4, side=6, p_range=0.3, sigma_t=0.02, sigma_theta=0.01, sigma_range=0.7)
+    B = GeneratedBatch(3, seed=987654321, lib_path=twin_lib, dim=3, **spec)
+    for t in range(3):
+        w = world3(987654321, t, **spec)
+        a = B.arrays(t)
+        poses, beacons = B.truth(t)
+        R, T = spec["n_robots"], spec["n_poses"]
+        assert a["dim"] == 3 and poses.shape == (R * T, 12) and beacons.shape == (4, 3)
+        assert np.array_equal(poses[:, :3], np.array([p for r in range(R) for p in w["pos"][r]], dtype=float))
+        assert np.array_equal(poses[:, 3:].reshape(-1, 3, 3), np.array([rot3(o) for r in range(R) for o in w["ori"][r]], dtype=float))
+        assert np.array_equal(beacons, np.array(w["beacons"], dtype=float))
+        assert np.array_equal(a["rel_base"], np.array([o[0] for o in w["odom"]], np.int32)) and np.array_equal(a["rel_to"], np.array([o[1] for o in w["odom"]], np.int32))
+        np.testing.assert_allclose(a["rel_t"], np.array([o[2] for o in w["odom"]]), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(a["rel_R"], np.array([o[3] for o in w["odom"]]), rtol=0, atol=1e-12)
+        np.testing.assert_allclose(np.einsum("nij,nkj->nik", a["rel_R"], a["rel_R"]), np.broadcast_to(np.eye(3), a["rel_R"].shape), atol=1e-12)
+        assert np.all(np.linalg.det(a["rel_R"]) > 0.999)
+        rg = w["ranges"]
+        assert len(rg) == len(a["rng_a"]) > 30
+        assert np.array_equal(a["rng_a"], np.array([x[0] for x in rg], np.int32)) and np.array_equal(a["rng_b"], np.array([x[1] for x in rg], np.int32))
+        np.testing.assert_allclose(a["rng_dist"], np.array([x[2] for x in rg]), rtol=0, atol=1e-12)
+        # the walk: unit steps along the body x axis, inside the cube; turns are quarter turns
+        P3 = poses[:, :3].reshape(R, T, 3)
+        Rw = poses[:, 3:].reshape(R, T, 3, 3)
+        assert P3.min() >= 0 and P3.max() <= spec["side"]
+        assert np.array_equal(P3[:, 1:] - P3[:, :-1], Rw[:, :-1, :, 0])
+    assert np.array_equal(poses[0], [0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1])  # robot A starts at the origin with the identity orientation (the pinned pose)
+    one = GeneratedBatch(1, seed=987654321 + 2, lib_path=twin_lib, dim=3, **spec)
+    assert np.array_equal(one.arrays(0)["rng_dist"], B.arrays(2)["rng_dist"]) and np.array_equal(one.truth(0)[0], B.truth(2)[0])
+    res = solve_score_batch(B.graphs(), "SOCP", lib_path=twin_lib)
+    assert all(r.solved for r in res)
+    err = B.trajectory_errors(1, res[1])
+    assert set(err) == {"A", "B", "C"} and err["A"]["translation_rmse"] < 1.0 and err["A"]["heading_max"] < 0.3
+    gt = B.truth_results(1)
+    assert gt.poses["A0"].shape == (4, 4) and B.trajectory_errors(1, gt)["C"]["translation_max"] == 0.0 and B.trajectory_errors(1, gt)["C"]["heading_max"] < 1e-7
+
+
 @pytest.mark.gpu
 def test_device_generator_equals_the_host_loops(hip_lib, twin_lib):
     """The kernels (one thread per robot walk / per (trial, group, timestep) of the ranges, a scan in between) against the host
     loops of the twin: every integer (positions, headings, beacons, endpoints, counts) bit for bit, every real to a few ulps of
     the math libraries (sin, cos, log, sqrt, atan2 of device and host); BASELINE configs[4]'s shape and an odd one."""
-    for spec in (dict(n_robots=4, n_poses=1000, n_beacons=4), dict(n_robots=7, n_poses=129, n_beacons=9, side=11, p_range=0.33, sigma_range=0.5)):
+    for spec in (dict(n_robots=4, n_poses=1000, n_beacons=4), dict(n_robots=7, n_poses=129, n_beacons=9, side=11, p_range=0.33, sigma_range=0.5),
+                 dict(n_robots=4, n_poses=600, n_beacons=4, side=12, dim=3), dict(n_robots=5, n_poses=77, n_beacons=7, side=5, p_range=0.4, dim=3)):
         dev = GeneratedBatch(5, seed=4000, lib_path=hip_lib, **spec)
         ref = GeneratedBatch(5, seed=4000, lib_path=twin_lib, **spec)
         for i in range(5):
@@ -186,6 +233,9 @@ def test_device_generator_equals_the_host_loops(hip_lib, twin_lib):
             for k in ("rel_t", "rel_R", "rel_kappa", "rel_tau", "rng_dist", "rng_prec"):
                 np.testing.assert_allclose(a[k], b[k], rtol=0, atol=1e-12, err_msg=f"{spec} {i} {k}")
             (pa, ba), (pb, bb) = dev.truth(i), ref.truth(i)
+            if spec.get("dim") == 3:
+                assert np.array_equal(pa, pb) and np.array_equal(ba, bb)  # (positions and integer rotation matrices)
+                continue
             assert np.array_equal(pa[:, :2], pb[:, :2]) and np.array_equal(ba, bb)
             np.testing.assert_allclose(pa[:, 2], pb[:, 2], atol=1e-15)
     # worlds in a row of one batch: the handle is built from the arrays the generator left ON THE DEVICE (score_create_from_generated);
@@ -212,6 +262,23 @@ def test_device_generator_equals_the_host_loops(hip_lib, twin_lib):
     assert all(r.solved and r.info["newton_iters"] > 0 for r in res)
     again = solve_score(graphs[3], "SOCP")
     assert again.info["pobj"] == pytest.approx(res[3].info["pobj"], rel=1e-9)
+    # 3-D worlds through the product (resident arrays, device assembler for 3 x 4 pose matrices, 4 x 4 chain blocks), certified
+    B3 = GeneratedBatch(4, seed=5100, n_robots=3, n_poses=300, n_beacons=4, side=10, p_range=0.2, dim=3, lib_path=hip_lib)
+    g3 = B3.graphs()
+    r3 = solve_score_batch(g3, "SOCP")
+    assert all(r.solved and r.info["newton_iters"] > 0 for r in r3)
+    err = B3.trajectory_errors(2, r3[2])
+    assert max(v["translation_rmse"] for v in err.values()) < 3.0
+    from oracle import score_oracle as so
+    from score_amd.native import assemble_native
+
+    qp = assemble_native(g3[0], "SOCP", arrays=B3.arrays(0)).qp
+    sv = ConicSolver([qp], {})
+    out = sv.solve()[0]
+    sv.close()
+    cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, out.x, out.y, out.s)
+    assert out.solved and cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4, cert
+    assert out.info["pobj"] == pytest.approx(r3[0].info["pobj"], rel=1e-6)
 
 
 @pytest.mark.gpu
