@@ -2151,8 +2151,8 @@ struct HipBackend {
         // (one launch applies the chain kernel to every round's right-hand side: a vector of n_tot per round)
         link_tmp_p.alloc((size_t)link_rounds * (size_t)h.n_tot); link_tmp_rz.alloc((size_t)link_rounds * (h.prec_work.size() + 4096));
         if (n_join_seps) link_zb.alloc((size_t)link_rounds * (size_t)h.bs * (size_t)n_join_seps);
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_link_cap<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLinkMaxU * kLinkMaxU * (int)sizeof(double)));
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_link_cap<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLinkMaxU * kLinkMaxU * (int)sizeof(double)));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_link_cap<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLinkMaxU * kLinkMaxU * (int)sizeof(double)));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_link_cap<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLinkMaxU * kLinkMaxU * (int)sizeof(double)));
         LinkArgs la = link_args();
         hipLaunchKernelGGL(k_link_positions, dim3(16), dim3(kLinkThreads), 0, stream, la, n_link_probs);
         hipLaunchKernelGGL(k_link_rhs, dim3((unsigned)((n_link_u + kLinkThreads - 1) / kLinkThreads)), dim3(kLinkThreads), 0, stream, la);
@@ -2193,8 +2193,8 @@ struct HipBackend {
         }
         link_suspend = false;
         // (up to 48 unknowns: one wavefront per problem, no block barriers; beyond: four wavefronts)
-        if (link_max_u <= 48) hipLaunchKernelGGL(k_link_cap<64>, dim3((unsigned)n_link_probs), dim3(64), (size_t)2 * link_max_u * link_max_u * sizeof(double), stream, la);
-        else hipLaunchKernelGGL(k_link_cap<256>, dim3((unsigned)n_link_probs), dim3(256), (size_t)2 * link_max_u * link_max_u * sizeof(double), stream, la);
+        if (link_max_u <= 48) hipLaunchKernelGGL(k_link_cap<true>, dim3((unsigned)n_link_probs), dim3(256), (size_t)2 * link_max_u * link_max_u * sizeof(double), stream, la);
+        else hipLaunchKernelGGL(k_link_cap<false>, dim3((unsigned)n_link_probs), dim3(256), (size_t)2 * link_max_u * link_max_u * sizeof(double), stream, la);
     }
     template <int BS, int MODE>
     void link_apply_bs(const PrecArgs& pa) {

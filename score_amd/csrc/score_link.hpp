@@ -266,48 +266,80 @@ __global__ __launch_bounds__(kLinkThreads) void k_link_rhs(LinkArgs a) {
     if (i < a.n_u_total) a.rhs[(size_t)a.uround[i] * a.n_tot + a.ucol[i]] = 1.0;
 }
 
-// Q = (I + G Z[U,:])^-1 G, one workgroup per problem; dynamic LDS: G and S, n_u x n_u doubles each.  Gauss-Jordan with partial
-// pivoting, rows never moved or scaled on the way (the pivot of step k is the largest entry of column k among the rows not
-// used yet; a used row is left with its pivot as the only entry of its column): four barriers per step -- the first build had
-// eight, and its 123 us for n_u = 36 were barriers, not arithmetic.  NT = 64 (n_u <= 48): one wavefront, no block barrier at all.
-template <int NT>
-__global__ __launch_bounds__(NT) void k_link_cap(LinkArgs a) {
+// Q = (I + G Z[U,:])^-1 G, one workgroup of 256 per problem; dynamic LDS: G and S, n_u x n_u doubles each.
+// Phase 1 (all four wavefronts): G from H's values; the nonzeros of every row of G listed (a row holds the unknowns of the
+// node's link partners: a handful); S = I + G Z[U,:] with one lane per entry and the entry's few columns of Z requested together
+// (the first builds walked all n_u columns with two dependent global loads per nonzero: 40-160 us of the kernel's 120-280).
+// Phase 2: Gauss-Jordan with partial pivoting, rows never moved or scaled on the way (the pivot of step k is the largest entry
+// of column k among the rows not used yet; a used row keeps its pivot as the only entry of its column), a lane owning columns of
+// [S | G] and walking down the rows eight at a time.  ONEWAVE (n_u <= 48): wavefronts 1-3 leave after phase 1 and phase 2 runs
+// on one wavefront with no block barrier at all; otherwise four wavefronts and four barriers per step.
+constexpr int kLinkRowNnz = 16;
+template <bool ONEWAVE>
+__global__ __launch_bounds__(256) void k_link_cap(LinkArgs a) {
+    constexpr int NT1 = 256, NT = ONEWAVE ? 64 : 256;
     extern __shared__ __attribute__((aligned(16))) double link_lds[];
     __shared__ int piv_of[kLinkMaxU];      // step k -> its pivot row
     __shared__ char used[kLinkMaxU];
     __shared__ double fcol[kLinkMaxU];
+    __shared__ int s_ucol[kLinkMaxU], s_round[kLinkMaxU], s_super[kLinkMaxU], s_cnt[kLinkMaxU];
+    __shared__ unsigned char s_rowc[kLinkMaxU * kLinkRowNnz];
     __shared__ double wv[4];
     __shared__ int wi[4];
     __shared__ int bad;
     static_assert(kLinkMaxU <= 128, "the pivot search looks at 128 rows");
-    auto sync = [] {
-        if (NT == 64) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-        else __syncthreads();
-    };
     const LinkProb P = a.probs[blockIdx.x];
     const int n = P.n_u, t = threadIdx.x;
     double* G = link_lds;
     double* S = link_lds + n * n;
-    for (int e = t; e < n * n; e += NT) {
+    // ---- phase 1 ----
+    for (int e = t; e < n * n; e += NT1) {
         const int pos = a.pos[P.q_off + e];
         G[e] = pos >= 0 ? a.Hval[pos] : 0.0;
     }
-    for (int i = t; i < n; i += NT) used[i] = 0;
+    if (t < n) { s_ucol[t] = a.ucol[P.u_begin + t]; s_round[t] = a.uround[P.u_begin + t]; s_super[t] = a.usuper[P.u_begin + t]; used[t] = 0; }
     if (t == 0) bad = 0;
-    sync();
-    for (int e = t; e < n * n; e += NT) {
+    __syncthreads();
+    if (t < n) {  // the nonzero columns of row t of G (an entry of the mask that holds a zero value is skipped as well)
+        int cnt = 0;
+        for (int c = 0; c < n; ++c)
+            if (G[t * n + c] != 0.0) { if (cnt < kLinkRowNnz) s_rowc[t * kLinkRowNnz + cnt] = (unsigned char)c; ++cnt; }
+        s_cnt[t] = cnt;
+    }
+    __syncthreads();
+    for (int e = t; e < n * n; e += NT1) {
         const int ra = e / n, cb = e - ra * n;
-        // S[ra][cb] = delta + sum_c G[ra][c] Z_cb[u_c],  Z_cb = column of unknown cb: round(cb)'s vector on cb's chain only
-        const int sup_b = a.usuper[P.u_begin + cb];
-        const double* __restrict__ Zb = a.Zr + (size_t)a.uround[P.u_begin + cb] * a.n_tot;
+        // S[ra][cb] = delta + sum_c G[ra][c] Z_cb[u_c],  Z_cb = column of unknown cb: round(cb)'s vector, nonzero on cb's chain only
+        const int sup_b = s_super[cb], cnt = s_cnt[ra];
+        const double* __restrict__ Zb = a.Zr + (size_t)s_round[cb] * a.n_tot;
         double acc = ra == cb ? 1.0 : 0.0;
-        for (int c = 0; c < n; ++c) {
-            const double g = G[ra * n + c];
-            if (g != 0.0 && a.usuper[P.u_begin + c] == sup_b) acc += g * Zb[a.ucol[P.u_begin + c]];
+        if (cnt <= kLinkRowNnz) {
+            for (int j0 = 0; j0 < cnt; j0 += 4) {
+                double zv[4], gv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int c = s_rowc[ra * kLinkRowNnz + min(j0 + q, cnt - 1)];
+                    gv[q] = (j0 + q < cnt && s_super[c] == sup_b) ? G[ra * n + c] : 0.0;
+                    zv[q] = Zb[s_ucol[c]];  // (a valid address whatever the weight)
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc += gv[q] * zv[q];
+            }
+        } else {  // (a node with more link partners than the list holds: the plain walk)
+            for (int c = 0; c < n; ++c) {
+                const double g = G[ra * n + c];
+                if (g != 0.0 && s_super[c] == sup_b) acc += g * Zb[s_ucol[c]];
+            }
         }
         S[e] = acc;
     }
-    sync();
+    __syncthreads();
+    if (ONEWAVE && t >= 64) return;
+    // ---- phase 2 ----
+    auto sync = [] {
+        if (ONEWAVE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+        else __syncthreads();
+    };
     for (int k = 0; k < n; ++k) {
         // pivot: the largest |S[i][k]| among the rows not used yet (ties: the smallest row)
         {
@@ -340,17 +372,13 @@ __global__ __launch_bounds__(NT) void k_link_cap(LinkArgs a) {
         const double inv = 1.0 / S[pr * n + k];
         for (int i = t; i < n; i += NT) fcol[i] = (i == pr) ? 0.0 : S[i * n + k] * inv;
         sync();
-        // every other row: row_i -= (S[i][k] / pivot) * row_pr, all rows at once (the factors were set aside: the update
-        // overwrites column k; the pivot row stays as it is)
-        // (a lane owns columns of [S | G] and walks down the rows: consecutive lanes touch consecutive words, the factor is a
-        //  broadcast, and there is no index division in the loop -- the first single-wavefront build spent 280 us on those)
+        // every other row: row_i -= (S[i][k] / pivot) * row_pr; a lane owns columns of [S | G] and walks down the rows eight at a
+        // time (every read requested before the first write)
         for (int c = t; c < 2 * n; c += NT) {
             double* M = c < n ? S : G;
             const int cc = c < n ? c : c - n;
             const double pv = M[pr * n + cc];
             if (pv != 0.0) {
-                // (eight rows per trip, every read requested before the first write: a row at a time, the loop was a chain of
-                //  LDS round trips -- 3 us per step)
                 constexpr int kRows = 8;
                 for (int i0 = 0; i0 < n; i0 += kRows) {
                     double mv[kRows], fv[kRows];
