@@ -42,7 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from bench_legs import (  # noqa: E402  (the legs: workloads, Monte-Carlo, CPU baselines, roofline helpers -- bench_legs.py)
-    HBM_PEAK_GBS, Dist, MonteCarlo, algorithmic_bytes, config5_leg, cpu_baseline, economy_leg, end_to_end, long_chain_leg, make_headline, mc_groups,
+    HBM_PEAK_GBS, MC_SEED0, Dist, MonteCarlo, algorithmic_bytes, config5_leg, cpu_baseline, economy_leg, end_to_end, long_chain_leg, make_headline, mc_groups,
     mc_models, newton_probe, pmc_traffic, roofline_block, roofline_newton, run_montecarlo_leg, solver_lib, survey_prec_bytes, three_d_leg,
 )
 
