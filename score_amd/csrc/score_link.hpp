@@ -272,9 +272,8 @@ __global__ __launch_bounds__(kLinkThreads) void k_link_rhs(LinkArgs a) {
 // (the first builds walked all n_u columns with two dependent global loads per nonzero: 40-160 us of the kernel's 120-280).
 // Phase 2: Gauss-Jordan with partial pivoting, rows never moved or scaled on the way (the pivot of step k is the largest entry
 // of column k among the rows not used yet; a used row keeps its pivot as the only entry of its column), a lane owning columns of
-// [S | G] and walking down the rows eight at a time; the owner of column k + 1 finds the next pivot on its way.  ONEWAVE
-// (n_u <= 48): wavefronts 1-3 leave after phase 1 and phase 2 runs on one wavefront with no block barrier at all; otherwise
-// four wavefronts and two barriers per step.
+// [S | G] and walking down the rows eight at a time.  ONEWAVE (n_u <= 48): wavefronts 1-3 leave after phase 1 and phase 2 runs
+// on one wavefront with no block barrier at all; otherwise four wavefronts and four barriers per step.
 constexpr int kLinkRowNnz = 16;
 template <bool ONEWAVE>
 __global__ __launch_bounds__(256) void k_link_cap(LinkArgs a) {
@@ -285,8 +284,10 @@ __global__ __launch_bounds__(256) void k_link_cap(LinkArgs a) {
     __shared__ double fcol[kLinkMaxU];
     __shared__ int s_ucol[kLinkMaxU], s_round[kLinkMaxU], s_super[kLinkMaxU], s_cnt[kLinkMaxU];
     __shared__ unsigned char s_rowc[kLinkMaxU * kLinkRowNnz];
+    __shared__ double wv[4];
+    __shared__ int wi[4];
     __shared__ int bad;
-    static_assert(kLinkMaxU <= 128, "the used-row set is two 64-bit words");
+    static_assert(kLinkMaxU <= 128, "the pivot search looks at 128 rows");
     const LinkProb P = a.probs[blockIdx.x];
     const int n = P.n_u, t = threadIdx.x;
     double* G = link_lds;
@@ -339,24 +340,35 @@ __global__ __launch_bounds__(256) void k_link_cap(LinkArgs a) {
         if (ONEWAVE) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
         else __syncthreads();
     };
-    // The pivot of step k + 1 is found by the lane that owns column k + 1 while it walks down that column in step k's
-    // elimination (it sees every updated entry anyway): no reduction, two barriers per step.
-    __shared__ int s_piv;
-    __shared__ double s_pval;
-    unsigned long long used_lo = 0ull, used_hi = 0ull;  // (every lane keeps the same set: uniform)
-    auto is_used = [&](int i) { return i < 64 ? ((used_lo >> i) & 1ull) != 0 : ((used_hi >> (i - 64)) & 1ull) != 0; };
-    if (t == 0) {  // the first pivot: column 0
-        double bv = -1.0;
-        int bi = 0;
-        for (int i = 0; i < n; ++i) { const double x = fabs(S[i * n]); if (x > bv) { bv = x; bi = i; } }
-        s_piv = bi; s_pval = bv;
-    }
-    sync();
     for (int k = 0; k < n; ++k) {
-        const int pr = s_piv;
-        if (!(s_pval > 1e-300)) { if (t == 0) bad = 1; break; }  // (uniform: every lane reads the same words)
-        if (pr < 64) used_lo |= 1ull << pr; else used_hi |= 1ull << (pr - 64);
-        if (t == 0) piv_of[k] = pr;
+        // pivot: the largest |S[i][k]| among the rows not used yet (ties: the smallest row)
+        {
+            double v = -1.0;
+            int idx = 0x7fffffff;
+            for (int i = t; i < n; i += NT) {
+                const double x = used[i] ? -1.0 : fabs(S[i * n + k]);
+                if (x > v || (x == v && i < idx)) { v = x; idx = i; }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double ov = __shfl_down(v, off);
+                const int oi = __shfl_down(idx, off);
+                if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+            }
+            if ((t & 63) == 0) { wv[t >> 6] = v; wi[t >> 6] = idx; }
+        }
+        sync();
+        if (t == 0) {
+            double v = wv[0];
+            int idx = wi[0];
+            for (int w = 1; w < NT / 64; ++w)
+                if (wv[w] > v || (wv[w] == v && wi[w] < idx)) { v = wv[w]; idx = wi[w]; }
+            if (!(v > 1e-300)) bad = 1;
+            piv_of[k] = idx; used[idx] = 1;
+        }
+        sync();
+        if (bad) break;  // (uniform)
+        const int pr = piv_of[k];
         const double inv = 1.0 / S[pr * n + k];
         for (int i = t; i < n; i += NT) fcol[i] = (i == pr) ? 0.0 : S[i * n + k] * inv;
         sync();
@@ -365,11 +377,8 @@ __global__ __launch_bounds__(256) void k_link_cap(LinkArgs a) {
         for (int c = t; c < 2 * n; c += NT) {
             double* M = c < n ? S : G;
             const int cc = c < n ? c : c - n;
-            const bool scout = (c == k + 1);  // (k + 1 < n: a column of S)
             const double pv = M[pr * n + cc];
-            double bv = -1.0;
-            int bi = 0;
-            if (pv != 0.0 || scout) {
+            if (pv != 0.0) {
                 constexpr int kRows = 8;
                 for (int i0 = 0; i0 < n; i0 += kRows) {
                     double mv[kRows], fv[kRows];
@@ -380,19 +389,12 @@ __global__ __launch_bounds__(256) void k_link_cap(LinkArgs a) {
                     }
 #pragma unroll
                     for (int q = 0; q < kRows; ++q)
-                        if (i0 + q < n) {
-                            const double nv = mv[q] - fv[q] * pv;  // (fcol[pr] = 0: the pivot row stays)
-                            M[(i0 + q) * n + cc] = nv;
-                            if (scout && !is_used(i0 + q)) { const double x = fabs(nv); if (x > bv) { bv = x; bi = i0 + q; } }
-                        }
+                        if (i0 + q < n) M[(i0 + q) * n + cc] = mv[q] - fv[q] * pv;  // (fcol[pr] = 0: the pivot row stays)
                 }
             }
-            if (scout) { s_piv = bi; s_pval = bv; }
         }
-        if (k + 1 == n && t == 0) s_pval = 1.0;
         sync();
     }
-    sync();
     const bool singular = bad != 0;
     // row piv_of[k] now holds d_k e_k' in S: unknown k's row of Q is that row of G over d_k
     for (int e = t; e < n * n; e += NT) {
