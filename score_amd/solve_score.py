@@ -115,6 +115,23 @@ def _runtime_s(info: dict) -> float:
     return (float(info.get("setup_ms", 0.0)) + float(info.get("solve_ms", 0.0))) * 1e-3
 
 
+def _loop_closure_settings(settings: dict, user: Optional[dict], has_loop_closures: bool, lib_path: Optional[str]) -> None:
+    """Loop closures (gurobi_utils.py:407-430) are stiff couplings outside the per-robot chains the ADMM loop's preconditioner
+    captures.  Where the splitting loop has to converge by itself -- polish off, the plain QCQP loop, or the oracle's CPU twin, which
+    has no polish -- such graphs start with 16 PCG iterations per KKT solve.  The default solver does not need that any more: its
+    Newton preconditioner carries the loop closures (round 6, csrc/score_link.hpp), and six warm-up iterations at 16 PCG
+    iterations each had become a fifth of the solve (profiles/r06_lc_warmup.txt: 150 -> 119 ms over 19 graphs, same optima)."""
+    if not has_loop_closures or "cg_iters" in (user or {}):
+        return
+    alone = not int(settings.get("polish", 1)) or bool(os.environ.get("SCORE_QCQP_PLAIN"))
+    if not alone:
+        from .solver import load_library
+
+        alone = load_library(lib_path).score_backend().decode() != "hip-gfx950"
+    if alone:
+        settings.update(cg_iters=16, cg_target=0.1)
+
+
 def _resolve_args(args, relaxation_type):
     """Accept both the reference signature ``solve_score(data, relaxation)`` and
     the stale example's ``solve_score(data, solver_params, relaxation)``
@@ -294,15 +311,12 @@ def solve_score_batch(
         raise ValueError(f"qcqp_mode {qcqp_mode} is not supported")
     models = list(_models) if _models is not None else _models_for(datas, relaxation_type, qcqp_mode, lib_path, assembler)
     settings = dict(DEFAULT_SOLVER_SETTINGS)
-    if any((d.n_loop_closures if hasattr(d, "arrays") else len(d.loop_closure_measurements)) for d in datas):
-        # loop closures are stiff couplings outside the per-robot chains the
-        # preconditioner captures: start with more PCG iterations per KKT solve
-        settings.update(cg_iters=16, cg_target=0.1)
     if relaxation_type == QCQP_RELAXATION and qcqp_mode == "direct" and os.environ.get("SCORE_QCQP_PLAIN"):
         # (the plain splitting loop on the program as given; by default the library solves the direct form in its head form,
         #  csrc/score_headform.hpp, with the default settings)
         settings.update(cg_iters=8, adaptive_rho=0)
     settings.update(solver_settings or {})
+    _loop_closure_settings(settings, solver_settings, any((d.n_loop_closures if hasattr(d, "arrays") else len(d.loop_closure_measurements)) for d in datas), lib_path)
     if assembler == "device":
         # model construction inside score_create_from_graphs, the estimate straight from the device (score_read_estimates):
         # rounded poses, landmarks, range variables -- no x / y / s copies, no index maps on the host
@@ -386,11 +400,10 @@ def solve_problem_with_intermediate_iterates(
     model = _model_for(data, relaxation_type, qcqp_mode, lib_path)
     settings = dict(DEFAULT_SOLVER_SETTINGS)
     n_lc = int(data.n_loop_closures) if hasattr(data, "arrays") else len(data.loop_closure_measurements)  # (ArrayGraph or objects)
-    if n_lc:
-        settings.update(cg_iters=16, cg_target=0.1)
     if relaxation_type == QCQP_RELAXATION and qcqp_mode == "direct" and os.environ.get("SCORE_QCQP_PLAIN"):
         settings.update(cg_iters=8, adaptive_rho=0)
     settings.update(solver_settings or {})
+    _loop_closure_settings(settings, solver_settings, bool(n_lc), lib_path)
     every = max(1, int(every))
     solver = ConicSolver([model.qp], settings, lib_path=lib_path)
     warmup = int(solver.settings.polish_warmup) if solver.settings.polish else 0
