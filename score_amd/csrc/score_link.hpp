@@ -33,16 +33,17 @@
 
 namespace score {
 
-constexpr int kLinkMaxU = 96;       // unknowns of one problem the correction covers (8 loop closures in 2-D, 4 in 3-D)
-constexpr int kLinkMaxRounds = 24;  // unknowns of one (whole) chain: applications of the chain kernel per refresh
+constexpr int kLinkMaxU = 96;       // unknowns of one independent group (make_link_plan): the system k_link_cap solves in LDS
+constexpr int kLinkMaxRounds = 48;  // unknowns of one (whole) chain: right-hand sides of the chain kernel per refresh
+constexpr int kLinkMaxNodes = 256;  // linked nodes of one problem
 constexpr int kLinkThreads = 256;
 
 struct LinkItem {   // one affected chain (a segment of a long chain: every segment of it) of a problem
     int32_t prob, chain, work, sep_col;  // work: its slot of the r'z partial sums; sep_col: separator to its right (-1: none)
     int32_t u[kLinkMaxRounds];           // per round: the unknown (index into the handle's unknown list) whose column this chain carries, -1 none
 };
-struct LinkProb {
-    int32_t prob, u_begin, n_u, q_off;   // q_off: first entry of the problem's n_u x n_u tables (mask / positions / Q')
+struct LinkProb {  // one independent group of a problem's unknowns (make_link_plan): a system of its own
+    int32_t prob, u_begin, n_u, q_off;   // q_off: first entry of the group's n_u x n_u tables (mask / positions / Q')
 };
 
 // ---- host: which chain nodes do relative-pose terms couple outside the chains? (pairs of global first columns) ----
@@ -160,7 +161,7 @@ inline void make_link_plan(const HostSystem& h, const std::vector<int32_t>& pair
         int ia = find(pairs[k]), ib = find(pairs[k + 1]);
         const int32_t sa = super[(size_t)fa->second.first], sb = super[(size_t)fb->second.first];
         const int add_a = ia < 0 ? bs : 0, add_b = ib < 0 ? bs : 0;
-        if ((int)N.size() * bs + add_a + add_b > kLinkMaxU || rounds_of[sa] + add_a + (sa == sb ? add_b : 0) > kLinkMaxRounds ||
+        if ((int)N.size() + 2 > kLinkMaxNodes || rounds_of[sa] + add_a + (sa == sb ? add_b : 0) > kLinkMaxRounds ||
             rounds_of[sb] + add_b + (sa == sb ? add_a : 0) > kLinkMaxRounds) {
             over[(size_t)p] = 1;
             L.pairs_used -= (int)used[(size_t)p].size();
@@ -176,25 +177,60 @@ inline void make_link_plan(const HostSystem& h, const std::vector<int32_t>& pair
     for (int p = 0; p < h.count; ++p) {
         auto& N = nodes[(size_t)p];
         if (N.empty()) continue;
-        LinkProb P{};
-        P.prob = p; P.u_begin = (int32_t)L.ucol.size(); P.n_u = (int32_t)N.size() * bs; P.q_off = (int32_t)L.mask.size();
-        for (Node& nd : N) {
-            nd.u0 = (int32_t)L.ucol.size();
-            for (int a = 0; a < bs; ++a) {
-                L.ucol.push_back(nd.col + a);
-                L.uround.push_back(next_round[nd.sup]++);
-                L.usuper.push_back(nd.sup);
-            }
+        // The unknowns fall into independent groups: two nodes belong together when they sit on the same (whole) chain -- Z
+        // couples them -- or are a linked pair -- G does.  A loop closure couples row k of one pose with row k of another and the
+        // rows' chains are separate, so a 2-D problem splits into at least two groups (3-D: three), more when the loop closures
+        // sit on different robots.  Every group is a system of its own for k_link_cap / k_link_solve (a LinkProb): the
+        // Gauss-Jordan steps, which are a chain of LDS round trips each, shrink with the largest group, not with the problem.
+        std::vector<int> root(N.size());
+        for (size_t i = 0; i < N.size(); ++i) root[i] = (int)i;
+        auto find_root = [&](int i) { while (root[(size_t)i] != i) i = root[(size_t)i] = root[(size_t)root[(size_t)i]]; return i; };
+        for (size_t i = 0; i < N.size(); ++i)
+            for (size_t j = i + 1; j < N.size(); ++j)
+                if (N[i].sup == N[j].sup) root[(size_t)find_root((int)j)] = find_root((int)i);
+        for (const auto& pr : used[(size_t)p]) root[(size_t)find_root(pr.second)] = find_root(pr.first);
+        std::vector<int> group_roots;
+        for (size_t i = 0; i < N.size(); ++i) {
+            const int r = find_root((int)i);
+            if (std::find(group_roots.begin(), group_roots.end(), r) == group_roots.end()) group_roots.push_back(r);
         }
-        L.mask.resize(L.mask.size() + (size_t)P.n_u * P.n_u, 0);
-        for (const auto& pr : used[(size_t)p])
-            for (int a = 0; a < bs; ++a)
-                for (int b = 0; b < bs; ++b) {
-                    const int ua = N[(size_t)pr.first].u0 - P.u_begin + a, ub = N[(size_t)pr.second].u0 - P.u_begin + b;
-                    L.mask[(size_t)P.q_off + (size_t)ua * P.n_u + ub] = 1;
-                    L.mask[(size_t)P.q_off + (size_t)ub * P.n_u + ua] = 1;
+        {   // (a group beyond what k_link_cap holds in LDS: the problem keeps the chain preconditioner alone)
+            bool too_big = false;
+            for (int gr : group_roots) {
+                int cnt = 0;
+                for (size_t i = 0; i < N.size(); ++i) cnt += find_root((int)i) == gr ? bs : 0;
+                too_big = too_big || cnt > kLinkMaxU;
+            }
+            if (too_big) { L.pairs_used -= (int)used[(size_t)p].size(); continue; }
+        }
+        const int32_t u_first = (int32_t)L.ucol.size();
+        for (int gr : group_roots) {
+            LinkProb P{};
+            P.prob = p; P.u_begin = (int32_t)L.ucol.size(); P.q_off = (int32_t)L.mask.size();
+            for (size_t i = 0; i < N.size(); ++i) {
+                if (find_root((int)i) != gr) continue;
+                Node& nd = N[i];
+                nd.u0 = (int32_t)L.ucol.size();
+                for (int a = 0; a < bs; ++a) {
+                    L.ucol.push_back(nd.col + a);
+                    L.uround.push_back(next_round[nd.sup]++);
+                    L.usuper.push_back(nd.sup);
                 }
-        L.probs.push_back(P);
+            }
+            P.n_u = (int32_t)L.ucol.size() - P.u_begin;
+            L.mask.resize(L.mask.size() + (size_t)P.n_u * P.n_u, 0);
+            for (const auto& pr : used[(size_t)p]) {
+                if (find_root(pr.first) != gr) continue;
+                for (int a = 0; a < bs; ++a)
+                    for (int b = 0; b < bs; ++b) {
+                        const int ua = N[(size_t)pr.first].u0 - P.u_begin + a, ub = N[(size_t)pr.second].u0 - P.u_begin + b;
+                        L.mask[(size_t)P.q_off + (size_t)ua * P.n_u + ub] = 1;
+                        L.mask[(size_t)P.q_off + (size_t)ub * P.n_u + ua] = 1;
+                    }
+            }
+            L.probs.push_back(P);
+        }
+        const int32_t u_last = (int32_t)L.ucol.size();
         for (const auto& pr : used[(size_t)p]) { L.pair_cols.push_back(N[(size_t)pr.first].col); L.pair_cols.push_back(N[(size_t)pr.second].col); }
         // the affected chains: every segment of every whole chain that carries an unknown
         std::vector<int32_t> sups;
@@ -213,7 +249,7 @@ inline void make_link_plan(const HostSystem& h, const std::vector<int32_t>& pair
                 LinkItem it{};
                 it.prob = p; it.chain = sg.first; it.work = work_of[(size_t)sg.first]; it.sep_col = sg.second;
                 for (int r = 0; r < kLinkMaxRounds; ++r) it.u[r] = -1;
-                for (size_t u = (size_t)P.u_begin; u < (size_t)P.u_begin + P.n_u; ++u)
+                for (size_t u = (size_t)u_first; u < (size_t)u_last; ++u)
                     if (L.usuper[u] == s) it.u[L.uround[u]] = (int32_t)u;
                 L.items.push_back(it);
             }
