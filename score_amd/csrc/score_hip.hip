@@ -2162,7 +2162,7 @@ struct HipBackend {
         LinkArgs la{};
         la.probs = link_probs.d; la.items = link_items.d; la.ucol = link_ucol.d; la.uround = link_uround.d; la.usuper = link_usuper.d;
         la.mask = link_mask.d; la.pos = link_pos.d; la.Qt = link_Qt.d; la.t = link_t.d; la.Zr = link_Zr.d; la.rhs = link_rhs.d;
-        la.n_tot = H->n_tot; la.rounds = link_rounds; la.n_u_total = n_link_u; la.round = 0;
+        la.n_tot = H->n_tot; la.rounds = link_rounds; la.n_u_total = n_link_u;
         la.Hptr = Hm.ptr.d; la.Hcol = Hm.col.d; la.Hval = Hm.val.d;
         la.chains = chainsH.d; la.node_col = node_col.d; la.done = link_zero.d; la.status = link_status.d;
         return la;

@@ -272,7 +272,7 @@ struct LinkArgs {
     double* Zr;              // rounds x n_tot: round r's applications of the chain kernel
     double* rhs;             // rounds x n_tot, zero except for a 1 at every unknown, in its round's vector
     int64_t n_tot;
-    int rounds, n_u_total, round;
+    int rounds, n_u_total;
     const int32_t* Hptr;
     const int32_t* Hcol;
     const double* Hval;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void k_link_cap(LinkArgs a) {
     constexpr int NT1 = 256, NT = ONEWAVE ? 64 : 256;
     extern __shared__ __attribute__((aligned(16))) double link_lds[];
     __shared__ int piv_of[kLinkMaxU];      // step k -> its pivot row
-    __shared__ char used[kLinkMaxU];
+    __shared__ char used[kLinkMaxU];       // rows that have been a pivot
     __shared__ double fcol[kLinkMaxU];
     __shared__ int s_ucol[kLinkMaxU], s_round[kLinkMaxU], s_super[kLinkMaxU], s_cnt[kLinkMaxU];
     __shared__ unsigned char s_rowc[kLinkMaxU * kLinkRowNnz];

@@ -1466,3 +1466,50 @@ def test_loop_closures_inside_the_newton_preconditioner(case, fixtures, hip_lib,
     for k, r in enumerate(res):
         assert r.solved and r.info["pobj"] == pytest.approx(a[k].info["pobj"], rel=1e-7, abs=1e-7)
     assert 2 * sum(res[k].info["newton_cg_iters"] for k in with_lc) <= sum(b[k].info["newton_cg_iters"] for k in with_lc)
+
+
+def test_loop_closure_edge_cases_in_the_link_correction(hip_lib, monkeypatch):
+    """Loop closures the generators never draw: BETWEEN robots (what a multi-session data set has), onto the pinned pose (a
+    constant, no unknown), between chain neighbours (a second odometry edge: inside the chain already), the same pair twice.
+    Array path and graph path must find the same links (bit-equal handles), the optimum must be the one without the correction
+    and the oracle's."""
+    from score_amd import compat
+    from score_amd.native import assemble_native, graph_arrays
+
+    _hip_only(hip_lib)
+    fg = make_manhattan(n_robots=3, n_poses=150, n_beacons=3, seed=77, p_range=0.15)
+    rng = np.random.default_rng(5)
+
+    def lc(a, i, b, j):
+        Ta, Tb = fg.pose_variables[a][i].transformation_matrix, fg.pose_variables[b][j].transformation_matrix
+        rel = np.linalg.inv(Ta) @ Tb
+        return compat.PoseMeasurement2D(fg.pose_variables[a][i].name, fg.pose_variables[b][j].name, float(rel[0, 2] + 0.01 * rng.standard_normal()),
+                                        float(rel[1, 2] + 0.01 * rng.standard_normal()), float(np.arctan2(rel[1, 0], rel[0, 0]) + 0.002 * rng.standard_normal()), 1e4, 2.5e5)
+
+    fg.loop_closure_measurements = [lc(0, 40, 1, 90), lc(2, 10, 1, 30), lc(0, 0, 2, 120), lc(1, 70, 1, 71), lc(0, 100, 0, 20), lc(0, 20, 0, 100), lc(2, 140, 0, 60)]
+    qp = assemble_native(fg, "SOCP", lib_path=hip_lib).qp
+    outs = {}
+    for name, env in (("links", None), ("plain", "1")):
+        if env:
+            monkeypatch.setenv("SCORE_NO_LINKS", env)
+        else:
+            monkeypatch.delenv("SCORE_NO_LINKS", raising=False)
+        sol = ConicSolver([qp], {}, lib_path=hip_lib)
+        outs[name] = (sol.solve()[0], _links_info(sol), sol.debug_get("link_pairs"))
+        sol.close()
+    monkeypatch.delenv("SCORE_NO_LINKS", raising=False)
+    (a, ia, pa), (b, ib, _) = outs["links"], outs["plain"]
+    # four real links (A40-B90, C10-B30, A100-A20 once, C140-A60), two rows each: the pinned pose, the neighbours and the
+    # repeated pair add none
+    assert ia["pairs"] == ia["used"] == 8 and ia["singular"] == 0 and ib["used"] == 0, (ia, ib)
+    assert a.solved and b.solved and a.info["pobj"] == pytest.approx(b.info["pobj"], rel=1e-7, abs=1e-7)
+    assert 2 * a.info["newton_cg_iters"] <= b.info["newton_cg_iters"], (a.info["newton_cg_iters"], b.info["newton_cg_iters"])
+    rp, u, info = so.newton_solve(fg, tol=1e-12)
+    assert a.info["pobj"] == pytest.approx(info["objective"], rel=1e-6, abs=1e-7)
+    cert = so.kkt_certificate(qp.P, qp.q, qp.A, qp.b, 0, qp.soc_dims, a.x, a.y, a.s)
+    assert cert["primal_res_inf"] < 1e-5 and cert["dual_res_inf"] < 1e-4, cert
+    g = ConicSolver.from_graphs([graph_arrays(fg)], 0, {}, lib_path=hip_lib)
+    assert _links_info(g) == ia and np.array_equal(g.debug_get("link_pairs"), pa)
+    gi, _ = g.solve_estimates()
+    g.close()
+    assert gi[0]["status"] == 1 and gi[0]["newton_cg_iters"] == a.info["newton_cg_iters"] and gi[0]["pobj"] == a.info["pobj"]
