@@ -2202,6 +2202,10 @@ struct HipBackend {
         la.done = pa.done;
         la.r = (MODE == PREC_INIT) ? pa.r_in : pa.r;
         la.z = pa.z; la.p = pa.p; la.rz_out = pa.rz_out;
+        if (link_plan.max_items <= kLinkGroupItems) {  // (a workgroup per group: t and the group's chains in one launch)
+            hipLaunchKernelGGL((k_link_group<BS, MODE>), dim3((unsigned)n_link_probs), dim3(kLinkApplyThreads), 0, stream, la);
+            return;
+        }
         hipLaunchKernelGGL(k_link_solve, dim3((unsigned)n_link_probs), dim3(128), 0, stream, la);
         hipLaunchKernelGGL((k_link_apply<BS, MODE>), dim3((unsigned)n_link_items), dim3(kLinkApplyThreads), 0, stream, la);
     }

@@ -44,6 +44,7 @@ struct LinkItem {   // one affected chain (a segment of a long chain: every segm
 };
 struct LinkProb {  // one independent group of a problem's unknowns (make_link_plan): a system of its own
     int32_t prob, u_begin, n_u, q_off;   // q_off: first entry of the group's n_u x n_u tables (mask / positions / Q')
+    int32_t item_begin, item_count;      // the group's affected chains in LinkPlan::items
 };
 
 // ---- host: which chain nodes do relative-pose terms couple outside the chains? (pairs of global first columns) ----
@@ -104,7 +105,7 @@ struct LinkPlan {
     std::vector<int32_t> ucol, uround, usuper;  // per unknown: global column, its round, its (whole) chain
     std::vector<uint8_t> mask;                  // per problem n_u x n_u: 1 = (a, b) lie in linked nodes (an entry of G)
     std::vector<int32_t> pair_cols;             // the node pairs inside the preconditioner (global first columns, two per pair)
-    int rounds = 0;
+    int rounds = 0, max_items = 0;              // max_items: the most chains any group touches
     int pairs_total = 0, pairs_used = 0;
     bool empty() const { return items.empty(); }
 };
@@ -203,7 +204,6 @@ inline void make_link_plan(const HostSystem& h, const std::vector<int32_t>& pair
             }
             if (too_big) { L.pairs_used -= (int)used[(size_t)p].size(); continue; }
         }
-        const int32_t u_first = (int32_t)L.ucol.size();
         for (int gr : group_roots) {
             LinkProb P{};
             P.prob = p; P.u_begin = (int32_t)L.ucol.size(); P.q_off = (int32_t)L.mask.size();
@@ -228,34 +228,37 @@ inline void make_link_plan(const HostSystem& h, const std::vector<int32_t>& pair
                         L.mask[(size_t)P.q_off + (size_t)ub * P.n_u + ua] = 1;
                     }
             }
+            // the group's affected chains: every segment of every whole chain that carries one of its unknowns
+            P.item_begin = (int32_t)L.items.size();
+            std::vector<int32_t> sups;
+            for (size_t i = 0; i < N.size(); ++i)
+                if (find_root((int)i) == gr && std::find(sups.begin(), sups.end(), N[i].sup) == sups.end()) sups.push_back(N[i].sup);
+            for (int32_t sc : sups) {
+                std::vector<std::pair<int32_t, int32_t>> segs;  // (chain, separator to the right or -1)
+                bool joined = false;
+                for (const JoinItem& it : h.join_items)
+                    if (h.join_chains[(size_t)it.jc].first_chain == sc) {
+                        const JoinChain& jc = h.join_chains[(size_t)it.jc];
+                        segs.push_back({it.chain, it.seg + 1 < jc.n_seg ? h.join_sep_col[(size_t)jc.sep_begin + it.seg] : -1});
+                        joined = true;
+                    }
+                if (!joined) segs.push_back({sc, -1});
+                for (const auto& sg : segs) {
+                    LinkItem it{};
+                    it.prob = p; it.chain = sg.first; it.work = work_of[(size_t)sg.first]; it.sep_col = sg.second;
+                    for (int r = 0; r < kLinkMaxRounds; ++r) it.u[r] = -1;
+                    for (size_t u = (size_t)P.u_begin; u < (size_t)P.u_begin + P.n_u; ++u)
+                        if (L.usuper[u] == sc) it.u[L.uround[u]] = (int32_t)u;
+                    L.items.push_back(it);
+                }
+            }
+            P.item_count = (int32_t)L.items.size() - P.item_begin;
             L.probs.push_back(P);
         }
-        const int32_t u_last = (int32_t)L.ucol.size();
         for (const auto& pr : used[(size_t)p]) { L.pair_cols.push_back(N[(size_t)pr.first].col); L.pair_cols.push_back(N[(size_t)pr.second].col); }
-        // the affected chains: every segment of every whole chain that carries an unknown
-        std::vector<int32_t> sups;
-        for (const Node& nd : N) if (std::find(sups.begin(), sups.end(), nd.sup) == sups.end()) sups.push_back(nd.sup);
-        for (int32_t s : sups) {
-            std::vector<std::pair<int32_t, int32_t>> segs;  // (chain, separator to the right or -1)
-            bool joined = false;
-            for (const JoinItem& it : h.join_items)
-                if (h.join_chains[(size_t)it.jc].first_chain == s) {
-                    const JoinChain& jc = h.join_chains[(size_t)it.jc];
-                    segs.push_back({it.chain, it.seg + 1 < jc.n_seg ? h.join_sep_col[(size_t)jc.sep_begin + it.seg] : -1});
-                    joined = true;
-                }
-            if (!joined) segs.push_back({s, -1});
-            for (const auto& sg : segs) {
-                LinkItem it{};
-                it.prob = p; it.chain = sg.first; it.work = work_of[(size_t)sg.first]; it.sep_col = sg.second;
-                for (int r = 0; r < kLinkMaxRounds; ++r) it.u[r] = -1;
-                for (size_t u = (size_t)u_first; u < (size_t)u_last; ++u)
-                    if (L.usuper[u] == s) it.u[L.uround[u]] = (int32_t)u;
-                L.items.push_back(it);
-            }
-        }
     }
     for (int32_t r : L.uround) L.rounds = std::max(L.rounds, r + 1);
+    for (const LinkProb& P : L.probs) L.max_items = std::max(L.max_items, (int)P.item_count);
 }
 
 #if defined(__HIPCC__)
@@ -461,29 +464,30 @@ __global__ __launch_bounds__(128) void k_link_solve(LinkArgs a) {
 // z -= Z t on one affected chain (and the separator to its right); its r'z partial sum restated with the corrected z.
 // The rounds a chain carries are compacted first; an entry then requests kLinkBatch columns of Z at a time before it uses any
 // (a chain is ONE workgroup's work: a loop of dependent loads over 24 rounds took 100 us -- measured on the first build).
+// `tw`: the weights t by unknown -- global memory (k_link_apply) or the group's LDS copy minus `u_base` (k_link_group).
 constexpr int kLinkApplyThreads = 512;
 constexpr int kLinkBatch = 8;
+struct LinkApplyLds {
+    double red[16];
+    double ts[kLinkMaxRounds + kLinkBatch];
+    double traw[kLinkMaxRounds];
+    int rr[kLinkMaxRounds + kLinkBatch];
+    int n_act;
+};
 template <int BS, int MODE>
-__global__ __launch_bounds__(kLinkApplyThreads) void k_link_apply(LinkArgs a) {
-    __shared__ double red[16];
-    __shared__ double ts[kLinkMaxRounds + kLinkBatch];
-    __shared__ int rr[kLinkMaxRounds + kLinkBatch];
-    __shared__ int n_act;
-    const LinkItem it = a.items[blockIdx.x];
-    if (a.done[it.prob]) return;
+__device__ __forceinline__ void link_apply_chain(const LinkArgs& a, const LinkItem& it, const double* tw, int u_base, LinkApplyLds& L) {
     const int t = threadIdx.x;
-    __shared__ double traw[kLinkMaxRounds];
-    if (t < kLinkMaxRounds) traw[t] = (t < a.rounds && it.u[t] >= 0) ? a.t[it.u[t]] : 0.0;  // (every round's weight requested at once)
+    if (t < kLinkMaxRounds) L.traw[t] = (t < a.rounds && it.u[t] >= 0) ? tw[it.u[t] - u_base] : 0.0;  // (every round's weight requested at once)
     __syncthreads();
     if (t == 0) {
         int k = 0;
         for (int r = 0; r < a.rounds; ++r)
-            if (it.u[r] >= 0) { rr[k] = r; ts[k] = traw[r]; ++k; }
-        n_act = k;
-        for (int q = 0; q < kLinkBatch; ++q) { rr[k + q] = k ? rr[k - 1] : 0; ts[k + q] = 0.0; }  // (padding: a valid column of Z, weight 0)
+            if (it.u[r] >= 0) { L.rr[k] = r; L.ts[k] = L.traw[r]; ++k; }
+        L.n_act = k;
+        for (int q = 0; q < kLinkBatch; ++q) { L.rr[k + q] = k ? L.rr[k - 1] : 0; L.ts[k + q] = 0.0; }  // (padding: a valid column of Z, weight 0)
     }
     __syncthreads();
-    const int na = n_act;
+    const int na = L.n_act;
     const ChainDesc ch = a.chains[it.chain];
     const int NB = ch.N * BS, NE = NB + (it.sep_col >= 0 ? BS : 0);
     const double* __restrict__ Zr = a.Zr;
@@ -509,11 +513,11 @@ __global__ __launch_bounds__(kLinkApplyThreads) void k_link_apply(LinkArgs a) {
 #pragma unroll
             for (int j = 0; j < kLinkEnt; ++j)
 #pragma unroll
-                for (int q = 0; q < kLinkBatch; ++q) zv[j][q] = Zr[(size_t)rr[k0 + q] * a.n_tot + col[j]];
+                for (int q = 0; q < kLinkBatch; ++q) zv[j][q] = Zr[(size_t)L.rr[k0 + q] * a.n_tot + col[j]];
 #pragma unroll
             for (int j = 0; j < kLinkEnt; ++j)
 #pragma unroll
-                for (int q = 0; q < kLinkBatch; ++q) zz[j] -= zv[j][q] * ts[k0 + q];
+                for (int q = 0; q < kLinkBatch; ++q) zz[j] -= zv[j][q] * L.ts[k0 + q];
         }
 #pragma unroll
         for (int j = 0; j < kLinkEnt; ++j) {
@@ -524,8 +528,41 @@ __global__ __launch_bounds__(kLinkApplyThreads) void k_link_apply(LinkArgs a) {
             }
         }
     }
-    const double tot = block_sum_n<kLinkApplyThreads / 64>(local, red);
+    const double tot = block_sum_n<kLinkApplyThreads / 64>(local, L.red);
     if (t == 0) a.rz_out[it.work] = tot;
+}
+template <int BS, int MODE>
+__global__ __launch_bounds__(kLinkApplyThreads) void k_link_apply(LinkArgs a) {
+    __shared__ LinkApplyLds L;
+    const LinkItem it = a.items[blockIdx.x];
+    if (a.done[it.prob]) return;
+    link_apply_chain<BS, MODE>(a, it, a.t, 0, L);
+}
+// k_link_solve and k_link_apply in ONE launch, a workgroup per group: t = Q y[U] of the group, then its chains one after the
+// other -- nobody else touches a group's chains, so nothing is read that another workgroup overwrites.  Taken when no group
+// has more than kLinkGroupItems chains (HipBackend::link_apply): one launch shell (~5 us) less per application.
+constexpr int kLinkGroupItems = 4;
+template <int BS, int MODE>
+__global__ __launch_bounds__(kLinkApplyThreads) void k_link_group(LinkArgs a) {
+    __shared__ LinkApplyLds L;
+    __shared__ double v[kLinkMaxU], tg[kLinkMaxU];
+    const LinkProb P = a.probs[blockIdx.x];
+    if (a.done[P.prob]) return;  // frozen problem / a PCG whose gate has fired: the chain kernel wrote nothing either
+    const int t = threadIdx.x;
+    if (t < P.n_u) v[t] = a.z[a.ucol[P.u_begin + t]];
+    __syncthreads();
+    if (t < P.n_u) {
+        const double* __restrict__ Q = a.Qt + P.q_off;
+        double acc = 0.0;
+        for (int b = 0; b < P.n_u; ++b) acc += Q[b * P.n_u + t] * v[b];
+        tg[t] = acc;
+    }
+    __syncthreads();
+    for (int i = 0; i < P.item_count; ++i) {
+        const LinkItem it = a.items[P.item_begin + i];
+        link_apply_chain<BS, MODE>(a, it, tg, P.u_begin, L);
+        __syncthreads();
+    }
 }
 #endif  // __HIPCC__
 
