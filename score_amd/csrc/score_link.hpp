@@ -540,8 +540,10 @@ __global__ __launch_bounds__(kLinkApplyThreads) void k_link_apply(LinkArgs a) {
 }
 // k_link_solve and k_link_apply in ONE launch, a workgroup per group: t = Q y[U] of the group, then its chains one after the
 // other -- nobody else touches a group's chains, so nothing is read that another workgroup overwrites.  Taken when no group
-// has more than kLinkGroupItems chains (HipBackend::link_apply): one launch shell (~5 us) less per application.
-constexpr int kLinkGroupItems = 4;
+// has more than kLinkGroupItems chains (HipBackend::link_apply): one launch shell (~5 us) less per application.  (Measured: a
+// chain costs the workgroup ~10 us; with the three segments of a 2570-pose chain in a row the fused launch took 29-42 us against
+// 12 + 5 for the two launches -- hence two chains at most; 2 x 400 poses with 2 loop closures: 4.16 -> 3.87 ms per solve.)
+constexpr int kLinkGroupItems = 2;
 template <int BS, int MODE>
 __global__ __launch_bounds__(kLinkApplyThreads) void k_link_group(LinkArgs a) {
     __shared__ LinkApplyLds L;
