@@ -26,6 +26,7 @@
 #include "../../score_amd/csrc/score_gn.hpp"
 #include "../../score_amd/csrc/score_round.hpp"
 #include "../../score_amd/csrc/score_generate.hpp"
+#include "../../score_amd/csrc/score_link.hpp"  // (host part only: which loop closures the product's Newton preconditioner would carry -- the plan, for the CPU tests)
 #include "../../score_amd/csrc/score_polish_host.hpp"  // (layout checks only: band_check_h; the twin has no polish)
 
 namespace {
@@ -75,9 +76,17 @@ struct CpuBackend {
 
     bool device_setup_ok(const HostSystem&, const score_problem*, const score_settings&) const { return false; }  // (the twin IS the host setup)
     bool device_setup_ok_graphs(const HostSystem&, const score_graph*, const score_settings&) const { return false; }
-    void init(const HostSystem& h, const score_settings& s_, const score_problem* = nullptr, const score_graph* = nullptr) {
+    int64_t L_pairs() const { return link_plan.items.empty() ? 0 : (int64_t)link_plan.pair_cols.size(); }
+    LinkPlan link_plan;  // (the product's plan of loop closures inside its Newton preconditioner, score_link.hpp: host logic only here)
+    void init(const HostSystem& h, const score_settings& s_, const score_problem* probs = nullptr, const score_graph* graphs = nullptr) {
         H = &h;
         st = s_;
+        {
+            std::vector<int32_t> pairs;
+            if (graphs) find_link_pairs_graphs(h, graphs, pairs);
+            else if (probs) find_link_pairs_P(h, probs, pairs);
+            make_link_plan(h, pairs, link_plan);
+        }
         xtu.assign(h.n_tot + h.m_tot, 0.0);
         xy.assign(h.n_tot + h.m_tot, 0.0);
         s.assign(h.m_tot, 0.0);
@@ -346,6 +355,20 @@ struct CpuBackend {
             const double v[3] = {(double)h.rep, (double)h.K.col.size(), (double)h.G1.col.size()};
             if (out && len > 0) std::memcpy(out, v, sizeof(double) * (size_t)std::min<int64_t>(len, 3));
             return 3;
+        }
+        else if (nm == "links") {  // the product's link plan for this handle (score_link.hpp::make_link_plan), as the HIP backend reports it + groups
+            const LinkPlan& L = link_plan;
+            int max_u = 0;
+            for (const LinkProb& P : L.probs) max_u = std::max(max_u, (int)P.n_u);
+            const double v[9] = {(double)L.pairs_total, (double)L.pairs_used, (double)L.ucol.size(), (double)L.items.size(), (double)L.rounds, 0.0,
+                                 (double)L.probs.size(), (double)max_u, (double)L.max_items};
+            if (out && len > 0) std::memcpy(out, v, sizeof(double) * (size_t)std::min<int64_t>(len, 9));
+            return 9;
+        }
+        else if (nm == "link_pairs") {
+            const int64_t np_ = L_pairs();
+            if (out) for (int64_t i = 0; i < np_ && i < len; ++i) out[i] = (double)link_plan.pair_cols[(size_t)i];
+            return np_;
         }
         else if (nm == "band_check" || nm == "band_check_h") {
             // Layout check of the product's band view (score_band.hpp) on the host: build the view of K (as the

@@ -29,7 +29,10 @@
 #include <unordered_map>
 #include <vector>
 
+#include "score_host.hpp"
+#if defined(__HIPCC__)
 #include "score_join.hpp"
+#endif
 
 namespace score {
 

@@ -501,3 +501,52 @@ def test_graph_handles_and_the_estimate_read_back(twin_lib):
     with pytest.raises(RuntimeError, match="not made by ConicSolver.from_graphs"):
         plain.solve_estimates()
     plain.close()
+
+
+def _lc_between(fg, rng, a, i, b, j):
+    Ta, Tb = fg.pose_variables[a][i].transformation_matrix, fg.pose_variables[b][j].transformation_matrix
+    rel = np.linalg.inv(Ta) @ Tb
+    return compat.PoseMeasurement2D(fg.pose_variables[a][i].name, fg.pose_variables[b][j].name, float(rel[0, 2] + 0.01 * rng.standard_normal()),
+                                    float(rel[1, 2] + 0.01 * rng.standard_normal()), float(np.arctan2(rel[1, 0], rel[0, 0]) + 0.002 * rng.standard_normal()), 1e4, 2.5e5)
+
+
+def test_link_plan_host_logic(twin_lib):
+    """Host side of round 6's loop closures inside the Newton preconditioner (csrc/score_link.hpp: find_link_pairs_P,
+    make_link_plan -- compiled into the twin for this test; the kernels are GPU-tested): which node pairs are links (found in P's
+    pattern: a rotation row holding a non-neighbour chain column), how the unknowns split into independent groups, what the caps
+    refuse.  [pairs, pairs inside, unknowns, affected chains, rounds, -, groups, largest group, most chains per group]"""
+    from score_amd.native import assemble_native
+
+    def plan(fg):
+        sol = ConicSolver([assemble_native(fg, "SOCP", lib_path=twin_lib).qp], dict(polish=0), lib_path=twin_lib)
+        v, pairs = sol.debug_get("links"), sol.debug_get("link_pairs")
+        sol.close()
+        return [int(x) for x in v], pairs.astype(np.int64).reshape(-1, 2)
+
+    rng = np.random.default_rng(5)
+    fg = make_manhattan(n_robots=3, n_poses=150, n_beacons=3, seed=77, p_range=0.15)
+    assert plan(fg)[0][:4] == [0, 0, 0, 0]  # no loop closures: nothing
+    # between robots, onto the pinned pose (no unknown), chain neighbours (inside the chain), the same pair twice and reversed
+    fg.loop_closure_measurements = [_lc_between(fg, rng, 0, 40, 1, 90), _lc_between(fg, rng, 2, 10, 1, 30), _lc_between(fg, rng, 0, 0, 2, 120),
+                                    _lc_between(fg, rng, 1, 70, 1, 71), _lc_between(fg, rng, 0, 100, 0, 20), _lc_between(fg, rng, 0, 20, 0, 100),
+                                    _lc_between(fg, rng, 2, 140, 0, 60)]
+    v, pairs = plan(fg)
+    # 4 links x 2 rows; nodes: A20 A40 A60 A100 B30 B90 C10 C140 per row = 8 nodes x 3 unknowns x 2 rows; every robot's chain is
+    # affected in both rows (6 chains); A carries 4 nodes (12 rounds); the robots are all linked: one group per row, of 24
+    assert v[:5] == [8, 8, 48, 6, 12] and v[6:] == [2, 24, 3], v
+    n_rep = (3 * 150 - 1) * 3 + 3
+    assert len(pairs) == 8 and np.all(pairs[:, 0] < pairs[:, 1]) and np.all(pairs[4:] == pairs[:4] + n_rep)  # row 1 = row 0 shifted by a replica
+    assert [int(c) for c in pairs[:4, 0]] == sorted(int(c) for c in pairs[:4, 0])  # one canonical order whatever found them
+    # loop closures within robots: the groups are per robot and row
+    fg2 = make_manhattan(n_robots=4, n_poses=300, n_beacons=3, seed=78, n_loop_closures=20)
+    v2, _ = plan(fg2)
+    assert v2[0] == v2[1] > 20 and v2[6] >= 4 and v2[7] <= 96 and v2[8] == 1 and v2[2] == 3 * 2 * len({m.base_pose for m in fg2.loop_closure_measurements} | {m.to_pose for m in fg2.loop_closure_measurements} - {"A0"}) , v2
+    # beyond the caps (more than 48 unknowns on one chain): all of the problem's pairs or none
+    fg3 = make_manhattan(n_robots=1, n_poses=400, n_beacons=2, seed=79, n_loop_closures=12)
+    v3, p3 = plan(fg3)
+    assert v3[0] > 12 and v3[1] == 0 and v3[2] == 0 and len(p3) == 0, v3
+    # 3-D: 4 x 4 blocks, three rows
+    from conftest import graph_3d
+
+    v4, _ = plan(graph_3d())
+    assert v4[:5] == [3, 3, 24, 3, 8] and v4[6:] == [3, 8, 1], v4
