@@ -101,7 +101,115 @@ struct CpuBackend {
         cg_iters = st.cg_iters;
         reset();
     }
+    // ---- the loop closures inside the preconditioner (score_link.hpp), as host loops: the specification of the HIP backend's
+    //      link kernels ON THE ADMM SET (K).  z = y - Z t, y = T^-1 r (the chains), Z = T^-1 U, t = (I + G Z_U)^-1 G y_U, group by group.
+    std::vector<double> link_Zr;                 // rounds x n_tot
+    std::vector<std::vector<double>> link_Q;     // per group: n_u x n_u, row-major
+    bool link_on = false;
+    void chains_only(int pi) {  // z = T^-1 r on the chains of problem pi (Jacobi columns: r * dinv)
+        double unused = 0.0;
+        const bool keep = link_on;
+        link_on = false;
+        precond(pi, unused);
+        link_on = keep;
+    }
+    void link_refresh() {
+        const HostSystem& h = *H;
+        const LinkPlan& L = link_plan;
+        link_on = false;
+        if (L.empty() || std::getenv("SCORE_NO_LINKS") != nullptr) return;
+        const size_t n = (size_t)h.n_tot;
+        link_Zr.assign((size_t)L.rounds * n, 0.0);
+        std::vector<double> keep_r = r, keep_z = z;
+        for (int rd = 0; rd < L.rounds; ++rd) {
+            std::fill(r.begin(), r.end(), 0.0);
+            for (size_t u = 0; u < L.ucol.size(); ++u)
+                if (L.uround[u] == rd) r[(size_t)L.ucol[u]] = 1.0;
+            for (int pi = 0; pi < h.count; ++pi) chains_only(pi);
+            std::copy(z.begin(), z.begin() + (std::ptrdiff_t)n, link_Zr.begin() + (std::ptrdiff_t)((size_t)rd * n));
+        }
+        r = keep_r; z = keep_z;
+        link_Q.assign(L.probs.size(), {});
+        for (size_t g = 0; g < L.probs.size(); ++g) {
+            const LinkProb& P = L.probs[g];
+            const int m = P.n_u;
+            std::vector<double> G((size_t)m * m, 0.0), S((size_t)m * m, 0.0);
+            for (int a = 0; a < m; ++a)
+                for (int b = 0; b < m; ++b) {
+                    if (!L.mask[(size_t)P.q_off + (size_t)a * m + b]) continue;
+                    int32_t sa = 0, sb = 0;
+                    const int32_t ra = link_owner_col(h, P.prob, L.ucol[(size_t)P.u_begin + a], &sa), cb = link_owner_col(h, P.prob, L.ucol[(size_t)P.u_begin + b], &sb);
+                    if (sa != sb) continue;  // (a loop closure couples row k with row k: the same replica)
+                    const int pos = find_in_row(h.K, ra, cb);
+                    if (pos >= 0) G[(size_t)a * m + b] = h.K.val[(size_t)pos];
+                }
+            for (int a = 0; a < m; ++a)
+                for (int b = 0; b < m; ++b) {
+                    double acc = a == b ? 1.0 : 0.0;
+                    for (int c = 0; c < m; ++c)
+                        if (G[(size_t)a * m + c] != 0.0 && L.usuper[(size_t)P.u_begin + c] == L.usuper[(size_t)P.u_begin + b])
+                            acc += G[(size_t)a * m + c] * link_Zr[(size_t)L.uround[(size_t)P.u_begin + b] * n + (size_t)L.ucol[(size_t)P.u_begin + c]];
+                    S[(size_t)a * m + b] = acc;
+                }
+            // Q = S^-1 G: Gaussian elimination with partial pivoting on [S | G]
+            bool singular = false;
+            for (int k = 0; k < m && !singular; ++k) {
+                int piv = k;
+                for (int i = k + 1; i < m; ++i) if (std::fabs(S[(size_t)i * m + k]) > std::fabs(S[(size_t)piv * m + k])) piv = i;
+                if (!(std::fabs(S[(size_t)piv * m + k]) > 1e-300)) { singular = true; break; }
+                if (piv != k)
+                    for (int c = 0; c < m; ++c) { std::swap(S[(size_t)k * m + c], S[(size_t)piv * m + c]); std::swap(G[(size_t)k * m + c], G[(size_t)piv * m + c]); }
+                const double inv = 1.0 / S[(size_t)k * m + k];
+                for (int c = 0; c < m; ++c) { S[(size_t)k * m + c] *= inv; G[(size_t)k * m + c] *= inv; }
+                for (int i = 0; i < m; ++i) {
+                    if (i == k) continue;
+                    const double f = S[(size_t)i * m + k];
+                    if (f == 0.0) continue;
+                    for (int c = 0; c < m; ++c) { S[(size_t)i * m + c] -= f * S[(size_t)k * m + c]; G[(size_t)i * m + c] -= f * G[(size_t)k * m + c]; }
+                }
+            }
+            if (singular) std::fill(G.begin(), G.end(), 0.0);
+            link_Q[g] = std::move(G);
+        }
+        link_on = true;
+    }
+    // the correction of problem pi after its chains were applied; returns the new r'z of the problem
+    double link_correct(int pi) {
+        const HostSystem& h = *H;
+        const LinkPlan& L = link_plan;
+        const size_t n = (size_t)h.n_tot;
+        for (size_t g = 0; g < L.probs.size(); ++g) {
+            const LinkProb& P = L.probs[g];
+            if (P.prob != pi) continue;
+            const int m = P.n_u;
+            std::vector<double> v((size_t)m), t((size_t)m, 0.0);
+            for (int a = 0; a < m; ++a) v[(size_t)a] = z[(size_t)L.ucol[(size_t)P.u_begin + a]];
+            for (int a = 0; a < m; ++a)
+                for (int b = 0; b < m; ++b) t[(size_t)a] += link_Q[g][(size_t)a * m + b] * v[(size_t)b];
+            for (int i = 0; i < P.item_count; ++i) {
+                const LinkItem& it = L.items[(size_t)P.item_begin + i];
+                const ChainDesc& ch = h.chains[(size_t)it.chain];
+                for (int node = 0; node < ch.N; ++node)
+                    for (int c = 0; c < h.bs; ++c) {
+                        const size_t col = (size_t)h.node_col[(size_t)ch.node_begin + node] + c;
+                        double zz = z[col];
+                        for (int rd = 0; rd < L.rounds; ++rd)
+                            if (it.u[rd] >= 0) zz -= link_Zr[(size_t)rd * n + col] * t[(size_t)(it.u[rd] - P.u_begin)];
+                        z[col] = zz;
+                    }
+            }
+        }
+        double acc = 0.0;
+        for (int64_t i = h.xoff[pi]; i < h.xoff[pi + 1]; ++i) acc += r[(size_t)i] * z[(size_t)i];
+        return acc;
+    }
+    bool has_links(int pi) const {
+        for (const LinkProb& P : link_plan.probs) if (P.prob == pi) return true;
+        return false;
+    }
+
     void upload_rho(const HostSystem& h) {
+        link_refresh();  // (the chain factors have just changed: refresh_rho)
         // K changed: the carried product kx = K xt is recomputed once
         for (int pi = 0; pi < h.count; ++pi)
             for_rows(h.K, pi, 0, [&](int64_t row, int64_t o, int64_t sh) { kx[o] = row_dot(h.K, row, xtu.data() + sh); });
@@ -154,6 +262,7 @@ struct CpuBackend {
             }
         }
         rz = acc;
+        if (link_on && has_links(pi)) rz = link_correct(pi);
     }
 
     // linear mode: the same PCG as the loop above (precond() + row_dot), run to r'M^-1 r <= tol^2 r0'M^-1 r0

@@ -2116,36 +2116,54 @@ struct HipBackend {
         }
     }
 
-    // ---- loop closures inside the Newton preconditioner (score_link.hpp): Woodbury correction of the chain solve ----
+    // ---- loop closures inside the preconditioners (score_link.hpp): Woodbury correction of the chain solve, for the ADMM
+    //      loop's K (set 0) and for the Newton matrix (set 1) -- one plan, the sets' own positions, columns Z and matrices Q ----
     LinkPlan link_plan;
     int n_link_items = 0, n_link_probs = 0, n_link_u = 0, link_rounds = 0, link_max_u = 0;
     bool link_suspend = false;
+    bool link_set_on[2] = {false, false};
     DevBuf<LinkProb> link_probs;
     DevBuf<LinkItem> link_items;
-    DevBuf<int32_t> link_ucol, link_uround, link_usuper, link_pos, link_zero, link_status;
+    DevBuf<int32_t> link_ucol, link_uround, link_usuper, link_pcol[2], link_pshift[2], link_pos[2], link_zero, link_status[2];
     DevBuf<uint8_t> link_mask;
-    DevBuf<double> link_Qt, link_t, link_Zr, link_rhs, link_tmp_p, link_tmp_rz, link_zb;
+    DevBuf<double> link_Qt[2], link_Zr[2], link_t, link_rhs, link_tmp_p, link_tmp_rz, link_zb;
     void link_init(const HostSystem& h, const score_problem* probs, const score_graph* graphs) {
         n_link_items = n_link_probs = n_link_u = link_rounds = 0;
-        if (!st.polish || !Q.available || h.chainsH.empty() || std::getenv("SCORE_NO_LINKS") != nullptr) return;
+        link_set_on[0] = link_set_on[1] = false;
+        if (h.chains.empty() || split.active || std::getenv("SCORE_NO_LINKS") != nullptr) return;
         std::vector<int32_t> pairs;
         if (graphs) find_link_pairs_graphs(h, graphs, pairs);
         else if (probs) find_link_pairs_P(h, probs, pairs);
         if (pairs.empty()) return;
         make_link_plan(h, pairs, link_plan);
         const LinkPlan& L = link_plan;
-        if (st.verbose) std::fprintf(stderr, "[score setup] loop closures: %d node pairs outside the chains, %d inside the Newton preconditioner (%d unknowns, %d chains, %d rounds)\n",
-                                     L.pairs_total, L.pairs_used, (int)L.ucol.size(), (int)L.items.size(), L.rounds);
+        if (st.verbose) std::fprintf(stderr, "[score setup] loop closures: %d node pairs outside the chains, %d inside the preconditioners (%d unknowns in %d groups, %d chains, %d rounds)\n",
+                                     L.pairs_total, L.pairs_used, (int)L.ucol.size(), (int)L.probs.size(), (int)L.items.size(), L.rounds);
         if (L.empty()) return;
         n_link_items = (int)L.items.size(); n_link_probs = (int)L.probs.size(); n_link_u = (int)L.ucol.size(); link_rounds = L.rounds;
         link_max_u = 0;
         for (const LinkProb& P : L.probs) link_max_u = std::max(link_max_u, (int)P.n_u);
         link_probs.upload(L.probs); link_items.upload(L.items);
         link_ucol.upload(L.ucol); link_uround.upload(L.uround); link_usuper.upload(L.usuper); link_mask.upload(L.mask);
-        link_pos.alloc(L.mask.size());
+        const bool sets[2] = {true, st.polish != 0 && Q.available};
+        {   // where an unknown's row is looked up: K of a replicated problem holds replica 0's rows, the Newton matrix every row
+            std::vector<int32_t> prob_of((size_t)n_link_u, 0);
+            for (const LinkProb& P : L.probs)
+                for (int a = 0; a < P.n_u; ++a) prob_of[(size_t)P.u_begin + a] = P.prob;
+            for (int set = 0; set < 2; ++set) {
+                if (!sets[set]) continue;
+                std::vector<int32_t> pc((size_t)n_link_u), ps((size_t)n_link_u, 0);
+                for (int u = 0; u < n_link_u; ++u) pc[(size_t)u] = set == 0 ? link_owner_col(h, prob_of[(size_t)u], L.ucol[(size_t)u], &ps[(size_t)u]) : L.ucol[(size_t)u];
+                link_pcol[set].upload(pc); link_pshift[set].upload(ps);
+            }
+        }
         ZeroGroup zl;
-        zl.add(link_status, (size_t)n_link_probs);
-        zl.add(link_Qt, L.mask.size()); zl.add(link_t, (size_t)n_link_u); zl.add(link_Zr, (size_t)link_rounds * (size_t)h.n_tot);
+        for (int set = 0; set < 2; ++set) {
+            if (!sets[set]) continue;
+            link_pos[set].alloc(L.mask.size());
+            zl.add(link_status[set], (size_t)n_link_probs); zl.add(link_Qt[set], L.mask.size()); zl.add(link_Zr[set], (size_t)link_rounds * (size_t)h.n_tot);
+        }
+        zl.add(link_t, (size_t)n_link_u);
         zl.add(link_rhs, (size_t)link_rounds * (size_t)h.n_tot); zl.add(link_zero, (size_t)h.count);
         zl.commit(stream);
         // (one launch applies the chain kernel to every round's right-hand side: a vector of n_tot per round)
@@ -2153,52 +2171,59 @@ struct HipBackend {
         if (n_join_seps) link_zb.alloc((size_t)link_rounds * (size_t)h.bs * (size_t)n_join_seps);
         HIP_CHECK(hipFuncSetAttribute((const void*)k_link_cap<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLinkMaxU * kLinkMaxU * (int)sizeof(double)));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_link_cap<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kLinkMaxU * kLinkMaxU * (int)sizeof(double)));
-        LinkArgs la = link_args();
-        hipLaunchKernelGGL(k_link_positions, dim3(16), dim3(kLinkThreads), 0, stream, la, n_link_probs);
+        for (int set = 0; set < 2; ++set) {
+            if (!sets[set]) continue;
+            link_set_on[set] = true;
+            LinkArgs la = link_args(set == 1);
+            hipLaunchKernelGGL(k_link_positions, dim3(16), dim3(kLinkThreads), 0, stream, la, n_link_probs);
+        }
+        LinkArgs la = link_args(false);
         hipLaunchKernelGGL(k_link_rhs, dim3((unsigned)((n_link_u + kLinkThreads - 1) / kLinkThreads)), dim3(kLinkThreads), 0, stream, la);
         HIP_CHECK(hipGetLastError());
+        link_refresh(false);  // (K's chains were factored before the plan existed; the Newton set's follow its first factorisation)
     }
-    LinkArgs link_args() {
+    LinkArgs link_args(bool newton_set) {
+        const int set = newton_set ? 1 : 0;
         LinkArgs la{};
         la.probs = link_probs.d; la.items = link_items.d; la.ucol = link_ucol.d; la.uround = link_uround.d; la.usuper = link_usuper.d;
-        la.mask = link_mask.d; la.pos = link_pos.d; la.Qt = link_Qt.d; la.t = link_t.d; la.Zr = link_Zr.d; la.rhs = link_rhs.d;
+        la.mask = link_mask.d; la.pcol = link_pcol[set].d; la.pshift = link_pshift[set].d; la.pos = link_pos[set].d;
+        la.Qt = link_Qt[set].d; la.t = link_t.d; la.Zr = link_Zr[set].d; la.rhs = link_rhs.d;
         la.n_tot = H->n_tot; la.rounds = link_rounds; la.n_u_total = n_link_u;
-        la.Hptr = Hm.ptr.d; la.Hcol = Hm.col.d; la.Hval = Hm.val.d;
-        la.chains = chainsH.d; la.node_col = node_col.d; la.done = link_zero.d; la.status = link_status.d;
+        if (newton_set) { la.Hptr = Hm.ptr.d; la.Hcol = Hm.col.d; la.Hval = Hm.val.d; }
+        else { la.Hptr = K.ptr.d; la.Hcol = K.col.d; la.Hval = K.val.d; }
+        la.chains = newton_set ? chainsH.d : chains.d; la.node_col = node_col.d; la.done = link_zero.d; la.status = link_status[set].d;
         return la;
     }
-    // after every factorisation of the Newton matrix's chains: the columns Z = T^-1 U (one application of the chain kernel --
-    // second level included -- per round) and Q = (I + G Z[U,:])^-1 G
-    void link_refresh() {
-        if (!n_link_items) return;
-        LinkArgs la = link_args();
+    // after every factorisation of a set's chains: the columns Z = T^-1 U (one application of the chain kernel -- second level
+    // included -- to every round's right-hand side at once) and Q = (I + G Z[U,:])^-1 G
+    void link_refresh(bool newton_set) {
+        if (!n_link_items || !link_set_on[newton_set ? 1 : 0]) return;
+        LinkArgs la = link_args(newton_set);
         PrecArgs pa{};
-        pa.work = prec_work.d; pa.chains = chainsH.d; pa.levels = levelsH.d; pa.rec = prec_recH.d; pa.fac = q_fac.d;
-        pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = q_dinv.d; pa.done = link_zero.d;
-        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = q_hblk_part.d; pa.uni = uni_for(hblocks());
+        pa.work = prec_work.d; pa.chains = newton_set ? chainsH.d : chains.d; pa.levels = newton_set ? levelsH.d : levels.d;
+        pa.rec = newton_set ? prec_recH.d : prec_rec.d; pa.fac = newton_set ? q_fac.d : fac.d;
+        pa.node_col = node_col.d; pa.diag_cols = diag_cols.d; pa.dinv = newton_set ? q_dinv.d : dinv.d; pa.done = link_zero.d;
+        pa.prec_part_ptr = prec_part_ptr.d; pa.kblk_part_ptr = newton_set ? q_hblk_part.d : kblk_part_ptr.d;
+        pa.uni = uni_for(newton_set ? hblocks() : kblocks());
         pa.r = link_rhs.d; pa.r_in = link_rhs.d; pa.p = link_tmp_p.d; pa.w = w.d; pa.xt = link_tmp_p.d; pa.kx = link_tmp_p.d;
         pa.pw_part = nullptr; pa.rz_in = nullptr; pa.rz_out = link_tmp_rz.d;
         // (the right-hand sides -- unit vectors, round r's in vector r -- were written once, at link_init: the chain kernel does
         //  not touch r_in)
-        pa.z = link_Zr.d;
+        pa.z = la.Zr;
         link_suspend = true;
-        if (split.active || link_rounds == 1) {  // (the split chain kernel takes one vector per launch)
-            for (int r = 0; r < link_rounds; ++r) {
-                pa.r = link_rhs.d + (size_t)r * (size_t)H->n_tot; pa.r_in = pa.r; pa.z = link_Zr.d + (size_t)r * (size_t)H->n_tot;
-                launch_prec<PREC_INIT>(pa);
-            }
-        } else {
+        if (link_rounds == 1) launch_prec<PREC_INIT>(pa);
+        else {
             pa.n_vec = link_rounds; pa.vec_stride = (long long)H->n_tot;
             launch_prec<PREC_INIT>(pa);
         }
         link_suspend = false;
-        // (up to 48 unknowns: one wavefront per problem, no block barriers; beyond: four wavefronts)
+        // (up to 48 unknowns: Gauss-Jordan on one wavefront, no block barriers; beyond: four wavefronts)
         if (link_max_u <= 48) hipLaunchKernelGGL(k_link_cap<true>, dim3((unsigned)n_link_probs), dim3(256), (size_t)2 * link_max_u * link_max_u * sizeof(double), stream, la);
         else hipLaunchKernelGGL(k_link_cap<false>, dim3((unsigned)n_link_probs), dim3(256), (size_t)2 * link_max_u * link_max_u * sizeof(double), stream, la);
     }
     template <int BS, int MODE>
-    void link_apply_bs(const PrecArgs& pa) {
-        LinkArgs la = link_args();
+    void link_apply_bs(const PrecArgs& pa, bool newton_set) {
+        LinkArgs la = link_args(newton_set);
         la.done = pa.done;
         la.r = (MODE == PREC_INIT) ? pa.r_in : pa.r;
         la.z = pa.z; la.p = pa.p; la.rz_out = pa.rz_out;
@@ -2210,12 +2235,12 @@ struct HipBackend {
         hipLaunchKernelGGL((k_link_apply<BS, MODE>), dim3((unsigned)n_link_items), dim3(kLinkApplyThreads), 0, stream, la);
     }
     template <int MODE>
-    void link_apply(const PrecArgs& pa) {
+    void link_apply(const PrecArgs& pa, bool newton_set) {
         switch (H->bs) {
-            case 1: link_apply_bs<1, MODE>(pa); break;
-            case 2: link_apply_bs<2, MODE>(pa); break;
-            case 3: link_apply_bs<3, MODE>(pa); break;
-            default: link_apply_bs<4, MODE>(pa); break;
+            case 1: link_apply_bs<1, MODE>(pa, newton_set); break;
+            case 2: link_apply_bs<2, MODE>(pa, newton_set); break;
+            case 3: link_apply_bs<3, MODE>(pa, newton_set); break;
+            default: link_apply_bs<4, MODE>(pa, newton_set); break;
         }
     }
 
@@ -2275,7 +2300,7 @@ struct HipBackend {
                                    fa.levels, (const int32_t*)deep_map.d, (const float*)shadow, newton_set ? deepH.d : deepK.d, fa.skip, bs * bs);
         }
         join_refresh(newton_set);  // (segmented long chains: separators' inverse diagonals, spikes, Schur factors)
-        if (newton_set) link_refresh();  // (loop closures: the Woodbury columns and the capacitance matrix, score_link.hpp)
+        link_refresh(newton_set);  // (loop closures: the Woodbury columns and the capacitance matrix, score_link.hpp)
     }
 
     ConeArgs cone_args(const double* gathered) {
@@ -2468,7 +2493,7 @@ struct HipBackend {
         // segmented long chains: the second level (score_join.hpp) after every application of the chain kernel
         if (n_join_items && !join_suspend && !pa.debug_skip) join_apply<MODE>(pa, newton_set);
         // loop closures (score_link.hpp): the Woodbury correction of the Newton set's chain solve
-        if (n_link_items && newton_set && !link_suspend && !join_suspend && !pa.debug_skip) link_apply<MODE>(pa);
+        if (n_link_items && link_set_on[newton_set ? 1 : 0] && !link_suspend && !join_suspend && !pa.debug_skip) link_apply<MODE>(pa, newton_set);
     }
     template <int BS, int MODE>
     void launch_prec_bs(const PrecArgs& pa_in, int slot, bool use_fac32) {
@@ -3074,8 +3099,11 @@ struct HipBackend {
             if (n_link_probs && out) {
                 std::vector<int32_t> stt((size_t)n_link_probs);
                 HIP_CHECK(sync_stream(stream));
-                HIP_CHECK(hipMemcpy(stt.data(), link_status.d, sizeof(int32_t) * (size_t)n_link_probs, hipMemcpyDeviceToHost));
-                for (int32_t x : stt) v[5] += x;
+                for (int set = 0; set < 2; ++set) {
+                    if (!link_set_on[set]) continue;
+                    HIP_CHECK(hipMemcpy(stt.data(), link_status[set].d, sizeof(int32_t) * (size_t)n_link_probs, hipMemcpyDeviceToHost));
+                    for (int32_t x : stt) v[5] += x;
+                }
             }
             if (out && len > 0) std::memcpy(out, v, sizeof(double) * (size_t)std::min<int64_t>(len, 6));
             return 6;

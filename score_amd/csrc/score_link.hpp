@@ -264,6 +264,18 @@ inline void make_link_plan(const HostSystem& h, const std::vector<int32_t>& pair
     for (const LinkProb& P : L.probs) L.max_items = std::max(L.max_items, (int)P.item_count);
 }
 
+// The column whose row of a row-replicated K holds the entries of `col` (K stores replica 0's rows: a column of replica k maps to
+// its replica-0 sibling; tail columns and general problems map to themselves).  `shift` receives the distance.
+inline int32_t link_owner_col(const HostSystem& h, int p, int32_t col, int32_t* shift = nullptr) {
+    int32_t sh = 0;
+    if (h.rep > 1) {
+        const int64_t local = (int64_t)col - h.xoff[(size_t)p], nr = h.rep_n[(size_t)p];
+        if (nr > 0 && local < (int64_t)h.rep * nr) sh = (int32_t)((local / nr) * nr);
+    }
+    if (shift) *shift = sh;
+    return col - sh;
+}
+
 #if defined(__HIPCC__)
 struct LinkArgs {
     const LinkProb* probs;
@@ -272,7 +284,9 @@ struct LinkArgs {
     const int32_t* uround;
     const int32_t* usuper;
     const uint8_t* mask;
-    int32_t* pos;            // per problem n_u x n_u: position of H[u_a, u_b] in the Newton matrix's values (-1: no entry of G)
+    const int32_t* pcol;     // per unknown: the column its row / column is looked up under (K of a replicated problem stores replica
+    const int32_t* pshift;   //   0's rows: link_owner_col; otherwise the unknown's own column) and the distance to it
+    int32_t* pos;            // per group n_u x n_u: position of M[u_a, u_b] in the matrix's values (-1: no entry of G)
     double* Qt;              // per problem n_u x n_u: Q transposed (thread a of k_link_solve reads Qt[b n_u + a])
     double* t;               // per unknown: t = Q y[U]
     double* Zr;              // rounds x n_tot: round r's applications of the chain kernel
@@ -297,7 +311,9 @@ __global__ __launch_bounds__(kLinkThreads) void k_link_positions(LinkArgs a, int
         const LinkProb P = a.probs[q];
         for (int e = blockIdx.x * kLinkThreads + threadIdx.x; e < P.n_u * P.n_u; e += gridDim.x * kLinkThreads) {
             const int ua = e / P.n_u, ub = e - ua * P.n_u;
-            a.pos[P.q_off + e] = a.mask[P.q_off + e] ? hb_find(a.Hptr, a.Hcol, a.ucol[P.u_begin + ua], a.ucol[P.u_begin + ub]) : -1;
+            // (a loop closure couples row k with row k: both unknowns in the same replica)
+            const bool same = a.pshift[P.u_begin + ua] == a.pshift[P.u_begin + ub];
+            a.pos[P.q_off + e] = (a.mask[P.q_off + e] && same) ? hb_find(a.Hptr, a.Hcol, a.pcol[P.u_begin + ua], a.pcol[P.u_begin + ub]) : -1;
         }
     }
 }

@@ -116,12 +116,12 @@ def _runtime_s(info: dict) -> float:
 
 
 def _loop_closure_settings(settings: dict, user: Optional[dict], has_loop_closures: bool, lib_path: Optional[str]) -> None:
-    """Loop closures (gurobi_utils.py:407-430) are stiff couplings outside the per-robot chains the ADMM loop's preconditioner
-    captures.  Where the splitting loop has to converge by itself -- polish off, the plain QCQP loop, or the oracle's CPU twin, which
-    has no polish -- such graphs start with 16 PCG iterations per KKT solve.  The default solver does not need that any more: its
-    Newton preconditioner carries the loop closures (round 6, csrc/score_link.hpp), and six warm-up iterations at 16 PCG
-    iterations each had become a fifth of the solve (profiles/r06_lc_warmup.txt: 150 -> 119 ms over 19 graphs, same optima)."""
-    if not has_loop_closures or "cg_iters" in (user or {}):
+    """Loop closures (gurobi_utils.py:407-430) are stiff couplings outside the per-robot chains.  Since round 6 both preconditioners
+    carry them (csrc/score_link.hpp: the ADMM loop's K and the Newton matrix; the oracle's CPU twin restates the correction), and
+    such graphs run with the default 2 PCG iterations per KKT solve -- measured on the twin, 2 x 397 poses with 2 loop closures,
+    ADMM alone: 3 900 PCG iterations against 37 600 with the 16 per step of rounds 1-5.  Only with the correction switched off
+    (SCORE_NO_LINKS) does a run in which the ADMM loop has to converge by itself get those 16 back."""
+    if not has_loop_closures or "cg_iters" in (user or {}) or not os.environ.get("SCORE_NO_LINKS"):
         return
     alone = not int(settings.get("polish", 1)) or bool(os.environ.get("SCORE_QCQP_PLAIN"))
     if not alone:
