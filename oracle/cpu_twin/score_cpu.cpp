@@ -268,6 +268,7 @@ struct CpuBackend {
     // linear mode: the same PCG as the loop above (precond() + row_dot), run to r'M^-1 r <= tol^2 r0'M^-1 r0
     bool linear_solve(const HostSystem& h, const double* rhs, double* x, double rel_tol, int max_iters, int* used_out) {
         const int64_t n = h.n_tot;
+        link_refresh();  // (the driver has just refactored the chains for the values of this solve)
         std::vector<double> xs((size_t)n, 0.0);
         for (int64_t i = 0; i < n; ++i) r[i] = rhs[i];
         double rz = 0.0;
