@@ -21,7 +21,8 @@
 // z -= Z t, and the chain's r'z partial sum restated with the corrected z) -- two launches because the first reads what the
 // second overwrites, as in score_join.hpp.  Graphs without loop closures never come here (n_items == 0: no launch, no buffer).
 //
-// The ADMM loop's K keeps T alone (the default solver runs six ADMM iterations); SCORE_NO_LINKS=1 switches the correction off.
+// Two sets of these buffers (HipBackend::link_*[2]): one for the ADMM loop's K (refreshed with every penalty change), one
+// for the Newton matrix H (refreshed with every k_factor).  SCORE_NO_LINKS=1 switches the correction off for both.
 #pragma once
 
 #include <algorithm>
