@@ -64,32 +64,7 @@ thread_local std::string g_err;
 // not run dry while its driver sleeps.  Rounds 4-5 spun, then yielded: with idle CPUs around a yield returns at once, and every
 // driver thread burnt a full CPU for the length of its solves -- 2.6-2.8 ms of host CPU per problem (BENCH_r05), which caps eight
 // ranks on the 16 CPUs the boxes grant at a third of the GPUs' capacity.
-struct HostWaitStats {
-    std::atomic<long long> spin_ns{0}, sleep_ns{0}, waits{0}, sleeps{0};
-    std::atomic<int> active_solves{0};
-};
-inline HostWaitStats& wait_stats() { static HostWaitStats s; return s; }
-constexpr long kEconomySleepNs = 25000;
-constexpr int kEconomyDepth = 6;
-// Policy (SCORE_WAIT_POLICY = auto | spin | economy; default auto): economy when the waiting drivers would take more than half
-// of the CPUs this rank may use (host_threads(): affinity, cgroup quota, LOCAL_WORLD_SIZE) -- measured on one MI355X box with 16
-// CPUs granted, 64 fresh graphs per sweep on 4 driver threads: spinning 2 232-2 267 problems/s at 2.3-2.5 ms of CPU per problem,
-// economy 2 073-2 098 at 1.36-1.53 (profiles/r06_economy_ab.txt): a lone rank with idle CPUs keeps the 7 %, eight ranks on those 16
-// CPUs (two each) cannot afford 4 spinning drivers per rank and sleep.
-inline int wait_policy() {  // 0 auto, 1 spin, 2 economy
-    static const int v = [] {
-        const char* e = std::getenv("SCORE_WAIT_POLICY");
-        if (!e) return 0;
-        const std::string s(e);
-        return s == "spin" ? 1 : s == "economy" ? 2 : 0;
-    }();
-    return v;
-}
-inline bool economy_waits() {
-    const int pol = wait_policy();
-    if (pol) return pol == 2;
-    return 2 * wait_stats().active_solves.load(std::memory_order_relaxed) > host_threads();
-}
+// (HostWaitStats, wait_policy(), economy_waits(): score_host.hpp -- the host thread teams follow the same policy)
 inline void economy_sleep() {
     static thread_local bool slack_set = false;
     if (!slack_set) { prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0); slack_set = true; }  // (default 50 us: a 25 us sleep would take 75)

@@ -106,6 +106,34 @@ inline int host_threads() {
     return n;
 }
 
+// ---- how host threads wait (the drivers for the device: score_hip.hip; the team workers for their next job: below) ----
+struct HostWaitStats {
+    std::atomic<long long> spin_ns{0}, sleep_ns{0}, waits{0}, sleeps{0};
+    std::atomic<int> active_solves{0};
+};
+inline HostWaitStats& wait_stats() { static HostWaitStats s; return s; }
+constexpr long kEconomySleepNs = 25000;
+constexpr int kEconomyDepth = 6;
+// Policy (SCORE_WAIT_POLICY = auto | spin | economy; default auto): economy when the waiting drivers would take more than half
+// of the CPUs this rank may use (host_threads(): affinity, cgroup quota, LOCAL_WORLD_SIZE) -- measured on one MI355X box with 16
+// CPUs granted, 64 fresh graphs per sweep on 4 driver threads: spinning 2 232-2 267 problems/s at 2.3-2.5 ms of CPU per problem,
+// economy 2 073-2 098 at 1.36-1.53 (profiles/r06_economy_ab.txt): a lone rank with idle CPUs keeps the 7 %, eight ranks on those 16
+// CPUs (two each) cannot afford 4 spinning drivers per rank and sleep.
+inline int wait_policy() {  // 0 auto, 1 spin, 2 economy
+    static const int v = [] {
+        const char* e = std::getenv("SCORE_WAIT_POLICY");
+        if (!e) return 0;
+        const std::string s(e);
+        return s == "spin" ? 1 : s == "economy" ? 2 : 0;
+    }();
+    return v;
+}
+inline bool economy_waits() {
+    const int pol = wait_policy();
+    if (pol) return pol == 2;
+    return 2 * wait_stats().active_solves.load(std::memory_order_relaxed) > host_threads();
+}
+
 // The thread budget.  Handles are created concurrently (the lock-step groups of solve_score_batch, one host thread
 // each; the polish structures of a handle on a thread of their own; model construction on a pool): every such
 // builder opens a BuildScope for its duration, and every parallel region takes, at the moment it starts, what is
@@ -146,7 +174,11 @@ struct BuildScope {
 // variable, and the caller spins for the last part before it sleeps: the parallel phases of one setup follow each other
 // within tens of microseconds, and waking 15 sleepers through one mutex cost 0.1-0.2 ms per phase -- more than many of
 // the phases themselves (a headline score_create is ~29 ms of single-thread work and took 10 ms on 16 threads).
-constexpr int team_spin_us() { return 120; }
+// Round 6, under economy waits (several drivers / ranks share the CPUs): a worker spins for 20 us, and only when it TOOK PART in
+// the job before -- notify_all wakes the whole team, and a region of four parts left eleven workers spinning for 120 us each:
+// the team workers were half of the host CPU of a fresh-graph sweep (profiles/r06_economy_ab.txt: 1.30 -> 1.07 ms per problem).
+// With CPUs to spare everybody keeps the 120 us (cold workers asleep cost a headline score_create 0.3 ms).
+inline int team_spin_us(bool warm = true) { return economy_waits() ? (warm ? 20 : 0) : 120; }
 struct HostTeam {
     std::mutex m;
     std::condition_variable cv_work, cv_done;
@@ -160,8 +192,7 @@ struct HostTeam {
     explicit HostTeam(int n_workers) {
         for (int w = 0; w < n_workers; ++w) workers.emplace_back([this, w] { loop(w + 1); });
     }
-    static bool spin_until(const std::function<bool()>& ready) {
-        const int limit = team_spin_us();
+    static bool spin_until(const std::function<bool()>& ready, int limit) {
         if (limit <= 0) return ready();
         const auto t0 = std::chrono::steady_clock::now();
         for (int i = 0;; ++i) {
@@ -176,11 +207,13 @@ struct HostTeam {
     }
     void loop(int part) {
         uint64_t seen = 0;
+        bool warm = false;  // took part in the job before: the next phase of the same setup follows within tens of microseconds
         for (;;) {
-            if (!spin_until([&] { return gen.load(std::memory_order_acquire) != seen; })) {
+            if (!spin_until([&] { return gen.load(std::memory_order_acquire) != seen; }, team_spin_us(warm))) {
                 std::unique_lock<std::mutex> lk(m);
                 cv_work.wait(lk, [&] { return gen.load(std::memory_order_acquire) != seen; });
             }
+            warm = false;
             const uint64_t g = gen.load(std::memory_order_acquire);
             const std::function<void(int)>* j = slot[g & 1].job.load(std::memory_order_relaxed);
             const int parts = slot[g & 1].parts.load(std::memory_order_relaxed);
@@ -191,6 +224,7 @@ struct HostTeam {
             seen = g;
             if (part >= parts) continue;
             (*j)(part);
+            warm = true;
             if (remaining.fetch_sub(1, std::memory_order_acq_rel) == 1) {
                 std::lock_guard<std::mutex> lk(m);
                 cv_done.notify_one();
@@ -208,7 +242,7 @@ struct HostTeam {
         }
         cv_work.notify_all();
         f(0);
-        if (!spin_until([&] { return remaining.load(std::memory_order_acquire) == 0; })) {
+        if (!spin_until([&] { return remaining.load(std::memory_order_acquire) == 0; }, team_spin_us())) {
             std::unique_lock<std::mutex> lk(m);
             cv_done.wait(lk, [&] { return remaining.load(std::memory_order_acquire) == 0; });
         }

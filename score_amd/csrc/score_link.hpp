@@ -490,21 +490,22 @@ constexpr int kLinkBatch = 8;
 struct LinkApplyLds {
     double red[16];
     double ts[kLinkMaxRounds + kLinkBatch];
-    double traw[kLinkMaxRounds];
     int rr[kLinkMaxRounds + kLinkBatch];
     int n_act;
 };
+// (`it` stays in global memory: a copy of the 212-byte record indexed by the lane number would live in scratch)
 template <int BS, int MODE>
 __device__ __forceinline__ void link_apply_chain(const LinkArgs& a, const LinkItem& it, const double* tw, int u_base, LinkApplyLds& L) {
+    static_assert(kLinkMaxRounds <= 64, "the rounds of a chain are compacted by one wavefront");
     const int t = threadIdx.x;
-    if (t < kLinkMaxRounds) L.traw[t] = (t < a.rounds && it.u[t] >= 0) ? tw[it.u[t] - u_base] : 0.0;  // (every round's weight requested at once)
-    __syncthreads();
-    if (t == 0) {
-        int k = 0;
-        for (int r = 0; r < a.rounds; ++r)
-            if (it.u[r] >= 0) { L.rr[k] = r; L.ts[k] = L.traw[r]; ++k; }
-        L.n_act = k;
-        for (int q = 0; q < kLinkBatch; ++q) { L.rr[k + q] = k ? L.rr[k - 1] : 0; L.ts[k + q] = 0.0; }  // (padding: a valid column of Z, weight 0)
+    if (t < 64) {  // the rounds this chain carries, in order, by ballot: every round's weight requested at once
+        const int u = t < a.rounds ? it.u[min(t, kLinkMaxRounds - 1)] : -1;
+        const double w = u >= 0 ? tw[max(u, u_base) - u_base] : 0.0;
+        const unsigned long long m = __ballot(u >= 0);
+        const int k = __popcll(m & ((1ull << t) - 1ull)), n = __popcll(m);
+        if (u >= 0) { L.rr[k] = t; L.ts[k] = w; }
+        if (t < kLinkBatch) { L.rr[n + t] = m ? 63 - __clzll((long long)m) : 0; L.ts[n + t] = 0.0; }  // (padding: a valid column of Z, weight 0)
+        if (t == 0) L.n_act = n;
     }
     __syncthreads();
     const int na = L.n_act;
@@ -554,7 +555,7 @@ __device__ __forceinline__ void link_apply_chain(const LinkArgs& a, const LinkIt
 template <int BS, int MODE>
 __global__ __launch_bounds__(kLinkApplyThreads) void k_link_apply(LinkArgs a) {
     __shared__ LinkApplyLds L;
-    const LinkItem it = a.items[blockIdx.x];
+    const LinkItem& it = a.items[blockIdx.x];
     if (a.done[it.prob]) return;
     link_apply_chain<BS, MODE>(a, it, a.t, 0, L);
 }
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(kLinkApplyThreads) void k_link_group(LinkArgs a) {
     }
     __syncthreads();
     for (int i = 0; i < P.item_count; ++i) {
-        const LinkItem it = a.items[P.item_begin + i];
+        const LinkItem& it = a.items[P.item_begin + i];
         link_apply_chain<BS, MODE>(a, it, tg, P.u_begin, L);
         __syncthreads();
     }
