@@ -1025,8 +1025,37 @@ struct HipBackend {
         DevBuf<double> o0, o1;
         DevBuf<long long> result;
     };
+    // rows' records contiguous and in row order (offsets row_off[0 .. n_rows]): every row sorted by (column, position) into
+    // key_out / idx_out (score_setup_device.hpp, k_row_rank_sort); sk0 / sk1: two scratch arrays of rec_max keys for the long rows
+    static int pos_bits(int64_t rec_max) { int b = 1; while (((int64_t)1 << b) < rec_max) ++b; return b; }
+    struct RowSort {
+        DevBuf<int32_t> seg;   // begin[cap], end[cap], count
+        int32_t cap = 0;
+        size_t bytes = 0;
+    };
+    void sort_rows_plan(RowSort& rs, int64_t n_rows, int64_t rec_max, int bits, unsigned long long* sk0, unsigned long long* sk1) {
+        rs.cap = (int32_t)(rec_max / kShortRow + 1);
+        rs.seg.alloc((size_t)2 * rs.cap + 1);
+        HIP_CHECK(rocprim::segmented_radix_sort_keys(nullptr, rs.bytes, sk0, sk1, (unsigned)rec_max, (unsigned)rs.cap, rs.seg.d, rs.seg.d + rs.cap, 0,
+                                                     (unsigned)(bits + pos_bits(rec_max)), stream));
+    }
+    void sort_rows(RowSort& rs, int64_t n_rows, int64_t rec_max, int bits, const unsigned long long* key_in, unsigned long long* key_out, uint32_t* idx_out,
+                   unsigned long long* sk0, unsigned long long* sk1, const long long* row_off, void* scratch, const uint32_t* idx_in = nullptr) {
+        RowSortArgs a{};
+        a.key = key_in; a.idx = idx_in; a.off = row_off; a.key_out = key_out; a.idx_out = idx_out; a.sk = sk0;
+        a.seg_b = rs.seg.d; a.seg_e = rs.seg.d + rs.cap; a.seg_n = rs.seg.d + 2 * rs.cap; a.seg_cap = rs.cap;
+        a.rec_max = rec_max; a.n_rows = n_rows; a.pbits = pos_bits(rec_max);
+        const unsigned grec = (unsigned)((rec_max + 255) / 256);
+        HIP_CHECK(hipMemsetAsync(rs.seg.d, 0, ((size_t)2 * rs.cap + 1) * sizeof(int32_t), stream));
+        hipLaunchKernelGGL(k_row_rank_sort, dim3(grec), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(k_rows_long_list, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, a);
+        HIP_CHECK(rocprim::segmented_radix_sort_keys(scratch, rs.bytes, sk0, sk1, (unsigned)rec_max, (unsigned)rs.cap, a.seg_b, a.seg_e, 0,
+                                                     (unsigned)(bits + a.pbits), stream));
+        a.sk = sk1;
+        hipLaunchKernelGGL(k_row_keys_back, dim3(grec), dim3(256), 0, stream, a);
+    }
     void merge_records(int64_t n_rows, int64_t rec_max, DevBuf<unsigned long long>& key0, DevBuf<uint32_t>& idx0, const double* v0,
-                       const double* v1, int32_t qcol, double* qout, MergeOut& out) {
+                       const double* v1, int32_t qcol, double* qout, MergeOut& out, const long long* row_off = nullptr) {
         DevBuf<unsigned long long> key1, flag, flag_s;
         DevBuf<uint32_t> idx1;
         DevBuf<int32_t> row_cnt;
@@ -1036,20 +1065,42 @@ struct HipBackend {
         long_run.alloc((size_t)long_max);
         out.ptr.alloc((size_t)n_rows + 1); out.col.alloc((size_t)rec_max + 64); out.o0.alloc((size_t)rec_max + 64);
         if (v1) out.o1.alloc((size_t)rec_max + 64);
+        // records in no particular order (the assembler's): into their rows' slots first -- count, scan, scatter
+        DevBuf<unsigned long long> key_b;
+        DevBuf<uint32_t> idx_b;
+        DevBuf<long long> cnt_b;
+        DevBuf<unsigned int> cur_b;
+        const bool bucket = !row_off;
         {
             ZeroGroup zg;
             zg.add(row_cnt, (size_t)n_rows + 1); zg.add(out.result, 2);
+            if (bucket) { zg.add(cnt_b, (size_t)n_rows + 2); zg.add(cur_b, (size_t)n_rows + 1); }
             zg.commit(stream);
         }
         int bits = 1;
         while (((int64_t)1 << bits) <= n_rows) ++bits;  // (the padding row n_rows sorts last)
-        size_t tb = 0, tb2 = 0, tb3 = 0;
-        HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb, key0.d, key1.d, idx0.d, idx1.d, (size_t)rec_max, 0, 32 + bits, stream));
+        if (qcol >= 0) bits = 31;                         // (the q records' column, kQCol, is the largest there is)
+        size_t tb = 0, tb2 = 0, tb3 = 0, tb4 = 0;
+        if (bucket) {
+            key_b.alloc((size_t)rec_max); idx_b.alloc((size_t)rec_max);
+            HIP_CHECK(rocprim::exclusive_scan(nullptr, tb4, cnt_b.d, cnt_b.d, (long long)0, (size_t)n_rows + 2, rocprim::plus<long long>(), stream));
+        }
+        RowSort rs;
+        sort_rows_plan(rs, n_rows, rec_max, bits, flag.d, flag_s.d);  // (the flag arrays are free until k_rec_flags)
+        tb = rs.bytes;
         HIP_CHECK(rocprim::inclusive_scan(nullptr, tb2, flag.d, flag_s.d, (size_t)rec_max, rocprim::plus<unsigned long long>(), stream));
         HIP_CHECK(rocprim::exclusive_scan(nullptr, tb3, row_cnt.d, out.ptr.d, (int32_t)0, (size_t)n_rows + 1, rocprim::plus<int32_t>(), stream));
         DevBuf<unsigned char> scratch;
-        scratch.alloc(std::max(tb, std::max(tb2, tb3)) + 256);
-        HIP_CHECK(rocprim::radix_sort_pairs((void*)scratch.d, tb, key0.d, key1.d, idx0.d, idx1.d, (size_t)rec_max, 0, 32 + bits, stream));
+        scratch.alloc(std::max(std::max(tb, tb4), std::max(tb2, tb3)) + 256);
+        if (bucket) {
+            const unsigned grec0 = (unsigned)((rec_max + 255) / 256);
+            hipLaunchKernelGGL(k_rec_count, dim3(grec0), dim3(256), 0, stream, (const unsigned long long*)key0.d, rec_max, n_rows, (unsigned long long*)cnt_b.d);
+            HIP_CHECK(rocprim::exclusive_scan((void*)scratch.d, tb4, cnt_b.d, cnt_b.d, (long long)0, (size_t)n_rows + 2, rocprim::plus<long long>(), stream));
+            hipLaunchKernelGGL(k_rec_scatter, dim3(grec0), dim3(256), 0, stream, (const unsigned long long*)key0.d, (const uint32_t*)idx0.d, rec_max, n_rows,
+                               (const long long*)cnt_b.d, cur_b.d, key_b.d, idx_b.d);
+            hipLaunchKernelGGL(k_rec_pad, dim3(grec0), dim3(256), 0, stream, key_b.d, idx_b.d, (const long long*)(cnt_b.d + n_rows), rec_max, n_rows);
+            sort_rows(rs, n_rows, rec_max, bits, key_b.d, key1.d, idx1.d, flag.d, flag_s.d, cnt_b.d, (void*)scratch.d, idx_b.d);
+        } else sort_rows(rs, n_rows, rec_max, bits, key0.d, key1.d, idx1.d, flag.d, flag_s.d, row_off, (void*)scratch.d);
         RecArgs ra{};
         ra.n_rows = n_rows; ra.rec_max = rec_max; ra.key = key1.d; ra.idx = idx1.d; ra.v0 = v0; ra.v1 = v1;
         ra.flag = flag.d; ra.row_cnt = row_cnt.d; ra.col = out.col.d; ra.o0 = out.o0.d; ra.o1 = v1 ? out.o1.d : nullptr;
@@ -1461,7 +1512,7 @@ struct HipBackend {
         hipLaunchKernelGGL(k_kb_expand<64>, dim3(g64), dim3(256), 0, stream, ka);
         hipLaunchKernelGGL(k_rec_pad, dim3((unsigned)((rec_max + 255) / 256)), dim3(256), 0, stream, key0.d, kidx0.d, (const long long*)(kcnt.d + n), rec_max, n);
         MergeOut mo;
-        merge_records(n, rec_max, key0, kidx0, v0.d, v1.d, -1, nullptr, mo);
+        merge_records(n, rec_max, key0, kidx0, v0.d, v1.d, -1, nullptr, mo, (const long long*)kcnt.d);  // (kcnt: the rows' record offsets)
         pt.mark("  device setup: G1 / G2 / A / K queued");
         // ---- first trip back: counts, row pointers, norms ----
         struct Pinned {
@@ -3447,7 +3498,9 @@ struct HipBackend {
             int bits = 1;
             while (((int64_t)1 << bits) <= n) ++bits;  // (the sentinel row n sorts last)
             HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, cnt.d, off.d, (long long)0, (size_t)n + 1, rocprim::plus<long long>(), stream));
-            HIP_CHECK(rocprim::radix_sort_pairs(nullptr, tb2, key0.d, key1.d, idx0.d, idx1.d, (size_t)rec_max, 0, 32 + bits, stream));
+            RowSort rs;  // (every row's records sorted where they lie: sort_rows)
+            sort_rows_plan(rs, n, rec_max, bits, flag.d, flag_s.d);
+            tb2 = rs.bytes;
             HIP_CHECK(rocprim::inclusive_scan(nullptr, tb3, flag.d, flag_s.d, (size_t)rec_max, rocprim::plus<unsigned long long>(), stream));
             DevBuf<unsigned char> scratch;
             scratch.alloc(std::max(tb, std::max(tb2, tb3)) + 256);
@@ -3456,7 +3509,7 @@ struct HipBackend {
             hipLaunchKernelGGL(k_hb_expand<8>, dim3(g8), dim3(256), 0, stream, a);
             hipLaunchKernelGGL(k_hb_expand<64>, dim3(g64), dim3(256), 0, stream, a);
             hipLaunchKernelGGL(k_hb_pad, dim3(grec), dim3(256), 0, stream, a);
-            HIP_CHECK(rocprim::radix_sort_pairs((void*)scratch.d, tb2, key0.d, key1.d, idx0.d, idx1.d, (size_t)rec_max, 0, 32 + bits, stream));
+            sort_rows(rs, n, rec_max, bits, key0.d, key1.d, idx1.d, flag.d, flag_s.d, off.d, (void*)scratch.d);
             HScatterArgs sa{};
             sa.n = n; sa.rec_max = rec_max; sa.key = key1.d; sa.idx = idx1.d; sa.rcone = rcone.d; sa.rab = rab.d; sa.rcoef = rcoef.d;
             sa.flag = flag.d; sa.Hcol = Hm.col.d; sa.Hrow = hrow.d; sa.Pon = q_Pon.d; sa.cptr = q_cptr.d;

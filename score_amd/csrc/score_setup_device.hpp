@@ -386,6 +386,93 @@ __global__ __launch_bounds__(256) void k_rec_pad(unsigned long long* __restrict_
     idx[s] = 0;
 }
 
+// ---- records laid out row by row (the K and Newton-matrix builders: every row's records are contiguous, the rows in order) ----
+// The stable sort by (row, column) is then a sort of every row's records by (column, position): position is unique, so whatever a
+// sort does with ties the order is the stable one.  Round 5 sent every record through seven onesweep passes of a 50-bit key (a third
+// of a create's kernel time, two runtime fills per pass).  Round 6: a row of at most kShortRow records is sorted by RANK -- a lane
+// per record counts the row's records that come before its own (the row's keys are read by all of its lanes at once: broadcasts out
+// of L1) and writes the record to its place; the few long rows (landmark rows: thousands of records) are listed and go through a
+// segmented radix sort (rocprim: a block per row) with key = column << pbits | position, pbits = the bits of rec_max.
+// (rocprim's segmented sort for ALL rows was tried first: its warp-sort kernel for small segments took 246 us for 218 k rows.)
+constexpr int kShortRow = 128;
+struct RowSortArgs {
+    const unsigned long long* key;   // records, row << 32 | column (tail: row n_rows)
+    const uint32_t* idx;             // position of a record before it was put into its row's slots (nullptr: where it lies)
+    const long long* off;            // n_rows + 1 record offsets
+    unsigned long long* key_out; uint32_t* idx_out;
+    unsigned long long* sk;          // sort keys of the long rows' records (in: k_row_rank_sort writes, out: k_row_keys_back reads)
+    int32_t* seg_b; int32_t* seg_e; int32_t* seg_n; int32_t seg_cap;   // the long rows as segments (unused entries stay [0, 0))
+    int64_t rec_max, n_rows;
+    int pbits;
+};
+__global__ __launch_bounds__(256) void k_row_rank_sort(RowSortArgs a) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.rec_max) return;
+    const unsigned long long k = a.key[s];
+    const int64_t row = (int64_t)(k >> 32);
+    if (row >= a.n_rows) { a.key_out[s] = k; a.idx_out[s] = 0; return; }  // the padding tail
+    const int64_t b = a.off[row], e = a.off[row + 1];
+    const uint32_t mine = (uint32_t)k;
+    const uint32_t me = a.idx ? a.idx[s] : (uint32_t)s;
+    if (e - b > kShortRow) { a.sk[s] = ((unsigned long long)mine << a.pbits) | (unsigned long long)me; return; }
+    const uint32_t* __restrict__ cols = reinterpret_cast<const uint32_t*>(a.key);  // (little-endian: the column is the low word)
+    int rank = 0;
+    for (int64_t j0 = b; j0 < e; j0 += 4) {
+        uint32_t c[4], o[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = min(j0 + u, e - 1);
+            c[u] = cols[2 * j];
+            o[u] = a.idx ? a.idx[j] : (uint32_t)j;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rank += (j0 + u < e && (c[u] < mine || (c[u] == mine && o[u] < me))) ? 1 : 0;
+    }
+    a.key_out[b + rank] = k;
+    a.idx_out[b + rank] = me;
+}
+// records in no particular order (the assembler's: measurement by measurement) into their rows' slots: count, scan, scatter -- the
+// order inside a row is whatever the atomics make it; the sort by (column, original position) that follows does not depend on it
+// (the padding records -- switched-off slots anywhere in the array, all of row n_rows -- take no part: a hundred thousand atomics on
+//  ONE counter took 3 ms; the tail of the row-ordered arrays is padded afterwards, k_rec_pad)
+__global__ __launch_bounds__(256) void k_rec_count(const unsigned long long* __restrict__ key, int64_t rec_max, int64_t n_rows, unsigned long long* __restrict__ cnt) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= rec_max) return;
+    const int64_t row = (int64_t)(key[s] >> 32);
+    if (row < n_rows) atomicAdd(&cnt[row], 1ull);
+}
+__global__ __launch_bounds__(256) void k_rec_scatter(const unsigned long long* __restrict__ key, const uint32_t* __restrict__ idx, int64_t rec_max, int64_t n_rows,
+                                                     const long long* __restrict__ off, unsigned int* __restrict__ cur,
+                                                     unsigned long long* __restrict__ key_b, uint32_t* __restrict__ idx_b) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= rec_max) return;
+    const unsigned long long k = key[s];
+    const int64_t row = (int64_t)(k >> 32);
+    if (row >= n_rows) return;
+    const int64_t at = off[row] + (int64_t)atomicAdd(&cur[row], 1u);
+    key_b[at] = k;
+    idx_b[at] = idx[s];
+}
+__global__ __launch_bounds__(256) void k_rows_long_list(RowSortArgs a) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= a.n_rows) return;
+    const int64_t b = a.off[r], e = a.off[r + 1];
+    if (e - b <= kShortRow) return;
+    const int at = atomicAdd(a.seg_n, 1);
+    if (at < a.seg_cap) { a.seg_b[at] = (int32_t)b; a.seg_e[at] = (int32_t)e; }
+}
+// ... and back, for the long rows: slot s keeps its row (a row's records stay in the row's slots)
+__global__ __launch_bounds__(256) void k_row_keys_back(RowSortArgs a) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= a.rec_max) return;
+    const unsigned long long k = a.key[s];
+    const int64_t row = (int64_t)(k >> 32);
+    if (row >= a.n_rows || a.off[row + 1] - a.off[row] <= kShortRow) return;
+    const unsigned long long v = a.sk[s];
+    a.key_out[s] = (k & 0xffffffff00000000ull) | (v >> a.pbits);
+    a.idx_out[s] = (uint32_t)(v & ((1ull << a.pbits) - 1ull));
+}
+
 // ---- K = P + sigma I + rho A'A as K0 + rho K1: the records of every stored row (append_problem, score_host.hpp) ----
 struct KBuildArgs {
     int64_t n;
