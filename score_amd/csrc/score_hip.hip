@@ -26,6 +26,7 @@
 #include <malloc.h>
 #include <mutex>
 #include <string>
+#include <optional>
 #include <vector>
 
 #include "score_driver.hpp"
@@ -369,6 +370,7 @@ struct StageArena {
         if (!bytes) return true;
         if (bytes > stage_limit_bytes()) return false;
         if (inflight + bytes > kMaxInflight && inflight > 0) {  // everything queued so far has to leave its slots: start over
+            flush();
             HIP_CHECK(sync_stream(st));
             inflight = 0; at = 0;
             cur = chunks.empty() ? nullptr : (char*)chunks[0];
@@ -379,9 +381,32 @@ struct StageArena {
             score::parallel_ranges((int64_t)bytes, (int64_t)1 << 19, [&](int, int64_t b0, int64_t b1) { std::memcpy(pin + b0, (const char*)src + b0, (size_t)(b1 - b0)); });
         else
             std::memcpy(pin, src, bytes);
-        HIP_CHECK(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, st));
         inflight += bytes;
+        if (batch_depth > 0) {
+            // Inside an UploadBatch: tables that follow each other go up in ONE transfer when both their pinned slots and their
+            // device buffers are neighbours (both arenas hand out 256-byte-aligned pieces in order, so a run of `x.upload(v)` calls
+            // is exactly that).  The alignment gap between two of them is sent as zeros: it belongs to no buffer (or is the zeroed
+            // padding of upload_padded).  Nothing that reads the tables may be launched before the batch closes.
+            const size_t span = (pend_bytes + 255) & ~(size_t)255;
+            if (pend_bytes && pend_st == st && pend_dst + span == (char*)dst && pend_pin + span == pin) {
+                if (span > pend_bytes) std::memset(pend_pin + pend_bytes, 0, span - pend_bytes);
+                pend_bytes = span + bytes;
+            } else {
+                flush();
+                pend_dst = (char*)dst; pend_pin = pin; pend_bytes = bytes; pend_st = st;
+            }
+            return true;
+        }
+        HIP_CHECK(hipMemcpyAsync(dst, pin, bytes, hipMemcpyHostToDevice, st));
         return true;
+    }
+    int batch_depth = 0;
+    char* pend_dst = nullptr; char* pend_pin = nullptr; size_t pend_bytes = 0; hipStream_t pend_st = nullptr;
+    void flush() {
+        if (!pend_bytes) return;
+        const size_t nb = pend_bytes;
+        pend_bytes = 0;
+        HIP_CHECK(hipMemcpyAsync(pend_dst, pend_pin, nb, hipMemcpyHostToDevice, pend_st));
     }
     // (the caller has synchronised the stream the transfers were queued on)
     void release() {
@@ -392,6 +417,20 @@ struct StageArena {
     ~StageArena() { release(); }
 };
 thread_local StageArena* tl_stage = nullptr;  // set while a handle's setup uploads on this thread
+// A run of small uploads with no launch in between (round 6: a create issued ~60 transfers of 2-5 us each, most of them tables
+// that follow each other): opened around such a run, closed (= the merged transfers queued) before anything reads the tables.
+struct UploadBatch {
+    StageArena* a;
+    UploadBatch() : a(tl_stage) { if (a) ++a->batch_depth; }
+    ~UploadBatch() {
+        if (!a) return;
+        if (--a->batch_depth == 0) {
+            try { a->flush(); } catch (...) { a->pend_bytes = 0; }  // (a failed transfer surfaces at the next checked call on the stream)
+        }
+    }
+    UploadBatch(const UploadBatch&) = delete;
+    UploadBatch& operator=(const UploadBatch&) = delete;
+};
 
 // Host <-> device copies never hand PAGEABLE memory to the runtime.  For a transfer of a megabyte or more the runtime registers
 // the caller's pages with the driver; when the caller later frees that memory (NumPy arrays of the previous solve, the vectors
@@ -566,6 +605,7 @@ struct CsrBufs {
     // the tile tables of a matrix whose pattern is already on the device (ptr, col filled by kernels: the Newton matrix built
     // by score_polish_device.hpp); M.ptr is its host copy
     void adopt_tiles(const Csr& M, const RowBlocks& rb) {
+        UploadBatch ub;
         first_row.upload(rb.first_row);
         blk_prob.upload(rb.prob);
         blk_rs.upload(rb.rs);
@@ -583,6 +623,7 @@ struct CsrBufs {
     // values = false: the value array is only allocated (zeroed); a kernel fills it
     // columns = false: the column array is only allocated as well (pad zeroed); a kernel fills it
     void upload(const Csr& M, const RowBlocks& rb, const std::vector<int32_t>* sp = nullptr, bool values = true, bool columns = true) {
+        UploadBatch ub;
         ptr.upload(M.ptr);
         // The SpMV issues its loads unconditionally on clamped indices; for an empty tile at the
         // very end of the matrix the clamp lands one past the last nonzero.  Pad with harmless
@@ -636,6 +677,7 @@ struct BandBufs {
         on = L.on;
         if (!on) return;
         nblocks = L.nb();
+        UploadBatch ub;
         V.alloc((size_t)L.v_size + 64);
         HIP_CHECK(hipMemsetAsync(V.d, 0, V.n * sizeof(double), tl_copy_stream));  // padding slots stay zero for ever
         rem_col.upload_padded(L.rem_col, 64);
@@ -1139,6 +1181,7 @@ struct HipBackend {
         for (int p = 0; p <= count; ++p) { xo32[(size_t)p] = (int32_t)h.xoff[p]; ro32[(size_t)p] = (int32_t)h.roff[p]; }
         for (int p = 0; p < count; ++p) nr32[(size_t)p] = h.rep > 1 ? (int32_t)h.rep_n[(size_t)p] : 0;
         ArenaSwap persist(&arena);
+        UploadBatch ub;
         tab_xoff.upload(xo32); tab_roff.upload(ro32); tab_nr.upload(nr32);
     }
     void raw_from_problems(const HostSystem& h, const score_problem* probs, RawDev& R) {
@@ -1658,7 +1701,7 @@ struct HipBackend {
             cone_row.upload(h.cone_row); cone_dim.upload(h.cone_dim); cone_type.upload(h.cone_type);
             setup_on_device(h, probs, graphs);
             start_band_layout();
-            K.adopt_tiles(h.K, h.rbK); G1.adopt_tiles(h.G1, h.rbG1); G2.adopt_tiles(h.G2, h.rbG2);
+            { UploadBatch ub; K.adopt_tiles(h.K, h.rbK); G1.adopt_tiles(h.G1, h.rbG1); G2.adopt_tiles(h.G2, h.rbG2); }
             pt.mark("  device setup");
         } else
         K.upload(h.K, h.rbK, nullptr, false);  // (values: K0 + rho K1, on the device -- derive_rho_data)
@@ -1693,6 +1736,7 @@ struct HipBackend {
                     vf.push_back((int32_t)r); ve.push_back((int32_t)std::min<int64_t>(r + kThreads, h.xoff[p + 1])); vp.push_back(p);
                 }
             n_vblocks = (int)vf.size();
+            UploadBatch ub;
             vb_first.upload(vf); vb_end.upload(ve); vb_prob.upload(vp);
         }
         if (!h.device_setup) A_ptr.upload(h.A.ptr);
@@ -1733,7 +1777,7 @@ struct HipBackend {
         }
         pt.mark("  uploads: A, q, b, 1/D, 1/E");
         if (!h.device_setup) { cone_row.upload(h.cone_row); cone_dim.upload(h.cone_dim); cone_type.upload(h.cone_type); }
-        cone_block_first.upload(h.cone_block_first); cone_block_prob.upload(h.cone_block_prob);
+        { UploadBatch ub; cone_block_first.upload(h.cone_block_first); cone_block_prob.upload(h.cone_block_prob); }
         {   // the cone tables (row pointers, the entries of the small cones again by cone index): from A on the device
             const size_t nc = h.cone_row.size();
             cone_meta.alloc(2 * nc); cone_cols.alloc(8 * nc); cone_vals.alloc(8 * nc);
@@ -1748,6 +1792,8 @@ struct HipBackend {
         }
         n_cone_blocks = (int)h.cone_block_prob.size();
         pt.mark("  uploads: cone records");
+        {   // (the chain tables below: one run of uploads, nothing launched in between -- UploadBatch)
+        UploadBatch ub_tables;
         {
             std::vector<int2> lg;
             for (int bl = 0; bl < n_cone_blocks; ++bl)
@@ -1828,6 +1874,7 @@ struct HipBackend {
             if (!split.active) { n_prec = (int)h.prec_work.size(); active_part_ptr = h.prec_part_ptr; }
         }
         prec_part_ptr.upload(active_part_ptr);
+        }
         if (st.verbose)
             std::fprintf(stderr, "[score setup] chain preconditioner: %s, %d work items (%zu chains)\n",
                          split.active ? "split (one wavefront per chain part)" : "one workgroup per chain", n_prec, h.chains.size());
@@ -2029,6 +2076,8 @@ struct HipBackend {
         if (!n_join_items) return;
         for (const JoinChain& jc : h.join_chains)
             if (jc.n_seg - 1 > kJoinMaxSeps) throw std::runtime_error("internal: a segmented chain with more separators than the join kernel holds (build_system keeps such chains whole)");
+        std::optional<UploadBatch> ub_join;
+        ub_join.emplace();
         join_jc.upload(h.join_chains); join_items.upload(h.join_items);
         join_sep_col.upload(h.join_sep_col); join_sep_diag.upload(h.join_sep_diag);
         // pseudo-nodes for the position look-up (k_hb_positions): [separator | prev = last node of the segment before it] and
@@ -2044,6 +2093,7 @@ struct HipBackend {
                 pc[2 * sp + 1] = h.node_col[(size_t)cr.node_begin]; pp[2 * sp + 1] = b;
             }
         join_pcol.upload(pc); join_pprev.upload(pp);
+        ub_join.reset();
         const size_t b2 = (size_t)h.bs * h.bs, nb = 2 * (size_t)h.bs;
         ZeroGroup zj;
         zj.add(join_W_K, nb * (size_t)h.n_tot); zj.add(join_rhs, (size_t)h.n_tot); zj.add(join_data_K, 5 * b2 * (size_t)n_join_seps);
@@ -2169,6 +2219,8 @@ struct HipBackend {
         n_link_items = (int)L.items.size(); n_link_probs = (int)L.probs.size(); n_link_u = (int)L.ucol.size(); link_rounds = L.rounds;
         link_max_u = 0;
         for (const LinkProb& P : L.probs) link_max_u = std::max(link_max_u, (int)P.n_u);
+        std::optional<UploadBatch> ub_link;
+        ub_link.emplace();
         link_probs.upload(L.probs); link_items.upload(L.items);
         link_ucol.upload(L.ucol); link_uround.upload(L.uround); link_usuper.upload(L.usuper); link_mask.upload(L.mask);
         const bool sets[2] = {true, st.polish != 0 && Q.available};
@@ -2183,6 +2235,7 @@ struct HipBackend {
                 link_pcol[set].upload(pc); link_pshift[set].upload(ps);
             }
         }
+        ub_link.reset();
         ZeroGroup zl;
         for (int set = 0; set < 2; ++set) {
             if (!sets[set]) continue;
@@ -3625,6 +3678,7 @@ struct HipBackend {
         if (!Q.available) return;
         if (!on_device) {
             hm_nnz = (int64_t)Q.Hm.col.size();
+            UploadBatch ub;
             Hm.upload(Q.Hm, Q.rbH, nullptr, false);
             q_Pon.upload(Q.Pon); q_ccoef.upload(Q.ccoef); q_cptr.upload(Q.cptr); q_ccone.upload(Q.ccone); q_cab.upload(Q.cab);
             q_head.upload(Q.head_col); q_ishead.upload(Q.is_head); q_aabs.upload(Q.a_abs); q_ck.upload(Q.ck);
@@ -3632,6 +3686,8 @@ struct HipBackend {
             q_posd.upload(Q.pos_diag); q_poss.upload(Q.pos_sub); q_diagpos.upload(Q.diag_pos);
         }
         pt.mark("  polish: uploads");
+        std::optional<UploadBatch> ub_polish;  // (tables and zeroed buffers only from here to join_init_newton: nothing is launched)
+        ub_polish.emplace();
         Hb.upload(std::move(Q.band));
         if (st.verbose)
             std::fprintf(stderr, "[score setup] band view of H: %s (%d band + %d csr + %d diag tiles, %d slots per row)\n", Hb.on ? "on" : "off",
@@ -3669,6 +3725,7 @@ struct HipBackend {
             }
             q_seg_begin.upload(sb); q_seg_end.upload(se);
         }
+        ub_polish.reset();
         join_init_newton(h);
     }
 
