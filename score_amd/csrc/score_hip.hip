@@ -417,12 +417,65 @@ struct StageArena {
     ~StageArena() { release(); }
 };
 thread_local StageArena* tl_stage = nullptr;  // set while a handle's setup uploads on this thread
-// A run of small uploads with no launch in between (round 6: a create issued ~60 transfers of 2-5 us each, most of them tables
-// that follow each other): opened around such a run, closed (= the merged transfers queued) before anything reads the tables.
+// Small fills likewise (a create issued ~40 runtime fills of ~5 us each: padding entries, counters, sentinels): inside a batch they
+// are listed and written by ONE launch of k_fill_list when the batch closes (before the merged transfers: "zero, then upload into
+// it" keeps its order).  Fills of a megabyte or more are issued at once (their buffers are nobody's upload target).
+constexpr int kFillListMax = 24;
+struct FillSeg { uint32_t* p; unsigned long long words; uint32_t pattern; uint32_t blk0; };
+struct FillList { FillSeg s[kFillListMax]; int count; };
+constexpr unsigned kFillWordsPerBlock = 256 * 16;
+__global__ __launch_bounds__(256) void k_fill_list(FillList L) {
+    int q = 0;
+    while (q + 1 < L.count && L.s[q + 1].blk0 <= blockIdx.x) ++q;
+    const FillSeg sg = L.s[q];
+    const unsigned long long w0 = (unsigned long long)(blockIdx.x - sg.blk0) * kFillWordsPerBlock;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const unsigned long long w = w0 + (unsigned long long)u * 256 + threadIdx.x;
+        if (w < sg.words) sg.p[w] = sg.pattern;
+    }
+}
+struct FillBatchState {
+    int depth = 0;
+    hipStream_t st = nullptr;
+    FillList L{};
+    unsigned blocks = 0;
+    void flush() {
+        if (!L.count) return;
+        const unsigned g = blocks;
+        const FillList out = L;
+        L.count = 0; blocks = 0;
+        hipLaunchKernelGGL(k_fill_list, dim3(g), dim3(256), 0, st, out);
+        HIP_CHECK(hipGetLastError());
+    }
+    void add(void* p, size_t bytes, uint32_t pattern, hipStream_t s) {
+        if (L.count && (s != st || L.count == kFillListMax)) flush();
+        st = s;
+        FillSeg& sg = L.s[L.count++];
+        sg.p = (uint32_t*)p; sg.words = bytes / 4; sg.pattern = pattern; sg.blk0 = blocks;
+        blocks += (unsigned)((sg.words + kFillWordsPerBlock - 1) / kFillWordsPerBlock);
+    }
+};
+thread_local FillBatchState tl_fills;
+// every fill of the library goes through these two (pattern: a 32-bit word)
+inline void fill_words_async(void* p, uint32_t pattern, size_t bytes, hipStream_t st) {
+    if (!bytes) return;
+    if (tl_fills.depth > 0 && bytes < ((size_t)1 << 20) && bytes % 4 == 0 && ((uintptr_t)p % 4) == 0) { tl_fills.add(p, bytes, pattern, st); return; }
+    if (pattern == 0) HIP_CHECK(hipMemsetAsync(p, 0, bytes, st));
+    else if (bytes % 4 == 0) HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)p, (int)pattern, bytes / 4, st));
+    else throw std::runtime_error("fill_words_async: a patterned fill of a size that is no multiple of 4");
+}
+inline void fill_zero_async(void* p, size_t bytes, hipStream_t st) { fill_words_async(p, 0u, bytes, st); }
+// A run of small uploads and fills with no launch in between (round 6: a create issued ~60 transfers of 2-5 us each, most of them
+// tables that follow each other): opened around such a run, closed (= the listed fills written, the merged transfers queued)
+// before anything reads the buffers.
 struct UploadBatch {
     StageArena* a;
-    UploadBatch() : a(tl_stage) { if (a) ++a->batch_depth; }
+    UploadBatch() : a(tl_stage) { if (a) ++a->batch_depth; ++tl_fills.depth; }
     ~UploadBatch() {
+        if (--tl_fills.depth == 0) {
+            try { tl_fills.flush(); } catch (...) { tl_fills.L.count = 0; tl_fills.blocks = 0; }
+        }
         if (!a) return;
         if (--a->batch_depth == 0) {
             try { a->flush(); } catch (...) { a->pend_bytes = 0; }  // (a failed transfer surfaces at the next checked call on the stream)
@@ -517,7 +570,7 @@ struct DevBuf {
     // upload into an allocation with `pad` extra zeroed elements at the end
     void upload_padded(const std::vector<T>& h, size_t pad) {
         if (h.size() + pad != n || !d) alloc(h.size() + pad);
-        HIP_CHECK(hipMemsetAsync(d + h.size(), 0, pad * sizeof(T), tl_copy_stream));
+        fill_zero_async(d + h.size(), pad * sizeof(T), tl_copy_stream);
         if (tl_stage && tl_stage->upload(d, h.data(), h.size() * sizeof(T), tl_copy_stream)) return;
         if (!h.empty()) staged_h2d(d, h.data(), h.size() * sizeof(T), tl_copy_stream);
         HIP_CHECK(sync_stream(tl_copy_stream));
@@ -535,7 +588,7 @@ struct DevBuf {
             const size_t n16 = bytes / 16;
             const unsigned grid = (unsigned)std::min<size_t>((n16 + 255) / 256, 4096);
             hipLaunchKernelGGL(k_zero16, dim3(grid), dim3(256), 0, st, (uint4*)d, n16);
-        } else if (n) HIP_CHECK(hipMemsetAsync(d, 0, bytes, st));
+        } else if (n) fill_zero_async(d, bytes, st);
     }
     // a window into somebody else's allocation
     void view(T* ptr, size_t count) {
@@ -572,7 +625,7 @@ struct ZeroGroup {
         if (!tl_arena) throw std::runtime_error("ZeroGroup: no arena");
         char* base = (char*)tl_arena->take(total);
         for (const Item& it : items) { *it.d = base + it.off; *it.n = it.count; }
-        HIP_CHECK(hipMemsetAsync(base, 0, total, st));
+        fill_zero_async(base, total, st);
         items.clear();
         total = 0;
     }
@@ -592,9 +645,9 @@ struct CsrBufs {
     void alloc_long(int n_long, int n_slots) {
         long_part.alloc((size_t)std::max(1, n_slots) * kLongVals);
         long_cnt.alloc((size_t)std::max(1, n_long));
-        HIP_CHECK(hipMemsetAsync(long_cnt.d, 0, long_cnt.n * sizeof(unsigned long long), tl_copy_stream));
+        fill_zero_async(long_cnt.d, long_cnt.n * sizeof(unsigned long long), tl_copy_stream);
         // (every slot starts as "not published": the polling mode of the split rows -- CsrDev::long_spin -- reads it that way)
-        HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)long_part.d, (int)kLongSentinel32, long_part.n * 2, tl_copy_stream));
+        fill_words_async(long_part.d, (uint32_t)kLongSentinel32, long_part.n * sizeof(double), tl_copy_stream);
     }
     int spin_max_tiles = 0;  // long_spin when the matrix has at most this many tiles (0: never); set where the matrix is made
     DevBuf<double> val;
@@ -632,13 +685,13 @@ struct CsrBufs {
             col.upload_padded(M.col, 64);
         } else {
             col.alloc(M.col.size() + 64);
-            HIP_CHECK(hipMemsetAsync(col.d + M.col.size(), 0, 64 * sizeof(int32_t), tl_copy_stream));
+            fill_zero_async(col.d + M.col.size(), 64 * sizeof(int32_t), tl_copy_stream);
         }
         if (values) {
             val.upload_padded(M.val, 64);
         } else {
             val.alloc(M.col.size() + 64);
-            HIP_CHECK(hipMemsetAsync(val.d, 0, val.n * sizeof(double), tl_copy_stream));
+            fill_zero_async(val.d, val.n * sizeof(double), tl_copy_stream);
         }
         first_row.upload(rb.first_row);
         blk_prob.upload(rb.prob);
@@ -679,7 +732,7 @@ struct BandBufs {
         nblocks = L.nb();
         UploadBatch ub;
         V.alloc((size_t)L.v_size + 64);
-        HIP_CHECK(hipMemsetAsync(V.d, 0, V.n * sizeof(double), tl_copy_stream));  // padding slots stay zero for ever
+        fill_zero_async(V.d, V.n * sizeof(double), tl_copy_stream);  // padding slots stay zero for ever
         rem_col.upload_padded(L.rem_col, 64);
         rowseg.upload(L.rowseg); dst.upload(L.dst); prob.upload(L.prob); rs.upload(L.rs); part_ptr.upload(L.part_ptr);
         std::vector<int4> m((size_t)nblocks), m2((size_t)nblocks);
@@ -693,8 +746,8 @@ struct BandBufs {
         lng.upload(lg);
         long_part.alloc((size_t)std::max(1, L.n_long_slots) * kLongVals);
         long_cnt.alloc((size_t)std::max(1, L.n_long));
-        HIP_CHECK(hipMemsetAsync(long_cnt.d, 0, long_cnt.n * sizeof(unsigned long long), tl_copy_stream));
-        HIP_CHECK(hipMemsetD32Async((hipDeviceptr_t)long_part.d, (int)kLongSentinel32, long_part.n * 2, tl_copy_stream));
+        fill_zero_async(long_cnt.d, long_cnt.n * sizeof(unsigned long long), tl_copy_stream);
+        fill_words_async(long_part.d, (uint32_t)kLongSentinel32, long_part.n * sizeof(double), tl_copy_stream);
     }
     BandDev dev() const {
         BandDev d{};
@@ -1078,6 +1131,7 @@ struct HipBackend {
     void sort_rows_plan(RowSort& rs, int64_t n_rows, int64_t rec_max, int bits, unsigned long long* sk0, unsigned long long* sk1) {
         rs.cap = (int32_t)(rec_max / kShortRow + 1);
         rs.seg.alloc((size_t)2 * rs.cap + 1);
+        fill_zero_async(rs.seg.d, ((size_t)2 * rs.cap + 1) * sizeof(int32_t), stream);  // (unused segments stay [0, 0))
         HIP_CHECK(rocprim::segmented_radix_sort_keys(nullptr, rs.bytes, sk0, sk1, (unsigned)rec_max, (unsigned)rs.cap, rs.seg.d, rs.seg.d + rs.cap, 0,
                                                      (unsigned)(bits + pos_bits(rec_max)), stream));
     }
@@ -1088,7 +1142,6 @@ struct HipBackend {
         a.seg_b = rs.seg.d; a.seg_e = rs.seg.d + rs.cap; a.seg_n = rs.seg.d + 2 * rs.cap; a.seg_cap = rs.cap;
         a.rec_max = rec_max; a.n_rows = n_rows; a.pbits = pos_bits(rec_max);
         const unsigned grec = (unsigned)((rec_max + 255) / 256);
-        HIP_CHECK(hipMemsetAsync(rs.seg.d, 0, ((size_t)2 * rs.cap + 1) * sizeof(int32_t), stream));
         hipLaunchKernelGGL(k_row_rank_sort, dim3(grec), dim3(256), 0, stream, a);
         hipLaunchKernelGGL(k_rows_long_list, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, stream, a);
         HIP_CHECK(rocprim::segmented_radix_sort_keys(scratch, rs.bytes, sk0, sk1, (unsigned)rec_max, (unsigned)rs.cap, a.seg_b, a.seg_e, 0,
@@ -1113,6 +1166,8 @@ struct HipBackend {
         DevBuf<long long> cnt_b;
         DevBuf<unsigned int> cur_b;
         const bool bucket = !row_off;
+        std::optional<UploadBatch> fills;  // (the fills below in one launch; closed before the first kernel)
+        fills.emplace();
         {
             ZeroGroup zg;
             zg.add(row_cnt, (size_t)n_rows + 1); zg.add(out.result, 2);
@@ -1130,6 +1185,7 @@ struct HipBackend {
         RowSort rs;
         sort_rows_plan(rs, n_rows, rec_max, bits, flag.d, flag_s.d);  // (the flag arrays are free until k_rec_flags)
         tb = rs.bytes;
+        fills.reset();
         HIP_CHECK(rocprim::inclusive_scan(nullptr, tb2, flag.d, flag_s.d, (size_t)rec_max, rocprim::plus<unsigned long long>(), stream));
         HIP_CHECK(rocprim::exclusive_scan(nullptr, tb3, row_cnt.d, out.ptr.d, (int32_t)0, (size_t)n_rows + 1, rocprim::plus<int32_t>(), stream));
         DevBuf<unsigned char> scratch;
@@ -1375,7 +1431,7 @@ struct HipBackend {
         key0.alloc((size_t)rec_max); idx0.alloc((size_t)rec_max); val.alloc((size_t)rec_max);
         R.Ac.alloc((size_t)ae + 1); R.Av.alloc((size_t)ae + 1);
         R.qraw.alloc((size_t)n); R.braw.alloc((size_t)std::max<int64_t>(1, m));
-        HIP_CHECK(hipMemsetAsync(R.qraw.d, 0, (size_t)n * sizeof(double), stream));
+        fill_zero_async(R.qraw.d, (size_t)n * sizeof(double), stream);
         GaArgs a{};
         a.d = d; a.relaxation = relax; a.count = count; a.probs = d_gp.d;
         a.rel_prob = rel_prob.d; a.rng_prob = rng_prob.d; a.pri_prob = pri_prob.d; a.pin_prob = pin_prob.d;
@@ -1440,8 +1496,9 @@ struct HipBackend {
         const int64_t g2_nnz = nnzP_full + ae;  // (graph path: an upper bound)
         // (A's padding: k_g_scale_a writes it)
         if (R.exact) {
-            HIP_CHECK(hipMemsetAsync(G2.col.d + g2_nnz, 0, 64 * sizeof(int32_t), stream));
-            HIP_CHECK(hipMemsetAsync(G2.val.d + g2_nnz, 0, 64 * sizeof(double), stream));
+            UploadBatch fills;
+            fill_zero_async(G2.col.d + g2_nnz, 64 * sizeof(int32_t), stream);
+            fill_zero_async(G2.val.d + g2_nnz, 64 * sizeof(double), stream);
         }
         DevBuf<int32_t> atp, arow;
         DevBuf<uint32_t> idx0, atpos, akey0, akey1;
@@ -1488,9 +1545,9 @@ struct HipBackend {
         const unsigned gcol = (unsigned)((n + 3) / 4), ggrp = (unsigned)std::max<int64_t>(1, (ngroups + 255) / 256);
         const unsigned gapp = (unsigned)std::max<int64_t>(1, (std::max(n, ngroups) + 255) / 256);
         for (int it = 0; it < std::max(0, st.scale_iters); ++it) {
-            if (ae) hipLaunchKernelGGL(k_rz_colsA, dim3((unsigned)((ae + 255) / 256)), dim3(256), 0, stream, rz);
+            const unsigned ga_blocks = (unsigned)((ae + 255) / 256), gg_blocks = ngroups ? ggrp : 0u;
+            if (ga_blocks + gg_blocks) hipLaunchKernelGGL(k_rz_colsA, dim3(ga_blocks + gg_blocks), dim3(256), 0, stream, rz, (int)ga_blocks);
             hipLaunchKernelGGL(k_rz_cols, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, stream, rz);
-            if (ngroups) hipLaunchKernelGGL(k_rz_groups, dim3(ggrp), dim3(256), 0, stream, rz);
             hipLaunchKernelGGL(k_rz_apply, dim3(gapp), dim3(256), 0, stream, rz);
         }
         HIP_CHECK(hipGetLastError());
@@ -1598,7 +1655,7 @@ struct HipBackend {
         HIP_CHECK(hipMemcpyAsync(K.col.d, mo.col.d, ((size_t)nnzK + 64) * sizeof(int32_t), hipMemcpyDeviceToDevice, stream));
         HIP_CHECK(hipMemcpyAsync(K0d.d, mo.o0.d, ((size_t)nnzK + 64) * sizeof(double), hipMemcpyDeviceToDevice, stream));
         HIP_CHECK(hipMemcpyAsync(K1d.d, mo.o1.d, ((size_t)nnzK + 64) * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        HIP_CHECK(hipMemsetAsync(K.val.d, 0, K.val.n * sizeof(double), stream));
+        fill_zero_async(K.val.d, K.val.n * sizeof(double), stream);
         h.K.col.resize((size_t)nnzK);
         {
             Pinned kc((size_t)std::max<int64_t>(1, nnzK) * sizeof(int32_t), st.device);
@@ -1745,8 +1802,7 @@ struct HipBackend {
         } else if (derive_ag) {
             const size_t nz = h.A.col.size();
             A_col.alloc(nz + 64); A_val.alloc(nz + 64);
-            HIP_CHECK(hipMemsetAsync(A_col.d + nz, 0, 64 * sizeof(int32_t), stream));
-            HIP_CHECK(hipMemsetAsync(A_val.d + nz, 0, 64 * sizeof(double), stream));
+            { UploadBatch fills; fill_zero_async(A_col.d + nz, 64 * sizeof(int32_t), stream); fill_zero_async(A_val.d + nz, 64 * sizeof(double), stream); }
             DeriveArgs da{};
             da.n = h.n_tot; da.m = h.m_tot; da.nnzA = (int64_t)nz; da.rep = h.rep; da.nr = h.rep > 1 ? h.rep_n[0] : 0;
             da.P_ptr = ruiz_dev.Pp.d; da.P_col = ruiz_dev.Pc.d; da.P_val = ruiz_dev.Pv.d;
@@ -3523,7 +3579,9 @@ struct HipBackend {
             flag.alloc((size_t)rec_max); flag_s.alloc((size_t)rec_max);
             rcone.alloc((size_t)rec_max); rab.alloc((size_t)rec_max); rcoef.alloc((size_t)rec_max); hrow.alloc((size_t)rec_max);
             long_ent.alloc((size_t)long_max);
-            HIP_CHECK(hipMemsetAsync(result.d, 0, 3 * sizeof(long long), stream));
+            std::optional<UploadBatch> fills;  // (counters, the sort's segment list, the predecessor table: one fill launch, one transfer)
+            fills.emplace();
+            fill_zero_async(result.d, 3 * sizeof(long long), stream);
             {
                 std::vector<int32_t> pc(h.node_col.size(), -1);  // column of the chain predecessor
                 for (const auto& ch : h.chains)
@@ -3540,20 +3598,20 @@ struct HipBackend {
             const int64_t long_cap = rec_max / kLongRowEntries + 1;
             DevBuf<int32_t> long_rows, n_long_rows;
             long_rows.alloc((size_t)long_cap); n_long_rows.alloc(1);
-            HIP_CHECK(hipMemsetAsync(n_long_rows.d, 0, sizeof(int32_t), stream));
+            fill_zero_async(n_long_rows.d, sizeof(int32_t), stream);
+            int bits = 1;
+            while (((int64_t)1 << bits) <= n) ++bits;  // (the sentinel row n sorts last)
+            RowSort rs;  // (every row's records sorted where they lie: sort_rows)
+            sort_rows_plan(rs, n, rec_max, bits, flag.d, flag_s.d);
+            fills.reset();
             hipLaunchKernelGGL(k_row_classify, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const int32_t*)G2.ptr.d, n, long_rows.d, n_long_rows.d);
             const unsigned g8 = (unsigned)((n + 31) / 32), g64 = (unsigned)((long_cap + 3) / 4);
             a.long_rows = long_rows.d; a.n_long_rows = n_long_rows.d;
             a.rec_cnt = cnt.d;
             hipLaunchKernelGGL(k_hb_count<8>, dim3(g8), dim3(256), 0, stream, a);
             hipLaunchKernelGGL(k_hb_count<64>, dim3(g64), dim3(256), 0, stream, a);
-            size_t tb = 0, tb2 = 0, tb3 = 0;
-            int bits = 1;
-            while (((int64_t)1 << bits) <= n) ++bits;  // (the sentinel row n sorts last)
+            size_t tb = 0, tb2 = rs.bytes, tb3 = 0;
             HIP_CHECK(rocprim::exclusive_scan(nullptr, tb, cnt.d, off.d, (long long)0, (size_t)n + 1, rocprim::plus<long long>(), stream));
-            RowSort rs;  // (every row's records sorted where they lie: sort_rows)
-            sort_rows_plan(rs, n, rec_max, bits, flag.d, flag_s.d);
-            tb2 = rs.bytes;
             HIP_CHECK(rocprim::inclusive_scan(nullptr, tb3, flag.d, flag_s.d, (size_t)rec_max, rocprim::plus<unsigned long long>(), stream));
             DevBuf<unsigned char> scratch;
             scratch.alloc(std::max(tb, std::max(tb2, tb3)) + 256);

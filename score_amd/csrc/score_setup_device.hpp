@@ -104,7 +104,11 @@ struct RzArgs {
 // wavefront by column, and the last lane of every run folds its maximum into the column's cell with an integer atomic max on the
 // bit pattern (non-negative doubles order like their bits; a maximum does not depend on the order: deterministic).  The P part
 // and the scale itself: eight lanes per column (a row of P holds a dozen entries).  cmax is zeroed by k_rz_apply.
-__global__ __launch_bounds__(256) void k_rz_colsA(RzArgs a) {
+__device__ __forceinline__ void rz_groups_body(const RzArgs& a, int64_t g);
+// (one launch: the first blocks_a blocks sweep A's entries, the rest the cone groups -- both read the scales of the pass before
+//  and nothing of each other; four launches per pass were three quarters launch shell)
+__global__ __launch_bounds__(256) void k_rz_colsA(RzArgs a, int blocks_a) {
+    if ((int)blockIdx.x >= blocks_a) { rz_groups_body(a, (int64_t)((int)blockIdx.x - blocks_a) * 256 + threadIdx.x); return; }
     const int lane = threadIdx.x & 63;
     const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool on = k < a.nnzA;
@@ -140,8 +144,7 @@ __global__ __launch_bounds__(256) void k_rz_cols(RzArgs a) {
         a.d[j] = mx > 1e-12 ? 1.0 / sqrt(mx) : 1.0;
     }
 }
-__global__ __launch_bounds__(256) void k_rz_groups(RzArgs a) {
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void rz_groups_body(const RzArgs& a, int64_t g) {
     if (g >= a.ngroups) return;
     const int r0 = a.gstart[g];
     const int rend = g + 1 < a.ngroups ? a.gstart[g + 1] : (int)a.m;
