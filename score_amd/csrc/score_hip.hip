@@ -26,6 +26,7 @@
 #include <malloc.h>
 #include <mutex>
 #include <string>
+#include <memory>
 #include <optional>
 #include <vector>
 
@@ -1396,7 +1397,9 @@ struct HipBackend {
         DevBuf<unsigned char> pack;
         pack.alloc(pack_bytes);
         auto cp = [&](size_t o_, const void* src, size_t bytes) { if (bytes) std::memcpy(hb + o_, src, bytes); };
-        for (int p = 0; p < count; ++p) {
+        // (graph by graph on the host team: 5 MB of copies for a 16-trial handle)
+        score::parallel_ranges((int64_t)count, 1, [&](int, int64_t p_lo, int64_t p_hi) {
+        for (int p = (int)p_lo; p < (int)p_hi; ++p) {
             const score_graph& g = graphs[p];
             const size_t eo = (size_t)rel_off[(size_t)p], ro = (size_t)rng_off[(size_t)p], po = (size_t)pri_off[(size_t)p];
             if (!gen_src) {
@@ -1413,6 +1416,7 @@ struct HipBackend {
             std::fill((int32_t*)(hb + o_prip) + po, (int32_t*)(hb + o_prip) + po + g.n_lprior, p);
             std::fill((int32_t*)(hb + o_pinp) + pin_off[(size_t)p], (int32_t*)(hb + o_pinp) + pin_off[(size_t)p + 1], p);
         }
+        });
         cp(o_pin, pin_edge.data(), (size_t)n_pin * i4);
         cp(o_gp, gp.data(), (size_t)count * sizeof(GaProb));
         HIP_CHECK(hipMemcpyAsync(pack.d, hb, pack_bytes, hipMemcpyHostToDevice, stream));
@@ -1615,11 +1619,7 @@ struct HipBackend {
         merge_records(n, rec_max, key0, kidx0, v0.d, v1.d, -1, nullptr, mo, (const long long*)kcnt.d);  // (kcnt: the rows' record offsets)
         pt.mark("  device setup: G1 / G2 / A / K queued");
         // ---- first trip back: counts, row pointers, norms ----
-        struct Pinned {
-            void* p = nullptr; size_t bytes = 0; int dev;
-            Pinned(size_t b, int d) : bytes(b), dev(d) { p = block_cache().take(bytes, dev, true); }
-            ~Pinned() { block_cache().give(p, bytes, dev, true); }
-        };
+        using Pinned = PinnedBlock;
         const size_t o_res = 0, o_norm = 16, o_kp = o_norm + (size_t)4 * count * sizeof(double);
         const size_t o_g1 = o_kp + ((size_t)n + 1) * sizeof(int32_t), o_g2 = o_g1 + ((size_t)n + 1) * sizeof(int32_t);
         Pinned back(o_g2 + ((size_t)n + 1) * sizeof(int32_t), st.device);
@@ -1656,20 +1656,34 @@ struct HipBackend {
         HIP_CHECK(hipMemcpyAsync(K0d.d, mo.o0.d, ((size_t)nnzK + 64) * sizeof(double), hipMemcpyDeviceToDevice, stream));
         HIP_CHECK(hipMemcpyAsync(K1d.d, mo.o1.d, ((size_t)nnzK + 64) * sizeof(double), hipMemcpyDeviceToDevice, stream));
         fill_zero_async(K.val.d, K.val.n * sizeof(double), stream);
-        h.K.col.resize((size_t)nnzK);
-        {
-            Pinned kc((size_t)std::max<int64_t>(1, nnzK) * sizeof(int32_t), st.device);
-            HIP_CHECK(hipMemcpyAsync(kc.p, mo.col.d, (size_t)nnzK * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
-            // (the tiles of G1 / G2 need their row pointers only: laid out while K's columns travel)
+        {   // K's columns for the host's band layout: they stay in the pinned block they arrive in until the layout job (or, without
+            // one, init) copies them into h.K.col -- 8 MB of resize + memcpy on this thread were 0.5 ms of a 16-trial create
+            kcols_pin = std::make_shared<PinnedBlock>((size_t)std::max<int64_t>(1, nnzK) * sizeof(int32_t), st.device);
+            kcols_n = nnzK;
+            HIP_CHECK(hipMemcpyAsync(kcols_pin->p, mo.col.d, (size_t)nnzK * sizeof(int32_t), hipMemcpyDeviceToHost, stream));
             h.G1.nrows = h.G2.nrows = h.K.nrows = h.K.ncols = n;
             HIP_CHECK(sync_stream(stream));
-            std::memcpy(h.K.col.data(), kc.p, (size_t)nnzK * sizeof(int32_t));
         }
         make_system_rowblocks(h);
         fill_kkt_bytes(h);
         pt.mark("  device setup: K columns back, tiles");
     }
 
+    struct PinnedBlock {
+        void* p = nullptr; size_t bytes = 0; int dev;
+        PinnedBlock(size_t b, int d) : bytes(b), dev(d) { p = block_cache().take(bytes, dev, true); }
+        ~PinnedBlock() { block_cache().give(p, bytes, dev, true); }
+        PinnedBlock(const PinnedBlock&) = delete;
+        PinnedBlock& operator=(const PinnedBlock&) = delete;
+    };
+    std::shared_ptr<PinnedBlock> kcols_pin;  // K's columns as they came back from the device setup (adopt_k_columns)
+    int64_t kcols_n = 0;
+    void adopt_k_columns(HostSystem& h) {
+        if (!kcols_pin) return;
+        const int32_t* src = (const int32_t*)kcols_pin->p;
+        h.K.col.assign(src, src + kcols_n);
+        kcols_pin.reset();
+    }
     void init(HostSystem& h, const score_settings& s_, const score_problem* probs = nullptr, const score_graph* graphs = nullptr) {
         H = &h;
         st = s_;
@@ -1730,8 +1744,9 @@ struct HipBackend {
         std::future<BandLayout> band_layout_job;
         auto start_band_layout = [&] {
         if (band_k(h) && !h.chains.empty())  // the band view of K only reads the finished host system: laid out on a thread of its own
-            band_layout_job = std::async(std::launch::async, [&h] {
+            band_layout_job = std::async(std::launch::async, [&h, this] {
                 BuildScope scope;
+                adopt_k_columns(h);  // (device setup: the columns are still in their pinned block)
                 std::vector<char> use(h.chains.size());
                 for (size_t ci = 0; ci < h.chains.size(); ++ci) use[ci] = h.chain_owner[ci] == (int32_t)ci;
                 std::vector<RowSegment> sg;
@@ -1758,6 +1773,7 @@ struct HipBackend {
             cone_row.upload(h.cone_row); cone_dim.upload(h.cone_dim); cone_type.upload(h.cone_type);
             setup_on_device(h, probs, graphs);
             start_band_layout();
+            if (!band_layout_job.valid()) adopt_k_columns(h);  // (no layout job to do it)
             { UploadBatch ub; K.adopt_tiles(h.K, h.rbK); G1.adopt_tiles(h.G1, h.rbG1); G2.adopt_tiles(h.G2, h.rbG2); }
             pt.mark("  device setup");
         } else
