@@ -245,6 +245,17 @@ def test_device_assembler_equals_the_host_assembler(fixtures, hip_lib, monkeypat
     cases.append((graphs_of(("graph3d",)), "QCQP", dict(cg_iters=8, adaptive_rho=0)))
     cases.append(([make_manhattan(n_robots=2 + k, n_poses=300 + 170 * k, n_beacons=2, seed=90 + k) for k in range(3)], "SOCP", {}))
     cases.append(([make_config(3)], "SOCP", {}))
+    # round 6, the per-row sort of the records (k_row_rank_sort): a pose tied to sixty others by loop closures -- its rows of P hold
+    # more records than a lane ranks (the listed long rows: segmented radix sort) --, beside a two-pose graph
+    hub = make_manhattan(n_robots=1, n_poses=80, n_beacons=2, seed=97, p_range=0.5)
+    from score_amd import compat
+    T = [pv.transformation_matrix for pv in hub.pose_variables[0]]
+    for j in range(12, 72):
+        rel = np.linalg.inv(T[5]) @ T[j]
+        hub.loop_closure_measurements.append(compat.PoseMeasurement2D("A5", f"A{j}", float(rel[0, 2]), float(rel[1, 2]),
+                                                                      float(np.arctan2(rel[1, 0], rel[0, 0])), 1e4, 2.5e5))
+    cases.append(([hub, make_manhattan(n_robots=1, n_poses=2, n_beacons=1, seed=98, p_range=1.0)], "SOCP", {}))
+    cases.append(([hub], "QCQP", dict(cg_iters=8, adaptive_rho=0)))
     for k, (graphs, relax, st) in enumerate(cases):
         arrays = [graph_arrays(g) for g in graphs]
         if relax == "QCQP":
