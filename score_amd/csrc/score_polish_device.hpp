@@ -4,7 +4,8 @@
 // union of P's entries and the cone couplings, P on that pattern, and for every entry the list of (cone, block index,
 // coefficient) contributions in the order the host meets them -- from the matrices the handle has just uploaded (G2 = [P | A'],
 // A, the head flags): every row EXPANDS into records (key = row << 32 | column; P entries first, then the contributions in
-// the host loop's order: entries of A' of the row, tail index b, entries of A's row), a stable radix sort by key groups them,
+// the host loop's order: entries of A' of the row, tail index b, entries of A's row), a stable sort by key groups them (every row sorted where it lies:
+// k_row_rank_sort, score_setup_device.hpp),
 // one scan numbers the entries (runs of equal keys) and the contributions, one scatter writes Hcol, P-on-pattern, cptr and the
 // lists.  Equal to the host build entry by entry and contribution by contribution (the sort is stable, the records are laid
 // out in the host loop's order), so k_hassemble sums the same terms in the same order:

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void k_unscale(const double* __restrict__ xy, 
 
 // ---- records -> CSR with summed values: the merge step shared by the builders of K (and of P, device assembler) ----
 // A builder lays records out in the host loop's order: key = row << 32 | column (row = n: padding, sorts last), two values
-// per record.  After the stable sort by key an entry is a run of equal keys; it adds its records ONE AFTER THE OTHER in that
+// per record.  After the stable sort by key (HipBackend::sort_rows: row by row, see k_row_rank_sort below) an entry is a run of equal keys; it adds its records ONE AFTER THE OTHER in that
 // order (what the host's merge does) -- a run of more than kLongRun records is handed to a wavefront (k_rec_long).
 constexpr int kLongRun = 48;
 struct RecArgs {
