@@ -195,13 +195,19 @@ class ConicSolver:
                 raise ValueError(f"unknown solver setting {k}")
             setattr(st, k, v)
         self.settings = st
-        gs = (ScoreGraph * self.count)()
-        keep = []
+        # worlds of ONE generated batch (score_amd.generate), in a row: the library builds the handle from the arrays the
+        # generator left on the device (score_create_from_generated) -- the same program, nothing of a world uploaded again
+        # (and no ``struct score_graph`` made here: 0.1 ms a graph under the interpreter lock)
+        owner = arrays[0].get("_owner") if self.count else None
+        first = arrays[0].get("_index") if owner is not None else None
+        resident = (owner is not None and getattr(owner, "_h", None) and getattr(getattr(owner, "lib", None), "_handle", None) == self.lib._handle
+                    and all(a.get("_owner") is owner and a.get("_index") == first + i for i, a in enumerate(arrays)))
+        gs = None if resident else (ScoreGraph * self.count)()
         self.ns, self.ms = [], []
         for i, a in enumerate(arrays):
-            g = score_graph_struct(a, int(relaxation))
-            keep.append(g)
-            C.memmove(C.byref(gs[i]), C.byref(g), C.sizeof(ScoreGraph))
+            if not resident:
+                g = score_graph_struct(a, int(relaxation))
+                C.memmove(C.byref(gs[i]), C.byref(g), C.sizeof(ScoreGraph))
             d = int(a["dim"])
             Np, Nl, Nr = len(a["pose_names"]), len(a["landmark_names"]), len(a["rng_a"])
             n_rep = (Np - 1) * (d + 1) + Nl + (Nr if relaxation else 0)
@@ -214,12 +220,6 @@ class ConicSolver:
             self._est_dims = (d, int(relaxation), est_per)
         self._keep = []
         self._h = C.c_void_p()
-        # worlds of ONE generated batch (score_amd.generate), in a row: the library builds the handle from the arrays the
-        # generator left on the device (score_create_from_generated) -- the same program, nothing of a world uploaded again
-        owner = arrays[0].get("_owner") if self.count else None
-        first = arrays[0].get("_index") if owner is not None else None
-        resident = (owner is not None and getattr(owner, "_h", None) and getattr(getattr(owner, "lib", None), "_handle", None) == self.lib._handle
-                    and all(a.get("_owner") is owner and a.get("_index") == first + i for i, a in enumerate(arrays)))
         if resident:
             self.lib.score_create_from_generated.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(ScoreSettings), C.POINTER(C.c_void_p)]
             rc = self.lib.score_create_from_generated(owner._h, int(first), self.count, int(relaxation), C.byref(st), C.byref(self._h))
