@@ -73,6 +73,7 @@ struct CpuBackend {
     bool polish_available() const { return false; }
     void set_newton_limit(int) {}
     void cg_reduction(std::vector<double>& out) { out = cg_red; }
+    std::vector<double> prec_part, dot_part;  // partial sums, added in a fixed order (the same bits whatever the thread team)
 
     bool device_setup_ok(const HostSystem&, const score_problem*, const score_settings&) const { return false; }  // (the twin IS the host setup)
     bool device_setup_ok_graphs(const HostSystem&, const score_graph*, const score_settings&) const { return false; }
@@ -240,9 +241,12 @@ struct CpuBackend {
     void precond(int pi, double& rz) {  // z = M^{-1} r for problem pi, returns r'z
         const HostSystem& h = *H;
         const int w0 = h.prec_part_ptr[pi], w1 = h.prec_part_ptr[pi + 1];
-        double acc = 0;
-#pragma omp parallel for reduction(+ : acc) schedule(dynamic, 1)
+        // (a partial sum per work item, added up in the items' order -- what the chain kernel's workgroups and the reduction
+        //  behind them do: the same bits whatever the team of threads; an OpenMP reduction adds in the order the threads finish)
+        prec_part.assign((size_t)(w1 - w0), 0.0);
+#pragma omp parallel for schedule(dynamic, 1)
         for (int wi = w0; wi < w1; ++wi) {
+            double acc = 0;
             const PrecWork& pw = h.prec_work[wi];
             if (pw.kind == 0) {
                 const ChainDesc& ch = h.chains[pw.index];
@@ -260,7 +264,10 @@ struct CpuBackend {
                     acc += r[col] * z[col];
                 }
             }
+            prec_part[(size_t)(wi - w0)] = acc;
         }
+        double acc = 0;
+        for (double v : prec_part) acc += v;
         rz = acc;
         if (link_on && has_links(pi)) rz = link_correct(pi);
     }
@@ -327,8 +334,17 @@ struct CpuBackend {
             for_rows(h.K, pi, 0, [&](int64_t row, int64_t o, int64_t sh) {
                 w[o] = (j == 1) ? row_dot(h.K, row, p.data() + sh) : row_dot(h.K, row, z.data() + sh) + beta_prev * w[o];
             });
-#pragma omp parallel for reduction(+ : pw) schedule(static)
-            for (int64_t i = x0; i < x1; ++i) pw += p[i] * w[i];
+            {   // p'w in pieces of 1024 entries, the pieces added in order (see precond)
+                const int64_t nch = (x1 - x0 + 1023) / 1024;
+                dot_part.assign((size_t)nch, 0.0);
+#pragma omp parallel for schedule(static)
+                for (int64_t c = 0; c < nch; ++c) {
+                    double acc = 0;
+                    for (int64_t i = x0 + c * 1024; i < std::min(x1, x0 + (c + 1) * 1024); ++i) acc += p[i] * w[i];
+                    dot_part[(size_t)c] = acc;
+                }
+                for (double v : dot_part) pw += v;
+            }
             const double a = pw > 0 ? rz / pw : 0.0;
 #pragma omp parallel for schedule(static)
             for (int64_t i = x0; i < x1; ++i) {

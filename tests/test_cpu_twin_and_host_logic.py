@@ -213,7 +213,8 @@ def test_flat_arrays_are_kept_on_the_graph_and_follow_its_lists(twin_lib):
     assert len(c.distances) == nr - 1 and getattr(fg, native._CACHE_ATTR)[1] is not kept[1]
     fg.range_measurements.append(last)
     d = solve_score(fg, "SOCP", lib_path=twin_lib)
-    # (a noise-free graph: the optimum is 0 and pobj is what the OpenMP reductions of the twin leave of it, +-1e-9 run to run)
+    # (a noise-free graph: the optimum is 0; the twin adds its partial sums in a fixed order since round 6 -- before, pobj here was
+    #  what the OpenMP reductions left of it, +-1e-9 run to run)
     assert len(d.distances) == nr and d.info["pobj"] == pytest.approx(a.info["pobj"], rel=1e-9, abs=1e-8)
     # same list, same length, another element: seen through the first / last identities; an in-place edit needs the explicit call
     fg.range_measurements[-1] = compat.FGRangeMeasurement(last.association, dist=last.dist + 1.0, stddev=last.stddev)
