@@ -1546,7 +1546,7 @@ struct HipBackend {
         rz.P_ptr = Pp_d; rz.P_col = Pc_d; rz.P_val = Pv_d; rz.A_ptr = A_ptr.d; rz.A_col = Ac_d; rz.A_val = Av_d;
         rz.atp = atp.d; rz.atpos = atpos.d; rz.arow = arow.d; rz.gstart = cone_row.d;
         rz.D = Dd.d; rz.E = Ed.d; rz.d = dsc.d; rz.e = esc.d; rz.n = n; rz.m = m; rz.ngroups = ngroups; rz.tab = tab;
-        const unsigned gcol = (unsigned)((n + 3) / 4), ggrp = (unsigned)std::max<int64_t>(1, (ngroups + 255) / 256);
+        const unsigned ggrp = (unsigned)std::max<int64_t>(1, (ngroups + 255) / 256);
         const unsigned gapp = (unsigned)std::max<int64_t>(1, (std::max(n, ngroups) + 255) / 256);
         for (int it = 0; it < std::max(0, st.scale_iters); ++it) {
             const unsigned ga_blocks = (unsigned)((ae + 255) / 256), gg_blocks = ngroups ? ggrp : 0u;
@@ -1601,7 +1601,6 @@ struct HipBackend {
         ka.g2_ptr = G2.ptr.d; ka.g2_split = G2.split.d; ka.g2_col = G2.col.d; ka.g2_val = G2.val.d;
         ka.A_ptr = A_ptr.d; ka.A_col = A_col.d; ka.A_val = A_val.d;
         ka.rec_cnt = kcnt.d; ka.key = key0.d; ka.idx = kidx0.d; ka.v0 = v0.d; ka.v1 = v1.d;
-        const unsigned grow4 = (unsigned)((n + 1 + 3) / 4);
         ka.long_rows = long_rows.d; ka.n_long_rows = n_long_rows.d;
         hipLaunchKernelGGL(k_kb_count<8>, dim3(g8), dim3(256), 0, stream, ka);
         hipLaunchKernelGGL(k_kb_count<64>, dim3(g64), dim3(256), 0, stream, ka);
@@ -2938,7 +2937,6 @@ struct HipBackend {
     void time_iteration(int warmup, int iters, double* us, int with_events) {
         if (cg_iters != 2) throw std::runtime_error("score_time_iteration: needs cg_iters == 2");
         iters = std::max(1, iters);
-        const HostSystem& h = *H;
         int khz = 0;
         HIP_CHECK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, st.device));
         if (khz <= 0) throw std::runtime_error("score_time_iteration: no wall clock rate");
